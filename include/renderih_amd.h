@@ -1,0 +1,205 @@
+/*
+ * renderih_amd.h -- C ABI of librenderih_amd.so (MI355X / gfx950 hot-path kernels).
+ *
+ * The reference (adwardlee/RenderIH) has no native boundary on this path: its hot path is
+ * torch operators called from Python (models/encoder.py, models/model_attn/{gcn,self_attn,img_attn,inter_attn,DualGraph}.py, models/decoder.py,
+ * models/manolayer.py), which dispatch to cuDNN/cuBLAS.  This header is the boundary a maintainer
+ * binds instead (ctypes stub in INTEGRATION.md): each entry point names the reference op group
+ * (file:line) it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 (or int32 where said) owned by the caller
+ *     (PyTorch's caching allocator); the library never allocates or frees device memory;
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it, no host sync;
+ *   - return value: 0 = ok, otherwise a hipError_t (>0) or a negative argument-check code;
+ *     no C++ exception crosses the ABI;
+ *   - activations are NHWC ("pixels x channels", channel fastest); a matrix is the H=W=1 case.
+ */
+#ifndef RENDERIH_AMD_H
+#define RENDERIH_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RIH_OK 0
+#define RIH_EINVAL (-1)
+
+/* ------------------------------------------------------------------------------------------------
+ * rih_gemm: C = epilogue(alpha * A (*) B) on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32).
+ *
+ * One kernel family covers every dense contraction of the path:
+ *   conv2d forward / data-gradient (A gathered im2col-style from an NHWC tensor)
+ *       replaces torch conv2d in models/encoder.py:52,112-116,172 + torchvision resnet50,
+ *       models/model_attn/img_attn.py:62 (patch conv)
+ *   conv2d / linear weight-gradient (A = im2col^T, split-K over pixels)
+ *   nn.Linear forward/backward          models/model_attn/{gcn.py:66,self_attn.py:66-76,inter_attn.py:85-107}
+ *   attention QK^T, PV and their gradients (two-level batch strides = batch x head)
+ *       models/model_attn/self_attn.py:70-74, inter_attn.py:93-107
+ *
+ * a_mode 0: A(m,k): m = (img,ho,wo) output pixel, k = (kh,kw,ci); element =
+ *           X[img][(ho*strideA - padH + kh)/upS][(wo*strideA - padW + kw)/upS][ci]  (0 when out of range or
+ *           not divisible by upS; upS>1 expresses the data-gradient of a strided conv).  K-contiguous.
+ * a_mode 1: A(m,k): m = (kh,kw,ci), k = (img,ho,wo) -- the transpose gather, M-contiguous (weight grad).
+ * b_mode 0: B(k,n) = Bp[k*ldb + n]   (row-major [K][N])
+ * b_mode 1: B(k,n) = Bp[n*ldb + k]   ([N][K], e.g. an nn.Linear / 1x1-conv weight as stored)
+ * Epilogue (splitk==1): C[m*ldc+n] = act(alpha*acc + bias[n] + R[m*ldr+n]); with splitk>1 raw partial sums
+ *           go to C + split*sCsplit and rih_splitk_reduce finishes.
+ */
+typedef struct rih_gemm_desc {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;   /* [N] or NULL */
+    const float* R;      /* residual [M][ldr] or NULL */
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc, ldr;
+    int32_t a_mode, b_mode;
+    /* batching: grid.z = nb1 * nb2 * splitk */
+    int32_t nb1, nb2;
+    int64_t sA1, sA2, sB1, sB2, sC1, sC2;
+    int32_t splitk;      /* >= 1 */
+    int32_t kchunk;      /* K range per split, multiple of 32 */
+    int64_t sCsplit;
+    float alpha;
+    int32_t relu;
+    /* im2col geometry of A (a plain matrix is H=W=Ho=Wo=KH=KW=1, strideA=upS=1, pad=0, Cin=K or M) */
+    int32_t H, W, Cin, Ho, Wo, KH, KW, strideA, upS, padH, padW;
+    int32_t tile;        /* 0: 128x128, 1: 128x64, 2: 64x64 */
+} rih_gemm_desc;
+
+int rih_gemm(const rih_gemm_desc* d, void* stream);
+
+/* Sum split-K partials P[S][M][N] (M = taps*Cin rows ordered (tap,ci)) into a weight gradient laid out
+ * like the parameter: dst[(n*CinValid + ci)*taps + tap]  (OIHW for convs, [out][in] for nn.Linear).
+ * Rows with ci >= CinValid (channel padding) are dropped.  accumulate!=0 adds to dst. */
+int rih_splitk_reduce(const float* P, int S, int M, int N, float* dst, int Cin, int taps, int CinValid,
+                      int accumulate, void* stream);
+
+/* Repack an OIHW conv weight for rih_gemm: dst[((kh*KW+kw)*Ci_pad + ci)*Cout + co] (forward, b_mode 0) or,
+ * with for_dgrad!=0, dst[(((KH-1-kh)*KW + (KW-1-kw))*Cout + co)*Ci_pad + ci] (flipped, in/out swapped). */
+int rih_pack_conv_weight(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int CinPad,
+                         int for_dgrad, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layout, pooling, resampling   (models/encoder.py:107-113 stem, :31 nn.Upsample, :155-158 avgpool)   */
+int rih_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cpad, void* stream);
+int rih_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int ldx, void* stream);
+int rih_maxpool3x3s2_fwd(const float* x, float* y, int8_t* arg, int N, int H, int W, int C, void* stream);
+int rih_maxpool3x3s2_bwd(const float* dy, const int8_t* arg, float* dx, int N, int H, int W, int C, void* stream);
+int rih_avgpool_fwd(const float* x, float* y, int N, int HW, int C, void* stream);
+int rih_avgpool_bwd(const float* dy, float* dx, int N, int HW, int C, void* stream);
+int rih_upsample2x_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int rih_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm2d (NHWC, rows = N*H*W)   (torchvision resnet bn*, models/encoder.py:54, model_zoo/__init__.py:57)
+ * ws: caller workspace, >= rih_bn_ws_floats(rows, C) floats.                                           */
+int64_t rih_bn_ws_floats(int rows, int C);
+/* training statistics: mean[C], invstd[C]; updates running_mean/var (momentum, unbiased var) when non-NULL */
+int rih_bn_stats(const float* x, int rows, int C, float eps, float momentum, float* mean, float* invstd,
+                 float* running_mean, float* running_var, float* ws, void* stream);
+/* eval statistics from running buffers */
+int rih_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean,
+                      float* invstd, void* stream);
+/* y = act((x-mean)*invstd*gamma + beta + residual) */
+int rih_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                 const float* residual, float* y, int rows, int C, int relu, void* stream);
+/* backward of the above (training statistics): given dy and the forward output y (for the ReLU mask),
+ * produces dx, dgamma, dbeta and, when dres != NULL, the residual-branch gradient (= masked dy).
+ * frozen_stats != 0: eval-mode backward (statistics are constants). */
+int rih_bn_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+               const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C,
+               int relu, int frozen_stats, float* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row-wise ops on [rows][D] matrices (decoder)                                                         */
+/* y = act(LayerNorm(x (+ x2)) * g + b); saves mean/rstd per row   (nn.LayerNorm eps=1e-6, gcn.py:91-97 ...) */
+int rih_layernorm_fwd(const float* x, const float* x2, const float* g, const float* b, float* y, float* mean,
+                      float* rstd, int rows, int D, float eps, int relu, void* stream);
+/* dx (= gradient wrt x and x2), dg/db accumulated via ws (>= 2*nblk*D floats, nblk = rih_ln_nblk(rows)) */
+int rih_ln_nblk(int rows);
+int rih_layernorm_bwd(const float* dy, const float* x, const float* x2, const float* y, const float* g,
+                      const float* mean, const float* rstd, float* dx, float* dg, float* db, int rows, int D,
+                      int relu, float* ws, void* stream);
+/* softmax over the last dim of [rows][ld] (first `cols` entries), optional inverted dropout with a
+ * counter-based hash RNG: P (pre-dropout probabilities) and Pd (post-dropout, may alias P when p==0) */
+int rih_softmax_fwd(const float* S, float* P, float* Pd, int64_t rows, int cols, int ld, float drop_p,
+                    uint64_t seed, void* stream);
+/* dS = alpha * P * (dPd*mask/(1-p) - sum_j(dPd*mask/(1-p) * P)), written in place over dPd */
+int rih_softmax_bwd(const float* P, float* dPd, int64_t rows, int cols, int ld, float drop_p, uint64_t seed,
+                    float alpha, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise / gather                                                                                 */
+/* y = a + dropout(b) (inverted dropout, p may be 0); b_bcast_rows>0: b is [b_bcast_rows][D] broadcast over the batch */
+int rih_add_dropout(const float* a, const float* b, float* y, int64_t n, int D, int b_bcast_rows, float drop_p,
+                    uint64_t seed, void* stream);
+/* backward of dropout: dx = dy * mask/(1-p) */
+int rih_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64_t seed, void* stream);
+/* y = max(x,0);  dx = dy * (y>0) */
+int rih_relu_fwd(const float* x, float* y, int64_t n, void* stream);
+int rih_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+/* column sums of [rows][C] (bias gradients); ws >= rih_colsum_ws_floats(rows,C) */
+int64_t rih_colsum_ws_floats(int rows, int C);
+int rih_colsum(const float* x, int rows, int C, int ldx, float* out, int accumulate, float* ws, void* stream);
+/* out[b][i][:] = x[b][idx[i]][:]  (graph_perm gathers, nearest upsample along V, token slicing) */
+int rih_gather_rows(const float* x, const int32_t* idx, float* y, int B, int Vin, int Vout, int D, void* stream);
+/* dx[b][idx[i]][:] += dy[b][i][:]  with dx zero-initialised by the callee (deterministic, via inverse lists) */
+int rih_scatter_rows_add(const float* dy, const int32_t* inv_ptr, const int32_t* inv_idx, float* dx, int B, int Vin,
+                         int Vout, int D, void* stream);
+
+/* Orthographic projection uv = (scale*img)*xyz[:2] + (trans*img/2 + img/2)   (utils/manoutils.py:26-44)
+ * v[B][V][3], scale[B], trans[B][2] -> out[B][V][2]; backward gives dv (z component 0), dscale, dtrans. */
+int rih_project_fwd(const float* v, const float* scale, const float* trans, float* out, int B, int V,
+                    float img_size, void* stream);
+int rih_project_bwd(const float* dout, const float* v, const float* scale, float* dv, float* dscale,
+                    float* dtrans, int B, int V, float img_size, void* stream);
+
+/* Chebyshev K=2 feature build: y[b][v][2f+0] = x[b][v][f], y[b][v][2f+1] = sum_j L[v][j] x[b][j][f]
+ * with L in CSR (models/model_attn/gcn.py:34-69).  Backward takes CSR of L^T. */
+int rih_cheby_fwd(const float* x, const int32_t* indptr, const int32_t* indices, const float* vals, float* y,
+                  int B, int V, int F, void* stream);
+int rih_cheby_bwd(const float* dy, const int32_t* t_indptr, const int32_t* t_indices, const float* t_vals,
+                  float* dx, int B, int V, int F, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * MANO linear-blend-skinning layer   (models/manolayer.py:250-322)
+ * Constant model (uploaded once by the caller, device pointers):
+ *   comps[45][45] (PCA basis rows), hands_mean[45], shapedirs[778][3][10], posedirs[778][3][135],
+ *   v_template[778][3], J_reg[16][778] (dense), weights[778][16], parent[16] (host array).
+ * Per call: root[B][9], pose (PCA coeffs [B][ncomp] if ncomp>0, else rotation matrices [B][15][9]),
+ *   shape[B][10], trans[B][3] or NULL, scale[B] or NULL.  Outputs v[B][778][3], j[B][21][3].
+ * ws: >= rih_mano_ws_floats(B) floats, kept by the caller for the backward.                            */
+typedef struct rih_mano_model {
+    const float* comps;
+    const float* hands_mean;
+    const float* shapedirs;
+    const float* posedirs;
+    const float* v_template;
+    const float* J_reg;
+    const float* weights;
+    int32_t parent[16];
+} rih_mano_model;
+
+int64_t rih_mano_ws_floats(int B);
+int rih_mano_fwd(const rih_mano_model* m, const float* root, const float* pose, int ncomp, const float* shape,
+                 const float* trans, const float* scale, int center_idx, int new_skel, float* v, float* j,
+                 float* ws, int B, void* stream);
+/* gradients wrt root/pose/shape/trans/scale (any may be NULL) given dv[B][778][3], dj[B][21][3] */
+int rih_mano_bwd(const rih_mano_model* m, const float* root, const float* pose, int ncomp, const float* shape,
+                 const float* trans, const float* scale, int center_idx, int new_skel, const float* dv,
+                 const float* dj, const float* ws, float* d_root, float* d_pose, float* d_shape, float* d_trans,
+                 float* d_scale, float* ws_bwd, int B, void* stream);
+int64_t rih_mano_bwd_ws_floats(int B);
+
+/* library / device info */
+int rih_version(void);
+const char* rih_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RENDERIH_AMD_H */

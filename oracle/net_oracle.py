@@ -1,0 +1,269 @@
+"""ORACLE (test infrastructure, not product): CPU fp32 restatement of the reference network forward.
+
+A functional, plain-PyTorch-CPU restatement of the RenderIH/IntagHand pose network
+(`models.model.HandNET_GCN`, ResNet50 variant) driven by a reference-keyed `state_dict`.
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this file;
+the product (`renderih_amd/`) never does.
+
+Pinning: `tests/golden/make_golden.py` imports the *real* reference modules from /root/reference
+(under import stubs) and stores their outputs for seeded inputs/weights in `tests/golden/*.npz`;
+`tests/test_oracle_golden.py` checks this restatement against those fixtures (parity pinned by
+reference-generated vectors; the reference's own tests pin nothing numeric for this path).
+
+Each function cites the reference file:line it follows (paths relative to /root/reference).
+Everything is differentiable through torch autograd, so the same code is the gradient oracle.
+"""
+import math
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+IMG_SIZE = 256  # dataset/dataset_utils.py:4
+
+
+# ----------------------------------------------------------------------------- primitives
+def _bn(sd, p, x, training, eps=1e-5):
+    """nn.BatchNorm2d forward (batch statistics when training, running stats otherwise)."""
+    return F.batch_norm(x, None if training else sd[p + 'running_mean'],
+                        None if training else sd[p + 'running_var'],
+                        sd[p + 'weight'], sd[p + 'bias'], training, 0.1, eps)
+
+
+def _ln(sd, p, x, eps=1e-6):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + 'weight'], sd[p + 'bias'], eps)
+
+
+def _lin(sd, p, x):
+    return F.linear(x, sd[p + 'weight'], sd.get(p + 'bias'))
+
+
+# ----------------------------------------------------------------------------- encoder
+def _bottleneck(sd, p, x, stride, training):
+    """torchvision Bottleneck v1.5 (stride on the 3x3), used via models/encoder.py:81-83."""
+    out = F.relu(_bn(sd, p + 'bn1.', F.conv2d(x, sd[p + 'conv1.weight']), training))
+    out = F.relu(_bn(sd, p + 'bn2.', F.conv2d(out, sd[p + 'conv2.weight'], stride=stride, padding=1), training))
+    out = _bn(sd, p + 'bn3.', F.conv2d(out, sd[p + 'conv3.weight']), training)
+    if (p + 'downsample.0.weight') in sd:
+        x = _bn(sd, p + 'downsample.1.', F.conv2d(x, sd[p + 'downsample.0.weight'], stride=stride), training)
+    return F.relu(out + x)
+
+
+def resnet_trunk(sd, x, training, p='encoder.resnet.', layers=(3, 4, 6, 3)):
+    """models/encoder.py:107-116 (ResNetSimple.forward, trunk part)."""
+    x = F.conv2d(x, sd[p + 'conv1.weight'], stride=2, padding=3)
+    x = F.relu(_bn(sd, p + 'bn1.', x, training))
+    x = F.max_pool2d(x, 3, 2, 1)
+    feats = []
+    for li, n in enumerate(layers):
+        for b in range(n):
+            stride = 2 if (b == 0 and li > 0) else 1
+            x = _bottleneck(sd, '%slayer%d.%d.' % (p, li + 1, b), x, stride, training)
+        feats.append(x)
+    x4, x3, x2, x1 = feats
+    return x1, x2, x3, x4
+
+
+def aux_decoder(sd, p, x, training):
+    """models/encoder.py:21-64 ResNetSimple_decoder: [1x1 conv->ReLU->BN] then 3x[bilinear x2 -> 3x3 conv->ReLU->BN]."""
+    fmaps = []
+    x = _bn(sd, p + 'models.0.2.', F.relu(F.conv2d(x, sd[p + 'models.0.0.weight'])), training)
+    fmaps.append(x)
+    for i in (1, 2, 3):
+        x = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
+        x = F.relu(F.conv2d(x, sd['%smodels.%d.1.weight' % (p, i)], padding=1))
+        x = _bn(sd, '%smodels.%d.3.' % (p, i), x, training)
+        fmaps.append(x)
+    out = F.conv2d(x, sd[p + 'final_layer.weight'], sd[p + 'final_layer.bias'])
+    return out, fmaps
+
+
+def encoder_forward(sd, img, training):
+    """models/encoder.py:107-126."""
+    x1, x2, x3, x4 = resnet_trunk(sd, img, training)
+    hms, hms_f = aux_decoder(sd, 'encoder.hms_decoder.', x1, training)
+    out, dp_f = aux_decoder(sd, 'encoder.dp_decoder.', x1, training)
+    return hms, out[:, :2], out[:, 2:], [x1, x2, x3, x4], hms_f, dp_f
+
+
+def mid_forward(sd, img_f, hms_f, dp_f, training, p='mid_model.'):
+    """models/encoder.py:165-173 resnet_mid.forward; conv1x1 = conv->ReLU->BN (model_zoo/__init__.py:56-62)."""
+    gf = F.adaptive_avg_pool2d(img_f[0], 1).flatten(1)
+    fmaps = []
+    for i in range(4):
+        x = torch.cat((hms_f[i], dp_f[i]), 1)
+        if i > 0:
+            x = torch.cat((x, img_f[i]), 1)
+        x = F.relu(F.conv2d(x, sd['%sconvs.%d.0.weight' % (p, i)]))
+        fmaps.append(_bn(sd, '%sconvs.%d.2.' % (p, i), x, training))
+    return gf, fmaps
+
+
+# ----------------------------------------------------------------------------- decoder blocks
+def cheby(sd, p, x, L):
+    """models/model_attn/gcn.py:34-69 with K=2: features interleaved as (fin, k)."""
+    x1 = torch.matmul(L, x)                                  # B x V x F  (== mm(L, x0) per batch column)
+    xc = torch.stack((x, x1), dim=-1).flatten(-2)            # B x V x (F*2), index = f*2+k
+    return _lin(sd, p, xc)
+
+
+def gcn_resblock(sd, p, x, L):
+    """models/model_attn/gcn.py:99-110 (norm1 output is overwritten: dead, note N2)."""
+    x1 = cheby(sd, p + 'fc1.', x, L)
+    x1 = F.relu(_ln(sd, p + 'norm2.', x1))
+    x1 = cheby(sd, p + 'fc2.', x1, L)
+    x2 = _lin(sd, p + 'shortcut.', x)
+    return _ln(sd, p + 'norm3.', x1 + x2)
+
+
+def graph_layer(sd, p, x, L, n=4):
+    """models/model_attn/gcn.py:131-138."""
+    for i in range(n):
+        x = gcn_resblock(sd, '%sGCN_blocks.%d.' % (p, i), x, L)
+        if i != n - 1:
+            x = F.relu(x)
+    return x
+
+
+def mlp_res(sd, p, x):
+    """models/model_attn/self_attn.py:17-33."""
+    return x + _lin(sd, p + 'fc2.', F.relu(_lin(sd, p + 'fc1.', _ln(sd, p + 'layer_norm.', x))))
+
+
+def _mha(q, k, v, h):
+    B, Sq, D = q.shape
+    d = D // h
+    q = q.view(B, Sq, h, d).transpose(1, 2)
+    k = k.view(B, -1, h, d).transpose(1, 2)
+    v = v.view(B, -1, h, d).transpose(1, 2)
+    a = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / (d ** 0.5), -1)
+    return torch.matmul(a, v).transpose(1, 2).contiguous().view(B, Sq, D)
+
+
+def self_attn(sd, p, x, h=4):
+    """models/model_attn/self_attn.py:63-85 (dropout = identity here)."""
+    y = _ln(sd, p + 'layer_norm.', x)
+    o = _mha(_lin(sd, p + 'w_qs.', y), _lin(sd, p + 'w_ks.', y), _lin(sd, p + 'w_vs.', y), h)
+    x = x + _lin(sd, p + 'fc.', o)
+    return mlp_res(sd, p + 'ff.', x)
+
+
+def img_ex(sd, p, img, verts, patch):
+    """models/model_attn/img_attn.py:51-67,79-92,109-113."""
+    B = img.shape[0]
+    g = F.relu(F.conv2d(img, sd[p + 'encoder.proj.weight'], sd[p + 'encoder.proj.bias'], stride=patch))
+    g = g.view(B, g.shape[1], -1).transpose(-1, -2) + sd[p + 'encoder.position_embeddings.weight']
+    g = self_attn(sd, p + 'encoder.self_attn.', g)
+    g = _lin(sd, p + 'attn.fc.', g)
+    V = verts.shape[1]
+    x = self_attn(sd, p + 'attn.Attn.', torch.cat([verts, g], 1))
+    return x[:, :V]
+
+
+def inter_attn(sd, p, Lf, Rf, h=4):
+    """models/model_attn/inter_attn.py:73-125 (shared w_qs/w_ks/w_vs/fc for both hands, note N5)."""
+    Lf = self_attn(sd, p + 'L_self_attn_layer.', Lf)
+    Rf = self_attn(sd, p + 'R_self_attn_layer.', Rf)
+    L2 = _ln(sd, p + 'layer_norm1.', Lf)
+    R2 = _ln(sd, p + 'layer_norm2.', Rf)
+    Lq, Lk, Lv = (_lin(sd, p + w, L2) for w in ('w_qs.', 'w_ks.', 'w_vs.'))
+    Rq, Rk, Rv = (_lin(sd, p + w, R2) for w in ('w_qs.', 'w_ks.', 'w_vs.'))
+    feat_R2L = _mha(Lq, Rk, Rv, h)      # softmax(Lq Rk^T) Rv
+    feat_L2R = _mha(Rq, Lk, Lv, h)
+    Lf = mlp_res(sd, p + 'ffL.', Lf + _lin(sd, p + 'fc.', feat_R2L))
+    Rf = mlp_res(sd, p + 'ffR.', Rf + _lin(sd, p + 'fc.', feat_L2R))
+    return Lf, Rf
+
+
+def dual_graph(sd, p, Lf, Rf, fmaps, L_left, L_right):
+    """models/model_attn/DualGraph.py:62-91,130-139."""
+    patches = (1, 2, 4)
+    for i in range(3):
+        q = '%slayers.%d.' % (p, i)
+        pe = sd[q + 'position_embeddings.weight']
+        Lf = graph_layer(sd, q + 'graph_left.', Lf + pe, L_left[i])
+        Rf = graph_layer(sd, q + 'graph_right.', Rf + pe, L_right[i])
+        Lf = img_ex(sd, q + 'img_ex_left.', fmaps[i], Lf, patches[i])
+        Rf = img_ex(sd, q + 'img_ex_right.', fmaps[i], Rf, patches[i])
+        Lf, Rf = inter_attn(sd, q + 'attn.', Lf, Rf)
+        if i != 2:
+            Lf = Lf.repeat_interleave(2, dim=1)      # nn.Upsample(nearest) along V, DualGraph.py:11-18
+            Rf = Rf.repeat_interleave(2, dim=1)
+    return Lf, Rf
+
+
+def projection_batch(scale, trans2d, v, img_size=IMG_SIZE):
+    """utils/manoutils.py:26-44."""
+    s = (scale * img_size).view(-1, 1, 1)
+    t = (trans2d * img_size / 2 + img_size / 2).unsqueeze(1)
+    return s * v[..., :2] + t
+
+
+def decoder_forward(sd, graph, gf, fmaps, p='decoder.'):
+    """models/decoder.py:128-174.  `graph` = dict(left=..., right=...) with dense 'L' list (63,126,252),
+    'perm' (1008) and 'perm_reverse' (778) as the reference ctor derives them (decoder.py:51-75)."""
+    fmaps = fmaps[:-1]
+    B = gf.shape[0]
+    dc = sd[p + 'dense_coor'] * 2 - 1
+    feats = {}
+    for side in ('left', 'right'):
+        pe = dc[graph[side]['perm']]                             # vert_to_GCN
+        pe = pe.view(63, 16, 3).mean(1)                          # graph_avg_pool p=16 (graph_utils.py:35-42)
+        g = _ln(sd, '%sgf_layer_%s.1.' % (p, side), _lin(sd, '%sgf_layer_%s.0.' % (p, side), gf))
+        feats[side] = torch.cat([g.unsqueeze(1).repeat(1, 63, 1), pe.unsqueeze(0).repeat(B, 1, 1)], -1)
+    Lf, Rf = dual_graph(sd, p + 'dual_gcn.', feats['left'], feats['right'], fmaps,
+                        graph['left']['L'], graph['right']['L'])
+    out = {'left': Lf, 'right': Rf}
+    scale, trans2d, v3c, v2c, v3, v2, v3m, v2m = ({} for _ in range(8))
+    for side in ('left', 'right'):
+        f = out[side]
+        t = _lin(sd, p + 'avg_head.', f.transpose(-1, -2))[..., 0]
+        t = _lin(sd, p + 'params_head.', t)
+        scale[side], trans2d[side] = t[:, 0], t[:, 1:]
+        v3c[side] = _lin(sd, p + 'coord_head.', f)
+        v2c[side] = projection_batch(scale[side], trans2d[side], v3c[side])
+        v3[side] = F.linear(v3c[side].transpose(1, 2), sd[p + 'unsample_layer.weight']).transpose(1, 2)
+        v2[side] = projection_batch(scale[side], trans2d[side], v3[side])
+        pr = graph[side]['perm_reverse']
+        v3m[side] = [v3c[side].repeat_interleave(4, dim=1)[:, pr]]
+        v2m[side] = [v2c[side].repeat_interleave(4, dim=1)[:, pr]]
+    result = {'verts3d': v3, 'verts2d': v2}
+    paramsDict = {'scale': scale, 'trans2d': trans2d}
+    handDictList = [{'verts3d': v3c, 'verts2d': v2c}]
+    otherInfo = {'verts3d_MANO_list': v3m, 'verts2d_MANO_list': v2m}
+    return result, paramsDict, handDictList, otherInfo
+
+
+def handnet_forward(sd, graph, img, training=False, taps=None):
+    """models/model.py:25-37 HandNET_GCN.forward."""
+    hms, mask, dp, img_f, hms_f, dp_f = encoder_forward(sd, img, training)
+    gf, fmaps = mid_forward(sd, img_f, hms_f, dp_f, training)
+    if taps is not None:
+        taps.update(x1=img_f[0], x2=img_f[1], x3=img_f[2], x4=img_f[3], gf=gf,
+                    fmap0=fmaps[0], fmap1=fmaps[1], fmap2=fmaps[2], fmap3=fmaps[3],
+                    hms_f3=hms_f[3], dp_f0=dp_f[0])
+    result, paramsDict, handDictList, otherInfo = decoder_forward(sd, graph, gf, fmaps)
+    otherInfo['hms'], otherInfo['mask'], otherInfo['dense'] = hms, mask, dp
+    return result, paramsDict, handDictList, otherInfo
+
+
+def graph_from_dicts(left_dict, right_dict):
+    """What decoder.__init__ derives from the two graph dicts (decoder.py:51-75, gcn.py:79-86)."""
+    g = {}
+    for side, d in (('left', left_dict), ('right', right_dict)):
+        Ls = list(d['coarsen_graphs_L'])[::-1][:3]             # reversed: 63, 126, 252
+        g[side] = {'L': [torch.from_numpy(np.asarray(L.astype(np.float32).todense())).float() for L in Ls],
+                   'perm': torch.as_tensor(np.asarray(d['graph_perm']), dtype=torch.long),
+                   'perm_reverse': torch.as_tensor(np.asarray(d['graph_perm_reverse'])[:778], dtype=torch.long)}
+    return g
+
+
+def scalar_loss(outputs):
+    """Fixed scalar used for gradient parity (covers every differentiable output of the 4-tuple)."""
+    result, params, hd, other = outputs
+    s = 0.
+    for side in ('left', 'right'):
+        s = s + result['verts3d'][side].abs().sum() + 1e-2 * result['verts2d'][side].abs().sum()
+        s = s + hd[0]['verts3d'][side].pow(2).sum() + 1e-4 * hd[0]['verts2d'][side].pow(2).sum()
+        s = s + params['scale'][side].sum() + params['trans2d'][side].pow(2).sum()
+    s = s + 1e-3 * other['hms'].pow(2).sum() + 1e-3 * other['mask'].abs().sum() + 1e-3 * other['dense'].pow(2).sum()
+    return s

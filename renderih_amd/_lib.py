@@ -1,0 +1,114 @@
+"""ctypes binding of librenderih_amd.so (the C ABI declared in include/renderih_amd.h).
+
+The product path has no fallback: if the library is missing or a kernel launch fails, it raises.
+"""
+import ctypes as C
+import os
+
+from . import _build
+
+c_f = C.c_void_p          # device float*
+c_i = C.c_int
+c_l = C.c_int64
+c_u64 = C.c_uint64
+c_fl = C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p), ('bias', C.c_void_p), ('R', C.c_void_p),
+                ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
+                ('lda', C.c_int32), ('ldb', C.c_int32), ('ldc', C.c_int32), ('ldr', C.c_int32),
+                ('a_mode', C.c_int32), ('b_mode', C.c_int32),
+                ('nb1', C.c_int32), ('nb2', C.c_int32),
+                ('sA1', C.c_int64), ('sA2', C.c_int64), ('sB1', C.c_int64), ('sB2', C.c_int64),
+                ('sC1', C.c_int64), ('sC2', C.c_int64),
+                ('splitk', C.c_int32), ('kchunk', C.c_int32), ('sCsplit', C.c_int64),
+                ('alpha', C.c_float), ('relu', C.c_int32),
+                ('H', C.c_int32), ('W', C.c_int32), ('Cin', C.c_int32), ('Ho', C.c_int32), ('Wo', C.c_int32),
+                ('KH', C.c_int32), ('KW', C.c_int32), ('strideA', C.c_int32), ('upS', C.c_int32),
+                ('padH', C.c_int32), ('padW', C.c_int32), ('tile', C.c_int32)]
+
+
+class ManoModel(C.Structure):
+    _fields_ = [('comps', C.c_void_p), ('hands_mean', C.c_void_p), ('shapedirs', C.c_void_p),
+                ('posedirs', C.c_void_p), ('v_template', C.c_void_p), ('J_reg', C.c_void_p),
+                ('weights', C.c_void_p), ('parent', C.c_int32 * 16)]
+
+
+# name -> (restype, argtypes); must list every symbol include/renderih_amd.h declares
+SIGNATURES = {
+    'rih_gemm': (c_i, [C.POINTER(GemmDesc), C.c_void_p]),
+    'rih_splitk_reduce': (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_pack_conv_weight': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_nchw_to_nhwc': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_nhwc_to_nchw': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_maxpool3x3s2_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_maxpool3x3s2_bwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_avgpool_fwd': (c_i, [c_f, c_f, c_i, c_i, c_i, C.c_void_p]),
+    'rih_avgpool_bwd': (c_i, [c_f, c_f, c_i, c_i, c_i, C.c_void_p]),
+    'rih_upsample2x_fwd': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_upsample2x_bwd': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_bn_ws_floats': (c_l, [c_i, c_i]),
+    'rih_bn_stats': (c_i, [c_f, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f, C.c_void_p]),
+    'rih_bn_eval_stats': (c_i, [c_f, c_f, c_i, c_fl, c_f, c_f, C.c_void_p]),
+    'rih_bn_apply': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, C.c_void_p]),
+    'rih_bn_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, C.c_void_p]),
+    'rih_layernorm_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_i, C.c_void_p]),
+    'rih_ln_nblk': (c_i, [c_i]),
+    'rih_layernorm_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, C.c_void_p]),
+    'rih_softmax_fwd': (c_i, [c_f, c_f, c_f, c_l, c_i, c_i, c_fl, c_u64, C.c_void_p]),
+    'rih_softmax_bwd': (c_i, [c_f, c_f, c_l, c_i, c_i, c_fl, c_u64, c_fl, C.c_void_p]),
+    'rih_add_dropout': (c_i, [c_f, c_f, c_f, c_l, c_i, c_i, c_fl, c_u64, C.c_void_p]),
+    'rih_dropout_bwd': (c_i, [c_f, c_f, c_l, c_fl, c_u64, C.c_void_p]),
+    'rih_relu_fwd': (c_i, [c_f, c_f, c_l, C.c_void_p]),
+    'rih_relu_bwd': (c_i, [c_f, c_f, c_f, c_l, C.c_void_p]),
+    'rih_colsum_ws_floats': (c_l, [c_i, c_i]),
+    'rih_colsum': (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_f, C.c_void_p]),
+    'rih_gather_rows': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_scatter_rows_add': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_project_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, C.c_void_p]),
+    'rih_project_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, C.c_void_p]),
+    'rih_cheby_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, C.c_void_p]),
+    'rih_cheby_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, C.c_void_p]),
+    'rih_mano_ws_floats': (c_l, [c_i]),
+    'rih_mano_bwd_ws_floats': (c_l, [c_i]),
+    'rih_mano_fwd': (c_i, [C.POINTER(ManoModel), c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_i,
+                           C.c_void_p]),
+    'rih_mano_bwd': (c_i, [C.POINTER(ManoModel), c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f,
+                           c_f, c_f, c_f, c_f, c_f, c_f, c_i, C.c_void_p]),
+    'rih_version': (c_i, []),
+    'rih_arch': (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load (building if needed and possible) the shared library; raise if that fails."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path) or _build.needs_build():
+        try:
+            _build.build(verbose=False)
+        except Exception as e:  # noqa: BLE001
+            if not os.path.exists(path):
+                raise RuntimeError('librenderih_amd.so is missing and could not be built with hipcc (%s); '
+                                   'run `python -m renderih_amd._build`' % e)
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError => a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError('renderih_amd: %s failed with code %d' % (what, code))

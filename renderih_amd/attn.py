@@ -1,0 +1,323 @@
+"""GCN + attention blocks of the mesh decoder on the HIP ops (drop-in for models/model_attn/*.py).
+
+Parameter names follow the reference (`GCN_blocks.M.{norm1,fc1,norm2,fc2,shortcut,norm3}`, `w_qs/w_ks/w_vs/fc`,
+`layer_norm`, `ff.{layer_norm,fc1,fc2}`, `L_self_attn_layer`, `ffL/ffR` ...).  nn.Linear / nn.LayerNorm /
+nn.Embedding objects only hold parameters; compute goes through `renderih_amd.ops`.
+
+Reference quirks kept (SURVEY.md notes N2, N5, N6): `norm1` of every GCN_ResBlock is dead; inter_attn shares
+w_qs/w_ks/w_vs/fc between the hands; LayerNorm eps is 1e-6; Chebyshev features are interleaved (f, k).
+"""
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _xavier(layer):
+    """models/model_attn/*.py `weights_init`: xavier_uniform_ on Conv2d/Linear weights, zero bias."""
+    if isinstance(layer, (nn.Conv2d, nn.Linear)):
+        nn.init.xavier_uniform_(layer.weight.data)
+        if isinstance(layer, nn.Linear) and layer.bias is not None:
+            nn.init.constant_(layer.bias.data, 0.0)
+
+
+class DropCtx:
+    """Dropout bookkeeping for one forward: probability, base seed and a call counter (each dropout site draws a
+    distinct stream of the counter-based RNG; the mask is recomputed, not stored, in backward)."""
+
+    def __init__(self, p=0.0, training=False):
+        self.p = float(p) if training else 0.0
+        self.base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if self.p > 0 else 0
+        self.n = 0
+
+    def seed(self):
+        self.n += 1
+        return (self.base << 20) + self.n * 0x9E3779B1
+
+
+def _lin(m, x, residual=None, relu=False):
+    return ops.linear(x, m.weight, m.bias, residual=residual, relu=relu)
+
+
+def _ln(m, x, x2=None, relu=False):
+    return ops.layernorm(x, m.weight, m.bias, eps=m.eps, x2=x2, relu=relu)
+
+
+def _drop_add(dc, a, b):
+    """a + dropout(b)."""
+    return ops.add_dropout(a, b, dc.p, dc.seed() if dc.p > 0 else 0)
+
+
+def _lin_drop_res(dc, m, x, res):
+    """res + dropout(linear(x)); the add is fused into the GEMM epilogue when dropout is off."""
+    if dc.p > 0:
+        return _drop_add(dc, res, _lin(m, x))
+    return _lin(m, x, residual=res)
+
+
+class GraphCSR:
+    """Device CSR of a graph Laplacian and of its transpose (for the backward), fp32 like the reference's dense L."""
+
+    def __init__(self, L):
+        L = sp.csr_matrix(L).astype(np.float32)
+        L.sort_indices()
+        Lt = sp.csr_matrix(L.T)
+        Lt.sort_indices()
+        self.host = (L, Lt)
+        self.dev = None
+        self.n = L.shape[0]
+
+    def on(self, device):
+        if self.dev is None or self.dev[0][0].device != device:
+            def up(M):
+                return (torch.as_tensor(M.indptr.astype(np.int32), device=device),
+                        torch.as_tensor(M.indices.astype(np.int32), device=device),
+                        torch.as_tensor(M.data.astype(np.float32), device=device))
+            self.dev = (up(self.host[0]), up(self.host[1]))
+        return self.dev
+
+
+class GCN_ResBlock(nn.Module):
+    """models/model_attn/gcn.py:72-110."""
+
+    def __init__(self, in_dim, out_dim, mid_dim, graph_L, graph_k, drop_out=0.01):
+        super().__init__()
+        assert graph_k == 2, 'the reference configuration uses Chebyshev order K=2'
+        if isinstance(graph_L, np.ndarray):
+            dense = torch.from_numpy(graph_L).float()
+        else:
+            dense = torch.from_numpy(np.asarray(sp.csr_matrix(graph_L).astype(np.float32).todense())).float()
+        self.register_buffer('graph_L', dense, persistent=False)     # same non-persistent buffer as the reference
+        self._csr = GraphCSR(dense.numpy())
+        self.graph_k = graph_k
+        self.in_dim = in_dim
+        self.norm1 = nn.LayerNorm(in_dim, eps=1e-6)                  # dead in the reference forward (N2); kept for keys
+        self.fc1 = nn.Linear(in_dim * graph_k, mid_dim)
+        self.norm2 = nn.LayerNorm(out_dim, eps=1e-6)
+        self.fc2 = nn.Linear(mid_dim * graph_k, out_dim)
+        self.dropout = nn.Dropout(drop_out)
+        self.shortcut = nn.Linear(in_dim, out_dim)
+        self.norm3 = nn.LayerNorm(out_dim, eps=1e-6)
+
+    def forward(self, x, dc, relu_out):
+        csr, csr_t = self._csr.on(x.device)
+        x1 = _lin(self.fc1, ops.cheby_features(x, csr, csr_t))
+        x1 = _ln(self.norm2, x1, relu=True)
+        x1c = ops.cheby_features(x1, csr, csr_t)
+        if dc.p > 0:
+            x1 = _drop_add(dc, None, _lin(self.fc2, x1c))
+            return _ln(self.norm3, x1, x2=_lin(self.shortcut, x), relu=relu_out)
+        x2 = _lin(self.shortcut, x)
+        return _ln(self.norm3, _lin(self.fc2, x1c, residual=x2), relu=relu_out)
+
+
+class GraphLayer(nn.Module):
+    """models/model_attn/gcn.py:113-138."""
+
+    def __init__(self, in_dim=256, out_dim=256, graph_L=None, graph_k=2, graph_layer_num=3, drop_out=0.01):
+        super().__init__()
+        self.GCN_blocks = nn.ModuleList()
+        self.GCN_blocks.append(GCN_ResBlock(in_dim, out_dim, out_dim, graph_L, graph_k, drop_out))
+        for _ in range(graph_layer_num - 1):
+            self.GCN_blocks.append(GCN_ResBlock(out_dim, out_dim, out_dim, graph_L, graph_k, drop_out))
+        for m in self.modules():
+            _xavier(m)
+
+    def forward(self, x, dc):
+        n = len(self.GCN_blocks)
+        for i, blk in enumerate(self.GCN_blocks):
+            x = blk(x, dc, relu_out=(i != n - 1))        # F.relu between blocks fused into norm3's kernel
+        return x
+
+
+class MLP_res_block(nn.Module):
+    """models/model_attn/self_attn.py:17-33."""
+
+    def __init__(self, in_dim, hid_dim, dropout=0.1):
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(in_dim, eps=1e-6)
+        self.fc1 = nn.Linear(in_dim, hid_dim)
+        self.fc2 = nn.Linear(hid_dim, in_dim)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+
+    def forward(self, x, dc):
+        h = _lin(self.fc1, _ln(self.layer_norm, x), relu=True)
+        if dc.p > 0:
+            h = _drop_add(dc, None, h)
+        return _lin_drop_res(dc, self.fc2, h, x)
+
+
+class SelfAttn(nn.Module):
+    """models/model_attn/self_attn.py:36-85 (pre-LN multi-head self attention + MLP block)."""
+
+    def __init__(self, f_dim, hid_dim=None, n_heads=4, d_q=None, d_v=None, dropout=0.1):
+        super().__init__()
+        d_q = f_dim // n_heads if d_q is None else d_q
+        d_v = f_dim // n_heads if d_v is None else d_v
+        hid_dim = f_dim if hid_dim is None else hid_dim
+        assert d_q == d_v == f_dim // n_heads
+        self.n_heads, self.d_q, self.d_v, self.f_dim = n_heads, d_q, d_v, f_dim
+        self.norm = d_q ** 0.5
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.w_qs = nn.Linear(f_dim, n_heads * d_q)
+        self.w_ks = nn.Linear(f_dim, n_heads * d_q)
+        self.w_vs = nn.Linear(f_dim, n_heads * d_v)
+        self.layer_norm = nn.LayerNorm(f_dim, eps=1e-6)
+        self.fc = nn.Linear(n_heads * d_v, f_dim)
+        self.ff = MLP_res_block(f_dim, hid_dim, dropout)
+
+    def forward(self, x, dc):
+        y = _ln(self.layer_norm, x)
+        o = ops.attention(_lin(self.w_qs, y), _lin(self.w_ks, y), _lin(self.w_vs, y), self.n_heads,
+                          dc.p, dc.seed() if dc.p > 0 else 0)
+        x = _lin_drop_res(dc, self.fc, o, x)
+        return self.ff(x, dc)
+
+
+class img_feat_to_grid(nn.Module):
+    """models/model_attn/img_attn.py:38-67: patch conv + ReLU -> 64 tokens + position embedding -> SelfAttn."""
+
+    def __init__(self, img_size, img_f_dim, grid_size, grid_f_dim, n_heads=4, dropout=0.01):
+        super().__init__()
+        self.img_f_dim, self.img_size, self.grid_f_dim, self.grid_size = img_f_dim, img_size, grid_f_dim, grid_size
+        self.position_embeddings = nn.Embedding(grid_size * grid_size, grid_f_dim)
+        patch = img_size // grid_size
+        self.proj = nn.Conv2d(img_f_dim, grid_f_dim, kernel_size=patch, stride=patch)
+        self.self_attn = SelfAttn(grid_f_dim, n_heads=n_heads, hid_dim=grid_f_dim, dropout=dropout)
+
+    def forward(self, img, dc):
+        B, H, W, Cc = img.shape                                  # NHWC
+        assert Cc == self.img_f_dim and H == self.img_size and W == self.img_size
+        g = ops.conv2d(img, self.proj.weight, self.proj.bias, stride=self.proj.stride[0], pad=0, relu=True)
+        g = g.view(B, self.grid_size * self.grid_size, self.grid_f_dim)      # token = (h, w) row-major, as the reference
+        g = ops.add_rows_bcast(g, self.position_embeddings.weight)
+        return self.self_attn(g, dc)
+
+
+class img_attn(nn.Module):
+    """models/model_attn/img_attn.py:70-92."""
+
+    def __init__(self, verts_f_dim, img_f_dim, n_heads=4, d_q=None, d_v=None, dropout=0.1):
+        super().__init__()
+        self.img_f_dim, self.verts_f_dim = img_f_dim, verts_f_dim
+        self.fc = nn.Linear(img_f_dim, verts_f_dim)
+        self.Attn = SelfAttn(verts_f_dim, n_heads=n_heads, hid_dim=verts_f_dim, dropout=dropout)
+
+    def forward(self, verts_f, img_f, dc):
+        V = verts_f.shape[1]
+        x = torch.cat([verts_f, _lin(self.fc, img_f)], dim=1)    # token concat / slice: copies only
+        x = self.Attn(x, dc)
+        return x[:, :V]
+
+
+class img_ex(nn.Module):
+    """models/model_attn/img_attn.py:95-113."""
+
+    def __init__(self, img_size, img_f_dim, grid_size, grid_f_dim, verts_f_dim, n_heads=4, dropout=0.01):
+        super().__init__()
+        self.verts_f_dim = verts_f_dim
+        self.encoder = img_feat_to_grid(img_size, img_f_dim, grid_size, grid_f_dim, n_heads, dropout)
+        self.attn = img_attn(verts_f_dim, grid_f_dim, n_heads=n_heads, dropout=dropout)
+        for m in self.modules():
+            _xavier(m)
+
+    def forward(self, img, verts_f, dc):
+        return self.attn(verts_f, self.encoder(img, dc), dc)
+
+
+class inter_attn(nn.Module):
+    """models/model_attn/inter_attn.py:38-125: per-hand SelfAttn, then cross-hand attention with shared projections."""
+
+    def __init__(self, f_dim, n_heads=4, d_q=None, d_v=None, dropout=0.1):
+        super().__init__()
+        self.L_self_attn_layer = SelfAttn(f_dim, n_heads=n_heads, hid_dim=f_dim, dropout=dropout)
+        self.R_self_attn_layer = SelfAttn(f_dim, n_heads=n_heads, hid_dim=f_dim, dropout=dropout)
+        d_q = f_dim // n_heads if d_q is None else d_q
+        d_v = f_dim // n_heads if d_v is None else d_v
+        self.n_heads, self.d_q, self.d_v, self.f_dim = n_heads, d_q, d_v, f_dim
+        self.norm = d_q ** 0.5
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.w_qs = nn.Linear(f_dim, n_heads * d_q)
+        self.w_ks = nn.Linear(f_dim, n_heads * d_q)
+        self.w_vs = nn.Linear(f_dim, n_heads * d_v)
+        self.fc = nn.Linear(n_heads * d_v, f_dim)
+        self.layer_norm1 = nn.LayerNorm(f_dim, eps=1e-6)
+        self.layer_norm2 = nn.LayerNorm(f_dim, eps=1e-6)
+        self.ffL = MLP_res_block(f_dim, f_dim, dropout)
+        self.ffR = MLP_res_block(f_dim, f_dim, dropout)
+        for m in self.modules():
+            _xavier(m)
+
+    def forward(self, Lf, Rf, dc):
+        Lf = self.L_self_attn_layer(Lf, dc)
+        Rf = self.R_self_attn_layer(Rf, dc)
+        L2 = _ln(self.layer_norm1, Lf)
+        R2 = _ln(self.layer_norm2, Rf)
+        Lq, Lk, Lv = _lin(self.w_qs, L2), _lin(self.w_ks, L2), _lin(self.w_vs, L2)
+        Rq, Rk, Rv = _lin(self.w_qs, R2), _lin(self.w_ks, R2), _lin(self.w_vs, R2)
+        sd = (lambda: dc.seed()) if dc.p > 0 else (lambda: 0)
+        feat_R2L = ops.attention(Lq, Rk, Rv, self.n_heads, dc.p, sd())     # softmax(Lq Rk^T) Rv  (inter_attn.py:93-104)
+        feat_L2R = ops.attention(Rq, Lk, Lv, self.n_heads, dc.p, sd())
+        Lf = self.ffL(_lin_drop_res(dc, self.fc, feat_R2L, Lf), dc)
+        Rf = self.ffR(_lin_drop_res(dc, self.fc, feat_L2R, Rf), dc)
+        return Lf, Rf
+
+
+class DualGraphLayer(nn.Module):
+    """models/model_attn/DualGraph.py:21-91."""
+
+    def __init__(self, verts_in_dim=256, verts_out_dim=256, graph_L_Left=None, graph_L_Right=None, graph_k=2,
+                 graph_layer_num=4, img_size=64, img_f_dim=256, grid_size=8, grid_f_dim=128, n_heads=4, dropout=0.01):
+        super().__init__()
+        self.verts_num = graph_L_Left.shape[0]
+        self.verts_in_dim, self.img_size, self.img_f_dim = verts_in_dim, img_size, img_f_dim
+        self.position_embeddings = nn.Embedding(self.verts_num, self.verts_in_dim)
+        self.graph_left = GraphLayer(verts_in_dim, verts_out_dim, graph_L_Left, graph_k, graph_layer_num, dropout)
+        self.graph_right = GraphLayer(verts_in_dim, verts_out_dim, graph_L_Right, graph_k, graph_layer_num, dropout)
+        self.img_ex_left = img_ex(img_size, img_f_dim, grid_size, grid_f_dim, verts_out_dim, n_heads, dropout)
+        self.img_ex_right = img_ex(img_size, img_f_dim, grid_size, grid_f_dim, verts_out_dim, n_heads, dropout)
+        self.attn = inter_attn(verts_out_dim, n_heads=n_heads, dropout=dropout)
+
+    def forward(self, Lf, Rf, img_f, dc):
+        assert Lf.shape[1] == self.verts_num and Lf.shape[2] == self.verts_in_dim
+        pe = self.position_embeddings.weight
+        Lf = self.graph_left(ops.add_rows_bcast(Lf, pe), dc)
+        Rf = self.graph_right(ops.add_rows_bcast(Rf, pe), dc)
+        Lf = self.img_ex_left(img_f, Lf, dc)
+        Rf = self.img_ex_right(img_f, Rf, dc)
+        return self.attn(Lf, Rf, dc)
+
+
+class DualGraph(nn.Module):
+    """models/model_attn/DualGraph.py:94-139."""
+
+    def __init__(self, verts_in_dim=(512, 256, 128), verts_out_dim=(256, 128, 64), graph_L_Left=None,
+                 graph_L_Right=None, graph_k=(2, 2, 2), graph_layer_num=(4, 4, 4), img_size=(16, 32, 64),
+                 img_f_dim=(256, 256, 256), grid_size=(8, 8, 16), grid_f_dim=(256, 128, 64), n_heads=4, dropout=0.01):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        for i in range(len(verts_in_dim)):
+            self.layers.append(DualGraphLayer(verts_in_dim[i], verts_out_dim[i], graph_L_Left[i], graph_L_Right[i],
+                                              graph_k[i], graph_layer_num[i], img_size[i], img_f_dim[i], grid_size[i],
+                                              grid_f_dim[i], n_heads, dropout))
+        self._up = {}
+
+    def _upsample2(self, x):
+        """nn.Upsample(scale_factor=2, nearest) along V (DualGraph.py:11-18) as a row gather."""
+        V = x.shape[1]
+        key = (V, x.device)
+        if key not in self._up:
+            self._up[key] = ops.RowIndex(np.arange(2 * V) // 2, V, x.device)
+        return self._up[key](x)
+
+    def forward(self, Lf, Rf, img_f_list, dc):
+        for i, layer in enumerate(self.layers):
+            Lf, Rf = layer(Lf, Rf, img_f_list[i], dc)
+            if i != len(self.layers) - 1:
+                Lf, Rf = self._upsample2(Lf), self._upsample2(Rf)
+        return Lf, Rf

@@ -1,0 +1,1051 @@
+// rih_elem.hip -- HBM-bound kernels of the RenderIH pose network for gfx950: layout changes, pooling,
+// bilinear resampling, BatchNorm (training statistics, apply, backward), LayerNorm, softmax(+dropout),
+// residual/dropout adds, column sums, row gathers and the Chebyshev graph feature build.
+//
+// Everything is NHWC / row-major with the channel (feature) dimension fastest, so a wavefront's 64 lanes
+// touch consecutive addresses; float4 (16 B/lane) accesses wherever the channel count allows.  Row
+// reductions (LayerNorm, softmax) use one wavefront per row and DPP/xor shuffles over 64 lanes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/renderih_amd.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+inline int grid_for(long long n, int per_thread = 1) {
+    long long b = (n + (long long)TPB * per_thread - 1) / ((long long)TPB * per_thread);
+    if (b < 1) b = 1;
+    if (b > 16384) b = 16384;
+    return (int)b;
+}
+
+#define GRID_STRIDE(i, n) \
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// counter-based RNG for dropout: 32 uniform bits from (seed, element index)
+__device__ __forceinline__ uint32_t rih_hash(uint64_t seed, uint64_t idx) {
+    uint64_t x = idx * 0x9E3779B97F4A7C15ull + seed;
+    x ^= x >> 32;
+    x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    return (uint32_t)x;
+}
+__device__ __forceinline__ uint32_t drop_thresh(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t < 0.0) t = 0.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+
+// ------------------------------------------------------------------------------------------------ layout
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int H, int W,
+                                    int Cpad) {
+    const long long total = (long long)N * H * W * Cpad;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % Cpad);
+        const long long pix = i / Cpad;
+        const int hw = (int)(pix % ((long long)H * W));
+        const int n = (int)(pix / ((long long)H * W));
+        y[i] = (c < C) ? x[((long long)n * C + c) * H * W + hw] : 0.f;
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int H, int W,
+                                    int ldx) {
+    const long long total = (long long)N * C * H * W;
+    GRID_STRIDE(i, total) {
+        const int hw = (int)(i % ((long long)H * W));
+        const long long t = i / ((long long)H * W);
+        const int c = (int)(t % C);
+        const int n = (int)(t / C);
+        y[i] = x[((long long)n * H * W + hw) * ldx + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pooling
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int8_t* __restrict__ arg, int N,
+                                   int H, int W, int C, int Ho, int Wo) {
+    const long long total = (long long)N * Ho * Wo * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float best = -INFINITY;
+        int bi = 0;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hi = ho * 2 - 1 + kh;
+            if (hi < 0 || hi >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wi = wo * 2 - 1 + kw;
+                if (wi < 0 || wi >= W) continue;
+                const float v = x[(((long long)n * H + hi) * W + wi) * C + c];
+                if (v > best || v != v) { best = v; bi = kh * 3 + kw; }
+            }
+        }
+        y[i] = best;
+        arg[i] = (int8_t)bi;
+    }
+}
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int8_t* __restrict__ arg,
+                                   float* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
+    const long long total = (long long)N * H * W * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int wi = (int)(t % W);
+        t /= W;
+        const int hi = (int)(t % H);
+        const int n = (int)(t / H);
+        float s = 0.f;
+        for (int ho = hi / 2; ho <= (hi + 1) / 2; ++ho) {
+            if (ho >= Ho) continue;
+            const int kh = hi + 1 - 2 * ho;
+            if (kh < 0 || kh > 2) continue;
+            for (int wo = wi / 2; wo <= (wi + 1) / 2; ++wo) {
+                if (wo >= Wo) continue;
+                const int kw = wi + 1 - 2 * wo;
+                if (kw < 0 || kw > 2) continue;
+                const long long o = (((long long)n * Ho + ho) * Wo + wo) * C + c;
+                if (arg[o] == kh * 3 + kw) s += dy[o];
+            }
+        }
+        dx[i] = s;
+    }
+}
+
+__global__ void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int HW, int C) {
+    const long long total = (long long)N * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        const int n = (int)(i / C);
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) s += x[((long long)n * HW + p) * C + c];
+        y[i] = s / (float)HW;
+    }
+}
+
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int HW, int C) {
+    const long long total = (long long)N * HW * C;
+    const float inv = 1.f / (float)HW;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        const int n = (int)(i / ((long long)HW * C));
+        dx[i] = dy[(long long)n * C + c] * inv;
+    }
+}
+
+// bilinear x2, align_corners=True (nn.Upsample in models/encoder.py:51)
+__device__ __forceinline__ void bil_src(int o, float scale, int in_size, int& i0, int& i1, float& l1) {
+    const float src = scale * (float)o;
+    i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+__global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sw = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const long long total = (long long)N * Ho * Wo * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        int h0, h1, w0, w1;
+        float lh, lw;
+        bil_src(ho, sh, H, h0, h1, lh);
+        bil_src(wo, sw, W, w0, w1, lw);
+        const float* b = x + (long long)n * H * W * C + c;
+        const float x00 = b[((long long)h0 * W + w0) * C], x01 = b[((long long)h0 * W + w1) * C];
+        const float x10 = b[((long long)h1 * W + w0) * C], x11 = b[((long long)h1 * W + w1) * C];
+        const float hl0 = 1.f - lh, wl0 = 1.f - lw;
+        y[i] = hl0 * (wl0 * x00 + lw * x01) + lh * (wl0 * x10 + lw * x11);
+    }
+}
+
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W,
+                                      int C) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sw = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const long long total = (long long)N * H * W * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int wi = (int)(t % W);
+        t /= W;
+        const int hi = (int)(t % H);
+        const int n = (int)(t / H);
+        float s = 0.f;
+        for (int ho = max(0, 2 * hi - 2); ho <= min(Ho - 1, 2 * hi + 3); ++ho) {
+            int h0, h1;
+            float lh;
+            bil_src(ho, sh, H, h0, h1, lh);
+            const float wh = ((h0 == hi) ? (1.f - lh) : 0.f) + ((h1 == hi) ? lh : 0.f);
+            if (wh == 0.f) continue;
+            for (int wo = max(0, 2 * wi - 2); wo <= min(Wo - 1, 2 * wi + 3); ++wo) {
+                int w0, w1;
+                float lw;
+                bil_src(wo, sw, W, w0, w1, lw);
+                const float ww = ((w0 == wi) ? (1.f - lw) : 0.f) + ((w1 == wi) ? lw : 0.f);
+                if (ww == 0.f) continue;
+                s += wh * ww * dy[(((long long)n * Ho + ho) * Wo + wo) * C + c];
+            }
+        }
+        dx[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ column reductions
+// Shared helper for per-channel reductions over rows of an [rows][C] matrix (C % 4 == 0):
+// block = 256 threads = cgb channel-quads x rt row-threads; grid = (ceil(C/4/cgb), nchunk).
+struct ColGeom {
+    int cgb, rt, gx, nchunk, rows_per_chunk;
+};
+inline ColGeom col_geom(int rows, int C) {
+    ColGeom g;
+    const int CG = C / 4;
+    g.cgb = CG < 64 ? CG : 64;
+    int p = 1;
+    while (p * 2 <= g.cgb) p *= 2;       // power of two <= cgb so that 256 % cgb == 0
+    g.cgb = p;
+    g.rt = TPB / g.cgb;
+    g.gx = (CG + g.cgb - 1) / g.cgb;
+    int want = 2048 / g.gx;
+    if (want < 1) want = 1;
+    int maxc = (rows + g.rt * 4 - 1) / (g.rt * 4);
+    if (maxc < 1) maxc = 1;
+    g.nchunk = want < maxc ? want : maxc;
+    if (g.nchunk > 1024) g.nchunk = 1024;
+    g.rows_per_chunk = (rows + g.nchunk - 1) / g.nchunk;
+    g.nchunk = (rows + g.rows_per_chunk - 1) / g.rows_per_chunk;
+    return g;
+}
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// reduce `v1`,`v2` (per-thread float4 partials) across the rt row-threads of a block; thread ry==0 returns the sum
+template <int NV>
+__device__ __forceinline__ void block_col_reduce(float4 (&v)[NV], int cg, int ry, int cgb, int rt) {
+    __shared__ float4 red[TPB];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        red[ry * cgb + cg] = v[k];
+        __syncthreads();
+        for (int s = rt >> 1; s > 0; s >>= 1) {
+            if (ry < s) red[ry * cgb + cg] = f4add(red[ry * cgb + cg], red[(ry + s) * cgb + cg]);
+            __syncthreads();
+        }
+        v[k] = red[cg];
+        __syncthreads();
+    }
+}
+
+// BN training statistics, pass 1: shifted sums  sum(x - x0), sum((x - x0)^2) per chunk, x0 = first row
+__global__ __launch_bounds__(TPB) void bn_stats_partial_kernel(const float* __restrict__ x, int rows, int C, int cgb,
+                                                               int rt, int rows_per_chunk, float* __restrict__ ws) {
+    const int cg = threadIdx.x % cgb, ry = threadIdx.x / cgb;
+    const int g = blockIdx.x * cgb + cg;
+    const int CG = C / 4;
+    const int chunk = blockIdx.y, nchunk = gridDim.y;
+    float4 acc[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    if (g < CG) {
+        const float4 sh = *reinterpret_cast<const float4*>(x + g * 4);
+        const int r0 = chunk * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+        for (int r = r0 + ry; r < r1; r += rt) {
+            const float4 v = *reinterpret_cast<const float4*>(x + (long long)r * C + g * 4);
+            const float dx = v.x - sh.x, dy = v.y - sh.y, dz = v.z - sh.z, dw = v.w - sh.w;
+            acc[0].x += dx; acc[0].y += dy; acc[0].z += dz; acc[0].w += dw;
+            acc[1].x += dx * dx; acc[1].y += dy * dy; acc[1].z += dz * dz; acc[1].w += dw * dw;
+        }
+    }
+    block_col_reduce<2>(acc, cg, ry, cgb, rt);
+    if (ry == 0 && g < CG) {
+        *reinterpret_cast<float4*>(ws + ((long long)0 * nchunk + chunk) * C + g * 4) = acc[0];
+        *reinterpret_cast<float4*>(ws + ((long long)1 * nchunk + chunk) * C + g * 4) = acc[1];
+    }
+}
+
+__global__ void bn_stats_final_kernel(const float* __restrict__ x, const float* __restrict__ ws, int rows, int C,
+                                      int nchunk, float eps, float momentum, float* __restrict__ mean,
+                                      float* __restrict__ invstd, float* __restrict__ rmean, float* __restrict__ rvar) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        s1 += (double)ws[((long long)0 * nchunk + k) * C + c];
+        s2 += (double)ws[((long long)1 * nchunk + k) * C + c];
+    }
+    const double n = (double)rows;
+    const double d = s1 / n;
+    const double m = (double)x[c] + d;
+    double var = s2 / n - d * d;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean != nullptr) {
+        const double unb = (rows > 1) ? var * n / (n - 1.0) : var;
+        rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * m);
+        rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+    }
+}
+
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, int C, float eps,
+                                     float* __restrict__ mean, float* __restrict__ invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = rmean[c];
+    invstd[c] = 1.f / sqrtf(rvar[c] + eps);
+}
+
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ y,
+                                long long nquads, int C, int relu) {
+    const int CG = C / 4;
+    GRID_STRIDE(i, nquads) {
+        const int g = (int)(i % CG);
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 m = reinterpret_cast<const float4*>(mean)[g];
+        const float4 is = reinterpret_cast<const float4*>(invstd)[g];
+        const float4 ga = reinterpret_cast<const float4*>(gamma)[g];
+        const float4 be = reinterpret_cast<const float4*>(beta)[g];
+        float4 o;
+        o.x = (v.x - m.x) * (is.x * ga.x) + be.x;
+        o.y = (v.y - m.y) * (is.y * ga.y) + be.y;
+        o.z = (v.z - m.z) * (is.z * ga.z) + be.z;
+        o.w = (v.w - m.w) * (is.w * ga.w) + be.w;
+        if (res != nullptr) {
+            const float4 r = reinterpret_cast<const float4*>(res)[i];
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
+// BN backward pass 1: per-channel sum(dym), sum(dym * xhat), dym = dy * (y>0) when relu
+__global__ __launch_bounds__(TPB) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ y,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, int rows, int C, int cgb,
+                                                             int rt, int rows_per_chunk, int relu,
+                                                             float* __restrict__ ws) {
+    const int cg = threadIdx.x % cgb, ry = threadIdx.x / cgb;
+    const int g = blockIdx.x * cgb + cg;
+    const int CG = C / 4;
+    const int chunk = blockIdx.y, nchunk = gridDim.y;
+    float4 acc[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    if (g < CG) {
+        const float4 m = reinterpret_cast<const float4*>(mean)[g];
+        const float4 is = reinterpret_cast<const float4*>(invstd)[g];
+        const int r0 = chunk * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+        for (int r = r0 + ry; r < r1; r += rt) {
+            const long long o = (long long)r * C + g * 4;
+            float4 d = *reinterpret_cast<const float4*>(dy + o);
+            const float4 v = *reinterpret_cast<const float4*>(x + o);
+            if (relu) {
+                const float4 yy = *reinterpret_cast<const float4*>(y + o);
+                if (!(yy.x > 0.f)) d.x = 0.f;
+                if (!(yy.y > 0.f)) d.y = 0.f;
+                if (!(yy.z > 0.f)) d.z = 0.f;
+                if (!(yy.w > 0.f)) d.w = 0.f;
+            }
+            acc[0].x += d.x; acc[0].y += d.y; acc[0].z += d.z; acc[0].w += d.w;
+            acc[1].x += d.x * ((v.x - m.x) * is.x);
+            acc[1].y += d.y * ((v.y - m.y) * is.y);
+            acc[1].z += d.z * ((v.z - m.z) * is.z);
+            acc[1].w += d.w * ((v.w - m.w) * is.w);
+        }
+    }
+    block_col_reduce<2>(acc, cg, ry, cgb, rt);
+    if (ry == 0 && g < CG) {
+        *reinterpret_cast<float4*>(ws + ((long long)0 * nchunk + chunk) * C + g * 4) = acc[0];
+        *reinterpret_cast<float4*>(ws + ((long long)1 * nchunk + chunk) * C + g * 4) = acc[1];
+    }
+}
+
+// finalize: sums[0][C] = sum dym, sums[1][C] = sum dym*xhat (also the dbeta / dgamma outputs)
+__global__ void two_sum_final_kernel(const float* __restrict__ ws, int C, int nchunk, float* __restrict__ out0,
+                                     float* __restrict__ out1) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        s1 += (double)ws[((long long)0 * nchunk + k) * C + c];
+        s2 += (double)ws[((long long)1 * nchunk + k) * C + c];
+    }
+    out0[c] = (float)s1;
+    out1[c] = (float)s2;
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                    const float* __restrict__ y, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ sum_dy, const float* __restrict__ sum_dyxh,
+                                    float* __restrict__ dx, float* __restrict__ dres, long long nquads, int C,
+                                    float inv_rows, int relu, int frozen) {
+    const int CG = C / 4;
+    GRID_STRIDE(i, nquads) {
+        const int g = (int)(i % CG);
+        float4 d = reinterpret_cast<const float4*>(dy)[i];
+        if (relu) {
+            const float4 yy = reinterpret_cast<const float4*>(y)[i];
+            if (!(yy.x > 0.f)) d.x = 0.f;
+            if (!(yy.y > 0.f)) d.y = 0.f;
+            if (!(yy.z > 0.f)) d.z = 0.f;
+            if (!(yy.w > 0.f)) d.w = 0.f;
+        }
+        if (dres != nullptr) reinterpret_cast<float4*>(dres)[i] = d;
+        const float4 is = reinterpret_cast<const float4*>(invstd)[g];
+        const float4 ga = reinterpret_cast<const float4*>(gamma)[g];
+        float4 o;
+        if (frozen) {
+            o.x = d.x * is.x * ga.x; o.y = d.y * is.y * ga.y; o.z = d.z * is.z * ga.z; o.w = d.w * is.w * ga.w;
+        } else {
+            const float4 v = reinterpret_cast<const float4*>(x)[i];
+            const float4 m = reinterpret_cast<const float4*>(mean)[g];
+            const float4 s1 = reinterpret_cast<const float4*>(sum_dy)[g];
+            const float4 s2 = reinterpret_cast<const float4*>(sum_dyxh)[g];
+            o.x = (d.x - s1.x * inv_rows - ((v.x - m.x) * is.x) * (s2.x * inv_rows)) * (is.x * ga.x);
+            o.y = (d.y - s1.y * inv_rows - ((v.y - m.y) * is.y) * (s2.y * inv_rows)) * (is.y * ga.y);
+            o.z = (d.z - s1.z * inv_rows - ((v.z - m.z) * is.z) * (s2.z * inv_rows)) * (is.z * ga.z);
+            o.w = (d.w - s1.w * inv_rows - ((v.w - m.w) * is.w) * (s2.w * inv_rows)) * (is.w * ga.w);
+        }
+        reinterpret_cast<float4*>(dx)[i] = o;
+    }
+}
+
+// generic column sum (bias gradients): any C, scalar path; block = 64 channels x 4 row-threads
+__global__ __launch_bounds__(TPB) void colsum_partial_kernel(const float* __restrict__ x, int rows, int C, int ldx,
+                                                             int rows_per_chunk, float* __restrict__ ws) {
+    __shared__ float red[TPB];
+    const int cl = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int chunk = blockIdx.y;
+    float s = 0.f;
+    if (c < C) {
+        const int r0 = chunk * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+        for (int r = r0 + ry; r < r1; r += 4) s += x[(long long)r * ldx + c];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (ry == 0 && c < C) ws[(long long)chunk * C + c] = red[cl] + red[64 + cl] + red[128 + cl] + red[192 + cl];
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ ws, int C, int nchunk, float* __restrict__ out,
+                                    int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < nchunk; ++k) s += (double)ws[(long long)k * C + c];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+inline int colsum_nchunk(int rows, int C) {
+    const int gx = (C + 63) / 64;
+    int want = 1024 / gx;
+    if (want < 1) want = 1;
+    int maxc = (rows + 63) / 64;
+    if (maxc < 1) maxc = 1;
+    return want < maxc ? want : maxc;
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+constexpr int LN_MAXPER = 16;   // D <= 1024
+
+__global__ __launch_bounds__(TPB) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ x2,
+                                                            const float* __restrict__ g, const float* __restrict__ b,
+                                                            float* __restrict__ y, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int rows, int D, float eps,
+                                                            int relu) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nper = (D + 63) / 64;
+    for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+        float v[LN_MAXPER];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXPER; ++i) {
+            const int e = lane + 64 * i;
+            float t = 0.f;
+            if (i < nper && e < D) {
+                t = x[(long long)r * D + e];
+                if (x2 != nullptr) t += x2[(long long)r * D + e];
+            }
+            v[i] = t;
+            s += t;
+        }
+        const float m = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXPER; ++i) {
+            const int e = lane + 64 * i;
+            if (i < nper && e < D) { const float d = v[i] - m; q += d * d; }
+        }
+        const float var = wave_sum(q) / (float)D;
+        const float rs = 1.f / sqrtf(var + eps);
+#pragma unroll
+        for (int i = 0; i < LN_MAXPER; ++i) {
+            const int e = lane + 64 * i;
+            if (i < nper && e < D) {
+                float o = (v[i] - m) * rs * g[e] + b[e];
+                if (relu) o = fmaxf(o, 0.f);
+                y[(long long)r * D + e] = o;
+            }
+        }
+        if (lane == 0) { mean[r] = m; rstd[r] = rs; }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ x2, const float* __restrict__ y,
+                                                            const float* __restrict__ g,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dx,
+                                                            float* __restrict__ ws, int rows, int D, int relu) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nper = (D + 63) / 64;
+    float dgacc[LN_MAXPER], dbacc[LN_MAXPER];
+#pragma unroll
+    for (int i = 0; i < LN_MAXPER; ++i) { dgacc[i] = 0.f; dbacc[i] = 0.f; }
+    for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+        const float m = mean[r], rs = rstd[r];
+        float xh[LN_MAXPER], gd[LN_MAXPER];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXPER; ++i) {
+            const int e = lane + 64 * i;
+            xh[i] = 0.f;
+            gd[i] = 0.f;
+            if (i < nper && e < D) {
+                float t = x[(long long)r * D + e];
+                if (x2 != nullptr) t += x2[(long long)r * D + e];
+                float d = dy[(long long)r * D + e];
+                if (relu && !(y[(long long)r * D + e] > 0.f)) d = 0.f;
+                const float h = (t - m) * rs;
+                xh[i] = h;
+                dgacc[i] += d * h;
+                dbacc[i] += d;
+                const float gdy = d * g[e];
+                gd[i] = gdy;
+                c1 += gdy;
+                c2 += gdy * h;
+            }
+        }
+        c1 = wave_sum(c1) / (float)D;
+        c2 = wave_sum(c2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < LN_MAXPER; ++i) {
+            const int e = lane + 64 * i;
+            if (i < nper && e < D) dx[(long long)r * D + e] = rs * (gd[i] - c1 - xh[i] * c2);
+        }
+    }
+    // reduce dg/db over the 4 waves of the block, write ws[blk][{dg,db}][D]
+#pragma unroll
+    for (int i = 0; i < LN_MAXPER; ++i) {
+        if (i < nper) {
+            const int e = lane + 64 * i;
+            red[wave][lane] = dgacc[i];
+            __syncthreads();
+            if (wave == 0 && e < D)
+                ws[((long long)blockIdx.x * 2 + 0) * D + e] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+            __syncthreads();
+            red[wave][lane] = dbacc[i];
+            __syncthreads();
+            if (wave == 0 && e < D)
+                ws[((long long)blockIdx.x * 2 + 1) * D + e] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void ln_param_final_kernel(const float* __restrict__ ws, int D, int nblk, float* __restrict__ dg,
+                                      float* __restrict__ db) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= D) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        a += (double)ws[((long long)k * 2 + 0) * D + e];
+        b += (double)ws[((long long)k * 2 + 1) * D + e];
+    }
+    dg[e] = (float)a;
+    db[e] = (float)b;
+}
+
+// ------------------------------------------------------------------------------------------------ softmax
+constexpr int SM_MAXPER = 16;   // cols <= 1024
+
+__global__ __launch_bounds__(TPB) void softmax_fwd_kernel(const float* __restrict__ S, float* __restrict__ P,
+                                                          float* __restrict__ Pd, long long rows, int cols, int ld,
+                                                          float drop_p, uint64_t seed) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nper = (cols + 63) / 64;
+    const uint32_t thr = drop_thresh(drop_p);
+    const float keep_scale = (drop_p > 0.f) ? 1.f / (1.f - drop_p) : 1.f;
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
+        float v[SM_MAXPER];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < SM_MAXPER; ++i) {
+            const int j = lane + 64 * i;
+            v[i] = -INFINITY;
+            if (i < nper && j < cols) { v[i] = S[r * ld + j]; mx = fmaxf(mx, v[i]); }
+        }
+        mx = wave_max(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < SM_MAXPER; ++i) {
+            const int j = lane + 64 * i;
+            if (i < nper && j < cols) { v[i] = expf(v[i] - mx); s += v[i]; }
+        }
+        s = wave_sum(s);
+        const float inv = 1.f / s;
+#pragma unroll
+        for (int i = 0; i < SM_MAXPER; ++i) {
+            const int j = lane + 64 * i;
+            if (i < nper && j < cols) {
+                const float pr = v[i] * inv;
+                P[r * ld + j] = pr;
+                if (drop_p > 0.f) {
+                    const bool keep = rih_hash(seed, (uint64_t)(r * cols + j)) >= thr;
+                    Pd[r * ld + j] = keep ? pr * keep_scale : 0.f;
+                } else if (Pd != P) {
+                    Pd[r * ld + j] = pr;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dPd,
+                                                          long long rows, int cols, int ld, float drop_p, uint64_t seed,
+                                                          float alpha) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nper = (cols + 63) / 64;
+    const uint32_t thr = drop_thresh(drop_p);
+    const float keep_scale = (drop_p > 0.f) ? 1.f / (1.f - drop_p) : 1.f;
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
+        float pv[SM_MAXPER], dp[SM_MAXPER];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < SM_MAXPER; ++i) {
+            const int j = lane + 64 * i;
+            pv[i] = 0.f;
+            dp[i] = 0.f;
+            if (i < nper && j < cols) {
+                pv[i] = P[r * ld + j];
+                float d = dPd[r * ld + j];
+                if (drop_p > 0.f) {
+                    const bool keep = rih_hash(seed, (uint64_t)(r * cols + j)) >= thr;
+                    d = keep ? d * keep_scale : 0.f;
+                }
+                dp[i] = d;
+                dot += d * pv[i];
+            }
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int i = 0; i < SM_MAXPER; ++i) {
+            const int j = lane + 64 * i;
+            if (i < nper && j < cols) dPd[r * ld + j] = alpha * pv[i] * (dp[i] - dot);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise
+__global__ void add_dropout_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                                   long long n, long long bmod, float drop_p, uint64_t seed) {
+    const uint32_t thr = drop_thresh(drop_p);
+    const float keep_scale = (drop_p > 0.f) ? 1.f / (1.f - drop_p) : 1.f;
+    GRID_STRIDE(i, n) {
+        float bv = b[bmod > 0 ? (i % bmod) : i];
+        if (drop_p > 0.f) bv = (rih_hash(seed, (uint64_t)i) >= thr) ? bv * keep_scale : 0.f;
+        y[i] = (a != nullptr ? a[i] : 0.f) + bv;
+    }
+}
+
+__global__ void dropout_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long long n, float drop_p,
+                                   uint64_t seed) {
+    const uint32_t thr = drop_thresh(drop_p);
+    const float keep_scale = (drop_p > 0.f) ? 1.f / (1.f - drop_p) : 1.f;
+    GRID_STRIDE(i, n) {
+        float d = dy[i];
+        if (drop_p > 0.f) d = (rih_hash(seed, (uint64_t)i) >= thr) ? d * keep_scale : 0.f;
+        dx[i] = d;
+    }
+}
+
+__global__ void relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+    GRID_STRIDE(i, n) y[i] = fmaxf(x[i], 0.f);
+}
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                long long n) {
+    GRID_STRIDE(i, n) dx[i] = (y[i] > 0.f) ? dy[i] : 0.f;
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx, float* __restrict__ y,
+                                   int B, int Vin, int Vout, int D) {
+    const long long total = (long long)B * Vout * D;
+    GRID_STRIDE(i, total) {
+        const int d = (int)(i % D);
+        const long long t = i / D;
+        const int v = (int)(t % Vout);
+        const int b = (int)(t / Vout);
+        y[i] = x[((long long)b * Vin + idx[v]) * D + d];
+    }
+}
+
+__global__ void scatter_rows_add_kernel(const float* __restrict__ dy, const int32_t* __restrict__ inv_ptr,
+                                        const int32_t* __restrict__ inv_idx, float* __restrict__ dx, int B, int Vin,
+                                        int Vout, int D) {
+    const long long total = (long long)B * Vin * D;
+    GRID_STRIDE(i, total) {
+        const int d = (int)(i % D);
+        const long long t = i / D;
+        const int v = (int)(t % Vin);
+        const int b = (int)(t / Vin);
+        float s = 0.f;
+        for (int k = inv_ptr[v]; k < inv_ptr[v + 1]; ++k) s += dy[((long long)b * Vout + inv_idx[k]) * D + d];
+        dx[i] = s;
+    }
+}
+
+__global__ void cheby_fwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ indptr,
+                                 const int32_t* __restrict__ indices, const float* __restrict__ vals,
+                                 float* __restrict__ y, int B, int V, int F) {
+    const long long total = (long long)B * V * F;
+    GRID_STRIDE(i, total) {
+        const int f = (int)(i % F);
+        const long long t = i / F;
+        const int v = (int)(t % V);
+        const int b = (int)(t / V);
+        const float* xb = x + (long long)b * V * F + f;
+        float s = 0.f;
+        for (int k = indptr[v]; k < indptr[v + 1]; ++k) s += vals[k] * xb[(long long)indices[k] * F];
+        float2 o;
+        o.x = xb[(long long)v * F];
+        o.y = s;
+        reinterpret_cast<float2*>(y)[i] = o;
+    }
+}
+
+__global__ void cheby_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ indptr,
+                                 const int32_t* __restrict__ indices, const float* __restrict__ vals,
+                                 float* __restrict__ dx, int B, int V, int F) {
+    const long long total = (long long)B * V * F;
+    GRID_STRIDE(i, total) {
+        const int f = (int)(i % F);
+        const long long t = i / F;
+        const int v = (int)(t % V);
+        const int b = (int)(t / V);
+        const float* db = dy + (long long)b * V * 2 * F + 2 * f;
+        float s = db[(long long)v * 2 * F];
+        for (int k = indptr[v]; k < indptr[v + 1]; ++k) s += vals[k] * db[(long long)indices[k] * 2 * F + 1];
+        dx[i] = s;
+    }
+}
+
+// orthographic projection uv = (scale*img) * xyz[:2] + (trans*img/2 + img/2)   (utils/manoutils.py:26-44)
+__global__ void project_fwd_kernel(const float* __restrict__ v, const float* __restrict__ scale,
+                                   const float* __restrict__ trans, float* __restrict__ out, int B, int V, float img) {
+    const long long total = (long long)B * V;
+    GRID_STRIDE(i, total) {
+        const int b = (int)(i / V);
+        const float s = scale[b] * img;
+        const float t0 = trans[b * 2 + 0] * img / 2.f + img / 2.f;
+        const float t1 = trans[b * 2 + 1] * img / 2.f + img / 2.f;
+        out[i * 2 + 0] = s * v[i * 3 + 0] + t0;
+        out[i * 2 + 1] = s * v[i * 3 + 1] + t1;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void project_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ v,
+                                                          const float* __restrict__ scale, float* __restrict__ dv,
+                                                          float* __restrict__ dscale, float* __restrict__ dtrans,
+                                                          int V, float img) {
+    __shared__ float red[3][TPB / 64];
+    const int b = blockIdx.x;
+    const float s = scale[b] * img;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = threadIdx.x; i < V; i += TPB) {
+        const long long o = (long long)b * V + i;
+        const float d0 = dout[o * 2 + 0], d1 = dout[o * 2 + 1];
+        dv[o * 3 + 0] = s * d0;
+        dv[o * 3 + 1] = s * d1;
+        dv[o * 3 + 2] = 0.f;
+        a0 += d0 * v[o * 3 + 0] + d1 * v[o * 3 + 1];
+        a1 += d0;
+        a2 += d1;
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = a0; red[1][wave] = a1; red[2][wave] = a2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        for (int w = 0; w < TPB / 64; ++w) { r0 += red[0][w]; r1 += red[1][w]; r2 += red[2][w]; }
+        dscale[b] = r0 * img;
+        dtrans[b * 2 + 0] = r1 * img / 2.f;
+        dtrans[b * 2 + 1] = r2 * img / 2.f;
+    }
+}
+
+}  // namespace
+
+#define STREAM ((hipStream_t)stream)
+#define LAUNCH_RET() return (int)hipGetLastError()
+
+extern "C" int rih_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cpad, void* stream) {
+    if (!x || !y || N < 1 || C < 1 || H < 1 || W < 1 || Cpad < C) return RIH_EINVAL;
+    const long long total = (long long)N * H * W * Cpad;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(TPB), 0, STREAM, x, y, N, C, H, W, Cpad);
+    LAUNCH_RET();
+}
+extern "C" int rih_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int ldx, void* stream) {
+    if (!x || !y || N < 1 || C < 1 || H < 1 || W < 1 || ldx < C) return RIH_EINVAL;
+    const long long total = (long long)N * H * W * C;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(TPB), 0, STREAM, x, y, N, C, H, W, ldx);
+    LAUNCH_RET();
+}
+extern "C" int rih_maxpool3x3s2_fwd(const float* x, float* y, int8_t* arg, int N, int H, int W, int C, void* stream) {
+    if (!x || !y || !arg || N < 1 || H < 1 || W < 1 || C < 1) return RIH_EINVAL;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo * C;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, STREAM, x, y, arg, N, H, W, C, Ho, Wo);
+    LAUNCH_RET();
+}
+extern "C" int rih_maxpool3x3s2_bwd(const float* dy, const int8_t* arg, float* dx, int N, int H, int W, int C,
+                                    void* stream) {
+    if (!dy || !dx || !arg || N < 1 || H < 1 || W < 1 || C < 1) return RIH_EINVAL;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)N * H * W * C;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, STREAM, dy, arg, dx, N, H, W, C, Ho, Wo);
+    LAUNCH_RET();
+}
+extern "C" int rih_avgpool_fwd(const float* x, float* y, int N, int HW, int C, void* stream) {
+    if (!x || !y || N < 1 || HW < 1 || C < 1) return RIH_EINVAL;
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for((long long)N * C)), dim3(TPB), 0, STREAM, x, y, N, HW, C);
+    LAUNCH_RET();
+}
+extern "C" int rih_avgpool_bwd(const float* dy, float* dx, int N, int HW, int C, void* stream) {
+    if (!dy || !dx || N < 1 || HW < 1 || C < 1) return RIH_EINVAL;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((long long)N * HW * C)), dim3(TPB), 0, STREAM, dy, dx, N, HW, C);
+    LAUNCH_RET();
+}
+extern "C" int rih_upsample2x_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    if (!x || !y || N < 1 || H < 1 || W < 1 || C < 1) return RIH_EINVAL;
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for((long long)N * 4 * H * W * C)), dim3(TPB), 0, STREAM, x, y,
+                       N, H, W, C);
+    LAUNCH_RET();
+}
+extern "C" int rih_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+    if (!dy || !dx || N < 1 || H < 1 || W < 1 || C < 1) return RIH_EINVAL;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((long long)N * H * W * C)), dim3(TPB), 0, STREAM, dy, dx, N,
+                       H, W, C);
+    LAUNCH_RET();
+}
+
+extern "C" int64_t rih_bn_ws_floats(int rows, int C) {
+    if (rows < 1 || C < 4 || (C % 4) != 0) return 0;
+    const ColGeom g = col_geom(rows, C);
+    return (int64_t)2 * g.nchunk * C + 2 * C;
+}
+extern "C" int rih_bn_stats(const float* x, int rows, int C, float eps, float momentum, float* mean, float* invstd,
+                            float* running_mean, float* running_var, float* ws, void* stream) {
+    if (!x || !mean || !invstd || !ws || rows < 1 || C < 4 || (C % 4) != 0) return RIH_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return RIH_EINVAL;
+    const ColGeom g = col_geom(rows, C);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(g.gx, g.nchunk), dim3(TPB), 0, STREAM, x, rows, C, g.cgb, g.rt,
+                       g.rows_per_chunk, ws);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 127) / 128), dim3(128), 0, STREAM, x, ws, rows, C, g.nchunk, eps,
+                       momentum, mean, invstd, running_mean, running_var);
+    LAUNCH_RET();
+}
+extern "C" int rih_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean,
+                                 float* invstd, void* stream) {
+    if (!running_mean || !running_var || !mean || !invstd || C < 1) return RIH_EINVAL;
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 127) / 128), dim3(128), 0, STREAM, running_mean, running_var, C,
+                       eps, mean, invstd);
+    LAUNCH_RET();
+}
+extern "C" int rih_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, const float* residual, float* y, int rows, int C, int relu,
+                            void* stream) {
+    if (!x || !mean || !invstd || !gamma || !beta || !y || rows < 1 || C < 4 || (C % 4) != 0) return RIH_EINVAL;
+    const long long nq = (long long)rows * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(nq)), dim3(TPB), 0, STREAM, x, mean, invstd, gamma, beta, residual,
+                       y, nq, C, relu);
+    LAUNCH_RET();
+}
+extern "C" int rih_bn_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                          const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C,
+                          int relu, int frozen_stats, float* ws, void* stream) {
+    if (!dy || !x || !mean || !invstd || !gamma || !dx || !dgamma || !dbeta || !ws) return RIH_EINVAL;
+    if (relu && !y) return RIH_EINVAL;
+    if (rows < 1 || C < 4 || (C % 4) != 0) return RIH_EINVAL;
+    const ColGeom g = col_geom(rows, C);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(g.gx, g.nchunk), dim3(TPB), 0, STREAM, dy, x, y, mean, invstd, rows, C,
+                       g.cgb, g.rt, g.rows_per_chunk, relu, ws);
+    hipLaunchKernelGGL(two_sum_final_kernel, dim3((C + 127) / 128), dim3(128), 0, STREAM, ws, C, g.nchunk, dbeta, dgamma);
+    const long long nq = (long long)rows * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nq)), dim3(TPB), 0, STREAM, dy, x, y, mean, invstd, gamma,
+                       dbeta, dgamma, dx, dres, nq, C, 1.f / (float)rows, relu, frozen_stats);
+    LAUNCH_RET();
+}
+
+extern "C" int rih_ln_nblk(int rows) {
+    int n = (rows + 15) / 16;
+    if (n < 1) n = 1;
+    if (n > 512) n = 512;
+    return n;
+}
+extern "C" int rih_layernorm_fwd(const float* x, const float* x2, const float* g, const float* b, float* y, float* mean,
+                                 float* rstd, int rows, int D, float eps, int relu, void* stream) {
+    if (!x || !g || !b || !y || !mean || !rstd || rows < 1 || D < 1 || D > 64 * LN_MAXPER) return RIH_EINVAL;
+    int blocks = (rows + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks), dim3(TPB), 0, STREAM, x, x2, g, b, y, mean, rstd, rows, D, eps,
+                       relu);
+    LAUNCH_RET();
+}
+extern "C" int rih_layernorm_bwd(const float* dy, const float* x, const float* x2, const float* y, const float* g,
+                                 const float* mean, const float* rstd, float* dx, float* dg, float* db, int rows, int D,
+                                 int relu, float* ws, void* stream) {
+    if (!dy || !x || !g || !mean || !rstd || !dx || !dg || !db || !ws) return RIH_EINVAL;
+    if (relu && !y) return RIH_EINVAL;
+    if (rows < 1 || D < 1 || D > 64 * LN_MAXPER) return RIH_EINVAL;
+    const int nblk = rih_ln_nblk(rows);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(TPB), 0, STREAM, dy, x, x2, y, g, mean, rstd, dx, ws, rows,
+                       D, relu);
+    hipLaunchKernelGGL(ln_param_final_kernel, dim3((D + 127) / 128), dim3(128), 0, STREAM, ws, D, nblk, dg, db);
+    LAUNCH_RET();
+}
+extern "C" int rih_softmax_fwd(const float* S, float* P, float* Pd, int64_t rows, int cols, int ld, float drop_p,
+                               uint64_t seed, void* stream) {
+    if (!S || !P || !Pd || rows < 1 || cols < 1 || cols > 64 * SM_MAXPER || ld < cols) return RIH_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f) return RIH_EINVAL;
+    if (drop_p > 0.f && Pd == P) return RIH_EINVAL;
+    long long blocks = (rows + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((int)blocks), dim3(TPB), 0, STREAM, S, P, Pd, (long long)rows, cols, ld,
+                       drop_p, seed);
+    LAUNCH_RET();
+}
+extern "C" int rih_softmax_bwd(const float* P, float* dPd, int64_t rows, int cols, int ld, float drop_p, uint64_t seed,
+                               float alpha, void* stream) {
+    if (!P || !dPd || rows < 1 || cols < 1 || cols > 64 * SM_MAXPER || ld < cols) return RIH_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f) return RIH_EINVAL;
+    long long blocks = (rows + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((int)blocks), dim3(TPB), 0, STREAM, P, dPd, (long long)rows, cols, ld,
+                       drop_p, seed, alpha);
+    LAUNCH_RET();
+}
+
+extern "C" int rih_add_dropout(const float* a, const float* b, float* y, int64_t n, int D, int b_bcast_rows,
+                               float drop_p, uint64_t seed, void* stream) {
+    if (!b || !y || n < 1 || D < 1 || b_bcast_rows < 0 || drop_p < 0.f || drop_p >= 1.f) return RIH_EINVAL;
+    const long long bmod = (long long)b_bcast_rows * D;
+    hipLaunchKernelGGL(add_dropout_kernel, dim3(grid_for(n, 4)), dim3(TPB), 0, STREAM, a, b, y, (long long)n, bmod, drop_p,
+                       seed);
+    LAUNCH_RET();
+}
+extern "C" int rih_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64_t seed, void* stream) {
+    if (!dy || !dx || n < 1 || drop_p < 0.f || drop_p >= 1.f) return RIH_EINVAL;
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n, 4)), dim3(TPB), 0, STREAM, dy, dx, (long long)n, drop_p, seed);
+    LAUNCH_RET();
+}
+extern "C" int rih_relu_fwd(const float* x, float* y, int64_t n, void* stream) {
+    if (!x || !y || n < 1) return RIH_EINVAL;
+    hipLaunchKernelGGL(relu_fwd_kernel, dim3(grid_for(n, 4)), dim3(TPB), 0, STREAM, x, y, (long long)n);
+    LAUNCH_RET();
+}
+extern "C" int rih_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+    if (!dy || !y || !dx || n < 1) return RIH_EINVAL;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n, 4)), dim3(TPB), 0, STREAM, dy, y, dx, (long long)n);
+    LAUNCH_RET();
+}
+extern "C" int64_t rih_colsum_ws_floats(int rows, int C) {
+    if (rows < 1 || C < 1) return 0;
+    return (int64_t)colsum_nchunk(rows, C) * C;
+}
+extern "C" int rih_colsum(const float* x, int rows, int C, int ldx, float* out, int accumulate, float* ws,
+                          void* stream) {
+    if (!x || !out || !ws || rows < 1 || C < 1 || ldx < C) return RIH_EINVAL;
+    const int nchunk = colsum_nchunk(rows, C);
+    const int rpc = (rows + nchunk - 1) / nchunk;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, nchunk), dim3(TPB), 0, STREAM, x, rows, C, ldx, rpc, ws);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 127) / 128), dim3(128), 0, STREAM, ws, C, nchunk, out, accumulate);
+    LAUNCH_RET();
+}
+extern "C" int rih_gather_rows(const float* x, const int32_t* idx, float* y, int B, int Vin, int Vout, int D,
+                               void* stream) {
+    if (!x || !idx || !y || B < 1 || Vin < 1 || Vout < 1 || D < 1) return RIH_EINVAL;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long long)B * Vout * D)), dim3(TPB), 0, STREAM, x, idx, y, B,
+                       Vin, Vout, D);
+    LAUNCH_RET();
+}
+extern "C" int rih_scatter_rows_add(const float* dy, const int32_t* inv_ptr, const int32_t* inv_idx, float* dx, int B,
+                                    int Vin, int Vout, int D, void* stream) {
+    if (!dy || !inv_ptr || !inv_idx || !dx || B < 1 || Vin < 1 || Vout < 1 || D < 1) return RIH_EINVAL;
+    hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(grid_for((long long)B * Vin * D)), dim3(TPB), 0, STREAM, dy, inv_ptr,
+                       inv_idx, dx, B, Vin, Vout, D);
+    LAUNCH_RET();
+}
+extern "C" int rih_cheby_fwd(const float* x, const int32_t* indptr, const int32_t* indices, const float* vals, float* y,
+                             int B, int V, int F, void* stream) {
+    if (!x || !indptr || !indices || !vals || !y || B < 1 || V < 1 || F < 1) return RIH_EINVAL;
+    hipLaunchKernelGGL(cheby_fwd_kernel, dim3(grid_for((long long)B * V * F)), dim3(TPB), 0, STREAM, x, indptr, indices,
+                       vals, y, B, V, F);
+    LAUNCH_RET();
+}
+extern "C" int rih_cheby_bwd(const float* dy, const int32_t* t_indptr, const int32_t* t_indices, const float* t_vals,
+                             float* dx, int B, int V, int F, void* stream) {
+    if (!dy || !t_indptr || !t_indices || !t_vals || !dx || B < 1 || V < 1 || F < 1) return RIH_EINVAL;
+    hipLaunchKernelGGL(cheby_bwd_kernel, dim3(grid_for((long long)B * V * F)), dim3(TPB), 0, STREAM, dy, t_indptr,
+                       t_indices, t_vals, dx, B, V, F);
+    LAUNCH_RET();
+}
+
+extern "C" int rih_project_fwd(const float* v, const float* scale, const float* trans, float* out, int B, int V,
+                               float img_size, void* stream) {
+    if (!v || !scale || !trans || !out || B < 1 || V < 1) return RIH_EINVAL;
+    hipLaunchKernelGGL(project_fwd_kernel, dim3(grid_for((long long)B * V)), dim3(TPB), 0, STREAM, v, scale, trans, out,
+                       B, V, img_size);
+    LAUNCH_RET();
+}
+extern "C" int rih_project_bwd(const float* dout, const float* v, const float* scale, float* dv, float* dscale,
+                               float* dtrans, int B, int V, float img_size, void* stream) {
+    if (!dout || !v || !scale || !dv || !dscale || !dtrans || B < 1 || V < 1) return RIH_EINVAL;
+    hipLaunchKernelGGL(project_bwd_kernel, dim3(B), dim3(TPB), 0, STREAM, dout, v, scale, dv, dscale, dtrans, V,
+                       img_size);
+    LAUNCH_RET();
+}
+
+extern "C" int rih_version(void) { return 1; }
+extern "C" const char* rih_arch(void) { return "gfx950"; }

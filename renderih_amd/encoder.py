@@ -1,0 +1,203 @@
+"""CNN encoder side of the pose network on the HIP ops (drop-in for the reference's models/encoder.py).
+
+Module/parameter names reproduce the reference's `state_dict`: torchvision-style
+`resnet.*`, `hms_decoder.models.N.M.*`, `dp_decoder.*`, `mid_model.convs.N.{0,2}.*`.  The nn.Conv2d /
+nn.BatchNorm2d objects are parameter containers only -- their torch forward is never called; the forward
+below runs NHWC through `renderih_amd.ops` (implicit-GEMM MFMA convs, fused BN(+residual)(+ReLU)).
+
+Reference behaviour kept on purpose: trunk = Conv->BN->ReLU (torchvision Bottleneck v1.5, stride on the
+3x3); aux decoders and mid convs = Conv->ReLU->BN (encoder.py:52-54, model_zoo/__init__.py:56-62);
+`resnet.fc` exists but is unused; mid.convs[3] is computed although the decoder drops it.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def bn_act(bn, x, residual=None, relu=False):
+    """nn.BatchNorm2d semantics (train: batch stats + running update; eval: running stats) on NHWC."""
+    y = ops.batchnorm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual=residual,
+                      training=bn.training, relu=relu, eps=bn.eps, momentum=bn.momentum)
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return y
+
+
+def conv(m, x, relu=False):
+    """nn.Conv2d container -> HIP conv (square kernel/stride/padding as everywhere in this network)."""
+    return ops.conv2d(x, m.weight, m.bias, stride=m.stride[0], pad=m.padding[0], relu=relu)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = bn_act(self.bn1, conv(self.conv1, x), relu=True)
+        out = bn_act(self.bn2, conv(self.conv2, out), relu=True)
+        idt = x
+        if self.downsample is not None:
+            idt = bn_act(self.downsample[1], conv(self.downsample[0], x))
+        return bn_act(self.bn3, conv(self.conv3, out), residual=idt, relu=True)
+
+
+class ResNetTrunk(nn.Module):
+    """torchvision.models.resnet50/101 layout (the reference pins torchvision 0.13.1, README.md:30)."""
+
+    def __init__(self, layers=(3, 4, 6, 3)):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.layer1 = self._make(64, layers[0], 1)
+        self.layer2 = self._make(128, layers[1], 2)
+        self.layer3 = self._make(256, layers[2], 2)
+        self.layer4 = self._make(512, layers[3], 2)
+        self.fc = nn.Linear(2048, 1000)       # present in reference checkpoints, never used (encoder.py:107-116)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+    def _make(self, planes, n, stride):
+        ds = None
+        if stride != 1 or self.inplanes != planes * 4:
+            ds = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride, bias=False),
+                               nn.BatchNorm2d(planes * 4))
+        blocks = [Bottleneck(self.inplanes, planes, stride, ds)]
+        self.inplanes = planes * 4
+        for _ in range(1, n):
+            blocks.append(Bottleneck(self.inplanes, planes))
+        return nn.Sequential(*blocks)
+
+    def forward(self, x):
+        """x: NHWC image padded to 4 channels.  Returns x4,x3,x2,x1 (NHWC)."""
+        x = bn_act(self.bn1, conv(self.conv1, x), relu=True)
+        x = ops.maxpool3x3s2(x)
+        x4 = self.layer1(x)
+        x3 = self.layer2(x4)
+        x2 = self.layer3(x3)
+        x1 = self.layer4(x2)
+        return x4, x3, x2, x1
+
+
+def _zoo_weights_init(layer):
+    """models/model_zoo/__init__.py:35-43 (kaiming_normal_ for Conv2d / Linear)."""
+    if isinstance(layer, nn.Conv2d):
+        nn.init.kaiming_normal_(layer.weight.data)
+    elif isinstance(layer, nn.Linear):
+        nn.init.kaiming_normal_(layer.weight.data)
+        if layer.bias is not None:
+            nn.init.constant_(layer.bias.data, 0.0)
+
+
+class ResNetSimple_decoder(nn.Module):
+    """models/encoder.py:21-64: [1x1 conv, ReLU, BN] @8 then 3x [bilinear x2, 3x3 conv, ReLU, BN], 1x1 head."""
+
+    def __init__(self, expansion=4, fDim=(256, 256, 256, 256), direction=('flat', 'up', 'up', 'up'), out_dim=3):
+        super().__init__()
+        self.models = nn.ModuleList()
+        fDim = [512 * expansion] + list(fDim)
+        for i, d in enumerate(direction):
+            k = 1 if d == 'flat' else 3
+            layers = []
+            if d == 'up':
+                layers.append(nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True))
+            layers += [nn.Conv2d(fDim[i], fDim[i + 1], k, 1, (k - 1) // 2, bias=False), nn.ReLU(inplace=True),
+                       nn.BatchNorm2d(fDim[i + 1])]
+            self.models.append(nn.Sequential(*layers))
+        self.final_layer = nn.Conv2d(fDim[-1], out_dim, 1, 1, 0)
+
+    def forward(self, x):
+        fmaps = []
+        for seq in self.models:
+            mods = list(seq)
+            if isinstance(mods[0], nn.Upsample):
+                x = ops.upsample_bilinear2x(x)
+                mods = mods[1:]
+            x = bn_act(mods[2], conv(mods[0], x, relu=True))
+            fmaps.append(x)
+        return conv(self.final_layer, x), fmaps
+
+
+class ResNetSimple(nn.Module):
+    """models/encoder.py:67-126."""
+
+    def __init__(self, model_type='resnet50', pretrained=False, fmapDim=(256, 256, 256, 256), handNum=2, heatmapDim=21):
+        super().__init__()
+        layers = {'resnet50': (3, 4, 6, 3), 'resnet101': (3, 4, 23, 3), 'resnet152': (3, 8, 36, 3)}
+        if model_type not in layers:
+            raise NotImplementedError('bottleneck ResNets only (the reference path uses resnet50)')
+        self.resnet = ResNetTrunk(layers[model_type])
+        self.expansion = 4
+        self.hms_decoder = ResNetSimple_decoder(self.expansion, fmapDim, out_dim=heatmapDim * handNum)
+        for m in self.hms_decoder.modules():
+            _zoo_weights_init(m)
+        self.dp_decoder = ResNetSimple_decoder(self.expansion, fmapDim, out_dim=handNum + 3 * handNum)
+        self.handNum = handNum
+        for m in self.dp_decoder.modules():
+            _zoo_weights_init(m)
+
+    def forward(self, img):
+        """img: [B,3,256,256] NCHW fp32 (the reference's input contract).  Feature maps come back NHWC
+        (internal layout); hms/mask/dp are converted to the reference's NCHW."""
+        x = ops.nchw_to_nhwc(img, cpad=4)
+        x4, x3, x2, x1 = self.resnet(x)
+        hms, hms_fmaps = self.hms_decoder(x1)
+        out, dp_fmaps = self.dp_decoder(x1)
+        mask = ops.nhwc_to_nchw(out, 0, self.handNum)
+        dp = ops.nhwc_to_nchw(out, self.handNum, out.shape[-1])
+        return ops.nhwc_to_nchw(hms), mask, dp, [x1, x2, x3, x4], hms_fmaps, dp_fmaps
+
+
+def conv1x1(in_channels, out_channels):
+    """models/model_zoo/__init__.py:56-62: Conv(no bias) -> ReLU -> BN."""
+    bn = nn.BatchNorm2d(out_channels)
+    nn.init.constant_(bn.weight, 1.)
+    return nn.Sequential(nn.Conv2d(in_channels, out_channels, 1, 1, 0, bias=False), nn.ReLU(inplace=True), bn)
+
+
+class resnet_mid(nn.Module):
+    """models/encoder.py:129-173."""
+
+    def __init__(self, model_type='resnet50', in_fmapDim=(256, 256, 256, 256), out_fmapDim=(256, 256, 256, 256)):
+        super().__init__()
+        self.expansion = 4
+        self.img_fmaps_dim = [512 * 4, 256 * 4, 128 * 4, 64 * 4]
+        self.convs = nn.ModuleList()
+        for i in range(len(out_fmapDim)):
+            inDim = in_fmapDim[i] * 2 + (self.img_fmaps_dim[i] if i > 0 else 0)
+            self.convs.append(conv1x1(inDim, out_fmapDim[i]))
+        self.global_feature_dim = 512 * self.expansion
+        self.fmaps_dim = list(out_fmapDim)
+
+    def get_info(self):
+        return {'global_feature_dim': self.global_feature_dim, 'fmaps_dim': self.fmaps_dim}
+
+    def forward(self, img_fmaps, hms_fmaps, dp_fmaps):
+        gf = ops.global_avgpool(img_fmaps[0])
+        fmaps = []
+        for i, seq in enumerate(self.convs):
+            parts = [hms_fmaps[i], dp_fmaps[i]] + ([img_fmaps[i]] if i > 0 else [])
+            x = torch.cat(parts, dim=-1)                     # channel concat = last dim in NHWC (pure copy)
+            fmaps.append(bn_act(seq[2], conv(seq[0], x, relu=True)))
+        return gf, fmaps
+
+
+def load_encoder(cfg):
+    """models/encoder.py:355-374 (ResNet branch; `pretrained=True` there is a download and is ignored offline)."""
+    et = cfg.MODEL.ENCODER_TYPE
+    if et.find('resnet') != -1:
+        encoder = ResNetSimple(model_type=et, pretrained=False, fmapDim=[128, 128, 128, 128], handNum=2, heatmapDim=21)
+        mid_model = resnet_mid(model_type=et, in_fmapDim=[128, 128, 128, 128], out_fmapDim=cfg.MODEL.DECONV_DIMS)
+        return encoder, mid_model
+    raise NotImplementedError('encoder type %s: HRNet-W32 variant is the next scope row (SURVEY 8a5)' % et)

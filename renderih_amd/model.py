@@ -1,0 +1,80 @@
+"""Drop-in for the reference's models/model.py: `HandNET_GCN(nn.Module)` + `load_model(cfg)`.
+
+forward(img [B,3,256,256] NCHW fp32 on the GPU) -> (result, paramsDict, handDictList, otherInfo), the same
+4-tuple of dicts as models/model.py:25-37; `state_dict()` keys/shapes equal the reference's (Appendix A).
+"""
+import os
+import pickle
+import torch
+import torch.nn as nn
+
+from . import assets
+from .config import load_cfg
+from .encoder import load_encoder, ResNetSimple, resnet_mid
+from .decoder import decoder as Decoder
+
+
+class HandNET_GCN(nn.Module):
+    def __init__(self, encoder, mid_model, decoder):
+        super().__init__()
+        self.encoder = encoder
+        self.mid_model = mid_model
+        self.decoder = decoder
+
+    def forward(self, img):
+        hms, mask, dp, img_fmaps, hms_fmaps, dp_fmaps = self.encoder(img)
+        global_feature, fmaps = self.mid_model(img_fmaps, hms_fmaps, dp_fmaps)
+        result, paramsDict, handDictList, otherInfo = self.decoder(global_feature, fmaps)
+        if hms is not None:
+            otherInfo['hms'] = hms
+        if mask is not None:
+            otherInfo['mask'] = mask
+        if dp is not None:
+            otherInfo['dense'] = dp
+        return result, paramsDict, handDictList, otherInfo
+
+
+Model = HandNET_GCN     # BASELINE.json's north_star calls it `models.model.Model`
+
+
+def _maybe_pickle(root, rel):
+    path = os.path.join(root, str(rel))
+    if os.path.exists(path):
+        with open(path, 'rb') as f:
+            return pickle.load(f)
+    return None
+
+
+def load_decoder(cfg, encoder_info, asset_root=None):
+    """models/decoder.py:177-210.  Reads the reference's misc/*.pkl when present under `asset_root` (default:
+    the repo root, like the reference); otherwise the packaged graph asset + seeded synthetic stand-ins."""
+    root = asset_root or os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    left = _maybe_pickle(root, cfg.MISC.GRAPH_LEFT_DICT_PATH) or assets.load_graph_dict('left')
+    right = _maybe_pickle(root, cfg.MISC.GRAPH_RIGHT_DICT_PATH) or assets.load_graph_dict('right')
+    dense = _maybe_pickle(root, cfg.MISC.DENSE_COLOR)
+    if dense is None:
+        dense = assets.synthetic_dense_coor()
+    up = _maybe_pickle(root, cfg.MISC.UPSAMPLE_PATH)
+    if up is None:
+        up = assets.synthetic_upsample_weight()
+    return Decoder(global_feature_dim=encoder_info['global_feature_dim'], f_in_Dim=encoder_info['fmaps_dim'],
+                   f_out_Dim=cfg.MODEL.IMG_DIMS, gcn_in_dim=cfg.MODEL.GCN_IN_DIM, gcn_out_dim=cfg.MODEL.GCN_OUT_DIM,
+                   graph_k=cfg.MODEL.graph_k, graph_layer_num=cfg.MODEL.graph_layer_num, vertex_num=778,
+                   dense_coor=dense, left_graph_dict=left, right_graph_dict=right, num_attn_heads=4,
+                   upsample_weight=torch.from_numpy(up).float(), dropout=cfg.TRAIN.dropout)
+
+
+def load_model(cfg=None):
+    if cfg is None or isinstance(cfg, str):
+        cfg = load_cfg(cfg)
+    encoder, mid_model = load_encoder(cfg)
+    dec = load_decoder(cfg, mid_model.get_info())
+    return HandNET_GCN(encoder, mid_model, dec)
+
+
+def build_model(dropout=0.05, encoder_type='resnet50'):
+    """The BASELINE configuration (ResNet50 + attention decoder) without a config file."""
+    cfg = load_cfg(None)
+    cfg.MODEL.ENCODER_TYPE = encoder_type
+    cfg.TRAIN.dropout = dropout
+    return load_model(cfg)

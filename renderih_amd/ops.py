@@ -1,0 +1,682 @@
+"""Operators of the pose network as `torch.autograd.Function`s over the HIP C ABI.
+
+PyTorch supplies device memory (caching allocator), the current HIP stream and autograd bookkeeping;
+all arithmetic runs in librenderih_amd.so.  Activations are NHWC; every tensor is fp32, contiguous,
+on the GPU.  There is no CPU or eager fallback: a missing library or a non-GPU tensor raises.
+"""
+import ctypes as C
+import math
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check
+
+
+def _L():
+    return _lib.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('renderih_amd ops need GPU tensors (HIP kernels only, no CPU fallback)')
+        if t.dtype != torch.float32:
+            raise RuntimeError('renderih_amd ops are fp32; got %s' % t.dtype)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
+# --------------------------------------------------------------------------------------------- GEMM plumbing
+def pick_tile(M, N, batch=1):
+    """0: 128x128, 1: 128x64, 2: 64x64 -- fill 256 CUs (x ~3 resident blocks) before growing the tile."""
+    if N <= 64:
+        return 1 if _cdiv(M, 128) * batch >= 384 else 2
+    if _cdiv(M, 128) * _cdiv(N, 128) * batch >= 384:
+        return 0
+    return 2
+
+
+_TILE_MN = {0: (128, 128), 1: (128, 64), 2: (64, 64)}
+
+
+def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=None, ldr=0,
+         nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, kchunk=0, sCsplit=0, alpha=1.0, relu=False,
+         geom=None, tile=None):
+    """Enqueue one rih_gemm.  A/B/Cout/bias/R are tensors or raw device pointers."""
+    d = GemmDesc()
+    d.A = A if isinstance(A, int) else A.data_ptr()
+    d.B = B if isinstance(B, int) else B.data_ptr()
+    d.C = Cout if isinstance(Cout, int) else Cout.data_ptr()
+    d.bias = _p(bias)
+    d.R = _p(R)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
+    d.a_mode, d.b_mode = a_mode, b_mode
+    d.nb1, d.nb2 = nb1, nb2
+    d.sA1, d.sA2 = sA
+    d.sB1, d.sB2 = sB
+    d.sC1, d.sC2 = sC
+    d.splitk, d.kchunk, d.sCsplit = splitk, kchunk, sCsplit
+    d.alpha = alpha
+    d.relu = 1 if relu else 0
+    if geom is None:
+        cin = K if a_mode == 0 else M
+        geom = (1, 1, cin, 1, 1, 1, 1, 1, 1, 0, 0)
+    (d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.strideA, d.upS, d.padH, d.padW) = geom
+    d.tile = pick_tile(M, N, nb1 * nb2 * splitk) if tile is None else tile
+    check(_L().rih_gemm(C.byref(d), _stream()), 'rih_gemm')
+
+
+def _wgrad(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid):
+    """dw (parameter layout) = im2col(x)^T @ dy with split-K over the Kpix pixels."""
+    tile = 2 if (Ncols <= 64 or Mrows <= 64) else 0
+    bm, bn = _TILE_MN[tile]
+    tiles = _cdiv(Mrows, bm) * _cdiv(Ncols, bn)
+    splitk = max(1, min(1024 // max(tiles, 1), _cdiv(Kpix, 128)))
+    kchunk = _cdiv(_cdiv(Kpix, splitk), 32) * 32
+    splitk = _cdiv(Kpix, kchunk)
+    part = torch.empty((splitk, Mrows, Ncols), device=x.device, dtype=torch.float32)
+    if splitk == 1:
+        # single pass still goes through the reduce kernel for the layout change; raw epilogue = alpha 1, no bias
+        gemm(x, dy, part, Mrows, Ncols, Kpix, ldx, ldy, Ncols, a_mode=1, b_mode=0, geom=geom, tile=tile)
+    else:
+        gemm(x, dy, part, Mrows, Ncols, Kpix, ldx, ldy, Ncols, a_mode=1, b_mode=0, splitk=splitk, kchunk=kchunk,
+             sCsplit=Mrows * Ncols, geom=geom, tile=tile)
+    check(_L().rih_splitk_reduce(part.data_ptr(), splitk, Mrows, Ncols, dw.data_ptr(), Cin_pad, taps, Cin_valid, 0,
+                                 _stream()), 'rih_splitk_reduce')
+
+
+def colsum(x2d, rows, Ccols, ldx=None):
+    ldx = Ccols if ldx is None else ldx
+    out = torch.empty((Ccols,), device=x2d.device, dtype=torch.float32)
+    ws = torch.empty((int(_L().rih_colsum_ws_floats(rows, Ccols)),), device=x2d.device, dtype=torch.float32)
+    check(_L().rih_colsum(x2d.data_ptr(), rows, Ccols, ldx, out.data_ptr(), 0, ws.data_ptr(), _stream()), 'rih_colsum')
+    return out
+
+
+# --------------------------------------------------------------------------------------------- conv / linear
+class Conv2dFn(torch.autograd.Function):
+    """NHWC conv2d (+bias, +ReLU epilogue) = implicit GEMM on the fp32 MFMA pipe.
+    x: [N,H,W,Cx] (Cx >= Cin, extra channels must be zero), w: [Cout,Cin,KH,KW] (the nn.Conv2d parameter)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, relu):
+        _chk(x, w, bias)
+        x = _c(x)
+        w = _c(w)
+        N, H, W_, Cx = x.shape
+        Cout, Cin, KH, KW = w.shape
+        Ho = (H + 2 * pad - KH) // stride + 1
+        Wo = (W_ + 2 * pad - KW) // stride + 1
+        y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+        M, K = N * Ho * Wo, KH * KW * Cx
+        geom = (H, W_, Cx, Ho, Wo, KH, KW, stride, 1, pad, pad)
+        if KH * KW == 1 and Cx == Cin:
+            gemm(x, w, y, M, Cout, K, Cx, Cin, Cout, a_mode=0, b_mode=1, bias=bias, relu=relu, geom=geom)
+        else:
+            wp = torch.empty((K, Cout), device=x.device, dtype=torch.float32)
+            check(_L().rih_pack_conv_weight(w.data_ptr(), wp.data_ptr(), Cout, Cin, KH, KW, Cx, 0, _stream()),
+                  'rih_pack_conv_weight')
+            gemm(x, wp, y, M, Cout, K, Cx, Cout, Cout, a_mode=0, b_mode=0, bias=bias, relu=relu, geom=geom)
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.cfg = (stride, pad, relu, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, relu, has_bias = ctx.cfg
+        N, H, W_, Cx = x.shape
+        Cout, Cin, KH, KW = w.shape
+        dy = _c(dy)
+        _, Ho, Wo, _ = dy.shape
+        M = N * Ho * Wo
+        lib = _L()
+        if relu:
+            dyr = torch.empty_like(dy)
+            check(lib.rih_relu_bwd(dy.data_ptr(), y.data_ptr(), dyr.data_ptr(), dy.numel(), _stream()), 'rih_relu_bwd')
+            dy = dyr
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            Mx = N * H * W_
+            geom = (Ho, Wo, Cout, H, W_, KH, KW, 1, stride, KH - 1 - pad, KW - 1 - pad)
+            if KH * KW == 1 and Cx == Cin:
+                gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cin, Cx, a_mode=0, b_mode=0, geom=geom)
+            else:
+                wd = torch.empty((KH * KW * Cout, Cx), device=x.device, dtype=torch.float32)
+                check(lib.rih_pack_conv_weight(w.data_ptr(), wd.data_ptr(), Cout, Cin, KH, KW, Cx, 1, _stream()),
+                      'rih_pack_conv_weight')
+                gemm(dy, wd, dx, Mx, Cx, KH * KW * Cout, Cout, Cx, Cx, a_mode=0, b_mode=0, geom=geom)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            geom = (H, W_, Cx, Ho, Wo, KH, KW, stride, 1, pad, pad)
+            _wgrad(x, dy, dw, M, KH * KW * Cx, Cout, Cx, Cout, geom, Cx, KH * KW, Cin)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy, M, Cout)
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, relu=False):
+    return Conv2dFn.apply(x, w, bias, stride, pad, relu)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x @ w^T + bias + residual) for x [..., K], w [N, K] (the nn.Linear parameter, read in place)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, relu):
+        _chk(x, w, bias, residual)
+        x = _c(x)
+        w = _c(w)
+        Nf, K = w.shape
+        M = x.numel() // K
+        y = torch.empty(x.shape[:-1] + (Nf,), device=x.device, dtype=torch.float32)
+        if residual is not None:
+            residual = _c(residual)
+        gemm(x, w, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, bias=bias, R=residual, ldr=Nf, relu=relu)
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.cfg = (relu, bias is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        relu, has_bias, has_res = ctx.cfg
+        Nf, K = w.shape
+        M = x.numel() // K
+        dy = _c(dy)
+        lib = _L()
+        if relu:
+            dyr = torch.empty_like(dy)
+            check(lib.rih_relu_bwd(dy.data_ptr(), y.data_ptr(), dyr.data_ptr(), dy.numel(), _stream()), 'rih_relu_bwd')
+            dy = dyr
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(dy, w, dx, M, K, Nf, Nf, K, K, a_mode=0, b_mode=0)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            _wgrad(x, dy, dw, M, K, Nf, K, Nf, (1, 1, K, 1, 1, 1, 1, 1, 1, 0, 0), K, 1, K)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy, M, Nf)
+        dres = dy if (has_res and ctx.needs_input_grad[3]) else None
+        return dx, dw, db, dres, None
+
+
+def linear(x, w, bias=None, residual=None, relu=False):
+    return LinearFn.apply(x, w, bias, residual, relu)
+
+
+# --------------------------------------------------------------------------------------------- batch norm
+class BatchNormFn(torch.autograd.Function):
+    """nn.BatchNorm2d on NHWC rows (+ residual add + ReLU).  Training: batch statistics, running buffers updated
+    in place (momentum 0.1, unbiased running_var) exactly like torch; eval: running statistics."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, residual, training, relu, eps, momentum):
+        _chk(x, gamma, beta, rmean, rvar, residual)
+        x = _c(x)
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        lib = _L()
+        mean = torch.empty((Cc,), device=x.device, dtype=torch.float32)
+        invstd = torch.empty((Cc,), device=x.device, dtype=torch.float32)
+        ws = torch.empty((int(lib.rih_bn_ws_floats(rows, Cc)),), device=x.device, dtype=torch.float32)
+        if training:
+            check(lib.rih_bn_stats(x.data_ptr(), rows, Cc, eps, momentum, mean.data_ptr(), invstd.data_ptr(),
+                                   _p(rmean), _p(rvar), ws.data_ptr(), _stream()), 'rih_bn_stats')
+        else:
+            check(lib.rih_bn_eval_stats(rmean.data_ptr(), rvar.data_ptr(), Cc, eps, mean.data_ptr(),
+                                        invstd.data_ptr(), _stream()), 'rih_bn_eval_stats')
+        y = torch.empty_like(x)
+        if residual is not None:
+            residual = _c(residual)
+        check(lib.rih_bn_apply(x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                               _p(residual), y.data_ptr(), rows, Cc, 1 if relu else 0, _stream()), 'rih_bn_apply')
+        ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma)
+        ctx.cfg = (training, relu, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, invstd, gamma = ctx.saved_tensors
+        training, relu, has_res = ctx.cfg
+        dy = _c(dy)
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        lib = _L()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        dg = torch.empty_like(gamma)
+        db = torch.empty_like(gamma)
+        ws = torch.empty((int(lib.rih_bn_ws_floats(rows, Cc)),), device=x.device, dtype=torch.float32)
+        check(lib.rih_bn_bwd(dy.data_ptr(), x.data_ptr(), _p(y), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                             dx.data_ptr(), _p(dres), dg.data_ptr(), db.data_ptr(), rows, Cc, 1 if relu else 0,
+                             0 if training else 1, ws.data_ptr(), _stream()), 'rih_bn_bwd')
+        return dx, dg, db, None, None, dres, None, None, None, None
+
+
+def batchnorm(x, gamma, beta, rmean, rvar, residual=None, training=True, relu=False, eps=1e-5, momentum=0.1):
+    return BatchNormFn.apply(x, gamma, beta, rmean, rvar, residual, training, relu, eps, momentum)
+
+
+# --------------------------------------------------------------------------------------------- layout / pooling
+def nchw_to_nhwc(x, cpad=None):
+    """Input-side layout change (no gradient: the image is a leaf input)."""
+    _chk(x)
+    x = _c(x)
+    N, Cc, H, W_ = x.shape
+    cpad = Cc if cpad is None else cpad
+    y = torch.empty((N, H, W_, cpad), device=x.device, dtype=torch.float32)
+    check(_L().rih_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), N, Cc, H, W_, cpad, _stream()), 'rih_nchw_to_nhwc')
+    return y
+
+
+class NhwcToNchwFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c0, c1):
+        _chk(x)
+        x = _c(x)
+        N, H, W_, Cx = x.shape
+        y = torch.empty((N, c1 - c0, H, W_), device=x.device, dtype=torch.float32)
+        check(_L().rih_nhwc_to_nchw(x.data_ptr() + 4 * c0, y.data_ptr(), N, c1 - c0, H, W_, Cx, _stream()),
+              'rih_nhwc_to_nchw')
+        ctx.cfg = (c0, c1, Cx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        c0, c1, Cx = ctx.cfg
+        dy = _c(dy)
+        N, Cc, H, W_ = dy.shape
+        if c0 == 0 and c1 == Cx:
+            dx = torch.empty((N, H, W_, Cx), device=dy.device, dtype=torch.float32)
+            check(_L().rih_nchw_to_nhwc(dy.data_ptr(), dx.data_ptr(), N, Cc, H, W_, Cc, _stream()), 'rih_nchw_to_nhwc')
+            return dx, None, None
+        part = torch.empty((N, H, W_, Cc), device=dy.device, dtype=torch.float32)
+        check(_L().rih_nchw_to_nhwc(dy.data_ptr(), part.data_ptr(), N, Cc, H, W_, Cc, _stream()), 'rih_nchw_to_nhwc')
+        dx = torch.zeros((N, H, W_, Cx), device=dy.device, dtype=torch.float32)
+        dx[..., c0:c1] = part
+        return dx, None, None
+
+
+def nhwc_to_nchw(x, c0=0, c1=None):
+    """[N,H,W,C] -> [N,c1-c0,H,W] (user-facing outputs hms / mask / dense)."""
+    return NhwcToNchwFn.apply(x, c0, x.shape[-1] if c1 is None else c1)
+
+
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        x = _c(x)
+        N, H, W_, Cc = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W_ - 1) // 2 + 1
+        y = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
+        arg = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=torch.int8)
+        check(_L().rih_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), arg.data_ptr(), N, H, W_, Cc, _stream()),
+              'rih_maxpool3x3s2_fwd')
+        ctx.save_for_backward(arg)
+        ctx.shape = (N, H, W_, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        N, H, W_, Cc = ctx.shape
+        dy = _c(dy)
+        dx = torch.empty((N, H, W_, Cc), device=dy.device, dtype=torch.float32)
+        check(_L().rih_maxpool3x3s2_bwd(dy.data_ptr(), arg.data_ptr(), dx.data_ptr(), N, H, W_, Cc, _stream()),
+              'rih_maxpool3x3s2_bwd')
+        return dx
+
+
+def maxpool3x3s2(x):
+    return MaxPoolFn.apply(x)
+
+
+class AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        x = _c(x)
+        N, H, W_, Cc = x.shape
+        y = torch.empty((N, Cc), device=x.device, dtype=torch.float32)
+        check(_L().rih_avgpool_fwd(x.data_ptr(), y.data_ptr(), N, H * W_, Cc, _stream()), 'rih_avgpool_fwd')
+        ctx.shape = (N, H, W_, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W_, Cc = ctx.shape
+        dy = _c(dy)
+        dx = torch.empty((N, H, W_, Cc), device=dy.device, dtype=torch.float32)
+        check(_L().rih_avgpool_bwd(dy.data_ptr(), dx.data_ptr(), N, H * W_, Cc, _stream()), 'rih_avgpool_bwd')
+        return dx
+
+
+def global_avgpool(x):
+    return AvgPoolFn.apply(x)
+
+
+class Upsample2xFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        x = _c(x)
+        N, H, W_, Cc = x.shape
+        y = torch.empty((N, 2 * H, 2 * W_, Cc), device=x.device, dtype=torch.float32)
+        check(_L().rih_upsample2x_fwd(x.data_ptr(), y.data_ptr(), N, H, W_, Cc, _stream()), 'rih_upsample2x_fwd')
+        ctx.shape = (N, H, W_, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W_, Cc = ctx.shape
+        dy = _c(dy)
+        dx = torch.empty((N, H, W_, Cc), device=dy.device, dtype=torch.float32)
+        check(_L().rih_upsample2x_bwd(dy.data_ptr(), dx.data_ptr(), N, H, W_, Cc, _stream()), 'rih_upsample2x_bwd')
+        return dx
+
+
+def upsample_bilinear2x(x):
+    return Upsample2xFn.apply(x)
+
+
+# --------------------------------------------------------------------------------------------- row-wise ops
+class LayerNormFn(torch.autograd.Function):
+    """y = act(LayerNorm(x (+ x2))); the optional second input fuses the residual add in front of the norm."""
+
+    @staticmethod
+    def forward(ctx, x, x2, g, b, eps, relu):
+        _chk(x, x2, g, b)
+        x = _c(x)
+        if x2 is not None:
+            x2 = _c(x2)
+        D = x.shape[-1]
+        rows = x.numel() // D
+        y = torch.empty_like(x)
+        mean = torch.empty((rows,), device=x.device, dtype=torch.float32)
+        rstd = torch.empty((rows,), device=x.device, dtype=torch.float32)
+        check(_L().rih_layernorm_fwd(x.data_ptr(), _p(x2), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                     rstd.data_ptr(), rows, D, eps, 1 if relu else 0, _stream()), 'rih_layernorm_fwd')
+        ctx.save_for_backward(x, x2, y if relu else None, g, mean, rstd)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x2, y, g, mean, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        D = x.shape[-1]
+        rows = x.numel() // D
+        lib = _L()
+        dx = torch.empty_like(x)
+        dg = torch.empty_like(g)
+        db = torch.empty_like(g)
+        ws = torch.empty((2 * lib.rih_ln_nblk(rows) * D,), device=x.device, dtype=torch.float32)
+        check(lib.rih_layernorm_bwd(dy.data_ptr(), x.data_ptr(), _p(x2), _p(y), g.data_ptr(), mean.data_ptr(),
+                                    rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, D,
+                                    1 if ctx.relu else 0, ws.data_ptr(), _stream()), 'rih_layernorm_bwd')
+        return dx, (dx if x2 is not None else None), dg, db, None, None
+
+
+def layernorm(x, g, b, eps=1e-6, x2=None, relu=False):
+    return LayerNormFn.apply(x, x2, g, b, eps, relu)
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d)) [dropout] v over `heads` heads; q [B,Sq,D], k/v [B,Sk,D] (heads split the last dim).
+    QK^T / PV and their gradients are batched (batch x head) fp32-MFMA GEMMs reading the head slices in place; the
+    row softmax (+ dropout) is one wavefront per row with xor-shuffle reductions."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, drop_p, seed):
+        _chk(q, k, v)
+        q, k, v = _c(q), _c(k), _c(v)
+        B, Sq, D = q.shape
+        Sk = k.shape[1]
+        d = D // heads
+        ldP = _cdiv(Sk, 4) * 4
+        alpha = 1.0 / math.sqrt(d)
+        lib = _L()
+        P = torch.empty((B, heads, Sq, ldP), device=q.device, dtype=torch.float32)
+        gemm(q, k, P, Sq, Sk, d, D, D, ldP, a_mode=0, b_mode=1, nb1=B, nb2=heads, sA=(Sq * D, d), sB=(Sk * D, d),
+             sC=(heads * Sq * ldP, Sq * ldP), alpha=alpha)
+        Pd = torch.empty_like(P) if drop_p > 0 else P
+        check(lib.rih_softmax_fwd(P.data_ptr(), P.data_ptr(), Pd.data_ptr(), B * heads * Sq, Sk, ldP, drop_p, seed,
+                                  _stream()), 'rih_softmax_fwd')
+        out = torch.empty((B, Sq, D), device=q.device, dtype=torch.float32)
+        gemm(Pd, v, out, Sq, d, Sk, ldP, D, D, a_mode=0, b_mode=0, nb1=B, nb2=heads,
+             sA=(heads * Sq * ldP, Sq * ldP), sB=(Sk * D, d), sC=(Sq * D, d))
+        ctx.save_for_backward(q, k, v, P, Pd if drop_p > 0 else None)
+        ctx.cfg = (heads, drop_p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, P, Pd = ctx.saved_tensors
+        heads, drop_p, seed = ctx.cfg
+        if Pd is None:
+            Pd = P
+        do = _c(do)
+        B, Sq, D = q.shape
+        Sk = k.shape[1]
+        d = D // heads
+        ldP = P.shape[-1]
+        alpha = 1.0 / math.sqrt(d)
+        sP = (heads * Sq * ldP, Sq * ldP)
+        dS = torch.empty_like(P)
+        gemm(do, v, dS, Sq, Sk, d, D, D, ldP, a_mode=0, b_mode=1, nb1=B, nb2=heads, sA=(Sq * D, d), sB=(Sk * D, d),
+             sC=sP)
+        check(_L().rih_softmax_bwd(P.data_ptr(), dS.data_ptr(), B * heads * Sq, Sk, ldP, drop_p, seed, alpha,
+                                   _stream()), 'rih_softmax_bwd')
+        dq = torch.empty_like(q)
+        dk = torch.empty_like(k)
+        dv = torch.empty_like(v)
+        gemm(dS, k, dq, Sq, d, Sk, ldP, D, D, a_mode=0, b_mode=0, nb1=B, nb2=heads, sA=sP, sB=(Sk * D, d),
+             sC=(Sq * D, d))
+        gemm(dS, q, dk, Sk, d, Sq, ldP, D, D, a_mode=1, b_mode=0, nb1=B, nb2=heads, sA=sP, sB=(Sq * D, d),
+             sC=(Sk * D, d))
+        gemm(Pd, do, dv, Sk, d, Sq, ldP, D, D, a_mode=1, b_mode=0, nb1=B, nb2=heads, sA=sP, sB=(Sq * D, d),
+             sC=(Sk * D, d))
+        return dq, dk, dv, None, None, None
+
+
+def attention(q, k, v, heads, drop_p=0.0, seed=0):
+    return AttentionFn.apply(q, k, v, heads, drop_p, seed)
+
+
+class AddDropoutFn(torch.autograd.Function):
+    """y = a + dropout(b); `bcast_rows` > 0 broadcasts b ([rows, D]) over the leading batch dim (position embeddings)."""
+
+    @staticmethod
+    def forward(ctx, a, b, drop_p, seed, bcast_rows):
+        _chk(a, b)
+        if a is not None:
+            a = _c(a)
+        b = _c(b)
+        ref = a if a is not None else b
+        y = torch.empty_like(ref)
+        D = ref.shape[-1]
+        check(_L().rih_add_dropout(_p(a), b.data_ptr(), y.data_ptr(), y.numel(), D, bcast_rows, drop_p, seed,
+                                   _stream()), 'rih_add_dropout')
+        ctx.cfg = (drop_p, seed, bcast_rows, a is not None, tuple(b.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        drop_p, seed, bcast_rows, has_a, bshape = ctx.cfg
+        dy = _c(dy)
+        da = dy if (has_a and ctx.needs_input_grad[0]) else None
+        db = None
+        if ctx.needs_input_grad[1]:
+            if bcast_rows > 0:
+                D = dy.shape[-1]
+                Bn = dy.numel() // (bcast_rows * D)
+                db = colsum(dy, Bn, bcast_rows * D).view(bshape)
+            elif drop_p > 0:
+                db = torch.empty_like(dy)
+                check(_L().rih_dropout_bwd(dy.data_ptr(), db.data_ptr(), dy.numel(), drop_p, seed, _stream()),
+                      'rih_dropout_bwd')
+            else:
+                db = dy
+        return da, db, None, None, None
+
+
+def add_dropout(a, b, drop_p=0.0, seed=0):
+    return AddDropoutFn.apply(a, b, drop_p, seed, 0)
+
+
+def add_rows_bcast(a, e):
+    """a [B,V,D] + e [V,D] (nn.Embedding of arange(V), DualGraph.py:76-80 / img_attn.py:57-64)."""
+    return AddDropoutFn.apply(a, e, 0.0, 0, e.shape[0])
+
+
+class ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        x = _c(x)
+        y = torch.empty_like(x)
+        check(_L().rih_relu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), 'rih_relu_fwd')
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        check(_L().rih_relu_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), _stream()), 'rih_relu_bwd')
+        return dx
+
+
+def relu(x):
+    return ReluFn.apply(x)
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """y[b, i, :] = x[b, idx[i], :]; `inv` = (ptr, list) CSR of the inverse map for the deterministic backward."""
+
+    @staticmethod
+    def forward(ctx, x, idx, inv_ptr, inv_idx):
+        _chk(x)
+        x = _c(x)
+        B, Vin, D = x.shape
+        Vout = idx.numel()
+        y = torch.empty((B, Vout, D), device=x.device, dtype=torch.float32)
+        check(_L().rih_gather_rows(x.data_ptr(), idx.data_ptr(), y.data_ptr(), B, Vin, Vout, D, _stream()),
+              'rih_gather_rows')
+        ctx.save_for_backward(inv_ptr, inv_idx)
+        ctx.shape = (B, Vin, Vout, D)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        inv_ptr, inv_idx = ctx.saved_tensors
+        B, Vin, Vout, D = ctx.shape
+        dy = _c(dy)
+        dx = torch.empty((B, Vin, D), device=dy.device, dtype=torch.float32)
+        check(_L().rih_scatter_rows_add(dy.data_ptr(), inv_ptr.data_ptr(), inv_idx.data_ptr(), dx.data_ptr(), B, Vin,
+                                        Vout, D, _stream()), 'rih_scatter_rows_add')
+        return dx, None, None, None
+
+
+class RowIndex:
+    """A fixed row-index map (graph permutation, nearest upsample, token slice) with its inverse lists."""
+
+    def __init__(self, idx, vin, device):
+        import numpy as np
+        idx = np.asarray(idx, dtype=np.int64)
+        order = np.argsort(idx, kind='stable')
+        counts = np.bincount(idx, minlength=vin)
+        ptr = np.zeros(vin + 1, np.int64)
+        ptr[1:] = np.cumsum(counts)
+        self.vin = vin
+        self.idx = torch.as_tensor(idx, dtype=torch.int32, device=device)
+        self.inv_ptr = torch.as_tensor(ptr, dtype=torch.int32, device=device)
+        self.inv_idx = torch.as_tensor(order, dtype=torch.int32, device=device)
+
+    def __call__(self, x):
+        assert x.shape[1] == self.vin
+        return GatherRowsFn.apply(x, self.idx, self.inv_ptr, self.inv_idx)
+
+
+class ChebyFn(torch.autograd.Function):
+    """[x, L x] interleaved on the feature dim (graph_conv_cheby K=2, gcn.py:34-69) with L in CSR."""
+
+    @staticmethod
+    def forward(ctx, x, csr, csr_t):
+        _chk(x)
+        x = _c(x)
+        B, V, F_ = x.shape
+        y = torch.empty((B, V, 2 * F_), device=x.device, dtype=torch.float32)
+        check(_L().rih_cheby_fwd(x.data_ptr(), csr[0].data_ptr(), csr[1].data_ptr(), csr[2].data_ptr(), y.data_ptr(),
+                                 B, V, F_, _stream()), 'rih_cheby_fwd')
+        ctx.csr_t = csr_t
+        ctx.shape = (B, V, F_)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, V, F_ = ctx.shape
+        dy = _c(dy)
+        t = ctx.csr_t
+        dx = torch.empty((B, V, F_), device=dy.device, dtype=torch.float32)
+        check(_L().rih_cheby_bwd(dy.data_ptr(), t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), dx.data_ptr(), B, V,
+                                 F_, _stream()), 'rih_cheby_bwd')
+        return dx, None, None
+
+
+def cheby_features(x, csr, csr_t):
+    return ChebyFn.apply(x, csr, csr_t)
+
+
+class ProjectFn(torch.autograd.Function):
+    """Orthographic projection of utils/manoutils.py:26-44: uv = (scale*img)*xyz[:2] + (trans*img/2 + img/2)."""
+
+    @staticmethod
+    def forward(ctx, v, scale, trans, img_size):
+        _chk(v, scale, trans)
+        v, scale, trans = _c(v), _c(scale), _c(trans)
+        B, V, _ = v.shape
+        out = torch.empty((B, V, 2), device=v.device, dtype=torch.float32)
+        check(_L().rih_project_fwd(v.data_ptr(), scale.data_ptr(), trans.data_ptr(), out.data_ptr(), B, V,
+                                   float(img_size), _stream()), 'rih_project_fwd')
+        ctx.save_for_backward(v, scale)
+        ctx.img = float(img_size)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        v, scale = ctx.saved_tensors
+        dout = _c(dout)
+        B, V, _ = v.shape
+        dv = torch.empty_like(v)
+        ds = torch.empty_like(scale)
+        dt = torch.empty((B, 2), device=v.device, dtype=torch.float32)
+        check(_L().rih_project_bwd(dout.data_ptr(), v.data_ptr(), scale.data_ptr(), dv.data_ptr(), ds.data_ptr(),
+                                   dt.data_ptr(), B, V, ctx.img, _stream()), 'rih_project_bwd')
+        return dv, ds, dt, None
+
+
+def projection_batch(scale, trans2d, v, img_size=256):
+    return ProjectFn.apply(v, scale, trans2d, img_size)

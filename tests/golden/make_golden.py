@@ -1,0 +1,217 @@
+"""Generate tests/golden/*.npz by running the REAL reference modules (from /root/reference) on CPU.
+
+Run in the build container only:  python tests/golden/make_golden.py
+The reference's own tests pin no numeric result for this path, so these
+reference-generated vectors are what pins the oracle (tests/test_oracle_golden.py) and, through it and
+directly, the HIP path (tests/test_gpu_*.py).
+
+Fixtures:
+  net_eval.npz / net_train.npz : HandNET_GCN (ResNet50 variant), B=2, seeded image + seeded weights
+      (renderih_amd.testing.deterministic_state), eval mode / train mode with dropout=0.
+      Outputs of the forward 4-tuple (full for small tensors, signature for big ones), tapped
+      intermediates, and for train: scalar loss, parameter-gradient signatures, BN running stats.
+  mano_*.npz : reference ManoLayer on a synthetic MANO-shaped pickle, several call conventions,
+      outputs and input gradients.
+"""
+import os
+import sys
+import tempfile
+import warnings
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, '..', '..'))
+sys.path.insert(0, HERE)
+import ref_stubs  # noqa: E402
+
+ref_stubs.install()                     # puts /root/reference first on sys.path
+warnings.filterwarnings('ignore')
+
+from models.encoder import ResNetSimple, resnet_mid                   # noqa: E402  (reference)
+from models.decoder import decoder as RefDecoder                     # noqa: E402  (reference)
+from models.model import HandNET_GCN                                 # noqa: E402  (reference)
+from models.manolayer import ManoLayer, rodrigues_batch              # noqa: E402  (reference)
+
+# our package is imported by file path pieces that do not collide with the reference's `models`
+import importlib.util  # noqa: E402
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+assets = _load('rih_assets', os.path.join(ROOT, 'renderih_amd', 'assets.py'))
+testing = _load('rih_testing', os.path.join(ROOT, 'renderih_amd', 'testing.py'))
+net_oracle = _load('net_oracle', os.path.join(ROOT, 'oracle', 'net_oracle.py'))
+
+
+def build_reference_model(dropout=0.0):
+    enc = ResNetSimple(model_type='resnet50', pretrained=True, fmapDim=[128] * 4, handNum=2, heatmapDim=21)
+    mid = resnet_mid(model_type='resnet50', in_fmapDim=[128] * 4, out_fmapDim=[256] * 4)
+    dec = RefDecoder(global_feature_dim=2048, f_in_Dim=[256] * 4, f_out_Dim=[256, 128, 64],
+                     gcn_in_dim=[512, 256, 128], gcn_out_dim=[256, 128, 64], graph_k=2, graph_layer_num=4,
+                     left_graph_dict=assets.load_graph_dict('left'), right_graph_dict=assets.load_graph_dict('right'),
+                     vertex_num=778, dense_coor=assets.synthetic_dense_coor(), num_attn_heads=4,
+                     upsample_weight=torch.from_numpy(assets.synthetic_upsample_weight()), dropout=dropout)
+    return HandNET_GCN(enc, mid, dec)
+
+
+def pack(store, name, t):
+    t = t.detach()
+    if t.numel() <= 20000:
+        store[name] = t.cpu().numpy()
+    else:
+        st, sa = testing.signature(t)
+        store[name + '#stats'] = st
+        store[name + '#samp'] = sa
+
+
+def tap_hooks(model, taps):
+    hs = []
+    enc = model.encoder
+    for nm, mod in (('x4', enc.resnet.layer1), ('x3', enc.resnet.layer2), ('x2', enc.resnet.layer3),
+                    ('x1', enc.resnet.layer4), ('stem', enc.resnet.maxpool),
+                    ('hms_f3', enc.hms_decoder.models[3]), ('dp_f0', enc.dp_decoder.models[0]),
+                    ('fmap0', model.mid_model.convs[0]), ('fmap1', model.mid_model.convs[1]),
+                    ('fmap2', model.mid_model.convs[2]), ('fmap3', model.mid_model.convs[3]),
+                    ('gcn0_left', model.decoder.dual_gcn.layers[0].graph_left),
+                    ('imgex0_left', model.decoder.dual_gcn.layers[0].img_ex_left)):
+        hs.append(mod.register_forward_hook(lambda m, i, o, nm=nm: taps.__setitem__(nm, o)))
+
+    def dgl_hook(idx):
+        def f(m, i, o):
+            taps['dgl%d_L' % idx], taps['dgl%d_R' % idx] = o
+        return f
+    for i in range(3):
+        hs.append(model.decoder.dual_gcn.layers[i].register_forward_hook(dgl_hook(i)))
+    return hs
+
+
+def net_fixture(mode):
+    torch.manual_seed(0)
+    model = build_reference_model(dropout=0.0)
+    sd = testing.deterministic_state(model.state_dict(), seed=0)
+    model.load_state_dict(sd)
+    model.train(mode == 'train')
+    img = testing.seeded_image(2, seed=0)
+    taps = {}
+    hs = tap_hooks(model, taps)
+    store = {}
+    if mode == 'eval':
+        with torch.no_grad():
+            out = model(img)
+    else:
+        out = model(img)
+    for h in hs:
+        h.remove()
+    for k, v in testing.flatten_outputs(out).items():
+        pack(store, 'out/' + k, v)
+    for k, v in taps.items():
+        pack(store, 'tap/' + k, v)
+    if mode == 'train':
+        loss = net_oracle.scalar_loss(out)
+        loss.backward()
+        store['loss'] = np.float64(loss.item())
+        names = []
+        for k, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            names.append(k)
+            st, sa = testing.signature(p.grad, nsamp=32)
+            store['grad/' + k + '#stats'] = st
+            store['grad/' + k + '#samp'] = sa
+        store['grad_names'] = np.array(names)
+        nsd = model.state_dict()
+        for k in ('encoder.resnet.bn1.running_mean', 'encoder.resnet.bn1.running_var',
+                  'encoder.resnet.layer4.2.bn3.running_mean', 'encoder.resnet.layer4.2.bn3.running_var',
+                  'mid_model.convs.1.2.running_var', 'encoder.hms_decoder.models.2.3.running_mean',
+                  'encoder.resnet.bn1.num_batches_tracked'):
+            store['bnstat/' + k] = nsd[k].numpy()
+    path = os.path.join(HERE, 'net_%s.npz' % mode)
+    np.savez_compressed(path, **store)
+    print('wrote', path, os.path.getsize(path), 'bytes,', len(store), 'arrays')
+
+
+def mano_fixture():
+    tmp = tempfile.mkdtemp()
+    store = {}
+    for side in ('right', 'left'):
+        pkl = assets.write_synthetic_mano_pkl(os.path.join(tmp, 'MANO_%s.pkl' % side.upper()), side, seed=0)
+        cases = [
+            # name, B, ncomp or 'rot', center_idx, trans, scale, new_skel
+            ('pca45', 5, 45, 9, True, True, False),
+            ('pca30', 3, 30, 9, True, False, False),
+            ('pca6_nocenter', 2, 6, None, False, False, False),
+            ('rot', 4, 'rot', 9, False, True, False),
+            ('newskel', 2, 45, 0, True, True, True),
+            ('zero_pose', 2, 45, 9, False, False, False),
+            ('b1', 1, 45, 9, True, True, False),
+            ('b19', 19, 45, 9, True, True, False),
+        ]
+        for name, B, nc, center, use_t, use_s, new_skel in cases:
+            g = torch.Generator().manual_seed(zlibseed(side + name))
+            use_pca = nc != 'rot'
+            layer = ManoLayer(pkl, center_idx=center, use_pca=use_pca, new_skel=new_skel)
+            root = rodrigues_batch(torch.randn(B, 3, generator=g) * 0.7).requires_grad_(True)
+            if use_pca:
+                pose = (torch.randn(B, nc, generator=g) * (0.0 if name == 'zero_pose' else 0.8)).requires_grad_(True)
+                if name == 'zero_pose':     # (near-)zero axis-angle: exercises the +1e-8 epsilon path (N7)
+                    with torch.no_grad():
+                        pose.copy_(layer.axis2pca(torch.zeros(1, 45)).repeat(B, 1))
+            else:
+                pose = rodrigues_batch(torch.randn(B * 15, 3, generator=g) * 0.6).view(B, 15, 3, 3).requires_grad_(True)
+            shape = (torch.randn(B, 10, generator=g)).requires_grad_(True)
+            trans = (torch.randn(B, 3, generator=g) * 0.1).requires_grad_(True) if use_t else None
+            scale = (torch.rand(B, generator=g) + 0.5).requires_grad_(True) if use_s else None
+            v, j = layer(root, pose, shape, trans=trans, scale=scale)
+            wv = torch.randn(v.shape, generator=g)
+            wj = torch.randn(j.shape, generator=g)
+            (v * wv).sum().add((j * wj).sum()).backward()
+            key = 'mano/%s/%s/' % (side, name)
+            meta = dict(B=B, ncomp=-1 if nc == 'rot' else nc, center=-1 if center is None else center,
+                        use_t=int(use_t), use_s=int(use_s), new_skel=int(new_skel))
+            for k2, val in meta.items():
+                store[key + 'meta_' + k2] = np.int64(val)
+            for nm, t in (('root', root), ('pose', pose), ('shape', shape), ('trans', trans), ('scale', scale),
+                          ('wv', wv), ('wj', wj), ('v', v), ('j', j)):
+                if t is not None:
+                    store[key + nm] = t.detach().numpy()
+            for nm, t in (('root', root), ('pose', pose), ('shape', shape), ('trans', trans), ('scale', scale)):
+                if t is not None:
+                    store[key + 'grad_' + nm] = t.grad.numpy()
+    path = os.path.join(HERE, 'mano.npz')
+    np.savez_compressed(path, **store)
+    print('wrote', path, os.path.getsize(path), 'bytes,', len(store), 'arrays')
+
+
+def keys_fixture():
+    """Reference state_dict schema (key -> shape) for the ResNet50 variant."""
+    import json
+    torch.manual_seed(0)
+    model = build_reference_model(dropout=0.05)
+    sch = {k: list(v.shape) for k, v in model.state_dict().items()}
+    path = os.path.join(HERE, 'state_keys.json')
+    with open(path, 'w') as f:
+        json.dump(sch, f)
+    print('wrote', path, len(sch), 'keys')
+
+
+def zlibseed(s):
+    import zlib
+    return zlib.crc32(s.encode()) & 0x7FFFFFFF
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['eval', 'train', 'mano', 'keys']
+    if 'keys' in which:
+        keys_fixture()
+    if 'mano' in which:
+        mano_fixture()
+    if 'eval' in which:
+        net_fixture('eval')
+    if 'train' in which:
+        net_fixture('train')

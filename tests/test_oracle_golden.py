@@ -1,0 +1,88 @@
+"""Pin the oracle (oracle/*.py, a CPU restatement) to vectors produced by the REAL reference
+(tests/golden/make_golden.py).  CPU only."""
+import os
+import numpy as np
+import pytest
+import torch
+
+from oracle import net_oracle, mano_oracle
+from renderih_amd import assets, testing
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _check(store, name, t, rtol=1e-4, atol_frac=1e-5):
+    if name in store:
+        testing.assert_close(t, torch.from_numpy(store[name]), rtol, atol_frac, name)
+    else:
+        st, sa = testing.signature(t, nsamp=len(store[name + '#samp']))
+        want_st, want_sa = store[name + '#stats'], store[name + '#samp']
+        assert st[4] == want_st[4], name
+        testing.assert_close(torch.from_numpy(sa), torch.from_numpy(want_sa), rtol, atol_frac * 10, name + '#samp')
+        np.testing.assert_allclose(st[1:4], want_st[1:4], rtol=1e-4, err_msg=name + '#stats')
+
+
+def _oracle_state():
+    """Reference-keyed state dict without importing the reference: keys/shapes from our module tree."""
+    from renderih_amd.model import build_model
+    m = build_model(dropout=0.0)
+    return testing.deterministic_state(m.state_dict(), seed=0)
+
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_network_oracle_matches_reference(mode):
+    z = np.load(os.path.join(GOLDEN, 'net_%s.npz' % mode))
+    sd = _oracle_state()
+    graph = net_oracle.graph_from_dicts(assets.load_graph_dict('left'), assets.load_graph_dict('right'))
+    img = testing.seeded_image(2, seed=0)
+    taps = {}
+    if mode == 'train':
+        for k, v in sd.items():
+            if v.is_floating_point() and 'running' not in k and 'dense_coor' not in k:
+                v.requires_grad_(True)
+    with torch.set_grad_enabled(mode == 'train'):
+        out = net_oracle.handnet_forward(sd, graph, img, training=(mode == 'train'), taps=taps)
+    for k, v in testing.flatten_outputs(out).items():
+        _check(z, 'out/' + k, v)
+    for k, v in taps.items():
+        if ('tap/' + k) in z or ('tap/' + k + '#samp') in z:
+            _check(z, 'tap/' + k, v)
+    if mode == 'train':
+        loss = net_oracle.scalar_loss(out)
+        assert abs(loss.item() - float(z['loss'])) <= 1e-5 * abs(float(z['loss']))
+        loss.backward()
+        names = list(z['grad_names'])
+        got = {k for k, v in sd.items() if v.grad is not None}
+        assert set(names) == got, (set(names) ^ got)
+        for k in names:
+            if k.endswith('w_ks.bias'):
+                continue    # exactly zero in exact arithmetic (softmax is shift invariant): pure round-off noise
+            st, sa = testing.signature(sd[k].grad, nsamp=32)
+            testing.assert_close(torch.from_numpy(sa), torch.from_numpy(z['grad/' + k + '#samp']),
+                                 1e-3, 1e-4, 'grad/' + k)
+
+
+def _mano_cases(z, side):
+    names = sorted({k.split('/')[2] for k in z.files if k.startswith('mano/%s/' % side)})
+    return names
+
+
+@pytest.mark.parametrize('side', ['right', 'left'])
+def test_mano_oracle_matches_reference(side):
+    z = np.load(os.path.join(GOLDEN, 'mano.npz'))
+    c = mano_oracle.constants_from_dict(assets.synthetic_mano_dict(side, seed=0))
+    for name in _mano_cases(z, side):
+        key = 'mano/%s/%s/' % (side, name)
+        g = lambda n: torch.from_numpy(z[key + n]).requires_grad_(True) if (key + n) in z.files else None
+        root, pose, shape, trans, scale = g('root'), g('pose'), g('shape'), g('trans'), g('scale')
+        center = int(z[key + 'meta_center'])
+        v, j = mano_oracle.mano_forward(c, root, pose, shape, trans, scale,
+                                        center_idx=None if center < 0 else center,
+                                        use_pca=int(z[key + 'meta_ncomp']) > 0,
+                                        new_skel=bool(z[key + 'meta_new_skel']))
+        testing.assert_close(v, torch.from_numpy(z[key + 'v']), 1e-5, 1e-6, key + 'v')
+        testing.assert_close(j, torch.from_numpy(z[key + 'j']), 1e-5, 1e-6, key + 'j')
+        ((v * torch.from_numpy(z[key + 'wv'])).sum() + (j * torch.from_numpy(z[key + 'wj'])).sum()).backward()
+        for nm, t in (('root', root), ('pose', pose), ('shape', shape), ('trans', trans), ('scale', scale)):
+            if t is not None:
+                testing.assert_close(t.grad, torch.from_numpy(z[key + 'grad_' + nm]), 1e-4, 1e-5, key + 'grad_' + nm)
