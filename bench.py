@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the pose-network hot path (forward + loss + backward + optimizer step) on MI355X.
+
+Workload = BASELINE.json configs[1]: batch 64 per GPU, 256x256 RGB, ResNet50 encoder + GCN/attention mesh decoder
+(the reference's `HandNET_GCN`), fp32, training mode with the reference's dropout 0.05, synthetic inputs/labels,
+random-init weights.  N>1: one process per GPU (torch.distributed, backend "nccl" = RCCL), plain data parallel with
+the reference's DDP(find_unused_parameters=True) semantics; weak scaling (batch 64 per GPU).
+
+Prints ONE JSON line (rank 0).  `roofline`: the fp32-MFMA GEMM/implicit-conv kernel family (rih_gemm), timed live with
+HIP events on the launch stream; achieved = SURVEY 8d algorithmic FLOPs (53.2 GFLOP/img fwd+bwd) x images per step /
+GEMM-family time per step; peak = 157.3 TFLOP/s dense fp32 MFMA.  `cpu_baseline`: the CPU oracle (a port of the
+reference's PyTorch-CPU path) timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMG_FWD_BWD = 53.2      # 3 x 17.72 GFLOP/img forward (conv + matmul, 2*MAC)
+PEAK_FP32_MFMA_TF = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def synth_batch(B, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, 3, 256, 256, generator=g)
+    lab = {'v3d_l': 0.05 * torch.randn(B, 778, 3, generator=g), 'v3d_r': 0.05 * torch.randn(B, 778, 3, generator=g),
+           'v2d_l': 256 * torch.rand(B, 778, 2, generator=g), 'v2d_r': 256 * torch.rand(B, 778, 2, generator=g),
+           'root_rel': 0.05 * torch.randn(B, 3, generator=g)}
+    return img.to(device), {k: v.to(device) for k, v in lab.items()}
+
+
+def cpu_baseline(seconds=20.0, batch=4):
+    """Oracle (CPU port of the reference path) forward+backward, bounded wall time."""
+    from oracle import net_oracle
+    from renderih_amd import assets
+    from renderih_amd.model import build_model
+    torch.manual_seed(0)
+    m = build_model(0.0)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and 'running' not in k and 'dense_coor' not in k:
+            v.requires_grad_(True)
+    graph = net_oracle.graph_from_dicts(assets.load_graph_dict('left'), assets.load_graph_dict('right'))
+    img = torch.randn(batch, 3, 256, 256)
+    n, t_total = 0, 0.0
+    t_start = time.time()
+    for it in range(50):
+        t0 = time.time()
+        out = net_oracle.handnet_forward(sd, graph, img, training=True)
+        net_oracle.scalar_loss(out).backward()
+        dt = time.time() - t0
+        if it > 0:                    # first iteration is warm-up
+            n += 1
+            t_total += dt
+        if time.time() - t_start > seconds and n >= 1:
+            break
+    return {'value': round(batch * n / t_total, 3), 'unit': 'images/sec', 'cores': torch.get_num_threads(),
+            'kind': 'port', 'sample': 'oracle fwd+bwd, batch %d, %d timed iterations (~%.0fs)' % (batch, n, t_total)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='per-GPU batch')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (HIP kernels only, no CPU fallback)')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)
+
+    from renderih_amd import ops, assets
+    from renderih_amd.model import build_model
+    from renderih_amd.loss import GraphLoss, calc_loss_GCN
+    from renderih_amd.manolayer import ManoLayer
+
+    torch.manual_seed(0)
+    model = build_model(dropout=0.05).to(device).train()
+    model.decoder.unsample_layer.weight.requires_grad_(False)          # core/gcn_trainer.py:102-103
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=True)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=3e-4, weight_decay=1e-2)
+
+    mano = {s: ManoLayer(assets.synthetic_mano_dict(s)) for s in ('left', 'right')}
+    gl = {s: GraphLoss(mano[s].J_regressor, mano[s].get_faces(), level=4, device=device) for s in ('left', 'right')}
+    conv = model.decoder.converter
+    B = args.batch
+    img, lab = synth_batch(B, device, seed=rank)
+
+    def step():
+        out = net(img)
+        loss, _ = calc_loss_GCN(None, 0, gl['left'], gl['right'], conv['left'], conv['right'], *out,
+                                lab['v2d_l'], lab['v2d_r'], lab['v3d_l'], lab['v3d_r'], lab['root_rel'], 256)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        ops.PROFILE = []
+        step()
+        torch.cuda.synchronize()
+        recs = ops.PROFILE
+        ops.PROFILE = None
+        ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in recs)
+        launched = sum(f for f, _, _, _ in recs)
+        by = {}
+        for f, e0, e1, tag in recs:
+            k = 'tile%d a%d b%d' % (tag[6], tag[4], tag[5])
+            a = by.setdefault(k, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1)
+            a[2] += f
+        top = max(by.items(), key=lambda kv: kv[1][1])
+        achieved = GFLOP_PER_IMG_FWD_BWD * B / ms            # GFLOP / ms = TFLOP/s
+        roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s',
+                'frac': round(achieved / PEAK_FP32_MFMA_TF, 4), 'traffic': None,
+                'kernel': 'rih_gemm (gemm_kernel<BM,BN,AMODE,BMODE>, v_mfma_f32_32x32x2_f32)',
+                'launches_per_step': len(recs), 'gemm_ms_per_step': round(ms, 3),
+                'launched_tflops': round(launched / ms / 1e9, 2),
+                'avg_launch_us': round(1000.0 * ms / max(len(recs), 1), 2),
+                'top_variant': {'name': top[0], 'launches': top[1][0], 'ms': round(top[1][1], 3),
+                                'tflops': round(top[1][2] / top[1][1] / 1e9, 2)}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        n_img = B * world * args.steps
+        line = {'metric': 'images/sec fwd+bwd @256x256 two-hand', 'value': round(n_img / elapsed, 2),
+                'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': round(1000.0 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+                'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'config': {'workload': 'BASELINE configs[1]: batch=64/GPU 256x256 ResNet50 + cross-hand attention decoder, '
+                                       'fwd + loss + bwd + Adam step, dropout 0.05, fp32',
+                           'global_batch': B * world, 'parallelism': 'dp%d' % world, 'loss': round(final_loss, 4)},
+                'roofline': roof, 'cpu_baseline': cpu}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,579 @@
+// rih_mano.hip -- MANO linear-blend-skinning layer (models/manolayer.py:250-322) for gfx950.
+//
+// Forward = two kernels:
+//   mano_pose_kernel   one workgroup per hand: PCA -> axis-angle -> Rodrigues, shape blend, joint regression,
+//                      kinematic chain (16 SE3), the 13 "special" vertices (5 finger tips + 8 new_skel vertices),
+//                      21 output joints, centre/scale/translation.  Everything small stays in LDS.
+//   mano_vertex_kernel vertex-tiled: a 64-vertex tile of the pose-blend basis (64 x 405 fp32 = 101 KB of the
+//                      1.26 MB posedirs) is pinned in LDS once per workgroup and reused for every hand of the
+//                      workgroup's batch chunk; lane = vertex (LDS row stride 405 is odd -> conflict-free
+//                      ds_read_b32), per-hand pose features and SE3s come in through scalar loads (wave-uniform).
+// Backward = one workgroup per hand (mano_bwd_kernel): reverse LBS, chain, blend shapes, Rodrigues, PCA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/renderih_amd.h"
+
+namespace {
+
+constexpr int NV = 778, NVC = 778 * 3, NJ = 16, NPF = 135;
+constexpr int TILE_V = 64;
+constexpr int NTILES = (NV + TILE_V - 1) / TILE_V;   // 13
+
+// per-hand workspace layout (floats)
+constexpr int OFF_R = 0;            // [16][9]   R[0] = root, R[1..15] = local joint rotations
+constexpr int OFF_JT = 144;         // [16][3]   rest joints
+constexpr int OFF_G = 192;          // [16][12]  global SE3 (3x4 row-major)
+constexpr int OFF_POST = 384;       // centre[3], scale, trans[3], pad
+constexpr int OFF_J21C = 392;       // [21][3]   joints - centre (before scale/trans), +1 pad
+constexpr int OFF_VS = 456;         // [778*3]   v_shaped
+constexpr int OFF_VT = OFF_VS + NVC;     // v_tpose (shape + pose blend)
+constexpr int OFF_VSC = OFF_VT + NVC;    // v_skinned - centre
+constexpr int WS_STRIDE = OFF_VSC + NVC + 2;   // 7460
+
+__constant__ int c_new_order[21] = {0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20};
+__constant__ int c_special[13] = {745, 317, 444, 556, 673, 63, 144, 271, 220, 148, 290, 770, 83};
+// new_skel: joint 5 <- (63,144), 9 <- (271,220), 13 <- (148,290), 17 <- (770,83)   (manolayer.py:316-320)
+__constant__ int c_ns_joint[4] = {5, 9, 13, 17};
+
+struct Model {
+    const float* comps;
+    const float* hands_mean;
+    const float* shapedirs;
+    const float* posedirs;
+    const float* v_template;
+    const float* J_reg;
+    const float* weights;
+    int parent[16];
+};
+
+__device__ __forceinline__ void rodrigues_fwd(const float* ax, float* R) {
+    // manolayer.py:32-48: angle = ||axis|| + 1e-8, R = I + sin K + (1-cos) K^2
+    const float n = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    const float th = n + 1e-8f;
+    const float a0 = ax[0] / th, a1 = ax[1] / th, a2 = ax[2] / th;
+    const float s = sinf(th), c1 = 1.f - cosf(th);
+    const float K[9] = {0.f, -a2, a1, a2, 0.f, -a0, -a1, a0, 0.f};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float k2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) k2 += K[r * 3 + k] * K[k * 3 + c];
+            R[r * 3 + c] = ((r == c) ? 1.f : 0.f) + s * K[r * 3 + c] + c1 * k2;
+        }
+}
+
+__device__ __forceinline__ void rodrigues_bwd(const float* ax, const float* D, float* dax) {
+    const float n = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    const float th = n + 1e-8f;
+    const float a[3] = {ax[0] / th, ax[1] / th, ax[2] / th};
+    const float s = sinf(th), c = cosf(th), c1 = 1.f - c;
+    const float K[9] = {0.f, -a[2], a[1], a[2], 0.f, -a[0], -a[1], a[0], 0.f};
+    const float aa = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+    float dth = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            const float k2 = a[r] * a[cc] - ((r == cc) ? aa : 0.f);
+            dth += D[r * 3 + cc] * (c * K[r * 3 + cc] + s * k2);
+        }
+    const float tr = D[0] + D[4] + D[8];
+    const float sk[3] = {D[7] - D[5], D[2] - D[6], D[3] - D[1]};
+    float da[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float rowdot = 0.f, coldot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { rowdot += D[k * 3 + j] * a[j]; coldot += D[j * 3 + k] * a[j]; }
+        da[k] = s * sk[k] + c1 * (rowdot + coldot - 2.f * a[k] * tr);
+    }
+    const float dadot = da[0] * ax[0] + da[1] * ax[1] + da[2] * ax[2];
+    const float coef = (n > 0.f) ? (dth - dadot / (th * th)) / n : 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dax[k] = da[k] / th + coef * ax[k];
+}
+
+// ------------------------------------------------------------------------------------------------ forward A
+__global__ __launch_bounds__(256) void mano_pose_kernel(Model m, const float* __restrict__ root,
+                                                        const float* __restrict__ pose, int ncomp,
+                                                        const float* __restrict__ shape,
+                                                        const float* __restrict__ trans,
+                                                        const float* __restrict__ scale, int center_idx, int new_skel,
+                                                        float* __restrict__ jout, float* __restrict__ ws) {
+    __shared__ float s_axis[48];
+    __shared__ float s_R[NJ * 9];
+    __shared__ float s_beta[10];
+    __shared__ float s_vs[NVC];
+    __shared__ float s_jt[NJ * 3];
+    __shared__ float s_G[NJ * 12];
+    __shared__ float s_src[21 * 3];      // 16 chain joints + 5 tips (skinned, un-centred)
+    __shared__ float s_sp[13 * 3];       // skinned special vertices
+    __shared__ float s_post[8];
+    const int b = blockIdx.x, t = threadIdx.x;
+    float* w = ws + (long long)b * WS_STRIDE;
+
+    if (t < 10) s_beta[t] = shape[b * 10 + t];
+    if (ncomp > 0 && t < 45) {
+        float a = m.hands_mean[t];
+        for (int c = 0; c < ncomp; ++c) a += pose[(long long)b * ncomp + c] * m.comps[c * 45 + t];
+        s_axis[t] = a;
+    }
+    __syncthreads();
+    if (t < NJ) {
+        float R[9];
+        if (t == 0) {
+            for (int e = 0; e < 9; ++e) R[e] = root[(long long)b * 9 + e];
+        } else if (ncomp > 0) {
+            rodrigues_fwd(&s_axis[(t - 1) * 3], R);
+        } else {
+            for (int e = 0; e < 9; ++e) R[e] = pose[((long long)b * 15 + (t - 1)) * 9 + e];
+        }
+        for (int e = 0; e < 9; ++e) { s_R[t * 9 + e] = R[e]; w[OFF_R + t * 9 + e] = R[e]; }
+    }
+    for (int i = t; i < NVC; i += 256) {
+        float v = m.v_template[i];
+#pragma unroll
+        for (int s = 0; s < 10; ++s) v += m.shapedirs[i * 10 + s] * s_beta[s];
+        s_vs[i] = v;
+        w[OFF_VS + i] = v;
+    }
+    __syncthreads();
+    {   // joint regression: thread -> (joint = t/16, part = t%16)
+        const int j = t >> 4, part = t & 15;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int v = part; v < NV; v += 16) {
+            const float wv = m.J_reg[j * NV + v];
+            a0 += wv * s_vs[v * 3 + 0];
+            a1 += wv * s_vs[v * 3 + 1];
+            a2 += wv * s_vs[v * 3 + 2];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            a0 += __shfl_xor(a0, o, 64);
+            a1 += __shfl_xor(a1, o, 64);
+            a2 += __shfl_xor(a2, o, 64);
+        }
+        if (part == 0) {
+            s_jt[j * 3 + 0] = a0; s_jt[j * 3 + 1] = a1; s_jt[j * 3 + 2] = a2;
+            w[OFF_JT + j * 3 + 0] = a0; w[OFF_JT + j * 3 + 1] = a1; w[OFF_JT + j * 3 + 2] = a2;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {   // kinematic chain (manolayer.py:274-289)
+        for (int i = 0; i < NJ; ++i) {
+            const float* R = &s_R[i * 9];
+            const float* jv = &s_jt[i * 3];
+            float tl[3];
+            for (int r = 0; r < 3; ++r) tl[r] = jv[r] - (R[r * 3] * jv[0] + R[r * 3 + 1] * jv[1] + R[r * 3 + 2] * jv[2]);
+            float* G = &s_G[i * 12];
+            if (i == 0) {
+                for (int r = 0; r < 3; ++r) {
+                    for (int c = 0; c < 3; ++c) G[r * 4 + c] = R[r * 3 + c];
+                    G[r * 4 + 3] = tl[r];
+                }
+                for (int r = 0; r < 3; ++r) s_src[r] = jv[r];
+            } else {
+                const float* P = &s_G[m.parent[i] * 12];
+                for (int r = 0; r < 3; ++r) {
+                    for (int c = 0; c < 3; ++c)
+                        G[r * 4 + c] = P[r * 4] * R[c] + P[r * 4 + 1] * R[3 + c] + P[r * 4 + 2] * R[6 + c];
+                    G[r * 4 + 3] = P[r * 4] * tl[0] + P[r * 4 + 1] * tl[1] + P[r * 4 + 2] * tl[2] + P[r * 4 + 3];
+                    s_src[i * 3 + r] = P[r * 4] * jv[0] + P[r * 4 + 1] * jv[1] + P[r * 4 + 2] * jv[2] + P[r * 4 + 3];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (t < NJ * 12) w[OFF_G + t] = s_G[t];
+    // special vertices: pose blend (thread -> (k, c)), then skinning (thread -> k)
+    __shared__ float s_spt[13 * 3];
+    if (t < 39) {
+        const int k = t / 3, c = t % 3;
+        const int vc = c_special[k] * 3 + c;
+        float v = s_vs[vc];
+        for (int p = 0; p < NPF; ++p) {
+            const float pf = s_R[9 + p] - (((p % 9) % 4 == 0) ? 1.f : 0.f);
+            v += m.posedirs[(long long)vc * NPF + p] * pf;
+        }
+        s_spt[t] = v;
+    }
+    __syncthreads();
+    if (t < 13) {
+        const int v = c_special[t];
+        float T[12];
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        for (int j = 0; j < NJ; ++j) {
+            const float wj = m.weights[v * NJ + j];
+            for (int e = 0; e < 12; ++e) T[e] += wj * s_G[j * 12 + e];
+        }
+        const float* x = &s_spt[t * 3];
+        for (int r = 0; r < 3; ++r) s_sp[t * 3 + r] = T[r * 4] * x[0] + T[r * 4 + 1] * x[1] + T[r * 4 + 2] * x[2] + T[r * 4 + 3];
+    }
+    __syncthreads();
+    if (t < 15) s_src[48 + t] = s_sp[t];     // tips = special[0..4]
+    __syncthreads();
+    if (t == 0) {
+        float ctr[3] = {0.f, 0.f, 0.f};
+        if (center_idx >= 0) for (int c = 0; c < 3; ++c) ctr[c] = s_src[c_new_order[center_idx] * 3 + c];
+        s_post[0] = ctr[0]; s_post[1] = ctr[1]; s_post[2] = ctr[2];
+        s_post[3] = scale ? scale[b] : 1.f;
+        for (int c = 0; c < 3; ++c) s_post[4 + c] = trans ? trans[b * 3 + c] : 0.f;
+        s_post[7] = 0.f;
+    }
+    __syncthreads();
+    if (t < 8) w[OFF_POST + t] = s_post[t];
+    if (t < 63) {
+        const int k = t / 3, c = t % 3;
+        const float jc = s_src[c_new_order[k] * 3 + c] - s_post[c];
+        w[OFF_J21C + t] = jc;
+        float o = jc * s_post[3] + s_post[4 + c];
+        if (new_skel) {
+            for (int q = 0; q < 4; ++q)
+                if (c_ns_joint[q] == k) {
+                    const float va = (s_sp[(5 + 2 * q) * 3 + c] - s_post[c]) * s_post[3] + s_post[4 + c];
+                    const float vb = (s_sp[(6 + 2 * q) * 3 + c] - s_post[c]) * s_post[3] + s_post[4 + c];
+                    o = (va + vb) / 2.f;
+                }
+        }
+        jout[(long long)b * 63 + t] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward B
+__global__ __launch_bounds__(256) void mano_vertex_kernel(Model m, float* __restrict__ vout, float* __restrict__ ws,
+                                                          int B, int hands_per_block) {
+    __shared__ float s_pd[TILE_V * 405];      // posedirs tile pinned in LDS (103,680 B)
+    const int tile = blockIdx.x;
+    const int v0 = tile * TILE_V;
+    const int nrows = min(TILE_V, NV - v0);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    {
+        const float* src = m.posedirs + (long long)v0 * 405;
+        const int n = nrows * 405;
+        for (int i = t; i < n; i += 256) s_pd[i] = src[i];
+    }
+    __syncthreads();
+    const int v = v0 + lane;
+    const bool valid = lane < nrows;
+    float wgt[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) wgt[j] = valid ? m.weights[v * NJ + j] : 0.f;
+    const float* pd = &s_pd[lane * 405];
+    const int h0 = blockIdx.y * hands_per_block;
+    const int h1 = min(B, h0 + hands_per_block);
+    for (int hh = h0 + wave; hh < h1; hh += 4) {
+        const int h = __builtin_amdgcn_readfirstlane(hh);
+        float* __restrict__ w = ws + (long long)h * WS_STRIDE;
+        const float* __restrict__ Rl = w + OFF_R + 9;       // local rotations of joints 1..15 -> pose feature
+        float vt[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vt[c] = valid ? w[OFF_VS + v * 3 + c] : 0.f;
+        if (valid) {
+#pragma unroll 5
+            for (int p = 0; p < NPF; ++p) {
+                const float pf = Rl[p] - (((p % 9) % 4 == 0) ? 1.f : 0.f);
+                vt[0] += pd[p] * pf;
+                vt[1] += pd[NPF + p] * pf;
+                vt[2] += pd[2 * NPF + p] * pf;
+            }
+        }
+        float T[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        const float* __restrict__ G = w + OFF_G;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] += wgt[j] * G[j * 12 + e];
+        const float cx = w[OFF_POST + 0], cy = w[OFF_POST + 1], cz = w[OFF_POST + 2];
+        const float sc = w[OFF_POST + 3];
+        const float tx = w[OFF_POST + 4], ty = w[OFF_POST + 5], tz = w[OFF_POST + 6];
+        if (valid) {
+            const float x = T[0] * vt[0] + T[1] * vt[1] + T[2] * vt[2] + T[3] - cx;
+            const float y = T[4] * vt[0] + T[5] * vt[1] + T[6] * vt[2] + T[7] - cy;
+            const float z = T[8] * vt[0] + T[9] * vt[1] + T[10] * vt[2] + T[11] - cz;
+            float* o = vout + ((long long)h * NV + v) * 3;
+            o[0] = x * sc + tx;
+            o[1] = y * sc + ty;
+            o[2] = z * sc + tz;
+            w[OFF_VT + v * 3 + 0] = vt[0]; w[OFF_VT + v * 3 + 1] = vt[1]; w[OFF_VT + v * 3 + 2] = vt[2];
+            w[OFF_VSC + v * 3 + 0] = x; w[OFF_VSC + v * 3 + 1] = y; w[OFF_VSC + v * 3 + 2] = z;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void mano_bwd_kernel(Model m, const float* __restrict__ pose, int ncomp,
+                                                       int center_idx, int new_skel, int has_scale,
+                                                       const float* __restrict__ dv, const float* __restrict__ dj,
+                                                       const float* __restrict__ ws, float* __restrict__ d_root,
+                                                       float* __restrict__ d_pose, float* __restrict__ d_shape,
+                                                       float* __restrict__ d_trans, float* __restrict__ d_scale) {
+    __shared__ float s_dvs[NVC];           // dv_eff -> dv_skin -> dv_tpose -> dv_shaped (in place)
+    __shared__ float s_M[NV * 12];         // per-vertex outer products dv_skin x [v_t;1]
+    __shared__ float s_G[NJ * 12], s_R[NJ * 9], s_jt[NJ * 3];
+    __shared__ float s_dG[NJ * 12], s_dR[NJ * 9], s_djt[NJ * 3];
+    __shared__ float s_djeff[63], s_dsrc[63];
+    __shared__ float s_dpf[NPF];
+    __shared__ float s_axis[48], s_dax[48];
+    __shared__ float s_red[4];
+    __shared__ float s_sh[250];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float* w = ws + (long long)b * WS_STRIDE;
+    const float* dvb = dv + (long long)b * NVC;
+    const float* djb = dj + (long long)b * 63;
+
+    if (t < NJ * 12) { s_G[t] = w[OFF_G + t]; s_dG[t] = 0.f; }
+    if (t < NJ * 9) { s_R[t] = w[OFF_R + t]; s_dR[t] = 0.f; }
+    if (t < NJ * 3) { s_jt[t] = w[OFF_JT + t]; s_djt[t] = 0.f; }
+    if (t < 63) {
+        float d = djb[t];
+        if (new_skel) {
+            const int k = t / 3;
+            if (k == 5 || k == 9 || k == 13 || k == 17) d = 0.f;
+        }
+        s_djeff[t] = d;
+    }
+    if (ncomp > 0 && t < 45) {
+        float a = m.hands_mean[t];
+        for (int c = 0; c < ncomp; ++c) a += pose[(long long)b * ncomp + c] * m.comps[c * 45 + t];
+        s_axis[t] = a;
+    }
+    const float sc = w[OFF_POST + 3];
+    // 1. effective vertex gradient (new_skel joints are averages of output vertices)
+    float p_sv0 = 0.f, p_sv1 = 0.f, p_sv2 = 0.f, p_dot = 0.f;
+    for (int i = t; i < NVC; i += 256) {
+        float d = dvb[i];
+        if (new_skel) {
+            const int v = i / 3, c = i - v * 3;
+            for (int q = 0; q < 8; ++q)
+                if (c_special[5 + q] == v) d += 0.5f * djb[c_ns_joint[q >> 1] * 3 + c];
+        }
+        s_dvs[i] = d;
+        const int c = i % 3;
+        if (c == 0) p_sv0 += d; else if (c == 1) p_sv1 += d; else p_sv2 += d;
+        p_dot += d * w[OFF_VSC + i];
+    }
+    __syncthreads();
+    if (t < 63) p_dot += s_djeff[t] * w[OFF_J21C + t];
+    const float sv0 = block_sum_256(p_sv0, s_red);
+    const float sv1 = block_sum_256(p_sv1, s_red);
+    const float sv2 = block_sum_256(p_sv2, s_red);
+    const float dot = block_sum_256(p_dot, s_red);
+    float sj[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < 21; ++k) { sj[0] += s_djeff[k * 3]; sj[1] += s_djeff[k * 3 + 1]; sj[2] += s_djeff[k * 3 + 2]; }
+    const float st[3] = {sv0 + sj[0], sv1 + sj[1], sv2 + sj[2]};
+    if (t == 0) {
+        if (d_trans) for (int c = 0; c < 3; ++c) d_trans[b * 3 + c] = st[c];
+        if (d_scale && has_scale) d_scale[b] = dot;
+    }
+    // 3. joint-side gradients in `src` order (16 chain joints + 5 tips)
+    if (t < 63) {
+        const int k = t / 3, c = t % 3;
+        float d = sc * s_djeff[t];
+        if (center_idx >= 0 && k == center_idx) d -= sc * st[c];
+        s_dsrc[c_new_order[k] * 3 + c] = d;
+    }
+    __syncthreads();
+    for (int i = t; i < NVC; i += 256) {
+        float d = sc * s_dvs[i];
+        const int v = i / 3, c = i - v * 3;
+        for (int q = 0; q < 5; ++q)
+            if (c_special[q] == v) d += s_dsrc[(16 + q) * 3 + c];
+        s_dvs[i] = d;                       // dv_skin
+    }
+    __syncthreads();
+    // 4. through the skinning: dv_tpose = T_v^T dv_skin ; M_v = dv_skin x [v_t;1]
+    for (int v = t; v < NV; v += 256) {
+        float Tr[9];
+        for (int e = 0; e < 9; ++e) Tr[e] = 0.f;
+        for (int j = 0; j < NJ; ++j) {
+            const float wj = m.weights[v * NJ + j];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) Tr[r * 3 + c] += wj * s_G[j * 12 + r * 4 + c];
+        }
+        const float d[3] = {s_dvs[v * 3], s_dvs[v * 3 + 1], s_dvs[v * 3 + 2]};
+        const float x[3] = {w[OFF_VT + v * 3], w[OFF_VT + v * 3 + 1], w[OFF_VT + v * 3 + 2]};
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) s_M[v * 12 + r * 4 + c] = d[r] * x[c];
+            s_M[v * 12 + r * 4 + 3] = d[r];
+        }
+        for (int c = 0; c < 3; ++c) s_dvs[v * 3 + c] = Tr[c] * d[0] + Tr[3 + c] * d[1] + Tr[6 + c] * d[2];
+    }
+    __syncthreads();
+    // 5. dG = W^T M
+    if (t < NJ * 12) {
+        const int j = t / 12, e = t % 12;
+        float a = 0.f;
+        for (int v = 0; v < NV; ++v) a += m.weights[v * NJ + j] * s_M[v * 12 + e];
+        s_dG[t] = a;
+    }
+    __syncthreads();
+    // 6.-7. joints and kinematic chain, sequential (16 tiny steps)
+    if (t == 0) {
+        for (int c = 0; c < 3; ++c) s_djt[c] += s_dsrc[c];
+        for (int i = 1; i < NJ; ++i) {
+            const int p = m.parent[i];
+            const float* dji = &s_dsrc[i * 3];
+            const float* P = &s_G[p * 12];
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) s_dG[p * 12 + r * 4 + c] += dji[r] * s_jt[i * 3 + c];
+                s_dG[p * 12 + r * 4 + 3] += dji[r];
+            }
+            for (int c = 0; c < 3; ++c) s_djt[i * 3 + c] += P[c] * dji[0] + P[4 + c] * dji[1] + P[8 + c] * dji[2];
+        }
+        for (int i = NJ - 1; i >= 0; --i) {
+            const float* R = &s_R[i * 9];
+            const float* jv = &s_jt[i * 3];
+            const float* dGi = &s_dG[i * 12];
+            float dRl[9], dtl[3];
+            if (i > 0) {
+                const int p = m.parent[i];
+                const float* P = &s_G[p * 12];
+                float tl[3];
+                for (int r = 0; r < 3; ++r) tl[r] = jv[r] - (R[r * 3] * jv[0] + R[r * 3 + 1] * jv[1] + R[r * 3 + 2] * jv[2]);
+                for (int r = 0; r < 3; ++r) {
+                    for (int c = 0; c < 3; ++c) {
+                        // dRp += dRg * Ri^T + dtg x tl^T
+                        s_dG[p * 12 + r * 4 + c] += dGi[r * 4] * R[c * 3] + dGi[r * 4 + 1] * R[c * 3 + 1] +
+                                                    dGi[r * 4 + 2] * R[c * 3 + 2] + dGi[r * 4 + 3] * tl[c];
+                    }
+                    s_dG[p * 12 + r * 4 + 3] += dGi[r * 4 + 3];
+                }
+                for (int r = 0; r < 3; ++r) {
+                    for (int c = 0; c < 3; ++c)
+                        dRl[r * 3 + c] = P[r] * dGi[c] + P[4 + r] * dGi[4 + c] + P[8 + r] * dGi[8 + c];
+                    dtl[r] = P[r] * dGi[3] + P[4 + r] * dGi[7] + P[8 + r] * dGi[11];
+                }
+            } else {
+                for (int r = 0; r < 3; ++r) {
+                    for (int c = 0; c < 3; ++c) dRl[r * 3 + c] = dGi[r * 4 + c];
+                    dtl[r] = dGi[r * 4 + 3];
+                }
+            }
+            // local: t_l = (I - R) j  ->  dR -= dtl x j^T ; dj += dtl - R^T dtl
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) s_dR[i * 9 + r * 3 + c] = dRl[r * 3 + c] - dtl[r] * jv[c];
+            for (int c = 0; c < 3; ++c)
+                s_djt[i * 3 + c] += dtl[c] - (R[c] * dtl[0] + R[3 + c] * dtl[1] + R[6 + c] * dtl[2]);
+        }
+    }
+    __syncthreads();
+    // 8. pose-blend gradient: dpf[p] = sum_vc posedirs[vc][p] * dv_tpose[vc]
+    if (t < NPF) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int vc = 0;
+        for (; vc + 3 < NVC; vc += 4) {
+            a0 += m.posedirs[(long long)vc * NPF + t] * s_dvs[vc];
+            a1 += m.posedirs[(long long)(vc + 1) * NPF + t] * s_dvs[vc + 1];
+            a2 += m.posedirs[(long long)(vc + 2) * NPF + t] * s_dvs[vc + 2];
+            a3 += m.posedirs[(long long)(vc + 3) * NPF + t] * s_dvs[vc + 3];
+        }
+        for (; vc < NVC; ++vc) a0 += m.posedirs[(long long)vc * NPF + t] * s_dvs[vc];
+        s_dpf[t] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    if (t < NPF) s_dR[9 + t] += s_dpf[t];
+    // 9. joint-regressor term -> dv_shaped
+    for (int i = t; i < NVC; i += 256) {
+        const int v = i / 3, c = i - v * 3;
+        float a = s_dvs[i];
+        for (int j = 0; j < NJ; ++j) a += m.J_reg[j * NV + v] * s_djt[j * 3 + c];
+        s_dvs[i] = a;
+    }
+    __syncthreads();
+    // 10. shape gradient
+    if (t < 250) {
+        const int s = t % 10, part = t / 10;
+        float a = 0.f;
+        for (int vc = part; vc < NVC; vc += 25) a += m.shapedirs[vc * 10 + s] * s_dvs[vc];
+        s_sh[t] = a;
+    }
+    __syncthreads();
+    if (t < 10 && d_shape) {
+        float a = 0.f;
+        for (int part = 0; part < 25; ++part) a += s_sh[part * 10 + t];
+        d_shape[b * 10 + t] = a;
+    }
+    // 11. rotations
+    if (t < 9 && d_root) d_root[(long long)b * 9 + t] = s_dR[t];
+    if (d_pose) {
+        if (ncomp > 0) {
+            if (t < 15) rodrigues_bwd(&s_axis[t * 3], &s_dR[(t + 1) * 9], &s_dax[t * 3]);
+            __syncthreads();
+            if (t < ncomp) {
+                float a = 0.f;
+                for (int k = 0; k < 45; ++k) a += s_dax[k] * m.comps[t * 45 + k];
+                d_pose[(long long)b * ncomp + t] = a;
+            }
+        } else if (t < NPF) {
+            d_pose[(long long)b * NPF + t] = s_dR[9 + t];
+        }
+    }
+}
+
+Model to_model(const rih_mano_model* m) {
+    Model o;
+    o.comps = m->comps; o.hands_mean = m->hands_mean; o.shapedirs = m->shapedirs; o.posedirs = m->posedirs;
+    o.v_template = m->v_template; o.J_reg = m->J_reg; o.weights = m->weights;
+    for (int i = 0; i < 16; ++i) o.parent[i] = m->parent[i];
+    return o;
+}
+
+bool model_ok(const rih_mano_model* m) {
+    if (!m || !m->hands_mean || !m->shapedirs || !m->posedirs || !m->v_template || !m->J_reg || !m->weights) return false;
+    if (m->parent[0] >= 0) return false;
+    for (int i = 1; i < 16; ++i)
+        if (m->parent[i] < 0 || m->parent[i] >= i) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int64_t rih_mano_ws_floats(int B) { return B > 0 ? (int64_t)B * WS_STRIDE : 0; }
+extern "C" int64_t rih_mano_bwd_ws_floats(int B) { return B > 0 ? 4 : 0; }   // backward keeps its scratch in LDS
+
+extern "C" int rih_mano_fwd(const rih_mano_model* m, const float* root, const float* pose, int ncomp,
+                            const float* shape, const float* trans, const float* scale, int center_idx, int new_skel,
+                            float* v, float* j, float* ws, int B, void* stream) {
+    if (!model_ok(m) || !root || !pose || !shape || !v || !j || !ws || B < 1) return RIH_EINVAL;
+    if (ncomp < 0 || ncomp > 45 || center_idx >= 21) return RIH_EINVAL;
+    if (ncomp > 0 && !m->comps) return RIH_EINVAL;
+    const Model mm = to_model(m);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mano_pose_kernel, dim3(B), dim3(256), 0, s, mm, root, pose, ncomp, shape, trans, scale,
+                       center_idx, new_skel, j, ws);
+    // enough workgroups to cover 256 CUs, as few posedirs-tile reloads as that allows
+    int chunks = (1024 + NTILES - 1) / NTILES;
+    if (chunks > (B + 3) / 4) chunks = (B + 3) / 4;
+    if (chunks < 1) chunks = 1;
+    const int hpb = (B + chunks - 1) / chunks;
+    chunks = (B + hpb - 1) / hpb;
+    hipLaunchKernelGGL(mano_vertex_kernel, dim3(NTILES, chunks), dim3(256), 0, s, mm, v, ws, B, hpb);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rih_mano_bwd(const rih_mano_model* m, const float* root, const float* pose, int ncomp,
+                            const float* shape, const float* trans, const float* scale, int center_idx, int new_skel,
+                            const float* dv, const float* dj, const float* ws, float* d_root, float* d_pose,
+                            float* d_shape, float* d_trans, float* d_scale, float* ws_bwd, int B, void* stream) {
+    (void)root; (void)shape; (void)trans; (void)ws_bwd;
+    if (!model_ok(m) || !pose || !dv || !dj || !ws || B < 1) return RIH_EINVAL;
+    if (ncomp < 0 || ncomp > 45 || center_idx >= 21) return RIH_EINVAL;
+    if (ncomp > 0 && !m->comps) return RIH_EINVAL;
+    const Model mm = to_model(m);
+    hipLaunchKernelGGL(mano_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mm, pose, ncomp, center_idx,
+                       new_skel, scale ? 1 : 0, dv, dj, ws, d_root, d_pose, d_shape, d_trans, d_scale);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,103 @@
+"""Training loss of the graph model as plain torch ops on the GPU (host-side mirror of core/Loss.py).
+
+SURVEY.md 8a row a15 / 8f-2: the loss sits right after the hot path; its FLOPs are negligible, so round 1 keeps it
+as PyTorch elementwise ops (fusing it into HIP kernels is the "next" row).  Semantics follow
+core/Loss.py:20-164 (GraphLoss) and :201-277 (calc_loss_GCN): SmoothL1 on 3-D vertices and regressed joints,
+MSE on normalised 2-D vertices, face-normal and edge-length terms, the same at the coarse (252-vertex) level, aux
+(hms/mask/dense) loss disabled, edge term gated by epoch >= NORM_EPOCH, right hand shifted by root_rel.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+NEW_ORDER = [0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20]
+TIPS = [745, 317, 444, 556, 673]
+
+DEFAULT_WEIGHTS = {'LABEL_3D': 100.0, 'LABEL_2D': 50.0, 'NORMAL': 10.0, 'EDGE': 2000.0, 'NORM_EPOCH': 50,
+                   'UPSAMPLE': 1.0}
+
+
+def joint_regressor_21(J_regressor):
+    """core/Loss.py:38-53: 16 MANO joints + 5 one-hot finger tips, reordered to the 21-joint convention."""
+    tips = torch.zeros((5, J_regressor.shape[1]), dtype=J_regressor.dtype, device=J_regressor.device)
+    for i, v in enumerate(TIPS):
+        tips[i, v] = 1.0
+    return torch.cat([J_regressor, tips], 0)[NEW_ORDER].contiguous()
+
+
+class GraphLoss:
+    def __init__(self, J_regressor, faces, level=4, device='cuda', upsample_weight=None):
+        self.device = device
+        self.level = level + 1
+        self.J_regressor = joint_regressor_21(J_regressor.clone().detach().float()).to(device)
+        self.faces = torch.from_numpy(np.asarray(faces).astype(np.int64)).to(device)
+        self.upsample_weight = None if upsample_weight is None else upsample_weight.to(device)
+
+    @staticmethod
+    def _edges(v, faces):
+        t = v[:, faces]                                             # B x F x 3 x 3
+        return torch.stack([t[:, :, 0] - t[:, :, 1], t[:, :, 1] - t[:, :, 2], t[:, :, 2] - t[:, :, 0]], dim=2)
+
+    def norm_loss(self, pred, gt):
+        eg, ep = self._edges(gt, self.faces), self._edges(pred, self.faces)
+        n = F.normalize(torch.cross(eg[:, :, 0], eg[:, :, 1], dim=-1), dim=-1).unsqueeze(2)
+        d = torch.sum(F.normalize(ep, dim=-1) * n, dim=-1)
+        return F.smooth_l1_loss(d, torch.zeros_like(d))
+
+    def edge_loss(self, pred, gt):
+        lg = torch.linalg.norm(self._edges(gt, self.faces), dim=-1)
+        lp = torch.linalg.norm(self._edges(pred, self.faces), dim=-1)
+        return F.smooth_l1_loss(lp, lg)
+
+    def calc_mano_loss(self, v3d_pred, v2d_pred, v3d_gt, v2d_gt, img_size):
+        return {'vert2d_loss': F.mse_loss(v2d_pred / img_size * 2 - 1, v2d_gt / img_size * 2 - 1),
+                'vert3d_loss': F.smooth_l1_loss(v3d_pred, v3d_gt),
+                'joint_loss': F.smooth_l1_loss(torch.matmul(self.J_regressor, v3d_pred),
+                                               torch.matmul(self.J_regressor, v3d_gt)),
+                'norm_loss': self.norm_loss(v3d_pred, v3d_gt),
+                'edge_loss': self.edge_loss(v3d_pred, v3d_gt)}
+
+    @staticmethod
+    def _down(x, p=2):
+        B, V, D = x.shape
+        return x.view(B, V // p, p, D).mean(2)                      # AvgPool1d(p) along V
+
+    def calc_loss(self, converter, v3d_gt, v2d_gt, v3d_pred, v2d_pred, v3dList, v2dList, img_size):
+        mano = self.calc_mano_loss(v3d_pred, v2d_pred, v3d_gt, v2d_gt, img_size)
+        g3, g2 = converter.vert_to_GCN(v3d_gt), converter.vert_to_GCN(v2d_gt)
+        l3, l2 = [], []
+        for _ in range(self.level):
+            l3.append(g3)
+            l2.append(g2)
+            g3, g2 = self._down(g3), self._down(g2)
+        coarse = {'v3d_loss': [], 'v2d_loss': []}
+        for p3, p2 in zip(v3dList, v2dList):
+            j = [t.shape[1] for t in l3].index(p3.shape[1])
+            coarse['v3d_loss'].append(F.smooth_l1_loss(p3, l3[j]))
+            coarse['v2d_loss'].append(F.mse_loss(p2 / img_size * 2 - 1, l2[j] / img_size * 2 - 1))
+        return mano, coarse
+
+
+def calc_loss_GCN(weights, epoch, loss_left, loss_right, converter_left, converter_right, result, paramsDict,
+                  handDictList, otherInfo, v2d_l, v2d_r, v3d_l, v3d_r, root_rel, img_size=256, upsample_weight=None):
+    """core/Loss.py:201-277 (aux loss disabled there, :211)."""
+    w = dict(DEFAULT_WEIGHTS)
+    w.update(weights or {})
+    v3d_r = v3d_r + root_rel.unsqueeze(1)
+    out = {}
+    for side, gl, conv, v3, v2 in (('left', loss_left, converter_left, v3d_l, v2d_l),
+                                   ('right', loss_right, converter_right, v3d_r, v2d_r)):
+        out[side] = gl.calc_loss(conv, v3, v2, result['verts3d'][side], result['verts2d'][side],
+                                 [h['verts3d'][side] for h in handDictList],
+                                 [h['verts2d'][side] for h in handDictList], img_size)
+    mano = {k: (out['left'][0][k] + out['right'][0][k]) / 2 for k in out['left'][0]}
+    alpha = 0 if epoch < w['NORM_EPOCH'] else 1
+    total = w['LABEL_3D'] * mano['vert3d_loss'] + w['LABEL_2D'] * mano['vert2d_loss'] + \
+        w['LABEL_3D'] * mano['joint_loss'] + w['NORMAL'] * mano['norm_loss'] + alpha * w['EDGE'] * mano['edge_loss']
+    for i in range(len(out['left'][1]['v3d_loss'])):
+        total = total + w['LABEL_3D'] * (out['left'][1]['v3d_loss'][i] + out['right'][1]['v3d_loss'][i]) / 2 \
+            + w['LABEL_2D'] * (out['left'][1]['v2d_loss'][i] + out['right'][1]['v2d_loss'][i]) / 2
+    if upsample_weight is not None and loss_left.upsample_weight is not None:
+        total = total + w['UPSAMPLE'] * F.smooth_l1_loss(upsample_weight - loss_left.upsample_weight,
+                                                         torch.zeros_like(upsample_weight))
+    return total, mano

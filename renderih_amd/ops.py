@@ -54,6 +54,10 @@ def pick_tile(M, N, batch=1):
 
 _TILE_MN = {0: (128, 128), 1: (128, 64), 2: (64, 64)}
 
+# When set to a list, every rih_gemm launch is bracketed by HIP events on the launch stream and
+# (flops, start, end, tag) is appended -- bench.py uses this for the live roofline measurement.
+PROFILE = None
+
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=None, ldr=0,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, kchunk=0, sCsplit=0, alpha=1.0, relu=False,
@@ -80,6 +84,13 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
         geom = (1, 1, cin, 1, 1, 1, 1, 1, 1, 0, 0)
     (d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.strideA, d.upS, d.padH, d.padW) = geom
     d.tile = pick_tile(M, N, nb1 * nb2 * splitk) if tile is None else tile
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_L().rih_gemm(C.byref(d), _stream()), 'rih_gemm')
+        e1.record()
+        PROFILE.append((2.0 * M * N * K * nb1 * nb2, e0, e1, (M, N, K, nb1 * nb2, a_mode, b_mode, d.tile, splitk)))
+        return
     check(_L().rih_gemm(C.byref(d), _stream()), 'rih_gemm')
 
 

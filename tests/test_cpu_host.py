@@ -1,0 +1,106 @@
+"""CPU-side checks: C ABI surface, state_dict schema, config shim, asset loading, drop-in import paths."""
+import json
+import os
+import re
+import subprocess
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+def test_library_exports_every_declared_symbol():
+    from renderih_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'renderih_amd.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(rih_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.SIGNATURES.keys())
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.lib_path()], capture_output=True, text=True).stdout
+    exported = set(re.findall(r' T (rih_[a-z0-9_]+)', out))
+    assert declared <= exported, declared - exported
+    assert lib.rih_version() >= 1 and lib.rih_arch() == b'gfx950'
+
+
+def test_gemm_desc_layout_matches_c():
+    """ctypes mirror of rih_gemm_desc must have the C compiler's layout (checked with a tiny C program)."""
+    from renderih_amd._lib import GemmDesc
+    import ctypes
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "renderih_amd.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",' \
+          'sizeof(rih_gemm_desc),offsetof(rih_gemm_desc,sA1),offsetof(rih_gemm_desc,sCsplit),' \
+          'offsetof(rih_gemm_desc,alpha),offsetof(rih_gemm_desc,tile));return 0;}'
+    import tempfile
+    d = tempfile.mkdtemp()
+    open(os.path.join(d, 'a.c'), 'w').write(src)
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), os.path.join(d, 'a.c'), '-o', os.path.join(d, 'a')])
+    got = [int(x) for x in subprocess.check_output([os.path.join(d, 'a')]).split()]
+    assert got == [ctypes.sizeof(GemmDesc), GemmDesc.sA1.offset, GemmDesc.sCsplit.offset, GemmDesc.alpha.offset,
+                   GemmDesc.tile.offset]
+
+
+def test_ops_refuse_cpu_tensors():
+    from renderih_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.relu(torch.zeros(4))
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.zeros(2, 4), torch.zeros(3, 4))
+
+
+def test_state_dict_schema_equals_reference():
+    from renderih_amd.model import build_model
+    ref = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'state_keys.json')))
+    sd = build_model(0.05).state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    assert {k: list(v.shape) for k, v in sd.items()} == ref
+
+
+def test_dropin_import_paths_and_config(tmp_path):
+    import models.model as mm
+    import models.manolayer as ml
+    from renderih_amd.config import load_cfg
+    assert mm.Model is mm.HandNET_GCN and callable(mm.load_model)
+    assert hasattr(ml, 'ManoLayer') and hasattr(ml, 'rodrigues_batch')
+    y = tmp_path / 'c.yaml'
+    y.write_text('MODEL:\n  ENCODER_TYPE: resnet50\nTRAIN:\n  dropout: 0.0\nEXTRA:\n  k: 1\n')
+    cfg = load_cfg(str(y))
+    assert cfg.TRAIN.dropout == 0.0 and cfg.MODEL.GCN_IN_DIM == [512, 256, 128] and cfg.EXTRA.k == 1
+    m = mm.load_model(str(y))
+    assert m.decoder.dropout_p == 0.0
+    assert m.decoder.unsample_layer.weight.shape == (778, 252)
+    assert tuple(m.decoder.get_upsample_weight().shape) == (778, 252)
+    v = torch.arange(778 * 3, dtype=torch.float32).view(1, 778, 3)
+    conv = m.decoder.converter['left']
+    g = conv.vert_to_GCN(v)
+    assert g.shape == (1, 1008, 3)
+    assert torch.equal(conv.GCN_to_vert(g), v)           # the permutation round-trips real vertices
+
+
+def test_graph_assets_match_reference_statistics():
+    """Laplacians 1008/504/252/126/63 with nnz 5638/2994/1572/842/423."""
+    from renderih_amd import assets
+    for side in ('left', 'right'):
+        g = assets.load_graph_dict(side)
+        assert [L.shape[0] for L in g['coarsen_graphs_L']] == [1008, 504, 252, 126, 63]
+        if side == 'left':
+            assert [L.nnz for L in g['coarsen_graphs_L']] == [5638, 2994, 1572, 842, 423]
+        assert len(g['graph_perm']) == 1008 and len(g['graph_perm_reverse']) == 1008
+        assert g['mesh_faces'].shape == (1538, 3)
+
+
+def test_mano_helpers_cpu_roundtrip(tmp_path):
+    """Host-side helpers (not the HIP path): axis<->pca and Rmat2axis round trips."""
+    from renderih_amd import assets
+    from renderih_amd.manolayer import ManoLayer, rodrigues_batch
+    layer = ManoLayer(assets.synthetic_mano_dict('right'))
+    g = torch.Generator().manual_seed(1)
+    axis = torch.randn(4, 45, generator=g) * 0.5
+    assert torch.allclose(layer.pca2axis(layer.axis2pca(axis)), axis, atol=1e-4)
+    R = layer.axis2Rmat(axis)
+    assert torch.allclose(layer.Rmat2axis(R), axis, atol=1e-3)
+    fr = layer.get_local_frame(torch.zeros(2, 10))
+    assert fr.shape == (2, 15, 3, 3)
+    assert torch.allclose(rodrigues_batch(torch.zeros(1, 3)), torch.eye(3).unsqueeze(0), atol=1e-6)

@@ -1,0 +1,95 @@
+"""GPU parity of the fused MANO LBS kernels against the reference-generated golden vectors and the CPU oracle."""
+import os
+import numpy as np
+import pytest
+import torch
+
+from renderih_amd import assets
+from renderih_amd.testing import assert_close
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _layer(side, center, use_pca, new_skel):
+    from renderih_amd.manolayer import ManoLayer
+    return ManoLayer(assets.synthetic_mano_dict(side, seed=0), center_idx=center, use_pca=use_pca,
+                     new_skel=new_skel).cuda()
+
+
+@pytest.mark.parametrize('side', ['right', 'left'])
+def test_mano_matches_reference_golden(side):
+    z = np.load(os.path.join(GOLDEN, 'mano.npz'))
+    names = sorted({k.split('/')[2] for k in z.files if k.startswith('mano/%s/' % side)})
+    assert len(names) >= 8
+    for name in names:
+        key = 'mano/%s/%s/' % (side, name)
+        g = lambda n: torch.from_numpy(z[key + n]).cuda().requires_grad_(True) if (key + n) in z.files else None
+        root, pose, shape, trans, scale = g('root'), g('pose'), g('shape'), g('trans'), g('scale')
+        center = int(z[key + 'meta_center'])
+        layer = _layer(side, None if center < 0 else center, int(z[key + 'meta_ncomp']) > 0,
+                       bool(z[key + 'meta_new_skel']))
+        v, j = layer(root, pose, shape, trans=trans, scale=scale)
+        assert_close(v, torch.from_numpy(z[key + 'v']), 1e-4, 1e-5, key + 'v')
+        assert_close(j, torch.from_numpy(z[key + 'j']), 1e-4, 1e-5, key + 'j')
+        ((v * torch.from_numpy(z[key + 'wv']).cuda()).sum() + (j * torch.from_numpy(z[key + 'wj']).cuda()).sum()).backward()
+        for nm, t in (('root', root), ('pose', pose), ('shape', shape), ('trans', trans), ('scale', scale)):
+            if t is not None:
+                assert_close(t.grad, torch.from_numpy(z[key + 'grad_' + nm]), 1e-3, 1e-4, key + 'grad_' + nm)
+
+
+@pytest.mark.parametrize('B', [1, 2, 64, 257])
+def test_mano_matches_oracle(B):
+    from oracle import mano_oracle
+    from renderih_amd.manolayer import rodrigues_batch
+    d = assets.synthetic_mano_dict('right', seed=0)
+    c = mano_oracle.constants_from_dict(d)
+    layer = _layer('right', 9, True, False)
+    g = torch.Generator().manual_seed(B)
+    root = rodrigues_batch(torch.randn(B, 3, generator=g))
+    pose, shape = torch.randn(B, 45, generator=g) * 0.7, torch.randn(B, 10, generator=g)
+    trans, scale = torch.randn(B, 3, generator=g) * 0.1, torch.rand(B, generator=g) + 0.5
+    ins = [t.clone().requires_grad_(True) for t in (root, pose, shape, trans, scale)]
+    vr, jr = mano_oracle.mano_forward(c, *ins)
+    wv, wj = torch.randn(vr.shape, generator=g), torch.randn(jr.shape, generator=g)
+    ((vr * wv).sum() + (jr * wj).sum()).backward()
+    gin = [t.clone().cuda().requires_grad_(True) for t in (root, pose, shape, trans, scale)]
+    v, j = layer(gin[0], gin[1], gin[2], trans=gin[3], scale=gin[4])
+    assert_close(v, vr, 1e-4, 1e-5, 'v')
+    assert_close(j, jr, 1e-4, 1e-5, 'j')
+    ((v * wv.cuda()).sum() + (j * wj.cuda()).sum()).backward()
+    for nm, a, b in zip(('root', 'pose', 'shape', 'trans', 'scale'), gin, ins):
+        assert_close(a.grad, b.grad, 1e-3, 1e-4, 'grad ' + nm)
+
+
+def test_mano_properties_large_batch():
+    """B=4096 (micro-benchmark size): size-independent properties -- translation equivariance, scale homogeneity,
+    batch independence -- instead of an oracle run."""
+    from renderih_amd.manolayer import rodrigues_batch
+    layer = _layer('right', 9, True, False)
+    B = 4096
+    g = torch.Generator().manual_seed(0)
+    root = rodrigues_batch(torch.randn(B, 3, generator=g)).cuda()
+    pose, shape = (torch.randn(B, 45, generator=g) * 0.7).cuda(), torch.randn(B, 10, generator=g).cuda()
+    t = (torch.randn(B, 3, generator=g) * 0.1).cuda()
+    v0, j0 = layer(root, pose, shape)
+    v1, j1 = layer(root, pose, shape, trans=t)
+    assert_close(v1 - t.unsqueeze(1), v0, 1e-4, 1e-5, 'translation equivariance')
+    s = (torch.rand(B, generator=g) + 0.5).cuda()
+    v2, j2 = layer(root, pose, shape, scale=s)
+    assert_close(v2, v0 * s.view(-1, 1, 1), 1e-4, 1e-5, 'scale homogeneity')
+    v3, j3 = layer(root[100:103], pose[100:103], shape[100:103])
+    assert_close(v3, v0[100:103], 1e-5, 1e-6, 'batch independence')
+    assert float(j0[:, 9].abs().max()) < 1e-6          # centred on joint 9
+
+
+def test_mano_reads_mutated_shapedirs():
+    """Callers flip shapedirs in place after construction (dataset/interhand.py:22-25); forward must see it."""
+    from renderih_amd.manolayer import rodrigues_batch
+    layer = _layer('left', 9, True, False)
+    root = rodrigues_batch(torch.zeros(2, 3)).cuda()
+    pose, shape = torch.zeros(2, 45).cuda(), torch.ones(2, 10).cuda()
+    a, _ = layer(root, pose, shape)
+    layer.shapedirs[:, 0, :] *= -1
+    b, _ = layer(root, pose, shape)
+    assert float((a - b).abs().max()) > 1e-4

@@ -1,0 +1,350 @@
+"""GPU parity tests of each HIP operator against plain PyTorch fp32 (CPU) of the same op -- forward and backward.
+Tolerance (fp32 bar of BASELINE.json): |a-b| <= 1e-4*|b| + 1e-5*max|b| for outputs, 1e-3 / 1e-4 for gradients."""
+import math
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from renderih_amd.testing import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return torch.device('cuda:0')
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, bias, relu
+    (2, 16, 16, 64, 64, 1, 1, 0, False, False),
+    (2, 16, 16, 64, 128, 3, 1, 1, False, False),
+    (2, 16, 16, 128, 128, 3, 2, 1, False, False),
+    (3, 17, 15, 32, 48, 3, 1, 1, False, True),
+    (2, 16, 16, 256, 512, 1, 2, 0, False, False),
+    (2, 32, 32, 3, 64, 7, 2, 3, False, False),
+    (2, 16, 16, 256, 128, 2, 2, 0, True, True),
+    (2, 32, 32, 256, 64, 4, 4, 0, True, True),
+    (2, 8, 8, 128, 42, 1, 1, 0, True, False),
+    (2, 8, 8, 128, 8, 1, 1, 0, True, False),
+    (5, 9, 9, 72, 200, 3, 1, 1, False, False),
+    (1, 64, 64, 64, 256, 1, 1, 0, False, True),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d(case):
+    from renderih_amd import ops
+    N, H, W, Cin, Cout, k, s, p, bias, relu = case
+    x = rnd(N, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=1.0 / math.sqrt(Cin * k * k))
+    b = rnd(Cout, seed=3) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, stride=s, padding=p)
+    if relu:
+        yr = F.relu(yr)
+    gy = rnd(*yr.shape, seed=4)
+    yr.backward(gy)
+
+    d = dev()
+    cpad = 4 if Cin == 3 else Cin
+    xg = torch.zeros(N, H, W, cpad)
+    xg[..., :Cin] = nhwc(x)
+    xg = xg.to(d).requires_grad_(Cin != 3)
+    wg = w.to(d).requires_grad_(True)
+    bg = b.to(d).requires_grad_(True) if bias else None
+    yg = ops.conv2d(xg, wg, bg, stride=s, pad=p, relu=relu)
+    assert_close(nchw(yg), yr, what='conv y %s' % (case,))
+    yg.backward(nhwc(gy).to(d))
+    assert_close(wg.grad, wr.grad, 1e-3, 1e-4, 'conv dw %s' % (case,))
+    if Cin != 3:
+        assert_close(nchw(xg.grad), xr.grad, 1e-3, 1e-4, 'conv dx %s' % (case,))
+    if bias:
+        assert_close(bg.grad, br.grad, 1e-3, 1e-4, 'conv db %s' % (case,))
+
+
+LIN_CASES = [(126, 512, 256, True, False, False), (126, 2048, 509, True, False, False), (100, 64, 3, True, False, False),
+             (128, 252, 1, True, False, False), (6, 252, 778, False, False, False), (4032, 128, 128, True, True, True),
+             (300, 256, 256, True, False, True), (8064, 64, 64, True, True, False)]
+
+
+@pytest.mark.parametrize('case', LIN_CASES)
+def test_linear(case):
+    from renderih_amd import ops
+    M, K, N, bias, relu, res = case
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K))
+    b = rnd(N, seed=3) if bias else None
+    r = rnd(M, N, seed=5) if res else None
+    ts = [t.clone().requires_grad_(True) if t is not None else None for t in (x, w, b, r)]
+    yr = F.linear(ts[0], ts[1], ts[2])
+    if res:
+        yr = yr + ts[3]
+    if relu:
+        yr = F.relu(yr)
+    gy = rnd(M, N, seed=4)
+    yr.backward(gy)
+    d = dev()
+    tg = [t.to(d).requires_grad_(True) if t is not None else None for t in (x, w, b, r)]
+    yg = ops.linear(tg[0], tg[1], tg[2], residual=tg[3], relu=relu)
+    assert_close(yg, yr, what='linear y %s' % (case,))
+    yg.backward(gy.to(d))
+    for name, a, bb in zip(('dx', 'dw', 'db', 'dres'), tg, ts):
+        if a is not None:
+            assert_close(a.grad, bb.grad, 1e-3, 1e-4, 'linear %s %s' % (name, case))
+
+
+@pytest.mark.parametrize('training', [True, False])
+@pytest.mark.parametrize('relu,res', [(True, True), (True, False), (False, False)])
+@pytest.mark.parametrize('shape', [(2, 16, 16, 64), (3, 7, 9, 256), (2, 4, 4, 2048), (1, 64, 64, 128)])
+def test_batchnorm(training, relu, res, shape):
+    from renderih_amd import ops
+    N, H, W, Cc = shape
+    x = rnd(N, Cc, H, W, seed=1) * 2 + 0.5
+    r = rnd(N, Cc, H, W, seed=2) if res else None
+    g, b = torch.rand(Cc) + 0.5, rnd(Cc, seed=3) * 0.1
+    rm, rv = rnd(Cc, seed=4) * 0.1, torch.rand(Cc) + 0.5
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    rm_r, rv_r = rm.clone(), rv.clone()
+    yr = F.batch_norm(xr, rm_r, rv_r, gr, br, training, 0.1, 1e-5)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    gy = rnd(*yr.shape, seed=5)
+    yr.backward(gy)
+    d = dev()
+    xg = nhwc(x).to(d).requires_grad_(True)
+    gg, bg = g.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+    rg = nhwc(r).to(d).requires_grad_(True) if res else None
+    rm_g, rv_g = rm.to(d), rv.to(d)
+    yg = ops.batchnorm(xg, gg, bg, rm_g, rv_g, residual=rg, training=training, relu=relu)
+    assert_close(nchw(yg), yr, what='bn y')
+    yg.backward(nhwc(gy).to(d))
+    assert_close(nchw(xg.grad), xr.grad, 1e-3, 1e-4, 'bn dx')
+    assert_close(gg.grad, gr.grad, 1e-3, 1e-4, 'bn dgamma')
+    assert_close(bg.grad, br.grad, 1e-3, 1e-4, 'bn dbeta')
+    if res:
+        assert_close(nchw(rg.grad), rr.grad, 1e-3, 1e-4, 'bn dres')
+    assert_close(rm_g, rm_r, 1e-4, 1e-5, 'bn running_mean')
+    assert_close(rv_g, rv_r, 1e-4, 1e-5, 'bn running_var')
+
+
+@pytest.mark.parametrize('rows,D,x2,relu', [(126, 64, False, False), (4, 509, False, False), (300, 256, True, True),
+                                             (1000, 128, True, False), (64, 512, False, True)])
+def test_layernorm(rows, D, x2, relu):
+    from renderih_amd import ops
+    x, y2 = rnd(rows, D, seed=1) * 2 + 0.3, (rnd(rows, D, seed=2) if x2 else None)
+    g, b = torch.rand(D) + 0.5, rnd(D, seed=3) * 0.1
+    ts = [t.clone().requires_grad_(True) if t is not None else None for t in (x, y2, g, b)]
+    inp = ts[0] + ts[1] if x2 else ts[0]
+    yr = F.layer_norm(inp, (D,), ts[2], ts[3], 1e-6)
+    if relu:
+        yr = F.relu(yr)
+    gy = rnd(rows, D, seed=4)
+    yr.backward(gy)
+    d = dev()
+    tg = [t.to(d).requires_grad_(True) if t is not None else None for t in (x, y2, g, b)]
+    yg = ops.layernorm(tg[0], tg[2], tg[3], eps=1e-6, x2=tg[1], relu=relu)
+    assert_close(yg, yr, what='ln y')
+    yg.backward(gy.to(d))
+    for name, a, bb in zip(('dx', 'dx2', 'dg', 'db'), tg, ts):
+        if a is not None:
+            assert_close(a.grad, bb.grad, 1e-3, 1e-4, 'ln ' + name)
+
+
+def _mha_ref(q, k, v, h):
+    B, Sq, D = q.shape
+    d = D // h
+    qq = q.view(B, Sq, h, d).transpose(1, 2)
+    kk = k.view(B, -1, h, d).transpose(1, 2)
+    vv = v.view(B, -1, h, d).transpose(1, 2)
+    a = torch.softmax(qq @ kk.transpose(-1, -2) / d ** 0.5, -1)
+    return (a @ vv).transpose(1, 2).contiguous().view(B, Sq, D), a
+
+
+@pytest.mark.parametrize('B,Sq,Sk,D,h', [(2, 64, 64, 256, 4), (2, 127, 127, 256, 4), (2, 190, 190, 128, 4),
+                                          (3, 316, 316, 64, 4), (2, 63, 63, 256, 4), (2, 126, 252, 128, 4)])
+def test_attention(B, Sq, Sk, D, h):
+    from renderih_amd import ops
+    q, k, v = rnd(B, Sq, D, seed=1), rnd(B, Sk, D, seed=2), rnd(B, Sk, D, seed=3)
+    ts = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    yr, _ = _mha_ref(*ts, h)
+    gy = rnd(B, Sq, D, seed=4)
+    yr.backward(gy)
+    d = dev()
+    tg = [t.to(d).requires_grad_(True) for t in (q, k, v)]
+    yg = ops.attention(tg[0], tg[1], tg[2], h)
+    assert_close(yg, yr, what='attn out')
+    yg.backward(gy.to(d))
+    for name, a, bb in zip(('dq', 'dk', 'dv'), tg, ts):
+        assert_close(a.grad, bb.grad, 1e-3, 1e-4, 'attn ' + name)
+
+
+def _hash_np(seed, idx):
+    """numpy mirror of rih_hash (csrc/rih_elem.hip)."""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    x = (idx.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)) & M
+    for _ in range(2):
+        x ^= x >> np.uint64(32)
+        x = (x * np.uint64(0xD6E8FEB86659FD93)) & M
+    x ^= x >> np.uint64(32)
+    return (x & np.uint64(0xFFFFFFFF)).astype(np.uint64)
+
+
+def test_attention_dropout_matches_hash_mask():
+    from renderih_amd import ops
+    B, S, D, h, p, seed = 2, 100, 64, 4, 0.25, 123456789
+    q, k, v = rnd(B, S, D, seed=1), rnd(B, S, D, seed=2), rnd(B, S, D, seed=3)
+    with np.errstate(over='ignore'):
+        keep = _hash_np(seed, np.arange(B * h * S * S)) >= np.uint64(int(p * 2 ** 32))
+    keep = torch.from_numpy(keep.reshape(B, h, S, S))
+    assert abs(keep.float().mean().item() - (1 - p)) < 0.01
+    ts = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    _, a = _mha_ref(*ts, h)
+    a = a * keep / (1 - p)
+    vv = ts[2].view(B, S, h, D // h).transpose(1, 2)
+    yr = (a @ vv).transpose(1, 2).contiguous().view(B, S, D)
+    gy = rnd(B, S, D, seed=4)
+    yr.backward(gy)
+    d = dev()
+    tg = [t.to(d).requires_grad_(True) for t in (q, k, v)]
+    yg = ops.attention(tg[0], tg[1], tg[2], h, p, seed)
+    assert_close(yg, yr, what='attn+dropout out')
+    yg.backward(gy.to(d))
+    for name, a_, bb in zip(('dq', 'dk', 'dv'), tg, ts):
+        assert_close(a_.grad, bb.grad, 1e-3, 1e-4, 'attn+dropout ' + name)
+
+
+def test_add_dropout_and_bcast():
+    from renderih_amd import ops
+    d = dev()
+    a, b = rnd(4, 63, 128, seed=1), rnd(4, 63, 128, seed=2)
+    ag, bg = a.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+    y = ops.add_dropout(ag, bg, 0.0, 0)
+    assert_close(y, a + b, what='add')
+    p, seed = 0.3, 42
+    y = ops.add_dropout(ag, bg, p, seed)
+    with np.errstate(over='ignore'):
+        keep = torch.from_numpy((_hash_np(seed, np.arange(a.numel())) >= np.uint64(int(p * 2 ** 32))).reshape(a.shape))
+    assert_close(y, a + b * keep / (1 - p), what='add_dropout')
+    gy = rnd(*a.shape, seed=3)
+    y.backward(gy.to(d))
+    assert_close(ag.grad, gy, what='add_dropout da')
+    assert_close(bg.grad, gy * keep / (1 - p), what='add_dropout db')
+    e = rnd(63, 128, seed=5)
+    eg = e.to(d).requires_grad_(True)
+    ag.grad = None
+    y = ops.add_rows_bcast(ag, eg)
+    assert_close(y, a + e, what='bcast add')
+    y.backward(gy.to(d))
+    assert_close(eg.grad, gy.sum(0), 1e-4, 1e-5, 'bcast de')
+
+
+def test_pool_upsample_layout():
+    from renderih_amd import ops
+    d = dev()
+    x = rnd(2, 64, 18, 18, seed=1)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    gy = rnd(*yr.shape, seed=2)
+    yr.backward(gy)
+    xg = nhwc(x).to(d).requires_grad_(True)
+    yg = ops.maxpool3x3s2(xg)
+    assert_close(nchw(yg), yr, what='maxpool')
+    yg.backward(nhwc(gy).to(d))
+    assert_close(nchw(xg.grad), xr.grad, what='maxpool dx')
+
+    for H in (8, 16, 5):
+        x = rnd(2, 128, H, H + 1, seed=3)
+        xr = x.clone().requires_grad_(True)
+        yr = F.interpolate(xr, scale_factor=2, mode='bilinear', align_corners=True)
+        gy = rnd(*yr.shape, seed=4)
+        yr.backward(gy)
+        xg = nhwc(x).to(d).requires_grad_(True)
+        yg = ops.upsample_bilinear2x(xg)
+        assert_close(nchw(yg), yr, what='upsample %d' % H)
+        yg.backward(nhwc(gy).to(d))
+        assert_close(nchw(xg.grad), xr.grad, 1e-4, 1e-5, 'upsample dx %d' % H)
+
+    x = rnd(3, 2048, 8, 8, seed=5)
+    xr = x.clone().requires_grad_(True)
+    yr = F.adaptive_avg_pool2d(xr, 1).flatten(1)
+    gy = rnd(3, 2048, seed=6)
+    yr.backward(gy)
+    xg = nhwc(x).to(d).requires_grad_(True)
+    yg = ops.global_avgpool(xg)
+    assert_close(yg, yr, what='avgpool')
+    yg.backward(gy.to(d))
+    assert_close(nchw(xg.grad), xr.grad, what='avgpool dx')
+
+    img = rnd(2, 3, 32, 32, seed=7)
+    y = ops.nchw_to_nhwc(img.to(d), cpad=4)
+    assert torch.equal(y[..., :3].cpu(), nhwc(img)) and float(y[..., 3].abs().max()) == 0.0
+    t = rnd(2, 16, 16, 8, seed=8)
+    tg = t.to(d).requires_grad_(True)
+    a, b = ops.nhwc_to_nchw(tg, 0, 2), ops.nhwc_to_nchw(tg, 2, 8)
+    assert torch.equal(a.cpu(), nchw(t)[:, :2]) and torch.equal(b.cpu(), nchw(t)[:, 2:])
+    (a.sum() + 2 * b.sum()).backward()
+    want = torch.ones_like(t)
+    want[..., 2:] = 2
+    assert torch.equal(tg.grad.cpu(), want)
+
+
+def test_cheby_gather_project():
+    from renderih_amd import ops, assets
+    from renderih_amd.attn import GraphCSR
+    d = dev()
+    L = assets.load_graph_dict('left')['coarsen_graphs_L'][3]      # 126 vertices
+    Ld = torch.from_numpy(np.asarray(L.todense(), dtype=np.float32))
+    csr, csr_t = GraphCSR(Ld.numpy()).on(d)
+    x = rnd(3, 126, 64, seed=1)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.stack((xr, torch.matmul(Ld, xr)), -1).flatten(-2)
+    gy = rnd(*yr.shape, seed=2)
+    yr.backward(gy)
+    xg = x.to(d).requires_grad_(True)
+    yg = ops.cheby_features(xg, csr, csr_t)
+    assert_close(yg, yr, what='cheby')
+    yg.backward(gy.to(d))
+    assert_close(xg.grad, xr.grad, 1e-4, 1e-5, 'cheby dx')
+
+    idx = np.random.RandomState(0).randint(0, 50, size=120)
+    g = ops.RowIndex(idx, 50, d)
+    x = rnd(2, 50, 3, seed=3)
+    xr = x.clone().requires_grad_(True)
+    yr = xr[:, torch.from_numpy(idx)]
+    gy = rnd(*yr.shape, seed=4)
+    yr.backward(gy)
+    xg = x.to(d).requires_grad_(True)
+    yg = g(xg)
+    assert torch.equal(yg.cpu(), yr.detach())
+    yg.backward(gy.to(d))
+    assert_close(xg.grad, xr.grad, 1e-5, 1e-6, 'gather dx')
+
+    v, s, t = rnd(4, 778, 3, seed=5) * 0.1, torch.rand(4) + 0.5, rnd(4, 2, seed=6) * 0.2
+    ts = [a.clone().requires_grad_(True) for a in (v, s, t)]
+    yr = (ts[1] * 256).view(-1, 1, 1) * ts[0][..., :2] + (ts[2] * 128 + 128).unsqueeze(1)
+    gy = rnd(4, 778, 2, seed=7)
+    yr.backward(gy)
+    tg = [a.to(d).requires_grad_(True) for a in (v, s, t)]
+    yg = ops.projection_batch(tg[1], tg[2], tg[0], 256)
+    assert_close(yg, yr, what='project')
+    yg.backward(gy.to(d))
+    for name, a, b in zip(('dv', 'dscale', 'dtrans'), tg, ts):
+        assert_close(a.grad, b.grad, 1e-4, 1e-5, 'project ' + name)
