@@ -72,6 +72,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='per-GPU batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--dump-gemm', default=None, help='write the per-launch GEMM profile of one step to this JSON file')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -149,6 +150,12 @@ def main():
             a[0] += 1
             a[1] += e0.elapsed_time(e1)
             a[2] += f
+        if args.dump_gemm:
+            rows = sorted(([round(e0.elapsed_time(e1) * 1000, 1), round(f / max(e0.elapsed_time(e1), 1e-6) / 1e9, 2)] + list(tag)
+                           for f, e0, e1, tag in recs), reverse=True)
+            with open(args.dump_gemm, 'w') as fh:
+                json.dump({'columns': ['us', 'launched_tflops', 'M', 'N', 'K', 'batch', 'a_mode', 'b_mode', 'tile', 'splitk'],
+                           'rows': rows, 'by_variant': by}, fh)
         top = max(by.items(), key=lambda kv: kv[1][1])
         achieved = GFLOP_PER_IMG_FWD_BWD * B / ms            # GFLOP / ms = TFLOP/s
         roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s',

@@ -267,3 +267,38 @@ def scalar_loss(outputs):
         s = s + params['scale'][side].sum() + params['trans2d'][side].pow(2).sum()
     s = s + 1e-3 * other['hms'].pow(2).sum() + 1e-3 * other['mask'].abs().sum() + 1e-3 * other['dense'].pow(2).sum()
     return s
+
+
+def run(sd, graph, img, training, dtype=torch.float32, with_grad=False):
+    """Convenience for tests: forward (and scalar-loss backward) at a chosen dtype.
+    Returns (flat outputs, {param name: grad}) with the flat names of renderih_amd.testing.flatten_outputs."""
+    s = {}
+    for k, v in sd.items():
+        t = v.detach().clone()
+        if t.is_floating_point():
+            t = t.to(dtype)
+            if with_grad and 'running' not in k and 'dense_coor' not in k:
+                t.requires_grad_(True)
+        s[k] = t
+    g = {h: {'L': [L.to(dtype) for L in graph[h]['L']], 'perm': graph[h]['perm'],
+             'perm_reverse': graph[h]['perm_reverse']} for h in graph}
+    with torch.set_grad_enabled(with_grad):
+        out = handnet_forward(s, g, img.to(dtype), training=training)
+    grads = {}
+    if with_grad:
+        scalar_loss(out).backward()
+        grads = {k: v.grad for k, v in s.items() if v.is_floating_point() and v.grad is not None}
+    result, params, hd, other = out
+    flat = {}
+    for side in ('left', 'right'):
+        flat['result.verts3d.' + side] = result['verts3d'][side]
+        flat['result.verts2d.' + side] = result['verts2d'][side]
+        flat['params.scale.' + side] = params['scale'][side]
+        flat['params.trans2d.' + side] = params['trans2d'][side]
+        flat['hand0.verts3d.' + side] = hd[0]['verts3d'][side]
+        flat['hand0.verts2d.' + side] = hd[0]['verts2d'][side]
+        flat['other.verts3d_MANO.' + side] = other['verts3d_MANO_list'][side][0]
+        flat['other.verts2d_MANO.' + side] = other['verts2d_MANO_list'][side][0]
+    for k in ('hms', 'mask', 'dense'):
+        flat['other.' + k] = other[k]
+    return {k: v.detach() for k, v in flat.items()}, grads

@@ -92,6 +92,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; it must be the HIP runtime already in the process when our
+    # library (same soname) is loaded, otherwise two runtimes disagree about the device (hipErrorNoDevice).
+    import torch  # noqa: F401
     path = _build.LIB
     if not os.path.exists(path) or _build.needs_build():
         try:

@@ -60,7 +60,7 @@ class GraphLoss:
     @staticmethod
     def _down(x, p=2):
         B, V, D = x.shape
-        return x.view(B, V // p, p, D).mean(2)                      # AvgPool1d(p) along V
+        return x[:, :V // p * p].reshape(B, V // p, p, D).mean(2)   # AvgPool1d(p) along V (floor, like torch)
 
     def calc_loss(self, converter, v3d_gt, v2d_gt, v3d_pred, v2d_pred, v3dList, v2dList, img_size):
         mano = self.calc_mano_loss(v3d_pred, v2d_pred, v3d_gt, v2d_gt, img_size)

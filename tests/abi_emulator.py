@@ -1,0 +1,408 @@
+"""Test infrastructure: a numpy/torch-CPU emulation of the C ABI (include/renderih_amd.h) on host memory.
+
+There is no GPU in the build container, so the host-side logic of `renderih_amd.ops` / the module tree (descriptor
+geometry, strides, packing, split-K, backward formulas wiring, dropout seeds) is exercised on CPU by swapping the
+loaded library for this object: every entry point is restated from the header's contract, reading and writing the
+caller's tensors through their raw pointers.  It is NOT a product fallback -- only tests install it
+(`with emulated_abi(): ...`), and the kernels themselves are still only proven by the `-m gpu` tests.
+"""
+import contextlib
+import ctypes as C
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _f(ptr, n):
+    return np.ctypeslib.as_array((C.c_float * int(n)).from_address(int(ptr)))
+
+
+def _i32(ptr, n):
+    return np.ctypeslib.as_array((C.c_int32 * int(n)).from_address(int(ptr)))
+
+
+def _i8(ptr, n):
+    return np.ctypeslib.as_array((C.c_int8 * int(n)).from_address(int(ptr)))
+
+
+def hash_np(seed, idx):
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over='ignore'):
+        x = (idx.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)) & M
+        for _ in range(2):
+            x ^= x >> np.uint64(32)
+            x = (x * np.uint64(0xD6E8FEB86659FD93)) & M
+        x ^= x >> np.uint64(32)
+    return x & np.uint64(0xFFFFFFFF)
+
+
+def keep_mask(seed, n, p):
+    if p <= 0:
+        return np.ones(n, np.float32)
+    thr = np.uint64(min(int(float(np.float32(p)) * 4294967296.0), 4294967295))
+    return (hash_np(seed, np.arange(n)) >= thr).astype(np.float32) / np.float32(1.0 - p)
+
+
+class EmulatedLib:
+    # ------------------------------------------------------------------ GEMM family
+    def _gather(self, base, idx, valid):
+        n = int(idx[valid].max()) + 1 if valid.any() else 1
+        mem = _f(base, n)
+        out = np.zeros(idx.shape, np.float32)
+        out[valid] = mem[idx[valid]]
+        return out
+
+    def rih_gemm(self, dref, stream):
+        d = dref._obj
+        M, N, K = d.M, d.N, d.K
+        taps = d.KH * d.KW
+        assert d.splitk >= 1 and (taps == 1 or d.Cin % 4 == 0)
+        for b1 in range(d.nb1):
+            for b2 in range(d.nb2):
+                Ab = d.A + 4 * (b1 * d.sA1 + b2 * d.sA2)
+                Bb = d.B + 4 * (b1 * d.sB1 + b2 * d.sB2)
+                Cb = d.C + 4 * (b1 * d.sC1 + b2 * d.sC2)
+                if d.a_mode == 0:
+                    m = np.arange(M)
+                    wo, t = m % d.Wo, m // d.Wo
+                    ho, img = t % d.Ho, t // d.Ho
+                    k = np.arange(K)
+                    tap, ci = k // d.Cin, k % d.Cin
+                    kh, kw = tap // d.KW, tap % d.KW
+                    hi = (ho * d.strideA - d.padH)[:, None] + kh[None, :]
+                    wi = (wo * d.strideA - d.padW)[:, None] + kw[None, :]
+                    valid = (hi >= 0) & (wi >= 0) & (hi % d.upS == 0) & (wi % d.upS == 0) & (tap < taps)[None, :]
+                    hi, wi = hi // d.upS, wi // d.upS
+                    valid &= (hi < d.H) & (wi < d.W)
+                    idx = ((img[:, None] * d.H + hi) * d.W + wi) * d.lda + ci[None, :]
+                else:
+                    m = np.arange(M)
+                    tap, ci = m // d.Cin, m % d.Cin
+                    kh, kw = tap // d.KW, tap % d.KW
+                    k = np.arange(K)
+                    wo, t = k % d.Wo, k // d.Wo
+                    ho, img = t % d.Ho, t // d.Ho
+                    hi = (ho * d.strideA - d.padH)[None, :] + kh[:, None]
+                    wi = (wo * d.strideA - d.padW)[None, :] + kw[:, None]
+                    valid = (hi >= 0) & (wi >= 0) & (hi < d.H) & (wi < d.W) & (tap < taps)[:, None]
+                    idx = ((img[None, :] * d.H + hi) * d.W + wi) * d.lda + ci[:, None]
+                idx = np.where(valid, idx, 0)
+                A = self._gather(Ab, idx, valid)
+                kk, nn = np.meshgrid(np.arange(K), np.arange(N), indexing='ij')
+                bidx = kk * d.ldb + nn if d.b_mode == 0 else nn * d.ldb + kk
+                Bm = self._gather(Bb, bidx, np.ones_like(bidx, bool)) if K > 0 else np.zeros((0, N), np.float32)
+                cm, cn = np.meshgrid(np.arange(M), np.arange(N), indexing='ij')
+                if d.splitk > 1:
+                    assert d.kchunk % 32 == 0
+                    for s in range(d.splitk):
+                        k0, k1 = s * d.kchunk, min(K, (s + 1) * d.kchunk)
+                        part = A[:, k0:k1] @ Bm[k0:k1]
+                        mem = _f(Cb + 4 * s * d.sCsplit, (M - 1) * d.ldc + N)
+                        mem[(cm * d.ldc + cn).ravel()] = part.ravel()
+                    continue
+                out = np.float32(d.alpha) * (A @ Bm)
+                if d.bias:
+                    out = out + _f(d.bias, N)[None, :]
+                if d.R:
+                    r = _f(d.R + 4 * 0, (M - 1) * d.ldr + N)
+                    out = out + r[(cm * d.ldr + cn).ravel()].reshape(M, N)
+                if d.relu:
+                    out = np.maximum(out, 0)
+                mem = _f(Cb, (M - 1) * d.ldc + N)
+                mem[(cm * d.ldc + cn).ravel()] = out.astype(np.float32).ravel()
+        return 0
+
+    def rih_splitk_reduce(self, P, S, M, N, dst, Cin, taps, CinValid, accumulate, stream):
+        p = _f(P, S * M * N).reshape(S, M, N).sum(0)
+        out = _f(dst, N * CinValid * taps)
+        m = np.arange(M)
+        tap, ci = m // Cin, m % Cin
+        ok = ci < CinValid
+        for n in range(N):
+            o = (n * CinValid + ci[ok]) * taps + tap[ok]
+            out[o] = (out[o] if accumulate else 0) + p[ok, n]
+        return 0
+
+    def rih_pack_conv_weight(self, w, dst, Cout, Cin, KH, KW, CinPad, for_dgrad, stream):
+        W = _f(w, Cout * Cin * KH * KW).reshape(Cout, Cin, KH * KW)
+        Wp = np.zeros((Cout, CinPad, KH * KW), np.float32)
+        Wp[:, :Cin] = W
+        if not for_dgrad:
+            out = Wp.transpose(2, 1, 0)                       # [tap][ci][co]
+        else:
+            out = Wp[:, :, ::-1].transpose(2, 0, 1)           # [tap'][co][ci]
+        _f(dst, out.size)[:] = np.ascontiguousarray(out).ravel()
+        return 0
+
+    # ------------------------------------------------------------------ layout / pooling
+    def rih_nchw_to_nhwc(self, x, y, N, Cc, H, W, Cpad, stream):
+        X = _f(x, N * Cc * H * W).reshape(N, Cc, H, W)
+        Y = np.zeros((N, H, W, Cpad), np.float32)
+        Y[..., :Cc] = X.transpose(0, 2, 3, 1)
+        _f(y, Y.size)[:] = Y.ravel()
+        return 0
+
+    def rih_nhwc_to_nchw(self, x, y, N, Cc, H, W, ldx, stream):
+        X = _f(x, (N * H * W - 1) * ldx + Cc)
+        idx = (np.arange(N * H * W)[:, None] * ldx + np.arange(Cc)[None, :])
+        _f(y, N * Cc * H * W)[:] = X[idx].reshape(N, H, W, Cc).transpose(0, 3, 1, 2).ravel()
+        return 0
+
+    def rih_maxpool3x3s2_fwd(self, x, y, arg, N, H, W, Cc, stream):
+        X = torch.from_numpy(_f(x, N * H * W * Cc).reshape(N, H, W, Cc).copy()).permute(0, 3, 1, 2)
+        Y, idx = F.max_pool2d(X, 3, 2, 1, return_indices=True)
+        Ho, Wo = Y.shape[2:]
+        hi, wi = idx // W, idx % W
+        ho = torch.arange(Ho).view(1, 1, Ho, 1)
+        wo = torch.arange(Wo).view(1, 1, 1, Wo)
+        a = (hi - (ho * 2 - 1)) * 3 + (wi - (wo * 2 - 1))
+        _f(y, Y.numel())[:] = Y.permute(0, 2, 3, 1).contiguous().numpy().ravel()
+        _i8(arg, Y.numel())[:] = a.permute(0, 2, 3, 1).contiguous().numpy().astype(np.int8).ravel()
+        return 0
+
+    def rih_maxpool3x3s2_bwd(self, dy, arg, dx, N, H, W, Cc, stream):
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        DY = _f(dy, N * Ho * Wo * Cc).reshape(N, Ho, Wo, Cc)
+        A = _i8(arg, N * Ho * Wo * Cc).reshape(N, Ho, Wo, Cc).astype(np.int64)
+        DX = np.zeros((N, H, W, Cc), np.float32)
+        n, ho, wo, c = np.meshgrid(np.arange(N), np.arange(Ho), np.arange(Wo), np.arange(Cc), indexing='ij')
+        hi, wi = ho * 2 - 1 + A // 3, wo * 2 - 1 + A % 3
+        np.add.at(DX, (n, hi, wi, c), DY)
+        _f(dx, DX.size)[:] = DX.ravel()
+        return 0
+
+    def rih_avgpool_fwd(self, x, y, N, HW, Cc, stream):
+        _f(y, N * Cc)[:] = _f(x, N * HW * Cc).reshape(N, HW, Cc).mean(1).ravel()
+        return 0
+
+    def rih_avgpool_bwd(self, dy, dx, N, HW, Cc, stream):
+        d = _f(dy, N * Cc).reshape(N, 1, Cc) / np.float32(HW)
+        _f(dx, N * HW * Cc)[:] = np.broadcast_to(d, (N, HW, Cc)).ravel()
+        return 0
+
+    def rih_upsample2x_fwd(self, x, y, N, H, W, Cc, stream):
+        X = torch.from_numpy(_f(x, N * H * W * Cc).reshape(N, H, W, Cc).copy()).permute(0, 3, 1, 2)
+        Y = F.interpolate(X, scale_factor=2, mode='bilinear', align_corners=True)
+        _f(y, Y.numel())[:] = Y.permute(0, 2, 3, 1).contiguous().numpy().ravel()
+        return 0
+
+    def rih_upsample2x_bwd(self, dy, dx, N, H, W, Cc, stream):
+        with torch.enable_grad():
+            X = torch.zeros(N, Cc, H, W, requires_grad=True)
+            Y = F.interpolate(X, scale_factor=2, mode='bilinear', align_corners=True)
+            G = torch.from_numpy(_f(dy, N * 4 * H * W * Cc).reshape(N, 2 * H, 2 * W, Cc).copy()).permute(0, 3, 1, 2)
+            Y.backward(G)
+        _f(dx, N * H * W * Cc)[:] = X.grad.permute(0, 2, 3, 1).contiguous().numpy().ravel()
+        return 0
+
+    # ------------------------------------------------------------------ batch norm
+    def rih_bn_ws_floats(self, rows, Cc):
+        return 8
+
+    def rih_bn_stats(self, x, rows, Cc, eps, momentum, mean, invstd, rmean, rvar, ws, stream):
+        X = _f(x, rows * Cc).reshape(rows, Cc).astype(np.float64)
+        m, v = X.mean(0), X.var(0)
+        _f(mean, Cc)[:] = m
+        _f(invstd, Cc)[:] = 1.0 / np.sqrt(v + eps)
+        if rmean:
+            rm, rv = _f(rmean, Cc), _f(rvar, Cc)
+            rm[:] = (1 - momentum) * rm + momentum * m
+            rv[:] = (1 - momentum) * rv + momentum * v * rows / max(rows - 1, 1)
+        return 0
+
+    def rih_bn_eval_stats(self, rmean, rvar, Cc, eps, mean, invstd, stream):
+        _f(mean, Cc)[:] = _f(rmean, Cc)
+        _f(invstd, Cc)[:] = 1.0 / np.sqrt(_f(rvar, Cc) + np.float32(eps))
+        return 0
+
+    def rih_bn_apply(self, x, mean, invstd, gamma, beta, res, y, rows, Cc, relu, stream):
+        X = _f(x, rows * Cc).reshape(rows, Cc)
+        o = (X - _f(mean, Cc)) * (_f(invstd, Cc) * _f(gamma, Cc)) + _f(beta, Cc)
+        if res:
+            o = o + _f(res, rows * Cc).reshape(rows, Cc)
+        if relu:
+            o = np.maximum(o, 0)
+        _f(y, rows * Cc)[:] = o.ravel()
+        return 0
+
+    def rih_bn_bwd(self, dy, x, y, mean, invstd, gamma, dx, dres, dgamma, dbeta, rows, Cc, relu, frozen, ws, stream):
+        D = _f(dy, rows * Cc).reshape(rows, Cc).copy()
+        if relu:
+            D[_f(y, rows * Cc).reshape(rows, Cc) <= 0] = 0
+        X = _f(x, rows * Cc).reshape(rows, Cc)
+        xh = (X - _f(mean, Cc)) * _f(invstd, Cc)
+        s1, s2 = D.sum(0, dtype=np.float64), (D * xh).sum(0, dtype=np.float64)
+        _f(dbeta, Cc)[:] = s1
+        _f(dgamma, Cc)[:] = s2
+        sc = _f(invstd, Cc) * _f(gamma, Cc)
+        if frozen:
+            o = D * sc
+        else:
+            o = (D - (s1 / rows).astype(np.float32) - xh * (s2 / rows).astype(np.float32)) * sc
+        _f(dx, rows * Cc)[:] = o.ravel()
+        if dres:
+            _f(dres, rows * Cc)[:] = D.ravel()
+        return 0
+
+    # ------------------------------------------------------------------ row-wise
+    def rih_ln_nblk(self, rows):
+        return 1
+
+    def rih_layernorm_fwd(self, x, x2, g, b, y, mean, rstd, rows, D, eps, relu, stream):
+        X = _f(x, rows * D).reshape(rows, D).copy()
+        if x2:
+            X += _f(x2, rows * D).reshape(rows, D)
+        m = X.mean(1, keepdims=True)
+        v = ((X - m) ** 2).mean(1, keepdims=True)
+        rs = 1.0 / np.sqrt(v + np.float32(eps))
+        o = (X - m) * rs * _f(g, D) + _f(b, D)
+        if relu:
+            o = np.maximum(o, 0)
+        _f(y, rows * D)[:] = o.ravel()
+        _f(mean, rows)[:] = m.ravel()
+        _f(rstd, rows)[:] = rs.ravel()
+        return 0
+
+    def rih_layernorm_bwd(self, dy, x, x2, y, g, mean, rstd, dx, dg, db, rows, D, relu, ws, stream):
+        Dy = _f(dy, rows * D).reshape(rows, D).copy()
+        if relu:
+            Dy[_f(y, rows * D).reshape(rows, D) <= 0] = 0
+        X = _f(x, rows * D).reshape(rows, D).copy()
+        if x2:
+            X += _f(x2, rows * D).reshape(rows, D)
+        m, rs = _f(mean, rows).reshape(rows, 1), _f(rstd, rows).reshape(rows, 1)
+        xh = (X - m) * rs
+        gd = Dy * _f(g, D)
+        c1, c2 = gd.mean(1, keepdims=True), (gd * xh).mean(1, keepdims=True)
+        _f(dx, rows * D)[:] = (rs * (gd - c1 - xh * c2)).ravel()
+        _f(dg, D)[:] = (Dy * xh).sum(0)
+        _f(db, D)[:] = Dy.sum(0)
+        return 0
+
+    def rih_softmax_fwd(self, S, P, Pd, rows, cols, ld, drop_p, seed, stream):
+        idx = np.arange(rows)[:, None] * ld + np.arange(cols)[None, :]
+        s = _f(S, (rows - 1) * ld + cols)[idx]
+        e = np.exp(s - s.max(1, keepdims=True))
+        p = (e / e.sum(1, keepdims=True)).astype(np.float32)
+        _f(P, (rows - 1) * ld + cols)[idx.ravel()] = p.ravel()
+        if drop_p > 0:
+            _f(Pd, (rows - 1) * ld + cols)[idx.ravel()] = p.ravel() * keep_mask(seed, rows * cols, drop_p)
+        elif Pd != P:
+            _f(Pd, (rows - 1) * ld + cols)[idx.ravel()] = p.ravel()
+        return 0
+
+    def rih_softmax_bwd(self, P, dPd, rows, cols, ld, drop_p, seed, alpha, stream):
+        idx = np.arange(rows)[:, None] * ld + np.arange(cols)[None, :]
+        p = _f(P, (rows - 1) * ld + cols)[idx]
+        mem = _f(dPd, (rows - 1) * ld + cols)
+        d = mem[idx] * keep_mask(seed, rows * cols, drop_p).reshape(rows, cols)
+        dot = (d * p).sum(1, keepdims=True)
+        mem[idx.ravel()] = (np.float32(alpha) * p * (d - dot)).ravel()
+        return 0
+
+    # ------------------------------------------------------------------ elementwise / gathers
+    def rih_add_dropout(self, a, b, y, n, D, bcast_rows, drop_p, seed, stream):
+        bm = bcast_rows * D
+        bv = _f(b, bm if bm > 0 else n)
+        bv = bv[np.arange(n) % bm] if bm > 0 else bv.copy()
+        bv = bv * keep_mask(seed, n, drop_p)
+        _f(y, n)[:] = (_f(a, n) if a else 0) + bv
+        return 0
+
+    def rih_dropout_bwd(self, dy, dx, n, drop_p, seed, stream):
+        _f(dx, n)[:] = _f(dy, n) * keep_mask(seed, n, drop_p)
+        return 0
+
+    def rih_relu_fwd(self, x, y, n, stream):
+        _f(y, n)[:] = np.maximum(_f(x, n), 0)
+        return 0
+
+    def rih_relu_bwd(self, dy, y, dx, n, stream):
+        _f(dx, n)[:] = np.where(_f(y, n) > 0, _f(dy, n), 0)
+        return 0
+
+    def rih_colsum_ws_floats(self, rows, Cc):
+        return 8
+
+    def rih_colsum(self, x, rows, Cc, ldx, out, accumulate, ws, stream):
+        idx = np.arange(rows)[:, None] * ldx + np.arange(Cc)[None, :]
+        s = _f(x, (rows - 1) * ldx + Cc)[idx].sum(0, dtype=np.float64)
+        o = _f(out, Cc)
+        o[:] = (o if accumulate else 0) + s
+        return 0
+
+    def rih_gather_rows(self, x, idx, y, B, Vin, Vout, D, stream):
+        X = _f(x, B * Vin * D).reshape(B, Vin, D)
+        _f(y, B * Vout * D)[:] = X[:, _i32(idx, Vout)].ravel()
+        return 0
+
+    def rih_scatter_rows_add(self, dy, inv_ptr, inv_idx, dx, B, Vin, Vout, D, stream):
+        DY = _f(dy, B * Vout * D).reshape(B, Vout, D)
+        ptr, lst = _i32(inv_ptr, Vin + 1), _i32(inv_idx, Vout)
+        DX = np.zeros((B, Vin, D), np.float32)
+        for v in range(Vin):
+            for k in range(ptr[v], ptr[v + 1]):
+                DX[:, v] += DY[:, lst[k]]
+        _f(dx, DX.size)[:] = DX.ravel()
+        return 0
+
+    def _csr(self, indptr, indices, vals, V):
+        import scipy.sparse as sp
+        ip = _i32(indptr, V + 1).copy()
+        return sp.csr_matrix((_f(vals, ip[-1]).copy(), _i32(indices, ip[-1]).copy(), ip), shape=(V, V))
+
+    def rih_cheby_fwd(self, x, indptr, indices, vals, y, B, V, Fd, stream):
+        L = self._csr(indptr, indices, vals, V)
+        X = _f(x, B * V * Fd).reshape(B, V, Fd)
+        LX = np.stack([L @ X[b] for b in range(B)])
+        _f(y, B * V * 2 * Fd)[:] = np.stack((X, LX), -1).reshape(B, V, 2 * Fd).ravel()
+        return 0
+
+    def rih_cheby_bwd(self, dy, indptr, indices, vals, dx, B, V, Fd, stream):
+        Lt = self._csr(indptr, indices, vals, V)
+        DY = _f(dy, B * V * 2 * Fd).reshape(B, V, Fd, 2)
+        out = DY[..., 0] + np.stack([Lt @ DY[b, :, :, 1] for b in range(B)])
+        _f(dx, B * V * Fd)[:] = out.ravel()
+        return 0
+
+    def rih_project_fwd(self, v, scale, trans, out, B, V, img, stream):
+        Vv = _f(v, B * V * 3).reshape(B, V, 3)
+        s = (_f(scale, B) * np.float32(img)).reshape(B, 1, 1)
+        t = (_f(trans, B * 2).reshape(B, 1, 2) * np.float32(img) / 2 + np.float32(img) / 2)
+        _f(out, B * V * 2)[:] = (s * Vv[..., :2] + t).ravel()
+        return 0
+
+    def rih_project_bwd(self, dout, v, scale, dv, dscale, dtrans, B, V, img, stream):
+        D = _f(dout, B * V * 2).reshape(B, V, 2)
+        Vv = _f(v, B * V * 3).reshape(B, V, 3)
+        s = (_f(scale, B) * np.float32(img)).reshape(B, 1, 1)
+        o = np.zeros((B, V, 3), np.float32)
+        o[..., :2] = s * D
+        _f(dv, B * V * 3)[:] = o.ravel()
+        _f(dscale, B)[:] = (D * Vv[..., :2]).sum((1, 2)) * np.float32(img)
+        _f(dtrans, B * 2)[:] = (D.sum(1) * np.float32(img) / 2).ravel()
+        return 0
+
+    def rih_version(self):
+        return 1
+
+    def rih_arch(self):
+        return b'emulated'
+
+
+@contextlib.contextmanager
+def emulated_abi():
+    """Route renderih_amd.ops through the emulation on CPU tensors (tests only)."""
+    from renderih_amd import _lib, ops
+
+    class _FakeStream:
+        cuda_stream = 0
+
+    saved = (_lib._lib, ops._chk, ops._stream)
+    _lib._lib = EmulatedLib()
+    ops._chk = lambda *a: None
+    ops._stream = lambda: 0
+    try:
+        yield
+    finally:
+        _lib._lib, ops._chk, ops._stream = saved

@@ -1,0 +1,76 @@
+"""CPU validation of the host-side logic (renderih_amd.ops + module tree) against PyTorch/the oracle, with the C ABI
+emulated on host memory (tests/abi_emulator.py).  The kernels themselves are proven by the -m gpu tests; this pins
+descriptor geometry, packing, strides, split-K plumbing, backward wiring and the module forward graph."""
+import numpy as np
+import pytest
+import torch
+
+import test_gpu_ops as G
+from abi_emulator import emulated_abi
+from renderih_amd import assets, testing
+from renderih_amd.testing import assert_close
+
+
+@pytest.fixture(autouse=True)
+def _emulate(monkeypatch):
+    monkeypatch.setattr(G, 'dev', lambda: torch.device('cpu'))
+    with emulated_abi():
+        yield
+
+
+@pytest.mark.parametrize('case', G.CONV_CASES[:10])
+def test_conv2d_host_logic(case):
+    G.test_conv2d(case)
+
+
+@pytest.mark.parametrize('case', G.LIN_CASES[:5] + G.LIN_CASES[6:7])
+def test_linear_host_logic(case):
+    G.test_linear(case)
+
+
+def test_other_ops_host_logic():
+    G.test_batchnorm(True, True, True, (2, 16, 16, 64))
+    G.test_batchnorm(False, True, False, (3, 7, 9, 256))
+    G.test_layernorm(4, 509, False, False)
+    G.test_layernorm(300, 256, True, True)
+    G.test_attention(2, 127, 127, 256, 4)
+    G.test_attention(2, 126, 252, 128, 4)
+    G.test_attention_dropout_matches_hash_mask()
+    G.test_add_dropout_and_bcast()
+    G.test_cheby_gather_project()
+
+
+def test_pool_layout_host_logic(monkeypatch):
+    G.test_pool_upsample_layout()
+
+
+def test_model_host_logic_matches_oracle():
+    """Whole network, B=2, train mode, dropout 0: forward outputs and all parameter gradients.  Train-mode BN over
+    <=128 samples amplifies fp32 round-off to ~1e-4, so the bar is anchored on the fp64 oracle (testing.py)."""
+    from oracle import net_oracle
+    from renderih_amd.model import build_model
+    m = build_model(0.0)
+    sd = testing.deterministic_state(m.state_dict(), seed=3)
+    m.load_state_dict(sd)
+    m.train()
+    img = testing.seeded_image(2, 4)
+    got = testing.flatten_outputs(m(img))
+    graph = net_oracle.graph_from_dicts(assets.load_graph_dict('left'), assets.load_graph_dict('right'))
+    w32, g32 = net_oracle.run(sd, graph, img, True, torch.float32, True)
+    w64, g64 = net_oracle.run(sd, graph, img, True, torch.float64, True)
+    for k in w64:
+        testing.assert_fp32_equivalent(got[k], w32[k], w64[k], what=k)
+    net_oracle.scalar_loss(_unflatten(got)).backward()
+    from test_gpu_model import _grad_report
+    params = [(k, p.grad) for k, p in m.named_parameters() if p.grad is not None]
+    assert {k for k, _ in params} == set(g64.keys())
+    _grad_report(params, g32, g64)
+    assert int(m.encoder.resnet.bn1.num_batches_tracked) == 1
+
+
+def _unflatten(f):
+    sides = ('left', 'right')
+    return ({'verts3d': {s: f['result.verts3d.' + s] for s in sides}, 'verts2d': {s: f['result.verts2d.' + s] for s in sides}},
+            {'scale': {s: f['params.scale.' + s] for s in sides}, 'trans2d': {s: f['params.trans2d.' + s] for s in sides}},
+            [{'verts3d': {s: f['hand0.verts3d.' + s] for s in sides}, 'verts2d': {s: f['hand0.verts2d.' + s] for s in sides}}],
+            {'hms': f['other.hms'], 'mask': f['other.mask'], 'dense': f['other.dense']})
