@@ -28,6 +28,11 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -235,12 +240,12 @@ inline ColGeom col_geom(int rows, int C) {
     g.cgb = p;
     g.rt = TPB / g.cgb;
     g.gx = (CG + g.cgb - 1) / g.cgb;
-    int want = 2048 / g.gx;
+    int want = 1024 / g.gx;
     if (want < 1) want = 1;
     int maxc = (rows + g.rt * 4 - 1) / (g.rt * 4);
     if (maxc < 1) maxc = 1;
     g.nchunk = want < maxc ? want : maxc;
-    if (g.nchunk > 1024) g.nchunk = 1024;
+    if (g.nchunk > 256) g.nchunk = 256;
     g.rows_per_chunk = (rows + g.nchunk - 1) / g.nchunk;
     g.nchunk = (rows + g.rows_per_chunk - 1) / g.rows_per_chunk;
     return g;
@@ -290,16 +295,22 @@ __global__ __launch_bounds__(TPB) void bn_stats_partial_kernel(const float* __re
     }
 }
 
-__global__ void bn_stats_final_kernel(const float* __restrict__ x, const float* __restrict__ ws, int rows, int C,
-                                      int nchunk, float eps, float momentum, float* __restrict__ mean,
-                                      float* __restrict__ invstd, float* __restrict__ rmean, float* __restrict__ rvar) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per channel: lanes stride over the chunk partials, fp64 xor-shuffle reduction
+__global__ __launch_bounds__(TPB) void bn_stats_final_kernel(const float* __restrict__ x, const float* __restrict__ ws,
+                                                             int rows, int C, int nchunk, float eps, float momentum,
+                                                             float* __restrict__ mean, float* __restrict__ invstd,
+                                                             float* __restrict__ rmean, float* __restrict__ rvar) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
+    for (int k = lane; k < nchunk; k += 64) {
         s1 += (double)ws[((long long)0 * nchunk + k) * C + c];
         s2 += (double)ws[((long long)1 * nchunk + k) * C + c];
     }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if (lane != 0) return;
     const double n = (double)rows;
     const double d = s1 / n;
     const double m = (double)x[c] + d;
@@ -389,18 +400,20 @@ __global__ __launch_bounds__(TPB) void bn_bwd_partial_kernel(const float* __rest
     }
 }
 
-// finalize: sums[0][C] = sum dym, sums[1][C] = sum dym*xhat (also the dbeta / dgamma outputs)
-__global__ void two_sum_final_kernel(const float* __restrict__ ws, int C, int nchunk, float* __restrict__ out0,
-                                     float* __restrict__ out1) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// finalize: out0[C] = sum dym, out1[C] = sum dym*xhat (also the dbeta / dgamma outputs); one wavefront per channel
+__global__ __launch_bounds__(TPB) void two_sum_final_kernel(const float* __restrict__ ws, int C, int nchunk,
+                                                            float* __restrict__ out0, float* __restrict__ out1) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
+    for (int k = lane; k < nchunk; k += 64) {
         s1 += (double)ws[((long long)0 * nchunk + k) * C + c];
         s2 += (double)ws[((long long)1 * nchunk + k) * C + c];
     }
-    out0[c] = (float)s1;
-    out1[c] = (float)s2;
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if (lane == 0) { out0[c] = (float)s1; out1[c] = (float)s2; }
 }
 
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -457,19 +470,22 @@ __global__ __launch_bounds__(TPB) void colsum_partial_kernel(const float* __rest
     if (ry == 0 && c < C) ws[(long long)chunk * C + c] = red[cl] + red[64 + cl] + red[128 + cl] + red[192 + cl];
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ ws, int C, int nchunk, float* __restrict__ out,
-                                    int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(TPB) void colsum_final_kernel(const float* __restrict__ ws, int C, int nchunk,
+                                                           float* __restrict__ out, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (c >= C) return;
     double s = 0.0;
-    for (int k = 0; k < nchunk; ++k) s += (double)ws[(long long)k * C + c];
-    out[c] = accumulate ? out[c] + (float)s : (float)s;
+    for (int k = lane; k < nchunk; k += 64) s += (double)ws[(long long)k * C + c];
+    s = wave_sum_d(s);
+    if (lane == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 inline int colsum_nchunk(int rows, int C) {
     const int gx = (C + 63) / 64;
-    int want = 1024 / gx;
+    int want = 512 / gx;
     if (want < 1) want = 1;
+    if (want > 128) want = 128;
     int maxc = (rows + 63) / 64;
     if (maxc < 1) maxc = 1;
     return want < maxc ? want : maxc;
@@ -584,17 +600,19 @@ __global__ __launch_bounds__(TPB) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
-__global__ void ln_param_final_kernel(const float* __restrict__ ws, int D, int nblk, float* __restrict__ dg,
-                                      float* __restrict__ db) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(TPB) void ln_param_final_kernel(const float* __restrict__ ws, int D, int nblk,
+                                                             float* __restrict__ dg, float* __restrict__ db) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (e >= D) return;
     double a = 0.0, b = 0.0;
-    for (int k = 0; k < nblk; ++k) {
+    for (int k = lane; k < nblk; k += 64) {
         a += (double)ws[((long long)k * 2 + 0) * D + e];
         b += (double)ws[((long long)k * 2 + 1) * D + e];
     }
-    dg[e] = (float)a;
-    db[e] = (float)b;
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    if (lane == 0) { dg[e] = (float)a; db[e] = (float)b; }
 }
 
 // ------------------------------------------------------------------------------------------------ softmax
@@ -882,7 +900,7 @@ extern "C" int rih_bn_stats(const float* x, int rows, int C, float eps, float mo
     const ColGeom g = col_geom(rows, C);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(g.gx, g.nchunk), dim3(TPB), 0, STREAM, x, rows, C, g.cgb, g.rt,
                        g.rows_per_chunk, ws);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 127) / 128), dim3(128), 0, STREAM, x, ws, rows, C, g.nchunk, eps,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 3) / 4), dim3(TPB), 0, STREAM, x, ws, rows, C, g.nchunk, eps,
                        momentum, mean, invstd, running_mean, running_var);
     LAUNCH_RET();
 }
@@ -911,7 +929,7 @@ extern "C" int rih_bn_bwd(const float* dy, const float* x, const float* y, const
     const ColGeom g = col_geom(rows, C);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(g.gx, g.nchunk), dim3(TPB), 0, STREAM, dy, x, y, mean, invstd, rows, C,
                        g.cgb, g.rt, g.rows_per_chunk, relu, ws);
-    hipLaunchKernelGGL(two_sum_final_kernel, dim3((C + 127) / 128), dim3(128), 0, STREAM, ws, C, g.nchunk, dbeta, dgamma);
+    hipLaunchKernelGGL(two_sum_final_kernel, dim3((C + 3) / 4), dim3(TPB), 0, STREAM, ws, C, g.nchunk, dbeta, dgamma);
     const long long nq = (long long)rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nq)), dim3(TPB), 0, STREAM, dy, x, y, mean, invstd, gamma,
                        dbeta, dgamma, dx, dres, nq, C, 1.f / (float)rows, relu, frozen_stats);
@@ -921,7 +939,7 @@ extern "C" int rih_bn_bwd(const float* dy, const float* x, const float* y, const
 extern "C" int rih_ln_nblk(int rows) {
     int n = (rows + 15) / 16;
     if (n < 1) n = 1;
-    if (n > 512) n = 512;
+    if (n > 256) n = 256;
     return n;
 }
 extern "C" int rih_layernorm_fwd(const float* x, const float* x2, const float* g, const float* b, float* y, float* mean,
@@ -942,7 +960,7 @@ extern "C" int rih_layernorm_bwd(const float* dy, const float* x, const float* x
     const int nblk = rih_ln_nblk(rows);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(TPB), 0, STREAM, dy, x, x2, y, g, mean, rstd, dx, ws, rows,
                        D, relu);
-    hipLaunchKernelGGL(ln_param_final_kernel, dim3((D + 127) / 128), dim3(128), 0, STREAM, ws, D, nblk, dg, db);
+    hipLaunchKernelGGL(ln_param_final_kernel, dim3((D + 3) / 4), dim3(TPB), 0, STREAM, ws, D, nblk, dg, db);
     LAUNCH_RET();
 }
 extern "C" int rih_softmax_fwd(const float* S, float* P, float* Pd, int64_t rows, int cols, int ld, float drop_p,
@@ -1000,7 +1018,7 @@ extern "C" int rih_colsum(const float* x, int rows, int C, int ldx, float* out, 
     const int nchunk = colsum_nchunk(rows, C);
     const int rpc = (rows + nchunk - 1) / nchunk;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, nchunk), dim3(TPB), 0, STREAM, x, rows, C, ldx, rpc, ws);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 127) / 128), dim3(128), 0, STREAM, ws, C, nchunk, out, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 3) / 4), dim3(TPB), 0, STREAM, ws, C, nchunk, out, accumulate);
     LAUNCH_RET();
 }
 extern "C" int rih_gather_rows(const float* x, const int32_t* idx, float* y, int B, int Vin, int Vout, int D,
