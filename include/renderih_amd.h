@@ -67,7 +67,7 @@ typedef struct rih_gemm_desc {
     int32_t relu;
     /* im2col geometry of A (a plain matrix is H=W=Ho=Wo=KH=KW=1, strideA=upS=1, pad=0, Cin=K or M) */
     int32_t H, W, Cin, Ho, Wo, KH, KW, strideA, upS, padH, padW;
-    int32_t tile;        /* 0: 128x128, 1: 128x64, 2: 64x64 */
+    int32_t tile;        /* 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32 */
 } rih_gemm_desc;
 
 int rih_gemm(const rih_gemm_desc* d, void* stream);
@@ -77,6 +77,10 @@ int rih_gemm(const rih_gemm_desc* d, void* stream);
  * Rows with ci >= CinValid (channel padding) are dropped.  accumulate!=0 adds to dst. */
 int rih_splitk_reduce(const float* P, int S, int M, int N, float* dst, int Cin, int taps, int CinValid,
                       int accumulate, void* stream);
+
+/* Finish a forward split-K GEMM: C[m*ldc+n] = act(alpha * sum_s P[s][m][n] + bias[n] + R[m*ldr+n]). */
+int rih_splitk_finish(const float* P, int S, int M, int N, float* C, int ldc, const float* bias, const float* R,
+                      int ldr, float alpha, int relu, void* stream);
 
 /* Repack an OIHW conv weight for rih_gemm: dst[((kh*KW+kw)*Ci_pad + ci)*Cout + co] (forward, b_mode 0) or,
  * with for_dgrad!=0, dst[(((KH-1-kh)*KW + (KW-1-kw))*Cout + co)*Ci_pad + ci] (flipped, in/out swapped). */

@@ -39,6 +39,7 @@ class ManoModel(C.Structure):
 SIGNATURES = {
     'rih_gemm': (c_i, [C.POINTER(GemmDesc), C.c_void_p]),
     'rih_splitk_reduce': (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_splitk_finish': (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_fl, c_i, C.c_void_p]),
     'rih_pack_conv_weight': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
     'rih_nchw_to_nhwc': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
     'rih_nhwc_to_nchw': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),

@@ -172,8 +172,10 @@ class SelfAttn(nn.Module):
 
     def forward(self, x, dc):
         y = _ln(self.layer_norm, x)
-        o = ops.attention(_lin(self.w_qs, y), _lin(self.w_ks, y), _lin(self.w_vs, y), self.n_heads,
-                          dc.p, dc.seed() if dc.p > 0 else 0)
+        # one fused QKV projection: the three nn.Linear parameters are stacked (a copy) into a [3D, D] operand
+        w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight], 0)
+        b = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias], 0)
+        o = ops.self_attention_packed(ops.linear(y, w, b), self.n_heads, dc.p, dc.seed() if dc.p > 0 else 0)
         x = _lin_drop_res(dc, self.fc, o, x)
         return self.ff(x, dc)
 
@@ -258,11 +260,13 @@ class inter_attn(nn.Module):
         Rf = self.R_self_attn_layer(Rf, dc)
         L2 = _ln(self.layer_norm1, Lf)
         R2 = _ln(self.layer_norm2, Rf)
-        Lq, Lk, Lv = _lin(self.w_qs, L2), _lin(self.w_ks, L2), _lin(self.w_vs, L2)
-        Rq, Rk, Rv = _lin(self.w_qs, R2), _lin(self.w_ks, R2), _lin(self.w_vs, R2)
+        # shared projections (N5): stacked once into a [3D, D] operand, one fused QKV GEMM per hand
+        w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight], 0)
+        b = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias], 0)
         sd = (lambda: dc.seed()) if dc.p > 0 else (lambda: 0)
-        feat_R2L = ops.attention(Lq, Rk, Rv, self.n_heads, dc.p, sd())     # softmax(Lq Rk^T) Rv  (inter_attn.py:93-104)
-        feat_L2R = ops.attention(Rq, Lk, Lv, self.n_heads, dc.p, sd())
+        # feat_R2L = softmax(Lq Rk^T) Rv, feat_L2R = softmax(Rq Lk^T) Lv  (inter_attn.py:93-104)
+        feat_R2L, feat_L2R = ops.cross_attention_packed(ops.linear(L2, w, b), ops.linear(R2, w, b), self.n_heads,
+                                                        dc.p, sd(), sd())
         Lf = self.ffL(_lin_drop_res(dc, self.fc, feat_R2L, Lf), dc)
         Rf = self.ffR(_lin_drop_res(dc, self.fc, feat_L2R, Rf), dc)
         return Lf, Rf

@@ -44,11 +44,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-template <int BM, int BN, int AMODE, int BMODE>
+template <int BM, int BN, int AMODE, int BMODE, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     constexpr int LDAS = BM + 4;
     constexpr int LDBS = BN + 4;
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int WGN = (BN >= 64) ? 2 : 1;             // wave grid: WGM x WGN = 4 waves
+    constexpr int WGM = 4 / WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NPA = BM / 32, NPB = BN / 32;
 
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
 
     const int tilesN = (p.N + BN - 1) / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -122,73 +124,72 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         for (int i = 0; i < NPA; ++i) { a_base[i] = 0; a_hi0[i] = 0; a_wi0[i] = 0; }
     }
 
+    // Loads are branch-free: every lane always issues its loads (an invalid element reads a safe in-bounds dummy
+    // address) and a 4-bit-per-load validity mask is applied when the registers are written to LDS.  Nothing touches a
+    // loaded value before that point, so all global loads of a k-tile are in flight together across the MFMA phase.
     float4 areg[NPA], breg[NPB];
+    unsigned amask = 0, bmask = 0;          // bit (4*i + e): element e of load i is valid
+
+    auto ld4 = [&](const float* ptr, unsigned bits) -> float4 {
+        float4 v;
+        if (VEC) {      // 16-byte aligned rows: one dwordx4 (a partially valid tail quad stays inside the row pitch)
+            v = *reinterpret_cast<const float4*>(ptr);
+        } else {        // unaligned / odd pitch: four scalar loads, an invalid element re-reads element 0
+            v.x = ptr[0];
+            v.y = ptr[(bits >> 1) & 1u];
+            v.z = ptr[((bits >> 2) & 1u) * 2u];
+            v.w = ptr[((bits >> 3) & 1u) * 3u];
+        }
+        return v;
+    };
+    auto mask4 = [](float4 v, unsigned bits) -> float4 {
+        v.x = (bits & 1u) ? v.x : 0.f;
+        v.y = (bits & 2u) ? v.y : 0.f;
+        v.z = (bits & 4u) ? v.z : 0.f;
+        v.w = (bits & 8u) ? v.w : 0.f;
+        return v;
+    };
+    auto first_bits = [](int nvalid) -> unsigned {      // mask of the first min(nvalid,4) elements
+        return nvalid >= 4 ? 15u : (nvalid <= 0 ? 0u : ((1u << nvalid) - 1u));
+    };
 
     auto load_A = [&](int ktile) {
+        amask = 0;
         if (AMODE == 0) {
+            const unsigned kbits = (a_kh < p.KH) ? first_bits(p.Cin - a_ci) : 0u;
 #pragma unroll
             for (int i = 0; i < NPA; ++i) {
-                float4 v = zero4();
-                if (a_kh < p.KH) {
-                    int hi = a_hi0[i] + a_kh, wi = a_wi0[i] + a_kw;
-                    bool ok = (hi >= 0) && (wi >= 0);
-                    if (p.upS > 1) {
-                        ok = ok && (hi % p.upS == 0) && (wi % p.upS == 0);
-                        hi /= p.upS;
-                        wi /= p.upS;
-                    }
-                    ok = ok && (hi < p.H) && (wi < p.W);
-                    if (ok) {
-                        const float* ptr = A + a_base[i] + ((long long)hi * p.W + wi) * p.lda + a_ci;
-                        const int rem = p.Cin - a_ci;      // valid elements of this quad inside the tap
-                        if (p.vecA) {
-                            v = *reinterpret_cast<const float4*>(ptr);
-                            if (rem < 4) {
-                                if (rem < 2) v.y = 0.f;
-                                if (rem < 3) v.z = 0.f;
-                                v.w = 0.f;
-                            }
-                        } else {
-                            v.x = ptr[0];
-                            if (rem > 1) v.y = ptr[1];
-                            if (rem > 2) v.z = ptr[2];
-                            if (rem > 3) v.w = ptr[3];
-                        }
-                    }
+                int hi = a_hi0[i] + a_kh, wi = a_wi0[i] + a_kw;
+                bool ok = (hi >= 0) && (wi >= 0) && (kbits != 0u);
+                if (p.upS > 1) {
+                    ok = ok && (hi % p.upS == 0) && (wi % p.upS == 0);
+                    hi /= p.upS;
+                    wi /= p.upS;
                 }
-                areg[i] = v;
+                ok = ok && (hi < p.H) && (wi < p.W);
+                const unsigned bits = ok ? kbits : 0u;
+                const long long off = ok ? (a_base[i] + ((long long)hi * p.W + wi) * p.lda + a_ci) : 0ll;
+                areg[i] = ld4(A + off, bits);
+                amask |= bits << (4 * i);
             }
         } else {
             const int akr = tid / QA;
+            const unsigned mbits = (a_kh < p.KH) ? first_bits(a_mvalid) : 0u;
 #pragma unroll
             for (int i = 0; i < NPA; ++i) {
-                float4 v = zero4();
                 const int k = ktile + akr + RA * i;
-                if (k < kend && a_mvalid > 0 && a_kh < p.KH) {
-                    const int wo = k % p.Wo;
-                    const int t = k / p.Wo;
-                    const int ho = t % p.Ho;
-                    const int img = t / p.Ho;
-                    const int hi = ho * p.strideA - p.padH + a_kh;
-                    const int wi = wo * p.strideA - p.padW + a_kw;
-                    if (hi >= 0 && wi >= 0 && hi < p.H && wi < p.W) {
-                        const float* ptr = A + ((long long)(img * p.H + hi) * p.W + wi) * p.lda + a_ci;
-                        if (p.vecA) {
-                            v = *reinterpret_cast<const float4*>(ptr);
-                            if (a_mvalid < 4) {
-                                if (a_mvalid < 2) v.y = 0.f;
-                                if (a_mvalid < 3) v.z = 0.f;
-                                v.w = 0.f;
-                            }
-                        } else {
-                            v.x = ptr[0];
-                            if (a_mvalid > 1) v.y = ptr[1];
-                            if (a_mvalid > 2) v.z = ptr[2];
-                            if (a_mvalid > 3) v.w = ptr[3];
-                        }
-                    }
-                }
-                areg[i] = v;
+                const int kc = min(k, kend - 1);
+                const int wo = kc % p.Wo;
+                const int t = kc / p.Wo;
+                const int ho = t % p.Ho;
+                const int img = t / p.Ho;
+                const int hi = ho * p.strideA - p.padH + a_kh;
+                const int wi = wo * p.strideA - p.padW + a_kw;
+                const bool ok = (k < kend) && (mbits != 0u) && hi >= 0 && wi >= 0 && hi < p.H && wi < p.W;
+                const unsigned bits = ok ? mbits : 0u;
+                const long long off = ok ? (((long long)(img * p.H + hi) * p.W + wi) * p.lda + a_ci) : 0ll;
+                areg[i] = ld4(A + off, bits);
+                amask |= bits << (4 * i);
             }
         }
     };
@@ -208,62 +209,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             const int arow = tid >> 3, aq = tid & 7;
 #pragma unroll
             for (int i = 0; i < NPA; ++i) {
+                const float4 v = mask4(areg[i], (amask >> (4 * i)) & 15u);
                 float* dst = As + (aq * 4) * LDAS + arow + 32 * i;
-                dst[0] = areg[i].x;
-                dst[LDAS] = areg[i].y;
-                dst[2 * LDAS] = areg[i].z;
-                dst[3 * LDAS] = areg[i].w;
+                dst[0] = v.x;
+                dst[LDAS] = v.y;
+                dst[2 * LDAS] = v.z;
+                dst[3 * LDAS] = v.w;
             }
         } else {
             const int amq = tid % QA, akr = tid / QA;
 #pragma unroll
             for (int i = 0; i < NPA; ++i)
-                *reinterpret_cast<float4*>(As + (akr + RA * i) * LDAS + amq * 4) = areg[i];
+                *reinterpret_cast<float4*>(As + (akr + RA * i) * LDAS + amq * 4) =
+                    mask4(areg[i], (amask >> (4 * i)) & 15u);
         }
     };
 
     // ------------------------------------------------------------------ B loader
     constexpr int QB = BN / 4, RB = 256 / QB;
     auto load_B = [&](int ktile) {
+        bmask = 0;
         if (BMODE == 0) {
             const int bnq = tid % QB, bkr = tid / QB;
             const int n = n0 + bnq * 4;
+            const unsigned nbits = first_bits(p.N - n);
 #pragma unroll
             for (int i = 0; i < NPB; ++i) {
-                float4 v = zero4();
                 const int k = ktile + bkr + RB * i;
-                if (k < kend && n < p.N) {
-                    const float* ptr = B + (long long)k * p.ldb + n;
-                    if (p.vecB && n + 3 < p.N) {
-                        v = *reinterpret_cast<const float4*>(ptr);
-                    } else {
-                        v.x = ptr[0];
-                        if (n + 1 < p.N) v.y = ptr[1];
-                        if (n + 2 < p.N) v.z = ptr[2];
-                        if (n + 3 < p.N) v.w = ptr[3];
-                    }
-                }
-                breg[i] = v;
+                const unsigned bits = (k < kend) ? nbits : 0u;
+                const long long off = bits ? ((long long)k * p.ldb + n) : 0ll;
+                breg[i] = ld4(B + off, bits);
+                bmask |= bits << (4 * i);
             }
         } else {
             const int brow = tid >> 3, bq = tid & 7;
             const int k = ktile + bq * 4;
+            const unsigned kbits = first_bits(kend - k);
 #pragma unroll
             for (int i = 0; i < NPB; ++i) {
-                float4 v = zero4();
                 const int n = n0 + brow + 32 * i;
-                if (n < p.N && k < kend) {
-                    const float* ptr = B + (long long)n * p.ldb + k;
-                    if (p.vecB && k + 3 < kend) {
-                        v = *reinterpret_cast<const float4*>(ptr);
-                    } else {
-                        v.x = ptr[0];
-                        if (k + 1 < kend) v.y = ptr[1];
-                        if (k + 2 < kend) v.z = ptr[2];
-                        if (k + 3 < kend) v.w = ptr[3];
-                    }
-                }
-                breg[i] = v;
+                const unsigned bits = (n < p.N) ? kbits : 0u;
+                const long long off = bits ? ((long long)n * p.ldb + k) : 0ll;
+                breg[i] = ld4(B + off, bits);
+                bmask |= bits << (4 * i);
             }
         }
     };
@@ -273,16 +261,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             const int bnq = tid % QB, bkr = tid / QB;
 #pragma unroll
             for (int i = 0; i < NPB; ++i)
-                *reinterpret_cast<float4*>(Bs + (bkr + RB * i) * LDBS + bnq * 4) = breg[i];
+                *reinterpret_cast<float4*>(Bs + (bkr + RB * i) * LDBS + bnq * 4) =
+                    mask4(breg[i], (bmask >> (4 * i)) & 15u);
         } else {
             const int brow = tid >> 3, bq = tid & 7;
 #pragma unroll
             for (int i = 0; i < NPB; ++i) {
+                const float4 v = mask4(breg[i], (bmask >> (4 * i)) & 15u);
                 float* dst = Bs + (bq * 4) * LDBS + brow + 32 * i;
-                dst[0] = breg[i].x;
-                dst[LDBS] = breg[i].y;
-                dst[2 * LDBS] = breg[i].z;
-                dst[3 * LDBS] = breg[i].w;
+                dst[0] = v.x;
+                dst[LDBS] = v.y;
+                dst[2 * LDBS] = v.z;
+                dst[3 * LDBS] = v.w;
             }
         }
     };
@@ -315,18 +305,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             load_A(kbeg + (t + 1) * BK);
             load_B(kbeg + (t + 1) * BK);
         }
+        {
+            float av[2][TM], bv[2][TN];
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float av[TM], bv[TN];
+            for (int i = 0; i < TM; ++i) av[0][i] = a_rd[i * 32];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = a_rd[(kk * 2) * LDAS + i * 32];
+            for (int j = 0; j < TN; ++j) bv[0][j] = b_rd[j * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = b_rd[(kk * 2) * LDBS + j * 32];
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                const int cur = kk & 1, nxt = cur ^ 1;
+                if (kk + 1 < BK / 2) {      // LDS operands of step kk+1 are requested before the MFMAs of step kk
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i) av[nxt][i] = a_rd[((kk + 1) * 2) * LDAS + i * 32];
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) bv[nxt][j] = b_rd[((kk + 1) * 2) * LDBS + j * 32];
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+            }
         }
         __syncthreads();
         if (more) {
@@ -362,28 +361,73 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     }
 }
 
-template <int BM, int BN>
-int launch_tile(const GemmArgs& a, int a_mode, int b_mode, dim3 grid, hipStream_t s) {
+template <int BM, int BN, bool VEC>
+int launch_tile_v(const GemmArgs& a, int a_mode, int b_mode, dim3 grid, hipStream_t s) {
     dim3 block(256);
-    if (a_mode == 0 && b_mode == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, 0, 0>), grid, block, 0, s, a);
-    else if (a_mode == 0 && b_mode == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, 0, 1>), grid, block, 0, s, a);
-    else if (a_mode == 1 && b_mode == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, 1, 0>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, 1, 1>), grid, block, 0, s, a);
+    if (a_mode == 0 && b_mode == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, 0, 0, VEC>), grid, block, 0, s, a);
+    else if (a_mode == 0 && b_mode == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, 0, 1, VEC>), grid, block, 0, s, a);
+    else if (a_mode == 1 && b_mode == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, 1, 0, VEC>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, 1, 1, VEC>), grid, block, 0, s, a);
     return (int)hipGetLastError();
 }
 
-__global__ void splitk_reduce_kernel(const float* __restrict__ P, int S, int M, int N, float* __restrict__ dst,
-                                     int Cin, int taps, int CinValid, int accumulate) {
+template <int BM, int BN>
+int launch_tile(const GemmArgs& a, int a_mode, int b_mode, dim3 grid, hipStream_t s) {
+    // the vector variant needs 16-byte aligned rows on both operands and whole quads along B's contiguous dim
+    if (a.vecA && a.vecB) return launch_tile_v<BM, BN, true>(a, a_mode, b_mode, grid, s);
+    return launch_tile_v<BM, BN, false>(a, a_mode, b_mode, grid, s);
+}
+
+// Sum S split-K partials P[S][M][N] and store in parameter layout dst[(n*CinValid + ci)*taps + tap], m = tap*Cin + ci.
+// 32x32 tiles go through LDS so that both the partial reads (along n) and the stores (along ci) are coalesced.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ P, int S, int M, int N,
+                                                            float* __restrict__ dst, int Cin, int taps, int CinValid,
+                                                            int accumulate) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // ty in 0..7
+    const int tilesN = (N + 31) / 32;
+    const int m0 = (blockIdx.x / tilesN) * 32, n0 = (blockIdx.x % tilesN) * 32;
+    const long long MN = (long long)M * N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty + 8 * i, n = n0 + tx;
+        float s = 0.f;
+        if (m < M && n < N) {
+            const float* p = P + (long long)m * N + n;
+            for (int k = 0; k < S; ++k) s += p[(long long)k * MN];
+        }
+        tile[ty + 8 * i][tx] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + tx, n = n0 + ty + 8 * i;
+        if (m < M && n < N) {
+            const int tap = m / Cin, ci = m - tap * Cin;
+            if (ci < CinValid) {
+                const long long o = ((long long)n * CinValid + ci) * taps + tap;
+                const float v = tile[tx][ty + 8 * i];
+                dst[o] = accumulate ? dst[o] + v : v;
+            }
+        }
+    }
+}
+
+// Forward split-K finish: C[m*ldc+n] = act(alpha * sum_s P[s][m][n] + bias[n] + R[m*ldr+n])
+__global__ void splitk_finish_kernel(const float* __restrict__ P, int S, int M, int N, float* __restrict__ C, int ldc,
+                                     const float* __restrict__ bias, const float* __restrict__ R, int ldr, float alpha,
+                                     int relu) {
     const long long total = (long long)M * N;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const int m = (int)(i / N), n = (int)(i - (long long)m * N);
-        const int tap = m / Cin, ci = m - tap * Cin;
-        if (ci >= CinValid) continue;
         float s = 0.f;
         for (int k = 0; k < S; ++k) s += P[(long long)k * total + i];
-        const long long o = ((long long)n * CinValid + ci) * taps + tap;
-        dst[o] = accumulate ? dst[o] + s : s;
+        s *= alpha;
+        if (bias != nullptr) s += bias[n];
+        if (R != nullptr) s += R[(long long)m * ldr + n];
+        if (relu) s = fmaxf(s, 0.f);
+        C[(long long)m * ldc + n] = s;
     }
 }
 
@@ -439,6 +483,7 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
     int bm = 128, bn = 128;
     if (d->tile == 1) { bm = 128; bn = 64; }
     else if (d->tile == 2) { bm = 64; bn = 64; }
+    else if (d->tile == 3) { bm = 128; bn = 32; }
     else if (d->tile != 0) return RIH_EINVAL;
     const long long tiles = (long long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn);
     const long long gz = (long long)d->nb1 * d->nb2 * d->splitk;
@@ -447,16 +492,27 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (d->tile == 0) return launch_tile<128, 128>(a, d->a_mode, d->b_mode, grid, s);
     if (d->tile == 1) return launch_tile<128, 64>(a, d->a_mode, d->b_mode, grid, s);
+    if (d->tile == 3) return launch_tile<128, 32>(a, d->a_mode, d->b_mode, grid, s);
     return launch_tile<64, 64>(a, d->a_mode, d->b_mode, grid, s);
 }
 
 extern "C" int rih_splitk_reduce(const float* P, int S, int M, int N, float* dst, int Cin, int taps, int CinValid,
                                  int accumulate, void* stream) {
     if (!P || !dst || S < 1 || M < 1 || N < 1 || Cin < 1 || taps < 1 || CinValid < 1) return RIH_EINVAL;
+    const long long blocks = (long long)((M + 31) / 32) * ((N + 31) / 32);
+    if (blocks > 0x7fffffffLL) return RIH_EINVAL;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P, S, M, N, dst,
+                       Cin, taps, CinValid, accumulate);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rih_splitk_finish(const float* P, int S, int M, int N, float* C, int ldc, const float* bias,
+                                 const float* R, int ldr, float alpha, int relu, void* stream) {
+    if (!P || !C || S < 1 || M < 1 || N < 1 || ldc < N || (R && ldr < N)) return RIH_EINVAL;
     const long long total = (long long)M * N;
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, S, M, N, dst, Cin,
-                       taps, CinValid, accumulate);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, S, M, N, C, ldc, bias, R,
+                       ldr, alpha, relu);
     return (int)hipGetLastError();
 }
 

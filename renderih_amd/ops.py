@@ -44,7 +44,9 @@ def _cdiv(a, b):
 
 # --------------------------------------------------------------------------------------------- GEMM plumbing
 def pick_tile(M, N, batch=1):
-    """0: 128x128, 1: 128x64, 2: 64x64 -- fill 256 CUs (x ~3 resident blocks) before growing the tile."""
+    """0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32 -- fill 256 CUs (x ~3 resident blocks) before growing the tile."""
+    if N <= 32:
+        return 3
     if N <= 64:
         return 1 if _cdiv(M, 128) * batch >= 384 else 2
     if _cdiv(M, 128) * _cdiv(N, 128) * batch >= 384:
@@ -52,7 +54,7 @@ def pick_tile(M, N, batch=1):
     return 2
 
 
-_TILE_MN = {0: (128, 128), 1: (128, 64), 2: (64, 64)}
+_TILE_MN = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32)}
 
 # When set to a list, every rih_gemm launch is bracketed by HIP events on the launch stream and
 # (flops, start, end, tag) is appended -- bench.py uses this for the live roofline measurement.
@@ -84,6 +86,22 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
         geom = (1, 1, cin, 1, 1, 1, 1, 1, 1, 0, 0)
     (d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.strideA, d.upS, d.padH, d.padW) = geom
     d.tile = pick_tile(M, N, nb1 * nb2 * splitk) if tile is None else tile
+    if splitk == 1 and nb1 * nb2 == 1 and K >= 1024 and not isinstance(Cout, int):
+        # few output tiles but a long reduction (e.g. the 4x4 patch conv: 64 tiles, K=4096): split K over
+        # workgroups and finish (bias / residual / ReLU) in a second pass
+        bm, bn = _TILE_MN[d.tile]
+        tiles = _cdiv(M, bm) * _cdiv(N, bn)
+        if tiles < 128:
+            sk = min(_cdiv(K, 256), _cdiv(256, tiles))
+            if sk > 1:
+                kc = _cdiv(_cdiv(K, sk), 32) * 32
+                sk = _cdiv(K, kc)
+                part = torch.empty((sk, M, N), device=Cout.device, dtype=torch.float32)
+                gemm(A, B, part, M, N, K, lda, ldb, N, a_mode=a_mode, b_mode=b_mode, splitk=sk, kchunk=kc,
+                     sCsplit=M * N, geom=geom, tile=d.tile)
+                check(_L().rih_splitk_finish(part.data_ptr(), sk, M, N, d.C, ldc, d.bias or 0, d.R or 0, ldr,
+                                             alpha, 1 if relu else 0, _stream()), 'rih_splitk_finish')
+                return
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -96,7 +114,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
 
 def _wgrad(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid):
     """dw (parameter layout) = im2col(x)^T @ dy with split-K over the Kpix pixels."""
-    tile = 2 if (Ncols <= 64 or Mrows <= 64) else 0
+    tile = 3 if Ncols <= 32 else (2 if (Ncols <= 64 or Mrows <= 64) else 0)
     bm, bn = _TILE_MN[tile]
     tiles = _cdiv(Mrows, bm) * _cdiv(Ncols, bn)
     splitk = max(1, min(1024 // max(tiles, 1), _cdiv(Kpix, 128)))
@@ -453,6 +471,44 @@ def layernorm(x, g, b, eps=1e-6, x2=None, relu=False):
     return LayerNormFn.apply(x, x2, g, b, eps, relu)
 
 
+def _attn_forward(q, q_ld, k, v, kv_ld, B, Sq, Sk, D, heads, drop_p, seed, device):
+    """q/k/v: raw device pointers to the first element of [B,S,*] slices with row pitch q_ld / kv_ld."""
+    d = D // heads
+    ldP = _cdiv(Sk, 4) * 4
+    alpha = 1.0 / math.sqrt(d)
+    P = torch.empty((B, heads, Sq, ldP), device=device, dtype=torch.float32)
+    gemm(q, k, P, Sq, Sk, d, q_ld, kv_ld, ldP, a_mode=0, b_mode=1, nb1=B, nb2=heads, sA=(Sq * q_ld, d),
+         sB=(Sk * kv_ld, d), sC=(heads * Sq * ldP, Sq * ldP), alpha=alpha)
+    Pd = torch.empty_like(P) if drop_p > 0 else P
+    check(_L().rih_softmax_fwd(P.data_ptr(), P.data_ptr(), Pd.data_ptr(), B * heads * Sq, Sk, ldP, drop_p, seed,
+                               _stream()), 'rih_softmax_fwd')
+    out = torch.empty((B, Sq, D), device=device, dtype=torch.float32)
+    gemm(Pd, v, out, Sq, d, Sk, ldP, kv_ld, D, a_mode=0, b_mode=0, nb1=B, nb2=heads,
+         sA=(heads * Sq * ldP, Sq * ldP), sB=(Sk * kv_ld, d), sC=(Sq * D, d))
+    return out, P, (Pd if drop_p > 0 else None)
+
+
+def _attn_backward(do, q, q_ld, k, v, kv_ld, dq, dq_ld, dk, dv, dkv_ld, P, Pd, B, Sq, Sk, D, heads, drop_p, seed):
+    """Writes dq / dk / dv (raw pointers, row pitches dq_ld / dkv_ld) given do [B,Sq,D] (contiguous tensor)."""
+    if Pd is None:
+        Pd = P
+    d = D // heads
+    ldP = P.shape[-1]
+    alpha = 1.0 / math.sqrt(d)
+    sP = (heads * Sq * ldP, Sq * ldP)
+    dS = torch.empty_like(P)
+    gemm(do, v, dS, Sq, Sk, d, D, kv_ld, ldP, a_mode=0, b_mode=1, nb1=B, nb2=heads, sA=(Sq * D, d),
+         sB=(Sk * kv_ld, d), sC=sP)
+    check(_L().rih_softmax_bwd(P.data_ptr(), dS.data_ptr(), B * heads * Sq, Sk, ldP, drop_p, seed, alpha,
+                               _stream()), 'rih_softmax_bwd')
+    gemm(dS, k, dq, Sq, d, Sk, ldP, kv_ld, dq_ld, a_mode=0, b_mode=0, nb1=B, nb2=heads, sA=sP, sB=(Sk * kv_ld, d),
+         sC=(Sq * dq_ld, d))
+    gemm(dS, q, dk, Sk, d, Sq, ldP, q_ld, dkv_ld, a_mode=1, b_mode=0, nb1=B, nb2=heads, sA=sP, sB=(Sq * q_ld, d),
+         sC=(Sk * dkv_ld, d))
+    gemm(Pd, do, dv, Sk, d, Sq, ldP, D, dkv_ld, a_mode=1, b_mode=0, nb1=B, nb2=heads, sA=sP, sB=(Sq * D, d),
+         sC=(Sk * dkv_ld, d))
+
+
 class AttentionFn(torch.autograd.Function):
     """softmax(q k^T / sqrt(d)) [dropout] v over `heads` heads; q [B,Sq,D], k/v [B,Sk,D] (heads split the last dim).
     QK^T / PV and their gradients are batched (batch x head) fp32-MFMA GEMMs reading the head slices in place; the
@@ -464,20 +520,9 @@ class AttentionFn(torch.autograd.Function):
         q, k, v = _c(q), _c(k), _c(v)
         B, Sq, D = q.shape
         Sk = k.shape[1]
-        d = D // heads
-        ldP = _cdiv(Sk, 4) * 4
-        alpha = 1.0 / math.sqrt(d)
-        lib = _L()
-        P = torch.empty((B, heads, Sq, ldP), device=q.device, dtype=torch.float32)
-        gemm(q, k, P, Sq, Sk, d, D, D, ldP, a_mode=0, b_mode=1, nb1=B, nb2=heads, sA=(Sq * D, d), sB=(Sk * D, d),
-             sC=(heads * Sq * ldP, Sq * ldP), alpha=alpha)
-        Pd = torch.empty_like(P) if drop_p > 0 else P
-        check(lib.rih_softmax_fwd(P.data_ptr(), P.data_ptr(), Pd.data_ptr(), B * heads * Sq, Sk, ldP, drop_p, seed,
-                                  _stream()), 'rih_softmax_fwd')
-        out = torch.empty((B, Sq, D), device=q.device, dtype=torch.float32)
-        gemm(Pd, v, out, Sq, d, Sk, ldP, D, D, a_mode=0, b_mode=0, nb1=B, nb2=heads,
-             sA=(heads * Sq * ldP, Sq * ldP), sB=(Sk * D, d), sC=(Sq * D, d))
-        ctx.save_for_backward(q, k, v, P, Pd if drop_p > 0 else None)
+        out, P, Pd = _attn_forward(q.data_ptr(), D, k.data_ptr(), v.data_ptr(), D, B, Sq, Sk, D, heads, drop_p, seed,
+                                   q.device)
+        ctx.save_for_backward(q, k, v, P, Pd)
         ctx.cfg = (heads, drop_p, seed)
         return out
 
@@ -485,34 +530,92 @@ class AttentionFn(torch.autograd.Function):
     def backward(ctx, do):
         q, k, v, P, Pd = ctx.saved_tensors
         heads, drop_p, seed = ctx.cfg
-        if Pd is None:
-            Pd = P
         do = _c(do)
         B, Sq, D = q.shape
         Sk = k.shape[1]
-        d = D // heads
-        ldP = P.shape[-1]
-        alpha = 1.0 / math.sqrt(d)
-        sP = (heads * Sq * ldP, Sq * ldP)
-        dS = torch.empty_like(P)
-        gemm(do, v, dS, Sq, Sk, d, D, D, ldP, a_mode=0, b_mode=1, nb1=B, nb2=heads, sA=(Sq * D, d), sB=(Sk * D, d),
-             sC=sP)
-        check(_L().rih_softmax_bwd(P.data_ptr(), dS.data_ptr(), B * heads * Sq, Sk, ldP, drop_p, seed, alpha,
-                                   _stream()), 'rih_softmax_bwd')
-        dq = torch.empty_like(q)
-        dk = torch.empty_like(k)
-        dv = torch.empty_like(v)
-        gemm(dS, k, dq, Sq, d, Sk, ldP, D, D, a_mode=0, b_mode=0, nb1=B, nb2=heads, sA=sP, sB=(Sk * D, d),
-             sC=(Sq * D, d))
-        gemm(dS, q, dk, Sk, d, Sq, ldP, D, D, a_mode=1, b_mode=0, nb1=B, nb2=heads, sA=sP, sB=(Sq * D, d),
-             sC=(Sk * D, d))
-        gemm(Pd, do, dv, Sk, d, Sq, ldP, D, D, a_mode=1, b_mode=0, nb1=B, nb2=heads, sA=sP, sB=(Sq * D, d),
-             sC=(Sk * D, d))
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        _attn_backward(do, q.data_ptr(), D, k.data_ptr(), v.data_ptr(), D, dq.data_ptr(), D, dk.data_ptr(),
+                       dv.data_ptr(), D, P, Pd, B, Sq, Sk, D, heads, drop_p, seed)
         return dq, dk, dv, None, None, None
 
 
 def attention(q, k, v, heads, drop_p=0.0, seed=0):
     return AttentionFn.apply(q, k, v, heads, drop_p, seed)
+
+
+class SelfAttentionPackedFn(torch.autograd.Function):
+    """Self attention on a packed projection qkv [B,S,3D] (columns [q | k | v], the output of one fused QKV GEMM);
+    head slices are read in place with row pitch 3D and the gradient is written straight into one [B,S,3D] buffer."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, drop_p, seed):
+        _chk(qkv)
+        qkv = _c(qkv)
+        B, S, D3 = qkv.shape
+        D = D3 // 3
+        p0 = qkv.data_ptr()
+        out, P, Pd = _attn_forward(p0, D3, p0 + 4 * D, p0 + 8 * D, D3, B, S, S, D, heads, drop_p, seed, qkv.device)
+        ctx.save_for_backward(qkv, P, Pd)
+        ctx.cfg = (heads, drop_p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, P, Pd = ctx.saved_tensors
+        heads, drop_p, seed = ctx.cfg
+        do = _c(do)
+        B, S, D3 = qkv.shape
+        D = D3 // 3
+        dqkv = torch.empty_like(qkv)
+        p0, g0 = qkv.data_ptr(), dqkv.data_ptr()
+        _attn_backward(do, p0, D3, p0 + 4 * D, p0 + 8 * D, D3, g0, D3, g0 + 4 * D, g0 + 8 * D, D3, P, Pd, B, S, S, D,
+                       heads, drop_p, seed)
+        return dqkv, None, None, None
+
+
+def self_attention_packed(qkv, heads, drop_p=0.0, seed=0):
+    return SelfAttentionPackedFn.apply(qkv, heads, drop_p, seed)
+
+
+class CrossAttentionPackedFn(torch.autograd.Function):
+    """The cross-hand attention pair of inter_attn.py:93-107 on packed projections Lqkv, Rqkv [B,V,3D]:
+    feat_R2L = softmax(Lq Rk^T / sqrt(d)) Rv,  feat_L2R = softmax(Rq Lk^T / sqrt(d)) Lv.
+    One autograd node so that each packed gradient buffer is written exactly once (q part by one direction, k/v part
+    by the other)."""
+
+    @staticmethod
+    def forward(ctx, Lqkv, Rqkv, heads, drop_p, seed_r2l, seed_l2r):
+        _chk(Lqkv, Rqkv)
+        Lqkv, Rqkv = _c(Lqkv), _c(Rqkv)
+        B, V, D3 = Lqkv.shape
+        D = D3 // 3
+        l0, r0 = Lqkv.data_ptr(), Rqkv.data_ptr()
+        o_r2l, P1, Pd1 = _attn_forward(l0, D3, r0 + 4 * D, r0 + 8 * D, D3, B, V, V, D, heads, drop_p, seed_r2l, Lqkv.device)
+        o_l2r, P2, Pd2 = _attn_forward(r0, D3, l0 + 4 * D, l0 + 8 * D, D3, B, V, V, D, heads, drop_p, seed_l2r, Lqkv.device)
+        ctx.save_for_backward(Lqkv, Rqkv, P1, Pd1, P2, Pd2)
+        ctx.cfg = (heads, drop_p, seed_r2l, seed_l2r)
+        return o_r2l, o_l2r
+
+    @staticmethod
+    def backward(ctx, d_r2l, d_l2r):
+        Lqkv, Rqkv, P1, Pd1, P2, Pd2 = ctx.saved_tensors
+        heads, drop_p, seed_r2l, seed_l2r = ctx.cfg
+        d_r2l, d_l2r = _c(d_r2l), _c(d_l2r)
+        B, V, D3 = Lqkv.shape
+        D = D3 // 3
+        dL, dR = torch.empty_like(Lqkv), torch.empty_like(Rqkv)
+        l0, r0, gl, gr = Lqkv.data_ptr(), Rqkv.data_ptr(), dL.data_ptr(), dR.data_ptr()
+        # R2L: q from L, k/v from R
+        _attn_backward(d_r2l, l0, D3, r0 + 4 * D, r0 + 8 * D, D3, gl, D3, gr + 4 * D, gr + 8 * D, D3, P1, Pd1, B, V, V, D,
+                       heads, drop_p, seed_r2l)
+        # L2R: q from R, k/v from L
+        _attn_backward(d_l2r, r0, D3, l0 + 4 * D, l0 + 8 * D, D3, gr, D3, gl + 4 * D, gl + 8 * D, D3, P2, Pd2, B, V, V, D,
+                       heads, drop_p, seed_l2r)
+        return dL, dR, None, None, None, None
+
+
+def cross_attention_packed(Lqkv, Rqkv, heads, drop_p=0.0, seed_r2l=0, seed_l2r=0):
+    return CrossAttentionPackedFn.apply(Lqkv, Rqkv, heads, drop_p, seed_r2l, seed_l2r)
 
 
 class AddDropoutFn(torch.autograd.Function):

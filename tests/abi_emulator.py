@@ -123,6 +123,18 @@ class EmulatedLib:
             out[o] = (out[o] if accumulate else 0) + p[ok, n]
         return 0
 
+    def rih_splitk_finish(self, P, S, M, N, Cp, ldc, bias, R, ldr, alpha, relu, stream):
+        out = np.float32(alpha) * _f(P, S * M * N).reshape(S, M, N).sum(0)
+        cm, cn = np.meshgrid(np.arange(M), np.arange(N), indexing='ij')
+        if bias:
+            out = out + _f(bias, N)[None, :]
+        if R:
+            out = out + _f(R, (M - 1) * ldr + N)[(cm * ldr + cn).ravel()].reshape(M, N)
+        if relu:
+            out = np.maximum(out, 0)
+        _f(Cp, (M - 1) * ldc + N)[(cm * ldc + cn).ravel()] = out.astype(np.float32).ravel()
+        return 0
+
     def rih_pack_conv_weight(self, w, dst, Cout, Cin, KH, KW, CinPad, for_dgrad, stream):
         W = _f(w, Cout * Cin * KH * KW).reshape(Cout, Cin, KH * KW)
         Wp = np.zeros((Cout, CinPad, KH * KW), np.float32)
