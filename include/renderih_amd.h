@@ -74,8 +74,9 @@ int rih_gemm(const rih_gemm_desc* d, void* stream);
 
 /* Sum split-K partials P[S][M][N] (M = taps*Cin rows ordered (tap,ci)) into a weight gradient laid out
  * like the parameter: dst[(n*CinValid + ci)*taps + tap]  (OIHW for convs, [out][in] for nn.Linear).
- * Rows with ci >= CinValid (channel padding) are dropped.  accumulate!=0 adds to dst. */
-int rih_splitk_reduce(const float* P, int S, int M, int N, float* dst, int Cin, int taps, int CinValid,
+ * Rows with ci >= CinValid (channel padding) are dropped.  accumulate!=0 adds to dst.
+ * P is scratch: slab 0 is overwritten with the sum. */
+int rih_splitk_reduce(float* P, int S, int M, int N, float* dst, int Cin, int taps, int CinValid,
                       int accumulate, void* stream);
 
 /* Finish a forward split-K GEMM: C[m*ldc+n] = act(alpha * sum_s P[s][m][n] + bias[n] + R[m*ldr+n]). */

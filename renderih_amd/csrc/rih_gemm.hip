@@ -378,25 +378,32 @@ int launch_tile(const GemmArgs& a, int a_mode, int b_mode, dim3 grid, hipStream_
     return launch_tile_v<BM, BN, false>(a, a_mode, b_mode, grid, s);
 }
 
-// Sum S split-K partials P[S][M][N] and store in parameter layout dst[(n*CinValid + ci)*taps + tap], m = tap*Cin + ci.
-// 32x32 tiles go through LDS so that both the partial reads (along n) and the stores (along ci) are coalesced.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ P, int S, int M, int N,
-                                                            float* __restrict__ dst, int Cin, int taps, int CinValid,
-                                                            int accumulate) {
+// Split-K reduction for weight gradients, two coalesced passes:
+//   1. sum the S partial slabs into slab 0 (in place; linear, float4 where possible),
+//   2. transpose slab 0 [M][N] (m = tap*Cin + ci) into the parameter layout dst[(n*CinValid + ci)*taps + tap]
+//      through 32x32 LDS tiles, so reads run along n and stores along ci.
+__global__ void splitk_sum_kernel(float* __restrict__ P, int S, long long MN) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < MN;
+         i += (long long)gridDim.x * blockDim.x) {
+        float s0 = 0.f, s1 = 0.f;
+        int k = 0;
+        for (; k + 1 < S; k += 2) { s0 += P[(long long)k * MN + i]; s1 += P[(long long)(k + 1) * MN + i]; }
+        if (k < S) s0 += P[(long long)k * MN + i];
+        P[i] = s0 + s1;
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_transpose_kernel(const float* __restrict__ P, int M, int N,
+                                                               float* __restrict__ dst, int Cin, int taps,
+                                                               int CinValid, int accumulate) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // ty in 0..7
     const int tilesN = (N + 31) / 32;
     const int m0 = (blockIdx.x / tilesN) * 32, n0 = (blockIdx.x % tilesN) * 32;
-    const long long MN = (long long)M * N;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + ty + 8 * i, n = n0 + tx;
-        float s = 0.f;
-        if (m < M && n < N) {
-            const float* p = P + (long long)m * N + n;
-            for (int k = 0; k < S; ++k) s += p[(long long)k * MN];
-        }
-        tile[ty + 8 * i][tx] = s;
+        tile[ty + 8 * i][tx] = (m < M && n < N) ? P[(long long)m * N + n] : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -496,12 +503,17 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
     return launch_tile<64, 64>(a, d->a_mode, d->b_mode, grid, s);
 }
 
-extern "C" int rih_splitk_reduce(const float* P, int S, int M, int N, float* dst, int Cin, int taps, int CinValid,
+extern "C" int rih_splitk_reduce(float* P, int S, int M, int N, float* dst, int Cin, int taps, int CinValid,
                                  int accumulate, void* stream) {
     if (!P || !dst || S < 1 || M < 1 || N < 1 || Cin < 1 || taps < 1 || CinValid < 1) return RIH_EINVAL;
+    const long long MN = (long long)M * N;
+    if (S > 1) {
+        const int sb = (int)((MN + 255) / 256 < 8192 ? (MN + 255) / 256 : 8192);
+        hipLaunchKernelGGL(splitk_sum_kernel, dim3(sb), dim3(256), 0, (hipStream_t)stream, P, S, MN);
+    }
     const long long blocks = (long long)((M + 31) / 32) * ((N + 31) / 32);
     if (blocks > 0x7fffffffLL) return RIH_EINVAL;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P, S, M, N, dst,
+    hipLaunchKernelGGL(splitk_transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P, M, N, dst,
                        Cin, taps, CinValid, accumulate);
     return (int)hipGetLastError();
 }

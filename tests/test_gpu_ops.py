@@ -348,3 +348,39 @@ def test_cheby_gather_project():
     yg.backward(gy.to(d))
     for name, a, b in zip(('dv', 'dscale', 'dtrans'), tg, ts):
         assert_close(a.grad, b.grad, 1e-4, 1e-5, 'project ' + name)
+
+
+@pytest.mark.parametrize('B,S,D,h', [(2, 64, 256, 4), (2, 190, 128, 4), (2, 316, 64, 4)])
+def test_self_attention_packed(B, S, D, h):
+    from renderih_amd import ops
+    qkv = rnd(B, S, 3 * D, seed=1)
+    t = qkv.clone().requires_grad_(True)
+    yr, _ = _mha_ref(t[..., :D].contiguous(), t[..., D:2 * D].contiguous(), t[..., 2 * D:].contiguous(), h)
+    gy = rnd(B, S, D, seed=2)
+    yr.backward(gy)
+    d = dev()
+    g = qkv.to(d).clone().requires_grad_(True)
+    yg = ops.self_attention_packed(g, h)
+    assert_close(yg, yr, what='packed self-attn out')
+    yg.backward(gy.to(d))
+    assert_close(g.grad, t.grad, 1e-3, 1e-4, 'packed self-attn dqkv')
+
+
+@pytest.mark.parametrize('B,V,D,h', [(2, 63, 256, 4), (2, 252, 64, 4)])
+def test_cross_attention_packed(B, V, D, h):
+    from renderih_amd import ops
+    L, R = rnd(B, V, 3 * D, seed=1), rnd(B, V, 3 * D, seed=2)
+    tl, tr = L.clone().requires_grad_(True), R.clone().requires_grad_(True)
+    sl = lambda t, i: t[..., i * D:(i + 1) * D].contiguous()
+    r2l, _ = _mha_ref(sl(tl, 0), sl(tr, 1), sl(tr, 2), h)
+    l2r, _ = _mha_ref(sl(tr, 0), sl(tl, 1), sl(tl, 2), h)
+    g1, g2 = rnd(B, V, D, seed=3), rnd(B, V, D, seed=4)
+    ((r2l * g1).sum() + (l2r * g2).sum()).backward()
+    d = dev()
+    gl, gr = L.to(d).clone().requires_grad_(True), R.to(d).clone().requires_grad_(True)
+    a, b = ops.cross_attention_packed(gl, gr, h)
+    assert_close(a, r2l, what='cross R2L')
+    assert_close(b, l2r, what='cross L2R')
+    ((a * g1.to(d)).sum() + (b * g2.to(d)).sum()).backward()
+    assert_close(gl.grad, tl.grad, 1e-3, 1e-4, 'cross dL')
+    assert_close(gr.grad, tr.grad, 1e-3, 1e-4, 'cross dR')

@@ -1,0 +1,99 @@
+#!/usr/bin/env python
+"""Micro-benchmark of rih_gemm on the shapes that dominate a training step (from profiles/*/gemm_profile*.json):
+every tile configuration per shape, HIP-event timed over a batch of launches.  Run on the GPU box:
+    python tools/gemm_bench.py > gpurun_out/gemm_bench.log"""
+import os
+import sys
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from renderih_amd import ops  # noqa: E402
+
+dev = torch.device('cuda:0')
+
+
+def time_launch(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1000.0      # us
+
+
+def conv_fwd(N, H, W, Cin, Cout, k, s, p, tiles=(0, 1, 2)):
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = torch.randn(N, H, W, Cin, device=dev)
+    wp = torch.randn(k * k * Cin, Cout, device=dev)
+    y = torch.empty(N, Ho, Wo, Cout, device=dev)
+    M, K = N * Ho * Wo, k * k * Cin
+    geom = (H, W, Cin, Ho, Wo, k, k, s, 1, p, p)
+    out = []
+    for t in tiles:
+        us = time_launch(lambda: ops.gemm(x, wp, y, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=t))
+        out.append('t%d %7.1fus %6.1fTF' % (t, us, 2.0 * M * Cout * K / us / 1e6))
+    print('conv fwd  N%d %dx%d Cin%d Cout%d k%d s%d | M%d N%d K%d | %s' % (N, H, W, Cin, Cout, k, s, M, Cout, K, '  '.join(out)), flush=True)
+
+
+def wgrad(N, H, W, Cin, Cout, k, s, p, splits=(None,), tiles=(0, 2)):
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = torch.randn(N, H, W, Cin, device=dev)
+    dy = torch.randn(N, Ho, Wo, Cout, device=dev)
+    Kpix, Mrows = N * Ho * Wo, k * k * Cin
+    geom = (H, W, Cin, Ho, Wo, k, k, s, 1, p, p)
+    out = []
+    for t in tiles:
+        bm, bn = ops._TILE_MN[t]
+        ntiles = -(-Mrows // bm) * -(-Cout // bn)
+        for target in (256, 512, 1024, 2048):
+            sk = max(1, min(target // max(ntiles, 1), -(-Kpix // 128)))
+            kc = -(-(-(-Kpix // sk)) // 32) * 32
+            sk = -(-Kpix // kc)
+            part = torch.empty(sk, Mrows, Cout, device=dev)
+            us = time_launch(lambda: ops.gemm(x, dy, part, Mrows, Cout, Kpix, Cin, Cout, Cout, a_mode=1, b_mode=0,
+                                              splitk=sk, kchunk=kc, sCsplit=Mrows * Cout, geom=geom, tile=t) if sk > 1 else
+                             ops.gemm(x, dy, part, Mrows, Cout, Kpix, Cin, Cout, Cout, a_mode=1, b_mode=0, geom=geom, tile=t))
+            out.append('t%d sk%3d %6.1fus %5.1fTF' % (t, sk, us, 2.0 * Mrows * Cout * Kpix / us / 1e6))
+    print('wgrad N%d %dx%d Cin%d Cout%d k%d s%d | M%d N%d K%d | %s' % (N, H, W, Cin, Cout, k, s, Mrows, Cout, Kpix, ' | '.join(out)), flush=True)
+
+
+def linear_fwd(M, K, Nf, tiles=(0, 1, 2, 3)):
+    x = torch.randn(M, K, device=dev)
+    w = torch.randn(Nf, K, device=dev)
+    y = torch.empty(M, Nf, device=dev)
+    out = []
+    for t in tiles:
+        bm, bn = ops._TILE_MN[t]
+        if bn < 64 and Nf > 64:
+            continue
+        us = time_launch(lambda: ops.gemm(x, w, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, tile=t))
+        out.append('t%d %6.1fus %5.1fTF' % (t, us, 2.0 * M * Nf * K / us / 1e6))
+    print('linear M%d K%d N%d | %s' % (M, K, Nf, '  '.join(out)), flush=True)
+
+
+if __name__ == '__main__':
+    B = 64
+    conv_fwd(B, 64, 64, 128, 128, 3, 1, 1)        # aux decoder 64x64 stage
+    conv_fwd(B, 64, 64, 64, 64, 3, 1, 1)          # layer1 3x3
+    conv_fwd(B, 32, 32, 128, 128, 3, 1, 1)
+    conv_fwd(B, 16, 16, 256, 256, 3, 1, 1)
+    conv_fwd(B, 8, 8, 512, 512, 3, 1, 1)
+    conv_fwd(B, 64, 64, 256, 64, 1, 1, 0)
+    conv_fwd(B, 64, 64, 64, 256, 1, 1, 0)
+    conv_fwd(B, 16, 16, 1024, 256, 1, 1, 0)
+    conv_fwd(B, 8, 8, 2048, 512, 1, 1, 0)
+    conv_fwd(B, 64, 64, 512, 256, 1, 1, 0)
+    wgrad(B, 32, 32, 128, 128, 3, 1, 1)
+    wgrad(B, 64, 64, 64, 64, 3, 1, 1)
+    wgrad(B, 16, 16, 256, 256, 3, 1, 1)
+    wgrad(B, 8, 8, 512, 512, 3, 1, 1)
+    wgrad(B, 16, 16, 1024, 256, 1, 1, 0)
+    wgrad(B * 63, 1, 1, 256, 256, 1, 1, 0)        # decoder linear weight grad
+    wgrad(B * 252, 1, 1, 64, 64, 1, 1, 0)
+    for M, K, Nf in ((4032, 256, 256), (4032, 512, 256), (8064, 128, 128), (16128, 64, 64), (8128, 256, 768),
+                     (20224, 64, 192), (4096, 256, 768)):
+        linear_fwd(M, K, Nf)

@@ -23,3 +23,6 @@ find /tmp/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof/ \;
 find /tmp/prof -type f | head -20 >> gpurun_out/prof.log
 ls -la gpurun_out/prof
 fi
+if [ "${GEMMBENCH}" = "1" ]; then
+timeout 600 python tools/gemm_bench.py > gpurun_out/gemm_bench.log 2>&1; tail -3 gpurun_out/gemm_bench.log
+fi
