@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     // ------------------------------------------------------------------ A loader state
     // AMODE 0: thread -> (row = tid/8 (+32 per pass), k-quad = tid%8)
     // AMODE 1: thread -> (k-row = tid/(BM/4) (+256/(BM/4) per pass), m-quad = tid%(BM/4))
-    long long a_base[NPA];
-    int a_hi0[NPA], a_wi0[NPA];
+    unsigned a_base[NPA];           // element offset of the row's image (host guarantees the A extent < 2^31)
+    int a_hw0[NPA];                 // packed (hi0 | wi0 << 16), hi0/wi0 = top-left input coordinate of the row's window
     int a_kh, a_kw, a_ci;           // AMODE 0: running (kh,kw,ci) of this thread's k-quad; AMODE 1: fixed tap of m-quad
     int a_mvalid = 0;               // AMODE 1: number of valid elements in this thread's m-quad (0..4)
     constexpr int QA = BM / 4, RA = 256 / QA;
@@ -98,13 +98,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 const int t = m / p.Wo;
                 const int ho = t % p.Ho;
                 const int img = t / p.Ho;
-                a_base[i] = (long long)img * p.H * p.W * p.lda;
-                a_hi0[i] = ho * p.strideA - p.padH;
-                a_wi0[i] = wo * p.strideA - p.padW;
+                a_base[i] = (unsigned)img * (unsigned)(p.H * p.W) * (unsigned)p.lda;
+                const int hi0 = ho * p.strideA - p.padH, wi0 = wo * p.strideA - p.padW;
+                a_hw0[i] = (hi0 & 0xffff) | (wi0 << 16);
             } else {
                 a_base[i] = 0;
-                a_hi0[i] = -(1 << 28);
-                a_wi0[i] = -(1 << 28);
+                a_hw0[i] = (int)0x80008000;     // hi0 = wi0 = -32768: never in range
             }
         }
         const int kg = kbeg + aq * 4;
@@ -121,7 +120,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         a_kw = tap - a_kh * p.KW;
         a_mvalid = max(0, min(4, p.M - mm));
 #pragma unroll
-        for (int i = 0; i < NPA; ++i) { a_base[i] = 0; a_hi0[i] = 0; a_wi0[i] = 0; }
+        for (int i = 0; i < NPA; ++i) { a_base[i] = 0; a_hw0[i] = 0; }
     }
 
     // Loads are branch-free: every lane always issues its loads (an invalid element reads a safe in-bounds dummy
@@ -159,7 +158,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             const unsigned kbits = (a_kh < p.KH) ? first_bits(p.Cin - a_ci) : 0u;
 #pragma unroll
             for (int i = 0; i < NPA; ++i) {
-                int hi = a_hi0[i] + a_kh, wi = a_wi0[i] + a_kw;
+                int hi = (int)(short)(a_hw0[i] & 0xffff) + a_kh, wi = (a_hw0[i] >> 16) + a_kw;
                 bool ok = (hi >= 0) && (wi >= 0) && (kbits != 0u);
                 if (p.upS > 1) {
                     ok = ok && (hi % p.upS == 0) && (wi % p.upS == 0);
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 }
                 ok = ok && (hi < p.H) && (wi < p.W);
                 const unsigned bits = ok ? kbits : 0u;
-                const long long off = ok ? (a_base[i] + ((long long)hi * p.W + wi) * p.lda + a_ci) : 0ll;
+                const unsigned off = ok ? (a_base[i] + (unsigned)(hi * p.W + wi) * (unsigned)p.lda + (unsigned)a_ci) : 0u;
                 areg[i] = ld4(A + off, bits);
                 amask |= bits << (4 * i);
             }
@@ -187,7 +186,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 const int wi = wo * p.strideA - p.padW + a_kw;
                 const bool ok = (k < kend) && (mbits != 0u) && hi >= 0 && wi >= 0 && hi < p.H && wi < p.W;
                 const unsigned bits = ok ? mbits : 0u;
-                const long long off = ok ? (((long long)(img * p.H + hi) * p.W + wi) * p.lda + a_ci) : 0ll;
+                const unsigned off = ok ? ((unsigned)((img * p.H + hi) * p.W + wi) * (unsigned)p.lda + (unsigned)a_ci) : 0u;
                 areg[i] = ld4(A + off, bits);
                 amask |= bits << (4 * i);
             }
@@ -237,7 +236,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             for (int i = 0; i < NPB; ++i) {
                 const int k = ktile + bkr + RB * i;
                 const unsigned bits = (k < kend) ? nbits : 0u;
-                const long long off = bits ? ((long long)k * p.ldb + n) : 0ll;
+                const unsigned off = bits ? ((unsigned)k * (unsigned)p.ldb + (unsigned)n) : 0u;
                 breg[i] = ld4(B + off, bits);
                 bmask |= bits << (4 * i);
             }
@@ -249,7 +248,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             for (int i = 0; i < NPB; ++i) {
                 const int n = n0 + brow + 32 * i;
                 const unsigned bits = (n < p.N) ? kbits : 0u;
-                const long long off = bits ? ((long long)n * p.ldb + k) : 0ll;
+                const unsigned off = bits ? ((unsigned)n * (unsigned)p.ldb + (unsigned)k) : 0u;
                 breg[i] = ld4(B + off, bits);
                 bmask |= bits << (4 * i);
             }
@@ -320,11 +319,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) bv[nxt][j] = b_rd[((kk + 1) * 2) * LDBS + j * 32];
                 }
+                // pin the order: hipcc otherwise sinks the reads next to their MFMAs and exposes the LDS latency
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
@@ -472,6 +474,16 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
         return RIH_EINVAL;
     if (d->a_mode == 1 && d->upS != 1) return RIH_EINVAL;
     if (d->KH * d->KW > 1 && (d->Cin % 4) != 0) return RIH_EINVAL;   // quads must not straddle taps
+    {   // 32-bit element offsets inside one batch slice of A and B; window coordinates packed in 16 bits
+        const long long rowsA = (d->a_mode == 0) ? (long long)d->M : (long long)d->K;
+        const long long imgs = (rowsA + (long long)d->Ho * d->Wo - 1) / ((long long)d->Ho * d->Wo);
+        if (imgs * d->H * d->W * (long long)d->lda >= (1ll << 31)) return RIH_EINVAL;
+        const long long rowsB = (d->b_mode == 0) ? (long long)d->K : (long long)d->N;
+        if (rowsB * (long long)d->ldb >= (1ll << 31)) return RIH_EINVAL;
+        if (d->H > 16000 || d->W > 16000 || d->Ho > 16000 || d->Wo > 16000 || d->strideA > 64 || d->padH > 64 ||
+            d->padW > 64 || d->KH > 64 || d->KW > 64)
+            return RIH_EINVAL;
+    }
     GemmArgs a;
     a.A = d->A; a.B = d->B; a.C = d->C; a.bias = d->bias; a.R = d->R;
     a.M = d->M; a.N = d->N; a.K = d->K;

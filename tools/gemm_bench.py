@@ -77,6 +77,12 @@ def linear_fwd(M, K, Nf, tiles=(0, 1, 2, 3)):
 
 if __name__ == '__main__':
     B = 64
+    if '--quick' in sys.argv:       # a few launches for PMC collection
+        conv_fwd(B, 64, 64, 128, 128, 3, 1, 1, tiles=(0,))
+        conv_fwd(B, 16, 16, 1024, 256, 1, 1, 0, tiles=(0,))
+        wgrad(B, 32, 32, 128, 128, 3, 1, 1, tiles=(0,))
+        linear_fwd(4032, 256, 256, tiles=(2,))
+        sys.exit(0)
     conv_fwd(B, 64, 64, 128, 128, 3, 1, 1)        # aux decoder 64x64 stage
     conv_fwd(B, 64, 64, 64, 64, 3, 1, 1)          # layer1 3x3
     conv_fwd(B, 32, 32, 128, 128, 3, 1, 1)

@@ -26,3 +26,8 @@ fi
 if [ "${GEMMBENCH}" = "1" ]; then
 timeout 600 python tools/gemm_bench.py > gpurun_out/gemm_bench.log 2>&1; tail -3 gpurun_out/gemm_bench.log
 fi
+if [ "${PMC}" = "1" ]; then
+R=$GRAFT_REPO_ROOT
+cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc -o pmc -- python $R/tools/gemm_bench.py --quick > $R/gpurun_out/pmc.log 2>&1
+cd $R; mkdir -p gpurun_out/pmc; find /tmp/pmc -name "*counter_collection*.csv" -exec cp {} gpurun_out/pmc/ \; ; ls -la gpurun_out/pmc; find /tmp/pmc -type f | head >> gpurun_out/pmc.log
+fi
