@@ -68,6 +68,11 @@ typedef struct rih_gemm_desc {
     /* im2col geometry of A (a plain matrix is H=W=Ho=Wo=KH=KW=1, strideA=upS=1, pad=0, Cin=K or M) */
     int32_t H, W, Cin, Ho, Wo, KH, KW, strideA, upS, padH, padW;
     int32_t tile;        /* 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32 */
+    int32_t engine;      /* 0: native f32 MFMA (v_mfma_f32_32x32x2_f32, 157 TF peak);
+                            1: fp32 emulated on the bf16 MFMA pipe: each operand split into three bf16 terms
+                               (hi+mid+lo, 24 significand bits), six v_mfma_f32_32x32x16_bf16 products, fp32
+                               accumulate -- same accuracy as engine 0 (error <= ~2^-23 relative per product),
+                               2.5 PF / 6 = 417 TF peak.  Tiles 0,1,2 only (tile 3 always runs engine 0). */
 } rih_gemm_desc;
 
 int rih_gemm(const rih_gemm_desc* d, void* stream);

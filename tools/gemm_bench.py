@@ -25,6 +25,17 @@ def time_launch(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1000.0      # us
 
 
+def err_vs_fp64(got, A2d, B2d):
+    """max |got - fp64| / max|fp64| and the same for a plain fp32 torch matmul (rocBLAS) as the yardstick."""
+    ref = A2d.double() @ B2d.double()
+    e = float((got.double().view_as(ref) - ref).abs().max() / ref.abs().max())
+    e32 = float(((A2d @ B2d).double() - ref).abs().max() / ref.abs().max())
+    return e, e32
+
+
+ENGINES = (0, 1)
+
+
 def conv_fwd(N, H, W, Cin, Cout, k, s, p, tiles=(0, 1, 2)):
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     x = torch.randn(N, H, W, Cin, device=dev)
@@ -34,8 +45,13 @@ def conv_fwd(N, H, W, Cin, Cout, k, s, p, tiles=(0, 1, 2)):
     geom = (H, W, Cin, Ho, Wo, k, k, s, 1, p, p)
     out = []
     for t in tiles:
-        us = time_launch(lambda: ops.gemm(x, wp, y, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=t))
-        out.append('t%d %7.1fus %6.1fTF' % (t, us, 2.0 * M * Cout * K / us / 1e6))
+        for e in ENGINES:
+            us = time_launch(lambda: ops.gemm(x, wp, y, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=t, engine=e))
+            out.append('t%de%d %7.1fus %6.1fTF' % (t, e, us, 2.0 * M * Cout * K / us / 1e6))
+    if k == 1 and s == 1:
+        for e in ENGINES:
+            ops.gemm(x, wp, y, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=0, engine=e)
+            out.append('e%d err %.1e (fp32 blas %.1e)' % ((e,) + err_vs_fp64(y, x.view(M, K), wp)))
     print('conv fwd  N%d %dx%d Cin%d Cout%d k%d s%d | M%d N%d K%d | %s' % (N, H, W, Cin, Cout, k, s, M, Cout, K, '  '.join(out)), flush=True)
 
 
@@ -54,10 +70,11 @@ def wgrad(N, H, W, Cin, Cout, k, s, p, splits=(None,), tiles=(0, 2)):
             kc = -(-(-(-Kpix // sk)) // 32) * 32
             sk = -(-Kpix // kc)
             part = torch.empty(sk, Mrows, Cout, device=dev)
-            us = time_launch(lambda: ops.gemm(x, dy, part, Mrows, Cout, Kpix, Cin, Cout, Cout, a_mode=1, b_mode=0,
-                                              splitk=sk, kchunk=kc, sCsplit=Mrows * Cout, geom=geom, tile=t) if sk > 1 else
-                             ops.gemm(x, dy, part, Mrows, Cout, Kpix, Cin, Cout, Cout, a_mode=1, b_mode=0, geom=geom, tile=t))
-            out.append('t%d sk%3d %6.1fus %5.1fTF' % (t, sk, us, 2.0 * Mrows * Cout * Kpix / us / 1e6))
+            for e in ENGINES:
+                us = time_launch(lambda: ops.gemm(x, dy, part, Mrows, Cout, Kpix, Cin, Cout, Cout, a_mode=1, b_mode=0,
+                                                  splitk=sk, kchunk=kc, sCsplit=Mrows * Cout, geom=geom, tile=t, engine=e) if sk > 1 else
+                                 ops.gemm(x, dy, part, Mrows, Cout, Kpix, Cin, Cout, Cout, a_mode=1, b_mode=0, geom=geom, tile=t, engine=e))
+                out.append('t%de%d sk%3d %6.1fus %5.1fTF' % (t, e, sk, us, 2.0 * Mrows * Cout * Kpix / us / 1e6))
     print('wgrad N%d %dx%d Cin%d Cout%d k%d s%d | M%d N%d K%d | %s' % (N, H, W, Cin, Cout, k, s, Mrows, Cout, Kpix, ' | '.join(out)), flush=True)
 
 
@@ -70,8 +87,12 @@ def linear_fwd(M, K, Nf, tiles=(0, 1, 2, 3)):
         bm, bn = ops._TILE_MN[t]
         if bn < 64 and Nf > 64:
             continue
-        us = time_launch(lambda: ops.gemm(x, w, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, tile=t))
-        out.append('t%d %6.1fus %5.1fTF' % (t, us, 2.0 * M * Nf * K / us / 1e6))
+        for e in (ENGINES if t != 3 else (0,)):
+            us = time_launch(lambda: ops.gemm(x, w, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, tile=t, engine=e))
+            out.append('t%de%d %6.1fus %5.1fTF' % (t, e, us, 2.0 * M * Nf * K / us / 1e6))
+    for e in ENGINES:
+        ops.gemm(x, w, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, tile=2, engine=e)
+        out.append('e%d err %.1e (fp32 blas %.1e)' % ((e,) + err_vs_fp64(y, x, w.t())))
     print('linear M%d K%d N%d | %s' % (M, K, Nf, '  '.join(out)), flush=True)
 
 
@@ -81,7 +102,6 @@ if __name__ == '__main__':
         conv_fwd(B, 64, 64, 128, 128, 3, 1, 1, tiles=(0,))
         conv_fwd(B, 16, 16, 1024, 256, 1, 1, 0, tiles=(0,))
         wgrad(B, 32, 32, 128, 128, 3, 1, 1, tiles=(0,))
-        linear_fwd(4032, 256, 256, tiles=(2,))
         sys.exit(0)
     conv_fwd(B, 64, 64, 128, 128, 3, 1, 1)        # aux decoder 64x64 stage
     conv_fwd(B, 64, 64, 64, 64, 3, 1, 1)          # layer1 3x3
