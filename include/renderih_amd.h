@@ -67,7 +67,9 @@ typedef struct rih_gemm_desc {
     int32_t relu;
     /* im2col geometry of A (a plain matrix is H=W=Ho=Wo=KH=KW=1, strideA=upS=1, pad=0, Cin=K or M) */
     int32_t H, W, Cin, Ho, Wo, KH, KW, strideA, upS, padH, padW;
-    int32_t tile;        /* 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32 */
+    int32_t tile;        /* 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32 (engine 0 only),
+                            4: 256x128 software-pipelined (engine 1 only; operands must satisfy the split fast-path
+                               preconditions documented at gemm_split_kernel, else RIH_EINVAL) */
     int32_t engine;      /* 0: native f32 MFMA (v_mfma_f32_32x32x2_f32, 157 TF peak);
                             1: fp32 emulated on the bf16 MFMA pipe: each operand split into three bf16 terms
                                (hi+mid+lo, 24 significand bits), six v_mfma_f32_32x32x16_bf16 products, fp32

@@ -65,10 +65,11 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& 
     l = pk_bf16(ra, rb);
 }
 // LDS operand tile of the split engine: per plane [rows][16 dwords] (one row = 32 k as bf16, no padding).  The 16-byte
-// chunk c (8 consecutive k) of logical row m lives at physical row m ^ ((m>>2)&1), chunk c ^ ((m>>2)&3): the b128
+// chunk c (8 consecutive k) of logical row m lives at physical row m ^ ((m>>4)&1), chunk c ^ ((m>>2)&3): the b128
 // operand fetches (one chunk per lane, 32 consecutive rows per half-wave) and the b64 stores of the K-contiguous
-// loaders are bank-conflict free; the transposing (K-strided) loaders pay a 2-way store conflict.
-__device__ __forceinline__ int lds_row(int m) { return (m ^ ((m >> 2) & 1)) * 16; }
+// loaders are bank-conflict free; the transposing (K-strided) loaders, whose 16-lane store groups hit 16 different
+// row-quads at one k-quad, pay the unavoidable 2-way store conflict (8 distinct bank pairs exist for a fixed k-quad).
+__device__ __forceinline__ int lds_row(int m) { return (m ^ ((m >> 4) & 1)) * 16; }
 __device__ __forceinline__ int lds_swz(int m) { return (m >> 2) & 3; }
 
 template <int BM, int BN, int AMODE, int BMODE, bool VEC, int ENGINE>
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < NPA; ++i) { a_off[i] = 0; a_val[i] = 0; }
-        const int fl = amq & 1;
+        const int fl = (amq >> 2) & 1;          // = lds_row's flip bit of rows 4*amq..4*amq+3
         const int sw = (NPA == 4) ? 4 * ((akr >> 1) ^ (amq & 3)) + 2 * (akr & 1) : 4 * ((akr >> 2) ^ (amq & 3)) + (akr & 3);
 #pragma unroll
         for (int j = 0; j < 4; ++j) a_st[j] = (4 * amq + (j ^ fl)) * 16 + sw;
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
         const unsigned base = (n < p.N) ? ((unsigned)(bkr * NPB) * (unsigned)p.ldb + (unsigned)n) * 4u : OOB;
 #pragma unroll
         for (int i = 0; i < NPB; ++i) b_off[i] = base + (unsigned)i * (unsigned)p.ldb * 4u;
-        const int fl = bnq & 1;
+        const int fl = (bnq >> 2) & 1;
         const int sw = (NPB == 4) ? 4 * ((bkr >> 1) ^ (bnq & 3)) + 2 * (bkr & 1) : 4 * ((bkr >> 2) ^ (bnq & 3)) + (bkr & 3);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b_st[j] = (4 * bnq + (j ^ fl)) * 16 + sw;
@@ -869,6 +870,372 @@ int launch_split(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 gri
     return (int)hipGetLastError();
 }
 
+// ================================================================================================
+// Split engine, 256x128 block tile (tile id 4), software-pipelined in one instruction stream per SIMD.
+// Measured on MI355X: in the 128x128 kernels above the matrix pipe idles while (a) all waves of a block fetch their
+// MFMA operands from LDS at the same moment after each barrier and (b) late global loads are waited for.  Here:
+//   * 4 wavefronts (2x2), wave tile 128x64 = 4x2 MFMA tiles; a pipeline step is ONE k16 half-tile = 48 MFMAs;
+//   * LDS is a ring of four k16 half-stages (4 x 36 KiB): step h multiplies operands that are already in registers,
+//     prefetches the operands of step h+1 from slot (h+1)%4 (18 ds_read_b128), converts the raw fp32 registers of
+//     step h+2 (one k-tile ahead) into slot (h+2)%4 and re-issues the global loads of those registers for step h+4
+//     (two k-tiles ahead); one barrier per step;
+//   * the conversion units and loads are spread over the six 8-MFMA groups of the step so that VALU / LDS / VMEM
+//     instructions issue in the shadow of the matrix pipe (~4.5 of them per MFMA).
+// Half-stage layout per bf16 plane: [rows][8 dwords]; logical row m, 16-byte chunk c (8 k) -> physical row
+// m ^ ((m>>2)&3), chunk c ^ ((m>>4)&1): conflict-free b128 operand reads and K-contiguous b64 stores, 2-way (b64) /
+// 4-way (b32) conflicts on the transposing stores (the minimum for 16/32 lanes writing one k-column).
+// Preconditions as gemm_split_kernel.
+__device__ __forceinline__ int hs_row(int m) { return (m ^ ((m >> 2) & 3)) * 8; }
+__device__ __forceinline__ int hs_swz(int m) { return (m >> 4) & 1; }
+
+template <int AMODE, int BMODE, bool PLAIN>
+__global__ __launch_bounds__(256, 1) void gemm_split256_kernel(const GemmArgs p) {
+    constexpr int BM = 256, BN = 128;
+    constexpr int HPA = BM * 8, HPB = BN * 8;           // dwords per plane of a half-stage
+    constexpr int HSTAGE = 3 * (HPA + HPB);             // 9216 dwords = 36 KiB
+    constexpr int WM = 128, WN = 64, TM = 4, TN = 2;
+
+    __shared__ __attribute__((aligned(16))) unsigned smem[4 * HSTAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tilesN = (p.N + BN - 1) / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (bid / tilesN) * BM;
+    const int n0 = (bid % tilesN) * BN;
+
+    const int z = blockIdx.z;
+    const int split = z % p.splitk;
+    const int bz = z / p.splitk;
+    const int b2 = bz % p.nb2, b1 = bz / p.nb2;
+    float* __restrict__ C = p.C + b1 * p.sC1 + b2 * p.sC2 + split * p.sCsplit;
+    const __amdgpu_buffer_rsrc_t rA =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + b1 * p.sA1 + b2 * p.sA2), (short)0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + b1 * p.sB1 + b2 * p.sB2), (short)0, (int)p.b_bytes, 0x00020000);
+
+    const int kbeg = split * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int ntiles = (kend - kbeg + BK - 1) / BK;
+
+    // ------------------------------------------------------------------ per-thread loader constants
+    const int r4 = tid >> 2, qh = tid & 3;      // K-contiguous operands: row (+64 per pass), k-quad inside the half
+    unsigned a_off[4], a_val[4];
+    int a_st;                                   // LDS store offset (dwords) inside a half-stage
+    const int amq = tid & 63, akr = tid >> 6;   // AMODE 1: m-quad (64), k-quad inside the half (4)
+    int a1_wo[2] = {0, 0}, a1_ho[2] = {0, 0}, a1_img[2] = {0, 0};
+    int a1_kh = 0, a1_kw = 0;
+    unsigned a1_base = 0;
+    if (AMODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + r4 + 64 * i;
+            a_val[i] = 0;
+            if (m >= p.M) {
+                a_off[i] = OOB;
+            } else if (PLAIN) {
+                a_off[i] = ((unsigned)m * (unsigned)p.lda + 4u * qh) * 4u;
+            } else {
+                const int wo = m % p.Wo;
+                const int t = m / p.Wo;
+                const int ho = t % p.Ho;
+                const int img = t / p.Ho;
+                const int hi0 = ho * p.strideA - p.padH, wi0 = wo * p.strideA - p.padW;
+                a_off[i] = (unsigned)((((img * p.H + hi0) * p.W + wi0) * p.lda + 4 * qh) * 4);
+                unsigned bits = 0;
+                for (int kh = 0; kh < p.KH; ++kh)
+                    for (int kw = 0; kw < p.KW; ++kw)
+                        if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W)
+                            bits |= 1u << (kh * p.KW + kw);
+                a_val[i] = bits;
+            }
+        }
+        a_st = hs_row(r4) + 4 * ((qh >> 1) ^ hs_swz(r4)) + 2 * (qh & 1);      // + 512 per pass (64 rows)
+    } else {
+        const int mm = m0 + 4 * amq;
+        if (mm >= p.M) {
+            a1_base = OOB;
+        } else if (PLAIN) {
+            a1_base = ((unsigned)(akr * 4) * (unsigned)p.lda + (unsigned)mm) * 4u;
+        } else {
+            const int tap = mm / p.Cin;
+            a1_base = (unsigned)(mm - tap * p.Cin) * 4u;
+            a1_kh = tap / p.KW;
+            a1_kw = tap - a1_kh * p.KW;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int k0 = kbeg + 16 * s + akr * 4;
+                a1_wo[s] = k0 % p.Wo;
+                const int t = k0 / p.Wo;
+                a1_ho[s] = t % p.Ho;
+                a1_img[s] = t / p.Ho;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a_off[i] = 0; a_val[i] = 0; }
+        // row 4*amq + j -> physical row 4*amq + (j ^ (amq&3)); chunk (akr>>1) ^ ((amq>>2)&1), quad-half akr&1
+        a_st = (4 * amq) * 8 + 4 * ((akr >> 1) ^ ((amq >> 2) & 1)) + 2 * (akr & 1);
+    }
+
+    unsigned b_off[2];
+    int b_st;
+    const int bnq = tid & 31, bkr = tid >> 5;   // BMODE 0: n-quad (32), k-pair inside the half (8)
+    if (BMODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int n = n0 + r4 + 64 * i;
+            b_off[i] = (n < p.N) ? ((unsigned)n * (unsigned)p.ldb + 4u * qh) * 4u : OOB;
+        }
+        b_st = hs_row(r4) + 4 * ((qh >> 1) ^ hs_swz(r4)) + 2 * (qh & 1);
+    } else {
+        const int n = n0 + 4 * bnq;
+        const unsigned base = (n < p.N) ? ((unsigned)(bkr * 2) * (unsigned)p.ldb + (unsigned)n) * 4u : OOB;
+        b_off[0] = base;
+        b_off[1] = base + (unsigned)p.ldb * 4u;
+        b_st = (4 * bnq) * 8 + 4 * ((bkr >> 2) ^ ((bnq >> 2) & 1)) + (bkr & 3);
+    }
+
+    // wave-uniform (tap, channel) walk of the conv A-gather; stands on the k-tile whose loads are issued next
+    int u_tap = 0, u_ci = 0, u_kh = 0, u_kw = 0;
+    if (AMODE == 0 && !PLAIN) {
+        u_tap = kbeg / p.Cin;
+        u_ci = kbeg - u_tap * p.Cin;
+        u_kh = u_tap / p.KW;
+        u_kw = u_tap - u_kh * p.KW;
+    }
+
+    float4 rawA[2][4], rawB[2][2];
+
+    // loads of half `s` (k16) of the k-tile starting at `ktile`; a tile at or beyond kend arrives as zeros
+    auto load_A = [&](int ktile, int s) {
+        if (AMODE == 0) {
+            if (PLAIN) {
+                const unsigned ku = (ktile + 16 * s + 4 * qh < kend) ? (unsigned)(ktile + 16 * s) * 4u : OOB;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rawA[s][i] = bload4(rA, a_off[i] + ku);
+            } else {
+                const unsigned tapoff = (unsigned)(((u_kh * p.W + u_kw) * p.lda + u_ci + 16 * s) * 4);
+                const unsigned tapbit = (ktile < kend) ? (1u << (u_tap & 31)) : 0u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rawA[s][i] = bload4(rA, (a_val[i] & tapbit) ? a_off[i] + tapoff : OOB);
+            }
+        } else {
+            if (PLAIN) {
+                const unsigned ku =
+                    (ktile + 16 * s + akr * 4 < kend) ? (unsigned)(ktile + 16 * s) * (unsigned)p.lda * 4u : OOB;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rawA[s][i] = bload4(rA, a1_base + ku + (unsigned)i * (unsigned)p.lda * 4u);
+            } else {
+                const int hi = a1_ho[s] * p.strideA - p.padH + a1_kh;
+                const int wi = a1_wo[s] * p.strideA - p.padW + a1_kw;
+                const bool rowok = (ktile + 16 * s + akr * 4 < kend) && (unsigned)hi < (unsigned)p.H;
+                const unsigned rowoff = (unsigned)((((a1_img[s] * p.H + hi) * p.W + wi) * p.lda) * 4) + a1_base;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = rowok && (unsigned)(wi + i * p.strideA) < (unsigned)p.W;
+                    rawA[s][i] = bload4(rA, ok ? rowoff + (unsigned)(i * p.strideA * p.lda * 4) : OOB);
+                }
+            }
+        }
+    };
+    auto advance_A = [&]() {        // once per k-tile, before the loads of its first half
+        if (AMODE == 0 && !PLAIN) {
+            u_ci += BK;
+            if (u_ci >= p.Cin) {
+                u_ci = 0;
+                ++u_tap;
+                if (++u_kw == p.KW) { u_kw = 0; ++u_kh; }
+            }
+        }
+        if (AMODE == 1 && !PLAIN) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                a1_wo[s] += BK;
+                while (a1_wo[s] >= p.Wo) { a1_wo[s] -= p.Wo; ++a1_ho[s]; }
+                while (a1_ho[s] >= p.Ho) { a1_ho[s] -= p.Ho; ++a1_img[s]; }
+            }
+        }
+    };
+    auto load_B = [&](int ktile, int s) {
+        if (BMODE == 1) {
+            const unsigned ku = (ktile + 16 * s + 4 * qh < kend) ? (unsigned)(ktile + 16 * s) * 4u : OOB;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) rawB[s][i] = bload4(rB, b_off[i] + ku);
+        } else {
+            const unsigned ku =
+                (ktile + 16 * s + bkr * 2 < kend) ? (unsigned)(ktile + 16 * s) * (unsigned)p.ldb * 4u : OOB;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) rawB[s][i] = bload4(rB, b_off[i] + ku);
+        }
+    };
+
+    auto put4 = [](unsigned* u, int plane, float x0, float x1, float x2, float x3) {
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split2(x0, x1, h0, m0_, l0);
+        split2(x2, x3, h1, m1, l1);
+        *reinterpret_cast<uint2*>(u) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(u + plane) = make_uint2(m0_, m1);
+        *reinterpret_cast<uint2*>(u + 2 * plane) = make_uint2(l0, l1);
+    };
+    auto put2 = [](unsigned* u, int plane, float x0, float x1) {
+        unsigned h, m, l;
+        split2(x0, x1, h, m, l);
+        u[0] = h;
+        u[plane] = m;
+        u[2 * plane] = l;
+    };
+    auto elem = [](const float4& v, int j) -> float { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); };
+    // conversion unit u (0..3) of half s of the raw A registers -> half-stage `hs`
+    auto conv_A = [&](unsigned* hs, int s, int u) {
+        if (AMODE == 0) {
+            put4(hs + a_st + 512 * u, HPA, rawA[s][u].x, rawA[s][u].y, rawA[s][u].z, rawA[s][u].w);
+        } else {
+            put4(hs + a_st + 8 * (u ^ (amq & 3)), HPA, elem(rawA[s][0], u), elem(rawA[s][1], u), elem(rawA[s][2], u),
+                 elem(rawA[s][3], u));
+        }
+    };
+    // conversion slot u (0..1) of half s of the raw B registers
+    auto conv_B = [&](unsigned* hs, int s, int u) {
+        unsigned* bs = hs + 3 * HPA;
+        if (BMODE == 1) {
+            put4(bs + b_st + 512 * u, HPB, rawB[s][u].x, rawB[s][u].y, rawB[s][u].z, rawB[s][u].w);
+        } else {
+            put2(bs + b_st + 8 * ((2 * u) ^ (bnq & 3)), HPB, elem(rawB[s][0], 2 * u), elem(rawB[s][1], 2 * u));
+            put2(bs + b_st + 8 * ((2 * u + 1) ^ (bnq & 3)), HPB, elem(rawB[s][0], 2 * u + 1), elem(rawB[s][1], 2 * u + 1));
+        }
+    };
+
+    // ------------------------------------------------------------------ operand fetch
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int ma = wm * WM + l31, nb = wn * WN + l31;
+    const int sa_rd = hs_row(ma) + 4 * (lhi ^ hs_swz(ma));
+    const int sb_rd = 3 * HPA + hs_row(nb) + 4 * (lhi ^ hs_swz(nb));
+    bf16x8 av[2][3][TM], bv[2][3][TN];
+    auto fetch = [&](const unsigned* hs, int set) {     // in order of first use: A.lo B.hi | A.hi B.lo | A.mid B.mid
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            av[set][2][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(hs + 2 * HPA + sa_rd + i * 256));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            bv[set][0][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(hs + sb_rd + j * 256));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            av[set][0][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(hs + sa_rd + i * 256));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            bv[set][2][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(hs + 2 * HPB + sb_rd + j * 256));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            av[set][1][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(hs + HPA + sa_rd + i * 256));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            bv[set][1][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(hs + HPB + sb_rd + j * 256));
+    };
+
+    // ------------------------------------------------------------------ prologue
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { load_A(kbeg, s); load_B(kbeg, s); }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) conv_A(smem + s * HSTAGE, s, u);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) conv_B(smem + s * HSTAGE, s, u);
+    }
+    advance_A();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { load_A(kbeg + BK, s); load_B(kbeg + BK, s); }
+    __syncthreads();
+    fetch(smem, 0);
+
+    // ------------------------------------------------------------------ main loop: step h = 2t + s
+    for (int t = 0; t < ntiles; ++t) {
+        const int k2 = kbeg + (t + 2) * BK;         // k-tile whose loads are issued during this iteration
+        unsigned* slot_t0 = smem + ((2 * t) & 3) * HSTAGE;      // slots of steps (t,0), (t,1); (t+1, s) = slot (t, s) ^ 2
+        unsigned* slot_t1 = smem + ((2 * t + 1) & 3) * HSTAGE;
+        unsigned* slot_n0 = smem + ((2 * t + 2) & 3) * HSTAGE;
+        unsigned* slot_n1 = smem + ((2 * t + 3) & 3) * HSTAGE;
+        (void)slot_t0;
+#define RIH_SPLIT_TERM(S_, PA_, PB_)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =      \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[S_][PA_][i], bv[S_][PB_][j], acc[i][j], 0, 0, 0);
+        // group G of step S: 8 MFMAs + one conversion unit of step (t+1, S) (+ reload of its registers for t+2)
+#define RIH_GROUP(S_, G_, PA_, PB_, DST_)                                                                         \
+    RIH_SPLIT_TERM(S_, PA_, PB_)                                                                                  \
+    if ((G_) < 4) conv_A(DST_, S_, (G_));                                                                         \
+    if ((G_) == 3) { if ((S_) == 0) advance_A(); load_A(k2, S_); }                                                \
+    if ((G_) >= 4) conv_B(DST_, S_, (G_) - 4);                                                                    \
+    if ((G_) == 5) load_B(k2, S_);                                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+        // ---- step (t, 0): operands in set 0; prefetch step (t, 1) into set 1
+        fetch(slot_t1, 1);
+        RIH_GROUP(0, 0, 2, 0, slot_n0)
+        RIH_GROUP(0, 1, 0, 2, slot_n0)
+        RIH_GROUP(0, 2, 1, 1, slot_n0)
+        RIH_GROUP(0, 3, 1, 0, slot_n0)
+        RIH_GROUP(0, 4, 0, 1, slot_n0)
+        RIH_GROUP(0, 5, 0, 0, slot_n0)
+        __syncthreads();
+        // ---- step (t, 1): operands in set 1; prefetch step (t+1, 0) into set 0
+        fetch(slot_n0, 0);
+        RIH_GROUP(1, 0, 2, 0, slot_n1)
+        RIH_GROUP(1, 1, 0, 2, slot_n1)
+        RIH_GROUP(1, 2, 1, 1, slot_n1)
+        RIH_GROUP(1, 3, 1, 0, slot_n1)
+        RIH_GROUP(1, 4, 0, 1, slot_n1)
+        RIH_GROUP(1, 5, 0, 0, slot_n1)
+        __syncthreads();
+#undef RIH_GROUP
+#undef RIH_SPLIT_TERM
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    const bool raw = (p.splitk > 1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + l31;
+            const float bv_ = (!raw && p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (m < p.M && n < p.N) {
+                    float v = acc[i][j][r];
+                    if (!raw) {
+                        v = v * p.alpha + bv_;
+                        if (p.R != nullptr) v += p.R[(long long)m * p.ldr + n];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                    }
+                    C[(long long)m * p.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
+int launch_split256(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 grid, hipStream_t s) {
+    dim3 block(256);
+#define RIH_LS(AM_, BM_, PL_) hipLaunchKernelGGL((gemm_split256_kernel<AM_, BM_, PL_>), grid, block, 0, s, a)
+    if (a_mode == 0 && b_mode == 0) { if (plain) RIH_LS(0, 0, true); else RIH_LS(0, 0, false); }
+    else if (a_mode == 0 && b_mode == 1) { if (plain) RIH_LS(0, 1, true); else RIH_LS(0, 1, false); }
+    else if (a_mode == 1 && b_mode == 0) { if (plain) RIH_LS(1, 0, true); else RIH_LS(1, 0, false); }
+    else return RIH_EINVAL;
+#undef RIH_LS
+    return (int)hipGetLastError();
+}
+
 // Split-K reduction for weight gradients, two coalesced passes:
 //   1. sum the S partial slabs into slab 0 (in place; linear, float4 where possible),
 //   2. transpose slab 0 [M][N] (m = tap*Cin + ci) into the parameter layout dst[(n*CinValid + ci)*taps + tap]
@@ -990,10 +1357,11 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
     a.vecB = b16 ? 1 : 0;
     a.a_bytes = a.b_bytes = 0;
     int bm = 128, bn = 128;
-    if (d->tile == 1) { bm = 128; bn = 64; }
+    if (d->tile == 4) { bm = 256; bn = 128; }
+    else if (d->tile == 1) { bm = 128; bn = 64; }
     else if (d->tile == 2) { bm = 64; bn = 64; }
     else if (d->tile == 3) { bm = 128; bn = 32; }
-    else if (d->tile != 0) return RIH_EINVAL;
+    else if (d->tile != 0 && d->tile != 4) return RIH_EINVAL;
     const long long tiles = (long long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn);
     const long long gz = (long long)d->nb1 * d->nb2 * d->splitk;
     if (tiles > 0x7fffffffLL || gz > 65535) return RIH_EINVAL;
@@ -1014,6 +1382,13 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
         if (d->a_mode == 0 && !plain) ok = ok && (d->Cin % 32 == 0) && (d->KH * d->KW <= 32);
         if (d->a_mode == 1) ok = ok && (d->M % 4 == 0) && (plain || (d->Wo % 4 == 0 && d->Cin % 4 == 0));
         if (d->b_mode == 0) ok = ok && (d->N % 4 == 0);
+        if (d->tile == 4) {     // 256x128 kernel: no general-kernel fallback, the caller must respect the preconditions
+            ok = ok && !(d->a_mode == 1 && d->b_mode == 1);
+            if (!ok) return RIH_EINVAL;
+            a.a_bytes = (unsigned)a_bytes;
+            a.b_bytes = (unsigned)b_bytes;
+            return launch_split256(a, d->a_mode, d->b_mode, plain, grid, s);
+        }
         if (ok) {
             a.a_bytes = (unsigned)a_bytes;
             a.b_bytes = (unsigned)b_bytes;
@@ -1022,6 +1397,7 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
             return launch_split<64, 64>(a, d->a_mode, d->b_mode, plain, grid, s);
         }
     }
+    if (d->tile == 4) return RIH_EINVAL;    // 256x128 exists only on the split engine's fast path
     if (d->tile == 0) return launch_tile<128, 128>(a, d->a_mode, d->b_mode, d->engine, grid, s);
     if (d->tile == 1) return launch_tile<128, 64>(a, d->a_mode, d->b_mode, d->engine, grid, s);
     if (d->tile == 3) return launch_tile<128, 32>(a, d->a_mode, d->b_mode, 0, grid, s);

@@ -43,18 +43,44 @@ def _cdiv(a, b):
 
 
 # --------------------------------------------------------------------------------------------- GEMM plumbing
-def pick_tile(M, N, batch=1):
-    """0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32 -- fill 256 CUs (x ~3 resident blocks) before growing the tile."""
+def pick_tile(M, N, batch=1, engine=None, K=0):
+    """0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32 -- fill 256 CUs (x 2-3 resident blocks) before growing the tile.
+    Returns the tile id; `plan_gemm` adds the forward split-K decision."""
+    return plan_gemm(M, N, K, batch, engine)[0]
+
+
+def plan_gemm(M, N, K, batch=1, engine=None):
+    """(tile, splitk) for a forward GEMM.  Measured on MI355X (tools/gemm_bench.py): the split engine wants >= ~1.5
+    blocks per CU and long k-loops (its per-block prologue/epilogue is expensive), so deep-K problems with few
+    output tiles are split over K instead of shrinking the tile."""
+    e = ENGINE if engine is None else engine
     if N <= 32:
-        return 3
-    if N <= 64:
-        return 1 if _cdiv(M, 128) * batch >= 384 else 2
-    if _cdiv(M, 128) * _cdiv(N, 128) * batch >= 384:
-        return 0
-    return 2
+        return 3, 1
+    t0 = _cdiv(M, 128) * _cdiv(N, 128) * batch
+    t1 = _cdiv(M, 128) * _cdiv(N, 64) * batch
+    if e == 1:
+        if N > 64 and t0 >= 384:
+            return 0, 1
+        if t1 >= 384:
+            return 1, 1
+        if batch == 1 and K >= 2048 and N > 64 and t0 >= 32:
+            return 0, max(1, min(_cdiv(K, 512), _cdiv(512, t0)))
+        tile = 2
+    else:
+        if N <= 64:
+            tile = 1 if t1 >= 384 * 2 else 2      # (historic rule: cdiv(M,128)*batch >= 384)
+        elif t0 >= 384:
+            return 0, 1
+        else:
+            tile = 2
+    bm, bn = _TILE_MN[tile]
+    tiles = _cdiv(M, bm) * _cdiv(N, bn) * batch
+    if batch == 1 and K >= 1024 and tiles < 128:
+        return tile, max(1, min(_cdiv(K, 256), _cdiv(256, tiles)))
+    return tile, 1
 
 
-_TILE_MN = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32)}
+_TILE_MN = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (256, 128)}
 
 # MFMA engine of rih_gemm (include/renderih_amd.h): 1 = fp32 emulated on the bf16 pipe (three-term split, six
 # products, fp32 accumulate -- fp32-grade accuracy at up to 417 TF), 0 = native f32 MFMA (157 TF).  Tile 3 (N <= 32)
@@ -92,23 +118,23 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
         cin = K if a_mode == 0 else M
         geom = (1, 1, cin, 1, 1, 1, 1, 1, 1, 0, 0)
     (d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.strideA, d.upS, d.padH, d.padW) = geom
-    d.tile = pick_tile(M, N, nb1 * nb2 * splitk) if tile is None else tile
-    if splitk == 1 and nb1 * nb2 == 1 and K >= 1024 and not isinstance(Cout, int):
-        # few output tiles but a long reduction (e.g. the 4x4 patch conv: 64 tiles, K=4096): split K over
+    auto_sk = 1
+    if tile is None:
+        d.tile, auto_sk = plan_gemm(M, N, K, nb1 * nb2 * splitk, d.engine)
+    else:
+        d.tile = tile
+    if auto_sk > 1 and splitk == 1 and nb1 * nb2 == 1 and not isinstance(Cout, int):
+        # few output tiles but a long reduction (e.g. the 8x8 3x3 convs, the 4x4 patch conv): split K over
         # workgroups and finish (bias / residual / ReLU) in a second pass
-        bm, bn = _TILE_MN[d.tile]
-        tiles = _cdiv(M, bm) * _cdiv(N, bn)
-        if tiles < 128:
-            sk = min(_cdiv(K, 256), _cdiv(256, tiles))
-            if sk > 1:
-                kc = _cdiv(_cdiv(K, sk), 32) * 32
-                sk = _cdiv(K, kc)
-                part = torch.empty((sk, M, N), device=Cout.device, dtype=torch.float32)
-                gemm(A, B, part, M, N, K, lda, ldb, N, a_mode=a_mode, b_mode=b_mode, splitk=sk, kchunk=kc,
-                     sCsplit=M * N, geom=geom, tile=d.tile, engine=d.engine)
-                check(_L().rih_splitk_finish(part.data_ptr(), sk, M, N, d.C, ldc, d.bias or 0, d.R or 0, ldr,
-                                             alpha, 1 if relu else 0, _stream()), 'rih_splitk_finish')
-                return
+        kc = _cdiv(_cdiv(K, auto_sk), 32) * 32
+        sk = _cdiv(K, kc)
+        if sk > 1:
+            part = torch.empty((sk, M, N), device=Cout.device, dtype=torch.float32)
+            gemm(A, B, part, M, N, K, lda, ldb, N, a_mode=a_mode, b_mode=b_mode, splitk=sk, kchunk=kc,
+                 sCsplit=M * N, geom=geom, tile=d.tile, engine=d.engine)
+            check(_L().rih_splitk_finish(part.data_ptr(), sk, M, N, d.C, ldc, d.bias or 0, d.R or 0, ldr,
+                                         alpha, 1 if relu else 0, _stream()), 'rih_splitk_finish')
+            return
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -124,7 +150,8 @@ def _wgrad(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_val
     tile = 3 if Ncols <= 32 else (2 if (Ncols <= 64 or Mrows <= 64) else 0)
     bm, bn = _TILE_MN[tile]
     tiles = _cdiv(Mrows, bm) * _cdiv(Ncols, bn)
-    splitk = max(1, min(1024 // max(tiles, 1), _cdiv(Kpix, 128)))
+    target = 512 if (ENGINE == 1 and tile == 0) else 1024     # measured optimum of resident split-K slices
+    splitk = max(1, min(target // max(tiles, 1), _cdiv(Kpix, 128)))
     kchunk = _cdiv(_cdiv(Kpix, splitk), 32) * 32
     splitk = _cdiv(Kpix, kchunk)
     part = torch.empty((splitk, Mrows, Ncols), device=x.device, dtype=torch.float32)

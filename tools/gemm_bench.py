@@ -50,8 +50,13 @@ def conv_fwd(N, H, W, Cin, Cout, k, s, p, tiles=(0, 1, 2)):
             out.append('t%de%d %7.1fus %6.1fTF' % (t, e, us, 2.0 * M * Cout * K / us / 1e6))
     if k == 1 and s == 1:
         for e in ENGINES:
-            ops.gemm(x, wp, y, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=0, engine=e)
-            out.append('e%d err %.1e (fp32 blas %.1e)' % ((e,) + err_vs_fp64(y, x.view(M, K), wp)))
+            ops.gemm(x, wp, y, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=tiles[-1], engine=e)
+            out.append('t%de%d err %.1e (fp32 blas %.1e)' % ((tiles[-1], e) + err_vs_fp64(y, x.view(M, K), wp)))
+    else:   # conv: compare the last tile's result with the first tile's (same engine)
+        y0 = torch.empty_like(y)
+        ops.gemm(x, wp, y0, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=tiles[0], engine=ENGINES[-1])
+        ops.gemm(x, wp, y, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=tiles[-1], engine=ENGINES[-1])
+        out.append('t%d vs t%d maxdiff %.1e' % (tiles[-1], tiles[0], float((y - y0).abs().max() / y0.abs().max())))
     print('conv fwd  N%d %dx%d Cin%d Cout%d k%d s%d | M%d N%d K%d | %s' % (N, H, W, Cin, Cout, k, s, M, Cout, K, '  '.join(out)), flush=True)
 
 
@@ -62,6 +67,7 @@ def wgrad(N, H, W, Cin, Cout, k, s, p, splits=(None,), tiles=(0, 2)):
     Kpix, Mrows = N * Ho * Wo, k * k * Cin
     geom = (H, W, Cin, Ho, Wo, k, k, s, 1, p, p)
     out = []
+    res = []
     for t in tiles:
         bm, bn = ops._TILE_MN[t]
         ntiles = -(-Mrows // bm) * -(-Cout // bn)
@@ -75,6 +81,9 @@ def wgrad(N, H, W, Cin, Cout, k, s, p, splits=(None,), tiles=(0, 2)):
                                                   splitk=sk, kchunk=kc, sCsplit=Mrows * Cout, geom=geom, tile=t, engine=e) if sk > 1 else
                                  ops.gemm(x, dy, part, Mrows, Cout, Kpix, Cin, Cout, Cout, a_mode=1, b_mode=0, geom=geom, tile=t, engine=e))
                 out.append('t%de%d sk%3d %6.1fus %5.1fTF' % (t, e, sk, us, 2.0 * Mrows * Cout * Kpix / us / 1e6))
+        res.append(part.sum(0))
+    if len(res) > 1:
+        out.append('t%d vs t%d maxdiff %.1e' % (tiles[-1], tiles[0], float((res[-1] - res[0]).abs().max() / res[0].abs().max())))
     print('wgrad N%d %dx%d Cin%d Cout%d k%d s%d | M%d N%d K%d | %s' % (N, H, W, Cin, Cout, k, s, Mrows, Cout, Kpix, ' | '.join(out)), flush=True)
 
 
@@ -91,13 +100,32 @@ def linear_fwd(M, K, Nf, tiles=(0, 1, 2, 3)):
             us = time_launch(lambda: ops.gemm(x, w, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, tile=t, engine=e))
             out.append('t%de%d %6.1fus %5.1fTF' % (t, e, us, 2.0 * M * Nf * K / us / 1e6))
     for e in ENGINES:
-        ops.gemm(x, w, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, tile=2, engine=e)
-        out.append('e%d err %.1e (fp32 blas %.1e)' % ((e,) + err_vs_fp64(y, x, w.t())))
+        ops.gemm(x, w, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, tile=tiles[-1], engine=e)
+        out.append('t%de%d err %.1e (fp32 blas %.1e)' % ((tiles[-1], e) + err_vs_fp64(y, x, w.t())))
     print('linear M%d K%d N%d | %s' % (M, K, Nf, '  '.join(out)), flush=True)
 
 
 if __name__ == '__main__':
     B = 64
+    if '--e1' in sys.argv:          # split-engine iteration set
+        globals()['ENGINES'] = (1,)
+        conv_fwd(B, 64, 64, 128, 128, 3, 1, 1, tiles=(0, 4))
+        conv_fwd(B, 32, 32, 128, 128, 3, 1, 1, tiles=(0, 4))
+        conv_fwd(B, 16, 16, 256, 256, 3, 1, 1, tiles=(0, 1, 4))
+        conv_fwd(B, 8, 8, 512, 512, 3, 1, 1, tiles=(1, 2, 4))
+        conv_fwd(B, 64, 64, 512, 256, 1, 1, 0, tiles=(0, 4))
+        conv_fwd(B, 64, 64, 64, 256, 1, 1, 0, tiles=(0, 4))
+        conv_fwd(B, 16, 16, 1024, 256, 1, 1, 0, tiles=(0, 4))
+        wgrad(B, 32, 32, 128, 128, 3, 1, 1, tiles=(0, 4))
+        wgrad(B, 16, 16, 256, 256, 3, 1, 1, tiles=(0, 4))
+        wgrad(B, 16, 16, 1024, 256, 1, 1, 0, tiles=(0, 4))
+        linear_fwd(8128, 256, 768, tiles=(0, 2, 4))
+        sys.exit(0)
+    if '--pmc4' in sys.argv:
+        globals()['ENGINES'] = (1,)
+        conv_fwd(B, 64, 64, 128, 128, 3, 1, 1, tiles=(0, 4))
+        wgrad(B, 32, 32, 128, 128, 3, 1, 1, tiles=(0,))
+        sys.exit(0)
     if '--quick' in sys.argv:       # a few launches for PMC collection
         conv_fwd(B, 64, 64, 128, 128, 3, 1, 1, tiles=(0,))
         conv_fwd(B, 16, 16, 1024, 256, 1, 1, 0, tiles=(0,))
