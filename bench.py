@@ -6,9 +6,11 @@ Workload = BASELINE.json configs[1]: batch 64 per GPU, 256x256 RGB, ResNet50 enc
 random-init weights.  N>1: one process per GPU (torch.distributed, backend "nccl" = RCCL), plain data parallel with
 the reference's DDP(find_unused_parameters=True) semantics; weak scaling (batch 64 per GPU).
 
-Prints ONE JSON line (rank 0).  `roofline`: the fp32-MFMA GEMM/implicit-conv kernel family (rih_gemm), timed live with
-HIP events on the launch stream; achieved = SURVEY 8d algorithmic FLOPs (53.2 GFLOP/img fwd+bwd) x images per step /
-GEMM-family time per step; peak = 157.3 TFLOP/s dense fp32 MFMA.  `cpu_baseline`: the CPU oracle (a port of the
+Prints ONE JSON line (rank 0).  `roofline`: the GEMM/implicit-conv kernel family (rih_gemm), timed live with HIP events
+on the launch stream; achieved = SURVEY 8d algorithmic FLOPs (53.2 GFLOP/img fwd+bwd) x images per step / GEMM-family
+time per step.  The default engine computes every fp32 product as six bf16 MFMA products (three-term operand split,
+fp32 accumulate; DESIGN.md 3.1), so its peak is the dense bf16 MFMA peak / 6 = 416.7 TFLOP/s of fp32-equivalent work;
+the native f32 MFMA peak (157.3 TFLOP/s, engine 0, RIH_GEMM_ENGINE=0) is reported next to it.  `cpu_baseline`: the CPU oracle (a port of the
 reference's PyTorch-CPU path) timed on this box's host cores on a bounded sample (rank 0, N=1 only).
 """
 import argparse
@@ -24,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_IMG_FWD_BWD = 53.2      # 3 x 17.72 GFLOP/img forward (conv + matmul, 2*MAC)
 PEAK_FP32_MFMA_TF = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TF = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 
 
 def synth_batch(B, device, seed):
@@ -158,9 +161,15 @@ def main():
                            'rows': rows, 'by_variant': by}, fh)
         top = max(by.items(), key=lambda kv: kv[1][1])
         achieved = GFLOP_PER_IMG_FWD_BWD * B / ms            # GFLOP / ms = TFLOP/s
-        roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s',
-                'frac': round(achieved / PEAK_FP32_MFMA_TF, 4), 'traffic': None,
-                'kernel': 'rih_gemm (gemm_kernel<BM,BN,AMODE,BMODE>, v_mfma_f32_32x32x2_f32)',
+        split = (ops.ENGINE == 1)
+        peak = PEAK_BF16_MFMA_TF / 6.0 if split else PEAK_FP32_MFMA_TF
+        roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                'frac': round(achieved / peak, 4), 'traffic': None,
+                'kernel': ('rih_gemm engine 1 (gemm_split_kernel / gemm_split256_kernel: fp32 = 6 x '
+                           'v_mfma_f32_32x32x16_bf16 on a 3-term bf16 split; peak = 2500 TF/s bf16 dense / 6)'
+                           if split else 'rih_gemm engine 0 (gemm_kernel, v_mfma_f32_32x32x2_f32)'),
+                'native_f32_mfma_peak': PEAK_FP32_MFMA_TF,
+                'frac_of_native_f32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TF, 4),
                 'launches_per_step': len(recs), 'gemm_ms_per_step': round(ms, 3),
                 'launched_tflops': round(launched / ms / 1e9, 2),
                 'avg_launch_us': round(1000.0 * ms / max(len(recs), 1), 2),
@@ -179,7 +188,9 @@ def main():
                 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                 'config': {'workload': 'BASELINE configs[1]: batch=64/GPU 256x256 ResNet50 + cross-hand attention decoder, '
                                        'fwd + loss + bwd + Adam step, dropout 0.05, fp32',
-                           'global_batch': B * world, 'parallelism': 'dp%d' % world, 'loss': round(final_loss, 4)},
+                           'global_batch': B * world, 'parallelism': 'dp%d' % world, 'loss': round(final_loss, 4),
+                           'gemm_engine': ('fp32 via 3-term bf16 split, 6 MFMA products, fp32 accumulate (fp32-grade error)'
+                                           if ops.ENGINE == 1 else 'native f32 MFMA')},
                 'roofline': roof, 'cpu_baseline': cpu}
         print(json.dumps(line), flush=True)
     if world > 1:
