@@ -72,11 +72,15 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=64, help='per-GPU batch')
+    ap.add_argument('--encoder', default='resnet50', choices=['resnet50', 'hrnet32'],
+                    help='resnet50 = BASELINE configs[1]/[2] (the headline metric); hrnet32 = configs[3]')
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 64, hrnet32: 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--dump-gemm', default=None, help='write the per-launch GEMM profile of one step to this JSON file')
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 32 if args.encoder == 'hrnet32' else 64
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -95,7 +99,7 @@ def main():
     from renderih_amd.manolayer import ManoLayer
 
     torch.manual_seed(0)
-    model = build_model(dropout=0.05).to(device).train()
+    model = build_model(dropout=0.05, encoder_type=args.encoder).to(device).train()
     model.decoder.unsample_layer.weight.requires_grad_(False)          # core/gcn_trainer.py:102-103
     net = model
     if world > 1:
@@ -160,7 +164,8 @@ def main():
                 json.dump({'columns': ['us', 'launched_tflops', 'M', 'N', 'K', 'batch', 'a_mode', 'b_mode', 'tile', 'splitk'],
                            'rows': rows, 'by_variant': by}, fh)
         top = max(by.items(), key=lambda kv: kv[1][1])
-        achieved = GFLOP_PER_IMG_FWD_BWD * B / ms            # GFLOP / ms = TFLOP/s
+        gflop_img = GFLOP_PER_IMG_FWD_BWD if args.encoder == 'resnet50' else 88.5     # 3 x 29.49 (HRNet-W32)
+        achieved = gflop_img * B / ms            # GFLOP / ms = TFLOP/s
         split = (ops.ENGINE == 1)
         peak = PEAK_BF16_MFMA_TF / 6.0 if split else PEAK_FP32_MFMA_TF
         roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
@@ -186,8 +191,10 @@ def main():
                 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': round(1000.0 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
                 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                'config': {'workload': 'BASELINE configs[1]: batch=64/GPU 256x256 ResNet50 + cross-hand attention decoder, '
-                                       'fwd + loss + bwd + Adam step, dropout 0.05, fp32',
+                'config': {'workload': ('BASELINE configs[1]: batch=%d/GPU 256x256 ResNet50 + cross-hand attention decoder, '
+                                        'fwd + loss + bwd + Adam step, dropout 0.05, fp32' % B) if args.encoder == 'resnet50'
+                           else ('BASELINE configs[3] model: batch=%d/GPU 256x256 HRNet-W32 + cross-hand attention decoder, '
+                                 'fwd + loss + bwd + Adam step, dropout 0.05, fp32' % B),
                            'global_batch': B * world, 'parallelism': 'dp%d' % world, 'loss': round(final_loss, 4),
                            'gemm_engine': ('fp32 via 3-term bf16 split, 6 MFMA products, fp32 accumulate (fp32-grade error)'
                                            if ops.ENGINE == 1 else 'native f32 MFMA')},

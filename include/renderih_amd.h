@@ -105,6 +105,16 @@ int rih_avgpool_fwd(const float* x, float* y, int N, int HW, int C, void* stream
 int rih_avgpool_bwd(const float* dy, float* dx, int N, int HW, int C, void* stream);
 int rih_upsample2x_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int rih_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* bilinear x`factor`, align_corners=True: [N,H,W,C] -> [N,factor*H,factor*W,C]
+ * (F.interpolate in models/encoder.py:228-230: the HRNet branches are brought to 64x64 with x2 / x4 / x8) */
+int rih_upsample_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int factor, void* stream);
+int rih_upsample_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int factor, void* stream);
+/* nearest x`factor` upsample fused with the running sum of HighResolutionModule's fuse layer
+ * (models/model_zoo/hrnet.py:181-183, 229-236): y = add + up(x) (add may be NULL); C % 4 == 0.
+ * Backward of the upsample branch: dx = sum of dy over each factor x factor block (the `add` branch gets dy). */
+int rih_nearest_up_add_fwd(const float* x, const float* add, float* y, int N, int H, int W, int C, int factor,
+                           void* stream);
+int rih_nearest_up_bwd(const float* dy, float* dx, int N, int H, int W, int C, int factor, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm2d (NHWC, rows = N*H*W)   (torchvision resnet bn*, models/encoder.py:54, model_zoo/__init__.py:57)

@@ -1,2 +1,3 @@
 """`models.encoder` drop-in (reference: models/encoder.py)."""
-from renderih_amd.encoder import ResNetSimple, ResNetSimple_decoder, resnet_mid, load_encoder  # noqa: F401
+from renderih_amd.encoder import (ResNetSimple, ResNetSimple_decoder, resnet_mid, HRnet_encoder, hrnet_mid,  # noqa: F401
+                                  load_encoder)

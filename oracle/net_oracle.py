@@ -98,6 +98,115 @@ def mid_forward(sd, img_f, hms_f, dp_f, training, p='mid_model.'):
     return gf, fmaps
 
 
+
+# ----------------------------------------------------------------------------- HRNet variant
+def _cb(sd, p, x, training, stride=1, pad=0, relu=False):
+    """Conv (bias optional) + BN (+ReLU): the Sequential(conv, bn[, relu]) pattern of model_zoo/hrnet.py."""
+    x = _bn(sd, p + '1.', F.conv2d(x, sd[p + '0.weight'], sd.get(p + '0.bias'), stride=stride, padding=pad), training)
+    return F.relu(x) if relu else x
+
+
+def _basic_block(sd, p, x, training):
+    """model_zoo/hrnet.py:28-58 BasicBlock (stride 1, no downsample inside HRNet branches)."""
+    out = F.relu(_bn(sd, p + 'bn1.', F.conv2d(x, sd[p + 'conv1.weight'], padding=1), training))
+    out = _bn(sd, p + 'bn2.', F.conv2d(out, sd[p + 'conv2.weight'], padding=1), training)
+    return F.relu(out + x)
+
+
+def _count(sd, prefix):
+    """Number of consecutive integer children `prefix + '<i>.'` present in the state dict."""
+    n = 0
+    while any(k.startswith('%s%d.' % (prefix, n)) for k in sd):
+        n += 1
+    return n
+
+
+def hr_module(sd, p, xs, training):
+    """model_zoo/hrnet.py:102-238 HighResolutionModule.forward."""
+    nb = len(xs)
+    ys = []
+    for i in range(nb):
+        x = xs[i]
+        for b in range(_count(sd, '%sbranches.%d.' % (p, i))):
+            x = _basic_block(sd, '%sbranches.%d.%d.' % (p, i, b), x, training)
+        ys.append(x)
+    if nb == 1:
+        return ys
+    out = []
+    for i in range(nb):
+        acc = None
+        for j in range(nb):
+            if j == i:
+                t = ys[j]
+            elif j > i:       # 1x1 conv + BN + nearest upsample  (:170-183)
+                t = _cb(sd, '%sfuse_layers.%d.%d.' % (p, i, j), ys[j], training)
+                t = F.interpolate(t, scale_factor=2 ** (j - i), mode='nearest')
+            else:             # chain of stride-2 3x3 conv + BN, ReLU on all but the last  (:186-207)
+                t = ys[j]
+                for k in range(i - j):
+                    t = _cb(sd, '%sfuse_layers.%d.%d.%d.' % (p, i, j, k), t, training, stride=2, pad=1,
+                            relu=(k != i - j - 1))
+            acc = t if acc is None else acc + t
+        out.append(F.relu(acc))
+    return out
+
+
+def hrnet_trunk(sd, x, training, p='encoder.hrnet.'):
+    """model_zoo/hrnet.py:490-527 HighResolutionNet.forward, head_type 'none'."""
+    x = F.relu(_bn(sd, p + 'bn1.', F.conv2d(x, sd[p + 'conv1.weight'], stride=2, padding=1), training))
+    x = F.relu(_bn(sd, p + 'bn2.', F.conv2d(x, sd[p + 'conv2.weight'], stride=2, padding=1), training))
+    for b in range(_count(sd, p + 'layer1.')):
+        x = _bottleneck(sd, '%slayer1.%d.' % (p, b), x, 1, training)
+    ys = [x]
+    for s in (2, 3, 4):
+        tp = '%stransition%d.' % (p, s - 1)
+        nb = len(ys) + 1
+        xs = []
+        for i in range(nb):
+            if i < len(ys):
+                if ('%s%d.0.weight' % (tp, i)) in sd:          # width change of an existing branch (stage 2 only)
+                    xs.append(_cb(sd, '%s%d.' % (tp, i), ys[i] if s == 2 else ys[-1], training, pad=1, relu=True))
+                else:
+                    xs.append(ys[i])
+            else:                                               # new branch from the LAST previous output (:507-523)
+                t = ys[-1]
+                for j in range(_count(sd, '%s%d.' % (tp, i))):
+                    t = _cb(sd, '%s%d.%d.' % (tp, i, j), t, training, stride=2, pad=1, relu=True)
+                xs.append(t)
+        for m in range(_count(sd, '%sstage%d.' % (p, s))):
+            xs = hr_module(sd, '%sstage%d.%d.' % (p, s, m), xs, training)
+        ys = xs
+    return ys
+
+
+def hrnet_encoder_forward(sd, img, training):
+    """models/encoder.py:223-240 HRnet_encoder.forward."""
+    ys = hrnet_trunk(sd, img, training)
+    size = ys[0].shape[2:]
+    x = torch.cat([ys[0]] + [F.interpolate(y, size=size, mode='bilinear', align_corners=True) for y in ys[1:]], 1)
+
+    def head(p):
+        h = F.relu(_bn(sd, p + '1.', F.conv2d(x, sd[p + '0.weight'], sd[p + '0.bias']), training))
+        return F.conv2d(h, sd[p + '3.weight'], sd[p + '3.bias'])
+    hms = head('encoder.hms_decoder.')
+    out = head('encoder.dp_decoder.')
+    return hms, out[:, 0], out[:, 1:], ys[::-1], None, None
+
+
+def hrnet_mid_forward(sd, img_f, training, p='mid_model.'):
+    """models/encoder.py:333-352 hrnet_mid.forward (img_f coarsest first)."""
+    fmaps = []
+    for i in range(4):
+        x = F.relu(F.conv2d(img_f[i], sd['%sconvs.%d.0.weight' % (p, i)]))
+        fmaps.append(_bn(sd, '%sconvs.%d.2.' % (p, i), x, training))
+    fine = img_f[::-1]
+    y = _bottleneck(sd, p + 'incre_modules.0.0.', fine[0], 1, training)
+    for i in range(3):
+        d = _cb(sd, '%sdownsamp_modules.%d.' % (p, i), y, training, stride=2, pad=1, relu=True)
+        y = _bottleneck(sd, '%sincre_modules.%d.0.' % (p, i + 1), fine[i + 1], 1, training) + d
+    y = _cb(sd, p + 'final_layer.', y, training, relu=True)
+    return F.adaptive_avg_pool2d(y, 1).flatten(1), fmaps
+
 # ----------------------------------------------------------------------------- decoder blocks
 def cheby(sd, p, x, L):
     """models/model_attn/gcn.py:34-69 with K=2: features interleaved as (fin, k)."""
@@ -234,13 +343,20 @@ def decoder_forward(sd, graph, gf, fmaps, p='decoder.'):
 
 
 def handnet_forward(sd, graph, img, training=False, taps=None):
-    """models/model.py:25-37 HandNET_GCN.forward."""
-    hms, mask, dp, img_f, hms_f, dp_f = encoder_forward(sd, img, training)
-    gf, fmaps = mid_forward(sd, img_f, hms_f, dp_f, training)
-    if taps is not None:
-        taps.update(x1=img_f[0], x2=img_f[1], x3=img_f[2], x4=img_f[3], gf=gf,
-                    fmap0=fmaps[0], fmap1=fmaps[1], fmap2=fmaps[2], fmap3=fmaps[3],
-                    hms_f3=hms_f[3], dp_f0=dp_f[0])
+    """models/model.py:25-37 HandNET_GCN.forward (ResNet or HRNet encoder, told apart by the state-dict keys)."""
+    if 'encoder.hrnet.conv1.weight' in sd:
+        hms, mask, dp, img_f, hms_f, dp_f = hrnet_encoder_forward(sd, img, training)
+        gf, fmaps = hrnet_mid_forward(sd, img_f, training)
+        if taps is not None:
+            taps.update(x1=img_f[0], x2=img_f[1], x3=img_f[2], x4=img_f[3], gf=gf,
+                        fmap0=fmaps[0], fmap1=fmaps[1], fmap2=fmaps[2], fmap3=fmaps[3])
+    else:
+        hms, mask, dp, img_f, hms_f, dp_f = encoder_forward(sd, img, training)
+        gf, fmaps = mid_forward(sd, img_f, hms_f, dp_f, training)
+        if taps is not None:
+            taps.update(x1=img_f[0], x2=img_f[1], x3=img_f[2], x4=img_f[3], gf=gf,
+                        fmap0=fmaps[0], fmap1=fmaps[1], fmap2=fmaps[2], fmap3=fmaps[3],
+                        hms_f3=hms_f[3], dp_f0=dp_f[0])
     result, paramsDict, handDictList, otherInfo = decoder_forward(sd, graph, gf, fmaps)
     otherInfo['hms'], otherInfo['mask'], otherInfo['dense'] = hms, mask, dp
     return result, paramsDict, handDictList, otherInfo

@@ -49,6 +49,10 @@ SIGNATURES = {
     'rih_avgpool_bwd': (c_i, [c_f, c_f, c_i, c_i, c_i, C.c_void_p]),
     'rih_upsample2x_fwd': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
     'rih_upsample2x_bwd': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_upsample_bilinear_fwd': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_upsample_bilinear_bwd': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_nearest_up_add_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_nearest_up_bwd': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
     'rih_bn_ws_floats': (c_l, [c_i, c_i]),
     'rih_bn_stats': (c_i, [c_f, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f, C.c_void_p]),
     'rih_bn_eval_stats': (c_i, [c_f, c_f, c_i, c_fl, c_f, c_f, C.c_void_p]),

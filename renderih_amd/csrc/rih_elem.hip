@@ -159,7 +159,8 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restri
     }
 }
 
-// bilinear x2, align_corners=True (nn.Upsample in models/encoder.py:51)
+// bilinear xF (F = 2, 4, 8 ...), align_corners=True (nn.Upsample in models/encoder.py:51; F.interpolate in
+// models/encoder.py:228-230 for the HRNet heads)
 __device__ __forceinline__ void bil_src(int o, float scale, int in_size, int& i0, int& i1, float& l1) {
     const float src = scale * (float)o;
     i0 = (int)src;
@@ -168,8 +169,9 @@ __device__ __forceinline__ void bil_src(int o, float scale, int in_size, int& i0
     l1 = src - (float)i0;
 }
 
-__global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
-    const int Ho = 2 * H, Wo = 2 * W;
+__global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C,
+                                      int F) {
+    const int Ho = F * H, Wo = F * W;
     const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float sw = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
     const long long total = (long long)N * Ho * Wo * C;
@@ -193,8 +195,8 @@ __global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __rest
 }
 
 __global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W,
-                                      int C) {
-    const int Ho = 2 * H, Wo = 2 * W;
+                                      int C, int F) {
+    const int Ho = F * H, Wo = F * W;
     const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float sw = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
     const long long total = (long long)N * H * W * C;
@@ -206,13 +208,13 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __res
         const int hi = (int)(t % H);
         const int n = (int)(t / H);
         float s = 0.f;
-        for (int ho = max(0, 2 * hi - 2); ho <= min(Ho - 1, 2 * hi + 3); ++ho) {
+        for (int ho = max(0, F * hi - F - 1); ho <= min(Ho - 1, F * hi + 2 * F); ++ho) {
             int h0, h1;
             float lh;
             bil_src(ho, sh, H, h0, h1, lh);
             const float wh = ((h0 == hi) ? (1.f - lh) : 0.f) + ((h1 == hi) ? lh : 0.f);
             if (wh == 0.f) continue;
-            for (int wo = max(0, 2 * wi - 2); wo <= min(Wo - 1, 2 * wi + 3); ++wo) {
+            for (int wo = max(0, F * wi - F - 1); wo <= min(Wo - 1, F * wi + 2 * F); ++wo) {
                 int w0, w1;
                 float lw;
                 bil_src(wo, sw, W, w0, w1, lw);
@@ -222,6 +224,54 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __res
             }
         }
         dx[i] = s;
+    }
+}
+
+// nearest xF upsample fused with the accumulation of HighResolutionModule's fuse sum (model_zoo/hrnet.py:181-183,
+// 229-236): y[n, ho, wo, :] = add[n, ho, wo, :] + x[n, ho/F, wo/F, :]
+__global__ void nearest_up_add_kernel(const float* __restrict__ x, const float* __restrict__ add, float* __restrict__ y,
+                                      int N, int H, int W, int C4, int F) {
+    const int Ho = F * H, Wo = F * W;
+    const long long total = (long long)N * Ho * Wo * C4;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float4* a4 = reinterpret_cast<const float4*>(add);
+    float4* y4 = reinterpret_cast<float4*>(y);
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4);
+        long long t = i / C4;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float4 v = x4[(((long long)n * H + ho / F) * W + wo / F) * C4 + c];
+        if (add != nullptr) {
+            const float4 a = a4[i];
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        y4[i] = v;
+    }
+}
+// dx[n, h, w, :] = sum of dy over the FxF block
+__global__ void nearest_up_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C4,
+                                      int F) {
+    const int Wo = F * W;
+    const long long total = (long long)N * H * W * C4;
+    const float4* d4 = reinterpret_cast<const float4*>(dy);
+    float4* x4 = reinterpret_cast<float4*>(dx);
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4);
+        long long t = i / C4;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int a = 0; a < F; ++a)
+            for (int b = 0; b < F; ++b) {
+                const float4 v = d4[(((long long)n * F * H + (F * h + a)) * Wo + (F * w + b)) * C4 + c];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        x4[i] = s;
     }
 }
 
@@ -875,16 +925,35 @@ extern "C" int rih_avgpool_bwd(const float* dy, float* dx, int N, int HW, int C,
     hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((long long)N * HW * C)), dim3(TPB), 0, STREAM, dy, dx, N, HW, C);
     LAUNCH_RET();
 }
-extern "C" int rih_upsample2x_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
-    if (!x || !y || N < 1 || H < 1 || W < 1 || C < 1) return RIH_EINVAL;
-    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for((long long)N * 4 * H * W * C)), dim3(TPB), 0, STREAM, x, y,
-                       N, H, W, C);
+extern "C" int rih_upsample_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int factor, void* stream) {
+    if (!x || !y || N < 1 || H < 1 || W < 1 || C < 1 || factor < 1 || factor > 64) return RIH_EINVAL;
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for((long long)N * factor * factor * H * W * C)), dim3(TPB), 0,
+                       STREAM, x, y, N, H, W, C, factor);
     LAUNCH_RET();
 }
-extern "C" int rih_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
-    if (!dy || !dx || N < 1 || H < 1 || W < 1 || C < 1) return RIH_EINVAL;
+extern "C" int rih_upsample_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int factor, void* stream) {
+    if (!dy || !dx || N < 1 || H < 1 || W < 1 || C < 1 || factor < 1 || factor > 64) return RIH_EINVAL;
     hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((long long)N * H * W * C)), dim3(TPB), 0, STREAM, dy, dx, N,
-                       H, W, C);
+                       H, W, C, factor);
+    LAUNCH_RET();
+}
+extern "C" int rih_upsample2x_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    return rih_upsample_bilinear_fwd(x, y, N, H, W, C, 2, stream);
+}
+extern "C" int rih_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+    return rih_upsample_bilinear_bwd(dy, dx, N, H, W, C, 2, stream);
+}
+extern "C" int rih_nearest_up_add_fwd(const float* x, const float* add, float* y, int N, int H, int W, int C, int factor,
+                                      void* stream) {
+    if (!x || !y || N < 1 || H < 1 || W < 1 || C < 4 || (C % 4) != 0 || factor < 1 || factor > 64) return RIH_EINVAL;
+    hipLaunchKernelGGL(nearest_up_add_kernel, dim3(grid_for((long long)N * factor * factor * H * W * (C / 4))), dim3(TPB),
+                       0, STREAM, x, add, y, N, H, W, C / 4, factor);
+    LAUNCH_RET();
+}
+extern "C" int rih_nearest_up_bwd(const float* dy, float* dx, int N, int H, int W, int C, int factor, void* stream) {
+    if (!dy || !dx || N < 1 || H < 1 || W < 1 || C < 4 || (C % 4) != 0 || factor < 1 || factor > 64) return RIH_EINVAL;
+    hipLaunchKernelGGL(nearest_up_bwd_kernel, dim3(grid_for((long long)N * H * W * (C / 4))), dim3(TPB), 0, STREAM, dy, dx,
+                       N, H, W, C / 4, factor);
     LAUNCH_RET();
 }
 

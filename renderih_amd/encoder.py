@@ -193,11 +193,92 @@ class resnet_mid(nn.Module):
         return gf, fmaps
 
 
+def _hr_name(model_type):
+    name = 'w' + model_type[model_type.find('hrnet') + 5:]
+    assert name in ('w18', 'w18_small_v1', 'w18_small_v2', 'w30', 'w32', 'w40', 'w44', 'w48', 'w64'), name
+    return name
+
+
+class HRnet_encoder(nn.Module):
+    """models/encoder.py:176-240: HRNet trunk; the four branch maps are brought to the finest resolution (bilinear,
+    align_corners) and concatenated for the two 1x1 heads (heatmaps 42 ch; mask 1 ch + dense 6 ch)."""
+
+    def __init__(self, model_type, pretrained='', handNum=2, heatmapDim=21):
+        super().__init__()
+        from .hrnet import HighResolutionNet
+        self.hrnet = HighResolutionNet(_hr_name(model_type), in_channels=3)
+        self.fmaps_dim = list(self.hrnet.stage_widths[-1])[::-1]           # coarsest first, e.g. [256,128,64,32]
+        self.hms_decoder = self.mask_decoder(heatmapDim * handNum)
+        self.dp_decoder = self.mask_decoder(1 + 3 * handNum)
+        for dec in (self.hms_decoder, self.dp_decoder):
+            for m in dec.modules():
+                _zoo_weights_init(m)
+
+    def mask_decoder(self, outDim=3):
+        c = sum(self.fmaps_dim)
+        return nn.Sequential(nn.Conv2d(c, c, 1, 1, 0), nn.BatchNorm2d(c), nn.ReLU(inplace=True), nn.Conv2d(c, outDim, 1, 1, 0))
+
+    @staticmethod
+    def _head(seq, x):
+        return conv(seq[3], bn_act(seq[1], conv(seq[0], x), relu=True))
+
+    def forward(self, img):
+        ys = self.hrnet(ops.nchw_to_nhwc(img, cpad=4))
+        h0 = ys[0].shape[1]
+        x = torch.cat([ys[0]] + [ops.upsample_bilinear(y, h0 // y.shape[1]) for y in ys[1:]], dim=-1)
+        hms = self._head(self.hms_decoder, x)
+        out = self._head(self.dp_decoder, x)
+        mask = ops.nhwc_to_nchw(out, 0, 1)[:, 0]                 # `out[:, 0]`: [B, 64, 64]  (encoder.py:235)
+        dp = ops.nhwc_to_nchw(out, 1, out.shape[-1])
+        return ops.nhwc_to_nchw(hms), mask, dp, ys[::-1], None, None
+
+
+class hrnet_mid(nn.Module):
+    """models/encoder.py:243-352: per-branch 1x1 adapters for the decoder + the HRNet classification-style head
+    (Bottleneck per branch, stride-2 3x3 down-sampling chain, 1x1 to 2048, global average) as the global feature."""
+
+    def __init__(self, model_type, in_fmapDim=(256, 256, 256, 256), out_fmapDim=(256, 256, 256, 256)):
+        super().__init__()
+        _hr_name(model_type)
+        in_fmapDim = list(in_fmapDim)
+        self.convs = nn.ModuleList([conv1x1(in_fmapDim[i], out_fmapDim[i]) for i in range(len(out_fmapDim))])
+        self.global_feature_dim = 2048
+        self.fmaps_dim = list(out_fmapDim)
+        from .hrnet import make_layer
+        pre = in_fmapDim[::-1]                                            # finest first
+        head = [32, 64, 128, 256]
+        self.incre_modules = nn.ModuleList([make_layer(Bottleneck, c, head[i], 1) for i, c in enumerate(pre)])
+        self.downsamp_modules = nn.ModuleList([
+            nn.Sequential(nn.Conv2d(head[i] * 4, head[i + 1] * 4, 3, 2, 1), nn.BatchNorm2d(head[i + 1] * 4, momentum=0.1),
+                          nn.ReLU(inplace=True)) for i in range(len(pre) - 1)])
+        self.final_layer = nn.Sequential(nn.Conv2d(head[3] * 4, 2048, 1, 1, 0), nn.BatchNorm2d(2048, momentum=0.1),
+                                         nn.ReLU(inplace=True))
+
+    def get_info(self):
+        return {'global_feature_dim': self.global_feature_dim, 'fmaps_dim': self.fmaps_dim}
+
+    def forward(self, img_fmaps, hms_fmaps=None, dp_fmaps=None):
+        """img_fmaps: branch maps, coarsest first (NHWC)."""
+        fmaps = [bn_act(seq[2], conv(seq[0], img_fmaps[i], relu=True)) for i, seq in enumerate(self.convs)]
+        fine_first = img_fmaps[::-1]
+        y = self.incre_modules[0](fine_first[0])
+        for i, ds in enumerate(self.downsamp_modules):
+            down = bn_act(ds[1], conv(ds[0], y), relu=True)
+            y = ops.add_dropout(self.incre_modules[i + 1](fine_first[i + 1]), down)
+        y = bn_act(self.final_layer[1], conv(self.final_layer[0], y), relu=True)
+        return ops.global_avgpool(y), fmaps
+
+
 def load_encoder(cfg):
-    """models/encoder.py:355-374 (ResNet branch; `pretrained=True` there is a download and is ignored offline)."""
+    """models/encoder.py:355-374 (`pretrained=True` / ENCODER_PRETRAIN_PATH loading there is a download / an optional
+    file and is not done here: weights come from `load_state_dict`)."""
     et = cfg.MODEL.ENCODER_TYPE
     if et.find('resnet') != -1:
         encoder = ResNetSimple(model_type=et, pretrained=False, fmapDim=[128, 128, 128, 128], handNum=2, heatmapDim=21)
         mid_model = resnet_mid(model_type=et, in_fmapDim=[128, 128, 128, 128], out_fmapDim=cfg.MODEL.DECONV_DIMS)
         return encoder, mid_model
-    raise NotImplementedError('encoder type %s: HRNet-W32 variant is the next scope row (SURVEY 8a5)' % et)
+    if et.find('hrnet') != -1:
+        encoder = HRnet_encoder(model_type=et, pretrained='', handNum=2, heatmapDim=21)
+        mid_model = hrnet_mid(model_type=et, in_fmapDim=encoder.fmaps_dim, out_fmapDim=cfg.MODEL.DECONV_DIMS)
+        return encoder, mid_model
+    raise NotImplementedError('encoder type %s' % et)

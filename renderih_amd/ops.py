@@ -439,28 +439,70 @@ def global_avgpool(x):
     return AvgPoolFn.apply(x)
 
 
-class Upsample2xFn(torch.autograd.Function):
+class UpsampleBilinearFn(torch.autograd.Function):
+    """Bilinear x`factor`, align_corners=True (nn.Upsample / F.interpolate of models/encoder.py:31,228-230), NHWC."""
+
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, factor):
         _chk(x)
         x = _c(x)
         N, H, W_, Cc = x.shape
-        y = torch.empty((N, 2 * H, 2 * W_, Cc), device=x.device, dtype=torch.float32)
-        check(_L().rih_upsample2x_fwd(x.data_ptr(), y.data_ptr(), N, H, W_, Cc, _stream()), 'rih_upsample2x_fwd')
-        ctx.shape = (N, H, W_, Cc)
+        y = torch.empty((N, factor * H, factor * W_, Cc), device=x.device, dtype=torch.float32)
+        check(_L().rih_upsample_bilinear_fwd(x.data_ptr(), y.data_ptr(), N, H, W_, Cc, factor, _stream()),
+              'rih_upsample_bilinear_fwd')
+        ctx.shape = (N, H, W_, Cc, factor)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        N, H, W_, Cc = ctx.shape
+        N, H, W_, Cc, factor = ctx.shape
         dy = _c(dy)
         dx = torch.empty((N, H, W_, Cc), device=dy.device, dtype=torch.float32)
-        check(_L().rih_upsample2x_bwd(dy.data_ptr(), dx.data_ptr(), N, H, W_, Cc, _stream()), 'rih_upsample2x_bwd')
-        return dx
+        check(_L().rih_upsample_bilinear_bwd(dy.data_ptr(), dx.data_ptr(), N, H, W_, Cc, factor, _stream()),
+              'rih_upsample_bilinear_bwd')
+        return dx, None
+
+
+def upsample_bilinear(x, factor):
+    return UpsampleBilinearFn.apply(x, factor)
 
 
 def upsample_bilinear2x(x):
-    return Upsample2xFn.apply(x)
+    return UpsampleBilinearFn.apply(x, 2)
+
+
+class NearestUpAddFn(torch.autograd.Function):
+    """y = acc + nearest_upsample(x, factor) on NHWC tensors (acc may be None): the cross-resolution sum of
+    HighResolutionModule's fuse layers (models/model_zoo/hrnet.py:181-183, 229-236) in one pass."""
+
+    @staticmethod
+    def forward(ctx, x, acc, factor):
+        _chk(x, acc)
+        x = _c(x)
+        N, H, W_, Cc = x.shape
+        if acc is not None:
+            acc = _c(acc)
+            assert tuple(acc.shape) == (N, factor * H, factor * W_, Cc)
+        y = torch.empty((N, factor * H, factor * W_, Cc), device=x.device, dtype=torch.float32)
+        check(_L().rih_nearest_up_add_fwd(x.data_ptr(), _p(acc), y.data_ptr(), N, H, W_, Cc, factor, _stream()),
+              'rih_nearest_up_add_fwd')
+        ctx.shape = (N, H, W_, Cc, factor, acc is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W_, Cc, factor, has_acc = ctx.shape
+        dy = _c(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((N, H, W_, Cc), device=dy.device, dtype=torch.float32)
+            check(_L().rih_nearest_up_bwd(dy.data_ptr(), dx.data_ptr(), N, H, W_, Cc, factor, _stream()),
+                  'rih_nearest_up_bwd')
+        return dx, (dy if (has_acc and ctx.needs_input_grad[1]) else None), None
+
+
+def nearest_up_add(x, acc, factor):
+    return NearestUpAddFn.apply(x, acc, factor)
 
 
 # --------------------------------------------------------------------------------------------- row-wise ops

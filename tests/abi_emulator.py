@@ -192,19 +192,38 @@ class EmulatedLib:
         _f(dx, N * HW * Cc)[:] = np.broadcast_to(d, (N, HW, Cc)).ravel()
         return 0
 
-    def rih_upsample2x_fwd(self, x, y, N, H, W, Cc, stream):
+    def rih_upsample_bilinear_fwd(self, x, y, N, H, W, Cc, f, stream):
         X = torch.from_numpy(_f(x, N * H * W * Cc).reshape(N, H, W, Cc).copy()).permute(0, 3, 1, 2)
-        Y = F.interpolate(X, scale_factor=2, mode='bilinear', align_corners=True)
+        Y = F.interpolate(X, scale_factor=f, mode='bilinear', align_corners=True)
         _f(y, Y.numel())[:] = Y.permute(0, 2, 3, 1).contiguous().numpy().ravel()
         return 0
 
-    def rih_upsample2x_bwd(self, dy, dx, N, H, W, Cc, stream):
+    def rih_upsample_bilinear_bwd(self, dy, dx, N, H, W, Cc, f, stream):
         with torch.enable_grad():
             X = torch.zeros(N, Cc, H, W, requires_grad=True)
-            Y = F.interpolate(X, scale_factor=2, mode='bilinear', align_corners=True)
-            G = torch.from_numpy(_f(dy, N * 4 * H * W * Cc).reshape(N, 2 * H, 2 * W, Cc).copy()).permute(0, 3, 1, 2)
+            Y = F.interpolate(X, scale_factor=f, mode='bilinear', align_corners=True)
+            G = torch.from_numpy(_f(dy, N * f * f * H * W * Cc).reshape(N, f * H, f * W, Cc).copy()).permute(0, 3, 1, 2)
             Y.backward(G)
         _f(dx, N * H * W * Cc)[:] = X.grad.permute(0, 2, 3, 1).contiguous().numpy().ravel()
+        return 0
+
+    def rih_upsample2x_fwd(self, x, y, N, H, W, Cc, stream):
+        return self.rih_upsample_bilinear_fwd(x, y, N, H, W, Cc, 2, stream)
+
+    def rih_upsample2x_bwd(self, dy, dx, N, H, W, Cc, stream):
+        return self.rih_upsample_bilinear_bwd(dy, dx, N, H, W, Cc, 2, stream)
+
+    def rih_nearest_up_add_fwd(self, x, add, y, N, H, W, Cc, f, stream):
+        X = _f(x, N * H * W * Cc).reshape(N, H, W, Cc)
+        Y = np.repeat(np.repeat(X, f, axis=1), f, axis=2)
+        if add:
+            Y = Y + _f(add, N * f * f * H * W * Cc).reshape(N, f * H, f * W, Cc)
+        _f(y, Y.size)[:] = Y.ravel()
+        return 0
+
+    def rih_nearest_up_bwd(self, dy, dx, N, H, W, Cc, f, stream):
+        G = _f(dy, N * f * f * H * W * Cc).reshape(N, H, f, W, f, Cc)
+        _f(dx, N * H * W * Cc)[:] = G.sum(axis=(2, 4)).ravel()
         return 0
 
     # ------------------------------------------------------------------ batch norm

@@ -28,7 +28,7 @@ import ref_stubs  # noqa: E402
 ref_stubs.install()                     # puts /root/reference first on sys.path
 warnings.filterwarnings('ignore')
 
-from models.encoder import ResNetSimple, resnet_mid                   # noqa: E402  (reference)
+from models.encoder import ResNetSimple, resnet_mid, HRnet_encoder, hrnet_mid  # noqa: E402  (reference)
 from models.decoder import decoder as RefDecoder                     # noqa: E402  (reference)
 from models.model import HandNET_GCN                                 # noqa: E402  (reference)
 from models.manolayer import ManoLayer, rodrigues_batch              # noqa: E402  (reference)
@@ -49,9 +49,13 @@ testing = _load('rih_testing', os.path.join(ROOT, 'renderih_amd', 'testing.py'))
 net_oracle = _load('net_oracle', os.path.join(ROOT, 'oracle', 'net_oracle.py'))
 
 
-def build_reference_model(dropout=0.0):
-    enc = ResNetSimple(model_type='resnet50', pretrained=True, fmapDim=[128] * 4, handNum=2, heatmapDim=21)
-    mid = resnet_mid(model_type='resnet50', in_fmapDim=[128] * 4, out_fmapDim=[256] * 4)
+def build_reference_model(dropout=0.0, encoder='resnet50'):
+    if encoder.startswith('hrnet'):     # models/encoder.py:366-372
+        enc = HRnet_encoder(model_type=encoder, pretrained='', handNum=2, heatmapDim=21)
+        mid = hrnet_mid(model_type=encoder, in_fmapDim=enc.fmaps_dim, out_fmapDim=[256] * 4)
+    else:
+        enc = ResNetSimple(model_type='resnet50', pretrained=True, fmapDim=[128] * 4, handNum=2, heatmapDim=21)
+        mid = resnet_mid(model_type='resnet50', in_fmapDim=[128] * 4, out_fmapDim=[256] * 4)
     dec = RefDecoder(global_feature_dim=2048, f_in_Dim=[256] * 4, f_out_Dim=[256, 128, 64],
                      gcn_in_dim=[512, 256, 128], gcn_out_dim=[256, 128, 64], graph_k=2, graph_layer_num=4,
                      left_graph_dict=assets.load_graph_dict('left'), right_graph_dict=assets.load_graph_dict('right'),
@@ -91,15 +95,31 @@ def tap_hooks(model, taps):
     return hs
 
 
-def net_fixture(mode):
+def hr_tap_hooks(model, taps):
+    hs = []
+    for i in range(4):
+        hs.append(model.mid_model.convs[i].register_forward_hook(lambda m, a, o, i=i: taps.__setitem__('fmap%d' % i, o)))
+    def stage_hook(tag):        # a forward hook must return None (anything else replaces the module output)
+        def f(m, a, o):
+            for k, t in enumerate(o):
+                taps['%s_b%d' % (tag, k)] = t.detach().clone()
+        return f
+    hs.append(model.encoder.hrnet.stage2.register_forward_hook(stage_hook('s2')))
+    hs.append(model.encoder.hrnet.stage4.register_forward_hook(stage_hook('s4')))
+    hs.append(model.mid_model.register_forward_hook(lambda m, a, o: taps.__setitem__('gf', o[0])))
+    return hs
+
+
+def net_fixture(mode, encoder='resnet50'):
     torch.manual_seed(0)
-    model = build_reference_model(dropout=0.0)
+    hr = encoder.startswith('hrnet')
+    model = build_reference_model(dropout=0.0, encoder=encoder)
     sd = testing.deterministic_state(model.state_dict(), seed=0)
     model.load_state_dict(sd)
     model.train(mode == 'train')
     img = testing.seeded_image(2, seed=0)
     taps = {}
-    hs = tap_hooks(model, taps)
+    hs = hr_tap_hooks(model, taps) if hr else tap_hooks(model, taps)
     store = {}
     if mode == 'eval':
         with torch.no_grad():
@@ -126,12 +146,17 @@ def net_fixture(mode):
             store['grad/' + k + '#samp'] = sa
         store['grad_names'] = np.array(names)
         nsd = model.state_dict()
-        for k in ('encoder.resnet.bn1.running_mean', 'encoder.resnet.bn1.running_var',
+        bnkeys = ('encoder.hrnet.bn1.running_mean', 'encoder.hrnet.bn1.running_var',
+                  'encoder.hrnet.stage4.2.fuse_layers.3.0.2.1.running_var',
+                  'encoder.hrnet.stage3.1.branches.2.3.bn2.running_mean', 'mid_model.final_layer.1.running_var',
+                  'encoder.hms_decoder.1.running_mean', 'encoder.hrnet.bn1.num_batches_tracked') if hr else \
+                 ('encoder.resnet.bn1.running_mean', 'encoder.resnet.bn1.running_var',
                   'encoder.resnet.layer4.2.bn3.running_mean', 'encoder.resnet.layer4.2.bn3.running_var',
                   'mid_model.convs.1.2.running_var', 'encoder.hms_decoder.models.2.3.running_mean',
-                  'encoder.resnet.bn1.num_batches_tracked'):
+                  'encoder.resnet.bn1.num_batches_tracked')
+        for k in bnkeys:
             store['bnstat/' + k] = nsd[k].numpy()
-    path = os.path.join(HERE, 'net_%s.npz' % mode)
+    path = os.path.join(HERE, 'net_%s%s.npz' % ('hrnet_' if hr else '', mode))
     np.savez_compressed(path, **store)
     print('wrote', path, os.path.getsize(path), 'bytes,', len(store), 'arrays')
 
@@ -189,15 +214,16 @@ def mano_fixture():
 
 
 def keys_fixture():
-    """Reference state_dict schema (key -> shape) for the ResNet50 variant."""
+    """Reference state_dict schema (key -> shape) for the ResNet50 and HRNet-W32 variants."""
     import json
-    torch.manual_seed(0)
-    model = build_reference_model(dropout=0.05)
-    sch = {k: list(v.shape) for k, v in model.state_dict().items()}
-    path = os.path.join(HERE, 'state_keys.json')
-    with open(path, 'w') as f:
-        json.dump(sch, f)
-    print('wrote', path, len(sch), 'keys')
+    for enc, fn in (('resnet50', 'state_keys.json'), ('hrnet32', 'state_keys_hrnet32.json')):
+        torch.manual_seed(0)
+        model = build_reference_model(dropout=0.05, encoder=enc)
+        sch = {k: list(v.shape) for k, v in model.state_dict().items()}
+        path = os.path.join(HERE, fn)
+        with open(path, 'w') as f:
+            json.dump(sch, f)
+        print('wrote', path, len(sch), 'keys')
 
 
 def zlibseed(s):
@@ -206,7 +232,10 @@ def zlibseed(s):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['eval', 'train', 'mano', 'keys']
+    which = sys.argv[1:] or ['eval', 'train', 'mano', 'keys', 'hrnet']
+    if 'hrnet' in which:
+        net_fixture('eval', 'hrnet32')
+        net_fixture('train', 'hrnet32')
     if 'keys' in which:
         keys_fixture()
     if 'mano' in which:

@@ -44,6 +44,27 @@ def test_other_ops_host_logic():
 
 def test_pool_layout_host_logic(monkeypatch):
     G.test_pool_upsample_layout()
+    G.test_resample_hrnet(4, 5, 7, 32)
+    G.test_resample_hrnet(2, 8, 8, 64)
+
+
+def test_hrnet_host_logic_matches_oracle():
+    """HRNet-W32 variant, B=1, eval mode (running-statistics BN: well conditioned), forward only: the module graph
+    (transitions, fuse sums, heads, mid head) against the oracle at 1e-4."""
+    from oracle import net_oracle
+    from renderih_amd.model import build_model
+    m = build_model(0.0, 'hrnet32')
+    sd = testing.deterministic_state(m.state_dict(), seed=3)
+    m.load_state_dict(sd)
+    m.eval()
+    img = testing.seeded_image(1, 4)
+    with torch.no_grad():
+        got = testing.flatten_outputs(m(img))
+        graph = net_oracle.graph_from_dicts(assets.load_graph_dict('left'), assets.load_graph_dict('right'))
+        want = testing.flatten_outputs(net_oracle.handnet_forward(sd, graph, img, training=False))
+    for k in want:
+        if not k.startswith('params.'):
+            assert testing.rel_err(got[k], want[k]) < 1e-4, (k, testing.rel_err(got[k], want[k]))
 
 
 def test_model_host_logic_matches_oracle():

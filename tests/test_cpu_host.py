@@ -58,6 +58,15 @@ def test_state_dict_schema_equals_reference():
     assert {k: list(v.shape) for k, v in sd.items()} == ref
 
 
+def test_state_dict_schema_equals_reference_hrnet32():
+    """HRNet-W32 variant (ENCODER_TYPE hrnet32): same key set and shapes as the reference's module tree."""
+    from renderih_amd.model import build_model
+    ref = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'state_keys_hrnet32.json')))
+    sd = build_model(0.05, 'hrnet32').state_dict()
+    assert set(sd.keys()) == set(ref.keys()), sorted(set(sd.keys()) ^ set(ref.keys()))[:10]
+    assert {k: list(v.shape) for k, v in sd.items()} == ref
+
+
 def test_dropin_import_paths_and_config(tmp_path):
     import models.model as mm
     import models.manolayer as ml

@@ -12,11 +12,11 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 
 
-def _build(dropout=0.0, seed=0):
+def _build(dropout=0.0, seed=0, encoder='resnet50'):
     from renderih_amd.model import build_model
     from renderih_amd import _lib
     _lib.load()
-    m = build_model(dropout)
+    m = build_model(dropout, encoder)
     sd = testing.deterministic_state(m.state_dict(), seed=seed)
     m.load_state_dict(sd)
     return m.to('cuda:0'), sd
@@ -49,8 +49,8 @@ def _grad_report(named_grads, g32, g64, k=6.0, floor=2e-4):
     floor, and every tensor within max(5%, 20 x that reference error) of max|ref|."""
     n, loose, gross = 0, [], []
     for name, g in named_grads:
-        if name.endswith('w_ks.bias'):
-            continue            # exactly zero in exact arithmetic (softmax shift invariance): round-off noise only
+        if testing.is_null_gradient(name):
+            continue            # exactly zero in exact arithmetic: round-off noise only
         ref64, ref32 = g64[name], g32[name]
         scale = float(ref64.abs().max().clamp_min(1e-30))
         e_got = float((g.detach().double().cpu() - ref64).abs().max()) / scale
@@ -160,3 +160,37 @@ def test_full_size_batch_properties():
     for k, v in big.items():
         assert torch.isfinite(v).all(), k
         assert_close(v[5:6], one[k], 1e-4, 1e-5, 'batch-independence ' + k)
+
+
+# ------------------------------------------------------------------------------------------------ HRNet-W32 variant
+def test_hrnet_eval_matches_reference_golden():
+    """ENCODER_TYPE hrnet32 (BASELINE config 4), eval mode: strict 1e-4 against vectors the real reference produced."""
+    z = np.load(os.path.join(GOLDEN, 'net_hrnet_eval.npz'))
+    m, _ = _build(0.0, encoder='hrnet32')
+    m.eval()
+    with torch.no_grad():
+        out = m(testing.seeded_image(2, 0).cuda())
+    for k, v in testing.flatten_outputs(out).items():
+        _check_golden(z, 'out/' + k, v)
+
+
+@pytest.mark.parametrize('training', [False, True])
+def test_hrnet_matches_fp64_oracle(training):
+    """Forward outputs and every parameter gradient of the HRNet-W32 variant, anchored on the fp64 oracle."""
+    from oracle import net_oracle
+    m, sd = _build(0.0, seed=7, encoder='hrnet32')
+    m.train(training)
+    img = testing.seeded_image(2, 13)
+    graph = net_oracle.graph_from_dicts(assets.load_graph_dict('left'), assets.load_graph_dict('right'))
+    w32, g32 = net_oracle.run(sd, graph, img, training, torch.float32, True)
+    w64, g64 = net_oracle.run(sd, graph, img, training, torch.float64, True)
+    out = m(img.cuda())
+    got = testing.flatten_outputs(out)
+    for k in w64:
+        testing.assert_fp32_equivalent(got[k], w32[k], w64[k], k=4.0, floor=2e-5, what=k)
+    net_oracle.scalar_loss(out).backward()
+    params = [(k, p.grad) for k, p in m.named_parameters() if p.grad is not None]
+    assert {k for k, _ in params} == set(g64.keys())
+    _grad_report(params, g32, g64)
+    if training:
+        assert int(m.encoder.hrnet.bn1.num_batches_tracked) == 1

@@ -306,6 +306,38 @@ def test_pool_upsample_layout():
     assert torch.equal(tg.grad.cpu(), want)
 
 
+@pytest.mark.parametrize('f,H,W,C', [(2, 8, 8, 64), (4, 16, 16, 128), (8, 8, 8, 256), (4, 5, 7, 32)])
+def test_resample_hrnet(f, H, W, C):
+    """Bilinear x2/x4/x8 (align_corners, HRNet heads) and the fused nearest-upsample + add of the HRNet fuse layers."""
+    from renderih_amd import ops
+    d = dev()
+    x = rnd(2, C, H, W, seed=11)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, size=(f * H, f * W), mode='bilinear', align_corners=True)
+    gy = rnd(*yr.shape, seed=12)
+    yr.backward(gy)
+    xg = nhwc(x).to(d).requires_grad_(True)
+    yg = ops.upsample_bilinear(xg, f)
+    assert_close(nchw(yg), yr, what='bilinear x%d' % f)
+    yg.backward(nhwc(gy).to(d))
+    assert_close(nchw(xg.grad), xr.grad, 1e-4, 1e-5, 'bilinear x%d dx' % f)
+
+    acc = rnd(2, C, f * H, f * W, seed=13)
+    xr = x.clone().requires_grad_(True)
+    ar = acc.clone().requires_grad_(True)
+    yr = ar + F.interpolate(xr, scale_factor=f, mode='nearest')
+    yr.backward(gy)
+    xg = nhwc(x).to(d).requires_grad_(True)
+    ag = nhwc(acc).to(d).requires_grad_(True)
+    yg = ops.nearest_up_add(xg, ag, f)
+    assert_close(nchw(yg), yr, what='nearest x%d + add' % f)
+    yg.backward(nhwc(gy).to(d))
+    assert_close(nchw(xg.grad), xr.grad, 1e-4, 1e-5, 'nearest x%d dx' % f)
+    assert_close(nchw(ag.grad), ar.grad, what='nearest add grad')
+    y0 = ops.nearest_up_add(nhwc(x).to(d), None, f)
+    assert_close(nchw(y0), F.interpolate(x, scale_factor=f, mode='nearest'), what='nearest x%d' % f)
+
+
 def test_cheby_gather_project():
     from renderih_amd import ops, assets
     from renderih_amd.attn import GraphCSR
