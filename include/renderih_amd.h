@@ -75,6 +75,12 @@ typedef struct rih_gemm_desc {
                                (hi+mid+lo, 24 significand bits), six v_mfma_f32_32x32x16_bf16 products, fp32
                                accumulate -- same accuracy as engine 0 (error <= ~2^-23 relative per product),
                                2.5 PF / 6 = 417 TF peak.  Tiles 0,1,2 only (tile 3 always runs engine 0). */
+    /* Strided output rows (cS > 1; a_mode 0, splitk 1, no residual): GEMM row m = (img, i, j) over (Ho, Wo) is stored
+     * to pixel (img, i*cS + cOH, j*cS + cOW) of a [*, cH, cW, ldc] tensor.  Used to compute the data gradient of a
+     * stride-s convolution as s*s dense sub-convolutions, one per output parity class (each with the kernel taps
+     * kh = kh0 + s*t that can reach that class, packed by rih_pack_conv_weight_sub), instead of one convolution over
+     * a zero-stuffed gradient (upS) in which (s*s-1)/(s*s) of the products are structural zeros.  cS <= 1: off. */
+    int32_t cS, cOH, cOW, cH, cW;
 } rih_gemm_desc;
 
 int rih_gemm(const rih_gemm_desc* d, void* stream);
@@ -94,6 +100,10 @@ int rih_splitk_finish(const float* P, int S, int M, int N, float* C, int ldc, co
  * with for_dgrad!=0, dst[(((KH-1-kh)*KW + (KW-1-kw))*Cout + co)*Ci_pad + ci] (flipped, in/out swapped). */
 int rih_pack_conv_weight(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int CinPad,
                          int for_dgrad, void* stream);
+/* Tap subset for one parity class of a strided data gradient:
+ * dst[((th*Tw + tw)*Cout + co)*CinPad + ci] = w[co][ci][kh0 + step*(Th-1-th)][kw0 + step*(Tw-1-tw)]. */
+int rih_pack_conv_weight_sub(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int CinPad, int kh0,
+                             int kw0, int step, int Th, int Tw, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Layout, pooling, resampling   (models/encoder.py:107-113 stem, :31 nn.Upsample, :155-158 avgpool)   */

@@ -36,6 +36,7 @@ struct GemmArgs {
     int H, W, Cin, Ho, Wo, KH, KW, strideA, upS, padH, padW;
     int vecA, vecB;
     unsigned a_bytes, b_bytes;      // extent of one batch slice of A / B (split fast path: buffer range check)
+    int cS, cOH, cOW, cH, cW;       // strided output rows (parity classes of a strided-conv data gradient)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -46,6 +47,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// Row of C that GEMM row m = (img, i, j) over (Ho, Wo) is stored to.  cS <= 1: row m.  cS > 1: pixel
+// (img, i*cS + cOH, j*cS + cOW) of a [*, cH, cW] tensor -- one parity class of a strided convolution's data gradient.
+__device__ __forceinline__ long long c_row(const GemmArgs& p, int m) {
+    if (p.cS <= 1) return m;
+    const int j = m % p.Wo;
+    const int t = m / p.Wo;
+    const int i = t % p.Ho;
+    const int img = t / p.Ho;
+    return ((long long)img * p.cH + (i * p.cS + p.cOH)) * p.cW + (j * p.cS + p.cOW);
+}
 
 // ---- split engine (ENGINE 1): fp32 operands are split on the way into LDS into three bf16 planes
 // x = hi + mid + lo (round-to-nearest at every level, residual <= 2^-24 |x|) and the product is formed on the bf16
@@ -487,7 +499,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                         if (p.R != nullptr) v += p.R[(long long)m * p.ldr + n];
                         if (p.relu) v = fmaxf(v, 0.f);
                     }
-                    C[(long long)m * p.ldc + n] = v;
+                    C[c_row(p, m) * p.ldc + n] = v;
                 }
             }
         }
@@ -538,6 +550,9 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off)
 
 template <int BM, int BN, int AMODE, int BMODE, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
+    // global->register prefetch depth: k-tiles in flight.  The 64x64 tile (decoder-sized problems: a handful of
+    // k-tiles, 12 MFMAs each) is bound by the load round trip per k-tile, so it keeps three tiles in flight.
+    constexpr int PF = 1;     // (measured: 3 tiles in flight for the 64x64 tile changes nothing, the floor is elsewhere)
     constexpr int PLANE_A = BM * 16, PLANE_B = BN * 16;
     constexpr int WGN = 2, WGM = 2;
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -664,27 +679,25 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
         u_kw = u_tap - u_kh * p.KW;
     }
 
-    float4 areg[NPA], breg[NPB];
+    float4 areg[PF][NPA], breg[PF][NPB];
 
-    auto load_A = [&](int ktile) {
+    auto load_A = [&](int ktile, int st) {
         if (AMODE == 0) {
             if (PLAIN) {
                 const unsigned ku = (ktile + 4 * q8 < kend) ? (unsigned)ktile * 4u : OOB;
 #pragma unroll
-                for (int i = 0; i < NPA; ++i) areg[i] = bload4(rA, a_off[i] + ku);
+                for (int i = 0; i < NPA; ++i) areg[st][i] = bload4(rA, a_off[i] + ku);
             } else {
                 const unsigned tapoff = (unsigned)(((u_kh * p.W + u_kw) * p.lda + u_ci) * 4);
+                const unsigned tapbit = (ktile < kend) ? (1u << (u_tap & 31)) : 0u;
 #pragma unroll
-                for (int i = 0; i < NPA; ++i) {
-                    const bool ok = (a_val[i] >> u_tap) & 1u;
-                    areg[i] = bload4(rA, ok ? a_off[i] + tapoff : OOB);
-                }
+                for (int i = 0; i < NPA; ++i) areg[st][i] = bload4(rA, (a_val[i] & tapbit) ? a_off[i] + tapoff : OOB);
             }
         } else {
             if (PLAIN) {
                 const unsigned ku = (ktile + akr * NPA < kend) ? (unsigned)ktile * (unsigned)p.lda * 4u : OOB;
 #pragma unroll
-                for (int i = 0; i < NPA; ++i) areg[i] = bload4(rA, a1_base + ku + (unsigned)i * (unsigned)p.lda * 4u);
+                for (int i = 0; i < NPA; ++i) areg[st][i] = bload4(rA, a1_base + ku + (unsigned)i * (unsigned)p.lda * 4u);
             } else {
                 const int hi = a1_ho * p.strideA - p.padH + a1_kh;
                 const int wi = a1_wo * p.strideA - p.padW + a1_kw;
@@ -693,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int i = 0; i < NPA; ++i) {
                     const bool ok = rowok && (unsigned)(wi + i * p.strideA) < (unsigned)p.W;
-                    areg[i] = bload4(rA, ok ? rowoff + (unsigned)(i * p.strideA * p.lda * 4) : OOB);
+                    areg[st][i] = bload4(rA, ok ? rowoff + (unsigned)(i * p.strideA * p.lda * 4) : OOB);
                 }
             }
         }
@@ -713,15 +726,15 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
             while (a1_ho >= p.Ho) { a1_ho -= p.Ho; ++a1_img; }
         }
     };
-    auto load_B = [&](int ktile) {
+    auto load_B = [&](int ktile, int st) {
         if (BMODE == 1) {
             const unsigned ku = (ktile + 4 * q8 < kend) ? (unsigned)ktile * 4u : OOB;
 #pragma unroll
-            for (int i = 0; i < NPB; ++i) breg[i] = bload4(rB, b_off[i] + ku);
+            for (int i = 0; i < NPB; ++i) breg[st][i] = bload4(rB, b_off[i] + ku);
         } else {
             const unsigned ku = (ktile + bkr * NPB < kend) ? (unsigned)ktile * (unsigned)p.ldb * 4u : OOB;
 #pragma unroll
-            for (int i = 0; i < NPB; ++i) breg[i] = bload4(rB, b_off[i] + ku);
+            for (int i = 0; i < NPB; ++i) breg[st][i] = bload4(rB, b_off[i] + ku);
         }
     };
 
@@ -758,13 +771,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
             put2(base + st[3], plane, reg[0].w, reg[1].w);
         }
     };
-    auto store_A = [&]() {
-        if (AMODE == 0) store_kcontig(As, PLANE_A, areg, a_st, NPA);
-        else store_kstrided(As, PLANE_A, areg, a_st, NPA);
+    auto store_A = [&](int st) {
+        if (AMODE == 0) store_kcontig(As, PLANE_A, areg[st], a_st, NPA);
+        else store_kstrided(As, PLANE_A, areg[st], a_st, NPA);
     };
-    auto store_B = [&]() {
-        if (BMODE == 1) store_kcontig(Bs, PLANE_B, breg, b_st, NPB);
-        else store_kstrided(Bs, PLANE_B, breg, b_st, NPB);
+    auto store_B = [&](int st) {
+        if (BMODE == 1) store_kcontig(Bs, PLANE_B, breg[st], b_st, NPB);
+        else store_kstrided(Bs, PLANE_B, breg[st], b_st, NPB);
     };
 
     // ------------------------------------------------------------------ main loop
@@ -776,13 +789,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (ntiles > 0) {
-        load_A(kbeg);
-        load_B(kbeg);
-        store_A();
-        store_B();
+    // prologue: tiles 0..PF-1 in flight (a tile at or beyond kend arrives as zeros and is never multiplied)
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        if (j > 0) advance_A();
+        load_A(kbeg + j * BK, j);
+        load_B(kbeg + j * BK, j);
     }
-    __syncthreads();
 
     const int l31 = lane & 31, lhi = lane >> 5;
     int sa_off[2], sb_off[2];
@@ -795,41 +808,43 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
         }
     }
 
-    for (int t = 0; t < ntiles; ++t) {
-        const bool more = (t + 1 < ntiles);
-        if (more) {
-            advance_A();
-            load_A(kbeg + (t + 1) * BK);
-            load_B(kbeg + (t + 1) * BK);
-        }
+    for (int t = 0; t < ntiles; t += PF) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 av[3][TM], bv[3][TN];
+        for (int j = 0; j < PF; ++j) {
+            if (t + j < ntiles) {           // uniform
+                // register set j holds tile t+j: convert it into LDS, then refill the set with tile t+j+PF so that
+                // the load flies during the MFMAs of this and the next PF-1 tiles
+                store_A(j);
+                store_B(j);
+                advance_A();
+                load_A(kbeg + (t + j + PF) * BK, j);
+                load_B(kbeg + (t + j + PF) * BK, j);
+                __syncthreads();
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 av[3][TM], bv[3][TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    av[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(As + pl * PLANE_A + sa_off[s] + i * 512));
+                    for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    bv[pl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + pl * PLANE_B + sb_off[s] + j * 512));
-            }
+                        for (int i = 0; i < TM; ++i)
+                            av[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(As + pl * PLANE_A + sa_off[s] + i * 512));
+#pragma unroll
+                        for (int jj = 0; jj < TN; ++jj)
+                            bv[pl][jj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + pl * PLANE_B + sb_off[s] + jj * 512));
+                    }
 #define RIH_SPLIT_TERM(PA_, PB_)                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =      \
-        __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA_][i], bv[PB_][j], acc[i][j], 0, 0, 0);
-            RIH_SPLIT_TERM(2, 0)
-            RIH_SPLIT_TERM(0, 2)
-            RIH_SPLIT_TERM(1, 1)
-            RIH_SPLIT_TERM(1, 0)
-            RIH_SPLIT_TERM(0, 1)
-            RIH_SPLIT_TERM(0, 0)
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int jj = 0; jj < TN; ++jj) acc[i][jj] =  \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA_][i], bv[PB_][jj], acc[i][jj], 0, 0, 0);
+                    RIH_SPLIT_TERM(2, 0)
+                    RIH_SPLIT_TERM(0, 2)
+                    RIH_SPLIT_TERM(1, 1)
+                    RIH_SPLIT_TERM(1, 0)
+                    RIH_SPLIT_TERM(0, 1)
+                    RIH_SPLIT_TERM(0, 0)
 #undef RIH_SPLIT_TERM
-        }
-        __syncthreads();
-        if (more) {
-            store_A();
-            store_B();
-            __syncthreads();
+                }
+                __syncthreads();
+            }
         }
     }
 
@@ -851,7 +866,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
                         if (p.R != nullptr) v += p.R[(long long)m * p.ldr + n];
                         if (p.relu) v = fmaxf(v, 0.f);
                     }
-                    C[(long long)m * p.ldc + n] = v;
+                    C[c_row(p, m) * p.ldc + n] = v;
                 }
             }
         }
@@ -1218,7 +1233,7 @@ __global__ __launch_bounds__(256, 1) void gemm_split256_kernel(const GemmArgs p)
                         if (p.R != nullptr) v += p.R[(long long)m * p.ldr + n];
                         if (p.relu) v = fmaxf(v, 0.f);
                     }
-                    C[(long long)m * p.ldc + n] = v;
+                    C[c_row(p, m) * p.ldc + n] = v;
                 }
             }
         }
@@ -1319,7 +1334,35 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+// tap subset of a conv weight for one parity class of a strided data gradient (see rih_pack_conv_weight_sub)
+__global__ void pack_conv_weight_sub_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin,
+                                            int KH, int KW, int CinPad, int kh0, int kw0, int step, int Th, int Tw) {
+    const long long total = (long long)Th * Tw * Cout * CinPad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % CinPad);
+        long long t = i / CinPad;
+        const int co = (int)(t % Cout);
+        t /= Cout;
+        const int tw = (int)(t % Tw), th = (int)(t / Tw);
+        const int kh = kh0 + step * (Th - 1 - th), kw = kw0 + step * (Tw - 1 - tw);
+        dst[i] = (ci < Cin) ? w[(((long long)co * Cin + ci) * KH + kh) * KW + kw] : 0.f;
+    }
+}
+
 }  // namespace
+
+extern "C" int rih_pack_conv_weight_sub(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int CinPad,
+                                        int kh0, int kw0, int step, int Th, int Tw, void* stream) {
+    if (!w || !dst || Cout < 1 || Cin < 1 || KH < 1 || KW < 1 || CinPad < Cin || step < 1 || Th < 1 || Tw < 1 ||
+        kh0 < 0 || kw0 < 0 || kh0 + step * (Th - 1) >= KH || kw0 + step * (Tw - 1) >= KW)
+        return RIH_EINVAL;
+    const long long total = (long long)Th * Tw * Cout * CinPad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_conv_weight_sub_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, dst, Cout, Cin,
+                       KH, KW, CinPad, kh0, kw0, step, Th, Tw);
+    return (int)hipGetLastError();
+}
 
 extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->B || !d->C) return RIH_EINVAL;
@@ -1356,6 +1399,10 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
     a.vecA = a16 ? 1 : 0;
     a.vecB = b16 ? 1 : 0;
     a.a_bytes = a.b_bytes = 0;
+    a.cS = d->cS; a.cOH = d->cOH; a.cOW = d->cOW; a.cH = d->cH; a.cW = d->cW;
+    if (d->cS > 1 && (d->splitk != 1 || d->a_mode != 0 || d->R != nullptr || d->cH < 1 || d->cW < 1 || d->cOH < 0 ||
+                      d->cOW < 0 || d->nb1 * d->nb2 != 1))
+        return RIH_EINVAL;
     int bm = 128, bn = 128;
     if (d->tile == 4) { bm = 256; bn = 128; }
     else if (d->tile == 1) { bm = 128; bn = 64; }

@@ -95,9 +95,12 @@ PROFILE = None
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=None, ldr=0,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, kchunk=0, sCsplit=0, alpha=1.0, relu=False,
-         geom=None, tile=None, engine=None):
-    """Enqueue one rih_gemm.  A/B/Cout/bias/R are tensors or raw device pointers."""
+         geom=None, tile=None, engine=None, cstride=None):
+    """Enqueue one rih_gemm.  A/B/Cout/bias/R are tensors or raw device pointers.
+    cstride = (s, oh, ow, H, W): store GEMM row (img, i, j) to pixel (img, i*s+oh, j*s+ow) of a [*, H, W] tensor."""
     d = GemmDesc()
+    if cstride is not None:
+        d.cS, d.cOH, d.cOW, d.cH, d.cW = cstride
     d.engine = ENGINE if engine is None else engine
     d.A = A if isinstance(A, int) else A.data_ptr()
     d.B = B if isinstance(B, int) else B.data_ptr()
@@ -123,7 +126,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
         d.tile, auto_sk = plan_gemm(M, N, K, nb1 * nb2 * splitk, d.engine)
     else:
         d.tile = tile
-    if auto_sk > 1 and splitk == 1 and nb1 * nb2 == 1 and not isinstance(Cout, int):
+    if auto_sk > 1 and splitk == 1 and nb1 * nb2 == 1 and not isinstance(Cout, int) and cstride is None:
         # few output tiles but a long reduction (e.g. the 8x8 3x3 convs, the 4x4 patch conv): split K over
         # workgroups and finish (bias / residual / ReLU) in a second pass
         kc = _cdiv(_cdiv(K, auto_sk), 32) * 32
@@ -216,7 +219,34 @@ class Conv2dFn(torch.autograd.Function):
             check(lib.rih_relu_bwd(dy.data_ptr(), y.data_ptr(), dyr.data_ptr(), dy.numel(), _stream()), 'rih_relu_bwd')
             dy = dyr
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and stride > 1:
+            # strided conv: s*s dense sub-convolutions, one per parity class (oh, ow) of the input pixel; class rows
+            # are written straight into dx (rih_gemm_desc.cS); a zero-stuffed single GEMM would multiply
+            # (s*s-1)/(s*s) structural zeros
+            classes = []
+            for oh in range(stride):
+                for ow in range(stride):
+                    kh0, kw0 = (oh + pad) % stride, (ow + pad) % stride
+                    Th, Tw = len(range(kh0, KH, stride)), len(range(kw0, KW, stride))
+                    Hc, Wc = len(range(oh, H, stride)), len(range(ow, W_, stride))
+                    if Hc > 0 and Wc > 0:
+                        classes.append((oh, ow, kh0, kw0, Th, Tw, Hc, Wc))
+            dense = all(c[4] > 0 and c[5] > 0 for c in classes)
+            dx = torch.empty_like(x) if dense else torch.zeros_like(x)
+            for oh, ow, kh0, kw0, Th, Tw, Hc, Wc in classes:
+                if Th == 0 or Tw == 0:
+                    continue
+                padh, padw = Th - 1 - (oh + pad - kh0) // stride, Tw - 1 - (ow + pad - kw0) // stride
+                geom = (Ho, Wo, Cout, Hc, Wc, Th, Tw, 1, 1, padh, padw)
+                if KH * KW == 1 and Cx == Cin:
+                    wd = w
+                else:
+                    wd = torch.empty((Th * Tw * Cout, Cx), device=x.device, dtype=torch.float32)
+                    check(lib.rih_pack_conv_weight_sub(w.data_ptr(), wd.data_ptr(), Cout, Cin, KH, KW, Cx, kh0, kw0,
+                                                       stride, Th, Tw, _stream()), 'rih_pack_conv_weight_sub')
+                gemm(dy, wd, dx, N * Hc * Wc, Cx, Th * Tw * Cout, Cout, Cx, Cx, a_mode=0, b_mode=0, geom=geom,
+                     cstride=(stride, oh, ow, H, W_))
+        elif ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             Mx = N * H * W_
             geom = (Ho, Wo, Cout, H, W_, KH, KW, 1, stride, KH - 1 - pad, KW - 1 - pad)

@@ -91,7 +91,13 @@ class EmulatedLib:
                 kk, nn = np.meshgrid(np.arange(K), np.arange(N), indexing='ij')
                 bidx = kk * d.ldb + nn if d.b_mode == 0 else nn * d.ldb + kk
                 Bm = self._gather(Bb, bidx, np.ones_like(bidx, bool)) if K > 0 else np.zeros((0, N), np.float32)
-                cm, cn = np.meshgrid(np.arange(M), np.arange(N), indexing='ij')
+                crow = np.arange(M)
+                if d.cS > 1:        # strided output rows (parity class of a strided-conv data gradient)
+                    assert d.a_mode == 0 and d.splitk == 1 and not d.R
+                    cj, ct = crow % d.Wo, crow // d.Wo
+                    ci_, cimg = ct % d.Ho, ct // d.Ho
+                    crow = (cimg * d.cH + ci_ * d.cS + d.cOH) * d.cW + cj * d.cS + d.cOW
+                cm, cn = np.meshgrid(crow, np.arange(N), indexing='ij')
                 if d.splitk > 1:
                     assert d.kchunk % 32 == 0
                     for s in range(d.splitk):
@@ -105,10 +111,11 @@ class EmulatedLib:
                     out = out + _f(d.bias, N)[None, :]
                 if d.R:
                     r = _f(d.R + 4 * 0, (M - 1) * d.ldr + N)
-                    out = out + r[(cm * d.ldr + cn).ravel()].reshape(M, N)
+                    lm, ln = np.meshgrid(np.arange(M), np.arange(N), indexing='ij')
+                    out = out + r[(lm * d.ldr + ln).ravel()].reshape(M, N)
                 if d.relu:
                     out = np.maximum(out, 0)
-                mem = _f(Cb, (M - 1) * d.ldc + N)
+                mem = _f(Cb, int(crow.max()) * d.ldc + N)
                 mem[(cm * d.ldc + cn).ravel()] = out.astype(np.float32).ravel()
         return 0
 
@@ -144,6 +151,15 @@ class EmulatedLib:
         else:
             out = Wp[:, :, ::-1].transpose(2, 0, 1)           # [tap'][co][ci]
         _f(dst, out.size)[:] = np.ascontiguousarray(out).ravel()
+        return 0
+
+    def rih_pack_conv_weight_sub(self, w, dst, Cout, Cin, KH, KW, CinPad, kh0, kw0, step, Th, Tw, stream):
+        W = _f(w, Cout * Cin * KH * KW).reshape(Cout, Cin, KH, KW)
+        out = np.zeros((Th, Tw, Cout, CinPad), np.float32)
+        for th in range(Th):
+            for tw in range(Tw):
+                out[th, tw, :, :Cin] = W[:, :, kh0 + step * (Th - 1 - th), kw0 + step * (Tw - 1 - tw)]
+        _f(dst, out.size)[:] = out.ravel()
         return 0
 
     # ------------------------------------------------------------------ layout / pooling

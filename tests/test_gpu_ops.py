@@ -43,6 +43,8 @@ CONV_CASES = [
     (2, 8, 8, 128, 8, 1, 1, 0, True, False),
     (5, 9, 9, 72, 200, 3, 1, 1, False, False),
     (1, 64, 64, 64, 256, 1, 1, 0, False, True),
+    (2, 15, 17, 64, 96, 3, 2, 1, False, False),      # odd sizes: the parity classes of the strided dgrad differ in size
+    (2, 13, 13, 32, 64, 1, 2, 0, False, False),
 ]
 
 

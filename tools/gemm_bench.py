@@ -121,6 +121,14 @@ if __name__ == '__main__':
         wgrad(B, 16, 16, 1024, 256, 1, 1, 0, tiles=(0, 4))
         linear_fwd(8128, 256, 768, tiles=(0, 2, 4))
         sys.exit(0)
+    if '--small' in sys.argv:
+        globals()['ENGINES'] = (1,)
+        for M, K, Nf in ((16128, 64, 64), (16128, 64, 128), (8064, 128, 128), (4032, 256, 256), (4032, 512, 256),
+                         (8128, 256, 768), (20224, 64, 192)):
+            linear_fwd(M, K, Nf, tiles=(2,))
+        wgrad(B * 63, 1, 1, 256, 256, 1, 1, 0, tiles=(2,))
+        wgrad(B * 252, 1, 1, 64, 64, 1, 1, 0, tiles=(2,))
+        sys.exit(0)
     if '--pmc4' in sys.argv:
         globals()['ENGINES'] = (1,)
         conv_fwd(B, 64, 64, 128, 128, 3, 1, 1, tiles=(0, 4))
