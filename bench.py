@@ -29,6 +29,19 @@ PEAK_FP32_MFMA_TF = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 
 PEAK_BF16_MFMA_TF = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 
 
+def measured_traffic():
+    """HBM traffic of the rih_gemm family per step from the newest committed PMC collection (profiles/*/traffic_*.json;
+    bench.py cannot run rocprofv3 on itself).  None when no collection is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'traffic_*.json')))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        d = json.load(fh)
+    return {'hbm_read_GB_per_step': d['fetch_GB_per_step_corrected'], 'hbm_write_GB_per_step': d['write_GB_per_step'],
+            'from': os.path.relpath(files[-1], ROOT), 'note': 'ResNet50 B=64 step; ' + d['correction']}
+
+
 def synth_batch(B, device, seed):
     g = torch.Generator().manual_seed(seed)
     img = torch.randn(B, 3, 256, 256, generator=g)
@@ -169,7 +182,8 @@ def main():
         split = (ops.ENGINE == 1)
         peak = PEAK_BF16_MFMA_TF / 6.0 if split else PEAK_FP32_MFMA_TF
         roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                'frac': round(achieved / peak, 4), 'traffic': None,
+                'frac': round(achieved / peak, 4),
+                'traffic': measured_traffic() if args.encoder == 'resnet50' and B == 64 else None,
                 'kernel': ('rih_gemm engine 1 (gemm_split_kernel / gemm_split256_kernel: fp32 = 6 x '
                            'v_mfma_f32_32x32x16_bf16 on a 3-term bf16 split; peak = 2500 TF/s bf16 dense / 6)'
                            if split else 'rih_gemm engine 0 (gemm_kernel, v_mfma_f32_32x32x2_f32)'),

@@ -1,0 +1,32 @@
+#!/bin/bash
+# HBM traffic of the rih_gemm kernels during bench steps: two separate --pmc passes (FETCH_SIZE, WRITE_SIZE cannot share a
+# pass on gfx950, MI355X_MICROARCH.md "rocprofv3 PMC slots"); counters only with --kernel-trace.
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/pmc
+export TMPDIR=/tmp
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $R/gpurun_out/pmc/traffic_$c.log 2>&1
+  f=$(find /tmp/pmc_$c -name "*counter_collection*.csv" | head -1)
+  python - "$f" "$c" <<'PY' > $R/gpurun_out/pmc/traffic_$c.txt
+import csv, sys, collections
+f, c = sys.argv[1], sys.argv[2]
+agg = collections.OrderedDict()
+for r in csv.DictReader(open(f)):
+    if r['Counter_Name'] != c:
+        continue
+    k = r['Kernel_Name']
+    name = k[k.index('gemm'):k.index('>') + 1] if 'gemm_' in k else ('other: ' + k.split('(')[0][-60:])
+    a = agg.setdefault(name, [0, 0.0])
+    a[0] += 1
+    a[1] += float(r['Counter_Value'])
+tot_g = sum(v[1] for k, v in agg.items() if k.startswith('gemm'))
+n_g = sum(v[0] for k, v in agg.items() if k.startswith('gemm'))
+print('%s (raw counter units as reported by rocprofv3; 3 bench steps incl. warm-up)' % c)
+print('rih_gemm kernels: launches %d total %.6g per-launch %.6g' % (n_g, tot_g, tot_g / max(n_g, 1)))
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+    print('%12.6g  n=%5d  per-launch %10.5g  %s' % (v[1], v[0], v[1] / v[0], k))
+PY
+  tail -30 $R/gpurun_out/pmc/traffic_$c.txt | head -8
+done
