@@ -106,11 +106,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int wm = wave / WGN, wn = wave % WGN;
 
     const int tilesN = (p.N + BN - 1) / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // Workgroups are dispatched x-fastest and round-robin over the 8 XCDs.  Remap so that each XCD (private L2) gets a
+    // contiguous run of output tiles -- and, for a split-K launch, of (split, tile) pairs with the tile fastest, so
+    // that all tiles reading one K-range of the operands sit on the same XCD instead of fetching it eight times.
+    int bid, z = blockIdx.z;
+    if (p.splitk > 1 && gridDim.z == (unsigned)p.splitk) {
+        const int c = xcd_remap(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z);
+        bid = c % gridDim.x;
+        z = c / gridDim.x;
+    } else {
+        bid = xcd_remap(blockIdx.x, gridDim.x);
+    }
     const int m0 = (bid / tilesN) * BM;
     const int n0 = (bid % tilesN) * BN;
 
-    const int z = blockIdx.z;
     const int split = z % p.splitk;
     const int bz = z / p.splitk;
     const int b2 = bz % p.nb2, b1 = bz / p.nb2;
@@ -570,11 +579,20 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
     const int wm = wave / WGN, wn = wave % WGN;
 
     const int tilesN = (p.N + BN - 1) / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // Workgroups are dispatched x-fastest and round-robin over the 8 XCDs.  Remap so that each XCD (private L2) gets a
+    // contiguous run of output tiles -- and, for a split-K launch, of (split, tile) pairs with the tile fastest, so
+    // that all tiles reading one K-range of the operands sit on the same XCD instead of fetching it eight times.
+    int bid, z = blockIdx.z;
+    if (p.splitk > 1 && gridDim.z == (unsigned)p.splitk) {
+        const int c = xcd_remap(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z);
+        bid = c % gridDim.x;
+        z = c / gridDim.x;
+    } else {
+        bid = xcd_remap(blockIdx.x, gridDim.x);
+    }
     const int m0 = (bid / tilesN) * BM;
     const int n0 = (bid % tilesN) * BN;
 
-    const int z = blockIdx.z;
     const int split = z % p.splitk;
     const int bz = z / p.splitk;
     const int b2 = bz % p.nb2, b1 = bz / p.nb2;
@@ -918,11 +936,20 @@ __global__ __launch_bounds__(256, 1) void gemm_split256_kernel(const GemmArgs p)
     const int wm = wave >> 1, wn = wave & 1;
 
     const int tilesN = (p.N + BN - 1) / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // Workgroups are dispatched x-fastest and round-robin over the 8 XCDs.  Remap so that each XCD (private L2) gets a
+    // contiguous run of output tiles -- and, for a split-K launch, of (split, tile) pairs with the tile fastest, so
+    // that all tiles reading one K-range of the operands sit on the same XCD instead of fetching it eight times.
+    int bid, z = blockIdx.z;
+    if (p.splitk > 1 && gridDim.z == (unsigned)p.splitk) {
+        const int c = xcd_remap(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z);
+        bid = c % gridDim.x;
+        z = c / gridDim.x;
+    } else {
+        bid = xcd_remap(blockIdx.x, gridDim.x);
+    }
     const int m0 = (bid / tilesN) * BM;
     const int n0 = (bid % tilesN) * BN;
 
-    const int z = blockIdx.z;
     const int split = z % p.splitk;
     const int bz = z / p.splitk;
     const int b2 = bz % p.nb2, b1 = bz / p.nb2;
