@@ -4,7 +4,9 @@
 Workload = BASELINE.json configs[1]: batch 64 per GPU, 256x256 RGB, ResNet50 encoder + GCN/attention mesh decoder
 (the reference's `HandNET_GCN`), fp32, training mode with the reference's dropout 0.05, synthetic inputs/labels,
 random-init weights.  N>1: one process per GPU (torch.distributed, backend "nccl" = RCCL), plain data parallel with
-the reference's DDP(find_unused_parameters=True) semantics; weak scaling (batch 64 per GPU).
+the reference's DDP semantics (gradient averaging, grad-less parameters tolerated, per-GPU BatchNorm) through one
+bucketed RCCL all-reduce per step (renderih_amd/dp.py; `--ddp` switches to torch DDP itself); weak scaling (batch 64
+per GPU).
 
 Prints ONE JSON line (rank 0).  `roofline`: the GEMM/implicit-conv kernel family (rih_gemm), timed live with HIP events
 on the launch stream; achieved = SURVEY 8d algorithmic FLOPs (53.2 GFLOP/img fwd+bwd) x images per step / GEMM-family
@@ -90,6 +92,11 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 64, hrnet32: 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--ddp', action='store_true',
+                    help='N>1: use torch DistributedDataParallel(find_unused_parameters=True) like the reference trainer '
+                         'instead of renderih_amd.dp.GradAllReducer (same gradients, ~25 ms/step more host work)')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='initialise RCCL and wrap the model in DDP even at world size 1 (exercises the N>1 code path)')
     ap.add_argument('--dump-gemm', default=None, help='write the per-launch GEMM profile of one step to this JSON file')
     args = ap.parse_args()
     if args.batch is None:
@@ -102,9 +109,12 @@ def main():
         raise SystemExit('bench.py needs a GPU (HIP kernels only, no CPU fallback)')
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from renderih_amd import ops, assets
     from renderih_amd.model import build_model
@@ -115,8 +125,12 @@ def main():
     model = build_model(dropout=0.05, encoder_type=args.encoder).to(device).train()
     model.decoder.unsample_layer.weight.requires_grad_(False)          # core/gcn_trainer.py:102-103
     net = model
-    if world > 1:
+    reducer = None
+    if dist_on and args.ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=True)
+    elif dist_on:
+        from renderih_amd.dp import GradAllReducer
+        reducer = GradAllReducer(model)                 # one 156 MB bucket, one RCCL all-reduce after backward
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=3e-4, weight_decay=1e-2)
 
     mano = {s: ManoLayer(assets.synthetic_mano_dict(s)) for s in ('left', 'right')}
@@ -131,11 +145,13 @@ def main():
                                 lab['v2d_l'], lab['v2d_r'], lab['v3d_l'], lab['v3d_r'], lab['root_rel'], 256)
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        if reducer is not None:
+            reducer.reduce()
         opt.step()
         return loss
 
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
 
     for _ in range(args.warmup):
@@ -148,7 +164,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -214,7 +230,7 @@ def main():
                                            if ops.ENGINE == 1 else 'native f32 MFMA')},
                 'roofline': roof, 'cpu_baseline': cpu}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

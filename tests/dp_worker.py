@@ -33,6 +33,19 @@ def main():
         scalar_loss(m(img)).backward()
         local = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
         nograd = sorted(k for k, p in m.named_parameters() if p.grad is None)
+        # (a) the package's own reducer (renderih_amd/dp.py, what bench.py uses for N > 1)
+        from renderih_amd.dp import GradAllReducer
+        red = GradAllReducer(m)
+        assert red.reduce() == len(local)
+        for k, p in m.named_parameters():
+            if k in local:
+                want = local[k].clone()
+                dist.all_reduce(want)
+                want /= world
+                assert float((p.grad - want).abs().max()) <= 1e-6 * float(want.abs().max() + 1e-30), k
+            else:
+                assert p.grad is None, k
+        # (b) torch DDP as the reference trainer wraps the model
         m.zero_grad(set_to_none=True)
         for mod in m.modules():                                        # undo the running-stat update of the first pass
             if isinstance(mod, torch.nn.BatchNorm2d):
