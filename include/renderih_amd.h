@@ -81,16 +81,24 @@ typedef struct rih_gemm_desc {
      * kh = kh0 + s*t that can reach that class, packed by rih_pack_conv_weight_sub), instead of one convolution over
      * a zero-stuffed gradient (upS) in which (s*s-1)/(s*s) of the products are structural zeros.  cS <= 1: off. */
     int32_t cS, cOH, cOW, cH, cW;
+    /* a_mode 1 only: A(ones_row, k) = 1 for every k < K, whatever memory holds (rows > ones_row up to M are junk).
+     * Appending this row to a weight-gradient GEMM makes C(ones_row, n) = sum_k B(k, n), the bias gradient, so that
+     * no separate column-sum pass over dy is needed (rih_splitk_reduce_bias picks the row up).  0 = off. */
+    int32_t ones_row;
 } rih_gemm_desc;
 
 int rih_gemm(const rih_gemm_desc* d, void* stream);
 
 /* Sum split-K partials P[S][M][N] (M = taps*Cin rows ordered (tap,ci)) into a weight gradient laid out
  * like the parameter: dst[(n*CinValid + ci)*taps + tap]  (OIHW for convs, [out][in] for nn.Linear).
- * Rows with ci >= CinValid (channel padding) are dropped.  accumulate!=0 adds to dst.
- * P is scratch: slab 0 is overwritten with the sum. */
+ * Rows with ci >= CinValid (channel padding) are dropped.  accumulate!=0 adds to dst.  One launch, fixed summation
+ * order (deterministic). */
 int rih_splitk_reduce(float* P, int S, int M, int N, float* dst, int Cin, int taps, int CinValid,
                       int accumulate, void* stream);
+/* Same on slabs of Mp >= M rows; with db != NULL (Mp >= M+1) slab row M -- produced by a weight-gradient GEMM whose A
+ * operand carries an all-ones row there (rih_gemm_desc.ones_row) -- is summed into the bias gradient db[N]. */
+int rih_splitk_reduce_bias(const float* P, int S, int Mp, int M, int N, float* dst, int Cin, int taps, int CinValid,
+                           int accumulate, float* db, void* stream);
 
 /* Finish a forward split-K GEMM: C[m*ldc+n] = act(alpha * sum_s P[s][m][n] + bias[n] + R[m*ldr+n]). */
 int rih_splitk_finish(const float* P, int S, int M, int N, float* C, int ldc, const float* bias, const float* R,

@@ -27,7 +27,7 @@ class GemmDesc(C.Structure):
                 ('H', C.c_int32), ('W', C.c_int32), ('Cin', C.c_int32), ('Ho', C.c_int32), ('Wo', C.c_int32),
                 ('KH', C.c_int32), ('KW', C.c_int32), ('strideA', C.c_int32), ('upS', C.c_int32),
                 ('padH', C.c_int32), ('padW', C.c_int32), ('tile', C.c_int32), ('engine', C.c_int32),
-                ('cS', C.c_int32), ('cOH', C.c_int32), ('cOW', C.c_int32), ('cH', C.c_int32), ('cW', C.c_int32)]
+                ('cS', C.c_int32), ('cOH', C.c_int32), ('cOW', C.c_int32), ('cH', C.c_int32), ('cW', C.c_int32), ('ones_row', C.c_int32)]
 
 
 class ManoModel(C.Structure):
@@ -40,6 +40,7 @@ class ManoModel(C.Structure):
 SIGNATURES = {
     'rih_gemm': (c_i, [C.POINTER(GemmDesc), C.c_void_p]),
     'rih_splitk_reduce': (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_splitk_reduce_bias': (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f, C.c_void_p]),
     'rih_splitk_finish': (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_fl, c_i, C.c_void_p]),
     'rih_pack_conv_weight': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
     'rih_pack_conv_weight_sub': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),

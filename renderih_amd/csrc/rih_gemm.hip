@@ -37,6 +37,7 @@ struct GemmArgs {
     int vecA, vecB;
     unsigned a_bytes, b_bytes;      // extent of one batch slice of A / B (split fast path: buffer range check)
     int cS, cOH, cOW, cH, cW;       // strided output rows (parity classes of a strided-conv data gradient)
+    int ones_row;                   // a_mode 1: A(ones_row, k) = 1 for every valid k (bias gradient row); 0 = off
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -47,6 +48,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void set_elem(float4& v, int e, float x) {
+    if (e == 0) v.x = x; else if (e == 1) v.y = x; else if (e == 2) v.z = x; else v.w = x;
+}
 
 // Row of C that GEMM row m = (img, i, j) over (Ho, Wo) is stored to.  cS <= 1: row m.  cS > 1: pixel
 // (img, i*cS + cOH, j*cS + cOW) of a [*, cH, cW] tensor -- one parity class of a strided convolution's data gradient.
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     int a_hw0[NPA];                 // packed (hi0 | wi0 << 16), hi0/wi0 = top-left input coordinate of the row's window
     int a_kh, a_kw, a_ci;           // AMODE 0: running (kh,kw,ci) of this thread's k-quad; AMODE 1: fixed tap of m-quad
     int a_mvalid = 0;               // AMODE 1: number of valid elements in this thread's m-quad (0..4)
+    int a_one = -1;                 // AMODE 1: element of the m-quad that is the all-ones row, or -1
     constexpr int QA = BM / 4, RA = 256 / QA;
     if (AMODE == 0) {
         const int arow = tid >> 3, aq = tid & 7;
@@ -170,6 +175,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         a_kh = tap / p.KW;
         a_kw = tap - a_kh * p.KW;
         a_mvalid = max(0, min(4, p.M - mm));
+        if (p.ones_row > 0 && p.ones_row >= mm && p.ones_row < mm + 4) a_one = p.ones_row - mm;
 #pragma unroll
         for (int i = 0; i < NPA; ++i) { a_base[i] = 0; a_hw0[i] = 0; }
     }
@@ -240,6 +246,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 const unsigned off = ok ? ((unsigned)((img * p.H + hi) * p.W + wi) * (unsigned)p.lda + (unsigned)a_ci) : 0u;
                 areg[i] = ld4(A + off, bits);
                 amask |= bits << (4 * i);
+                if (a_one >= 0 && k < kend) {       // the all-ones row of the bias gradient
+                    set_elem(areg[i], a_one, 1.f);
+                    amask |= (1u << a_one) << (4 * i);
+                }
             }
         }
     };
@@ -615,6 +625,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
     const int amq = tid % QA, akr = tid / QA;
     int a1_wo = 0, a1_ho = 0, a1_img = 0, a1_kh = 0, a1_kw = 0;
     unsigned a1_base = 0;       // byte offset of (channel quad) -- OOB when the m-quad is out of range
+    int a1_one = -1;            // element of this thread's m-quad that is the all-ones (bias-gradient) row, or -1
+    if (AMODE == 1 && p.ones_row > 0 && p.ones_row >= m0 + 4 * amq && p.ones_row < m0 + 4 * amq + 4)
+        a1_one = p.ones_row - (m0 + 4 * amq);
     if (AMODE == 0) {
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
@@ -716,6 +729,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
                 const unsigned ku = (ktile + akr * NPA < kend) ? (unsigned)ktile * (unsigned)p.lda * 4u : OOB;
 #pragma unroll
                 for (int i = 0; i < NPA; ++i) areg[st][i] = bload4(rA, a1_base + ku + (unsigned)i * (unsigned)p.lda * 4u);
+                if (a1_one >= 0) {
+                    const float one = (ktile + akr * NPA < kend) ? 1.f : 0.f;       // K % NPA == 0: all or nothing
+#pragma unroll
+                    for (int i = 0; i < NPA; ++i) set_elem(areg[st][i], a1_one, one);
+                }
             } else {
                 const int hi = a1_ho * p.strideA - p.padH + a1_kh;
                 const int wi = a1_wo * p.strideA - p.padW + a1_kw;
@@ -725,6 +743,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
                 for (int i = 0; i < NPA; ++i) {
                     const bool ok = rowok && (unsigned)(wi + i * p.strideA) < (unsigned)p.W;
                     areg[st][i] = bload4(rA, ok ? rowoff + (unsigned)(i * p.strideA * p.lda * 4) : OOB);
+                }
+                if (a1_one >= 0) {
+                    const float one = (ktile + akr * NPA < kend) ? 1.f : 0.f;
+#pragma unroll
+                    for (int i = 0; i < NPA; ++i) set_elem(areg[st][i], a1_one, one);
                 }
             }
         }
@@ -1278,33 +1301,53 @@ int launch_split256(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 
     return (int)hipGetLastError();
 }
 
-// Split-K reduction for weight gradients, two coalesced passes:
-//   1. sum the S partial slabs into slab 0 (in place; linear, float4 where possible),
-//   2. transpose slab 0 [M][N] (m = tap*Cin + ci) into the parameter layout dst[(n*CinValid + ci)*taps + tap]
-//      through 32x32 LDS tiles, so reads run along n and stores along ci.
-__global__ void splitk_sum_kernel(float* __restrict__ P, int S, long long MN) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < MN;
-         i += (long long)gridDim.x * blockDim.x) {
-        float s0 = 0.f, s1 = 0.f;
-        int k = 0;
-        for (; k + 1 < S; k += 2) { s0 += P[(long long)k * MN + i]; s1 += P[(long long)(k + 1) * MN + i]; }
-        if (k < S) s0 += P[(long long)k * MN + i];
-        P[i] = s0 + s1;
+// One-launch split-K reduction for weight gradients: each 256-thread block sums a 32x32 tile of the S partial slabs
+// P[s][Mp][N] in a fixed order (deterministic) and writes it transposed into the parameter layout through LDS; blocks
+// past the tile range sum slab row M (the all-ones row of the A operand = column sums of dy) into the bias gradient.
+__global__ __launch_bounds__(256) void splitk_reduce_fused_kernel(const float* __restrict__ P, int S, int Mp, int M, int N,
+                                                                  float* __restrict__ dst, int Cin, int taps, int CinValid,
+                                                                  int accumulate, float* __restrict__ db, int ntiles) {
+    const long long slab = (long long)Mp * N;
+    if ((int)blockIdx.x >= ntiles) {
+        const int n = ((int)blockIdx.x - ntiles) * 256 + threadIdx.x;
+        if (n < N) {
+            const float* q = P + (long long)M * N + n;
+            float s0 = 0.f, s1 = 0.f;
+            int k = 0;
+            for (; k + 1 < S; k += 2) { s0 += q[(long long)k * slab]; s1 += q[(long long)(k + 1) * slab]; }
+            if (k < S) s0 += q[(long long)k * slab];
+            db[n] = s0 + s1;
+        }
+        return;
     }
-}
-
-__global__ __launch_bounds__(256) void splitk_transpose_kernel(const float* __restrict__ P, int M, int N,
-                                                               float* __restrict__ dst, int Cin, int taps,
-                                                               int CinValid, int accumulate) {
     __shared__ float tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // ty in 0..7
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int tilesN = (N + 31) / 32;
     const int m0 = (blockIdx.x / tilesN) * 32, n0 = (blockIdx.x % tilesN) * 32;
+    float acc[4][2];
+    const float* q[4];
+    bool ok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + ty + 8 * i, n = n0 + tx;
-        tile[ty + 8 * i][tx] = (m < M && n < N) ? P[(long long)m * N + n] : 0.f;
+        ok[i] = (m < M && n < N);
+        q[i] = P + (ok[i] ? (long long)m * N + n : 0);
+        acc[i][0] = acc[i][1] = 0.f;
     }
+    int k = 0;
+    for (; k + 1 < S; k += 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i][0] += q[i][(long long)k * slab];
+            acc[i][1] += q[i][(long long)(k + 1) * slab];
+        }
+    }
+    if (k < S) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][0] += q[i][(long long)k * slab];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[ty + 8 * i][tx] = ok[i] ? acc[i][0] + acc[i][1] : 0.f;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1427,6 +1470,8 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
     a.vecB = b16 ? 1 : 0;
     a.a_bytes = a.b_bytes = 0;
     a.cS = d->cS; a.cOH = d->cOH; a.cOW = d->cOW; a.cH = d->cH; a.cW = d->cW;
+    a.ones_row = d->ones_row;
+    if (d->ones_row != 0 && (d->a_mode != 1 || d->ones_row < 0 || d->ones_row >= d->M || d->tile == 4)) return RIH_EINVAL;
     if (d->cS > 1 && (d->splitk != 1 || d->a_mode != 0 || d->R != nullptr || d->cH < 1 || d->cW < 1 || d->cOH < 0 ||
                       d->cOW < 0 || d->nb1 * d->nb2 != 1))
         return RIH_EINVAL;
@@ -1448,7 +1493,8 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
                             d->H == d->Ho && d->W == d->Wo);
         const long long rowsA = (d->a_mode == 0) ? (long long)d->M : (long long)d->K;
         const long long imgs = (rowsA + (long long)d->Ho * d->Wo - 1) / ((long long)d->Ho * d->Wo);
-        const long long a_bytes = plain ? ((rowsA - 1) * d->lda + ((d->a_mode == 0) ? d->K : d->M)) * 4ll
+        const int colsA = (d->a_mode == 0) ? d->K : (d->ones_row > 0 ? d->ones_row : d->M);
+        const long long a_bytes = plain ? ((rowsA - 1) * d->lda + colsA) * 4ll
                                         : imgs * d->H * d->W * (long long)d->lda * 4ll;
         const long long rowsB = (d->b_mode == 0) ? (long long)d->K : (long long)d->N;
         const long long b_bytes = ((rowsB - 1) * d->ldb + ((d->b_mode == 0) ? d->N : d->K)) * 4ll;
@@ -1478,19 +1524,21 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
     return launch_tile<64, 64>(a, d->a_mode, d->b_mode, d->engine, grid, s);
 }
 
+extern "C" int rih_splitk_reduce_bias(const float* P, int S, int Mp, int M, int N, float* dst, int Cin, int taps,
+                                      int CinValid, int accumulate, float* db, void* stream) {
+    if (!P || !dst || S < 1 || M < 1 || Mp < M || N < 1 || Cin < 1 || taps < 1 || CinValid < 1) return RIH_EINVAL;
+    if (db && Mp < M + 1) return RIH_EINVAL;
+    const long long tiles = (long long)((M + 31) / 32) * ((N + 31) / 32);
+    const long long blocks = tiles + (db ? (N + 255) / 256 : 0);
+    if (blocks > 0x7fffffffLL) return RIH_EINVAL;
+    hipLaunchKernelGGL(splitk_reduce_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P, S, Mp, M,
+                       N, dst, Cin, taps, CinValid, accumulate, db, (int)tiles);
+    return (int)hipGetLastError();
+}
+
 extern "C" int rih_splitk_reduce(float* P, int S, int M, int N, float* dst, int Cin, int taps, int CinValid,
                                  int accumulate, void* stream) {
-    if (!P || !dst || S < 1 || M < 1 || N < 1 || Cin < 1 || taps < 1 || CinValid < 1) return RIH_EINVAL;
-    const long long MN = (long long)M * N;
-    if (S > 1) {
-        const int sb = (int)((MN + 255) / 256 < 8192 ? (MN + 255) / 256 : 8192);
-        hipLaunchKernelGGL(splitk_sum_kernel, dim3(sb), dim3(256), 0, (hipStream_t)stream, P, S, MN);
-    }
-    const long long blocks = (long long)((M + 31) / 32) * ((N + 31) / 32);
-    if (blocks > 0x7fffffffLL) return RIH_EINVAL;
-    hipLaunchKernelGGL(splitk_transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P, M, N, dst,
-                       Cin, taps, CinValid, accumulate);
-    return (int)hipGetLastError();
+    return rih_splitk_reduce_bias(P, S, M, M, N, dst, Cin, taps, CinValid, accumulate, nullptr, stream);
 }
 
 extern "C" int rih_splitk_finish(const float* P, int S, int M, int N, float* C, int ldc, const float* bias,

@@ -95,12 +95,13 @@ PROFILE = None
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=None, ldr=0,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, kchunk=0, sCsplit=0, alpha=1.0, relu=False,
-         geom=None, tile=None, engine=None, cstride=None):
+         geom=None, tile=None, engine=None, cstride=None, ones_row=0):
     """Enqueue one rih_gemm.  A/B/Cout/bias/R are tensors or raw device pointers.
     cstride = (s, oh, ow, H, W): store GEMM row (img, i, j) to pixel (img, i*s+oh, j*s+ow) of a [*, H, W] tensor."""
     d = GemmDesc()
     if cstride is not None:
         d.cS, d.cOH, d.cOW, d.cH, d.cW = cstride
+    d.ones_row = ones_row
     d.engine = ENGINE if engine is None else engine
     d.A = A if isinstance(A, int) else A.data_ptr()
     d.B = B if isinstance(B, int) else B.data_ptr()
@@ -148,24 +149,27 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
     check(_L().rih_gemm(C.byref(d), _stream()), 'rih_gemm')
 
 
-def _wgrad(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid):
-    """dw (parameter layout) = im2col(x)^T @ dy with split-K over the Kpix pixels."""
-    tile = 3 if Ncols <= 32 else (2 if (Ncols <= 64 or Mrows <= 64) else 0)
+def _wgrad(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db=None):
+    """dw (parameter layout) = im2col(x)^T @ dy with split-K over the Kpix pixels.  With `db` (bias gradient, [Ncols])
+    the A operand gets an all-ones row behind its Mrows rows, so the same GEMM also produces the column sums of dy."""
+    Mp = Mrows + 4 if db is not None else Mrows
+    tile = 3 if Ncols <= 32 else (2 if (Ncols <= 64 or Mp <= 64) else 0)
     bm, bn = _TILE_MN[tile]
-    tiles = _cdiv(Mrows, bm) * _cdiv(Ncols, bn)
+    tiles = _cdiv(Mp, bm) * _cdiv(Ncols, bn)
     target = 512 if (ENGINE == 1 and tile == 0) else 1024     # measured optimum of resident split-K slices
     splitk = max(1, min(target // max(tiles, 1), _cdiv(Kpix, 128)))
     kchunk = _cdiv(_cdiv(Kpix, splitk), 32) * 32
     splitk = _cdiv(Kpix, kchunk)
-    part = torch.empty((splitk, Mrows, Ncols), device=x.device, dtype=torch.float32)
+    part = torch.empty((splitk, Mp, Ncols), device=x.device, dtype=torch.float32)
+    ones = Mrows if db is not None else 0
     if splitk == 1:
-        # single pass still goes through the reduce kernel for the layout change; raw epilogue = alpha 1, no bias
-        gemm(x, dy, part, Mrows, Ncols, Kpix, ldx, ldy, Ncols, a_mode=1, b_mode=0, geom=geom, tile=tile)
+        # a single slice still goes through the reduce kernel for the layout change; raw epilogue = alpha 1, no bias
+        gemm(x, dy, part, Mp, Ncols, Kpix, ldx, ldy, Ncols, a_mode=1, b_mode=0, geom=geom, tile=tile, ones_row=ones)
     else:
-        gemm(x, dy, part, Mrows, Ncols, Kpix, ldx, ldy, Ncols, a_mode=1, b_mode=0, splitk=splitk, kchunk=kchunk,
-             sCsplit=Mrows * Ncols, geom=geom, tile=tile)
-    check(_L().rih_splitk_reduce(part.data_ptr(), splitk, Mrows, Ncols, dw.data_ptr(), Cin_pad, taps, Cin_valid, 0,
-                                 _stream()), 'rih_splitk_reduce')
+        gemm(x, dy, part, Mp, Ncols, Kpix, ldx, ldy, Ncols, a_mode=1, b_mode=0, splitk=splitk, kchunk=kchunk,
+             sCsplit=Mp * Ncols, geom=geom, tile=tile, ones_row=ones)
+    check(_L().rih_splitk_reduce_bias(part.data_ptr(), splitk, Mp, Mrows, Ncols, dw.data_ptr(), Cin_pad, taps, Cin_valid,
+                                      0, _p(db), _stream()), 'rih_splitk_reduce_bias')
 
 
 def colsum(x2d, rows, Ccols, ldx=None):
@@ -257,11 +261,14 @@ class Conv2dFn(torch.autograd.Function):
                 check(lib.rih_pack_conv_weight(w.data_ptr(), wd.data_ptr(), Cout, Cin, KH, KW, Cx, 1, _stream()),
                       'rih_pack_conv_weight')
                 gemm(dy, wd, dx, Mx, Cx, KH * KW * Cout, Cout, Cx, Cx, a_mode=0, b_mode=0, geom=geom)
+        want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
+            if want_db:
+                db = torch.empty((Cout,), device=x.device, dtype=torch.float32)
             geom = (H, W_, Cx, Ho, Wo, KH, KW, stride, 1, pad, pad)
-            _wgrad(x, dy, dw, M, KH * KW * Cx, Cout, Cx, Cout, geom, Cx, KH * KW, Cin)
-        if has_bias and ctx.needs_input_grad[2]:
+            _wgrad(x, dy, dw, M, KH * KW * Cx, Cout, Cx, Cout, geom, Cx, KH * KW, Cin, db=db)
+        elif want_db:
             db = colsum(dy, M, Cout)
         return dx, dw, db, None, None, None
 
@@ -304,10 +311,13 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             gemm(dy, w, dx, M, K, Nf, Nf, K, K, a_mode=0, b_mode=0)
+        want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            _wgrad(x, dy, dw, M, K, Nf, K, Nf, (1, 1, K, 1, 1, 1, 1, 1, 1, 0, 0), K, 1, K)
-        if has_bias and ctx.needs_input_grad[2]:
+            if want_db:
+                db = torch.empty((Nf,), device=x.device, dtype=torch.float32)
+            _wgrad(x, dy, dw, M, K, Nf, K, Nf, (1, 1, K, 1, 1, 1, 1, 1, 1, 0, 0), K, 1, K, db=db)
+        elif want_db:
             db = colsum(dy, M, Nf)
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres, None

@@ -86,8 +86,12 @@ class EmulatedLib:
                     wi = (wo * d.strideA - d.padW)[None, :] + kw[:, None]
                     valid = (hi >= 0) & (wi >= 0) & (hi < d.H) & (wi < d.W) & (tap < taps)[:, None]
                     idx = ((img[None, :] * d.H + hi) * d.W + wi) * d.lda + ci[:, None]
+                    if d.ones_row > 0:      # rows >= ones_row are not read from memory
+                        valid[d.ones_row:] = False
                 idx = np.where(valid, idx, 0)
                 A = self._gather(Ab, idx, valid)
+                if d.a_mode == 1 and d.ones_row > 0:
+                    A[d.ones_row, :] = 1.0
                 kk, nn = np.meshgrid(np.arange(K), np.arange(N), indexing='ij')
                 bidx = kk * d.ldb + nn if d.b_mode == 0 else nn * d.ldb + kk
                 Bm = self._gather(Bb, bidx, np.ones_like(bidx, bool)) if K > 0 else np.zeros((0, N), np.float32)
@@ -120,7 +124,13 @@ class EmulatedLib:
         return 0
 
     def rih_splitk_reduce(self, P, S, M, N, dst, Cin, taps, CinValid, accumulate, stream):
-        p = _f(P, S * M * N).reshape(S, M, N).sum(0)
+        return self.rih_splitk_reduce_bias(P, S, M, M, N, dst, Cin, taps, CinValid, accumulate, 0, stream)
+
+    def rih_splitk_reduce_bias(self, P, S, Mp, M, N, dst, Cin, taps, CinValid, accumulate, db, stream):
+        p = _f(P, S * Mp * N).reshape(S, Mp, N).sum(0)
+        if db:
+            _f(db, N)[:] = p[M]
+        p = p[:M]
         out = _f(dst, N * CinValid * taps)
         m = np.arange(M)
         tap, ci = m // Cin, m % Cin
