@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_fused_kernel(const float* _
         acc[i][0] = acc[i][1] = 0.f;
     }
     int k = 0;
-    for (; k + 1 < S; k += 2) {
+    for (; k + 1 < S; k += 2) {         // (a 4-way unroll was measured 4x slower: keep 8 loads in flight per lane)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             acc[i][0] += q[i][(long long)k * slab];

@@ -153,7 +153,9 @@ def _wgrad(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_val
     """dw (parameter layout) = im2col(x)^T @ dy with split-K over the Kpix pixels.  With `db` (bias gradient, [Ncols])
     the A operand gets an all-ones row behind its Mrows rows, so the same GEMM also produces the column sums of dy."""
     Mp = Mrows + 4 if db is not None else Mrows
-    tile = 3 if Ncols <= 32 else (2 if (Ncols <= 64 or Mp <= 64) else 0)
+    # small weight matrices (decoder Linears, <= 4x4 tiles of 128): 64x64 tiles give 4x the resident slices per split
+    small = _cdiv(Mp, 128) * _cdiv(Ncols, 128) < 16
+    tile = 3 if Ncols <= 32 else (2 if (Ncols <= 64 or Mp <= 64 or (ENGINE == 1 and small)) else 0)
     bm, bn = _TILE_MN[tile]
     tiles = _cdiv(Mp, bm) * _cdiv(Ncols, bn)
     target = 512 if (ENGINE == 1 and tile == 0) else 1024     # measured optimum of resident split-K slices
