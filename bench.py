@@ -92,6 +92,8 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 64, hrnet32: 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true',
+                    help='launch every kernel from Python each step instead of replaying a captured hipGraph')
     ap.add_argument('--ddp', action='store_true',
                     help='N>1: use torch DistributedDataParallel(find_unused_parameters=True) like the reference trainer '
                          'instead of renderih_amd.dp.GradAllReducer (same gradients, ~25 ms/step more host work)')
@@ -139,16 +141,47 @@ def main():
     B = args.batch
     img, lab = synth_batch(B, device, seed=rank)
 
-    def step():
+    def fwd_bwd():
         out = net(img)
         loss, _ = calc_loss_GCN(None, 0, gl['left'], gl['right'], conv['left'], conv['right'], *out,
                                 lab['v2d_l'], lab['v2d_r'], lab['v3d_l'], lab['v3d_r'], lab['root_rel'], 256)
-        opt.zero_grad(set_to_none=True)
         loss.backward()
+        return loss
+
+    def step_eager():
+        opt.zero_grad(set_to_none=True)
+        loss = fwd_bwd()
         if reducer is not None:
             reducer.reduce()
         opt.step()
         return loss
+
+    # hipGraph: forward + loss + backward (~2700 kernel launches, ~55 ms of Python/launch work per step, about as
+    # long as the GPU work itself) are captured once and replayed; the ~110 launches of gradient exchange + Adam stay
+    # eager.  Dropout masks stay fresh because the kernels add a device-resident seed word that the graph advances.
+    use_graph = not args.no_graph and not args.ddp
+    step = step_eager
+    if use_graph:
+        seed_word = torch.zeros(1, dtype=torch.int64, device=device)
+        ops.DROPOUT_SEED_TENSOR = seed_word
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                      # warm-up on the capture stream (lazy index tables, allocator)
+                step_eager()
+        torch.cuda.current_stream().wait_stream(side)
+        opt.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            seed_word.add_(0x9E3779B1)
+            static_loss = fwd_bwd()
+
+        def step():
+            graph.replay()                          # gradients are rewritten in place in the graph's static buffers
+            if reducer is not None:
+                reducer.reduce()
+            opt.step()
+            return static_loss
 
     def barrier():
         if dist_on:
@@ -173,7 +206,7 @@ def main():
     roof = None
     if not args.no_roofline and rank == 0:
         ops.PROFILE = []
-        step()
+        step_eager()
         torch.cuda.synchronize()
         recs = ops.PROFILE
         ops.PROFILE = None
@@ -226,6 +259,7 @@ def main():
                            else ('BASELINE configs[3] model: batch=%d/GPU 256x256 HRNet-W32 + cross-hand attention decoder, '
                                  'fwd + loss + bwd + Adam step, dropout 0.05, fp32' % B),
                            'global_batch': B * world, 'parallelism': 'dp%d' % world, 'loss': round(final_loss, 4),
+                           'hipgraph': bool(use_graph),
                            'gemm_engine': ('fp32 via 3-term bf16 split, 6 MFMA products, fp32 accumulate (fp32-grade error)'
                                            if ops.ENGINE == 1 else 'native f32 MFMA')},
                 'roofline': roof, 'cpu_baseline': cpu}

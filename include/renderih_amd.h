@@ -165,20 +165,24 @@ int rih_layernorm_bwd(const float* dy, const float* x, const float* x2, const fl
                       const float* mean, const float* rstd, float* dx, float* dg, float* db, int rows, int D,
                       int relu, float* ws, void* stream);
 /* softmax over the last dim of [rows][ld] (first `cols` entries), optional inverted dropout with a
- * counter-based hash RNG: P (pre-dropout probabilities) and Pd (post-dropout, may alias P when p==0) */
+ * counter-based hash RNG: P (pre-dropout probabilities) and Pd (post-dropout, may alias P when p==0).
+ * Every dropout entry point takes the stream id of the mask as `seed` plus an optional DEVICE word `seed_dev` (may be
+ * NULL) that is added to it on the GPU: a training step captured in a hipGraph advances that word inside the graph
+ * and gets a fresh mask at every replay, with no host involvement. */
 int rih_softmax_fwd(const float* S, float* P, float* Pd, int64_t rows, int cols, int ld, float drop_p,
-                    uint64_t seed, void* stream);
+                    uint64_t seed, const uint64_t* seed_dev, void* stream);
 /* dS = alpha * P * (dPd*mask/(1-p) - sum_j(dPd*mask/(1-p) * P)), written in place over dPd */
 int rih_softmax_bwd(const float* P, float* dPd, int64_t rows, int cols, int ld, float drop_p, uint64_t seed,
-                    float alpha, void* stream);
+                    const uint64_t* seed_dev, float alpha, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise / gather                                                                                 */
 /* y = a + dropout(b) (inverted dropout, p may be 0); b_bcast_rows>0: b is [b_bcast_rows][D] broadcast over the batch */
 int rih_add_dropout(const float* a, const float* b, float* y, int64_t n, int D, int b_bcast_rows, float drop_p,
-                    uint64_t seed, void* stream);
+                    uint64_t seed, const uint64_t* seed_dev, void* stream);
 /* backward of dropout: dx = dy * mask/(1-p) */
-int rih_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64_t seed, void* stream);
+int rih_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64_t seed, const uint64_t* seed_dev,
+                    void* stream);
 /* y = max(x,0);  dx = dy * (y>0) */
 int rih_relu_fwd(const float* x, float* y, int64_t n, void* stream);
 int rih_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);

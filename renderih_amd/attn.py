@@ -29,7 +29,10 @@ class DropCtx:
 
     def __init__(self, p=0.0, training=False):
         self.p = float(p) if training else 0.0
-        self.base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if self.p > 0 else 0
+        if self.p > 0 and ops.DROPOUT_SEED_TENSOR is None:
+            self.base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())     # host RNG (torch.manual_seed controls it)
+        else:
+            self.base = 0x5EED      # the per-step entropy comes from the device-resident seed word (hipGraph replay)
         self.n = 0
 
     def seed(self):

@@ -680,7 +680,9 @@ constexpr int SM_MAXPER = 16;   // cols <= 1024
 
 __global__ __launch_bounds__(TPB) void softmax_fwd_kernel(const float* __restrict__ S, float* __restrict__ P,
                                                           float* __restrict__ Pd, long long rows, int cols, int ld,
-                                                          float drop_p, uint64_t seed) {
+                                                          float drop_p, uint64_t seed,
+                                                          const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev != nullptr) seed += *seed_dev;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nper = (cols + 63) / 64;
     const uint32_t thr = drop_thresh(drop_p);
@@ -722,7 +724,9 @@ __global__ __launch_bounds__(TPB) void softmax_fwd_kernel(const float* __restric
 
 __global__ __launch_bounds__(TPB) void softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dPd,
                                                           long long rows, int cols, int ld, float drop_p, uint64_t seed,
+                                                          const uint64_t* __restrict__ seed_dev,
                                                           float alpha) {
+    if (seed_dev != nullptr) seed += *seed_dev;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nper = (cols + 63) / 64;
     const uint32_t thr = drop_thresh(drop_p);
@@ -757,7 +761,9 @@ __global__ __launch_bounds__(TPB) void softmax_bwd_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------------------ elementwise
 __global__ void add_dropout_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
-                                   long long n, long long bmod, float drop_p, uint64_t seed) {
+                                   long long n, long long bmod, float drop_p, uint64_t seed,
+                                   const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev != nullptr) seed += *seed_dev;
     const uint32_t thr = drop_thresh(drop_p);
     const float keep_scale = (drop_p > 0.f) ? 1.f / (1.f - drop_p) : 1.f;
     GRID_STRIDE(i, n) {
@@ -768,7 +774,8 @@ __global__ void add_dropout_kernel(const float* __restrict__ a, const float* __r
 }
 
 __global__ void dropout_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long long n, float drop_p,
-                                   uint64_t seed) {
+                                   uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev != nullptr) seed += *seed_dev;
     const uint32_t thr = drop_thresh(drop_p);
     const float keep_scale = (drop_p > 0.f) ? 1.f / (1.f - drop_p) : 1.f;
     GRID_STRIDE(i, n) {
@@ -1045,38 +1052,40 @@ extern "C" int rih_layernorm_bwd(const float* dy, const float* x, const float* x
     LAUNCH_RET();
 }
 extern "C" int rih_softmax_fwd(const float* S, float* P, float* Pd, int64_t rows, int cols, int ld, float drop_p,
-                               uint64_t seed, void* stream) {
+                               uint64_t seed, const uint64_t* seed_dev, void* stream) {
     if (!S || !P || !Pd || rows < 1 || cols < 1 || cols > 64 * SM_MAXPER || ld < cols) return RIH_EINVAL;
     if (drop_p < 0.f || drop_p >= 1.f) return RIH_EINVAL;
     if (drop_p > 0.f && Pd == P) return RIH_EINVAL;
     long long blocks = (rows + 3) / 4;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(softmax_fwd_kernel, dim3((int)blocks), dim3(TPB), 0, STREAM, S, P, Pd, (long long)rows, cols, ld,
-                       drop_p, seed);
+                       drop_p, seed, seed_dev);
     LAUNCH_RET();
 }
 extern "C" int rih_softmax_bwd(const float* P, float* dPd, int64_t rows, int cols, int ld, float drop_p, uint64_t seed,
-                               float alpha, void* stream) {
+                               const uint64_t* seed_dev, float alpha, void* stream) {
     if (!P || !dPd || rows < 1 || cols < 1 || cols > 64 * SM_MAXPER || ld < cols) return RIH_EINVAL;
     if (drop_p < 0.f || drop_p >= 1.f) return RIH_EINVAL;
     long long blocks = (rows + 3) / 4;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3((int)blocks), dim3(TPB), 0, STREAM, P, dPd, (long long)rows, cols, ld,
-                       drop_p, seed, alpha);
+                       drop_p, seed, seed_dev, alpha);
     LAUNCH_RET();
 }
 
 extern "C" int rih_add_dropout(const float* a, const float* b, float* y, int64_t n, int D, int b_bcast_rows,
-                               float drop_p, uint64_t seed, void* stream) {
+                               float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream) {
     if (!b || !y || n < 1 || D < 1 || b_bcast_rows < 0 || drop_p < 0.f || drop_p >= 1.f) return RIH_EINVAL;
     const long long bmod = (long long)b_bcast_rows * D;
     hipLaunchKernelGGL(add_dropout_kernel, dim3(grid_for(n, 4)), dim3(TPB), 0, STREAM, a, b, y, (long long)n, bmod, drop_p,
-                       seed);
+                       seed, seed_dev);
     LAUNCH_RET();
 }
-extern "C" int rih_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64_t seed, void* stream) {
+extern "C" int rih_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64_t seed,
+                               const uint64_t* seed_dev, void* stream) {
     if (!dy || !dx || n < 1 || drop_p < 0.f || drop_p >= 1.f) return RIH_EINVAL;
-    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n, 4)), dim3(TPB), 0, STREAM, dy, dx, (long long)n, drop_p, seed);
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n, 4)), dim3(TPB), 0, STREAM, dy, dx, (long long)n, drop_p, seed,
+                       seed_dev);
     LAUNCH_RET();
 }
 extern "C" int rih_relu_fwd(const float* x, float* y, int64_t n, void* stream) {

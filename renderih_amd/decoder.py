@@ -20,12 +20,21 @@ class GCN_vert_convert():
     def __init__(self, vertex_num=1, graph_perm_reverse=[0], graph_perm=[0]):
         self.graph_perm_reverse = graph_perm_reverse[:vertex_num]
         self.graph_perm = graph_perm
+        self._dev = {}
+
+    def _index(self, name, device):
+        """The index list as a device tensor, uploaded once per device: indexing with a host list would copy it to
+        the GPU on every call (a synchronous transfer that also cannot be captured in a hipGraph)."""
+        key = (name, device)
+        if key not in self._dev:
+            self._dev[key] = torch.as_tensor(np.asarray(getattr(self, name), dtype=np.int64), device=device)
+        return self._dev[key]
 
     def vert_to_GCN(self, x):
-        return x[:, self.graph_perm]
+        return x[:, self._index('graph_perm', x.device)]
 
     def GCN_to_vert(self, x):
-        return x[:, self.graph_perm_reverse]
+        return x[:, self._index('graph_perm_reverse', x.device)]
 
 
 class decoder(nn.Module):

@@ -88,6 +88,16 @@ _TILE_MN = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (256, 128
 import os as _os
 ENGINE = int(_os.environ.get('RIH_GEMM_ENGINE', '1'))
 
+# Optional device-resident dropout seed word (a 1-element int64 CUDA tensor): when set, every dropout kernel adds
+# *DROPOUT_SEED_TENSOR to its seed on the GPU.  A training step captured in a hipGraph advances the word inside the graph
+# (`tensor.add_(1)`) and so draws fresh masks at every replay; forward and backward of one step see the same value.
+DROPOUT_SEED_TENSOR = None
+
+
+def _seed_dev():
+    return 0 if DROPOUT_SEED_TENSOR is None else DROPOUT_SEED_TENSOR.data_ptr()
+
+
 # When set to a list, every rih_gemm launch is bracketed by HIP events on the launch stream and
 # (flops, start, end, tag) is appended -- bench.py uses this for the live roofline measurement.
 PROFILE = None
@@ -599,7 +609,7 @@ def _attn_forward(q, q_ld, k, v, kv_ld, B, Sq, Sk, D, heads, drop_p, seed, devic
          sB=(Sk * kv_ld, d), sC=(heads * Sq * ldP, Sq * ldP), alpha=alpha)
     Pd = torch.empty_like(P) if drop_p > 0 else P
     check(_L().rih_softmax_fwd(P.data_ptr(), P.data_ptr(), Pd.data_ptr(), B * heads * Sq, Sk, ldP, drop_p, seed,
-                               _stream()), 'rih_softmax_fwd')
+                               _seed_dev(), _stream()), 'rih_softmax_fwd')
     out = torch.empty((B, Sq, D), device=device, dtype=torch.float32)
     gemm(Pd, v, out, Sq, d, Sk, ldP, kv_ld, D, a_mode=0, b_mode=0, nb1=B, nb2=heads,
          sA=(heads * Sq * ldP, Sq * ldP), sB=(Sk * kv_ld, d), sC=(Sq * D, d))
@@ -617,8 +627,8 @@ def _attn_backward(do, q, q_ld, k, v, kv_ld, dq, dq_ld, dk, dv, dkv_ld, P, Pd, B
     dS = torch.empty_like(P)
     gemm(do, v, dS, Sq, Sk, d, D, kv_ld, ldP, a_mode=0, b_mode=1, nb1=B, nb2=heads, sA=(Sq * D, d),
          sB=(Sk * kv_ld, d), sC=sP)
-    check(_L().rih_softmax_bwd(P.data_ptr(), dS.data_ptr(), B * heads * Sq, Sk, ldP, drop_p, seed, alpha,
-                               _stream()), 'rih_softmax_bwd')
+    check(_L().rih_softmax_bwd(P.data_ptr(), dS.data_ptr(), B * heads * Sq, Sk, ldP, drop_p, seed, _seed_dev(),
+                               alpha, _stream()), 'rih_softmax_bwd')
     gemm(dS, k, dq, Sq, d, Sk, ldP, kv_ld, dq_ld, a_mode=0, b_mode=0, nb1=B, nb2=heads, sA=sP, sB=(Sk * kv_ld, d),
          sC=(Sq * dq_ld, d))
     gemm(dS, q, dk, Sk, d, Sq, ldP, q_ld, dkv_ld, a_mode=1, b_mode=0, nb1=B, nb2=heads, sA=sP, sB=(Sq * q_ld, d),
@@ -749,7 +759,7 @@ class AddDropoutFn(torch.autograd.Function):
         y = torch.empty_like(ref)
         D = ref.shape[-1]
         check(_L().rih_add_dropout(_p(a), b.data_ptr(), y.data_ptr(), y.numel(), D, bcast_rows, drop_p, seed,
-                                   _stream()), 'rih_add_dropout')
+                                   _seed_dev(), _stream()), 'rih_add_dropout')
         ctx.cfg = (drop_p, seed, bcast_rows, a is not None, tuple(b.shape))
         return y
 
@@ -766,8 +776,8 @@ class AddDropoutFn(torch.autograd.Function):
                 db = colsum(dy, Bn, bcast_rows * D).view(bshape)
             elif drop_p > 0:
                 db = torch.empty_like(dy)
-                check(_L().rih_dropout_bwd(dy.data_ptr(), db.data_ptr(), dy.numel(), drop_p, seed, _stream()),
-                      'rih_dropout_bwd')
+                check(_L().rih_dropout_bwd(dy.data_ptr(), db.data_ptr(), dy.numel(), drop_p, seed, _seed_dev(),
+                                           _stream()), 'rih_dropout_bwd')
             else:
                 db = dy
         return da, db, None, None, None

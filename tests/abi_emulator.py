@@ -44,6 +44,13 @@ def keep_mask(seed, n, p):
 
 
 class EmulatedLib:
+    @staticmethod
+    def _seed(seed, seed_dev):
+        """seed + *seed_dev (mod 2^64), the device-side seed word being host memory under emulation."""
+        if seed_dev:
+            seed = (int(seed) + int(np.ctypeslib.as_array((C.c_uint64 * 1).from_address(int(seed_dev)))[0])) % (1 << 64)
+        return seed
+
     # ------------------------------------------------------------------ GEMM family
     def _gather(self, base, idx, valid):
         n = int(idx[valid].max()) + 1 if valid.any() else 1
@@ -336,7 +343,8 @@ class EmulatedLib:
         _f(db, D)[:] = Dy.sum(0)
         return 0
 
-    def rih_softmax_fwd(self, S, P, Pd, rows, cols, ld, drop_p, seed, stream):
+    def rih_softmax_fwd(self, S, P, Pd, rows, cols, ld, drop_p, seed, seed_dev, stream):
+        seed = self._seed(seed, seed_dev)
         idx = np.arange(rows)[:, None] * ld + np.arange(cols)[None, :]
         s = _f(S, (rows - 1) * ld + cols)[idx]
         e = np.exp(s - s.max(1, keepdims=True))
@@ -348,7 +356,8 @@ class EmulatedLib:
             _f(Pd, (rows - 1) * ld + cols)[idx.ravel()] = p.ravel()
         return 0
 
-    def rih_softmax_bwd(self, P, dPd, rows, cols, ld, drop_p, seed, alpha, stream):
+    def rih_softmax_bwd(self, P, dPd, rows, cols, ld, drop_p, seed, seed_dev, alpha, stream):
+        seed = self._seed(seed, seed_dev)
         idx = np.arange(rows)[:, None] * ld + np.arange(cols)[None, :]
         p = _f(P, (rows - 1) * ld + cols)[idx]
         mem = _f(dPd, (rows - 1) * ld + cols)
@@ -358,7 +367,8 @@ class EmulatedLib:
         return 0
 
     # ------------------------------------------------------------------ elementwise / gathers
-    def rih_add_dropout(self, a, b, y, n, D, bcast_rows, drop_p, seed, stream):
+    def rih_add_dropout(self, a, b, y, n, D, bcast_rows, drop_p, seed, seed_dev, stream):
+        seed = self._seed(seed, seed_dev)
         bm = bcast_rows * D
         bv = _f(b, bm if bm > 0 else n)
         bv = bv[np.arange(n) % bm] if bm > 0 else bv.copy()
@@ -366,7 +376,8 @@ class EmulatedLib:
         _f(y, n)[:] = (_f(a, n) if a else 0) + bv
         return 0
 
-    def rih_dropout_bwd(self, dy, dx, n, drop_p, seed, stream):
+    def rih_dropout_bwd(self, dy, dx, n, drop_p, seed, seed_dev, stream):
+        seed = self._seed(seed, seed_dev)
         _f(dx, n)[:] = _f(dy, n) * keep_mask(seed, n, drop_p)
         return 0
 

@@ -194,3 +194,83 @@ def test_hrnet_matches_fp64_oracle(training):
     _grad_report(params, g32, g64)
     if training:
         assert int(m.encoder.hrnet.bn1.num_batches_tracked) == 1
+
+
+# ------------------------------------------------------------------------------------------------ hipGraph capture
+def _sgd_losses(m, img, steps, capture, dropout_seed=None):
+    """`steps` plain-SGD steps on the scalar loss; forward+backward either launched eagerly or replayed from a hipGraph."""
+    from oracle.net_oracle import scalar_loss
+    from renderih_amd import ops
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1e-15)      # the seeded weights give gradients ~1e9: keep the walk tiny but non-zero
+    ops.DROPOUT_SEED_TENSOR = dropout_seed
+    losses = []
+    try:
+        def fwd_bwd():
+            loss = scalar_loss(m(img))
+            loss.backward()
+            return loss
+        if not capture:
+            for _ in range(steps):
+                opt.zero_grad(set_to_none=True)
+                if dropout_seed is not None:
+                    dropout_seed.add_(7)
+                losses.append(float(fwd_bwd()))
+                opt.step()
+            return losses
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            opt.zero_grad(set_to_none=True)
+            fwd_bwd()                                   # warm-up (no optimizer step: keep the weights)
+        torch.cuda.current_stream().wait_stream(side)
+        for mod in m.modules():                         # undo the warm-up's BatchNorm bookkeeping
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.reset_running_stats()
+        opt.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            if dropout_seed is not None:
+                dropout_seed.add_(7)
+            static_loss = fwd_bwd()
+        for _ in range(steps):
+            g.replay()
+            losses.append(float(static_loss))
+            opt.step()
+        return losses
+    finally:
+        ops.DROPOUT_SEED_TENSOR = None
+
+
+def test_hipgraph_training_step_matches_eager():
+    """Forward + loss + backward captured in a hipGraph and replayed: same losses as launching every kernel from
+    Python (dropout off: bit-identical kernels, so the trajectories agree to round-off of the loss reduction)."""
+    img = testing.seeded_image(2, 21).cuda()
+    m1, _ = _build(0.0, seed=9)
+    m1.train()
+    eager = _sgd_losses(m1, img, 3, capture=False)
+    m2, _ = _build(0.0, seed=9)
+    m2.train()
+    graph = _sgd_losses(m2, img, 3, capture=True)
+    for a, b in zip(eager, graph):
+        assert abs(a - b) <= 1e-6 * abs(a), (eager, graph)
+    assert eager[0] != eager[1]                     # the optimizer really moved the weights
+    for (k, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p, q), k
+
+
+def test_hipgraph_replay_draws_fresh_dropout_masks():
+    """With the device-resident seed word advanced inside the graph, every replay uses new dropout masks, and the same
+    word value reproduces the eager result."""
+    img = testing.seeded_image(2, 22).cuda()
+    m, _ = _build(0.3, seed=9)
+    m.train()
+    seed = torch.zeros(1, dtype=torch.int64, device='cuda')
+    g_losses = _sgd_losses(m, img, 3, capture=True, dropout_seed=seed)
+    assert len({round(v, 3) for v in g_losses}) == 3, g_losses          # three different masks
+    m2, _ = _build(0.3, seed=9)
+    m2.train()
+    seed2 = torch.zeros(1, dtype=torch.int64, device='cuda')            # capture records the advance, replays run it
+    e_losses = _sgd_losses(m2, img, 3, capture=False, dropout_seed=seed2)
+    for a, b in zip(e_losses, g_losses):
+        assert abs(a - b) <= 1e-5 * abs(a), (e_losses, g_losses)
