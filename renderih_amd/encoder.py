@@ -20,8 +20,19 @@ def bn_act(bn, x, residual=None, relu=False):
     y = ops.batchnorm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual=residual,
                       training=bn.training, relu=relu, eps=bn.eps, momentum=bn.momentum)
     if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        _PENDING_TRACKED.append(bn.num_batches_tracked)
     return y
+
+
+_PENDING_TRACKED = []
+
+
+def flush_batches_tracked():
+    """`num_batches_tracked += 1` of every BatchNorm that ran since the last flush, as ONE multi-tensor launch
+    (65 one-element kernels per forward otherwise).  Called at the end of HandNET_GCN.forward."""
+    if _PENDING_TRACKED:
+        torch._foreach_add_(list(_PENDING_TRACKED), 1)
+        _PENDING_TRACKED.clear()
 
 
 def conv(m, x, relu=False):

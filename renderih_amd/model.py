@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from . import assets
 from .config import load_cfg
-from .encoder import load_encoder, ResNetSimple, resnet_mid
+from .encoder import load_encoder, ResNetSimple, resnet_mid, flush_batches_tracked
 from .decoder import decoder as Decoder
 
 
@@ -24,6 +24,7 @@ class HandNET_GCN(nn.Module):
     def forward(self, img):
         hms, mask, dp, img_fmaps, hms_fmaps, dp_fmaps = self.encoder(img)
         global_feature, fmaps = self.mid_model(img_fmaps, hms_fmaps, dp_fmaps)
+        flush_batches_tracked()
         result, paramsDict, handDictList, otherInfo = self.decoder(global_feature, fmaps)
         if hms is not None:
             otherInfo['hms'] = hms
