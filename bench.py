@@ -120,7 +120,7 @@ def main():
 
     from renderih_amd import ops, assets
     from renderih_amd.model import build_model
-    from renderih_amd.loss import GraphLoss, calc_loss_GCN
+    from renderih_amd.loss import GraphLoss, FusedMeshLoss, calc_loss_GCN_fused
     from renderih_amd.manolayer import ManoLayer
 
     torch.manual_seed(0)
@@ -140,13 +140,14 @@ def main():
     mano = {s: ManoLayer(assets.synthetic_mano_dict(s)) for s in ('left', 'right')}
     gl = {s: GraphLoss(mano[s].J_regressor, mano[s].get_faces(), level=4, device=device) for s in ('left', 'right')}
     conv = model.decoder.converter
+    fused_loss = FusedMeshLoss(gl['left'], gl['right'], conv['left'], conv['right'])      # core/Loss.py on one HIP kernel
     B = args.batch
     img, lab = synth_batch(B, device, seed=rank)
 
     def fwd_bwd():
         out = net(img)
-        loss, _ = calc_loss_GCN(None, 0, gl['left'], gl['right'], conv['left'], conv['right'], *out,
-                                lab['v2d_l'], lab['v2d_r'], lab['v3d_l'], lab['v3d_r'], lab['root_rel'], 256)
+        loss, _ = calc_loss_GCN_fused(fused_loss, 0, *out, lab['v2d_l'], lab['v2d_r'], lab['v3d_l'], lab['v3d_r'],
+                                      lab['root_rel'])
         loss.backward()
         return loss
 

@@ -239,6 +239,35 @@ int rih_mano_bwd(const rih_mano_model* m, const float* root, const float* pose, 
                  float* d_scale, float* ws_bwd, int B, void* stream);
 int64_t rih_mano_bwd_ws_floats(int B);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused mesh loss   (core/Loss.py:68-164 GraphLoss.calc_loss, :201-277 calc_loss_GCN; aux loss disabled there)
+ * Constant topology of one hand (device pointers, uploaded once by the caller):
+ *   faces[F][3]; vptr[V+1], vlist[3F]: for every vertex the list of (face*3 + corner) it belongs to, ascending;
+ *   J[NJ][V] dense joint regressor incl. the 5 finger tips, reordered (Loss.py:38-53); perm[Vc*pool] = graph_perm
+ *   (vert_to_GCN); pool = 2^k consecutive graph-order vertices are average-pooled pairwise into one coarse vertex.
+ * rih_mesh_loss (one launch per hand): predictions v3d_pred[B][V][3], v2d_pred[B][V][2], c3d_pred[B][Vc][3],
+ *   c2d_pred[B][Vc][2]; labels v3d_gt, v2d_gt; gt_shift[B][3] or NULL is added to v3d_gt (root_rel of the right hand).
+ *   term_weights[7] (HOST array, order v2d, v3d, joint, normal, edge, coarse-3d, coarse-2d) = weight of the raw SUM of
+ *   each term in the total, i.e. LOSS_WEIGHT / element count / 2 (hand average).  Writes the gradient of the total
+ *   with respect to the four prediction tensors and partial[B][8] (raw sums of the seven terms per image).
+ * rih_mesh_loss_final: out[0] = total over both hands; out[1..7] = the seven terms as the reference reports them
+ *   (mean over elements, averaged over the hands); counts[7] = element counts (HOST array). */
+typedef struct rih_mesh_topo {
+    const int32_t* faces;
+    const int32_t* vptr;
+    const int32_t* vlist;
+    const float* J;
+    const int32_t* perm;
+    int32_t V, F, NJ, Vc, pool;
+} rih_mesh_topo;
+
+int rih_mesh_loss(const rih_mesh_topo* topo, const float* v3d_pred, const float* v2d_pred, const float* c3d_pred,
+                  const float* c2d_pred, const float* v3d_gt, const float* v2d_gt, const float* gt_shift,
+                  const float* term_weights, float img_size, float* g_v3d, float* g_v2d, float* g_c3d, float* g_c2d,
+                  float* partial, int B, void* stream);
+int rih_mesh_loss_final(const float* partial_left, const float* partial_right, int B, const float* term_weights,
+                        const float* counts, float* out, void* stream);
+
 /* library / device info */
 int rih_version(void);
 const char* rih_arch(void);

@@ -36,6 +36,12 @@ class ManoModel(C.Structure):
                 ('weights', C.c_void_p), ('parent', C.c_int32 * 16)]
 
 
+class MeshTopo(C.Structure):
+    _fields_ = [('faces', C.c_void_p), ('vptr', C.c_void_p), ('vlist', C.c_void_p), ('J', C.c_void_p),
+                ('perm', C.c_void_p), ('V', C.c_int32), ('F', C.c_int32), ('NJ', C.c_int32), ('Vc', C.c_int32),
+                ('pool', C.c_int32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/renderih_amd.h declares
 SIGNATURES = {
     'rih_gemm': (c_i, [C.POINTER(GemmDesc), C.c_void_p]),
@@ -84,6 +90,9 @@ SIGNATURES = {
                            C.c_void_p]),
     'rih_mano_bwd': (c_i, [C.POINTER(ManoModel), c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f,
                            c_f, c_f, c_f, c_f, c_f, c_f, c_i, C.c_void_p]),
+    'rih_mesh_loss': (c_i, [C.POINTER(MeshTopo), c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.POINTER(C.c_float), c_fl,
+                            c_f, c_f, c_f, c_f, c_f, c_i, C.c_void_p]),
+    'rih_mesh_loss_final': (c_i, [c_f, c_f, c_i, C.POINTER(C.c_float), C.POINTER(C.c_float), c_f, C.c_void_p]),
     'rih_version': (c_i, []),
     'rih_arch': (C.c_char_p, []),
 }

@@ -101,3 +101,112 @@ def calc_loss_GCN(weights, epoch, loss_left, loss_right, converter_left, convert
         total = total + w['UPSAMPLE'] * F.smooth_l1_loss(upsample_weight - loss_left.upsample_weight,
                                                          torch.zeros_like(upsample_weight))
     return total, mano
+
+
+# ------------------------------------------------------------------------------------------------ fused HIP loss
+class _MeshLossFn(torch.autograd.Function):
+    """Total loss of calc_loss_GCN for both hands in three launches (rih_mesh_loss x 2 + rih_mesh_loss_final); the
+    kernel already produced the gradients, backward only scales them by the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, fused, v3l, v2l, c3l, c2l, v3r, v2r, c3r, c2r, gt3l, gt2l, gt3r, gt2r, root_rel):
+        import ctypes as C
+        from . import _lib
+        from .ops import _stream, check
+        lib = _lib.load()
+        B = v3l.shape[0]
+        w, cnt = fused.weights(B)
+        wa = (C.c_float * 7)(*w)
+        ca = (C.c_float * 7)(*cnt)
+        preds = [t.contiguous() for t in (v3l, v2l, c3l, c2l, v3r, v2r, c3r, c2r)]
+        grads = [torch.empty_like(t) for t in preds]
+        parts = torch.empty((2, B, 8), device=v3l.device, dtype=torch.float32)
+        out = torch.empty((8,), device=v3l.device, dtype=torch.float32)
+        for h, (gt3, gt2, shift) in enumerate(((gt3l, gt2l, None), (gt3r, gt2r, root_rel))):
+            p, g = preds[4 * h:4 * h + 4], grads[4 * h:4 * h + 4]
+            topo = fused.topo('left' if h == 0 else 'right', v3l.device)
+            check(lib.rih_mesh_loss(C.byref(topo), p[0].data_ptr(), p[1].data_ptr(), p[2].data_ptr(), p[3].data_ptr(),
+                                    gt3.contiguous().data_ptr(), gt2.contiguous().data_ptr(),
+                                    0 if shift is None else shift.contiguous().data_ptr(), wa, float(fused.img_size),
+                                    g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(),
+                                    parts[h].data_ptr(), B, _stream()), 'rih_mesh_loss')
+        check(lib.rih_mesh_loss_final(parts[0].data_ptr(), parts[1].data_ptr(), B, wa, ca, out.data_ptr(), _stream()),
+              'rih_mesh_loss_final')
+        ctx.save_for_backward(*grads)
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms):
+        grads = [g.clone() for g in ctx.saved_tensors]      # the saved gradients may be read again (retain_graph)
+        torch._foreach_mul_(grads, g_total)
+        return (None,) + tuple(grads) + (None,) * 5
+
+
+class FusedMeshLoss:
+    """GPU drop-in for `calc_loss_GCN` (same arguments and total) on the fused HIP kernel.  Holds the constant
+    topology of both hands on the device: faces, vertex->face adjacency, 21-joint regressor, graph permutation."""
+
+    def __init__(self, loss_left, loss_right, converter_left, converter_right, weights=None, img_size=256):
+        self.w = dict(DEFAULT_WEIGHTS)
+        self.w.update(weights or {})
+        self.img_size = img_size
+        self.epoch = 0
+        self._host = {}
+        for side, gl, conv in (('left', loss_left, converter_left), ('right', loss_right, converter_right)):
+            faces = gl.faces.detach().cpu().numpy().astype(np.int32)
+            V = gl.J_regressor.shape[1]
+            order = np.argsort(faces.reshape(-1), kind='stable')            # entries (face*3 + corner) grouped by vertex
+            counts = np.bincount(faces.reshape(-1), minlength=V)
+            vptr = np.zeros(V + 1, np.int32)
+            vptr[1:] = np.cumsum(counts)
+            perm = np.asarray(conv.graph_perm, dtype=np.int32)
+            self._host[side] = dict(faces=faces, vptr=vptr, vlist=order.astype(np.int32),
+                                    J=gl.J_regressor.detach().cpu().float().contiguous(), perm=perm, V=V, F=faces.shape[0],
+                                    NJ=gl.J_regressor.shape[0])
+        self._dev = {}
+        self.Vc = None
+
+    def weights(self, B):
+        h = self._host['left']
+        V, F, NJ, Vc = h['V'], h['F'], h['NJ'], self.Vc
+        cnt = [B * V * 2, B * V * 3, B * NJ * 3, B * F * 3, B * F * 3, B * Vc * 3, B * Vc * 2]
+        alpha = 0.0 if self.epoch < self.w['NORM_EPOCH'] else 1.0
+        lw = [self.w['LABEL_2D'], self.w['LABEL_3D'], self.w['LABEL_3D'], self.w['NORMAL'], alpha * self.w['EDGE'],
+              self.w['LABEL_3D'], self.w['LABEL_2D']]
+        return [0.5 * a / c for a, c in zip(lw, cnt)], [float(c) for c in cnt]
+
+    def topo(self, side, device):
+        from ._lib import MeshTopo
+        key = (side, device)
+        if key not in self._dev:
+            h = self._host[side]
+            t = {k: torch.as_tensor(h[k], device=device) for k in ('faces', 'vptr', 'vlist', 'perm')}
+            t['J'] = h['J'].to(device)
+            pool = h['perm'].shape[0] // self.Vc
+            assert pool * self.Vc == h['perm'].shape[0] and pool & (pool - 1) == 0
+            self._dev[key] = (t, MeshTopo(t['faces'].data_ptr(), t['vptr'].data_ptr(), t['vlist'].data_ptr(),
+                                          t['J'].data_ptr(), t['perm'].data_ptr(), h['V'], h['F'], h['NJ'], self.Vc, pool))
+        return self._dev[key][1]
+
+    def __call__(self, epoch, result, handDictList, v2d_l, v2d_r, v3d_l, v3d_r, root_rel):
+        """Returns (total, terms) with terms = [total, vert2d, vert3d, joint, norm, edge, coarse3d, coarse2d]."""
+        self.epoch = epoch
+        assert len(handDictList) == 1, 'one coarse level (the reference decoder emits exactly one)'
+        hd = handDictList[0]
+        Vc = hd['verts3d']['left'].shape[1]
+        if self.Vc not in (None, Vc):
+            self._dev = {}
+        self.Vc = Vc
+        total, terms = _MeshLossFn.apply(self, result['verts3d']['left'], result['verts2d']['left'], hd['verts3d']['left'],
+                                         hd['verts2d']['left'], result['verts3d']['right'], result['verts2d']['right'],
+                                         hd['verts3d']['right'], hd['verts2d']['right'], v3d_l, v2d_l, v3d_r, v2d_r, root_rel)
+        return total, terms
+
+
+def calc_loss_GCN_fused(fused, epoch, result, paramsDict, handDictList, otherInfo, v2d_l, v2d_r, v3d_l, v3d_r, root_rel):
+    """`calc_loss_GCN` on the fused kernel: same total; the mano dict carries the reference's five terms."""
+    total, terms = fused(epoch, result, handDictList, v2d_l, v2d_r, v3d_l, v3d_r, root_rel)
+    mano = {'vert2d_loss': terms[1], 'vert3d_loss': terms[2], 'joint_loss': terms[3], 'norm_loss': terms[4],
+            'edge_loss': terms[5]}
+    return total, mano

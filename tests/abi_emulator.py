@@ -179,6 +179,61 @@ class EmulatedLib:
         _f(dst, out.size)[:] = out.ravel()
         return 0
 
+    # ------------------------------------------------------------------ fused mesh loss
+    def rih_mesh_loss(self, tp, v3p, v2p, c3p, c2p, v3g, v2g, shift, w, img, g3, g2, gc3, gc2, partial, B, stream):
+        tp = tp._obj
+        V, Fn, NJ, Vc, pool = tp.V, tp.F, tp.NJ, tp.Vc, tp.pool
+        faces = torch.from_numpy(_i32(tp.faces, Fn * 3).reshape(Fn, 3).astype(np.int64))
+        J = torch.from_numpy(_f(tp.J, NJ * V).reshape(NJ, V).copy())
+        perm = torch.from_numpy(_i32(tp.perm, Vc * pool).astype(np.int64))
+        w = [float(w[i]) for i in range(7)]
+        P3 = torch.from_numpy(_f(v3p, B * V * 3).reshape(B, V, 3).copy()).requires_grad_(True)
+        P2 = torch.from_numpy(_f(v2p, B * V * 2).reshape(B, V, 2).copy()).requires_grad_(True)
+        C3 = torch.from_numpy(_f(c3p, B * Vc * 3).reshape(B, Vc, 3).copy()).requires_grad_(True)
+        C2 = torch.from_numpy(_f(c2p, B * Vc * 2).reshape(B, Vc, 2).copy()).requires_grad_(True)
+        G3 = torch.from_numpy(_f(v3g, B * V * 3).reshape(B, V, 3).copy())
+        G2 = torch.from_numpy(_f(v2g, B * V * 2).reshape(B, V, 2).copy())
+        if shift:
+            G3 = G3 + torch.from_numpy(_f(shift, B * 3).reshape(B, 1, 3).copy())
+
+        def edges(v):
+            t_ = v[:, faces]
+            return torch.stack([t_[:, :, 0] - t_[:, :, 1], t_[:, :, 1] - t_[:, :, 2], t_[:, :, 2] - t_[:, :, 0]], 2)
+
+        def sl1(x):
+            return torch.where(x.abs() < 1, 0.5 * x * x, x.abs() - 0.5)
+        with torch.enable_grad():
+            s2 = 2.0 / img
+            ep, eg = edges(P3), edges(G3)
+            n = F.normalize(torch.cross(eg[:, :, 0], eg[:, :, 1], dim=-1), dim=-1).unsqueeze(2)
+            g3c, g2c = G3[:, perm], G2[:, perm]
+            p = pool
+            while p > 1:
+                g3c = g3c.reshape(B, -1, 2, 3).mean(2)
+                g2c = g2c.reshape(B, -1, 2, 2).mean(2)
+                p //= 2
+            terms = [((P2 * s2 - 1) - (G2 * s2 - 1)).pow(2).sum((1, 2)), sl1(P3 - G3).sum((1, 2)),
+                     sl1(torch.matmul(J, P3) - torch.matmul(J, G3)).sum((1, 2)),
+                     sl1((F.normalize(ep, dim=-1) * n).sum(-1)).sum((1, 2)),
+                     sl1(torch.linalg.norm(ep, dim=-1) - torch.linalg.norm(eg, dim=-1)).sum((1, 2)),
+                     sl1(C3 - g3c).sum((1, 2)), ((C2 * s2 - 1) - (g2c * s2 - 1)).pow(2).sum((1, 2))]
+            total = sum(wi * ti.sum() for wi, ti in zip(w, terms))
+            total.backward()
+        for ptr, tns in ((g3, P3), (g2, P2), (gc3, C3), (gc2, C2)):
+            _f(ptr, tns.numel())[:] = tns.grad.numpy().ravel()
+        out = _f(partial, B * 8).reshape(B, 8)
+        for i, ti in enumerate(terms):
+            out[:, i] = ti.detach().numpy()
+        return 0
+
+    def rih_mesh_loss_final(self, pl, pr, B, w, cnt, out, stream):
+        s = _f(pl, B * 8).reshape(B, 8).sum(0) + _f(pr, B * 8).reshape(B, 8).sum(0)
+        o = _f(out, 8)
+        o[0] = sum(float(w[i]) * float(s[i]) for i in range(7))
+        for i in range(7):
+            o[1 + i] = 0.5 * float(s[i]) / float(cnt[i])
+        return 0
+
     # ------------------------------------------------------------------ layout / pooling
     def rih_nchw_to_nhwc(self, x, y, N, Cc, H, W, Cpad, stream):
         X = _f(x, N * Cc * H * W).reshape(N, Cc, H, W)

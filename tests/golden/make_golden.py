@@ -213,6 +213,69 @@ def mano_fixture():
     print('wrote', path, os.path.getsize(path), 'bytes,', len(store), 'arrays')
 
 
+def loss_fixture():
+    """Reference training loss (core/Loss.py: GraphLoss + calc_loss_GCN) on seeded predictions / labels, with the
+    gradients with respect to every prediction tensor, for epoch < NORM_EPOCH (edge term off) and >= (on)."""
+    import pickle
+    import core.Loss as RefLoss                                     # reference (needs utils.manoutils -> cv2/yacs stubs)
+    from utils.config import load_cfg
+    tmp = tempfile.mkdtemp()
+    up = os.path.join(tmp, 'upsample.pkl')
+    with open(up, 'wb') as f:
+        pickle.dump(assets.synthetic_upsample_weight(), f)
+    RefLoss.get_upsample_path = lambda: up                          # misc/upsample.pkl is not in the checkout
+    cfg = load_cfg(os.path.join(ref_stubs.REF, 'utils', 'defaults.yaml'))
+    from models.model_zoo import GCN_vert_convert
+    store = {}
+    B = 3
+    g = torch.Generator().manual_seed(123)
+    mano = {s: assets.synthetic_mano_dict(s) for s in ('left', 'right')}
+    conv, gl = {}, {}
+    for s in ('left', 'right'):
+        gd = assets.load_graph_dict(s)
+        conv[s] = GCN_vert_convert(vertex_num=778, graph_perm_reverse=gd['graph_perm_reverse'], graph_perm=gd['graph_perm'])
+        J = torch.from_numpy(np.asarray(mano[s]['J_regressor'].todense(), np.float32))
+        gl[s] = RefLoss.GraphLoss(J, np.asarray(mano[s]['f']), level=4, device='cpu')
+    t = {}
+    for s in ('left', 'right'):
+        t['v3d_gt_' + s] = 0.05 * torch.randn(B, 778, 3, generator=g)
+        t['v2d_gt_' + s] = 256 * torch.rand(B, 778, 2, generator=g)
+        t['v3d_' + s] = (t['v3d_gt_' + s] + 0.02 * torch.randn(B, 778, 3, generator=g)).requires_grad_(True)
+        t['v2d_' + s] = (t['v2d_gt_' + s] + 8 * torch.randn(B, 778, 2, generator=g)).requires_grad_(True)
+        t['c3d_' + s] = (0.05 * torch.randn(B, 252, 3, generator=g)).requires_grad_(True)
+        t['c2d_' + s] = (256 * torch.rand(B, 252, 2, generator=g)).requires_grad_(True)
+    # a few large residuals so that both SmoothL1 branches are exercised
+    with torch.no_grad():
+        t['v3d_left'][0, :5] += 3.0
+        t['c3d_right'][1, :3] -= 2.5
+    t['root_rel'] = 0.05 * torch.randn(B, 3, generator=g)
+    for k, v in t.items():
+        store['in/' + k] = v.detach().numpy()
+    for epoch in (0, 60):
+        for v in t.values():
+            if v.requires_grad:
+                v.grad = None
+        result = {'verts3d': {s: t['v3d_' + s] for s in ('left', 'right')}, 'verts2d': {s: t['v2d_' + s] for s in ('left', 'right')}}
+        hd = [{'verts3d': {s: t['c3d_' + s] for s in ('left', 'right')}, 'verts2d': {s: t['c2d_' + s] for s in ('left', 'right')}}]
+        total, _, mano_d, coarse_d = RefLoss.calc_loss_GCN(
+            cfg, epoch, gl['left'], gl['right'], conv['left'], conv['right'], result, None, hd, None, None, None, None,
+            t['v2d_gt_left'], None, t['v2d_gt_right'], None, t['v3d_gt_left'], torch.zeros(B, 21, 3),
+            t['v3d_gt_right'], torch.zeros(B, 21, 3), t['root_rel'], 256)
+        total.backward()
+        key = 'e%d/' % epoch
+        store[key + 'total'] = np.float64(total.item())
+        for k in ('vert2d_loss', 'vert3d_loss', 'joint_loss', 'norm_loss', 'edge_loss'):
+            store[key + k] = np.float64(mano_d[k].item())
+        store[key + 'c3d_loss'] = np.float64(coarse_d['v3d_loss'][0].item())
+        store[key + 'c2d_loss'] = np.float64(coarse_d['v2d_loss'][0].item())
+        for k, v in t.items():
+            if v.requires_grad:
+                store[key + 'grad_' + k] = v.grad.numpy().copy()
+    path = os.path.join(HERE, 'loss.npz')
+    np.savez_compressed(path, **store)
+    print('wrote', path, os.path.getsize(path), 'bytes,', len(store), 'arrays')
+
+
 def keys_fixture():
     """Reference state_dict schema (key -> shape) for the ResNet50 and HRNet-W32 variants."""
     import json
@@ -232,7 +295,9 @@ def zlibseed(s):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['eval', 'train', 'mano', 'keys', 'hrnet']
+    which = sys.argv[1:] or ['eval', 'train', 'mano', 'keys', 'hrnet', 'loss']
+    if 'loss' in which:
+        loss_fixture()
     if 'hrnet' in which:
         net_fixture('eval', 'hrnet32')
         net_fixture('train', 'hrnet32')

@@ -97,3 +97,35 @@ def _unflatten(f):
             {'scale': {s: f['params.scale.' + s] for s in sides}, 'trans2d': {s: f['params.trans2d.' + s] for s in sides}},
             [{'verts3d': {s: f['hand0.verts3d.' + s] for s in sides}, 'verts2d': {s: f['hand0.verts2d.' + s] for s in sides}}],
             {'hms': f['other.hms'], 'mask': f['other.mask'], 'dense': f['other.dense']})
+
+
+@pytest.mark.parametrize('epoch', [0, 60])
+def test_fused_loss_host_logic_matches_reference_golden(epoch):
+    """Host side of the fused mesh loss (topology tables, weights, autograd plumbing) with the kernel emulated, against
+    the values and gradients of the reference's own core/Loss.py (tests/golden/loss.npz)."""
+    import os
+    from test_oracle_golden import _loss_inputs, GOLDEN
+    from renderih_amd.loss import FusedMeshLoss, calc_loss_GCN_fused
+    z = np.load(os.path.join(GOLDEN, 'loss.npz'))
+    t, conv, gl = _loss_inputs(z)
+    preds = ['v3d_left', 'v3d_right', 'v2d_left', 'v2d_right', 'c3d_left', 'c3d_right', 'c2d_left', 'c2d_right']
+    for k in preds:
+        t[k].requires_grad_(True)
+    fused = FusedMeshLoss(gl['left'], gl['right'], conv['left'], conv['right'])
+    result = {'verts3d': {s: t['v3d_' + s] for s in ('left', 'right')}, 'verts2d': {s: t['v2d_' + s] for s in ('left', 'right')}}
+    hd = [{'verts3d': {s: t['c3d_' + s] for s in ('left', 'right')}, 'verts2d': {s: t['c2d_' + s] for s in ('left', 'right')}}]
+    import renderih_amd.ops as ops_mod
+    orig = ops_mod._stream
+    ops_mod._stream = lambda: 0
+    try:
+        total, mano = calc_loss_GCN_fused(fused, epoch, result, None, hd, None, t['v2d_gt_left'], t['v2d_gt_right'],
+                                          t['v3d_gt_left'], t['v3d_gt_right'], t['root_rel'])
+        total.backward()
+    finally:
+        ops_mod._stream = orig
+    key = 'e%d/' % epoch
+    assert abs(total.item() - float(z[key + 'total'])) <= 1e-5 * abs(float(z[key + 'total']))
+    for k in ('vert2d_loss', 'vert3d_loss', 'joint_loss', 'norm_loss', 'edge_loss'):
+        assert abs(mano[k].item() - float(z[key + k])) <= 1e-5 * abs(float(z[key + k])) + 1e-12, k
+    for k in preds:
+        assert_close(t[k].grad, torch.from_numpy(z[key + 'grad_' + k]), 1e-4, 1e-6, 'grad ' + k)

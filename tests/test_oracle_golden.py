@@ -87,3 +87,40 @@ def test_mano_oracle_matches_reference(side):
         for nm, t in (('root', root), ('pose', pose), ('shape', shape), ('trans', trans), ('scale', scale)):
             if t is not None:
                 testing.assert_close(t.grad, torch.from_numpy(z[key + 'grad_' + nm]), 1e-4, 1e-5, key + 'grad_' + nm)
+
+
+def _loss_inputs(z, device='cpu'):
+    from renderih_amd.decoder import GCN_vert_convert
+    from renderih_amd.loss import GraphLoss
+    t = {k[3:]: torch.from_numpy(z[k]).to(device) for k in z.files if k.startswith('in/')}
+    conv, gl = {}, {}
+    for s in ('left', 'right'):
+        gd = assets.load_graph_dict(s)
+        md = assets.synthetic_mano_dict(s)
+        conv[s] = GCN_vert_convert(vertex_num=778, graph_perm_reverse=gd['graph_perm_reverse'], graph_perm=gd['graph_perm'])
+        J = torch.from_numpy(np.asarray(md['J_regressor'].todense(), np.float32))
+        gl[s] = GraphLoss(J, np.asarray(md['f']), level=4, device=device)
+    return t, conv, gl
+
+
+@pytest.mark.parametrize('epoch', [0, 60])
+def test_loss_mirror_matches_reference(epoch):
+    """renderih_amd/loss.py (torch mirror of core/Loss.py, and the checker of the fused HIP loss) against values and
+    gradients the reference's own GraphLoss / calc_loss_GCN produced (tests/golden/make_golden.py loss)."""
+    from renderih_amd.loss import calc_loss_GCN
+    z = np.load(os.path.join(GOLDEN, 'loss.npz'))
+    t, conv, gl = _loss_inputs(z)
+    preds = ['v3d_left', 'v3d_right', 'v2d_left', 'v2d_right', 'c3d_left', 'c3d_right', 'c2d_left', 'c2d_right']
+    for k in preds:
+        t[k].requires_grad_(True)
+    result = {'verts3d': {s: t['v3d_' + s] for s in ('left', 'right')}, 'verts2d': {s: t['v2d_' + s] for s in ('left', 'right')}}
+    hd = [{'verts3d': {s: t['c3d_' + s] for s in ('left', 'right')}, 'verts2d': {s: t['c2d_' + s] for s in ('left', 'right')}}]
+    total, mano = calc_loss_GCN(None, epoch, gl['left'], gl['right'], conv['left'], conv['right'], result, None, hd, None,
+                                t['v2d_gt_left'], t['v2d_gt_right'], t['v3d_gt_left'], t['v3d_gt_right'], t['root_rel'], 256)
+    total.backward()
+    key = 'e%d/' % epoch
+    assert abs(total.item() - float(z[key + 'total'])) <= 1e-5 * abs(float(z[key + 'total']))
+    for k in ('vert2d_loss', 'vert3d_loss', 'joint_loss', 'norm_loss', 'edge_loss'):
+        assert abs(mano[k].item() - float(z[key + k])) <= 1e-5 * abs(float(z[key + k])) + 1e-12, k
+    for k in preds:
+        testing.assert_close(t[k].grad, torch.from_numpy(z[key + 'grad_' + k]), 1e-4, 1e-6, 'grad ' + k)

@@ -7,7 +7,7 @@ python -c "import torch;print(torch.__version__, torch.cuda.is_available(), torc
 rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6 >> gpurun_out/env.log
 nproc >> gpurun_out/env.log; lscpu | grep "Model name" >> gpurun_out/env.log
 if [ "${SKIP_TESTS}" != "1" ]; then
-timeout ${T_TEST:-900} python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider ${PYTEST_ARGS} > gpurun_out/pytest_gpu.log 2>&1
+timeout ${T_TEST:-900} python -m pytest ${PYTEST_ARGS:-tests} -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
 tail -5 gpurun_out/pytest_gpu.log
 fi
