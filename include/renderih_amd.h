@@ -159,11 +159,13 @@ int rih_bn_bwd(const float* dy, const float* x, const float* y, const float* mea
 /* y = act(LayerNorm(x (+ x2)) * g + b); saves mean/rstd per row   (nn.LayerNorm eps=1e-6, gcn.py:91-97 ...) */
 int rih_layernorm_fwd(const float* x, const float* x2, const float* g, const float* b, float* y, float* mean,
                       float* rstd, int rows, int D, float eps, int relu, void* stream);
-/* dx (= gradient wrt x and x2), dg/db accumulated via ws (>= 2*nblk*D floats, nblk = rih_ln_nblk(rows)) */
+/* dx (= gradient wrt x and x2), dg/db accumulated via ws (>= 2*nblk*D floats, nblk = rih_ln_nblk(rows)).
+ * dres (may be NULL): [rows][D] added to dx -- the gradient arriving over a skip connection around the norm
+ * (x + f(LN(x)), self_attn.py:26-33, 84-85), so that autograd needs no separate accumulation pass. */
 int rih_ln_nblk(int rows);
 int rih_layernorm_bwd(const float* dy, const float* x, const float* x2, const float* y, const float* g,
-                      const float* mean, const float* rstd, float* dx, float* dg, float* db, int rows, int D,
-                      int relu, float* ws, void* stream);
+                      const float* mean, const float* rstd, const float* dres, float* dx, float* dg, float* db, int rows,
+                      int D, int relu, float* ws, void* stream);
 /* softmax over the last dim of [rows][ld] (first `cols` entries), optional inverted dropout with a
  * counter-based hash RNG: P (pre-dropout probabilities) and Pd (post-dropout, may alias P when p==0).
  * Every dropout entry point takes the stream id of the mask as `seed` plus an optional DEVICE word `seed_dev` (may be

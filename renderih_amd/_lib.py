@@ -69,7 +69,7 @@ SIGNATURES = {
     'rih_bn_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, C.c_void_p]),
     'rih_layernorm_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_i, C.c_void_p]),
     'rih_ln_nblk': (c_i, [c_i]),
-    'rih_layernorm_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, C.c_void_p]),
+    'rih_layernorm_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, C.c_void_p]),
     'rih_softmax_fwd': (c_i, [c_f, c_f, c_f, c_l, c_i, c_i, c_fl, c_u64, C.c_void_p, C.c_void_p]),
     'rih_softmax_bwd': (c_i, [c_f, c_f, c_l, c_i, c_i, c_fl, c_u64, C.c_void_p, c_fl, C.c_void_p]),
     'rih_add_dropout': (c_i, [c_f, c_f, c_f, c_l, c_i, c_i, c_fl, c_u64, C.c_void_p, C.c_void_p]),

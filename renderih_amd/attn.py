@@ -147,7 +147,8 @@ class MLP_res_block(nn.Module):
         self.dropout2 = nn.Dropout(dropout)
 
     def forward(self, x, dc):
-        h = _lin(self.fc1, _ln(self.layer_norm, x), relu=True)
+        y, x = ops.layernorm_skip(x, self.layer_norm.weight, self.layer_norm.bias, eps=self.layer_norm.eps)
+        h = _lin(self.fc1, y, relu=True)
         if dc.p > 0:
             h = _drop_add(dc, None, h)
         return _lin_drop_res(dc, self.fc2, h, x)
@@ -174,7 +175,7 @@ class SelfAttn(nn.Module):
         self.ff = MLP_res_block(f_dim, hid_dim, dropout)
 
     def forward(self, x, dc):
-        y = _ln(self.layer_norm, x)
+        y, x = ops.layernorm_skip(x, self.layer_norm.weight, self.layer_norm.bias, eps=self.layer_norm.eps)
         # one fused QKV projection: the three nn.Linear parameters are stacked (a copy) into a [3D, D] operand
         w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight], 0)
         b = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias], 0)

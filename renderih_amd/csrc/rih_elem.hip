@@ -601,7 +601,8 @@ __global__ __launch_bounds__(TPB) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ x2, const float* __restrict__ y,
                                                             const float* __restrict__ g,
                                                             const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, float* __restrict__ dx,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ dres, float* __restrict__ dx,
                                                             float* __restrict__ ws, int rows, int D, int relu) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -638,7 +639,11 @@ __global__ __launch_bounds__(TPB) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < LN_MAXPER; ++i) {
             const int e = lane + 64 * i;
-            if (i < nper && e < D) dx[(long long)r * D + e] = rs * (gd[i] - c1 - xh[i] * c2);
+            if (i < nper && e < D) {
+                float v = rs * (gd[i] - c1 - xh[i] * c2);
+                if (dres != nullptr) v += dres[(long long)r * D + e];      // gradient of a skip connection around the norm
+                dx[(long long)r * D + e] = v;
+            }
         }
     }
     // reduce dg/db over the 4 waves of the block, write ws[blk][{dg,db}][D]
@@ -1040,14 +1045,14 @@ extern "C" int rih_layernorm_fwd(const float* x, const float* x2, const float* g
     LAUNCH_RET();
 }
 extern "C" int rih_layernorm_bwd(const float* dy, const float* x, const float* x2, const float* y, const float* g,
-                                 const float* mean, const float* rstd, float* dx, float* dg, float* db, int rows, int D,
-                                 int relu, float* ws, void* stream) {
+                                 const float* mean, const float* rstd, const float* dres, float* dx, float* dg, float* db,
+                                 int rows, int D, int relu, float* ws, void* stream) {
     if (!dy || !x || !g || !mean || !rstd || !dx || !dg || !db || !ws) return RIH_EINVAL;
     if (relu && !y) return RIH_EINVAL;
     if (rows < 1 || D < 1 || D > 64 * LN_MAXPER) return RIH_EINVAL;
     const int nblk = rih_ln_nblk(rows);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(TPB), 0, STREAM, dy, x, x2, y, g, mean, rstd, dx, ws, rows,
-                       D, relu);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(TPB), 0, STREAM, dy, x, x2, y, g, mean, rstd, dres, dx, ws,
+                       rows, D, relu);
     hipLaunchKernelGGL(ln_param_final_kernel, dim3((D + 3) / 4), dim3(TPB), 0, STREAM, ws, D, nblk, dg, db);
     LAUNCH_RET();
 }

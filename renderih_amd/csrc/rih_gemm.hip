@@ -508,14 +508,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * WN + j * 32 + l31;
             const float bv = (!raw && p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+            float rv[16];       // residual operand: all 16 loads of the tile in flight before the first store
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                rv[r] = (!raw && p.R != nullptr && m < p.M && n < p.N) ? p.R[(long long)m * p.ldr + n] : 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (m < p.M && n < p.N) {
                     float v = acc[i][j][r];
                     if (!raw) {
-                        v = v * p.alpha + bv;
-                        if (p.R != nullptr) v += p.R[(long long)m * p.ldr + n];
+                        v = v * p.alpha + bv + rv[r];
                         if (p.relu) v = fmaxf(v, 0.f);
                     }
                     C[c_row(p, m) * p.ldc + n] = v;
@@ -897,14 +902,19 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * WN + j * 32 + l31;
             const float bv = (!raw && p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+            float rv[16];       // residual operand: all 16 loads of the tile in flight before the first store
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                rv[r] = (!raw && p.R != nullptr && m < p.M && n < p.N) ? p.R[(long long)m * p.ldr + n] : 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (m < p.M && n < p.N) {
                     float v = acc[i][j][r];
                     if (!raw) {
-                        v = v * p.alpha + bv;
-                        if (p.R != nullptr) v += p.R[(long long)m * p.ldr + n];
+                        v = v * p.alpha + bv + rv[r];
                         if (p.relu) v = fmaxf(v, 0.f);
                     }
                     C[c_row(p, m) * p.ldc + n] = v;
@@ -1273,14 +1283,19 @@ __global__ __launch_bounds__(256, 1) void gemm_split256_kernel(const GemmArgs p)
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * WN + j * 32 + l31;
             const float bv_ = (!raw && p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+            float rv[16];       // residual operand: all 16 loads of the tile in flight before the first store
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                rv[r] = (!raw && p.R != nullptr && m < p.M && n < p.N) ? p.R[(long long)m * p.ldr + n] : 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (m < p.M && n < p.N) {
                     float v = acc[i][j][r];
                     if (!raw) {
-                        v = v * p.alpha + bv_;
-                        if (p.R != nullptr) v += p.R[(long long)m * p.ldr + n];
+                        v = v * p.alpha + bv_ + rv[r];
                         if (p.relu) v = fmaxf(v, 0.f);
                     }
                     C[c_row(p, m) * p.ldc + n] = v;

@@ -54,11 +54,14 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        out = bn_act(self.bn1, conv(self.conv1, x), relu=True)
+        # the skip path is fed from conv1's second output (an alias of x): its gradient is added inside conv1's
+        # data-gradient GEMM instead of by a separate pass over the activation (ops.Conv2dFn)
+        c1 = self.conv1
+        out, idt = ops.conv2d_skip(x, c1.weight, c1.bias, stride=c1.stride[0], pad=c1.padding[0])
+        out = bn_act(self.bn1, out, relu=True)
         out = bn_act(self.bn2, conv(self.conv2, out), relu=True)
-        idt = x
         if self.downsample is not None:
-            idt = bn_act(self.downsample[1], conv(self.downsample[0], x))
+            idt = bn_act(self.downsample[1], conv(self.downsample[0], idt))
         return bn_act(self.bn3, conv(self.conv3, out), residual=idt, relu=True)
 
 

@@ -51,8 +51,11 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        out = bn_act(self.bn1, conv(self.conv1, x), relu=True)
-        idt = x if self.downsample is None else bn_act(self.downsample[1], conv(self.downsample[0], x))
+        c1 = self.conv1
+        out, idt = ops.conv2d_skip(x, c1.weight, c1.bias, stride=c1.stride[0], pad=c1.padding[0])
+        out = bn_act(self.bn1, out, relu=True)
+        if self.downsample is not None:
+            idt = bn_act(self.downsample[1], conv(self.downsample[0], idt))
         return bn_act(self.bn2, conv(self.conv2, out), residual=idt, relu=True)
 
 

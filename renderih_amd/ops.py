@@ -198,7 +198,10 @@ class Conv2dFn(torch.autograd.Function):
     x: [N,H,W,Cx] (Cx >= Cin, extra channels must be zero), w: [Cout,Cin,KH,KW] (the nn.Conv2d parameter)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, relu):
+    def forward(ctx, x, w, bias, stride, pad, relu, skip=False):
+        """skip=True: also return x itself (an alias).  A residual block feeds its skip path from that second output;
+        the gradient arriving there is then added inside the data-gradient GEMM's epilogue (residual operand R)
+        instead of by an autograd accumulation pass over the whole activation."""
         _chk(x, w, bias)
         x = _c(x)
         w = _c(w)
@@ -218,12 +221,16 @@ class Conv2dFn(torch.autograd.Function):
             gemm(x, wp, y, M, Cout, K, Cx, Cout, Cout, a_mode=0, b_mode=0, bias=bias, relu=relu, geom=geom)
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.cfg = (stride, pad, relu, bias is not None)
+        if skip:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, w, y = ctx.saved_tensors
         stride, pad, relu, has_bias = ctx.cfg
+        if dskip is not None:
+            dskip = _c(dskip)
         N, H, W_, Cx = x.shape
         Cout, Cin, KH, KW = w.shape
         dy = _c(dy)
@@ -262,17 +269,19 @@ class Conv2dFn(torch.autograd.Function):
                                                        stride, Th, Tw, _stream()), 'rih_pack_conv_weight_sub')
                 gemm(dy, wd, dx, N * Hc * Wc, Cx, Th * Tw * Cout, Cout, Cx, Cx, a_mode=0, b_mode=0, geom=geom,
                      cstride=(stride, oh, ow, H, W_))
+            if dskip is not None:
+                dx = dx + dskip
         elif ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             Mx = N * H * W_
             geom = (Ho, Wo, Cout, H, W_, KH, KW, 1, stride, KH - 1 - pad, KW - 1 - pad)
             if KH * KW == 1 and Cx == Cin:
-                gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cin, Cx, a_mode=0, b_mode=0, geom=geom)
+                gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cin, Cx, a_mode=0, b_mode=0, geom=geom, R=dskip, ldr=Cx)
             else:
                 wd = torch.empty((KH * KW * Cout, Cx), device=x.device, dtype=torch.float32)
                 check(lib.rih_pack_conv_weight(w.data_ptr(), wd.data_ptr(), Cout, Cin, KH, KW, Cx, 1, _stream()),
                       'rih_pack_conv_weight')
-                gemm(dy, wd, dx, Mx, Cx, KH * KW * Cout, Cout, Cx, Cx, a_mode=0, b_mode=0, geom=geom)
+                gemm(dy, wd, dx, Mx, Cx, KH * KW * Cout, Cout, Cx, Cx, a_mode=0, b_mode=0, geom=geom, R=dskip, ldr=Cx)
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
@@ -282,11 +291,18 @@ class Conv2dFn(torch.autograd.Function):
             _wgrad(x, dy, dw, M, KH * KW * Cx, Cout, Cx, Cout, geom, Cx, KH * KW, Cin, db=db)
         elif want_db:
             db = colsum(dy, M, Cout)
-        return dx, dw, db, None, None, None
+        if dx is None and dskip is not None:
+            dx = dskip
+        return dx, dw, db, None, None, None, None
 
 
 def conv2d(x, w, bias=None, stride=1, pad=0, relu=False):
-    return Conv2dFn.apply(x, w, bias, stride, pad, relu)
+    return Conv2dFn.apply(x, w, bias, stride, pad, relu, False)
+
+
+def conv2d_skip(x, w, bias=None, stride=1, pad=0, relu=False):
+    """(conv(x), x) -- see Conv2dFn.forward: use the second value for the block's skip path."""
+    return Conv2dFn.apply(x, w, bias, stride, pad, relu, True)
 
 
 class LinearFn(torch.autograd.Function):
@@ -559,10 +575,13 @@ def nearest_up_add(x, acc, factor):
 
 # --------------------------------------------------------------------------------------------- row-wise ops
 class LayerNormFn(torch.autograd.Function):
-    """y = act(LayerNorm(x (+ x2))); the optional second input fuses the residual add in front of the norm."""
+    """y = act(LayerNorm(x (+ x2))); the optional second input fuses the residual add in front of the norm.
+    skip=True additionally returns x itself (an alias) as a second output: the caller uses it for the skip connection
+    around the normalised branch (x + f(LN(x))), and the gradient arriving there is added to dx inside the backward
+    kernel instead of by an autograd accumulation pass."""
 
     @staticmethod
-    def forward(ctx, x, x2, g, b, eps, relu):
+    def forward(ctx, x, x2, g, b, eps, relu, skip):
         _chk(x, x2, g, b)
         x = _c(x)
         if x2 is not None:
@@ -576,12 +595,17 @@ class LayerNormFn(torch.autograd.Function):
                                      rstd.data_ptr(), rows, D, eps, 1 if relu else 0, _stream()), 'rih_layernorm_fwd')
         ctx.save_for_backward(x, x2, y if relu else None, g, mean, rstd)
         ctx.relu = relu
+        ctx.skip = skip
+        if skip:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, x2, y, g, mean, rstd = ctx.saved_tensors
         dy = _c(dy)
+        if dskip is not None:
+            dskip = _c(dskip)
         D = x.shape[-1]
         rows = x.numel() // D
         lib = _L()
@@ -590,13 +614,18 @@ class LayerNormFn(torch.autograd.Function):
         db = torch.empty_like(g)
         ws = torch.empty((2 * lib.rih_ln_nblk(rows) * D,), device=x.device, dtype=torch.float32)
         check(lib.rih_layernorm_bwd(dy.data_ptr(), x.data_ptr(), _p(x2), _p(y), g.data_ptr(), mean.data_ptr(),
-                                    rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, D,
+                                    rstd.data_ptr(), _p(dskip), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, D,
                                     1 if ctx.relu else 0, ws.data_ptr(), _stream()), 'rih_layernorm_bwd')
-        return dx, (dx if x2 is not None else None), dg, db, None, None
+        return dx, (dx if x2 is not None else None), dg, db, None, None, None
 
 
 def layernorm(x, g, b, eps=1e-6, x2=None, relu=False):
-    return LayerNormFn.apply(x, x2, g, b, eps, relu)
+    return LayerNormFn.apply(x, x2, g, b, eps, relu, False)
+
+
+def layernorm_skip(x, g, b, eps=1e-6):
+    """(LayerNorm(x), x) -- see LayerNormFn: use the second value for the skip connection around the branch."""
+    return LayerNormFn.apply(x, None, g, b, eps, False, True)
 
 
 def _attn_forward(q, q_ld, k, v, kv_ld, B, Sq, Sk, D, heads, drop_p, seed, device):

@@ -382,7 +382,7 @@ class EmulatedLib:
         _f(rstd, rows)[:] = rs.ravel()
         return 0
 
-    def rih_layernorm_bwd(self, dy, x, x2, y, g, mean, rstd, dx, dg, db, rows, D, relu, ws, stream):
+    def rih_layernorm_bwd(self, dy, x, x2, y, g, mean, rstd, dres, dx, dg, db, rows, D, relu, ws, stream):
         Dy = _f(dy, rows * D).reshape(rows, D).copy()
         if relu:
             Dy[_f(y, rows * D).reshape(rows, D) <= 0] = 0
@@ -393,7 +393,10 @@ class EmulatedLib:
         xh = (X - m) * rs
         gd = Dy * _f(g, D)
         c1, c2 = gd.mean(1, keepdims=True), (gd * xh).mean(1, keepdims=True)
-        _f(dx, rows * D)[:] = (rs * (gd - c1 - xh * c2)).ravel()
+        out = rs * (gd - c1 - xh * c2)
+        if dres:
+            out = out + _f(dres, rows * D).reshape(rows, D)
+        _f(dx, rows * D)[:] = out.ravel()
         _f(dg, D)[:] = (Dy * xh).sum(0)
         _f(db, D)[:] = Dy.sum(0)
         return 0
