@@ -1316,7 +1316,7 @@ int launch_split256(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 
     return (int)hipGetLastError();
 }
 
-// One-launch split-K reduction for weight gradients: each 256-thread block sums a 32x32 tile of the S partial slabs
+// One-launch split-K reduction for weight gradients: each 256-thread block sums an 8x32 tile of the S partial slabs
 // P[s][Mp][N] in a fixed order (deterministic) and writes it transposed into the parameter layout through LDS; blocks
 // past the tile range sum slab row M (the all-ones row of the A operand = column sums of dy) into the bias gradient.
 __global__ __launch_bounds__(256) void splitk_reduce_fused_kernel(const float* __restrict__ P, int S, int Mp, int M, int N,
@@ -1335,43 +1335,36 @@ __global__ __launch_bounds__(256) void splitk_reduce_fused_kernel(const float* _
         }
         return;
     }
-    __shared__ float tile[32][33];
+    // 8 (m) x 32 (n) tile per block, one output element per thread: four times the blocks of a 32x32 tile, and the
+    // S-long reduction of a thread is a single stream of independent loads (the kernel is latency-bound: decoder
+    // weight gradients are 64x64 .. 512x768 outputs summed over 30-130 slabs)
+    __shared__ float tile[8][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int tilesN = (N + 31) / 32;
-    const int m0 = (blockIdx.x / tilesN) * 32, n0 = (blockIdx.x % tilesN) * 32;
-    float acc[4][2];
-    const float* q[4];
-    bool ok[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + ty + 8 * i, n = n0 + tx;
-        ok[i] = (m < M && n < N);
-        q[i] = P + (ok[i] ? (long long)m * N + n : 0);
-        acc[i][0] = acc[i][1] = 0.f;
-    }
-    int k = 0;
-    for (; k + 1 < S; k += 2) {         // (a 4-way unroll was measured 4x slower: keep 8 loads in flight per lane)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[i][0] += q[i][(long long)k * slab];
-            acc[i][1] += q[i][(long long)(k + 1) * slab];
+    const int m0 = (blockIdx.x / tilesN) * 8, n0 = (blockIdx.x % tilesN) * 32;
+    {
+        const int m = m0 + ty, n = n0 + tx;
+        const bool ok = (m < M && n < N);
+        const float* q = P + (ok ? (long long)m * N + n : 0);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = 0;
+        for (; k + 3 < S; k += 4) {
+            a0 += q[(long long)k * slab];
+            a1 += q[(long long)(k + 1) * slab];
+            a2 += q[(long long)(k + 2) * slab];
+            a3 += q[(long long)(k + 3) * slab];
         }
+        for (; k < S; ++k) a0 += q[(long long)k * slab];
+        tile[ty][tx] = ok ? (a0 + a1) + (a2 + a3) : 0.f;
     }
-    if (k < S) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][0] += q[i][(long long)k * slab];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) tile[ty + 8 * i][tx] = ok[i] ? acc[i][0] + acc[i][1] : 0.f;
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + tx, n = n0 + ty + 8 * i;
+    {
+        const int m = m0 + (threadIdx.x & 7), n = n0 + (threadIdx.x >> 3);
         if (m < M && n < N) {
             const int tap = m / Cin, ci = m - tap * Cin;
             if (ci < CinValid) {
                 const long long o = ((long long)n * CinValid + ci) * taps + tap;
-                const float v = tile[tx][ty + 8 * i];
+                const float v = tile[threadIdx.x & 7][threadIdx.x >> 3];
                 dst[o] = accumulate ? dst[o] + v : v;
             }
         }
@@ -1543,7 +1536,7 @@ extern "C" int rih_splitk_reduce_bias(const float* P, int S, int Mp, int M, int 
                                       int CinValid, int accumulate, float* db, void* stream) {
     if (!P || !dst || S < 1 || M < 1 || Mp < M || N < 1 || Cin < 1 || taps < 1 || CinValid < 1) return RIH_EINVAL;
     if (db && Mp < M + 1) return RIH_EINVAL;
-    const long long tiles = (long long)((M + 31) / 32) * ((N + 31) / 32);
+    const long long tiles = (long long)((M + 7) / 8) * ((N + 31) / 32);
     const long long blocks = tiles + (db ? (N + 255) / 256 : 0);
     if (blocks > 0x7fffffffLL) return RIH_EINVAL;
     hipLaunchKernelGGL(splitk_reduce_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P, S, Mp, M,
