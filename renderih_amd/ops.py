@@ -59,6 +59,8 @@ def plan_gemm(M, N, K, batch=1, engine=None):
     t0 = _cdiv(M, 128) * _cdiv(N, 128) * batch
     t1 = _cdiv(M, 128) * _cdiv(N, 64) * batch
     if e == 1:
+        if K <= 256 and _cdiv(M, 64) * _cdiv(N, 64) * batch >= 512:
+            return 2, 1       # short reductions are bound by the output stream: more, smaller tiles in flight win
         if N > 64 and t0 >= 384:
             return 0, 1
         if t1 >= 384:
@@ -164,11 +166,12 @@ def _wgrad(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_val
     the A operand gets an all-ones row behind its Mrows rows, so the same GEMM also produces the column sums of dy."""
     Mp = Mrows + 4 if db is not None else Mrows
     # small weight matrices (decoder Linears, <= 4x4 tiles of 128): 64x64 tiles give 4x the resident slices per split
-    small = _cdiv(Mp, 128) * _cdiv(Ncols, 128) < 16
+    small = _cdiv(Mp, 128) * _cdiv(Ncols, 128) <= 4
     tile = 3 if Ncols <= 32 else (2 if (Ncols <= 64 or Mp <= 64 or (ENGINE == 1 and small)) else 0)
     bm, bn = _TILE_MN[tile]
     tiles = _cdiv(Mp, bm) * _cdiv(Ncols, bn)
-    target = 512 if (ENGINE == 1 and tile == 0) else 1024     # measured optimum of resident split-K slices
+    # measured optimum of resident split-K slices (tools/tile_sweep.py): ~512 workgroups, 256 for a single tile
+    target = (256 if tiles == 1 else 512) if ENGINE == 1 else 1024
     splitk = max(1, min(target // max(tiles, 1), _cdiv(Kpix, 128)))
     kchunk = _cdiv(_cdiv(Kpix, splitk), 32) * 32
     splitk = _cdiv(Kpix, kchunk)
