@@ -29,7 +29,8 @@ _PENDING_TRACKED = []
 
 def flush_batches_tracked():
     """`num_batches_tracked += 1` of every BatchNorm that ran since the last flush, as ONE multi-tensor launch
-    (65 one-element kernels per forward otherwise).  Called at the end of HandNET_GCN.forward."""
+    (65 one-element kernels per forward otherwise).  Called at the end of every encoder / mid-model forward (and of
+    HandNET_GCN.forward), so a sub-module used on its own keeps torch's BatchNorm bookkeeping too."""
     if _PENDING_TRACKED:
         torch._foreach_add_(list(_PENDING_TRACKED), 1)
         _PENDING_TRACKED.clear()
@@ -170,6 +171,7 @@ class ResNetSimple(nn.Module):
         out, dp_fmaps = self.dp_decoder(x1)
         mask = ops.nhwc_to_nchw(out, 0, self.handNum)
         dp = ops.nhwc_to_nchw(out, self.handNum, out.shape[-1])
+        flush_batches_tracked()
         return ops.nhwc_to_nchw(hms), mask, dp, [x1, x2, x3, x4], hms_fmaps, dp_fmaps
 
 
@@ -204,6 +206,7 @@ class resnet_mid(nn.Module):
             parts = [hms_fmaps[i], dp_fmaps[i]] + ([img_fmaps[i]] if i > 0 else [])
             x = torch.cat(parts, dim=-1)                     # channel concat = last dim in NHWC (pure copy)
             fmaps.append(bn_act(seq[2], conv(seq[0], x, relu=True)))
+        flush_batches_tracked()
         return gf, fmaps
 
 
@@ -244,6 +247,7 @@ class HRnet_encoder(nn.Module):
         out = self._head(self.dp_decoder, x)
         mask = ops.nhwc_to_nchw(out, 0, 1)[:, 0]                 # `out[:, 0]`: [B, 64, 64]  (encoder.py:235)
         dp = ops.nhwc_to_nchw(out, 1, out.shape[-1])
+        flush_batches_tracked()
         return ops.nhwc_to_nchw(hms), mask, dp, ys[::-1], None, None
 
 
@@ -280,6 +284,7 @@ class hrnet_mid(nn.Module):
             down = bn_act(ds[1], conv(ds[0], y), relu=True)
             y = ops.add_dropout(self.incre_modules[i + 1](fine_first[i + 1]), down)
         y = bn_act(self.final_layer[1], conv(self.final_layer[0], y), relu=True)
+        flush_batches_tracked()
         return ops.global_avgpool(y), fmaps
 
 
