@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $R/gpurun_out/pmc/traffic_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $R/gpurun_out/pmc/traffic_$c.log 2>&1
   f=$(find /tmp/pmc_$c -name "*counter_collection*.csv" | head -1)
   python - "$f" "$c" <<'PY' > $R/gpurun_out/pmc/traffic_$c.txt
 import csv, sys, collections
