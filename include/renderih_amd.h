@@ -85,6 +85,12 @@ typedef struct rih_gemm_desc {
      * Appending this row to a weight-gradient GEMM makes C(ones_row, n) = sum_k B(k, n), the bias gradient, so that
      * no separate column-sum pass over dy is needed (rih_splitk_reduce_bias picks the row up).  0 = off. */
     int32_t ones_row;
+    int32_t reserved0;   /* keeps the 64-bit fields below aligned; set 0 */
+    /* Per-nb1-slice strides (in floats) of bias and R.  With nb1 = 2 and sB1 / sBias1 = the distance between the left-
+     * and the right-hand parameter tensors, the two per-hand nn.Linear layers of the decoder
+     * (models/model_attn/DualGraph.py:83-89 runs them one after the other) execute as ONE launch on activations
+     * stacked [2][rows][K].  0 = bias / R shared by all slices. */
+    int64_t sBias1, sR1;
 } rih_gemm_desc;
 
 int rih_gemm(const rih_gemm_desc* d, void* stream);
@@ -99,6 +105,11 @@ int rih_splitk_reduce(float* P, int S, int M, int N, float* dst, int Cin, int ta
  * operand carries an all-ones row there (rih_gemm_desc.ones_row) -- is summed into the bias gradient db[N]. */
 int rih_splitk_reduce_bias(const float* P, int S, int Mp, int M, int N, float* dst, int Cin, int taps, int CinValid,
                            int accumulate, float* db, void* stream);
+/* nb independent reductions in one launch: slice b reads P + b*sP and writes dst + b*sDst, db + b*sDb (the split-K
+ * partials of an nb1-batched weight-gradient GEMM, e.g. the paired left/right-hand layers). */
+int rih_splitk_reduce_bias_batched(const float* P, int S, int Mp, int M, int N, float* dst, int Cin, int taps,
+                                   int CinValid, int accumulate, float* db, int nb, int64_t sP, int64_t sDst,
+                                   int64_t sDb, void* stream);
 
 /* Finish a forward split-K GEMM: C[m*ldc+n] = act(alpha * sum_s P[s][m][n] + bias[n] + R[m*ldr+n]). */
 int rih_splitk_finish(const float* P, int S, int M, int N, float* C, int ldc, const float* bias, const float* R,
@@ -166,6 +177,15 @@ int rih_ln_nblk(int rows);
 int rih_layernorm_bwd(const float* dy, const float* x, const float* x2, const float* y, const float* g,
                       const float* mean, const float* rstd, const float* dres, float* dx, float* dg, float* db, int rows,
                       int D, int relu, float* ws, void* stream);
+/* `groups` independent LayerNorms in one launch (the left- and the right-hand layer of DualGraph.py:83-89 on
+ * activations stacked [groups][rows][D]): group q uses the parameters g + q*sG, b + q*sB (distances in floats between
+ * the two layers' parameter tensors, may be negative) and, in the backward, writes dg + q*D, db + q*D; ws >= groups * 2*nblk*D floats. */
+int rih_layernorm_fwd_grouped(const float* x, const float* x2, const float* g, const float* b, float* y, float* mean,
+                              float* rstd, int groups, int rows, int D, int64_t sG, int64_t sB, float eps, int relu,
+                              void* stream);
+int rih_layernorm_bwd_grouped(const float* dy, const float* x, const float* x2, const float* y, const float* g,
+                              const float* mean, const float* rstd, const float* dres, float* dx, float* dg, float* db,
+                              int groups, int rows, int D, int64_t sG, int relu, float* ws, void* stream);
 /* softmax over the last dim of [rows][ld] (first `cols` entries), optional inverted dropout with a
  * counter-based hash RNG: P (pre-dropout probabilities) and Pd (post-dropout, may alias P when p==0).
  * Every dropout entry point takes the stream id of the mask as `seed` plus an optional DEVICE word `seed_dev` (may be

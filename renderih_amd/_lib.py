@@ -27,7 +27,8 @@ class GemmDesc(C.Structure):
                 ('H', C.c_int32), ('W', C.c_int32), ('Cin', C.c_int32), ('Ho', C.c_int32), ('Wo', C.c_int32),
                 ('KH', C.c_int32), ('KW', C.c_int32), ('strideA', C.c_int32), ('upS', C.c_int32),
                 ('padH', C.c_int32), ('padW', C.c_int32), ('tile', C.c_int32), ('engine', C.c_int32),
-                ('cS', C.c_int32), ('cOH', C.c_int32), ('cOW', C.c_int32), ('cH', C.c_int32), ('cW', C.c_int32), ('ones_row', C.c_int32)]
+                ('cS', C.c_int32), ('cOH', C.c_int32), ('cOW', C.c_int32), ('cH', C.c_int32), ('cW', C.c_int32), ('ones_row', C.c_int32),
+                ('reserved0', C.c_int32), ('sBias1', C.c_int64), ('sR1', C.c_int64)]
 
 
 class ManoModel(C.Structure):
@@ -46,6 +47,8 @@ class MeshTopo(C.Structure):
 SIGNATURES = {
     'rih_gemm': (c_i, [C.POINTER(GemmDesc), C.c_void_p]),
     'rih_splitk_reduce': (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_splitk_reduce_bias_batched': (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_l, c_l, c_l,
+                                             C.c_void_p]),
     'rih_splitk_reduce_bias': (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f, C.c_void_p]),
     'rih_splitk_finish': (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_fl, c_i, C.c_void_p]),
     'rih_pack_conv_weight': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
@@ -69,6 +72,8 @@ SIGNATURES = {
     'rih_bn_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, C.c_void_p]),
     'rih_layernorm_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_i, C.c_void_p]),
     'rih_ln_nblk': (c_i, [c_i]),
+    'rih_layernorm_fwd_grouped': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_l, c_l, c_fl, c_i, C.c_void_p]),
+    'rih_layernorm_bwd_grouped': (c_i, [c_f] * 11 + [c_i, c_i, c_i, c_l, c_i, c_f, C.c_void_p]),
     'rih_layernorm_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, C.c_void_p]),
     'rih_softmax_fwd': (c_i, [c_f, c_f, c_f, c_l, c_i, c_i, c_fl, c_u64, C.c_void_p, C.c_void_p]),
     'rih_softmax_bwd': (c_i, [c_f, c_f, c_l, c_i, c_i, c_fl, c_u64, C.c_void_p, c_fl, C.c_void_p]),

@@ -60,6 +60,22 @@ def _lin_drop_res(dc, m, x, res):
     return _lin(m, x, residual=res)
 
 
+def _lin_pair(mL, mR, X, residual=None, relu=False):
+    return ops.linear_pair(X, mL, mR, residual=residual, relu=relu)
+
+
+def _lin_drop_res_pair(dc, mL, mR, X, res):
+    if dc.p > 0:
+        return _drop_add(dc, res, _lin_pair(mL, mR, X))
+    return _lin_pair(mL, mR, X, residual=res)
+
+
+# ---- hands-stacked execution -------------------------------------------------------------------------------------
+# `forward_pair(left_module, right_module, X, ...)` below run the left- and the right-hand instance of a block on
+# X [2, B, V, D] (slice 0 = left) with one launch per layer pair instead of one per hand; the arithmetic per hand is
+# that of `forward`.  DualGraph.forward takes this route when ops.PAIR_HANDS is set.
+
+
 class GraphCSR:
     """Device CSR of a graph Laplacian and of its transpose (for the backward), fp32 like the reference's dense L."""
 
@@ -94,6 +110,7 @@ class GCN_ResBlock(nn.Module):
             dense = torch.from_numpy(np.asarray(sp.csr_matrix(graph_L).astype(np.float32).todense())).float()
         self.register_buffer('graph_L', dense, persistent=False)     # same non-persistent buffer as the reference
         self._csr = GraphCSR(dense.numpy())
+        self._pair_cache = {}
         self.graph_k = graph_k
         self.in_dim = in_dim
         self.norm1 = nn.LayerNorm(in_dim, eps=1e-6)                  # dead in the reference forward (N2); kept for keys
@@ -116,6 +133,37 @@ class GCN_ResBlock(nn.Module):
         return _ln(self.norm3, _lin(self.fc2, x1c, residual=x2), relu=relu_out)
 
 
+    @staticmethod
+    def forward_pair(L, R, X, dc, relu_out):
+        _, B, V, _ = X.shape
+        if L._same_graph(R):
+            csr, csr_t = L._csr.on(X.device)
+
+            def cheb(t):
+                return ops.cheby_features(t.reshape(2 * B, V, t.shape[-1]), csr, csr_t).view(2, B, V, -1)
+        else:           # user-supplied graphs that differ between the hands: per-hand gathers, stacked again
+            cl, cr = L._csr.on(X.device), R._csr.on(X.device)
+
+            def cheb(t):
+                return torch.stack([ops.cheby_features(t[0], *cl), ops.cheby_features(t[1], *cr)])
+        x1 = _lin_pair(L.fc1, R.fc1, cheb(X))
+        x1 = ops.layernorm_pair(x1, L.norm2, R.norm2, relu=True)
+        x1c = cheb(x1)
+        if dc.p > 0:
+            x1 = _drop_add(dc, None, _lin_pair(L.fc2, R.fc2, x1c))
+            return ops.layernorm_pair(x1, L.norm3, R.norm3, x2=_lin_pair(L.shortcut, R.shortcut, X), relu=relu_out)
+        x2 = _lin_pair(L.shortcut, R.shortcut, X)
+        return ops.layernorm_pair(_lin_pair(L.fc2, R.fc2, x1c, residual=x2), L.norm3, R.norm3, relu=relu_out)
+
+    def _same_graph(self, other):
+        key = ('same', id(other))
+        if self._pair_cache.get('key') != key:
+            self._pair_cache['key'] = key
+            self._pair_cache['same'] = bool(self.graph_L.shape == other.graph_L.shape and
+                                            torch.equal(self.graph_L.cpu(), other.graph_L.cpu()))
+        return self._pair_cache['same']
+
+
 class GraphLayer(nn.Module):
     """models/model_attn/gcn.py:113-138."""
 
@@ -135,6 +183,14 @@ class GraphLayer(nn.Module):
         return x
 
 
+    @staticmethod
+    def forward_pair(L, R, X, dc):
+        n = len(L.GCN_blocks)
+        for i, (bl, br) in enumerate(zip(L.GCN_blocks, R.GCN_blocks)):
+            X = GCN_ResBlock.forward_pair(bl, br, X, dc, relu_out=(i != n - 1))
+        return X
+
+
 class MLP_res_block(nn.Module):
     """models/model_attn/self_attn.py:17-33."""
 
@@ -152,6 +208,15 @@ class MLP_res_block(nn.Module):
         if dc.p > 0:
             h = _drop_add(dc, None, h)
         return _lin_drop_res(dc, self.fc2, h, x)
+
+
+    @staticmethod
+    def forward_pair(L, R, X, dc):
+        y, X = ops.layernorm_pair_skip(X, L.layer_norm, R.layer_norm)
+        h = _lin_pair(L.fc1, R.fc1, y, relu=True)
+        if dc.p > 0:
+            h = _drop_add(dc, None, h)
+        return _lin_drop_res_pair(dc, L.fc2, R.fc2, h, X)
 
 
 class SelfAttn(nn.Module):
@@ -184,6 +249,19 @@ class SelfAttn(nn.Module):
         return self.ff(x, dc)
 
 
+    @staticmethod
+    def forward_pair(L, R, X, dc):
+        _, B, S, D = X.shape
+        y, X = ops.layernorm_pair_skip(X, L.layer_norm, R.layer_norm)
+        # both hands' fused QKV operands stacked once into [2, 3D, D]
+        w = torch.cat([L.w_qs.weight, L.w_ks.weight, L.w_vs.weight, R.w_qs.weight, R.w_ks.weight, R.w_vs.weight], 0)
+        b = torch.cat([L.w_qs.bias, L.w_ks.bias, L.w_vs.bias, R.w_qs.bias, R.w_ks.bias, R.w_vs.bias], 0)
+        qkv = ops.LinearPairFn.apply(y, w.view(2, 3 * D, D), None, b.view(2, 3 * D), None, None, False)
+        o = ops.self_attention_packed(qkv.view(2 * B, S, 3 * D), L.n_heads, dc.p, dc.seed() if dc.p > 0 else 0)
+        X = _lin_drop_res_pair(dc, L.fc, R.fc, o.view(2, B, S, D), X)
+        return MLP_res_block.forward_pair(L.ff, R.ff, X, dc)
+
+
 class img_feat_to_grid(nn.Module):
     """models/model_attn/img_attn.py:38-67: patch conv + ReLU -> 64 tokens + position embedding -> SelfAttn."""
 
@@ -204,6 +282,15 @@ class img_feat_to_grid(nn.Module):
         return self.self_attn(g, dc)
 
 
+    @staticmethod
+    def forward_pair(L, R, img, dc):
+        B = img.shape[0]
+        g = ops.patch_conv_pair(img, L.proj, R.proj)                 # [2,B,gs,gs,Dg], ReLU fused
+        g = g.view(2, B, L.grid_size * L.grid_size, L.grid_f_dim)
+        g = ops.add_rows_pair(g, L.position_embeddings.weight, R.position_embeddings.weight)
+        return SelfAttn.forward_pair(L.self_attn, R.self_attn, g, dc)
+
+
 class img_attn(nn.Module):
     """models/model_attn/img_attn.py:70-92."""
 
@@ -220,6 +307,14 @@ class img_attn(nn.Module):
         return x[:, :V]
 
 
+    @staticmethod
+    def forward_pair(L, R, X, img_f, dc):
+        V = X.shape[2]
+        x = torch.cat([X, _lin_pair(L.fc, R.fc, img_f)], dim=2)
+        x = SelfAttn.forward_pair(L.Attn, R.Attn, x, dc)
+        return x[:, :, :V]
+
+
 class img_ex(nn.Module):
     """models/model_attn/img_attn.py:95-113."""
 
@@ -233,6 +328,11 @@ class img_ex(nn.Module):
 
     def forward(self, img, verts_f, dc):
         return self.attn(verts_f, self.encoder(img, dc), dc)
+
+
+    @staticmethod
+    def forward_pair(L, R, img, X, dc):
+        return img_attn.forward_pair(L.attn, R.attn, X, img_feat_to_grid.forward_pair(L.encoder, R.encoder, img, dc), dc)
 
 
 class inter_attn(nn.Module):
@@ -276,6 +376,17 @@ class inter_attn(nn.Module):
         return Lf, Rf
 
 
+    def forward_pair(self, X, dc):
+        X = SelfAttn.forward_pair(self.L_self_attn_layer, self.R_self_attn_layer, X, dc)
+        X2 = ops.layernorm_pair(X, self.layer_norm1, self.layer_norm2)
+        w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight], 0)
+        b = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias], 0)
+        sd = (lambda: dc.seed()) if dc.p > 0 else (lambda: 0)
+        # shared projections (N5): ONE fused QKV GEMM over both hands' rows, then the two cross-hand directions
+        feat = ops.cross_attention_stacked(ops.linear(X2, w, b), self.n_heads, dc.p, sd(), sd())
+        return MLP_res_block.forward_pair(self.ffL, self.ffR, _lin_drop_res(dc, self.fc, feat, X), dc)
+
+
 class DualGraphLayer(nn.Module):
     """models/model_attn/DualGraph.py:21-91."""
 
@@ -301,6 +412,15 @@ class DualGraphLayer(nn.Module):
         return self.attn(Lf, Rf, dc)
 
 
+    def forward_pair(self, X, img_f, dc):
+        _, B, V, D = X.shape
+        assert V == self.verts_num and D == self.verts_in_dim
+        X = ops.add_rows_bcast(X.reshape(2 * B, V, D), self.position_embeddings.weight).view(2, B, V, D)
+        X = GraphLayer.forward_pair(self.graph_left, self.graph_right, X, dc)
+        X = img_ex.forward_pair(self.img_ex_left, self.img_ex_right, img_f, X, dc)
+        return self.attn.forward_pair(X, dc)
+
+
 class DualGraph(nn.Module):
     """models/model_attn/DualGraph.py:94-139."""
 
@@ -324,8 +444,20 @@ class DualGraph(nn.Module):
         return self._up[key](x)
 
     def forward(self, Lf, Rf, img_f_list, dc):
+        if ops.PAIR_HANDS:
+            X = self.forward_stacked(torch.stack([Lf, Rf]), img_f_list, dc)
+            return X[0], X[1]
         for i, layer in enumerate(self.layers):
             Lf, Rf = layer(Lf, Rf, img_f_list[i], dc)
             if i != len(self.layers) - 1:
                 Lf, Rf = self._upsample2(Lf), self._upsample2(Rf)
         return Lf, Rf
+
+    def forward_stacked(self, X, img_f_list, dc):
+        """X [2,B,V,D] (left, right) -> [2,B,4V,D']: every per-hand layer pair is one launch."""
+        for i, layer in enumerate(self.layers):
+            X = layer.forward_pair(X, img_f_list[i], dc)
+            if i != len(self.layers) - 1:
+                _, B, V, D = X.shape
+                X = self._upsample2(X.reshape(2 * B, V, D)).view(2, B, 2 * V, D)
+        return X

@@ -558,7 +558,13 @@ __global__ __launch_bounds__(TPB) void layernorm_fwd_kernel(const float* __restr
                                                             const float* __restrict__ g, const float* __restrict__ b,
                                                             float* __restrict__ y, float* __restrict__ mean,
                                                             float* __restrict__ rstd, int rows, int D, float eps,
-                                                            int relu) {
+                                                            int relu, long long sG, long long sB) {
+    {   // blockIdx.y = group (left / right hand): `rows` rows each, stacked activations, parameter sets sG / sB apart
+        const long long go = (long long)blockIdx.y * rows;
+        x += go * D; y += go * D; mean += go; rstd += go;
+        if (x2 != nullptr) x2 += go * D;
+        g += blockIdx.y * sG; b += blockIdx.y * sB;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nper = (D + 63) / 64;
     for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
@@ -603,7 +609,17 @@ __global__ __launch_bounds__(TPB) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ dres, float* __restrict__ dx,
-                                                            float* __restrict__ ws, int rows, int D, int relu) {
+                                                            float* __restrict__ ws, int rows, int D, int relu,
+                                                            long long sG) {
+    {
+        const long long go = (long long)blockIdx.y * rows;
+        dy += go * D; x += go * D; dx += go * D; mean += go; rstd += go;
+        if (x2 != nullptr) x2 += go * D;
+        if (y != nullptr) y += go * D;
+        if (dres != nullptr) dres += go * D;
+        g += blockIdx.y * sG;
+        ws += (long long)blockIdx.y * gridDim.x * 2 * D;
+    }
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nper = (D + 63) / 64;
@@ -667,6 +683,9 @@ __global__ __launch_bounds__(TPB) void layernorm_bwd_kernel(const float* __restr
 
 __global__ __launch_bounds__(TPB) void ln_param_final_kernel(const float* __restrict__ ws, int D, int nblk,
                                                              float* __restrict__ dg, float* __restrict__ db) {
+    ws += (long long)blockIdx.y * nblk * 2 * D;     // group: dg / db are [groups][D]
+    dg += (long long)blockIdx.y * D;
+    db += (long long)blockIdx.y * D;
     const int lane = threadIdx.x & 63;
     const int e = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (e >= D) return;
@@ -825,7 +844,8 @@ __global__ void scatter_rows_add_kernel(const float* __restrict__ dy, const int3
     }
 }
 
-__global__ void cheby_fwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ indptr,
+// scalar forms: any F
+__global__ void cheby_fwd_scalar_kernel(const float* __restrict__ x, const int32_t* __restrict__ indptr,
                                  const int32_t* __restrict__ indices, const float* __restrict__ vals,
                                  float* __restrict__ y, int B, int V, int F) {
     const long long total = (long long)B * V * F;
@@ -844,7 +864,7 @@ __global__ void cheby_fwd_kernel(const float* __restrict__ x, const int32_t* __r
     }
 }
 
-__global__ void cheby_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ indptr,
+__global__ void cheby_bwd_scalar_kernel(const float* __restrict__ dy, const int32_t* __restrict__ indptr,
                                  const int32_t* __restrict__ indices, const float* __restrict__ vals,
                                  float* __restrict__ dx, int B, int V, int F) {
     const long long total = (long long)B * V * F;
@@ -857,6 +877,55 @@ __global__ void cheby_bwd_kernel(const float* __restrict__ dy, const int32_t* __
         float s = db[(long long)v * 2 * F];
         for (int k = indptr[v]; k < indptr[v + 1]; ++k) s += vals[k] * db[(long long)indices[k] * 2 * F + 1];
         dx[i] = s;
+    }
+}
+
+// four features per lane (F % 4 == 0 in every layer of the decoder): 16-byte gathers of the neighbour rows, two 16-byte
+// stores of the interleaved (x, Lx) pairs; the CSR row (indptr / indices / vals) is read once per four outputs
+__global__ void cheby_fwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ indptr,
+                                 const int32_t* __restrict__ indices, const float* __restrict__ vals,
+                                 float* __restrict__ y, int B, int V, int F) {
+    const int F4 = F >> 2;
+    const long long total = (long long)B * V * F4;
+    GRID_STRIDE(i, total) {
+        const int f4 = (int)(i % F4);
+        const long long t = i / F4;
+        const int v = (int)(t % V);
+        const int b = (int)(t / V);
+        const float4* xb = reinterpret_cast<const float4*>(x + (long long)b * V * F) + f4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = indptr[v]; k < indptr[v + 1]; ++k) {
+            const float w = vals[k];
+            const float4 n = xb[(long long)indices[k] * F4];
+            s.x += w * n.x; s.y += w * n.y; s.z += w * n.z; s.w += w * n.w;
+        }
+        const float4 c = xb[(long long)v * F4];
+        float4* o = reinterpret_cast<float4*>(y) + 2 * i;
+        o[0] = make_float4(c.x, s.x, c.y, s.y);
+        o[1] = make_float4(c.z, s.z, c.w, s.w);
+    }
+}
+
+__global__ void cheby_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ indptr,
+                                 const int32_t* __restrict__ indices, const float* __restrict__ vals,
+                                 float* __restrict__ dx, int B, int V, int F) {
+    const int F4 = F >> 2;
+    const long long total = (long long)B * V * F4;
+    GRID_STRIDE(i, total) {
+        const int f4 = (int)(i % F4);
+        const long long t = i / F4;
+        const int v = (int)(t % V);
+        const int b = (int)(t / V);
+        // dy row = [B][V][2F] as float4 pairs: (d x0, d Lx0, d x1, d Lx1), (d x2, d Lx2, d x3, d Lx3)
+        const float4* db = reinterpret_cast<const float4*>(dy + (long long)b * V * 2 * F) + 2 * f4;
+        const float4 a0 = db[(long long)v * 2 * F4], a1 = db[(long long)v * 2 * F4 + 1];
+        float4 s = make_float4(a0.x, a0.z, a1.x, a1.z);
+        for (int k = indptr[v]; k < indptr[v + 1]; ++k) {
+            const float w = vals[k];
+            const float4 n0 = db[(long long)indices[k] * 2 * F4], n1 = db[(long long)indices[k] * 2 * F4 + 1];
+            s.x += w * n0.y; s.y += w * n0.w; s.z += w * n1.y; s.w += w * n1.w;
+        }
+        reinterpret_cast<float4*>(dx)[i] = s;
     }
 }
 
@@ -1035,26 +1104,38 @@ extern "C" int rih_ln_nblk(int rows) {
     if (n > 1024) n = 1024;
     return n;
 }
-extern "C" int rih_layernorm_fwd(const float* x, const float* x2, const float* g, const float* b, float* y, float* mean,
-                                 float* rstd, int rows, int D, float eps, int relu, void* stream) {
+extern "C" int rih_layernorm_fwd_grouped(const float* x, const float* x2, const float* g, const float* b, float* y,
+                                         float* mean, float* rstd, int groups, int rows, int D, int64_t sG, int64_t sB,
+                                         float eps, int relu, void* stream) {
     if (!x || !g || !b || !y || !mean || !rstd || rows < 1 || D < 1 || D > 64 * LN_MAXPER) return RIH_EINVAL;
+    if (groups < 1 || groups > 65535) return RIH_EINVAL;
     int blocks = (rows + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks), dim3(TPB), 0, STREAM, x, x2, g, b, y, mean, rstd, rows, D, eps,
-                       relu);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks, groups), dim3(TPB), 0, STREAM, x, x2, g, b, y, mean, rstd, rows,
+                       D, eps, relu, (long long)sG, (long long)sB);
+    LAUNCH_RET();
+}
+extern "C" int rih_layernorm_fwd(const float* x, const float* x2, const float* g, const float* b, float* y, float* mean,
+                                 float* rstd, int rows, int D, float eps, int relu, void* stream) {
+    return rih_layernorm_fwd_grouped(x, x2, g, b, y, mean, rstd, 1, rows, D, 0, 0, eps, relu, stream);
+}
+extern "C" int rih_layernorm_bwd_grouped(const float* dy, const float* x, const float* x2, const float* y, const float* g,
+                                         const float* mean, const float* rstd, const float* dres, float* dx, float* dg,
+                                         float* db, int groups, int rows, int D, int64_t sG, int relu, float* ws,
+                                         void* stream) {
+    if (!dy || !x || !g || !mean || !rstd || !dx || !dg || !db || !ws) return RIH_EINVAL;
+    if (relu && !y) return RIH_EINVAL;
+    if (rows < 1 || D < 1 || D > 64 * LN_MAXPER || groups < 1 || groups > 65535) return RIH_EINVAL;
+    const int nblk = rih_ln_nblk(rows);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk, groups), dim3(TPB), 0, STREAM, dy, x, x2, y, g, mean, rstd, dres,
+                       dx, ws, rows, D, relu, (long long)sG);
+    hipLaunchKernelGGL(ln_param_final_kernel, dim3((D + 3) / 4, groups), dim3(TPB), 0, STREAM, ws, D, nblk, dg, db);
     LAUNCH_RET();
 }
 extern "C" int rih_layernorm_bwd(const float* dy, const float* x, const float* x2, const float* y, const float* g,
                                  const float* mean, const float* rstd, const float* dres, float* dx, float* dg, float* db,
                                  int rows, int D, int relu, float* ws, void* stream) {
-    if (!dy || !x || !g || !mean || !rstd || !dx || !dg || !db || !ws) return RIH_EINVAL;
-    if (relu && !y) return RIH_EINVAL;
-    if (rows < 1 || D < 1 || D > 64 * LN_MAXPER) return RIH_EINVAL;
-    const int nblk = rih_ln_nblk(rows);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(TPB), 0, STREAM, dy, x, x2, y, g, mean, rstd, dres, dx, ws,
-                       rows, D, relu);
-    hipLaunchKernelGGL(ln_param_final_kernel, dim3((D + 3) / 4), dim3(TPB), 0, STREAM, ws, D, nblk, dg, db);
-    LAUNCH_RET();
+    return rih_layernorm_bwd_grouped(dy, x, x2, y, g, mean, rstd, dres, dx, dg, db, 1, rows, D, 0, relu, ws, stream);
 }
 extern "C" int rih_softmax_fwd(const float* S, float* P, float* Pd, int64_t rows, int cols, int ld, float drop_p,
                                uint64_t seed, const uint64_t* seed_dev, void* stream) {
@@ -1133,15 +1214,23 @@ extern "C" int rih_scatter_rows_add(const float* dy, const int32_t* inv_ptr, con
 extern "C" int rih_cheby_fwd(const float* x, const int32_t* indptr, const int32_t* indices, const float* vals, float* y,
                              int B, int V, int F, void* stream) {
     if (!x || !indptr || !indices || !vals || !y || B < 1 || V < 1 || F < 1) return RIH_EINVAL;
-    hipLaunchKernelGGL(cheby_fwd_kernel, dim3(grid_for((long long)B * V * F)), dim3(TPB), 0, STREAM, x, indptr, indices,
-                       vals, y, B, V, F);
+    if (F % 4 == 0)
+        hipLaunchKernelGGL(cheby_fwd_kernel, dim3(grid_for((long long)B * V * (F / 4))), dim3(TPB), 0, STREAM, x, indptr,
+                           indices, vals, y, B, V, F);
+    else
+        hipLaunchKernelGGL(cheby_fwd_scalar_kernel, dim3(grid_for((long long)B * V * F)), dim3(TPB), 0, STREAM, x, indptr,
+                           indices, vals, y, B, V, F);
     LAUNCH_RET();
 }
 extern "C" int rih_cheby_bwd(const float* dy, const int32_t* t_indptr, const int32_t* t_indices, const float* t_vals,
                              float* dx, int B, int V, int F, void* stream) {
     if (!dy || !t_indptr || !t_indices || !t_vals || !dx || B < 1 || V < 1 || F < 1) return RIH_EINVAL;
-    hipLaunchKernelGGL(cheby_bwd_kernel, dim3(grid_for((long long)B * V * F)), dim3(TPB), 0, STREAM, dy, t_indptr,
-                       t_indices, t_vals, dx, B, V, F);
+    if (F % 4 == 0)
+        hipLaunchKernelGGL(cheby_bwd_kernel, dim3(grid_for((long long)B * V * (F / 4))), dim3(TPB), 0, STREAM, dy, t_indptr,
+                           t_indices, t_vals, dx, B, V, F);
+    else
+        hipLaunchKernelGGL(cheby_bwd_scalar_kernel, dim3(grid_for((long long)B * V * F)), dim3(TPB), 0, STREAM, dy,
+                           t_indptr, t_indices, t_vals, dx, B, V, F);
     LAUNCH_RET();
 }
 

@@ -31,6 +31,7 @@ struct GemmArgs {
     int lda, ldb, ldc, ldr;
     int nb2, splitk, kchunk;
     long long sA1, sA2, sB1, sB2, sC1, sC2, sCsplit;
+    long long sBias1, sR1;          // per-nb1-slice strides of bias / R (paired left/right-hand GEMMs)
     float alpha;
     int relu;
     int H, W, Cin, Ho, Wo, KH, KW, strideA, upS, padH, padW;
@@ -130,6 +131,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const float* __restrict__ A = p.A + b1 * p.sA1 + b2 * p.sA2;
     const float* __restrict__ B = p.B + b1 * p.sB1 + b2 * p.sB2;
     float* __restrict__ C = p.C + b1 * p.sC1 + b2 * p.sC2 + split * p.sCsplit;
+    const float* __restrict__ biasp = p.bias != nullptr ? p.bias + b1 * p.sBias1 : nullptr;
+    const float* __restrict__ Rp = p.R != nullptr ? p.R + b1 * p.sR1 : nullptr;
 
     const int kbeg = split * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
@@ -507,12 +510,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * WN + j * 32 + l31;
-            const float bv = (!raw && p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+            const float bv = (!raw && biasp != nullptr && n < p.N) ? biasp[n] : 0.f;
             float rv[16];       // residual operand: all 16 loads of the tile in flight before the first store
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                rv[r] = (!raw && p.R != nullptr && m < p.M && n < p.N) ? p.R[(long long)m * p.ldr + n] : 0.f;
+                rv[r] = (!raw && Rp != nullptr && m < p.M && n < p.N) ? Rp[(long long)m * p.ldr + n] : 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -612,6 +615,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
     const int bz = z / p.splitk;
     const int b2 = bz % p.nb2, b1 = bz / p.nb2;
     float* __restrict__ C = p.C + b1 * p.sC1 + b2 * p.sC2 + split * p.sCsplit;
+    const float* __restrict__ biasp = p.bias != nullptr ? p.bias + b1 * p.sBias1 : nullptr;
+    const float* __restrict__ Rp = p.R != nullptr ? p.R + b1 * p.sR1 : nullptr;
     const __amdgpu_buffer_rsrc_t rA =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + b1 * p.sA1 + b2 * p.sA2), (short)0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB =
@@ -901,12 +906,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * WN + j * 32 + l31;
-            const float bv = (!raw && p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+            const float bv = (!raw && biasp != nullptr && n < p.N) ? biasp[n] : 0.f;
             float rv[16];       // residual operand: all 16 loads of the tile in flight before the first store
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                rv[r] = (!raw && p.R != nullptr && m < p.M && n < p.N) ? p.R[(long long)m * p.ldr + n] : 0.f;
+                rv[r] = (!raw && Rp != nullptr && m < p.M && n < p.N) ? Rp[(long long)m * p.ldr + n] : 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -987,6 +992,8 @@ __global__ __launch_bounds__(256, 1) void gemm_split256_kernel(const GemmArgs p)
     const int bz = z / p.splitk;
     const int b2 = bz % p.nb2, b1 = bz / p.nb2;
     float* __restrict__ C = p.C + b1 * p.sC1 + b2 * p.sC2 + split * p.sCsplit;
+    const float* __restrict__ biasp = p.bias != nullptr ? p.bias + b1 * p.sBias1 : nullptr;
+    const float* __restrict__ Rp = p.R != nullptr ? p.R + b1 * p.sR1 : nullptr;
     const __amdgpu_buffer_rsrc_t rA =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + b1 * p.sA1 + b2 * p.sA2), (short)0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB =
@@ -1282,12 +1289,12 @@ __global__ __launch_bounds__(256, 1) void gemm_split256_kernel(const GemmArgs p)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * WN + j * 32 + l31;
-            const float bv_ = (!raw && p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+            const float bv_ = (!raw && biasp != nullptr && n < p.N) ? biasp[n] : 0.f;
             float rv[16];       // residual operand: all 16 loads of the tile in flight before the first store
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                rv[r] = (!raw && p.R != nullptr && m < p.M && n < p.N) ? p.R[(long long)m * p.ldr + n] : 0.f;
+                rv[r] = (!raw && Rp != nullptr && m < p.M && n < p.N) ? Rp[(long long)m * p.ldr + n] : 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1321,7 +1328,12 @@ int launch_split256(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 
 // past the tile range sum slab row M (the all-ones row of the A operand = column sums of dy) into the bias gradient.
 __global__ __launch_bounds__(256) void splitk_reduce_fused_kernel(const float* __restrict__ P, int S, int Mp, int M, int N,
                                                                   float* __restrict__ dst, int Cin, int taps, int CinValid,
-                                                                  int accumulate, float* __restrict__ db, int ntiles) {
+                                                                  int accumulate, float* __restrict__ db, int ntiles,
+                                                                  long long sP, long long sDst, long long sDb) {
+    // blockIdx.y = independent reductions of one launch (paired left/right-hand weight gradients)
+    P += blockIdx.y * sP;
+    dst += blockIdx.y * sDst;
+    if (db != nullptr) db += blockIdx.y * sDb;
     const long long slab = (long long)Mp * N;
     if ((int)blockIdx.x >= ntiles) {
         const int n = ((int)blockIdx.x - ntiles) * 256 + threadIdx.x;
@@ -1468,6 +1480,7 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
     a.nb2 = d->nb2; a.splitk = d->splitk;
     a.kchunk = (d->splitk > 1) ? d->kchunk : ((d->K + BK - 1) / BK) * BK + BK;
     a.sA1 = d->sA1; a.sA2 = d->sA2; a.sB1 = d->sB1; a.sB2 = d->sB2; a.sC1 = d->sC1; a.sC2 = d->sC2;
+    a.sBias1 = d->sBias1; a.sR1 = d->sR1;
     a.sCsplit = d->sCsplit;
     a.alpha = d->alpha; a.relu = d->relu;
     a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.KH = d->KH; a.KW = d->KW;
@@ -1532,16 +1545,24 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
     return launch_tile<64, 64>(a, d->a_mode, d->b_mode, d->engine, grid, s);
 }
 
-extern "C" int rih_splitk_reduce_bias(const float* P, int S, int Mp, int M, int N, float* dst, int Cin, int taps,
-                                      int CinValid, int accumulate, float* db, void* stream) {
+extern "C" int rih_splitk_reduce_bias_batched(const float* P, int S, int Mp, int M, int N, float* dst, int Cin, int taps,
+                                              int CinValid, int accumulate, float* db, int nb, int64_t sP, int64_t sDst,
+                                              int64_t sDb, void* stream) {
     if (!P || !dst || S < 1 || M < 1 || Mp < M || N < 1 || Cin < 1 || taps < 1 || CinValid < 1) return RIH_EINVAL;
     if (db && Mp < M + 1) return RIH_EINVAL;
+    if (nb < 1 || nb > 65535) return RIH_EINVAL;
     const long long tiles = (long long)((M + 7) / 8) * ((N + 31) / 32);
     const long long blocks = tiles + (db ? (N + 255) / 256 : 0);
     if (blocks > 0x7fffffffLL) return RIH_EINVAL;
-    hipLaunchKernelGGL(splitk_reduce_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P, S, Mp, M,
-                       N, dst, Cin, taps, CinValid, accumulate, db, (int)tiles);
+    hipLaunchKernelGGL(splitk_reduce_fused_kernel, dim3((unsigned)blocks, (unsigned)nb), dim3(256), 0, (hipStream_t)stream,
+                       P, S, Mp, M, N, dst, Cin, taps, CinValid, accumulate, db, (int)tiles, (long long)sP,
+                       (long long)sDst, (long long)sDb);
     return (int)hipGetLastError();
+}
+
+extern "C" int rih_splitk_reduce_bias(const float* P, int S, int Mp, int M, int N, float* dst, int Cin, int taps,
+                                      int CinValid, int accumulate, float* db, void* stream) {
+    return rih_splitk_reduce_bias_batched(P, S, Mp, M, N, dst, Cin, taps, CinValid, accumulate, db, 1, 0, 0, 0, stream);
 }
 
 extern "C" int rih_splitk_reduce(float* P, int S, int M, int N, float* dst, int Cin, int taps, int CinValid,

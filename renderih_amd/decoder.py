@@ -150,13 +150,29 @@ class decoder(nn.Module):
         Lf = torch.cat([rep(gl.unsqueeze(1)), pel], dim=-1)
         Rf = torch.cat([rep(gr.unsqueeze(1)), per], dim=-1)
 
-        Lf, Rf = self.dual_gcn(Lf, Rf, fmaps, dc)
-
         scale, trans2d = {}, {}
-        feats = {'left': Lf, 'right': Rf}
         verts3d, verts2d = {}, {}
         result = {'verts3d': {}, 'verts2d': {}}
-        for hand_type in ['left', 'right']:
+        if ops.PAIR_HANDS:
+            # the heads are shared between the hands (decoder.py:143-163): run them once over the stacked batch
+            f = self.dual_gcn.forward_stacked(torch.stack([Lf, Rf]), fmaps, dc)
+            f = f.reshape(2 * bs, f.shape[2], f.shape[3])
+            temp = _lin(self.avg_head, f.transpose(-1, -2).contiguous())[..., 0]
+            temp = _lin(self.params_head, temp)
+            v3 = _lin(self.coord_head, f)
+            v2 = ops.projection_batch(temp[:, 0], temp[:, 1:], v3, IMG_SIZE)
+            up = ops.linear(v3.transpose(1, 2).contiguous(), self.unsample_layer.weight).transpose(1, 2).contiguous()
+            up2 = ops.projection_batch(temp[:, 0], temp[:, 1:], up, IMG_SIZE)
+            for h, hand_type in enumerate(['left', 'right']):
+                sl = slice(h * bs, (h + 1) * bs)
+                scale[hand_type], trans2d[hand_type] = temp[sl, 0], temp[sl, 1:]
+                verts3d[hand_type], verts2d[hand_type] = v3[sl], v2[sl]
+                result['verts3d'][hand_type], result['verts2d'][hand_type] = up[sl], up2[sl]
+            feats = None
+        else:
+            Lf, Rf = self.dual_gcn(Lf, Rf, fmaps, dc)
+            feats = {'left': Lf, 'right': Rf}
+        for hand_type in (['left', 'right'] if feats is not None else []):
             f = feats[hand_type]
             temp = _lin(self.avg_head, f.transpose(-1, -2).contiguous())[..., 0]
             temp = _lin(self.params_head, temp)

@@ -6,6 +6,7 @@ on the GPU.  There is no CPU or eager fallback: a missing library or a non-GPU t
 """
 import ctypes as C
 import math
+import os
 import torch
 
 from . import _lib
@@ -100,6 +101,9 @@ def _seed_dev():
     return 0 if DROPOUT_SEED_TENSOR is None else DROPOUT_SEED_TENSOR.data_ptr()
 
 
+# Run the per-hand decoder layers as paired launches on hands-stacked activations (LinearPairFn & co. below).
+PAIR_HANDS = os.environ.get('RIH_PAIR_HANDS', '1') != '0'
+
 # When set to a list, every rih_gemm launch is bracketed by HIP events on the launch stream and
 # (flops, start, end, tag) is appended -- bench.py uses this for the live roofline measurement.
 PROFILE = None
@@ -107,13 +111,14 @@ PROFILE = None
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=None, ldr=0,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, kchunk=0, sCsplit=0, alpha=1.0, relu=False,
-         geom=None, tile=None, engine=None, cstride=None, ones_row=0):
+         geom=None, tile=None, engine=None, cstride=None, ones_row=0, sBias=0, sR=0):
     """Enqueue one rih_gemm.  A/B/Cout/bias/R are tensors or raw device pointers.
     cstride = (s, oh, ow, H, W): store GEMM row (img, i, j) to pixel (img, i*s+oh, j*s+ow) of a [*, H, W] tensor."""
     d = GemmDesc()
     if cstride is not None:
         d.cS, d.cOH, d.cOW, d.cH, d.cW = cstride
     d.ones_row = ones_row
+    d.sBias1, d.sR1 = sBias, sR
     d.engine = ENGINE if engine is None else engine
     d.A = A if isinstance(A, int) else A.data_ptr()
     d.B = B if isinstance(B, int) else B.data_ptr()
@@ -161,30 +166,47 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
     check(_L().rih_gemm(C.byref(d), _stream()), 'rih_gemm')
 
 
-def _wgrad(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db=None):
+def _pdiff(a, b):
+    """Distance in floats between the storage of two fp32 tensors: the nb1 stride that walks from a left-hand parameter
+    to the right-hand one, so that both hands' layers run as one batched launch."""
+    d = b.data_ptr() - a.data_ptr()
+    assert d % 4 == 0
+    return d // 4
+
+
+def _wgrad(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db=None, nb=1, sx=0, sdy=0):
     """dw (parameter layout) = im2col(x)^T @ dy with split-K over the Kpix pixels.  With `db` (bias gradient, [Ncols])
-    the A operand gets an all-ones row behind its Mrows rows, so the same GEMM also produces the column sums of dy."""
+    the A operand gets an all-ones row behind its Mrows rows, so the same GEMM also produces the column sums of dy.
+    nb > 1: that many independent gradients in one GEMM + one reduce launch (x / dy slices sx / sdy floats apart, sx = 0
+    for a shared input; dw [nb, ...] and db [nb, Ncols] contiguous)."""
     Mp = Mrows + 4 if db is not None else Mrows
     # small weight matrices (decoder Linears, <= 4x4 tiles of 128): 64x64 tiles give 4x the resident slices per split
     small = _cdiv(Mp, 128) * _cdiv(Ncols, 128) <= 4
     tile = 3 if Ncols <= 32 else (2 if (Ncols <= 64 or Mp <= 64 or (ENGINE == 1 and small)) else 0)
     bm, bn = _TILE_MN[tile]
-    tiles = _cdiv(Mp, bm) * _cdiv(Ncols, bn)
+    tiles = _cdiv(Mp, bm) * _cdiv(Ncols, bn) * nb
     # measured optimum of resident split-K slices (tools/tile_sweep.py): ~512 workgroups, 256 for a single tile
     target = (256 if tiles == 1 else 512) if ENGINE == 1 else 1024
     splitk = max(1, min(target // max(tiles, 1), _cdiv(Kpix, 128)))
     kchunk = _cdiv(_cdiv(Kpix, splitk), 32) * 32
     splitk = _cdiv(Kpix, kchunk)
-    part = torch.empty((splitk, Mp, Ncols), device=x.device, dtype=torch.float32)
+    part = torch.empty((nb, splitk, Mp, Ncols), device=x.device, dtype=torch.float32)
     ones = Mrows if db is not None else 0
+    batch = dict(nb1=nb, sA=(sx, 0), sB=(sdy, 0), sC=(splitk * Mp * Ncols, 0)) if nb > 1 else {}
     if splitk == 1:
         # a single slice still goes through the reduce kernel for the layout change; raw epilogue = alpha 1, no bias
-        gemm(x, dy, part, Mp, Ncols, Kpix, ldx, ldy, Ncols, a_mode=1, b_mode=0, geom=geom, tile=tile, ones_row=ones)
+        gemm(x, dy, part, Mp, Ncols, Kpix, ldx, ldy, Ncols, a_mode=1, b_mode=0, geom=geom, tile=tile, ones_row=ones,
+             **batch)
     else:
         gemm(x, dy, part, Mp, Ncols, Kpix, ldx, ldy, Ncols, a_mode=1, b_mode=0, splitk=splitk, kchunk=kchunk,
-             sCsplit=Mp * Ncols, geom=geom, tile=tile, ones_row=ones)
-    check(_L().rih_splitk_reduce_bias(part.data_ptr(), splitk, Mp, Mrows, Ncols, dw.data_ptr(), Cin_pad, taps, Cin_valid,
-                                      0, _p(db), _stream()), 'rih_splitk_reduce_bias')
+             sCsplit=Mp * Ncols, geom=geom, tile=tile, ones_row=ones, **batch)
+    if nb == 1:
+        check(_L().rih_splitk_reduce_bias(part.data_ptr(), splitk, Mp, Mrows, Ncols, dw.data_ptr(), Cin_pad, taps,
+                                          Cin_valid, 0, _p(db), _stream()), 'rih_splitk_reduce_bias')
+    else:
+        check(_L().rih_splitk_reduce_bias_batched(part.data_ptr(), splitk, Mp, Mrows, Ncols, dw.data_ptr(), Cin_pad, taps,
+                                                  Cin_valid, 0, _p(db), nb, splitk * Mp * Ncols, dw.numel() // nb,
+                                                  Ncols, _stream()), 'rih_splitk_reduce_bias_batched')
 
 
 def colsum(x2d, rows, Ccols, ldx=None):
@@ -356,6 +378,122 @@ class LinearFn(torch.autograd.Function):
 
 def linear(x, w, bias=None, residual=None, relu=False):
     return LinearFn.apply(x, w, bias, residual, relu)
+
+
+# ------------------------------------------------------------------------- paired left/right-hand layers
+# The decoder runs every block once per hand with separate parameters (DualGraph.py:83-89).  With the two hands'
+# activations stacked [2][rows][D] each such pair of layers is ONE launch: the GEMM batch index walks from the left
+# parameter tensor to the right one (rih_gemm_desc.sB1 / sBias1 = their distance in memory).
+class LinearPairFn(torch.autograd.Function):
+    """y[h] = act(x[h] @ w_h^T + b_h + residual[h]), h = left, right;  x [2, ..., K] -> y [2, ..., N].
+    wR / bR None: wL [2, N, K] and bL [2, N] hold both hands' parameters (the stacked fused QKV operand)."""
+
+    @staticmethod
+    def forward(ctx, x, wL, wR, bL, bR, residual, relu):
+        _chk(x, wL, wR, bL, bR, residual)
+        x, wL = _c(x), _c(wL)
+        assert x.shape[0] == 2
+        stacked = wR is None
+        if stacked:
+            assert wL.dim() == 3 and wL.shape[0] == 2 and bR is None
+            Nf, K = wL.shape[1:]
+            sW, sBias = Nf * K, (0 if bL is None else Nf)
+            if bL is not None:
+                bL = _c(bL)
+        else:
+            wR = _c(wR)
+            assert wL.shape == wR.shape and (bL is None) == (bR is None)
+            Nf, K = wL.shape
+            sW, sBias = _pdiff(wL, wR), (0 if bL is None else _pdiff(bL, bR))
+        M = x.numel() // (2 * K)
+        y = torch.empty(x.shape[:-1] + (Nf,), device=x.device, dtype=torch.float32)
+        if residual is not None:
+            residual = _c(residual)
+        gemm(x, wL, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, bias=bL, R=residual, ldr=Nf, relu=relu, nb1=2,
+             sA=(M * K, 0), sB=(sW, 0), sC=(M * Nf, 0), sBias=sBias, sR=M * Nf)
+        ctx.save_for_backward(x, wL, wR, y if relu else None)
+        ctx.cfg = (relu, bL is not None, residual is not None, stacked, Nf, K, sW)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wL, wR, y = ctx.saved_tensors
+        relu, has_bias, has_res, stacked, Nf, K, sW = ctx.cfg
+        M = x.numel() // (2 * K)
+        dy = _c(dy)
+        if relu:
+            dyr = torch.empty_like(dy)
+            check(_L().rih_relu_bwd(dy.data_ptr(), y.data_ptr(), dyr.data_ptr(), dy.numel(), _stream()), 'rih_relu_bwd')
+            dy = dyr
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(dy, wL, dx, M, K, Nf, Nf, K, K, a_mode=0, b_mode=0, nb1=2, sA=(M * Nf, 0), sB=(sW, 0), sC=(M * K, 0))
+        dw = torch.empty((2, Nf, K), device=x.device, dtype=torch.float32)
+        db = torch.empty((2, Nf), device=x.device, dtype=torch.float32) if has_bias else None
+        _wgrad(x, dy, dw, M, K, Nf, K, Nf, (1, 1, K, 1, 1, 1, 1, 1, 1, 0, 0), K, 1, K, db=db, nb=2, sx=M * K, sdy=M * Nf)
+        dres = dy if (has_res and ctx.needs_input_grad[5]) else None
+        if stacked:
+            return dx, dw, None, db, None, dres, None
+        return dx, dw[0], dw[1], (db[0] if has_bias else None), (db[1] if has_bias else None), dres, None
+
+
+def linear_pair(x, mL, mR, residual=None, relu=False):
+    """Both hands' nn.Linear (modules mL, mR) on the stacked activation x [2, ..., K]."""
+    return LinearPairFn.apply(x, mL.weight, mR.weight, mL.bias, mR.bias, residual, relu)
+
+
+class PatchConvPairFn(torch.autograd.Function):
+    """relu(conv(x, w_h) + b_h) for both hands on ONE shared NHWC map x, for the patch convolution of
+    img_feat_to_grid (img_attn.py:47-62: kernel = stride = patch, no padding) -> y [2, N, g, g, Cout].
+    The non-overlapping patches make the data gradient a plain GEMM dy @ W^T whose rows are whole patches; it is
+    un-patchified by one permuted copy instead of stride^2 parity-class sub-convolutions per hand."""
+
+    @staticmethod
+    def forward(ctx, x, wL, wR, bL, bR):
+        _chk(x, wL, wR, bL, bR)
+        x, wL, wR = _c(x), _c(wL), _c(wR)
+        N, H, W_, Cx = x.shape
+        Cout, Cin, KH, KW = wL.shape
+        assert wR.shape == wL.shape and KH == KW and H % KH == 0 and W_ % KW == 0 and Cx == Cin
+        g_h, g_w = H // KH, W_ // KW
+        M, K = N * g_h * g_w, KH * KW * Cx
+        wp = torch.empty((2, K, Cout), device=x.device, dtype=torch.float32)
+        for h, w in enumerate((wL, wR)):
+            check(_L().rih_pack_conv_weight(w.data_ptr(), wp[h].data_ptr(), Cout, Cin, KH, KW, Cx, 0, _stream()),
+                  'rih_pack_conv_weight')
+        y = torch.empty((2, N, g_h, g_w, Cout), device=x.device, dtype=torch.float32)
+        geom = (H, W_, Cx, g_h, g_w, KH, KW, KH, 1, 0, 0)
+        gemm(x, wp, y, M, Cout, K, Cx, Cout, Cout, a_mode=0, b_mode=0, bias=bL, relu=True, geom=geom, nb1=2,
+             sA=(0, 0), sB=(K * Cout, 0), sC=(M * Cout, 0), sBias=_pdiff(bL, bR))
+        ctx.save_for_backward(x, wp, y)
+        ctx.cfg = (tuple(wL.shape), geom)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wp, y = ctx.saved_tensors
+        (Cout, Cin, KH, KW), geom = ctx.cfg
+        N, H, W_, Cx = x.shape
+        g_h, g_w = H // KH, W_ // KW
+        M, K = N * g_h * g_w, KH * KW * Cx
+        dy = _c(dy)
+        dyr = torch.empty_like(dy)
+        check(_L().rih_relu_bwd(dy.data_ptr(), y.data_ptr(), dyr.data_ptr(), dy.numel(), _stream()), 'rih_relu_bwd')
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxp = torch.empty((2, M, K), device=x.device, dtype=torch.float32)       # rows = patches, cols = (kh, kw, ci)
+            gemm(dyr, wp, dxp, M, K, Cout, Cout, Cout, K, a_mode=0, b_mode=1, nb1=2, sA=(M * Cout, 0),
+                 sB=(K * Cout, 0), sC=(M * K, 0))
+            dx = (dxp[0] + dxp[1]).view(N, g_h, g_w, KH, KW, Cx).permute(0, 1, 3, 2, 4, 5).reshape(N, H, W_, Cx)
+        dw = torch.empty((2, Cout, Cin, KH, KW), device=x.device, dtype=torch.float32)
+        db = torch.empty((2, Cout), device=x.device, dtype=torch.float32)
+        _wgrad(x, dyr, dw, M, K, Cout, Cx, Cout, geom, Cx, KH * KW, Cin, db=db, nb=2, sx=0, sdy=M * Cout)
+        return dx, dw[0], dw[1], db[0], db[1]
+
+
+def patch_conv_pair(x, cL, cR):
+    return PatchConvPairFn.apply(x, cL.weight, cR.weight, cL.bias, cR.bias)
 
 
 # --------------------------------------------------------------------------------------------- batch norm
@@ -631,7 +769,59 @@ def layernorm_skip(x, g, b, eps=1e-6):
     return LayerNormFn.apply(x, None, g, b, eps, False, True)
 
 
-def _attn_forward(q, q_ld, k, v, kv_ld, B, Sq, Sk, D, heads, drop_p, seed, device):
+class LayerNormPairFn(torch.autograd.Function):
+    """LayerNormFn for both hands in one launch: x (and x2) stacked [2, ..., D], parameters (gL, bL) / (gR, bR)."""
+
+    @staticmethod
+    def forward(ctx, x, x2, gL, gR, bL, bR, eps, relu, skip):
+        _chk(x, x2, gL, gR, bL, bR)
+        x = _c(x)
+        if x2 is not None:
+            x2 = _c(x2)
+        assert x.shape[0] == 2
+        D = x.shape[-1]
+        rows = x.numel() // (2 * D)
+        y = torch.empty_like(x)
+        mean = torch.empty((2 * rows,), device=x.device, dtype=torch.float32)
+        rstd = torch.empty((2 * rows,), device=x.device, dtype=torch.float32)
+        check(_L().rih_layernorm_fwd_grouped(x.data_ptr(), _p(x2), gL.data_ptr(), bL.data_ptr(), y.data_ptr(),
+                                             mean.data_ptr(), rstd.data_ptr(), 2, rows, D, _pdiff(gL, gR), _pdiff(bL, bR),
+                                             eps, 1 if relu else 0, _stream()), 'rih_layernorm_fwd_grouped')
+        ctx.save_for_backward(x, x2, y if relu else None, gL, gR, mean, rstd)
+        ctx.relu = relu
+        if skip:
+            return y, x.view_as(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, dskip=None):
+        x, x2, y, gL, gR, mean, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        if dskip is not None:
+            dskip = _c(dskip)
+        D = x.shape[-1]
+        rows = x.numel() // (2 * D)
+        lib = _L()
+        dx = torch.empty_like(x)
+        dg = torch.empty((2, D), device=x.device, dtype=torch.float32)
+        db = torch.empty((2, D), device=x.device, dtype=torch.float32)
+        ws = torch.empty((2 * 2 * lib.rih_ln_nblk(rows) * D,), device=x.device, dtype=torch.float32)
+        check(lib.rih_layernorm_bwd_grouped(dy.data_ptr(), x.data_ptr(), _p(x2), _p(y), gL.data_ptr(), mean.data_ptr(),
+                                            rstd.data_ptr(), _p(dskip), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), 2,
+                                            rows, D, _pdiff(gL, gR), 1 if ctx.relu else 0, ws.data_ptr(), _stream()),
+              'rih_layernorm_bwd_grouped')
+        return dx, (dx if x2 is not None else None), dg[0], dg[1], db[0], db[1], None, None, None
+
+
+def layernorm_pair(x, mL, mR, x2=None, relu=False):
+    return LayerNormPairFn.apply(x, x2, mL.weight, mR.weight, mL.bias, mR.bias, mL.eps, relu, False)
+
+
+def layernorm_pair_skip(x, mL, mR):
+    return LayerNormPairFn.apply(x, None, mL.weight, mR.weight, mL.bias, mR.bias, mL.eps, False, True)
+
+
+def _attn_forward(q, q_ld, k, v, kv_ld, B, Sq, Sk, D, heads, drop_p, seed, device, out=None):
     """q/k/v: raw device pointers to the first element of [B,S,*] slices with row pitch q_ld / kv_ld."""
     d = D // heads
     ldP = _cdiv(Sk, 4) * 4
@@ -642,7 +832,8 @@ def _attn_forward(q, q_ld, k, v, kv_ld, B, Sq, Sk, D, heads, drop_p, seed, devic
     Pd = torch.empty_like(P) if drop_p > 0 else P
     check(_L().rih_softmax_fwd(P.data_ptr(), P.data_ptr(), Pd.data_ptr(), B * heads * Sq, Sk, ldP, drop_p, seed,
                                _seed_dev(), _stream()), 'rih_softmax_fwd')
-    out = torch.empty((B, Sq, D), device=device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((B, Sq, D), device=device, dtype=torch.float32)
     gemm(Pd, v, out, Sq, d, Sk, ldP, kv_ld, D, a_mode=0, b_mode=0, nb1=B, nb2=heads,
          sA=(heads * Sq * ldP, Sq * ldP), sB=(Sk * kv_ld, d), sC=(Sq * D, d))
     return out, P, (Pd if drop_p > 0 else None)
@@ -776,6 +967,74 @@ class CrossAttentionPackedFn(torch.autograd.Function):
 
 def cross_attention_packed(Lqkv, Rqkv, heads, drop_p=0.0, seed_r2l=0, seed_l2r=0):
     return CrossAttentionPackedFn.apply(Lqkv, Rqkv, heads, drop_p, seed_r2l, seed_l2r)
+
+
+class CrossAttentionStackedFn(torch.autograd.Function):
+    """CrossAttentionPackedFn on the hands-stacked projection qkv [2,B,V,3D] -> [2,B,V,D]: slice 0 = feat_R2L (left
+    queries over right keys / values), slice 1 = feat_L2R."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, drop_p, seed_r2l, seed_l2r):
+        _chk(qkv)
+        qkv = _c(qkv)
+        _, B, V, D3 = qkv.shape
+        D = D3 // 3
+        l0, r0 = qkv[0].data_ptr(), qkv[1].data_ptr()
+        out = torch.empty((2, B, V, D), device=qkv.device, dtype=torch.float32)
+        _, P1, Pd1 = _attn_forward(l0, D3, r0 + 4 * D, r0 + 8 * D, D3, B, V, V, D, heads, drop_p, seed_r2l, qkv.device,
+                                   out=out[0])
+        _, P2, Pd2 = _attn_forward(r0, D3, l0 + 4 * D, l0 + 8 * D, D3, B, V, V, D, heads, drop_p, seed_l2r, qkv.device,
+                                   out=out[1])
+        ctx.save_for_backward(qkv, P1, Pd1, P2, Pd2)
+        ctx.cfg = (heads, drop_p, seed_r2l, seed_l2r)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, P1, Pd1, P2, Pd2 = ctx.saved_tensors
+        heads, drop_p, seed_r2l, seed_l2r = ctx.cfg
+        do = _c(do)
+        _, B, V, D3 = qkv.shape
+        D = D3 // 3
+        dqkv = torch.empty_like(qkv)
+        l0, r0, gl, gr = qkv[0].data_ptr(), qkv[1].data_ptr(), dqkv[0].data_ptr(), dqkv[1].data_ptr()
+        _attn_backward(do[0], l0, D3, r0 + 4 * D, r0 + 8 * D, D3, gl, D3, gr + 4 * D, gr + 8 * D, D3, P1, Pd1, B, V, V, D,
+                       heads, drop_p, seed_r2l)
+        _attn_backward(do[1], r0, D3, l0 + 4 * D, l0 + 8 * D, D3, gr, D3, gl + 4 * D, gl + 8 * D, D3, P2, Pd2, B, V, V, D,
+                       heads, drop_p, seed_l2r)
+        return dqkv, None, None, None, None
+
+
+def cross_attention_stacked(qkv, heads, drop_p=0.0, seed_r2l=0, seed_l2r=0):
+    return CrossAttentionStackedFn.apply(qkv, heads, drop_p, seed_r2l, seed_l2r)
+
+
+class AddRowsPairFn(torch.autograd.Function):
+    """x [2,B,T,D] + e_h [T,D] (the per-hand position embeddings of img_feat_to_grid, img_attn.py:57-64)."""
+
+    @staticmethod
+    def forward(ctx, x, eL, eR):
+        _chk(x, eL, eR)
+        x, eL, eR = _c(x), _c(eL), _c(eR)
+        y = torch.empty_like(x)
+        T, D = eL.shape
+        for h, e in enumerate((eL, eR)):
+            check(_L().rih_add_dropout(x[h].data_ptr(), e.data_ptr(), y[h].data_ptr(), y[h].numel(), D, T, 0.0, 0,
+                                       _seed_dev(), _stream()), 'rih_add_dropout')
+        ctx.T = T
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        T, D = ctx.T, dy.shape[-1]
+        Bn = dy[0].numel() // (T * D)
+        de = [colsum(dy[h], Bn, T * D).view(T, D) if ctx.needs_input_grad[1 + h] else None for h in (0, 1)]
+        return dy, de[0], de[1]
+
+
+def add_rows_pair(x, eL, eR):
+    return AddRowsPairFn.apply(x, eL, eR)
 
 
 class AddDropoutFn(torch.autograd.Function):

@@ -119,9 +119,9 @@ class EmulatedLib:
                     continue
                 out = np.float32(d.alpha) * (A @ Bm)
                 if d.bias:
-                    out = out + _f(d.bias, N)[None, :]
+                    out = out + _f(d.bias + 4 * b1 * d.sBias1, N)[None, :]
                 if d.R:
-                    r = _f(d.R + 4 * 0, (M - 1) * d.ldr + N)
+                    r = _f(d.R + 4 * b1 * d.sR1, (M - 1) * d.ldr + N)
                     lm, ln = np.meshgrid(np.arange(M), np.arange(N), indexing='ij')
                     out = out + r[(lm * d.ldr + ln).ravel()].reshape(M, N)
                 if d.relu:
@@ -132,6 +132,13 @@ class EmulatedLib:
 
     def rih_splitk_reduce(self, P, S, M, N, dst, Cin, taps, CinValid, accumulate, stream):
         return self.rih_splitk_reduce_bias(P, S, M, M, N, dst, Cin, taps, CinValid, accumulate, 0, stream)
+
+    def rih_splitk_reduce_bias_batched(self, P, S, Mp, M, N, dst, Cin, taps, CinValid, accumulate, db, nb, sP, sDst, sDb,
+                                       stream):
+        for b in range(nb):
+            self.rih_splitk_reduce_bias(P + 4 * b * sP, S, Mp, M, N, dst + 4 * b * sDst, Cin, taps, CinValid, accumulate,
+                                        db + 4 * b * sDb if db else 0, stream)
+        return 0
 
     def rih_splitk_reduce_bias(self, P, S, Mp, M, N, dst, Cin, taps, CinValid, accumulate, db, stream):
         p = _f(P, S * Mp * N).reshape(S, Mp, N).sum(0)
@@ -380,6 +387,22 @@ class EmulatedLib:
         _f(y, rows * D)[:] = o.ravel()
         _f(mean, rows)[:] = m.ravel()
         _f(rstd, rows)[:] = rs.ravel()
+        return 0
+
+    def rih_layernorm_fwd_grouped(self, x, x2, g, b, y, mean, rstd, groups, rows, D, sG, sB, eps, relu, stream):
+        for q in range(groups):
+            o = 4 * q * rows * D
+            self.rih_layernorm_fwd(x + o, x2 + o if x2 else 0, g + 4 * q * sG, b + 4 * q * sB, y + o,
+                                   mean + 4 * q * rows, rstd + 4 * q * rows, rows, D, eps, relu, stream)
+        return 0
+
+    def rih_layernorm_bwd_grouped(self, dy, x, x2, y, g, mean, rstd, dres, dx, dg, db, groups, rows, D, sG, relu, ws,
+                                  stream):
+        for q in range(groups):
+            o = 4 * q * rows * D
+            self.rih_layernorm_bwd(dy + o, x + o, x2 + o if x2 else 0, y + o if y else 0, g + 4 * q * sG,
+                                   mean + 4 * q * rows, rstd + 4 * q * rows, dres + o if dres else 0, dx + o,
+                                   dg + 4 * q * D, db + 4 * q * D, rows, D, relu, ws, stream)
         return 0
 
     def rih_layernorm_bwd(self, dy, x, x2, y, g, mean, rstd, dres, dx, dg, db, rows, D, relu, ws, stream):

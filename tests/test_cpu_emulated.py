@@ -42,6 +42,86 @@ def test_other_ops_host_logic():
     G.test_cheby_gather_project()
 
 
+def test_paired_layers_host_logic():
+    """Strides between separately allocated left/right parameters, stacked QKV operand, batched split-K reduce, grouped
+    LayerNorm, shared-input patch conv: the descriptor plumbing of the hands-stacked decoder path."""
+    G.test_linear_pair(126, 256, 128, False, True, False)
+    G.test_linear_pair(380, 64, 192, False, False, True)
+    G.test_linear_pair(33, 12, 6, True, True, False)
+    G.test_layernorm_pair(190, 128, False, False, True)
+    G.test_layernorm_pair(126, 256, True, True, False)
+    G.test_patch_conv_pair(2, 16, 256, 128, 2)
+    G.test_patch_conv_pair(2, 16, 32, 48, 4)
+    G.test_patch_conv_pair(3, 8, 32, 48, 1)
+    G.test_cross_attention_stacked_and_rows_pair()
+
+
+@pytest.mark.parametrize('same_graph', [True, False])
+def test_paired_decoder_equals_sequential(monkeypatch, same_graph):
+    """The hands-stacked decoder (one launch per left/right layer pair, shared heads over the stacked batch) computes
+    what the per-hand sequence computes: outputs and every parameter / input gradient, dropout off.  same_graph=False
+    exercises the fallback for user-supplied Laplacians that differ between the hands."""
+    from renderih_amd import ops
+    from renderih_amd.attn import GCN_ResBlock
+    from renderih_amd.model import build_model
+    dec = build_model(0.0).decoder
+    dec.load_state_dict(testing.deterministic_state(dec.state_dict(), seed=5))
+    dec.train()
+    if not same_graph:
+        monkeypatch.setattr(GCN_ResBlock, '_same_graph', lambda self, other: False)
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(1, dec.gf_dim, generator=g)
+    f0 = [torch.randn(1, s, s, 256, generator=g) * 0.5 for s in (8, 16, 32)] + [torch.zeros(1, 64, 64, 256)]
+
+    def run(pair):
+        monkeypatch.setattr(ops, 'PAIR_HANDS', pair)
+        dec.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        fm = [t.clone().requires_grad_(True) for t in f0]
+        result, params, hands, other = dec(x, fm)
+        outs = {}
+        for side in ('left', 'right'):
+            outs['v3d_' + side] = result['verts3d'][side]
+            outs['v2d_' + side] = result['verts2d'][side]
+            outs['c3d_' + side] = hands[0]['verts3d'][side]
+            # one tensor: the scale alone can be a near-cancelled sum whose round-off is not comparable
+            outs['cam_' + side] = torch.cat([params['scale'][side][:, None], params['trans2d'][side]], 1)
+            outs['m3d_' + side] = other['verts3d_MANO_list'][side][0]
+            outs['m2d_' + side] = other['verts2d_MANO_list'][side][0]
+        gen = torch.Generator().manual_seed(3)
+        loss = sum((v * torch.randn(v.shape, generator=gen)).sum() for v in outs.values())
+        loss.backward()
+        grads = {k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None}
+        grads['x'] = x.grad.clone()
+        for i, t in enumerate(fm[:3]):
+            grads['fmap%d' % i] = t.grad.clone()
+        return {k: v.detach().clone() for k, v in outs.items()}, grads
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    for k in o0:
+        assert_close(o1[k], o0[k], 1e-4, 1e-5, 'paired vs sequential ' + k)
+    assert set(g1) == set(g0)
+    for k in g0:
+        if not testing.is_null_gradient(k):
+            assert_close(g1[k], g0[k], 2e-3, 2e-4, 'paired vs sequential grad ' + k)
+
+
+def test_paired_decoder_runs_with_dropout(monkeypatch):
+    from renderih_amd import ops
+    from renderih_amd.model import build_model
+    dec = build_model(0.05).decoder
+    dec.train()
+    monkeypatch.setattr(ops, 'PAIR_HANDS', True)
+    torch.manual_seed(0)
+    x = torch.randn(1, dec.gf_dim)
+    fm = [torch.randn(1, s, s, 256) * 0.5 for s in (8, 16, 32)] + [torch.zeros(1, 64, 64, 256)]
+    result = dec(x, fm)[0]
+    s = sum(v.sum() for v in result['verts3d'].values())
+    s.backward()
+    assert torch.isfinite(s) and all(torch.isfinite(p.grad).all() for p in dec.parameters() if p.grad is not None)
+
+
 def test_pool_layout_host_logic(monkeypatch):
     G.test_pool_upsample_layout()
     G.test_resample_hrnet(4, 5, 7, 32)

@@ -30,16 +30,18 @@ def test_gemm_desc_layout_matches_c():
     """ctypes mirror of rih_gemm_desc must have the C compiler's layout (checked with a tiny C program)."""
     from renderih_amd._lib import GemmDesc
     import ctypes
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "renderih_amd.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",' \
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "renderih_amd.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",' \
           'sizeof(rih_gemm_desc),offsetof(rih_gemm_desc,sA1),offsetof(rih_gemm_desc,sCsplit),' \
-          'offsetof(rih_gemm_desc,alpha),offsetof(rih_gemm_desc,tile),offsetof(rih_gemm_desc,engine),offsetof(rih_gemm_desc,ones_row));return 0;}'
+          'offsetof(rih_gemm_desc,alpha),offsetof(rih_gemm_desc,tile),offsetof(rih_gemm_desc,engine),offsetof(rih_gemm_desc,ones_row),' \
+          'offsetof(rih_gemm_desc,sBias1),offsetof(rih_gemm_desc,sR1));return 0;}'
     import tempfile
     d = tempfile.mkdtemp()
     open(os.path.join(d, 'a.c'), 'w').write(src)
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), os.path.join(d, 'a.c'), '-o', os.path.join(d, 'a')])
     got = [int(x) for x in subprocess.check_output([os.path.join(d, 'a')]).split()]
     assert got == [ctypes.sizeof(GemmDesc), GemmDesc.sA1.offset, GemmDesc.sCsplit.offset, GemmDesc.alpha.offset,
-                   GemmDesc.tile.offset, GemmDesc.engine.offset, GemmDesc.ones_row.offset]
+                   GemmDesc.tile.offset, GemmDesc.engine.offset, GemmDesc.ones_row.offset, GemmDesc.sBias1.offset,
+                   GemmDesc.sR1.offset]
 
 
 def test_ops_refuse_cpu_tensors():

@@ -274,3 +274,20 @@ def test_hipgraph_replay_draws_fresh_dropout_masks():
     e_losses = _sgd_losses(m2, img, 3, capture=False, dropout_seed=seed2)
     for a, b in zip(e_losses, g_losses):
         assert abs(a - b) <= 1e-5 * abs(a), (e_losses, g_losses)
+
+
+def test_paired_decoder_equals_sequential_on_gpu(monkeypatch):
+    """ops.PAIR_HANDS (one launch per left/right layer pair) against the per-hand launch sequence, same weights and
+    image: eval-mode outputs at the fp32 bar.  (The paired path is the default, so its gradients are what
+    test_model_matches_fp64_oracle / the train golden check; the sequential path keeps this comparison.)"""
+    from renderih_amd import ops
+    m, _ = _build(0.0, seed=2)
+    img = testing.seeded_image(2, 7).to('cuda:0')
+    m.eval()
+    outs = {}
+    for pair in (True, False):
+        monkeypatch.setattr(ops, 'PAIR_HANDS', pair)
+        with torch.no_grad():
+            outs[pair] = {k: v.cpu() for k, v in testing.flatten_outputs(m(img)).items()}
+    for k in outs[False]:
+        assert_close(outs[True][k], outs[False][k], 1e-4, 1e-5, 'paired vs sequential ' + k)

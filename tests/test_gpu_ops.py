@@ -455,3 +455,135 @@ def test_gemm_tile4_pipelined_kernel(case):
         zs.append(z)
     assert_close(zs[1], zs[0], 1e-5, 1e-6, 'tile4 linear')
     assert_close(zs[1], (a.double() @ b.double().t()).float(), 1e-5, 1e-6, 'tile4 linear vs fp64')
+
+
+# ------------------------------------------------------------------------------- hands-stacked (paired) layers
+def _leaf(t, d):
+    return t.detach().clone().to(d).requires_grad_(True)
+
+
+@pytest.mark.parametrize('M,K,N,relu,res,stacked', [(126, 256, 128, False, True, False), (380, 64, 192, False, False, True),
+                                                    (64, 512, 64, True, False, False), (33, 12, 6, False, True, False)])
+def test_linear_pair(M, K, N, relu, res, stacked):
+    """Both hands' nn.Linear in one launch (bias / weight / residual walk by per-slice strides) vs two F.linear."""
+    from renderih_amd import ops
+    d = dev()
+    x = rnd(2, 3, M, K, seed=1)
+    w = rnd(2, N, K, seed=2, scale=1 / math.sqrt(K))
+    b = rnd(2, N, seed=3)
+    r = rnd(2, 3, M, N, seed=4) if res else None
+    gy = rnd(2, 3, M, N, seed=5)
+    ts = [t.clone().requires_grad_(True) if t is not None else None for t in (x, w, b, r)]
+    yr = torch.stack([F.linear(ts[0][h], ts[1][h], ts[2][h]) for h in (0, 1)])
+    if res:
+        yr = yr + ts[3]
+    if relu:
+        yr = F.relu(yr)
+    yr.backward(gy)
+    xg = _leaf(x, d)
+    rg = _leaf(r, d) if res else None
+    if stacked:
+        wg, bg = _leaf(w, d), _leaf(b, d)
+        yg = ops.LinearPairFn.apply(xg, wg, None, bg, None, rg, relu)
+    else:
+        pad = torch.zeros(7 * 4, device=d)          # separately allocated parameters: arbitrary distance in memory
+        wl, wr_, bl, br_ = _leaf(w[0], d), _leaf(w[1], d), _leaf(b[0], d), _leaf(b[1], d)
+        assert pad.numel() == 28
+        yg = ops.LinearPairFn.apply(xg, wl, wr_, bl, br_, rg, relu)
+    assert_close(yg, yr, what='linear_pair y')
+    yg.backward(gy.to(d))
+    assert_close(xg.grad, ts[0].grad, 1e-3, 1e-4, 'linear_pair dx')
+    if stacked:
+        assert_close(wg.grad, ts[1].grad, 1e-3, 1e-4, 'linear_pair dw')
+        assert_close(bg.grad, ts[2].grad, 1e-3, 1e-4, 'linear_pair db')
+    else:
+        for h, (a, bb) in enumerate(((wl, bl), (wr_, br_))):
+            assert_close(a.grad, ts[1].grad[h], 1e-3, 1e-4, 'linear_pair dw%d' % h)
+            assert_close(bb.grad, ts[2].grad[h], 1e-3, 1e-4, 'linear_pair db%d' % h)
+    if res:
+        assert_close(rg.grad, ts[3].grad, 1e-3, 1e-4, 'linear_pair dres')
+
+
+@pytest.mark.parametrize('rows,D,relu,x2,skip', [(190, 128, False, False, True), (126, 256, True, True, False),
+                                                 (5, 509, False, False, False)])
+def test_layernorm_pair(rows, D, relu, x2, skip):
+    from renderih_amd import ops
+    d = dev()
+    x, xb = rnd(2, rows, D, seed=1) * 2 + 0.3, (rnd(2, rows, D, seed=2) if x2 else None)
+    g, b = rnd(2, D, seed=3) + 1, rnd(2, D, seed=4)
+    gy, gs = rnd(2, rows, D, seed=5), rnd(2, rows, D, seed=6)
+    ts = [t.clone().requires_grad_(True) if t is not None else None for t in (x, xb, g, b)]
+    xin = ts[0] + ts[1] if x2 else ts[0]
+    yr = torch.stack([F.layer_norm(xin[h], (D,), ts[2][h], ts[3][h], 1e-6) for h in (0, 1)])
+    if relu:
+        yr = F.relu(yr)
+    ((yr * gy).sum() + ((ts[0] * gs).sum() if skip else 0)).backward()
+    xg = _leaf(x, d)
+    x2g = _leaf(xb, d) if x2 else None
+    ps = [_leaf(t, d) for t in (g[0], g[1], b[0], b[1])]
+    out = ops.LayerNormPairFn.apply(xg, x2g, ps[0], ps[1], ps[2], ps[3], 1e-6, relu, skip)
+    yg = out[0] if skip else out
+    assert_close(yg, yr, what='layernorm_pair y')
+    ((yg * gy.to(d)).sum() + ((out[1] * gs.to(d)).sum() if skip else 0)).backward()
+    assert_close(xg.grad, ts[0].grad, 1e-3, 1e-4, 'layernorm_pair dx')
+    if x2:
+        assert_close(x2g.grad, ts[1].grad, 1e-3, 1e-4, 'layernorm_pair dx2')
+    for h in (0, 1):
+        assert_close(ps[h].grad, ts[2].grad[h], 1e-3, 1e-4, 'layernorm_pair dg%d' % h)
+        assert_close(ps[2 + h].grad, ts[3].grad[h], 1e-3, 1e-4, 'layernorm_pair db%d' % h)
+
+
+@pytest.mark.parametrize('N,H,Cin,Cout,p', [(2, 16, 256, 128, 2), (2, 32, 64, 64, 4), (3, 8, 32, 48, 1)])
+def test_patch_conv_pair(N, H, Cin, Cout, p):
+    """relu(conv(x, w_h) + b_h), kernel = stride = patch, for both hands on one shared map; the data gradient is the
+    un-patchified GEMM, summed over the hands."""
+    from renderih_amd import ops
+    d = dev()
+    x = rnd(N, Cin, H, H, seed=1)
+    w = rnd(2, Cout, Cin, p, p, seed=2, scale=1 / math.sqrt(Cin * p * p))
+    b = rnd(2, Cout, seed=3)
+    g = H // p
+    gy = rnd(2, N, g, g, Cout, seed=4)
+    ts = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    yr = torch.stack([nhwc(F.relu(F.conv2d(ts[0], ts[1][h], ts[2][h], stride=p))) for h in (0, 1)])
+    yr.backward(gy)
+    xg = _leaf(nhwc(x), d)
+    ps = [_leaf(t, d) for t in (w[0], w[1], b[0], b[1])]
+    yg = ops.PatchConvPairFn.apply(xg, *ps)
+    assert_close(yg, yr, what='patch_conv_pair y')
+    yg.backward(gy.to(d))
+    assert_close(nchw(xg.grad), ts[0].grad, 1e-3, 1e-4, 'patch_conv_pair dx')
+    for h in (0, 1):
+        assert_close(ps[h].grad, ts[1].grad[h], 1e-3, 1e-4, 'patch_conv_pair dw%d' % h)
+        assert_close(ps[2 + h].grad, ts[2].grad[h], 1e-3, 1e-4, 'patch_conv_pair db%d' % h)
+
+
+def test_cross_attention_stacked_and_rows_pair():
+    from renderih_amd import ops
+    d = dev()
+    B, V, D, h = 2, 63, 128, 4
+    qkv = rnd(2, B, V, 3 * D, seed=1)
+    g1 = rnd(2, B, V, D, seed=2)
+    a = _leaf(qkv, d)
+    o = ops.cross_attention_stacked(a, h)
+    b0, b1 = _leaf(qkv[0], d), _leaf(qkv[1], d)
+    r2l, l2r = ops.cross_attention_packed(b0, b1, h)
+    assert torch.equal(o[0], r2l) and torch.equal(o[1], l2r)
+    o.backward(g1.to(d))
+    (r2l * g1[0].to(d)).sum().backward(retain_graph=True)
+    (l2r * g1[1].to(d)).sum().backward()
+    assert_close(a.grad[0], b0.grad, 1e-5, 1e-6, 'cross stacked dL')
+    assert_close(a.grad[1], b1.grad, 1e-5, 1e-6, 'cross stacked dR')
+
+    x, e = rnd(2, 3, 64, 32, seed=3), rnd(2, 64, 32, seed=4)
+    xr, er = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
+    yr = xr + er[:, None]
+    gy = rnd(2, 3, 64, 32, seed=5)
+    yr.backward(gy)
+    xg, el, er_ = _leaf(x, d), _leaf(e[0], d), _leaf(e[1], d)
+    yg = ops.add_rows_pair(xg, el, er_)
+    assert_close(yg, yr, what='add_rows_pair')
+    yg.backward(gy.to(d))
+    assert_close(xg.grad, xr.grad, 1e-5, 1e-6, 'add_rows_pair dx')
+    assert_close(el.grad, er.grad[0], 1e-4, 1e-5, 'add_rows_pair de0')
+    assert_close(er_.grad, er.grad[1], 1e-4, 1e-5, 'add_rows_pair de1')
