@@ -183,11 +183,17 @@ def _wgrad(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_val
     # small weight matrices (decoder Linears, <= 4x4 tiles of 128): 64x64 tiles give 4x the resident slices per split
     small = _cdiv(Mp, 128) * _cdiv(Ncols, 128) <= 4
     tile = 3 if Ncols <= 32 else (2 if (Ncols <= 64 or Mp <= 64 or (ENGINE == 1 and small)) else 0)
+    if nb > 1 and ENGINE == 1 and Ncols > 32:
+        tile = 2            # paired decoder layers (tools/pair_sweep.py): 64x64 tiles win at every measured shape
     bm, bn = _TILE_MN[tile]
     tiles = _cdiv(Mp, bm) * _cdiv(Ncols, bn) * nb
-    # measured optimum of resident split-K slices (tools/tile_sweep.py): ~512 workgroups, 256 for a single tile
-    target = (256 if tiles == 1 else 512) if ENGINE == 1 else 1024
-    splitk = max(1, min(target // max(tiles, 1), _cdiv(Kpix, 128)))
+    if nb > 1 and ENGINE == 1:
+        # measured optimum (profiles/r01/pair_sweep_v15.log): k-chunks of ~320 pixels per slice, at most ~1024 workgroups
+        splitk = max(1, min(int(round(Kpix / 320.0)), 1024 // max(tiles, 1), _cdiv(Kpix, 128)))
+    else:
+        # measured optimum of resident split-K slices (tools/tile_sweep.py): ~512 workgroups, 256 for a single tile
+        target = (256 if tiles == 1 else 512) if ENGINE == 1 else 1024
+        splitk = max(1, min(target // max(tiles, 1), _cdiv(Kpix, 128)))
     kchunk = _cdiv(_cdiv(Kpix, splitk), 32) * 32
     splitk = _cdiv(Kpix, kchunk)
     part = torch.empty((nb, splitk, Mp, Ncols), device=x.device, dtype=torch.float32)
@@ -464,8 +470,24 @@ class PatchConvPairFn(torch.autograd.Function):
                   'rih_pack_conv_weight')
         y = torch.empty((2, N, g_h, g_w, Cout), device=x.device, dtype=torch.float32)
         geom = (H, W_, Cx, g_h, g_w, KH, KW, KH, 1, 0, 0)
-        gemm(x, wp, y, M, Cout, K, Cx, Cout, Cout, a_mode=0, b_mode=0, bias=bL, relu=True, geom=geom, nb1=2,
-             sA=(0, 0), sB=(K * Cout, 0), sC=(M * Cout, 0), sBias=_pdiff(bL, bR))
+        tile = plan_gemm(M, Cout, K, 2)[0]
+        bm, bn = _TILE_MN[tile]
+        tiles = _cdiv(M, bm) * _cdiv(Cout, bn) * 2
+        sk = max(1, min(_cdiv(K, 256), _cdiv(512, tiles))) if (K >= 1024 and tiles < 256) else 1
+        kc = _cdiv(_cdiv(K, sk), 32) * 32
+        sk = _cdiv(K, kc)
+        if sk > 1:
+            # long reduction, few output tiles (the 4x4 patches of the 32x32 map: K = 4096): split K over workgroups,
+            # finish (bias, ReLU) per hand
+            part = torch.empty((2, sk, M, Cout), device=x.device, dtype=torch.float32)
+            gemm(x, wp, part, M, Cout, K, Cx, Cout, Cout, a_mode=0, b_mode=0, geom=geom, nb1=2, sA=(0, 0),
+                 sB=(K * Cout, 0), sC=(sk * M * Cout, 0), splitk=sk, kchunk=kc, sCsplit=M * Cout, tile=tile)
+            for h, b in enumerate((bL, bR)):
+                check(_L().rih_splitk_finish(part[h].data_ptr(), sk, M, Cout, y[h].data_ptr(), Cout, b.data_ptr(), 0, 0,
+                                             1.0, 1, _stream()), 'rih_splitk_finish')
+        else:
+            gemm(x, wp, y, M, Cout, K, Cx, Cout, Cout, a_mode=0, b_mode=0, bias=bL, relu=True, geom=geom, nb1=2,
+                 sA=(0, 0), sB=(K * Cout, 0), sC=(M * Cout, 0), sBias=_pdiff(bL, bR), tile=tile)
         ctx.save_for_backward(x, wp, y)
         ctx.cfg = (tuple(wL.shape), geom)
         return y

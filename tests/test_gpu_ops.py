@@ -533,7 +533,8 @@ def test_layernorm_pair(rows, D, relu, x2, skip):
         assert_close(ps[2 + h].grad, ts[3].grad[h], 1e-3, 1e-4, 'layernorm_pair db%d' % h)
 
 
-@pytest.mark.parametrize('N,H,Cin,Cout,p', [(2, 16, 256, 128, 2), (2, 32, 64, 64, 4), (3, 8, 32, 48, 1)])
+@pytest.mark.parametrize('N,H,Cin,Cout,p', [(2, 16, 256, 128, 2), (2, 32, 64, 64, 4), (3, 8, 32, 48, 1),
+                                            (2, 16, 64, 48, 4)])     # the last one: K = 1024, two tiles -> forward split-K
 def test_patch_conv_pair(N, H, Cin, Cout, p):
     """relu(conv(x, w_h) + b_h), kernel = stride = patch, for both hands on one shared map; the data gradient is the
     un-patchified GEMM, summed over the hands."""
