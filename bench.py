@@ -178,6 +178,8 @@ def main():
         with torch.cuda.graph(graph):
             seed_word.add_(0x9E3779B1)
             static_loss = fwd_bwd()
+        if reducer is not None:
+            reducer.use_static_grads()              # replays rewrite these gradient buffers in place
 
         def step():
             graph.replay()                          # gradients are rewritten in place in the graph's static buffers

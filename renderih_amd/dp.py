@@ -30,6 +30,7 @@ class GradAllReducer:
             n += (p.numel() + 3) // 4 * 4               # keep every slice 16-byte aligned
         self.flat = torch.zeros(n, device=dev, dtype=dt)
         self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, self.params)]
+        self.static = None
         if broadcast_parameters and self.world > 1:
             with torch.no_grad():
                 buf = torch.cat([p.detach().reshape(-1) for p in self.params])
@@ -41,13 +42,21 @@ class GradAllReducer:
             for b in module.buffers():
                 dist.broadcast(b, 0, group=process_group)
 
+    def use_static_grads(self):
+        """Call once after a training step has been captured in a hipGraph (torch.cuda.graph) and before the first
+        `reduce()`: every replay rewrites the gradient tensors that exist NOW in place, so `reduce()` must keep
+        reading those buffers -- not `.grad`, which it rebinds to views of the bucket."""
+        self.static = [p.grad for p in self.params]
+
     @torch.no_grad()
     def reduce(self):
-        """Call after backward(): averages every existing `.grad` over the ranks (in place of the local gradient)."""
-        have = [i for i, p in enumerate(self.params) if p.grad is not None]
+        """Call after backward() (or after a graph replay): averages every existing gradient over the ranks and leaves
+        the result in `.grad` (a view into the bucket)."""
+        src = self.static if self.static is not None else [p.grad for p in self.params]
+        have = [i for i, g in enumerate(src) if g is not None]
         if len(have) != len(self.params):
             self.flat.zero_()                           # slots of grad-less parameters must contribute zeros
-        torch._foreach_copy_([self.views[i] for i in have], [self.params[i].grad for i in have])
+        torch._foreach_copy_([self.views[i] for i in have], [src[i] for i in have])
         if self.world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.mul_(1.0 / self.world)

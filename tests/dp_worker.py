@@ -45,6 +45,26 @@ def main():
                 assert float((p.grad - want).abs().max()) <= 1e-6 * float(want.abs().max() + 1e-30), k
             else:
                 assert p.grad is None, k
+        # (a') replayed steps (hipGraph): the graph rewrites fixed gradient buffers in place while `.grad` already points
+        # into the bucket -- the reducer must keep reading the buffers (bench.py: use_static_grads after capture)
+        m.zero_grad(set_to_none=True)
+        red2 = GradAllReducer(m, broadcast_parameters=False)
+        static = {}
+        for k, p in m.named_parameters():
+            if k in local:
+                static[k] = local[k].clone()
+                p.grad = static[k]
+        red2.use_static_grads()
+        for scale in (1.0, -3.0):                                      # "replay": new values land in the same buffers
+            for k in static:
+                static[k].copy_(local[k] * scale)
+            assert red2.reduce() == len(local)
+            for k, p in m.named_parameters():
+                if k in local:
+                    want = local[k].clone() * scale
+                    dist.all_reduce(want)
+                    want /= world
+                    assert float((p.grad - want).abs().max()) <= 1e-6 * float(want.abs().max() + 1e-30), (k, scale)
         # (b) torch DDP as the reference trainer wraps the model
         m.zero_grad(set_to_none=True)
         for mod in m.modules():                                        # undo the running-stat update of the first pass

@@ -197,8 +197,9 @@ def test_hrnet_matches_fp64_oracle(training):
 
 
 # ------------------------------------------------------------------------------------------------ hipGraph capture
-def _sgd_losses(m, img, steps, capture, dropout_seed=None):
-    """`steps` plain-SGD steps on the scalar loss; forward+backward either launched eagerly or replayed from a hipGraph."""
+def _sgd_losses(m, img, steps, capture, dropout_seed=None, reducer=None):
+    """`steps` plain-SGD steps on the scalar loss; forward+backward either launched eagerly or replayed from a hipGraph.
+    `reducer`: a GradAllReducer run between backward and the optimizer step, as bench.py does for N > 1."""
     from oracle.net_oracle import scalar_loss
     from renderih_amd import ops
     params = [p for p in m.parameters() if p.requires_grad]
@@ -233,9 +234,13 @@ def _sgd_losses(m, img, steps, capture, dropout_seed=None):
             if dropout_seed is not None:
                 dropout_seed.add_(7)
             static_loss = fwd_bwd()
+        if reducer is not None:
+            reducer.use_static_grads()
         for _ in range(steps):
             g.replay()
             losses.append(float(static_loss))
+            if reducer is not None:
+                reducer.reduce()
             opt.step()
         return losses
     finally:
@@ -255,6 +260,32 @@ def test_hipgraph_training_step_matches_eager():
     for a, b in zip(eager, graph):
         assert abs(a - b) <= 1e-6 * abs(a), (eager, graph)
     assert eager[0] != eager[1]                     # the optimizer really moved the weights
+    for (k, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p, q), k
+
+
+def test_hipgraph_replay_with_gradient_reducer_tracks_eager():
+    """bench.py's N > 1 step: graph replay -> GradAllReducer.reduce() (RCCL; world size 1 here, so the average is the
+    local gradient) -> optimizer.  `.grad` is rebound to the reducer's bucket after the first step while the graph keeps
+    writing its own buffers: the losses and the weights must still follow the eager trajectory step by step."""
+    import torch.distributed as dist
+    from renderih_amd.dp import GradAllReducer
+    img = testing.seeded_image(2, 21).cuda()
+    m1, _ = _build(0.0, seed=9)
+    m1.train()
+    eager = _sgd_losses(m1, img, 3, capture=False)
+    m2, _ = _build(0.0, seed=9)
+    m2.train()
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        graph = _sgd_losses(m2, img, 3, capture=True, reducer=GradAllReducer(m2))
+    finally:
+        dist.destroy_process_group()
+    for a, b in zip(eager, graph):
+        assert abs(a - b) <= 1e-6 * abs(a), (eager, graph)
+    assert eager[0] != eager[1] != eager[2]
     for (k, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
         assert torch.equal(p, q), k
 
