@@ -144,8 +144,8 @@ def main():
     B = args.batch
     img, lab = synth_batch(B, device, seed=rank)
 
-    def fwd_bwd():
-        out = net(img)
+    def fwd_bwd(module=None):
+        out = (net if module is None else module)(img)
         loss, _ = calc_loss_GCN_fused(fused_loss, 0, *out, lab['v2d_l'], lab['v2d_r'], lab['v3d_l'], lab['v3d_r'],
                                       lab['root_rel'])
         loss.backward()
@@ -211,7 +211,9 @@ def main():
     roof = None
     if not args.no_roofline and rank == 0:
         ops.PROFILE = []
-        step_eager()
+        opt.zero_grad(set_to_none=True)
+        fwd_bwd(model)  # local forward + loss + backward on the bare module: the other ranks are not in this block, so
+        #                 no collective may be issued here (no reducer, no DDP wrapper)
         torch.cuda.synchronize()
         recs = ops.PROFILE
         ops.PROFILE = None
