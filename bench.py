@@ -35,7 +35,12 @@ def measured_traffic():
     """HBM traffic of the rih_gemm family per step from the newest committed PMC collection (profiles/*/traffic_*.json;
     bench.py cannot run rocprofv3 on itself).  None when no collection is committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'traffic_*.json')))
+    import re
+
+    def version(path):      # profiles/rNN/traffic_vMM.json -> (NN, MM): newest round, newest collection
+        m = re.search(r'r(\d+)[/\\]traffic_v(\d+)\.json$', path)
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'traffic_*.json')), key=version)
     if not files:
         return None
     with open(files[-1]) as fh:
