@@ -58,13 +58,17 @@ def synth_batch(B, device, seed):
     return img.to(device), {k: v.to(device) for k, v in lab.items()}
 
 
-def cpu_baseline(seconds=20.0, batch=4):
+def cpu_baseline(seconds=20.0, batch=4, family='a'):
     """Oracle (CPU port of the reference path) forward+backward, bounded wall time."""
     from oracle import net_oracle
     from renderih_amd import assets
     from renderih_amd.model import build_model
     torch.manual_seed(0)
-    m = build_model(0.0)
+    if family == 'b':
+        from renderih_amd.lijun import build_graph_model
+        m = build_graph_model(0.0)
+    else:
+        m = build_model(0.0)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     for k, v in sd.items():
         if v.is_floating_point() and 'running' not in k and 'dense_coor' not in k:
@@ -94,6 +98,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--encoder', default='resnet50', choices=['resnet50', 'hrnet32'],
                     help='resnet50 = BASELINE configs[1]/[2] (the headline metric); hrnet32 = configs[3]')
+    ap.add_argument('--family', default='a', choices=['a', 'b'],
+                    help="a = models/model.py (the headline configuration); b = the reference's second family, "
+                         "common/myhand/lijun_model_graph.load_graph_model (SURVEY 8f rank 1; resnet50 only)")
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 64, hrnet32: 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -129,7 +136,13 @@ def main():
     from renderih_amd.manolayer import ManoLayer
 
     torch.manual_seed(0)
-    model = build_model(dropout=0.05, encoder_type=args.encoder).to(device).train()
+    if args.family == 'b':
+        if args.encoder != 'resnet50':
+            raise SystemExit('--family b is the resnet50 configuration of lijun_model_graph')
+        from renderih_amd.lijun import build_graph_model
+        model = build_graph_model(dropout=0.05).to(device).train()
+    else:
+        model = build_model(dropout=0.05, encoder_type=args.encoder).to(device).train()
     model.decoder.unsample_layer.weight.requires_grad_(False)          # core/gcn_trainer.py:102-103
     net = model
     reducer = None
@@ -249,12 +262,14 @@ def main():
                            'rows': rows, 'by_variant': by}, fh)
         top = max(by.items(), key=lambda kv: kv[1][1])
         gflop_img = GFLOP_PER_IMG_FWD_BWD if args.encoder == 'resnet50' else 88.5     # 3 x 29.49 (HRNet-W32)
+        if args.family == 'b':
+            gflop_img = 39.8        # 3 x 13.27 GFLOP/img forward (torch flop counter on the oracle)
         achieved = gflop_img * B / ms            # GFLOP / ms = TFLOP/s
         split = (ops.ENGINE == 1)
         peak = PEAK_BF16_MFMA_TF / 6.0 if split else PEAK_FP32_MFMA_TF
         roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                 'frac': round(achieved / peak, 4),
-                'traffic': measured_traffic() if args.encoder == 'resnet50' and B == 64 else None,
+                'traffic': measured_traffic() if args.encoder == 'resnet50' and B == 64 and args.family == 'a' else None,
                 'kernel': ('rih_gemm engine 1 (gemm_split_kernel / gemm_split256_kernel: fp32 = 6 x '
                            'v_mfma_f32_32x32x16_bf16 on a 3-term bf16 split; peak = 2500 TF/s bf16 dense / 6)'
                            if split else 'rih_gemm engine 0 (gemm_kernel, v_mfma_f32_32x32x2_f32)'),
@@ -269,7 +284,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(family=args.family)
 
     if rank == 0:
         n_img = B * world * args.steps
@@ -277,7 +292,10 @@ def main():
                 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': round(1000.0 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
                 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                'config': {'workload': ('BASELINE configs[1]: batch=%d/GPU 256x256 ResNet50 + cross-hand attention decoder, '
+                'config': {'workload': ('second model family (common/myhand/lijun_model_graph.load_graph_model): batch=%d/GPU '
+                                        '256x256 ResNet50 trunk + MLP-block dual-graph decoder, fwd + loss + bwd + Adam step, '
+                                        'dropout 0.05, fp32' % B) if args.family == 'b' else
+                           ('BASELINE configs[1]: batch=%d/GPU 256x256 ResNet50 + cross-hand attention decoder, '
                                         'fwd + loss + bwd + Adam step, dropout 0.05, fp32' % B) if args.encoder == 'resnet50'
                            else ('BASELINE configs[3] model: batch=%d/GPU 256x256 HRNet-W32 + cross-hand attention decoder, '
                                  'fwd + loss + bwd + Adam step, dropout 0.05, fp32' % B),

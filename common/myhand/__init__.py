@@ -1,7 +1,6 @@
-"""Drop-in import path: with this repository's root on sys.path in place of the reference's, the reference's
-callers (`apps/train_gcn.py`, `apps/eval_interhand.py`, `core/gcn_trainer.py`) import `models.model`,
-`models.manolayer`, `models.encoder`, `models.decoder` from here and get the MI355X-native implementations
-in `renderih_amd/`."""
+"""`common.myhand.{lijun_model_graph, encoder_lijun, decoder_lijun_graph}` of the reference, served by
+`renderih_amd.lijun` (MI355X-native).  Other `common.myhand.*` modules resolve to the reference checkout when it is on
+sys.path."""
 
 import os as _os
 import sys as _sys

@@ -300,6 +300,70 @@ def dual_graph(sd, p, Lf, Rf, fmaps, L_left, L_right):
     return Lf, Rf
 
 
+# ----------------------------------------------------------------------------- second model family (common/myhand)
+def lijun_mid_forward(sd, img_f, training, p='mid_model.'):
+    """common/myhand/encoder_lijun.py:139-146: global feature = avg-pool of the coarsest trunk map; every trunk map goes
+    through Conv1x1 -> ReLU -> BN (model_zoo/__init__.py:56-62)."""
+    gf = F.adaptive_avg_pool2d(img_f[0], 1).flatten(1)
+    fmaps = [_bn(sd, '%sconvs.%d.2.' % (p, i), F.relu(F.conv2d(x, sd['%sconvs.%d.0.weight' % (p, i)])), training)
+             for i, x in enumerate(img_f)]
+    return gf, fmaps
+
+
+def lijun_resblock(sd, p, x):
+    """common/myhand/model_attn/DualGraph_lijun.py:47-58 (MLP block; norm1 is live here)."""
+    x1 = _lin(sd, p + 'fc1.', F.relu(_ln(sd, p + 'norm1.', x)))
+    x1 = _lin(sd, p + 'fc2.', F.relu(_ln(sd, p + 'norm2.', x1)))
+    return _ln(sd, p + 'norm3.', x1 + _lin(sd, p + 'shortcut.', x))
+
+
+def lijun_graph_layer(sd, p, x, n=4):
+    """DualGraph_lijun.py:82-88."""
+    for i in range(n):
+        x = lijun_resblock(sd, '%sGCN_blocks.%d.' % (p, i), x)
+        if i != n - 1:
+            x = F.relu(x)
+    return x
+
+
+def lijun_inter_attn(sd, p, Lf, Rf, h=4):
+    """common/myhand/model_attn/inter_attn_lijun.py:79-125: both hands normalised from Lf+Rf; scores from each hand's own
+    q.k^T, values from the other hand."""
+    Lf = self_attn(sd, p + 'L_self_attn_layer.', Lf)
+    Rf = self_attn(sd, p + 'R_self_attn_layer.', Rf)
+    L2 = _ln(sd, p + 'layer_norm1.', Lf + Rf)
+    R2 = _ln(sd, p + 'layer_norm2.', Rf + Lf)
+    Lq, Lk, Lv = (_lin(sd, p + w, L2) for w in ('w_qs.', 'w_ks.', 'w_vs.'))
+    Rq, Rk, Rv = (_lin(sd, p + w, R2) for w in ('w_qs.', 'w_ks.', 'w_vs.'))
+    feat_R2L = _mha(Lq, Lk, Rv, h)      # softmax(Lq Lk^T) Rv   (:94,:110)
+    feat_L2R = _mha(Rq, Rk, Lv, h)      # softmax(Rq Rk^T) Lv   (:95,:109)
+    Lf = mlp_res(sd, p + 'ffL.', Lf + _lin(sd, p + 'fc.', feat_R2L))
+    Rf = mlp_res(sd, p + 'ffR.', Rf + _lin(sd, p + 'fc.', feat_L2R))
+    return Lf, Rf
+
+
+def lijun_dual_graph(sd, p, Lf, Rf, fmaps):
+    """DualGraph_lijun.py:136-163,197-207."""
+    patches = (1, 2, 4)
+    for i in range(3):
+        q = '%slayers.%d.' % (p, i)
+        pe = sd[q + 'position_embeddings.weight']
+        Lf = lijun_graph_layer(sd, q + 'graph_left.', Lf + pe)
+        Rf = lijun_graph_layer(sd, q + 'graph_right.', Rf + pe)
+        Lf = img_ex(sd, q + 'img_ex_left.', fmaps[i], Lf, patches[i])
+        Rf = img_ex(sd, q + 'img_ex_right.', fmaps[i], Rf, patches[i])
+        Lf, Rf = lijun_inter_attn(sd, q + 'attn.', Lf, Rf)
+        if i != 2:
+            Lf = Lf.repeat_interleave(2, dim=1)
+            Rf = Rf.repeat_interleave(2, dim=1)
+    return Lf, Rf
+
+
+def is_family_b(sd):
+    """lijun_model_graph.HandNET_GCN state: ResNet trunk, no auxiliary decoders, mid convs on the raw 2048-ch map."""
+    return 'encoder.resnet.conv1.weight' in sd and 'encoder.hms_decoder.final_layer.weight' not in sd
+
+
 def projection_batch(scale, trans2d, v, img_size=IMG_SIZE):
     """utils/manoutils.py:26-44."""
     s = (scale * img_size).view(-1, 1, 1)
@@ -307,8 +371,9 @@ def projection_batch(scale, trans2d, v, img_size=IMG_SIZE):
     return s * v[..., :2] + t
 
 
-def decoder_forward(sd, graph, gf, fmaps, p='decoder.'):
-    """models/decoder.py:128-174.  `graph` = dict(left=..., right=...) with dense 'L' list (63,126,252),
+def decoder_forward(sd, graph, gf, fmaps, p='decoder.', family_b=False):
+    """models/decoder.py:128-174; family_b=True: common/myhand/decoder_lijun_graph.py:247-300 (same heads on
+    DualGraph_lijun, `verts*_MANO_list` left empty).  `graph` = dict(left=..., right=...) with dense 'L' list (63,126,252),
     'perm' (1008) and 'perm_reverse' (778) as the reference ctor derives them (decoder.py:51-75)."""
     fmaps = fmaps[:-1]
     B = gf.shape[0]
@@ -319,8 +384,11 @@ def decoder_forward(sd, graph, gf, fmaps, p='decoder.'):
         pe = pe.view(63, 16, 3).mean(1)                          # graph_avg_pool p=16 (graph_utils.py:35-42)
         g = _ln(sd, '%sgf_layer_%s.1.' % (p, side), _lin(sd, '%sgf_layer_%s.0.' % (p, side), gf))
         feats[side] = torch.cat([g.unsqueeze(1).repeat(1, 63, 1), pe.unsqueeze(0).repeat(B, 1, 1)], -1)
-    Lf, Rf = dual_graph(sd, p + 'dual_gcn.', feats['left'], feats['right'], fmaps,
-                        graph['left']['L'], graph['right']['L'])
+    if family_b:
+        Lf, Rf = lijun_dual_graph(sd, p + 'dual_gcn.', feats['left'], feats['right'], fmaps)
+    else:
+        Lf, Rf = dual_graph(sd, p + 'dual_gcn.', feats['left'], feats['right'], fmaps,
+                            graph['left']['L'], graph['right']['L'])
     out = {'left': Lf, 'right': Rf}
     scale, trans2d, v3c, v2c, v3, v2, v3m, v2m = ({} for _ in range(8))
     for side in ('left', 'right'):
@@ -333,8 +401,8 @@ def decoder_forward(sd, graph, gf, fmaps, p='decoder.'):
         v3[side] = F.linear(v3c[side].transpose(1, 2), sd[p + 'unsample_layer.weight']).transpose(1, 2)
         v2[side] = projection_batch(scale[side], trans2d[side], v3[side])
         pr = graph[side]['perm_reverse']
-        v3m[side] = [v3c[side].repeat_interleave(4, dim=1)[:, pr]]
-        v2m[side] = [v2c[side].repeat_interleave(4, dim=1)[:, pr]]
+        v3m[side] = [] if family_b else [v3c[side].repeat_interleave(4, dim=1)[:, pr]]
+        v2m[side] = [] if family_b else [v2c[side].repeat_interleave(4, dim=1)[:, pr]]
     result = {'verts3d': v3, 'verts2d': v2}
     paramsDict = {'scale': scale, 'trans2d': trans2d}
     handDictList = [{'verts3d': v3c, 'verts2d': v2c}]
@@ -344,6 +412,13 @@ def decoder_forward(sd, graph, gf, fmaps, p='decoder.'):
 
 def handnet_forward(sd, graph, img, training=False, taps=None):
     """models/model.py:25-37 HandNET_GCN.forward (ResNet or HRNet encoder, told apart by the state-dict keys)."""
+    if is_family_b(sd):             # common/myhand/lijun_model_graph.py:26-33
+        x1, x2, x3, x4 = resnet_trunk(sd, img, training)
+        img_f = [x1, x2, x3, x4]
+        gf, fmaps = lijun_mid_forward(sd, img_f, training)
+        if taps is not None:
+            taps.update(x1=x1, x2=x2, x3=x3, x4=x4, gf=gf, fmap0=fmaps[0], fmap1=fmaps[1], fmap2=fmaps[2], fmap3=fmaps[3])
+        return decoder_forward(sd, graph, gf, fmaps, family_b=True)
     if 'encoder.hrnet.conv1.weight' in sd:
         hms, mask, dp, img_f, hms_f, dp_f = hrnet_encoder_forward(sd, img, training)
         gf, fmaps = hrnet_mid_forward(sd, img_f, training)
@@ -381,7 +456,8 @@ def scalar_loss(outputs):
         s = s + result['verts3d'][side].abs().sum() + 1e-2 * result['verts2d'][side].abs().sum()
         s = s + hd[0]['verts3d'][side].pow(2).sum() + 1e-4 * hd[0]['verts2d'][side].pow(2).sum()
         s = s + params['scale'][side].sum() + params['trans2d'][side].pow(2).sum()
-    s = s + 1e-3 * other['hms'].pow(2).sum() + 1e-3 * other['mask'].abs().sum() + 1e-3 * other['dense'].pow(2).sum()
+    if 'hms' in other:              # the second model family has no auxiliary heads
+        s = s + 1e-3 * other['hms'].pow(2).sum() + 1e-3 * other['mask'].abs().sum() + 1e-3 * other['dense'].pow(2).sum()
     return s
 
 
@@ -413,8 +489,10 @@ def run(sd, graph, img, training, dtype=torch.float32, with_grad=False):
         flat['params.trans2d.' + side] = params['trans2d'][side]
         flat['hand0.verts3d.' + side] = hd[0]['verts3d'][side]
         flat['hand0.verts2d.' + side] = hd[0]['verts2d'][side]
-        flat['other.verts3d_MANO.' + side] = other['verts3d_MANO_list'][side][0]
-        flat['other.verts2d_MANO.' + side] = other['verts2d_MANO_list'][side][0]
+        if other['verts3d_MANO_list'][side]:
+            flat['other.verts3d_MANO.' + side] = other['verts3d_MANO_list'][side][0]
+            flat['other.verts2d_MANO.' + side] = other['verts2d_MANO_list'][side][0]
     for k in ('hms', 'mask', 'dense'):
-        flat['other.' + k] = other[k]
+        if k in other:
+            flat['other.' + k] = other[k]
     return {k: v.detach() for k, v in flat.items()}, grads

@@ -41,8 +41,9 @@ class decoder(nn.Module):
     def __init__(self, global_feature_dim=2048, f_in_Dim=[256, 256, 256, 256], f_out_Dim=[128, 64, 32],
                  gcn_in_dim=[256, 128, 128], gcn_out_dim=[128, 128, 64], graph_k=2, graph_layer_num=4,
                  left_graph_dict={}, right_graph_dict={}, vertex_num=778, dense_coor=None, num_attn_heads=4,
-                 upsample_weight=None, dropout=0.05):
+                 upsample_weight=None, dropout=0.05, dual_graph_cls=DualGraph, mano_lists=True):
         super().__init__()
+        self.mano_lists = mano_lists        # family (b) (renderih_amd/lijun.py) leaves the *_MANO_list outputs empty
         assert len(f_in_Dim) == 4
         f_in_Dim = f_in_Dim[:-1]
         assert len(gcn_in_dim) == 3
@@ -76,7 +77,7 @@ class decoder(nn.Module):
             self._perm[hand_type] = (np.asarray(graph_dict[hand_type]['graph_perm'], dtype=np.int64),
                                      np.asarray(graph_dict[hand_type]['graph_perm_reverse'], dtype=np.int64)[:vertex_num])
 
-        self.dual_gcn = DualGraph(verts_in_dim=self.gcn_in_dim, verts_out_dim=self.gcn_out_dim,
+        self.dual_gcn = dual_graph_cls(verts_in_dim=self.gcn_in_dim, verts_out_dim=self.gcn_out_dim,
                                   graph_L_Left=graph_L['left'][:3], graph_L_Right=graph_L['right'][:3],
                                   graph_k=[graph_k] * 3, graph_layer_num=[graph_layer_num] * 3, img_size=[8, 16, 32],
                                   img_f_dim=f_in_Dim, grid_size=[8, 8, 8], grid_f_dim=f_out_Dim,
@@ -188,7 +189,7 @@ class decoder(nn.Module):
         handDictList = [{'verts3d': verts3d, 'verts2d': verts2d}]
 
         otherInfo = {'verts3d_MANO_list': {'left': [], 'right': []}, 'verts2d_MANO_list': {'left': [], 'right': []}}
-        for hand_type in ['left', 'right']:
+        for hand_type in (['left', 'right'] if self.mano_lists else []):
             p = self.vNum_all // self.vNum_out
             # graph_upsample(x, p) then GCN_to_vert (decoder.py:165-172) == one gather with idx = perm_reverse // p
             g = self._rowidx('mano_' + hand_type, self._perm[hand_type][1] // p, self.vNum_out, dev)

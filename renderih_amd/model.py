@@ -46,7 +46,7 @@ def _maybe_pickle(root, rel):
     return None
 
 
-def load_decoder(cfg, encoder_info, asset_root=None):
+def load_decoder(cfg, encoder_info, asset_root=None, decoder_cls=None, extra=None):
     """models/decoder.py:177-210.  Reads the reference's misc/*.pkl when present under `asset_root` (default:
     the repo root, like the reference); otherwise the packaged graph asset + seeded synthetic stand-ins."""
     root = asset_root or os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
@@ -58,7 +58,8 @@ def load_decoder(cfg, encoder_info, asset_root=None):
     up = _maybe_pickle(root, cfg.MISC.UPSAMPLE_PATH)
     if up is None:
         up = assets.synthetic_upsample_weight()
-    return Decoder(global_feature_dim=encoder_info['global_feature_dim'], f_in_Dim=encoder_info['fmaps_dim'],
+    return (decoder_cls or Decoder)(**(extra or {}), global_feature_dim=encoder_info['global_feature_dim'],
+                                    f_in_Dim=encoder_info['fmaps_dim'],
                    f_out_Dim=cfg.MODEL.IMG_DIMS, gcn_in_dim=cfg.MODEL.GCN_IN_DIM, gcn_out_dim=cfg.MODEL.GCN_OUT_DIM,
                    graph_k=cfg.MODEL.graph_k, graph_layer_num=cfg.MODEL.graph_layer_num, vertex_num=778,
                    dense_coor=dense, left_graph_dict=left, right_graph_dict=right, num_attn_heads=4,

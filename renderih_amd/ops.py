@@ -993,42 +993,48 @@ def cross_attention_packed(Lqkv, Rqkv, heads, drop_p=0.0, seed_r2l=0, seed_l2r=0
 
 class CrossAttentionStackedFn(torch.autograd.Function):
     """CrossAttentionPackedFn on the hands-stacked projection qkv [2,B,V,3D] -> [2,B,V,D]: slice 0 = feat_R2L (left
-    queries over right keys / values), slice 1 = feat_L2R."""
+    queries over right keys / values), slice 1 = feat_L2R.
+    own_keys=True is the second model family's variant (inter_attn_lijun.py:94-112): the scores are each hand's OWN
+    q.k^T, only the values come from the other hand: slice 0 = softmax(Lq Lk^T) Rv, slice 1 = softmax(Rq Rk^T) Lv."""
 
     @staticmethod
-    def forward(ctx, qkv, heads, drop_p, seed_r2l, seed_l2r):
+    def forward(ctx, qkv, heads, drop_p, seed_r2l, seed_l2r, own_keys):
         _chk(qkv)
         qkv = _c(qkv)
         _, B, V, D3 = qkv.shape
         D = D3 // 3
         l0, r0 = qkv[0].data_ptr(), qkv[1].data_ptr()
+        kl, kr = (l0, r0) if own_keys else (r0, l0)         # whose keys the left / the right queries see
         out = torch.empty((2, B, V, D), device=qkv.device, dtype=torch.float32)
-        _, P1, Pd1 = _attn_forward(l0, D3, r0 + 4 * D, r0 + 8 * D, D3, B, V, V, D, heads, drop_p, seed_r2l, qkv.device,
+        _, P1, Pd1 = _attn_forward(l0, D3, kl + 4 * D, r0 + 8 * D, D3, B, V, V, D, heads, drop_p, seed_r2l, qkv.device,
                                    out=out[0])
-        _, P2, Pd2 = _attn_forward(r0, D3, l0 + 4 * D, l0 + 8 * D, D3, B, V, V, D, heads, drop_p, seed_l2r, qkv.device,
+        _, P2, Pd2 = _attn_forward(r0, D3, kr + 4 * D, l0 + 8 * D, D3, B, V, V, D, heads, drop_p, seed_l2r, qkv.device,
                                    out=out[1])
         ctx.save_for_backward(qkv, P1, Pd1, P2, Pd2)
-        ctx.cfg = (heads, drop_p, seed_r2l, seed_l2r)
+        ctx.cfg = (heads, drop_p, seed_r2l, seed_l2r, own_keys)
         return out
 
     @staticmethod
     def backward(ctx, do):
         qkv, P1, Pd1, P2, Pd2 = ctx.saved_tensors
-        heads, drop_p, seed_r2l, seed_l2r = ctx.cfg
+        heads, drop_p, seed_r2l, seed_l2r, own_keys = ctx.cfg
         do = _c(do)
         _, B, V, D3 = qkv.shape
         D = D3 // 3
         dqkv = torch.empty_like(qkv)
         l0, r0, gl, gr = qkv[0].data_ptr(), qkv[1].data_ptr(), dqkv[0].data_ptr(), dqkv[1].data_ptr()
-        _attn_backward(do[0], l0, D3, r0 + 4 * D, r0 + 8 * D, D3, gl, D3, gr + 4 * D, gr + 8 * D, D3, P1, Pd1, B, V, V, D,
+        kl, kr, gkl, gkr = (l0, r0, gl, gr) if own_keys else (r0, l0, gr, gl)
+        # every slot of dqkv is written exactly once: q by its own direction, k by the direction that read it, v by
+        # the other hand's direction
+        _attn_backward(do[0], l0, D3, kl + 4 * D, r0 + 8 * D, D3, gl, D3, gkl + 4 * D, gr + 8 * D, D3, P1, Pd1, B, V, V, D,
                        heads, drop_p, seed_r2l)
-        _attn_backward(do[1], r0, D3, l0 + 4 * D, l0 + 8 * D, D3, gr, D3, gl + 4 * D, gl + 8 * D, D3, P2, Pd2, B, V, V, D,
+        _attn_backward(do[1], r0, D3, kr + 4 * D, l0 + 8 * D, D3, gr, D3, gkr + 4 * D, gl + 8 * D, D3, P2, Pd2, B, V, V, D,
                        heads, drop_p, seed_l2r)
-        return dqkv, None, None, None, None
+        return dqkv, None, None, None, None, None
 
 
-def cross_attention_stacked(qkv, heads, drop_p=0.0, seed_r2l=0, seed_l2r=0):
-    return CrossAttentionStackedFn.apply(qkv, heads, drop_p, seed_r2l, seed_l2r)
+def cross_attention_stacked(qkv, heads, drop_p=0.0, seed_r2l=0, seed_l2r=0, own_keys=False):
+    return CrossAttentionStackedFn.apply(qkv, heads, drop_p, seed_r2l, seed_l2r, own_keys)
 
 
 class AddRowsPairFn(torch.autograd.Function):

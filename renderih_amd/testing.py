@@ -68,10 +68,12 @@ def flatten_outputs(outputs):
         flat['params.trans2d.' + side] = params['trans2d'][side]
         flat['hand0.verts3d.' + side] = hd[0]['verts3d'][side]
         flat['hand0.verts2d.' + side] = hd[0]['verts2d'][side]
-        flat['other.verts3d_MANO.' + side] = other['verts3d_MANO_list'][side][0]
-        flat['other.verts2d_MANO.' + side] = other['verts2d_MANO_list'][side][0]
+        if other['verts3d_MANO_list'][side]:           # empty in the second model family (renderih_amd/lijun.py)
+            flat['other.verts3d_MANO.' + side] = other['verts3d_MANO_list'][side][0]
+            flat['other.verts2d_MANO.' + side] = other['verts2d_MANO_list'][side][0]
     for k in ('hms', 'mask', 'dense'):
-        flat['other.' + k] = other[k]
+        if k in other:
+            flat['other.' + k] = other[k]
     return flat
 
 

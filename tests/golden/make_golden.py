@@ -10,6 +10,8 @@ Fixtures:
       (renderih_amd.testing.deterministic_state), eval mode / train mode with dropout=0.
       Outputs of the forward 4-tuple (full for small tensors, signature for big ones), tapped
       intermediates, and for train: scalar loss, parameter-gradient signatures, BN running stats.
+  net_lijun_eval.npz / net_lijun_train.npz, state_keys_lijun.json : the second model family
+      (common/myhand/lijun_model_graph.HandNET_GCN), same recipe.
   mano_*.npz : reference ManoLayer on a synthetic MANO-shaped pickle, several call conventions,
       outputs and input gradients.
 """
@@ -289,13 +291,105 @@ def keys_fixture():
         print('wrote', path, len(sch), 'keys')
 
 
+def build_reference_model_b(dropout=0.0):
+    """The reference's second family: common/myhand/lijun_model_graph.HandNET_GCN as `load_graph_model` assembles it
+    (lijun_model_graph.py:36-53; mano_flag=True as in main/config.py:80), on the packaged graph assets."""
+    import types
+    ref_stubs.install_family_b(assets)
+    torch.Tensor.cuda = lambda self, *a, **k: self          # the decoder ctor moves MANO tables to the GPU (unused here)
+    import common.myhand.lijun_model_graph as lm                         # reference
+    from common.myhand.encoder_lijun import ResNetSimple as EncB, resnet_mid as MidB      # reference
+    from common.myhand.decoder_lijun_graph import decoder as DecB        # reference
+    enc = EncB(model_type='resnet50', pretrained=True, fmapDim=[128] * 4, handNum=2, heatmapDim=21)
+    mid = MidB(model_type='resnet50', in_fmapDim=[2048, 1024, 512, 256], out_fmapDim=[256] * 4)
+    cfg = types.SimpleNamespace(render=False, edge=True, normal=True, vert2d=True, dice=False)
+    dec = DecB(cfg, global_feature_dim=2048, f_in_Dim=[256] * 4, f_out_Dim=[256, 128, 64],
+               gcn_in_dim=[512, 256, 128], gcn_out_dim=[256, 128, 64], graph_k=2, graph_layer_num=4,
+               left_graph_dict=assets.load_graph_dict('left'), right_graph_dict=assets.load_graph_dict('right'),
+               vertex_num=778, dense_coor=assets.synthetic_dense_coor(), num_attn_heads=4,
+               upsample_weight=torch.from_numpy(assets.synthetic_upsample_weight()), dropout=dropout, mano_flag=True)
+    return lm.HandNET_GCN(enc, mid, dec, False)
+
+
+def lijun_fixture(mode):
+    """net_lijun_eval.npz / net_lijun_train.npz: the second family, B=2, seeded image + weights; outputs, taps and (train)
+    scalar loss, parameter-gradient signatures, BN running statistics."""
+    torch.manual_seed(0)
+    model = build_reference_model_b(dropout=0.0)
+    sd = testing.deterministic_state(model.state_dict(), seed=4)
+    model.load_state_dict(sd)
+    model.train(mode == 'train')
+    img = testing.seeded_image(2, seed=5)
+    taps = {}
+    hs = []
+    for nm, mod in (('x1', model.encoder.resnet.layer4), ('x4', model.encoder.resnet.layer1),
+                    ('fmap0', model.mid_model.convs[0]), ('fmap2', model.mid_model.convs[2]),
+                    ('gcn0_left', model.decoder.dual_gcn.layers[0].graph_left),
+                    ('imgex0_right', model.decoder.dual_gcn.layers[0].img_ex_right)):
+        hs.append(mod.register_forward_hook(lambda m, i, o, nm=nm: taps.__setitem__(nm, o)))
+
+    def dgl_hook(idx):
+        def f(m, i, o):
+            taps['dgl%d_L' % idx], taps['dgl%d_R' % idx] = o
+        return f
+    for i in range(3):
+        hs.append(model.decoder.dual_gcn.layers[i].register_forward_hook(dgl_hook(i)))
+    store = {}
+    if mode == 'eval':
+        with torch.no_grad():
+            out = model(img)
+    else:
+        out = model(img)
+    for h in hs:
+        h.remove()
+    assert out[3]['verts3d_MANO_list'] == {'left': [], 'right': []}
+    for k, v in testing.flatten_outputs(out).items():
+        pack(store, 'out/' + k, v)
+    for k, v in taps.items():
+        pack(store, 'tap/' + k, v)
+    if mode == 'train':
+        loss = net_oracle.scalar_loss(out)
+        loss.backward()
+        store['loss'] = np.float64(loss.item())
+        names = []
+        for k, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            names.append(k)
+            st, sa = testing.signature(p.grad, nsamp=32)
+            store['grad/' + k + '#stats'] = st
+            store['grad/' + k + '#samp'] = sa
+        store['grad_names'] = np.array(names)
+        nsd = model.state_dict()
+        for k in ('encoder.resnet.bn1.running_mean', 'encoder.resnet.layer4.2.bn3.running_var',
+                  'mid_model.convs.0.2.running_mean', 'mid_model.convs.3.2.running_var',
+                  'encoder.resnet.bn1.num_batches_tracked'):
+            store['bnstat/' + k] = nsd[k].numpy()
+    path = os.path.join(HERE, 'net_lijun_%s.npz' % mode)
+    np.savez_compressed(path, **store)
+    print('wrote', path, os.path.getsize(path), 'bytes,', len(store), 'arrays')
+
+
+def lijun_keys_fixture():
+    import json
+    sch = {k: list(v.shape) for k, v in build_reference_model_b(0.05).state_dict().items()}
+    path = os.path.join(HERE, 'state_keys_lijun.json')
+    with open(path, 'w') as f:
+        json.dump(sch, f)
+    print('wrote', path, len(sch), 'keys')
+
+
 def zlibseed(s):
     import zlib
     return zlib.crc32(s.encode()) & 0x7FFFFFFF
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['eval', 'train', 'mano', 'keys', 'hrnet', 'loss']
+    which = sys.argv[1:] or ['eval', 'train', 'mano', 'keys', 'hrnet', 'loss', 'lijun']
+    if 'lijun' in which:
+        lijun_keys_fixture()
+        lijun_fixture('eval')
+        lijun_fixture('train')
     if 'loss' in which:
         loss_fixture()
     if 'hrnet' in which:

@@ -147,3 +147,54 @@ def install():
         scipy.sparse.csr = csr
     if REF not in sys.path:
         sys.path.insert(0, REF)
+
+
+def install_family_b(assets):
+    """Extra shims for the reference's second model family (common/myhand/lijun_model_graph.py and friends): the MANO
+    wrapper (needs the licence-gated pickles and `manopth`), the trainer's global config (creates directories on import)
+    and the mmcv focal loss are replaced by stand-ins; none of them takes part in the network forward that the
+    fixtures record (decoder_lijun_graph.py:247-300 never calls them)."""
+    import numpy as np
+    install()
+
+    cfgm = types.ModuleType('main.config')
+    cfgm.cfg = types.SimpleNamespace(mano_flag=True, render=False, normal=True, edge=True, vert2d=True, dice=False,
+                                     sdf=False, lambda_sdf=1000000, lambda_render=100, lambda_normal=10,
+                                     lambda_edge=100, sdf_thresh=0.01, data_type='interhand_dataaug', mano_path='')
+    main = types.ModuleType('main')
+    main.config = cfgm
+    sys.modules.setdefault('main', main)
+    sys.modules.setdefault('main.config', cfgm)
+
+    class _Layer:
+        def __init__(self, side):
+            d = assets.synthetic_mano_dict(side)
+            self.faces = np.asarray(d['f'])
+            self.shapedirs = torch.from_numpy(np.asarray(d['shapedirs'], np.float32))
+            self.J_regressor = torch.from_numpy(np.asarray(d['J_regressor'].todense(), np.float32))
+
+        def cuda(self):
+            return self
+
+    class MANO(nn.Module):
+        def __init__(self, hand_type='right'):
+            super().__init__()
+            self.hand_type = hand_type
+            self.layer = _Layer(hand_type)
+
+    class Jr:
+        def __init__(self, J_regressor, device='cpu'):
+            self.J_regressor = J_regressor
+
+        def __call__(self, v):
+            return torch.matmul(self.J_regressor, v)
+
+    mano = types.ModuleType('common.utils.mano')
+    mano.MANO, mano.Jr = MANO, Jr
+    sys.modules.setdefault('common.utils.mano', mano)
+    fl = types.ModuleType('common.utils.focal_loss')
+    fl.FocalLoss = type('FocalLoss', (nn.Module,), {})
+    sys.modules.setdefault('common.utils.focal_loss', fl)
+    bb = types.ModuleType('common.myhand.bbox_decoder')
+    bb.load_decoder_cliff = lambda *a, **k: None
+    sys.modules.setdefault('common.myhand.bbox_decoder', bb)

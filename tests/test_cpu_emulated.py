@@ -172,6 +172,33 @@ def test_model_host_logic_matches_oracle():
     assert int(m.encoder.resnet.bn1.num_batches_tracked) == 1
 
 
+def test_family_b_host_logic_matches_oracle():
+    """Second model family (renderih_amd/lijun.py = common/myhand/lijun_model_graph.HandNET_GCN), B=2, train mode,
+    dropout 0: forward outputs and all parameter gradients against the oracle, fp64-anchored like the first family."""
+    from oracle import net_oracle
+    from renderih_amd.lijun import build_graph_model
+    m = build_graph_model(0.0)
+    sd = testing.deterministic_state(m.state_dict(), seed=11)       # a draw without near-zero ReLU inputs that flip
+    m.load_state_dict(sd)                                            # between fp32 evaluation orders (_grad_report)
+    m.train()
+    img = testing.seeded_image(2, 12)
+    out = m(img)
+    assert out[3]['verts3d_MANO_list'] == {'left': [], 'right': []} and 'hms' not in out[3]
+    got = testing.flatten_outputs(out)
+    graph = net_oracle.graph_from_dicts(assets.load_graph_dict('left'), assets.load_graph_dict('right'))
+    w32, g32 = net_oracle.run(sd, graph, img, True, torch.float32, True)
+    w64, g64 = net_oracle.run(sd, graph, img, True, torch.float64, True)
+    assert set(got) == set(w64)
+    for k in w64:
+        testing.assert_fp32_equivalent(got[k], w32[k], w64[k], what=k)
+    net_oracle.scalar_loss(out).backward()
+    from test_gpu_model import _grad_report
+    params = [(k, p.grad) for k, p in m.named_parameters() if p.grad is not None]
+    assert {k for k, _ in params} == set(g64.keys())
+    _grad_report(params, g32, g64)
+    assert int(m.encoder.resnet.bn1.num_batches_tracked) == 1
+
+
 def _unflatten(f):
     sides = ('left', 'right')
     return ({'verts3d': {s: f['result.verts3d.' + s] for s in sides}, 'verts2d': {s: f['result.verts2d.' + s] for s in sides}},

@@ -69,9 +69,23 @@ def test_state_dict_schema_equals_reference_hrnet32():
     assert {k: list(v.shape) for k, v in sd.items()} == ref
 
 
+def test_state_dict_schema_equals_reference_family_b():
+    """common/myhand/lijun_model_graph.load_graph_model (mano_flag=True, main/config.py:80): same keys, order, shapes."""
+    from renderih_amd.lijun import build_graph_model
+    ref = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'state_keys_lijun.json')))
+    sd = build_graph_model(0.05).state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    assert {k: list(v.shape) for k, v in sd.items()} == ref
+
+
 def test_dropin_import_paths_and_config(tmp_path):
     import models.model as mm
     import models.manolayer as ml
+    import common.myhand.lijun_model_graph as lg
+    import common.myhand.encoder_lijun as le
+    import common.myhand.decoder_lijun_graph as ld
+    assert callable(lg.load_graph_model) and lg.HandNET_GCN.__module__ == 'renderih_amd.lijun'
+    assert callable(le.load_encoder) and callable(ld.load_decoder) and hasattr(ld, 'ParamRegressor')
     from renderih_amd.config import load_cfg
     assert mm.Model is mm.HandNET_GCN and callable(mm.load_model)
     assert hasattr(ml, 'ManoLayer') and hasattr(ml, 'rodrigues_batch')

@@ -322,3 +322,72 @@ def test_paired_decoder_equals_sequential_on_gpu(monkeypatch):
             outs[pair] = {k: v.cpu() for k, v in testing.flatten_outputs(m(img)).items()}
     for k in outs[False]:
         assert_close(outs[True][k], outs[False][k], 1e-4, 1e-5, 'paired vs sequential ' + k)
+
+
+# ------------------------------------------------------------------------------ second model family
+def _build_b(dropout=0.0, seed=4):
+    from renderih_amd import _lib
+    from renderih_amd.lijun import build_graph_model
+    _lib.load()
+    m = build_graph_model(dropout)
+    sd = testing.deterministic_state(m.state_dict(), seed=seed)
+    m.load_state_dict(sd)
+    return m.to('cuda:0'), sd
+
+
+def test_family_b_eval_matches_reference_golden():
+    """common/myhand/lijun_model_graph.HandNET_GCN, eval mode: strict 1e-4 parity with vectors the real reference
+    modules produced (tests/golden/make_golden.py lijun)."""
+    z = np.load(os.path.join(GOLDEN, 'net_lijun_eval.npz'))
+    m, _ = _build_b(0.0)
+    m.eval()
+    with torch.no_grad():
+        out = m(testing.seeded_image(2, 5).cuda())
+    assert out[3]['verts3d_MANO_list'] == {'left': [], 'right': []} and 'hms' not in out[3]
+    flat = testing.flatten_outputs(out)
+    assert {('out/' + k) for k in flat} == {k.split('#')[0] for k in z.files if k.startswith('out/')}
+    for k, v in flat.items():
+        _check_golden(z, 'out/' + k, v)
+
+
+def test_family_b_train_matches_reference_golden():
+    """Train mode, B=2 (ill conditioned, see test_model_train_matches_reference_golden): forward, loss, the set of
+    parameters that receive gradients, BatchNorm running statistics."""
+    z = np.load(os.path.join(GOLDEN, 'net_lijun_train.npz'))
+    m, _ = _build_b(0.0)
+    m.train()
+    out = m(testing.seeded_image(2, 5).cuda())
+    for k, v in testing.flatten_outputs(out).items():
+        _check_golden(z, 'out/' + k, v, 2e-3, 1e-3)
+    from oracle.net_oracle import scalar_loss
+    loss = scalar_loss(out)
+    assert abs(loss.item() - float(z['loss'])) <= 1e-3 * abs(float(z['loss']))
+    loss.backward()
+    names = [str(n) for n in z['grad_names']]
+    got = {k for k, p in m.named_parameters() if p.grad is not None}
+    assert set(names) == got, sorted(set(names) ^ got)[:10]
+    sd = m.state_dict()
+    for k in z.files:
+        if k.startswith('bnstat/'):
+            assert_close(sd[k[7:]].float(), torch.from_numpy(np.asarray(z[k])).float(), 1e-3, 1e-4, k)
+
+
+@pytest.mark.parametrize('training', [False, True])
+def test_family_b_matches_fp64_oracle(training):
+    """Forward outputs and every parameter gradient of the second family vs the CPU oracle, anchored on its fp64 run."""
+    from oracle import net_oracle
+    m, sd = _build_b(0.0, seed=11)
+    m.train(training)
+    img = testing.seeded_image(2, 12)
+    graph = net_oracle.graph_from_dicts(assets.load_graph_dict('left'), assets.load_graph_dict('right'))
+    w32, g32 = net_oracle.run(sd, graph, img, training, torch.float32, True)
+    w64, g64 = net_oracle.run(sd, graph, img, training, torch.float64, True)
+    out = m(img.cuda())
+    got = testing.flatten_outputs(out)
+    assert set(got) == set(w64)
+    for k in w64:
+        testing.assert_fp32_equivalent(got[k], w32[k], w64[k], k=4.0, floor=2e-5, what=k)
+    net_oracle.scalar_loss(out).backward()
+    params = [(k, p.grad) for k, p in m.named_parameters() if p.grad is not None]
+    assert {k for k, _ in params} == set(g64.keys())
+    _grad_report(params, g32, g64)
