@@ -294,6 +294,20 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
 int rih_version(void);
 const char* rih_arch(void);
 
+/* ------------------------------------------------------------------------------------------------
+ * Evaluation metrics of one hand (apps/eval_interhand.py:334-415, common/utils/intag_eval.py:92-143,217-283):
+ * joints = Jreg [NJ][V] x vertices unless given (j_pred / j_gt may be NULL), both point sets made relative to joint
+ * `root_idx`, prediction rescaled by |gt bone| / |pred bone| (bone = joints bone_a, bone_b);
+ *   j_err_ori [B][NJ], v_err_ori [B][V]   |pred - gt| before rescaling      (any of the four may be NULL)
+ *   j_err     [B][NJ], v_err     [B][V]   |pred * scale - gt|
+ *   pa        [B][2]                      Procrustes-aligned mean joint / vertex error (PA-MPJPE, PA-MPVPE): optimal
+ *                                         similarity transform of the root-relative prediction onto the ground truth
+ *   j_pred_out [B][NJ][3] (may be NULL)   the joints regressed from v_pred
+ * V <= 1024, NJ <= 32.  One workgroup per image; no workspace. */
+int rih_hand_metrics(const float* v_pred, const float* v_gt, const float* j_pred, const float* j_gt, const float* Jreg,
+                     int B, int V, int NJ, int root_idx, int bone_a, int bone_b, float* j_err_ori, float* v_err_ori,
+                     float* j_err, float* v_err, float* pa, float* j_pred_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

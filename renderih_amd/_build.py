@@ -9,7 +9,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'librenderih_amd.so')
-SOURCES = ['rih_gemm.hip', 'rih_elem.hip', 'rih_mano.hip', 'rih_loss.hip']
+SOURCES = ['rih_gemm.hip', 'rih_elem.hip', 'rih_mano.hip', 'rih_loss.hip', 'rih_metrics.hip']
+HEADERS = ['rih_procrustes.h']
 
 
 def hipcc():
@@ -23,7 +24,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, '..', 'include', 'renderih_amd.h')]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(HERE, '..', 'include', 'renderih_amd.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -45,6 +45,7 @@ class MeshTopo(C.Structure):
 
 # name -> (restype, argtypes); must list every symbol include/renderih_amd.h declares
 SIGNATURES = {
+    'rih_hand_metrics': (c_i, [c_f] * 5 + [c_i] * 6 + [c_f] * 6 + [C.c_void_p]),
     'rih_gemm': (c_i, [C.POINTER(GemmDesc), C.c_void_p]),
     'rih_splitk_reduce': (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
     'rih_splitk_reduce_bias_batched': (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_l, c_l, c_l,

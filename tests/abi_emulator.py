@@ -186,6 +186,40 @@ class EmulatedLib:
         _f(dst, out.size)[:] = out.ravel()
         return 0
 
+    # ------------------------------------------------------------------ evaluation metrics
+    def rih_hand_metrics(self, v_pred, v_gt, j_pred, j_gt, Jreg, B, V, NJ, root_idx, bone_a, bone_b, j_err_ori, v_err_ori,
+                         j_err, v_err, pa, j_pred_out, stream):
+        vp = _f(v_pred, B * V * 3).reshape(B, V, 3).astype(np.float64)
+        vg = _f(v_gt, B * V * 3).reshape(B, V, 3).astype(np.float64)
+        J = _f(Jreg, NJ * V).reshape(NJ, V).astype(np.float64) if Jreg else None
+        jp = _f(j_pred, B * NJ * 3).reshape(B, NJ, 3).astype(np.float64) if j_pred else J @ vp
+        jg = _f(j_gt, B * NJ * 3).reshape(B, NJ, 3).astype(np.float64) if j_gt else J @ vg
+        if j_pred_out:
+            _f(j_pred_out, B * NJ * 3)[:] = jp.ravel()
+        rp, rg = jp[:, root_idx:root_idx + 1], jg[:, root_idx:root_idx + 1]
+        sc = (np.linalg.norm(jg[:, bone_a] - jg[:, bone_b], axis=-1) /
+              np.linalg.norm(jp[:, bone_a] - jp[:, bone_b], axis=-1)).reshape(B, 1, 1)
+        P = _f(pa, B * 2).reshape(B, 2)
+        for k, (x1, x2, eo, es) in enumerate(((jp - rp, jg - rg, j_err_ori, j_err), (vp - rp, vg - rg, v_err_ori, v_err))):
+            n = x1.shape[1]
+            if eo:
+                _f(eo, B * n)[:] = np.linalg.norm(x1 - x2, axis=-1).ravel()
+            if es:
+                _f(es, B * n)[:] = np.linalg.norm(x1 * sc - x2, axis=-1).ravel()
+            for b in range(B):          # Procrustes through the SVD (the kernel takes Horn's quaternion route)
+                a, g = x1[b].T, x2[b].T
+                mu1, mu2 = a.mean(1, keepdims=True), g.mean(1, keepdims=True)
+                X1, X2 = a - mu1, g - mu2
+                K = X1 @ X2.T
+                U, _, Vh = np.linalg.svd(K)
+                Z = np.eye(3)
+                Z[2, 2] = np.sign(np.linalg.det(U @ Vh))
+                R = Vh.T @ Z @ U.T
+                s = np.trace(R @ K) / (X1 ** 2).sum()
+                hat = s * (R @ a) + (mu2 - s * (R @ mu1))
+                P[b, k] = np.linalg.norm(hat - g, axis=0).mean()
+        return 0
+
     # ------------------------------------------------------------------ fused mesh loss
     def rih_mesh_loss(self, tp, v3p, v2p, c3p, c2p, v3g, v2g, shift, w, img, g3, g2, gc3, gc2, partial, B, stream):
         tp = tp._obj

@@ -379,13 +379,65 @@ def lijun_keys_fixture():
     print('wrote', path, len(sch), 'keys')
 
 
+def metrics_fixture():
+    """metrics.npz: the reference's evaluation helpers (common/utils/intag_eval.py: Jr, eval_hand2,
+    batch_compute_similarity_transform_torch) on seeded prediction / ground-truth meshes of both hands."""
+    import types
+    tv = sys.modules['torchvision']
+    if not hasattr(tv, 'transforms'):
+        tv.transforms = types.ModuleType('torchvision.transforms')
+        sys.modules['torchvision.transforms'] = tv.transforms
+    import common.utils.intag_eval as ie                              # reference
+    g = torch.Generator().manual_seed(77)
+    B = 5
+    store = {}
+    lists = [{'left': [], 'right': []} for _ in range(4)]
+    data = {}
+    for side in ('left', 'right'):
+        md = assets.synthetic_mano_dict(side)
+        J16 = torch.from_numpy(np.asarray(md['J_regressor'].todense(), np.float32))
+        jr = ie.Jr(J16, device='cpu')
+        v_gt = torch.from_numpy(np.asarray(md['v_template'], np.float32)).unsqueeze(0).repeat(B, 1, 1) \
+            + 0.01 * torch.randn(B, 778, 3, generator=g) + 0.3 * torch.randn(B, 1, 3, generator=g)
+        # prediction = rotated, scaled, shifted, noisy ground truth (so that the alignment has work to do)
+        A = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))[0]
+        A = A * torch.sign(torch.det(A)).view(-1, 1, 1)
+        v_pred = (v_gt @ A.transpose(1, 2)) * (0.8 + 0.4 * torch.rand(B, 1, 1, generator=g)) \
+            + 0.05 * torch.randn(B, 1, 3, generator=g) + 0.004 * torch.randn(B, 778, 3, generator=g)
+        j_gt, j_pred = jr(v_gt), jr(v_pred)
+        data[side] = (v_gt, v_pred, j_gt, j_pred)
+        store['in/Jreg_' + side] = jr.J_regressor.numpy()
+        store['in/J16_' + side] = J16.numpy()
+        store['in/v_gt_' + side], store['in/v_pred_' + side] = v_gt.numpy(), v_pred.numpy()
+        store['out/j_gt_' + side], store['out/j_pred_' + side] = j_gt.numpy(), j_pred.numpy()
+        # PA errors exactly as apps/eval_interhand.py:388-407 (root = joint 0)
+        jp0, jg0 = j_pred - j_pred[:, 0:1], j_gt - j_gt[:, 0:1]
+        vp0, vg0 = v_pred - j_pred[:, 0:1], v_gt - j_gt[:, 0:1]
+        hat = ie.batch_compute_similarity_transform_torch(jp0, jg0)
+        store['out/pa_mpjpe_' + side] = torch.sqrt(((hat - jg0) ** 2).sum(-1)).mean(-1).numpy()
+        hat = ie.batch_compute_similarity_transform_torch(vp0, vg0)
+        store['out/pa_mpvpe_' + side] = torch.sqrt(((hat - vg0) ** 2).sum(-1)).mean(-1).numpy()
+        store['out/j_err_ori_' + side] = torch.linalg.norm(jp0 - jg0, dim=-1).numpy()
+        store['out/v_err_ori_' + side] = torch.linalg.norm(vp0 - vg0, dim=-1).numpy()
+    (vlg, vlp, jlg, jlp), (vrg, vrp, jrg, jrp) = data['left'], data['right']
+    ie.eval_hand2(vlg, vrg, jlg, jrg, vlp, vrp, jlp, jrp, *lists)
+    for side in ('left', 'right'):
+        store['out/j_err_' + side] = lists[0][side][0]
+        store['out/v_err_' + side] = lists[1][side][0]
+    path = os.path.join(HERE, 'metrics.npz')
+    np.savez_compressed(path, **store)
+    print('wrote', path, os.path.getsize(path), 'bytes,', len(store), 'arrays')
+
+
 def zlibseed(s):
     import zlib
     return zlib.crc32(s.encode()) & 0x7FFFFFFF
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['eval', 'train', 'mano', 'keys', 'hrnet', 'loss', 'lijun']
+    which = sys.argv[1:] or ['eval', 'train', 'mano', 'keys', 'hrnet', 'loss', 'lijun', 'metrics']
+    if 'metrics' in which:
+        metrics_fixture()
     if 'lijun' in which:
         lijun_keys_fixture()
         lijun_fixture('eval')
