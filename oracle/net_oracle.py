@@ -13,7 +13,6 @@ reference-generated vectors; the reference's own tests pin nothing numeric for t
 Each function cites the reference file:line it follows (paths relative to /root/reference).
 Everything is differentiable through torch autograd, so the same code is the gradient oracle.
 """
-import math
 import numpy as np
 import torch
 import torch.nn.functional as F

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .attn import (DropCtx, MLP_res_block, SelfAttn, _drop_add, _lin, _lin_drop_res, _lin_pair, _xavier, img_ex)
+from .attn import DropCtx, MLP_res_block, SelfAttn, _drop_add, _lin_drop_res, _lin_pair, _xavier, img_ex
 from .decoder import decoder as _DecoderA
 from .encoder import ResNetTrunk, bn_act, conv, conv1x1, flush_batches_tracked
 

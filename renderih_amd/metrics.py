@@ -2,7 +2,6 @@
 apps/eval_interhand.py:334-415 / common/utils/intag_eval.py:217-283 (`eval_hand2`) on one HIP kernel per hand
 (`rih_hand_metrics`): joint regression, root alignment, bone-length rescaling, per-joint / per-vertex errors and the
 Procrustes-aligned errors that the reference computes with torch.svd on the host."""
-import numpy as np
 import torch
 
 from . import ops

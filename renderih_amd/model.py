@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from . import assets
 from .config import load_cfg
-from .encoder import load_encoder, ResNetSimple, resnet_mid, flush_batches_tracked
+from .encoder import load_encoder, flush_batches_tracked
 from .decoder import decoder as Decoder
 
 
