@@ -295,6 +295,29 @@ int rih_version(void);
 const char* rih_arch(void);
 
 /* ------------------------------------------------------------------------------------------------
+ * MANO parameter head of the reference's `load_new_model` network (common/myhand/decoder_lijun_mano.py:112-160,247-300)
+ * nn.Hardswish and scale*tanh (the ParamRegressor MLP, `F.tanh(shape) * 3`): elementwise, n floats. */
+int rih_hardswish_fwd(const float* x, float* y, int64_t n, void* stream);
+int rih_hardswish_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+int rih_tanh_scale_fwd(const float* x, float* y, int64_t n, float scale, void* stream);
+int rih_tanh_scale_bwd(const float* dy, const float* y, float* dx, int64_t n, float scale, void* stream);
+/* x [n][6] (viewed (3,2): two column vectors) -> Gram-Schmidt rotation matrix R [n][3][3] (decoder_lijun_mano.py:118-125)
+ * and its axis-angle vector aa [n][3] through the quaternion (common/myhand/utils/comm.py:176-324, NaN -> 0).
+ * Backward: dx = J_R^T dR + J_aa^T daa (either gradient may be NULL), exact (forward-mode dual numbers). */
+int rih_rot6d_fwd(const float* x, float* R, float* aa, int n, void* stream);
+int rih_rot6d_bwd(const float* x, const float* dR, const float* daa, float* dx, int n, void* stream);
+/* axis-angle [n][3] -> rotation matrix [n][3][3], angle = |axis| + 1e-8 (common/utils/manolayer.py:32-48) */
+int rih_rodrigues_fwd(const float* a, float* R, int n, void* stream);
+int rih_rodrigues_bwd(const float* a, const float* dR, float* da, int n, void* stream);
+/* vout = (v - j[root]) * s, s = target / |j[ja] - j[jb]| per mesh (decoder_lijun_mano.py:262-267: root-centred,
+ * bone-length-normalised MANO mesh, target 0.095 m); sout [B].  Backward: dv [B][V][3], dj [B][NJ][3] from dvout and
+ * (may be NULL) dsout. */
+int rih_center_scale_fwd(const float* v, const float* j, int B, int V, int NJ, int root, int ja, int jb, float target,
+                         float* vout, float* sout, void* stream);
+int rih_center_scale_bwd(const float* v, const float* j, const float* dvout, const float* dsout, int B, int V, int NJ,
+                         int root, int ja, int jb, float target, float* dv, float* dj, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Evaluation metrics of one hand (apps/eval_interhand.py:334-415, common/utils/intag_eval.py:92-143,217-283):
  * joints = Jreg [NJ][V] x vertices unless given (j_pred / j_gt may be NULL), both point sets made relative to joint
  * `root_idx`, prediction rescaled by |gt bone| / |pred bone| (bone = joints bone_a, bone_b);

@@ -358,6 +358,51 @@ def lijun_dual_graph(sd, p, Lf, Rf, fmaps):
     return Lf, Rf
 
 
+def param_regressor(sd, p, v):
+    """common/myhand/decoder_lijun_mano.py:112-160 (Hardswish MLP, rot6d -> rotation matrix -> axis-angle)."""
+    from oracle import pose_oracle as po
+    n = v.shape[0]
+    feat = F.hardswish(_lin(sd, p + 'fc.2.', F.hardswish(_lin(sd, p + 'fc.0.', v.reshape(n, -1)))))
+    rot6d = _lin(sd, p + 'fc_pose.2.', F.hardswish(_lin(sd, p + 'fc_pose.0.', feat)))
+    R = po.rot6d_to_rotmat(rot6d)
+    pose = po.rotation_matrix_to_angle_axis(R).reshape(n, -1)
+    shape = _lin(sd, p + 'fc_shape.2.', F.hardswish(_lin(sd, p + 'fc_shape.0.', feat)))
+    return pose, shape, R
+
+
+def mano_tail(sd, mano, scale, trans2d, v3c, p='decoder.'):
+    """decoder_lijun_mano.py:241-300: up-sampled meshes -> MANO parameters -> MANO layer -> root-centred, bone-length-
+    normalised meshes.  `mano` = {'left': constants, 'right': constants} of oracle/mano_oracle.py (after the ctor's
+    shapedirs sign fix, :167-169)."""
+    from oracle import mano_oracle, pose_oracle as po
+    v3d, root, pred, slen = {}, {}, {}, {}
+    for side in ('left', 'right'):
+        v3d[side] = F.linear(v3c[side].transpose(1, 2), sd[p + 'unsample_layer.weight']).transpose(1, 2)
+        Jr = sd['%smano_%s.joint_regressor_torch' % (p, side)]
+        root[side] = torch.einsum('bik,ji->bjk', v3d[side], Jr)[:, 0]
+        pose, shape, _ = param_regressor(sd, p + 'param_regressor.', v3d[side])
+        shape = torch.tanh(shape) * 3
+        consts = dict(mano[side])
+        # a persistent buffer of the model, registered under two names (mano_X.layer and mano_X_layer are the same
+        # module, decoder_lijun_mano.py:160-163): load_state_dict applies the second key last
+        consts['hands_components'] = sd['%smano_%s_layer.hands_components' % (p, side)]
+        v, j = mano_oracle.mano_forward(consts, po.rodrigues_batch(pose[:, :3]), pose[:, 3:], shape, None, None,
+                                        center_idx=None, use_pca=True, new_skel=False)
+        v, j = v * 1000 / 1000, j * 1000 / 1000           # common/utils/manolayer.py:323-325 returns mm; :256-257 divide
+        length = torch.linalg.norm(j[:, 9:10] - j[:, 0:1], dim=-1)
+        slen[side] = (0.095 / length).reshape(-1, 1, 1)
+        pred[side] = {'verts3d': (v - j[:, 0:1]) * slen[side], 'joints3d': j, 'mano_pose': pose, 'mano_shape': shape}
+    root_rel = root['right'] - root['left']
+    result = {'verts3d': {'left': pred['left']['verts3d'], 'right': pred['right']['verts3d'] + root_rel.reshape(-1, 1, 3)},
+              'verts2d': {s_: projection_batch(scale[s_], trans2d[s_], pred[s_]['verts3d']) for s_ in ('left', 'right')},
+              'v3d_left': v3d['left'], 'v3d_right': v3d['right']}
+    params = {'scale': scale, 'trans2d': trans2d, 'scalelength_left': slen['left'], 'scalelength_right': slen['right'],
+              'root_rel': root_rel}
+    other = {'length': (slen['left'] + slen['right']) / 2, 'root_rel': root_rel,
+             'verts3d_MANO_list': pred, 'verts2d_MANO_list': {'left': [], 'right': []}}
+    return result, params, other
+
+
 def is_family_b(sd):
     """lijun_model_graph.HandNET_GCN state: ResNet trunk, no auxiliary decoders, mid convs on the raw 2048-ch map."""
     return 'encoder.resnet.conv1.weight' in sd and 'encoder.hms_decoder.final_layer.weight' not in sd
@@ -409,7 +454,7 @@ def decoder_forward(sd, graph, gf, fmaps, p='decoder.', family_b=False):
     return result, paramsDict, handDictList, otherInfo
 
 
-def handnet_forward(sd, graph, img, training=False, taps=None):
+def handnet_forward(sd, graph, img, training=False, taps=None, mano=None):
     """models/model.py:25-37 HandNET_GCN.forward (ResNet or HRNet encoder, told apart by the state-dict keys)."""
     if is_family_b(sd):             # common/myhand/lijun_model_graph.py:26-33
         x1, x2, x3, x4 = resnet_trunk(sd, img, training)
@@ -417,7 +462,12 @@ def handnet_forward(sd, graph, img, training=False, taps=None):
         gf, fmaps = lijun_mid_forward(sd, img_f, training)
         if taps is not None:
             taps.update(x1=x1, x2=x2, x3=x3, x4=x4, gf=gf, fmap0=fmaps[0], fmap1=fmaps[1], fmap2=fmaps[2], fmap3=fmaps[3])
-        return decoder_forward(sd, graph, gf, fmaps, family_b=True)
+        out = decoder_forward(sd, graph, gf, fmaps, family_b=True)
+        if 'decoder.mano_left.joint_regressor_torch' in sd:      # lijun_model_newgraph (MANO layer in the forward)
+            _, params, hd, _ = out
+            result, params, other = mano_tail(sd, mano, params['scale'], params['trans2d'], hd[0]['verts3d'])
+            return result, params, hd, other
+        return out
     if 'encoder.hrnet.conv1.weight' in sd:
         hms, mask, dp, img_f, hms_f, dp_f = hrnet_encoder_forward(sd, img, training)
         gf, fmaps = hrnet_mid_forward(sd, img_f, training)
@@ -455,12 +505,18 @@ def scalar_loss(outputs):
         s = s + result['verts3d'][side].abs().sum() + 1e-2 * result['verts2d'][side].abs().sum()
         s = s + hd[0]['verts3d'][side].pow(2).sum() + 1e-4 * hd[0]['verts2d'][side].pow(2).sum()
         s = s + params['scale'][side].sum() + params['trans2d'][side].pow(2).sum()
+    if isinstance(other.get('verts3d_MANO_list', {}).get('left'), dict):   # MANO model: parameters, joints, raw meshes
+        for side in ('left', 'right'):
+            m = other['verts3d_MANO_list'][side]
+            s = s + 10 * m['joints3d'].abs().sum() + m['mano_pose'].pow(2).sum() + m['mano_shape'].abs().sum()
+            s = s + result['v3d_' + side].pow(2).sum()
+        s = s + other['length'].sum() + other['root_rel'].abs().sum()
     if 'hms' in other:              # the second model family has no auxiliary heads
         s = s + 1e-3 * other['hms'].pow(2).sum() + 1e-3 * other['mask'].abs().sum() + 1e-3 * other['dense'].pow(2).sum()
     return s
 
 
-def run(sd, graph, img, training, dtype=torch.float32, with_grad=False):
+def run(sd, graph, img, training, dtype=torch.float32, with_grad=False, mano=None):
     """Convenience for tests: forward (and scalar-loss backward) at a chosen dtype.
     Returns (flat outputs, {param name: grad}) with the flat names of renderih_amd.testing.flatten_outputs."""
     s = {}
@@ -468,13 +524,16 @@ def run(sd, graph, img, training, dtype=torch.float32, with_grad=False):
         t = v.detach().clone()
         if t.is_floating_point():
             t = t.to(dtype)
-            if with_grad and 'running' not in k and 'dense_coor' not in k:
+            if with_grad and 'running' not in k and 'dense_coor' not in k and '.mano_' not in k:      # parameters only
                 t.requires_grad_(True)
         s[k] = t
     g = {h: {'L': [L.to(dtype) for L in graph[h]['L']], 'perm': graph[h]['perm'],
              'perm_reverse': graph[h]['perm_reverse']} for h in graph}
     with torch.set_grad_enabled(with_grad):
-        out = handnet_forward(s, g, img.to(dtype), training=training)
+        if mano is not None:
+            mano = {h: {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in mano[h].items()}
+                    for h in mano}
+        out = handnet_forward(s, g, img.to(dtype), training=training, mano=mano)
     grads = {}
     if with_grad:
         scalar_loss(out).backward()
@@ -488,10 +547,16 @@ def run(sd, graph, img, training, dtype=torch.float32, with_grad=False):
         flat['params.trans2d.' + side] = params['trans2d'][side]
         flat['hand0.verts3d.' + side] = hd[0]['verts3d'][side]
         flat['hand0.verts2d.' + side] = hd[0]['verts2d'][side]
-        if other['verts3d_MANO_list'][side]:
-            flat['other.verts3d_MANO.' + side] = other['verts3d_MANO_list'][side][0]
+        ml = other['verts3d_MANO_list'][side]
+        if isinstance(ml, dict):
+            for k2 in ('verts3d', 'joints3d', 'mano_pose', 'mano_shape'):
+                flat['other.mano.%s.%s' % (side, k2)] = ml[k2]
+            flat['result.v3d_' + side] = result['v3d_' + side]
+            flat['params.scalelength_' + side] = params['scalelength_' + side]
+        elif ml:
+            flat['other.verts3d_MANO.' + side] = ml[0]
             flat['other.verts2d_MANO.' + side] = other['verts2d_MANO_list'][side][0]
-    for k in ('hms', 'mask', 'dense'):
+    for k in ('hms', 'mask', 'dense', 'length', 'root_rel'):
         if k in other:
             flat['other.' + k] = other[k]
     return {k: v.detach() for k, v in flat.items()}, grads

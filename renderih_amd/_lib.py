@@ -45,6 +45,16 @@ class MeshTopo(C.Structure):
 
 # name -> (restype, argtypes); must list every symbol include/renderih_amd.h declares
 SIGNATURES = {
+    'rih_hardswish_fwd': (c_i, [c_f, c_f, c_l, C.c_void_p]),
+    'rih_hardswish_bwd': (c_i, [c_f, c_f, c_f, c_l, C.c_void_p]),
+    'rih_tanh_scale_fwd': (c_i, [c_f, c_f, c_l, c_fl, C.c_void_p]),
+    'rih_tanh_scale_bwd': (c_i, [c_f, c_f, c_f, c_l, c_fl, C.c_void_p]),
+    'rih_rot6d_fwd': (c_i, [c_f, c_f, c_f, c_i, C.c_void_p]),
+    'rih_rot6d_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, C.c_void_p]),
+    'rih_rodrigues_fwd': (c_i, [c_f, c_f, c_i, C.c_void_p]),
+    'rih_rodrigues_bwd': (c_i, [c_f, c_f, c_f, c_i, C.c_void_p]),
+    'rih_center_scale_fwd': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f, c_f, C.c_void_p]),
+    'rih_center_scale_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f, c_f, C.c_void_p]),
     'rih_hand_metrics': (c_i, [c_f] * 5 + [c_i] * 6 + [c_f] * 6 + [C.c_void_p]),
     'rih_gemm': (c_i, [C.POINTER(GemmDesc), C.c_void_p]),
     'rih_splitk_reduce': (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),

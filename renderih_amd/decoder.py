@@ -137,19 +137,33 @@ class decoder(nn.Module):
             self._cache[key] = ops.RowIndex(idx, vin, device)
         return self._cache[key]
 
+    def _initial_features(self, x):
+        """decoder.py:133-139: per-hand global feature (Linear + LN) tiled over the 63 coarse vertices + positional code."""
+        bs, dev = x.shape[0], x.device
+        pel, per = self._pe_const(bs)
+        rep = self._rowidx('rep', np.zeros(self.vNum_in, np.int64), 1, dev)       # .unsqueeze(1).repeat(1, V, 1)
+        gl = _ln(self.gf_layer_left[1], _lin(self.gf_layer_left[0], x))
+        gr = _ln(self.gf_layer_right[1], _lin(self.gf_layer_right[0], x))
+        return torch.cat([rep(gl.unsqueeze(1)), pel], dim=-1), torch.cat([rep(gr.unsqueeze(1)), per], dim=-1)
+
+    def _stacked_heads(self, f):
+        """The output heads, shared between the hands (decoder.py:143-163), on the hands-stacked features [2B,V,D]:
+        camera (scale | trans2d) [2B,3], coarse vertices [2B,252,3] and their projection, up-sampled vertices transposed
+        [2B,3,778]."""
+        temp = _lin(self.avg_head, f.transpose(-1, -2).contiguous())[..., 0]
+        temp = _lin(self.params_head, temp)
+        v3 = _lin(self.coord_head, f)
+        v2 = ops.projection_batch(temp[:, 0], temp[:, 1:], v3, IMG_SIZE)
+        upT = ops.linear(v3.transpose(1, 2).contiguous(), self.unsample_layer.weight)
+        return temp, v3, v2, upT
+
     def forward(self, x, fmaps):
         assert x.shape[1] == self.gf_dim
         fmaps = fmaps[:-1]
         bs = x.shape[0]
         dev = x.device
         dc = DropCtx(self.dropout_p, self.training)
-
-        pel, per = self._pe_const(bs)
-        rep = self._rowidx('rep', np.zeros(self.vNum_in, np.int64), 1, dev)       # .unsqueeze(1).repeat(1, V, 1)
-        gl = _ln(self.gf_layer_left[1], _lin(self.gf_layer_left[0], x))
-        gr = _ln(self.gf_layer_right[1], _lin(self.gf_layer_right[0], x))
-        Lf = torch.cat([rep(gl.unsqueeze(1)), pel], dim=-1)
-        Rf = torch.cat([rep(gr.unsqueeze(1)), per], dim=-1)
+        Lf, Rf = self._initial_features(x)
 
         scale, trans2d = {}, {}
         verts3d, verts2d = {}, {}
@@ -158,11 +172,8 @@ class decoder(nn.Module):
             # the heads are shared between the hands (decoder.py:143-163): run them once over the stacked batch
             f = self.dual_gcn.forward_stacked(torch.stack([Lf, Rf]), fmaps, dc)
             f = f.reshape(2 * bs, f.shape[2], f.shape[3])
-            temp = _lin(self.avg_head, f.transpose(-1, -2).contiguous())[..., 0]
-            temp = _lin(self.params_head, temp)
-            v3 = _lin(self.coord_head, f)
-            v2 = ops.projection_batch(temp[:, 0], temp[:, 1:], v3, IMG_SIZE)
-            up = ops.linear(v3.transpose(1, 2).contiguous(), self.unsample_layer.weight).transpose(1, 2).contiguous()
+            temp, v3, v2, upT = self._stacked_heads(f)
+            up = upT.transpose(1, 2).contiguous()
             up2 = ops.projection_batch(temp[:, 0], temp[:, 1:], up, IMG_SIZE)
             for h, hand_type in enumerate(['left', 'right']):
                 sl = slice(h * bs, (h + 1) * bs)

@@ -21,7 +21,8 @@ import torch.nn as nn
 
 from . import ops
 from .attn import DropCtx, MLP_res_block, SelfAttn, _drop_add, _lin_drop_res, _lin_pair, _xavier, img_ex
-from .decoder import decoder as _DecoderA
+from . import pose_head
+from .decoder import IMG_SIZE, decoder as _DecoderA
 from .encoder import ResNetTrunk, bn_act, conv, conv1x1, flush_batches_tracked
 
 
@@ -240,8 +241,8 @@ def make_linear_layers(feat_dims, relu_final=True, use_bn=False):
 
 
 class ParamRegressor(nn.Module):
-    """decoder_lijun_graph.py:126-160: parameter container (778*3 -> 1024 -> 512 -> {16 x 6D rotations, 10 shape}).
-    `decoder.forward` of this family never calls it; it exists so that reference checkpoints load with strict keys."""
+    """decoder_lijun_graph.py / decoder_lijun_mano.py:126-160: mesh (778*3) -> 1024 -> 512 -> {16 x 6D rotations,
+    10 shape} with Hardswish.  The graph model only carries its parameters; the MANO model (`decoder_mano`) calls it."""
 
     def __init__(self, joint_num=265):
         super().__init__()
@@ -249,6 +250,20 @@ class ParamRegressor(nn.Module):
         self.fc = make_linear_layers([self.joint_num * 3, 1024, 512], use_bn=False)
         self.fc_pose = make_linear_layers([512, 128, 16 * 6], relu_final=False)
         self.fc_shape = make_linear_layers([512, 128, 10], relu_final=False)
+
+    @staticmethod
+    def _mlp(seq, x):
+        for m in seq:
+            x = ops.linear(x, m.weight, m.bias) if isinstance(m, nn.Linear) else pose_head.hardswish(x)
+        return x
+
+    def forward(self, pose_3d):
+        """[N,778,3] -> axis-angle pose [N,48], shape [N,10], rotation matrices [N*16,3,3]   (:142-160)"""
+        n = pose_3d.shape[0]
+        feat = self._mlp(self.fc, pose_3d.reshape(n, self.joint_num * 3))
+        rot6d = self._mlp(self.fc_pose, feat)
+        pose_rotmat, aa = pose_head.rot6d_to_rotmat_aa(rot6d.view(n * 16, 6))
+        return aa.view(n, 48), self._mlp(self.fc_shape, feat), pose_rotmat
 
 
 class decoder(_DecoderA):
@@ -268,6 +283,84 @@ class decoder(_DecoderA):
         self.mano = mano_flag
         if self.mano:
             self.param_regressor = ParamRegressor(joint_num=778)
+
+
+class MANO(nn.Module):
+    """common/utils/mano.py:40-94: the MANO layer (`layer`, center_idx=None, PCA pose) + the 21-joint regressor buffer
+    (16 MANO joints + the finger-tip vertices 745/317/445/556/673, re-ordered)."""
+
+    def __init__(self, mano_data, hand_type='right'):
+        super().__init__()
+        from .manolayer import ManoLayer
+        self.hand_type = hand_type
+        self.layer = ManoLayer(mano_data, center_idx=None)
+        self.vertex_num = 778
+        J = self.layer.J_regressor.detach().clone()
+        tips = torch.zeros((5, J.shape[1]), dtype=J.dtype)
+        for i, v in enumerate((745, 317, 445, 556, 673)):
+            tips[i, v] = 1.0
+        J = torch.cat([J.cpu(), tips], 0)[[0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20]]
+        self.register_buffer('joint_regressor_torch', J.float().contiguous())
+
+    def get_3d_joints_T(self, verts_T):
+        """einsum('bik,ji->bjk') of mano.py:82-92 on the transposed mesh [B,3,778] -> [B,3,21]."""
+        return ops.linear(verts_T, self.joint_regressor_torch)
+
+
+class decoder_mano(decoder):
+    """common/myhand/decoder_lijun_mano.py:85-300 (`load_new_model`): the graph decoder, then per hand
+    ParamRegressor -> rot6d -> axis-angle, 3*tanh shape, the MANO layer inside the forward, the mesh centred on the
+    wrist and rescaled to a 9.5 cm wrist-to-middle-base bone, projected with the predicted camera."""
+
+    def __init__(self, cfg=None, mano_left=None, mano_right=None, **kw):
+        kw['mano_flag'] = True
+        super().__init__(cfg, **kw)
+        self.mano_left = MANO(mano_left, 'left')
+        self.mano_left_layer = self.mano_left.layer            # registered under both names, as in the reference
+        self.mano_right = MANO(mano_right, 'right')
+        self.mano_right_layer = self.mano_right.layer
+        with torch.no_grad():                                  # decoder_lijun_mano.py:167-169
+            if torch.sum(torch.abs(self.mano_left_layer.shapedirs[:, 0, :] - self.mano_right_layer.shapedirs[:, 0, :])) < 1:
+                self.mano_left_layer.shapedirs[:, 0, :] *= -1
+
+    def forward(self, x, fmaps):
+        assert x.shape[1] == self.gf_dim
+        fmaps = fmaps[:-1]
+        bs = x.shape[0]
+        dc = DropCtx(self.dropout_p, self.training)
+        Lf, Rf = self._initial_features(x)
+        f = self.dual_gcn.forward_stacked(torch.stack([Lf, Rf]), fmaps, dc)
+        temp, v3, v2, upT = self._stacked_heads(f.reshape(2 * bs, f.shape[2], f.shape[3]))
+        up = upT.transpose(1, 2).contiguous()                              # result['v3d_*']: [2B,778,3]
+        pose, shape, _ = self.param_regressor(up)                          # one regressor for both hands (:251-252)
+        shape = pose_head.tanh_scale(shape, 3.0)
+        root_R = pose_head.rodrigues(pose[:, :3])
+        sides = ('left', 'right')
+        scale, trans2d, verts3d, verts2d = {}, {}, {}, {}
+        result = {'verts3d': {}, 'verts2d': {}}
+        pred, slen, root = {}, {}, {}
+        for h, side in enumerate(sides):
+            sl = slice(h * bs, (h + 1) * bs)
+            mano = self.mano_left if side == 'left' else self.mano_right
+            scale[side], trans2d[side] = temp[sl, 0], temp[sl, 1:]
+            verts3d[side], verts2d[side] = v3[sl], v2[sl]
+            result['v3d_' + side] = up[sl]
+            root[side] = mano.get_3d_joints_T(upT[sl])[:, :, 0]           # wrist of the regressed mesh, [B,3]
+            mv, mj = mano.layer(root_R[sl], pose[sl, 3:], shape[sl])       # metres (the reference goes through mm)
+            vn, s = pose_head.center_scale(mv, mj, root=0, bone=(9, 0), target=0.095)
+            slen[side] = s.view(-1, 1, 1)
+            pred[side] = {'verts3d': vn, 'joints3d': mj, 'mano_pose': pose[sl], 'mano_shape': shape[sl]}
+            result['verts2d'][side] = ops.projection_batch(scale[side], trans2d[side], vn, IMG_SIZE)
+        root_rel = root['right'] - root['left']
+        result['verts3d']['left'] = pred['left']['verts3d']
+        result['verts3d']['right'] = pred['right']['verts3d'] + root_rel.reshape(-1, 1, 3)
+        handDictList = [{'verts3d': verts3d, 'verts2d': verts2d}]
+        otherInfo = {'length': (slen['left'] + slen['right']) / 2, 'root_rel': root_rel,
+                     'verts3d_MANO_list': {'left': pred['left'], 'right': pred['right']},
+                     'verts2d_MANO_list': {'left': [], 'right': []}}
+        paramsDict = {'scale': scale, 'trans2d': trans2d, 'scalelength_left': slen['left'],
+                      'scalelength_right': slen['right'], 'root_rel': root_rel}
+        return result, paramsDict, handDictList, otherInfo
 
 
 class HandNET_GCN(nn.Module):
@@ -311,6 +404,35 @@ def load_graph_model(cfg=None, cliff=False, mano_flag=True):
             state = {k[7:]: v for k, v in state.items()}
         model.load_state_dict(state, strict=False)
     return model
+
+
+def _mano_data(cfg, side, root=None):
+    """MISC.MANO_PATH/MANO_{LEFT,RIGHT}.pkl when present (licence-gated, not shipped); otherwise the seeded synthetic
+    MANO-shaped model of renderih_amd.assets (tests, benchmarks)."""
+    import os
+    from . import assets
+    base = root or os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    path = os.path.join(base, str(cfg.MISC.MANO_PATH), 'MANO_%s.pkl' % side.upper())
+    return path if os.path.exists(path) else assets.synthetic_mano_dict(side)
+
+
+def load_new_model(cfg=None, cliff=False):
+    """common/myhand/lijun_model_newgraph.py:35-70: encoder_lijun + decoder_lijun_mano (MANO layer in the forward)."""
+    from .config import load_cfg
+    from .model import load_decoder as _load_a
+    if cfg is None or isinstance(cfg, str):
+        cfg = load_cfg(cfg)
+    encoder, mid_model = load_encoder(cfg)
+    dec = _load_a(cfg, mid_model.get_info(), None, decoder_cls=decoder_mano,
+                  extra=dict(cfg=cfg, mano_left=_mano_data(cfg, 'left'), mano_right=_mano_data(cfg, 'right')))
+    return HandNET_GCN(encoder, mid_model, dec, cliff)
+
+
+def build_new_model(dropout=0.05):
+    from .config import load_cfg
+    cfg = load_cfg(None)
+    cfg.TRAIN.dropout = dropout
+    return load_new_model(cfg)
 
 
 def build_graph_model(dropout=0.05):

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 from torch.nn import Module
 
-from . import _lib
+from . import _lib, ops
 from ._lib import ManoModel, check
 
 
@@ -87,9 +87,7 @@ def build_mano_frame(skelBatch):
 class _ManoFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, layer, root, pose, shape, trans, scale):
-        for t in (root, pose, shape, trans, scale):
-            if t is not None and (not t.is_cuda or t.dtype != torch.float32):
-                raise RuntimeError('ManoLayer (HIP) needs fp32 GPU tensors; there is no CPU fallback')
+        ops._chk(root, pose, shape, trans, scale)        # fp32 GPU tensors only: there is no CPU fallback
         lib = _lib.load()
         B = root.shape[0]
         root_c, pose_c, shape_c = root.contiguous(), pose.contiguous(), shape.contiguous()
@@ -101,7 +99,7 @@ class _ManoFn(torch.autograd.Function):
         j = torch.empty((B, 21, 3), device=dev, dtype=torch.float32)
         ws = torch.empty((int(lib.rih_mano_ws_floats(B)),), device=dev, dtype=torch.float32)
         mm = layer._model_struct()
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = ops._stream()
         cidx = -1 if layer.center_idx is None else int(layer.center_idx)
         check(lib.rih_mano_fwd(C.byref(mm), root_c.data_ptr(), pose_c.data_ptr(), ncomp, shape_c.data_ptr(),
                                0 if trans_c is None else trans_c.data_ptr(),
@@ -132,8 +130,7 @@ class _ManoFn(torch.autograd.Function):
                                cidx, new_skel, dv.data_ptr(), dj.data_ptr(), ws.data_ptr(), d_root.data_ptr(),
                                d_pose.data_ptr(), d_shape.data_ptr(),
                                0 if d_trans is None else d_trans.data_ptr(),
-                               0 if d_scale is None else d_scale.data_ptr(), 0, B,
-                               torch.cuda.current_stream().cuda_stream), 'rih_mano_bwd')
+                               0 if d_scale is None else d_scale.data_ptr(), 0, B, ops._stream()), 'rih_mano_bwd')
         return None, d_root.view(root_shape), d_pose.view(pose_shape), d_shape, d_trans, d_scale
 
 
@@ -250,7 +247,8 @@ class ManoLayer(Module):
             mm.parent[i] = self.parent[i]
         for t in (self.hands_components, self.hands_mean, self.shapedirs, self.posedirs, self.v_template,
                   self.J_regressor, self.weights):
-            if not t.is_cuda or not t.is_contiguous():
+            ops._chk(t)
+            if not t.is_contiguous():
                 raise RuntimeError('ManoLayer buffers must be contiguous GPU tensors (call .cuda() on the layer)')
         return mm
 

@@ -68,10 +68,16 @@ def flatten_outputs(outputs):
         flat['params.trans2d.' + side] = params['trans2d'][side]
         flat['hand0.verts3d.' + side] = hd[0]['verts3d'][side]
         flat['hand0.verts2d.' + side] = hd[0]['verts2d'][side]
-        if other['verts3d_MANO_list'][side]:           # empty in the second model family (renderih_amd/lijun.py)
-            flat['other.verts3d_MANO.' + side] = other['verts3d_MANO_list'][side][0]
+        ml = other['verts3d_MANO_list'][side]
+        if isinstance(ml, dict):                        # MANO model of the second family: per-hand prediction dict
+            for k2 in ('verts3d', 'joints3d', 'mano_pose', 'mano_shape'):
+                flat['other.mano.%s.%s' % (side, k2)] = ml[k2]
+            flat['result.v3d_' + side] = result['v3d_' + side]
+            flat['params.scalelength_' + side] = params['scalelength_' + side]
+        elif ml:                                        # empty list in the graph model of the second family
+            flat['other.verts3d_MANO.' + side] = ml[0]
             flat['other.verts2d_MANO.' + side] = other['verts2d_MANO_list'][side][0]
-    for k in ('hms', 'mask', 'dense'):
+    for k in ('hms', 'mask', 'dense', 'length', 'root_rel'):
         if k in other:
             flat['other.' + k] = other[k]
     return flat

@@ -186,6 +186,132 @@ class EmulatedLib:
         _f(dst, out.size)[:] = out.ravel()
         return 0
 
+    # ------------------------------------------------------------------ MANO layer (through oracle/mano_oracle.py)
+    @staticmethod
+    def _mano_consts(mref):
+        m = mref._obj
+        t = lambda ptr, *shape: torch.from_numpy(_f(ptr, int(np.prod(shape))).reshape(shape).copy())
+        return {'hands_components': t(m.comps, 45, 45), 'hands_mean': t(m.hands_mean, 45),
+                'shapedirs': t(m.shapedirs, 778, 3, 10), 'posedirs': t(m.posedirs, 778, 3, 135),
+                'v_template': t(m.v_template, 778, 3), 'J_regressor': t(m.J_reg, 16, 778), 'weights': t(m.weights, 778, 16),
+                'parent': [int(m.parent[i]) for i in range(16)]}
+
+    def _mano_run(self, mref, root, pose, ncomp, shape, trans, scale, cidx, new_skel, B, grad=False):
+        from oracle import mano_oracle
+        c = self._mano_consts(mref)
+        g = lambda ptr, *sh: torch.from_numpy(_f(ptr, int(np.prod(sh))).reshape(sh).copy()).requires_grad_(grad)
+        ins = {'root': g(root, B, 3, 3), 'pose': g(pose, B, ncomp) if ncomp > 0 else g(pose, B, 15, 3, 3),
+               'shape': g(shape, B, 10), 'trans': g(trans, B, 3) if trans else None, 'scale': g(scale, B) if scale else None}
+        v, j = mano_oracle.mano_forward(c, ins['root'], ins['pose'], ins['shape'], ins['trans'], ins['scale'],
+                                        center_idx=None if cidx < 0 else cidx, use_pca=ncomp > 0, new_skel=bool(new_skel))
+        return ins, v, j
+
+    def rih_mano_ws_floats(self, B):
+        return 16 * B
+
+    def rih_mano_bwd_ws_floats(self, B):
+        return 16
+
+    def rih_mano_fwd(self, mref, root, pose, ncomp, shape, trans, scale, cidx, new_skel, v, j, ws, B, stream):
+        with torch.no_grad():
+            _, vv, jj = self._mano_run(mref, root, pose, ncomp, shape, trans, scale, cidx, new_skel, B)
+        _f(v, B * 778 * 3)[:] = vv.numpy().ravel()
+        _f(j, B * 21 * 3)[:] = jj.numpy().ravel()
+        return 0
+
+    def rih_mano_bwd(self, mref, root, pose, ncomp, shape, trans, scale, cidx, new_skel, dv, dj, ws, d_root, d_pose,
+                     d_shape, d_trans, d_scale, ws_bwd, B, stream):
+        with torch.enable_grad():
+            ins, vv, jj = self._mano_run(mref, root, pose, ncomp, shape, trans, scale, cidx, new_skel, B, grad=True)
+            ((vv * torch.from_numpy(_f(dv, B * 778 * 3).reshape(B, 778, 3).copy())).sum() +
+             (jj * torch.from_numpy(_f(dj, B * 21 * 3).reshape(B, 21, 3).copy())).sum()).backward()
+        for name, ptr in (('root', d_root), ('pose', d_pose), ('shape', d_shape), ('trans', d_trans), ('scale', d_scale)):
+            if ptr and ins[name] is not None:
+                gr = ins[name].grad
+                _f(ptr, gr.numel())[:] = gr.numpy().ravel()
+        return 0
+
+    # ------------------------------------------------------------------ MANO parameter head (rih_pose.hip)
+    def rih_hardswish_fwd(self, x, y, n, stream):
+        _f(y, n)[:] = F.hardswish(torch.from_numpy(_f(x, n).copy())).numpy()
+        return 0
+
+    @torch.enable_grad()
+    def rih_hardswish_bwd(self, dy, x, dx, n, stream):
+        t = torch.from_numpy(_f(x, n).copy()).requires_grad_(True)
+        F.hardswish(t).backward(torch.from_numpy(_f(dy, n).copy()))
+        _f(dx, n)[:] = t.grad.numpy()
+        return 0
+
+    def rih_tanh_scale_fwd(self, x, y, n, scale, stream):
+        _f(y, n)[:] = np.float32(scale) * np.tanh(_f(x, n))
+        return 0
+
+    def rih_tanh_scale_bwd(self, dy, y, dx, n, scale, stream):
+        t = _f(y, n) / np.float32(scale)
+        _f(dx, n)[:] = _f(dy, n) * np.float32(scale) * (1 - t * t)
+        return 0
+
+    def rih_rot6d_fwd(self, x, R, aa, n, stream):
+        from oracle import pose_oracle as po
+        Rm = po.rot6d_to_rotmat(torch.from_numpy(_f(x, n * 6).copy()).view(n, 6))
+        _f(R, n * 9)[:] = Rm.numpy().ravel()
+        _f(aa, n * 3)[:] = po.rotation_matrix_to_angle_axis(Rm).numpy().ravel()
+        return 0
+
+    @torch.enable_grad()
+    def rih_rot6d_bwd(self, x, dR, daa, dx, n, stream):
+        from oracle import pose_oracle as po
+        t = torch.from_numpy(_f(x, n * 6).copy()).view(n, 6).requires_grad_(True)
+        Rm = po.rot6d_to_rotmat(t)
+        a = po.rotation_matrix_to_angle_axis(Rm)
+        loss = 0
+        if dR:
+            loss = loss + (Rm * torch.from_numpy(_f(dR, n * 9).copy()).view(n, 3, 3)).sum()
+        if daa:
+            loss = loss + (a * torch.from_numpy(_f(daa, n * 3).copy()).view(n, 3)).sum()
+        loss.backward()
+        _f(dx, n * 6)[:] = t.grad.numpy().ravel()
+        return 0
+
+    def rih_rodrigues_fwd(self, a, R, n, stream):
+        from oracle import pose_oracle as po
+        _f(R, n * 9)[:] = po.rodrigues_batch(torch.from_numpy(_f(a, n * 3).copy()).view(n, 3)).numpy().ravel()
+        return 0
+
+    @torch.enable_grad()
+    def rih_rodrigues_bwd(self, a, dR, da, n, stream):
+        from oracle import pose_oracle as po
+        t = torch.from_numpy(_f(a, n * 3).copy()).view(n, 3).requires_grad_(True)
+        (po.rodrigues_batch(t) * torch.from_numpy(_f(dR, n * 9).copy()).view(n, 3, 3)).sum().backward()
+        _f(da, n * 3)[:] = t.grad.numpy().ravel()
+        return 0
+
+    @staticmethod
+    def _center_scale(v, j, root, ja, jb, target):
+        s = target / torch.linalg.norm(j[:, ja] - j[:, jb], dim=-1)
+        return (v - j[:, root:root + 1]) * s.view(-1, 1, 1), s
+
+    def rih_center_scale_fwd(self, v, j, B, V, NJ, root, ja, jb, target, vout, sout, stream):
+        o, s = self._center_scale(torch.from_numpy(_f(v, B * V * 3).copy()).view(B, V, 3),
+                                  torch.from_numpy(_f(j, B * NJ * 3).copy()).view(B, NJ, 3), root, ja, jb, target)
+        _f(vout, B * V * 3)[:] = o.numpy().ravel()
+        _f(sout, B)[:] = s.numpy()
+        return 0
+
+    @torch.enable_grad()
+    def rih_center_scale_bwd(self, v, j, dvout, dsout, B, V, NJ, root, ja, jb, target, dv, dj, stream):
+        tv = torch.from_numpy(_f(v, B * V * 3).copy()).view(B, V, 3).requires_grad_(True)
+        tj = torch.from_numpy(_f(j, B * NJ * 3).copy()).view(B, NJ, 3).requires_grad_(True)
+        o, s = self._center_scale(tv, tj, root, ja, jb, target)
+        loss = (o * torch.from_numpy(_f(dvout, B * V * 3).copy()).view(B, V, 3)).sum()
+        if dsout:
+            loss = loss + (s * torch.from_numpy(_f(dsout, B).copy())).sum()
+        loss.backward()
+        _f(dv, B * V * 3)[:] = tv.grad.numpy().ravel()
+        _f(dj, B * NJ * 3)[:] = tj.grad.numpy().ravel()
+        return 0
+
     # ------------------------------------------------------------------ evaluation metrics
     def rih_hand_metrics(self, v_pred, v_gt, j_pred, j_gt, Jreg, B, V, NJ, root_idx, bone_a, bone_b, j_err_ori, v_err_ori,
                          j_err, v_err, pa, j_pred_out, stream):

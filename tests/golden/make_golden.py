@@ -370,6 +370,89 @@ def lijun_fixture(mode):
     print('wrote', path, os.path.getsize(path), 'bytes,', len(store), 'arrays')
 
 
+def build_reference_model_new(dropout=0.0):
+    """common/myhand/lijun_model_newgraph.HandNET_GCN (`load_new_model`): encoder_lijun + decoder_lijun_mano with the
+    REAL common/utils/mano.MANO wrapper and common/utils/manolayer.ManoLayer on synthetic MANO-shaped pickles; only the
+    trainer's global config, `manopth` (imported, unused) and mmcv's focal loss are stand-ins, and `.cuda()` /
+    `.to('cuda')` are made no-ops (this container has no GPU)."""
+    import types
+    ref_stubs.install()
+    tmp = tempfile.mkdtemp()
+    for side in ('left', 'right'):
+        assets.write_synthetic_mano_pkl(os.path.join(tmp, 'MANO_%s.pkl' % side.upper()), side, seed=0)
+    cfgm = types.ModuleType('main.config')
+    cfgm.cfg = types.SimpleNamespace(mano_flag=True, render=False, normal=True, edge=True, vert2d=True, dice=False,
+                                     sdf=False, lambda_sdf=1e6, lambda_render=100, lambda_normal=10, lambda_edge=100,
+                                     sdf_thresh=0.01, data_type='x', mano_path=tmp, reverse=False)
+    main = types.ModuleType('main')
+    main.config = cfgm
+    sys.modules['main'], sys.modules['main.config'] = main, cfgm
+    sys.modules['manopth'] = types.ModuleType('manopth')
+    fl = types.ModuleType('common.utils.focal_loss')
+    fl.FocalLoss = type('FocalLoss', (torch.nn.Module,), {})
+    sys.modules['common.utils.focal_loss'] = fl
+    sys.modules.pop('common.utils.mano', None)              # a stand-in may be left over from the graph-model fixture
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    if not getattr(torch.Tensor.to, '_rih_patched', False):
+        _to = torch.Tensor.to
+
+        def to(self, *a, **k):
+            a = tuple(x for x in a if not (isinstance(x, str) and x.startswith('cuda')))
+            if isinstance(k.get('device'), str) and k['device'].startswith('cuda'):
+                k.pop('device')
+            return _to(self, *a, **k) if (a or k) else self
+        to._rih_patched = True
+        torch.Tensor.to = to
+    import common.myhand.lijun_model_newgraph as lm                     # reference
+    from common.myhand.encoder_lijun import ResNetSimple as EncB, resnet_mid as MidB      # reference
+    import common.myhand.decoder_lijun_mano as dm                       # reference
+    enc = EncB(model_type='resnet50', pretrained=True, fmapDim=[128] * 4, handNum=2, heatmapDim=21)
+    mid = MidB(model_type='resnet50', in_fmapDim=[2048, 1024, 512, 256], out_fmapDim=[256] * 4)
+    cfg = types.SimpleNamespace(render=False, edge=True, normal=True, vert2d=True, dice=False)
+    dec = dm.decoder(cfg, global_feature_dim=2048, f_in_Dim=[256] * 4, f_out_Dim=[256, 128, 64],
+                     gcn_in_dim=[512, 256, 128], gcn_out_dim=[256, 128, 64], graph_k=2, graph_layer_num=4,
+                     left_graph_dict=assets.load_graph_dict('left'), right_graph_dict=assets.load_graph_dict('right'),
+                     vertex_num=778, dense_coor=assets.synthetic_dense_coor(), num_attn_heads=4,
+                     upsample_weight=torch.from_numpy(assets.synthetic_upsample_weight()), dropout=dropout, mano_flag=True)
+    return lm.HandNET_GCN(enc, mid, dec, False)
+
+
+def newmodel_fixture():
+    """net_newlijun_{eval,train}.npz + state_keys_newlijun.json: the MANO-in-the-forward model of the second family."""
+    import json
+    model = build_reference_model_new(0.0)
+    sch = {k: list(v.shape) for k, v in model.state_dict().items()}
+    with open(os.path.join(HERE, 'state_keys_newlijun.json'), 'w') as f:
+        json.dump(sch, f)
+    for mode in ('eval', 'train'):
+        torch.manual_seed(0)
+        model = build_reference_model_new(0.0)
+        model.load_state_dict(testing.deterministic_state(model.state_dict(), seed=11))
+        model.train(mode == 'train')
+        img = testing.seeded_image(2, seed=12)
+        store = {}
+        with torch.set_grad_enabled(mode == 'train'):
+            out = model(img)
+        for k, v in testing.flatten_outputs(out).items():
+            pack(store, 'out/' + k, v)
+        if mode == 'train':
+            loss = net_oracle.scalar_loss(out)
+            loss.backward()
+            store['loss'] = np.float64(loss.item())
+            names = []
+            for k, p in model.named_parameters():
+                if p.grad is None:
+                    continue
+                names.append(k)
+                st, sa = testing.signature(p.grad, nsamp=32)
+                store['grad/' + k + '#stats'] = st
+                store['grad/' + k + '#samp'] = sa
+            store['grad_names'] = np.array(names)
+        path = os.path.join(HERE, 'net_newlijun_%s.npz' % mode)
+        np.savez_compressed(path, **store)
+        print('wrote', path, os.path.getsize(path), 'bytes,', len(store), 'arrays')
+
+
 def lijun_keys_fixture():
     import json
     sch = {k: list(v.shape) for k, v in build_reference_model_b(0.05).state_dict().items()}
@@ -435,7 +518,9 @@ def zlibseed(s):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['eval', 'train', 'mano', 'keys', 'hrnet', 'loss', 'lijun', 'metrics']
+    which = sys.argv[1:] or ['eval', 'train', 'mano', 'keys', 'hrnet', 'loss', 'lijun', 'metrics', 'newmodel']
+    if 'newmodel' in which:
+        newmodel_fixture()
     if 'metrics' in which:
         metrics_fixture()
     if 'lijun' in which:
