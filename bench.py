@@ -98,9 +98,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--encoder', default='resnet50', choices=['resnet50', 'hrnet32'],
                     help='resnet50 = BASELINE configs[1]/[2] (the headline metric); hrnet32 = configs[3]')
-    ap.add_argument('--family', default='a', choices=['a', 'b'],
+    ap.add_argument('--family', default='a', choices=['a', 'b', 'b-mano'],
                     help="a = models/model.py (the headline configuration); b = the reference's second family, "
-                         "common/myhand/lijun_model_graph.load_graph_model (SURVEY 8f rank 1; resnet50 only)")
+                         "common/myhand/lijun_model_graph.load_graph_model (SURVEY 8f rank 1; resnet50 only); "
+                         "b-mano = lijun_model_newgraph.load_new_model (MANO layer inside the forward)")
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 64, hrnet32: 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -136,11 +137,11 @@ def main():
     from renderih_amd.manolayer import ManoLayer
 
     torch.manual_seed(0)
-    if args.family == 'b':
+    if args.family != 'a':
         if args.encoder != 'resnet50':
-            raise SystemExit('--family b is the resnet50 configuration of lijun_model_graph')
-        from renderih_amd.lijun import build_graph_model
-        model = build_graph_model(dropout=0.05).to(device).train()
+            raise SystemExit('--family b / b-mano are resnet50 configurations')
+        from renderih_amd.lijun import build_graph_model, build_new_model
+        model = (build_graph_model if args.family == 'b' else build_new_model)(dropout=0.05).to(device).train()
     else:
         model = build_model(dropout=0.05, encoder_type=args.encoder).to(device).train()
     model.decoder.unsample_layer.weight.requires_grad_(False)          # core/gcn_trainer.py:102-103
@@ -262,8 +263,9 @@ def main():
                            'rows': rows, 'by_variant': by}, fh)
         top = max(by.items(), key=lambda kv: kv[1][1])
         gflop_img = GFLOP_PER_IMG_FWD_BWD if args.encoder == 'resnet50' else 88.5     # 3 x 29.49 (HRNet-W32)
-        if args.family == 'b':
-            gflop_img = 39.8        # 3 x 13.27 GFLOP/img forward (torch flop counter on the oracle)
+        if args.family != 'a':
+            gflop_img = 39.8        # 3 x 13.27 GFLOP/img forward (torch flop counter on the oracle; the
+            #                         MANO head of b-mano adds 0.01)
         achieved = gflop_img * B / ms            # GFLOP / ms = TFLOP/s
         split = (ops.ENGINE == 1)
         peak = PEAK_BF16_MFMA_TF / 6.0 if split else PEAK_FP32_MFMA_TF
@@ -284,7 +286,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(family=args.family)
+        cpu = cpu_baseline(family=args.family) if args.family != 'b-mano' else None
 
     if rank == 0:
         n_img = B * world * args.steps
@@ -295,6 +297,9 @@ def main():
                 'config': {'workload': ('second model family (common/myhand/lijun_model_graph.load_graph_model): batch=%d/GPU '
                                         '256x256 ResNet50 trunk + MLP-block dual-graph decoder, fwd + loss + bwd + Adam step, '
                                         'dropout 0.05, fp32' % B) if args.family == 'b' else
+                           ('second model family with the MANO layer in the forward (lijun_model_newgraph.load_new_model): '
+                            'batch=%d/GPU 256x256, fwd + loss + bwd + Adam step, dropout 0.05, fp32' % B)
+                           if args.family == 'b-mano' else
                            ('BASELINE configs[1]: batch=%d/GPU 256x256 ResNet50 + cross-hand attention decoder, '
                                         'fwd + loss + bwd + Adam step, dropout 0.05, fp32' % B) if args.encoder == 'resnet50'
                            else ('BASELINE configs[3] model: batch=%d/GPU 256x256 HRNet-W32 + cross-hand attention decoder, '
