@@ -192,11 +192,23 @@ def main():
             for _ in range(2):                      # warm-up on the capture stream (lazy index tables, allocator)
                 step_eager()
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()                    # no warm-up collective may still be in flight while capturing
+        if dist_on:
+            torch.distributed.barrier()
         opt.zero_grad(set_to_none=True)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            seed_word.add_(0x9E3779B1)
-            static_loss = fwd_bwd()
+        try:
+            with torch.cuda.graph(graph):
+                seed_word.add_(0x9E3779B1)
+                static_loss = fwd_bwd()
+        except Exception as exc:                    # keep the benchmark alive: the eager step issues the same collectives
+            print('[bench] hipGraph capture failed on rank %d (%s: %s); launching eagerly' % (rank, type(exc).__name__, exc),
+                  file=sys.stderr, flush=True)
+            use_graph = False
+            ops.DROPOUT_SEED_TENSOR = None
+            torch.cuda.synchronize()
+            opt.zero_grad(set_to_none=True)
+    if use_graph:
         if reducer is not None:
             reducer.use_static_grads()              # replays rewrite these gradient buffers in place
 
