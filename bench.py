@@ -45,7 +45,11 @@ def measured_traffic():
         return None
     with open(files[-1]) as fh:
         d = json.load(fh)
+    n = max(int(d.get('launches_per_step', 0)), 1)
     return {'hbm_read_GB_per_step': d['fetch_GB_per_step_corrected'], 'hbm_write_GB_per_step': d['write_GB_per_step'],
+            'launches_per_step': n,
+            'hbm_read_MB_per_launch': round(1000.0 * d['fetch_GB_per_step_corrected'] / n, 2),
+            'hbm_write_MB_per_launch': round(1000.0 * d['write_GB_per_step'] / n, 2),
             'from': os.path.relpath(files[-1], ROOT), 'note': 'ResNet50 B=64 step; ' + d['correction']}
 
 
