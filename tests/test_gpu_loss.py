@@ -10,6 +10,14 @@ from renderih_amd.testing import assert_close
 from test_oracle_golden import _loss_inputs, GOLDEN
 
 pytestmark = pytest.mark.gpu
+
+
+def dev():
+    """cuda:0 (tests/test_kernels_on_cpu.py re-runs these tests on the host-compiled kernels with this patched)"""
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return torch.device('cuda:0')
+
+
 PREDS = ['v3d_left', 'v3d_right', 'v2d_left', 'v2d_right', 'c3d_left', 'c3d_right', 'c2d_left', 'c2d_right']
 
 
@@ -23,7 +31,7 @@ def _dicts(t):
 def test_fused_loss_matches_reference_golden(epoch):
     from renderih_amd.loss import FusedMeshLoss, calc_loss_GCN_fused
     z = np.load(os.path.join(GOLDEN, 'loss.npz'))
-    t, conv, gl = _loss_inputs(z, device='cuda')
+    t, conv, gl = _loss_inputs(z, device=dev())
     for k in PREDS:
         t[k].requires_grad_(True)
     fused = FusedMeshLoss(gl['left'], gl['right'], conv['left'], conv['right'])
@@ -44,7 +52,7 @@ def test_fused_loss_matches_torch_mirror_at_full_batch():
     incoming gradient; two evaluations are bit-identical (no atomics)."""
     from renderih_amd.loss import FusedMeshLoss, calc_loss_GCN_fused, calc_loss_GCN
     z = np.load(os.path.join(GOLDEN, 'loss.npz'))
-    _, conv, gl = _loss_inputs(z, device='cuda')
+    _, conv, gl = _loss_inputs(z, device=dev())
     B = 64
     g = torch.Generator().manual_seed(7)
     t = {}
@@ -56,7 +64,7 @@ def test_fused_loss_matches_torch_mirror_at_full_batch():
         t['c3d_' + s] = 0.6 * torch.randn(B, 252, 3, generator=g)
         t['c2d_' + s] = 256 * torch.rand(B, 252, 2, generator=g)
     t['root_rel'] = 0.05 * torch.randn(B, 3, generator=g)
-    t = {k: v.cuda() for k, v in t.items()}
+    t = {k: v.to(dev()) for k, v in t.items()}
     fused = FusedMeshLoss(gl['left'], gl['right'], conv['left'], conv['right'])
     outs = []
     for mode in ('fused', 'fused', 'mirror'):

@@ -8,13 +8,21 @@ from renderih_amd import assets
 from renderih_amd.testing import assert_close
 
 pytestmark = pytest.mark.gpu
+
+
+def dev():
+    """cuda:0 (tests/test_kernels_on_cpu.py re-runs these tests on the host-compiled kernels with this patched)"""
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return torch.device('cuda:0')
+
+
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 
 
 def _layer(side, center, use_pca, new_skel):
     from renderih_amd.manolayer import ManoLayer
     return ManoLayer(assets.synthetic_mano_dict(side, seed=0), center_idx=center, use_pca=use_pca,
-                     new_skel=new_skel).cuda()
+                     new_skel=new_skel).to(dev())
 
 
 @pytest.mark.parametrize('side', ['right', 'left'])
@@ -24,7 +32,7 @@ def test_mano_matches_reference_golden(side):
     assert len(names) >= 8
     for name in names:
         key = 'mano/%s/%s/' % (side, name)
-        g = lambda n: torch.from_numpy(z[key + n]).cuda().requires_grad_(True) if (key + n) in z.files else None
+        g = lambda n: torch.from_numpy(z[key + n]).to(dev()).requires_grad_(True) if (key + n) in z.files else None
         root, pose, shape, trans, scale = g('root'), g('pose'), g('shape'), g('trans'), g('scale')
         center = int(z[key + 'meta_center'])
         layer = _layer(side, None if center < 0 else center, int(z[key + 'meta_ncomp']) > 0,
@@ -32,7 +40,7 @@ def test_mano_matches_reference_golden(side):
         v, j = layer(root, pose, shape, trans=trans, scale=scale)
         assert_close(v, torch.from_numpy(z[key + 'v']), 1e-4, 1e-5, key + 'v')
         assert_close(j, torch.from_numpy(z[key + 'j']), 1e-4, 1e-5, key + 'j')
-        ((v * torch.from_numpy(z[key + 'wv']).cuda()).sum() + (j * torch.from_numpy(z[key + 'wj']).cuda()).sum()).backward()
+        ((v * torch.from_numpy(z[key + 'wv']).to(dev())).sum() + (j * torch.from_numpy(z[key + 'wj']).to(dev())).sum()).backward()
         for nm, t in (('root', root), ('pose', pose), ('shape', shape), ('trans', trans), ('scale', scale)):
             if t is not None:
                 assert_close(t.grad, torch.from_numpy(z[key + 'grad_' + nm]), 1e-3, 1e-4, key + 'grad_' + nm)
@@ -53,11 +61,11 @@ def test_mano_matches_oracle(B):
     vr, jr = mano_oracle.mano_forward(c, *ins)
     wv, wj = torch.randn(vr.shape, generator=g), torch.randn(jr.shape, generator=g)
     ((vr * wv).sum() + (jr * wj).sum()).backward()
-    gin = [t.clone().cuda().requires_grad_(True) for t in (root, pose, shape, trans, scale)]
+    gin = [t.clone().to(dev()).requires_grad_(True) for t in (root, pose, shape, trans, scale)]
     v, j = layer(gin[0], gin[1], gin[2], trans=gin[3], scale=gin[4])
     assert_close(v, vr, 1e-4, 1e-5, 'v')
     assert_close(j, jr, 1e-4, 1e-5, 'j')
-    ((v * wv.cuda()).sum() + (j * wj.cuda()).sum()).backward()
+    ((v * wv.to(dev())).sum() + (j * wj.to(dev())).sum()).backward()
     for nm, a, b in zip(('root', 'pose', 'shape', 'trans', 'scale'), gin, ins):
         assert_close(a.grad, b.grad, 1e-3, 1e-4, 'grad ' + nm)
 
@@ -69,13 +77,13 @@ def test_mano_properties_large_batch():
     layer = _layer('right', 9, True, False)
     B = 4096
     g = torch.Generator().manual_seed(0)
-    root = rodrigues_batch(torch.randn(B, 3, generator=g)).cuda()
-    pose, shape = (torch.randn(B, 45, generator=g) * 0.7).cuda(), torch.randn(B, 10, generator=g).cuda()
-    t = (torch.randn(B, 3, generator=g) * 0.1).cuda()
+    root = rodrigues_batch(torch.randn(B, 3, generator=g)).to(dev())
+    pose, shape = (torch.randn(B, 45, generator=g) * 0.7).to(dev()), torch.randn(B, 10, generator=g).to(dev())
+    t = (torch.randn(B, 3, generator=g) * 0.1).to(dev())
     v0, j0 = layer(root, pose, shape)
     v1, j1 = layer(root, pose, shape, trans=t)
     assert_close(v1 - t.unsqueeze(1), v0, 1e-4, 1e-5, 'translation equivariance')
-    s = (torch.rand(B, generator=g) + 0.5).cuda()
+    s = (torch.rand(B, generator=g) + 0.5).to(dev())
     v2, j2 = layer(root, pose, shape, scale=s)
     assert_close(v2, v0 * s.view(-1, 1, 1), 1e-4, 1e-5, 'scale homogeneity')
     v3, j3 = layer(root[100:103], pose[100:103], shape[100:103])
@@ -87,8 +95,8 @@ def test_mano_reads_mutated_shapedirs():
     """Callers flip shapedirs in place after construction (dataset/interhand.py:22-25); forward must see it."""
     from renderih_amd.manolayer import rodrigues_batch
     layer = _layer('left', 9, True, False)
-    root = rodrigues_batch(torch.zeros(2, 3)).cuda()
-    pose, shape = torch.zeros(2, 45).cuda(), torch.ones(2, 10).cuda()
+    root = rodrigues_batch(torch.zeros(2, 3)).to(dev())
+    pose, shape = torch.zeros(2, 45).to(dev()), torch.ones(2, 10).to(dev())
     a, _ = layer(root, pose, shape)
     layer.shapedirs[:, 0, :] *= -1
     b, _ = layer(root, pose, shape)

@@ -158,11 +158,8 @@ def test_new_model_host_logic_matches_oracle():
         _model_vs_oracle(torch.device('cpu'), True)
 
 
-@pytest.mark.gpu
-def test_pose_head_kernels_match_oracle():
-    """rih_pose.hip on the GPU against torch autograd through the oracle functions."""
+def _pose_head_kernels_vs_oracle(d):
     from renderih_amd import pose_head
-    d = torch.device('cuda:0')
     g = torch.Generator().manual_seed(2)
     x = torch.randn(3000, 6, generator=g)
     xr = x.clone().requires_grad_(True)
@@ -170,7 +167,7 @@ def test_pose_head_kernels_match_oracle():
     aa = po.rotation_matrix_to_angle_axis(R)
     wR, wa = torch.randn(3000, 3, 3, generator=g), torch.randn(3000, 3, generator=g)
     ((R * wR).sum() + (aa * wa).sum()).backward()
-    xg = x.to(d).requires_grad_(True)
+    xg = x.detach().clone().to(d).requires_grad_(True)
     Rg, ag = pose_head.rot6d_to_rotmat_aa(xg)
     assert_close(Rg, R, 1e-4, 1e-5, 'rot6d R')
     assert_close(ag, aa, 1e-4, 1e-5, 'rot6d aa')
@@ -181,7 +178,7 @@ def test_pose_head_kernels_match_oracle():
     ar = a.clone().requires_grad_(True)
     w = torch.randn(500, 3, 3, generator=g)
     (po.rodrigues_batch(ar) * w).sum().backward()
-    agp = a.to(d).requires_grad_(True)
+    agp = a.detach().clone().to(d).requires_grad_(True)
     Rr = pose_head.rodrigues(agp)
     assert_close(Rr, po.rodrigues_batch(a), 1e-4, 1e-5, 'rodrigues')
     (Rr * w.to(d)).sum().backward()
@@ -189,7 +186,7 @@ def test_pose_head_kernels_match_oracle():
     t = torch.randn(7, 1024, generator=g) * 3
     for name, fn, ref in (('hardswish', pose_head.hardswish, torch.nn.functional.hardswish),
                           ('tanh3', lambda u: pose_head.tanh_scale(u, 3.0), lambda u: torch.tanh(u) * 3)):
-        tr, tg = t.clone().requires_grad_(True), t.to(d).requires_grad_(True)
+        tr, tg = t.detach().clone().requires_grad_(True), t.detach().clone().to(d).requires_grad_(True)
         yr, yg = ref(tr), fn(tg)
         assert_close(yg, yr, 1e-4, 1e-5, name)
         gy = torch.randn(7, 1024, generator=g)
@@ -202,13 +199,19 @@ def test_pose_head_kernels_match_oracle():
     outr = (vr - jr[:, 0:1]) * s.view(-1, 1, 1)
     gv, gs = torch.randn(5, 778, 3, generator=g), torch.randn(5, generator=g)
     ((outr * gv).sum() + (s * gs).sum()).backward()
-    vg, jg = v.to(d).requires_grad_(True), j.to(d).requires_grad_(True)
+    vg, jg = v.detach().clone().to(d).requires_grad_(True), j.detach().clone().to(d).requires_grad_(True)
     outg, sg = pose_head.center_scale(vg, jg)
     assert_close(outg, outr, 1e-4, 1e-5, 'center_scale')
     assert_close(sg, s, 1e-4, 1e-5, 'center_scale s')
     ((outg * gv.to(d)).sum() + (sg * gs.to(d)).sum()).backward()
     assert_close(vg.grad, vr.grad, 1e-3, 1e-4, 'center_scale dv')
     assert_close(jg.grad, jr.grad, 1e-3, 1e-4, 'center_scale dj')
+
+
+@pytest.mark.gpu
+def test_pose_head_kernels_match_oracle():
+    """rih_pose.hip on the GPU against torch autograd through the oracle functions."""
+    _pose_head_kernels_vs_oracle(torch.device('cuda:0'))
 
 
 @pytest.mark.gpu
