@@ -45,6 +45,8 @@ extern "C" {
  * a_mode 1: A(m,k): m = (kh,kw,ci), k = (img,ho,wo) -- the transpose gather, M-contiguous (weight grad).
  * b_mode 0: B(k,n) = Bp[k*ldb + n]   (row-major [K][N])
  * b_mode 1: B(k,n) = Bp[n*ldb + k]   ([N][K], e.g. an nn.Linear / 1x1-conv weight as stored)
+ * b_mode 2: B pre-split by rih_presplit_*: three bf16 planes [hi|mid|lo][N][ldb] (ldb = K rounded up to 32, zero padded);
+ *           engine 1 fast path with a_mode 0 only -- the kernel then spends no conversion instructions on B
  * Epilogue (splitk==1): C[m*ldc+n] = act(alpha*acc + bias[n] + R[m*ldr+n]); with splitk>1 raw partial sums
  *           go to C + split*sCsplit and rih_splitk_reduce finishes.
  */
@@ -110,6 +112,15 @@ int rih_splitk_reduce_bias(const float* P, int S, int Mp, int M, int N, float* d
 int rih_splitk_reduce_bias_batched(const float* P, int S, int Mp, int M, int N, float* dst, int Cin, int taps,
                                    int CinValid, int accumulate, float* db, int nb, int64_t sP, int64_t sDst,
                                    int64_t sDb, void* stream);
+
+/* Pre-split B operands for rih_gemm b_mode 2 (weights are constant within a training step, so their bf16 hi/mid/lo
+ * planes are produced once instead of inside every GEMM): dst = 3 * N * Kpad bf16, Kpad % 32 == 0.
+ * rih_presplit_matrix: from a plain b_mode 0 / 1 matrix.  rih_presplit_conv_weight: from an OIHW conv weight, as the
+ * forward operand (for_dgrad 0: N = Cout, K = KH*KW*CinPad) or as the (flipped) data-gradient operand of the tap subset
+ * kh0 + step*t, kw0 + step*t' (for_dgrad 1: N = CinPad, K = Th*Tw*Cout; the full gradient is 0, 0, 1, KH, KW). */
+int rih_presplit_matrix(const float* B, int b_mode, int K, int N, int ldb, void* dst, int Kpad, void* stream);
+int rih_presplit_conv_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int CinPad, int for_dgrad,
+                             int kh0, int kw0, int step, int Th, int Tw, int Kpad, void* stream);
 
 /* Finish a forward split-K GEMM: C[m*ldc+n] = act(alpha * sum_s P[s][m][n] + bias[n] + R[m*ldr+n]). */
 int rih_splitk_finish(const float* P, int S, int M, int N, float* C, int ldc, const float* bias, const float* R,

@@ -575,6 +575,16 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off)
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+__device__ __forceinline__ uint4 bloadu4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// BMODE 2: B arrives PRE-SPLIT -- three bf16 planes [hi | mid | lo][N][ldb] (k contiguous, ldb = K rounded up to 32,
+// zero padded), written once per step by rih_presplit_* because weights are constant within a step.  The B loader
+// is then a plain 16-byte copy global -> LDS (one 8-k chunk per lane and plane): no conversion instructions for B,
+// which is half of the split engine's VALU work on square tiles (see the plateau analysis above).
 template <int BM, int BN, int AMODE, int BMODE, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
     // global->register prefetch depth: k-tiles in flight.  The 64x64 tile (decoder-sized problems: a handful of
@@ -700,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
         }
         const int o = lds_row(row8) + 4 * ((q8 >> 1) ^ lds_swz(row8)) + 2 * (q8 & 1);
         b_st[0] = o; b_st[1] = o + 512; b_st[2] = o + 1024; b_st[3] = o + 1536;
-    } else {
+    } else {        // BMODE 0 (for BMODE 2 these values are dead)
         const int n = n0 + 4 * bnq;
         const unsigned base = (n < p.N) ? ((unsigned)(bkr * NPB) * (unsigned)p.ldb + (unsigned)n) * 4u : OOB;
 #pragma unroll
@@ -709,6 +719,21 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
         const int sw = (NPB == 4) ? 4 * ((bkr >> 1) ^ (bnq & 3)) + 2 * (bkr & 1) : 4 * ((bkr >> 2) ^ (bnq & 3)) + (bkr & 3);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b_st[j] = (4 * bnq + (j ^ fl)) * 16 + sw;
+    }
+
+    // BMODE 2 (pre-split planes): lane = (row tid>>2 (+64 per pass), 8-k chunk tid&3)
+    constexpr int BPASS = (BN + 63) / 64;
+    unsigned bp_off[BPASS];
+    int bp_st[BPASS];
+    const unsigned bp_plane = (unsigned)p.N * (unsigned)p.ldb * 2u;      // bytes per plane
+    if (BMODE == 2) {
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+            const int r = (tid >> 2) + 64 * i;
+            const int n = n0 + r;
+            bp_off[i] = (n < p.N && r < BN) ? ((unsigned)n * (unsigned)p.ldb + 8u * (tid & 3)) * 2u : OOB;
+            bp_st[i] = lds_row(r) + 4 * ((tid & 3) ^ lds_swz(r));
+        }
     }
 
     // wave-uniform walk over (tap, channel) for the conv A-gather: one tap per k-tile (Cin % 32 == 0)
@@ -721,6 +746,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
     }
 
     float4 areg[PF][NPA], breg[PF][NPB];
+    uint4 bpre[PF][3][BPASS];
 
     auto load_A = [&](int ktile, int st) {
         if (AMODE == 0) {
@@ -778,7 +804,14 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
         }
     };
     auto load_B = [&](int ktile, int st) {
-        if (BMODE == 1) {
+        if (BMODE == 2) {
+            const unsigned ku = (ktile < kend) ? (unsigned)ktile * 2u : OOB;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int i = 0; i < BPASS; ++i)
+                    bpre[st][pl][i] = bloadu4(rB, (bp_off[i] == OOB || ku == OOB) ? OOB : bp_off[i] + (unsigned)pl * bp_plane + ku);
+        } else if (BMODE == 1) {
             const unsigned ku = (ktile + 4 * q8 < kend) ? (unsigned)ktile * 4u : OOB;
 #pragma unroll
             for (int i = 0; i < NPB; ++i) breg[st][i] = bload4(rB, b_off[i] + ku);
@@ -827,7 +860,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
         else store_kstrided(As, PLANE_A, areg[st], a_st, NPA);
     };
     auto store_B = [&](int st) {
-        if (BMODE == 1) store_kcontig(Bs, PLANE_B, breg[st], b_st, NPB);
+        if (BMODE == 2) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int i = 0; i < BPASS; ++i)
+                    if ((tid >> 2) + 64 * i < BN) *reinterpret_cast<uint4*>(Bs + pl * PLANE_B + bp_st[i]) = bpre[st][pl][i];
+        } else if (BMODE == 1) store_kcontig(Bs, PLANE_B, breg[st], b_st, NPB);
         else store_kstrided(Bs, PLANE_B, breg[st], b_st, NPB);
     };
 
@@ -933,7 +972,8 @@ template <int BM, int BN>
 int launch_split(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 grid, hipStream_t s) {
     dim3 block(256);
 #define RIH_LS(AM_, BM_, PL_) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, AM_, BM_, PL_>), grid, block, 0, s, a)
-    if (a_mode == 0 && b_mode == 0) { if (plain) RIH_LS(0, 0, true); else RIH_LS(0, 0, false); }
+    if (a_mode == 0 && b_mode == 2) { if (plain) RIH_LS(0, 2, true); else RIH_LS(0, 2, false); }
+    else if (a_mode == 0 && b_mode == 0) { if (plain) RIH_LS(0, 0, true); else RIH_LS(0, 0, false); }
     else if (a_mode == 0 && b_mode == 1) { if (plain) RIH_LS(0, 1, true); else RIH_LS(0, 1, false); }
     else if (a_mode == 1 && b_mode == 0) { if (plain) RIH_LS(1, 0, true); else RIH_LS(1, 0, false); }
     else { if (plain) RIH_LS(1, 1, true); else RIH_LS(1, 1, false); }
@@ -1440,6 +1480,44 @@ __global__ void pack_conv_weight_sub_kernel(const float* __restrict__ w, float* 
     }
 }
 
+// Pre-split B operands for gemm_split_kernel<..., BMODE 2>: dst = three bf16 planes [hi | mid | lo][N][Kpad] (as dwords
+// [3][N][Kpad/2], k even in the low half), B(k, n) taken from
+//   mode 0 / 1: a plain matrix in b_mode 0 / 1 layout (src[k*ld + n] / src[n*ld + k]);
+//   mode 2: an OIHW conv weight as the forward operand, k = (tap, ci < CinPad), n = co;
+//   mode 3: an OIHW conv weight as the data-gradient operand of the tap subset (kh0 + step*t, kw0 + step*t'), flipped:
+//           k = ((th, tw), co), n = ci < CinPad  (the full stride-1 gradient is kh0 = kw0 = 0, step 1, Th x Tw = KH x KW).
+struct PresplitArgs {
+    const float* src;
+    unsigned* dst;
+    int N, K, Kpad, mode, ld;
+    int Cout, Cin, KH, KW, CinPad, kh0, kw0, step, Th, Tw;
+};
+__device__ __forceinline__ float presplit_fetch(const PresplitArgs& a, int n, int k) {
+    if (k >= a.K) return 0.f;
+    if (a.mode == 0) return a.src[(long long)k * a.ld + n];
+    if (a.mode == 1) return a.src[(long long)n * a.ld + k];
+    if (a.mode == 2) {
+        const int tap = k / a.CinPad, ci = k - tap * a.CinPad;
+        return ci < a.Cin ? a.src[((long long)n * a.Cin + ci) * (a.KH * a.KW) + tap] : 0.f;
+    }
+    const int co = k % a.Cout, t = k / a.Cout;
+    const int tw = t % a.Tw, th = t / a.Tw;
+    const int kh = a.kh0 + a.step * (a.Th - 1 - th), kw = a.kw0 + a.step * (a.Tw - 1 - tw);
+    return n < a.Cin ? a.src[(((long long)co * a.Cin + n) * a.KH + kh) * a.KW + kw] : 0.f;
+}
+__global__ void presplit_kernel(const PresplitArgs a) {
+    const int half = a.Kpad / 2;
+    const long long plane = (long long)a.N * half, total = plane;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / half), j = (int)(i - (long long)n * half);
+        unsigned h, m, l;
+        split2(presplit_fetch(a, n, 2 * j), presplit_fetch(a, n, 2 * j + 1), h, m, l);
+        a.dst[i] = h;
+        a.dst[i + plane] = m;
+        a.dst[i + 2 * plane] = l;
+    }
+}
+
 }  // namespace
 
 extern "C" int rih_pack_conv_weight_sub(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int CinPad,
@@ -1452,6 +1530,37 @@ extern "C" int rih_pack_conv_weight_sub(const float* w, float* dst, int Cout, in
     hipLaunchKernelGGL(pack_conv_weight_sub_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, dst, Cout, Cin,
                        KH, KW, CinPad, kh0, kw0, step, Th, Tw);
     return (int)hipGetLastError();
+}
+
+static int launch_presplit(const PresplitArgs& a, void* stream) {
+    const long long total = (long long)a.N * (a.Kpad / 2);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(presplit_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+extern "C" int rih_presplit_matrix(const float* B, int b_mode, int K, int N, int ldb, void* dst, int Kpad, void* stream) {
+    if (!B || !dst || (b_mode != 0 && b_mode != 1) || K < 1 || N < 1 || Kpad < K || Kpad % 32 != 0) return RIH_EINVAL;
+    if (ldb < (b_mode == 0 ? N : K)) return RIH_EINVAL;
+    PresplitArgs a = {};
+    a.src = B; a.dst = (unsigned*)dst; a.N = N; a.K = K; a.Kpad = Kpad; a.mode = b_mode; a.ld = ldb;
+    return launch_presplit(a, stream);
+}
+extern "C" int rih_presplit_conv_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int CinPad,
+                                        int for_dgrad, int kh0, int kw0, int step, int Th, int Tw, int Kpad, void* stream) {
+    if (!w || !dst || Cout < 1 || Cin < 1 || KH < 1 || KW < 1 || CinPad < Cin || Kpad % 32 != 0) return RIH_EINVAL;
+    PresplitArgs a = {};
+    a.src = w; a.dst = (unsigned*)dst; a.Kpad = Kpad;
+    a.Cout = Cout; a.Cin = Cin; a.KH = KH; a.KW = KW; a.CinPad = CinPad;
+    if (!for_dgrad) {
+        a.mode = 2; a.N = Cout; a.K = KH * KW * CinPad;
+    } else {
+        if (step < 1 || Th < 1 || Tw < 1 || kh0 < 0 || kw0 < 0 || kh0 + step * (Th - 1) >= KH || kw0 + step * (Tw - 1) >= KW)
+            return RIH_EINVAL;
+        a.mode = 3; a.N = CinPad; a.K = Th * Tw * Cout;
+        a.kh0 = kh0; a.kw0 = kw0; a.step = step; a.Th = Th; a.Tw = Tw;
+    }
+    if (Kpad < a.K) return RIH_EINVAL;
+    return launch_presplit(a, stream);
 }
 
 extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
@@ -1469,6 +1578,10 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
         if (imgs * d->H * d->W * (long long)d->lda >= (1ll << 31)) return RIH_EINVAL;
         const long long rowsB = (d->b_mode == 0) ? (long long)d->K : (long long)d->N;
         if (rowsB * (long long)d->ldb >= (1ll << 31)) return RIH_EINVAL;
+        if (d->b_mode < 0 || d->b_mode > 2) return RIH_EINVAL;
+        if (d->b_mode == 2 && (d->a_mode != 0 || d->engine != 1 || d->ldb % 32 != 0 || d->ldb < d->K || d->sB1 != 0 ||
+                               d->sB2 != 0 || d->tile > 2 || d->upS != 1))
+            return RIH_EINVAL;      // pre-split B: forward-type GEMMs on the split engine's fast path only
         if (d->H > 16000 || d->W > 16000 || d->Ho > 16000 || d->Wo > 16000 || d->strideA > 64 || d->padH > 64 ||
             d->padW > 64 || d->KH > 64 || d->KW > 64)
             return RIH_EINVAL;
@@ -1518,7 +1631,8 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
         const long long a_bytes = plain ? ((rowsA - 1) * d->lda + colsA) * 4ll
                                         : imgs * d->H * d->W * (long long)d->lda * 4ll;
         const long long rowsB = (d->b_mode == 0) ? (long long)d->K : (long long)d->N;
-        const long long b_bytes = ((rowsB - 1) * d->ldb + ((d->b_mode == 0) ? d->N : d->K)) * 4ll;
+        const long long b_bytes = (d->b_mode == 2) ? 3ll * d->N * d->ldb * 2ll
+                                                   : ((rowsB - 1) * d->ldb + ((d->b_mode == 0) ? d->N : d->K)) * 4ll;
         bool ok = a_bytes < (1ll << 31) && b_bytes < (1ll << 31) && d->K >= 1;
         if (d->a_mode == 0 && !plain) ok = ok && (d->Cin % 32 == 0) && (d->KH * d->KW <= 32);
         if (d->a_mode == 1) ok = ok && (d->M % 4 == 0) && (plain || (d->Wo % 4 == 0 && d->Cin % 4 == 0));
@@ -1538,6 +1652,7 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
             return launch_split<64, 64>(a, d->a_mode, d->b_mode, plain, grid, s);
         }
     }
+    if (d->b_mode == 2) return RIH_EINVAL;  // the general kernels do not read pre-split operands
     if (d->tile == 4) return RIH_EINVAL;    // 256x128 exists only on the split engine's fast path
     if (d->tile == 0) return launch_tile<128, 128>(a, d->a_mode, d->b_mode, d->engine, grid, s);
     if (d->tile == 1) return launch_tile<128, 64>(a, d->a_mode, d->b_mode, d->engine, grid, s);

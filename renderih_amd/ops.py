@@ -104,6 +104,32 @@ def _seed_dev():
 # Run the per-hand decoder layers as paired launches on hands-stacked activations (LinearPairFn & co. below).
 PAIR_HANDS = os.environ.get('RIH_PAIR_HANDS', '1') != '0'
 
+# Pre-split weight operands (rih_gemm b_mode 2): the bf16 hi/mid/lo planes of a convolution weight are produced once per
+# use by rih_presplit_conv_weight instead of inside the GEMM's loader.  OFF by default: written and verified on the
+# HIP-on-CPU harness (tests/test_kernels_on_cpu.py) after this round's GPU budget was spent -- not yet measured.
+PRESPLIT = os.environ.get('RIH_PRESPLIT', '0') == '1'
+
+
+def _presplit_weight(w, Cx, for_dgrad, sub=None):
+    """(planes, Kpad) of an OIHW weight as forward operand (N = Cout) or as data-gradient operand of the tap subset
+    `sub` = (kh0, kw0, step, Th, Tw) (N = Cx)."""
+    Cout, Cin, KH, KW = w.shape
+    kh0, kw0, step, Th, Tw = sub if sub is not None else (0, 0, 1, KH, KW)
+    K = KH * KW * Cx if not for_dgrad else Th * Tw * Cout
+    Nn = Cout if not for_dgrad else Cx
+    Kp = _cdiv(K, 32) * 32
+    planes = torch.empty((3, Nn, Kp // 2), device=w.device, dtype=torch.float32)       # one float = two bf16
+    check(_L().rih_presplit_conv_weight(w.data_ptr(), planes.data_ptr(), Cout, Cin, KH, KW, Cx, 1 if for_dgrad else 0,
+                                        kh0, kw0, step, Th, Tw, Kp, _stream()), 'rih_presplit_conv_weight')
+    return planes, Kp
+
+
+def _presplit_ok(Ngemm, Kchan, taps, engine=None):
+    """Preconditions of the b_mode 2 fast path: split engine, a 64-wide-or-larger tile, 32-channel-aligned gather."""
+    e = ENGINE if engine is None else engine
+    return PRESPLIT and e == 1 and Ngemm > 32 and Kchan % 32 == 0 and taps <= 32
+
+
 # When set to a list, every rih_gemm launch is bracketed by HIP events on the launch stream and
 # (flops, start, end, tag) is appended -- bench.py uses this for the live roofline measurement.
 PROFILE = None
@@ -243,7 +269,10 @@ class Conv2dFn(torch.autograd.Function):
         y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
         M, K = N * Ho * Wo, KH * KW * Cx
         geom = (H, W_, Cx, Ho, Wo, KH, KW, stride, 1, pad, pad)
-        if KH * KW == 1 and Cx == Cin:
+        if _presplit_ok(Cout, Cx, KH * KW):
+            wp, Kp = _presplit_weight(w, Cx, False)
+            gemm(x, wp, y, M, Cout, K, Cx, Kp, Cout, a_mode=0, b_mode=2, bias=bias, relu=relu, geom=geom)
+        elif KH * KW == 1 and Cx == Cin:
             gemm(x, w, y, M, Cout, K, Cx, Cin, Cout, a_mode=0, b_mode=1, bias=bias, relu=relu, geom=geom)
         else:
             wp = torch.empty((K, Cout), device=x.device, dtype=torch.float32)
@@ -292,6 +321,11 @@ class Conv2dFn(torch.autograd.Function):
                     continue
                 padh, padw = Th - 1 - (oh + pad - kh0) // stride, Tw - 1 - (ow + pad - kw0) // stride
                 geom = (Ho, Wo, Cout, Hc, Wc, Th, Tw, 1, 1, padh, padw)
+                if _presplit_ok(Cx, Cout, Th * Tw):
+                    wd, Kp = _presplit_weight(w, Cx, True, (kh0, kw0, stride, Th, Tw))
+                    gemm(dy, wd, dx, N * Hc * Wc, Cx, Th * Tw * Cout, Cout, Kp, Cx, a_mode=0, b_mode=2, geom=geom,
+                         cstride=(stride, oh, ow, H, W_))
+                    continue
                 if KH * KW == 1 and Cx == Cin:
                     wd = w
                 else:
@@ -306,7 +340,10 @@ class Conv2dFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             Mx = N * H * W_
             geom = (Ho, Wo, Cout, H, W_, KH, KW, 1, stride, KH - 1 - pad, KW - 1 - pad)
-            if KH * KW == 1 and Cx == Cin:
+            if _presplit_ok(Cx, Cout, KH * KW):
+                wd, Kp = _presplit_weight(w, Cx, True)
+                gemm(dy, wd, dx, Mx, Cx, KH * KW * Cout, Cout, Kp, Cx, a_mode=0, b_mode=2, geom=geom, R=dskip, ldr=Cx)
+            elif KH * KW == 1 and Cx == Cin:
                 gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cin, Cx, a_mode=0, b_mode=0, geom=geom, R=dskip, ldr=Cx)
             else:
                 wd = torch.empty((KH * KW * Cout, Cx), device=x.device, dtype=torch.float32)

@@ -100,8 +100,13 @@ class EmulatedLib:
                 if d.a_mode == 1 and d.ones_row > 0:
                     A[d.ones_row, :] = 1.0
                 kk, nn = np.meshgrid(np.arange(K), np.arange(N), indexing='ij')
-                bidx = kk * d.ldb + nn if d.b_mode == 0 else nn * d.ldb + kk
-                Bm = self._gather(Bb, bidx, np.ones_like(bidx, bool)) if K > 0 else np.zeros((0, N), np.float32)
+                if d.b_mode == 2:       # pre-split planes [3][N][ldb] bf16: B = hi + mid + lo
+                    raw = np.ctypeslib.as_array((C.c_uint16 * (3 * N * d.ldb)).from_address(int(d.B))).reshape(3, N, d.ldb)
+                    planes = (raw.astype(np.uint32) << 16).view(np.float32)
+                    Bm = (planes[0] + planes[1] + planes[2])[:, :K].T.astype(np.float32)
+                else:
+                    bidx = kk * d.ldb + nn if d.b_mode == 0 else nn * d.ldb + kk
+                    Bm = self._gather(Bb, bidx, np.ones_like(bidx, bool)) if K > 0 else np.zeros((0, N), np.float32)
                 crow = np.arange(M)
                 if d.cS > 1:        # strided output rows (parity class of a strided-conv data gradient)
                     assert d.a_mode == 0 and d.splitk == 1 and not d.R
@@ -129,6 +134,40 @@ class EmulatedLib:
                 mem = _f(Cb, int(crow.max()) * d.ldc + N)
                 mem[(cm * d.ldc + cn).ravel()] = out.astype(np.float32).ravel()
         return 0
+
+    @staticmethod
+    def _bf16_rne(x):
+        u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
+        return r.astype(np.uint16)
+
+    def _presplit_store(self, Bkn, dst, Kpad):
+        """Bkn [K][N] fp32 -> planes [3][N][Kpad] bf16 (hi, mid, lo; round to nearest even at every level)."""
+        K, N = Bkn.shape
+        x = np.zeros((N, Kpad), np.float32)
+        x[:, :K] = Bkn.T
+        out = np.ctypeslib.as_array((C.c_uint16 * (3 * N * Kpad)).from_address(int(dst))).reshape(3, N, Kpad)
+        for pl in range(3):
+            h = self._bf16_rne(x)
+            out[pl] = h
+            x = x - (h.astype(np.uint32) << 16).view(np.float32)
+        return 0
+
+    def rih_presplit_matrix(self, B, b_mode, K, N, ldb, dst, Kpad, stream):
+        src = _f(B, (K - 1) * ldb + N if b_mode == 0 else (N - 1) * ldb + K)
+        kk, nn = np.meshgrid(np.arange(K), np.arange(N), indexing='ij')
+        return self._presplit_store(src[kk * ldb + nn if b_mode == 0 else nn * ldb + kk], dst, Kpad)
+
+    def rih_presplit_conv_weight(self, w, dst, Cout, Cin, KH, KW, CinPad, for_dgrad, kh0, kw0, step, Th, Tw, Kpad, stream):
+        W = _f(w, Cout * Cin * KH * KW).reshape(Cout, Cin, KH, KW)
+        Wp = np.zeros((Cout, CinPad, KH, KW), np.float32)
+        Wp[:, :Cin] = W
+        if not for_dgrad:
+            Bkn = Wp.transpose(2, 3, 1, 0).reshape(KH * KW * CinPad, Cout)            # k = (tap, ci), n = co
+        else:
+            sel = Wp[:, :, [kh0 + step * (Th - 1 - t) for t in range(Th)]][:, :, :, [kw0 + step * (Tw - 1 - t) for t in range(Tw)]]
+            Bkn = sel.transpose(2, 3, 0, 1).reshape(Th * Tw * Cout, CinPad)            # k = ((th, tw), co), n = ci
+        return self._presplit_store(Bkn, dst, Kpad)
 
     def rih_splitk_reduce(self, P, S, M, N, dst, Cin, taps, CinValid, accumulate, stream):
         return self.rih_splitk_reduce_bias(P, S, M, M, N, dst, Cin, taps, CinValid, accumulate, 0, stream)

@@ -123,6 +123,15 @@ def test_paired_decoder_runs_with_dropout(monkeypatch):
     assert torch.isfinite(s) and all(torch.isfinite(p.grad).all() for p in dec.parameters() if p.grad is not None)
 
 
+def test_presplit_weight_host_logic(monkeypatch):
+    """ops.PRESPLIT (rih_gemm b_mode 2 + rih_presplit_conv_weight, off by default): descriptor / operand plumbing."""
+    from renderih_amd import ops
+    monkeypatch.setattr(ops, 'PRESPLIT', True)
+    G.test_conv2d((2, 8, 8, 64, 64, 3, 1, 1, True, True))
+    G.test_conv2d((1, 8, 8, 64, 64, 3, 2, 1, False, False))
+    G.test_conv2d((2, 8, 8, 64, 128, 1, 1, 0, False, True))
+
+
 def test_pool_layout_host_logic(monkeypatch):
     G.test_pool_upsample_layout()
     G.test_resample_hrnet(4, 5, 7, 32)

@@ -102,3 +102,38 @@ def test_mesh_loss_kernel():
 def test_metrics_and_pose_head_kernels():
     TMET._check_against_oracle(CPU)
     TP._pose_head_kernels_vs_oracle(CPU)
+
+
+@pytest.mark.parametrize('case', [
+    (2, 8, 8, 64, 64, 3, 1, 1, True, True),         # 3x3: forward + stride-1 data gradient read pre-split weights
+    (1, 8, 8, 64, 64, 3, 2, 1, False, False),       # strided: one pre-split tap subset per parity class
+    (2, 8, 8, 64, 128, 1, 1, 0, False, True),       # 1x1
+    (2, 4, 4, 96, 40, 1, 2, 0, True, False),        # N = 40: a partial 64-wide tile of plane rows
+])
+def test_presplit_weight_path(monkeypatch, case):
+    """rih_gemm b_mode 2 (B as pre-split bf16 planes from rih_presplit_conv_weight) against F.conv2d; off by default in
+    the product (ops.PRESPLIT), enabled here on the host-compiled kernels."""
+    from renderih_amd import ops
+    calls = []
+    real = ops._presplit_weight
+    monkeypatch.setattr(ops, 'PRESPLIT', True)
+    monkeypatch.setattr(ops, '_presplit_weight', lambda *a, **k: (calls.append(a[2]), real(*a, **k))[1])
+    G.test_conv2d(case)
+    N_, H_, W_, Cin, Cout = case[:5]
+    assert False in calls, calls                             # the forward operand went through it
+    assert (True in calls) == (Cin > 32 and Cout % 32 == 0), calls      # ... and the data-gradient operand where eligible
+
+
+def test_presplit_matrix_entry_point():
+    """rih_presplit_matrix on a plain [N][K] weight + b_mode 2 GEMM == the fp32 product."""
+    import math
+    from renderih_amd import ops
+    from renderih_amd._lib import check
+    M, K, N = 70, 100, 72
+    x, w = G.rnd(M, K, seed=1), G.rnd(N, K, seed=2, scale=1 / math.sqrt(K))
+    Kp = 128
+    planes = torch.empty(3, N, Kp // 2)
+    check(ops._L().rih_presplit_matrix(w.data_ptr(), 1, K, N, K, planes.data_ptr(), Kp, 0), 'rih_presplit_matrix')
+    y = torch.empty(M, N)
+    ops.gemm(x, planes, y, M, N, K, K, Kp, N, a_mode=0, b_mode=2, engine=1)
+    TMET.assert_close(y, (x.double() @ w.double().t()).float(), 1e-5, 1e-6, 'presplit matrix gemm')
