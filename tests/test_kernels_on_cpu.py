@@ -137,3 +137,86 @@ def test_presplit_matrix_entry_point():
     y = torch.empty(M, N)
     ops.gemm(x, planes, y, M, N, K, K, Kp, N, a_mode=0, b_mode=2, engine=1)
     TMET.assert_close(y, (x.double() @ w.double().t()).float(), 1e-5, 1e-6, 'presplit matrix gemm')
+
+
+def test_gemm_descriptor_fuzz_against_emulator():
+    """Differential test over the rih_gemm descriptor space: the real kernels (host build: general and split-engine fast
+    path, all tiles, both engines, im2col / transposed gathers, strides, padding, leading-dimension padding, split-K,
+    bias / residual / ReLU / alpha, the all-ones row, two-slice batches) against the independent numpy restatement of the
+    ABI in tests/abi_emulator.py, including that nothing outside the [M][N] window of C is written."""
+    import ctypes as C
+    import numpy as np
+    from abi_emulator import EmulatedLib
+    from host_kernels import load
+    from renderih_amd._lib import GemmDesc
+    host, emu = load(), EmulatedLib()
+    rs = np.random.RandomState(5)
+    cdiv = lambda a, b: -(-a // b)
+    checked = 0
+    for it in range(70):
+        engine, a_mode, b_mode = int(rs.randint(0, 2)), int(rs.randint(0, 2)), int(rs.randint(0, 2))
+        conv = rs.rand() < 0.5
+        nb1 = 1
+        if conv:
+            Nimg, H, W = int(rs.randint(1, 3)), int(rs.randint(3, 9)), int(rs.randint(3, 9))
+            Cin, KH, KW = int(rs.choice([4, 8, 32, 36, 64])), int(rs.choice([1, 2, 3])), int(rs.choice([1, 2, 3]))
+            stride, pad = int(rs.choice([1, 1, 2])), int(rs.randint(0, 2))
+            Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+            if Ho < 1 or Wo < 1:
+                continue
+            lda = Cin + int(rs.choice([0, 0, 4]))
+            pix, taps = Nimg * Ho * Wo, KH * KW
+            M, K = (pix, taps * Cin) if a_mode == 0 else (taps * Cin, pix)
+            a_size = Nimg * H * W * lda
+            geom = (H, W, Cin, Ho, Wo, KH, KW, stride, 1, pad, pad)
+        else:
+            M, K = int(rs.randint(1, 150)), int(rs.choice([4, 8, 20, 32, 36, 64, 100]))
+            lda = (K if a_mode == 0 else M) + int(rs.choice([0, 0, 4, 1]))
+            a_size = (M if a_mode == 0 else K) * lda
+            geom = (1, 1, (K if a_mode == 0 else M), 1, 1, 1, 1, 1, 1, 0, 0)
+            nb1 = int(rs.choice([1, 1, 2]))
+        N = int(rs.choice([3, 8, 24, 40, 64, 72, 130]))
+        ldb = (N if b_mode == 0 else K) + int(rs.choice([0, 0, 4]))
+        b_size = (K if b_mode == 0 else N) * ldb
+        splitk, kchunk = 1, 0
+        if rs.rand() < 0.3 and K >= 64:
+            kchunk = cdiv(cdiv(K, 2), 32) * 32
+            splitk = cdiv(K, kchunk)
+        ldc = N + int(rs.choice([0, 0, 4]))
+        tile = int(rs.choice([0, 1, 2, 3])) if (engine == 0 or N <= 32) else int(rs.choice([0, 1, 2]))
+        plain_ep = splitk == 1
+        use_bias, use_R, relu = plain_ep and rs.rand() < 0.5, plain_ep and rs.rand() < 0.3, plain_ep and rs.rand() < 0.3
+        Mp, ones_row = M, 0
+        if a_mode == 1 and rs.rand() < 0.4:
+            Mp, ones_row = M + 4, M
+        alpha = float(rs.choice([1.0, 0.5]))
+        A = rs.randn(nb1 * a_size + 8).astype(np.float32)
+        B = rs.randn(nb1 * b_size + 8).astype(np.float32)
+        sB1 = int(rs.choice([0, b_size])) if nb1 > 1 else 0
+        bias, R = rs.randn(nb1 * N).astype(np.float32), rs.randn(nb1 * Mp * (N + 4)).astype(np.float32)
+        outs = []
+        for lib in (host, emu):
+            Cc = np.full(nb1 * splitk * Mp * ldc + 8, 7.0, np.float32)
+            d = GemmDesc()
+            d.A, d.B, d.C = A.ctypes.data, B.ctypes.data, Cc.ctypes.data
+            d.bias, d.R = (bias.ctypes.data if use_bias else 0), (R.ctypes.data if use_R else 0)
+            d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ldr = Mp, N, K, lda, ldb, ldc, N + 4
+            d.a_mode, d.b_mode, d.nb1, d.nb2 = a_mode, b_mode, nb1, 1
+            d.sA1, d.sB1, d.sC1 = a_size, sB1, splitk * Mp * ldc
+            d.sBias1, d.sR1 = (N if rs.rand() < 2 else 0), Mp * (N + 4)
+            d.splitk, d.kchunk, d.sCsplit, d.alpha, d.relu = splitk, kchunk, Mp * ldc, alpha, 1 if relu else 0
+            (d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.strideA, d.upS, d.padH, d.padW) = geom
+            d.tile, d.engine, d.ones_row = tile, engine, ones_row
+            outs.append((lib.rih_gemm(C.byref(d), None), Cc))
+        (rc0, c0), (rc1, c1) = outs
+        assert rc0 == 0 and rc1 == 0, (it, rc0, rc1)
+        rows = ones_row + 1 if ones_row else Mp
+        what = 'case %d: e%d a%d b%d conv=%s M%d N%d K%d lda%d ldb%d ldc%d nb%d sk%d tile%d geom=%s' % (
+            it, engine, a_mode, b_mode, conv, Mp, N, K, lda, ldb, ldc, nb1, splitk, tile, geom)
+        v0 = c0[:nb1 * splitk * Mp * ldc].reshape(nb1 * splitk, Mp, ldc)
+        v1 = c1[:nb1 * splitk * Mp * ldc].reshape(nb1 * splitk, Mp, ldc)
+        sc = max(float(np.abs(v1[:, :rows, :N]).max()), 1e-6)
+        assert np.allclose(v0[:, :rows, :N], v1[:, :rows, :N], rtol=2e-5, atol=2e-5 * sc), what
+        assert (v0[:, :, N:] == 7.0).all() and (c0[nb1 * splitk * Mp * ldc:] == 7.0).all(), 'stray write, ' + what
+        checked += 1
+    assert checked >= 60
