@@ -138,10 +138,26 @@ inline void launch(dim3 grid, dim3 block, F&& fn) {
                     f.ctx.uc_link = nullptr;
                     makecontext(&f.ctx, (void (*)())trampoline, 0);
                 }
+                // Visiting order of the fibers within a scheduling round: HIPCPU_SCHED = forward (default) | reverse |
+                // random.  A kernel whose result depends on it has a missing barrier (a data race on the GPU).
+                static const int mode = [] {
+                    const char* e = getenv("HIPCPU_SCHED");
+                    return (e && e[0] == 'r' && e[1] == 'e') ? 1 : (e && e[0] == 'r' && e[1] == 'a') ? 2 : 0;
+                }();
+                static unsigned long long lcg = 0x9E3779B97F4A7C15ull;
+                std::vector<int> order(n);
+                for (int t = 0; t < n; ++t) order[t] = (mode == 1) ? n - 1 - t : t;
                 int remaining = n;
                 while (remaining > 0) {
                     remaining = 0;
-                    for (int t = 0; t < n; ++t) {
+                    if (mode == 2)
+                        for (int t = n - 1; t > 0; --t) {
+                            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+                            const int j = (int)((lcg >> 33) % (unsigned)(t + 1));
+                            const int tmp = order[t]; order[t] = order[j]; order[j] = tmp;
+                        }
+                    for (int k = 0; k < n; ++k) {
+                        const int t = order[k];
                         if (s.fibers[t].done) continue;
                         s.cur = &s.fibers[t];
                         swapcontext(&s.sched, &s.fibers[t].ctx);

@@ -220,3 +220,16 @@ def test_gemm_descriptor_fuzz_against_emulator():
         assert (v0[:, :, N:] == 7.0).all() and (c0[nb1 * splitk * Mp * ldc:] == 7.0).all(), 'stray write, ' + what
         checked += 1
     assert checked >= 60
+
+
+@pytest.mark.parametrize('sched', ['reverse'] + (['random'] if os.environ.get('HIPCPU_MORE') else []))
+def test_kernels_are_schedule_independent(sched):
+    """Missing-barrier detector: the fibers of a block are visited in reverse / random order per scheduling round
+    (HIPCPU_SCHED, read once per process -> a child process); a kernel with a data race on its LDS tiles would change
+    its result.  Subset: implicit-GEMM fast path, the four-slot-ring kernel, wavefront-reduction kernels, MANO, loss."""
+    import subprocess
+    env = dict(os.environ, HIPCPU_SCHED=sched)
+    sel = 'conv2d_kernels or tile4 or mesh_loss or mano_kernels or metrics_and_pose or graph_and_resampling'
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k', sel, '-p', 'no:cacheprovider'],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
