@@ -112,7 +112,12 @@ def test_new_model_schema_equals_reference():
 def test_new_model_oracle_matches_reference(mode):
     z = np.load(os.path.join(GOLDEN, 'net_newlijun_%s.npz' % mode))
     training = mode == 'train'
-    (w32, g32), (_, g64) = _oracle_runs(training)
+    if training:
+        (w32, g32), (_, g64) = _oracle_runs(True)
+    else:
+        _, sd = _oracle_state()
+        graph = net_oracle.graph_from_dicts(assets.load_graph_dict('left'), assets.load_graph_dict('right'))
+        w32, _ = net_oracle.run(sd, graph, testing.seeded_image(2, seed=12), False, torch.float32, False, mano=mano_consts())
     assert {('out/' + k) for k in w32} == {k.split('#')[0] for k in z.files if k.startswith('out/')}
     from test_oracle_golden import _check
     tol = (2e-3, 5e-4) if training else (1e-4, 1e-5)          # train-mode BN at B=2: see test_oracle_golden.py
