@@ -43,6 +43,9 @@ extern "C" {
  *           X[img][(ho*strideA - padH + kh)/upS][(wo*strideA - padW + kw)/upS][ci]  (0 when out of range or
  *           not divisible by upS; upS>1 expresses the data-gradient of a strided conv).  K-contiguous.
  * a_mode 1: A(m,k): m = (kh,kw,ci), k = (img,ho,wo) -- the transpose gather, M-contiguous (weight grad).
+ * a_mode 2: a_mode 0 on a PRE-SPLIT activation: A points to three bf16 planes [hi|mid|lo][pixels][lda] written by
+ *           rih_presplit_matrix(x, b_mode 1, K = channels, N = pixels); lda in bf16 elements (% 8), Cin % 32 == 0,
+ *           together with b_mode 2 only -- the kernel then converts nothing at all (engine 1 fast path).
  * b_mode 0: B(k,n) = Bp[k*ldb + n]   (row-major [K][N])
  * b_mode 1: B(k,n) = Bp[n*ldb + k]   ([N][K], e.g. an nn.Linear / 1x1-conv weight as stored)
  * b_mode 2: B pre-split by rih_presplit_*: three bf16 planes [hi|mid|lo][N][ldb] (ldb = K rounded up to 32, zero padded);

@@ -39,6 +39,7 @@ struct GemmArgs {
     unsigned a_bytes, b_bytes;      // extent of one batch slice of A / B (split fast path: buffer range check)
     int cS, cOH, cOW, cH, cW;       // strided output rows (parity classes of a strided-conv data gradient)
     int ones_row;                   // a_mode 1: A(ones_row, k) = 1 for every valid k (bias gradient row); 0 = off
+    unsigned a_plane;               // a_mode 2: bytes per pre-split plane of A (last: keeps the older kernels' kernarg offsets)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -585,7 +586,10 @@ __device__ __forceinline__ uint4 bloadu4(__amdgpu_buffer_rsrc_t r, unsigned off)
 // zero padded), written once per step by rih_presplit_* because weights are constant within a step.  The B loader
 // is then a plain 16-byte copy global -> LDS (one 8-k chunk per lane and plane): no conversion instructions for B,
 // which is half of the split engine's VALU work on square tiles (see the plateau analysis above).
-template <int BM, int BN, int AMODE, int BMODE, bool PLAIN>
+// APRE (a_mode 2): A arrives pre-split as well -- planes [hi | mid | lo][pixels][lda] bf16, channels contiguous, written
+// by rih_presplit_matrix on the NHWC activation; AMODE must be 0 (im2col / plain rows), the loader is the BMODE 2 one
+// plus the per-row window offsets and tap validity bits.  With both operands pre-split the kernel converts nothing.
+template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
     // global->register prefetch depth: k-tiles in flight.  The 64x64 tile (decoder-sized problems: a handful of
     // k-tiles, 12 MFMAs each) is bound by the load round trip per k-tile, so it keeps three tiles in flight.
@@ -721,6 +725,38 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
         for (int j = 0; j < 4; ++j) b_st[j] = (4 * bnq + (j ^ fl)) * 16 + sw;
     }
 
+    // APRE: lane = (row tid>>2 (+64 per pass), 8-channel chunk tid&3) of every plane
+    constexpr int APASS = (BM + 63) / 64;
+    unsigned ap_off[APASS], ap_val[APASS];
+    int ap_st[APASS];
+    if (APRE) {
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            const int r = (tid >> 2) + 64 * i;
+            const int m = m0 + r;
+            ap_val[i] = 0;
+            ap_st[i] = lds_row(r) + 4 * ((tid & 3) ^ lds_swz(r));
+            if (m >= p.M || r >= BM) {
+                ap_off[i] = OOB;
+            } else if (PLAIN) {
+                ap_off[i] = ((unsigned)m * (unsigned)p.lda + 8u * (tid & 3)) * 2u;
+            } else {
+                const int wo = m % p.Wo;
+                const int t = m / p.Wo;
+                const int ho = t % p.Ho;
+                const int img = t / p.Ho;
+                const int hi0 = ho * p.strideA - p.padH, wi0 = wo * p.strideA - p.padW;
+                ap_off[i] = (unsigned)((((img * p.H + hi0) * p.W + wi0) * p.lda + 8 * (tid & 3)) * 2);
+                unsigned bits = 0;
+                for (int kh = 0; kh < p.KH; ++kh)
+                    for (int kw = 0; kw < p.KW; ++kw)
+                        if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W)
+                            bits |= 1u << (kh * p.KW + kw);
+                ap_val[i] = bits;
+            }
+        }
+    }
+
     // BMODE 2 (pre-split planes): lane = (row tid>>2 (+64 per pass), 8-k chunk tid&3)
     constexpr int BPASS = (BN + 63) / 64;
     unsigned bp_off[BPASS];
@@ -747,9 +783,26 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
 
     float4 areg[PF][NPA], breg[PF][NPB];
     uint4 bpre[PF][3][BPASS];
+    uint4 apre[PF][3][APASS];
 
     auto load_A = [&](int ktile, int st) {
-        if (AMODE == 0) {
+        if (APRE) {
+            unsigned add, bit;
+            if (PLAIN) {
+                add = (unsigned)ktile * 2u;
+                bit = (ktile < kend) ? 1u : 0u;
+            } else {
+                add = (unsigned)(((u_kh * p.W + u_kw) * p.lda + u_ci) * 2);
+                bit = (ktile < kend) ? (1u << (u_tap & 31)) : 0u;
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int i = 0; i < APASS; ++i) {
+                    const bool ok = PLAIN ? (bit != 0u && ap_off[i] != OOB) : ((ap_val[i] & bit) != 0u);
+                    apre[st][pl][i] = bloadu4(rA, ok ? ap_off[i] + add + (unsigned)pl * p.a_plane : OOB);
+                }
+        } else if (AMODE == 0) {
             if (PLAIN) {
                 const unsigned ku = (ktile + 4 * q8 < kend) ? (unsigned)ktile * 4u : OOB;
 #pragma unroll
@@ -856,7 +909,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
         }
     };
     auto store_A = [&](int st) {
-        if (AMODE == 0) store_kcontig(As, PLANE_A, areg[st], a_st, NPA);
+        if (APRE) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int i = 0; i < APASS; ++i)
+                    if ((tid >> 2) + 64 * i < BM) *reinterpret_cast<uint4*>(As + pl * PLANE_A + ap_st[i]) = apre[st][pl][i];
+        } else if (AMODE == 0) store_kcontig(As, PLANE_A, areg[st], a_st, NPA);
         else store_kstrided(As, PLANE_A, areg[st], a_st, NPA);
     };
     auto store_B = [&](int st) {
@@ -972,7 +1031,11 @@ template <int BM, int BN>
 int launch_split(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 grid, hipStream_t s) {
     dim3 block(256);
 #define RIH_LS(AM_, BM_, PL_) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, AM_, BM_, PL_>), grid, block, 0, s, a)
-    if (a_mode == 0 && b_mode == 2) { if (plain) RIH_LS(0, 2, true); else RIH_LS(0, 2, false); }
+    if (a_mode == 2) {      // both operands pre-split (b_mode 2 enforced by rih_gemm)
+        if (plain) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 2, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 2, false, true>), grid, block, 0, s, a);
+    }
+    else if (a_mode == 0 && b_mode == 2) { if (plain) RIH_LS(0, 2, true); else RIH_LS(0, 2, false); }
     else if (a_mode == 0 && b_mode == 0) { if (plain) RIH_LS(0, 0, true); else RIH_LS(0, 0, false); }
     else if (a_mode == 0 && b_mode == 1) { if (plain) RIH_LS(0, 1, true); else RIH_LS(0, 1, false); }
     else if (a_mode == 1 && b_mode == 0) { if (plain) RIH_LS(1, 0, true); else RIH_LS(1, 0, false); }
@@ -1573,13 +1636,16 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
     if (d->a_mode == 1 && d->upS != 1) return RIH_EINVAL;
     if (d->KH * d->KW > 1 && (d->Cin % 4) != 0) return RIH_EINVAL;   // quads must not straddle taps
     {   // 32-bit element offsets inside one batch slice of A and B; window coordinates packed in 16 bits
-        const long long rowsA = (d->a_mode == 0) ? (long long)d->M : (long long)d->K;
+        const long long rowsA = (d->a_mode != 1) ? (long long)d->M : (long long)d->K;
         const long long imgs = (rowsA + (long long)d->Ho * d->Wo - 1) / ((long long)d->Ho * d->Wo);
         if (imgs * d->H * d->W * (long long)d->lda >= (1ll << 31)) return RIH_EINVAL;
         const long long rowsB = (d->b_mode == 0) ? (long long)d->K : (long long)d->N;
         if (rowsB * (long long)d->ldb >= (1ll << 31)) return RIH_EINVAL;
-        if (d->b_mode < 0 || d->b_mode > 2) return RIH_EINVAL;
-        if (d->b_mode == 2 && (d->a_mode != 0 || d->engine != 1 || d->ldb % 32 != 0 || d->ldb < d->K || d->sB1 != 0 ||
+        if (d->b_mode < 0 || d->b_mode > 2 || d->a_mode < 0 || d->a_mode > 2) return RIH_EINVAL;
+        if (d->a_mode == 2 && (d->b_mode != 2 || d->lda % 8 != 0 || d->sA1 != 0 || d->sA2 != 0 || d->nb1 * d->nb2 != 1 ||
+                               d->K % 32 != 0 || d->Cin % 32 != 0))
+            return RIH_EINVAL;      // pre-split A: im2col / plain rows of bf16 planes, together with pre-split B only
+        if (d->b_mode == 2 && (d->a_mode == 1 || d->engine != 1 || d->ldb % 32 != 0 || d->ldb < d->K || d->sB1 != 0 ||
                                d->sB2 != 0 || d->tile > 2 || d->upS != 1))
             return RIH_EINVAL;      // pre-split B: forward-type GEMMs on the split engine's fast path only
         if (d->H > 16000 || d->W > 16000 || d->Ho > 16000 || d->Wo > 16000 || d->strideA > 64 || d->padH > 64 ||
@@ -1603,10 +1669,11 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
     a.vecA = a16 ? 1 : 0;
     a.vecB = b16 ? 1 : 0;
     a.a_bytes = a.b_bytes = 0;
+    a.a_plane = 0;
     a.cS = d->cS; a.cOH = d->cOH; a.cOW = d->cOW; a.cH = d->cH; a.cW = d->cW;
     a.ones_row = d->ones_row;
     if (d->ones_row != 0 && (d->a_mode != 1 || d->ones_row < 0 || d->ones_row >= d->M || d->tile == 4)) return RIH_EINVAL;
-    if (d->cS > 1 && (d->splitk != 1 || d->a_mode != 0 || d->R != nullptr || d->cH < 1 || d->cW < 1 || d->cOH < 0 ||
+    if (d->cS > 1 && (d->splitk != 1 || d->a_mode == 1 || d->R != nullptr || d->cH < 1 || d->cW < 1 || d->cOH < 0 ||
                       d->cOW < 0 || d->nb1 * d->nb2 != 1))
         return RIH_EINVAL;
     int bm = 128, bn = 128;
@@ -1625,16 +1692,19 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
         // fast path of the split engine (see gemm_split_kernel for the preconditions)
         const bool plain = (d->KH == 1 && d->KW == 1 && d->strideA == 1 && d->padH == 0 && d->padW == 0 &&
                             d->H == d->Ho && d->W == d->Wo);
-        const long long rowsA = (d->a_mode == 0) ? (long long)d->M : (long long)d->K;
+        const long long rowsA = (d->a_mode != 1) ? (long long)d->M : (long long)d->K;
         const long long imgs = (rowsA + (long long)d->Ho * d->Wo - 1) / ((long long)d->Ho * d->Wo);
-        const int colsA = (d->a_mode == 0) ? d->K : (d->ones_row > 0 ? d->ones_row : d->M);
-        const long long a_bytes = plain ? ((rowsA - 1) * d->lda + colsA) * 4ll
-                                        : imgs * d->H * d->W * (long long)d->lda * 4ll;
+        const int colsA = (d->a_mode != 1) ? d->K : (d->ones_row > 0 ? d->ones_row : d->M);
+        const long long a_rows = plain ? rowsA : imgs * d->H * d->W;
+        const long long a_plane = a_rows * d->lda * 2ll;                   // a_mode 2: bytes per bf16 plane
+        const long long a_bytes = (d->a_mode == 2) ? 3ll * a_plane
+                                  : plain ? ((rowsA - 1) * d->lda + colsA) * 4ll
+                                          : imgs * d->H * d->W * (long long)d->lda * 4ll;
         const long long rowsB = (d->b_mode == 0) ? (long long)d->K : (long long)d->N;
         const long long b_bytes = (d->b_mode == 2) ? 3ll * d->N * d->ldb * 2ll
                                                    : ((rowsB - 1) * d->ldb + ((d->b_mode == 0) ? d->N : d->K)) * 4ll;
         bool ok = a_bytes < (1ll << 31) && b_bytes < (1ll << 31) && d->K >= 1;
-        if (d->a_mode == 0 && !plain) ok = ok && (d->Cin % 32 == 0) && (d->KH * d->KW <= 32);
+        if (d->a_mode != 1 && !plain) ok = ok && (d->Cin % 32 == 0) && (d->KH * d->KW <= 32);
         if (d->a_mode == 1) ok = ok && (d->M % 4 == 0) && (plain || (d->Wo % 4 == 0 && d->Cin % 4 == 0));
         if (d->b_mode == 0) ok = ok && (d->N % 4 == 0);
         if (d->tile == 4) {     // 256x128 kernel: no general-kernel fallback, the caller must respect the preconditions
@@ -1647,12 +1717,13 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
         if (ok) {
             a.a_bytes = (unsigned)a_bytes;
             a.b_bytes = (unsigned)b_bytes;
+            a.a_plane = (unsigned)a_plane;
             if (d->tile == 0) return launch_split<128, 128>(a, d->a_mode, d->b_mode, plain, grid, s);
             if (d->tile == 1) return launch_split<128, 64>(a, d->a_mode, d->b_mode, plain, grid, s);
             return launch_split<64, 64>(a, d->a_mode, d->b_mode, plain, grid, s);
         }
     }
-    if (d->b_mode == 2) return RIH_EINVAL;  // the general kernels do not read pre-split operands
+    if (d->b_mode == 2 || d->a_mode == 2) return RIH_EINVAL;  // the general kernels do not read pre-split operands
     if (d->tile == 4) return RIH_EINVAL;    // 256x128 exists only on the split engine's fast path
     if (d->tile == 0) return launch_tile<128, 128>(a, d->a_mode, d->b_mode, d->engine, grid, s);
     if (d->tile == 1) return launch_tile<128, 64>(a, d->a_mode, d->b_mode, d->engine, grid, s);

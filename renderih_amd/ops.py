@@ -107,7 +107,10 @@ PAIR_HANDS = os.environ.get('RIH_PAIR_HANDS', '1') != '0'
 # Pre-split weight operands (rih_gemm b_mode 2): the bf16 hi/mid/lo planes of a convolution weight are produced once per
 # use by rih_presplit_conv_weight instead of inside the GEMM's loader.  OFF by default: written and verified on the
 # HIP-on-CPU harness (tests/test_kernels_on_cpu.py) after this round's GPU budget was spent -- not yet measured.
-PRESPLIT = os.environ.get('RIH_PRESPLIT', '0') == '1'
+PRESPLIT = os.environ.get('RIH_PRESPLIT', '0') in ('1', '2')
+# RIH_PRESPLIT=2 additionally pre-splits the ACTIVATION operand of those GEMMs with a standalone pass (rih_gemm a_mode 2):
+# the experiment that tells whether producers (BatchNorm apply / backward) should emit bf16 planes themselves.
+PRESPLIT_ACT = os.environ.get('RIH_PRESPLIT', '0') == '2'
 
 
 def _presplit_weight(w, Cx, for_dgrad, sub=None):
@@ -122,6 +125,13 @@ def _presplit_weight(w, Cx, for_dgrad, sub=None):
     check(_L().rih_presplit_conv_weight(w.data_ptr(), planes.data_ptr(), Cout, Cin, KH, KW, Cx, 1 if for_dgrad else 0,
                                         kh0, kw0, step, Th, Tw, Kp, _stream()), 'rih_presplit_conv_weight')
     return planes, Kp
+
+
+def _presplit_act(x2d_rows, C, x):
+    """bf16 planes [3][rows][C] of an NHWC activation (rows = pixels, C % 32 == 0)."""
+    planes = torch.empty((3, x2d_rows, C // 2), device=x.device, dtype=torch.float32)
+    check(_L().rih_presplit_matrix(x.data_ptr(), 1, C, x2d_rows, C, planes.data_ptr(), C, _stream()), 'rih_presplit_matrix')
+    return planes
 
 
 def _presplit_ok(Ngemm, Kchan, taps, engine=None):
@@ -162,7 +172,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
     d.alpha = alpha
     d.relu = 1 if relu else 0
     if geom is None:
-        cin = K if a_mode == 0 else M
+        cin = K if a_mode != 1 else M
         geom = (1, 1, cin, 1, 1, 1, 1, 1, 1, 0, 0)
     (d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.strideA, d.upS, d.padH, d.padW) = geom
     auto_sk = 1
@@ -271,7 +281,11 @@ class Conv2dFn(torch.autograd.Function):
         geom = (H, W_, Cx, Ho, Wo, KH, KW, stride, 1, pad, pad)
         if _presplit_ok(Cout, Cx, KH * KW):
             wp, Kp = _presplit_weight(w, Cx, False)
-            gemm(x, wp, y, M, Cout, K, Cx, Kp, Cout, a_mode=0, b_mode=2, bias=bias, relu=relu, geom=geom)
+            if PRESPLIT_ACT:
+                gemm(_presplit_act(N * H * W_, Cx, x), wp, y, M, Cout, K, Cx, Kp, Cout, a_mode=2, b_mode=2, bias=bias,
+                     relu=relu, geom=geom)
+            else:
+                gemm(x, wp, y, M, Cout, K, Cx, Kp, Cout, a_mode=0, b_mode=2, bias=bias, relu=relu, geom=geom)
         elif KH * KW == 1 and Cx == Cin:
             gemm(x, w, y, M, Cout, K, Cx, Cin, Cout, a_mode=0, b_mode=1, bias=bias, relu=relu, geom=geom)
         else:
@@ -316,6 +330,7 @@ class Conv2dFn(torch.autograd.Function):
                         classes.append((oh, ow, kh0, kw0, Th, Tw, Hc, Wc))
             dense = all(c[4] > 0 and c[5] > 0 for c in classes)
             dx = torch.empty_like(x) if dense else torch.zeros_like(x)
+            dyp = None
             for oh, ow, kh0, kw0, Th, Tw, Hc, Wc in classes:
                 if Th == 0 or Tw == 0:
                     continue
@@ -323,8 +338,14 @@ class Conv2dFn(torch.autograd.Function):
                 geom = (Ho, Wo, Cout, Hc, Wc, Th, Tw, 1, 1, padh, padw)
                 if _presplit_ok(Cx, Cout, Th * Tw):
                     wd, Kp = _presplit_weight(w, Cx, True, (kh0, kw0, stride, Th, Tw))
-                    gemm(dy, wd, dx, N * Hc * Wc, Cx, Th * Tw * Cout, Cout, Kp, Cx, a_mode=0, b_mode=2, geom=geom,
-                         cstride=(stride, oh, ow, H, W_))
+                    if PRESPLIT_ACT:
+                        if dyp is None:
+                            dyp = _presplit_act(N * Ho * Wo, Cout, dy)
+                        gemm(dyp, wd, dx, N * Hc * Wc, Cx, Th * Tw * Cout, Cout, Kp, Cx, a_mode=2, b_mode=2, geom=geom,
+                             cstride=(stride, oh, ow, H, W_))
+                    else:
+                        gemm(dy, wd, dx, N * Hc * Wc, Cx, Th * Tw * Cout, Cout, Kp, Cx, a_mode=0, b_mode=2, geom=geom,
+                             cstride=(stride, oh, ow, H, W_))
                     continue
                 if KH * KW == 1 and Cx == Cin:
                     wd = w
@@ -342,7 +363,11 @@ class Conv2dFn(torch.autograd.Function):
             geom = (Ho, Wo, Cout, H, W_, KH, KW, 1, stride, KH - 1 - pad, KW - 1 - pad)
             if _presplit_ok(Cx, Cout, KH * KW):
                 wd, Kp = _presplit_weight(w, Cx, True)
-                gemm(dy, wd, dx, Mx, Cx, KH * KW * Cout, Cout, Kp, Cx, a_mode=0, b_mode=2, geom=geom, R=dskip, ldr=Cx)
+                if PRESPLIT_ACT:
+                    gemm(_presplit_act(M, Cout, dy), wd, dx, Mx, Cx, KH * KW * Cout, Cout, Kp, Cx, a_mode=2, b_mode=2,
+                         geom=geom, R=dskip, ldr=Cx)
+                else:
+                    gemm(dy, wd, dx, Mx, Cx, KH * KW * Cout, Cout, Kp, Cx, a_mode=0, b_mode=2, geom=geom, R=dskip, ldr=Cx)
             elif KH * KW == 1 and Cx == Cin:
                 gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cin, Cx, a_mode=0, b_mode=0, geom=geom, R=dskip, ldr=Cx)
             else:

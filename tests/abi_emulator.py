@@ -69,7 +69,13 @@ class EmulatedLib:
                 Ab = d.A + 4 * (b1 * d.sA1 + b2 * d.sA2)
                 Bb = d.B + 4 * (b1 * d.sB1 + b2 * d.sB2)
                 Cb = d.C + 4 * (b1 * d.sC1 + b2 * d.sC2)
-                if d.a_mode == 0:
+                if d.a_mode == 2:       # a_mode 0 on pre-split planes [3][pixels][lda] bf16: rebuild the fp32 activation
+                    pix = (-(-M // (d.Ho * d.Wo))) * d.H * d.W
+                    raw = np.ctypeslib.as_array((C.c_uint16 * (3 * pix * d.lda)).from_address(int(d.A))).reshape(3, -1)
+                    pl = (raw.astype(np.uint32) << 16).view(np.float32)
+                    self._a2 = np.ascontiguousarray(pl[0] + pl[1] + pl[2], np.float32)
+                    Ab = self._a2.ctypes.data
+                if d.a_mode != 1:
                     m = np.arange(M)
                     wo, t = m % d.Wo, m // d.Wo
                     ho, img = t % d.Ho, t // d.Ho
@@ -109,7 +115,7 @@ class EmulatedLib:
                     Bm = self._gather(Bb, bidx, np.ones_like(bidx, bool)) if K > 0 else np.zeros((0, N), np.float32)
                 crow = np.arange(M)
                 if d.cS > 1:        # strided output rows (parity class of a strided-conv data gradient)
-                    assert d.a_mode == 0 and d.splitk == 1 and not d.R
+                    assert d.a_mode != 1 and d.splitk == 1 and not d.R
                     cj, ct = crow % d.Wo, crow // d.Wo
                     ci_, cimg = ct % d.Ho, ct // d.Ho
                     crow = (cimg * d.cH + ci_ * d.cS + d.cOH) * d.cW + cj * d.cS + d.cOW

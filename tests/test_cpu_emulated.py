@@ -130,6 +130,9 @@ def test_presplit_weight_host_logic(monkeypatch):
     G.test_conv2d((2, 8, 8, 64, 64, 3, 1, 1, True, True))
     G.test_conv2d((1, 8, 8, 64, 64, 3, 2, 1, False, False))
     G.test_conv2d((2, 8, 8, 64, 128, 1, 1, 0, False, True))
+    monkeypatch.setattr(ops, 'PRESPLIT_ACT', True)              # + pre-split activations (a_mode 2)
+    G.test_conv2d((2, 8, 8, 64, 64, 3, 1, 1, True, True))
+    G.test_conv2d((1, 8, 8, 64, 64, 3, 2, 1, False, False))
 
 
 def test_pool_layout_host_logic(monkeypatch):

@@ -123,6 +123,25 @@ def test_presplit_weight_path(monkeypatch, case):
     assert (True in calls) == (Cin > 32 and Cout % 32 == 0), calls      # ... and the data-gradient operand where eligible
 
 
+@pytest.mark.parametrize('case', [
+    (2, 8, 8, 64, 64, 3, 1, 1, True, True),
+    (1, 8, 8, 64, 64, 3, 2, 1, False, False),
+    (2, 8, 8, 64, 128, 1, 1, 0, False, True),
+    (1, 9, 7, 32, 96, 3, 1, 1, True, False),        # odd sizes: partial row passes, halo taps
+])
+def test_presplit_activation_path(monkeypatch, case):
+    """RIH_PRESPLIT=2: both GEMM operands pre-split (rih_gemm a_mode 2 + b_mode 2, activation planes from a standalone
+    rih_presplit_matrix pass) -- forward, stride-1 and parity-class data gradients against F.conv2d."""
+    from renderih_amd import ops
+    acts = []
+    real = ops._presplit_act
+    monkeypatch.setattr(ops, 'PRESPLIT', True)
+    monkeypatch.setattr(ops, 'PRESPLIT_ACT', True)
+    monkeypatch.setattr(ops, '_presplit_act', lambda *a, **k: (acts.append(a[1]), real(*a, **k))[1])
+    G.test_conv2d(case)
+    assert len(acts) >= 1, 'the activation planes were never used'
+
+
 def test_presplit_matrix_entry_point():
     """rih_presplit_matrix on a plain [N][K] weight + b_mode 2 GEMM == the fp32 product."""
     import math

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Per-shape effect of pre-split weight operands (rih_gemm b_mode 2, ops.PRESPLIT) on the ResNet50 convolutions of one
 B=64 step: forward GEMM with the weight converted inside the kernel (b_mode 0 / 1) vs read as pre-split bf16 planes,
-with and without the presplit pass itself.  Every candidate = 20 launches replayed from a hipGraph.  End to end:
+with and without the presplit pass itself, and with the activation pre-split as well (a_mode 2: the GEMM converts
+nothing; the activation pass is timed separately -- it would be folded into the producing BatchNorm kernel).  Every candidate = 20 launches replayed from a hipGraph.  End to end:
 `RIH_PRESPLIT=1 python bench.py`."""
 import os
 import sys
@@ -37,10 +38,14 @@ def one(H, Cin, Cout, k):
     def full():
         pl, kp = ops._presplit_weight(w, Cin, False)
         ops.gemm(x, pl, y, M, Cout, K, Cin, kp, Cout, a_mode=0, b_mode=2, geom=geom, engine=1)
-    t0, t1, t2 = time_graph(base), time_graph(only), time_graph(full)
+    xp = ops._presplit_act(B * H * H, Cin, x)
+    both = lambda: ops.gemm(xp, planes, y, M, Cout, K, Cin, Kp, Cout, a_mode=2, b_mode=2, geom=geom, engine=1)
+    act = lambda: ops._presplit_act(B * H * H, Cin, x)
+    t0, t1, t2, t3, t4 = time_graph(base), time_graph(only), time_graph(full), time_graph(both), time_graph(act)
     fl = 2.0 * M * Cout * K / 1e6
-    print('fwd %3dx%-3d %4d->%-4d k%d | in-kernel split %7.1f us (%5.1f TF) | pre-split GEMM %7.1f us (%5.1f TF) | + presplit pass'
-          ' %7.1f us | %+5.1f%%' % (H, H, Cin, Cout, k, t0, fl / t0, t1, fl / t1, t2, 100 * (t2 / t0 - 1)), flush=True)
+    print('fwd %3dx%-3d %4d->%-4d k%d | in-kernel split %7.1f us (%5.1f TF) | B pre-split %7.1f us (%5.1f TF), with its pass'
+          ' %7.1f us (%+5.1f%%) | A and B pre-split %7.1f us (%5.1f TF), activation pass %6.1f us'
+          % (H, H, Cin, Cout, k, t0, fl / t0, t1, fl / t1, t2, 100 * (t2 / t0 - 1), t3, fl / t3, t4), flush=True)
     return t0, t2
 
 
