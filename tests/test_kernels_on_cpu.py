@@ -252,3 +252,67 @@ def test_kernels_are_schedule_independent(sched):
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k', sel, '-p', 'no:cacheprovider'],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_presplit_gemm_descriptor_fuzz_against_emulator():
+    """As the descriptor fuzz above, for the pre-split operand modes (b_mode 2 with a_mode 0 or 2): conv gathers with
+    strides / padding / 2x2..3x3 taps, plain rows, split-K, all three tiles, partial N tiles."""
+    import ctypes as C
+    import numpy as np
+    from abi_emulator import EmulatedLib
+    from host_kernels import load
+    from renderih_amd._lib import GemmDesc
+    host, emu = load(), EmulatedLib()
+    rs = np.random.RandomState(3)
+    cdiv = lambda a, b: -(-a // b)
+    checked = 0
+    for it in range(28):
+        conv = rs.rand() < 0.6
+        Cin = int(rs.choice([32, 64, 96]))
+        if conv:
+            Nimg, H, W = int(rs.randint(1, 3)), int(rs.randint(3, 9)), int(rs.randint(3, 9))
+            KH, KW, stride, pad = int(rs.choice([1, 2, 3])), int(rs.choice([1, 2, 3])), int(rs.choice([1, 2])), int(rs.randint(0, 2))
+            Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+            if Ho < 1 or Wo < 1:
+                continue
+            M, K, pix = Nimg * Ho * Wo, KH * KW * Cin, Nimg * H * W
+            geom = (H, W, Cin, Ho, Wo, KH, KW, stride, 1, pad, pad)
+        else:
+            M = int(rs.randint(1, 200))
+            K = Cin * int(rs.choice([1, 2]))
+            pix, Cin = M, K
+            geom = (1, 1, K, 1, 1, 1, 1, 1, 1, 0, 0)
+        N, a_pre = int(rs.choice([33, 40, 64, 72, 130])), rs.rand() < 0.5
+        X, Bkn = rs.randn(pix, Cin).astype(np.float32), rs.randn(K, N).astype(np.float32)
+        Kp = cdiv(K, 32) * 32
+        pB, pA = np.zeros(3 * N * Kp, np.uint16), np.zeros(3 * pix * Cin, np.uint16)
+        assert host.rih_presplit_matrix(Bkn.ctypes.data, 0, K, N, N, pB.ctypes.data, Kp, None) == 0
+        assert host.rih_presplit_matrix(X.ctypes.data, 1, Cin, pix, Cin, pA.ctypes.data, Cin, None) == 0
+        splitk, kchunk = 1, 0
+        if rs.rand() < 0.3 and K >= 64:
+            kchunk = cdiv(cdiv(K, 2), 32) * 32
+            splitk = cdiv(K, kchunk)
+        tile, ldc = int(rs.choice([0, 1, 2])), N + int(rs.choice([0, 4]))
+        use_bias, relu = splitk == 1 and rs.rand() < 0.5, splitk == 1 and rs.rand() < 0.3
+        bias = rs.randn(N).astype(np.float32)
+        outs = []
+        for lib in (host, emu):
+            Cc = np.full(splitk * M * ldc + 8, 7.0, np.float32)
+            d = GemmDesc()
+            d.A, d.B, d.C = (pA if a_pre else X).ctypes.data, pB.ctypes.data, Cc.ctypes.data
+            d.bias, d.R = (bias.ctypes.data if use_bias else 0), 0
+            d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, Cin, Kp, ldc
+            d.a_mode, d.b_mode, d.nb1, d.nb2 = (2 if a_pre else 0), 2, 1, 1
+            d.splitk, d.kchunk, d.sCsplit, d.alpha, d.relu = splitk, kchunk, M * ldc, 1.0, 1 if relu else 0
+            (d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.strideA, d.upS, d.padH, d.padW) = geom
+            d.tile, d.engine = tile, 1
+            outs.append((lib.rih_gemm(C.byref(d), None), Cc))
+        (r0, c0), (r1, c1) = outs
+        what = 'case %d conv=%s a_pre=%s M%d N%d K%d sk%d tile%d geom=%s' % (it, conv, a_pre, M, N, K, splitk, tile, geom)
+        assert r0 == 0 and r1 == 0, what
+        v0, v1 = c0[:splitk * M * ldc].reshape(splitk, M, ldc), c1[:splitk * M * ldc].reshape(splitk, M, ldc)
+        sc = max(float(np.abs(v1[:, :, :N]).max()), 1e-6)
+        assert np.allclose(v0[:, :, :N], v1[:, :, :N], rtol=2e-5, atol=2e-5 * sc), what
+        assert (v0[:, :, N:] == 7.0).all() and (c0[splitk * M * ldc:] == 7.0).all(), 'stray write, ' + what
+        checked += 1
+    assert checked >= 22
