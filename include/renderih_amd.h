@@ -309,6 +309,16 @@ int rih_version(void);
 const char* rih_arch(void);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused attention forward (models/model_attn/self_attn.py:70-76, inter_attn.py:93-107): out = softmax(alpha q k^T)
+ * [dropout] v per (image, head) in ONE launch; q / k / v are head-sliced in place (row pitches q_ld / kv_ld, head h at
+ * column h*d), out [B][Sq][ld_out] at column h*d.  P and Pd [B][heads][Sq][ldP] receive the probabilities before / after
+ * dropout for the backward (Pd may equal P when drop_p == 0).  d in {16, 32, 64}, Sk <= 320.  Dropout mask and seed as
+ * rih_softmax_fwd.  Not yet measured on hardware (see csrc/rih_attn.hip). */
+int rih_attention_fwd_fused(const float* q, int q_ld, const float* k, const float* v, int kv_ld, int B, int heads, int Sq,
+                            int Sk, int d, float alpha, float drop_p, uint64_t seed, const uint64_t* seed_dev, float* P,
+                            float* Pd, int ldP, float* out, int ld_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * MANO parameter head of the reference's `load_new_model` network (common/myhand/decoder_lijun_mano.py:112-160,247-300)
  * nn.Hardswish and scale*tanh (the ParamRegressor MLP, `F.tanh(shape) * 3`): elementwise, n floats. */
 int rih_hardswish_fwd(const float* x, float* y, int64_t n, void* stream);

@@ -1,0 +1,225 @@
+// rih_attn.hip -- fused attention forward for gfx950: softmax(alpha Q K^T) [dropout] V for one (image, head) and a block
+// of 128 query rows per workgroup, without the score matrix making a round trip through memory.
+//
+// Today (renderih_amd/ops.py::_attn_forward) this is three launches -- a batched QK^T GEMM that writes S, a softmax
+// kernel that reads S and writes P (and the dropped copy Pd), a batched PV GEMM that reads Pd.  Here the 32 x Sk scores of
+// a wavefront's 32 query rows stay in registers (Sk <= 320: ten MFMA accumulator tiles), the row softmax is done on the
+// accumulator layout with 5 xor-shuffles per reduction, P / Pd are written once (the backward kernels of ops.py still
+// consume them), and P V runs from registers through a small per-wavefront LDS transpose.  K and V are streamed in
+// 32-key tiles through LDS, shared by the four wavefronts.  fp32 MFMA (v_mfma_f32_32x32x2_f32): the products are tiny
+// (<= 4 MFLOP per workgroup), the kernel is latency / traffic bound.
+//
+// STATUS: written after the round's GPU budget was spent; verified on the HIP-on-CPU harness
+// (tests/test_kernels_on_cpu.py::test_fused_attention_forward) against the three-launch path and torch, dropout masks
+// included; not yet run or measured on a GPU, therefore OFF by default (ops.FUSED_ATTN / RIH_FUSED_ATTN=1).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/renderih_amd.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+constexpr int TPB = 256;
+constexpr int NTMAX = 10;           // key tiles of 32: Sk <= 320
+
+__device__ __forceinline__ uint32_t attn_hash(uint64_t seed, uint64_t idx) {       // = rih_hash of rih_elem.hip
+    uint64_t x = idx * 0x9E3779B97F4A7C15ull + seed;
+    x ^= x >> 32;
+    x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    return (uint32_t)x;
+}
+__device__ __forceinline__ uint32_t attn_thresh(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t < 0.0) t = 0.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+// reductions over the 32 lanes that hold one accumulator row (lanes with equal lane>>5)
+__device__ __forceinline__ float row_max(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int DH>
+__global__ __launch_bounds__(TPB) void attn_fwd_fused_kernel(const float* __restrict__ q, int q_ld,
+                                                             const float* __restrict__ k, const float* __restrict__ v,
+                                                             int kv_ld, int heads, int Sq, int Sk, float alpha,
+                                                             float drop_p, uint64_t seed,
+                                                             const uint64_t* __restrict__ seed_dev, float* __restrict__ P,
+                                                             float* __restrict__ Pd, int ldP, float* __restrict__ out,
+                                                             int ld_out) {
+    constexpr int CT = (DH + 31) / 32;              // 32-wide column tiles of the output
+    __shared__ float Ks[32][DH + 1];
+    __shared__ float Vs[32][DH + 1];
+    __shared__ float Ps[TPB / 64][32][33];
+    if (seed_dev != nullptr) seed += *seed_dev;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const float* qb = q + (long long)b * Sq * q_ld + h * DH;
+    const float* kb = k + (long long)b * Sk * kv_ld + h * DH;
+    const float* vb = v + (long long)b * Sk * kv_ld + h * DH;
+    const int nt = (Sk + 31) / 32;
+
+    // A operand of Q K^T: lane l supplies Q[q0 + l%32][2t + l/32]
+    float qa[DH / 2];
+    {
+        const int qr = q0 + l31;
+#pragma unroll
+        for (int t = 0; t < DH / 2; ++t) qa[t] = (qr < Sq) ? qb[(long long)qr * q_ld + 2 * t + lhi] : 0.f;
+    }
+
+    // ---- pass 1: scores of the wavefront's 32 rows against every key tile
+    floatx16 s[NTMAX];
+#pragma unroll
+    for (int j = 0; j < NTMAX; ++j) {
+        if (j < nt) {                               // uniform over the block
+            __syncthreads();
+            for (int i = tid; i < 32 * DH; i += TPB) {
+                const int kr = i / DH, c = i - kr * DH, key = 32 * j + kr;
+                Ks[kr][c] = (key < Sk) ? kb[(long long)key * kv_ld + c] : 0.f;
+            }
+            __syncthreads();
+            floatx16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < DH / 2; ++t)        // B operand: lane l supplies K[key l%32][channel 2t + l/32]
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[t], Ks[l31][2 * t + lhi], acc, 0, 0, 0);
+            s[j] = acc;
+        }
+    }
+
+    // ---- row softmax on the accumulator layout: register r of lane l = row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31
+    float mx[16], sm[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx[r] = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NTMAX; ++j)
+        if (j < nt) {
+            const bool valid = 32 * j + l31 < Sk;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = valid ? s[j][r] * alpha : -INFINITY;
+                s[j][r] = x;
+                mx[r] = fmaxf(mx[r], x);
+            }
+        }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { mx[r] = row_max(mx[r]); sm[r] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < NTMAX; ++j)
+        if (j < nt) {
+            const bool valid = 32 * j + l31 < Sk;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = valid ? expf(s[j][r] - mx[r]) : 0.f;
+                s[j][r] = e;
+                sm[r] += e;
+            }
+        }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sm[r] = 1.f / row_sum(sm[r]);
+
+    // probabilities out (P for the backward, Pd = dropped copy that multiplies V); s[] then holds Pd
+    const uint32_t thr = attn_thresh(drop_p);
+    const float keep_scale = (drop_p > 0.f) ? 1.f / (1.f - drop_p) : 1.f;
+#pragma unroll
+    for (int j = 0; j < NTMAX; ++j)
+        if (j < nt) {
+            const int col = 32 * j + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = q0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                float pr = s[j][r] * sm[r];
+                if (row < Sq && col < Sk) {
+                    const long long ridx = (long long)bh * Sq + row;
+                    P[ridx * ldP + col] = pr;
+                    if (drop_p > 0.f) {
+                        const bool keep = attn_hash(seed, (uint64_t)(ridx * Sk + col)) >= thr;
+                        pr = keep ? pr * keep_scale : 0.f;
+                        Pd[ridx * ldP + col] = pr;
+                    } else if (Pd != P) {
+                        Pd[ridx * ldP + col] = pr;
+                    }
+                } else {
+                    pr = 0.f;
+                }
+                s[j][r] = pr;
+            }
+        }
+
+    // ---- pass 2: O = Pd V, key tile by key tile; Pd goes through LDS to turn accumulator layout into operand layout
+    floatx16 o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NTMAX; ++j) {
+        if (j < nt) {
+            __syncthreads();
+            for (int i = tid; i < 32 * DH; i += TPB) {
+                const int kr = i / DH, c = i - kr * DH, key = 32 * j + kr;
+                Vs[kr][c] = (key < Sk) ? vb[(long long)key * kv_ld + c] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Ps[wave][(r & 3) + 8 * (r >> 2) + 4 * lhi][l31] = s[j][r];
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {          // A: Pd[row l%32][key 2t + l/32];  B: V[key 2t + l/32][channel l%32 (+32 ct)]
+                const float a = Ps[wave][l31][2 * t + lhi];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int c = l31 + 32 * ct;
+                    const float bval = (c < DH) ? Vs[2 * t + lhi][c] : 0.f;
+                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bval, o[ct], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = l31 + 32 * ct;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = q0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (row < Sq && c < DH) out[((long long)b * Sq + row) * ld_out + h * DH + c] = o[ct][r];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int rih_attention_fwd_fused(const float* q, int q_ld, const float* k, const float* v, int kv_ld, int B, int heads,
+                                       int Sq, int Sk, int d, float alpha, float drop_p, uint64_t seed,
+                                       const uint64_t* seed_dev, float* P, float* Pd, int ldP, float* out, int ld_out,
+                                       void* stream) {
+    if (!q || !k || !v || !P || !Pd || !out || B < 1 || heads < 1 || Sq < 1 || Sk < 1) return RIH_EINVAL;
+    if (Sk > 32 * NTMAX || ldP < Sk || q_ld < d || kv_ld < d || ld_out < heads * d) return RIH_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && Pd == P)) return RIH_EINVAL;
+    if ((long long)B * heads > 65535) return RIH_EINVAL;
+    const dim3 grid((Sq + 127) / 128, B * heads), block(TPB);
+    hipStream_t s = (hipStream_t)stream;
+    if (d == 16)
+        hipLaunchKernelGGL((attn_fwd_fused_kernel<16>), grid, block, 0, s, q, q_ld, k, v, kv_ld, heads, Sq, Sk, alpha, drop_p,
+                           seed, seed_dev, P, Pd, ldP, out, ld_out);
+    else if (d == 32)
+        hipLaunchKernelGGL((attn_fwd_fused_kernel<32>), grid, block, 0, s, q, q_ld, k, v, kv_ld, heads, Sq, Sk, alpha, drop_p,
+                           seed, seed_dev, P, Pd, ldP, out, ld_out);
+    else if (d == 64)
+        hipLaunchKernelGGL((attn_fwd_fused_kernel<64>), grid, block, 0, s, q, q_ld, k, v, kv_ld, heads, Sq, Sk, alpha, drop_p,
+                           seed, seed_dev, P, Pd, ldP, out, ld_out);
+    else
+        return RIH_EINVAL;
+    return (int)hipGetLastError();
+}

@@ -905,12 +905,26 @@ def layernorm_pair_skip(x, mL, mR):
     return LayerNormPairFn.apply(x, None, mL.weight, mR.weight, mL.bias, mR.bias, mL.eps, False, True)
 
 
+# One-launch attention forward (csrc/rih_attn.hip) instead of QK^T GEMM + softmax + PV GEMM.  OFF by default: verified on
+# the HIP-on-CPU harness only (written after the round's GPU budget was spent), not yet measured.
+FUSED_ATTN = os.environ.get('RIH_FUSED_ATTN', '0') == '1'
+
+
 def _attn_forward(q, q_ld, k, v, kv_ld, B, Sq, Sk, D, heads, drop_p, seed, device, out=None):
     """q/k/v: raw device pointers to the first element of [B,S,*] slices with row pitch q_ld / kv_ld."""
     d = D // heads
     ldP = _cdiv(Sk, 4) * 4
     alpha = 1.0 / math.sqrt(d)
     P = torch.empty((B, heads, Sq, ldP), device=device, dtype=torch.float32)
+    if FUSED_ATTN and d in (16, 32, 64) and Sk <= 320 and B * heads <= 65535:
+        Pd = torch.empty_like(P) if drop_p > 0 else P
+        if out is None:
+            out = torch.empty((B, Sq, D), device=device, dtype=torch.float32)
+        ptr = lambda t: t if isinstance(t, int) else t.data_ptr()
+        check(_L().rih_attention_fwd_fused(ptr(q), q_ld, ptr(k), ptr(v), kv_ld, B, heads, Sq, Sk, d, alpha, drop_p, seed,
+                                           _seed_dev(), P.data_ptr(), Pd.data_ptr(), ldP, out.data_ptr(), D, _stream()),
+              'rih_attention_fwd_fused')
+        return out, P, (Pd if drop_p > 0 else None)
     gemm(q, k, P, Sq, Sk, d, q_ld, kv_ld, ldP, a_mode=0, b_mode=1, nb1=B, nb2=heads, sA=(Sq * q_ld, d),
          sB=(Sk * kv_ld, d), sC=(heads * Sq * ldP, Sq * ldP), alpha=alpha)
     Pd = torch.empty_like(P) if drop_p > 0 else P

@@ -231,6 +231,39 @@ class EmulatedLib:
         _f(dst, out.size)[:] = out.ravel()
         return 0
 
+    # ------------------------------------------------------------------ fused attention forward
+    def rih_attention_fwd_fused(self, q, q_ld, k, v, kv_ld, B, heads, Sq, Sk, d, alpha, drop_p, seed, seed_dev, P, Pd, ldP,
+                                out, ld_out, stream):
+        seed = self._seed(seed, seed_dev)
+        Q = _f(q, (B * Sq - 1) * q_ld + heads * d)
+        Kk = _f(k, (B * Sk - 1) * kv_ld + heads * d)
+        Vv = _f(v, (B * Sk - 1) * kv_ld + heads * d)
+        Pm, Pdm = _f(P, B * heads * Sq * ldP), _f(Pd, B * heads * Sq * ldP)
+        O = _f(out, (B * Sq - 1) * ld_out + heads * d)
+        cols = np.arange(d)
+        for b in range(B):
+            for h in range(heads):
+                qi = ((b * Sq + np.arange(Sq))[:, None] * q_ld + h * d + cols[None, :])
+                ki = ((b * Sk + np.arange(Sk))[:, None] * kv_ld + h * d + cols[None, :])
+                s = np.float32(alpha) * (Q[qi] @ Kk[ki].T)
+                e = np.exp(s - s.max(1, keepdims=True))
+                p = (e / e.sum(1, keepdims=True)).astype(np.float32)
+                r0 = (b * heads + h) * Sq
+                pidx = (r0 + np.arange(Sq))[:, None] * ldP + np.arange(Sk)[None, :]
+                Pm[pidx.ravel()] = p.ravel()
+                pd = p
+                if drop_p > 0:
+                    idx = ((r0 + np.arange(Sq))[:, None] * Sk + np.arange(Sk)[None, :]).ravel()
+                    thr = np.uint64(min(int(float(np.float32(drop_p)) * 4294967296.0), 4294967295))
+                    keep = (hash_np(seed, idx) >= thr).astype(np.float32) / np.float32(1.0 - drop_p)
+                    pd = (p.ravel() * keep).reshape(Sq, Sk)
+                    Pdm[pidx.ravel()] = pd.ravel()
+                elif Pd != P:
+                    Pdm[pidx.ravel()] = p.ravel()
+                oi = ((b * Sq + np.arange(Sq))[:, None] * ld_out + h * d + cols[None, :])
+                O[oi.ravel()] = (pd @ Vv[ki]).astype(np.float32).ravel()
+        return 0
+
     # ------------------------------------------------------------------ MANO layer (through oracle/mano_oracle.py)
     @staticmethod
     def _mano_consts(mref):

@@ -135,6 +135,17 @@ def test_presplit_weight_host_logic(monkeypatch):
     G.test_conv2d((1, 8, 8, 64, 64, 3, 2, 1, False, False))
 
 
+def test_fused_attention_host_logic(monkeypatch):
+    """ops.FUSED_ATTN (off by default): pointer / pitch plumbing of rih_attention_fwd_fused."""
+    from renderih_amd import ops
+    monkeypatch.setattr(ops, 'FUSED_ATTN', True)
+    G.test_attention(2, 63, 63, 64, 4)
+    G.test_attention_dropout_matches_hash_mask()
+    G.test_self_attention_packed(2, 40, 64, 4)
+    G.test_cross_attention_packed(2, 63, 128, 4)
+    G.test_cross_attention_stacked_and_rows_pair()
+
+
 def test_pool_layout_host_logic(monkeypatch):
     G.test_pool_upsample_layout()
     G.test_resample_hrnet(4, 5, 7, 32)

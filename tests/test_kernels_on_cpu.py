@@ -85,6 +85,24 @@ def test_tile4_pipelined_gemm_kernel():
     G.test_gemm_tile4_pipelined_kernel((1, 16, 16, 32, 128, 3, 1, 1))        # M = 256: one 256x128 tile, 4-slot ring
 
 
+def test_fused_attention_forward(monkeypatch):
+    """csrc/rih_attn.hip (one launch: QK^T, row softmax on the MFMA accumulator layout, dropout, PV) behind
+    ops.FUSED_ATTN: outputs, the saved probabilities (through the unchanged backward kernels: gradients) and the dropout
+    masks against torch -- head dims 16 / 32 / 64, ragged key counts, several 128-row query blocks."""
+    from renderih_amd import ops
+    calls = []
+    monkeypatch.setattr(ops, 'FUSED_ATTN', True)
+    real = ops._L().rih_attention_fwd_fused
+    monkeypatch.setattr(ops._L(), 'rih_attention_fwd_fused', lambda *a: (calls.append(a[9]), real(*a))[1], raising=False)
+    G.test_attention(2, 63, 63, 64, 4)              # d = 16
+    G.test_attention(1, 150, 190, 128, 4)           # d = 32, two query blocks, Sk not a multiple of 32
+    G.test_attention(1, 127, 127, 256, 4)           # d = 64
+    G.test_attention_dropout_matches_hash_mask()
+    G.test_self_attention_packed(2, 40, 64, 4)      # q / k / v read in place from the packed projection
+    G.test_cross_attention_packed(1, 63, 128, 4)
+    assert {16, 32, 64} <= set(calls), calls
+
+
 @pytest.mark.parametrize('B', [1, 2])
 def test_mano_kernels(B):
     TMANO.test_mano_matches_oracle(B)
