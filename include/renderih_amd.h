@@ -317,6 +317,13 @@ const char* rih_arch(void);
 int rih_attention_fwd_fused(const float* q, int q_ld, const float* k, const float* v, int kv_ld, int B, int heads, int Sq,
                             int Sk, int d, float alpha, float drop_p, uint64_t seed, const uint64_t* seed_dev, float* P,
                             float* Pd, int ldP, float* out, int ld_out, void* stream);
+/* Query side of the attention backward in ONE launch (replaces the dO V^T GEMM, rih_softmax_bwd and the dS K GEMM):
+ * dS = alpha * P * (m*dPd - rowsum(m*dPd*P)) with dPd = dO V^T and m the regenerated dropout mask (x 1/(1-p)), written to
+ * dS [B][heads][Sq][ldP] for the key-side products (dK = dS^T q, dV = Pd^T dO stay batched GEMMs), and dq = dS k written
+ * to dq [B][Sq][dq_ld] at column h*d.  dO [B][Sq][do_ld] head-sliced like q.  Same limits as the forward. */
+int rih_attention_bwd_dq_fused(const float* dO, int do_ld, const float* k, const float* v, int kv_ld, int B, int heads,
+                               int Sq, int Sk, int d, float alpha, float drop_p, uint64_t seed, const uint64_t* seed_dev,
+                               const float* P, float* dS, int ldP, float* dq, int dq_ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MANO parameter head of the reference's `load_new_model` network (common/myhand/decoder_lijun_mano.py:112-160,247-300)

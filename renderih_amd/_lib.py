@@ -45,6 +45,8 @@ class MeshTopo(C.Structure):
 
 # name -> (restype, argtypes); must list every symbol include/renderih_amd.h declares
 SIGNATURES = {
+    'rih_attention_bwd_dq_fused': (c_i, [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_u64, c_f, c_f, c_f,
+                                         c_i, c_f, c_i, C.c_void_p]),
     'rih_attention_fwd_fused': (c_i, [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_u64, c_f, c_f, c_f, c_i,
                                       c_f, c_i, C.c_void_p]),
     'rih_presplit_matrix': (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, C.c_void_p]),

@@ -9,9 +9,12 @@
 // 32-key tiles through LDS, shared by the four wavefronts.  fp32 MFMA (v_mfma_f32_32x32x2_f32): the products are tiny
 // (<= 4 MFLOP per workgroup), the kernel is latency / traffic bound.
 //
+// The query side of the backward (dO V^T -> softmax backward -> dS K) has the same shape and is the second kernel of
+// this file; the key-side products reduce over query rows (across workgroups) and stay batched GEMMs.
+//
 // STATUS: written after the round's GPU budget was spent; verified on the HIP-on-CPU harness
-// (tests/test_kernels_on_cpu.py::test_fused_attention_forward) against the three-launch path and torch, dropout masks
-// included; not yet run or measured on a GPU, therefore OFF by default (ops.FUSED_ATTN / RIH_FUSED_ATTN=1).
+// (tests/test_kernels_on_cpu.py::test_fused_attention_forward) against the unfused path and torch (outputs, gradients,
+// dropout masks); not yet run or measured on a GPU, therefore OFF by default (ops.FUSED_ATTN / RIH_FUSED_ATTN=1).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/renderih_amd.h"
@@ -198,6 +201,139 @@ __global__ __launch_bounds__(TPB) void attn_fwd_fused_kernel(const float* __rest
     }
 }
 
+// Backward, query side: for a block of 128 query rows of one (image, head)
+//   dPd = dO V^T  ->  d = mask * dPd,  D = rowsum(d * P),  dS = alpha * P * (d - D)  (= rih_softmax_bwd)  ->  dQ = dS K
+// in one launch (today: a batched GEMM that writes dPd, the softmax-backward kernel that rewrites it in place, a
+// batched GEMM that reads it).  dS is still written once, for the key-side products dK = dS^T Q and dV = Pd^T dO, which
+// remain batched GEMMs.  Same structure as the forward kernel: dO rows are the A operand of pass 1 against V tiles, the
+// 32 x Sk tile of dS stays in accumulator registers, pass 2 multiplies it with K tiles through the LDS transpose.
+template <int DH>
+__global__ __launch_bounds__(TPB) void attn_bwd_dq_fused_kernel(const float* __restrict__ dO, int do_ld,
+                                                                const float* __restrict__ k, const float* __restrict__ v,
+                                                                int kv_ld, int heads, int Sq, int Sk, float alpha,
+                                                                float drop_p, uint64_t seed,
+                                                                const uint64_t* __restrict__ seed_dev,
+                                                                const float* __restrict__ P, float* __restrict__ dS, int ldP,
+                                                                float* __restrict__ dq, int dq_ld) {
+    constexpr int CT = (DH + 31) / 32;
+    __shared__ float Ts[32][DH + 1];                // V tile in pass 1, K tile in pass 2
+    __shared__ float Ps[TPB / 64][32][33];
+    if (seed_dev != nullptr) seed += *seed_dev;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const float* dob = dO + (long long)b * Sq * do_ld + h * DH;
+    const float* kb = k + (long long)b * Sk * kv_ld + h * DH;
+    const float* vb = v + (long long)b * Sk * kv_ld + h * DH;
+    const int nt = (Sk + 31) / 32;
+    float da[DH / 2];
+    {
+        const int qr = q0 + l31;
+#pragma unroll
+        for (int t = 0; t < DH / 2; ++t) da[t] = (qr < Sq) ? dob[(long long)qr * do_ld + 2 * t + lhi] : 0.f;
+    }
+    floatx16 s[NTMAX];
+#pragma unroll
+    for (int j = 0; j < NTMAX; ++j) {
+        if (j < nt) {
+            __syncthreads();
+            for (int i = tid; i < 32 * DH; i += TPB) {
+                const int kr = i / DH, c = i - kr * DH, key = 32 * j + kr;
+                Ts[kr][c] = (key < Sk) ? vb[(long long)key * kv_ld + c] : 0.f;
+            }
+            __syncthreads();
+            floatx16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < DH / 2; ++t)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(da[t], Ts[l31][2 * t + lhi], acc, 0, 0, 0);
+            s[j] = acc;
+        }
+    }
+    // d = mask * dPd, D = rowsum(d * P); P is read again in the second sweep (an L2 hit) rather than held in 160 more
+    // registers
+    const uint32_t thr = attn_thresh(drop_p);
+    const float keep_scale = (drop_p > 0.f) ? 1.f / (1.f - drop_p) : 1.f;
+    float dot[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dot[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NTMAX; ++j)
+        if (j < nt) {
+            const int col = 32 * j + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = q0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                float pr = 0.f, d = 0.f;
+                if (row < Sq && col < Sk) {
+                    const long long ridx = (long long)bh * Sq + row;
+                    pr = P[ridx * ldP + col];
+                    d = s[j][r];
+                    if (drop_p > 0.f) d = (attn_hash(seed, (uint64_t)(ridx * Sk + col)) >= thr) ? d * keep_scale : 0.f;
+                }
+                s[j][r] = d;
+                dot[r] += d * pr;
+            }
+        }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dot[r] = row_sum(dot[r]);
+#pragma unroll
+    for (int j = 0; j < NTMAX; ++j)
+        if (j < nt) {
+            const int col = 32 * j + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = q0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                float g = 0.f;
+                if (row < Sq && col < Sk) {
+                    const long long at = ((long long)bh * Sq + row) * ldP + col;
+                    g = alpha * P[at] * (s[j][r] - dot[r]);
+                    dS[at] = g;
+                }
+                s[j][r] = g;
+            }
+        }
+    // dQ = dS K
+    floatx16 o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NTMAX; ++j) {
+        if (j < nt) {
+            __syncthreads();
+            for (int i = tid; i < 32 * DH; i += TPB) {
+                const int kr = i / DH, c = i - kr * DH, key = 32 * j + kr;
+                Ts[kr][c] = (key < Sk) ? kb[(long long)key * kv_ld + c] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Ps[wave][(r & 3) + 8 * (r >> 2) + 4 * lhi][l31] = s[j][r];
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float a = Ps[wave][l31][2 * t + lhi];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int c = l31 + 32 * ct;
+                    const float bval = (c < DH) ? Ts[2 * t + lhi][c] : 0.f;
+                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bval, o[ct], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = l31 + 32 * ct;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = q0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (row < Sq && c < DH) dq[((long long)b * Sq + row) * dq_ld + h * DH + c] = o[ct][r];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int rih_attention_fwd_fused(const float* q, int q_ld, const float* k, const float* v, int kv_ld, int B, int heads,
@@ -219,6 +355,29 @@ extern "C" int rih_attention_fwd_fused(const float* q, int q_ld, const float* k,
     else if (d == 64)
         hipLaunchKernelGGL((attn_fwd_fused_kernel<64>), grid, block, 0, s, q, q_ld, k, v, kv_ld, heads, Sq, Sk, alpha, drop_p,
                            seed, seed_dev, P, Pd, ldP, out, ld_out);
+    else
+        return RIH_EINVAL;
+    return (int)hipGetLastError();
+}
+
+extern "C" int rih_attention_bwd_dq_fused(const float* dO, int do_ld, const float* k, const float* v, int kv_ld, int B,
+                                          int heads, int Sq, int Sk, int d, float alpha, float drop_p, uint64_t seed,
+                                          const uint64_t* seed_dev, const float* P, float* dS, int ldP, float* dq, int dq_ld,
+                                          void* stream) {
+    if (!dO || !k || !v || !P || !dS || !dq || B < 1 || heads < 1 || Sq < 1 || Sk < 1) return RIH_EINVAL;
+    if (Sk > 32 * NTMAX || ldP < Sk || do_ld < heads * d || kv_ld < d || dq_ld < d) return RIH_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f || (long long)B * heads > 65535) return RIH_EINVAL;
+    const dim3 grid((Sq + 127) / 128, B * heads), block(TPB);
+    hipStream_t s = (hipStream_t)stream;
+    if (d == 16)
+        hipLaunchKernelGGL((attn_bwd_dq_fused_kernel<16>), grid, block, 0, s, dO, do_ld, k, v, kv_ld, heads, Sq, Sk, alpha,
+                           drop_p, seed, seed_dev, P, dS, ldP, dq, dq_ld);
+    else if (d == 32)
+        hipLaunchKernelGGL((attn_bwd_dq_fused_kernel<32>), grid, block, 0, s, dO, do_ld, k, v, kv_ld, heads, Sq, Sk, alpha,
+                           drop_p, seed, seed_dev, P, dS, ldP, dq, dq_ld);
+    else if (d == 64)
+        hipLaunchKernelGGL((attn_bwd_dq_fused_kernel<64>), grid, block, 0, s, dO, do_ld, k, v, kv_ld, heads, Sq, Sk, alpha,
+                           drop_p, seed, seed_dev, P, dS, ldP, dq, dq_ld);
     else
         return RIH_EINVAL;
     return (int)hipGetLastError();

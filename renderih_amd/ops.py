@@ -945,13 +945,20 @@ def _attn_backward(do, q, q_ld, k, v, kv_ld, dq, dq_ld, dk, dv, dkv_ld, P, Pd, B
     ldP = P.shape[-1]
     alpha = 1.0 / math.sqrt(d)
     sP = (heads * Sq * ldP, Sq * ldP)
-    dS = torch.empty_like(P)
-    gemm(do, v, dS, Sq, Sk, d, D, kv_ld, ldP, a_mode=0, b_mode=1, nb1=B, nb2=heads, sA=(Sq * D, d),
-         sB=(Sk * kv_ld, d), sC=sP)
-    check(_L().rih_softmax_bwd(P.data_ptr(), dS.data_ptr(), B * heads * Sq, Sk, ldP, drop_p, seed, _seed_dev(),
-                               alpha, _stream()), 'rih_softmax_bwd')
-    gemm(dS, k, dq, Sq, d, Sk, ldP, kv_ld, dq_ld, a_mode=0, b_mode=0, nb1=B, nb2=heads, sA=sP, sB=(Sk * kv_ld, d),
-         sC=(Sq * dq_ld, d))
+    ptr = lambda t: t if isinstance(t, int) else t.data_ptr()
+    if FUSED_ATTN and d in (16, 32, 64) and Sk <= 320 and B * heads <= 65535:
+        dS = torch.empty_like(P)
+        check(_L().rih_attention_bwd_dq_fused(do.data_ptr(), D, ptr(k), ptr(v), kv_ld, B, heads, Sq, Sk, d, alpha, drop_p,
+                                              seed, _seed_dev(), P.data_ptr(), dS.data_ptr(), ldP, ptr(dq), dq_ld,
+                                              _stream()), 'rih_attention_bwd_dq_fused')
+    else:
+        dS = torch.empty_like(P)
+        gemm(do, v, dS, Sq, Sk, d, D, kv_ld, ldP, a_mode=0, b_mode=1, nb1=B, nb2=heads, sA=(Sq * D, d),
+             sB=(Sk * kv_ld, d), sC=sP)
+        check(_L().rih_softmax_bwd(P.data_ptr(), dS.data_ptr(), B * heads * Sq, Sk, ldP, drop_p, seed, _seed_dev(),
+                                   alpha, _stream()), 'rih_softmax_bwd')
+        gemm(dS, k, dq, Sq, d, Sk, ldP, kv_ld, dq_ld, a_mode=0, b_mode=0, nb1=B, nb2=heads, sA=sP, sB=(Sk * kv_ld, d),
+             sC=(Sq * dq_ld, d))
     gemm(dS, q, dk, Sk, d, Sq, ldP, q_ld, dkv_ld, a_mode=1, b_mode=0, nb1=B, nb2=heads, sA=sP, sB=(Sq * q_ld, d),
          sC=(Sk * dkv_ld, d))
     gemm(Pd, do, dv, Sk, d, Sq, ldP, D, dkv_ld, a_mode=1, b_mode=0, nb1=B, nb2=heads, sA=sP, sB=(Sq * D, d),

@@ -264,6 +264,34 @@ class EmulatedLib:
                 O[oi.ravel()] = (pd @ Vv[ki]).astype(np.float32).ravel()
         return 0
 
+    def rih_attention_bwd_dq_fused(self, dO, do_ld, k, v, kv_ld, B, heads, Sq, Sk, d, alpha, drop_p, seed, seed_dev, P, dS,
+                                   ldP, dq, dq_ld, stream):
+        seed = self._seed(seed, seed_dev)
+        G = _f(dO, (B * Sq - 1) * do_ld + heads * d)
+        Kk = _f(k, (B * Sk - 1) * kv_ld + heads * d)
+        Vv = _f(v, (B * Sk - 1) * kv_ld + heads * d)
+        Pm, dSm = _f(P, B * heads * Sq * ldP), _f(dS, B * heads * Sq * ldP)
+        dQ = _f(dq, (B * Sq - 1) * dq_ld + heads * d)
+        cols = np.arange(d)
+        for b in range(B):
+            for h in range(heads):
+                gi = ((b * Sq + np.arange(Sq))[:, None] * do_ld + h * d + cols[None, :])
+                ki = ((b * Sk + np.arange(Sk))[:, None] * kv_ld + h * d + cols[None, :])
+                r0 = (b * heads + h) * Sq
+                pidx = (r0 + np.arange(Sq))[:, None] * ldP + np.arange(Sk)[None, :]
+                p = Pm[pidx]
+                dp = G[gi] @ Vv[ki].T
+                if drop_p > 0:
+                    idx = ((r0 + np.arange(Sq))[:, None] * Sk + np.arange(Sk)[None, :]).ravel()
+                    thr = np.uint64(min(int(float(np.float32(drop_p)) * 4294967296.0), 4294967295))
+                    keep = (hash_np(seed, idx) >= thr).astype(np.float32) / np.float32(1.0 - drop_p)
+                    dp = dp * keep.reshape(Sq, Sk)
+                ds = (np.float32(alpha) * p * (dp - (dp * p).sum(1, keepdims=True))).astype(np.float32)
+                dSm[pidx.ravel()] = ds.ravel()
+                qi = ((b * Sq + np.arange(Sq))[:, None] * dq_ld + h * d + cols[None, :])
+                dQ[qi.ravel()] = (ds @ Kk[ki]).astype(np.float32).ravel()
+        return 0
+
     # ------------------------------------------------------------------ MANO layer (through oracle/mano_oracle.py)
     @staticmethod
     def _mano_consts(mref):

@@ -136,7 +136,7 @@ def test_presplit_weight_host_logic(monkeypatch):
 
 
 def test_fused_attention_host_logic(monkeypatch):
-    """ops.FUSED_ATTN (off by default): pointer / pitch plumbing of rih_attention_fwd_fused."""
+    """ops.FUSED_ATTN (off by default): pointer / pitch plumbing of rih_attention_fwd_fused / _bwd_dq_fused."""
     from renderih_amd import ops
     monkeypatch.setattr(ops, 'FUSED_ATTN', True)
     G.test_attention(2, 63, 63, 64, 4)

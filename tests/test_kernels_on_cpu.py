@@ -86,14 +86,19 @@ def test_tile4_pipelined_gemm_kernel():
 
 
 def test_fused_attention_forward(monkeypatch):
-    """csrc/rih_attn.hip (one launch: QK^T, row softmax on the MFMA accumulator layout, dropout, PV) behind
-    ops.FUSED_ATTN: outputs, the saved probabilities (through the unchanged backward kernels: gradients) and the dropout
-    masks against torch -- head dims 16 / 32 / 64, ragged key counts, several 128-row query blocks."""
+    """csrc/rih_attn.hip behind ops.FUSED_ATTN -- forward (one launch: QK^T, row softmax on the MFMA accumulator
+    layout, dropout, PV) and the query side of the backward (one launch: dO V^T, softmax backward with the regenerated
+    mask, dS K): outputs, gradients and the dropout masks against torch -- head dims 16 / 32 / 64, ragged key counts,
+    several 128-row query blocks."""
     from renderih_amd import ops
     calls = []
     monkeypatch.setattr(ops, 'FUSED_ATTN', True)
     real = ops._L().rih_attention_fwd_fused
     monkeypatch.setattr(ops._L(), 'rih_attention_fwd_fused', lambda *a: (calls.append(a[9]), real(*a))[1], raising=False)
+    bcalls = []
+    breal = ops._L().rih_attention_bwd_dq_fused
+    monkeypatch.setattr(ops._L(), 'rih_attention_bwd_dq_fused', lambda *a: (bcalls.append(a[9]), breal(*a))[1],
+                        raising=False)
     G.test_attention(2, 63, 63, 64, 4)              # d = 16
     G.test_attention(1, 150, 190, 128, 4)           # d = 32, two query blocks, Sk not a multiple of 32
     G.test_attention(1, 127, 127, 256, 4)           # d = 64
@@ -101,6 +106,7 @@ def test_fused_attention_forward(monkeypatch):
     G.test_self_attention_packed(2, 40, 64, 4)      # q / k / v read in place from the packed projection
     G.test_cross_attention_packed(1, 63, 128, 4)
     assert {16, 32, 64} <= set(calls), calls
+    assert {16, 32, 64} <= set(bcalls), bcalls      # the query-side backward kernel ran too (gradients checked above)
 
 
 @pytest.mark.parametrize('B', [1, 2])
