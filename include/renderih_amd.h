@@ -326,6 +326,45 @@ int rih_attention_bwd_dq_fused(const float* dO, int do_ld, const float* k, const
                                const float* P, float* dS, int ldP, float* dq, int dq_ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * fp16-storage inference backbone (BASELINE configs[4]; csrc/rih_half.hip).  Eval-mode only: every BatchNorm of
+ * models/encoder.py is folded -- Conv->BN(->ReLU) (trunk, encoder.py:107-116) into weights (rih_hpack_conv_weight's
+ * `scale`) and `bias`; Conv->ReLU->BN (aux decoders encoder.py:52-54, mid convs model_zoo/__init__.py:56-62) into
+ * post_scale / post_shift.  Activations are NHWC fp16 with a pixel pitch (ldx / ldr / ldy, in elements) so that channel
+ * slices of a wider tensor can be read and written in place (the channel concatenations of encoder.py:160-171 are never
+ * copied).  fp32 accumulation (v_mfma_f32_32x32x16_f16), fp32 epilogue:
+ *   y[pix][co] = post( relu?( sum_k x[...] w[co][k] + bias[co] + res[pix][co] ) ),  post(u) = u*post_scale[co] + post_shift[co]
+ * Requirements: Cin % 8 == 0, ldx % 8 == 0, x / w / zero 16-byte aligned, Kpad % 64 == 0, Ho/Wo consistent with the
+ * geometry; `zero` points at >= 16 bytes of zeros in device memory (source of every padded operand chunk).  16-byte
+ * epilogue accesses are used when y / res rows are aligned (ldy % 8 (fp16) or % 4 (fp32), ldr % 8), scalar otherwise. */
+typedef struct rih_hconv_desc {
+    const void* x;            /* fp16 [N][H][W][ldx], channels [0, Cin) */
+    const void* w;            /* fp16 [Cout][Kpad] from rih_hpack_conv_weight, k = (kh, kw, ci) */
+    const void* zero;
+    const float* bias;        /* [Cout] or NULL */
+    const float* post_scale;  /* [Cout] or NULL (both or neither) */
+    const float* post_shift;
+    const void* res;          /* fp16 [pixels][ldr] or NULL */
+    void* y;                  /* [pixels][ldy] fp16, or fp32 when out_f32 */
+    int32_t N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+    int32_t ldx, ldr, ldy, Kpad;
+    int32_t relu, out_f32;
+} rih_hconv_desc;
+int rih_hconv(const rih_hconv_desc* d, void* stream);
+/* fp32 OIHW -> fp16 [Cout][Kpad], k = (kh*KW + kw)*CinPad + ci, times scale[co] when scale != NULL; zero padded. */
+int rih_hpack_conv_weight(const float* w, const float* scale, void* dst, int Cout, int Cin, int KH, int KW, int CinPad,
+                          int Kpad, void* stream);
+/* Eval BatchNorm as an affine map: scale = gamma/sqrt(var+eps), shift = beta - mean*scale + scale*conv_bias
+ * (gamma / beta / conv_bias may be NULL = 1 / 0 / 0). */
+int rih_hbn_fold(const float* gamma, const float* beta, const float* mean, const float* var, const float* conv_bias,
+                 float eps, float* scale, float* shift, int C, void* stream);
+/* [N][C][H][W] fp32 (C <= 8) -> [N][H][W][8] fp16, channels >= C zero. */
+int rih_himage_nchw_to_nhwc8(const float* img, void* out, int N, int C, int H, int W, void* stream);
+/* fp16 NHWC 3x3 stride-2 pad-1 max-pool, bilinear x2 (align_corners=True), global average pool (fp32 [N][C] out). */
+int rih_hmaxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int ldx, int ldy, void* stream);
+int rih_hupsample2x(const void* x, void* y, int N, int H, int W, int C, int ldx, int ldy, void* stream);
+int rih_havgpool(const void* x, float* y, int N, int HW, int C, int ldx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * MANO parameter head of the reference's `load_new_model` network (common/myhand/decoder_lijun_mano.py:112-160,247-300)
  * nn.Hardswish and scale*tanh (the ParamRegressor MLP, `F.tanh(shape) * 3`): elementwise, n floats. */
 int rih_hardswish_fwd(const float* x, float* y, int64_t n, void* stream);

@@ -31,6 +31,13 @@ class GemmDesc(C.Structure):
                 ('reserved0', C.c_int32), ('sBias1', C.c_int64), ('sR1', C.c_int64)]
 
 
+class HConvDesc(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('zero', C.c_void_p), ('bias', C.c_void_p),
+                ('post_scale', C.c_void_p), ('post_shift', C.c_void_p), ('res', C.c_void_p), ('y', C.c_void_p)] + \
+               [(n, C.c_int32) for n in ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad', 'Ho', 'Wo',
+                                         'ldx', 'ldr', 'ldy', 'Kpad', 'relu', 'out_f32')]
+
+
 class ManoModel(C.Structure):
     _fields_ = [('comps', C.c_void_p), ('hands_mean', C.c_void_p), ('shapedirs', C.c_void_p),
                 ('posedirs', C.c_void_p), ('v_template', C.c_void_p), ('J_reg', C.c_void_p),
@@ -45,6 +52,13 @@ class MeshTopo(C.Structure):
 
 # name -> (restype, argtypes); must list every symbol include/renderih_amd.h declares
 SIGNATURES = {
+    'rih_hconv': (c_i, [C.POINTER(HConvDesc), C.c_void_p]),
+    'rih_hpack_conv_weight': (c_i, [c_f, c_f, C.c_void_p, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_hbn_fold': (c_i, [c_f, c_f, c_f, c_f, c_f, c_fl, c_f, c_f, c_i, C.c_void_p]),
+    'rih_himage_nchw_to_nhwc8': (c_i, [c_f, C.c_void_p, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_hmaxpool3x3s2': (c_i, [C.c_void_p, C.c_void_p, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_hupsample2x': (c_i, [C.c_void_p, C.c_void_p, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_havgpool': (c_i, [C.c_void_p, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
     'rih_attention_bwd_dq_fused': (c_i, [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_u64, c_f, c_f, c_f,
                                          c_i, c_f, c_i, C.c_void_p]),
     'rih_attention_fwd_fused': (c_i, [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_u64, c_f, c_f, c_f, c_i,

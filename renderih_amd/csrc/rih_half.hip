@@ -1,0 +1,457 @@
+// rih_half.hip -- fp16-storage inference backbone for gfx950 (BASELINE configs[4]: "batch=256 fp16, hipGraph-captured").
+//
+// In eval mode every BatchNorm of the CNN encoder is a per-channel affine map, so Conv->BN(->ReLU) (torchvision trunk,
+// models/encoder.py:107-116) folds into the convolution's weights and bias, and Conv->ReLU->BN (aux decoders
+// models/encoder.py:52-54, mid convs models/model_zoo/__init__.py:56-62) into a post-activation scale/shift: the whole
+// encoder becomes a chain of convolutions with fused epilogues plus a max-pool, three bilinear upsamples and an average
+// pool.  Activations and weights are stored as fp16 (half the HBM traffic of the fp32 path), products accumulate in fp32
+// on v_mfma_f32_32x32x16_f16 (one MFMA pass instead of the split engine's six), epilogue arithmetic is fp32.
+//
+// hconv_kernel: implicit GEMM  Y[pixel][cout] = sum_k A[pixel][k] W[cout][k],  k = (kh, kw, cin), NHWC fp16 input.
+//   * 128 x BN output tile per workgroup (BN = 128 or 64), 4 wavefronts as 2 x 2, each 64 x BN/2 = 2 x (BN/64) MFMA tiles;
+//     k-tiles of 64 (4 MFMA k-steps), two LDS stages.
+//   * Operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass).  One
+//     wave-instruction fills 8 rows x 128 B; the LDS image is lane-linear, so the XOR swizzle that makes the ds_read_b128
+//     operand fetches bank-conflict free (16-byte chunk c of row r lives at chunk c ^ ((r>>1)&7)) is applied on the SOURCE
+//     address.  A lane whose chunk is padding (conv halo, pixel >= M, k >= K, cout >= Cout) reads a 16-byte zero page instead.
+//   * the (tap, channel) walk of the im2col gather is per lane and incremental (no division in the loop); Cin % 8 == 0 so a
+//     chunk never straddles a tap.
+//   * epilogue: accumulators -> LDS (fp32) -> each lane owns 8 consecutive output channels of a pixel: + bias + residual
+//     (16-byte load) -> ReLU -> post scale/shift -> one 16-byte fp16 store (or two fp32 stores for the tensors handed to
+//     the fp32 mesh decoder).
+// STATUS: written after the round's GPU budget was spent; verified on the HIP-on-CPU harness (tests/test_half.py) against
+// torch on fp16-rounded operands; not yet run or measured on a GPU.  Opt-in (HandNET_GCN.use_fp16_backbone()).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/renderih_amd.h"
+
+namespace {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+constexpr int TPB = 256;
+constexpr int BM = 128;
+constexpr int BKH = 64;                 // halves per k-tile = 128 bytes per LDS row
+constexpr int ROWB = 128;               // bytes per LDS row
+constexpr int STAGE_LD = 36;            // epilogue staging: floats per row (32 + pad, keeps 16-byte alignment)
+
+struct HConvArgs {
+    const half_t* x;
+    const half_t* w;
+    const half_t* zero;
+    const float* bias;
+    const float* post_scale;
+    const float* post_shift;
+    const half_t* res;
+    void* y;
+    int M, Cout, Kpad;
+    int H, W, Cin, KH, KW, stride, pad, Ho, Wo;
+    int ldx, ldr, ldy, relu, out_f32, vec;
+};
+
+__device__ __forceinline__ int xcd_chunk(int bid, int nwg) {       // each XCD (private L2) gets a contiguous run of tiles
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+__device__ __forceinline__ void glds16(const half_t* src, unsigned char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// ok ? a : b on addresses WITHOUT control flow: hipcc otherwise sinks each LDS-DMA into both arms of a branch (one arm has a
+// scalar base) and the loader becomes a chain of divergent branches
+__device__ __forceinline__ const half_t* pick(bool ok, const half_t* a, const half_t* b) {
+    const uintptr_t m = (uintptr_t)0 - (uintptr_t)ok;
+    return (const half_t*)(((uintptr_t)a & m) | ((uintptr_t)b & ~m));
+}
+
+__device__ __forceinline__ float clamp_h(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
+
+template <int BN>
+__global__ __launch_bounds__(TPB, 2) void hconv_kernel(const HConvArgs p) {
+    constexpr int WN = BN / 2, TN = WN / 32;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = BM / 32, NB = BN / 32;               // LDS-DMA instructions per wave and k-tile
+    static_assert(2 * STAGE >= 4 * 64 * STAGE_LD * 4, "epilogue staging must fit in the operand stages");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tilesN = (p.Cout + BN - 1) / BN;
+    const int bid = xcd_chunk(blockIdx.x, gridDim.x);
+    const int m0 = (bid / tilesN) * BM, n0 = (bid % tilesN) * BN;
+
+    // ------------------------------------------------------------ loader state: rows 32 i + 8 wave + lane/8, one chunk
+    const int lrow = 8 * wave + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((lrow >> 1) & 7);       // logical 8-half chunk this lane fetches (same for all i)
+    int hi0[NA], wi0[NA], pix[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + 32 * i + lrow;
+        if (m < p.M) {
+            const int wo = m % p.Wo;
+            const int t = m / p.Wo;
+            const int ho = t % p.Ho;
+            const int img = t / p.Ho;
+            hi0[i] = ho * p.stride - p.pad;
+            wi0[i] = wo * p.stride - p.pad;
+            pix[i] = (img * p.H + hi0[i]) * p.W + wi0[i];
+        } else {
+            hi0[i] = -(1 << 24);                            // every tap fails the range test
+            wi0[i] = 0;
+            pix[i] = 0;
+        }
+    }
+    int kh, kw, ci;
+    {
+        const int k = 8 * chunk;
+        const int tap = k / p.Cin;
+        ci = k - tap * p.Cin;
+        kh = tap / p.KW;
+        kw = tap - kh * p.KW;
+    }
+    const half_t* wsrc[NB];                                 // rows beyond Cout: the zero page, step 0
+    int wstep[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int n = n0 + 32 * i + lrow;
+        wsrc[i] = (n < p.Cout) ? p.w + (long long)n * p.Kpad + 8 * chunk : p.zero;
+        wstep[i] = (n < p.Cout) ? BKH : 0;
+    }
+    const int ntiles = p.Kpad / BKH;
+
+    auto stage = [&](int buf) {
+        unsigned char* a_dst = smem + buf * STAGE + (8 * wave) * ROWB + lane * 16;
+        const bool kok = kh < p.KH;
+        const int tapoff = kh * p.W + kw;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const bool ok = (int)kok & (int)((unsigned)(hi0[i] + kh) < (unsigned)p.H) & (int)((unsigned)(wi0[i] + kw) < (unsigned)p.W);
+            const long long off = (long long)(pix[i] + tapoff) * p.ldx + ci;
+            glds16(pick(ok, p.x + off, p.zero), a_dst + 32 * i * ROWB);
+        }
+        unsigned char* b_dst = a_dst + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            glds16(wsrc[i], b_dst + 32 * i * ROWB);
+            wsrc[i] += wstep[i];
+        }
+        ci += BKH;                                          // advance the (tap, channel) walk by one k-tile
+        while (ci >= p.Cin) {
+            ci -= p.Cin;
+            if (++kw == p.KW) { kw = 0; ++kh; }
+        }
+    };
+
+    floatx16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    stage(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) stage(buf ^ 1);          // lands while this tile is multiplied
+        const unsigned char* As = smem + buf * STAGE;
+        const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int s = 0; s < BKH / 16; ++s) {
+            const int c = 2 * s + lhi;                      // lanes 0-31 supply k 0..7 of the step, lanes 32-63 k 8..15
+            half8 a[2], b[TN];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = wm * 64 + i * 32 + l31;
+                a[i] = *(const half8*)(As + r * ROWB + 16 * (c ^ ((r >> 1) & 7)));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * WN + j * 32 + l31;
+                b[j] = *(const half8*)(Bs + r * ROWB + 16 * (c ^ ((r >> 1) & 7)));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                                    // tile t+1 has landed, nobody still reads tile t
+    }
+
+    // ------------------------------------------------------------ epilogue through LDS: 8 output channels per lane
+    float* st = (float*)smem + wave * 64 * STAGE_LD;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        if (j > 0) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * STAGE_LD + l31] = acc[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int item = lane + 64 * q, row = item >> 2, ch = item & 3;
+            const int m = m0 + wm * 64 + row, n = n0 + wn * WN + j * 32 + 8 * ch;
+            if (m >= p.M || n >= p.Cout) continue;
+            const float4 v0 = *(const float4*)(st + row * STAGE_LD + 8 * ch), v1 = *(const float4*)(st + row * STAGE_LD + 8 * ch + 4);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            const bool full = p.vec && n + 8 <= p.Cout;
+            const int cnt = full ? 8 : min(8, p.Cout - n);
+            float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (p.res != nullptr) {
+                const half_t* rp = p.res + (long long)m * p.ldr + n;
+                if (full) {
+                    const half8 h = *(const half8*)rp;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rv[e] = (float)h[e];
+                } else {
+                    for (int e = 0; e < cnt; ++e) rv[e] = (float)rp[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (e < cnt) {
+                    float u = v[e] + rv[e];
+                    if (p.bias != nullptr) u += p.bias[n + e];
+                    if (p.relu) u = fmaxf(u, 0.f);
+                    if (p.post_scale != nullptr) u = u * p.post_scale[n + e] + p.post_shift[n + e];
+                    v[e] = u;
+                }
+            }
+            if (p.out_f32) {
+                float* yp = (float*)p.y + (long long)m * p.ldy + n;
+                if (full) {
+                    *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    for (int e = 0; e < cnt; ++e) yp[e] = v[e];
+                }
+            } else {
+                half_t* yp = (half_t*)p.y + (long long)m * p.ldy + n;
+                if (full) {
+                    half8 h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = (half_t)clamp_h(v[e]);
+                    *(half8*)yp = h;
+                } else {
+                    for (int e = 0; e < cnt; ++e) yp[e] = (half_t)clamp_h(v[e]);
+                }
+            }
+        }
+    }
+}
+
+// fp32 OIHW weights -> fp16 [Cout][Kpad], k = (kh, kw, ci) with ci padded to CinPad, times an optional per-cout scale (the
+// folded BatchNorm); zero beyond K
+__global__ void hpack_weight_kernel(const float* __restrict__ w, const float* __restrict__ scale, half_t* __restrict__ dst,
+                                    int Cout, int Cin, int KH, int KW, int CinPad, int Kpad) {
+    const long long total = (long long)Cout * Kpad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kpad), n = (int)(i / Kpad);
+        const int tap = k / CinPad, ci = k - tap * CinPad;
+        float v = 0.f;
+        if (tap < KH * KW && ci < Cin) {
+            const int kh = tap / KW, kw = tap - kh * KW;
+            v = w[(((long long)n * Cin + ci) * KH + kh) * KW + kw];
+            if (scale != nullptr) v *= scale[n];
+        }
+        dst[i] = (half_t)clamp_h(v);
+    }
+}
+
+// BatchNorm (eval) -> scale = gamma / sqrt(var + eps), shift = beta - mean * scale (+ scale * conv_bias)
+__global__ void hbn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                                const float* __restrict__ var, const float* __restrict__ conv_bias, float eps,
+                                float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s = (gamma != nullptr ? gamma[c] : 1.f) / sqrtf(var[c] + eps);
+    scale[c] = s;
+    shift[c] = (beta != nullptr ? beta[c] : 0.f) - mean[c] * s + (conv_bias != nullptr ? conv_bias[c] * s : 0.f);
+}
+
+// NCHW fp32 image -> NHWC fp16 with the channels padded to 8 (one 16-byte store per pixel)
+__global__ void himage_kernel(const float* __restrict__ img, half_t* __restrict__ out, int N, int C, int HW) {
+    const long long total = (long long)N * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int pxl = (int)(i % HW), n = (int)(i / HW);
+        half8 h;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) h[c] = (c < C) ? (half_t)clamp_h(img[((long long)n * C + c) * HW + pxl]) : (half_t)0.f;
+        *(half8*)(out + i * 8) = h;
+    }
+}
+
+// 3x3 stride 2 pad 1 max-pool (torchvision trunk), 8 channels per lane
+__global__ void hmaxpool_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int N, int H, int W, int C, int ldx,
+                                int ldy, int Ho, int Wo) {
+    const int C8 = C / 8;
+    const long long total = (long long)N * Ho * Wo * C8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8) * 8;
+        long long t = i / C8;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho), n = (int)(t / Ho);
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hi = 2 * ho - 1 + kh;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wi = 2 * wo - 1 + kw;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const half8 h = *(const half8*)(x + (((long long)n * H + hi) * W + wi) * ldx + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)h[e]);
+            }
+        }
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)m[e];
+        *(half8*)(y + (((long long)n * Ho + ho) * Wo + wo) * ldy + c) = o;
+    }
+}
+
+// bilinear x2, align_corners=True (nn.Upsample of models/encoder.py:51), same source-index arithmetic as the fp32 kernel
+__device__ __forceinline__ void hbil_src(int o, float scale, int in_size, int& i0, int& i1, float& l1) {
+    const float src = scale * (float)o;
+    i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+    l1 = src - (float)i0;
+}
+__global__ void hupsample2x_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int N, int H, int W, int C, int ldx,
+                                   int ldy) {
+    const int Ho = 2 * H, Wo = 2 * W, C8 = C / 8;
+    const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sw = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const long long total = (long long)N * Ho * Wo * C8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8) * 8;
+        long long t = i / C8;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho), n = (int)(t / Ho);
+        int h0, h1, w0, w1;
+        float lh, lw;
+        hbil_src(ho, sh, H, h0, h1, lh);
+        hbil_src(wo, sw, W, w0, w1, lw);
+        const half_t* b = x + (long long)n * H * W * ldx + c;
+        const half8 x00 = *(const half8*)(b + ((long long)h0 * W + w0) * ldx), x01 = *(const half8*)(b + ((long long)h0 * W + w1) * ldx);
+        const half8 x10 = *(const half8*)(b + ((long long)h1 * W + w0) * ldx), x11 = *(const half8*)(b + ((long long)h1 * W + w1) * ldx);
+        const float hl0 = 1.f - lh, wl0 = 1.f - lw;
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            o[e] = (half_t)(hl0 * (wl0 * (float)x00[e] + lw * (float)x01[e]) + lh * (wl0 * (float)x10[e] + lw * (float)x11[e]));
+        *(half8*)(y + (((long long)n * Ho + ho) * Wo + wo) * ldy + c) = o;
+    }
+}
+
+// global average pool of an NHWC fp16 map -> fp32 [N][C]: one wavefront per (image, 64-channel group) strides the pixels
+__global__ void havgpool_kernel(const half_t* __restrict__ x, float* __restrict__ y, int N, int HW, int C, int ldx) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), n = blockIdx.y;
+    const int part = threadIdx.x >> 6;                      // 4 pixel partitions
+    __shared__ float red[4][64];
+    float s = 0.f;
+    if (c < C)
+        for (int p = part; p < HW; p += 4) s += (float)x[((long long)n * HW + p) * ldx + c];
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && c < C) y[(long long)n * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)HW;
+}
+
+inline int hgrid(long long n) { return (int)((n + 255) / 256 < 65535 * 16 ? (n + 255) / 256 : 65535 * 16); }
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int rih_hconv(const rih_hconv_desc* d, void* stream) {
+    if (!d || !d->x || !d->w || !d->y || !d->zero) return RIH_EINVAL;
+    if (d->N < 1 || d->H < 1 || d->W < 1 || d->Cin < 8 || d->Cin % 8 != 0 || d->Cout < 1 || d->KH < 1 || d->KW < 1) return RIH_EINVAL;
+    if (d->stride < 1 || d->pad < 0 || d->Ho < 1 || d->Wo < 1) return RIH_EINVAL;
+    if (d->Ho != (d->H + 2 * d->pad - d->KH) / d->stride + 1 || d->Wo != (d->W + 2 * d->pad - d->KW) / d->stride + 1) return RIH_EINVAL;
+    const long long K = (long long)d->KH * d->KW * d->Cin;
+    if (d->Kpad % BKH != 0 || d->Kpad < K) return RIH_EINVAL;
+    if (d->ldx < d->Cin || d->ldx % 8 != 0 || d->ldy < d->Cout || !al16(d->x) || !al16(d->w) || !al16(d->zero)) return RIH_EINVAL;
+    if (d->res != nullptr && d->ldr < d->Cout) return RIH_EINVAL;
+    if ((d->post_scale == nullptr) != (d->post_shift == nullptr)) return RIH_EINVAL;
+    const long long M = (long long)d->N * d->Ho * d->Wo;
+    if (M > 0x7fffffffLL || (long long)d->N * d->H * d->W > 0x7fffffffLL) return RIH_EINVAL;
+    HConvArgs a;
+    a.x = (const half_t*)d->x; a.w = (const half_t*)d->w; a.zero = (const half_t*)d->zero;
+    a.bias = d->bias; a.post_scale = d->post_scale; a.post_shift = d->post_shift;
+    a.res = (const half_t*)d->res; a.y = d->y;
+    a.M = (int)M; a.Cout = d->Cout; a.Kpad = d->Kpad;
+    a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.ldx = d->ldx; a.ldr = d->ldr; a.ldy = d->ldy; a.relu = d->relu; a.out_f32 = d->out_f32;
+    // 16-byte epilogue accesses need aligned rows on every tensor they touch
+    a.vec = al16(d->y) && d->ldy % (d->out_f32 ? 4 : 8) == 0 && (d->res == nullptr || (al16(d->res) && d->ldr % 8 == 0));
+    hipStream_t s = (hipStream_t)stream;
+    const long long tilesM = (M + BM - 1) / BM;
+    if (d->Cout > 64) {
+        const long long tiles = tilesM * ((d->Cout + 127) / 128);
+        if (tiles > 0x7fffffffLL) return RIH_EINVAL;
+        hipLaunchKernelGGL((hconv_kernel<128>), dim3((unsigned)tiles), dim3(TPB), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((hconv_kernel<64>), dim3((unsigned)tilesM), dim3(TPB), 0, s, a);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int rih_hpack_conv_weight(const float* w, const float* scale, void* dst, int Cout, int Cin, int KH, int KW,
+                                     int CinPad, int Kpad, void* stream) {
+    if (!w || !dst || Cout < 1 || Cin < 1 || KH < 1 || KW < 1 || CinPad < Cin || CinPad % 8 != 0) return RIH_EINVAL;
+    if (Kpad % BKH != 0 || Kpad < KH * KW * CinPad) return RIH_EINVAL;
+    hipLaunchKernelGGL(hpack_weight_kernel, dim3(hgrid((long long)Cout * Kpad)), dim3(256), 0, (hipStream_t)stream, w, scale,
+                       (half_t*)dst, Cout, Cin, KH, KW, CinPad, Kpad);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rih_hbn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
+                            const float* conv_bias, float eps, float* scale, float* shift, int C, void* stream) {
+    if (!mean || !var || !scale || !shift || C < 1) return RIH_EINVAL;
+    hipLaunchKernelGGL(hbn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var,
+                       conv_bias, eps, scale, shift, C);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rih_himage_nchw_to_nhwc8(const float* img, void* out, int N, int C, int H, int W, void* stream) {
+    if (!img || !out || N < 1 || C < 1 || C > 8 || H < 1 || W < 1 || !al16(out)) return RIH_EINVAL;
+    hipLaunchKernelGGL(himage_kernel, dim3(hgrid((long long)N * H * W)), dim3(256), 0, (hipStream_t)stream, img, (half_t*)out,
+                       N, C, H * W);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rih_hmaxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int ldx, int ldy, void* stream) {
+    if (!x || !y || N < 1 || H < 1 || W < 1 || C < 8 || C % 8 != 0 || ldx < C || ldy < C || ldx % 8 != 0 || ldy % 8 != 0 ||
+        !al16(x) || !al16(y))
+        return RIH_EINVAL;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    hipLaunchKernelGGL(hmaxpool_kernel, dim3(hgrid((long long)N * Ho * Wo * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)x, (half_t*)y, N, H, W, C, ldx, ldy, Ho, Wo);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rih_hupsample2x(const void* x, void* y, int N, int H, int W, int C, int ldx, int ldy, void* stream) {
+    if (!x || !y || N < 1 || H < 1 || W < 1 || C < 8 || C % 8 != 0 || ldx < C || ldy < C || ldx % 8 != 0 || ldy % 8 != 0 ||
+        !al16(x) || !al16(y))
+        return RIH_EINVAL;
+    hipLaunchKernelGGL(hupsample2x_kernel, dim3(hgrid((long long)N * 4 * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)x, (half_t*)y, N, H, W, C, ldx, ldy);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rih_havgpool(const void* x, float* y, int N, int HW, int C, int ldx, void* stream) {
+    if (!x || !y || N < 1 || N > 65535 || HW < 1 || C < 1 || ldx < C) return RIH_EINVAL;
+    hipLaunchKernelGGL(havgpool_kernel, dim3((C + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, y, N, HW,
+                       C, ldx);
+    return (int)hipGetLastError();
+}

@@ -292,6 +292,85 @@ class EmulatedLib:
                 dQ[qi.ravel()] = (ds @ Kk[ki]).astype(np.float32).ravel()
         return 0
 
+    # ------------------------------------------------------------------ fp16 inference backbone (csrc/rih_half.hip)
+    @staticmethod
+    def _h(ptr, n):
+        return np.ctypeslib.as_array((C.c_uint16 * int(n)).from_address(int(ptr))).view(np.float16)
+
+    def _hview(self, ptr, pixels, ld, Cn):
+        """[pixels][ld] fp16 memory -> strided view [pixels][Cn] (the last row holds only Cn elements)."""
+        flat = self._h(ptr, (pixels - 1) * ld + Cn)
+        return np.lib.stride_tricks.as_strided(flat, (pixels, Cn), (2 * ld, 2))
+
+    def rih_hconv(self, dref, stream):
+        d = dref._obj
+        K = d.KH * d.KW * d.Cin
+        assert d.Cin % 8 == 0 and d.Kpad % 64 == 0 and d.Kpad >= K and d.ldx % 8 == 0 and d.zero
+        x = self._hview(d.x, d.N * d.H * d.W, d.ldx, d.Cin).astype(np.float32).reshape(d.N, d.H, d.W, d.Cin)
+        w = self._h(d.w, d.Cout * d.Kpad).reshape(d.Cout, d.Kpad)[:, :K].astype(np.float32)
+        w = torch.from_numpy(w.reshape(d.Cout, d.KH, d.KW, d.Cin).transpose(0, 3, 1, 2).copy())
+        y = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), w, None, d.stride, d.pad).permute(0, 2, 3, 1).numpy()
+        assert y.shape[1:3] == (d.Ho, d.Wo)
+        y = y.reshape(-1, d.Cout).astype(np.float32)
+        pixels = y.shape[0]
+        if d.res:
+            y = y + self._hview(d.res, pixels, d.ldr, d.Cout).astype(np.float32)
+        if d.bias:
+            y = y + _f(d.bias, d.Cout)[None, :]
+        if d.relu:
+            y = np.maximum(y, 0)
+        if d.post_scale:
+            y = y * _f(d.post_scale, d.Cout)[None, :] + _f(d.post_shift, d.Cout)[None, :]
+        if d.out_f32:
+            flat = _f(d.y, (pixels - 1) * d.ldy + d.Cout)
+            np.lib.stride_tricks.as_strided(flat, (pixels, d.Cout), (4 * d.ldy, 4))[:] = y
+        else:
+            self._hview(d.y, pixels, d.ldy, d.Cout)[:] = np.clip(y, -65504, 65504).astype(np.float16)
+        return 0
+
+    def rih_hpack_conv_weight(self, w, scale, dst, Cout, Cin, KH, KW, CinPad, Kpad, stream):
+        W = _f(w, Cout * Cin * KH * KW).reshape(Cout, Cin, KH, KW).copy()
+        if scale:
+            W = W * _f(scale, Cout)[:, None, None, None]
+        out = np.zeros((Cout, Kpad), np.float16)
+        packed = np.zeros((Cout, KH, KW, CinPad), np.float32)
+        packed[..., :Cin] = W.transpose(0, 2, 3, 1)
+        out[:, :KH * KW * CinPad] = np.clip(packed.reshape(Cout, -1), -65504, 65504).astype(np.float16)
+        self._h(dst, Cout * Kpad)[:] = out.ravel()
+        return 0
+
+    def rih_hbn_fold(self, gamma, beta, mean, var, conv_bias, eps, scale, shift, Cn, stream):
+        g = _f(gamma, Cn) if gamma else np.ones(Cn, np.float32)
+        b = _f(beta, Cn) if beta else np.zeros(Cn, np.float32)
+        s = (g / np.sqrt(_f(var, Cn) + np.float32(eps))).astype(np.float32)
+        _f(scale, Cn)[:] = s
+        _f(shift, Cn)[:] = b - _f(mean, Cn) * s + (_f(conv_bias, Cn) * s if conv_bias else 0)
+        return 0
+
+    def rih_himage_nchw_to_nhwc8(self, img, out, N, Cn, H, W, stream):
+        x = _f(img, N * Cn * H * W).reshape(N, Cn, H, W)
+        o = np.zeros((N, H, W, 8), np.float16)
+        o[..., :Cn] = x.transpose(0, 2, 3, 1).astype(np.float16)
+        self._h(out, o.size)[:] = o.ravel()
+        return 0
+
+    def rih_hmaxpool3x3s2(self, x, y, N, H, W, Cn, ldx, ldy, stream):
+        X = torch.from_numpy(self._hview(x, N * H * W, ldx, Cn).astype(np.float32).reshape(N, H, W, Cn)).permute(0, 3, 1, 2)
+        Y = F.max_pool2d(X, 3, 2, 1).permute(0, 2, 3, 1).numpy()
+        self._hview(y, N * Y.shape[1] * Y.shape[2], ldy, Cn)[:] = Y.reshape(-1, Cn).astype(np.float16)
+        return 0
+
+    def rih_hupsample2x(self, x, y, N, H, W, Cn, ldx, ldy, stream):
+        X = torch.from_numpy(self._hview(x, N * H * W, ldx, Cn).astype(np.float32).reshape(N, H, W, Cn)).permute(0, 3, 1, 2)
+        Y = F.interpolate(X, scale_factor=2, mode='bilinear', align_corners=True).permute(0, 2, 3, 1).numpy()
+        self._hview(y, N * 4 * H * W, ldy, Cn)[:] = Y.reshape(-1, Cn).astype(np.float16)
+        return 0
+
+    def rih_havgpool(self, x, y, N, HW, Cn, ldx, stream):
+        X = self._hview(x, N * HW, ldx, Cn).astype(np.float32).reshape(N, HW, Cn)
+        _f(y, N * Cn)[:] = X.mean(1).ravel()
+        return 0
+
     # ------------------------------------------------------------------ MANO layer (through oracle/mano_oracle.py)
     @staticmethod
     def _mano_consts(mref):

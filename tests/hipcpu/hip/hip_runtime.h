@@ -55,6 +55,12 @@ struct Fiber {
     dim3 tid;
     int flat = 0;
     bool done = true;
+    // LDS-DMA pieces issued by this thread that have not "landed" yet: applied when the thread reaches __syncthreads()
+    // (the vmcnt(0) hipcc puts in front of the barrier) -- the LATEST legal arrival, so a read before the barrier sees
+    // stale LDS exactly as it may on the hardware
+    struct Pending { void* dst; unsigned char data[16]; };
+    std::vector<Pending> pending;
+    void land() { for (auto& q : pending) std::memcpy(q.dst, q.data, 16); pending.clear(); }
 };
 
 struct State {
@@ -95,6 +101,7 @@ inline void trampoline() {
     State& s = S();
     Fiber* f = s.cur;
     s.body(s.body_arg);
+    f->land();
     f->done = true;
     --s.live;
     --s.wave_live[f->flat / WAVE];
@@ -175,7 +182,7 @@ inline void launch(dim3 grid, dim3 block, F&& fn) {
 #define blockDim (hipcpu::S().bdim)
 #define gridDim (hipcpu::S().gdim)
 
-static inline void __syncthreads() { hipcpu::block_barrier(); }
+static inline void __syncthreads() { hipcpu::S().cur->land(); hipcpu::block_barrier(); }
 
 template <typename T>
 static inline T __shfl_xor(T v, int mask, int width = 64) {

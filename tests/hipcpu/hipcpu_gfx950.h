@@ -5,12 +5,14 @@
 //       B (K x 32): lane l holds column l%32, the same k range
 //       C/D (32 x 32 fp32, 16 per lane): register r of lane l = row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31
 #pragma once
+#include <cstdio>
 
 struct hipcpu_rsrc { const char* base; unsigned bytes; };
 #define __amdgpu_buffer_rsrc_t hipcpu_rsrc
 typedef unsigned hipcpu_u32x4 __attribute__((ext_vector_type(4)));
 typedef float hipcpu_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 hipcpu_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hipcpu_f16x8 __attribute__((ext_vector_type(8)));
 
 static inline hipcpu_rsrc hipcpu_make_rsrc(const void* p, unsigned num) { return hipcpu_rsrc{(const char*)p, num}; }
 static inline hipcpu_u32x4 hipcpu_buffer_load_b128(hipcpu_rsrc r, unsigned off) {
@@ -65,3 +67,47 @@ static inline hipcpu_f32x16 hipcpu_mfma_32x32x16_bf16(hipcpu_bf16x8 a, hipcpu_bf
 }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipcpu_mfma_32x32x2_f32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipcpu_mfma_32x32x16_bf16((a), (b), (c))
+static inline hipcpu_f32x16 hipcpu_mfma_32x32x16_f16(hipcpu_f16x8 a, hipcpu_f16x8 b, hipcpu_f32x16 c) {
+    unsigned char* mine = hipcpu::xchg_slot(hipcpu::S().cur->flat);
+    std::memcpy(mine, &a, 16);
+    std::memcpy(mine + 16, &b, 16);
+    hipcpu::wave_barrier();
+    const int l = hipcpu::lane(), base = hipcpu::wave_base(), n = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            hipcpu_f16x8 av, bv;
+            std::memcpy(&av, hipcpu::xchg_slot(base + m + 32 * (k >> 3)), 16);
+            std::memcpy(&bv, hipcpu::xchg_slot(base + n + 32 * (k >> 3)) + 16, 16);
+            acc += (float)av[k & 7] * (float)bv[k & 7];
+        }
+        c[r] = acc;
+    }
+    hipcpu::wave_barrier();
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipcpu_mfma_32x32x16_f16((a), (b), (c))
+
+// LDS-DMA (global_load_lds_dwordx4): the hardware writes lane l's 16 bytes to M0 + 16*l with M0 taken from the FIRST lane's
+// LDS pointer (the compiler emits v_readfirstlane) -- the per-lane pointers are NOT a scatter.  The emulation therefore
+// exchanges the first lane's pointer and aborts if a lane's own pointer is not first + 16*lane.  The global bytes are read
+// at issue, the LDS write is deferred until the issuing thread's next __syncthreads() (see Fiber::pending).
+static inline void hipcpu_global_load_lds16(const void* g, void* lds, int size, int off) {
+    if (size != 16 || off != 0) { std::fprintf(stderr, "hipcpu: global_load_lds emulated for 16-byte pieces only\n"); std::abort(); }
+    void** mine = (void**)hipcpu::xchg_slot(hipcpu::S().cur->flat);
+    mine[0] = lds;
+    hipcpu::wave_barrier();
+    void* first = ((void**)hipcpu::xchg_slot(hipcpu::wave_base()))[0];
+    if ((unsigned char*)lds != (unsigned char*)first + 16 * hipcpu::lane()) {
+        std::fprintf(stderr, "hipcpu: global_load_lds destination is not lane-linear (lane %d)\n", hipcpu::lane());
+        std::abort();
+    }
+    hipcpu::Fiber::Pending q;
+    q.dst = lds;
+    std::memcpy(q.data, g, 16);
+    hipcpu::S().cur->pending.push_back(q);
+    hipcpu::wave_barrier();
+}
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) \
+    hipcpu_global_load_lds16((const void*)(g), (void*)(l), (size), (off))

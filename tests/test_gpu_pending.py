@@ -1,0 +1,34 @@
+"""First hardware contact of the code paths that were written AFTER this round's GPU budget was spent and are therefore
+OFF by default in the product: the fp16 inference backbone (csrc/rih_half.hip), the fused attention kernels
+(csrc/rih_attn.hip, RIH_FUSED_ATTN) and the pre-split GEMM operands (RIH_PRESPLIT).  They are verified on the HIP-on-CPU
+harness only.  Each group runs in its OWN interpreter with a time limit, so that a fault in an unproven kernel cannot take
+the proven suite down; a failing group is reported as xfail (with the tail of its output), a passing one as a pass.
+Once a group has passed on hardware it moves into the regular test files and its feature can be switched on."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+@pytest.mark.parametrize('group', ['half_kernels', 'half_backbone', 'fused_attention', 'presplit'])
+def test_pending_on_hardware(group):
+    cmd = [sys.executable, os.path.join(ROOT, 'tests', 'pending', 'run_pending.py'), group]
+    try:
+        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420)
+        out, code = p.stdout + p.stderr, p.returncode
+    except subprocess.TimeoutExpired as e:
+        out, code = 'TIMEOUT\n' + str(e.stdout or '')[-2000:], -1
+    log = os.path.join(ROOT, 'gpurun_out')
+    try:
+        os.makedirs(log, exist_ok=True)
+        with open(os.path.join(log, 'pending_%s.log' % group), 'w') as f:
+            f.write(out)
+    except OSError:
+        pass
+    print(out[-3000:])
+    if code != 0 or 'PENDING-OK' not in out:
+        pytest.xfail('not yet hardware-verified path failed its first GPU run (%s): %s' % (group, out[-600:]))

@@ -1,0 +1,183 @@
+"""fp16-storage inference backbone (renderih_amd/half.py, csrc/rih_half.hip) on the CPU:
+  * the kernels themselves, compiled for the host (tests/hipcpu: fibers, emulated v_mfma_f32_32x32x16_f16 and LDS-DMA with
+    the lane-linear destination rule and deferred landing), against torch on identically fp16-rounded operands;
+  * the host logic of HalfBackbone (BN folding, in-place channel concatenation, stage order) through the numpy/torch
+    restatement of the entry points (tests/abi_emulator.py), against the fp32 model.
+The same checks run on the GPU from tests/test_gpu_pending.py."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from renderih_amd import half          # noqa: E402
+
+F16 = torch.float16
+
+
+def _q(t):
+    return t.to(F16).float()
+
+
+def conv_case(dev, N, H, W, Cin, Cout, k, stride, pad, order, relu, res, out_f32, x_pad=0, y_pad=0, seed=0, cin_w=None):
+    """One PackedConv call against F.conv2d on fp16-rounded operands (fp32 accumulate), fp32 epilogue, final rounding."""
+    g = torch.Generator().manual_seed(seed)
+    cin_w = cin_w or Cin
+    conv = nn.Conv2d(cin_w, Cout, k, stride, pad, bias=(order is None)).to(dev)
+    bn = None
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (cin_w * k * k)) ** 0.5)
+        if conv.bias is not None:
+            conv.bias.copy_(torch.randn(Cout, generator=g) * 0.1)
+        if order is not None:
+            bn = nn.BatchNorm2d(Cout).to(dev).eval()
+            bn.weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(Cout, generator=g) * 0.2)
+            bn.running_mean.copy_(torch.randn(Cout, generator=g) * 0.2)
+            bn.running_var.copy_(torch.rand(Cout, generator=g) + 0.5)
+    pc = half.PackedConv(conv, bn, order, cin_pad=Cin)
+    xw = torch.zeros(N, H, W, Cin + x_pad, dtype=F16, device=dev)
+    xw[..., :cin_w] = torch.randn(N, H, W, cin_w, generator=g).to(F16).to(dev)
+    if x_pad:
+        xw[..., Cin:] = 7.0                           # neighbours of the slice must not leak in
+    x = xw[..., :Cin]
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    r = torch.randn(N, Ho, Wo, Cout, generator=g).to(F16).to(dev) if res else None
+    ydt = torch.float32 if out_f32 else F16
+    yw = torch.full((N, Ho, Wo, Cout + y_pad), -3.0, dtype=ydt, device=dev)
+    y = pc(x, relu=relu, res=r, out=yw[..., :Cout], out_f32=out_f32)
+    if y_pad:
+        assert bool((yw[..., Cout:] == -3.0).all()), 'wrote outside the channel slice'
+    # reference (always on the CPU: plain fp32 arithmetic whatever the device under test)
+    cpu = torch.device('cpu')
+    conv, x, y = conv.to(cpu), x.to(cpu), y.to(cpu)
+    bn = None if bn is None else bn.to(cpu)
+    r = None if r is None else r.to(cpu)
+    with torch.no_grad():
+        if order == 'conv-bn':
+            s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            t = bn.bias - bn.running_mean * s
+            wq = _q(conv.weight * s[:, None, None, None])
+        else:
+            wq = _q(conv.weight)
+        ref = F.conv2d(x[..., :cin_w].float().permute(0, 3, 1, 2), wq, None, stride, pad).permute(0, 2, 3, 1)
+        if order == 'conv-bn':
+            ref = ref + t
+        elif conv.bias is not None:
+            ref = ref + conv.bias
+        if r is not None:
+            ref = ref + r.float()
+        if relu:
+            ref = ref.clamp_min(0)
+        if order == 'conv-relu-bn':
+            s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            ref = ref * s + (bn.bias - bn.running_mean * s)
+    got = y.float()
+    tol = 1e-5 if out_f32 else 1.5e-3                 # fp16 output: one rounding (2^-11 relative) + summation order
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= tol * max(scale, 1.0) + 1e-6, (err, scale)
+    if not out_f32:                                   # almost all outputs are THE correctly rounded value
+        exact = (got == _q(ref)).float().mean().item()
+        assert exact > 0.97, exact
+
+
+def kernels_vs_torch(dev):
+    # trunk shapes: 1x1, 3x3 stride 1 / 2, downsample 1x1 stride 2, residual + ReLU, slices with a pixel pitch
+    conv_case(dev, 2, 6, 6, 64, 64, 1, 1, 0, 'conv-bn', True, False, False)
+    conv_case(dev, 1, 9, 7, 64, 64, 3, 1, 1, 'conv-bn', True, False, False, seed=1)
+    conv_case(dev, 1, 8, 8, 64, 128, 3, 2, 1, 'conv-bn', True, False, False, seed=2)
+    conv_case(dev, 2, 8, 8, 128, 256, 1, 2, 0, 'conv-bn', False, False, False, seed=3)
+    conv_case(dev, 1, 5, 5, 64, 256, 1, 1, 0, 'conv-bn', True, True, False, x_pad=8, y_pad=16, seed=4)
+    # stem: 7x7 stride 2, 3 input channels padded to 8 (a k-tile spans 8 taps)
+    conv_case(dev, 1, 20, 20, 8, 64, 7, 2, 3, 'conv-bn', True, False, False, seed=5, cin_w=3)
+    # aux decoder / mid conv order, fp32 output; head with a ragged channel count (scalar epilogue)
+    conv_case(dev, 1, 6, 6, 96, 64, 3, 1, 1, 'conv-relu-bn', True, False, False, y_pad=64, seed=6)
+    conv_case(dev, 1, 4, 4, 192, 64, 1, 1, 0, 'conv-relu-bn', True, False, True, seed=7)
+    conv_case(dev, 1, 5, 5, 64, 42, 1, 1, 0, None, False, False, True, seed=8)
+    conv_case(dev, 1, 5, 5, 64, 10, 1, 1, 0, None, False, False, False, seed=9)      # fp16, ld not a multiple of 8
+    # pooling / resampling
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 9, 10, 16, generator=g).to(F16)
+    ref = F.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(half.maxpool3x3s2(x.to(dev)).float().cpu(), ref)
+    xs = torch.randn(2, 5, 4, 24, generator=g).to(F16)
+    ref = F.interpolate(xs[..., 8:24].float().permute(0, 3, 1, 2), scale_factor=2, mode='bilinear',
+                        align_corners=True).permute(0, 2, 3, 1)
+    xv = xs.to(dev)[..., 8:24]
+    got = half.upsample2x(xv).float().cpu()
+    assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    ref = xs[..., 8:24].float().mean(dim=(1, 2))
+    assert (half.global_avgpool(xv).cpu() - ref).abs().max().item() < 1e-5
+    img = torch.randn(2, 3, 6, 5, generator=g)
+    o = half.image_to_nhwc8(img.to(dev)).cpu()
+    assert torch.equal(o[..., :3].float(), _q(img).permute(0, 2, 3, 1)) and bool((o[..., 3:] == 0).all())
+
+
+def test_half_kernels_on_cpu():
+    from hipcpu.host_kernels import host_kernels_abi
+    with host_kernels_abi():
+        kernels_vs_torch(torch.device('cpu'))
+
+
+def tiny_model(seed=0):
+    """The reference network with a ResNet trunk of one bottleneck per stage (same module classes, same dataflow)."""
+    from renderih_amd import encoder as E, testing
+    from renderih_amd.model import HandNET_GCN, load_decoder
+    from renderih_amd.config import load_cfg
+    cfg = load_cfg(None)
+    cfg.TRAIN.dropout = 0.0
+    enc = E.ResNetSimple('resnet50')
+    enc.resnet = E.ResNetTrunk((1, 1, 1, 1))
+    mid = E.resnet_mid('resnet50')
+    m = HandNET_GCN(enc, mid, load_decoder(cfg, mid.get_info()))
+    m.load_state_dict(testing.deterministic_state(m.state_dict(), seed=seed))
+    return m.eval()
+
+
+def backbone_vs_fp32(dev, B=1, size=256, tol=1e-2):
+    """HalfBackbone against the fp32 encoder + mid model of the same weights: every tensor handed to the decoder."""
+    from renderih_amd import testing
+    m = tiny_model().to(dev)
+    img = testing.seeded_image(B, 5)[..., :size, :size].contiguous().to(dev)
+    with torch.no_grad():
+        hms, mask, dp, img_fmaps, hms_fmaps, dp_fmaps = m.encoder(img)
+        gf, fmaps = m.mid_model(img_fmaps, hms_fmaps, dp_fmaps)
+        hb = half.HalfBackbone(m.encoder, m.mid_model)
+        hms2, mask2, dp2, gf2, fmaps2 = hb(img)
+    pairs = [('hms', hms, hms2), ('mask', mask, mask2), ('dp', dp, dp2), ('gf', gf, gf2)] + \
+            [('fmap%d' % i, a, b) for i, (a, b) in enumerate(zip(fmaps, fmaps2))]
+    worst = {}
+    for name, a, b in pairs:
+        assert a.shape == b.shape and b.dtype == torch.float32, (name, a.shape, b.shape, b.dtype)
+        worst[name] = testing.rel_err(b, a)
+        assert worst[name] < tol, (name, worst)
+    # and end to end through the fp32 mesh decoder
+    with torch.no_grad():
+        ref = testing.flatten_outputs(m(img))
+        m.use_fp16_backbone()
+        got = testing.flatten_outputs(m(img))
+        m.use_fp16_backbone(False)
+    for k in ('result.verts3d.left', 'result.verts3d.right'):
+        if k in ref:
+            assert testing.rel_err(got[k], ref[k]) < tol, (k, testing.rel_err(got[k], ref[k]))
+    return worst
+
+
+def test_half_backbone_host_logic():
+    from abi_emulator import emulated_abi
+    with emulated_abi():
+        backbone_vs_fp32(torch.device('cpu'))
+
+
+def test_half_backbone_requires_eval():
+    from abi_emulator import emulated_abi
+    with emulated_abi():
+        m = tiny_model().train()
+        with pytest.raises(RuntimeError):
+            m.use_fp16_backbone()

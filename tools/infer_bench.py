@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Inference-only throughput (BASELINE configs[4] shape: batch 256, eval mode, encoder + attention decoder, then the
-MANO layer on 2 x 256 hands) eagerly and replayed from a captured hipGraph.  fp32 (the split-bf16 MFMA engine); fp16
-storage is not implemented.  The whole forward is stream-ordered through the C ABI (no host sync, no allocation inside
+MANO layer on 2 x 256 hands) eagerly and replayed from a captured hipGraph.  Default fp32 (the split-bf16 MFMA engine);
+--fp16 runs encoder + mid model with fp16 storage and folded BatchNorm (renderih_amd/half.py; decoder and MANO stay fp32)
+and also reports the deviation of the predicted vertices from the fp32 path on the same inputs.  The whole forward is stream-ordered through the C ABI (no host sync, no allocation inside
 the library), which is what makes it capturable.
     python tools/infer_bench.py [--batch 256] [--iters 20]"""
 import argparse
@@ -23,6 +24,7 @@ def main():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--encoder', default='resnet50')
+    ap.add_argument('--fp16', action='store_true', help='fp16-storage backbone (HandNET_GCN.use_fp16_backbone)')
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
     torch.manual_seed(0)
@@ -30,6 +32,13 @@ def main():
     mano = {s: ManoLayer(assets.synthetic_mano_dict(s)).to(dev) for s in ('left', 'right')}
     B = a.batch
     img = torch.randn(B, 3, 256, 256, device=dev)
+    dev_err = None
+    if a.fp16:
+        with torch.no_grad():
+            ref32 = model(img[:8])[0]['verts3d']
+            model.use_fp16_backbone()
+            got16 = model(img[:8])[0]['verts3d']
+        dev_err = max(float((got16[s] - ref32[s]).abs().max() / ref32[s].abs().max()) for s in ('left', 'right'))
     root = rodrigues_batch(torch.randn(B, 3)).to(dev)
     pose, shape = (0.5 * torch.randn(B, 45)).to(dev), torch.randn(B, 10).to(dev)
 
@@ -65,7 +74,9 @@ def main():
     print(json.dumps({'metric': 'inference images/sec (eval forward + MANO layer), batch %d, %s' % (B, a.encoder),
                       'eager_img_s': round(B / t_eager, 1), 'hipgraph_img_s': round(B / t_graph, 1),
                       'eager_ms': round(1e3 * t_eager, 2), 'hipgraph_ms': round(1e3 * t_graph, 2),
-                      'graph_output_bit_identical_to_eager': same, 'dtype': 'f32'}))
+                      'graph_output_bit_identical_to_eager': same,
+                      'dtype': 'f16 backbone storage / f32 accumulate, f32 decoder' if a.fp16 else 'f32',
+                      'verts_rel_dev_vs_f32': dev_err}))
 
 
 if __name__ == '__main__':
