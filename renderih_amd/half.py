@@ -189,45 +189,64 @@ class _AuxDecoder:
         return self.head(x, out_f32=True)
 
 
+class _Trunk:
+    """torchvision ResNet trunk (stem, max-pool, bottleneck stages) -> [x1, x2, x3, x4] (coarsest first).  `slots[i]`, when
+    given, is the view the last block of the stage that produces x_i writes into (a slice of a wider tensor)."""
+
+    def __init__(self, r):
+        self.stem = PackedConv(r.conv1, r.bn1, 'conv-bn', cin_pad=8)
+        self.layers = [[_Block(b) for b in layer] for layer in (r.layer1, r.layer2, r.layer3, r.layer4)]
+        self.dims = [self.layers[3 - i][-1].c3.Cout for i in range(4)]            # channels of x1, x2, x3, x4
+
+    def stem_pool(self, img):
+        if img.shape[2] % 32 or img.shape[3] % 32:
+            raise ValueError('fp16 backbone: image sides must be multiples of 32')
+        return maxpool3x3s2(self.stem(image_to_nhwc8(img), relu=True))
+
+    def stages(self, x, slots=(None, None, None, None)):
+        outs = [None] * 4
+        for li, layer in enumerate(self.layers):
+            lvl = 3 - li
+            for bi, blk in enumerate(layer):
+                x = blk(x, out=slots[lvl] if bi == len(layer) - 1 else None)
+            outs[lvl] = x
+        return outs
+
+
+def _check_eval(*mods):
+    if any(m.training for m in mods):
+        raise RuntimeError('fp16 backbone folds BatchNorm running statistics: call model.eval() first')
+
+
 class HalfBackbone:
+    """models/encoder.py family: ResNetSimple (trunk + hms / dp aux decoders) + resnet_mid."""
+
     def __init__(self, encoder, mid_model):
         from .encoder import ResNetSimple, resnet_mid
         if not isinstance(encoder, ResNetSimple) or not isinstance(mid_model, resnet_mid):
             raise NotImplementedError('fp16 backbone: ResNet encoder family only')
-        if encoder.training or mid_model.training:
-            raise RuntimeError('fp16 backbone folds BatchNorm running statistics: call model.eval() first')
+        _check_eval(encoder, mid_model)
         with torch.no_grad():
-            r = encoder.resnet
-            self.stem = PackedConv(r.conv1, r.bn1, 'conv-bn', cin_pad=8)
-            self.layers = [[_Block(b) for b in layer] for layer in (r.layer1, r.layer2, r.layer3, r.layer4)]
+            self.trunk = _Trunk(encoder.resnet)
             self.hms = _AuxDecoder(encoder.hms_decoder)
             self.dp = _AuxDecoder(encoder.dp_decoder)
             self.mid = [PackedConv(seq[0], seq[2], 'conv-relu-bn') for seq in mid_model.convs]
+            zero_page(encoder.resnet.conv1.weight.device)
         self.handNum = encoder.handNum
         self.fdim = [st[1].Cout for st in self.hms.stages]                       # 256 x 4
-        self.img_dims = [self.layers[3 - i][-1].c3.Cout for i in range(4)]        # x1, x2, x3, x4 channels
 
     @torch.no_grad()
     def __call__(self, img):
-        B, _, H, W = img.shape
-        dev = img.device
-        x = maxpool3x3s2(self.stem(image_to_nhwc8(img), relu=True))
+        B = img.shape[0]
+        x = self.trunk.stem_pool(img)
         # concat buffers of the mid model, level i = 0..3 (x1 .. x4 resolution): [hms 256 | dp 256 | x_i (i > 0)]
         h, w = x.shape[1], x.shape[2]
-        if H % 32 or W % 32:
-            raise ValueError('fp16 backbone: image sides must be multiples of 32')
+        f = self.fdim
         cats = []
         for i in range(4):
-            width = 2 * self.fdim[i] + (self.img_dims[i] if i > 0 else 0)
-            cats.append(torch.empty((B, h >> (3 - i), w >> (3 - i), width), device=dev, dtype=F16))
-        for li, layer in enumerate(self.layers):
-            lvl = 3 - li
-            for bi, blk in enumerate(layer):
-                last = bi == len(layer) - 1
-                out = cats[lvl][..., 2 * self.fdim[lvl]:] if (last and lvl > 0) else None
-                x = blk(x, out=out)
-        x1 = x
-        f = self.fdim
+            width = 2 * f[i] + (self.trunk.dims[i] if i > 0 else 0)
+            cats.append(torch.empty((B, h >> (3 - i), w >> (3 - i), width), device=img.device, dtype=F16))
+        x1 = self.trunk.stages(x, [None] + [cats[i][..., 2 * f[i]:] for i in range(1, 4)])[0]
         hms = self.hms(x1, [cats[i][..., :f[i]] for i in range(4)])
         out = self.dp(x1, [cats[i][..., f[i]:2 * f[i]] for i in range(4)])
         gf = global_avgpool(x1)
@@ -235,3 +254,23 @@ class HalfBackbone:
         mask = ops.nhwc_to_nchw(out, 0, self.handNum)
         dp = ops.nhwc_to_nchw(out, self.handNum, out.shape[-1])
         return ops.nhwc_to_nchw(hms), mask, dp, gf, fmaps
+
+
+class HalfBackboneB:
+    """common/myhand/encoder_lijun.py family (what apps/eval_interhand.py instantiates): trunk only, one
+    [1x1 conv, ReLU, BN] per scale, global average pool.  Returns (global_feature, fmaps) in fp32."""
+
+    def __init__(self, encoder, mid_model):
+        from . import lijun
+        if not isinstance(encoder, lijun.ResNetSimple) or not isinstance(mid_model, lijun.resnet_mid):
+            raise NotImplementedError('fp16 backbone: ResNet encoder family only')
+        _check_eval(encoder, mid_model)
+        with torch.no_grad():
+            self.trunk = _Trunk(encoder.resnet)
+            self.mid = [PackedConv(seq[0], seq[2], 'conv-relu-bn') for seq in mid_model.convs]
+            zero_page(encoder.resnet.conv1.weight.device)
+
+    @torch.no_grad()
+    def __call__(self, img):
+        xs = self.trunk.stages(self.trunk.stem_pool(img))
+        return global_avgpool(xs[0]), [pc(x, relu=True, out_f32=True) for pc, x in zip(self.mid, xs)]

@@ -373,9 +373,24 @@ class HandNET_GCN(nn.Module):
         self.decoder = decoder
         self.cliff = cliff
 
+    _half = None
+
+    def use_fp16_backbone(self, enable=True):
+        """Inference only: encoder + mid_model with fp16 storage and folded BatchNorm (renderih_amd/half.py); see
+        renderih_amd.model.HandNET_GCN.use_fp16_backbone."""
+        if enable:
+            from .half import HalfBackboneB
+            self._half = HalfBackboneB(self.encoder, self.mid_model)
+        else:
+            self._half = None
+        return self
+
     def forward(self, img):
-        img_fmaps = self.encoder(img)
-        global_feature, fmaps = self.mid_model(img_fmaps)
+        if self._half is not None and not self.training and not torch.is_grad_enabled():
+            global_feature, fmaps = self._half(img)
+        else:
+            img_fmaps = self.encoder(img)
+            global_feature, fmaps = self.mid_model(img_fmaps)
         return self.decoder(global_feature, fmaps)
 
 

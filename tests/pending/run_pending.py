@@ -26,6 +26,7 @@ def half_backbone(dev):
     import test_half
     worst = test_half.backbone_vs_fp32(dev, B=2)
     print('fp16 backbone vs fp32 backbone, max relative error per tensor:', worst)
+    print('second family:', test_half.backbone_b_vs_fp32(dev, B=2))
     # the full ResNet50 model: finite outputs, close to the fp32 path, and capturable
     from renderih_amd.model import build_model
     from renderih_amd import testing

@@ -181,3 +181,33 @@ def test_half_backbone_requires_eval():
         m = tiny_model().train()
         with pytest.raises(RuntimeError):
             m.use_fp16_backbone()
+
+
+def backbone_b_vs_fp32(dev, B=1, tol=1e-2):
+    """Second family (encoder_lijun): HalfBackboneB against its fp32 encoder + mid model, and through the decoder."""
+    from renderih_amd import encoder as E, lijun, testing
+    m = lijun.build_graph_model(0.0)
+    m.encoder.resnet = E.ResNetTrunk((1, 1, 1, 1))
+    m.load_state_dict(testing.deterministic_state(m.state_dict(), seed=2))
+    m = m.to(dev).eval()
+    img = testing.seeded_image(B, 6).to(dev)
+    with torch.no_grad():
+        gf, fmaps = m.mid_model(m.encoder(img))
+        gf2, fmaps2 = half.HalfBackboneB(m.encoder, m.mid_model)(img)
+        worst = {'gf': testing.rel_err(gf2, gf)}
+        for i, (a, b) in enumerate(zip(fmaps, fmaps2)):
+            assert a.shape == b.shape and b.dtype == torch.float32
+            worst['fmap%d' % i] = testing.rel_err(b, a)
+        assert max(worst.values()) < tol, worst
+        ref = testing.flatten_outputs(m(img))
+        got = testing.flatten_outputs(m.use_fp16_backbone()(img))
+        m.use_fp16_backbone(False)
+    for k in ('result.verts3d.left', 'result.verts3d.right'):
+        assert testing.rel_err(got[k], ref[k]) < 3 * tol, (k, testing.rel_err(got[k], ref[k]))
+    return worst
+
+
+def test_half_backbone_family_b_host_logic():
+    from abi_emulator import emulated_abi
+    with emulated_abi():
+        backbone_b_vs_fp32(torch.device('cpu'))
