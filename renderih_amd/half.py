@@ -36,6 +36,7 @@ def _cdiv(a, b):
 
 
 _ZERO = {}
+TALLY = None        # set to {'flop': 0.0, 'bytes': 0.0, 'launches': 0} to count the convolutions' algorithmic work
 
 
 def zero_page(device):
@@ -122,6 +123,11 @@ class PackedConv:
         d.stride, d.pad, d.Ho, d.Wo, d.ldx, d.ldy, d.Kpad = self.stride, self.pad, Ho, Wo, ldx, ldy, self.Kpad
         d.relu, d.out_f32 = int(relu), int(out_f32)
         check(ops._L().rih_hconv(C.byref(d), ops._stream()), 'rih_hconv')
+        if TALLY is not None:               # algorithmic work of this launch (true Cin of the weights, no padding)
+            TALLY['flop'] += 2.0 * N * Ho * Wo * self.Cout * self.KH * self.KW * self.Cin_w
+            TALLY['bytes'] += 2.0 * (N * H * W * self.Cin_w + self.Cout * self.KH * self.KW * self.Cin_w) + \
+                (4.0 if out_f32 else 2.0) * N * Ho * Wo * self.Cout + (2.0 * N * Ho * Wo * self.Cout if res is not None else 0.0)
+            TALLY['launches'] += 1
         return out
 
 

@@ -32,13 +32,18 @@ def main():
     mano = {s: ManoLayer(assets.synthetic_mano_dict(s)).to(dev) for s in ('left', 'right')}
     B = a.batch
     img = torch.randn(B, 3, 256, 256, device=dev)
-    dev_err = None
+    dev_err = tally = None
     if a.fp16:
         with torch.no_grad():
             ref32 = model(img[:8])[0]['verts3d']
             model.use_fp16_backbone()
             got16 = model(img[:8])[0]['verts3d']
         dev_err = max(float((got16[s] - ref32[s]).abs().max() / ref32[s].abs().max()) for s in ('left', 'right'))
+        from renderih_amd import half
+        half.TALLY = {'flop': 0.0, 'bytes': 0.0, 'launches': 0}
+        with torch.no_grad():
+            model(img)
+        tally, half.TALLY = half.TALLY, None
     root = rodrigues_batch(torch.randn(B, 3)).to(dev)
     pose, shape = (0.5 * torch.randn(B, 45)).to(dev), torch.randn(B, 10).to(dev)
 
@@ -76,7 +81,12 @@ def main():
                       'eager_ms': round(1e3 * t_eager, 2), 'hipgraph_ms': round(1e3 * t_graph, 2),
                       'graph_output_bit_identical_to_eager': same,
                       'dtype': 'f16 backbone storage / f32 accumulate, f32 decoder' if a.fp16 else 'f32',
-                      'verts_rel_dev_vs_f32': dev_err}))
+                      'verts_rel_dev_vs_f32': dev_err,
+                      # algorithmic work of the fp16 convolutions per batch: divide by their summed rocprofv3 duration
+                      # (hconv_kernel rows of the kernel stats) for TFLOP/s against the 2.5 PF dense f16 MFMA peak
+                      'hconv_tflop_per_batch': round(tally['flop'] / 1e12, 3) if a.fp16 else None,
+                      'hconv_gb_per_batch': round(tally['bytes'] / 1e9, 3) if a.fp16 else None,
+                      'hconv_launches': tally['launches'] if a.fp16 else None}))
 
 
 if __name__ == '__main__':
