@@ -365,6 +365,26 @@ int rih_hupsample2x(const void* x, void* y, int N, int H, int W, int C, int ldx,
 int rih_havgpool(const void* x, float* y, int N, int HW, int C, int ldx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Input preparation of a batch resident on the GPU (csrc/rih_input.hip) -- core/loader.py:104-219
+ * `handDataset.process_data` and utils/manoutils.py:214-260 (`imgUtils.data_augmentation`, `add_noise`).
+ * rih_prepare_images: src [B][S][S][3] uint8 BGR (decoded crops).  minv [B][6] = the INVERSE (destination -> source)
+ *   of the matrix the reference hands to cv.warpAffine, in double precision (NULL: no warp); 8-bit INTER_LINEAR /
+ *   BORDER_CONSTANT fixed-point algorithm of OpenCV.  bright [B][4] = per-channel gain a_b, a_g, a_r and offset b of
+ *   `add_noise` (NULL: none).  flip [B] (NULL: none).  Outputs (each may be NULL): aug_u8 [B][S][S][3] the augmented
+ *   crop, ori [B][3][S][S] = BGR / 255, norm [B][3][S][S] = ImageNet-normalised RGB, norm_h8 [B][S][S][8] fp16 NHWC
+ *   (the input layout of rih_hconv's first layer).
+ * rih_prepare_labels: p2 [B][NP][2], p3 [B][NP][3] with NP = 2*(NV+NJ) points ordered [verts_left, joints_left,
+ *   verts_right, joints_right]; A [B][6] the first two rows of the float32 affine matrix (NULL: identity), R [B][9] the
+ *   in-plane rotation (NULL: identity); root-relative to joint `root_joint` of each hand, scaled so that the mean
+ *   |joint root - joint 0| equals bone_length (<= 0: off); flipped samples mirror x (2-D: img_size - x), negate
+ *   root_rel y/z as the reference does, and swap the hands in the output. */
+int rih_prepare_images(const uint8_t* src, int B, int S, const double* minv, const double* bright, const uint8_t* flip,
+                       uint8_t* aug_u8, float* ori, float* norm, void* norm_h8, void* stream);
+int rih_prepare_labels(const float* p2, const float* p3, int B, int NV, int NJ, const float* A, const float* R,
+                       const uint8_t* flip, float bone_length, int root_joint, float img_size, float* o2, float* o3,
+                       float* root_rel, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * MANO parameter head of the reference's `load_new_model` network (common/myhand/decoder_lijun_mano.py:112-160,247-300)
  * nn.Hardswish and scale*tanh (the ParamRegressor MLP, `F.tanh(shape) * 3`): elementwise, n floats. */
 int rih_hardswish_fwd(const float* x, float* y, int64_t n, void* stream);

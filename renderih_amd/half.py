@@ -78,7 +78,7 @@ class PackedConv:
 
     def __init__(self, conv, bn=None, order=None, cin_pad=None):
         w = conv.weight.detach()
-        assert w.dtype == torch.float32
+        ops._chk(w)
         self.Cout, self.Cin_w, self.KH, self.KW = w.shape
         self.Cin = cin_pad or self.Cin_w
         assert self.Cin % 8 == 0 and self.Cin >= self.Cin_w
@@ -101,6 +101,8 @@ class PackedConv:
               'rih_hpack_conv_weight')
 
     def __call__(self, x, relu=False, res=None, out=None, out_f32=False):
+        ops._chk(x, res, dtype=F16)
+        ops._chk(out, dtype=None)
         N, H, W, Cx, ldx = _geom(x)
         assert Cx == self.Cin and x.dtype == F16, (Cx, self.Cin, x.dtype)
         Ho = (H + 2 * self.pad - self.KH) // self.stride + 1
@@ -134,6 +136,7 @@ class PackedConv:
 def image_to_nhwc8(img):
     """[B,C<=8,H,W] fp32 NCHW -> [B,H,W,8] fp16."""
     B, Cc, H, W = img.shape
+    ops._chk(img, dtype=None)
     img = img.contiguous().float()
     out = torch.empty((B, H, W, 8), device=img.device, dtype=F16)
     check(ops._L().rih_himage_nchw_to_nhwc8(img.data_ptr(), out.data_ptr(), B, Cc, H, W, ops._stream()), 'rih_himage_nchw_to_nhwc8')
@@ -141,6 +144,7 @@ def image_to_nhwc8(img):
 
 
 def maxpool3x3s2(x):
+    ops._chk(x, dtype=F16)
     N, H, W, Cc, ld = _geom(x)
     y = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), device=x.device, dtype=F16)
     check(ops._L().rih_hmaxpool3x3s2(x.data_ptr(), y.data_ptr(), N, H, W, Cc, ld, Cc, ops._stream()), 'rih_hmaxpool3x3s2')
@@ -148,6 +152,7 @@ def maxpool3x3s2(x):
 
 
 def upsample2x(x):
+    ops._chk(x, dtype=F16)
     N, H, W, Cc, ld = _geom(x)
     y = torch.empty((N, 2 * H, 2 * W, Cc), device=x.device, dtype=F16)
     check(ops._L().rih_hupsample2x(x.data_ptr(), y.data_ptr(), N, H, W, Cc, ld, Cc, ops._stream()), 'rih_hupsample2x')
@@ -155,6 +160,7 @@ def upsample2x(x):
 
 
 def global_avgpool(x):
+    ops._chk(x, dtype=F16)
     N, H, W, Cc, ld = _geom(x)
     y = torch.empty((N, Cc), device=x.device, dtype=torch.float32)
     check(ops._L().rih_havgpool(x.data_ptr(), y.data_ptr(), N, H * W, Cc, ld, ops._stream()), 'rih_havgpool')

@@ -25,14 +25,14 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
-def _chk(*ts):
+def _chk(*ts, dtype=torch.float32):
     for t in ts:
         if t is None:
             continue
         if not t.is_cuda:
             raise RuntimeError('renderih_amd ops need GPU tensors (HIP kernels only, no CPU fallback)')
-        if t.dtype != torch.float32:
-            raise RuntimeError('renderih_amd ops are fp32; got %s' % t.dtype)
+        if dtype is not None and t.dtype != dtype:
+            raise RuntimeError('renderih_amd op expects %s; got %s' % (dtype, t.dtype))
 
 
 def _c(t):

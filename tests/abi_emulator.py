@@ -371,6 +371,65 @@ class EmulatedLib:
         _f(y, N * Cn)[:] = X.mean(1).ravel()
         return 0
 
+    # ------------------------------------------------------------------ input preparation (through oracle/input_oracle.py)
+    def rih_prepare_images(self, src, B, S, minv, bright, flip, aug_u8, ori, norm, norm_h8, stream):
+        from oracle import input_oracle as IO
+        u8 = lambda ptr, n: np.ctypeslib.as_array((C.c_uint8 * int(n)).from_address(int(ptr)))
+        f64 = lambda ptr, n: np.ctypeslib.as_array((C.c_double * int(n)).from_address(int(ptr)))
+        imgs = u8(src, B * S * S * 3).reshape(B, S, S, 3)
+        for b in range(B):
+            im = imgs[b]
+            if minv:
+                im = IO.warp_with_inverse(im, f64(minv, 6 * B)[6 * b:6 * b + 6], (S, S))
+            if bright:
+                br = f64(bright, 4 * B)[4 * b:4 * b + 4]
+                im = IO.add_brightness(im, br[:3], br[3])
+            if flip and u8(flip, B)[b]:
+                im = im[:, ::-1]
+            o, n = IO.image_tensors(np.ascontiguousarray(im))
+            if aug_u8:
+                u8(aug_u8, B * S * S * 3).reshape(B, S, S, 3)[b] = im
+            if ori:
+                _f(ori, B * 3 * S * S).reshape(B, 3, S, S)[b] = o
+            if norm:
+                _f(norm, B * 3 * S * S).reshape(B, 3, S, S)[b] = n
+            if norm_h8:
+                h = self._h(norm_h8, B * S * S * 8).reshape(B, S, S, 8)
+                h[b] = 0
+                h[b, ..., :3] = n.transpose(1, 2, 0).astype(np.float16)
+        return 0
+
+    def rih_prepare_labels(self, p2, p3, B, NV, NJ, A, R, flip, bone_length, root_joint, img_size, o2, o3, root_rel, stream):
+        NH = NV + NJ
+        NP = 2 * NH
+        P2, P3 = _f(p2, B * NP * 2).reshape(B, NP, 2), _f(p3, B * NP * 3).reshape(B, NP, 3)
+        O2, O3, RR = _f(o2, B * NP * 2).reshape(B, NP, 2), _f(o3, B * NP * 3).reshape(B, NP, 3), _f(root_rel, 3 * B).reshape(B, 3)
+        fl = np.ctypeslib.as_array((C.c_uint8 * int(B)).from_address(int(flip))) if flip else np.zeros(B, np.uint8)
+        for b in range(B):
+            q2, q3 = P2[b].copy(), P3[b].copy()
+            if A:
+                a = _f(A, 6 * B)[6 * b:6 * b + 6].reshape(2, 3)
+                q2 = (q2 @ a[:, :2].T + a[:, 2][None, :]).astype(np.float32)
+            if R:
+                q3 = (q3 @ _f(R, 9 * B)[9 * b:9 * b + 9].reshape(3, 3).T).astype(np.float32)
+            rl, rr = q3[NV + root_joint].copy(), q3[NH + NV + root_joint].copy()
+            rel = rr - rl
+            q3[:NH] -= rl
+            q3[NH:] -= rr
+            if bone_length > 0:
+                length = (np.linalg.norm(q3[NV + root_joint] - q3[NV]) + np.linalg.norm(q3[NH + NV + root_joint] - q3[NH + NV])) / 2
+                sc = np.float32(bone_length) / np.float32(length)
+                q3 = q3 * sc
+                rel = rel * sc
+            if fl[b]:
+                rel[1:] = -rel[1:]
+                q2[:, 0] = np.float32(img_size) - q2[:, 0]
+                q3[:, 0] = -q3[:, 0]
+                q2 = np.concatenate([q2[NH:], q2[:NH]])
+                q3 = np.concatenate([q3[NH:], q3[:NH]])
+            O2[b], O3[b], RR[b] = q2, q3, rel
+        return 0
+
     # ------------------------------------------------------------------ MANO layer (through oracle/mano_oracle.py)
     @staticmethod
     def _mano_consts(mref):
@@ -894,7 +953,7 @@ def emulated_abi():
 
     saved = (_lib._lib, ops._chk, ops._stream)
     _lib._lib = EmulatedLib()
-    ops._chk = lambda *a: None
+    ops._chk = lambda *a, **k: None
     ops._stream = lambda: 0
     try:
         yield

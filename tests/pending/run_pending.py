@@ -1,7 +1,7 @@
 """Runs ONE group of hardware checks for a code path that has not been on a GPU yet (see tests/test_gpu_pending.py, which
 starts this file in its own interpreter).  Exit code 0 = every check of the group passed on the GPU.
 
-    python tests/pending/run_pending.py half_kernels | half_backbone | fused_attention | presplit
+    python tests/pending/run_pending.py half_kernels | half_backbone | fused_attention | presplit | input_pipeline
 """
 import os
 import sys
@@ -66,9 +66,14 @@ def presplit(dev):
             G.test_conv2d(case)
 
 
+def input_pipeline(dev):
+    import test_input_pipeline
+    test_input_pipeline.prepare_vs_fixtures(dev)
+
+
 if __name__ == '__main__':
     assert torch.cuda.is_available(), 'needs a GPU'
     {'half_kernels': half_kernels, 'half_backbone': half_backbone, 'fused_attention': fused_attention,
-     'presplit': presplit}[sys.argv[1]](torch.device('cuda:0'))
+     'presplit': presplit, 'input_pipeline': input_pipeline}[sys.argv[1]](torch.device('cuda:0'))
     torch.cuda.synchronize()
     print('PENDING-OK', sys.argv[1])
