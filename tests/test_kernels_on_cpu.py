@@ -109,6 +109,22 @@ def test_fused_attention_forward(monkeypatch):
     assert {16, 32, 64} <= set(bcalls), bcalls      # the query-side backward kernel ran too (gradients checked above)
 
 
+def test_fused_attention_edge_shapes(monkeypatch):
+    """Tails of the fused attention kernels: one query row, one key, a key count of exactly 320 (the limit: ten MFMA tiles),
+    129 query rows (a second 128-row block with a single valid row), head dim 64 with few tokens."""
+    from renderih_amd import ops
+    monkeypatch.setattr(ops, 'FUSED_ATTN', True)
+    G.test_attention(1, 1, 1, 64, 4)
+    G.test_attention(1, 3, 320, 64, 4)
+    G.test_attention(2, 129, 33, 64, 4)
+    G.test_attention(1, 5, 7, 256, 4)
+    calls = []                                        # beyond the limit the three-launch path must take over
+    real = ops._L().rih_attention_fwd_fused
+    monkeypatch.setattr(ops._L(), 'rih_attention_fwd_fused', lambda *a: (calls.append(a), real(*a))[1], raising=False)
+    G.test_attention(1, 4, 321, 64, 4)
+    assert not calls
+
+
 @pytest.mark.parametrize('B', [1, 2])
 def test_mano_kernels(B):
     TMANO.test_mano_matches_oracle(B)
