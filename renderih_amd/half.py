@@ -211,9 +211,12 @@ class _Trunk:
         self.dims = [self.layers[3 - i][-1].c3.Cout for i in range(4)]            # channels of x1, x2, x3, x4
 
     def stem_pool(self, img):
-        if img.shape[2] % 32 or img.shape[3] % 32:
+        """img: the reference's [B,3,H,W] fp32 NCHW tensor, or the fp16 [B,H,W,8] tensor that
+        input_pipeline.BatchPreparer(fp16_nhwc8=True) writes (no fp32 image is then ever materialised)."""
+        x = img if (img.dtype == F16 and img.dim() == 4 and img.shape[-1] == 8) else image_to_nhwc8(img)
+        if x.shape[1] % 32 or x.shape[2] % 32:
             raise ValueError('fp16 backbone: image sides must be multiples of 32')
-        return maxpool3x3s2(self.stem(image_to_nhwc8(img), relu=True))
+        return maxpool3x3s2(self.stem(x, relu=True))
 
     def stages(self, x, slots=(None, None, None, None)):
         outs = [None] * 4

@@ -166,6 +166,11 @@ def backbone_vs_fp32(dev, B=1, size=256, tol=1e-2):
     for k in ('result.verts3d.left', 'result.verts3d.right'):
         if k in ref:
             assert testing.rel_err(got[k], ref[k]) < tol, (k, testing.rel_err(got[k], ref[k]))
+    # the fp16 NHWC8 image (what BatchPreparer(fp16_nhwc8=True) writes) is accepted in place of the fp32 NCHW one
+    with torch.no_grad():
+        a = hb(img)
+        b = hb(half.image_to_nhwc8(img))
+    assert all(torch.equal(x, y) for x, y in zip(a[:4], b[:4])) and all(torch.equal(x, y) for x, y in zip(a[4], b[4]))
     return worst
 
 
