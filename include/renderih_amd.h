@@ -385,6 +385,14 @@ int rih_prepare_labels(const float* p2, const float* p3, int B, int NV, int NJ, 
                        float* root_rel, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Interior distance field of closed triangle meshes (csrc/rih_sdf.hip) -- the reference's only native kernel,
+ * pose_data_optimize/sdf/sdf/csrc/sdf_cuda_kernel.cu:242-335 (`sdf_cuda`).  faces [F][3] int32 (shared by the batch),
+ * vertices [B][V][3] inside [-1,1]^3, phi [B][G][G][G] indexed [b][z][y][x]: distance from the voxel centre
+ * -1 + (i + 0.5) * 2/(G-1) to the closest triangle when the centre is inside the mesh (odd crossing count towards the
+ * corner (-1,-1,-1)), else 0.  No gradient (as in the reference). */
+int rih_sdf(float* phi, const int32_t* faces, const float* vertices, int B, int F, int V, int G, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * MANO parameter head of the reference's `load_new_model` network (common/myhand/decoder_lijun_mano.py:112-160,247-300)
  * nn.Hardswish and scale*tanh (the ParamRegressor MLP, `F.tanh(shape) * 3`): elementwise, n floats. */
 int rih_hardswish_fwd(const float* x, float* y, int64_t n, void* stream);

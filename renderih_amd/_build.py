@@ -9,7 +9,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'librenderih_amd.so')
-SOURCES = ['rih_gemm.hip', 'rih_elem.hip', 'rih_mano.hip', 'rih_loss.hip', 'rih_metrics.hip', 'rih_pose.hip', 'rih_attn.hip', 'rih_half.hip', 'rih_input.hip']
+SOURCES = ['rih_gemm.hip', 'rih_elem.hip', 'rih_mano.hip', 'rih_loss.hip', 'rih_metrics.hip', 'rih_pose.hip', 'rih_attn.hip', 'rih_half.hip', 'rih_input.hip', 'rih_sdf.hip']
 HEADERS = ['rih_procrustes.h', 'rih_pose_math.h']
 
 

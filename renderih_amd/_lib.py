@@ -52,6 +52,7 @@ class MeshTopo(C.Structure):
 
 # name -> (restype, argtypes); must list every symbol include/renderih_amd.h declares
 SIGNATURES = {
+    'rih_sdf': (c_i, [c_f, C.c_void_p, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
     'rih_prepare_images': (c_i, [C.c_void_p, c_i, c_i, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_f, c_f, C.c_void_p,
                                  C.c_void_p]),
     'rih_prepare_labels': (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, C.c_void_p, c_fl, c_i, c_fl, c_f, c_f, c_f, C.c_void_p]),

@@ -430,6 +430,14 @@ class EmulatedLib:
             O2[b], O3[b], RR[b] = q2, q3, rel
         return 0
 
+    # ------------------------------------------------------------------ SDF voxeliser (through oracle/sdf_oracle.py)
+    def rih_sdf(self, phi, faces, vertices, B, F, V, G, stream):
+        from oracle import sdf_oracle
+        fc = _i32(faces, 3 * F).reshape(F, 3)
+        vt = _f(vertices, B * V * 3).reshape(B, V, 3)
+        _f(phi, B * G * G * G)[:] = sdf_oracle.sdf(fc, vt, G).ravel()
+        return 0
+
     # ------------------------------------------------------------------ MANO layer (through oracle/mano_oracle.py)
     @staticmethod
     def _mano_consts(mref):

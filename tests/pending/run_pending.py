@@ -1,7 +1,7 @@
 """Runs ONE group of hardware checks for a code path that has not been on a GPU yet (see tests/test_gpu_pending.py, which
 starts this file in its own interpreter).  Exit code 0 = every check of the group passed on the GPU.
 
-    python tests/pending/run_pending.py half_kernels | half_backbone | fused_attention | presplit | input_pipeline
+    python tests/pending/run_pending.py half_kernels | half_backbone | fused_attention | presplit | input_pipeline | sdf
 """
 import os
 import sys
@@ -71,9 +71,14 @@ def input_pipeline(dev):
     test_input_pipeline.prepare_vs_fixtures(dev)
 
 
+def sdf(dev):
+    import test_sdf
+    test_sdf.sdf_vs_oracle(dev, G=16)
+
+
 if __name__ == '__main__':
     assert torch.cuda.is_available(), 'needs a GPU'
     {'half_kernels': half_kernels, 'half_backbone': half_backbone, 'fused_attention': fused_attention,
-     'presplit': presplit, 'input_pipeline': input_pipeline}[sys.argv[1]](torch.device('cuda:0'))
+     'presplit': presplit, 'input_pipeline': input_pipeline, 'sdf': sdf}[sys.argv[1]](torch.device('cuda:0'))
     torch.cuda.synchronize()
     print('PENDING-OK', sys.argv[1])

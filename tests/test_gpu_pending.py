@@ -1,7 +1,7 @@
 """First hardware contact of the code paths that were written AFTER this round's GPU budget was spent and are therefore
 OFF by default in the product: the fp16 inference backbone (csrc/rih_half.hip), the fused attention kernels
 (csrc/rih_attn.hip, RIH_FUSED_ATTN), the pre-split GEMM operands (RIH_PRESPLIT) and the batch input preparation
-(csrc/rih_input.hip).  They are verified on the HIP-on-CPU
+(csrc/rih_input.hip) and the SDF voxeliser (csrc/rih_sdf.hip).  They are verified on the HIP-on-CPU
 harness only.  Each group runs in its OWN interpreter with a time limit, so that a fault in an unproven kernel cannot take
 the proven suite down; a failing group is reported as xfail (with the tail of its output), a passing one as a pass.
 Once a group has passed on hardware it moves into the regular test files and its feature can be switched on."""
@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 
 
-@pytest.mark.parametrize('group', ['half_kernels', 'half_backbone', 'fused_attention', 'presplit', 'input_pipeline'])
+@pytest.mark.parametrize('group', ['half_kernels', 'half_backbone', 'fused_attention', 'presplit', 'input_pipeline', 'sdf'])
 def test_pending_on_hardware(group):
     cmd = [sys.executable, os.path.join(ROOT, 'tests', 'pending', 'run_pending.py'), group]
     try:
-        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420)
+        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
         out, code = p.stdout + p.stderr, p.returncode
     except subprocess.TimeoutExpired as e:
         out, code = 'TIMEOUT\n' + str(e.stdout or '')[-2000:], -1
