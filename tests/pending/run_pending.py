@@ -41,6 +41,15 @@ def half_backbone(dev):
         e = testing.rel_err(got[k], ref[k])
         print(k, 'fp16-vs-fp32 relative error', e)
         assert e < 3e-2, (k, e)
+    # replayed from a captured hipGraph: identical to the eager launch sequence
+    from renderih_amd.graph import GraphedInference
+    g = GraphedInference(m, img)
+    img2 = testing.seeded_image(2, 4).to(dev)
+    with torch.no_grad():
+        eager = testing.flatten_outputs(m(img2))
+    replay = testing.flatten_outputs(g(img2))
+    for k in ('result.verts3d.left', 'result.verts3d.right'):
+        assert torch.equal(replay[k], eager[k]), k
 
 
 def fused_attention(dev):
