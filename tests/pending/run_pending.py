@@ -1,7 +1,7 @@
 """Runs ONE group of hardware checks for a code path that has not been on a GPU yet (see tests/test_gpu_pending.py, which
 starts this file in its own interpreter).  Exit code 0 = every check of the group passed on the GPU.
 
-    python tests/pending/run_pending.py half_kernels | half_backbone | fused_attention | presplit | input_pipeline | sdf
+    python tests/pending/run_pending.py half_kernels | half_backbone | fused_attention | presplit | input_pipeline | sdf | graphed_inference
 """
 import os
 import sys
@@ -27,7 +27,7 @@ def half_backbone(dev):
     worst = test_half.backbone_vs_fp32(dev, B=2)
     print('fp16 backbone vs fp32 backbone, max relative error per tensor:', worst)
     print('second family:', test_half.backbone_b_vs_fp32(dev, B=2))
-    # the full ResNet50 model: finite outputs, close to the fp32 path, and capturable
+    # the full ResNet50 model: finite outputs, close to the fp32 path
     from renderih_amd.model import build_model
     from renderih_amd import testing
     m = build_model(0.0).to(dev).eval()
@@ -41,9 +41,15 @@ def half_backbone(dev):
         e = testing.rel_err(got[k], ref[k])
         print(k, 'fp16-vs-fp32 relative error', e)
         assert e < 3e-2, (k, e)
-    # replayed from a captured hipGraph: identical to the eager launch sequence
+
+
+def graphed_inference(dev):
+    """GraphedInference (fp32 path): a replay equals the eager launch sequence bit for bit."""
+    from renderih_amd.model import build_model
+    from renderih_amd import testing
     from renderih_amd.graph import GraphedInference
-    g = GraphedInference(m, img)
+    m = build_model(0.0).to(dev).eval()
+    g = GraphedInference(m, testing.seeded_image(2, 3).to(dev))
     img2 = testing.seeded_image(2, 4).to(dev)
     with torch.no_grad():
         eager = testing.flatten_outputs(m(img2))
@@ -88,6 +94,6 @@ def sdf(dev):
 if __name__ == '__main__':
     assert torch.cuda.is_available(), 'needs a GPU'
     {'half_kernels': half_kernels, 'half_backbone': half_backbone, 'fused_attention': fused_attention,
-     'presplit': presplit, 'input_pipeline': input_pipeline, 'sdf': sdf}[sys.argv[1]](torch.device('cuda:0'))
+     'presplit': presplit, 'input_pipeline': input_pipeline, 'sdf': sdf, 'graphed_inference': graphed_inference}[sys.argv[1]](torch.device('cuda:0'))
     torch.cuda.synchronize()
     print('PENDING-OK', sys.argv[1])
