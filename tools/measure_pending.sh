@@ -17,6 +17,7 @@ run bench_fusedattn env RIH_FUSED_ATTN=1 python bench.py --steps 10 --warmup 3
 run infer_f32       python tools/infer_bench.py --iters 10
 run infer_f16       python tools/infer_bench.py --iters 10 --fp16
 run infer_f16_b64   python tools/infer_bench.py --iters 10 --fp16 --batch 64
+run hconv_layers    python tools/hconv_bench.py --iters 10
 T=900 run prof_infer_f16 rocprofv3 --kernel-trace --stats -d "$OUT/prof_infer_f16" -- python tools/infer_bench.py --iters 5 --fp16
 find "$OUT/prof_infer_f16" -name '*kernel_stats*.csv' -exec cp {} "$OUT/infer_f16_kernel_stats.csv" \; 2>/dev/null
 echo done
