@@ -52,6 +52,38 @@ def test_ops_refuse_cpu_tensors():
         ops.linear(torch.zeros(2, 4), torch.zeros(3, 4))
 
 
+def test_hconv_desc_layout_matches_c():
+    """ctypes mirror of rih_hconv_desc against the C compiler's layout."""
+    from renderih_amd._lib import HConvDesc
+    import ctypes
+    import tempfile
+    fields = ['x', 'bias', 'res', 'y', 'N', 'Wo', 'ldx', 'Kpad', 'relu', 'out_f32']
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "renderih_amd.h"\nint main(){printf("%zu' + ' %zu' * len(fields) + \
+          '\\n",sizeof(rih_hconv_desc),' + ','.join('offsetof(rih_hconv_desc,%s)' % f for f in fields) + ');return 0;}'
+    d = tempfile.mkdtemp()
+    open(os.path.join(d, 'a.c'), 'w').write(src)
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), os.path.join(d, 'a.c'), '-o', os.path.join(d, 'a')])
+    got = [int(x) for x in subprocess.check_output([os.path.join(d, 'a')]).split()]
+    assert got == [ctypes.sizeof(HConvDesc)] + [getattr(HConvDesc, f).offset for f in fields]
+
+
+def test_new_host_modules_refuse_cpu_tensors():
+    """fp16 backbone, batch preparation, SDF, graphed inference: no CPU path either."""
+    import torch.nn as nn
+    from renderih_amd import half, input_pipeline, sdf, graph
+    with pytest.raises(RuntimeError):
+        half.PackedConv(nn.Conv2d(8, 8, 1))
+    with pytest.raises(RuntimeError):
+        half.maxpool3x3s2(torch.zeros(1, 4, 4, 8, dtype=torch.float16))
+    with pytest.raises(RuntimeError):
+        input_pipeline.BatchPreparer(train=False)(torch.zeros(1, 8, 8, 3, dtype=torch.uint8), torch.zeros(1, 1598, 2),
+                                                  torch.zeros(1, 1598, 3))
+    with pytest.raises(RuntimeError):
+        sdf.sdf(torch.zeros(4, 3, dtype=torch.int32), torch.zeros(1, 4, 3))
+    with pytest.raises(RuntimeError):
+        graph.GraphedInference(lambda t: t, torch.zeros(2))
+
+
 def test_state_dict_schema_equals_reference():
     from renderih_amd.model import build_model
     ref = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'state_keys.json')))
