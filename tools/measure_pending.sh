@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call that gives every path written after round 1's GPU budget was spent its first hardware numbers:
-#   gpurun --timeout 2400 -- 'bash tools/measure_pending.sh'
+#   gpurun --timeout 1800 -- 'bash tools/measure_pending.sh'      (about 20 GPU-minutes)
 # Writes gpurun_out/pending/*.log|json (copy what is to be judged into profiles/rNN/).  Every step has its own timeout; a
 # failing step does not stop the following ones.
 cd "$(dirname "$0")/.." || exit 1
@@ -9,11 +9,11 @@ OUT=gpurun_out/pending
 mkdir -p "$OUT"
 run() { name=$1; shift; echo "== $name: $*"; ( timeout "${T:-600}" "$@" ) > "$OUT/$name.log" 2>&1; echo "   exit $?"; tail -n 3 "$OUT/$name.log"; }
 
-T=1500 run pytest_pending python -m pytest tests/test_gpu_pending.py -q -m gpu -rxXs
-run bench_default   python bench.py --steps 10 --warmup 3
-run bench_presplit1 env RIH_PRESPLIT=1 python bench.py --steps 10 --warmup 3
-run bench_presplit2 env RIH_PRESPLIT=2 python bench.py --steps 10 --warmup 3
-run bench_fusedattn env RIH_FUSED_ATTN=1 python bench.py --steps 10 --warmup 3
+T=1200 run pytest_pending python -m pytest tests/test_gpu_pending.py -q -m gpu -rxXs
+run bench_default   python bench.py --steps 10 --warmup 3 --no-cpu-baseline
+run bench_presplit1 env RIH_PRESPLIT=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
+run bench_presplit2 env RIH_PRESPLIT=2 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
+run bench_fusedattn env RIH_FUSED_ATTN=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
 run infer_f32       python tools/infer_bench.py --iters 10
 run infer_f16       python tools/infer_bench.py --iters 10 --fp16
 run infer_f16_b64   python tools/infer_bench.py --iters 10 --fp16 --batch 64
