@@ -120,3 +120,57 @@ def test_metrics_kernel_matches_oracle_and_reference_golden():
     got = hand_metrics(vp.cuda(), vg.cuda(), Jreg.cuda())
     for k in ('j_err', 'v_err', 'pa_mpjpe', 'pa_mpvpe'):
         assert_close(got[k], want[k], 1e-4, 1e-5, 'B64 ' + k)
+
+
+def test_evaluate_loop_matches_reference_lines():
+    """renderih_amd.evaluate.evaluate against the arithmetic of apps/eval_interhand.py:298-420 restated in torch (root joint 0,
+    bone (1, 0), torch.svd Procrustes), on a stand-in network with fixed predictions; host logic through the ABI emulator."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from abi_emulator import emulated_abi
+    from renderih_amd import assets
+    from renderih_amd.evaluate import evaluate
+    from renderih_amd.metrics import joint_regressor_21
+    from oracle import metrics_oracle
+    g = torch.Generator().manual_seed(4)
+    jr = {s: joint_regressor_21(torch.from_numpy(np.asarray(assets.synthetic_mano_dict(s)['J_regressor'].todense()
+                                                               if hasattr(assets.synthetic_mano_dict(s)['J_regressor'], 'todense')
+                                                               else assets.synthetic_mano_dict(s)['J_regressor'])).float())
+          for s in ('left', 'right')}
+    batches, preds = [], []
+    for b in range(2):
+        vg = {s: torch.randn(3, 778, 3, generator=g) * 0.05 + (0.1 if s == 'left' else -0.1) for s in ('left', 'right')}
+        vp = {s: vg[s] * 1.1 + 0.01 * torch.randn(3, 778, 3, generator=g) for s in vg}
+        batches.append((torch.zeros(3, 3, 8, 8), None, vg['left'], None, vg['right']))
+        preds.append(vp)
+    it = iter(preds)
+    network = lambda img: ({'verts3d': next(it)}, None, None, None)
+    with emulated_abi():
+        summary, per = evaluate(network, [(b[0], torch.zeros(1), b[2], torch.zeros(1), b[4]) for b in batches], jr['left'], jr['right'])
+    # reference arithmetic
+    want = {k: {'left': [], 'right': []} for k in ('ori', 'scaled', 'pa')}
+    ptr, gtr = [], []
+    for bt, vp in zip(batches, preds):
+        roots = {}
+        for s, vg in (('left', bt[2]), ('right', bt[4])):
+            J = lambda v: torch.einsum('jv,bvc->bjc', jr[s], v)
+            jg, jp = J(vg), J(vp[s])
+            roots[s] = (jp[:, 0], jg[:, 0])
+            lg = torch.linalg.norm(jg[:, 1] - jg[:, 0], dim=-1)
+            lp = torch.linalg.norm(jp[:, 1] - jp[:, 0], dim=-1)
+            jg0, jp0 = jg - jg[:, 0:1], jp - jp[:, 0:1]
+            want['ori'][s].append(torch.linalg.norm(jp0 - jg0, dim=-1).numpy())
+            want['scaled'][s].append(torch.linalg.norm(jp0 * (lg / lp)[:, None, None] - jg0, dim=-1).numpy())
+            hat = metrics_oracle.similarity_transform(jp0, jg0)
+            want['pa'][s].append(torch.sqrt(((hat - jg0) ** 2).sum(-1)).mean(-1).numpy())
+        ptr.append((roots['left'][0] - roots['right'][0]).numpy())
+        gtr.append((roots['left'][1] - roots['right'][1]).numpy())
+    for s in ('left', 'right'):
+        for key, name in (('ori', 'j_err_ori'), ('scaled', 'j_err'), ('pa', 'pa_mpjpe')):
+            w = np.concatenate(want[key][s], 0)
+            assert np.abs(per[name][s] - w).max() < 2e-6 + 1e-4 * np.abs(w).max(), (s, key)
+    assert abs(summary['ori joint mpjpe']['all'] - 500 * (np.concatenate(want['ori']['left']).mean() +
+                                                           np.concatenate(want['ori']['right']).mean())) < 1e-3
+    mrrpe = np.sqrt(((np.concatenate(ptr) - np.concatenate(gtr)) ** 2).sum(1)).mean()
+    assert abs(summary['mrrpe'] - mrrpe) < 1e-6
