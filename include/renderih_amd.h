@@ -324,6 +324,11 @@ int rih_attention_fwd_fused(const float* q, int q_ld, const float* k, const floa
 int rih_attention_bwd_dq_fused(const float* dO, int do_ld, const float* k, const float* v, int kv_ld, int B, int heads,
                                int Sq, int Sk, int d, float alpha, float drop_p, uint64_t seed, const uint64_t* seed_dev,
                                const float* P, float* dS, int ldP, float* dq, int dq_ld, void* stream);
+/* Key side of the attention backward in ONE launch (replaces two transposed batched GEMMs): dv = Pd^T dO and
+ * dk = dS^T q, written to [B][Sk][dkv_ld] at column h*d.  Pd / dS [B][heads][Sq][ldP] (dS from the kernel above). */
+int rih_attention_bwd_dkv_fused(const float* dO, int do_ld, const float* q, int q_ld, int B, int heads, int Sq, int Sk,
+                                int d, const float* Pd, const float* dS, int ldP, float* dk, float* dv, int dkv_ld,
+                                void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * fp16-storage inference backbone (BASELINE configs[4]; csrc/rih_half.hip).  Eval-mode only: every BatchNorm of

@@ -10,7 +10,8 @@
 // (<= 4 MFLOP per workgroup), the kernel is latency / traffic bound.
 //
 // The query side of the backward (dO V^T -> softmax backward -> dS K) has the same shape and is the second kernel of
-// this file; the key-side products reduce over query rows (across workgroups) and stay batched GEMMs.
+// this file; the key-side products (dV = Pd^T dO, dK = dS^T Q) reduce over query rows, i.e. across those workgroups, and
+// are a third kernel blocked over keys: 2 launches for the backward instead of 5.
 //
 // STATUS: written after the round's GPU budget was spent; verified on the HIP-on-CPU harness
 // (tests/test_kernels_on_cpu.py::test_fused_attention_forward) against the unfused path and torch (outputs, gradients,
@@ -334,6 +335,73 @@ __global__ __launch_bounds__(TPB) void attn_bwd_dq_fused_kernel(const float* __r
     }
 }
 
+// Backward, key side: dV = Pd^T dO and dK = dS^T Q for a block of 128 keys of one (image, head) -- the two products that
+// reduce over the query rows.  A wavefront owns 32 keys; the A operands are read straight from the [Sq][ldP] matrices
+// (lane = key: 128-byte coalesced rows, 16 query rows per lane batched ahead of the MFMAs), the B operands (dO and Q rows)
+// are staged in LDS in blocks of 32 query rows and shared by the four wavefronts.
+template <int DH>
+__global__ __launch_bounds__(TPB) void attn_bwd_dkv_fused_kernel(const float* __restrict__ dO, int do_ld,
+                                                                 const float* __restrict__ q, int q_ld, int heads, int Sq, int Sk,
+                                                                 const float* __restrict__ Pd, const float* __restrict__ dS,
+                                                                 int ldP, float* __restrict__ dk, float* __restrict__ dv,
+                                                                 int dkv_ld) {
+    constexpr int CT = (DH + 31) / 32;
+    __shared__ float Os[32][DH + 1];
+    __shared__ float Qs[32][DH + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    const int key = blockIdx.x * 128 + wave * 32 + l31;                 // this lane's A-operand row
+    const float* dob = dO + (long long)b * Sq * do_ld + h * DH;
+    const float* qb = q + (long long)b * Sq * q_ld + h * DH;
+    const float* pdb = Pd + (long long)bh * Sq * ldP;
+    const float* dsb = dS + (long long)bh * Sq * ldP;
+    floatx16 av[CT], ak[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { av[ct][r] = 0.f; ak[ct][r] = 0.f; }
+    for (int q0 = 0; q0 < Sq; q0 += 32) {
+        __syncthreads();
+        for (int i = tid; i < 32 * DH; i += TPB) {
+            const int qr = i / DH, c = i - qr * DH, qq = q0 + qr;
+            Os[qr][c] = (qq < Sq) ? dob[(long long)qq * do_ld + c] : 0.f;
+            Qs[qr][c] = (qq < Sq) ? qb[(long long)qq * q_ld + c] : 0.f;
+        }
+        float pa[16], sa[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int qq = q0 + 2 * t + lhi;
+            const bool ok = qq < Sq && key < Sk;
+            pa[t] = ok ? pdb[(long long)qq * ldP + key] : 0.f;
+            sa[t] = ok ? dsb[(long long)qq * ldP + key] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int c = l31 + 32 * ct;
+                const float bo = (c < DH) ? Os[2 * t + lhi][c] : 0.f;
+                const float bq = (c < DH) ? Qs[2 * t + lhi][c] : 0.f;
+                av[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[t], bo, av[ct], 0, 0, 0);
+                ak[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[t], bq, ak[ct], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = l31 + 32 * ct;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kr = blockIdx.x * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (kr < Sk && c < DH) {
+                const long long at = ((long long)b * Sk + kr) * dkv_ld + h * DH + c;
+                dv[at] = av[ct][r];
+                dk[at] = ak[ct][r];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int rih_attention_fwd_fused(const float* q, int q_ld, const float* k, const float* v, int kv_ld, int B, int heads,
@@ -378,6 +446,24 @@ extern "C" int rih_attention_bwd_dq_fused(const float* dO, int do_ld, const floa
     else if (d == 64)
         hipLaunchKernelGGL((attn_bwd_dq_fused_kernel<64>), grid, block, 0, s, dO, do_ld, k, v, kv_ld, heads, Sq, Sk, alpha,
                            drop_p, seed, seed_dev, P, dS, ldP, dq, dq_ld);
+    else
+        return RIH_EINVAL;
+    return (int)hipGetLastError();
+}
+
+extern "C" int rih_attention_bwd_dkv_fused(const float* dO, int do_ld, const float* q, int q_ld, int B, int heads, int Sq,
+                                           int Sk, int d, const float* Pd, const float* dS, int ldP, float* dk, float* dv,
+                                           int dkv_ld, void* stream) {
+    if (!dO || !q || !Pd || !dS || !dk || !dv || B < 1 || heads < 1 || Sq < 1 || Sk < 1) return RIH_EINVAL;
+    if (ldP < Sk || do_ld < heads * d || q_ld < d || dkv_ld < d || (long long)B * heads > 65535) return RIH_EINVAL;
+    const dim3 grid((Sk + 127) / 128, B * heads), block(TPB);
+    hipStream_t s = (hipStream_t)stream;
+    if (d == 16)
+        hipLaunchKernelGGL((attn_bwd_dkv_fused_kernel<16>), grid, block, 0, s, dO, do_ld, q, q_ld, heads, Sq, Sk, Pd, dS, ldP, dk, dv, dkv_ld);
+    else if (d == 32)
+        hipLaunchKernelGGL((attn_bwd_dkv_fused_kernel<32>), grid, block, 0, s, dO, do_ld, q, q_ld, heads, Sq, Sk, Pd, dS, ldP, dk, dv, dkv_ld);
+    else if (d == 64)
+        hipLaunchKernelGGL((attn_bwd_dkv_fused_kernel<64>), grid, block, 0, s, dO, do_ld, q, q_ld, heads, Sq, Sk, Pd, dS, ldP, dk, dv, dkv_ld);
     else
         return RIH_EINVAL;
     return (int)hipGetLastError();

@@ -951,6 +951,10 @@ def _attn_backward(do, q, q_ld, k, v, kv_ld, dq, dq_ld, dk, dv, dkv_ld, P, Pd, B
         check(_L().rih_attention_bwd_dq_fused(do.data_ptr(), D, ptr(k), ptr(v), kv_ld, B, heads, Sq, Sk, d, alpha, drop_p,
                                               seed, _seed_dev(), P.data_ptr(), dS.data_ptr(), ldP, ptr(dq), dq_ld,
                                               _stream()), 'rih_attention_bwd_dq_fused')
+        check(_L().rih_attention_bwd_dkv_fused(do.data_ptr(), D, ptr(q), q_ld, B, heads, Sq, Sk, d, Pd.data_ptr(),
+                                               dS.data_ptr(), ldP, ptr(dk), ptr(dv), dkv_ld, _stream()),
+              'rih_attention_bwd_dkv_fused')
+        return
     else:
         dS = torch.empty_like(P)
         gemm(do, v, dS, Sq, Sk, d, D, kv_ld, ldP, a_mode=0, b_mode=1, nb1=B, nb2=heads, sA=(Sq * D, d),

@@ -292,6 +292,22 @@ class EmulatedLib:
                 dQ[qi.ravel()] = (ds @ Kk[ki]).astype(np.float32).ravel()
         return 0
 
+    def rih_attention_bwd_dkv_fused(self, dO, do_ld, q, q_ld, B, heads, Sq, Sk, d, Pd, dS, ldP, dk, dv, dkv_ld, stream):
+        G = _f(dO, (B * Sq - 1) * do_ld + heads * d)
+        Q = _f(q, (B * Sq - 1) * q_ld + heads * d)
+        Pm, Sm = _f(Pd, B * heads * Sq * ldP), _f(dS, B * heads * Sq * ldP)
+        DK, DV = _f(dk, (B * Sk - 1) * dkv_ld + heads * d), _f(dv, (B * Sk - 1) * dkv_ld + heads * d)
+        cols = np.arange(d)
+        for b in range(B):
+            for h in range(heads):
+                gi = ((b * Sq + np.arange(Sq))[:, None] * do_ld + h * d + cols[None, :])
+                qi = ((b * Sq + np.arange(Sq))[:, None] * q_ld + h * d + cols[None, :])
+                pidx = ((b * heads + h) * Sq + np.arange(Sq))[:, None] * ldP + np.arange(Sk)[None, :]
+                oi = ((b * Sk + np.arange(Sk))[:, None] * dkv_ld + h * d + cols[None, :])
+                DV[oi.ravel()] = (Pm[pidx].T @ G[gi]).astype(np.float32).ravel()
+                DK[oi.ravel()] = (Sm[pidx].T @ Q[qi]).astype(np.float32).ravel()
+        return 0
+
     # ------------------------------------------------------------------ fp16 inference backbone (csrc/rih_half.hip)
     @staticmethod
     def _h(ptr, n):

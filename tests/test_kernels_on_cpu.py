@@ -99,6 +99,10 @@ def test_fused_attention_forward(monkeypatch):
     breal = ops._L().rih_attention_bwd_dq_fused
     monkeypatch.setattr(ops._L(), 'rih_attention_bwd_dq_fused', lambda *a: (bcalls.append(a[9]), breal(*a))[1],
                         raising=False)
+    kcalls = []
+    kreal = ops._L().rih_attention_bwd_dkv_fused
+    monkeypatch.setattr(ops._L(), 'rih_attention_bwd_dkv_fused', lambda *a: (kcalls.append(a[8]), kreal(*a))[1],
+                        raising=False)
     G.test_attention(2, 63, 63, 64, 4)              # d = 16
     G.test_attention(1, 150, 190, 128, 4)           # d = 32, two query blocks, Sk not a multiple of 32
     G.test_attention(1, 127, 127, 256, 4)           # d = 64
@@ -107,6 +111,7 @@ def test_fused_attention_forward(monkeypatch):
     G.test_cross_attention_packed(1, 63, 128, 4)
     assert {16, 32, 64} <= set(calls), calls
     assert {16, 32, 64} <= set(bcalls), bcalls      # the query-side backward kernel ran too (gradients checked above)
+    assert {16, 32, 64} <= set(kcalls), kcalls      # ... and the key-side one
 
 
 def test_fused_attention_edge_shapes(monkeypatch):
