@@ -23,11 +23,11 @@ from . import ops
 from .attn import DropCtx, MLP_res_block, SelfAttn, _drop_add, _lin_drop_res, _lin_pair, _xavier, img_ex
 from . import pose_head
 from .decoder import IMG_SIZE, decoder as _DecoderA
-from .encoder import ResNetTrunk, bn_act, conv, conv1x1, flush_batches_tracked
+from .encoder import FoldableTrunk, ResNetTrunk, bn_act, conv, conv1x1, flush_batches_tracked
 
 
 # ------------------------------------------------------------------------------------------------ encoder / mid
-class ResNetSimple(nn.Module):
+class ResNetSimple(FoldableTrunk, nn.Module):
     """encoder_lijun.py:62-104: the torchvision ResNet trunk; forward returns [x1, x2, x3, x4] (coarsest first)."""
 
     def __init__(self, model_type='resnet50', pretrained=False, fmapDim=(256, 256, 256, 256), handNum=2, heatmapDim=21):
@@ -41,7 +41,7 @@ class ResNetSimple(nn.Module):
 
     def forward(self, img):
         """img: [B,3,256,256] NCHW fp32.  The maps come back NHWC (internal layout of this package)."""
-        x4, x3, x2, x1 = self.resnet(ops.nchw_to_nhwc(img, cpad=4))
+        x4, x3, x2, x1 = self._trunk(ops.nchw_to_nhwc(img, cpad=4))
         flush_batches_tracked()
         return [x1, x2, x3, x4]
 

@@ -398,6 +398,37 @@ def conv2d_skip(x, w, bias=None, stride=1, pad=0, relu=False):
     return Conv2dFn.apply(x, w, bias, stride, pad, relu, True)
 
 
+def pack_folded_conv(w, scale, cin_pad):
+    """Inference: OIHW conv weight times a per-output-channel scale (an eval BatchNorm folded in), packed once as the
+    [KH*KW*cin_pad, Cout] B operand of the forward implicit GEMM."""
+    _chk(w, scale)
+    Cout, Cin, KH, KW = w.shape
+    ws = _c(w.detach() * scale.view(-1, 1, 1, 1))
+    wp = torch.empty((KH * KW * cin_pad, Cout), device=w.device, dtype=torch.float32)
+    check(_L().rih_pack_conv_weight(ws.data_ptr(), wp.data_ptr(), Cout, Cin, KH, KW, cin_pad, 0, _stream()),
+          'rih_pack_conv_weight')
+    return wp
+
+
+def conv2d_packed(x, wp, KH, KW, bias=None, stride=1, pad=0, relu=False, residual=None):
+    """Inference-only convolution on a weight packed by `pack_folded_conv`: y = act(conv(x) + bias + residual) in one GEMM
+    launch (no autograd graph).  x [N,H,W,Cx] with Cx = the packing's cin_pad."""
+    _chk(x, wp, bias, residual)
+    x = _c(x)
+    N, H, W_, Cx = x.shape
+    K, Cout = wp.shape
+    assert K == KH * KW * Cx, (K, KH, KW, Cx)
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W_ + 2 * pad - KW) // stride + 1
+    y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    if residual is not None:
+        residual = _c(residual)
+        assert residual.shape == y.shape
+    gemm(x, wp, y, N * Ho * Wo, Cout, K, Cx, Cout, Cout, a_mode=0, b_mode=0, bias=bias, R=residual, ldr=Cout, relu=relu,
+         geom=(H, W_, Cx, Ho, Wo, KH, KW, stride, 1, pad, pad))
+    return y
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x @ w^T + bias + residual) for x [..., K], w [N, K] (the nn.Linear parameter, read in place)."""
 

@@ -15,6 +15,7 @@ run bench_presplit1 env RIH_PRESPLIT=1 python bench.py --steps 10 --warmup 3 --n
 run bench_presplit2 env RIH_PRESPLIT=2 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
 run bench_fusedattn env RIH_FUSED_ATTN=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
 run infer_f32       python tools/infer_bench.py --iters 10
+run infer_f32_fold  env RIH_FOLD_BN=1 python tools/infer_bench.py --iters 10
 run infer_f16       python tools/infer_bench.py --iters 10 --fp16
 run infer_f16_b64   python tools/infer_bench.py --iters 10 --fp16 --batch 64
 run hconv_layers    python tools/hconv_bench.py --iters 10
