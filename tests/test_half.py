@@ -140,7 +140,7 @@ def tiny_model(seed=0):
     return m.eval()
 
 
-def backbone_vs_fp32(dev, B=1, size=256, tol=1e-2):
+def backbone_vs_fp32(dev, B=1, size=256, tol=1e-2, through_decoder=True):
     """HalfBackbone against the fp32 encoder + mid model of the same weights: every tensor handed to the decoder."""
     from renderih_amd import testing
     m = tiny_model().to(dev)
@@ -157,6 +157,8 @@ def backbone_vs_fp32(dev, B=1, size=256, tol=1e-2):
         assert a.shape == b.shape and b.dtype == torch.float32, (name, a.shape, b.shape, b.dtype)
         worst[name] = testing.rel_err(b, a)
         assert worst[name] < tol, (name, worst)
+    if not through_decoder:
+        return worst
     # and end to end through the fp32 mesh decoder
     with torch.no_grad():
         ref = testing.flatten_outputs(m(img))
@@ -178,6 +180,15 @@ def test_half_backbone_host_logic():
     from abi_emulator import emulated_abi
     with emulated_abi():
         backbone_vs_fp32(torch.device('cpu'))
+
+
+@pytest.mark.skipif(os.environ.get('HIPCPU_MORE', '0') != '1', reason='3.5 min on the fiber harness: run with HIPCPU_MORE=1')
+def test_half_backbone_kernels_on_cpu():
+    """The whole folded backbone (75 launches: stem, pool, bottlenecks with in-place concat slices, aux decoders, mid convs,
+    average pool) through the REAL kernels on the harness, 32 x 32 input, against the fp32 modules."""
+    from hipcpu.host_kernels import host_kernels_abi
+    with host_kernels_abi():
+        backbone_vs_fp32(torch.device('cpu'), size=32, through_decoder=False)
 
 
 def test_half_backbone_requires_eval():
