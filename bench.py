@@ -321,7 +321,7 @@ def main():
                            else ('BASELINE configs[3] model: batch=%d/GPU 256x256 HRNet-W32 + cross-hand attention decoder, '
                                  'fwd + loss + bwd + Adam step, dropout 0.05, fp32' % B),
                            'global_batch': B * world, 'parallelism': 'dp%d' % world, 'loss': round(final_loss, 4),
-                           'hipgraph': bool(use_graph), 'presplit_weights': bool(ops.PRESPLIT),
+                           'hipgraph': bool(use_graph), 'presplit_weights': bool(ops.PRESPLIT), 'presplit_activations': bool(ops.PRESPLIT_ACT), 'fused_attention': bool(ops.FUSED_ATTN),
                            'gemm_engine': ('fp32 via 3-term bf16 split, 6 MFMA products, fp32 accumulate (fp32-grade error)'
                                            if ops.ENGINE == 1 else 'native f32 MFMA')},
                 'roofline': roof, 'cpu_baseline': cpu}
