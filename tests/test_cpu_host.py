@@ -164,3 +164,24 @@ def test_mano_helpers_cpu_roundtrip(tmp_path):
     fr = layer.get_local_frame(torch.zeros(2, 10))
     assert fr.shape == (2, 15, 3, 3)
     assert torch.allclose(rodrigues_batch(torch.zeros(1, 3)), torch.eye(3).unsqueeze(0), atol=1e-6)
+
+
+def test_checkpoint_conventions_round_trip(tmp_path):
+    """bare / {'epoch','network'} / 'module.'-prefixed files all load (core/gcn_trainer.py:90-100, 303-311)."""
+    import torch.nn as nn
+    from renderih_amd.checkpoint import load_checkpoint, save_checkpoint
+    src = nn.Sequential(nn.Linear(4, 3), nn.BatchNorm1d(3))
+    with torch.no_grad():
+        src[0].weight.fill_(0.25)
+    p1, p2, p3 = (str(tmp_path / n) for n in ('a.pth', 'b.pth', 'c.pth'))
+    save_checkpoint(src, p1, 7)
+    torch.save(src.state_dict(), p2)
+    torch.save({'epoch': 3, 'network': {'module.' + k: v for k, v in src.state_dict().items()}}, p3)
+    for path, epoch in ((p1, 7), (p2, None), (p3, 3)):
+        dst = nn.Sequential(nn.Linear(4, 3), nn.BatchNorm1d(3))
+        assert load_checkpoint(dst, path) == epoch
+        assert torch.equal(dst[0].weight, src[0].weight)
+    wrapped = nn.Module()
+    wrapped.module = src
+    save_checkpoint(wrapped, p1, 1)
+    assert set(torch.load(p1)['network']) == set(src.state_dict())
