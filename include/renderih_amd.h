@@ -369,6 +369,13 @@ int rih_hmaxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int ld
 int rih_hupsample2x(const void* x, void* y, int N, int H, int W, int C, int ldx, int ldy, void* stream);
 int rih_havgpool(const void* x, float* y, int N, int HW, int C, int ldx, void* stream);
 
+/* Contact deviation (apps/eval_interhand.py:481-490, utils/eval_metrics.py:30-50 `compute_cdev`): per sample, the mean over
+ * the ground-truth right-hand vertices whose nearest ground-truth left-hand vertex is within `contact` (3e-3 m) of
+ * |pred_left[nearest] - pred_right[v]|; NaN when there is no such vertex (the reference's nanmean then skips the sample).
+ * All meshes [B][V][3], V <= 1024; out [B]. */
+int rih_cdev(const float* pred_left, const float* pred_right, const float* gt_left, const float* gt_right, int B, int V,
+             float contact, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Input preparation of a batch resident on the GPU (csrc/rih_input.hip) -- core/loader.py:104-219
  * `handDataset.process_data` and utils/manoutils.py:214-260 (`imgUtils.data_augmentation`, `add_noise`).

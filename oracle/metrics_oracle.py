@@ -43,3 +43,21 @@ def hand_metrics(v_pred, v_gt, Jreg=None, j_pred=None, j_gt=None, root_idx=0, bo
     out['pa_mpjpe'] = torch.sqrt(((similarity_transform(jp, jg) - jg) ** 2).sum(-1)).mean(-1)
     out['pa_mpvpe'] = torch.sqrt(((similarity_transform(vp, vg) - vg) ** 2).sum(-1)).mean(-1)
     return out
+
+
+def compute_cdev(pred_v3d_o, pred_v3d_r, gt_left, gt_right, contact_dist=3e-3):
+    """utils/eval_metrics.py:30-50 (`compute_idx` + `compute_cdev`) with pytorch3d's `knn_points(K=1)` -- a third-party
+    dependency that is absent here -- restated as the exhaustive nearest neighbour (squared distances, first minimum):
+    everything else follows the reference line by line.  tests/test_metrics.py additionally runs the reference's own
+    `compute_cdev` with a stub `pytorch3d.ops.knn_points` of that definition."""
+    d2 = ((gt_right[:, :, None, :] - gt_left[:, None, :, :]) ** 2).sum(-1)
+    dist_ro, idx_ro = d2.min(dim=2)
+    dist_ro = dist_ro.sqrt()
+    vo = torch.gather(pred_v3d_o, 1, idx_ro[:, :, None].repeat(1, 1, 3))
+    disp = vo - pred_v3d_r
+    disp[dist_ro > contact_dist] = float('nan')
+    cd = (disp ** 2).sum(dim=2).sqrt()
+    nan = torch.isnan(cd)
+    cd = cd.clone()
+    cd[nan] = 0
+    return cd.sum(1) / (~nan).float().sum(1)

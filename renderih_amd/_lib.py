@@ -52,6 +52,7 @@ class MeshTopo(C.Structure):
 
 # name -> (restype, argtypes); must list every symbol include/renderih_amd.h declares
 SIGNATURES = {
+    'rih_cdev': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_f, C.c_void_p]),
     'rih_attention_bwd_dkv_fused': (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_f, c_i,
                                           C.c_void_p]),
     'rih_sdf': (c_i, [c_f, C.c_void_p, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),

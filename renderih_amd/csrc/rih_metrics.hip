@@ -180,3 +180,62 @@ extern "C" int rih_hand_metrics(const float* v_pred, const float* v_gt, const fl
                        NJ, root_idx, bone_a, bone_b, j_err_ori, v_err_ori, j_err, v_err, pa, j_pred_out);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Contact deviation of apps/eval_interhand.py:481-490 (utils/eval_metrics.py:30-50 `compute_idx` / `compute_cdev`): every
+// ground-truth right-hand vertex finds its nearest ground-truth left-hand vertex (pytorch3d knn_points, K = 1); where that
+// distance is within `contact` (3 mm) the predicted meshes should keep the pair together: out[b] = mean over those
+// vertices of |pred_left[nearest] - pred_right[v]|, NaN when the hands do not touch.  One workgroup per sample; the left
+// hand's vertices are staged in LDS (V x 12 bytes) and every lane scans them as broadcasts for its right-hand vertices.
+namespace {
+constexpr int CDEV_TPB = 256;
+constexpr int CDEV_MAXV = 1024;
+
+__global__ __launch_bounds__(CDEV_TPB) void cdev_kernel(const float* __restrict__ pred_l, const float* __restrict__ pred_r,
+                                                        const float* __restrict__ gt_l, const float* __restrict__ gt_r, int V,
+                                                        float contact, float* __restrict__ out) {
+    __shared__ float L[CDEV_MAXV * 3];
+    __shared__ float rs[CDEV_TPB];
+    __shared__ int rc[CDEV_TPB];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* gl = gt_l + (long long)b * V * 3;
+    for (int i = tid; i < V * 3; i += CDEV_TPB) L[i] = gl[i];
+    __syncthreads();
+    float sum = 0.f;
+    int cnt = 0;
+    for (int v = tid; v < V; v += CDEV_TPB) {
+        const float* p = gt_r + ((long long)b * V + v) * 3;
+        const float x = p[0], y = p[1], z = p[2];
+        float best = INFINITY;
+        int arg = 0;
+        for (int j = 0; j < V; ++j) {
+            const float dx = x - L[3 * j], dy = y - L[3 * j + 1], dz = z - L[3 * j + 2];
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < best) { best = d2; arg = j; }                  // first minimum wins
+        }
+        if (!(sqrtf(best) > contact)) {
+            const float* a = pred_l + ((long long)b * V + arg) * 3;
+            const float* c = pred_r + ((long long)b * V + v) * 3;
+            const float ex = a[0] - c[0], ey = a[1] - c[1], ez = a[2] - c[2];
+            sum += sqrtf(ex * ex + ey * ey + ez * ez);
+            ++cnt;
+        }
+    }
+    rs[tid] = sum;
+    rc[tid] = cnt;
+    __syncthreads();
+    for (int s = CDEV_TPB / 2; s > 0; s >>= 1) {
+        if (tid < s) { rs[tid] += rs[tid + s]; rc[tid] += rc[tid + s]; }
+        __syncthreads();
+    }
+    if (tid == 0) out[b] = rs[0] / (float)rc[0];                     // 0 / 0 = NaN: no contact in this sample (nanmean)
+}
+}  // namespace
+
+extern "C" int rih_cdev(const float* pred_left, const float* pred_right, const float* gt_left, const float* gt_right, int B,
+                        int V, float contact, float* out, void* stream) {
+    if (!pred_left || !pred_right || !gt_left || !gt_right || !out || B < 1 || V < 1 || V > CDEV_MAXV) return RIH_EINVAL;
+    hipLaunchKernelGGL(cdev_kernel, dim3(B), dim3(CDEV_TPB), 0, (hipStream_t)stream, pred_left, pred_right, gt_left, gt_right, V,
+                       contact, out);
+    return (int)hipGetLastError();
+}

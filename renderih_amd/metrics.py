@@ -60,3 +60,15 @@ def eval_hand2(verts_left_gt, verts_right_gt, joints_left_gt, joints_right_gt, v
         verts_loss[side].append(ve)
         pajoints_loss[side].append(je)
         paverts_loss[side].append(ve)
+
+
+def compute_cdev(pred_left, pred_right, gt_left, gt_right, contact=3e-3):
+    """utils/eval_metrics.py:36-50 (`compute_cdev(pred_v3d_o, pred_v3d_r, gt_left, gt_right)`): [B] contact deviation in
+    metres, NaN for samples whose ground-truth hands do not touch; one launch, no pytorch3d."""
+    ops._chk(pred_left, pred_right, gt_left, gt_right)
+    pl, pr, gl, gr = (ops._c(t) for t in (pred_left, pred_right, gt_left, gt_right))
+    B, V, _ = gl.shape
+    out = torch.empty(B, device=gl.device, dtype=torch.float32)
+    check(ops._L().rih_cdev(pl.data_ptr(), pr.data_ptr(), gl.data_ptr(), gr.data_ptr(), B, V, float(contact), out.data_ptr(),
+                            ops._stream()), 'rih_cdev')
+    return out

@@ -308,6 +308,12 @@ class EmulatedLib:
                 DK[oi.ravel()] = (Sm[pidx].T @ Q[qi]).astype(np.float32).ravel()
         return 0
 
+    def rih_cdev(self, pred_left, pred_right, gt_left, gt_right, B, V, contact, out, stream):
+        from oracle import metrics_oracle
+        t = lambda ptr: torch.from_numpy(_f(ptr, B * V * 3).reshape(B, V, 3).copy())
+        _f(out, B)[:] = metrics_oracle.compute_cdev(t(pred_left), t(pred_right), t(gt_left), t(gt_right), contact).numpy()
+        return 0
+
     # ------------------------------------------------------------------ fp16 inference backbone (csrc/rih_half.hip)
     @staticmethod
     def _h(ptr, n):

@@ -1,7 +1,7 @@
 """Runs ONE group of hardware checks for a code path that has not been on a GPU yet (see tests/test_gpu_pending.py, which
 starts this file in its own interpreter).  Exit code 0 = every check of the group passed on the GPU.
 
-    python tests/pending/run_pending.py half_kernels | half_backbone | fused_attention | presplit | input_pipeline | sdf | graphed_inference | folded_fp32
+    python tests/pending/run_pending.py half_kernels | half_backbone | fused_attention | presplit | input_pipeline | sdf | graphed_inference | folded_fp32 | cdev
 """
 import os
 import sys
@@ -64,6 +64,11 @@ def folded_fp32(dev):
     print('folded fp32 trunk vs plain eval path:', test_half.folded_fp32_trunk_vs_plain(dev, B=2))
 
 
+def cdev(dev):
+    import test_metrics
+    test_metrics.cdev_kernel_vs_fixture(dev)
+
+
 def fused_attention(dev):
     import test_gpu_ops as G
     from renderih_amd import ops
@@ -100,6 +105,6 @@ def sdf(dev):
 if __name__ == '__main__':
     assert torch.cuda.is_available(), 'needs a GPU'
     {'half_kernels': half_kernels, 'half_backbone': half_backbone, 'fused_attention': fused_attention,
-     'presplit': presplit, 'input_pipeline': input_pipeline, 'sdf': sdf, 'graphed_inference': graphed_inference, 'folded_fp32': folded_fp32}[sys.argv[1]](torch.device('cuda:0'))
+     'presplit': presplit, 'input_pipeline': input_pipeline, 'sdf': sdf, 'graphed_inference': graphed_inference, 'folded_fp32': folded_fp32, 'cdev': cdev}[sys.argv[1]](torch.device('cuda:0'))
     torch.cuda.synchronize()
     print('PENDING-OK', sys.argv[1])

@@ -174,3 +174,38 @@ def test_evaluate_loop_matches_reference_lines():
                                                            np.concatenate(want['ori']['right']).mean())) < 1e-3
     mrrpe = np.sqrt(((np.concatenate(ptr) - np.concatenate(gtr)) ** 2).sum(1)).mean()
     assert abs(summary['mrrpe'] - mrrpe) < 1e-6
+
+
+def _cdev_case():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cdev.npz'))
+    return {k: torch.from_numpy(g[k]) for k in g.files}
+
+
+def test_cdev_oracle_matches_reference_fixture():
+    """oracle compute_cdev against the reference's own utils/eval_metrics.compute_cdev (tests/golden/make_cdev_golden.py);
+    one sample has hands 0.5 m apart: NaN in both."""
+    from oracle import metrics_oracle
+    c = _cdev_case()
+    got = metrics_oracle.compute_cdev(c['pred_left'].clone(), c['pred_right'].clone(), c['gt_left'], c['gt_right'])
+    assert torch.isnan(c['cdev'][2]) and torch.equal(torch.isnan(got), torch.isnan(c['cdev']))
+    ok = ~torch.isnan(got)
+    assert torch.allclose(got[ok], c['cdev'][ok], rtol=1e-6, atol=0)
+
+
+def cdev_kernel_vs_fixture(dev):
+    from renderih_amd.metrics import compute_cdev
+    c = _cdev_case()
+    got = compute_cdev(*(c[k].to(dev) for k in ('pred_left', 'pred_right', 'gt_left', 'gt_right'))).cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(c['cdev']))
+    ok = ~torch.isnan(got)
+    assert torch.allclose(got[ok], c['cdev'][ok], rtol=2e-6, atol=0)
+
+
+def test_cdev_kernel_on_cpu():
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from hipcpu.host_kernels import host_kernels_abi
+    with host_kernels_abi():
+        cdev_kernel_vs_fixture(torch.device('cpu'))
