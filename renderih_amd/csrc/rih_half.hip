@@ -23,6 +23,7 @@
 // torch on fp16-rounded operands; not yet run or measured on a GPU.  Opt-in (HandNET_GCN.use_fp16_backbone()).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/renderih_amd.h"
 
 namespace {
@@ -70,7 +71,9 @@ __device__ __forceinline__ const half_t* pick(bool ok, const half_t* a, const ha
 
 __device__ __forceinline__ float clamp_h(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
 
-template <int BN>
+// GLDS = false: the same data movement through registers (16-byte global loads issued before a tile's MFMAs, ds_write_b128
+// after them) -- the conventional staging, kept as the A/B partner and fallback of the LDS-DMA path (RIH_HCONV_GLDS=0).
+template <int BN, bool GLDS>
 __global__ __launch_bounds__(TPB, 2) void hconv_kernel(const HConvArgs p) {
     constexpr int WN = BN / 2, TN = WN / 32;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
@@ -123,7 +126,9 @@ __global__ __launch_bounds__(TPB, 2) void hconv_kernel(const HConvArgs p) {
     }
     const int ntiles = p.Kpad / BKH;
 
-    auto stage = [&](int buf) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 regs[NA + NB];                                    // register staging (GLDS = false only)
+    auto stage = [&](int buf) {                             // issue the loads of the next k-tile
         unsigned char* a_dst = smem + buf * STAGE + (8 * wave) * ROWB + lane * 16;
         const bool kok = kh < p.KH;
         const int tapoff = kh * p.W + kw;
@@ -131,12 +136,15 @@ __global__ __launch_bounds__(TPB, 2) void hconv_kernel(const HConvArgs p) {
         for (int i = 0; i < NA; ++i) {
             const bool ok = (int)kok & (int)((unsigned)(hi0[i] + kh) < (unsigned)p.H) & (int)((unsigned)(wi0[i] + kw) < (unsigned)p.W);
             const long long off = (long long)(pix[i] + tapoff) * p.ldx + ci;
-            glds16(pick(ok, p.x + off, p.zero), a_dst + 32 * i * ROWB);
+            const half_t* src = pick(ok, p.x + off, p.zero);
+            if (GLDS) glds16(src, a_dst + 32 * i * ROWB);
+            else regs[i] = *(const u32x4*)src;
         }
         unsigned char* b_dst = a_dst + A_BYTES;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            glds16(wsrc[i], b_dst + 32 * i * ROWB);
+            if (GLDS) glds16(wsrc[i], b_dst + 32 * i * ROWB);
+            else regs[NA + i] = *(const u32x4*)wsrc[i];
             wsrc[i] += wstep[i];
         }
         ci += BKH;                                          // advance the (tap, channel) walk by one k-tile
@@ -144,6 +152,14 @@ __global__ __launch_bounds__(TPB, 2) void hconv_kernel(const HConvArgs p) {
             ci -= p.Cin;
             if (++kw == p.KW) { kw = 0; ++kh; }
         }
+    };
+    auto land = [&](int buf) {                              // GLDS = false: registers -> the same lane-linear LDS image
+        if (GLDS) return;
+        unsigned char* a_dst = smem + buf * STAGE + (8 * wave) * ROWB + lane * 16;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *(u32x4*)(a_dst + 32 * i * ROWB) = regs[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *(u32x4*)(a_dst + A_BYTES + 32 * i * ROWB) = regs[NA + i];
     };
 
     floatx16 acc[2][TN];
@@ -155,6 +171,7 @@ __global__ __launch_bounds__(TPB, 2) void hconv_kernel(const HConvArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     stage(0);
+    land(0);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
@@ -180,6 +197,7 @@ __global__ __launch_bounds__(TPB, 2) void hconv_kernel(const HConvArgs p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (t + 1 < ntiles) land(buf ^ 1);
         __syncthreads();                                    // tile t+1 has landed, nobody still reads tile t
     }
 
@@ -396,12 +414,15 @@ extern "C" int rih_hconv(const rih_hconv_desc* d, void* stream) {
     a.vec = al16(d->y) && d->ldy % (d->out_f32 ? 4 : 8) == 0 && (d->res == nullptr || (al16(d->res) && d->ldr % 8 == 0));
     hipStream_t s = (hipStream_t)stream;
     const long long tilesM = (M + BM - 1) / BM;
+    static const bool glds = [] { const char* e = getenv("RIH_HCONV_GLDS"); return !(e && e[0] == '0'); }();
     if (d->Cout > 64) {
         const long long tiles = tilesM * ((d->Cout + 127) / 128);
         if (tiles > 0x7fffffffLL) return RIH_EINVAL;
-        hipLaunchKernelGGL((hconv_kernel<128>), dim3((unsigned)tiles), dim3(TPB), 0, s, a);
+        if (glds) hipLaunchKernelGGL((hconv_kernel<128, true>), dim3((unsigned)tiles), dim3(TPB), 0, s, a);
+        else hipLaunchKernelGGL((hconv_kernel<128, false>), dim3((unsigned)tiles), dim3(TPB), 0, s, a);
     } else {
-        hipLaunchKernelGGL((hconv_kernel<64>), dim3((unsigned)tilesM), dim3(TPB), 0, s, a);
+        if (glds) hipLaunchKernelGGL((hconv_kernel<64, true>), dim3((unsigned)tilesM), dim3(TPB), 0, s, a);
+        else hipLaunchKernelGGL((hconv_kernel<64, false>), dim3((unsigned)tilesM), dim3(TPB), 0, s, a);
     }
     return (int)hipGetLastError();
 }

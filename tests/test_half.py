@@ -125,6 +125,16 @@ def test_half_kernels_on_cpu():
         kernels_vs_torch(torch.device('cpu'))
 
 
+def test_half_kernels_register_staging_on_cpu():
+    """hconv_kernel<.., GLDS = false> (RIH_HCONV_GLDS=0: global -> VGPR -> ds_write instead of LDS-DMA), the A/B partner and
+    fallback of the default; the switch is read once per process, hence the child interpreter."""
+    import subprocess
+    env = dict(os.environ, RIH_HCONV_GLDS='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', os.path.abspath(__file__), '-k', 'test_half_kernels_on_cpu'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and '1 passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def tiny_model(seed=0):
     """The reference network with a ResNet trunk of one bottleneck per stage (same module classes, same dataflow)."""
     from renderih_amd import encoder as E, testing

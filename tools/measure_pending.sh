@@ -19,6 +19,7 @@ run infer_f32_fold  env RIH_FOLD_BN=1 python tools/infer_bench.py --iters 10
 run infer_f16       python tools/infer_bench.py --iters 10 --fp16
 run infer_f16_b64   python tools/infer_bench.py --iters 10 --fp16 --batch 64
 run hconv_layers    python tools/hconv_bench.py --iters 10
+run hconv_layers_regstage env RIH_HCONV_GLDS=0 python tools/hconv_bench.py --iters 10
 T=900 run prof_infer_f16 rocprofv3 --kernel-trace --stats -d "$OUT/prof_infer_f16" -- python tools/infer_bench.py --iters 5 --fp16
 find "$OUT/prof_infer_f16" -name '*kernel_stats*.csv' -exec cp {} "$OUT/infer_f16_kernel_stats.csv" \; 2>/dev/null
 echo done
