@@ -1,7 +1,7 @@
 """Runs ONE group of hardware checks for a code path that has not been on a GPU yet (see tests/test_gpu_pending.py, which
 starts this file in its own interpreter).  Exit code 0 = every check of the group passed on the GPU.
 
-    python tests/pending/run_pending.py half_kernels | half_backbone | fused_attention | presplit | input_pipeline | sdf | graphed_inference | folded_fp32 | cdev
+    python tests/pending/run_pending.py half_kernels | half_backbone | fused_attention | presplit | input_pipeline | sdf | graphed_inference | folded_fp32 | cdev | half_kernels_regstage
 """
 import os
 import sys
@@ -20,6 +20,11 @@ def half_kernels(dev):
     test_half.conv_case(dev, 4, 32, 32, 256, 512, 3, 1, 1, 'conv-bn', True, True, False, seed=11)
     test_half.conv_case(dev, 8, 64, 64, 64, 64, 1, 1, 0, 'conv-bn', True, False, False, seed=12)
     test_half.conv_case(dev, 2, 16, 16, 1024, 2048, 1, 2, 0, 'conv-bn', False, False, False, seed=13)
+
+
+def half_kernels_regstage(dev):
+    os.environ['RIH_HCONV_GLDS'] = '0'          # read by the library at its first rih_hconv call
+    half_kernels(dev)
 
 
 def half_backbone(dev):
@@ -105,6 +110,6 @@ def sdf(dev):
 if __name__ == '__main__':
     assert torch.cuda.is_available(), 'needs a GPU'
     {'half_kernels': half_kernels, 'half_backbone': half_backbone, 'fused_attention': fused_attention,
-     'presplit': presplit, 'input_pipeline': input_pipeline, 'sdf': sdf, 'graphed_inference': graphed_inference, 'folded_fp32': folded_fp32, 'cdev': cdev}[sys.argv[1]](torch.device('cuda:0'))
+     'presplit': presplit, 'input_pipeline': input_pipeline, 'sdf': sdf, 'graphed_inference': graphed_inference, 'folded_fp32': folded_fp32, 'cdev': cdev, 'half_kernels_regstage': half_kernels_regstage}[sys.argv[1]](torch.device('cuda:0'))
     torch.cuda.synchronize()
     print('PENDING-OK', sys.argv[1])

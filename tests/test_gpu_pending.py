@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 
 
-@pytest.mark.parametrize('group', ['half_kernels', 'half_backbone', 'fused_attention', 'presplit', 'input_pipeline', 'sdf', 'graphed_inference', 'folded_fp32', 'cdev'])
+@pytest.mark.parametrize('group', ['half_kernels', 'half_kernels_regstage', 'half_backbone', 'fused_attention', 'presplit', 'input_pipeline', 'sdf', 'graphed_inference', 'folded_fp32', 'cdev'])
 def test_pending_on_hardware(group):
     cmd = [sys.executable, os.path.join(ROOT, 'tests', 'pending', 'run_pending.py'), group]
     try:
