@@ -1,4 +1,4 @@
-"""Runs ONE group of hardware checks for a code path that has not been on a GPU yet (see tests/test_gpu_pending.py, which
+"""Runs ONE group of hardware checks for a code path that has not been on a GPU yet (see tests/test_zz_gpu_pending.py, which
 starts this file in its own interpreter).  Exit code 0 = every check of the group passed on the GPU.
 
     python tests/pending/run_pending.py half_kernels | half_backbone | fused_attention | presplit | input_pipeline | sdf | graphed_inference | folded_fp32 | cdev | half_kernels_regstage

@@ -9,7 +9,7 @@ OUT=gpurun_out/pending
 mkdir -p "$OUT"
 run() { name=$1; shift; echo "== $name: $*"; ( timeout "${T:-600}" "$@" ) > "$OUT/$name.log" 2>&1; echo "   exit $?"; tail -n 3 "$OUT/$name.log"; }
 
-T=1200 run pytest_pending python -m pytest tests/test_gpu_pending.py -q -m gpu -rxXs
+T=1200 run pytest_pending python -m pytest tests/test_zz_gpu_pending.py -q -m gpu -rxXs
 run bench_default   python bench.py --steps 10 --warmup 3 --no-cpu-baseline
 run bench_presplit1 env RIH_PRESPLIT=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
 run bench_presplit2 env RIH_PRESPLIT=2 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
