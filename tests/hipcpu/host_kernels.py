@@ -10,7 +10,11 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, '..', '..'))
 CSRC = os.path.join(ROOT, 'renderih_amd', 'csrc')
-OUT = os.path.join(HERE, '_build', 'librenderih_cpu.so')
+# HIPCPU_ASAN=1: build with AddressSanitizer into a separate library (run python with LD_PRELOAD=<libclang_rt.asan-x86_64.so>
+# and ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0): out-of-bounds reads / writes of the kernels on the
+# caller's buffers, which plain host execution would silently tolerate, abort the test
+ASAN = os.environ.get('HIPCPU_ASAN', '0') == '1'
+OUT = os.path.join(HERE, '_build', 'librenderih_cpu_asan.so' if ASAN else 'librenderih_cpu.so')
 
 
 def clangxx():
@@ -32,14 +36,15 @@ def build(force=False):
     objs = []
     procs = []
     for s in srcs:                                   # one translation unit per process: the GEMM file dominates
-        o = os.path.join(os.path.dirname(OUT), os.path.basename(s) + '.o')
+        o = os.path.join(os.path.dirname(OUT), os.path.basename(s) + ('.asan.o' if ASAN else '.o'))
         objs.append(o)
-        procs.append(subprocess.Popen([clangxx(), '-x', 'c++', '-std=c++20', '-O1', '-fPIC', '-c', '-I', HERE,
+        procs.append(subprocess.Popen([clangxx(), '-x', 'c++', '-std=c++20', '-O1', '-fPIC', '-c', '-I', HERE] +
+                                      (['-fsanitize=address', '-fno-omit-frame-pointer', '-g'] if ASAN else []) + [
                                        '-I', os.path.join(ROOT, 'include'), '-Wno-unused-value', '-Wno-pass-failed', '-o', o, s]))
     for p in procs:
         if p.wait() != 0:
             raise RuntimeError('host build of the kernels failed')
-    subprocess.check_call([clangxx(), '-shared', '-o', OUT] + objs)
+    subprocess.check_call([clangxx(), '-shared', '-o', OUT] + (['-fsanitize=address', '-shared-libasan'] if ASAN else []) + objs)
     return OUT
 
 
