@@ -1,7 +1,7 @@
 """hipGraph replay of an inference forward (BASELINE configs[4]: "hipGraph-captured encoder+attention+MANO").
 
 The C ABI is stream-ordered and allocation-free, and the host modules allocate only through torch's caching allocator, so a
-whole eval forward (~1000 launches for the fp32 network, ~75 + decoder for the fp16 backbone) can be captured once and
+whole eval forward (~1000 launches for the fp32 network, ~76 + decoder for the fp16 backbone) can be captured once and
 replayed with one launch call; tools/infer_bench.py measures the difference.  `GraphedInference` packages the usual
 static-buffer protocol:
 
