@@ -194,7 +194,7 @@ def test_half_backbone_host_logic():
 
 @pytest.mark.skipif(os.environ.get('HIPCPU_MORE', '0') != '1', reason='3.5 min on the fiber harness: run with HIPCPU_MORE=1')
 def test_half_backbone_kernels_on_cpu():
-    """The whole folded backbone (76 launches: stem, pool, bottlenecks with in-place concat slices, aux decoders, mid convs,
+    """The whole folded backbone dataflow with one bottleneck per stage (stem, pool, bottlenecks with in-place concat slices, aux decoders, mid convs,
     average pool) through the REAL kernels on the harness, 32 x 32 input, against the fp32 modules."""
     from hipcpu.host_kernels import host_kernels_abi
     with host_kernels_abi():
