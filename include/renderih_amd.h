@@ -116,6 +116,52 @@ int rih_splitk_reduce_bias_batched(const float* P, int S, int Mp, int M, int N, 
                                    int CinValid, int accumulate, float* db, int nb, int64_t sP, int64_t sDst,
                                    int64_t sDb, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Conversion-free split-bf16 GEMM on pre-split "P3" operands (csrc/rih_gemm3.hip).  Replaces rih_gemm for the ResNet trunk
+ * of models/encoder.py:107-116 (torchvision resnet50 convolutions, forward and data gradient): the BatchNorm kernels that
+ * produce an activation / gradient write it in P3, the weights are converted once per step, and the GEMM stages operands
+ * global -> LDS by LDS-DMA with one barrier per 32-deep k-tile and converts nothing.
+ *
+ * P3 format of a row-major fp32 matrix [rows][C], C % 8 == 0, row pitch ld channels (ld % 8 == 0): 6 bytes per element;
+ *   the 16-byte unit (row r, channel group g = c/8, plane p: 0 hi, 1 mid, 2 lo) holds 8 bf16 at byte
+ *   ((r*ld/8 + g)*3 + p)*16, where x = hi + mid + lo with round-to-nearest at every level (|x - hi - mid - lo| <= 2^-24 |x|).
+ *
+ * rih_gemm_p3: C[m][n] = act(sum_k A(m,k) B(n,k) + bias[n] + R[m][n]); A(m,k): m = (img, ho, wo), k = (kh, kw, c),
+ *   element X[img][ho*stride - padH + kh][wo*stride - padW + kw][c] of the P3 tensor X[*][H][W][lda] (0 outside);
+ *   B = P3 [N][ldb] with ldb >= K = KH*KW*Cin.  Cin % 32 == 0, KH*KW <= 32, X smaller than 4 GiB.  A plain matrix product is
+ *   H = Ho = rows, W = Wo = 1 (or any factorisation), KH = KW = stride = 1, pad 0.  `zero`: >= 16 readable zero bytes
+ *   (16-byte aligned) that padding lanes load instead of the operand.  cS..cW as in rih_gemm_desc (strided output rows).
+ *   stats != NULL (requires M % tile rows == 0): additionally writes per-column statistics of the stored values,
+ *   stats[(tile_m*N + n)*2 + {0,1}] = (mean, sum of squared deviations from that mean) over the tile's rows; merge with
+ *   rih_bn_stats_merge (Chan's formula in double) -> the batch statistics of nn.BatchNorm2d without a pass over C.
+ *   tile 0: 256x128, 1: 128x128, 2: 128x64 (rows per tile: rih_gemm_p3_tile_rows).
+ * rih_p3_from_f32: fp32 [rows][C] (pitch ldx) -> P3 (pitch ldo).  rih_p3_conv_weight: OIHW weight -> P3 [N][Kpad] as forward
+ *   operand (for_dgrad 0: N = Cout, k = (tap, ci < CinPad)) or as flipped data-gradient operand of the tap subset
+ *   kh0 + step*t, kw0 + step*t' (for_dgrad 1: N = CinPad, k = ((th, tw), co)); same conventions as rih_presplit_conv_weight. */
+typedef struct rih_gemm_p3_desc {
+    const void* A;
+    const void* B;
+    const void* zero;
+    float* C;
+    const float* bias;   /* [N] or NULL */
+    const float* R;      /* residual [M][ldr] or NULL (not with cS > 1) */
+    float* stats;        /* [ceil(M/rows)][N][2] or NULL */
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc, ldr;
+    int32_t H, W, Cin, Ho, Wo, KH, KW, stride, padH, padW;
+    int32_t cS, cOH, cOW, cH, cW;
+    int32_t relu;
+    int32_t tile;
+    int32_t reserved0;
+} rih_gemm_p3_desc;
+int rih_gemm_p3(const rih_gemm_p3_desc* d, void* stream);
+int rih_gemm_p3_tile_rows(int tile);
+int rih_p3_from_f32(const float* x, int64_t rows, int C, int ldx, void* out, int ldo, void* stream);
+int rih_p3_conv_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int CinPad, int for_dgrad, int kh0,
+                       int kw0, int step, int Th, int Tw, int Kpad, void* stream);
+/* part [T][C][2] from rih_gemm_p3 (tiles of rows_per_tile rows) -> mean[C], biased variance var[C] */
+int rih_bn_stats_merge(const float* part, int T, int C, int rows_per_tile, float* mean, float* var, void* stream);
+
 /* Pre-split B operands for rih_gemm b_mode 2 (weights are constant within a training step, so their bf16 hi/mid/lo
  * planes are produced once instead of inside every GEMM): dst = 3 * N * Kpad bf16, Kpad % 32 == 0.
  * rih_presplit_matrix: from a plain b_mode 0 / 1 matrix.  rih_presplit_conv_weight: from an OIHW conv weight, as the
@@ -283,11 +329,12 @@ int64_t rih_mano_bwd_ws_floats(int B);
  *   (vert_to_GCN); pool = 2^k consecutive graph-order vertices are average-pooled pairwise into one coarse vertex.
  * rih_mesh_loss (one launch per hand): predictions v3d_pred[B][V][3], v2d_pred[B][V][2], c3d_pred[B][Vc][3],
  *   c2d_pred[B][Vc][2]; labels v3d_gt, v2d_gt; gt_shift[B][3] or NULL is added to v3d_gt (root_rel of the right hand).
- *   term_weights[7] (HOST array, order v2d, v3d, joint, normal, edge, coarse-3d, coarse-2d) = weight of the raw SUM of
- *   each term in the total, i.e. LOSS_WEIGHT / element count / 2 (hand average).  Writes the gradient of the total
+ *   term_weights[7] (DEVICE array, read by the kernel at run time so that a captured hipGraph follows in-place updates
+ *   such as the epoch gate of the edge term; order v2d, v3d, joint, normal, edge, coarse-3d, coarse-2d) = weight of the
+ *   raw SUM of each term in the total, i.e. LOSS_WEIGHT / element count / 2 (hand average).  Writes the gradient of the total
  *   with respect to the four prediction tensors and partial[B][8] (raw sums of the seven terms per image).
  * rih_mesh_loss_final: out[0] = total over both hands; out[1..7] = the seven terms as the reference reports them
- *   (mean over elements, averaged over the hands); counts[7] = element counts (HOST array). */
+ *   (mean over elements, averaged over the hands); counts[7] = element counts (DEVICE array). */
 typedef struct rih_mesh_topo {
     const int32_t* faces;
     const int32_t* vptr;
@@ -304,8 +351,13 @@ int rih_mesh_loss(const rih_mesh_topo* topo, const float* v3d_pred, const float*
 int rih_mesh_loss_final(const float* partial_left, const float* partial_right, int B, const float* term_weights,
                         const float* counts, float* out, void* stream);
 
-/* library / device info */
+/* library / device info.  RIH_ABI_VERSION is bumped whenever a struct layout or a signature of this header changes;
+ * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of the by-pointer structs
+ * (gemm desc, mano model, mesh topo, hconv desc), so a host binding can refuse a stale binary instead of handing it
+ * mis-laid-out structs. */
+#define RIH_ABI_VERSION 2
 int rih_version(void);
+int rih_abi_sizes(int32_t* out4);
 const char* rih_arch(void);
 
 /* ------------------------------------------------------------------------------------------------

@@ -1,16 +1,24 @@
 """Build librenderih_amd.so (hand-written HIP kernels + C ABI) for gfx950, in-tree.
 
 `hipcc --offload-arch=gfx950` cross-compiles without a GPU.  The .so is git-ignored but travels to the
-GPU box with the repo snapshot.  Rebuilds only when a source is newer than the library.
+GPU box with the repo snapshot.  Each source is compiled to its own object (in parallel, only when it or a header is
+newer than the object), then linked; nothing is rebuilt when the library is newer than every source.
 """
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'librenderih_amd.so')
-SOURCES = ['rih_gemm.hip', 'rih_elem.hip', 'rih_mano.hip', 'rih_loss.hip', 'rih_metrics.hip', 'rih_pose.hip', 'rih_attn.hip', 'rih_half.hip', 'rih_input.hip', 'rih_sdf.hip']
+SOURCES = ['rih_gemm.hip', 'rih_gemm3.hip', 'rih_elem.hip', 'rih_mano.hip', 'rih_loss.hip', 'rih_metrics.hip',
+           'rih_pose.hip', 'rih_attn.hip', 'rih_half.hip', 'rih_input.hip', 'rih_sdf.hip']
 HEADERS = ['rih_procrustes.h', 'rih_pose_math.h']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result',
+         # hipcc's SLP pass packs neighbouring f32 adds into v_pk_add_f32, which issues at a fraction of the scalar
+         # rate next to MFMAs (MI355X_MICROARCH.md, cycle constants): keep the split arithmetic scalar
+         '-fno-slp-vectorize']
 
 
 def hipcc():
@@ -20,26 +28,35 @@ def hipcc():
     return 'hipcc'
 
 
+def _deps():
+    return [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(HERE, '..', 'include', 'renderih_amd.h')]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(HERE, '..', 'include', 'renderih_amd.h')]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-Wno-unused-result',
-           # hipcc's SLP pass packs neighbouring f32 adds into v_pk_add_f32, which issues at a fraction of the scalar
-           # rate next to MFMAs (MI355X_MICROARCH.md, cycle constants): keep the split arithmetic scalar
-           '-fno-slp-vectorize', '-o', LIB] + srcs
-    if verbose:
-        print('[renderih_amd] building:', ' '.join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_t = max(os.path.getmtime(d) for d in _deps()[len(SOURCES):])
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s + '.o')
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append([hipcc()] + FLAGS + ['-c', src, '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print('[renderih_amd] building:', ' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + [os.path.join(OBJ, s + '.o') for s in SOURCES])
     return LIB
 
 

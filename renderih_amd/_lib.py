@@ -31,6 +31,14 @@ class GemmDesc(C.Structure):
                 ('reserved0', C.c_int32), ('sBias1', C.c_int64), ('sR1', C.c_int64)]
 
 
+class GemmP3Desc(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('zero', C.c_void_p), ('C', C.c_void_p), ('bias', C.c_void_p),
+                ('R', C.c_void_p), ('stats', C.c_void_p)] + \
+               [(n, C.c_int32) for n in ('M', 'N', 'K', 'lda', 'ldb', 'ldc', 'ldr', 'H', 'W', 'Cin', 'Ho', 'Wo', 'KH', 'KW',
+                                         'stride', 'padH', 'padW', 'cS', 'cOH', 'cOW', 'cH', 'cW', 'relu', 'tile',
+                                         'reserved0')]
+
+
 class HConvDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('zero', C.c_void_p), ('bias', C.c_void_p),
                 ('post_scale', C.c_void_p), ('post_shift', C.c_void_p), ('res', C.c_void_p), ('y', C.c_void_p)] + \
@@ -133,12 +141,20 @@ SIGNATURES = {
                            C.c_void_p]),
     'rih_mano_bwd': (c_i, [C.POINTER(ManoModel), c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f,
                            c_f, c_f, c_f, c_f, c_f, c_f, c_i, C.c_void_p]),
-    'rih_mesh_loss': (c_i, [C.POINTER(MeshTopo), c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.POINTER(C.c_float), c_fl,
+    'rih_mesh_loss': (c_i, [C.POINTER(MeshTopo), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_fl,
                             c_f, c_f, c_f, c_f, c_f, c_i, C.c_void_p]),
-    'rih_mesh_loss_final': (c_i, [c_f, c_f, c_i, C.POINTER(C.c_float), C.POINTER(C.c_float), c_f, C.c_void_p]),
+    'rih_mesh_loss_final': (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, C.c_void_p]),
+    'rih_gemm_p3': (c_i, [C.POINTER(GemmP3Desc), C.c_void_p]),
+    'rih_gemm_p3_tile_rows': (c_i, [c_i]),
+    'rih_p3_from_f32': (c_i, [c_f, c_l, c_i, c_i, C.c_void_p, c_i, C.c_void_p]),
+    'rih_p3_conv_weight': (c_i, [c_f, C.c_void_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_bn_stats_merge': (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),
     'rih_version': (c_i, []),
+    'rih_abi_sizes': (c_i, [C.POINTER(C.c_int32)]),
     'rih_arch': (C.c_char_p, []),
 }
+
+ABI_VERSION = 2      # = RIH_ABI_VERSION of include/renderih_amd.h
 
 _lib = None
 
@@ -160,14 +176,20 @@ def load():
         try:
             _build.build(verbose=False)
         except Exception as e:  # noqa: BLE001
-            if not os.path.exists(path):
-                raise RuntimeError('librenderih_amd.so is missing and could not be built with hipcc (%s); '
-                                   'run `python -m renderih_amd._build`' % e)
+            # never fall back silently to an older binary: its struct layouts / signatures may differ from this binding
+            raise RuntimeError('librenderih_amd.so is %s and could not be rebuilt with hipcc (%s); run '
+                               '`python -m renderih_amd._build`' % ('stale' if os.path.exists(path) else 'missing', e))
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError => a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    sizes = (C.c_int32 * 4)()
+    if lib.rih_version() != ABI_VERSION or lib.rih_abi_sizes(sizes) != 0 or list(sizes) != [
+            C.sizeof(GemmDesc), C.sizeof(ManoModel), C.sizeof(MeshTopo), C.sizeof(HConvDesc)]:
+        raise RuntimeError('librenderih_amd.so does not match this binding (ABI %d vs %d, struct sizes %s vs %s): rebuild '
+                           'with `python -m renderih_amd._build`' % (lib.rih_version(), ABI_VERSION, list(sizes),
+                           [C.sizeof(GemmDesc), C.sizeof(ManoModel), C.sizeof(MeshTopo), C.sizeof(HConvDesc)]))
     _lib = lib
     return lib
 

@@ -1249,5 +1249,13 @@ extern "C" int rih_project_bwd(const float* dout, const float* v, const float* s
     LAUNCH_RET();
 }
 
-extern "C" int rih_version(void) { return 1; }
+extern "C" int rih_version(void) { return RIH_ABI_VERSION; }
+extern "C" int rih_abi_sizes(int32_t* out4) {
+    if (!out4) return RIH_EINVAL;
+    out4[0] = (int32_t)sizeof(rih_gemm_desc);
+    out4[1] = (int32_t)sizeof(rih_mano_model);
+    out4[2] = (int32_t)sizeof(rih_mesh_topo);
+    out4[3] = (int32_t)sizeof(rih_hconv_desc);
+    return 0;
+}
 extern "C" const char* rih_arch(void) { return "gfx950"; }

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(TPB) void mesh_loss_kernel(Topo tp, const float* __
                                                         const float* __restrict__ c2d_pred,
                                                         const float* __restrict__ v3d_gt,
                                                         const float* __restrict__ v2d_gt,
-                                                        const float* __restrict__ gt_shift, Weights w, float img,
+                                                        const float* __restrict__ gt_shift,
+                                                        const float* __restrict__ wdev, float img,
                                                         float* __restrict__ g_v3d, float* __restrict__ g_v2d,
                                                         float* __restrict__ g_c3d, float* __restrict__ g_c2d,
                                                         float* __restrict__ partial) {
@@ -71,6 +72,8 @@ __global__ __launch_bounds__(TPB) void mesh_loss_kernel(Topo tp, const float* __
     __shared__ float s_red[4];
     const int b = blockIdx.x, t = threadIdx.x;
     const int V = tp.V, F = tp.F;
+    // term weights live in device memory so that a captured hipGraph follows the caller's epoch gate (edge term)
+    const Weights w{wdev[0], wdev[1], wdev[2], wdev[3], wdev[4], wdev[5], wdev[6]};
     const float* vp = v3d_pred + (long long)b * V * 3;
     const float* vg = v3d_gt + (long long)b * V * 3;
     float sh[3] = {0.f, 0.f, 0.f};
@@ -241,17 +244,15 @@ __global__ __launch_bounds__(TPB) void mesh_loss_kernel(Topo tp, const float* __
 }
 
 // out[0] = total; out[1..7] = the seven terms as the reference reports them (mean over elements, averaged over hands)
-__global__ void mesh_loss_final_kernel(const float* __restrict__ pl, const float* __restrict__ pr, int B, Weights w,
-                                       Weights cnt, float* __restrict__ out) {
+__global__ void mesh_loss_final_kernel(const float* __restrict__ pl, const float* __restrict__ pr, int B,
+                                       const float* __restrict__ wdev, const float* __restrict__ cdev,
+                                       float* __restrict__ out) {
     const int i = threadIdx.x;
     __shared__ float s_t[8];
     if (i < 7) {
         float sl = 0.f, sr = 0.f;
         for (int b = 0; b < B; ++b) { sl += pl[b * 8 + i]; sr += pr[b * 8 + i]; }
-        const float wi = (i == 0) ? w.v2d : (i == 1) ? w.v3d : (i == 2) ? w.joint : (i == 3) ? w.norm : (i == 4) ? w.edge
-                       : (i == 5) ? w.c3d : w.c2d;
-        const float ci = (i == 0) ? cnt.v2d : (i == 1) ? cnt.v3d : (i == 2) ? cnt.joint : (i == 3) ? cnt.norm
-                       : (i == 4) ? cnt.edge : (i == 5) ? cnt.c3d : cnt.c2d;
+        const float wi = wdev[i], ci = cdev[i];
         s_t[i] = wi * (sl + sr);
         out[1 + i] = 0.5f * (sl + sr) / ci;
     }
@@ -272,20 +273,15 @@ extern "C" int rih_mesh_loss(const rih_mesh_topo* tp, const float* v3d_pred, con
         tp->pool < 1 || tp->pool > MAXPOOL || (tp->pool & (tp->pool - 1)) != 0 || img_size <= 0.f)
         return RIH_EINVAL;
     Topo t{tp->faces, tp->vptr, tp->vlist, tp->J, tp->perm, tp->V, tp->F, tp->NJ, tp->Vc, tp->pool};
-    Weights w{term_weights[0], term_weights[1], term_weights[2], term_weights[3], term_weights[4], term_weights[5],
-              term_weights[6]};
     hipLaunchKernelGGL(mesh_loss_kernel, dim3(B), dim3(TPB), 0, (hipStream_t)stream, t, v3d_pred, v2d_pred, c3d_pred,
-                       c2d_pred, v3d_gt, v2d_gt, gt_shift, w, img_size, g_v3d, g_v2d, g_c3d, g_c2d, partial);
+                       c2d_pred, v3d_gt, v2d_gt, gt_shift, term_weights, img_size, g_v3d, g_v2d, g_c3d, g_c2d, partial);
     return (int)hipGetLastError();
 }
 
 extern "C" int rih_mesh_loss_final(const float* partial_left, const float* partial_right, int B, const float* term_weights,
                                    const float* counts, float* out, void* stream) {
     if (!partial_left || !partial_right || !term_weights || !counts || !out || B < 1) return RIH_EINVAL;
-    Weights w{term_weights[0], term_weights[1], term_weights[2], term_weights[3], term_weights[4], term_weights[5],
-              term_weights[6]};
-    Weights c{counts[0], counts[1], counts[2], counts[3], counts[4], counts[5], counts[6]};
-    hipLaunchKernelGGL(mesh_loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_left, partial_right, B, w,
-                       c, out);
+    hipLaunchKernelGGL(mesh_loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_left, partial_right, B,
+                       term_weights, counts, out);
     return (int)hipGetLastError();
 }

@@ -32,11 +32,14 @@ class GradAllReducer:
         self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, self.params)]
         self.static = None
         if broadcast_parameters and self.world > 1:
+            # the full module state like DDP's _sync_module_states: frozen parameters too (decoder.unsample_layer.weight,
+            # core/gcn_trainer.py:102), so ranks that initialised or loaded differently cannot diverge silently
+            every = list(module.parameters())
             with torch.no_grad():
-                buf = torch.cat([p.detach().reshape(-1) for p in self.params])
+                buf = torch.cat([p.detach().reshape(-1) for p in every])
                 dist.broadcast(buf, 0, group=process_group)
                 o = 0
-                for p in self.params:
+                for p in every:
                     p.copy_(buf[o:o + p.numel()].view_as(p))
                     o += p.numel()
             for b in module.buffers():

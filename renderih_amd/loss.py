@@ -115,9 +115,7 @@ class _MeshLossFn(torch.autograd.Function):
         from .ops import _stream, check
         lib = _lib.load()
         B = v3l.shape[0]
-        w, cnt = fused.weights(B)
-        wa = (C.c_float * 7)(*w)
-        ca = (C.c_float * 7)(*cnt)
+        wa, ca = fused.device_weights(B, v3l.device)     # device-resident: a captured graph follows set_epoch()
         preds = [t.contiguous() for t in (v3l, v2l, c3l, c2l, v3r, v2r, c3r, c2r)]
         grads = [torch.empty_like(t) for t in preds]
         parts = torch.empty((2, B, 8), device=v3l.device, dtype=torch.float32)
@@ -127,10 +125,12 @@ class _MeshLossFn(torch.autograd.Function):
             topo = fused.topo('left' if h == 0 else 'right', v3l.device)
             check(lib.rih_mesh_loss(C.byref(topo), p[0].data_ptr(), p[1].data_ptr(), p[2].data_ptr(), p[3].data_ptr(),
                                     gt3.contiguous().data_ptr(), gt2.contiguous().data_ptr(),
-                                    0 if shift is None else shift.contiguous().data_ptr(), wa, float(fused.img_size),
+                                    0 if shift is None else shift.contiguous().data_ptr(), wa.data_ptr(),
+                                    float(fused.img_size),
                                     g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(),
                                     parts[h].data_ptr(), B, _stream()), 'rih_mesh_loss')
-        check(lib.rih_mesh_loss_final(parts[0].data_ptr(), parts[1].data_ptr(), B, wa, ca, out.data_ptr(), _stream()),
+        check(lib.rih_mesh_loss_final(parts[0].data_ptr(), parts[1].data_ptr(), B, wa.data_ptr(), ca.data_ptr(),
+                                      out.data_ptr(), _stream()),
               'rih_mesh_loss_final')
         ctx.save_for_backward(*grads)
         ctx.mark_non_differentiable(out)
@@ -176,6 +176,32 @@ class FusedMeshLoss:
               self.w['LABEL_3D'], self.w['LABEL_2D']]
         return [0.5 * a / c for a, c in zip(lw, cnt)], [float(c) for c in cnt]
 
+    def device_weights(self, B, device):
+        """(weights[7], counts[7]) as views of one device tensor that the kernels read at run time.  The tensor is
+        rewritten IN PLACE (outside any stream capture) only when the values change -- batch size, or the epoch gate of
+        the edge term (core/Loss.py:211-220, NORM_EPOCH) -- so a hipGraph captured at epoch 0 picks the edge term up
+        when the trainer calls `set_epoch()` (or this loss eagerly) at a later epoch."""
+        w, cnt = self.weights(B)
+        vals = tuple(w) + tuple(cnt)
+        key = ('wdev', device)
+        if key not in self._dev:
+            self._dev[key] = [torch.zeros(14, device=device, dtype=torch.float32), None]
+        slot = self._dev[key]
+        if slot[1] != vals:
+            if torch.cuda.is_available() and device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('FusedMeshLoss: the term weights changed during stream capture (epoch gate or batch '
+                                   'size); call set_epoch() / run one eager step before capturing')
+            slot[0].copy_(torch.tensor(vals, dtype=torch.float32))
+            slot[1] = vals
+        return slot[0][:7], slot[0][7:]
+
+    def set_epoch(self, epoch, B=None, device=None):
+        """Move the epoch gate (edge term on from NORM_EPOCH).  With a replayed hipGraph pass the captured batch size and
+        device so that the device-resident weights are refreshed in place."""
+        self.epoch = epoch
+        if B is not None and device is not None and self.Vc is not None:
+            self.device_weights(B, torch.device(device))
+
     def topo(self, side, device):
         from ._lib import MeshTopo
         key = (side, device)
@@ -196,7 +222,9 @@ class FusedMeshLoss:
         hd = handDictList[0]
         Vc = hd['verts3d']['left'].shape[1]
         if self.Vc not in (None, Vc):
-            self._dev = {}
+            self._dev = {k: v for k, v in self._dev.items() if k[0] == 'wdev'}
+            for v in self._dev.values():
+                v[1] = None
         self.Vc = Vc
         total, terms = _MeshLossFn.apply(self, result['verts3d']['left'], result['verts2d']['left'], hd['verts3d']['left'],
                                          hd['verts2d']['left'], result['verts3d']['right'], result['verts2d']['right'],
@@ -204,9 +232,18 @@ class FusedMeshLoss:
         return total, terms
 
 
-def calc_loss_GCN_fused(fused, epoch, result, paramsDict, handDictList, otherInfo, v2d_l, v2d_r, v3d_l, v3d_r, root_rel):
-    """`calc_loss_GCN` on the fused kernel: same total; the mano dict carries the reference's five terms."""
+def calc_loss_GCN_fused(fused, epoch, result, paramsDict, handDictList, otherInfo, v2d_l, v2d_r, v3d_l, v3d_r, root_rel,
+                        upsample_weight=None, upsample_target=None):
+    """`calc_loss_GCN` on the fused kernel: same total; the mano dict carries the reference's five terms.
+    `upsample_weight` / `upsample_target`: the trainable up-sampling matrix and its initial value -- the UPSAMPLE term of
+    core/Loss.py:222-224, which the reference adds when the up-sampling layer is not frozen (a tiny torch expression on
+    one 778x252 matrix; with the default frozen layer both are None and the term is absent, as in the reference)."""
+    if (upsample_weight is None) != (upsample_target is None):
+        raise ValueError('calc_loss_GCN_fused: pass upsample_weight and upsample_target together (or neither)')
     total, terms = fused(epoch, result, handDictList, v2d_l, v2d_r, v3d_l, v3d_r, root_rel)
+    if upsample_weight is not None:
+        total = total + fused.w['UPSAMPLE'] * F.smooth_l1_loss(upsample_weight - upsample_target,
+                                                                torch.zeros_like(upsample_weight))
     mano = {'vert2d_loss': terms[1], 'vert3d_loss': terms[2], 'joint_loss': terms[3], 'norm_loss': terms[4],
             'edge_loss': terms[5]}
     return total, mano

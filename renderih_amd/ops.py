@@ -202,6 +202,78 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
     check(_L().rih_gemm(C.byref(d), _stream()), 'rih_gemm')
 
 
+# --------------------------------------------------------------------------------------------- P3 (pre-split) operands
+# csrc/rih_gemm3.hip: activations / weights stored as three bf16 planes interleaved per 8 channels (6 bytes per element);
+# the GEMM stages them by LDS-DMA and converts nothing.  A P3 tensor is a torch.uint8 tensor [..., 6 * C].
+_ZERO_PAGE = {}
+P3_TILES = {0: (256, 128), 1: (128, 128), 2: (128, 64)}
+
+
+def zero_page(device):
+    z = _ZERO_PAGE.get(device)
+    if z is None:
+        z = _ZERO_PAGE[device] = torch.zeros(256, device=device, dtype=torch.uint8)
+    return z
+
+
+def p3_from_f32(x2d_rows, C_, x, ldx=None, out=None):
+    """fp32 [rows][C_] (row pitch ldx) -> P3 [rows][6*C_] bytes."""
+    ldx = C_ if ldx is None else ldx
+    if out is None:
+        out = torch.empty((x2d_rows, 6 * C_), device=x.device, dtype=torch.uint8)
+    check(_L().rih_p3_from_f32(x.data_ptr(), x2d_rows, C_, ldx, out.data_ptr(), C_, _stream()), 'rih_p3_from_f32')
+    return out
+
+
+def p3_weight(w, Cx, for_dgrad, sub=None):
+    """(P3 tensor [N][6*Kpad], Kpad) of an OIHW weight as forward operand (N = Cout) or as data-gradient operand of the tap
+    subset `sub` = (kh0, kw0, step, Th, Tw) (N = Cx)."""
+    Cout, Cin, KH, KW = w.shape
+    kh0, kw0, step, Th, Tw = sub if sub is not None else (0, 0, 1, KH, KW)
+    K = KH * KW * Cx if not for_dgrad else Th * Tw * Cout
+    Nn = Cout if not for_dgrad else Cx
+    Kp = _cdiv(K, 32) * 32
+    out = torch.empty((Nn, 6 * Kp), device=w.device, dtype=torch.uint8)
+    check(_L().rih_p3_conv_weight(w.data_ptr(), out.data_ptr(), Cout, Cin, KH, KW, Cx, 1 if for_dgrad else 0,
+                                  kh0, kw0, step, Th, Tw, Kp, _stream()), 'rih_p3_conv_weight')
+    return out, Kp
+
+
+def plan_p3(M, N, K):
+    """Tile of a P3 GEMM: the largest tile that still gives every CU a workgroup."""
+    for t in (0, 1, 2):
+        bm, bn = P3_TILES[t]
+        if N > 64 or t == 2:
+            if _cdiv(M, bm) * _cdiv(N, bn) >= 256 or t == 2:
+                return t
+    return 2
+
+
+def gemm_p3(A, B, Cout, M, N, K, lda, ldb, ldc, geom, bias=None, R=None, ldr=0, relu=False, cstride=None, stats=None,
+            tile=None, variant=0):
+    """Enqueue one rih_gemm_p3.  geom = (H, W, Cin, Ho, Wo, KH, KW, stride, padH, padW)."""
+    d = _lib.GemmP3Desc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
+    d.zero = zero_page(Cout.device).data_ptr()
+    d.bias, d.R, d.stats = _p(bias), _p(R), _p(stats)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
+    (d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.stride, d.padH, d.padW) = geom
+    if cstride is not None:
+        d.cS, d.cOH, d.cOW, d.cH, d.cW = cstride
+    d.relu = 1 if relu else 0
+    d.tile = plan_p3(M, N, K) if tile is None else tile
+    d.reserved0 = variant           # timing experiments of tools/p3_variants.py only (results garbage when != 0)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_L().rih_gemm_p3(C.byref(d), _stream()), 'rih_gemm_p3')
+        e1.record()
+        PROFILE.append((2.0 * M * N * K, e0, e1, (M, N, K, 1, 3, 3, 10 + d.tile, 1, 1)))
+        return
+    check(_L().rih_gemm_p3(C.byref(d), _stream()), 'rih_gemm_p3')
+
+
 def _pdiff(a, b):
     """Distance in floats between the storage of two fp32 tensors: the nb1 stride that walks from a left-hand parameter
     to the right-hand one, so that both hands' layers run as one batched launch."""

@@ -627,7 +627,7 @@ class EmulatedLib:
         faces = torch.from_numpy(_i32(tp.faces, Fn * 3).reshape(Fn, 3).astype(np.int64))
         J = torch.from_numpy(_f(tp.J, NJ * V).reshape(NJ, V).copy())
         perm = torch.from_numpy(_i32(tp.perm, Vc * pool).astype(np.int64))
-        w = [float(w[i]) for i in range(7)]
+        w = [float(x) for x in _f(w, 7)]
         P3 = torch.from_numpy(_f(v3p, B * V * 3).reshape(B, V, 3).copy()).requires_grad_(True)
         P2 = torch.from_numpy(_f(v2p, B * V * 2).reshape(B, V, 2).copy()).requires_grad_(True)
         C3 = torch.from_numpy(_f(c3p, B * Vc * 3).reshape(B, Vc, 3).copy()).requires_grad_(True)
@@ -670,6 +670,7 @@ class EmulatedLib:
     def rih_mesh_loss_final(self, pl, pr, B, w, cnt, out, stream):
         s = _f(pl, B * 8).reshape(B, 8).sum(0) + _f(pr, B * 8).reshape(B, 8).sum(0)
         o = _f(out, 8)
+        w, cnt = _f(w, 7), _f(cnt, 7)
         o[0] = sum(float(w[i]) * float(s[i]) for i in range(7))
         for i in range(7):
             o[1 + i] = 0.5 * float(s[i]) / float(cnt[i])

@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.join(HERE, 'hipcpu'))
 import test_gpu_loss as TL          # noqa: E402
 import test_gpu_mano as TMANO       # noqa: E402
 import test_gpu_ops as G            # noqa: E402
+import test_gpu_p3 as TP3          # noqa: E402
 import test_metrics as TMET         # noqa: E402
 import test_pose_head as TP         # noqa: E402
 
@@ -24,7 +25,7 @@ CPU = torch.device('cpu')
 @pytest.fixture(autouse=True)
 def _host_kernels(monkeypatch):
     from host_kernels import host_kernels_abi
-    for mod in (G, TL, TMANO):
+    for mod in (G, TL, TMANO, TP3):
         monkeypatch.setattr(mod, 'dev', lambda: CPU)
     with host_kernels_abi():
         yield
@@ -79,6 +80,18 @@ def test_graph_and_resampling_kernels():
     G.test_cheby_gather_project()
     G.test_pool_upsample_layout()
     G.test_resample_hrnet(2, 4, 4, 32)
+
+
+def test_p3_gemm_kernels():
+    """csrc/rih_gemm3.hip: P3 format, LDS-DMA staged 6-product GEMM on all three tiles, epilogue, statistics, dgrad."""
+    TP3.test_p3_format_round_trip()
+    for case in TP3.P3_CONV_CASES:
+        TP3.test_p3_conv_forward(case)
+    TP3.test_p3_epilogue_bias_residual_relu()
+    TP3.test_p3_tile_statistics_and_merge(0, (1, 16, 16, 32, 128))
+    TP3.test_p3_tile_statistics_and_merge(2, (2, 8, 8, 32, 64))
+    TP3.test_p3_data_gradient((2, 9, 7, 32, 64, 3, 2, 1))
+    TP3.test_p3_data_gradient((2, 8, 8, 64, 32, 3, 1, 1))
 
 
 def test_tile4_pipelined_gemm_kernel():

@@ -1,0 +1,37 @@
+#!/bin/bash
+# PMC pass (cycle counters only, own run) over tools/p3_pmc_driver.py: per kernel variant clock, MFMA-busy, wait breakdown.
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/${1:-r02_pmc}
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+rm -rf /tmp/pmcp3
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmcp3 -o pmc -- python $R/tools/p3_pmc_driver.py > $OUT/driver.log 2>&1
+f=$(find /tmp/pmcp3 -name "*counter_collection*.csv" | head -1)
+cp "$f" $OUT/p3_counter_collection.csv
+python - "$f" "$OUT/driver.log" > $OUT/p3_pmc_table.txt <<'PY'
+import csv, collections, json, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+plan = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+disp = collections.OrderedDict()
+for r in rows:
+    k = r['Kernel_Name']
+    if 'gemm_p3_kernel' not in k and 'gemm_split_kernel' not in k and 'gemm_split256' not in k:
+        continue
+    d = disp.setdefault(int(r['Dispatch_Id']), {'name': k, 'dur': int(r['End_Timestamp']) - int(r['Start_Timestamp'])})
+    d[r['Counter_Name']] = float(r['Counter_Value'])
+ds = [disp[k] for k in sorted(disp)]
+i = 0
+print('%-46s %9s %8s %9s %8s %8s %8s %8s' % ('variant', 'dur us', 'clk GHz', 'mfma-busy', 'TF', 'wait_any', 'wait_ins', 'active'))
+for p in plan:
+    g = ds[i:i + p['count']][2:]      # skip two warm-up launches
+    i += p['count']
+    m = lambda c: sum(x[c] for x in g) / len(g)
+    dur = m('dur')
+    cyc = m('GRBM_GUI_ACTIVE') / 8
+    wc = m('SQ_WAVE_CYCLES')
+    print('%-46s %9.1f %8.2f %8.1f%% %8.1f %7.1f%% %7.1f%% %7.1f%%' % (p['label'], dur / 1e3, cyc / dur,
+          100 * m('SQ_VALU_MFMA_BUSY_CYCLES') / (cyc * 1024), p['flop'] / dur / 1e3, 100 * m('SQ_WAIT_ANY') / wc,
+          100 * m('SQ_WAIT_INST_ANY') / wc, 100 * m('SQ_ACTIVE_INST_ANY') / wc))
+PY
+cat $OUT/p3_pmc_table.txt
