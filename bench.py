@@ -8,9 +8,17 @@ the reference's DDP semantics (gradient averaging, grad-less parameters tolerate
 bucketed RCCL all-reduce per step (renderih_amd/dp.py; `--ddp` switches to torch DDP itself); weak scaling (batch 64
 per GPU).
 
+The step is `renderih_amd.train.TrainStep`: forward + fused mesh loss + backward in three stages captured as hipGraphs, each
+stage's gradient bucket all-reduced on a side stream while the next stage runs, fused Adam; `comm_ms_exposed` is the time the
+compute stream waited for the last bucket.  `eager_reference_loop` is what the reference's UNMODIFIED loop gets on this
+package (eager launches, torch mirror of core/Loss.py, foreach Adam) -- measured next to the headline so that the cost of not
+adopting the three-line TrainStep patch is visible.
+
 Prints ONE JSON line (rank 0).  `roofline`: the GEMM/implicit-conv kernel family (rih_gemm), timed live with HIP events
 on the launch stream; achieved = SURVEY 8d algorithmic FLOPs (53.2 GFLOP/img fwd+bwd) x images per step / GEMM-family
-time per step.  The default engine computes every fp32 product as six bf16 MFMA products (three-term operand split,
+time per step (`achieved_launched` = the FLOPs actually launched: dead branches are skipped).  `roofline_hbm`: the BatchNorm
+kernel family (largest HBM-bound group) the same way in GB/s against 8 TB/s; `roofline_mano`: the MANO layer micro-benchmark
+(4096 hands, PCA-45) in GB/s of its algorithmic bytes.  The default engine computes every fp32 product as six bf16 MFMA products (three-term operand split,
 fp32 accumulate; DESIGN.md 3.1), so its peak is the dense bf16 MFMA peak / 6 = 416.7 TFLOP/s of fp32-equivalent work;
 the native f32 MFMA peak (157.3 TFLOP/s, engine 0, RIH_GEMM_ENGINE=0) is reported next to it.  `cpu_baseline`: the CPU oracle (a port of the
 reference's PyTorch-CPU path) timed on this box's host cores on a bounded sample (rank 0, N=1 only).
@@ -62,8 +70,11 @@ def synth_batch(B, device, seed):
     return img.to(device), {k: v.to(device) for k, v in lab.items()}
 
 
-def cpu_baseline(seconds=20.0, batch=4, family='a'):
-    """Oracle (CPU port of the reference path) forward+backward, bounded wall time."""
+def cpu_baseline(seconds=25.0, batch=16, family='a'):
+    """The CPU baseline of SURVEY 8d -- the reference's PyTorch-CPU path, forward + backward at B = 16, 3 warm-up + up to 10
+    timed iterations -- on THIS box's host cores.  kind = "port": /root/reference does not exist on the GPU box, so the
+    timed code is oracle/net_oracle.py, the functional restatement of the reference modules (same torch CPU operators in the
+    same order, pinned to the real modules by tests/golden); bounded to ~`seconds` of timed work."""
     from oracle import net_oracle
     from renderih_amd import assets
     from renderih_amd.model import build_model
@@ -79,20 +90,32 @@ def cpu_baseline(seconds=20.0, batch=4, family='a'):
             v.requires_grad_(True)
     graph = net_oracle.graph_from_dicts(assets.load_graph_dict('left'), assets.load_graph_dict('right'))
     img = torch.randn(batch, 3, 256, 256)
-    n, t_total = 0, 0.0
+    warm, n, t_total = 3, 0, 0.0
     t_start = time.time()
-    for it in range(50):
+    for it in range(warm + 10):
         t0 = time.time()
         out = net_oracle.handnet_forward(sd, graph, img, training=True)
         net_oracle.scalar_loss(out).backward()
         dt = time.time() - t0
-        if it > 0:                    # first iteration is warm-up
+        if it >= warm or (time.time() - t_start > seconds and it >= 1):
             n += 1
             t_total += dt
         if time.time() - t_start > seconds and n >= 1:
             break
     return {'value': round(batch * n / t_total, 3), 'unit': 'images/sec', 'cores': torch.get_num_threads(),
-            'kind': 'port', 'sample': 'oracle fwd+bwd, batch %d, %d timed iterations (~%.0fs)' % (batch, n, t_total)}
+            'kind': 'port', 'sample': 'oracle (CPU restatement of the reference path) fwd+bwd, batch %d, %d timed iterations '
+                                      '(%.0f s) after %d warm-up' % (batch, n, t_total, min(warm, it))}
+
+
+def mano_roofline(device, hands=4096, iters=20):
+    """MANO layer micro-benchmark as a second, HBM-bound roofline entry."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import mano_bench
+    r = mano_bench.measure(hands, iters, device)
+    return {'bound': 'hbm', 'achieved': r['fwd_GBps'], 'peak': 8000.0, 'unit': 'GB/s', 'frac': r['fwd_frac_of_8TBps'],
+            'traffic': None, 'kernel': 'rih_mano_fwd (ManoLayer.forward, %d hands, PCA-45): %.1f us, %.0f hands/s; '
+            'algorithmic bytes = 1.46 MB basis + 9.9 KB per hand' % (hands, r['fwd_us'], r['fwd_hands_per_s']),
+            'fwdbwd_hands_per_s': r['fwdbwd_hands_per_s']}
 
 
 def main():
@@ -116,6 +139,9 @@ def main():
                          'instead of renderih_amd.dp.GradAllReducer (same gradients, ~25 ms/step more host work)')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise RCCL and wrap the model in DDP even at world size 1 (exercises the N>1 code path)')
+    ap.add_argument('--no-stages', action='store_true', help='one backward stage / one gradient bucket instead of three')
+    ap.add_argument('--no-overlap', action='store_true', help='all-reduce on the compute stream (no overlap with backward)')
+    ap.add_argument('--no-reference-loop', action='store_true', help="skip the 5-step measurement of the reference's unmodified loop")
     ap.add_argument('--dump-gemm', default=None, help='write the per-launch GEMM profile of one step to this JSON file')
     args = ap.parse_args()
     if args.batch is None:
@@ -150,12 +176,8 @@ def main():
         model = build_model(dropout=0.05, encoder_type=args.encoder).to(device).train()
     model.decoder.unsample_layer.weight.requires_grad_(False)          # core/gcn_trainer.py:102-103
     net = model
-    reducer = None
     if dist_on and args.ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=True)
-    elif dist_on:
-        from renderih_amd.dp import GradAllReducer
-        reducer = GradAllReducer(model)                 # one 156 MB bucket, one RCCL all-reduce after backward
     # the reference's optimizer (utils/defaults.yaml: Adam, lr 3e-4, weight decay 1e-2); fused=True = torch's single
     # multi-tensor kernel instead of ~10 foreach passes over the 39 M parameters (2.1 -> 0.3 ms per step)
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=3e-4, weight_decay=1e-2, fused=True)
@@ -167,91 +189,109 @@ def main():
     B = args.batch
     img, lab = synth_batch(B, device, seed=rank)
 
+    def loss_fn(out, labels):
+        return calc_loss_GCN_fused(fused_loss, 0, *out, labels['v2d_l'], labels['v2d_r'], labels['v3d_l'], labels['v3d_r'],
+                                   labels['root_rel'])[0]
+
     def fwd_bwd(module=None):
-        out = (net if module is None else module)(img)
-        loss, _ = calc_loss_GCN_fused(fused_loss, 0, *out, lab['v2d_l'], lab['v2d_r'], lab['v3d_l'], lab['v3d_r'],
-                                      lab['root_rel'])
+        loss = loss_fn((net if module is None else module)(img), lab)
         loss.backward()
         return loss
-
-    def step_eager():
-        opt.zero_grad(set_to_none=True)
-        loss = fwd_bwd()
-        if reducer is not None:
-            reducer.reduce()
-        opt.step()
-        return loss
-
-    # hipGraph: forward + loss + backward (~2700 kernel launches, ~55 ms of Python/launch work per step, about as
-    # long as the GPU work itself) are captured once and replayed; the ~110 launches of gradient exchange + Adam stay
-    # eager.  Dropout masks stay fresh because the kernels add a device-resident seed word that the graph advances.
-    use_graph = not args.no_graph and not args.ddp
-    step = step_eager
-    if use_graph:
-        seed_word = torch.zeros(1, dtype=torch.int64, device=device)
-        ops.DROPOUT_SEED_TENSOR = seed_word
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):                      # warm-up on the capture stream (lazy index tables, allocator)
-                step_eager()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()                    # no warm-up collective may still be in flight while capturing
-        if dist_on:
-            torch.distributed.barrier()
-        opt.zero_grad(set_to_none=True)
-        graph = torch.cuda.CUDAGraph()
-        try:
-            with torch.cuda.graph(graph):
-                seed_word.add_(0x9E3779B1)
-                static_loss = fwd_bwd()
-        except Exception as exc:                    # keep the benchmark alive: the eager step issues the same collectives
-            print('[bench] hipGraph capture failed on rank %d (%s: %s); launching eagerly' % (rank, type(exc).__name__, exc),
-                  file=sys.stderr, flush=True)
-            use_graph = False
-            ops.DROPOUT_SEED_TENSOR = None
-            torch.cuda.synchronize()
-            opt.zero_grad(set_to_none=True)
-    if use_graph:
-        if reducer is not None:
-            reducer.use_static_grads()              # replays rewrite these gradient buffers in place
-
-        def step():
-            graph.replay()                          # gradients are rewritten in place in the graph's static buffers
-            if reducer is not None:
-                reducer.reduce()
-            opt.step()
-            return static_loss
 
     def barrier():
         if dist_on:
             torch.distributed.barrier()
 
+    eager_ref = None
+    if rank == 0 and world == 1 and not args.no_reference_loop and not args.ddp:
+        # the reference's unmodified loop (core/gcn_trainer.py:219-251) on this package: eager launches, the torch mirror of
+        # core/Loss.py, optimizer.zero_grad / backward / step with torch's default (foreach) Adam
+        from renderih_amd.loss import calc_loss_GCN
+        opt_ref = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=3e-4, weight_decay=1e-2)
+        state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+        def ref_step():
+            opt_ref.zero_grad()
+            out = model(img)
+            loss, _ = calc_loss_GCN(None, 0, gl['left'], gl['right'], conv['left'], conv['right'], *out, lab['v2d_l'],
+                                    lab['v2d_r'], lab['v3d_l'], lab['v3d_r'], lab['root_rel'])
+            loss.backward()
+            opt_ref.step()
+        for _ in range(2):
+            ref_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ref_step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        eager_ref = {'images_per_sec': round(B / dt, 1), 'ms_per_step': round(1e3 * dt, 2),
+                     'what': 'unmodified reference loop on this package: eager kernel launches, core/Loss.py torch mirror, '
+                             'foreach Adam (no TrainStep, no hipGraph, no fused loss)'}
+        model.load_state_dict(state0)
+        del opt_ref, state0
+        for p_ in model.parameters():
+            p_.grad = None
+
+    use_graph = not args.no_graph and not args.ddp
+    trainer = None
+    if args.ddp:
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = fwd_bwd()
+            opt.step()
+            return loss
+    else:
+        from renderih_amd.train import TrainStep
+        try:
+            trainer = TrainStep(model, opt, loss_fn, (img, lab), use_graph=use_graph, stages=not args.no_stages,
+                                overlap=not args.no_overlap, force_exchange=args.force_dist)
+        except Exception as exc:                    # keep the benchmark alive if capture fails: same step, launched eagerly
+            print('[bench] hipGraph capture failed on rank %d (%s: %s); launching eagerly' % (rank, type(exc).__name__, exc),
+                  file=sys.stderr, flush=True)
+            use_graph = False
+            ops.DROPOUT_SEED_TENSOR = None
+            torch.cuda.synchronize()
+            trainer = TrainStep(model, opt, loss_fn, (img, lab), use_graph=False, stages=not args.no_stages,
+                                overlap=not args.no_overlap, force_exchange=args.force_dist)
+        use_graph = trainer.use_graph
+        step = trainer
+
     for _ in range(args.warmup):
         step()
     barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    ms_median = per_step[len(per_step) // 2]
     if dist_on:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.item())
+    comm_exposed = trainer.comm_ms_exposed() if trainer is not None else None
 
-    roof = None
+    roof = roof_hbm = roof_mano = None
     if not args.no_roofline and rank == 0:
         ops.PROFILE = []
-        opt.zero_grad(set_to_none=True)
+        ops.PROFILE_ELEM = []
+        for p_ in model.parameters():
+            p_.grad = None
         fwd_bwd(model)  # local forward + loss + backward on the bare module: the other ranks are not in this block, so
         #                 no collective may be issued here (no reducer, no DDP wrapper)
         torch.cuda.synchronize()
         recs = ops.PROFILE
+        erecs = ops.PROFILE_ELEM
         ops.PROFILE = None
+        ops.PROFILE_ELEM = None
         # an event pair around NOTHING still measures ~2-4 us (record/timestamp cost); calibrate it and take it off every
         # launch, otherwise the ~700 decoder-sized launches of 10-20 us are over-counted against the rocprofv3 durations
         pairs = []
@@ -285,8 +325,15 @@ def main():
         achieved = gflop_img * B / ms            # GFLOP / ms = TFLOP/s
         split = (ops.ENGINE == 1)
         peak = PEAK_BF16_MFMA_TF / 6.0 if split else PEAK_FP32_MFMA_TF
+        ems = sum(max(e0.elapsed_time(e1) - empty, 0.0) for _, e0, e1, _ in erecs)
+        ebytes = sum(b_ for b_, _, _, _ in erecs)
+        roof_hbm = {'bound': 'hbm', 'achieved': round(ebytes / max(ems, 1e-9) / 1e6, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                    'frac': round(ebytes / max(ems, 1e-9) / 1e6 / 8000.0, 4), 'traffic': None,
+                    'kernel': 'BatchNorm family (rih_bn_stats + rih_bn_apply, rih_bn_bwd: %d calls, %.2f ms and %.1f GB of '
+                              'algorithmic traffic per step; each call = 2 launches)' % (len(erecs), ems, ebytes / 1e9)}
         roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                 'frac': round(achieved / peak, 4),
+                'achieved_launched': round(launched / ms / 1e9, 2), 'frac_launched': round(launched / ms / 1e9 / peak, 4),
                 'traffic': measured_traffic() if args.encoder == 'resnet50' and B == 64 and args.family == 'a' else None,
                 'kernel': ('rih_gemm engine 1 (gemm_split_kernel / gemm_split256_kernel: fp32 = 6 x '
                            'v_mfma_f32_32x32x16_bf16 on a 3-term bf16 split; peak = 2500 TF/s bf16 dense / 6)'
@@ -300,6 +347,11 @@ def main():
                 'top_variant': {'name': top[0], 'launches': top[1][0], 'ms': round(top[1][1], 3),
                                 'tflops': round(top[1][2] / top[1][1] / 1e9, 2)}}
 
+    if not args.no_roofline and rank == 0 and world == 1:
+        try:
+            roof_mano = mano_roofline(device)
+        except Exception as exc:  # noqa: BLE001
+            print('[bench] MANO micro-benchmark failed: %s' % exc, file=sys.stderr, flush=True)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(family=args.family) if args.family != 'b-mano' else None
@@ -308,7 +360,8 @@ def main():
         n_img = B * world * args.steps
         line = {'metric': 'images/sec fwd+bwd @256x256 two-hand', 'value': round(n_img / elapsed, 2),
                 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-                'ms_per_step': round(1000.0 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+                'ms_per_step': round(1000.0 * elapsed / args.steps, 3), 'ms_per_step_median_hip_events': round(ms_median, 3),
+                'higher_is_better': True, 'scaling': 'weak',
                 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                 'config': {'workload': ('second model family (common/myhand/lijun_model_graph.load_graph_model): batch=%d/GPU '
                                         '256x256 ResNet50 trunk + MLP-block dual-graph decoder, fwd + loss + bwd + Adam step, '
@@ -321,10 +374,18 @@ def main():
                            else ('BASELINE configs[3] model: batch=%d/GPU 256x256 HRNet-W32 + cross-hand attention decoder, '
                                  'fwd + loss + bwd + Adam step, dropout 0.05, fp32' % B),
                            'global_batch': B * world, 'parallelism': 'dp%d' % world, 'loss': round(final_loss, 4),
-                           'hipgraph': bool(use_graph), 'presplit_weights': bool(ops.PRESPLIT), 'presplit_activations': bool(ops.PRESPLIT_ACT), 'fused_attention': bool(ops.FUSED_ATTN),
+                           'hipgraph': bool(use_graph),
+                           'backward_stages': (trainer.nstage if trainer is not None else 1),
+                           'gradient_buckets_MB': ([round(x / 1e6, 1) for x in trainer.bucket_bytes()] if trainer is not None else None),
+                           'grad_allreduce': ('none (1 rank)' if not dist_on else 'torch DDP' if args.ddp else
+                                              'per-stage buckets on a side stream, overlapped with the next backward stage'
+                                              if not args.no_overlap else 'per-stage buckets on the compute stream'),
+                           'presplit_weights': bool(ops.PRESPLIT), 'presplit_activations': bool(ops.PRESPLIT_ACT), 'fused_attention': bool(ops.FUSED_ATTN),
                            'gemm_engine': ('fp32 via 3-term bf16 split, 6 MFMA products, fp32 accumulate (fp32-grade error)'
                                            if ops.ENGINE == 1 else 'native f32 MFMA')},
-                'roofline': roof, 'cpu_baseline': cpu}
+                'comm_ms_exposed': (None if comm_exposed is None else round(comm_exposed, 3)),
+                'eager_reference_loop': eager_ref,
+                'roofline': roof, 'roofline_hbm': roof_hbm, 'roofline_mano': roof_mano, 'cpu_baseline': cpu}
         print(json.dumps(line), flush=True)
     if dist_on:
         torch.distributed.barrier()

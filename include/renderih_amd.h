@@ -298,7 +298,14 @@ int rih_cheby_bwd(const float* dy, const int32_t* t_indptr, const int32_t* t_ind
  *   v_template[778][3], J_reg[16][778] (dense), weights[778][16], parent[16] (host array).
  * Per call: root[B][9], pose (PCA coeffs [B][ncomp] if ncomp>0, else rotation matrices [B][15][9]),
  *   shape[B][10], trans[B][3] or NULL, scale[B] or NULL.  Outputs v[B][778][3], j[B][21][3].
- * ws: >= rih_mano_ws_floats(B) floats, kept by the caller for the backward.                            */
+ * packed: >= rih_mano_pack_floats() floats (16-byte aligned) written by rih_mano_pack from the model buffers: the blend
+ *   bases as one k-major matrix [148][2496] (posedirs | shapedirs | v_template, coordinates padded to 13 tiles of 192) and
+ *   the joint regressor folded onto template and shape basis.  Re-pack whenever a model buffer changes (the reference's
+ *   callers mutate shapedirs in place, dataset/interhand.py:22-25).
+ * rih_mano_fwd variant 0: ONE fused launch (workgroup = 64-vertex tile of the packed basis pinned in LDS x group of hand
+ *   chunks; pose chain per chunk, blend GEMM on v_mfma_f32_16x16x4_f32, skinning).  ws may be NULL (inference: only v and j
+ *   are written); with ws (>= rih_mano_ws_floats(B) floats, kept by the caller) it also stores what rih_mano_bwd needs.
+ *   variant 1: the two-kernel forward of round 1 (needs ws; kept for A/B timing).                                      */
 typedef struct rih_mano_model {
     const float* comps;
     const float* hands_mean;
@@ -311,9 +318,11 @@ typedef struct rih_mano_model {
 } rih_mano_model;
 
 int64_t rih_mano_ws_floats(int B);
-int rih_mano_fwd(const rih_mano_model* m, const float* root, const float* pose, int ncomp, const float* shape,
-                 const float* trans, const float* scale, int center_idx, int new_skel, float* v, float* j,
-                 float* ws, int B, void* stream);
+int64_t rih_mano_pack_floats(void);
+int rih_mano_pack(const rih_mano_model* m, float* packed, void* stream);
+int rih_mano_fwd(const rih_mano_model* m, const float* packed, const float* root, const float* pose, int ncomp,
+                 const float* shape, const float* trans, const float* scale, int center_idx, int new_skel, float* v,
+                 float* j, float* ws, int B, int variant, void* stream);
 /* gradients wrt root/pose/shape/trans/scale (any may be NULL) given dv[B][778][3], dj[B][21][3] */
 int rih_mano_bwd(const rih_mano_model* m, const float* root, const float* pose, int ncomp, const float* shape,
                  const float* trans, const float* scale, int center_idx, int new_skel, const float* dv,
@@ -355,7 +364,7 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
  * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of the by-pointer structs
  * (gemm desc, mano model, mesh topo, hconv desc), so a host binding can refuse a stale binary instead of handing it
  * mis-laid-out structs. */
-#define RIH_ABI_VERSION 2
+#define RIH_ABI_VERSION 3
 int rih_version(void);
 int rih_abi_sizes(int32_t* out4);
 const char* rih_arch(void);

@@ -137,7 +137,9 @@ SIGNATURES = {
     'rih_cheby_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, C.c_void_p]),
     'rih_mano_ws_floats': (c_l, [c_i]),
     'rih_mano_bwd_ws_floats': (c_l, [c_i]),
-    'rih_mano_fwd': (c_i, [C.POINTER(ManoModel), c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_i,
+    'rih_mano_pack_floats': (c_l, []),
+    'rih_mano_pack': (c_i, [C.POINTER(ManoModel), c_f, C.c_void_p]),
+    'rih_mano_fwd': (c_i, [C.POINTER(ManoModel), c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_i, c_i,
                            C.c_void_p]),
     'rih_mano_bwd': (c_i, [C.POINTER(ManoModel), c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f,
                            c_f, c_f, c_f, c_f, c_f, c_f, c_i, C.c_void_p]),
@@ -154,7 +156,7 @@ SIGNATURES = {
     'rih_arch': (C.c_char_p, []),
 }
 
-ABI_VERSION = 2      # = RIH_ABI_VERSION of include/renderih_amd.h
+ABI_VERSION = 3      # = RIH_ABI_VERSION of include/renderih_amd.h
 
 _lib = None
 

@@ -1,13 +1,19 @@
 // rih_mano.hip -- MANO linear-blend-skinning layer (models/manolayer.py:250-322) for gfx950.
 //
-// Forward = two kernels:
-//   mano_pose_kernel   one workgroup per hand: PCA -> axis-angle -> Rodrigues, shape blend, joint regression,
-//                      kinematic chain (16 SE3), the 13 "special" vertices (5 finger tips + 8 new_skel vertices),
-//                      21 output joints, centre/scale/translation.  Everything small stays in LDS.
-//   mano_vertex_kernel vertex-tiled: a 64-vertex tile of the pose-blend basis (64 x 405 fp32 = 101 KB of the
-//                      1.26 MB posedirs) is pinned in LDS once per workgroup and reused for every hand of the
-//                      workgroup's batch chunk; lane = vertex (LDS row stride 405 is odd -> conflict-free
-//                      ds_read_b32), per-hand pose features and SE3s come in through scalar loads (wave-uniform).
+// Forward = ONE kernel (mano_fused_kernel) over a packed basis:
+//   rih_mano_pack      (once per change of the model buffers; the host caches it on the buffers' version counters) lays the
+//                      blend bases out as one k-major matrix Bmat[148][2496]: rows 0..134 posedirs, 135..144 shapedirs,
+//                      145 v_template, 146..147 zero, columns = 778 x 3 coordinates padded to 13 x 192; and folds the joint
+//                      regressor into Jt = J_reg v_template [16][3], Js = J_reg shapedirs [16][3][10].
+//   mano_fused_kernel  workgroup = (tile of 64 vertices, group of hand chunks).  The tile of the basis (148 x 192 fp32 =
+//                      111 KB) is pinned in LDS for the whole workgroup.  Per chunk of 16 hands: (1) PCA -> axis-angle ->
+//                      Rodrigues, rest joints Jt + Js beta, 16-joint SE3 chain, tips, centre / scale / translation, all in
+//                      LDS (redone by each of the 13 vertex tiles: 3 kFLOP per hand against 90 kFLOP of tile work -- cheaper
+//                      than a round trip through memory and a second launch); (2) the blend GEMM
+//                      v_tpose[16 hands][192] = [pose feature | beta | 1][16][148] x Bmat tile on v_mfma_f32_16x16x4_f32
+//                      (exact fp32: a k-ordered fmaf chain); (3) skinning, lane = vertex, SE3s read from LDS.
+//                      Inference writes only v and j; with ws != NULL (training) it also fills the backward's workspace.
+//   (mano_pose_kernel / mano_vertex_kernel: the two-kernel forward of round 1, kept as `variant 1` for A/B timing.)
 // Backward = one workgroup per hand (mano_bwd_kernel): reverse LBS, chain, blend shapes, Rodrigues, PCA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -304,6 +310,287 @@ __global__ __launch_bounds__(256) void mano_vertex_kernel(Model m, float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------ packed basis
+constexpr int KP = 148;                 // 135 pose features + 10 betas + 1 (template) + 2 zero rows
+constexpr int NCP = NTILES * 192;       // 2496 padded coordinates
+constexpr int PK_JT = KP * NCP;         // Jt[16][3]
+constexpr int PK_JS = PK_JT + 48;       // Js[16][3][10]
+constexpr int PK_FLOATS = PK_JS + 480;
+
+__global__ void mano_pack_basis_kernel(Model m, float* __restrict__ pk) {
+    const long long total = (long long)KP * NCP;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i / NCP), n = (int)(i - (long long)k * NCP);
+        float v = 0.f;
+        if (n < NVC) {
+            if (k < NPF) v = m.posedirs[(long long)n * NPF + k];
+            else if (k < NPF + 10) v = m.shapedirs[n * 10 + (k - NPF)];
+            else if (k == NPF + 10) v = m.v_template[n];
+        }
+        pk[i] = v;
+    }
+}
+// one wavefront per output: Jt[j][c] = sum_v J_reg[j][v] v_template[v][c];  Js[j][c][s] = sum_v J_reg[j][v] shapedirs[v][c][s]
+__global__ void mano_pack_joints_kernel(Model m, float* __restrict__ pk) {
+    const int o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (o >= 528) return;
+    float a = 0.f;
+    if (o < 48) {
+        const int j = o / 3, c = o % 3;
+        for (int v = lane; v < NV; v += 64) a += m.J_reg[j * NV + v] * m.v_template[v * 3 + c];
+    } else {
+        const int q = o - 48, j = q / 30, c = (q / 10) % 3, sdx = q % 10;
+        for (int v = lane; v < NV; v += 64) a += m.J_reg[j * NV + v] * m.shapedirs[(v * 3 + c) * 10 + sdx];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if (lane == 0) pk[PK_JT + o] = a;
+}
+
+// ------------------------------------------------------------------------------------------------ fused forward
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int HC = 16;                  // hands per chunk = one 16-row MFMA block
+constexpr int LDPF = 149;               // odd row stride of the pose-feature operand: conflict-free column reads
+constexpr int GST = 200;                // per-hand SE3s (16 x 12) + post (8)
+constexpr int SCR = 392;                // per-hand phase-1 scratch: axis 48 | R 144 | jt 48 | src 63 | sp 39 | spt 39 | pad
+constexpr int S_AX = 0, S_RR = 48, S_JT = 192, S_SRC = 240, S_SP = 303, S_SPT = 342;
+constexpr int FUSED_LDS_FLOATS = KP * 192 + HC * LDPF + HC * GST + HC * SCR;     // 40,128 floats = 160,512 B
+static_assert(FUSED_LDS_FLOATS * 4 <= 163840, "LDS budget");
+static_assert(HC * 192 <= HC * SCR, "the v_tpose tile aliases the phase-1 scratch");
+
+__global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* __restrict__ pk,
+                                                         const float* __restrict__ root, const float* __restrict__ pose,
+                                                         int ncomp, const float* __restrict__ shape,
+                                                         const float* __restrict__ trans, const float* __restrict__ scale,
+                                                         int center_idx, int new_skel, float* __restrict__ vout,
+                                                         float* __restrict__ jout, float* __restrict__ ws, int B) {
+    __shared__ __attribute__((aligned(16))) float smem[FUSED_LDS_FLOATS];
+    float* s_B = smem;                          // [KP][192] basis tile
+    float* s_pf = s_B + KP * 192;               // [HC][LDPF] pose feature | beta | 1 | 0 0
+    float* s_G = s_pf + HC * LDPF;              // [HC][GST]
+    float* s_scr = s_G + HC * GST;              // [HC][SCR] phase-1 scratch, later [HC][192] v_tpose tile
+    const int tile = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int v0 = tile * TILE_V, n0 = tile * 192;
+    // does this workgroup need the 13 special vertices (tips / new_skel)?  Tile 0 writes the joints; every tile needs the
+    // centre joint, which is a tip when new_order[center] >= 16.
+    const bool centre_is_tip = center_idx >= 0 && c_new_order[center_idx] >= 16;
+    const bool need_special = (tile == 0) || centre_is_tip;
+
+    // pin the basis tile: rows are 192 contiguous floats of Bmat
+    for (int i = t; i < KP * 48; i += 256) {
+        const int k = i / 48, q = i - k * 48;
+        *reinterpret_cast<float4*>(s_B + k * 192 + 4 * q) = *reinterpret_cast<const float4*>(pk + (long long)k * NCP + n0 + 4 * q);
+    }
+    const int v = v0 + lane;
+    const bool valid = v < NV;
+    float wgt[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) wgt[j] = valid ? m.weights[v * NJ + j] : 0.f;
+
+    const int nchunks = (B + HC - 1) / HC;
+    for (int chunk = blockIdx.y; chunk < nchunks; chunk += gridDim.y) {
+        const int h0 = chunk * HC;
+        __syncthreads();                        // previous chunk's skinning is done with s_G / s_scr
+        // ---- phase 1a: axis-angle (PCA), beta, constant columns of the operand
+        for (int i = t; i < HC * 48; i += 256) {
+            const int hl = i / 48, e = i - hl * 48, h = h0 + hl;
+            float a = 0.f;
+            if (e < 45 && h < B && ncomp > 0) {
+                a = m.hands_mean[e];
+                for (int c = 0; c < ncomp; ++c) a += pose[(long long)h * ncomp + c] * m.comps[c * 45 + e];
+            }
+            s_scr[hl * SCR + S_AX + e] = a;
+        }
+        for (int i = t; i < HC * 13; i += 256) {
+            const int hl = i / 13, e = i - hl * 13, h = h0 + hl;
+            float x = 0.f;
+            if (h < B) x = (e < 10) ? shape[h * 10 + e] : (e == 10 ? 1.f : 0.f);
+            s_pf[hl * LDPF + NPF + e] = x;
+        }
+        __syncthreads();
+        // ---- phase 1b: rotations (thread = (hand, joint)), rest joints (thread = (hand, joint, coord))
+        if (t < HC * NJ) {
+            const int hl = t >> 4, j = t & 15, h = h0 + hl;
+            float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+            if (h < B) {
+                if (j == 0) {
+                    for (int e = 0; e < 9; ++e) R[e] = root[(long long)h * 9 + e];
+                } else if (ncomp > 0) {
+                    rodrigues_fwd(&s_scr[hl * SCR + S_AX + (j - 1) * 3], R);
+                } else {
+                    for (int e = 0; e < 9; ++e) R[e] = pose[((long long)h * 15 + (j - 1)) * 9 + e];
+                }
+            }
+            for (int e = 0; e < 9; ++e) {
+                s_scr[hl * SCR + S_RR + j * 9 + e] = R[e];
+                if (j > 0) s_pf[hl * LDPF + (j - 1) * 9 + e] = (h < B) ? R[e] - ((e % 4 == 0) ? 1.f : 0.f) : 0.f;
+            }
+            if (ws != nullptr && tile == 0 && h < B)
+                for (int e = 0; e < 9; ++e) ws[(long long)h * WS_STRIDE + OFF_R + j * 9 + e] = R[e];
+        }
+        for (int i = t; i < HC * 48; i += 256) {
+            const int hl = i / 48, e = i - hl * 48;
+            float a = pk[PK_JT + e];
+#pragma unroll
+            for (int sdx = 0; sdx < 10; ++sdx) a += pk[PK_JS + e * 10 + sdx] * s_pf[hl * LDPF + NPF + sdx];
+            s_scr[hl * SCR + S_JT + e] = a;
+            if (ws != nullptr && tile == 0 && h0 + hl < B) ws[(long long)(h0 + hl) * WS_STRIDE + OFF_JT + e] = a;
+        }
+        __syncthreads();
+        // ---- phase 1c: kinematic chain, one lane per hand (manolayer.py:274-289)
+        if (t < HC) {
+            const float* Rr = &s_scr[t * SCR + S_RR];
+            const float* jt = &s_scr[t * SCR + S_JT];
+            float* G = &s_G[t * GST];
+            float* src = &s_scr[t * SCR + S_SRC];
+            for (int i = 0; i < NJ; ++i) {
+                const float* R = Rr + i * 9;
+                const float* jv = jt + i * 3;
+                float tl[3];
+                for (int r = 0; r < 3; ++r) tl[r] = jv[r] - (R[r * 3] * jv[0] + R[r * 3 + 1] * jv[1] + R[r * 3 + 2] * jv[2]);
+                float* Gi = G + i * 12;
+                if (i == 0) {
+                    for (int r = 0; r < 3; ++r) {
+                        for (int c = 0; c < 3; ++c) Gi[r * 4 + c] = R[r * 3 + c];
+                        Gi[r * 4 + 3] = tl[r];
+                        src[r] = jv[r];
+                    }
+                } else {
+                    const float* P = G + m.parent[i] * 12;
+                    for (int r = 0; r < 3; ++r) {
+                        for (int c = 0; c < 3; ++c)
+                            Gi[r * 4 + c] = P[r * 4] * R[c] + P[r * 4 + 1] * R[3 + c] + P[r * 4 + 2] * R[6 + c];
+                        Gi[r * 4 + 3] = P[r * 4] * tl[0] + P[r * 4 + 1] * tl[1] + P[r * 4 + 2] * tl[2] + P[r * 4 + 3];
+                        src[i * 3 + r] = P[r * 4] * jv[0] + P[r * 4 + 1] * jv[1] + P[r * 4 + 2] * jv[2] + P[r * 4 + 3];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 1d: the 13 special vertices (5 tips + 8 new_skel), blend from the packed basis in global memory
+        if (need_special) {
+            for (int i = t; i < HC * 39; i += 256) {
+                const int hl = i / 39, e = i - hl * 39;
+                const int vc = c_special[e / 3] * 3 + e % 3;
+                float a = 0.f;
+                for (int k = 0; k < NPF + 11; ++k) a = fmaf(s_pf[hl * LDPF + k], pk[(long long)k * NCP + vc], a);
+                s_scr[hl * SCR + S_SPT + e] = a;
+            }
+            __syncthreads();
+            for (int i = t; i < HC * 13; i += 256) {
+                const int hl = i / 13, q = i - hl * 13, vv = c_special[q];
+                float T[12];
+                for (int e = 0; e < 12; ++e) T[e] = 0.f;
+                for (int j = 0; j < NJ; ++j) {
+                    const float wj = m.weights[vv * NJ + j];
+                    for (int e = 0; e < 12; ++e) T[e] += wj * s_G[hl * GST + j * 12 + e];
+                }
+                const float* x = &s_scr[hl * SCR + S_SPT + q * 3];
+                for (int r = 0; r < 3; ++r)
+                    s_scr[hl * SCR + S_SP + q * 3 + r] = T[r * 4] * x[0] + T[r * 4 + 1] * x[1] + T[r * 4 + 2] * x[2] + T[r * 4 + 3];
+            }
+            __syncthreads();
+            for (int i = t; i < HC * 15; i += 256) {
+                const int hl = i / 15, e = i - hl * 15;
+                s_scr[hl * SCR + S_SRC + 48 + e] = s_scr[hl * SCR + S_SP + e];       // tips = special[0..4]
+            }
+            __syncthreads();
+        }
+        // ---- phase 1e: centre / scale / translation; tile 0 writes the 21 joints (and the joint-side workspace)
+        if (t < HC) {
+            const int h = h0 + t;
+            float* post = &s_G[t * GST + 192];
+            for (int c = 0; c < 3; ++c) post[c] = (center_idx >= 0) ? s_scr[t * SCR + S_SRC + c_new_order[center_idx] * 3 + c] : 0.f;
+            post[3] = (scale != nullptr && h < B) ? scale[h] : 1.f;
+            for (int c = 0; c < 3; ++c) post[4 + c] = (trans != nullptr && h < B) ? trans[h * 3 + c] : 0.f;
+            post[7] = 0.f;
+        }
+        __syncthreads();
+        if (tile == 0) {
+            for (int i = t; i < HC * 63; i += 256) {
+                const int hl = i / 63, e = i - hl * 63, h = h0 + hl;
+                if (h >= B) continue;
+                const int k = e / 3, c = e % 3;
+                const float* post = &s_G[hl * GST + 192];
+                const float jc = s_scr[hl * SCR + S_SRC + c_new_order[k] * 3 + c] - post[c];
+                float o = jc * post[3] + post[4 + c];
+                if (new_skel) {
+                    for (int q = 0; q < 4; ++q)
+                        if (c_ns_joint[q] == k) {
+                            const float va = (s_scr[hl * SCR + S_SP + (5 + 2 * q) * 3 + c] - post[c]) * post[3] + post[4 + c];
+                            const float vb = (s_scr[hl * SCR + S_SP + (6 + 2 * q) * 3 + c] - post[c]) * post[3] + post[4 + c];
+                            o = (va + vb) / 2.f;
+                        }
+                }
+                jout[(long long)h * 63 + e] = o;
+                if (ws != nullptr) ws[(long long)h * WS_STRIDE + OFF_J21C + e] = jc;
+            }
+            if (ws != nullptr)
+                for (int i = t; i < HC * GST; i += 256) {
+                    const int hl = i / GST, e = i - hl * GST, h = h0 + hl;
+                    if (h < B) ws[(long long)h * WS_STRIDE + OFF_G + e] = s_G[i];     // OFF_POST = OFF_G + 192
+                }
+            __syncthreads();            // the scratch (src / sp) is overwritten by the v_tpose tile below
+        }
+        // ---- phase 2: v_tpose[16][192] = operand[16][148] x Bmat tile; wave w owns coordinate blocks 3w .. 3w+2
+        floatx4 acc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        {
+            const float* a_rd = s_pf + (lane & 15) * LDPF + (lane >> 4);
+            const float* b_rd = s_B + (lane >> 4) * 192 + wave * 48 + (lane & 15);
+#pragma unroll 4
+            for (int ks = 0; ks < KP / 4; ++ks) {
+                const float a = a_rd[4 * ks];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b_rd[4 * ks * 192 + 16 * j], acc[j], 0, 0, 0);
+            }
+        }
+        // C/D layout: column = lane & 15 (coordinate), row = 4 * (lane >> 4) + r (hand)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_scr[(4 * (lane >> 4) + r) * 192 + wave * 48 + 16 * j + (lane & 15)] = acc[j][r];
+        __syncthreads();
+        // ---- phase 3: skinning, lane = vertex, wave w takes hands w, w+4, ...
+        for (int hl = wave; hl < HC; hl += 4) {
+            const int h = h0 + hl;
+            if (h >= B) break;                                  // wave-uniform
+            const float* G = &s_G[hl * GST];
+            float T[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float4 g0 = *reinterpret_cast<const float4*>(G + j * 12);
+                const float4 g1 = *reinterpret_cast<const float4*>(G + j * 12 + 4);
+                const float4 g2 = *reinterpret_cast<const float4*>(G + j * 12 + 8);
+                T[0] += wgt[j] * g0.x; T[1] += wgt[j] * g0.y; T[2] += wgt[j] * g0.z; T[3] += wgt[j] * g0.w;
+                T[4] += wgt[j] * g1.x; T[5] += wgt[j] * g1.y; T[6] += wgt[j] * g1.z; T[7] += wgt[j] * g1.w;
+                T[8] += wgt[j] * g2.x; T[9] += wgt[j] * g2.y; T[10] += wgt[j] * g2.z; T[11] += wgt[j] * g2.w;
+            }
+            const float* post = G + 192;
+            const float vt0 = s_scr[hl * 192 + lane * 3], vt1 = s_scr[hl * 192 + lane * 3 + 1], vt2 = s_scr[hl * 192 + lane * 3 + 2];
+            if (valid) {
+                const float x = T[0] * vt0 + T[1] * vt1 + T[2] * vt2 + T[3] - post[0];
+                const float y = T[4] * vt0 + T[5] * vt1 + T[6] * vt2 + T[7] - post[1];
+                const float z = T[8] * vt0 + T[9] * vt1 + T[10] * vt2 + T[11] - post[2];
+                float* o = vout + ((long long)h * NV + v) * 3;
+                o[0] = x * post[3] + post[4];
+                o[1] = y * post[3] + post[5];
+                o[2] = z * post[3] + post[6];
+                if (ws != nullptr) {
+                    float* w = ws + (long long)h * WS_STRIDE;
+                    w[OFF_VT + v * 3 + 0] = vt0; w[OFF_VT + v * 3 + 1] = vt1; w[OFF_VT + v * 3 + 2] = vt2;
+                    w[OFF_VSC + v * 3 + 0] = x; w[OFF_VSC + v * 3 + 1] = y; w[OFF_VSC + v * 3 + 2] = z;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
 #pragma unroll
@@ -544,14 +831,37 @@ bool model_ok(const rih_mano_model* m) {
 extern "C" int64_t rih_mano_ws_floats(int B) { return B > 0 ? (int64_t)B * WS_STRIDE : 0; }
 extern "C" int64_t rih_mano_bwd_ws_floats(int B) { return B > 0 ? 4 : 0; }   // backward keeps its scratch in LDS
 
-extern "C" int rih_mano_fwd(const rih_mano_model* m, const float* root, const float* pose, int ncomp,
+extern "C" int64_t rih_mano_pack_floats(void) { return PK_FLOATS; }
+
+extern "C" int rih_mano_pack(const rih_mano_model* m, float* packed, void* stream) {
+    if (!model_ok(m) || !packed || ((uintptr_t)packed % 16) != 0) return RIH_EINVAL;
+    const Model mm = to_model(m);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mano_pack_basis_kernel, dim3(1024), dim3(256), 0, s, mm, packed);
+    hipLaunchKernelGGL(mano_pack_joints_kernel, dim3(132), dim3(256), 0, s, mm, packed);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rih_mano_fwd(const rih_mano_model* m, const float* packed, const float* root, const float* pose, int ncomp,
                             const float* shape, const float* trans, const float* scale, int center_idx, int new_skel,
-                            float* v, float* j, float* ws, int B, void* stream) {
-    if (!model_ok(m) || !root || !pose || !shape || !v || !j || !ws || B < 1) return RIH_EINVAL;
+                            float* v, float* j, float* ws, int B, int variant, void* stream) {
+    if (!model_ok(m) || !root || !pose || !shape || !v || !j || B < 1) return RIH_EINVAL;
     if (ncomp < 0 || ncomp > 45 || center_idx >= 21) return RIH_EINVAL;
     if (ncomp > 0 && !m->comps) return RIH_EINVAL;
     const Model mm = to_model(m);
     hipStream_t s = (hipStream_t)stream;
+    if (variant == 0) {
+        // ONE launch.  Workgroups = 13 vertex tiles x hand groups; about two workgroups per CU in total, so that the 111 KB
+        // basis tile a workgroup pins is amortised over several 16-hand chunks when the batch is large.
+        if (!packed || ((uintptr_t)packed % 16) != 0) return RIH_EINVAL;
+        const int nchunks = (B + HC - 1) / HC;
+        int groups = (512 + NTILES - 1) / NTILES;
+        if (groups > nchunks) groups = nchunks;
+        hipLaunchKernelGGL(mano_fused_kernel, dim3(NTILES, groups), dim3(256), 0, s, mm, packed, root, pose, ncomp, shape,
+                           trans, scale, center_idx, new_skel, v, j, ws, B);
+        return (int)hipGetLastError();
+    }
+    if (variant != 1 || !ws) return RIH_EINVAL;     // round-1 two-kernel forward (A/B timing): needs the workspace
     hipLaunchKernelGGL(mano_pose_kernel, dim3(B), dim3(256), 0, s, mm, root, pose, ncomp, shape, trans, scale,
                        center_idx, new_skel, j, ws);
     // enough workgroups to cover 256 CUs, as few posedirs-tile reloads as that allows

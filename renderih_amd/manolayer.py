@@ -84,6 +84,10 @@ def build_mano_frame(skelBatch):
     return frame[:, 1:]
 
 
+# 0: the fused single-launch forward; 1: round 1's two-kernel forward (A/B timing, tools/mano_bench.py --variant 1)
+VARIANT = 0
+
+
 class _ManoFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, layer, root, pose, shape, trans, scale):
@@ -97,14 +101,21 @@ class _ManoFn(torch.autograd.Function):
         dev = root.device
         v = torch.empty((B, 778, 3), device=dev, dtype=torch.float32)
         j = torch.empty((B, 21, 3), device=dev, dtype=torch.float32)
-        ws = torch.empty((int(lib.rih_mano_ws_floats(B)),), device=dev, dtype=torch.float32)
+        # the backward's workspace (29.8 KB per hand) is written only when a gradient can be asked for; inference moves
+        # nothing but the inputs, v and j
+        need_ws = any(ctx.needs_input_grad)
+        variant = VARIANT
+        ws = (torch.empty((int(lib.rih_mano_ws_floats(B)),), device=dev, dtype=torch.float32)
+              if (need_ws or variant == 1) else None)
         mm = layer._model_struct()
+        packed = layer._packed_basis(mm)
         stream = ops._stream()
         cidx = -1 if layer.center_idx is None else int(layer.center_idx)
-        check(lib.rih_mano_fwd(C.byref(mm), root_c.data_ptr(), pose_c.data_ptr(), ncomp, shape_c.data_ptr(),
-                               0 if trans_c is None else trans_c.data_ptr(),
+        check(lib.rih_mano_fwd(C.byref(mm), packed.data_ptr(), root_c.data_ptr(), pose_c.data_ptr(), ncomp,
+                               shape_c.data_ptr(), 0 if trans_c is None else trans_c.data_ptr(),
                                0 if scale_c is None else scale_c.data_ptr(), cidx, 1 if layer.new_skel else 0,
-                               v.data_ptr(), j.data_ptr(), ws.data_ptr(), B, stream), 'rih_mano_fwd')
+                               v.data_ptr(), j.data_ptr(), 0 if ws is None else ws.data_ptr(), B, variant, stream),
+              'rih_mano_fwd')
         ctx.layer = layer
         ctx.save_for_backward(root_c, pose_c, shape_c, trans_c, scale_c, ws)
         ctx.cfg = (ncomp, cidx, 1 if layer.new_skel else 0, tuple(pose.shape), tuple(root.shape))
@@ -233,6 +244,21 @@ class ManoLayer(Module):
     @staticmethod
     def SE3_apply(SE3, v):
         return (SE3[:, :3, :3].bmm(v.unsqueeze(2)) + SE3[:, :3, 3:4])[:, :, 0]
+
+    def _packed_basis(self, mm):
+        """The packed blend basis of the fused kernel (rih_mano_pack), rebuilt whenever one of the buffers it is made of was
+        replaced or modified in place (callers do that: dataset/interhand.py:22-25 `fix_shape` flips shapedirs) -- keyed on
+        the tensors' data pointers and version counters, so the steady state is one launch per forward."""
+        srcs = (self.shapedirs, self.posedirs, self.v_template, self.J_regressor)
+        key = tuple((t.data_ptr(), t._version) for t in srcs)
+        cache = getattr(self, '_pack_cache', None)
+        if cache is None or cache[0] != key:
+            lib = _lib.load()
+            buf = torch.empty((int(lib.rih_mano_pack_floats()),), device=self.posedirs.device, dtype=torch.float32)
+            check(lib.rih_mano_pack(C.byref(mm), buf.data_ptr(), ops._stream()), 'rih_mano_pack')
+            cache = (key, buf)
+            object.__setattr__(self, '_pack_cache', cache)
+        return cache[1]
 
     def _model_struct(self):
         mm = ManoModel()

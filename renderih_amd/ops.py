@@ -143,6 +143,19 @@ def _presplit_ok(Ngemm, Kchan, taps, engine=None):
 # When set to a list, every rih_gemm launch is bracketed by HIP events on the launch stream and
 # (flops, start, end, tag) is appended -- bench.py uses this for the live roofline measurement.
 PROFILE = None
+# Same for the BatchNorm family (the largest HBM-bound kernel group): (algorithmic bytes, start, end, tag) per call.
+PROFILE_ELEM = None
+
+
+def _elem_profile(nbytes, tag, fn):
+    if PROFILE_ELEM is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    PROFILE_ELEM.append((float(nbytes), e0, e1, tag))
+    return r
 
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=None, ldr=0,
@@ -698,17 +711,21 @@ class BatchNormFn(torch.autograd.Function):
         mean = torch.empty((Cc,), device=x.device, dtype=torch.float32)
         invstd = torch.empty((Cc,), device=x.device, dtype=torch.float32)
         ws = torch.empty((int(lib.rih_bn_ws_floats(rows, Cc)),), device=x.device, dtype=torch.float32)
-        if training:
-            check(lib.rih_bn_stats(x.data_ptr(), rows, Cc, eps, momentum, mean.data_ptr(), invstd.data_ptr(),
-                                   _p(rmean), _p(rvar), ws.data_ptr(), _stream()), 'rih_bn_stats')
-        else:
-            check(lib.rih_bn_eval_stats(rmean.data_ptr(), rvar.data_ptr(), Cc, eps, mean.data_ptr(),
-                                        invstd.data_ptr(), _stream()), 'rih_bn_eval_stats')
         y = torch.empty_like(x)
         if residual is not None:
             residual = _c(residual)
-        check(lib.rih_bn_apply(x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                               _p(residual), y.data_ptr(), rows, Cc, 1 if relu else 0, _stream()), 'rih_bn_apply')
+
+        def run():
+            if training:
+                check(lib.rih_bn_stats(x.data_ptr(), rows, Cc, eps, momentum, mean.data_ptr(), invstd.data_ptr(),
+                                       _p(rmean), _p(rvar), ws.data_ptr(), _stream()), 'rih_bn_stats')
+            else:
+                check(lib.rih_bn_eval_stats(rmean.data_ptr(), rvar.data_ptr(), Cc, eps, mean.data_ptr(),
+                                            invstd.data_ptr(), _stream()), 'rih_bn_eval_stats')
+            check(lib.rih_bn_apply(x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                   _p(residual), y.data_ptr(), rows, Cc, 1 if relu else 0, _stream()), 'rih_bn_apply')
+        # algorithmic bytes: statistics read x once (training), apply reads x (+ residual) and writes y
+        _elem_profile(4.0 * x.numel() * ((1 if training else 0) + 2 + (1 if residual is not None else 0)), 'bn_fwd', run)
         ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma)
         ctx.cfg = (training, relu, residual is not None)
         return y
@@ -726,9 +743,11 @@ class BatchNormFn(torch.autograd.Function):
         dg = torch.empty_like(gamma)
         db = torch.empty_like(gamma)
         ws = torch.empty((int(lib.rih_bn_ws_floats(rows, Cc)),), device=x.device, dtype=torch.float32)
-        check(lib.rih_bn_bwd(dy.data_ptr(), x.data_ptr(), _p(y), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                             dx.data_ptr(), _p(dres), dg.data_ptr(), db.data_ptr(), rows, Cc, 1 if relu else 0,
-                             0 if training else 1, ws.data_ptr(), _stream()), 'rih_bn_bwd')
+        # algorithmic bytes: reduction pass reads dy and x (+ y for the ReLU mask), apply reads them again and writes dx (+ dres)
+        _elem_profile(4.0 * x.numel() * (2 * (2 + (1 if relu else 0)) + 1 + (1 if has_res else 0)), 'bn_bwd', lambda: check(
+            lib.rih_bn_bwd(dy.data_ptr(), x.data_ptr(), _p(y), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                           dx.data_ptr(), _p(dres), dg.data_ptr(), db.data_ptr(), rows, Cc, 1 if relu else 0,
+                           0 if training else 1, ws.data_ptr(), _stream()), 'rih_bn_bwd'))
         return dx, dg, db, None, None, dres, None, None, None, None
 
 

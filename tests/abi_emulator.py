@@ -486,7 +486,13 @@ class EmulatedLib:
     def rih_mano_bwd_ws_floats(self, B):
         return 16
 
-    def rih_mano_fwd(self, mref, root, pose, ncomp, shape, trans, scale, cidx, new_skel, v, j, ws, B, stream):
+    def rih_mano_pack_floats(self):
+        return 148 * 2496 + 528
+
+    def rih_mano_pack(self, mref, packed, stream):
+        return 0            # the emulator evaluates the layer from the model buffers directly
+
+    def rih_mano_fwd(self, mref, packed, root, pose, ncomp, shape, trans, scale, cidx, new_skel, v, j, ws, B, variant, stream):
         with torch.no_grad():
             _, vv, jj = self._mano_run(mref, root, pose, ncomp, shape, trans, scale, cidx, new_skel, B)
         _f(v, B * 778 * 3)[:] = vv.numpy().ravel()

@@ -66,6 +66,26 @@ static inline hipcpu_f32x16 hipcpu_mfma_32x32x16_bf16(hipcpu_bf16x8 a, hipcpu_bf
     return c;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipcpu_mfma_32x32x2_f32((a), (b), (c))
+// v_mfma_f32_16x16x4_f32: A (16 x 4): lane l holds row l%16, k = l/16; B (4 x 16): lane l holds column l%16, k = l/16;
+// C/D (16 x 16 fp32, 4 per lane): register r of lane l = row 4*(l>>4) + r, column l&15.  A k-ordered fmaf chain like the hardware.
+typedef float hipcpu_f32x4 __attribute__((ext_vector_type(4)));
+static inline hipcpu_f32x4 hipcpu_mfma_16x16x4_f32(float a, float b, hipcpu_f32x4 c) {
+    float* mine = (float*)hipcpu::xchg_slot(hipcpu::S().cur->flat);
+    mine[0] = a; mine[1] = b;
+    hipcpu::wave_barrier();
+    const int l = hipcpu::lane(), base = hipcpu::wave_base(), n = l & 15, q = l >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int m = 4 * q + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k)
+            acc = __builtin_fmaf(((const float*)hipcpu::xchg_slot(base + m + 16 * k))[0],
+                                 ((const float*)hipcpu::xchg_slot(base + n + 16 * k))[1], acc);
+        c[r] = acc;
+    }
+    hipcpu::wave_barrier();
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipcpu_mfma_16x16x4_f32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipcpu_mfma_32x32x16_bf16((a), (b), (c))
 static inline hipcpu_f32x16 hipcpu_mfma_32x32x16_f16(hipcpu_f16x8 a, hipcpu_f16x8 b, hipcpu_f32x16 c) {
     unsigned char* mine = hipcpu::xchg_slot(hipcpu::S().cur->flat);

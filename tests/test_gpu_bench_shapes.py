@@ -1,0 +1,141 @@
+"""Parity AT THE SHAPES bench.py TIMES (BASELINE configs[1]: B = 64, 256x256, ResNet50 variant).
+
+(a) Every distinct convolution problem of the network at B = 64 (SURVEY 8d "per-kernel problem list": trunk, aux decoders, mid
+    convs, patch convs) through ops.conv2d -- forward, data gradient and weight gradient with the tiles / split-K values the
+    planner picks at those sizes (M = 262144-row tiles, the 256x128 pipelined kernel, split-K 14..128 weight gradients,
+    parity-class data gradients of the strided convs) -- against an fp64 restatement (im2col + matmul in double).
+    Tolerance: outputs 1e-4 relative + 1e-5 of the tensor maximum (the fp32 bar of BASELINE.json); gradients 1e-3 / 1e-4,
+    as in test_gpu_ops (the weight gradient reduces over up to 262144 pixels in fp32).
+(b) Training-mode forward of the whole network at B = 16 (>= 1024 samples per channel in every BatchNorm) against the CPU
+    oracle, anchored on the oracle's fp64 run: measured 2e-4 .. 9e-4 between the two fp32 implementations, so the plain 1e-4
+    bar does not hold in training mode even at this batch size (see the test's docstring).
+(c) One full training step at B = 64: every gradient finite, loss equal between two launches of the same step
+    (determinism of the split-K reductions at bench size)."""
+import math
+import pytest
+import torch
+import torch.nn.functional as F
+
+from renderih_amd import assets, testing
+from renderih_amd.testing import assert_close
+
+pytestmark = pytest.mark.gpu
+B = 64
+
+# (H, Cin, Cout, k, stride, pad, bias)  -- input spatial size H x H
+CONV_PROBLEMS = [
+    (256, 3, 64, 7, 2, 3, False),                                                            # stem
+    (64, 64, 64, 1, 1, 0, False), (64, 64, 64, 3, 1, 1, False), (64, 64, 256, 1, 1, 0, False), (64, 256, 64, 1, 1, 0, False),
+    (64, 256, 128, 1, 1, 0, False), (64, 128, 128, 3, 2, 1, False), (32, 128, 128, 3, 1, 1, False),
+    (32, 128, 512, 1, 1, 0, False), (32, 512, 128, 1, 1, 0, False), (64, 256, 512, 1, 2, 0, False),
+    (32, 512, 256, 1, 1, 0, False), (32, 256, 256, 3, 2, 1, False), (16, 256, 256, 3, 1, 1, False),
+    (16, 256, 1024, 1, 1, 0, False), (16, 1024, 256, 1, 1, 0, False), (32, 512, 1024, 1, 2, 0, False),
+    (16, 1024, 512, 1, 1, 0, False), (16, 512, 512, 3, 2, 1, False), (8, 512, 512, 3, 1, 1, False),
+    (8, 512, 2048, 1, 1, 0, False), (8, 2048, 512, 1, 1, 0, False), (16, 1024, 2048, 1, 2, 0, False),
+    (8, 2048, 128, 1, 1, 0, False), (16, 128, 128, 3, 1, 1, False), (32, 128, 128, 3, 1, 1, False),        # aux decoders
+    (64, 128, 128, 3, 1, 1, False), (64, 128, 42, 1, 1, 0, True), (64, 128, 8, 1, 1, 0, True),
+    (8, 256, 256, 1, 1, 0, False), (16, 1280, 256, 1, 1, 0, False), (32, 768, 256, 1, 1, 0, False),       # mid convs
+    (64, 512, 256, 1, 1, 0, False),
+    (16, 256, 128, 2, 2, 0, True), (32, 256, 64, 4, 4, 0, True),                                          # patch convs
+]
+
+
+def _ref_conv_fp64(x_nchw, w, b, stride, pad, gy):
+    """y, dx, dw, db of conv2d in double via im2col + matmul (rocBLAS dgemm) on the GPU."""
+    xd, wd, gd = x_nchw.double(), w.double(), gy.double()
+    N, Cin, H, W = xd.shape
+    Cout, _, k, _ = wd.shape
+    cols = F.unfold(xd, k, padding=pad, stride=stride)                      # [N, Cin*k*k, L]
+    wm = wd.reshape(Cout, -1)
+    y = torch.matmul(wm, cols)                                              # [N, Cout, L]
+    Ho = (H + 2 * pad - k) // stride + 1
+    if b is not None:
+        y = y + b.double()[None, :, None]
+    g2 = gd.reshape(N, Cout, -1)
+    dw = torch.einsum('ncl,nkl->ck', g2, cols).reshape(wd.shape)
+    dcols = torch.matmul(wm.t(), g2)
+    dx = F.fold(dcols, (H, W), k, padding=pad, stride=stride)
+    db = g2.sum((0, 2)) if b is not None else None
+    return y.reshape(N, Cout, Ho, Ho), dx, dw, db
+
+
+@pytest.mark.parametrize('prob', CONV_PROBLEMS)
+def test_conv_problem_at_bench_batch(prob):
+    from renderih_amd import ops
+    H, Cin, Cout, k, s, p, bias = prob
+    d = torch.device('cuda:0')
+    g = torch.Generator(device=d).manual_seed(1000 + H + 7 * Cin + 13 * Cout + k)
+    x = torch.randn(B, Cin, H, H, device=d, generator=g)
+    w = torch.randn(Cout, Cin, k, k, device=d, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, device=d, generator=g) if bias else None
+    Ho = (H + 2 * p - k) // s + 1
+    gy = torch.randn(B, Cout, Ho, Ho, device=d, generator=g)
+    yr, dxr, dwr, dbr = _ref_conv_fp64(x, w, b, s, p, gy)
+
+    cpad = 4 if Cin == 3 else Cin
+    xg = torch.zeros(B, H, H, cpad, device=d)
+    xg[..., :Cin] = x.permute(0, 2, 3, 1)
+    xg.requires_grad_(Cin != 3)
+    wg = w.clone().requires_grad_(True)
+    bg = b.clone().requires_grad_(True) if bias else None
+    yg = ops.conv2d(xg, wg, bg, stride=s, pad=p)
+    assert_close(yg.permute(0, 3, 1, 2), yr, what='y %s' % (prob,))
+    yg.backward(gy.permute(0, 2, 3, 1).contiguous())
+    assert_close(wg.grad, dwr, 1e-3, 1e-4, 'dw %s' % (prob,))
+    if Cin != 3:
+        assert_close(xg.grad.permute(0, 3, 1, 2), dxr, 1e-3, 1e-4, 'dx %s' % (prob,))
+    if bias:
+        assert_close(bg.grad, dbr, 1e-3, 1e-4, 'db %s' % (prob,))
+
+
+def _build(dropout=0.0, seed=0):
+    from renderih_amd.model import build_model
+    m = build_model(dropout)
+    sd = testing.deterministic_state(m.state_dict(), seed=seed)
+    m.load_state_dict(sd)
+    return m.to('cuda:0'), sd
+
+
+def test_train_mode_forward_at_b16_vs_oracle():
+    """Training-mode forward at B = 16 (batch statistics over >= 1024 samples per channel) against the CPU oracle on the same
+    weights and images.  Measured on MI355X (profiles/r02/pytest_shapes_m5.log): the HIP path is 2e-4 .. 9e-4 from the fp32
+    CPU oracle at this size -- NOT within 1e-4 -- so the comparison is anchored on the oracle's fp64 run to tell which side
+    the distance comes from: the HIP result must be within 1e-3 of fp64 outright, and no further from fp64 than twice the
+    fp32 CPU oracle's own distance (+2e-5).  The randomly initialised 50-layer network amplifies fp32 round-off through its
+    batch statistics even at this batch size; eval mode (running statistics) meets 1e-4 (test_gpu_model.py)."""
+    from oracle import net_oracle
+    m, sd = _build(0.0, seed=3)
+    m.train()
+    img = testing.seeded_image(16, 21)
+    graph = net_oracle.graph_from_dicts(assets.load_graph_dict('left'), assets.load_graph_dict('right'))
+    w32, _ = net_oracle.run(sd, graph, img, True, torch.float32, False)
+    w64, _ = net_oracle.run(sd, graph, img, True, torch.float64, False)
+    with torch.no_grad():
+        got = testing.flatten_outputs(m(img.cuda()))
+    report = {}
+    for k in w64:
+        if k.startswith('params.'):
+            continue        # per-image scalars can sit near zero; they are functions of the checked meshes
+        e_got, e_ref = testing.assert_fp32_equivalent(got[k], w32[k], w64[k], k=2.0, floor=2e-5, what=k)
+        assert e_got < 1e-3, (k, e_got)
+        report[k] = (e_got, e_ref, testing.rel_err(got[k], w32[k]))
+    print('B=16 train-mode forward: worst HIP-vs-fp64 %.2e, CPU-fp32-vs-fp64 %.2e, HIP-vs-CPU-fp32 %.2e'
+          % (max(v[0] for v in report.values()), max(v[1] for v in report.values()), max(v[2] for v in report.values())))
+
+
+def test_training_step_at_bench_batch_is_finite_and_deterministic():
+    """B = 64, the exact problem sizes of the timed step: forward + scalar loss + backward twice from the same state; all
+    gradients finite and bit-identical between the two runs (fixed-order split-K reductions, no atomics)."""
+    from oracle import net_oracle
+    m, _ = _build(0.0, seed=1)
+    m.train()
+    img = testing.seeded_image(64, 5).cuda()
+    grads = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        net_oracle.scalar_loss(m(img)).backward()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert len(grads[0]) > 800          # 843 live parameter tensors (the rest never receive a gradient)
+    for k, g in grads[0].items():
+        assert bool(torch.isfinite(g).all()), k
+        assert torch.equal(g, grads[1][k]), 'gradient of %s differs between two identical steps' % k

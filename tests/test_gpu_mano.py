@@ -46,7 +46,7 @@ def test_mano_matches_reference_golden(side):
                 assert_close(t.grad, torch.from_numpy(z[key + 'grad_' + nm]), 1e-3, 1e-4, key + 'grad_' + nm)
 
 
-@pytest.mark.parametrize('B', [1, 2, 64, 257])
+@pytest.mark.parametrize('B', [1, 2, 17, 64, 257])
 def test_mano_matches_oracle(B):
     from oracle import mano_oracle
     from renderih_amd.manolayer import rodrigues_batch
@@ -101,3 +101,30 @@ def test_mano_reads_mutated_shapedirs():
     layer.shapedirs[:, 0, :] *= -1
     b, _ = layer(root, pose, shape)
     assert float((a - b).abs().max()) > 1e-4
+
+
+@pytest.mark.parametrize('variant', [0, 1])
+def test_mano_inference_without_workspace_and_two_kernel_variant(variant):
+    """The fused forward under no_grad writes only v and j (no workspace is allocated) and equals the forward that also feeds
+    the backward; variant 1 (round 1's two-kernel forward, kept for A/B timing) agrees with the fused kernel to fp32 round-off
+    (the fused kernel sums the blend shapes in one k-ordered chain on the f32 MFMA, the old one in two VALU passes)."""
+    from renderih_amd import manolayer
+    from renderih_amd.manolayer import rodrigues_batch
+    layer = _layer('right', 9, True, True)
+    B = 21
+    g = torch.Generator().manual_seed(5)
+    root = rodrigues_batch(torch.randn(B, 3, generator=g)).to(dev())
+    pose, shape = (torch.randn(B, 45, generator=g) * 0.7).to(dev()), torch.randn(B, 10, generator=g).to(dev())
+    v_train, j_train = layer(root.clone().requires_grad_(True), pose, shape)
+    old = manolayer.VARIANT
+    try:
+        manolayer.VARIANT = variant
+        with torch.no_grad():
+            v_inf, j_inf = layer(root, pose, shape)
+    finally:
+        manolayer.VARIANT = old
+    if variant == 0:
+        assert torch.equal(v_inf, v_train.detach()) and torch.equal(j_inf, j_train.detach())
+    else:
+        assert_close(v_inf, v_train.detach(), 1e-5, 1e-6, 'two-kernel forward vs fused')
+        assert_close(j_inf, j_train.detach(), 1e-5, 1e-6, 'two-kernel joints vs fused')

@@ -391,3 +391,81 @@ def test_family_b_matches_fp64_oracle(training):
     params = [(k, p.grad) for k, p in m.named_parameters() if p.grad is not None]
     assert {k for k, _ in params} == set(g64.keys())
     _grad_report(params, g32, g64)
+
+
+# ------------------------------------------------------------------------------------------------ TrainStep helper
+def test_train_step_staged_graph_replay_matches_plain_backward():
+    """renderih_amd.train.TrainStep (three backward stages, three hipGraphs sharing a pool, fused optimizer outside): the
+    gradients it leaves in `.grad` equal those of a plain eager `loss.backward()` on the same state bit for bit, for the
+    first and for a replayed step, and the set of grad-less parameters is unchanged."""
+    from oracle.net_oracle import scalar_loss
+    from renderih_amd import ops
+    from renderih_amd.train import TrainStep
+    img = testing.seeded_image(2, 31).cuda()
+    m1, _ = _build(0.0, seed=11)
+    m1.train()
+    m1.decoder.unsample_layer.weight.requires_grad_(False)
+    scalar_loss(m1(img)).backward()
+    want = {k: p.grad.clone() for k, p in m1.named_parameters() if p.grad is not None}
+
+    m2, _ = _build(0.0, seed=11)
+    m2.train()
+    m2.decoder.unsample_layer.weight.requires_grad_(False)
+    opt = torch.optim.SGD([p for p in m2.parameters() if p.requires_grad], lr=0.0)      # lr 0: the state stays put
+    try:
+        step = TrainStep(m2, opt, lambda out, lab: scalar_loss(out), (img.clone(), {}), process_group=False)
+        assert step.use_graph and step.nstage == 3
+        for rep in range(2):
+            loss = step(img, {})
+            assert bool(torch.isfinite(loss))
+            got = {k: p.grad for k, p in m2.named_parameters() if p.grad is not None}
+            assert set(got) == set(want)
+            for k in want:
+                assert torch.equal(got[k], want[k]), 'replay %d: gradient of %s differs from the plain backward' % (rep, k)
+    finally:
+        ops.DROPOUT_SEED_TENSOR = None
+    # the module is unchanged for ordinary use: the trunk hook is inert outside the helper
+    m2.zero_grad(set_to_none=True)
+    scalar_loss(m2(img)).backward()
+    assert torch.equal(m2.encoder.resnet.conv1.weight.grad, want['encoder.resnet.conv1.weight'])
+
+
+def test_train_step_over_rccl_single_rank_reports_exposed_comm():
+    """The N > 1 code path of TrainStep with RCCL at world size 1 (bucket copies, side-stream all-reduce, `.grad` views into
+    the buckets, exposed-communication timing); the world-2 schedule itself is pinned on CPU by tests/test_train_step.py."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import torch.distributed as dist
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+from oracle.net_oracle import scalar_loss
+from renderih_amd import testing
+from renderih_amd.model import build_model
+from renderih_amd.train import TrainStep
+def build():
+    m = build_model(0.0); m.load_state_dict(testing.deterministic_state(m.state_dict(), seed=11)); m = m.cuda().train()
+    m.decoder.unsample_layer.weight.requires_grad_(False); return m
+img = testing.seeded_image(2, 31).cuda()
+m1 = build(); scalar_loss(m1(img)).backward()
+want = {k: p.grad.clone() for k, p in m1.named_parameters() if p.grad is not None}
+m2 = build()
+opt = torch.optim.SGD([p for p in m2.parameters() if p.requires_grad], lr=0.0)
+step = TrainStep(m2, opt, lambda out, lab: scalar_loss(out), (img.clone(), {}), force_exchange=True)
+assert step.exchange and step.overlap
+for rep in range(3):
+    step(img, {})
+got = {k: p.grad for k, p in m2.named_parameters() if p.grad is not None}
+assert set(got) == set(want)
+for k in want:
+    assert torch.equal(got[k], want[k]), k
+print('buckets', step.bucket_bytes(), 'exposed', step.comm_ms_exposed())
+dist.destroy_process_group()
+print('TRAINSTEP-RCCL-OK')
+''' % (root, root)
+    p = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and 'TRAINSTEP-RCCL-OK' in p.stdout, (p.stdout + p.stderr)[-3000:]

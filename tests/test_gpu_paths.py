@@ -1,0 +1,121 @@
+"""GPU tests of the opt-in / secondary code paths: fp16-storage inference backbone (csrc/rih_half.hip; LDS-DMA and
+register-staged loaders), fused attention kernels (csrc/rih_attn.hip), pre-split GEMM operands (rih_gemm a/b_mode 2), batch
+input preparation (csrc/rih_input.hip), SDF voxeliser (csrc/rih_sdf.hip), contact deviation, hipGraph-replayed inference and
+the BatchNorm-folded fp32 trunk.  All of them passed their first hardware run in round 1's driver suite (they were wrapped as
+xfail-on-failure then); they are ordinary tests now: a failure fails the suite."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return torch.device('cuda:0')
+
+
+def _half_kernels(d):
+    import test_half
+    test_half.kernels_vs_torch(d)
+    # larger than one tile in every direction, deep K
+    test_half.conv_case(d, 4, 32, 32, 256, 512, 3, 1, 1, 'conv-bn', True, True, False, seed=11)
+    test_half.conv_case(d, 8, 64, 64, 64, 64, 1, 1, 0, 'conv-bn', True, False, False, seed=12)
+    test_half.conv_case(d, 2, 16, 16, 1024, 2048, 1, 2, 0, 'conv-bn', False, False, False, seed=13)
+
+
+def test_fp16_conv_kernels_lds_dma():
+    _half_kernels(dev())
+
+
+def test_fp16_conv_kernels_register_staged():
+    """RIH_HCONV_GLDS=0 is read once per process by the library, hence its own interpreter."""
+    code = ('import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_paths as T; '
+            'T._half_kernels(torch.device("cuda:0")); torch.cuda.synchronize(); print("REGSTAGE-OK")'
+            % (ROOT, os.path.join(ROOT, 'tests')))
+    p = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, RIH_HCONV_GLDS='0'))
+    assert p.returncode == 0 and 'REGSTAGE-OK' in p.stdout, (p.stdout + p.stderr)[-3000:]
+
+
+def test_fp16_backbone_close_to_fp32():
+    import test_half
+    from renderih_amd import testing
+    from renderih_amd.model import build_model
+    d = dev()
+    test_half.backbone_vs_fp32(d, B=2)
+    test_half.backbone_b_vs_fp32(d, B=2)
+    m = build_model(0.0).to(d).eval()
+    img = testing.seeded_image(2, 3).to(d)
+    with torch.no_grad():
+        ref = testing.flatten_outputs(m(img))
+        m.use_fp16_backbone()
+        got = testing.flatten_outputs(m(img))
+    for k in ('result.verts3d.left', 'result.verts3d.right'):
+        assert bool(torch.isfinite(got[k]).all())
+        # inference mode with fp16 storage: not the 1e-4 parity path; measured 7e-4 at B=256
+        assert testing.rel_err(got[k], ref[k]) < 3e-2, k
+
+
+def test_graphed_inference_replay_is_bit_identical():
+    from renderih_amd import testing
+    from renderih_amd.graph import GraphedInference
+    from renderih_amd.model import build_model
+    d = dev()
+    m = build_model(0.0).to(d).eval()
+    g = GraphedInference(m, testing.seeded_image(2, 3).to(d))
+    img2 = testing.seeded_image(2, 4).to(d)
+    with torch.no_grad():
+        eager = testing.flatten_outputs(m(img2))
+    replay = testing.flatten_outputs(g(img2))
+    for k in ('result.verts3d.left', 'result.verts3d.right'):
+        assert torch.equal(replay[k], eager[k]), k
+
+
+def test_folded_batchnorm_fp32_trunk():
+    import test_half
+    test_half.conv2d_packed_vs_torch(dev())
+    test_half.folded_fp32_trunk_vs_plain(dev(), B=2)
+
+
+def test_contact_deviation_kernel():
+    import test_metrics
+    test_metrics.cdev_kernel_vs_fixture(dev())
+
+
+def test_fused_attention_kernels(monkeypatch):
+    import test_gpu_ops as G
+    from renderih_amd import ops
+    monkeypatch.setattr(ops, 'FUSED_ATTN', True)
+    G.test_attention(2, 63, 63, 64, 4)
+    G.test_attention(1, 150, 190, 128, 4)
+    G.test_attention(1, 127, 127, 256, 4)
+    G.test_attention(4, 316, 316, 128, 4)
+    G.test_attention_dropout_matches_hash_mask()
+    G.test_self_attention_packed(2, 40, 64, 4)
+    G.test_cross_attention_packed(2, 63, 128, 4)
+    G.test_cross_attention_stacked_and_rows_pair()
+
+
+@pytest.mark.parametrize('act', [False, True])
+def test_presplit_gemm_operands(monkeypatch, act):
+    import test_gpu_ops as G
+    from renderih_amd import ops
+    monkeypatch.setattr(ops, 'PRESPLIT', True)
+    monkeypatch.setattr(ops, 'PRESPLIT_ACT', act)
+    for case in G.CONV_CASES:
+        G.test_conv2d(case)
+
+
+def test_batch_input_preparation_matches_reference_fixtures():
+    import test_input_pipeline
+    test_input_pipeline.prepare_vs_fixtures(dev())
+
+
+def test_sdf_voxeliser():
+    import test_sdf
+    test_sdf.sdf_vs_oracle(dev(), G=16)

@@ -3,7 +3,7 @@
     the lane-linear destination rule and deferred landing), against torch on identically fp16-rounded operands;
   * the host logic of HalfBackbone (BN folding, in-place channel concatenation, stage order) through the numpy/torch
     restatement of the entry points (tests/abi_emulator.py), against the fp32 model.
-The same checks run on the GPU from tests/test_zz_gpu_pending.py."""
+The same checks run on the GPU from tests/test_gpu_paths.py."""
 import os
 import sys
 

@@ -152,6 +152,13 @@ def test_mano_kernels_reference_golden():
     TMANO.test_mano_matches_reference_golden('left')
 
 
+def test_mano_fused_forward_variants_and_cache():
+    TMANO.test_mano_inference_without_workspace_and_two_kernel_variant(0)
+    TMANO.test_mano_inference_without_workspace_and_two_kernel_variant(1)
+    TMANO.test_mano_reads_mutated_shapedirs()
+    TMANO.test_mano_matches_oracle(17)
+
+
 def test_mesh_loss_kernel():
     TL.test_fused_loss_matches_reference_golden(60)
 

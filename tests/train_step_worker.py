@@ -1,0 +1,89 @@
+"""One rank of the world_size-2 check of renderih_amd.train.TrainStep (launched by tests/test_train_step.py; gloo, CPU, the
+C ABI emulated on host memory).  Pins: the three backward stages reproduce the gradients of a plain `loss.backward()`;
+the buckets are all-reduced in reverse-autograd order, each right after its stage and before the next stage's backward is
+issued (the overlap schedule of SURVEY 8e / core/gcn_trainer.py:110-115's DDP); gradients are averaged over the ranks; the
+structurally grad-less parameters are in no bucket; parameters stay identical on every rank after the step."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def main():
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    torch.set_num_threads(2)
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    from abi_emulator import emulated_abi
+    from oracle.net_oracle import scalar_loss
+    from renderih_amd import testing
+    from renderih_amd.model import build_model
+    from renderih_amd.train import TrainStep
+    with emulated_abi():
+        m = build_model(0.0)
+        m.load_state_dict(testing.deterministic_state(m.state_dict(), seed=2 + rank))      # ranks start DIFFERENT
+        m.decoder.unsample_layer.weight.requires_grad_(False)          # core/gcn_trainer.py:102-103
+        m.train()
+        img = testing.seeded_image(1, 20 + rank)                       # each rank its own shard
+        opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+        order = []
+        step = TrainStep(m, opt, lambda out, lab: scalar_loss(out), (img, {}), use_graph=False, record_order=order)
+        # after construction every rank holds rank 0's parameters (frozen ones included)
+        if world > 1:
+            flat = torch.cat([p.detach().flatten() for p in m.parameters()])
+            ref = flat.clone()
+            dist.broadcast(ref, 0)
+            assert torch.equal(flat, ref), 'parameters not broadcast'
+        # reference: plain backward on the same module state (BatchNorm statistics are per rank, as in the reference)
+        m.zero_grad(set_to_none=True)
+        scalar_loss(m(img)).backward()
+        local = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        m.zero_grad(set_to_none=True)
+        before = {k: p.detach().clone() for k, p in m.named_parameters()}
+        loss = step(img, {})
+        assert torch.isfinite(loss)
+        # first call learns the live set, then reduces in stage order; the second call interleaves
+        order.clear()
+        for k, p in m.named_parameters():
+            p.data.copy_(before[k])
+        step(img, {})
+        assert order == [('stage', 0), ('reduce', 0), ('stage', 1), ('reduce', 1), ('stage', 2), ('reduce', 2)], order
+        n_live = 0
+        worst = 0.0
+        for k, p in m.named_parameters():
+            if k in local:
+                want = local[k].clone()
+                if world > 1:
+                    dist.all_reduce(want)
+                    want /= world
+                assert p.grad is not None, k
+                err = float((p.grad - want).abs().max() / (want.abs().max() + 1e-30))
+                worst = max(worst, err)
+                assert err < 2e-5, (k, err)
+                n_live += 1
+            else:
+                assert p.grad is None, k
+        sizes = step.bucket_bytes()
+        assert len(sizes) == 3 and sum(len(v) for v in step.live) == n_live
+        if world > 1:
+            flat = torch.cat([p.detach().flatten() for p in m.parameters()])
+            ref = flat.clone()
+            dist.broadcast(ref, 0)
+            assert torch.equal(flat, ref), 'parameters diverged after the step'
+        # the model still works outside the helper (the trunk hook is inert there)
+        m.zero_grad(set_to_none=True)
+        scalar_loss(m(img)).backward()
+        assert m.encoder.resnet.conv1.weight.grad is not None
+    print('rank %d ok: %d live tensors in buckets of %s bytes, worst rel err %.1e' % (rank, n_live, sizes, worst))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -46,7 +46,9 @@ def time_graph(fn, iters):
     return best[len(best) // 2]
 
 
-def measure(B, iters, dev):
+def measure(B, iters, dev, variant=0):
+    from renderih_amd import manolayer
+    manolayer.VARIANT = variant
     layer = ManoLayer(assets.synthetic_mano_dict('right')).to(dev)
     g = torch.Generator().manual_seed(0)
     root = rodrigues_batch(torch.randn(B, 3, generator=g)).to(dev)
@@ -79,9 +81,10 @@ def main():
     ap.add_argument('--hands', type=int, nargs='+', default=[128, 4096])
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--json', default=None)
+    ap.add_argument('--variant', type=int, default=0, help='0 = fused single-launch forward, 1 = round-1 two-kernel forward')
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
-    rows = [measure(B, a.iters, dev) for B in a.hands]
+    rows = [dict(measure(B, a.iters, dev, a.variant), variant=a.variant) for B in a.hands]
     for r in rows:
         print(json.dumps(r), flush=True)
     if a.json:

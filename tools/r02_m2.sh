@@ -7,5 +7,5 @@ mkdir -p "$OUT"
 run() { name=$1; shift; echo "== $name: $*"; ( timeout "${T:-300}" "$@" ) > "$OUT/$name.log" 2>&1; echo "   exit $?"; tail -n 3 "$OUT/$name.log" | cut -c1-400; }
 run pytest_p3  python -m pytest tests/test_gpu_p3.py -x -q -m gpu
 run p3_bench   python tools/p3_bench.py --json "$OUT/p3_bench.json"
-T=900 run pytest_gpu python -m pytest tests -x -q -m gpu --deselect tests/test_zz_gpu_pending.py
+T=900 run pytest_gpu python -m pytest tests -x -q -m gpu
 echo done
