@@ -319,6 +319,7 @@ typedef struct rih_mano_model {
 
 int64_t rih_mano_ws_floats(int B);
 int64_t rih_mano_pack_floats(void);
+int rih_mano_debug_stamps(long long* device_buf_13x16);   /* development aid: phase timestamps of the fused forward; NULL = off */
 int rih_mano_pack(const rih_mano_model* m, float* packed, void* stream);
 int rih_mano_fwd(const rih_mano_model* m, const float* packed, const float* root, const float* pose, int ncomp,
                  const float* shape, const float* trans, const float* scale, int center_idx, int new_skel, float* v,

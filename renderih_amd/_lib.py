@@ -138,6 +138,7 @@ SIGNATURES = {
     'rih_mano_ws_floats': (c_l, [c_i]),
     'rih_mano_bwd_ws_floats': (c_l, [c_i]),
     'rih_mano_pack_floats': (c_l, []),
+    'rih_mano_debug_stamps': (c_i, [C.c_void_p]),
     'rih_mano_pack': (c_i, [C.POINTER(ManoModel), c_f, C.c_void_p]),
     'rih_mano_fwd': (c_i, [C.POINTER(ManoModel), c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_i, c_i,
                            C.c_void_p]),

@@ -355,7 +355,7 @@ constexpr int LDPF = 149;               // odd row stride of the pose-feature op
 constexpr int GST = 200;                // per-hand SE3s (16 x 12) + post (8)
 constexpr int SCR = 392;                // per-hand phase-1 scratch: axis 48 | R 144 | jt 48 | src 63 | sp 39 | spt 39 | pad
 constexpr int S_AX = 0, S_RR = 48, S_JT = 192, S_SRC = 240, S_SP = 303, S_SPT = 342;
-constexpr int FUSED_LDS_FLOATS = KP * 192 + HC * LDPF + HC * GST + HC * SCR;     // 40,128 floats = 160,512 B
+constexpr int FUSED_LDS_FLOATS = KP * 192 + HC * LDPF + HC * GST + HC * SCR + 528 + 20;    // 40,676 floats = 162,704 B
 static_assert(FUSED_LDS_FLOATS * 4 <= 163840, "LDS budget");
 static_assert(HC * 192 <= HC * SCR, "the v_tpose tile aliases the phase-1 scratch");
 
@@ -364,12 +364,17 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
                                                          int ncomp, const float* __restrict__ shape,
                                                          const float* __restrict__ trans, const float* __restrict__ scale,
                                                          int center_idx, int new_skel, float* __restrict__ vout,
-                                                         float* __restrict__ jout, float* __restrict__ ws, int B) {
+                                                         float* __restrict__ jout, float* __restrict__ ws, int B,
+                                                         long long* __restrict__ dbg) {
     __shared__ __attribute__((aligned(16))) float smem[FUSED_LDS_FLOATS];
+    // phase timestamps (shader clock) of the first chunk of the workgroups (tile, group 0): development aid, dbg == NULL otherwise
+#define RIH_STAMP(i_) do { if (dbg != nullptr && threadIdx.x == 0 && blockIdx.y == 0 && chunk == 0) dbg[blockIdx.x * 16 + (i_)] = clock64(); } while (0)
     float* s_B = smem;                          // [KP][192] basis tile
     float* s_pf = s_B + KP * 192;               // [HC][LDPF] pose feature | beta | 1 | 0 0
     float* s_G = s_pf + HC * LDPF;              // [HC][GST]
     float* s_scr = s_G + HC * GST;              // [HC][SCR] phase-1 scratch, later [HC][192] v_tpose tile
+    float* s_J = s_scr + HC * SCR;              // Jt[48] | Js[480]: the joint regressor folded onto template / shape basis
+    int* s_depth = reinterpret_cast<int*>(s_J + 528);      // tree depth of the 16 joints, [16] = maximum
     const int tile = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int v0 = tile * TILE_V, n0 = tile * 192;
     // does this workgroup need the 13 special vertices (tips / new_skel)?  Tile 0 writes the joints; every tile needs the
@@ -382,6 +387,18 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
         const int k = i / 48, q = i - k * 48;
         *reinterpret_cast<float4*>(s_B + k * 192 + 4 * q) = *reinterpret_cast<const float4*>(pk + (long long)k * NCP + n0 + 4 * q);
     }
+    for (int i = t; i < 528; i += 256) s_J[i] = pk[PK_JT + i];
+    if (t < NJ) {
+        int d = 0;
+        for (int pp = m.parent[t]; pp >= 0; pp = m.parent[pp]) ++d;
+        s_depth[t] = d;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int mx = 0;
+        for (int j = 0; j < NJ; ++j) mx = max(mx, s_depth[j]);
+        s_depth[16] = mx;
+    }
     const int v = v0 + lane;
     const bool valid = v < NV;
     float wgt[NJ];
@@ -392,15 +409,24 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
     for (int chunk = blockIdx.y; chunk < nchunks; chunk += gridDim.y) {
         const int h0 = chunk * HC;
         __syncthreads();                        // previous chunk's skinning is done with s_G / s_scr
-        // ---- phase 1a: axis-angle (PCA), beta, constant columns of the operand
-        for (int i = t; i < HC * 48; i += 256) {
-            const int hl = i / 48, e = i - hl * 48, h = h0 + hl;
-            float a = 0.f;
-            if (e < 45 && h < B && ncomp > 0) {
-                a = m.hands_mean[e];
-                for (int c = 0; c < ncomp; ++c) a += pose[(long long)h * ncomp + c] * m.comps[c * 45 + e];
+        RIH_STAMP(0);
+        // ---- phase 1a: axis-angle = hands_mean + pose x comps as a 16 x 48 x 48 product on the f32 MFMA (waves 0..2 own 16
+        //      outputs each; all operand loads are issued before the first MFMA), beta and the constant operand columns
+        if (ncomp > 0 && wave < 3) {
+            const int hl = lane & 15, kq = lane >> 4, e = wave * 16 + (lane & 15);
+            float av[12], bv[12];
+#pragma unroll
+            for (int ks = 0; ks < 12; ++ks) {
+                const int k = 4 * ks + kq;
+                av[ks] = (k < ncomp && h0 + hl < B) ? pose[(long long)(h0 + hl) * ncomp + k] : 0.f;
+                bv[ks] = (k < ncomp && e < 45) ? m.comps[k * 45 + e] : 0.f;
             }
-            s_scr[hl * SCR + S_AX + e] = a;
+            floatx4 ax = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 12; ++ks) ax = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks], ax, 0, 0, 0);
+            const float mean = (e < 45) ? m.hands_mean[e] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_scr[(4 * kq + r) * SCR + S_AX + e] = ax[r] + mean;
         }
         for (int i = t; i < HC * 13; i += 256) {
             const int hl = i / 13, e = i - hl * 13, h = h0 + hl;
@@ -409,7 +435,18 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
             s_pf[hl * LDPF + NPF + e] = x;
         }
         __syncthreads();
-        // ---- phase 1b: rotations (thread = (hand, joint)), rest joints (thread = (hand, joint, coord))
+        RIH_STAMP(1);
+        // ---- phase 1b: rotations (thread = (hand, joint)) -> pose feature and local transforms L_j = [R_j | jt_j - R_j jt_j]
+        //      (parked in the SE3 slots), rest joints jt = Jt + Js beta
+        for (int i = t; i < HC * 48; i += 256) {
+            const int hl = i / 48, e = i - hl * 48;
+            float a = s_J[e];
+#pragma unroll
+            for (int sdx = 0; sdx < 10; ++sdx) a += s_J[48 + e * 10 + sdx] * s_pf[hl * LDPF + NPF + sdx];
+            s_scr[hl * SCR + S_JT + e] = a;
+            if (ws != nullptr && tile == 0 && h0 + hl < B) ws[(long long)(h0 + hl) * WS_STRIDE + OFF_JT + e] = a;
+        }
+        __syncthreads();
         if (t < HC * NJ) {
             const int hl = t >> 4, j = t & 15, h = h0 + hl;
             float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
@@ -422,60 +459,73 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
                     for (int e = 0; e < 9; ++e) R[e] = pose[((long long)h * 15 + (j - 1)) * 9 + e];
                 }
             }
-            for (int e = 0; e < 9; ++e) {
-                s_scr[hl * SCR + S_RR + j * 9 + e] = R[e];
-                if (j > 0) s_pf[hl * LDPF + (j - 1) * 9 + e] = (h < B) ? R[e] - ((e % 4 == 0) ? 1.f : 0.f) : 0.f;
+            const float* jv = &s_scr[hl * SCR + S_JT + j * 3];
+            float* L = &s_G[hl * GST + j * 12];
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) L[r * 4 + c] = R[r * 3 + c];
+                L[r * 4 + 3] = jv[r] - (R[r * 3] * jv[0] + R[r * 3 + 1] * jv[1] + R[r * 3 + 2] * jv[2]);
             }
+            if (j > 0)
+                for (int e = 0; e < 9; ++e) s_pf[hl * LDPF + (j - 1) * 9 + e] = (h < B) ? R[e] - ((e % 4 == 0) ? 1.f : 0.f) : 0.f;
             if (ws != nullptr && tile == 0 && h < B)
                 for (int e = 0; e < 9; ++e) ws[(long long)h * WS_STRIDE + OFF_R + j * 9 + e] = R[e];
         }
-        for (int i = t; i < HC * 48; i += 256) {
-            const int hl = i / 48, e = i - hl * 48;
-            float a = pk[PK_JT + e];
-#pragma unroll
-            for (int sdx = 0; sdx < 10; ++sdx) a += pk[PK_JS + e * 10 + sdx] * s_pf[hl * LDPF + NPF + sdx];
-            s_scr[hl * SCR + S_JT + e] = a;
-            if (ws != nullptr && tile == 0 && h0 + hl < B) ws[(long long)(h0 + hl) * WS_STRIDE + OFF_JT + e] = a;
-        }
         __syncthreads();
-        // ---- phase 1c: kinematic chain, one lane per hand (manolayer.py:274-289)
-        if (t < HC) {
-            const float* Rr = &s_scr[t * SCR + S_RR];
-            const float* jt = &s_scr[t * SCR + S_JT];
-            float* G = &s_G[t * GST];
-            float* src = &s_scr[t * SCR + S_SRC];
-            for (int i = 0; i < NJ; ++i) {
-                const float* R = Rr + i * 9;
-                const float* jv = jt + i * 3;
-                float tl[3];
-                for (int r = 0; r < 3; ++r) tl[r] = jv[r] - (R[r * 3] * jv[0] + R[r * 3 + 1] * jv[1] + R[r * 3 + 2] * jv[2]);
-                float* Gi = G + i * 12;
-                if (i == 0) {
-                    for (int r = 0; r < 3; ++r) {
-                        for (int c = 0; c < 3; ++c) Gi[r * 4 + c] = R[r * 3 + c];
-                        Gi[r * 4 + 3] = tl[r];
-                        src[r] = jv[r];
-                    }
-                } else {
-                    const float* P = G + m.parent[i] * 12;
-                    for (int r = 0; r < 3; ++r) {
-                        for (int c = 0; c < 3; ++c)
-                            Gi[r * 4 + c] = P[r * 4] * R[c] + P[r * 4 + 1] * R[3 + c] + P[r * 4 + 2] * R[6 + c];
-                        Gi[r * 4 + 3] = P[r * 4] * tl[0] + P[r * 4 + 1] * tl[1] + P[r * 4 + 2] * tl[2] + P[r * 4 + 3];
-                        src[i * 3 + r] = P[r * 4] * jv[0] + P[r * 4 + 1] * jv[1] + P[r * 4 + 2] * jv[2] + P[r * 4 + 3];
-                    }
+        RIH_STAMP(2);
+        // ---- phase 1c: kinematic chain by tree level (manolayer.py:274-289): G_j = G_parent(j) L_j, thread = (hand, joint,
+        //      row); a level reads its parents' finished SE3s, computes into registers, then overwrites its own slots
+        for (int lvl = 1; lvl <= s_depth[16]; ++lvl) {
+            float o[3][4];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {               // HC * 48 = 768 (hand, joint, row) items over 256 threads
+                const int i = t + 256 * q;
+                const int hl = i / 48, jr = i - hl * 48, j = jr / 3, r = jr - j * 3;
+                if (s_depth[j] == lvl) {
+                    const float* P = &s_G[hl * GST + m.parent[j] * 12 + r * 4];
+                    const float* L = &s_G[hl * GST + j * 12];
+                    o[q][0] = P[0] * L[0] + P[1] * L[4] + P[2] * L[8];
+                    o[q][1] = P[0] * L[1] + P[1] * L[5] + P[2] * L[9];
+                    o[q][2] = P[0] * L[2] + P[1] * L[6] + P[2] * L[10];
+                    o[q][3] = P[0] * L[3] + P[1] * L[7] + P[2] * L[11] + P[3];
                 }
             }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int i = t + 256 * q;
+                const int hl = i / 48, jr = i - hl * 48, j = jr / 3, r = jr - j * 3;
+                if (s_depth[j] == lvl) {
+                    float* Gj = &s_G[hl * GST + j * 12 + r * 4];
+                    Gj[0] = o[q][0]; Gj[1] = o[q][1]; Gj[2] = o[q][2]; Gj[3] = o[q][3];
+                }
+            }
+            __syncthreads();
+        }
+        // chain joint positions: src_j = G_j applied to the rest joint (= G_parent jt_j + t_parent)
+        for (int i = t; i < HC * 48; i += 256) {
+            const int hl = i / 48, jr = i - hl * 48, j = jr / 3, r = jr - j * 3;
+            const float* Gj = &s_G[hl * GST + j * 12 + r * 4];
+            const float* jv = &s_scr[hl * SCR + S_JT + j * 3];
+            s_scr[hl * SCR + S_SRC + jr] = Gj[0] * jv[0] + Gj[1] * jv[1] + Gj[2] * jv[2] + Gj[3];
         }
         __syncthreads();
-        // ---- phase 1d: the 13 special vertices (5 tips + 8 new_skel), blend from the packed basis in global memory
+        RIH_STAMP(3);
+        // ---- phase 1d: the 13 special vertices (5 tips + 8 new_skel): blend on the MFMA with the basis columns read straight
+        //      from the packed matrix (waves 0..2 own 16 of the 39 coordinates each), then skinning
         if (need_special) {
-            for (int i = t; i < HC * 39; i += 256) {
-                const int hl = i / 39, e = i - hl * 39;
-                const int vc = c_special[e / 3] * 3 + e % 3;
-                float a = 0.f;
-                for (int k = 0; k < NPF + 11; ++k) a = fmaf(s_pf[hl * LDPF + k], pk[(long long)k * NCP + vc], a);
-                s_scr[hl * SCR + S_SPT + e] = a;
+            if (wave < 3) {
+                const int kq = lane >> 4, n = wave * 16 + (lane & 15);
+                const int vc = (n < 39) ? c_special[n / 3] * 3 + n % 3 : 0;
+                float bv[KP / 4];
+#pragma unroll
+                for (int ks = 0; ks < KP / 4; ++ks) bv[ks] = pk[(long long)(4 * ks + kq) * NCP + vc];
+                const float* a_rd = s_pf + (lane & 15) * LDPF + kq;
+                floatx4 sp = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KP / 4; ++ks) sp = __builtin_amdgcn_mfma_f32_16x16x4f32(a_rd[4 * ks], bv[ks], sp, 0, 0, 0);
+                if (n < 39)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s_scr[(4 * kq + r) * SCR + S_SPT + n] = sp[r];
             }
             __syncthreads();
             for (int i = t; i < HC * 13; i += 256) {
@@ -497,6 +547,7 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
             }
             __syncthreads();
         }
+        RIH_STAMP(4);
         // ---- phase 1e: centre / scale / translation; tile 0 writes the 21 joints (and the joint-side workspace)
         if (t < HC) {
             const int h = h0 + t;
@@ -533,6 +584,7 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
                 }
             __syncthreads();            // the scratch (src / sp) is overwritten by the v_tpose tile below
         }
+        RIH_STAMP(5);
         // ---- phase 2: v_tpose[16][192] = operand[16][148] x Bmat tile; wave w owns coordinate blocks 3w .. 3w+2
         floatx4 acc[3];
 #pragma unroll
@@ -554,6 +606,7 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
 #pragma unroll
             for (int r = 0; r < 4; ++r) s_scr[(4 * (lane >> 4) + r) * 192 + wave * 48 + 16 * j + (lane & 15)] = acc[j][r];
         __syncthreads();
+        RIH_STAMP(6);
         // ---- phase 3: skinning, lane = vertex, wave w takes hands w, w+4, ...
         for (int hl = wave; hl < HC; hl += 4) {
             const int h = h0 + hl;
@@ -588,7 +641,9 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
                 }
             }
         }
+        RIH_STAMP(7);
     }
+#undef RIH_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -831,6 +886,10 @@ bool model_ok(const rih_mano_model* m) {
 extern "C" int64_t rih_mano_ws_floats(int B) { return B > 0 ? (int64_t)B * WS_STRIDE : 0; }
 extern "C" int64_t rih_mano_bwd_ws_floats(int B) { return B > 0 ? 4 : 0; }   // backward keeps its scratch in LDS
 
+static long long* g_mano_dbg = nullptr;
+// development aid: device buffer of 13 x 16 int64 that receives phase timestamps of the fused forward (NULL = off)
+extern "C" int rih_mano_debug_stamps(long long* buf) { g_mano_dbg = buf; return 0; }
+
 extern "C" int64_t rih_mano_pack_floats(void) { return PK_FLOATS; }
 
 extern "C" int rih_mano_pack(const rih_mano_model* m, float* packed, void* stream) {
@@ -858,7 +917,7 @@ extern "C" int rih_mano_fwd(const rih_mano_model* m, const float* packed, const 
         int groups = (512 + NTILES - 1) / NTILES;
         if (groups > nchunks) groups = nchunks;
         hipLaunchKernelGGL(mano_fused_kernel, dim3(NTILES, groups), dim3(256), 0, s, mm, packed, root, pose, ncomp, shape,
-                           trans, scale, center_idx, new_skel, v, j, ws, B);
+                           trans, scale, center_idx, new_skel, v, j, ws, B, g_mano_dbg);
         return (int)hipGetLastError();
     }
     if (variant != 1 || !ws) return RIH_EINVAL;     // round-1 two-kernel forward (A/B timing): needs the workspace

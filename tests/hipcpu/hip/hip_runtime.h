@@ -209,3 +209,6 @@ static inline int __builtin_amdgcn_readfirstlane_emul(int v) {
     hipcpu::launch(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); })
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 #include "../hipcpu_gfx950.h"
+
+// shader-clock read of the phase-stamp development aid (csrc/rih_mano.hip): no meaning on the host
+static inline long long clock64() { return 0; }

@@ -1,0 +1,26 @@
+#!/usr/bin/env python
+"""Phase timing of the fused MANO forward (shader-clock stamps of the first chunk of the workgroups (tile, group 0))."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from renderih_amd import assets, _lib
+from renderih_amd.manolayer import ManoLayer, rodrigues_batch
+dev = torch.device('cuda:0')
+lib = _lib.load()
+layer = ManoLayer(assets.synthetic_mano_dict('right')).to(dev)
+B = 4096
+g = torch.Generator().manual_seed(0)
+root = rodrigues_batch(torch.randn(B, 3, generator=g)).to(dev)
+pose, shape = (0.5 * torch.randn(B, 45, generator=g)).to(dev), torch.randn(B, 10, generator=g).to(dev)
+buf = torch.zeros(13 * 16, dtype=torch.int64, device=dev)
+with torch.no_grad():
+    layer(root, pose, shape)
+    torch.cuda.synchronize()
+    lib.rih_mano_debug_stamps(buf.data_ptr())
+    layer(root, pose, shape)
+    torch.cuda.synchronize()
+    lib.rih_mano_debug_stamps(0)
+s = buf.cpu().view(13, 16)
+names = ['1a pca/beta', '1b rot/jt', '1c chain', '1d special', '1e post/joints', '2 mfma', '3 skin']
+for tile in (0, 1, 12):
+    d = [int(s[tile, i + 1] - s[tile, i]) for i in range(7)]
+    print('tile %2d: ' % tile + ' | '.join('%s %d' % (n, x) for n, x in zip(names, d)) + ' | chunk total %d cycles' % (int(s[tile, 7] - s[tile, 0])))
