@@ -2,9 +2,14 @@
 `pose_data_optimize/sdf/sdf/csrc/sdf_cuda_kernel.cu:242-308` (`sdf_cuda_kernel`) with its helpers `point_segment_distance`
 (:69-88), `intersect_triangle` (:91-140), `point_triangle_distance` (:158-236).  Only tests/ may import this file.
 
-PARITY UNPINNED: the reference implementation exists only as a CUDA kernel (no CPU path, no test vectors in the reference),
-so it cannot be executed here; this file follows its source statement by statement in float32 and is additionally checked
-against closed-form fields (tests/test_sdf.py: sphere, cube).
+PINNED: the reference implementation exists only as a CUDA kernel, but its device code is plain C++, so oracle/Makefile
+compiles the reference's OWN source file for the host (oracle/_ref/libsdf_ref.so: `sdf_cuda_kernel<float>` from where it lies
+under /root/reference, run on the CPU by the fiber shim of tests/hipcpu).  tests/golden/sdf_ref.npz holds its outputs
+(tests/golden/make_sdf_golden.py); this restatement reproduces them with the same inside / outside decision for every voxel
+and |diff| <= 1.5e-7 (tests/test_sdf.py::test_oracle_matches_reference_kernel_golden; the reference evaluates the voxel centre
+in double and rounds once, numpy rounds twice).  One reference quirk is NOT restated: its host wrapper launches voxels / 512
+blocks rounded DOWN (sdf_cuda_kernel.cu:313), so for B * G^3 not a multiple of 512 the trailing voxels keep the caller's zeros;
+this oracle and the HIP kernel evaluate every voxel (identical for the reference's own G = 32).
 """
 import numpy as np
 

@@ -119,3 +119,4 @@ def test_batch_input_preparation_matches_reference_fixtures():
 def test_sdf_voxeliser():
     import test_sdf
     test_sdf.sdf_vs_oracle(dev(), G=16)
+    test_sdf.sdf_vs_reference_golden(dev())         # outputs of the reference's own kernel (oracle/_ref, tests/golden/sdf_ref.npz)

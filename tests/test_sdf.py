@@ -1,6 +1,7 @@
 """SDF voxeliser (csrc/rih_sdf.hip, renderih_amd/sdf.py; reference pose_data_optimize/sdf/sdf/csrc/sdf_cuda_kernel.cu).
-The reference kernel is CUDA-only and cannot run here: the oracle (a statement-by-statement float32 restatement) is checked
-against closed-form fields, the HIP kernel (host-compiled) against the oracle."""
+The oracle (a statement-by-statement float32 restatement) is pinned by golden vectors from the reference's OWN kernel source
+compiled for the host (oracle/Makefile -> oracle/_ref/libsdf_ref.so, tests/golden/make_sdf_golden.py) and checked against a
+closed-form field; the HIP kernel is checked against the oracle and against the same reference goldens."""
 import os
 import sys
 
@@ -56,6 +57,59 @@ def test_oracle_matches_closed_form_sphere():
     assert np.abs(phi[inside] - (R - r[inside])).max() < 0.02 * R
 
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'sdf_ref.npz')
+GOLDEN_CASES = ('spheres_g16', 'spheres_g12', 'bumpy_g20')
+
+
+def _written(phi):
+    """Voxels the reference actually writes: its host wrapper launches voxels / 512 blocks rounded down."""
+    return (phi.size // 512) * 512
+
+
+def test_oracle_matches_reference_kernel_golden():
+    z = np.load(GOLDEN)
+    for name in GOLDEN_CASES:
+        f, v, G, want = z[name + '/faces'], z[name + '/vertices'], int(z[name + '/grid']), z[name + '/phi']
+        got = sdf_oracle.sdf(f, v, G)
+        n = _written(want)
+        g, w = got.ravel()[:n], want.ravel()[:n]
+        assert ((g > 0) == (w > 0)).all(), name
+        assert np.abs(g - w).max() < 5e-7, (name, np.abs(g - w).max())
+        assert (want.ravel()[n:] == 0).all()            # never launched by the reference: the caller's zeros
+
+
+def test_oracle_matches_live_reference_kernel():
+    """When oracle/_ref/libsdf_ref.so is present (built here from /root/reference; it travels to the GPU box): a fresh random
+    closed surface through the reference kernel itself."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import make_sdf_golden
+    lib = make_sdf_golden.reference_lib()
+    if lib is None:
+        pytest.skip('oracle/_ref/libsdf_ref.so not built (needs /root/reference)')
+    rs = np.random.RandomState(11)
+    v, f = icosphere(0.55, 2, (0.05, -0.05, 0.1))
+    v = (v * (1 + 0.1 * rs.randn(v.shape[0], 1))).astype(np.float32)
+    want = make_sdf_golden.reference_sdf(lib, f, v[None], 16)
+    got = sdf_oracle.sdf(f, v[None], 16)
+    assert ((got > 0) == (want > 0)).mean() > 0.9995
+    same = (got > 0) == (want > 0)
+    assert np.abs(got - want)[same].max() < 5e-7
+
+
+def sdf_vs_reference_golden(dev):
+    """The HIP kernel against the outputs of the reference's own kernel."""
+    from renderih_amd.sdf import sdf
+    z = np.load(GOLDEN)
+    for name in GOLDEN_CASES:
+        f, v, G, want = z[name + '/faces'], z[name + '/vertices'], int(z[name + '/grid']), z[name + '/phi']
+        got = sdf(torch.from_numpy(f).to(dev), torch.from_numpy(v).to(dev), G).cpu().numpy()
+        n = _written(want)
+        g, w = got.ravel()[:n], want.ravel()[:n]
+        same = (g > 0) == (w > 0)
+        assert same.mean() > 0.999, (name, same.mean())     # a ray grazing an edge may flip with the rounding of one product
+        assert np.abs(g - w)[same].max() < 2e-6, name
+
+
 def sdf_vs_oracle(dev, G=12):
     from renderih_amd.sdf import sdf
     v1, f = icosphere(0.6, 1, (0.1, 0.0, -0.1))
@@ -73,6 +127,7 @@ def test_kernel_matches_oracle_on_cpu():
     from hipcpu.host_kernels import host_kernels_abi
     with host_kernels_abi():
         sdf_vs_oracle(torch.device('cpu'))
+        sdf_vs_reference_golden(torch.device('cpu'))
 
 
 def test_sdf_loss_host_logic():
