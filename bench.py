@@ -376,6 +376,7 @@ def main():
                            'global_batch': B * world, 'parallelism': 'dp%d' % world, 'loss': round(final_loss, 4),
                            'hipgraph': bool(use_graph),
                            'backward_stages': (trainer.nstage if trainer is not None else 1),
+                           'weight_gradients_on_side_stream': bool(trainer is not None and trainer.side_wgrad),
                            'gradient_buckets_MB': ([round(x / 1e6, 1) for x in trainer.bucket_bytes()] if trainer is not None else None),
                            'grad_allreduce': ('none (1 rank)' if not dist_on else 'torch DDP' if args.ddp else
                                               'per-stage buckets on a side stream, overlapped with the next backward stage'

@@ -287,6 +287,44 @@ def gemm_p3(A, B, Cout, M, N, K, lda, ldb, ldc, geom, bias=None, R=None, ldr=0, 
     check(_L().rih_gemm_p3(C.byref(d), _stream()), 'rih_gemm_p3')
 
 
+# --------------------------------------------------------------------------------------------- weight gradients off the
+# critical path (EXPERIMENT, off by default: RIH_SIDE_WGRAD=1).  The backward pass is a dependent chain of data-gradient
+# kernels; a layer's weight gradient (split-K GEMM + reduce, ~1/3 of all launches) feeds nothing but the optimizer.  With
+# SIDE_WGRAD set (renderih_amd.train.TrainStep does it around each backward stage) `_wgrad` enqueues its launches on a second
+# HIP stream that waits for everything issued so far and is joined at the end of the stage.  Measured on MI355X
+# (profiles/r02/bench_side_wgrad_m9.log): 43.89 vs 44.02 ms per step -- no gain: the step is bound by the SUM of kernel
+# times (every launch, even a 15 us decoder GEMM, fills the CUs with resident workgroups), not by launch gaps or by the
+# dependency chain; an eager (no hipGraph) step measures the same 44.0 ms.  Operands are kept alive until the join.
+class _SideWork:
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.keep = []
+        self.used = False
+
+
+SIDE_WGRAD = None
+
+
+def side_wgrad_begin(device):
+    global SIDE_WGRAD
+    if SIDE_WGRAD is None or SIDE_WGRAD.stream.device != device:
+        SIDE_WGRAD = _SideWork(device)
+    return SIDE_WGRAD
+
+
+def side_wgrad_join(disable=True):
+    """Make the current stream wait for the weight gradients issued on the side stream; drop the keep-alive references."""
+    global SIDE_WGRAD
+    sw = SIDE_WGRAD
+    if sw is not None:
+        if sw.used:
+            torch.cuda.current_stream().wait_stream(sw.stream)
+            sw.used = False
+        sw.keep.clear()
+        if disable:
+            SIDE_WGRAD = None
+
+
 def _pdiff(a, b):
     """Distance in floats between the storage of two fp32 tensors: the nb1 stride that walks from a left-hand parameter
     to the right-hand one, so that both hands' layers run as one batched launch."""
@@ -296,6 +334,17 @@ def _pdiff(a, b):
 
 
 def _wgrad(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db=None, nb=1, sx=0, sdy=0):
+    sw = SIDE_WGRAD
+    if sw is None or not x.is_cuda:
+        return _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db, nb, sx, sdy)
+    sw.stream.wait_stream(torch.cuda.current_stream())      # x, dy (and everything before them) are ready
+    with torch.cuda.stream(sw.stream):
+        _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db, nb, sx, sdy)
+    sw.keep.extend((x, dy, dw, db))
+    sw.used = True
+
+
+def _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db=None, nb=1, sx=0, sdy=0):
     """dw (parameter layout) = im2col(x)^T @ dy with split-K over the Kpix pixels.  With `db` (bias gradient, [Ncols])
     the A operand gets an all-ones row behind its Mrows rows, so the same GEMM also produces the column sums of dy.
     nb > 1: that many independent gradients in one GEMM + one reduce launch (x / dy slices sx / sdy floats apart, sx = 0

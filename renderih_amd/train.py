@@ -49,7 +49,7 @@ def stage_parameter_groups(model):
 
 class TrainStep:
     def __init__(self, model, optimizer, loss_fn, example_batch, process_group=None, use_graph=True, stages=True,
-                 overlap=True, record_order=None, force_exchange=False):
+                 overlap=True, record_order=None, force_exchange=False, side_wgrad=None):
         """model: HandNET_GCN (train mode, on its device).  optimizer: any torch optimizer over model's parameters.
         loss_fn(outputs, labels) -> scalar loss.  example_batch = (img, labels): tensors with the shapes / dtypes of
         every later call (static buffers of the graphs).  process_group: None = default group if torch.distributed is
@@ -66,6 +66,8 @@ class TrainStep:
             self.world = dist.get_world_size(process_group)
         self.groups = stage_parameter_groups(model) if stages else [[p for p in model.parameters() if p.requires_grad]]
         self.nstage = len(self.groups)
+        import os
+        self.side_wgrad = (os.environ.get('RIH_SIDE_WGRAD', '0') == '1') if side_wgrad is None else bool(side_wgrad)
         self.exchange = self.world > 1 or (force_exchange and dist.is_available() and dist.is_initialized())
         self.overlap = overlap and self.exchange
         self.img, self.labels = example_batch
@@ -124,6 +126,15 @@ class TrainStep:
         return self.loss_fn(out, self.labels)
 
     def _stage(self, i, loss, carry):
+        """Backward stage i with the weight gradients on the side stream (ops.SIDE_WGRAD), joined before returning."""
+        if self.side_wgrad and self.cuda:
+            ops.side_wgrad_begin(self.img.device)
+        try:
+            return self._stage_body(i, loss, carry)
+        finally:
+            ops.side_wgrad_join()
+
+    def _stage_body(self, i, loss, carry):
         """Backward stage i.  Returns (parameter gradients of the stage, carry for the next stage)."""
         g = self.groups[i]
         if self.nstage == 1:
