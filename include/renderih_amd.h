@@ -159,7 +159,12 @@ int rih_gemm_p3_tile_rows(int tile);
 int rih_p3_from_f32(const float* x, int64_t rows, int C, int ldx, void* out, int ldo, void* stream);
 int rih_p3_conv_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int CinPad, int for_dgrad, int kh0,
                        int kw0, int step, int Th, int Tw, int Kpad, void* stream);
-/* part [T][C][2] from rih_gemm_p3 (tiles of rows_per_tile rows) -> mean[C], biased variance var[C] */
+/* part [T][C][2] from rih_gemm_p3 (tiles of rows_per_tile rows) -> what rih_bn_stats produces: mean[C],
+ * invstd[C] = 1 / sqrt(biased var + eps) and, when running_mean / running_var != NULL, their momentum update with the unbiased
+ * variance (nn.BatchNorm2d training forward).  Chan's merge in double, one wavefront per channel. */
+int rih_bn_stats_from_tiles(const float* part, int T, int C, int rows_per_tile, float eps, float momentum, float* mean,
+                            float* invstd, float* running_mean, float* running_var, void* stream);
+/* part [T][C][2] (tiles of rows_per_tile rows) -> mean[C], biased variance var[C] */
 int rih_bn_stats_merge(const float* part, int T, int C, int rows_per_tile, float* mean, float* var, void* stream);
 
 /* Pre-split B operands for rih_gemm b_mode 2 (weights are constant within a training step, so their bf16 hi/mid/lo
@@ -217,13 +222,15 @@ int rih_bn_eval_stats(const float* running_mean, const float* running_var, int C
                       float* invstd, void* stream);
 /* y = act((x-mean)*invstd*gamma + beta + residual) */
 int rih_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                 const float* residual, float* y, int rows, int C, int relu, void* stream);
-/* backward of the above (training statistics): given dy and the forward output y (for the ReLU mask),
- * produces dx, dgamma, dbeta and, when dres != NULL, the residual-branch gradient (= masked dy).
+                 const float* residual, float* y, int rows, int C, int relu, uint8_t* relu_mask, void* stream);
+/* relu_mask (optional, relu != 0): rows*C/4 bytes, byte q = sign pattern of output quad q (bit e set: element 4q+e > 0).
+ * The backward then reads one byte per quad instead of the 16 bytes of y (it needs nothing else of y).
+ * backward of the above (training statistics): given dy and the ReLU pattern (relu_mask, or the forward output y when
+ * relu_mask == NULL), produces dx, dgamma, dbeta and, when dres != NULL, the residual-branch gradient (= masked dy).
  * frozen_stats != 0: eval-mode backward (statistics are constants). */
 int rih_bn_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
                const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C,
-               int relu, int frozen_stats, float* ws, void* stream);
+               int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row-wise ops on [rows][D] matrices (decoder)                                                         */
@@ -365,7 +372,7 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
  * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of the by-pointer structs
  * (gemm desc, mano model, mesh topo, hconv desc), so a host binding can refuse a stale binary instead of handing it
  * mis-laid-out structs. */
-#define RIH_ABI_VERSION 3
+#define RIH_ABI_VERSION 4
 int rih_version(void);
 int rih_abi_sizes(int32_t* out4);
 const char* rih_arch(void);

@@ -114,8 +114,8 @@ SIGNATURES = {
     'rih_bn_ws_floats': (c_l, [c_i, c_i]),
     'rih_bn_stats': (c_i, [c_f, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f, C.c_void_p]),
     'rih_bn_eval_stats': (c_i, [c_f, c_f, c_i, c_fl, c_f, c_f, C.c_void_p]),
-    'rih_bn_apply': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, C.c_void_p]),
-    'rih_bn_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, C.c_void_p]),
+    'rih_bn_apply': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, C.c_void_p, C.c_void_p]),
+    'rih_bn_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, C.c_void_p, C.c_void_p]),
     'rih_layernorm_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_i, C.c_void_p]),
     'rih_ln_nblk': (c_i, [c_i]),
     'rih_layernorm_fwd_grouped': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_l, c_l, c_fl, c_i, C.c_void_p]),
@@ -152,12 +152,13 @@ SIGNATURES = {
     'rih_p3_from_f32': (c_i, [c_f, c_l, c_i, c_i, C.c_void_p, c_i, C.c_void_p]),
     'rih_p3_conv_weight': (c_i, [c_f, C.c_void_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
     'rih_bn_stats_merge': (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),
+    'rih_bn_stats_from_tiles': (c_i, [c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, C.c_void_p]),
     'rih_version': (c_i, []),
     'rih_abi_sizes': (c_i, [C.POINTER(C.c_int32)]),
     'rih_arch': (C.c_char_p, []),
 }
 
-ABI_VERSION = 3      # = RIH_ABI_VERSION of include/renderih_amd.h
+ABI_VERSION = 4      # = RIH_ABI_VERSION of include/renderih_amd.h
 
 _lib = None
 

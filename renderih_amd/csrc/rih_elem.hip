@@ -396,7 +396,7 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const floa
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ y,
-                                long long nquads, int C, int relu) {
+                                long long nquads, int C, int relu, unsigned char* __restrict__ mask) {
     const int CG = C / 4;
     GRID_STRIDE(i, nquads) {
         const int g = (int)(i % CG);
@@ -414,7 +414,12 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
             const float4 r = reinterpret_cast<const float4*>(res)[i];
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
-        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        if (relu) {
+            // the backward needs only the sign pattern of the output: one byte per quad instead of re-reading y (16 bytes)
+            if (mask != nullptr)
+                mask[i] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
         reinterpret_cast<float4*>(y)[i] = o;
     }
 }
@@ -425,7 +430,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, int rows, int C, int cgb,
                                                              int rt, int rows_per_chunk, int relu,
-                                                             float* __restrict__ ws) {
+                                                             float* __restrict__ ws,
+                                                             const unsigned char* __restrict__ mask) {
     const int cg = threadIdx.x % cgb, ry = threadIdx.x / cgb;
     const int g = blockIdx.x * cgb + cg;
     const int CG = C / 4;
@@ -440,11 +446,19 @@ __global__ __launch_bounds__(TPB) void bn_bwd_partial_kernel(const float* __rest
             float4 d = *reinterpret_cast<const float4*>(dy + o);
             const float4 v = *reinterpret_cast<const float4*>(x + o);
             if (relu) {
-                const float4 yy = *reinterpret_cast<const float4*>(y + o);
-                if (!(yy.x > 0.f)) d.x = 0.f;
-                if (!(yy.y > 0.f)) d.y = 0.f;
-                if (!(yy.z > 0.f)) d.z = 0.f;
-                if (!(yy.w > 0.f)) d.w = 0.f;
+                if (mask != nullptr) {
+                    const unsigned bits = mask[(long long)r * CG + g];
+                    if (!(bits & 1u)) d.x = 0.f;
+                    if (!(bits & 2u)) d.y = 0.f;
+                    if (!(bits & 4u)) d.z = 0.f;
+                    if (!(bits & 8u)) d.w = 0.f;
+                } else {
+                    const float4 yy = *reinterpret_cast<const float4*>(y + o);
+                    if (!(yy.x > 0.f)) d.x = 0.f;
+                    if (!(yy.y > 0.f)) d.y = 0.f;
+                    if (!(yy.z > 0.f)) d.z = 0.f;
+                    if (!(yy.w > 0.f)) d.w = 0.f;
+                }
             }
             acc[0].x += d.x; acc[0].y += d.y; acc[0].z += d.z; acc[0].w += d.w;
             acc[1].x += d.x * ((v.x - m.x) * is.x);
@@ -481,17 +495,25 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ sum_dy, const float* __restrict__ sum_dyxh,
                                     float* __restrict__ dx, float* __restrict__ dres, long long nquads, int C,
-                                    float inv_rows, int relu, int frozen) {
+                                    float inv_rows, int relu, int frozen, const unsigned char* __restrict__ mask) {
     const int CG = C / 4;
     GRID_STRIDE(i, nquads) {
         const int g = (int)(i % CG);
         float4 d = reinterpret_cast<const float4*>(dy)[i];
         if (relu) {
-            const float4 yy = reinterpret_cast<const float4*>(y)[i];
-            if (!(yy.x > 0.f)) d.x = 0.f;
-            if (!(yy.y > 0.f)) d.y = 0.f;
-            if (!(yy.z > 0.f)) d.z = 0.f;
-            if (!(yy.w > 0.f)) d.w = 0.f;
+            if (mask != nullptr) {
+                const unsigned bits = mask[i];
+                if (!(bits & 1u)) d.x = 0.f;
+                if (!(bits & 2u)) d.y = 0.f;
+                if (!(bits & 4u)) d.z = 0.f;
+                if (!(bits & 8u)) d.w = 0.f;
+            } else {
+                const float4 yy = reinterpret_cast<const float4*>(y)[i];
+                if (!(yy.x > 0.f)) d.x = 0.f;
+                if (!(yy.y > 0.f)) d.y = 0.f;
+                if (!(yy.z > 0.f)) d.z = 0.f;
+                if (!(yy.w > 0.f)) d.w = 0.f;
+            }
         }
         if (dres != nullptr) reinterpret_cast<float4*>(dres)[i] = d;
         const float4 is = reinterpret_cast<const float4*>(invstd)[g];
@@ -1073,26 +1095,26 @@ extern "C" int rih_bn_eval_stats(const float* running_mean, const float* running
 }
 extern "C" int rih_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
                             const float* beta, const float* residual, float* y, int rows, int C, int relu,
-                            void* stream) {
+                            uint8_t* relu_mask, void* stream) {
     if (!x || !mean || !invstd || !gamma || !beta || !y || rows < 1 || C < 4 || (C % 4) != 0) return RIH_EINVAL;
     const long long nq = (long long)rows * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(nq)), dim3(TPB), 0, STREAM, x, mean, invstd, gamma, beta, residual,
-                       y, nq, C, relu);
+                       y, nq, C, relu, relu_mask);
     LAUNCH_RET();
 }
 extern "C" int rih_bn_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
                           const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C,
-                          int relu, int frozen_stats, float* ws, void* stream) {
+                          int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !dx || !dgamma || !dbeta || !ws) return RIH_EINVAL;
-    if (relu && !y) return RIH_EINVAL;
+    if (relu && !y && !relu_mask) return RIH_EINVAL;
     if (rows < 1 || C < 4 || (C % 4) != 0) return RIH_EINVAL;
     const ColGeom g = col_geom(rows, C);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(g.gx, g.nchunk), dim3(TPB), 0, STREAM, dy, x, y, mean, invstd, rows, C,
-                       g.cgb, g.rt, g.rows_per_chunk, relu, ws);
+                       g.cgb, g.rt, g.rows_per_chunk, relu, ws, relu_mask);
     hipLaunchKernelGGL(two_sum_final_kernel, dim3((C + 3) / 4), dim3(TPB), 0, STREAM, ws, C, g.nchunk, dbeta, dgamma);
     const long long nq = (long long)rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nq)), dim3(TPB), 0, STREAM, dy, x, y, mean, invstd, gamma,
-                       dbeta, dgamma, dx, dres, nq, C, 1.f / (float)rows, relu, frozen_stats);
+                       dbeta, dgamma, dx, dres, nq, C, 1.f / (float)rows, relu, frozen_stats, relu_mask);
     LAUNCH_RET();
 }
 

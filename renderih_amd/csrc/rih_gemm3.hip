@@ -394,6 +394,37 @@ __global__ void bn_stats_merge_kernel(const float* __restrict__ part, int T, int
     }
 }
 
+// the same merge with nn.BatchNorm2d's finalisation (bn_stats_final_kernel of rih_elem.hip)
+__global__ void bn_stats_from_tiles_kernel(const float* __restrict__ part, int T, int C, int rows_per_tile, float eps,
+                                           float momentum, float* __restrict__ mean_out, float* __restrict__ invstd,
+                                           float* __restrict__ rmean, float* __restrict__ rvar) {
+    const int c = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int t = lane; t < T; t += 64) s += (double)part[((long long)t * C + c) * 2];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const double mean = s / T;
+    double m2 = 0.0;
+    for (int t = lane; t < T; t += 64) {
+        const double d = (double)part[((long long)t * C + c) * 2] - mean;
+        m2 += (double)part[((long long)t * C + c) * 2 + 1] + (double)rows_per_tile * d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
+    if (lane != 0) return;
+    const double n = (double)T * rows_per_tile;
+    const double var = m2 / n;
+    mean_out[c] = (float)mean;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean != nullptr) {
+        const double unb = (n > 1.0) ? var * n / (n - 1.0) : var;
+        rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mean);
+        rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+    }
+}
+
 template <int WGM, int WGN, int TM, int TN, int VAR = 0>
 int launch_p3(const G3Args& a, hipStream_t s) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
@@ -477,5 +508,14 @@ extern "C" int rih_bn_stats_merge(const float* part, int T, int C, int rows_per_
     if (!part || !mean || !var || T < 1 || C < 1 || rows_per_tile < 1) return RIH_EINVAL;
     hipLaunchKernelGGL(bn_stats_merge_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, T, C, rows_per_tile,
                        mean, var);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rih_bn_stats_from_tiles(const float* part, int T, int C, int rows_per_tile, float eps, float momentum, float* mean,
+                                       float* invstd, float* running_mean, float* running_var, void* stream) {
+    if (!part || !mean || !invstd || T < 1 || C < 1 || rows_per_tile < 1) return RIH_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return RIH_EINVAL;
+    hipLaunchKernelGGL(bn_stats_from_tiles_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, T, C,
+                       rows_per_tile, eps, momentum, mean, invstd, running_mean, running_var);
     return (int)hipGetLastError();
 }

@@ -17,10 +17,10 @@ import torch.nn as nn
 from . import ops
 
 
-def bn_act(bn, x, residual=None, relu=False):
+def bn_act(bn, x, residual=None, relu=False, tile_stats=None):
     """nn.BatchNorm2d semantics (train: batch stats + running update; eval: running stats) on NHWC."""
     y = ops.batchnorm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual=residual,
-                      training=bn.training, relu=relu, eps=bn.eps, momentum=bn.momentum)
+                      training=bn.training, relu=relu, eps=bn.eps, momentum=bn.momentum, tile_stats=tile_stats)
     if bn.training and bn.num_batches_tracked is not None:
         _PENDING_TRACKED.append(bn.num_batches_tracked)
     return y
@@ -43,6 +43,19 @@ def conv(m, x, relu=False):
     return ops.conv2d(x, m.weight, m.bias, stride=m.stride[0], pad=m.padding[0], relu=relu)
 
 
+def conv_bn(cm, bn, x, residual=None, relu=False, conv_relu=False, skip=False):
+    """Conv2d followed by BatchNorm2d (Conv -> BN (-> ReLU) of the trunk, models/encoder.py:107-116, or Conv -> ReLU -> BN of
+    the aux decoders / mid convs, :52-54 with conv_relu=True).  skip=True: also returns the alias of x for the block's skip
+    path (ops.conv2d_skip).  (Taking the BatchNorm statistics from the convolution's GEMM epilogue was built and measured in
+    round 2: 45.1 vs 44.95 ms per step -- the statistics epilogue costs the big GEMMs as much as the 0.95 ms pass it removes --
+    so only the P3 kernel keeps that epilogue; `bn_act(tile_stats=...)` is its consumer.)"""
+    f = ops.conv2d_skip if skip else ops.conv2d
+    out = f(x, cm.weight, cm.bias, stride=cm.stride[0], pad=cm.padding[0], relu=conv_relu)
+    y, idt = out if skip else (out, None)
+    y = bn_act(bn, y, residual=residual, relu=relu)
+    return (y, idt) if skip else y
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -59,13 +72,11 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         # the skip path is fed from conv1's second output (an alias of x): its gradient is added inside conv1's
         # data-gradient GEMM instead of by a separate pass over the activation (ops.Conv2dFn)
-        c1 = self.conv1
-        out, idt = ops.conv2d_skip(x, c1.weight, c1.bias, stride=c1.stride[0], pad=c1.padding[0])
-        out = bn_act(self.bn1, out, relu=True)
-        out = bn_act(self.bn2, conv(self.conv2, out), relu=True)
+        out, idt = conv_bn(self.conv1, self.bn1, x, relu=True, skip=True)
+        out = conv_bn(self.conv2, self.bn2, out, relu=True)
         if self.downsample is not None:
-            idt = bn_act(self.downsample[1], conv(self.downsample[0], idt))
-        return bn_act(self.bn3, conv(self.conv3, out), residual=idt, relu=True)
+            idt = conv_bn(self.downsample[0], self.downsample[1], idt)
+        return conv_bn(self.conv3, self.bn3, out, residual=idt, relu=True)
 
 
 class ResNetTrunk(nn.Module):
@@ -98,7 +109,7 @@ class ResNetTrunk(nn.Module):
 
     def forward(self, x):
         """x: NHWC image padded to 4 channels.  Returns x4,x3,x2,x1 (NHWC)."""
-        x = bn_act(self.bn1, conv(self.conv1, x), relu=True)
+        x = conv_bn(self.conv1, self.bn1, x, relu=True)
         x = ops.maxpool3x3s2(x)
         x4 = self.layer1(x)
         x3 = self.layer2(x4)
@@ -211,7 +222,7 @@ class ResNetSimple_decoder(nn.Module):
             if isinstance(mods[0], nn.Upsample):
                 x = ops.upsample_bilinear2x(x)
                 mods = mods[1:]
-            x = bn_act(mods[2], conv(mods[0], x, relu=True))
+            x = conv_bn(mods[0], mods[2], x, conv_relu=True)
             fmaps.append(x)
         return conv(self.final_layer, x), fmaps
 
@@ -277,7 +288,7 @@ class resnet_mid(nn.Module):
         for i, seq in enumerate(self.convs):
             parts = [hms_fmaps[i], dp_fmaps[i]] + ([img_fmaps[i]] if i > 0 else [])
             x = torch.cat(parts, dim=-1)                     # channel concat = last dim in NHWC (pure copy)
-            fmaps.append(bn_act(seq[2], conv(seq[0], x, relu=True)))
+            fmaps.append(conv_bn(seq[0], seq[2], x, conv_relu=True))
         flush_batches_tracked()
         return gf, fmaps
 

@@ -751,7 +751,7 @@ class BatchNormFn(torch.autograd.Function):
     in place (momentum 0.1, unbiased running_var) exactly like torch; eval: running statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, residual, training, relu, eps, momentum):
+    def forward(ctx, x, gamma, beta, rmean, rvar, residual, training, relu, eps, momentum, tile_stats=None):
         _chk(x, gamma, beta, rmean, rvar, residual)
         x = _c(x)
         Cc = x.shape[-1]
@@ -763,25 +763,33 @@ class BatchNormFn(torch.autograd.Function):
         y = torch.empty_like(x)
         if residual is not None:
             residual = _c(residual)
+        # the backward needs only the sign pattern of a ReLU'd output: one byte per quad (rih_bn_apply relu_mask)
+        mask = torch.empty((x.numel() // 4,), device=x.device, dtype=torch.uint8) if relu else None
 
         def run():
-            if training:
+            if training and tile_stats is not None:       # statistics came out of the producing GEMM's epilogue
+                part, T, bm = tile_stats
+                assert T * bm == rows and part.shape[1] == Cc
+                check(lib.rih_bn_stats_from_tiles(part.data_ptr(), T, Cc, bm, eps, momentum, mean.data_ptr(), invstd.data_ptr(),
+                                                  _p(rmean), _p(rvar), _stream()), 'rih_bn_stats_from_tiles')
+            elif training:
                 check(lib.rih_bn_stats(x.data_ptr(), rows, Cc, eps, momentum, mean.data_ptr(), invstd.data_ptr(),
                                        _p(rmean), _p(rvar), ws.data_ptr(), _stream()), 'rih_bn_stats')
             else:
                 check(lib.rih_bn_eval_stats(rmean.data_ptr(), rvar.data_ptr(), Cc, eps, mean.data_ptr(),
                                             invstd.data_ptr(), _stream()), 'rih_bn_eval_stats')
             check(lib.rih_bn_apply(x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                   _p(residual), y.data_ptr(), rows, Cc, 1 if relu else 0, _stream()), 'rih_bn_apply')
+                                   _p(residual), y.data_ptr(), rows, Cc, 1 if relu else 0, _p(mask), _stream()), 'rih_bn_apply')
         # algorithmic bytes: statistics read x once (training), apply reads x (+ residual) and writes y
-        _elem_profile(4.0 * x.numel() * ((1 if training else 0) + 2 + (1 if residual is not None else 0)), 'bn_fwd', run)
-        ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma)
+        _elem_profile(x.numel() * (4.0 * ((1 if training and tile_stats is None else 0) + 2 + (1 if residual is not None else 0))
+                                   + (0.25 if relu else 0.0)), 'bn_fwd', run)
+        ctx.save_for_backward(x, mask, mean, invstd, gamma)
         ctx.cfg = (training, relu, residual is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, invstd, gamma = ctx.saved_tensors
+        x, mask, mean, invstd, gamma = ctx.saved_tensors
         training, relu, has_res = ctx.cfg
         dy = _c(dy)
         Cc = x.shape[-1]
@@ -792,16 +800,17 @@ class BatchNormFn(torch.autograd.Function):
         dg = torch.empty_like(gamma)
         db = torch.empty_like(gamma)
         ws = torch.empty((int(lib.rih_bn_ws_floats(rows, Cc)),), device=x.device, dtype=torch.float32)
-        # algorithmic bytes: reduction pass reads dy and x (+ y for the ReLU mask), apply reads them again and writes dx (+ dres)
-        _elem_profile(4.0 * x.numel() * (2 * (2 + (1 if relu else 0)) + 1 + (1 if has_res else 0)), 'bn_bwd', lambda: check(
-            lib.rih_bn_bwd(dy.data_ptr(), x.data_ptr(), _p(y), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+        # algorithmic bytes: reduction pass reads dy and x (+ 1 byte per quad of ReLU pattern), apply reads them again and
+        # writes dx (+ dres)
+        _elem_profile(x.numel() * (4.0 * (2 * 2 + 1 + (1 if has_res else 0)) + (0.5 if relu else 0.0)), 'bn_bwd', lambda: check(
+            lib.rih_bn_bwd(dy.data_ptr(), x.data_ptr(), 0, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                            dx.data_ptr(), _p(dres), dg.data_ptr(), db.data_ptr(), rows, Cc, 1 if relu else 0,
-                           0 if training else 1, ws.data_ptr(), _stream()), 'rih_bn_bwd'))
-        return dx, dg, db, None, None, dres, None, None, None, None
+                           0 if training else 1, ws.data_ptr(), _p(mask), _stream()), 'rih_bn_bwd'))
+        return dx, dg, db, None, None, dres, None, None, None, None, None
 
 
-def batchnorm(x, gamma, beta, rmean, rvar, residual=None, training=True, relu=False, eps=1e-5, momentum=0.1):
-    return BatchNormFn.apply(x, gamma, beta, rmean, rvar, residual, training, relu, eps, momentum)
+def batchnorm(x, gamma, beta, rmean, rvar, residual=None, training=True, relu=False, eps=1e-5, momentum=0.1, tile_stats=None):
+    return BatchNormFn.apply(x, gamma, beta, rmean, rvar, residual, training, relu, eps, momentum, tile_stats)
 
 
 # --------------------------------------------------------------------------------------------- layout / pooling

@@ -237,6 +237,7 @@ class TrainStep:
         if self.exchange:
             import torch.distributed as dist
             dist.barrier(group=self.group)
+            torch.cuda.synchronize()                # no collective may be in flight while a stream is capturing
         for p in self.model.parameters():
             p.grad = None
         self.graphs, self.static = [], []
@@ -245,7 +246,9 @@ class TrainStep:
             carry, loss = None, None
             for i in range(self.nstage):
                 gph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gph, pool=pool, stream=cap):
+                # thread_local: RCCL's watchdog thread polls events of finished collectives; under the default (global) mode
+                # such a call from another thread invalidates the capture (hipErrorStreamCaptureUnsupported)
+                with torch.cuda.graph(gph, pool=pool, stream=cap, capture_error_mode='thread_local'):
                     if i == 0:
                         seed_word.add_(0x9E3779B1)
                         loss = self._forward_loss()

@@ -141,6 +141,20 @@ class EmulatedLib:
                 mem[(cm * d.ldc + cn).ravel()] = out.astype(np.float32).ravel()
         return 0
 
+    def rih_bn_stats_from_tiles(self, part, T, Cc, rows_per_tile, eps, momentum, mean, invstd, rmean, rvar, stream):
+        p_ = _f(part, T * Cc * 2).reshape(T, Cc, 2).astype(np.float64)
+        m = p_[:, :, 0].mean(0)
+        m2 = (p_[:, :, 1] + rows_per_tile * (p_[:, :, 0] - m) ** 2).sum(0)
+        n = float(T * rows_per_tile)
+        var = m2 / n
+        _f(mean, Cc)[:] = m
+        _f(invstd, Cc)[:] = 1.0 / np.sqrt(var + eps)
+        if rmean:
+            unb = var * n / (n - 1.0) if n > 1 else var
+            _f(rmean, Cc)[:] = (1.0 - momentum) * _f(rmean, Cc) + momentum * m
+            _f(rvar, Cc)[:] = (1.0 - momentum) * _f(rvar, Cc) + momentum * unb
+        return 0
+
     @staticmethod
     def _bf16_rne(x):
         u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
@@ -782,19 +796,30 @@ class EmulatedLib:
         _f(invstd, Cc)[:] = 1.0 / np.sqrt(_f(rvar, Cc) + np.float32(eps))
         return 0
 
-    def rih_bn_apply(self, x, mean, invstd, gamma, beta, res, y, rows, Cc, relu, stream):
+    @staticmethod
+    def _u8view(ptr, n):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n,))
+
+    def rih_bn_apply(self, x, mean, invstd, gamma, beta, res, y, rows, Cc, relu, mask, stream):
         X = _f(x, rows * Cc).reshape(rows, Cc)
         o = (X - _f(mean, Cc)) * (_f(invstd, Cc) * _f(gamma, Cc)) + _f(beta, Cc)
         if res:
             o = o + _f(res, rows * Cc).reshape(rows, Cc)
         if relu:
+            if mask:            # one byte per quad of consecutive elements: bit e = element e of the quad is positive
+                bits = (o.reshape(-1, 4) > 0).astype(np.uint8)
+                self._u8view(mask, rows * Cc // 4)[:] = bits[:, 0] | (bits[:, 1] << 1) | (bits[:, 2] << 2) | (bits[:, 3] << 3)
             o = np.maximum(o, 0)
         _f(y, rows * Cc)[:] = o.ravel()
         return 0
 
-    def rih_bn_bwd(self, dy, x, y, mean, invstd, gamma, dx, dres, dgamma, dbeta, rows, Cc, relu, frozen, ws, stream):
+    def rih_bn_bwd(self, dy, x, y, mean, invstd, gamma, dx, dres, dgamma, dbeta, rows, Cc, relu, frozen, ws, mask, stream):
         D = _f(dy, rows * Cc).reshape(rows, Cc).copy()
-        if relu:
+        if relu and mask:
+            m = self._u8view(mask, rows * Cc // 4)
+            keep = np.stack([(m >> e) & 1 for e in range(4)], 1).reshape(rows, Cc).astype(bool)
+            D[~keep] = 0
+        elif relu:
             D[_f(y, rows * Cc).reshape(rows, Cc) <= 0] = 0
         X = _f(x, rows * Cc).reshape(rows, Cc)
         xh = (X - _f(mean, Cc)) * _f(invstd, Cc)

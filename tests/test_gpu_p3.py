@@ -114,6 +114,14 @@ def test_p3_tile_statistics_and_merge(tile, shape):
                                              ops._stream()), 'rih_bn_stats_merge')
     assert_close(mean, ref.mean(0).float(), 1e-4, 1e-5, 'p3 stats mean')
     assert_close(var, ref.var(0, unbiased=False).float(), 1e-4, 1e-5, 'p3 stats var')
+    # the same partials finalised like nn.BatchNorm2d's training forward (what ops.batchnorm(tile_stats=...) consumes)
+    invstd = torch.empty(Cout, device=d)
+    rm, rv = torch.zeros(Cout, device=d), torch.ones(Cout, device=d)
+    ops.check(_lib.load().rih_bn_stats_from_tiles(st.data_ptr(), T, Cout, ops.P3_TILES[tile][0], 1e-5, 0.1, mean.data_ptr(),
+                                                  invstd.data_ptr(), rm.data_ptr(), rv.data_ptr(), ops._stream()), 'from_tiles')
+    assert_close(invstd, (1.0 / torch.sqrt(ref.var(0, unbiased=False) + 1e-5)).float(), 1e-4, 1e-5, 'invstd')
+    assert_close(rm, (0.1 * ref.mean(0)).float(), 1e-4, 1e-5, 'running mean')
+    assert_close(rv, (0.9 + 0.1 * ref.var(0, unbiased=True)).float(), 1e-4, 1e-5, 'running var')
 
 
 @pytest.mark.parametrize('case', [(2, 8, 8, 64, 32, 3, 1, 1), (2, 9, 7, 32, 64, 3, 2, 1), (2, 8, 8, 64, 32, 1, 2, 0)])
