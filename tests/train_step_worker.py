@@ -75,6 +75,29 @@ def main():
             ref = flat.clone()
             dist.broadcast(ref, 0)
             assert torch.equal(flat, ref), 'parameters diverged after the step'
+        # ZeRO-1 as the reference's trainer builds it for distributed runs (core/gcn_trainer.py:121-125: torch's
+        # ZeroRedundancyOptimizer shards the optimiser state over the ranks): TrainStep only calls optimizer.step(), so the
+        # sharded optimiser drops in -- same parameters on every rank afterwards, and the same update as the plain optimiser
+        if world > 1:
+            from torch.distributed.optim import ZeroRedundancyOptimizer
+            after_plain = {k: p.detach().clone() for k, p in m.named_parameters()}
+            for k, p in m.named_parameters():
+                p.data.copy_(before[k])
+            zopt = ZeroRedundancyOptimizer([p for p in m.parameters() if p.requires_grad], optimizer_class=torch.optim.SGD,
+                                           lr=1e-3)
+            zstep = TrainStep(m, zopt, lambda out, lab: scalar_loss(out), (img, {}), use_graph=False)
+            zstep(img, {})
+            zstep(img, {})      # (the first call of a TrainStep learns the live set: two calls = two optimiser steps)
+            for k, p in m.named_parameters():
+                p.data.copy_(before[k])
+            zstep(img, {})
+            flat = torch.cat([p.detach().flatten() for p in m.parameters()])
+            ref = flat.clone()
+            dist.broadcast(ref, 0)
+            assert torch.equal(flat, ref), 'ZeRO: parameters differ between ranks'
+            worst_z = max(float((p.detach() - after_plain[k]).abs().max() / (after_plain[k].abs().max() + 1e-30))
+                          for k, p in m.named_parameters())
+            assert worst_z < 1e-6, worst_z
         # the model still works outside the helper (the trunk hook is inert there)
         m.zero_grad(set_to_none=True)
         scalar_loss(m(img)).backward()
