@@ -152,13 +152,15 @@ typedef struct rih_gemm_p3_desc {
     int32_t cS, cOH, cOW, cH, cW;
     int32_t relu;
     int32_t tile;
-    int32_t reserved0;
+    int32_t layout;      /* 0: interleaved P3 (above); 1: slab-major "P3S": [C/32][rows][12 units] for A (rows = all pixels of the
+                            tensor, lda ignored) and [K/32][N][12 units] for B -- the k-tile of consecutive pixels is contiguous,
+                            so the LDS-DMA stream consists of whole 128-byte lines */
 } rih_gemm_p3_desc;
 int rih_gemm_p3(const rih_gemm_p3_desc* d, void* stream);
 int rih_gemm_p3_tile_rows(int tile);
-int rih_p3_from_f32(const float* x, int64_t rows, int C, int ldx, void* out, int ldo, void* stream);
+int rih_p3_from_f32(const float* x, int64_t rows, int C, int ldx, void* out, int ldo, int layout, void* stream);
 int rih_p3_conv_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int CinPad, int for_dgrad, int kh0,
-                       int kw0, int step, int Th, int Tw, int Kpad, void* stream);
+                       int kw0, int step, int Th, int Tw, int Kpad, int layout, void* stream);
 /* part [T][C][2] from rih_gemm_p3 (tiles of rows_per_tile rows) -> what rih_bn_stats produces: mean[C],
  * invstd[C] = 1 / sqrt(biased var + eps) and, when running_mean / running_var != NULL, their momentum update with the unbiased
  * variance (nn.BatchNorm2d training forward).  Chan's merge in double, one wavefront per channel. */
@@ -372,7 +374,7 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
  * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of the by-pointer structs
  * (gemm desc, mano model, mesh topo, hconv desc), so a host binding can refuse a stale binary instead of handing it
  * mis-laid-out structs. */
-#define RIH_ABI_VERSION 4
+#define RIH_ABI_VERSION 5
 int rih_version(void);
 int rih_abi_sizes(int32_t* out4);
 const char* rih_arch(void);

@@ -36,7 +36,7 @@ class GemmP3Desc(C.Structure):
                 ('R', C.c_void_p), ('stats', C.c_void_p)] + \
                [(n, C.c_int32) for n in ('M', 'N', 'K', 'lda', 'ldb', 'ldc', 'ldr', 'H', 'W', 'Cin', 'Ho', 'Wo', 'KH', 'KW',
                                          'stride', 'padH', 'padW', 'cS', 'cOH', 'cOW', 'cH', 'cW', 'relu', 'tile',
-                                         'reserved0')]
+                                         'layout')]
 
 
 class HConvDesc(C.Structure):
@@ -149,8 +149,8 @@ SIGNATURES = {
     'rih_mesh_loss_final': (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, C.c_void_p]),
     'rih_gemm_p3': (c_i, [C.POINTER(GemmP3Desc), C.c_void_p]),
     'rih_gemm_p3_tile_rows': (c_i, [c_i]),
-    'rih_p3_from_f32': (c_i, [c_f, c_l, c_i, c_i, C.c_void_p, c_i, C.c_void_p]),
-    'rih_p3_conv_weight': (c_i, [c_f, C.c_void_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_p3_from_f32': (c_i, [c_f, c_l, c_i, c_i, C.c_void_p, c_i, c_i, C.c_void_p]),
+    'rih_p3_conv_weight': (c_i, [c_f, C.c_void_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
     'rih_bn_stats_merge': (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),
     'rih_bn_stats_from_tiles': (c_i, [c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, C.c_void_p]),
     'rih_version': (c_i, []),
@@ -158,7 +158,7 @@ SIGNATURES = {
     'rih_arch': (C.c_char_p, []),
 }
 
-ABI_VERSION = 4      # = RIH_ABI_VERSION of include/renderih_amd.h
+ABI_VERSION = 5      # = RIH_ABI_VERSION of include/renderih_amd.h
 
 _lib = None
 

@@ -13,6 +13,13 @@
 //   i.e. the three planes of 8 consecutive channels are 48 contiguous bytes and a 32-channel k-tile of one row is 192
 //   contiguous bytes (12 units = three 64-byte lines).  6 bytes per element.
 //
+// Slab-major variant "P3S" (desc.layout = 1): [C/32 slabs][rows][12 units] -- the 192 bytes of a row's k-tile are followed by
+//   the NEXT ROW's 192 bytes of the same k-tile, so the operand stream of a k-tile is contiguous over consecutive pixels and an
+//   LDS-DMA wave instruction (64 units = 5.3 rows) fetches whole 128-byte lines.  Measured motivation
+//   (profiles/r02/p3_variants_m4.log): with the interleaved layout every request is a 64-byte segment; the same bytes as
+//   full-line requests run 198 TF instead of 166 TF.  LDS image row-major [row][12 units], unit j of a row rotated to position
+//   (j + ((row >> 2) & 3)) % 12: conflict-free ds_read_b128 (searched exhaustively over the 16-lane read groups).
+//
 // gemm_p3_kernel: C[m][n] = sum_k A[m][k] B[n][k],  A = P3 activation with im2col gather (k = (kh, kw, c), one tap per
 //   k-tile of 32 since the channel count is a multiple of 32), B = P3 weight [N][K].
 //   * 8 wavefronts (4 x 2), block tile 256x128 / 128x128 / 128x64, wave tile (TM x TN) 32x32 MFMA blocks.
@@ -51,6 +58,7 @@ struct G3Args {
     int H, W, Ho, Wo, KH, KW, stride, padH, padW, Cin;
     int cS, cOH, cOW, cH, cW;
     int relu;
+    unsigned a_slab, b_slab;        // P3S: bytes per 32-channel slab of A (pixels * 192) and of B (N * 192)
 };
 
 __device__ __forceinline__ int xcd_remap3(int bid, int nwg) {
@@ -79,17 +87,18 @@ __device__ __forceinline__ long long c_row3(const G3Args& p, int m) {
     return ((long long)img * p.cH + (i * p.cS + p.cOH)) * p.cW + (j * p.cS + p.cOW);
 }
 
-// VAR (timing experiments only, results are garbage for VAR != 0): 1 = every octet of lanes streams 128 contiguous bytes of
-// a tile-private linear region (same bytes, full-line requests); 2 = no loads after the first k-tile (compute-only
-// ceiling of the loop structure); 3 = every lane reads the zero page (the LDS-DMA instructions without memory traffic)
-template <int WGM, int WGN, int TM, int TN, int VAR = 0>
+// SLAB = false: interleaved P3 operands, LDS image of 64-byte quads; SLAB = true: slab-major P3S operands, row-major LDS image.
+// (The loader ablations of profiles/r02/p3_variants_m4.log -- linear full-line source, no loads, zero page -- were timing
+// variants of this kernel at commit 20d9156..; they are not kept in the product.)
+template <int WGM, int WGN, int TM, int TN, bool SLAB = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_p3_kernel(const G3Args p) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int A_BYTES = BM * 192, B_BYTES = BN * 192, STAGE = A_BYTES + B_BYTES;
     constexpr int QPI = NT / 4;                                   // quads filled by one LDS-DMA instruction of the block
-    constexpr int NIA = (3 * BM + QPI - 1) / QPI, NIB = (3 * BN + QPI - 1) / QPI;
-    static_assert((3 * BM) % 16 == 0 && (3 * BN) % 16 == 0, "a wave instruction must not straddle the A/B regions");
+    constexpr int NIA = (3 * BM + QPI - 1) / QPI, NIB = (3 * BN + QPI - 1) / QPI;     // = ceil(12 BM / NT): same in both layouts
+    static_assert((3 * BM) % 16 == 0 && (3 * BN) % 16 == 0 && (12 * BM) % 64 == 0 && (12 * BN) % 64 == 0,
+                  "a wave instruction must not straddle the A/B regions");
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -100,25 +109,38 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_p3_kernel(const G3Args p)
     const int m0 = tm * BM, n0 = (bid % tilesN) * BN;
 
     // ------------------------------------------------------------ loader state
-    // instruction i of the A region fills quad Q = i*QPI + tid/4 = (jq, row); this lane supplies position tid&3 of it,
-    // i.e. unit j = 4 jq + ((pos - (row>>2)) & 3) of the row's k-tile
+    // interleaved: instruction i of the A region fills quad Q = i*QPI + tid/4 = (jq, row); this lane supplies position tid&3
+    //   of it, i.e. unit j = 4 jq + ((pos - (row>>2)) & 3) of the row's k-tile.
+    // slab-major: instruction i fills units U = i*NT + tid of the row-major image: row = U / 12, position U % 12, i.e. unit
+    //   j = (position - ((row>>2)&3)) mod 12; 64 consecutive lanes cover 5.3 consecutive rows = one contiguous source range.
     const int pos = tid & 3;
     unsigned a_off[NIA], a_val[NIA];
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
-        const int Q = i * QPI + (tid >> 2);
-        const int jq = Q / BM, row = Q % BM;
-        const int j = 4 * jq + ((pos - (row >> 2)) & 3);
+        int row, j;
+        bool live;
+        if (SLAB) {
+            const int U = i * NT + tid;
+            row = U / 12;
+            j = (U - row * 12 - ((row >> 2) & 3) + 12) % 12;
+            live = row < BM;
+        } else {
+            const int Q = i * QPI + (tid >> 2);
+            row = Q % BM;
+            j = 4 * (Q / BM) + ((pos - (row >> 2)) & 3);
+            live = Q < 3 * BM;
+        }
         const int m = m0 + row;
         a_off[i] = 0;
         a_val[i] = 0;
-        if (Q < 3 * BM && m < p.M) {
+        if (live && m < p.M) {
             const int wo = m % p.Wo;
             const int t = m / p.Wo;
             const int ho = t % p.Ho;
             const int img = t / p.Ho;
             const int hi0 = ho * p.stride - p.padH, wi0 = wo * p.stride - p.padW;
-            a_off[i] = (unsigned)(((img * p.H + hi0) * p.W + wi0) * p.lda * 6 + j * 16);      // wraps for hi0/wi0 < 0
+            if (SLAB) a_off[i] = (unsigned)(((img * p.H + hi0) * p.W + wi0) * 192 + j * 16);
+            else a_off[i] = (unsigned)(((img * p.H + hi0) * p.W + wi0) * p.lda * 6 + j * 16);      // wraps for hi0/wi0 < 0
             unsigned bits = 0;
             for (int kh = 0; kh < p.KH; ++kh)
                 for (int kw = 0; kw < p.KW; ++kw)
@@ -131,13 +153,28 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_p3_kernel(const G3Args p)
     int b_step[NIB];
 #pragma unroll
     for (int i = 0; i < NIB; ++i) {
-        const int Q = i * QPI + (tid >> 2);
-        const int jq = Q / BN, row = Q % BN;
-        const int j = 4 * jq + ((pos - (row >> 2)) & 3);
+        int row, j;
+        bool live;
+        if (SLAB) {
+            const int U = i * NT + tid;
+            row = U / 12;
+            j = (U - row * 12 - ((row >> 2) & 3) + 12) % 12;
+            live = row < BN;
+        } else {
+            const int Q = i * QPI + (tid >> 2);
+            row = Q % BN;
+            j = 4 * (Q / BN) + ((pos - (row >> 2)) & 3);
+            live = Q < 3 * BN;
+        }
         const int n = n0 + row;
-        const bool ok = Q < 3 * BN && n < p.N;
-        b_src[i] = ok ? p.B + ((long long)n * p.ldb * 6 + j * 16) : p.zero;
-        b_step[i] = ok ? 192 : 0;
+        const bool ok = live && n < p.N;
+        if (SLAB) {
+            b_src[i] = ok ? p.B + ((long long)n * 192 + j * 16) : p.zero;
+            b_step[i] = ok ? (int)p.b_slab : 0;
+        } else {
+            b_src[i] = ok ? p.B + ((long long)n * p.ldb * 6 + j * 16) : p.zero;
+            b_step[i] = ok ? 192 : 0;
+        }
     }
     // wave-uniform walk over (tap, channel): one tap per k-tile (Cin % 32 == 0)
     int u_tap = 0, u_ci = 0, u_kh = 0, u_kw = 0;
@@ -145,21 +182,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_p3_kernel(const G3Args p)
 
     auto issue = [&](int buf) {                                  // LDS-DMA of the next k-tile into stage `buf`
         unsigned char* dst = smem + buf * STAGE + tid * 16;
-        const unsigned tapoff = (unsigned)(((u_kh * p.W + u_kw) * p.lda + u_ci) * 6);
+        const unsigned tapoff = SLAB ? (unsigned)((u_kh * p.W + u_kw) * 192) + (unsigned)(u_ci >> 5) * p.a_slab
+                                     : (unsigned)(((u_kh * p.W + u_kw) * p.lda + u_ci) * 6);
         const unsigned tapbit = 1u << (u_tap & 31);
 #pragma unroll
         for (int i = 0; i < NIA; ++i) {
-            if ((i + 1) * QPI <= 3 * BM || (i * QPI + (tid >> 2)) < 3 * BM) {          // second test is wave-uniform
+            // the last instruction of a region may be partial; the test is wave-uniform in both layouts
+            const bool part = SLAB ? ((i + 1) * NT > 12 * BM) : ((i + 1) * QPI > 3 * BM);
+            if (!part || (SLAB ? (i * NT + tid) < 12 * BM : (i * QPI + (tid >> 2)) < 3 * BM)) {
                 const bool ok = (a_val[i] & tapbit) != 0u;
-                if (VAR == 0 || (VAR == 2 && u_tap == 0 && u_ci < 64)) glds16(pick(ok, p.A + (a_off[i] + tapoff), p.zero), dst + i * NT * 16);
-                if (VAR == 1) glds16(p.A + ((unsigned)(blockIdx.x & 63) * 2359296u + (unsigned)(u_tap * p.Cin + u_ci) * 1536u + (unsigned)(i * NT * 16 + tid * 16)), dst + i * NT * 16);
-                if (VAR == 3) glds16(p.zero, dst + i * NT * 16);
+                glds16(pick(ok, p.A + (a_off[i] + tapoff), p.zero), dst + i * NT * 16);
             }
         }
 #pragma unroll
         for (int i = 0; i < NIB; ++i) {
-            if ((i + 1) * QPI <= 3 * BN || (i * QPI + (tid >> 2)) < 3 * BN) {
-                if (VAR != 2 || (u_tap == 0 && u_ci < 64)) glds16(VAR == 3 ? p.zero : b_src[i], dst + A_BYTES + i * NT * 16);
+            const bool part = SLAB ? ((i + 1) * NT > 12 * BN) : ((i + 1) * QPI > 3 * BN);
+            if (!part || (SLAB ? (i * NT + tid) < 12 * BN : (i * QPI + (tid >> 2)) < 3 * BN)) {
+                glds16(b_src[i], dst + A_BYTES + i * NT * 16);
                 b_src[i] += b_step[i];
             }
         }
@@ -180,10 +219,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_p3_kernel(const G3Args p)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
                 const int j = (2 * s + lhi) * 3 + pl;
-                a_rd[s * 3 + pl] = ((j >> 2) * BM + ra) * 64 + (((j & 3) + (ra >> 2)) & 3) * 16;
-                b_rd[s * 3 + pl] = A_BYTES + ((j >> 2) * BN + rb) * 64 + (((j & 3) + (rb >> 2)) & 3) * 16;
+                if (SLAB) {
+                    a_rd[s * 3 + pl] = ra * 192 + ((j + ((ra >> 2) & 3)) % 12) * 16;
+                    b_rd[s * 3 + pl] = A_BYTES + rb * 192 + ((j + ((rb >> 2) & 3)) % 12) * 16;
+                } else {
+                    a_rd[s * 3 + pl] = ((j >> 2) * BM + ra) * 64 + (((j & 3) + (ra >> 2)) & 3) * 16;
+                    b_rd[s * 3 + pl] = A_BYTES + ((j >> 2) * BN + rb) * 64 + (((j & 3) + (rb >> 2)) & 3) * 16;
+                }
             }
     }
+    constexpr int RBLK = SLAB ? 32 * 192 : 2048;           // byte distance of the next 32-row block of a wave tile
 
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -205,10 +250,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_p3_kernel(const G3Args p)
             for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    av[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + a_rd[s * 3 + pl] + i * 2048));
+                    av[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + a_rd[s * 3 + pl] + i * RBLK));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    bv[pl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + b_rd[s * 3 + pl] + j * 2048));
+                    bv[pl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + b_rd[s * 3 + pl] + j * RBLK));
             }
             // smallest terms first; consecutive MFMAs rotate over the TM x TN accumulators
 #define RIH_P3_TERM(PA_, PB_)                                                                                     \
@@ -337,6 +382,22 @@ __global__ void p3_from_f32_kernel(const float* __restrict__ x, long long rows, 
     }
 }
 
+// slab-major P3S: out[((c/32) * rows + r) * 12 + ((c%32)/8) * 3 + plane] (16-byte units); thread = (slab, row, channel group)
+__global__ void p3s_from_f32_kernel(const float* __restrict__ x, long long rows, int C, int ldx, unsigned char* __restrict__ out) {
+    const long long total = rows * (C / 8);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int kg = (int)(i & 3);
+        const long long t = i >> 2;
+        const long long r = t % rows;
+        const int slab = (int)(t / rows);
+        const float* px = x + r * ldx + slab * 32 + kg * 8;
+        const float4 v0 = *reinterpret_cast<const float4*>(px);
+        const float4 v1 = *reinterpret_cast<const float4*>(px + 4);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        store_p3_group(out + (((long long)slab * rows + r) * 12 + kg * 3) * 16, v);
+    }
+}
+
 // OIHW conv weight -> P3 [N][Kpad]:
 //   for_dgrad 0: n = co, k = (tap, ci < CinPad)                       (forward operand)
 //   for_dgrad 1: n = ci < CinPad, k = ((th, tw), co), taps flipped, subset (kh0 + step*t, kw0 + step*t')  (data gradient)
@@ -357,7 +418,7 @@ __device__ __forceinline__ float p3w_fetch(const P3WArgs& a, int n, int k) {
     const int kh = a.kh0 + a.step * (a.Th - 1 - th), kw = a.kw0 + a.step * (a.Tw - 1 - tw);
     return n < a.Cin ? a.w[(((long long)co * a.Cin + n) * a.KH + kh) * a.KW + kw] : 0.f;
 }
-__global__ void p3_weight_kernel(const P3WArgs a) {
+__global__ void p3_weight_kernel(const P3WArgs a, int slab_major) {
     const int G = a.Kpad / 8;
     const long long total = (long long)a.N * G;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -365,7 +426,9 @@ __global__ void p3_weight_kernel(const P3WArgs a) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = p3w_fetch(a, n, 8 * g + e);
-        store_p3_group(a.dst + i * 48, v);
+        // interleaved: [n][k/8][plane]; slab-major: [k/32][n][(k%32)/8][plane]
+        const long long unit = slab_major ? (((long long)(g >> 2) * a.N + n) * 4 + (g & 3)) : i;
+        store_p3_group(a.dst + unit * 48, v);
     }
 }
 
@@ -425,12 +488,12 @@ __global__ void bn_stats_from_tiles_kernel(const float* __restrict__ part, int T
     }
 }
 
-template <int WGM, int WGN, int TM, int TN, int VAR = 0>
+template <int WGM, int WGN, int TM, int TN, bool SLAB = false>
 int launch_p3(const G3Args& a, hipStream_t s) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     const long long tiles = (long long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     if (tiles > 0x7fffffffLL) return RIH_EINVAL;
-    hipLaunchKernelGGL((gemm_p3_kernel<WGM, WGN, TM, TN, VAR>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), 0, s, a);
+    hipLaunchKernelGGL((gemm_p3_kernel<WGM, WGN, TM, TN, SLAB>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -461,30 +524,42 @@ extern "C" int rih_gemm_p3(const rih_gemm_p3_desc* d, void* stream) {
     a.cS = d->cS; a.cOH = d->cOH; a.cOW = d->cOW; a.cH = d->cH; a.cW = d->cW;
     a.relu = d->relu;
     hipStream_t s = (hipStream_t)stream;
-    if (d->reserved0 != 0) {        // timing experiments (see VAR); tile 0 only
-        if (d->tile != 0) return RIH_EINVAL;
-        if (d->reserved0 == 1) return launch_p3<4, 2, 2, 2, 1>(a, s);
-        if (d->reserved0 == 2) return launch_p3<4, 2, 2, 2, 2>(a, s);
-        if (d->reserved0 == 3) return launch_p3<4, 2, 2, 2, 3>(a, s);
-        return RIH_EINVAL;
+    if (d->layout == 1) {           // slab-major P3S operands
+        const long long npix = imgs * d->H * d->W;
+        if (npix * 192 >= (1ll << 32) || (long long)d->N * 192 >= (1ll << 31)) return RIH_EINVAL;
+        a.a_slab = (unsigned)(npix * 192);
+        a.b_slab = (unsigned)((long long)d->N * 192);
+        if (d->tile == 0) return launch_p3<4, 2, 2, 2, true>(a, s);
+        if (d->tile == 1) return launch_p3<4, 2, 1, 2, true>(a, s);
+        return launch_p3<4, 2, 1, 1, true>(a, s);
     }
+    if (d->layout != 0) return RIH_EINVAL;
+    a.a_slab = a.b_slab = 0;
     if (d->tile == 0) return launch_p3<4, 2, 2, 2>(a, s);       // 256 x 128
     if (d->tile == 1) return launch_p3<4, 2, 1, 2>(a, s);       // 128 x 128
     return launch_p3<4, 2, 1, 1>(a, s);                         // 128 x 64
 }
 
-extern "C" int rih_p3_from_f32(const float* x, int64_t rows, int C, int ldx, void* out, int ldo, void* stream) {
+extern "C" int rih_p3_from_f32(const float* x, int64_t rows, int C, int ldx, void* out, int ldo, int layout, void* stream) {
     if (!x || !out || rows < 1 || C < 8 || C % 8 != 0 || ldx < C || ldx % 4 != 0 || ldo < C || ldo % 8 != 0) return RIH_EINVAL;
     if (((uintptr_t)x | (uintptr_t)out) % 16 != 0) return RIH_EINVAL;
     const long long total = rows * (C / 8);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (layout == 1) {              // slab-major: whole 32-channel slabs
+        if (C % 32 != 0) return RIH_EINVAL;
+        hipLaunchKernelGGL(p3s_from_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)rows, C, ldx,
+                           (unsigned char*)out);
+        return (int)hipGetLastError();
+    }
+    if (layout != 0) return RIH_EINVAL;
     hipLaunchKernelGGL(p3_from_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)rows, C, ldx,
                        (unsigned char*)out, ldo);
     return (int)hipGetLastError();
 }
 
 extern "C" int rih_p3_conv_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int CinPad, int for_dgrad,
-                                  int kh0, int kw0, int step, int Th, int Tw, int Kpad, void* stream) {
+                                  int kh0, int kw0, int step, int Th, int Tw, int Kpad, int layout, void* stream) {
+    if (layout != 0 && layout != 1) return RIH_EINVAL;
     if (!w || !dst || Cout < 1 || Cin < 1 || KH < 1 || KW < 1 || CinPad < Cin || Kpad % 32 != 0) return RIH_EINVAL;
     P3WArgs a = {};
     a.w = w; a.dst = (unsigned char*)dst; a.Kpad = Kpad; a.for_dgrad = for_dgrad ? 1 : 0;
@@ -500,7 +575,7 @@ extern "C" int rih_p3_conv_weight(const float* w, void* dst, int Cout, int Cin, 
     if (Kpad < a.K) return RIH_EINVAL;
     const long long total = (long long)a.N * (Kpad / 8);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(p3_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(p3_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, layout);
     return (int)hipGetLastError();
 }
 

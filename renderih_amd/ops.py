@@ -229,16 +229,16 @@ def zero_page(device):
     return z
 
 
-def p3_from_f32(x2d_rows, C_, x, ldx=None, out=None):
-    """fp32 [rows][C_] (row pitch ldx) -> P3 [rows][6*C_] bytes."""
+def p3_from_f32(x2d_rows, C_, x, ldx=None, out=None, layout=0):
+    """fp32 [rows][C_] (row pitch ldx) -> P3 [rows][6*C_] bytes (layout 0) or slab-major P3S [C_/32][rows][192] (layout 1)."""
     ldx = C_ if ldx is None else ldx
     if out is None:
         out = torch.empty((x2d_rows, 6 * C_), device=x.device, dtype=torch.uint8)
-    check(_L().rih_p3_from_f32(x.data_ptr(), x2d_rows, C_, ldx, out.data_ptr(), C_, _stream()), 'rih_p3_from_f32')
+    check(_L().rih_p3_from_f32(x.data_ptr(), x2d_rows, C_, ldx, out.data_ptr(), C_, layout, _stream()), 'rih_p3_from_f32')
     return out
 
 
-def p3_weight(w, Cx, for_dgrad, sub=None):
+def p3_weight(w, Cx, for_dgrad, sub=None, layout=0):
     """(P3 tensor [N][6*Kpad], Kpad) of an OIHW weight as forward operand (N = Cout) or as data-gradient operand of the tap
     subset `sub` = (kh0, kw0, step, Th, Tw) (N = Cx)."""
     Cout, Cin, KH, KW = w.shape
@@ -248,7 +248,7 @@ def p3_weight(w, Cx, for_dgrad, sub=None):
     Kp = _cdiv(K, 32) * 32
     out = torch.empty((Nn, 6 * Kp), device=w.device, dtype=torch.uint8)
     check(_L().rih_p3_conv_weight(w.data_ptr(), out.data_ptr(), Cout, Cin, KH, KW, Cx, 1 if for_dgrad else 0,
-                                  kh0, kw0, step, Th, Tw, Kp, _stream()), 'rih_p3_conv_weight')
+                                  kh0, kw0, step, Th, Tw, Kp, layout, _stream()), 'rih_p3_conv_weight')
     return out, Kp
 
 
@@ -263,7 +263,7 @@ def plan_p3(M, N, K):
 
 
 def gemm_p3(A, B, Cout, M, N, K, lda, ldb, ldc, geom, bias=None, R=None, ldr=0, relu=False, cstride=None, stats=None,
-            tile=None, variant=0):
+            tile=None, layout=0):
     """Enqueue one rih_gemm_p3.  geom = (H, W, Cin, Ho, Wo, KH, KW, stride, padH, padW)."""
     d = _lib.GemmP3Desc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
@@ -276,7 +276,7 @@ def gemm_p3(A, B, Cout, M, N, K, lda, ldb, ldc, geom, bias=None, R=None, ldr=0, 
         d.cS, d.cOH, d.cOW, d.cH, d.cW = cstride
     d.relu = 1 if relu else 0
     d.tile = plan_p3(M, N, K) if tile is None else tile
-    d.reserved0 = variant           # timing experiments of tools/p3_variants.py only (results garbage when != 0)
+    d.layout = layout               # 0: interleaved P3, 1: slab-major P3S (both operands)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

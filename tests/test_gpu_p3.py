@@ -46,15 +46,15 @@ def test_p3_format_round_trip():
     assert bool((planes[2].abs() <= planes[0].abs() * 2.0 ** -16 + 1e-300).all())
 
 
-def conv_p3(x_nhwc, w, stride, pad, tile, bias=None, res=None, relu=False, stats=False):
-    """conv through rih_gemm_p3 on device tensors: x [N,H,W,Cin] fp32, w OIHW."""
+def conv_p3(x_nhwc, w, stride, pad, tile, bias=None, res=None, relu=False, stats=False, layout=0):
+    """conv through rih_gemm_p3 on device tensors: x [N,H,W,Cin] fp32, w OIHW; layout 1 = slab-major operands."""
     from renderih_amd import ops
     N, H, W, Cin = x_nhwc.shape
     Cout, _, KH, KW = w.shape
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     M, K = N * Ho * Wo, KH * KW * Cin
-    xp = ops.p3_from_f32(N * H * W, Cin, x_nhwc.contiguous())
-    wp, Kp = ops.p3_weight(w.contiguous(), Cin, False)
+    xp = ops.p3_from_f32(N * H * W, Cin, x_nhwc.contiguous(), layout=layout)
+    wp, Kp = ops.p3_weight(w.contiguous(), Cin, False, layout=layout)
     y = torch.full((N, Ho, Wo, Cout), float('nan'), device=x_nhwc.device)
     st = None
     if stats:
@@ -62,7 +62,7 @@ def conv_p3(x_nhwc, w, stride, pad, tile, bias=None, res=None, relu=False, stats
         assert M % bm == 0
         st = torch.full((M // bm, Cout, 2), float('nan'), device=x_nhwc.device)
     ops.gemm_p3(xp, wp, y, M, Cout, K, Cin, Kp, Cout, (H, W, Cin, Ho, Wo, KH, KW, stride, pad, pad), bias=bias, R=res,
-                ldr=Cout, relu=relu, stats=st, tile=tile)
+                ldr=Cout, relu=relu, stats=st, tile=tile, layout=layout)
     return y, st
 
 
@@ -77,14 +77,15 @@ P3_CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize('layout', [0, 1])
 @pytest.mark.parametrize('case', P3_CONV_CASES)
-def test_p3_conv_forward(case):
+def test_p3_conv_forward(case, layout):
     N, H, W, Cin, Cout, k, s, p, tile = case
     x = rnd(N, H, W, Cin, seed=1)
     w = rnd(Cout, Cin, k, k, seed=2, scale=1.0 / math.sqrt(Cin * k * k))
     ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), stride=s, padding=p).permute(0, 2, 3, 1)
-    y, _ = conv_p3(x.to(dev()), w.to(dev()), s, p, tile)
-    assert_close(y, ref.float(), what='p3 conv %s' % (case,))
+    y, _ = conv_p3(x.to(dev()), w.to(dev()), s, p, tile, layout=layout)
+    assert_close(y, ref.float(), what='p3 conv %s layout %d' % (case, layout))
 
 
 def test_p3_epilogue_bias_residual_relu():
@@ -93,8 +94,9 @@ def test_p3_epilogue_bias_residual_relu():
     b, r = rnd(Cout, seed=3), rnd(N, H, W, Cout, seed=4)
     ref = F.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double()).permute(0, 2, 3, 1) + r.double())
     d = dev()
-    y, _ = conv_p3(x.to(d), w.to(d), 1, 0, 2, bias=b.to(d), res=r.to(d), relu=True)
-    assert_close(y, ref.float(), what='p3 epilogue')
+    for layout in (0, 1):
+        y, _ = conv_p3(x.to(d), w.to(d), 1, 0, 2, bias=b.to(d), res=r.to(d), relu=True, layout=layout)
+        assert_close(y, ref.float(), what='p3 epilogue layout %d' % layout)
 
 
 @pytest.mark.parametrize('tile,shape', [(0, (2, 16, 16, 64, 128)), (1, (2, 8, 16, 32, 200)), (2, (4, 8, 8, 32, 64))])
@@ -124,8 +126,9 @@ def test_p3_tile_statistics_and_merge(tile, shape):
     assert_close(rv, (0.9 + 0.1 * ref.var(0, unbiased=True)).float(), 1e-4, 1e-5, 'running var')
 
 
+@pytest.mark.parametrize('layout', [0, 1])
 @pytest.mark.parametrize('case', [(2, 8, 8, 64, 32, 3, 1, 1), (2, 9, 7, 32, 64, 3, 2, 1), (2, 8, 8, 64, 32, 1, 2, 0)])
-def test_p3_data_gradient(case):
+def test_p3_data_gradient(case, layout):
     """dx of a convolution = GEMM of the (P3) output gradient with the flipped P3 weight operand; for stride s as s*s
     parity classes written in place through the strided output rows (the scheme of ops.Conv2dFn.backward)."""
     from renderih_amd import ops
@@ -138,7 +141,7 @@ def test_p3_data_gradient(case):
     d = dev()
     Ho, Wo = yr.shape[2], yr.shape[3]
     dy = gy.permute(0, 2, 3, 1).contiguous().to(d)
-    dyp = ops.p3_from_f32(N * Ho * Wo, Cout, dy)
+    dyp = ops.p3_from_f32(N * Ho * Wo, Cout, dy, layout=layout)
     wg = w.to(d)
     dx = torch.zeros(N, H, W, Cin, device=d)
     for oh in range(s):
@@ -149,7 +152,8 @@ def test_p3_data_gradient(case):
             if Th == 0 or Tw == 0 or Hc == 0 or Wc == 0:
                 continue
             padh, padw = Th - 1 - (oh + p - kh0) // s, Tw - 1 - (ow + p - kw0) // s
-            wd, Kp = ops.p3_weight(wg, Cin, True, (kh0, kw0, s, Th, Tw))
+            wd, Kp = ops.p3_weight(wg, Cin, True, (kh0, kw0, s, Th, Tw), layout=layout)
             ops.gemm_p3(dyp, wd, dx, N * Hc * Wc, Cin, Th * Tw * Cout, Cout, Kp, Cin,
-                        (Ho, Wo, Cout, Hc, Wc, Th, Tw, 1, padh, padw), cstride=(s, oh, ow, H, W) if s > 1 else None, tile=2)
+                        (Ho, Wo, Cout, Hc, Wc, Th, Tw, 1, padh, padw), cstride=(s, oh, ow, H, W) if s > 1 else None, tile=2,
+                        layout=layout)
     assert_close(dx.permute(0, 3, 1, 2), x.grad.float(), 1e-4, 1e-5, 'p3 dgrad %s' % (case,))

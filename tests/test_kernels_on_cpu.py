@@ -86,12 +86,14 @@ def test_p3_gemm_kernels():
     """csrc/rih_gemm3.hip: P3 format, LDS-DMA staged 6-product GEMM on all three tiles, epilogue, statistics, dgrad."""
     TP3.test_p3_format_round_trip()
     for case in TP3.P3_CONV_CASES:
-        TP3.test_p3_conv_forward(case)
+        TP3.test_p3_conv_forward(case, 0)
+        TP3.test_p3_conv_forward(case, 1)
     TP3.test_p3_epilogue_bias_residual_relu()
     TP3.test_p3_tile_statistics_and_merge(0, (1, 16, 16, 32, 128))
     TP3.test_p3_tile_statistics_and_merge(2, (2, 8, 8, 32, 64))
-    TP3.test_p3_data_gradient((2, 9, 7, 32, 64, 3, 2, 1))
-    TP3.test_p3_data_gradient((2, 8, 8, 64, 32, 3, 1, 1))
+    TP3.test_p3_data_gradient((2, 9, 7, 32, 64, 3, 2, 1), 0)
+    TP3.test_p3_data_gradient((2, 9, 7, 32, 64, 3, 2, 1), 1)
+    TP3.test_p3_data_gradient((2, 8, 8, 64, 32, 3, 1, 1), 1)
 
 
 def test_tile4_pipelined_gemm_kernel():

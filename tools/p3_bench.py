@@ -44,6 +44,13 @@ def one(H, Cin, Cout, k):
             continue
         res[t] = time_graph(lambda: ops.gemm_p3(xp, w3, y, M, Cout, K, Cin, Kp, Cout, g3, tile=t))
     err = float((y - y0).abs().max() / y0.abs().max())
+    xs = ops.p3_from_f32(M, Cin, x, layout=1)
+    ws, _ = ops.p3_weight(w, Cin, False, layout=1)
+    slab = {}
+    for t in res:
+        slab[t] = time_graph(lambda: ops.gemm_p3(xs, ws, y, M, Cout, K, Cin, Kp, Cout, g3, tile=t, layout=1))
+    err_s = float((y - y0).abs().max() / y0.abs().max())
+    ts = min(slab, key=slab.get)
     st = torch.empty(M // 128, Cout, 2, device=dev)
     tb = min(res, key=res.get)
     t_stats = time_graph(lambda: ops.gemm_p3(xp, w3, y, M, Cout, K, Cin, Kp, Cout, g3, tile=tb, stats=st))
@@ -51,11 +58,14 @@ def one(H, Cin, Cout, k):
     fl = 2.0 * M * Cout * K / 1e6
     row = {'H': H, 'Cin': Cin, 'Cout': Cout, 'k': k, 'base_us': round(t_base, 1), 'base_tf': round(fl / t_base, 1),
            'p3_us': {str(t): round(v, 1) for t, v in res.items()}, 'p3_best_tile': tb, 'p3_best_tf': round(fl / res[tb], 1),
-           'p3_with_stats_us': round(t_stats, 1), 'cvt_us': round(t_cvt, 1), 'max_rel_diff_vs_base': err}
+           'p3_with_stats_us': round(t_stats, 1), 'cvt_us': round(t_cvt, 1), 'max_rel_diff_vs_base': err,
+           'p3s_us': {str(t): round(v, 1) for t, v in slab.items()}, 'p3s_best_tile': ts, 'p3s_best_tf': round(fl / slab[ts], 1),
+           'p3s_max_rel_diff_vs_base': err_s}
     print('fwd %3dx%-3d %4d->%-4d k%d | split-in-kernel %7.1f us (%5.1f TF) | P3 %s | best t%d %5.1f TF (%.2fx), +stats %7.1f us'
-          ' | fp32->P3 pass %6.1f us | diff %.1e'
+          ' | fp32->P3 pass %6.1f us | diff %.1e || slab-major %s | best t%d %5.1f TF (%.2fx) diff %.1e'
           % (H, H, Cin, Cout, k, t_base, fl / t_base, ' '.join('t%d %7.1f' % (t, v) for t, v in res.items()), tb, fl / res[tb],
-             t_base / res[tb], t_stats, t_cvt, err), flush=True)
+             t_base / res[tb], t_stats, t_cvt, err, ' '.join('t%d %7.1f' % (t, v) for t, v in slab.items()), ts, fl / slab[ts],
+             t_base / slab[ts], err_s), flush=True)
     return row
 
 
@@ -69,6 +79,8 @@ if __name__ == '__main__':
             rows.append(one(*L))
     tb = sum(r['base_us'] for r in rows)
     tp = sum(min(r['p3_us'].values()) for r in rows)
-    print('sum over the listed shapes: %.1f us -> %.1f us (%.2fx)' % (tb, tp, tb / tp))
+    tsl = sum(min(r['p3s_us'].values()) for r in rows)
+    print('sum over the listed shapes: in-kernel split %.1f us -> P3 %.1f us (%.2fx) -> slab-major P3S %.1f us (%.2fx)'
+          % (tb, tp, tb / tp, tsl, tb / tsl))
     if a.json:
         json.dump(rows, open(a.json, 'w'), indent=1)
