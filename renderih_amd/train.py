@@ -22,6 +22,9 @@ What it does that the plain loop does not:
   ~2700 kernel launches.  Dropout masks stay fresh through the device-resident seed word (`ops.DROPOUT_SEED_TENSOR`).
 
 Stages need the ResNet trunk (`model.encoder.resnet`); other encoders run as one stage (still bucketed + graphed).
+Host-side bookkeeping of the forward that is not a kernel does not happen on a replay: `BatchNorm2d.num_batches_tracked` stays
+at its capture-time value (it only matters for `momentum=None`, which the reference never uses); running statistics are
+updated by the kernels and are correct.
 `comm_ms_exposed()` reports the time the compute stream waited for the last bucket after its own work was done.
 """
 import torch

@@ -12,7 +12,7 @@ cp "$f" $OUT/p3_counter_collection.csv
 python - "$f" "$OUT/driver.log" > $OUT/p3_pmc_table.txt <<'PY'
 import csv, collections, json, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-plan = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+plan = [json.loads(l) for l in open(sys.argv[2]) if l.startswith('[{')][0]      # rocprofv3 prints after the driver's last line
 disp = collections.OrderedDict()
 for r in rows:
     k = r['Kernel_Name']

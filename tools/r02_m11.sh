@@ -1,4 +1,6 @@
 #!/bin/bash
+# (historical: A/B of the BatchNorm statistics in the rih_gemm epilogue, RIH_FUSE_BN_STATS -- the code path was removed after this
+# measurement; the script is kept as the record of what profiles/r02/bench_m11_*.log ran)
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 OUT=gpurun_out/r02_m11
