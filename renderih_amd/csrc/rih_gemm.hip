@@ -40,6 +40,7 @@ struct GemmArgs {
     int cS, cOH, cOW, cH, cW;       // strided output rows (parity classes of a strided-conv data gradient)
     int ones_row;                   // a_mode 1: A(ones_row, k) = 1 for every valid k (bias gradient row); 0 = off
     unsigned a_plane;               // a_mode 2: bytes per pre-split plane of A (last: keeps the older kernels' kernarg offsets)
+    int epi_vec;                    // C, R, bias and every stride involved are 16-byte aligned: the epilogue may use 16-byte accesses
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -90,6 +91,68 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& 
 __device__ __forceinline__ int lds_row(int m) { return (m ^ ((m >> 4) & 1)) * 16; }
 __device__ __forceinline__ int lds_swz(int m) { return (m >> 2) & 3; }
 
+// Epilogue shared by the kernels below.  Accumulators -> LDS (one 32x32 block per wave at a time; the operand tiles are dead
+// by then) -> each lane owns 4 consecutive columns of a row: one 16-byte residual load and one 16-byte store per lane, 8 lanes
+// per 128-byte row segment -- a quarter of the store instructions of the column-per-lane C/D layout.  The store phase of these
+// kernels is issue-bound (all CUs write their tiles in lock-step, MI355X_MICROARCH.md "epilogue store tail"): measured on the
+// B = 64 step, GEMM family 24.0 -> 22.3 ms (profiles/r02/bench_m14_wide_epilogue.log).
+// `stg`: this wave's 32 x SLD floats of LDS; the caller guarantees a __syncthreads() since the last operand read.
+constexpr int SLD = 36;             // floats per staged row: 32 + pad, keeps float4 alignment
+template <int TM, int TN>
+__device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&acc)[TM][TN], float* stg, float* __restrict__ C,
+                                                 const float* __restrict__ biasp, const float* __restrict__ Rp, int mbase,
+                                                 int nbase, int lane) {
+    const bool raw = (p.splitk > 1);
+    const bool vec = p.epi_vec != 0;
+    const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (i + j > 0) __syncthreads();         // the previous block has been read back
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + l31] = acc[i][j][r];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = (lane >> 3) + 8 * q, c4 = (lane & 7) * 4;
+                const int m = mbase + i * 32 + row, n = nbase + j * 32 + c4;
+                if (m >= p.M || n >= p.N) continue;
+                float4 v = *reinterpret_cast<const float4*>(stg + row * SLD + c4);
+                float* crow = C + c_row(p, m) * p.ldc + n;
+                const bool full = vec && n + 3 < p.N;
+                if (!raw) {
+                    float4 b4 = zero4(), r4 = zero4();
+                    if (full) {
+                        if (biasp != nullptr) b4 = *reinterpret_cast<const float4*>(biasp + n);
+                        if (Rp != nullptr) r4 = *reinterpret_cast<const float4*>(Rp + (long long)m * p.ldr + n);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.N) {
+                                if (biasp != nullptr) set_elem(b4, e, biasp[n + e]);
+                                if (Rp != nullptr) set_elem(r4, e, Rp[(long long)m * p.ldr + n + e]);
+                            }
+                    }
+                    v.x = v.x * p.alpha + b4.x + r4.x;
+                    v.y = v.y * p.alpha + b4.y + r4.y;
+                    v.z = v.z * p.alpha + b4.z + r4.z;
+                    v.w = v.w * p.alpha + b4.w + r4.w;
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                }
+                if (full) {
+                    *reinterpret_cast<float4*>(crow) = v;
+                } else {
+                    crow[0] = v.x;
+                    if (n + 1 < p.N) crow[1] = v.y;
+                    if (n + 2 < p.N) crow[2] = v.z;
+                    if (n + 3 < p.N) crow[3] = v.w;
+                }
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int AMODE, int BMODE, bool VEC, int ENGINE>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     constexpr int LDAS = BM + 4;
@@ -101,7 +164,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NPA = BM / 32, NPB = BN / 32;
 
-    constexpr int SMEM_FLOATS = ENGINE ? 3 * (PLANE_A + PLANE_B) : BK * (LDAS + LDBS);
+    constexpr int OPER_FLOATS = ENGINE ? 3 * (PLANE_A + PLANE_B) : BK * (LDAS + LDBS);
+    constexpr int SMEM_FLOATS = OPER_FLOATS > 4 * 32 * 36 ? OPER_FLOATS : 4 * 32 * 36;      // >= the epilogue's staging area
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float* As = smem;
     float* Bs = smem + (ENGINE ? 3 * PLANE_A : BK * LDAS);
@@ -503,35 +567,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         }
     }
 
-    // ------------------------------------------------------------------ epilogue
-    // C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool raw = (p.splitk > 1);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WN + j * 32 + l31;
-            const float bv = (!raw && biasp != nullptr && n < p.N) ? biasp[n] : 0.f;
-            float rv[16];       // residual operand: all 16 loads of the tile in flight before the first store
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                rv[r] = (!raw && Rp != nullptr && m < p.M && n < p.N) ? Rp[(long long)m * p.ldr + n] : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m < p.M && n < p.N) {
-                    float v = acc[i][j][r];
-                    if (!raw) {
-                        v = v * p.alpha + bv + rv[r];
-                        if (p.relu) v = fmaxf(v, 0.f);
-                    }
-                    C[c_row(p, m) * p.ldc + n] = v;
-                }
-            }
-        }
-    }
+    // ------------------------------------------------------------------ epilogue (store_tiles_wide)
+    // C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); every path to here ends with a
+    // barrier (before the loop, and as the loop's last statement)
+    store_tiles_wide<TM, TN>(p, acc, smem + wave * (32 * SLD), C, biasp, Rp, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
 template <int BM, int BN, bool VEC, int ENGINE>
@@ -997,34 +1036,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
         }
     }
 
-    // ------------------------------------------------------------------ epilogue (as gemm_kernel)
-    const bool raw = (p.splitk > 1);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WN + j * 32 + l31;
-            const float bv = (!raw && biasp != nullptr && n < p.N) ? biasp[n] : 0.f;
-            float rv[16];       // residual operand: all 16 loads of the tile in flight before the first store
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                rv[r] = (!raw && Rp != nullptr && m < p.M && n < p.N) ? Rp[(long long)m * p.ldr + n] : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m < p.M && n < p.N) {
-                    float v = acc[i][j][r];
-                    if (!raw) {
-                        v = v * p.alpha + bv + rv[r];
-                        if (p.relu) v = fmaxf(v, 0.f);
-                    }
-                    C[c_row(p, m) * p.ldc + n] = v;
-                }
-            }
-        }
-    }
+    // ------------------------------------------------------------------ epilogue (store_tiles_wide; the main loop ended with a barrier)
+    store_tiles_wide<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
 template <int BM, int BN>
@@ -1385,34 +1398,8 @@ __global__ __launch_bounds__(256, 1) void gemm_split256_kernel(const GemmArgs p)
 #undef RIH_SPLIT_TERM
     }
 
-    // ------------------------------------------------------------------ epilogue
-    const bool raw = (p.splitk > 1);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WN + j * 32 + l31;
-            const float bv_ = (!raw && biasp != nullptr && n < p.N) ? biasp[n] : 0.f;
-            float rv[16];       // residual operand: all 16 loads of the tile in flight before the first store
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                rv[r] = (!raw && Rp != nullptr && m < p.M && n < p.N) ? Rp[(long long)m * p.ldr + n] : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m < p.M && n < p.N) {
-                    float v = acc[i][j][r];
-                    if (!raw) {
-                        v = v * p.alpha + bv_ + rv[r];
-                        if (p.relu) v = fmaxf(v, 0.f);
-                    }
-                    C[c_row(p, m) * p.ldc + n] = v;
-                }
-            }
-        }
-    }
+    // ------------------------------------------------------------------ epilogue (store_tiles_wide; the main loop ended with a barrier)
+    store_tiles_wide<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
 int launch_split256(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 grid, hipStream_t s) {
@@ -1672,6 +1659,12 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
     a.a_plane = 0;
     a.cS = d->cS; a.cOH = d->cOH; a.cOW = d->cOW; a.cH = d->cH; a.cW = d->cW;
     a.ones_row = d->ones_row;
+    {
+        const auto al4 = [](long long v) { return (v & 3) == 0; };
+        a.epi_vec = ((uintptr_t)d->C % 16 == 0) && al4(d->ldc) && al4(d->N) && al4(d->sC1) && al4(d->sC2) && al4(d->sCsplit) &&
+                    (d->R == nullptr || (((uintptr_t)d->R % 16 == 0) && al4(d->ldr) && al4(d->sR1))) &&
+                    (d->bias == nullptr || (((uintptr_t)d->bias % 16 == 0) && al4(d->sBias1)));
+    }
     if (d->ones_row != 0 && (d->a_mode != 1 || d->ones_row < 0 || d->ones_row >= d->M || d->tile == 4)) return RIH_EINVAL;
     if (d->cS > 1 && (d->splitk != 1 || d->a_mode == 1 || d->R != nullptr || d->cH < 1 || d->cW < 1 || d->cOH < 0 ||
                       d->cOW < 0 || d->nb1 * d->nb2 != 1))
