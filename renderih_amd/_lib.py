@@ -176,7 +176,10 @@ def load():
     # library (same soname) is loaded, otherwise two runtimes disagree about the device (hipErrorNoDevice).
     import torch  # noqa: F401
     path = _build.LIB
-    if not os.path.exists(path) or _build.needs_build():
+    ab = os.environ.get('RIH_AB_LIB')       # kernel A/B experiments on one GPU box: load this build instead (ABI-checked below)
+    if ab:
+        path = ab
+    elif not os.path.exists(path) or _build.needs_build():
         try:
             _build.build(verbose=False)
         except Exception as e:  # noqa: BLE001

@@ -13,6 +13,7 @@ namespace {
 
 constexpr int TPB = 256;
 
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 inline int grid_for(long long n, int per_thread = 1) {
     long long b = (n + (long long)TPB * per_thread - 1) / ((long long)TPB * per_thread);
     if (b < 1) b = 1;
@@ -82,18 +83,28 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ pooling
+// Vector width of the pooling / resampling kernels: V = 4 (16-byte accesses, channel quads) whenever C % 4 == 0, else scalar.
+template <int V> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<4> { using type = float4; };
+
+template <int V>
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int8_t* __restrict__ arg, int N,
                                    int H, int W, int C, int Ho, int Wo) {
-    const long long total = (long long)N * Ho * Wo * C;
+    using T = typename VecT<V>::type;
+    const int CV = C / V;
+    const long long total = (long long)N * Ho * Wo * CV;
     GRID_STRIDE(i, total) {
-        const int c = (int)(i % C);
-        long long t = i / C;
+        const int c = (int)(i % CV) * V;
+        long long t = i / CV;
         const int wo = (int)(t % Wo);
         t /= Wo;
         const int ho = (int)(t % Ho);
         const int n = (int)(t / Ho);
-        float best = -INFINITY;
-        int bi = 0;
+        float best[V];
+        int bi[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) { best[e] = -INFINITY; bi[e] = 0; }
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int hi = ho * 2 - 1 + kh;
@@ -102,26 +113,38 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
             for (int kw = 0; kw < 3; ++kw) {
                 const int wi = wo * 2 - 1 + kw;
                 if (wi < 0 || wi >= W) continue;
-                const float v = x[(((long long)n * H + hi) * W + wi) * C + c];
-                if (v > best || v != v) { best = v; bi = kh * 3 + kw; }
+                const T v = *reinterpret_cast<const T*>(x + (((long long)n * H + hi) * W + wi) * C + c);
+                const float* pv = reinterpret_cast<const float*>(&v);
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    if (pv[e] > best[e] || pv[e] != pv[e]) { best[e] = pv[e]; bi[e] = kh * 3 + kw; }
             }
         }
-        y[i] = best;
-        arg[i] = (int8_t)bi;
+        if constexpr (V == 4) {
+            reinterpret_cast<float4*>(y)[i] = make_float4(best[0], best[1], best[2], best[3]);
+            reinterpret_cast<unsigned*>(arg)[i] = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+        } else {
+            y[i] = best[0];
+            arg[i] = (int8_t)bi[0];
+        }
     }
 }
-
+template <int V>
 __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int8_t* __restrict__ arg,
                                    float* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
-    const long long total = (long long)N * H * W * C;
+    using T = typename VecT<V>::type;
+    const int CV = C / V;
+    const long long total = (long long)N * H * W * CV;
     GRID_STRIDE(i, total) {
-        const int c = (int)(i % C);
-        long long t = i / C;
+        const int c = (int)(i % CV) * V;
+        long long t = i / CV;
         const int wi = (int)(t % W);
         t /= W;
         const int hi = (int)(t % H);
         const int n = (int)(t / H);
-        float s = 0.f;
+        float s[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) s[e] = 0.f;
         for (int ho = hi / 2; ho <= (hi + 1) / 2; ++ho) {
             if (ho >= Ho) continue;
             const int kh = hi + 1 - 2 * ho;
@@ -131,10 +154,18 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int8_t* _
                 const int kw = wi + 1 - 2 * wo;
                 if (kw < 0 || kw > 2) continue;
                 const long long o = (((long long)n * Ho + ho) * Wo + wo) * C + c;
-                if (arg[o] == kh * 3 + kw) s += dy[o];
+                const T d = *reinterpret_cast<const T*>(dy + o);
+                const float* pd = reinterpret_cast<const float*>(&d);
+                unsigned a;
+                if constexpr (V == 4) a = *reinterpret_cast<const unsigned*>(arg + o);
+                else a = (unsigned)(unsigned char)arg[o];
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    if ((int)((a >> (8 * e)) & 0xffu) == kh * 3 + kw) s[e] += pd[e];
             }
         }
-        dx[i] = s;
+        if constexpr (V == 4) reinterpret_cast<float4*>(dx)[i] = make_float4(s[0], s[1], s[2], s[3]);
+        else dx[i] = s[0];
     }
 }
 
@@ -169,15 +200,17 @@ __device__ __forceinline__ void bil_src(int o, float scale, int in_size, int& i0
     l1 = src - (float)i0;
 }
 
+template <int V>
 __global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C,
                                       int F) {
-    const int Ho = F * H, Wo = F * W;
+    using T = typename VecT<V>::type;
+    const int Ho = F * H, Wo = F * W, CV = C / V;
     const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float sw = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
-    const long long total = (long long)N * Ho * Wo * C;
+    const long long total = (long long)N * Ho * Wo * CV;
     GRID_STRIDE(i, total) {
-        const int c = (int)(i % C);
-        long long t = i / C;
+        const int c = (int)(i % CV) * V;
+        long long t = i / CV;
         const int wo = (int)(t % Wo);
         t /= Wo;
         const int ho = (int)(t % Ho);
@@ -187,27 +220,38 @@ __global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __rest
         bil_src(ho, sh, H, h0, h1, lh);
         bil_src(wo, sw, W, w0, w1, lw);
         const float* b = x + (long long)n * H * W * C + c;
-        const float x00 = b[((long long)h0 * W + w0) * C], x01 = b[((long long)h0 * W + w1) * C];
-        const float x10 = b[((long long)h1 * W + w0) * C], x11 = b[((long long)h1 * W + w1) * C];
+        const T x00 = *reinterpret_cast<const T*>(b + ((long long)h0 * W + w0) * C);
+        const T x01 = *reinterpret_cast<const T*>(b + ((long long)h0 * W + w1) * C);
+        const T x10 = *reinterpret_cast<const T*>(b + ((long long)h1 * W + w0) * C);
+        const T x11 = *reinterpret_cast<const T*>(b + ((long long)h1 * W + w1) * C);
         const float hl0 = 1.f - lh, wl0 = 1.f - lw;
-        y[i] = hl0 * (wl0 * x00 + lw * x01) + lh * (wl0 * x10 + lw * x11);
+        T o;
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+            reinterpret_cast<float*>(&o)[e] =
+                hl0 * (wl0 * reinterpret_cast<const float*>(&x00)[e] + lw * reinterpret_cast<const float*>(&x01)[e]) +
+                lh * (wl0 * reinterpret_cast<const float*>(&x10)[e] + lw * reinterpret_cast<const float*>(&x11)[e]);
+        reinterpret_cast<T*>(y)[i] = o;
     }
 }
-
+template <int V>
 __global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W,
                                       int C, int F) {
-    const int Ho = F * H, Wo = F * W;
+    using T = typename VecT<V>::type;
+    const int Ho = F * H, Wo = F * W, CV = C / V;
     const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float sw = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
-    const long long total = (long long)N * H * W * C;
+    const long long total = (long long)N * H * W * CV;
     GRID_STRIDE(i, total) {
-        const int c = (int)(i % C);
-        long long t = i / C;
+        const int c = (int)(i % CV) * V;
+        long long t = i / CV;
         const int wi = (int)(t % W);
         t /= W;
         const int hi = (int)(t % H);
         const int n = (int)(t / H);
-        float s = 0.f;
+        float s[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) s[e] = 0.f;
         for (int ho = max(0, F * hi - F - 1); ho <= min(Ho - 1, F * hi + 2 * F); ++ho) {
             int h0, h1;
             float lh;
@@ -220,10 +264,13 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __res
                 bil_src(wo, sw, W, w0, w1, lw);
                 const float ww = ((w0 == wi) ? (1.f - lw) : 0.f) + ((w1 == wi) ? lw : 0.f);
                 if (ww == 0.f) continue;
-                s += wh * ww * dy[(((long long)n * Ho + ho) * Wo + wo) * C + c];
+                const T d = *reinterpret_cast<const T*>(dy + (((long long)n * Ho + ho) * Wo + wo) * C + c);
+#pragma unroll
+                for (int e = 0; e < V; ++e) s[e] += wh * ww * reinterpret_cast<const float*>(&d)[e];
             }
         }
-        dx[i] = s;
+        if constexpr (V == 4) reinterpret_cast<float4*>(dx)[i] = make_float4(s[0], s[1], s[2], s[3]);
+        else dx[i] = s[0];
     }
 }
 
@@ -441,30 +488,55 @@ __global__ __launch_bounds__(TPB) void bn_bwd_partial_kernel(const float* __rest
         const float4 m = reinterpret_cast<const float4*>(mean)[g];
         const float4 is = reinterpret_cast<const float4*>(invstd)[g];
         const int r0 = chunk * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
-        for (int r = r0 + ry; r < r1; r += rt) {
-            const long long o = (long long)r * C + g * 4;
-            float4 d = *reinterpret_cast<const float4*>(dy + o);
-            const float4 v = *reinterpret_cast<const float4*>(x + o);
-            if (relu) {
-                if (mask != nullptr) {
-                    const unsigned bits = mask[(long long)r * CG + g];
-                    if (!(bits & 1u)) d.x = 0.f;
-                    if (!(bits & 2u)) d.y = 0.f;
-                    if (!(bits & 4u)) d.z = 0.f;
-                    if (!(bits & 8u)) d.w = 0.f;
-                } else {
-                    const float4 yy = *reinterpret_cast<const float4*>(y + o);
-                    if (!(yy.x > 0.f)) d.x = 0.f;
-                    if (!(yy.y > 0.f)) d.y = 0.f;
-                    if (!(yy.z > 0.f)) d.z = 0.f;
-                    if (!(yy.w > 0.f)) d.w = 0.f;
-                }
+        auto gate = [&](float4& d, const float4 yy, unsigned bits) {
+            if (mask != nullptr) {
+                if (!(bits & 1u)) d.x = 0.f;
+                if (!(bits & 2u)) d.y = 0.f;
+                if (!(bits & 4u)) d.z = 0.f;
+                if (!(bits & 8u)) d.w = 0.f;
+            } else {
+                if (!(yy.x > 0.f)) d.x = 0.f;
+                if (!(yy.y > 0.f)) d.y = 0.f;
+                if (!(yy.z > 0.f)) d.z = 0.f;
+                if (!(yy.w > 0.f)) d.w = 0.f;
             }
+        };
+        auto add = [&](const float4 d, const float4 v) {
             acc[0].x += d.x; acc[0].y += d.y; acc[0].z += d.z; acc[0].w += d.w;
             acc[1].x += d.x * ((v.x - m.x) * is.x);
             acc[1].y += d.y * ((v.y - m.y) * is.y);
             acc[1].z += d.z * ((v.z - m.z) * is.z);
             acc[1].w += d.w * ((v.w - m.w) * is.w);
+        };
+        const float4 z4 = make_float4(0, 0, 0, 0);
+        const bool use_y = relu && mask == nullptr;
+        int r = r0 + ry;
+        // four rows per iteration: eight 16-byte loads (+ the mask bytes) in flight per lane; one row per iteration keeps
+        // this two-stream reduction at ~3.5 TB/s (profiles/r02/bench_kernel_stats_final.csv: 2.5 ms per step)
+        for (; r + 3 * rt < r1; r += 4 * rt) {
+            float4 d[4], v[4], yy[4];
+            unsigned bits[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long o = (long long)(r + u * rt) * C + g * 4;
+                d[u] = *reinterpret_cast<const float4*>(dy + o);
+                v[u] = *reinterpret_cast<const float4*>(x + o);
+                yy[u] = use_y ? *reinterpret_cast<const float4*>(y + o) : z4;
+                bits[u] = (relu && mask != nullptr) ? mask[(long long)(r + u * rt) * CG + g] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (relu) gate(d[u], yy[u], bits[u]);
+                add(d[u], v[u]);
+            }
+        }
+        for (; r < r1; r += rt) {
+            const long long o = (long long)r * C + g * 4;
+            float4 d = *reinterpret_cast<const float4*>(dy + o);
+            const float4 v = *reinterpret_cast<const float4*>(x + o);
+            if (relu)
+                gate(d, use_y ? *reinterpret_cast<const float4*>(y + o) : z4, mask != nullptr ? mask[(long long)r * CG + g] : 0u);
+            add(d, v);
         }
     }
     block_col_reduce<2>(acc, cg, ry, cgb, rt);
@@ -1017,7 +1089,10 @@ extern "C" int rih_maxpool3x3s2_fwd(const float* x, float* y, int8_t* arg, int N
     if (!x || !y || !arg || N < 1 || H < 1 || W < 1 || C < 1) return RIH_EINVAL;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)N * Ho * Wo * C;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, STREAM, x, y, arg, N, H, W, C, Ho, Wo);
+    if (C % 4 == 0 && al16(x) && al16(y) && al16(arg))
+        hipLaunchKernelGGL(maxpool_fwd_kernel<4>, dim3(grid_for(total / 4)), dim3(TPB), 0, STREAM, x, y, arg, N, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL(maxpool_fwd_kernel<1>, dim3(grid_for(total)), dim3(TPB), 0, STREAM, x, y, arg, N, H, W, C, Ho, Wo);
     LAUNCH_RET();
 }
 extern "C" int rih_maxpool3x3s2_bwd(const float* dy, const int8_t* arg, float* dx, int N, int H, int W, int C,
@@ -1025,7 +1100,10 @@ extern "C" int rih_maxpool3x3s2_bwd(const float* dy, const int8_t* arg, float* d
     if (!dy || !dx || !arg || N < 1 || H < 1 || W < 1 || C < 1) return RIH_EINVAL;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)N * H * W * C;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, STREAM, dy, arg, dx, N, H, W, C, Ho, Wo);
+    if (C % 4 == 0 && al16(dy) && al16(dx) && al16(arg))
+        hipLaunchKernelGGL(maxpool_bwd_kernel<4>, dim3(grid_for(total / 4)), dim3(TPB), 0, STREAM, dy, arg, dx, N, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel<1>, dim3(grid_for(total)), dim3(TPB), 0, STREAM, dy, arg, dx, N, H, W, C, Ho, Wo);
     LAUNCH_RET();
 }
 extern "C" int rih_avgpool_fwd(const float* x, float* y, int N, int HW, int C, void* stream) {
@@ -1040,14 +1118,20 @@ extern "C" int rih_avgpool_bwd(const float* dy, float* dx, int N, int HW, int C,
 }
 extern "C" int rih_upsample_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int factor, void* stream) {
     if (!x || !y || N < 1 || H < 1 || W < 1 || C < 1 || factor < 1 || factor > 64) return RIH_EINVAL;
-    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for((long long)N * factor * factor * H * W * C)), dim3(TPB), 0,
-                       STREAM, x, y, N, H, W, C, factor);
+    const long long total = (long long)N * factor * factor * H * W * C;
+    if (C % 4 == 0 && al16(x) && al16(y))
+        hipLaunchKernelGGL(upsample2x_fwd_kernel<4>, dim3(grid_for(total / 4)), dim3(TPB), 0, STREAM, x, y, N, H, W, C, factor);
+    else
+        hipLaunchKernelGGL(upsample2x_fwd_kernel<1>, dim3(grid_for(total)), dim3(TPB), 0, STREAM, x, y, N, H, W, C, factor);
     LAUNCH_RET();
 }
 extern "C" int rih_upsample_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int factor, void* stream) {
     if (!dy || !dx || N < 1 || H < 1 || W < 1 || C < 1 || factor < 1 || factor > 64) return RIH_EINVAL;
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((long long)N * H * W * C)), dim3(TPB), 0, STREAM, dy, dx, N,
-                       H, W, C, factor);
+    const long long total = (long long)N * H * W * C;
+    if (C % 4 == 0 && al16(dy) && al16(dx))
+        hipLaunchKernelGGL(upsample2x_bwd_kernel<4>, dim3(grid_for(total / 4)), dim3(TPB), 0, STREAM, dy, dx, N, H, W, C, factor);
+    else
+        hipLaunchKernelGGL(upsample2x_bwd_kernel<1>, dim3(grid_for(total)), dim3(TPB), 0, STREAM, dy, dx, N, H, W, C, factor);
     LAUNCH_RET();
 }
 extern "C" int rih_upsample2x_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {

@@ -60,8 +60,10 @@ def plan_gemm(M, N, K, batch=1, engine=None):
     t0 = _cdiv(M, 128) * _cdiv(N, 128) * batch
     t1 = _cdiv(M, 128) * _cdiv(N, 64) * batch
     if e == 1:
-        if K <= 256 and _cdiv(M, 64) * _cdiv(N, 64) * batch >= 512:
-            return 2, 1       # short reductions are bound by the output stream: more, smaller tiles in flight win
+        if (K <= 128 or (K <= 256 and N <= 64)) and _cdiv(M, 64) * _cdiv(N, 64) * batch >= 512:
+            # short reductions are bound by the output stream: more, smaller tiles in flight win.  (Up to K = 256 before the
+            # 16-byte-store epilogue; with it 128x128 wins from K = 256 on: profiles/r02/tile_sweep_m15.log)
+            return 2, 1
         if N > 64 and t0 >= 384:
             return 0, 1
         if t1 >= 384:
@@ -351,7 +353,9 @@ def _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin
     for a shared input; dw [nb, ...] and db [nb, Ncols] contiguous)."""
     Mp = Mrows + 4 if db is not None else Mrows
     # small weight matrices (decoder Linears, <= 4x4 tiles of 128): 64x64 tiles give 4x the resident slices per split
-    small = _cdiv(Mp, 128) * _cdiv(Ncols, 128) <= 4
+    # -- but only for short pixel reductions: from ~16k pixels on, 128x128 tiles with more K-slices win by 15-20%
+    # (profiles/r02/tile_sweep_m15.log: 256->128 @64x64, 128<->512 @32x32)
+    small = _cdiv(Mp, 128) * _cdiv(Ncols, 128) <= 4 and (Kpix < 16384 or nb > 1)
     tile = 3 if Ncols <= 32 else (2 if (Ncols <= 64 or Mp <= 64 or (ENGINE == 1 and small)) else 0)
     if nb > 1 and ENGINE == 1 and Ncols > 32:
         tile = 2            # paired decoder layers (tools/pair_sweep.py): 64x64 tiles win at every measured shape

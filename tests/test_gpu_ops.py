@@ -261,19 +261,20 @@ def test_add_dropout_and_bcast():
 def test_pool_upsample_layout():
     from renderih_amd import ops
     d = dev()
-    x = rnd(2, 64, 18, 18, seed=1)
-    xr = x.clone().requires_grad_(True)
-    yr = F.max_pool2d(xr, 3, 2, 1)
-    gy = rnd(*yr.shape, seed=2)
-    yr.backward(gy)
-    xg = nhwc(x).to(d).requires_grad_(True)
-    yg = ops.maxpool3x3s2(xg)
-    assert_close(nchw(yg), yr, what='maxpool')
-    yg.backward(nhwc(gy).to(d))
-    assert_close(nchw(xg.grad), xr.grad, what='maxpool dx')
+    for Cc in (64, 6):          # 16-byte (channel-quad) kernels and the scalar ones (C % 4 != 0)
+        x = rnd(2, Cc, 18, 18, seed=1)
+        xr = x.clone().requires_grad_(True)
+        yr = F.max_pool2d(xr, 3, 2, 1)
+        gy = rnd(*yr.shape, seed=2)
+        yr.backward(gy)
+        xg = nhwc(x).to(d).requires_grad_(True)
+        yg = ops.maxpool3x3s2(xg)
+        assert_close(nchw(yg), yr, what='maxpool C=%d' % Cc)
+        yg.backward(nhwc(gy).to(d))
+        assert_close(nchw(xg.grad), xr.grad, what='maxpool dx C=%d' % Cc)
 
-    for H in (8, 16, 5):
-        x = rnd(2, 128, H, H + 1, seed=3)
+    for H, Cc in ((8, 128), (16, 128), (5, 128), (7, 10)):
+        x = rnd(2, Cc, H, H + 1, seed=3)
         xr = x.clone().requires_grad_(True)
         yr = F.interpolate(xr, scale_factor=2, mode='bilinear', align_corners=True)
         gy = rnd(*yr.shape, seed=4)
