@@ -110,6 +110,17 @@ int rih_splitk_reduce(float* P, int S, int M, int N, float* dst, int Cin, int ta
  * operand carries an all-ones row there (rih_gemm_desc.ones_row) -- is summed into the bias gradient db[N]. */
 int rih_splitk_reduce_bias(const float* P, int S, int Mp, int M, int N, float* dst, int Cin, int taps, int CinValid,
                            int accumulate, float* db, void* stream);
+/* Any number of independent reductions (each as rih_splitk_reduce_bias) in ceil(n/60) launches: the split-K partials of
+ * the weight gradients of a whole backward stage are summed at the END of the stage instead of one small launch behind
+ * every weight-gradient GEMM (157 launches of ~8 us per ResNet50 step; a dependent kernel costs >= 4.5 us on this
+ * platform whatever its size).  `descs` is HOST memory, read before the call returns.  Same fixed summation order. */
+typedef struct rih_reduce_desc {
+    const float* P;         /* [S][Mp][N] partial slabs */
+    float* dst;             /* parameter-layout gradient, see rih_splitk_reduce */
+    float* db;              /* optional bias gradient [N] from slab row M, or NULL */
+    int32_t S, Mp, M, N, Cin, taps, CinValid, accumulate;
+} rih_reduce_desc;
+int rih_splitk_reduce_multi(const rih_reduce_desc* descs, int n, void* stream);
 /* nb independent reductions in one launch: slice b reads P + b*sP and writes dst + b*sDst, db + b*sDb (the split-K
  * partials of an nb1-batched weight-gradient GEMM, e.g. the paired left/right-hand layers). */
 int rih_splitk_reduce_bias_batched(const float* P, int S, int Mp, int M, int N, float* dst, int Cin, int taps,
@@ -374,7 +385,7 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
  * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of the by-pointer structs
  * (gemm desc, mano model, mesh topo, hconv desc), so a host binding can refuse a stale binary instead of handing it
  * mis-laid-out structs. */
-#define RIH_ABI_VERSION 5
+#define RIH_ABI_VERSION 6
 int rih_version(void);
 int rih_abi_sizes(int32_t* out4);
 const char* rih_arch(void);

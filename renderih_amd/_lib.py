@@ -39,6 +39,11 @@ class GemmP3Desc(C.Structure):
                                          'layout')]
 
 
+class ReduceDesc(C.Structure):
+    _fields_ = [('P', C.c_void_p), ('dst', C.c_void_p), ('db', C.c_void_p)] + \
+               [(n, C.c_int32) for n in ('S', 'Mp', 'M', 'N', 'Cin', 'taps', 'CinValid', 'accumulate')]
+
+
 class HConvDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('zero', C.c_void_p), ('bias', C.c_void_p),
                 ('post_scale', C.c_void_p), ('post_shift', C.c_void_p), ('res', C.c_void_p), ('y', C.c_void_p)] + \
@@ -95,6 +100,7 @@ SIGNATURES = {
     'rih_splitk_reduce': (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
     'rih_splitk_reduce_bias_batched': (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_l, c_l, c_l,
                                              C.c_void_p]),
+    'rih_splitk_reduce_multi': (c_i, [C.POINTER(ReduceDesc), c_i, C.c_void_p]),
     'rih_splitk_reduce_bias': (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f, C.c_void_p]),
     'rih_splitk_finish': (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_fl, c_i, C.c_void_p]),
     'rih_pack_conv_weight': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
@@ -158,7 +164,7 @@ SIGNATURES = {
     'rih_arch': (C.c_char_p, []),
 }
 
-ABI_VERSION = 5      # = RIH_ABI_VERSION of include/renderih_amd.h
+ABI_VERSION = 6      # = RIH_ABI_VERSION of include/renderih_amd.h
 
 _lib = None
 

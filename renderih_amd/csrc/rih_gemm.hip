@@ -1416,17 +1416,12 @@ int launch_split256(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 
 // One-launch split-K reduction for weight gradients: each 256-thread block sums an 8x32 tile of the S partial slabs
 // P[s][Mp][N] in a fixed order (deterministic) and writes it transposed into the parameter layout through LDS; blocks
 // past the tile range sum slab row M (the all-ones row of the A operand = column sums of dy) into the bias gradient.
-__global__ __launch_bounds__(256) void splitk_reduce_fused_kernel(const float* __restrict__ P, int S, int Mp, int M, int N,
-                                                                  float* __restrict__ dst, int Cin, int taps, int CinValid,
-                                                                  int accumulate, float* __restrict__ db, int ntiles,
-                                                                  long long sP, long long sDst, long long sDb) {
-    // blockIdx.y = independent reductions of one launch (paired left/right-hand weight gradients)
-    P += blockIdx.y * sP;
-    dst += blockIdx.y * sDst;
-    if (db != nullptr) db += blockIdx.y * sDb;
+__device__ __forceinline__ void splitk_reduce_block(const float* __restrict__ P, int S, int Mp, int M, int N,
+                                                    float* __restrict__ dst, int Cin, int taps, int CinValid, int accumulate,
+                                                    float* __restrict__ db, int ntiles, int bx) {
     const long long slab = (long long)Mp * N;
-    if ((int)blockIdx.x >= ntiles) {
-        const int n = ((int)blockIdx.x - ntiles) * 256 + threadIdx.x;
+    if (bx >= ntiles) {
+        const int n = (bx - ntiles) * 256 + threadIdx.x;
         if (n < N) {
             const float* q = P + (long long)M * N + n;
             float s0 = 0.f, s1 = 0.f;
@@ -1443,7 +1438,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_fused_kernel(const float* _
     __shared__ float tile[8][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int tilesN = (N + 31) / 32;
-    const int m0 = (blockIdx.x / tilesN) * 8, n0 = (blockIdx.x % tilesN) * 32;
+    const int m0 = (bx / tilesN) * 8, n0 = (bx % tilesN) * 32;
     {
         const int m = m0 + ty, n = n0 + tx;
         const bool ok = (m < M && n < N);
@@ -1471,6 +1466,37 @@ __global__ __launch_bounds__(256) void splitk_reduce_fused_kernel(const float* _
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_fused_kernel(const float* __restrict__ P, int S, int Mp, int M, int N,
+                                                                  float* __restrict__ dst, int Cin, int taps, int CinValid,
+                                                                  int accumulate, float* __restrict__ db, int ntiles,
+                                                                  long long sP, long long sDst, long long sDb) {
+    // blockIdx.y = independent reductions of one launch (paired left/right-hand weight gradients)
+    P += blockIdx.y * sP;
+    dst += blockIdx.y * sDst;
+    if (db != nullptr) db += blockIdx.y * sDb;
+    splitk_reduce_block(P, S, Mp, M, N, dst, Cin, taps, CinValid, accumulate, db, ntiles, (int)blockIdx.x);
+}
+
+// Many independent reductions in ONE launch (rih_splitk_reduce_multi): the descriptors travel by value in the kernel
+// argument (<= 4 KB), so the launch is self-contained -- no device table to upload, and a hipGraph captures it as is.
+// A block finds its descriptor by scanning the exclusive prefix of block counts (<= REDUCE_PACK scalar compares).
+constexpr int REDUCE_PACK = 60;
+struct ReducePack {
+    rih_reduce_desc d[REDUCE_PACK];
+    int first[REDUCE_PACK + 1];         // first block of descriptor i; first[n] = total
+    int ntiles[REDUCE_PACK];
+    int n;
+};
+static_assert(sizeof(ReducePack) <= 4096, "kernel argument limit");
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(const ReducePack pk) {
+    const int b = (int)blockIdx.x;
+    int i = 0;
+    while (i + 1 < pk.n && b >= pk.first[i + 1]) ++i;
+    const rih_reduce_desc& d = pk.d[i];
+    splitk_reduce_block(d.P, d.S, d.Mp, d.M, d.N, d.dst, d.Cin, d.taps, d.CinValid, d.accumulate, d.db, pk.ntiles[i],
+                        b - pk.first[i]);
 }
 
 // Forward split-K finish: C[m*ldc+n] = act(alpha * sum_s P[s][m][n] + bias[n] + R[m*ldr+n])
@@ -1736,6 +1762,33 @@ extern "C" int rih_splitk_reduce_bias_batched(const float* P, int S, int Mp, int
     hipLaunchKernelGGL(splitk_reduce_fused_kernel, dim3((unsigned)blocks, (unsigned)nb), dim3(256), 0, (hipStream_t)stream,
                        P, S, Mp, M, N, dst, Cin, taps, CinValid, accumulate, db, (int)tiles, (long long)sP,
                        (long long)sDst, (long long)sDb);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rih_splitk_reduce_multi(const rih_reduce_desc* descs, int n, void* stream) {
+    if (n < 0 || (n > 0 && !descs)) return RIH_EINVAL;
+    for (int i = 0; i < n; ++i) {
+        const rih_reduce_desc& d = descs[i];
+        if (!d.P || !d.dst || d.S < 1 || d.M < 1 || d.Mp < d.M || d.N < 1 || d.Cin < 1 || d.taps < 1 || d.CinValid < 1)
+            return RIH_EINVAL;
+        if (d.db && d.Mp < d.M + 1) return RIH_EINVAL;
+    }
+    for (int base = 0; base < n; base += REDUCE_PACK) {
+        ReducePack pk;
+        pk.n = (n - base < REDUCE_PACK) ? n - base : REDUCE_PACK;
+        long long total = 0;
+        for (int i = 0; i < pk.n; ++i) {
+            const rih_reduce_desc& d = descs[base + i];
+            const long long tiles = (long long)((d.M + 7) / 8) * ((d.N + 31) / 32);
+            pk.d[i] = d;
+            pk.ntiles[i] = (int)tiles;
+            pk.first[i] = (int)total;
+            total += tiles + (d.db ? (d.N + 255) / 256 : 0);
+            if (total > 0x7fffffffLL) return RIH_EINVAL;
+        }
+        pk.first[pk.n] = (int)total;
+        hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, pk);
+    }
     return (int)hipGetLastError();
 }
 

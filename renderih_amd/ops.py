@@ -335,6 +335,34 @@ def _pdiff(a, b):
     return d // 4
 
 
+# Deferred split-K reductions of weight gradients.  Inside `with deferred_reductions():` a weight gradient's partial slabs
+# are NOT summed behind its GEMM; the sums of all gradients of the block run in one launch per 60 gradients when the block
+# exits.  Valid only where nothing reads a weight gradient before the block ends -- renderih_amd.train.TrainStep wraps each
+# backward stage (torch.autograd.grad hands the gradients back untouched); plain loss.backward() must not use it, because
+# AccumulateGrad may add a gradient into an existing .grad immediately.
+_DEFERRED = None
+
+
+class deferred_reductions:
+    def __enter__(self):
+        global _DEFERRED
+        assert _DEFERRED is None, 'deferred_reductions does not nest'
+        _DEFERRED = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _DEFERRED
+        pending, _DEFERRED = _DEFERRED, None
+        if et is None and pending:
+            from ._lib import ReduceDesc
+            arr = (ReduceDesc * len(pending))()
+            for d, (_, P, _, dst, _, dbp, (S, Mp, M, N, Cin, taps, CinValid, acc)) in zip(arr, pending):
+                d.P, d.dst, d.db = P, dst, dbp
+                d.S, d.Mp, d.M, d.N, d.Cin, d.taps, d.CinValid, d.accumulate = S, Mp, M, N, Cin, taps, CinValid, acc
+            check(_L().rih_splitk_reduce_multi(arr, len(pending), _stream()), 'rih_splitk_reduce_multi')
+        return False
+
+
 def _wgrad(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db=None, nb=1, sx=0, sdy=0):
     sw = SIDE_WGRAD
     if sw is None or not x.is_cuda:
@@ -380,7 +408,14 @@ def _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin
     else:
         gemm(x, dy, part, Mp, Ncols, Kpix, ldx, ldy, Ncols, a_mode=1, b_mode=0, splitk=splitk, kchunk=kchunk,
              sCsplit=Mp * Ncols, geom=geom, tile=tile, ones_row=ones, **batch)
-    if nb == 1:
+    if _DEFERRED is not None:
+        # summed at the end of the backward stage by ONE launch per 60 gradients (deferred_reductions below)
+        per_dw, per_db = dw.numel() // nb, (Ncols if db is not None else 0)
+        for b in range(nb):
+            _DEFERRED.append((part, part.data_ptr() + 4 * b * splitk * Mp * Ncols, dw, dw.data_ptr() + 4 * b * per_dw, db,
+                              (db.data_ptr() + 4 * b * per_db) if db is not None else None,
+                              (splitk, Mp, Mrows, Ncols, Cin_pad, taps, Cin_valid, 0)))
+    elif nb == 1:
         check(_L().rih_splitk_reduce_bias(part.data_ptr(), splitk, Mp, Mrows, Ncols, dw.data_ptr(), Cin_pad, taps,
                                           Cin_valid, 0, _p(db), _stream()), 'rih_splitk_reduce_bias')
     else:

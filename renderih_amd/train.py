@@ -16,6 +16,9 @@ What it does that the plain loop does not:
   side stream while the next stage's backward runs on the compute stream; the optimizer waits for the last bucket only.
   Parameters that never receive a gradient (63 tensors incl. every `GCN_ResBlock.norm1`) are excluded from the
   buckets statically -- no per-iteration graph walk (`find_unused_parameters`), no per-parameter hooks.
+* **Batched split-K reductions.**  The partial slabs of a stage's weight gradients are summed by one launch per 60
+  gradients at the end of the stage (`ops.deferred_reductions`, `rih_splitk_reduce_multi`) instead of 157 small launches per
+  step, each of which costs a dependent-kernel slot (>= 4.5 us on this platform) whatever its size.
 * **hipGraph replay.**  Forward + loss + stage-1 backward, stage 2 and stage 3 are captured as three graphs sharing one
   memory pool and replayed back to back; the collectives stay eager between the replays (no dependence on RCCL's capture
   support), so the host cost per step is three graph launches + three collectives + one fused optimizer launch instead of
@@ -52,7 +55,7 @@ def stage_parameter_groups(model):
 
 class TrainStep:
     def __init__(self, model, optimizer, loss_fn, example_batch, process_group=None, use_graph=True, stages=True,
-                 overlap=True, record_order=None, force_exchange=False, side_wgrad=None):
+                 overlap=True, record_order=None, force_exchange=False, side_wgrad=None, defer_reduce=None):
         """model: HandNET_GCN (train mode, on its device).  optimizer: any torch optimizer over model's parameters.
         loss_fn(outputs, labels) -> scalar loss.  example_batch = (img, labels): tensors with the shapes / dtypes of
         every later call (static buffers of the graphs).  process_group: None = default group if torch.distributed is
@@ -71,6 +74,7 @@ class TrainStep:
         self.nstage = len(self.groups)
         import os
         self.side_wgrad = (os.environ.get('RIH_SIDE_WGRAD', '0') == '1') if side_wgrad is None else bool(side_wgrad)
+        self.defer_reduce = (os.environ.get('RIH_DEFER_REDUCE', '1') == '1') if defer_reduce is None else bool(defer_reduce)
         self.exchange = self.world > 1 or (force_exchange and dist.is_available() and dist.is_initialized())
         self.overlap = overlap and self.exchange
         self.img, self.labels = example_batch
@@ -130,6 +134,14 @@ class TrainStep:
 
     def _stage(self, i, loss, carry):
         """Backward stage i with the weight gradients on the side stream (ops.SIDE_WGRAD), joined before returning."""
+        if not self.defer_reduce:
+            return self._stage_wgrad(i, loss, carry)
+        # the split-K partial slabs of the stage's weight gradients are summed by one launch per 60 gradients at the end of
+        # the stage (ops.deferred_reductions): torch.autograd.grad returns the gradient tensors without reading them
+        with ops.deferred_reductions():
+            return self._stage_wgrad(i, loss, carry)
+
+    def _stage_wgrad(self, i, loss, carry):
         if self.side_wgrad and self.cuda:
             ops.side_wgrad_begin(self.img.device)
         try:

@@ -199,6 +199,13 @@ class EmulatedLib:
                                         db + 4 * b * sDb if db else 0, stream)
         return 0
 
+    def rih_splitk_reduce_multi(self, descs, n, stream):
+        for i in range(n):
+            d = descs[i]
+            self.rih_splitk_reduce_bias(d.P, d.S, d.Mp, d.M, d.N, d.dst, d.Cin, d.taps, d.CinValid, d.accumulate, d.db or 0,
+                                        stream)
+        return 0
+
     def rih_splitk_reduce_bias(self, P, S, Mp, M, N, dst, Cin, taps, CinValid, accumulate, db, stream):
         p = _f(P, S * Mp * N).reshape(S, Mp, N).sum(0)
         if db:

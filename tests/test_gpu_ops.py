@@ -505,6 +505,35 @@ def test_linear_pair(M, K, N, relu, res, stacked):
         assert_close(rg.grad, ts[3].grad, 1e-3, 1e-4, 'linear_pair dres')
 
 
+def test_deferred_reductions_equal_immediate():
+    """ops.deferred_reductions (rih_splitk_reduce_multi: the split-K partial slabs of many weight gradients summed by one
+    launch at the end of a backward stage) leaves bit-identical gradients: a strided 3x3 conv with bias, a 1x1 conv, an
+    nn.Linear with bias and a paired (left/right) Linear -- > 60 descriptors in total, so the packing splits launches."""
+    from renderih_amd import ops
+    d = dev()
+    x = nhwc(rnd(2, 32, 12, 12, seed=1)).to(d)
+    ws = [(rnd(48, 32, 3, 3, seed=2, scale=0.1).to(d).requires_grad_(True), rnd(48, seed=3).to(d).requires_grad_(True), 2, 1),
+          (rnd(24, 32, 1, 1, seed=4, scale=0.2).to(d).requires_grad_(True), None, 1, 0)]
+    xl = rnd(2, 5, 70, 40, seed=5).to(d)
+    wl, bl = rnd(2, 36, 40, seed=6, scale=0.2).to(d).requires_grad_(True), rnd(2, 36, seed=7).to(d).requires_grad_(True)
+    wm = [rnd(20, 40, seed=8 + i, scale=0.2).to(d).requires_grad_(True) for i in range(64)]
+
+    def loss():
+        t = sum(ops.conv2d(x, w, b, stride=s, pad=p).sum() * (i + 1) for i, (w, b, s, p) in enumerate(ws))
+        t = t + (ops.LinearPairFn.apply(xl, wl, None, bl, None, None, False) ** 2).sum()
+        for i, w in enumerate(wm):
+            t = t + (ops.linear(xl[0], w) * (0.5 + i)).sum()
+        return t
+
+    params = [w for w, _, _, _ in ws] + [ws[0][1], wl, bl] + wm
+    want = torch.autograd.grad([loss()], params)
+    with ops.deferred_reductions():
+        got = torch.autograd.grad([loss()], params)
+    assert ops._DEFERRED is None
+    for a, b in zip(got, want):
+        assert bool(torch.isfinite(b).all()) and torch.equal(a, b)
+
+
 @pytest.mark.parametrize('rows,D,relu,x2,skip', [(190, 128, False, False, True), (126, 256, True, True, False),
                                                  (5, 509, False, False, False)])
 def test_layernorm_pair(rows, D, relu, x2, skip):

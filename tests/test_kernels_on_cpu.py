@@ -63,6 +63,7 @@ def test_paired_layer_kernels():
     G.test_layernorm_pair(9, 200, True, True, False)
     G.test_patch_conv_pair(2, 8, 32, 16, 2)
     G.test_patch_conv_pair(1, 16, 64, 48, 4)                    # K = 1024: forward split-K + finish
+    G.test_deferred_reductions_equal_immediate()
 
 
 def test_norm_softmax_attention_kernels():

@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Cut ONE hipGraph replay of the training step out of a rocprofv3 kernel trace (CSV) and summarise it: per-kernel launches,
+total / average duration, and the idle time between consecutive kernels (the step boundary is the single maxpool_fwd launch).
+    python tools/step_from_trace.py trace.csv [--top 60]"""
+import collections
+import csv
+import re
+import sys
+
+
+def short(n):
+    n = re.sub(r'\(anonymous namespace\)::', '', n)
+    n = re.sub(r'^void ', '', n)
+    return n[:86]
+
+
+def main():
+    path = sys.argv[1]
+    top = int(sys.argv[sys.argv.index('--top') + 1]) if '--top' in sys.argv else 60
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    marks = [i for i, r in enumerate(rows) if 'maxpool_fwd' in r['Kernel_Name']]
+    a, b = marks[-2], marks[-1]           # the last complete step (a replay: the eager steps come first)
+    step = rows[a:b]
+    t0, t1 = int(step[0]['Start_Timestamp']), int(rows[b]['Start_Timestamp'])
+    agg = collections.OrderedDict()
+    busy, gaps, prev_end = 0, 0, None
+    for r in step:
+        s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        k = agg.setdefault(short(r['Kernel_Name']), [0, 0])
+        k[0] += 1
+        k[1] += e - s
+        busy += e - s
+        if prev_end is not None and s > prev_end:
+            gaps += s - prev_end
+        prev_end = max(prev_end or e, e)
+    print('step: %d launches, wall %.3f ms, sum of kernel durations %.3f ms, idle between kernels %.3f ms'
+          % (len(step), (t1 - t0) / 1e6, busy / 1e6, gaps / 1e6))
+    g = sum(v[1] for k, v in agg.items() if k.startswith('gemm'))
+    print('GEMM kernels %.3f ms, everything else %.3f ms' % (g / 1e6, (busy - g) / 1e6))
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+        print('%8.3f ms %5d x %8.1f us  %s' % (v[1] / 1e6, v[0], v[1] / v[0] / 1e3, k))
+
+
+if __name__ == '__main__':
+    main()
