@@ -132,6 +132,7 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 64, hrnet32: 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--torch-adam', action='store_true', help='torch.optim.Adam(fused=True) instead of renderih_amd.optim.Adam')
     ap.add_argument('--no-graph', action='store_true',
                     help='launch every kernel from Python each step instead of replaying a captured hipGraph')
     ap.add_argument('--ddp', action='store_true',
@@ -178,9 +179,13 @@ def main():
     net = model
     if dist_on and args.ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=True)
-    # the reference's optimizer (utils/defaults.yaml: Adam, lr 3e-4, weight decay 1e-2); fused=True = torch's single
-    # multi-tensor kernel instead of ~10 foreach passes over the 39 M parameters (2.1 -> 0.3 ms per step)
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=3e-4, weight_decay=1e-2, fused=True)
+    # the reference's optimizer (utils/defaults.yaml: Adam, lr 3e-4, weight decay 1e-2) as ONE launch over all 843 tensors
+    # (renderih_amd.optim.Adam = rih_adam_multi, torch.optim.Adam semantics and state_dict layout; --torch-adam = torch's
+    # fused multi-tensor Adam: 24 launches, 0.89 ms per step)
+    from renderih_amd import optim as rih_optim
+    adam = torch.optim.Adam if args.torch_adam else rih_optim.Adam
+    opt = adam([p for p in model.parameters() if p.requires_grad], lr=3e-4, weight_decay=1e-2,
+               **({'fused': True} if args.torch_adam else {}))
 
     mano = {s: ManoLayer(assets.synthetic_mano_dict(s)) for s in ('left', 'right')}
     gl = {s: GraphLoss(mano[s].J_regressor, mano[s].get_faces(), level=4, device=device) for s in ('left', 'right')}
@@ -381,6 +386,7 @@ def main():
                            'grad_allreduce': ('none (1 rank)' if not dist_on else 'torch DDP' if args.ddp else
                                               'per-stage buckets on a side stream, overlapped with the next backward stage'
                                               if not args.no_overlap else 'per-stage buckets on the compute stream'),
+                           'optimizer': 'torch.optim.Adam(fused=True)' if args.torch_adam else 'renderih_amd.optim.Adam (rih_adam_multi, one launch)',
                            'presplit_weights': bool(ops.PRESPLIT), 'presplit_activations': bool(ops.PRESPLIT_ACT), 'fused_attention': bool(ops.FUSED_ATTN),
                            'gemm_engine': ('fp32 via 3-term bf16 split, 6 MFMA products, fp32 accumulate (fp32-grade error)'
                                            if ops.ENGINE == 1 else 'native f32 MFMA')},

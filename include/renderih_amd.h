@@ -279,6 +279,22 @@ int rih_softmax_bwd(const float* P, float* dPd, int64_t rows, int cols, int ld, 
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise / gather                                                                                 */
+/* Adam / AdamW step (torch.optim.Adam / AdamW semantics, amsgrad off) over a table of parameter tensors in ONE launch:
+ * replaces the optimizer step of core/gcn_trainer.py:127 (torch.optim.Adam: 24 multi-tensor launches of ~37 us per ResNet50
+ * step, 4.7x the HBM time of the 7 passes it needs).  `table` (DEVICE memory): one entry per tensor; block b of the launch
+ * updates elements [blk_chunk[b]*C, (blk_chunk[b]+1)*C) of tensor blk_tensor[b], C = rih_adam_chunk() (both DEVICE int32
+ * arrays of nblocks entries, built once by the caller).  step >= 1 is the 1-based step count of the bias corrections. */
+typedef struct rih_adam_entry {
+    float* p;           /* parameter, updated in place */
+    const float* g;     /* gradient */
+    float* m;           /* exp_avg */
+    float* v;           /* exp_avg_sq */
+    int64_t n;          /* elements */
+} rih_adam_entry;
+int rih_adam_multi(const rih_adam_entry* table, const int32_t* blk_tensor, const int32_t* blk_chunk, int nblocks, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, int adamw, void* stream);
+int rih_adam_chunk(void);
+
 /* y = a + dropout(b) (inverted dropout, p may be 0); b_bcast_rows>0: b is [b_bcast_rows][D] broadcast over the batch */
 int rih_add_dropout(const float* a, const float* b, float* y, int64_t n, int D, int b_bcast_rows, float drop_p,
                     uint64_t seed, const uint64_t* seed_dev, void* stream);

@@ -100,6 +100,8 @@ SIGNATURES = {
     'rih_splitk_reduce': (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
     'rih_splitk_reduce_bias_batched': (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_l, c_l, c_l,
                                              C.c_void_p]),
+    'rih_adam_multi': (c_i, [C.c_void_p, C.c_void_p, C.c_void_p, c_i, c_fl, c_fl, c_fl, c_fl, c_fl, c_i, c_i, C.c_void_p]),
+    'rih_adam_chunk': (c_i, []),
     'rih_splitk_reduce_multi': (c_i, [C.POINTER(ReduceDesc), c_i, C.c_void_p]),
     'rih_splitk_reduce_bias': (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f, C.c_void_p]),
     'rih_splitk_finish': (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_fl, c_i, C.c_void_p]),

@@ -7,6 +7,7 @@
 // reductions (LayerNorm, softmax) use one wavefront per row and DPP/xor shuffles over 64 lanes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 #include "../../include/renderih_amd.h"
 
 namespace {
@@ -1068,6 +1069,62 @@ __global__ __launch_bounds__(TPB) void project_bwd_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------ optimizer
+// Adam / AdamW over a TABLE of parameter tensors in one launch.  A block owns one 4096-element chunk of one tensor
+// (blk_tensor / blk_chunk); 16-byte accesses when the tensor's four pointers allow.  The step is HBM-bound: 4 reads
+// + 3 writes per element.  Same update as torch.optim.Adam(amsgrad=False, maximize=False):
+//   g += wd * p  (Adam)  |  p *= 1 - lr * wd  (AdamW);  m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;
+//   p -= (lr / bias1) * m / (sqrt(v) / sqrt(bias2) + eps)
+constexpr int ADAM_CHUNK = 4096;
+struct AdamScalars {
+    float lr, beta1, beta2, eps, wd, step_size, inv_sqrt_bias2;
+    int adamw;
+};
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamScalars& a) {
+    if (a.wd != 0.f) {
+        if (a.adamw) p *= 1.f - a.lr * a.wd;
+        else g += a.wd * p;
+    }
+    m += (g - m) * (1.f - a.beta1);
+    v = v * a.beta2 + (1.f - a.beta2) * g * g;
+    const float denom = sqrtf(v) * a.inv_sqrt_bias2 + a.eps;
+    p -= a.step_size * (m / denom);
+}
+__global__ __launch_bounds__(TPB) void adam_multi_kernel(const rih_adam_entry* __restrict__ table,
+                                                         const int* __restrict__ blk_tensor,
+                                                         const int* __restrict__ blk_chunk, const AdamScalars a) {
+    const rih_adam_entry e = table[blk_tensor[blockIdx.x]];
+    const long long base = (long long)blk_chunk[blockIdx.x] * ADAM_CHUNK;
+    const long long n = e.n;
+    const bool vec = ((((uintptr_t)e.p | (uintptr_t)e.g | (uintptr_t)e.m | (uintptr_t)e.v) & 15) == 0);
+    if (vec) {
+#pragma unroll
+        for (int u = 0; u < ADAM_CHUNK / (TPB * 4); ++u) {
+            const long long i = base + ((long long)u * TPB + threadIdx.x) * 4;
+            if (i + 3 < n) {
+                float4 p = *reinterpret_cast<float4*>(e.p + i);
+                const float4 g = *reinterpret_cast<const float4*>(e.g + i);
+                float4 m = *reinterpret_cast<float4*>(e.m + i);
+                float4 v = *reinterpret_cast<float4*>(e.v + i);
+                adam_one(p.x, g.x, m.x, v.x, a);
+                adam_one(p.y, g.y, m.y, v.y, a);
+                adam_one(p.z, g.z, m.z, v.z, a);
+                adam_one(p.w, g.w, m.w, v.w, a);
+                *reinterpret_cast<float4*>(e.p + i) = p;
+                *reinterpret_cast<float4*>(e.m + i) = m;
+                *reinterpret_cast<float4*>(e.v + i) = v;
+            } else {
+                for (long long j = i; j < n && j < i + 4; ++j) adam_one(e.p[j], e.g[j], e.m[j], e.v[j], a);
+            }
+        }
+    } else {
+        for (int u = threadIdx.x; u < ADAM_CHUNK; u += TPB) {
+            const long long j = base + u;
+            if (j < n) adam_one(e.p[j], e.g[j], e.m[j], e.v[j], a);
+        }
+    }
+}
+
 }  // namespace
 
 #define STREAM ((hipStream_t)stream)
@@ -1264,6 +1321,22 @@ extern "C" int rih_softmax_bwd(const float* P, float* dPd, int64_t rows, int col
                        drop_p, seed, seed_dev, alpha);
     LAUNCH_RET();
 }
+
+extern "C" int rih_adam_multi(const rih_adam_entry* table, const int32_t* blk_tensor, const int32_t* blk_chunk, int nblocks,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, int step, int adamw,
+                              void* stream) {
+    if (!table || !blk_tensor || !blk_chunk || nblocks < 1 || step < 1) return RIH_EINVAL;
+    if (!(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f)) return RIH_EINVAL;
+    AdamScalars a;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.adamw = adamw;
+    // bias corrections in double on the host, as torch's Python loop computes them
+    const double b1 = 1.0 - pow((double)beta1, (double)step), b2 = 1.0 - pow((double)beta2, (double)step);
+    a.step_size = (float)((double)lr / b1);
+    a.inv_sqrt_bias2 = (float)(1.0 / sqrt(b2));
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)nblocks), dim3(TPB), 0, STREAM, table, blk_tensor, blk_chunk, a);
+    LAUNCH_RET();
+}
+extern "C" int rih_adam_chunk(void) { return ADAM_CHUNK; }
 
 extern "C" int rih_add_dropout(const float* a, const float* b, float* y, int64_t n, int D, int b_bcast_rows,
                                float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream) {

@@ -199,6 +199,38 @@ class EmulatedLib:
                                         db + 4 * b * sDb if db else 0, stream)
         return 0
 
+    def rih_adam_chunk(self):
+        return 4096
+
+    def rih_adam_multi(self, table, blk_tensor, blk_chunk, nblocks, lr, beta1, beta2, eps, wd, step, adamw, stream):
+        bt, bc = _i32(blk_tensor, nblocks), _i32(blk_chunk, nblocks)
+        nt = int(bt.max()) + 1
+        tab = np.ctypeslib.as_array((C.c_int64 * (5 * nt)).from_address(int(table))).reshape(nt, 5)
+        f = np.float32
+        lr, beta1, beta2, eps, wd = f(lr), f(beta1), f(beta2), f(eps), f(wd)
+        step_size = f(float(lr) / (1.0 - float(beta1) ** step))
+        isb2 = f(1.0 / np.sqrt(1.0 - float(beta2) ** step))
+        seen = set()
+        for b in range(nblocks):
+            t, c = int(bt[b]), int(bc[b])
+            assert (t, c) not in seen
+            seen.add((t, c))
+            pp, gp, mp, vp, n = (int(x) for x in tab[t])
+            lo, hi = c * 4096, min(n, (c + 1) * 4096)
+            assert lo < hi
+            p, g, m, v = _f(pp, n)[lo:hi], _f(gp, n)[lo:hi].copy(), _f(mp, n)[lo:hi], _f(vp, n)[lo:hi]
+            if wd != 0:
+                if adamw:
+                    p *= f(1) - lr * wd
+                else:
+                    g += wd * p
+            m += (g - m) * (f(1) - beta1)
+            v[:] = v * beta2 + (f(1) - beta2) * g * g
+            p -= step_size * (m / (np.sqrt(v) * isb2 + eps))
+        # every chunk of every tensor is covered exactly once
+        assert len(seen) == sum((int(n) + 4095) // 4096 for n in tab[:, 4])
+        return 0
+
     def rih_splitk_reduce_multi(self, descs, n, stream):
         for i in range(n):
             d = descs[i]

@@ -505,6 +505,44 @@ def test_linear_pair(M, K, N, relu, res, stacked):
         assert_close(rg.grad, ts[3].grad, 1e-3, 1e-4, 'linear_pair dres')
 
 
+@pytest.mark.parametrize('decoupled,wd', [(False, 0.0), (False, 1e-2), (True, 1e-2)])
+def test_adam_one_launch_matches_torch(decoupled, wd):
+    """renderih_amd.optim.Adam / AdamW (rih_adam_multi: every tensor of a parameter group in one launch) against
+    torch.optim.Adam / AdamW on the CPU over 4 steps: odd sizes (scalar tail, one element, exactly one chunk, chunk + 1),
+    a parameter without gradient, a gradient tensor rebound between steps (table rebuild), then a state_dict round trip into
+    the torch optimizer."""
+    from renderih_amd import optim
+    d = dev()
+    sizes = [(1,), (5,), (64, 3, 7, 7), (4096,), (4097,), (300, 257), (2048,)]
+    ref = [rnd(*s, seed=i).requires_grad_(True) for i, s in enumerate(sizes)] + [rnd(9, seed=50).requires_grad_(True)]
+    got = [t.detach().clone().to(d).requires_grad_(True) for t in ref]
+    kw = dict(lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd)
+    o_ref = (torch.optim.AdamW if decoupled else torch.optim.Adam)(ref, **kw)
+    o_got = (optim.AdamW if decoupled else optim.Adam)(got, **kw)
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(ref[:-1], got[:-1])):
+            g = rnd(*a.shape, seed=100 * step + i) * (10.0 ** (i - 3))
+            a.grad = g.clone()
+            if step == 2 or b.grad is None:
+                b.grad = g.clone().to(d)             # new tensor: the pointer table must follow
+            else:
+                b.grad.copy_(g)
+        o_ref.step()
+        o_got.step()
+        for i, (a, b) in enumerate(zip(ref, got)):
+            assert_close(b.detach(), a.detach(), 2e-6, 1e-7, 'adam step %d tensor %d' % (step, i))
+    assert torch.equal(got[-1].detach().cpu(), ref[-1].detach())            # no gradient: untouched, no state
+    assert got[-1] not in o_got.state or len(o_got.state[got[-1]]) == 0
+    # checkpoints are interchangeable with torch's optimizer
+    sd = o_got.state_dict()
+    o_t = (torch.optim.AdamW if decoupled else torch.optim.Adam)([t.detach().clone().requires_grad_(True) for t in got], **kw)
+    o_t.load_state_dict(sd)
+    st = o_t.state[o_t.param_groups[0]['params'][3]]
+    assert int(st['step']) == 4
+    assert_close(st['exp_avg'], o_ref.state[ref[3]]['exp_avg'], 1e-5, 1e-6, 'exp_avg after round trip')
+    assert_close(st['exp_avg_sq'], o_ref.state[ref[3]]['exp_avg_sq'], 1e-5, 1e-6, 'exp_avg_sq after round trip')
+
+
 def test_deferred_reductions_equal_immediate():
     """ops.deferred_reductions (rih_splitk_reduce_multi: the split-K partial slabs of many weight gradients summed by one
     launch at the end of a backward stage) leaves bit-identical gradients: a strided 3x3 conv with bias, a 1x1 conv, an
