@@ -776,6 +776,183 @@ __global__ __launch_bounds__(TPB) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
+// ---- 16-byte LayerNorm kernels for D = 64 / 128 / 256 / 512 / 1024 (every LayerNorm of the mesh decoder).
+// LPR lanes own one row (float4 per lane, VPT of them): a wavefront normalises 64 / LPR rows at once, the row reductions are
+// xor-shuffles inside the LPR-lane group.  Against the generic kernels above (one 4-byte element per lane and step, one row
+// per wavefront): a quarter of the memory instructions and up to four rows in flight per wavefront -- these launches are
+// latency-bound (8 .. 33 MB tensors), not HBM-bound.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float4 f4z() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int LPR, int VPT>
+__global__ __launch_bounds__(TPB) void layernorm_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ x2,
+                                                                const float* __restrict__ g, const float* __restrict__ b,
+                                                                float* __restrict__ y, float* __restrict__ mean,
+                                                                float* __restrict__ rstd, int rows, float eps, int relu,
+                                                                long long sG, long long sB) {
+    constexpr int D = LPR * 4 * VPT, RPW = 64 / LPR;
+    {
+        const long long go = (long long)blockIdx.y * rows;
+        x += go * D; y += go * D; mean += go; rstd += go;
+        if (x2 != nullptr) x2 += go * D;
+        g += blockIdx.y * sG; b += blockIdx.y * sB;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, l = lane % LPR;
+    float4 gg[VPT], bb[VPT];
+#pragma unroll
+    for (int q = 0; q < VPT; ++q) {
+        gg[q] = *reinterpret_cast<const float4*>(g + (l + LPR * q) * 4);
+        bb[q] = *reinterpret_cast<const float4*>(b + (l + LPR * q) * 4);
+    }
+    for (int r0 = (blockIdx.x * 4 + wave) * RPW; r0 < rows; r0 += gridDim.x * 4 * RPW) {
+        const int r = r0 + sub;
+        const bool ok = r < rows;
+        const long long ro = (long long)(ok ? r : 0) * D;
+        float4 v[VPT];
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            const int c = (l + LPR * q) * 4;
+            float4 t = *reinterpret_cast<const float4*>(x + ro + c);
+            if (x2 != nullptr) {
+                const float4 u = *reinterpret_cast<const float4*>(x2 + ro + c);
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            v[q] = t;
+            s += (t.x + t.y) + (t.z + t.w);
+        }
+        const float m = group_sum<LPR>(s) / (float)D;
+        float qq = 0.f;
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            const float a0 = v[q].x - m, a1 = v[q].y - m, a2 = v[q].z - m, a3 = v[q].w - m;
+            qq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+        const float var = group_sum<LPR>(qq) / (float)D;
+        const float rs = 1.f / sqrtf(var + eps);
+        if (ok) {
+#pragma unroll
+            for (int q = 0; q < VPT; ++q) {
+                float4 o;
+                o.x = (v[q].x - m) * rs * gg[q].x + bb[q].x;
+                o.y = (v[q].y - m) * rs * gg[q].y + bb[q].y;
+                o.z = (v[q].z - m) * rs * gg[q].z + bb[q].z;
+                o.w = (v[q].w - m) * rs * gg[q].w + bb[q].w;
+                if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                *reinterpret_cast<float4*>(y + ro + (l + LPR * q) * 4) = o;
+            }
+            if (l == 0) { mean[r] = m; rstd[r] = rs; }
+        }
+    }
+}
+
+template <int LPR, int VPT>
+__global__ __launch_bounds__(TPB) void layernorm_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ x2, const float* __restrict__ y,
+                                                                const float* __restrict__ g, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd,
+                                                                const float* __restrict__ dres, float* __restrict__ dx,
+                                                                float* __restrict__ ws, int rows, int relu, long long sG) {
+    constexpr int D = LPR * 4 * VPT, RPW = 64 / LPR;
+    {
+        const long long go = (long long)blockIdx.y * rows;
+        dy += go * D; x += go * D; dx += go * D; mean += go; rstd += go;
+        if (x2 != nullptr) x2 += go * D;
+        if (y != nullptr) y += go * D;
+        if (dres != nullptr) dres += go * D;
+        g += blockIdx.y * sG;
+        ws += (long long)blockIdx.y * gridDim.x * 2 * D;
+    }
+    __shared__ float4 red[4][LPR * VPT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, l = lane % LPR;
+    float4 gg[VPT], dgacc[VPT], dbacc[VPT];
+#pragma unroll
+    for (int q = 0; q < VPT; ++q) {
+        gg[q] = *reinterpret_cast<const float4*>(g + (l + LPR * q) * 4);
+        dgacc[q] = f4z();
+        dbacc[q] = f4z();
+    }
+    for (int r0 = (blockIdx.x * 4 + wave) * RPW; r0 < rows; r0 += gridDim.x * 4 * RPW) {
+        const int r = r0 + sub;
+        const bool ok = r < rows;
+        const long long ro = (long long)(ok ? r : 0) * D;
+        const float m = mean[ok ? r : 0], rs = rstd[ok ? r : 0];
+        float4 h[VPT], gd[VPT];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            const int c = (l + LPR * q) * 4;
+            float4 t = *reinterpret_cast<const float4*>(x + ro + c);
+            if (x2 != nullptr) {
+                const float4 u = *reinterpret_cast<const float4*>(x2 + ro + c);
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            float4 d = *reinterpret_cast<const float4*>(dy + ro + c);
+            if (relu) {
+                const float4 yy = *reinterpret_cast<const float4*>(y + ro + c);
+                if (!(yy.x > 0.f)) d.x = 0.f;
+                if (!(yy.y > 0.f)) d.y = 0.f;
+                if (!(yy.z > 0.f)) d.z = 0.f;
+                if (!(yy.w > 0.f)) d.w = 0.f;
+            }
+            if (!ok) d = f4z();
+            h[q] = make_float4((t.x - m) * rs, (t.y - m) * rs, (t.z - m) * rs, (t.w - m) * rs);
+            dgacc[q].x += d.x * h[q].x; dgacc[q].y += d.y * h[q].y; dgacc[q].z += d.z * h[q].z; dgacc[q].w += d.w * h[q].w;
+            dbacc[q].x += d.x; dbacc[q].y += d.y; dbacc[q].z += d.z; dbacc[q].w += d.w;
+            gd[q] = make_float4(d.x * gg[q].x, d.y * gg[q].y, d.z * gg[q].z, d.w * gg[q].w);
+            c1 += (gd[q].x + gd[q].y) + (gd[q].z + gd[q].w);
+            c2 += (gd[q].x * h[q].x + gd[q].y * h[q].y) + (gd[q].z * h[q].z + gd[q].w * h[q].w);
+        }
+        c1 = group_sum<LPR>(c1) / (float)D;
+        c2 = group_sum<LPR>(c2) / (float)D;
+        if (ok) {
+#pragma unroll
+            for (int q = 0; q < VPT; ++q) {
+                const int c = (l + LPR * q) * 4;
+                float4 o;
+                o.x = rs * (gd[q].x - c1 - h[q].x * c2);
+                o.y = rs * (gd[q].y - c1 - h[q].y * c2);
+                o.z = rs * (gd[q].z - c1 - h[q].z * c2);
+                o.w = rs * (gd[q].w - c1 - h[q].w * c2);
+                if (dres != nullptr) {
+                    const float4 e = *reinterpret_cast<const float4*>(dres + ro + c);
+                    o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+                }
+                *reinterpret_cast<float4*>(dx + ro + c) = o;
+            }
+        }
+    }
+    // dg / db: over the 64 / LPR rows of the wavefront by shuffles, over the 4 wavefronts through LDS -> ws[blk][{dg,db}][D]
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            float4 a = pass == 0 ? dgacc[q] : dbacc[q];
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) {
+                a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64);
+                a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+            }
+            if (sub == 0) red[wave][l + LPR * q] = a;
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < LPR * VPT; c += TPB) {
+            const float4 a = red[0][c], b2 = red[1][c], c2 = red[2][c], d2 = red[3][c];
+            *reinterpret_cast<float4*>(ws + ((long long)blockIdx.x * 2 + pass) * D + c * 4) =
+                make_float4((a.x + b2.x) + (c2.x + d2.x), (a.y + b2.y) + (c2.y + d2.y), (a.z + b2.z) + (c2.z + d2.z),
+                            (a.w + b2.w) + (c2.w + d2.w));
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(TPB) void ln_param_final_kernel(const float* __restrict__ ws, int D, int nblk,
                                                              float* __restrict__ dg, float* __restrict__ db) {
     ws += (long long)blockIdx.y * nblk * 2 * D;     // group: dg / db are [groups][D]
@@ -989,10 +1166,24 @@ __global__ void cheby_fwd_kernel(const float* __restrict__ x, const int32_t* __r
         const int b = (int)(t / V);
         const float4* xb = reinterpret_cast<const float4*>(x + (long long)b * V * F) + f4;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = indptr[v]; k < indptr[v + 1]; ++k) {
-            const float w = vals[k];
-            const float4 n = xb[(long long)indices[k] * F4];
-            s.x += w * n.x; s.y += w * n.y; s.z += w * n.z; s.w += w * n.w;
+        // four neighbours per round: their (index, weight) pairs, then their rows, are all in flight before the first FMA
+        // (a one-neighbour loop is a chain of two dependent loads per step: the kernel is latency-bound, not HBM-bound)
+        const int kend = indptr[v + 1];
+        for (int k = indptr[v]; k < kend; k += 4) {
+            int idx[4];
+            float w[4];
+            float4 n[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = k + j < kend;
+                idx[j] = in ? indices[k + j] : v;
+                w[j] = in ? vals[k + j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) n[j] = xb[(long long)idx[j] * F4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k + j < kend) { s.x += w[j] * n[j].x; s.y += w[j] * n[j].y; s.z += w[j] * n[j].z; s.w += w[j] * n[j].w; }
         }
         const float4 c = xb[(long long)v * F4];
         float4* o = reinterpret_cast<float4*>(y) + 2 * i;
@@ -1015,10 +1206,25 @@ __global__ void cheby_bwd_kernel(const float* __restrict__ dy, const int32_t* __
         const float4* db = reinterpret_cast<const float4*>(dy + (long long)b * V * 2 * F) + 2 * f4;
         const float4 a0 = db[(long long)v * 2 * F4], a1 = db[(long long)v * 2 * F4 + 1];
         float4 s = make_float4(a0.x, a0.z, a1.x, a1.z);
-        for (int k = indptr[v]; k < indptr[v + 1]; ++k) {
-            const float w = vals[k];
-            const float4 n0 = db[(long long)indices[k] * 2 * F4], n1 = db[(long long)indices[k] * 2 * F4 + 1];
-            s.x += w * n0.y; s.y += w * n0.w; s.z += w * n1.y; s.w += w * n1.w;
+        const int kend = indptr[v + 1];
+        for (int k = indptr[v]; k < kend; k += 4) {      // four neighbours in flight per round, see cheby_fwd_kernel
+            int idx[4];
+            float w[4];
+            float4 n0[4], n1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = k + j < kend;
+                idx[j] = in ? indices[k + j] : v;
+                w[j] = in ? vals[k + j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                n0[j] = db[(long long)idx[j] * 2 * F4];
+                n1[j] = db[(long long)idx[j] * 2 * F4 + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k + j < kend) { s.x += w[j] * n0[j].y; s.y += w[j] * n0[j].w; s.z += w[j] * n1[j].y; s.w += w[j] * n1[j].w; }
         }
         reinterpret_cast<float4*>(dx)[i] = s;
     }
@@ -1274,8 +1480,23 @@ extern "C" int rih_layernorm_fwd_grouped(const float* x, const float* x2, const 
     if (groups < 1 || groups > 65535) return RIH_EINVAL;
     int blocks = (rows + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks, groups), dim3(TPB), 0, STREAM, x, x2, g, b, y, mean, rstd, rows,
-                       D, eps, relu, (long long)sG, (long long)sB);
+    const bool vec = al16(x) && al16(g) && al16(b) && al16(y) && (x2 == nullptr || al16(x2)) && sG % 4 == 0 && sB % 4 == 0;
+#define RIH_LN_FWD(LPR_, VPT_)                                                                                          \
+    {                                                                                                                   \
+        int bl = (rows + 4 * (64 / LPR_) - 1) / (4 * (64 / LPR_));                                                      \
+        if (bl > 8192) bl = 8192;                                                                                       \
+        hipLaunchKernelGGL((layernorm_fwd_vec_kernel<LPR_, VPT_>), dim3(bl, groups), dim3(TPB), 0, STREAM, x, x2, g, b, y, \
+                           mean, rstd, rows, eps, relu, (long long)sG, (long long)sB);                                  \
+    }
+    if (vec && D == 64) RIH_LN_FWD(16, 1)
+    else if (vec && D == 128) RIH_LN_FWD(32, 1)
+    else if (vec && D == 256) RIH_LN_FWD(64, 1)
+    else if (vec && D == 512) RIH_LN_FWD(64, 2)
+    else if (vec && D == 1024) RIH_LN_FWD(64, 4)
+    else
+        hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks, groups), dim3(TPB), 0, STREAM, x, x2, g, b, y, mean, rstd, rows,
+                           D, eps, relu, (long long)sG, (long long)sB);
+#undef RIH_LN_FWD
     LAUNCH_RET();
 }
 extern "C" int rih_layernorm_fwd(const float* x, const float* x2, const float* g, const float* b, float* y, float* mean,
@@ -1290,8 +1511,20 @@ extern "C" int rih_layernorm_bwd_grouped(const float* dy, const float* x, const 
     if (relu && !y) return RIH_EINVAL;
     if (rows < 1 || D < 1 || D > 64 * LN_MAXPER || groups < 1 || groups > 65535) return RIH_EINVAL;
     const int nblk = rih_ln_nblk(rows);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk, groups), dim3(TPB), 0, STREAM, dy, x, x2, y, g, mean, rstd, dres,
-                       dx, ws, rows, D, relu, (long long)sG);
+    const bool vec = al16(dy) && al16(x) && al16(g) && al16(dx) && al16(ws) && (x2 == nullptr || al16(x2)) &&
+                     (y == nullptr || al16(y)) && (dres == nullptr || al16(dres)) && sG % 4 == 0;
+#define RIH_LN_BWD(LPR_, VPT_)                                                                                           \
+    hipLaunchKernelGGL((layernorm_bwd_vec_kernel<LPR_, VPT_>), dim3(nblk, groups), dim3(TPB), 0, STREAM, dy, x, x2, y, g, \
+                       mean, rstd, dres, dx, ws, rows, relu, (long long)sG);
+    if (vec && D == 64) RIH_LN_BWD(16, 1)
+    else if (vec && D == 128) RIH_LN_BWD(32, 1)
+    else if (vec && D == 256) RIH_LN_BWD(64, 1)
+    else if (vec && D == 512) RIH_LN_BWD(64, 2)
+    else if (vec && D == 1024) RIH_LN_BWD(64, 4)
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk, groups), dim3(TPB), 0, STREAM, dy, x, x2, y, g, mean, rstd, dres,
+                           dx, ws, rows, D, relu, (long long)sG);
+#undef RIH_LN_BWD
     hipLaunchKernelGGL(ln_param_final_kernel, dim3((D + 3) / 4, groups), dim3(TPB), 0, STREAM, ws, D, nblk, dg, db);
     LAUNCH_RET();
 }

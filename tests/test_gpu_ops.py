@@ -148,7 +148,8 @@ def test_batchnorm(training, relu, res, shape):
 
 
 @pytest.mark.parametrize('rows,D,x2,relu', [(126, 64, False, False), (4, 509, False, False), (300, 256, True, True),
-                                             (1000, 128, True, False), (64, 512, False, True)])
+                                             (1000, 128, True, False), (64, 512, False, True), (7, 1024, True, True),
+                                             (131, 64, True, True), (5, 128, False, False), (3, 200, True, True)])
 def test_layernorm(rows, D, x2, relu):
     from renderih_amd import ops
     x, y2 = rnd(rows, D, seed=1) * 2 + 0.3, (rnd(rows, D, seed=2) if x2 else None)
@@ -573,7 +574,8 @@ def test_deferred_reductions_equal_immediate():
 
 
 @pytest.mark.parametrize('rows,D,relu,x2,skip', [(190, 128, False, False, True), (126, 256, True, True, False),
-                                                 (5, 509, False, False, False)])
+                                                 (5, 509, False, False, False), (67, 64, True, False, True),
+                                                 (40, 64, False, True, False)])
 def test_layernorm_pair(rows, D, relu, x2, skip):
     from renderih_amd import ops
     d = dev()

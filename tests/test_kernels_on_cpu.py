@@ -73,6 +73,12 @@ def test_norm_softmax_attention_kernels():
     G.test_batchnorm(False, True, False, (2, 5, 3, 32))
     G.test_layernorm(4, 509, False, False)
     G.test_layernorm(70, 256, True, True)
+    G.test_layernorm(131, 64, True, True)          # 16-byte kernels: 4 rows per wavefront, ragged last group
+    G.test_layernorm(37, 128, False, False)
+    G.test_layernorm(9, 512, True, False)
+    G.test_layernorm(6, 1024, False, True)
+    G.test_layernorm_pair(67, 64, True, False, True)
+    G.test_layernorm_pair(40, 64, False, True, False)
     G.test_attention(2, 63, 63, 64, 4)
     G.test_attention_dropout_matches_hash_mask()
     G.test_self_attention_packed(2, 40, 64, 4)
