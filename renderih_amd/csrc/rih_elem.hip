@@ -1275,6 +1275,76 @@ __global__ __launch_bounds__(TPB) void project_bwd_kernel(const float* __restric
     }
 }
 
+// ---- Chebyshev feature build through LDS (V <= CH_MAXV vertices: the 63 / 126 / 252-vertex levels of the mesh decoder).
+// The gather kernels above read every vertex row ~7 times (once per neighbour; the backward even 2 x 16 bytes per neighbour for
+// 16 useful ones): 0.46 GB of L2 traffic for a 33 MB tensor, 36 us per launch.  Here a block owns one sample and a slice of
+// CH_FS channel quads, stages the V rows of the slice in LDS once (coalesced) and gathers from LDS.  Same summation order as
+// the gather kernels (bit-identical results).
+constexpr int CH_MAXV = 256, CH_FS = 4, CH_ITEMS = CH_MAXV * CH_FS / TPB;
+__global__ __launch_bounds__(TPB) void cheby_fwd_lds_kernel(const float* __restrict__ x, const int32_t* __restrict__ indptr,
+                                                            const int32_t* __restrict__ indices,
+                                                            const float* __restrict__ vals, float* __restrict__ y, int V,
+                                                            int F) {
+    __shared__ float4 t[CH_MAXV * CH_FS];
+    const int F4 = F >> 2, f4base = blockIdx.x * CH_FS, b = blockIdx.y;
+    const int nfs = min(CH_FS, F4 - f4base);
+    const float4* xb = reinterpret_cast<const float4*>(x + (long long)b * V * F) + f4base;
+    for (int i = threadIdx.x; i < V * CH_FS; i += TPB) {
+        const int v = i / CH_FS, j = i % CH_FS;
+        if (j < nfs) t[i] = xb[(long long)v * F4 + j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < V * CH_FS; i += TPB) {
+        const int v = i / CH_FS, j = i % CH_FS;
+        if (j >= nfs) continue;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = indptr[v]; k < indptr[v + 1]; ++k) {
+            const float w = vals[k];
+            const float4 n = t[indices[k] * CH_FS + j];
+            s.x += w * n.x; s.y += w * n.y; s.z += w * n.z; s.w += w * n.w;
+        }
+        const float4 c = t[i];
+        float4* o = reinterpret_cast<float4*>(y) + 2 * (((long long)b * V + v) * F4 + f4base + j);
+        o[0] = make_float4(c.x, s.x, c.y, s.y);
+        o[1] = make_float4(c.z, s.z, c.w, s.w);
+    }
+}
+__global__ __launch_bounds__(TPB) void cheby_bwd_lds_kernel(const float* __restrict__ dy, const int32_t* __restrict__ indptr,
+                                                            const int32_t* __restrict__ indices,
+                                                            const float* __restrict__ vals, float* __restrict__ dx, int V,
+                                                            int F) {
+    __shared__ float4 t[CH_MAXV * CH_FS];       // the Laplacian half (d Lx) of the slice's gradient rows
+    const int F4 = F >> 2, f4base = blockIdx.x * CH_FS, b = blockIdx.y;
+    const int nfs = min(CH_FS, F4 - f4base);
+    const float4* db = reinterpret_cast<const float4*>(dy + (long long)b * V * 2 * F) + 2 * f4base;
+    float4 own[CH_ITEMS];                       // the identity half (d x) of the item this thread finishes below
+#pragma unroll
+    for (int it = 0; it < CH_ITEMS; ++it) {
+        const int i = threadIdx.x + it * TPB;
+        const int v = i / CH_FS, j = i % CH_FS;
+        own[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < V * CH_FS && j < nfs) {
+            const float4 a0 = db[(long long)v * 2 * F4 + 2 * j], a1 = db[(long long)v * 2 * F4 + 2 * j + 1];
+            own[it] = make_float4(a0.x, a0.z, a1.x, a1.z);
+            t[i] = make_float4(a0.y, a0.w, a1.y, a1.w);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < CH_ITEMS; ++it) {
+        const int i = threadIdx.x + it * TPB;
+        const int v = i / CH_FS, j = i % CH_FS;
+        if (i >= V * CH_FS || j >= nfs) continue;
+        float4 s = own[it];
+        for (int k = indptr[v]; k < indptr[v + 1]; ++k) {
+            const float w = vals[k];
+            const float4 n = t[indices[k] * CH_FS + j];
+            s.x += w * n.x; s.y += w * n.y; s.z += w * n.z; s.w += w * n.w;
+        }
+        reinterpret_cast<float4*>(dx)[((long long)b * V + v) * F4 + f4base + j] = s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ optimizer
 // Adam / AdamW over a TABLE of parameter tensors in one launch.  A block owns one 4096-element chunk of one tensor
 // (blk_tensor / blk_chunk); 16-byte accesses when the tensor's four pointers allow.  The step is HBM-bound: 4 reads
@@ -1626,7 +1696,10 @@ extern "C" int rih_scatter_rows_add(const float* dy, const int32_t* inv_ptr, con
 extern "C" int rih_cheby_fwd(const float* x, const int32_t* indptr, const int32_t* indices, const float* vals, float* y,
                              int B, int V, int F, void* stream) {
     if (!x || !indptr || !indices || !vals || !y || B < 1 || V < 1 || F < 1) return RIH_EINVAL;
-    if (F % 4 == 0)
+    if (F % 4 == 0 && V <= CH_MAXV && B <= 65535 && al16(x) && al16(y))
+        hipLaunchKernelGGL(cheby_fwd_lds_kernel, dim3((F / 4 + CH_FS - 1) / CH_FS, B), dim3(TPB), 0, STREAM, x, indptr, indices,
+                           vals, y, V, F);
+    else if (F % 4 == 0)
         hipLaunchKernelGGL(cheby_fwd_kernel, dim3(grid_for((long long)B * V * (F / 4))), dim3(TPB), 0, STREAM, x, indptr,
                            indices, vals, y, B, V, F);
     else
@@ -1637,7 +1710,10 @@ extern "C" int rih_cheby_fwd(const float* x, const int32_t* indptr, const int32_
 extern "C" int rih_cheby_bwd(const float* dy, const int32_t* t_indptr, const int32_t* t_indices, const float* t_vals,
                              float* dx, int B, int V, int F, void* stream) {
     if (!dy || !t_indptr || !t_indices || !t_vals || !dx || B < 1 || V < 1 || F < 1) return RIH_EINVAL;
-    if (F % 4 == 0)
+    if (F % 4 == 0 && V <= CH_MAXV && B <= 65535 && al16(dy) && al16(dx))
+        hipLaunchKernelGGL(cheby_bwd_lds_kernel, dim3((F / 4 + CH_FS - 1) / CH_FS, B), dim3(TPB), 0, STREAM, dy, t_indptr,
+                           t_indices, t_vals, dx, V, F);
+    else if (F % 4 == 0)
         hipLaunchKernelGGL(cheby_bwd_kernel, dim3(grid_for((long long)B * V * (F / 4))), dim3(TPB), 0, STREAM, dy, t_indptr,
                            t_indices, t_vals, dx, B, V, F);
     else

@@ -346,19 +346,23 @@ def test_cheby_gather_project():
     from renderih_amd import ops, assets
     from renderih_amd.attn import GraphCSR
     d = dev()
-    L = assets.load_graph_dict('left')['coarsen_graphs_L'][3]      # 126 vertices
-    Ld = torch.from_numpy(np.asarray(L.todense(), dtype=np.float32))
-    csr, csr_t = GraphCSR(Ld.numpy()).on(d)
-    x = rnd(3, 126, 64, seed=1)
-    xr = x.clone().requires_grad_(True)
-    yr = torch.stack((xr, torch.matmul(Ld, xr)), -1).flatten(-2)
-    gy = rnd(*yr.shape, seed=2)
-    yr.backward(gy)
-    xg = x.to(d).requires_grad_(True)
-    yg = ops.cheby_features(xg, csr, csr_t)
-    assert_close(yg, yr, what='cheby')
-    yg.backward(gy.to(d))
-    assert_close(xg.grad, xr.grad, 1e-4, 1e-5, 'cheby dx')
+    # (graph level, F): LDS-staged kernels (V <= 256; F = 24: a partial channel slice), the gather kernels (504 vertices) and
+    # the scalar ones (F % 4 != 0)
+    for level, Fc in ((3, 64), (2, 256), (4, 24), (1, 32), (3, 6)):
+        L = assets.load_graph_dict('left')['coarsen_graphs_L'][level]
+        V = L.shape[0]
+        Ld = torch.from_numpy(np.asarray(L.todense(), dtype=np.float32))
+        csr, csr_t = GraphCSR(Ld.numpy()).on(d)
+        x = rnd(3, V, Fc, seed=1)
+        xr = x.clone().requires_grad_(True)
+        yr = torch.stack((xr, torch.matmul(Ld, xr)), -1).flatten(-2)
+        gy = rnd(*yr.shape, seed=2)
+        yr.backward(gy)
+        xg = x.to(d).requires_grad_(True)
+        yg = ops.cheby_features(xg, csr, csr_t)
+        assert_close(yg, yr, what='cheby V=%d F=%d' % (V, Fc))
+        yg.backward(gy.to(d))
+        assert_close(xg.grad, xr.grad, 1e-4, 1e-5, 'cheby dx V=%d F=%d' % (V, Fc))
 
     idx = np.random.RandomState(0).randint(0, 50, size=120)
     g = ops.RowIndex(idx, 50, d)
