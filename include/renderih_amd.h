@@ -197,6 +197,16 @@ int rih_splitk_finish(const float* P, int S, int M, int N, float* C, int ldc, co
  * with for_dgrad!=0, dst[(((KH-1-kh)*KW + (KW-1-kw))*Cout + co)*Ci_pad + ci] (flipped, in/out swapped). */
 int rih_pack_conv_weight(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int CinPad,
                          int for_dgrad, void* stream);
+/* Any number of weight operands packed in ceil(n/56) launches (every 3x3 / 7x7 / patch convolution of a training step needs
+ * its forward and its data-gradient operand once per step: 58 launches of ~6 us otherwise).  mode 0 = rih_pack_conv_weight
+ * (for_dgrad 0), mode 1 = rih_pack_conv_weight_sub (the full flipped operand is kh0 = kw0 = 0, step 1, Th = KH, Tw = KW).
+ * `descs` is HOST memory, read before the call returns. */
+typedef struct rih_pack_desc {
+    const float* w;         /* OIHW parameter */
+    float* dst;
+    int32_t Cout, Cin, KH, KW, CinPad, mode, kh0, kw0, step, Th, Tw, reserved;
+} rih_pack_desc;
+int rih_pack_conv_weight_multi(const rih_pack_desc* descs, int n, void* stream);
 /* Tap subset for one parity class of a strided data gradient:
  * dst[((th*Tw + tw)*Cout + co)*CinPad + ci] = w[co][ci][kh0 + step*(Th-1-th)][kw0 + step*(Tw-1-tw)]. */
 int rih_pack_conv_weight_sub(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int CinPad, int kh0,
@@ -254,6 +264,17 @@ int rih_layernorm_fwd(const float* x, const float* x2, const float* g, const flo
  * dres (may be NULL): [rows][D] added to dx -- the gradient arriving over a skip connection around the norm
  * (x + f(LN(x)), self_attn.py:26-33, 84-85), so that autograd needs no separate accumulation pass. */
 int rih_ln_nblk(int rows);
+/* rih_layernorm_bwd[_grouped] with dg == db == NULL leaves the parameter gradients as partials in ws ([groups][nblk][2][D]);
+ * rih_ln_param_final_multi finishes any number of them (one descriptor per group: ws + g*nblk*2*D, dg + g*D, db + g*D) in
+ * ceil(n/100) launches -- a backward stage's 50 LayerNorms cost one finishing launch instead of 50 (>= 4.5 us each).
+ * `descs` is HOST memory, read before the call returns. */
+typedef struct rih_ln_final_desc {
+    const float* ws;
+    float* dg;
+    float* db;
+    int32_t D, nblk;
+} rih_ln_final_desc;
+int rih_ln_param_final_multi(const rih_ln_final_desc* descs, int n, void* stream);
 int rih_layernorm_bwd(const float* dy, const float* x, const float* x2, const float* y, const float* g,
                       const float* mean, const float* rstd, const float* dres, float* dx, float* dg, float* db, int rows,
                       int D, int relu, float* ws, void* stream);

@@ -44,6 +44,16 @@ class ReduceDesc(C.Structure):
                [(n, C.c_int32) for n in ('S', 'Mp', 'M', 'N', 'Cin', 'taps', 'CinValid', 'accumulate')]
 
 
+class LnFinalDesc(C.Structure):
+    _fields_ = [('ws', C.c_void_p), ('dg', C.c_void_p), ('db', C.c_void_p), ('D', C.c_int32), ('nblk', C.c_int32)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('dst', C.c_void_p)] + \
+               [(n, C.c_int32) for n in ('Cout', 'Cin', 'KH', 'KW', 'CinPad', 'mode', 'kh0', 'kw0', 'step', 'Th', 'Tw',
+                                         'reserved')]
+
+
 class HConvDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('zero', C.c_void_p), ('bias', C.c_void_p),
                 ('post_scale', C.c_void_p), ('post_shift', C.c_void_p), ('res', C.c_void_p), ('y', C.c_void_p)] + \
@@ -102,6 +112,8 @@ SIGNATURES = {
                                              C.c_void_p]),
     'rih_adam_multi': (c_i, [C.c_void_p, C.c_void_p, C.c_void_p, c_i, c_fl, c_fl, c_fl, c_fl, c_fl, c_i, c_i, C.c_void_p]),
     'rih_adam_chunk': (c_i, []),
+    'rih_ln_param_final_multi': (c_i, [C.POINTER(LnFinalDesc), c_i, C.c_void_p]),
+    'rih_pack_conv_weight_multi': (c_i, [C.POINTER(PackDesc), c_i, C.c_void_p]),
     'rih_splitk_reduce_multi': (c_i, [C.POINTER(ReduceDesc), c_i, C.c_void_p]),
     'rih_splitk_reduce_bias': (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f, C.c_void_p]),
     'rih_splitk_finish': (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_fl, c_i, C.c_void_p]),

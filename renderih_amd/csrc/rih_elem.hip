@@ -1275,6 +1275,33 @@ __global__ __launch_bounds__(TPB) void project_bwd_kernel(const float* __restric
     }
 }
 
+// Parameter gradients of many LayerNorms finished by ONE launch (rih_ln_param_final_multi): the same per-channel reduction as
+// ln_param_final_kernel, the descriptors by value in the kernel argument (see splitk_reduce_multi_kernel in rih_gemm.hip).
+constexpr int LN_FINAL_PACK = 100;
+struct LnFinalPack {
+    rih_ln_final_desc d[LN_FINAL_PACK];
+    int first[LN_FINAL_PACK + 1];
+    int n;
+};
+static_assert(sizeof(LnFinalPack) <= 4096, "kernel argument limit");
+__global__ __launch_bounds__(TPB) void ln_param_final_multi_kernel(const LnFinalPack pk) {
+    const int bidx = (int)blockIdx.x;
+    int i = 0;
+    while (i + 1 < pk.n && bidx >= pk.first[i + 1]) ++i;
+    const rih_ln_final_desc& d = pk.d[i];
+    const int lane = threadIdx.x & 63;
+    const int e = (bidx - pk.first[i]) * (TPB / 64) + (threadIdx.x >> 6);
+    if (e >= d.D) return;
+    double a = 0.0, b = 0.0;
+    for (int k = lane; k < d.nblk; k += 64) {
+        a += (double)d.ws[((long long)k * 2 + 0) * d.D + e];
+        b += (double)d.ws[((long long)k * 2 + 1) * d.D + e];
+    }
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    if (lane == 0) { d.dg[e] = (float)a; d.db[e] = (float)b; }
+}
+
 // ---- Chebyshev feature build through LDS (V <= CH_MAXV vertices: the 63 / 126 / 252-vertex levels of the mesh decoder).
 // The gather kernels above read every vertex row ~7 times (once per neighbour; the backward even 2 x 16 bytes per neighbour for
 // 16 useful ones): 0.46 GB of L2 traffic for a 33 MB tensor, 36 us per launch.  Here a block owns one sample and a slice of
@@ -1577,7 +1604,7 @@ extern "C" int rih_layernorm_bwd_grouped(const float* dy, const float* x, const 
                                          const float* mean, const float* rstd, const float* dres, float* dx, float* dg,
                                          float* db, int groups, int rows, int D, int64_t sG, int relu, float* ws,
                                          void* stream) {
-    if (!dy || !x || !g || !mean || !rstd || !dx || !dg || !db || !ws) return RIH_EINVAL;
+    if (!dy || !x || !g || !mean || !rstd || !dx || !ws || ((dg == nullptr) != (db == nullptr))) return RIH_EINVAL;
     if (relu && !y) return RIH_EINVAL;
     if (rows < 1 || D < 1 || D > 64 * LN_MAXPER || groups < 1 || groups > 65535) return RIH_EINVAL;
     const int nblk = rih_ln_nblk(rows);
@@ -1595,7 +1622,26 @@ extern "C" int rih_layernorm_bwd_grouped(const float* dy, const float* x, const 
         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk, groups), dim3(TPB), 0, STREAM, dy, x, x2, y, g, mean, rstd, dres,
                            dx, ws, rows, D, relu, (long long)sG);
 #undef RIH_LN_BWD
-    hipLaunchKernelGGL(ln_param_final_kernel, dim3((D + 3) / 4, groups), dim3(TPB), 0, STREAM, ws, D, nblk, dg, db);
+    if (dg != nullptr)      // NULL: the caller finishes the parameter gradients later with rih_ln_param_final_multi
+        hipLaunchKernelGGL(ln_param_final_kernel, dim3((D + 3) / 4, groups), dim3(TPB), 0, STREAM, ws, D, nblk, dg, db);
+    LAUNCH_RET();
+}
+extern "C" int rih_ln_param_final_multi(const rih_ln_final_desc* descs, int n, void* stream) {
+    if (n < 0 || (n > 0 && !descs)) return RIH_EINVAL;
+    for (int i = 0; i < n; ++i)
+        if (!descs[i].ws || !descs[i].dg || !descs[i].db || descs[i].D < 1 || descs[i].nblk < 1) return RIH_EINVAL;
+    for (int base = 0; base < n; base += LN_FINAL_PACK) {
+        LnFinalPack pk;
+        pk.n = (n - base < LN_FINAL_PACK) ? n - base : LN_FINAL_PACK;
+        int total = 0;
+        for (int i = 0; i < pk.n; ++i) {
+            pk.d[i] = descs[base + i];
+            pk.first[i] = total;
+            total += (descs[base + i].D + 3) / 4;
+        }
+        pk.first[pk.n] = total;
+        hipLaunchKernelGGL(ln_param_final_multi_kernel, dim3(total), dim3(TPB), 0, STREAM, pk);
+    }
     LAUNCH_RET();
 }
 extern "C" int rih_layernorm_bwd(const float* dy, const float* x, const float* x2, const float* y, const float* g,

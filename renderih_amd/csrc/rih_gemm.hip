@@ -1555,6 +1555,43 @@ __global__ void pack_conv_weight_sub_kernel(const float* __restrict__ w, float* 
         dst[i] = (ci < Cin) ? w[(((long long)co * Cin + ci) * KH + kh) * KW + kw] : 0.f;
     }
 }
+// Every weight operand of a step packed by ONE launch (rih_pack_conv_weight_multi; descriptors by value, see
+// splitk_reduce_multi_kernel): mode 0 = forward operand [(tap, ci)][co], mode 1 = data-gradient operand of the tap subset
+// (kh0, kw0, step, Th, Tw), flipped, [((th, tw), co)][ci] -- the same element maps as the two kernels above.
+constexpr int PACK_PACK = 56;
+struct PackPack {
+    rih_pack_desc d[PACK_PACK];
+    int first[PACK_PACK + 1];
+    int n;
+};
+static_assert(sizeof(PackPack) <= 4096, "kernel argument limit");
+__global__ __launch_bounds__(256) void pack_conv_weight_multi_kernel(const PackPack pk) {
+    const int b = (int)blockIdx.x;
+    int k = 0;
+    while (k + 1 < pk.n && b >= pk.first[k + 1]) ++k;
+    const rih_pack_desc& d = pk.d[k];
+    const int nb = pk.first[k + 1] - pk.first[k];
+    const int taps = d.KH * d.KW;
+    const long long total = (d.mode == 0) ? (long long)taps * d.CinPad * d.Cout : (long long)d.Th * d.Tw * d.Cout * d.CinPad;
+    for (long long i = (long long)(b - pk.first[k]) * 256 + threadIdx.x; i < total; i += (long long)nb * 256) {
+        float v = 0.f;
+        if (d.mode == 0) {
+            const int co = (int)(i % d.Cout);
+            const long long t = i / d.Cout;
+            const int ci = (int)(t % d.CinPad), tap = (int)(t / d.CinPad);
+            if (ci < d.Cin) v = d.w[((long long)co * d.Cin + ci) * taps + tap];
+        } else {
+            const int ci = (int)(i % d.CinPad);
+            long long t = i / d.CinPad;
+            const int co = (int)(t % d.Cout);
+            t /= d.Cout;
+            const int tw = (int)(t % d.Tw), th = (int)(t / d.Tw);
+            const int kh = d.kh0 + d.step * (d.Th - 1 - th), kw = d.kw0 + d.step * (d.Tw - 1 - tw);
+            if (ci < d.Cin) v = d.w[(((long long)co * d.Cin + ci) * d.KH + kh) * d.KW + kw];
+        }
+        d.dst[i] = v;
+    }
+}
 
 // Pre-split B operands for gemm_split_kernel<..., BMODE 2>: dst = three bf16 planes [hi | mid | lo][N][Kpad] (as dwords
 // [3][N][Kpad/2], k even in the low half), B(k, n) taken from
@@ -1596,6 +1633,34 @@ __global__ void presplit_kernel(const PresplitArgs a) {
 
 }  // namespace
 
+extern "C" int rih_pack_conv_weight_multi(const rih_pack_desc* descs, int n, void* stream) {
+    if (n < 0 || (n > 0 && !descs)) return RIH_EINVAL;
+    for (int i = 0; i < n; ++i) {
+        const rih_pack_desc& d = descs[i];
+        if (!d.w || !d.dst || d.Cout < 1 || d.Cin < 1 || d.KH < 1 || d.KW < 1 || d.CinPad < d.Cin || (d.mode != 0 && d.mode != 1))
+            return RIH_EINVAL;
+        if (d.mode == 1 && (d.step < 1 || d.Th < 1 || d.Tw < 1 || d.kh0 < 0 || d.kw0 < 0 ||
+                            d.kh0 + d.step * (d.Th - 1) >= d.KH || d.kw0 + d.step * (d.Tw - 1) >= d.KW))
+            return RIH_EINVAL;
+    }
+    for (int base = 0; base < n; base += PACK_PACK) {
+        PackPack pk;
+        pk.n = (n - base < PACK_PACK) ? n - base : PACK_PACK;
+        int total = 0;
+        for (int i = 0; i < pk.n; ++i) {
+            const rih_pack_desc& d = descs[base + i];
+            const long long el = (d.mode == 0) ? (long long)d.KH * d.KW * d.CinPad * d.Cout : (long long)d.Th * d.Tw * d.Cout * d.CinPad;
+            long long nb = (el + 4095) / 4096;        // 16 elements per thread: these are latency-, not bandwidth-sized
+            if (nb > 1024) nb = 1024;
+            pk.d[i] = d;
+            pk.first[i] = total;
+            total += (int)nb;
+        }
+        pk.first[pk.n] = total;
+        hipLaunchKernelGGL(pack_conv_weight_multi_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, pk);
+    }
+    return (int)hipGetLastError();
+}
 extern "C" int rih_pack_conv_weight_sub(const float* w, float* dst, int Cout, int Cin, int KH, int KW, int CinPad,
                                         int kh0, int kw0, int step, int Th, int Tw, void* stream) {
     if (!w || !dst || Cout < 1 || Cin < 1 || KH < 1 || KW < 1 || CinPad < Cin || step < 1 || Th < 1 || Tw < 1 ||

@@ -341,18 +341,26 @@ def _pdiff(a, b):
 # backward stage (torch.autograd.grad hands the gradients back untouched); plain loss.backward() must not use it, because
 # AccumulateGrad may add a gradient into an existing .grad immediately.
 _DEFERRED = None
+_DEFERRED_LN = None         # same for the LayerNorm parameter gradients (rih_ln_param_final_multi)
 
 
 class deferred_reductions:
     def __enter__(self):
-        global _DEFERRED
+        global _DEFERRED, _DEFERRED_LN
         assert _DEFERRED is None, 'deferred_reductions does not nest'
-        _DEFERRED = []
+        _DEFERRED, _DEFERRED_LN = [], []
         return self
 
     def __exit__(self, et, ev, tb):
-        global _DEFERRED
+        global _DEFERRED, _DEFERRED_LN
         pending, _DEFERRED = _DEFERRED, None
+        ln, _DEFERRED_LN = _DEFERRED_LN, None
+        if et is None and ln:
+            from ._lib import LnFinalDesc
+            arr = (LnFinalDesc * len(ln))()
+            for d, (_, ws, _, dg, _, db, D, nblk) in zip(arr, ln):
+                d.ws, d.dg, d.db, d.D, d.nblk = ws, dg, db, D, nblk
+            check(_L().rih_ln_param_final_multi(arr, len(ln), _stream()), 'rih_ln_param_final_multi')
         if et is None and pending:
             from ._lib import ReduceDesc
             arr = (ReduceDesc * len(pending))()
@@ -433,6 +441,63 @@ def colsum(x2d, rows, Ccols, ldx=None):
 
 
 # --------------------------------------------------------------------------------------------- conv / linear
+class PackCache:
+    """Packed weight operands of a training step (k > 1 convolutions: forward [(tap, ci)][co] and flipped data-gradient
+    operands), kept in persistent buffers and refreshed by ONE rih_pack_conv_weight_multi launch at the start of the step
+    (`refresh()`) instead of one ~6 us launch in front of every such GEMM (58 per ResNet50 step).  renderih_amd.train.TrainStep
+    installs it around its step (`ops._PACK`); a request the cache has not seen is packed on the spot and joins the next
+    refresh.  Valid while the weights do not change between refresh() and the last use -- one optimizer step per refresh."""
+
+    def __init__(self):
+        self.entries = {}       # key -> (weight tensor, packed tensor, descriptor fields)
+        self.fresh = False
+
+    def refresh(self):
+        if self.entries:
+            from ._lib import PackDesc
+            arr = (PackDesc * len(self.entries))()
+            for d, (w, dst, f) in zip(arr, self.entries.values()):
+                d.w, d.dst = w.data_ptr(), dst.data_ptr()
+                (d.Cout, d.Cin, d.KH, d.KW, d.CinPad, d.mode, d.kh0, d.kw0, d.step, d.Th, d.Tw) = f
+            check(_L().rih_pack_conv_weight_multi(arr, len(self.entries), _stream()), 'rih_pack_conv_weight_multi')
+        self.fresh = True
+
+    def stale(self):
+        self.fresh = False
+
+
+_PACK = None
+
+
+def _packed_weight(w, Cx, for_dgrad, sub=None, out=None):
+    """Weight operand of an OIHW convolution weight: forward [(tap, ci)][co] (for_dgrad False) or the flipped data-gradient
+    operand of the tap subset `sub` = (kh0, kw0, step, Th, Tw) [((th, tw), co)][ci].  Through ops._PACK when one is installed."""
+    Cout, Cin, KH, KW = w.shape
+    kh0, kw0, step, Th, Tw = sub if sub is not None else (0, 0, 1, KH, KW)
+    shape = (KH * KW * Cx, Cout) if not for_dgrad else (Th * Tw * Cout, Cx)
+    pc = _PACK if out is None else None
+    if pc is not None:
+        # the entry holds a reference to the weight's storage, so the address cannot come back as another tensor
+        key = (w.data_ptr(), Cout, Cin, KH, KW, Cx, bool(for_dgrad), kh0, kw0, step, Th, Tw)
+        e = pc.entries.get(key)
+        if e is not None and pc.fresh:
+            return e[1]
+        if e is None:
+            dst = torch.empty(shape, device=w.device, dtype=torch.float32)
+            pc.entries[key] = (w.detach(), dst, (Cout, Cin, KH, KW, Cx, 1 if for_dgrad else 0, kh0, kw0, step, Th, Tw))
+        else:
+            dst = e[1]
+    else:
+        dst = out if out is not None else torch.empty(shape, device=w.device, dtype=torch.float32)
+    if not for_dgrad:
+        check(_L().rih_pack_conv_weight(w.data_ptr(), dst.data_ptr(), Cout, Cin, KH, KW, Cx, 0, _stream()),
+              'rih_pack_conv_weight')
+    else:
+        check(_L().rih_pack_conv_weight_sub(w.data_ptr(), dst.data_ptr(), Cout, Cin, KH, KW, Cx, kh0, kw0, step, Th, Tw,
+                                            _stream()), 'rih_pack_conv_weight_sub')
+    return dst
+
+
 class Conv2dFn(torch.autograd.Function):
     """NHWC conv2d (+bias, +ReLU epilogue) = implicit GEMM on the fp32 MFMA pipe.
     x: [N,H,W,Cx] (Cx >= Cin, extra channels must be zero), w: [Cout,Cin,KH,KW] (the nn.Conv2d parameter)."""
@@ -462,9 +527,7 @@ class Conv2dFn(torch.autograd.Function):
         elif KH * KW == 1 and Cx == Cin:
             gemm(x, w, y, M, Cout, K, Cx, Cin, Cout, a_mode=0, b_mode=1, bias=bias, relu=relu, geom=geom)
         else:
-            wp = torch.empty((K, Cout), device=x.device, dtype=torch.float32)
-            check(_L().rih_pack_conv_weight(w.data_ptr(), wp.data_ptr(), Cout, Cin, KH, KW, Cx, 0, _stream()),
-                  'rih_pack_conv_weight')
+            wp = _packed_weight(w, Cx, False)
             gemm(x, wp, y, M, Cout, K, Cx, Cout, Cout, a_mode=0, b_mode=0, bias=bias, relu=relu, geom=geom)
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.cfg = (stride, pad, relu, bias is not None)
@@ -523,9 +586,7 @@ class Conv2dFn(torch.autograd.Function):
                 if KH * KW == 1 and Cx == Cin:
                     wd = w
                 else:
-                    wd = torch.empty((Th * Tw * Cout, Cx), device=x.device, dtype=torch.float32)
-                    check(lib.rih_pack_conv_weight_sub(w.data_ptr(), wd.data_ptr(), Cout, Cin, KH, KW, Cx, kh0, kw0,
-                                                       stride, Th, Tw, _stream()), 'rih_pack_conv_weight_sub')
+                    wd = _packed_weight(w, Cx, True, (kh0, kw0, stride, Th, Tw))
                 gemm(dy, wd, dx, N * Hc * Wc, Cx, Th * Tw * Cout, Cout, Cx, Cx, a_mode=0, b_mode=0, geom=geom,
                      cstride=(stride, oh, ow, H, W_))
             if dskip is not None:
@@ -544,9 +605,7 @@ class Conv2dFn(torch.autograd.Function):
             elif KH * KW == 1 and Cx == Cin:
                 gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cin, Cx, a_mode=0, b_mode=0, geom=geom, R=dskip, ldr=Cx)
             else:
-                wd = torch.empty((KH * KW * Cout, Cx), device=x.device, dtype=torch.float32)
-                check(lib.rih_pack_conv_weight(w.data_ptr(), wd.data_ptr(), Cout, Cin, KH, KW, Cx, 1, _stream()),
-                      'rih_pack_conv_weight')
+                wd = _packed_weight(w, Cx, True)
                 gemm(dy, wd, dx, Mx, Cx, KH * KW * Cout, Cout, Cx, Cx, a_mode=0, b_mode=0, geom=geom, R=dskip, ldr=Cx)
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
@@ -732,8 +791,7 @@ class PatchConvPairFn(torch.autograd.Function):
         M, K = N * g_h * g_w, KH * KW * Cx
         wp = torch.empty((2, K, Cout), device=x.device, dtype=torch.float32)
         for h, w in enumerate((wL, wR)):
-            check(_L().rih_pack_conv_weight(w.data_ptr(), wp[h].data_ptr(), Cout, Cin, KH, KW, Cx, 0, _stream()),
-                  'rih_pack_conv_weight')
+            _packed_weight(w, Cx, False, out=wp[h])         # two operands of one strided GEMM: packed in place
         y = torch.empty((2, N, g_h, g_w, Cout), device=x.device, dtype=torch.float32)
         geom = (H, W_, Cx, g_h, g_w, KH, KW, KH, 1, 0, 0)
         tile = plan_gemm(M, Cout, K, 2)[0]
@@ -1056,10 +1114,15 @@ class LayerNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg = torch.empty_like(g)
         db = torch.empty_like(g)
-        ws = torch.empty((2 * lib.rih_ln_nblk(rows) * D,), device=x.device, dtype=torch.float32)
+        nblk = lib.rih_ln_nblk(rows)
+        ws = torch.empty((2 * nblk * D,), device=x.device, dtype=torch.float32)
+        defer = _DEFERRED is not None
         check(lib.rih_layernorm_bwd(dy.data_ptr(), x.data_ptr(), _p(x2), _p(y), g.data_ptr(), mean.data_ptr(),
-                                    rstd.data_ptr(), _p(dskip), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, D,
-                                    1 if ctx.relu else 0, ws.data_ptr(), _stream()), 'rih_layernorm_bwd')
+                                    rstd.data_ptr(), _p(dskip), dx.data_ptr(), 0 if defer else dg.data_ptr(),
+                                    0 if defer else db.data_ptr(), rows, D, 1 if ctx.relu else 0, ws.data_ptr(), _stream()),
+              'rih_layernorm_bwd')
+        if defer:
+            _DEFERRED_LN.append((ws, ws.data_ptr(), dg, dg.data_ptr(), db, db.data_ptr(), D, nblk))
         return dx, (dx if x2 is not None else None), dg, db, None, None, None
 
 
@@ -1108,11 +1171,17 @@ class LayerNormPairFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg = torch.empty((2, D), device=x.device, dtype=torch.float32)
         db = torch.empty((2, D), device=x.device, dtype=torch.float32)
-        ws = torch.empty((2 * 2 * lib.rih_ln_nblk(rows) * D,), device=x.device, dtype=torch.float32)
+        nblk = lib.rih_ln_nblk(rows)
+        ws = torch.empty((2 * 2 * nblk * D,), device=x.device, dtype=torch.float32)
+        defer = _DEFERRED is not None
         check(lib.rih_layernorm_bwd_grouped(dy.data_ptr(), x.data_ptr(), _p(x2), _p(y), gL.data_ptr(), mean.data_ptr(),
-                                            rstd.data_ptr(), _p(dskip), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), 2,
-                                            rows, D, _pdiff(gL, gR), 1 if ctx.relu else 0, ws.data_ptr(), _stream()),
-              'rih_layernorm_bwd_grouped')
+                                            rstd.data_ptr(), _p(dskip), dx.data_ptr(), 0 if defer else dg.data_ptr(),
+                                            0 if defer else db.data_ptr(), 2, rows, D, _pdiff(gL, gR),
+                                            1 if ctx.relu else 0, ws.data_ptr(), _stream()), 'rih_layernorm_bwd_grouped')
+        if defer:
+            for h in (0, 1):
+                _DEFERRED_LN.append((ws, ws.data_ptr() + 4 * h * nblk * 2 * D, dg, dg.data_ptr() + 4 * h * D, db,
+                                     db.data_ptr() + 4 * h * D, D, nblk))
         return dx, (dx if x2 is not None else None), dg[0], dg[1], db[0], db[1], None, None, None
 
 

@@ -19,6 +19,9 @@ What it does that the plain loop does not:
 * **Batched split-K reductions.**  The partial slabs of a stage's weight gradients are summed by one launch per 60
   gradients at the end of the stage (`ops.deferred_reductions`, `rih_splitk_reduce_multi`) instead of 157 small launches per
   step, each of which costs a dependent-kernel slot (>= 4.5 us on this platform) whatever its size.
+* **One weight-packing launch.**  The forward and data-gradient operand layouts of every k > 1 convolution are produced by one
+  `rih_pack_conv_weight_multi` launch at the start of the step into persistent buffers (`ops.PackCache`) instead of 58 small
+  launches in front of their GEMMs.
 * **hipGraph replay.**  Forward + loss + stage-1 backward, stage 2 and stage 3 are captured as three graphs sharing one
   memory pool and replayed back to back; the collectives stay eager between the replays (no dependence on RCCL's capture
   support), so the host cost per step is three graph launches + three collectives + one fused optimizer launch instead of
@@ -75,6 +78,7 @@ class TrainStep:
         import os
         self.side_wgrad = (os.environ.get('RIH_SIDE_WGRAD', '0') == '1') if side_wgrad is None else bool(side_wgrad)
         self.defer_reduce = (os.environ.get('RIH_DEFER_REDUCE', '1') == '1') if defer_reduce is None else bool(defer_reduce)
+        self.packs = ops.PackCache() if os.environ.get('RIH_PACK_CACHE', '1') == '1' else None
         self.exchange = self.world > 1 or (force_exchange and dist.is_available() and dist.is_initialized())
         self.overlap = overlap and self.exchange
         self.img, self.labels = example_batch
@@ -125,6 +129,11 @@ class TrainStep:
 
     def _forward_loss(self):
         self._bounds = self._cut = None
+        if self.packs is not None:
+            # every packed weight operand the step needs (forward and data-gradient layouts of the k > 1 convolutions) in one
+            # launch, before the first kernel of the forward pass; the per-call packs then find them ready (ops.PackCache)
+            ops._PACK = self.packs
+            self.packs.refresh()
         self._cutting = True
         try:
             out = self.model(self.img)
@@ -208,8 +217,33 @@ class TrainStep:
         return None
 
     # ------------------------------------------------------------------ eager step
+    def _shared_parameters(self, roots):
+        """Parameters that enter the autograd graph more than once (weight sharing).  Their gradient is the SUM of two
+        contributions, which autograd forms during the backward pass -- i.e. it would read a deferred reduction early."""
+        seen, uses, stack = set(), {}, [r.grad_fn for r in roots if r is not None and r.grad_fn is not None]
+        while stack:
+            fn = stack.pop()
+            if id(fn) in seen:
+                continue
+            seen.add(id(fn))
+            for nxt, _ in fn.next_functions:
+                if nxt is None:
+                    continue
+                if hasattr(nxt, 'variable'):            # AccumulateGrad: one incoming edge per use of the parameter
+                    uses[id(nxt)] = uses.get(id(nxt), 0) + 1
+                else:
+                    stack.append(nxt)
+        return sum(1 for n in uses.values() if n > 1)
+
     def _step_eager(self):
         loss = self._forward_loss()
+        if self.defer_reduce and self.live is None:
+            shared = self._shared_parameters([loss] + list(self._bounds or ()))
+            if shared:
+                import warnings
+                warnings.warn('TrainStep: %d parameters are used more than once in the forward pass; the batched split-K / '
+                              'LayerNorm reductions (defer_reduce) are turned off for this model' % shared)
+                self.defer_reduce = False
         carry, per_stage = None, []
         for i in range(self.nstage):
             if self.order is not None:
@@ -226,6 +260,9 @@ class TrainStep:
         return loss.detach()
 
     def _finish(self):
+        if self.packs is not None:      # the optimizer is about to change the weights: nothing may use the packed copies now
+            self.packs.stale()
+            ops._PACK = None
         if self.cuda and self.exchange and self.overlap:
             self._e_bwd = torch.cuda.Event(enable_timing=True)
             self._e_comm = torch.cuda.Event(enable_timing=True)
@@ -272,6 +309,9 @@ class TrainStep:
                 self.graphs.append(gph)
                 self.static.append(grads)
             self._static_loss = loss.detach()
+        if self.packs is not None:
+            self.packs.stale()
+            ops._PACK = None
         torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
         for i, grads in enumerate(self.static):

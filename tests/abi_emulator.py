@@ -264,6 +264,16 @@ class EmulatedLib:
         _f(Cp, (M - 1) * ldc + N)[(cm * ldc + cn).ravel()] = out.astype(np.float32).ravel()
         return 0
 
+    def rih_pack_conv_weight_multi(self, descs, n, stream):
+        for i in range(n):
+            d = descs[i]
+            if d.mode == 0:
+                self.rih_pack_conv_weight(d.w, d.dst, d.Cout, d.Cin, d.KH, d.KW, d.CinPad, 0, stream)
+            else:
+                self.rih_pack_conv_weight_sub(d.w, d.dst, d.Cout, d.Cin, d.KH, d.KW, d.CinPad, d.kh0, d.kw0, d.step, d.Th,
+                                              d.Tw, stream)
+        return 0
+
     def rih_pack_conv_weight(self, w, dst, Cout, Cin, KH, KW, CinPad, for_dgrad, stream):
         W = _f(w, Cout * Cin * KH * KW).reshape(Cout, Cin, KH * KW)
         Wp = np.zeros((Cout, CinPad, KH * KW), np.float32)
@@ -907,7 +917,16 @@ class EmulatedLib:
             o = 4 * q * rows * D
             self.rih_layernorm_bwd(dy + o, x + o, x2 + o if x2 else 0, y + o if y else 0, g + 4 * q * sG,
                                    mean + 4 * q * rows, rstd + 4 * q * rows, dres + o if dres else 0, dx + o,
-                                   dg + 4 * q * D, db + 4 * q * D, rows, D, relu, ws, stream)
+                                   dg + 4 * q * D if dg else 0, db + 4 * q * D if db else 0, rows, D, relu,
+                                   ws + 4 * q * self.rih_ln_nblk(rows) * 2 * D, stream)
+        return 0
+
+    def rih_ln_param_final_multi(self, descs, n, stream):
+        for i in range(n):
+            d = descs[i]
+            w = _f(d.ws, d.nblk * 2 * d.D).reshape(d.nblk, 2, d.D)
+            _f(d.dg, d.D)[:] = w[:, 0].sum(0)
+            _f(d.db, d.D)[:] = w[:, 1].sum(0)
         return 0
 
     def rih_layernorm_bwd(self, dy, x, x2, y, g, mean, rstd, dres, dx, dg, db, rows, D, relu, ws, stream):
@@ -925,8 +944,13 @@ class EmulatedLib:
         if dres:
             out = out + _f(dres, rows * D).reshape(rows, D)
         _f(dx, rows * D)[:] = out.ravel()
-        _f(dg, D)[:] = (Dy * xh).sum(0)
-        _f(db, D)[:] = Dy.sum(0)
+        if dg:
+            _f(dg, D)[:] = (Dy * xh).sum(0)
+            _f(db, D)[:] = Dy.sum(0)
+        else:       # deferred: partials [nblk][2][D] for rih_ln_param_final_multi (everything in block 0)
+            w = _f(ws, self.rih_ln_nblk(rows) * 2 * D).reshape(-1, 2, D)
+            w[:] = 0
+            w[0, 0], w[0, 1] = (Dy * xh).sum(0), Dy.sum(0)
         return 0
 
     def rih_softmax_fwd(self, S, P, Pd, rows, cols, ld, drop_p, seed, seed_dev, stream):

@@ -55,6 +55,7 @@ def test_paired_layers_host_logic():
     G.test_patch_conv_pair(3, 8, 32, 48, 1)
     G.test_patch_conv_pair(2, 16, 64, 48, 4)
     G.test_deferred_reductions_equal_immediate()
+    G.test_pack_cache_one_launch_equals_per_call_packs()
     G.test_adam_one_launch_matches_torch(False, 1e-2)
     G.test_adam_one_launch_matches_torch(True, 1e-2)
     G.test_cross_attention_stacked_and_rows_pair()

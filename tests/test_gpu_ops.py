@@ -560,19 +560,24 @@ def test_deferred_reductions_equal_immediate():
     xl = rnd(2, 5, 70, 40, seed=5).to(d)
     wl, bl = rnd(2, 36, 40, seed=6, scale=0.2).to(d).requires_grad_(True), rnd(2, 36, seed=7).to(d).requires_grad_(True)
     wm = [rnd(20, 40, seed=8 + i, scale=0.2).to(d).requires_grad_(True) for i in range(64)]
+    lns = [((rnd(40, seed=90 + i) + 1).to(d).requires_grad_(True), rnd(40, seed=95 + i).to(d).requires_grad_(True))
+           for i in range(5)]              # LayerNorm parameter gradients ride in the same deferral (rih_ln_param_final_multi)
 
     def loss():
         t = sum(ops.conv2d(x, w, b, stride=s, pad=p).sum() * (i + 1) for i, (w, b, s, p) in enumerate(ws))
         t = t + (ops.LinearPairFn.apply(xl, wl, None, bl, None, None, False) ** 2).sum()
         for i, w in enumerate(wm):
             t = t + (ops.linear(xl[0], w) * (0.5 + i)).sum()
+        for i, (g, b) in enumerate(lns[:3]):            # (every parameter is used ONCE: autograd must not sum two uses early)
+            t = t + (ops.layernorm(xl[1], g, b) * (1 + i)).sum()
+        t = t + (ops.LayerNormPairFn.apply(xl, None, lns[3][0], lns[4][0], lns[3][1], lns[4][1], 1e-6, True, False) ** 2).sum()
         return t
 
-    params = [w for w, _, _, _ in ws] + [ws[0][1], wl, bl] + wm
+    params = [w for w, _, _, _ in ws] + [ws[0][1], wl, bl] + wm + [p for gb in lns for p in gb]
     want = torch.autograd.grad([loss()], params)
     with ops.deferred_reductions():
         got = torch.autograd.grad([loss()], params)
-    assert ops._DEFERRED is None
+    assert ops._DEFERRED is None and ops._DEFERRED_LN is None
     for a, b in zip(got, want):
         assert bool(torch.isfinite(b).all()) and torch.equal(a, b)
 
@@ -662,3 +667,45 @@ def test_cross_attention_stacked_and_rows_pair():
     assert_close(xg.grad, xr.grad, 1e-5, 1e-6, 'add_rows_pair dx')
     assert_close(el.grad, er.grad[0], 1e-4, 1e-5, 'add_rows_pair de0')
     assert_close(er_.grad, er.grad[1], 1e-4, 1e-5, 'add_rows_pair de1')
+
+
+def test_pack_cache_one_launch_equals_per_call_packs():
+    """ops.PackCache (rih_pack_conv_weight_multi): after the recording pass, refresh() repacks every operand in one launch
+    from the CURRENT weights, and the convolutions (forward, strided and dense data gradients) give bit-identical results to
+    the per-call packs; a weight update between steps is picked up by the next refresh."""
+    from renderih_amd import ops
+    d = dev()
+    x = nhwc(rnd(2, 8, 13, 11, seed=1)).to(d).requires_grad_(True)
+    ws = [rnd(16, 8, 3, 3, seed=2, scale=0.2).to(d).requires_grad_(True), rnd(12, 16, 3, 3, seed=3, scale=0.2).to(d).requires_grad_(True),
+          rnd(8, 12, 2, 2, seed=4, scale=0.3).to(d).requires_grad_(True)]
+
+    def run():
+        h = ops.conv2d(x, ws[0], None, stride=1, pad=1)
+        h = ops.conv2d(h, ws[1], None, stride=2, pad=1)
+        h = ops.conv2d(h, ws[2], None, stride=2, pad=0)
+        return [h] + list(torch.autograd.grad([(h * h).sum()], [x] + ws))
+
+    want = run()
+    pc = ops.PackCache()
+    try:
+        ops._PACK = pc
+        first = run()                       # recording pass: packs on the spot
+        assert len(pc.entries) >= 5         # 3 forward operands + the dense and the parity-class data-gradient operands
+        pc.refresh()
+        second = run()                      # everything from the one-launch refresh
+        with torch.no_grad():
+            for w in ws:
+                w.mul_(1.5)
+        pc.stale()
+        ops._PACK = None
+        want2 = run()
+        ops._PACK = pc
+        pc.refresh()
+        third = run()
+    finally:
+        ops._PACK = None
+    for a, b, c in zip(want, first, second):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    for a, b in zip(want2, third):
+        assert torch.equal(a, b)
+    assert not torch.equal(want[0], want2[0])

@@ -64,6 +64,7 @@ def test_paired_layer_kernels():
     G.test_patch_conv_pair(2, 8, 32, 16, 2)
     G.test_patch_conv_pair(1, 16, 64, 48, 4)                    # K = 1024: forward split-K + finish
     G.test_deferred_reductions_equal_immediate()
+    G.test_pack_cache_one_launch_equals_per_call_packs()
     G.test_adam_one_launch_matches_torch(False, 1e-2)
     G.test_adam_one_launch_matches_torch(True, 1e-2)
 
