@@ -220,17 +220,22 @@ class TrainStep:
     def _shared_parameters(self, roots):
         """Parameters that enter the autograd graph more than once (weight sharing).  Their gradient is the SUM of two
         contributions, which autograd forms during the backward pass -- i.e. it would read a deferred reduction early."""
-        seen, uses, stack = set(), {}, [r.grad_fn for r in roots if r is not None and r.grad_fn is not None]
+        params = {id(p) for g in self.groups for p in g}      # (the detached trunk maps are leaves too, and used many times)
+        stack = [r.grad_fn for r in roots if r is not None and r.grad_fn is not None]
+        seen, uses, keep = set(), {}, []        # `keep`: the node wrappers are temporaries -- their id() is only unique alive
         while stack:
             fn = stack.pop()
             if id(fn) in seen:
                 continue
             seen.add(id(fn))
+            keep.append(fn)
             for nxt, _ in fn.next_functions:
                 if nxt is None:
                     continue
                 if hasattr(nxt, 'variable'):            # AccumulateGrad: one incoming edge per use of the parameter
-                    uses[id(nxt)] = uses.get(id(nxt), 0) + 1
+                    v = nxt.variable
+                    if id(v) in params:
+                        uses[id(v)] = uses.get(id(v), 0) + 1
                 else:
                     stack.append(nxt)
         return sum(1 for n in uses.values() if n > 1)

@@ -414,7 +414,7 @@ def test_train_step_staged_graph_replay_matches_plain_backward():
     opt = torch.optim.SGD([p for p in m2.parameters() if p.requires_grad], lr=0.0)      # lr 0: the state stays put
     try:
         step = TrainStep(m2, opt, lambda out, lab: scalar_loss(out), (img.clone(), {}), process_group=False)
-        assert step.use_graph and step.nstage == 3
+        assert step.use_graph and step.nstage == 3 and step.defer_reduce and step.packs is not None
         for rep in range(2):
             loss = step(img, {})
             assert bool(torch.isfinite(loss))

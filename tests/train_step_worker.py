@@ -47,6 +47,7 @@ def main():
         before = {k: p.detach().clone() for k, p in m.named_parameters()}
         loss = step(img, {})
         assert torch.isfinite(loss)
+        assert step.defer_reduce, 'the batched reductions were switched off: the shared-parameter guard misfired'
         # first call learns the live set, then reduces in stage order; the second call interleaves
         order.clear()
         for k, p in m.named_parameters():
