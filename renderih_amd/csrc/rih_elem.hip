@@ -1372,6 +1372,103 @@ __global__ __launch_bounds__(TPB) void cheby_bwd_lds_kernel(const float* __restr
     }
 }
 
+// ---- 16-byte softmax kernels (cols % 4 == 0, ld % 4 == 0: the 316-token attention of the finest mesh level, 64 / 256-token
+// ones): a lane owns column quads 4*lane + 256*i.  Same hash index per element as the scalar kernels (identical masks).
+template <int NV>
+__global__ __launch_bounds__(TPB) void softmax_fwd_vec_kernel(const float* __restrict__ S, float* __restrict__ P,
+                                                              float* __restrict__ Pd, long long rows, int cols, int ld,
+                                                              float drop_p, uint64_t seed,
+                                                              const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev != nullptr) seed += *seed_dev;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t thr = drop_thresh(drop_p);
+    const float keep_scale = (drop_p > 0.f) ? 1.f / (1.f - drop_p) : 1.f;
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
+        float4 v[NV];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * lane + 256 * i;
+            v[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            if (c < cols) {
+                v[i] = *reinterpret_cast<const float4*>(S + r * ld + c);
+                mx = fmaxf(mx, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+            }
+        }
+        mx = wave_max(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (4 * lane + 256 * i < cols) {
+                v[i].x = expf(v[i].x - mx); v[i].y = expf(v[i].y - mx); v[i].z = expf(v[i].z - mx); v[i].w = expf(v[i].w - mx);
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            }
+        }
+        s = wave_sum(s);
+        const float inv = 1.f / s;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * lane + 256 * i;
+            if (c < cols) {
+                const float4 pr = make_float4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+                *reinterpret_cast<float4*>(P + r * ld + c) = pr;
+                if (drop_p > 0.f) {
+                    const uint64_t base = (uint64_t)(r * cols + c);
+                    float4 o;
+                    o.x = rih_hash(seed, base) >= thr ? pr.x * keep_scale : 0.f;
+                    o.y = rih_hash(seed, base + 1) >= thr ? pr.y * keep_scale : 0.f;
+                    o.z = rih_hash(seed, base + 2) >= thr ? pr.z * keep_scale : 0.f;
+                    o.w = rih_hash(seed, base + 3) >= thr ? pr.w * keep_scale : 0.f;
+                    *reinterpret_cast<float4*>(Pd + r * ld + c) = o;
+                } else if (Pd != P) {
+                    *reinterpret_cast<float4*>(Pd + r * ld + c) = pr;
+                }
+            }
+        }
+    }
+}
+template <int NV>
+__global__ __launch_bounds__(TPB) void softmax_bwd_vec_kernel(const float* __restrict__ P, float* __restrict__ dPd,
+                                                              long long rows, int cols, int ld, float drop_p, uint64_t seed,
+                                                              const uint64_t* __restrict__ seed_dev, float alpha) {
+    if (seed_dev != nullptr) seed += *seed_dev;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t thr = drop_thresh(drop_p);
+    const float keep_scale = (drop_p > 0.f) ? 1.f / (1.f - drop_p) : 1.f;
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
+        float4 pv[NV], dp[NV];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * lane + 256 * i;
+            pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            dp[i] = pv[i];
+            if (c < cols) {
+                pv[i] = *reinterpret_cast<const float4*>(P + r * ld + c);
+                float4 d = *reinterpret_cast<const float4*>(dPd + r * ld + c);
+                if (drop_p > 0.f) {
+                    const uint64_t base = (uint64_t)(r * cols + c);
+                    d.x = rih_hash(seed, base) >= thr ? d.x * keep_scale : 0.f;
+                    d.y = rih_hash(seed, base + 1) >= thr ? d.y * keep_scale : 0.f;
+                    d.z = rih_hash(seed, base + 2) >= thr ? d.z * keep_scale : 0.f;
+                    d.w = rih_hash(seed, base + 3) >= thr ? d.w * keep_scale : 0.f;
+                }
+                dp[i] = d;
+                dot += (d.x * pv[i].x + d.y * pv[i].y) + (d.z * pv[i].z + d.w * pv[i].w);
+            }
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * lane + 256 * i;
+            if (c < cols)
+                *reinterpret_cast<float4*>(dPd + r * ld + c) =
+                    make_float4(alpha * pv[i].x * (dp[i].x - dot), alpha * pv[i].y * (dp[i].y - dot),
+                                alpha * pv[i].z * (dp[i].z - dot), alpha * pv[i].w * (dp[i].w - dot));
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ optimizer
 // Adam / AdamW over a TABLE of parameter tensors in one launch.  A block owns one 4096-element chunk of one tensor
 // (blk_tensor / blk_chunk); 16-byte accesses when the tensor's four pointers allow.  The step is HBM-bound: 4 reads
@@ -1656,8 +1753,16 @@ extern "C" int rih_softmax_fwd(const float* S, float* P, float* Pd, int64_t rows
     if (drop_p > 0.f && Pd == P) return RIH_EINVAL;
     long long blocks = (rows + 3) / 4;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((int)blocks), dim3(TPB), 0, STREAM, S, P, Pd, (long long)rows, cols, ld,
-                       drop_p, seed, seed_dev);
+    const bool vec = cols % 4 == 0 && ld % 4 == 0 && al16(S) && al16(P) && al16(Pd);
+#define RIH_SM(NV_) hipLaunchKernelGGL(softmax_fwd_vec_kernel<NV_>, dim3((int)blocks), dim3(TPB), 0, STREAM, S, P, Pd, \
+                                       (long long)rows, cols, ld, drop_p, seed, seed_dev)
+    if (vec && cols <= 256) RIH_SM(1);
+    else if (vec && cols <= 512) RIH_SM(2);
+    else if (vec) RIH_SM(4);
+    else
+        hipLaunchKernelGGL(softmax_fwd_kernel, dim3((int)blocks), dim3(TPB), 0, STREAM, S, P, Pd, (long long)rows, cols, ld,
+                           drop_p, seed, seed_dev);
+#undef RIH_SM
     LAUNCH_RET();
 }
 extern "C" int rih_softmax_bwd(const float* P, float* dPd, int64_t rows, int cols, int ld, float drop_p, uint64_t seed,
@@ -1666,8 +1771,16 @@ extern "C" int rih_softmax_bwd(const float* P, float* dPd, int64_t rows, int col
     if (drop_p < 0.f || drop_p >= 1.f) return RIH_EINVAL;
     long long blocks = (rows + 3) / 4;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((int)blocks), dim3(TPB), 0, STREAM, P, dPd, (long long)rows, cols, ld,
-                       drop_p, seed, seed_dev, alpha);
+    const bool vec = cols % 4 == 0 && ld % 4 == 0 && al16(P) && al16(dPd);
+#define RIH_SM(NV_) hipLaunchKernelGGL(softmax_bwd_vec_kernel<NV_>, dim3((int)blocks), dim3(TPB), 0, STREAM, P, dPd,   \
+                                       (long long)rows, cols, ld, drop_p, seed, seed_dev, alpha)
+    if (vec && cols <= 256) RIH_SM(1);
+    else if (vec && cols <= 512) RIH_SM(2);
+    else if (vec) RIH_SM(4);
+    else
+        hipLaunchKernelGGL(softmax_bwd_kernel, dim3((int)blocks), dim3(TPB), 0, STREAM, P, dPd, (long long)rows, cols, ld,
+                           drop_p, seed, seed_dev, alpha);
+#undef RIH_SM
     LAUNCH_RET();
 }
 

@@ -81,6 +81,7 @@ def test_norm_softmax_attention_kernels():
     G.test_layernorm_pair(67, 64, True, False, True)
     G.test_layernorm_pair(40, 64, False, True, False)
     G.test_attention(2, 63, 63, 64, 4)
+    G.test_attention(1, 316, 316, 64, 4)            # 16-byte softmax kernels, two column quads per lane
     G.test_attention_dropout_matches_hash_mask()
     G.test_self_attention_packed(2, 40, 64, 4)
     G.test_add_dropout_and_bcast()

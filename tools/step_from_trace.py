@@ -1,11 +1,14 @@
 #!/usr/bin/env python
 """Cut ONE hipGraph replay of the training step out of a rocprofv3 kernel trace (CSV) and summarise it: per-kernel launches,
-total / average duration, and the idle time between consecutive kernels (the step boundary is the single maxpool_fwd launch).
-    python tools/step_from_trace.py trace.csv [--top 60]"""
+total / average duration, and the idle time between consecutive kernels (the step boundary is a kernel launched once per step:
+maxpool_fwd for the ResNet trunk, --mark NAME otherwise).
+    python tools/step_from_trace.py trace.csv [--top 60] [--mark nchw_to_nhwc]"""
 import collections
 import csv
 import re
 import sys
+
+MARK = 'maxpool_fwd'
 
 
 def short(n):
@@ -17,9 +20,11 @@ def short(n):
 def main():
     path = sys.argv[1]
     top = int(sys.argv[sys.argv.index('--top') + 1]) if '--top' in sys.argv else 60
+    global MARK
+    MARK = sys.argv[sys.argv.index('--mark') + 1] if '--mark' in sys.argv else 'maxpool_fwd'
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    marks = [i for i, r in enumerate(rows) if 'maxpool_fwd' in r['Kernel_Name']]
+    marks = [i for i, r in enumerate(rows) if MARK in r["Kernel_Name"]]
     a, b = marks[-2], marks[-1]           # the last complete step (a replay: the eager steps come first)
     step = rows[a:b]
     t0, t1 = int(step[0]['Start_Timestamp']), int(rows[b]['Start_Timestamp'])
