@@ -359,6 +359,7 @@ constexpr int FUSED_LDS_FLOATS = KP * 192 + HC * LDPF + HC * GST + HC * SCR + 52
 static_assert(FUSED_LDS_FLOATS * 4 <= 163840, "LDS budget");
 static_assert(HC * 192 <= HC * SCR, "the v_tpose tile aliases the phase-1 scratch");
 
+template <bool HM>
 __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* __restrict__ pk,
                                                          const float* __restrict__ root, const float* __restrict__ pose,
                                                          int ncomp, const float* __restrict__ shape,
@@ -375,18 +376,27 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
     float* s_scr = s_G + HC * GST;              // [HC][SCR] phase-1 scratch, later [HC][192] v_tpose tile
     float* s_J = s_scr + HC * SCR;              // Jt[48] | Js[480]: the joint regressor folded onto template / shape basis
     int* s_depth = reinterpret_cast<int*>(s_J + 528);      // tree depth of the 16 joints, [16] = maximum
-    const int tile = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int v0 = tile * TILE_V, n0 = tile * 192;
+    // Two workgroup shapes.  !HM (small batches): workgroup = (vertex tile blockIdx.x, group of hand chunks blockIdx.y), the
+    // basis tile pinned once; the per-hand pose work of a chunk is repeated by each of the 13 tiles (47 % of a workgroup's
+    // cycles, profiles/r02/mano_phases_m8.log).  HM (hand-chunk major, >= 256 chunks): workgroup = group of hand chunks, pose
+    // work once per chunk, then the 13 basis tiles are streamed through the same LDS buffer from L2 (1.46 MB, L2-resident).
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tile_fixed = HM ? 0 : (int)blockIdx.x;
     // does this workgroup need the 13 special vertices (tips / new_skel)?  Tile 0 writes the joints; every tile needs the
     // centre joint, which is a tip when new_order[center] >= 16.
     const bool centre_is_tip = center_idx >= 0 && c_new_order[center_idx] >= 16;
-    const bool need_special = (tile == 0) || centre_is_tip;
+    const bool first_tile = HM || tile_fixed == 0;        // this workgroup writes the joints / joint-side workspace
+    const bool need_special = first_tile || centre_is_tip;
 
-    // pin the basis tile: rows are 192 contiguous floats of Bmat
-    for (int i = t; i < KP * 48; i += 256) {
-        const int k = i / 48, q = i - k * 48;
-        *reinterpret_cast<float4*>(s_B + k * 192 + 4 * q) = *reinterpret_cast<const float4*>(pk + (long long)k * NCP + n0 + 4 * q);
-    }
+    // the basis tile: rows are 192 contiguous floats of Bmat
+    auto load_basis = [&](int tile) {
+        const int n0 = tile * 192;
+        for (int i = t; i < KP * 48; i += 256) {
+            const int k = i / 48, q = i - k * 48;
+            *reinterpret_cast<float4*>(s_B + k * 192 + 4 * q) = *reinterpret_cast<const float4*>(pk + (long long)k * NCP + n0 + 4 * q);
+        }
+    };
+    if (!HM) load_basis(tile_fixed);
     for (int i = t; i < 528; i += 256) s_J[i] = pk[PK_JT + i];
     if (t < NJ) {
         int d = 0;
@@ -399,14 +409,16 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
         for (int j = 0; j < NJ; ++j) mx = max(mx, s_depth[j]);
         s_depth[16] = mx;
     }
-    const int v = v0 + lane;
-    const bool valid = v < NV;
     float wgt[NJ];
+    auto load_weights = [&](int tile) {
+        const int vv = tile * TILE_V + lane;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) wgt[j] = valid ? m.weights[v * NJ + j] : 0.f;
+        for (int j = 0; j < NJ; ++j) wgt[j] = (vv < NV) ? m.weights[vv * NJ + j] : 0.f;
+    };
+    if (!HM) load_weights(tile_fixed);
 
     const int nchunks = (B + HC - 1) / HC;
-    for (int chunk = blockIdx.y; chunk < nchunks; chunk += gridDim.y) {
+    for (int chunk = HM ? blockIdx.x : blockIdx.y; chunk < nchunks; chunk += HM ? gridDim.x : gridDim.y) {
         const int h0 = chunk * HC;
         __syncthreads();                        // previous chunk's skinning is done with s_G / s_scr
         RIH_STAMP(0);
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
 #pragma unroll
             for (int sdx = 0; sdx < 10; ++sdx) a += s_J[48 + e * 10 + sdx] * s_pf[hl * LDPF + NPF + sdx];
             s_scr[hl * SCR + S_JT + e] = a;
-            if (ws != nullptr && tile == 0 && h0 + hl < B) ws[(long long)(h0 + hl) * WS_STRIDE + OFF_JT + e] = a;
+            if (ws != nullptr && first_tile && h0 + hl < B) ws[(long long)(h0 + hl) * WS_STRIDE + OFF_JT + e] = a;
         }
         __syncthreads();
         if (t < HC * NJ) {
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
             }
             if (j > 0)
                 for (int e = 0; e < 9; ++e) s_pf[hl * LDPF + (j - 1) * 9 + e] = (h < B) ? R[e] - ((e % 4 == 0) ? 1.f : 0.f) : 0.f;
-            if (ws != nullptr && tile == 0 && h < B)
+            if (ws != nullptr && first_tile && h < B)
                 for (int e = 0; e < 9; ++e) ws[(long long)h * WS_STRIDE + OFF_R + j * 9 + e] = R[e];
         }
         __syncthreads();
@@ -558,7 +570,7 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
             post[7] = 0.f;
         }
         __syncthreads();
-        if (tile == 0) {
+        if (first_tile) {
             for (int i = t; i < HC * 63; i += 256) {
                 const int hl = i / 63, e = i - hl * 63, h = h0 + hl;
                 if (h >= B) continue;
@@ -585,6 +597,16 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
             __syncthreads();            // the scratch (src / sp) is overwritten by the v_tpose tile below
         }
         RIH_STAMP(5);
+        for (int tl = 0; tl < (HM ? NTILES : 1); ++tl) {
+        const int tile = HM ? tl : tile_fixed;
+        const int v = tile * TILE_V + lane;
+        const bool valid = v < NV;
+        if (HM) {
+            __syncthreads();        // the previous tile's skinning is done with the v_tpose tile; phase 1 with its scratch
+            load_basis(tile);
+            load_weights(tile);
+            __syncthreads();
+        }
         // ---- phase 2: v_tpose[16][192] = operand[16][148] x Bmat tile; wave w owns coordinate blocks 3w .. 3w+2
         floatx4 acc[3];
 #pragma unroll
@@ -641,6 +663,7 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
                 }
             }
         }
+        }   // tiles
         RIH_STAMP(7);
     }
 #undef RIH_STAMP
@@ -909,15 +932,21 @@ extern "C" int rih_mano_fwd(const rih_mano_model* m, const float* packed, const 
     if (ncomp > 0 && !m->comps) return RIH_EINVAL;
     const Model mm = to_model(m);
     hipStream_t s = (hipStream_t)stream;
-    if (variant == 0) {
+    if (variant == 0 || variant == 2 || variant == 3) {
         // ONE launch.  Workgroups = 13 vertex tiles x hand groups; about two workgroups per CU in total, so that the 111 KB
         // basis tile a workgroup pins is amortised over several 16-hand chunks when the batch is large.
         if (!packed || ((uintptr_t)packed % 16) != 0) return RIH_EINVAL;
         const int nchunks = (B + HC - 1) / HC;
+        if (variant == 2 || (variant == 0 && nchunks >= 256)) {
+            // hand-chunk major: the pose work of a chunk once, basis tiles streamed from L2 (one workgroup per CU: LDS)
+            hipLaunchKernelGGL(mano_fused_kernel<true>, dim3(nchunks < 256 ? nchunks : 256), dim3(256), 0, s, mm, packed, root,
+                               pose, ncomp, shape, trans, scale, center_idx, new_skel, v, j, ws, B, g_mano_dbg);
+            return (int)hipGetLastError();
+        }
         int groups = (512 + NTILES - 1) / NTILES;
         if (groups > nchunks) groups = nchunks;
-        hipLaunchKernelGGL(mano_fused_kernel, dim3(NTILES, groups), dim3(256), 0, s, mm, packed, root, pose, ncomp, shape,
-                           trans, scale, center_idx, new_skel, v, j, ws, B, g_mano_dbg);
+        hipLaunchKernelGGL(mano_fused_kernel<false>, dim3(NTILES, groups), dim3(256), 0, s, mm, packed, root, pose, ncomp,
+                           shape, trans, scale, center_idx, new_skel, v, j, ws, B, g_mano_dbg);
         return (int)hipGetLastError();
     }
     if (variant != 1 || !ws) return RIH_EINVAL;     // round-1 two-kernel forward (A/B timing): needs the workspace

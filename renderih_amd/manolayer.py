@@ -84,7 +84,8 @@ def build_mano_frame(skelBatch):
     return frame[:, 1:]
 
 
-# 0: the fused single-launch forward; 1: round 1's two-kernel forward (A/B timing, tools/mano_bench.py --variant 1)
+# 0: the fused single-launch forward (hand-chunk major from 4096 hands on); 2 / 3: force its hand-major / tile-major form;
+# 1: round 1's two-kernel forward (A/B timing, tools/mano_bench.py --variant 1)
 VARIANT = 0
 
 

@@ -103,11 +103,13 @@ def test_mano_reads_mutated_shapedirs():
     assert float((a - b).abs().max()) > 1e-4
 
 
-@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
 def test_mano_inference_without_workspace_and_two_kernel_variant(variant):
     """The fused forward under no_grad writes only v and j (no workspace is allocated) and equals the forward that also feeds
     the backward; variant 1 (round 1's two-kernel forward, kept for A/B timing) agrees with the fused kernel to fp32 round-off
-    (the fused kernel sums the blend shapes in one k-ordered chain on the f32 MFMA, the old one in two VALU passes)."""
+    (the fused kernel sums the blend shapes in one k-ordered chain on the f32 MFMA, the old one in two VALU passes).
+    Variants 2 / 3 force the hand-chunk-major / tile-major form of the fused kernel (variant 0 picks by batch size): same
+    arithmetic in the same order, bit-identical outputs -- also with the workspace (the training forward below, variant 2)."""
     from renderih_amd import manolayer
     from renderih_amd.manolayer import rodrigues_batch
     layer = _layer('right', 9, True, True)
@@ -123,8 +125,22 @@ def test_mano_inference_without_workspace_and_two_kernel_variant(variant):
             v_inf, j_inf = layer(root, pose, shape)
     finally:
         manolayer.VARIANT = old
-    if variant == 0:
+    if variant in (0, 2, 3):
         assert torch.equal(v_inf, v_train.detach()) and torch.equal(j_inf, j_train.detach())
+        if variant == 2:        # the hand-major form also has to fill the workspace of the backward: gradients must agree
+            r2 = root.clone().requires_grad_(True)
+            p2 = pose.clone().requires_grad_(True)
+            manolayer.VARIANT = 2
+            try:
+                v2, j2 = layer(r2, p2, shape)
+            finally:
+                manolayer.VARIANT = old
+            r0, p0 = root.clone().requires_grad_(True), pose.clone().requires_grad_(True)
+            v0, j0 = layer(r0, p0, shape)
+            gv = torch.randn(v0.shape, generator=torch.Generator().manual_seed(9)).to(v0.device)
+            (v2 * gv).sum().backward()
+            (v0 * gv).sum().backward()
+            assert torch.equal(v2, v0) and torch.equal(r2.grad, r0.grad) and torch.equal(p2.grad, p0.grad)
     else:
         assert_close(v_inf, v_train.detach(), 1e-5, 1e-6, 'two-kernel forward vs fused')
         assert_close(j_inf, j_train.detach(), 1e-5, 1e-6, 'two-kernel joints vs fused')

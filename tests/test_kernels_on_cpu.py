@@ -168,6 +168,8 @@ def test_mano_kernels_reference_golden():
 def test_mano_fused_forward_variants_and_cache():
     TMANO.test_mano_inference_without_workspace_and_two_kernel_variant(0)
     TMANO.test_mano_inference_without_workspace_and_two_kernel_variant(1)
+    TMANO.test_mano_inference_without_workspace_and_two_kernel_variant(2)      # hand-chunk-major form of the fused kernel
+    TMANO.test_mano_inference_without_workspace_and_two_kernel_variant(3)
     TMANO.test_mano_reads_mutated_shapedirs()
     TMANO.test_mano_matches_oracle(17)
 

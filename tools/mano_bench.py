@@ -81,7 +81,7 @@ def main():
     ap.add_argument('--hands', type=int, nargs='+', default=[128, 4096])
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--json', default=None)
-    ap.add_argument('--variant', type=int, default=0, help='0 = fused single-launch forward, 1 = round-1 two-kernel forward')
+    ap.add_argument('--variant', type=int, default=0, help='0 = fused single-launch forward (auto form), 2 / 3 = its hand-major / tile-major form, 1 = round-1 two-kernel forward')
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
     rows = [dict(measure(B, a.iters, dev, a.variant), variant=a.variant) for B in a.hands]
