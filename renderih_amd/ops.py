@@ -56,6 +56,10 @@ def plan_gemm(M, N, K, batch=1, engine=None):
     output tiles are split over K instead of shrinking the tile."""
     e = ENGINE if engine is None else engine
     if N <= 32:
+        # 16 < N <= 32 (HRNet's 32-channel branch): a half-empty split-engine tile beats the 128x32 tile of the native-f32
+        # engine by 6-9 % (profiles/r02/n32_bench_m31.log); below that the waste is too large
+        if e == 1 and N > 16 and _cdiv(M, 128) * batch >= 512:
+            return (1 if K >= 128 else 2), 1
         return 3, 1
     t0 = _cdiv(M, 128) * _cdiv(N, 128) * batch
     t1 = _cdiv(M, 128) * _cdiv(N, 64) * batch
@@ -393,6 +397,8 @@ def _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin
     # (profiles/r02/tile_sweep_m15.log: 256->128 @64x64, 128<->512 @32x32)
     small = _cdiv(Mp, 128) * _cdiv(Ncols, 128) <= 4 and (Kpix < 16384 or nb > 1)
     tile = 3 if Ncols <= 32 else (2 if (Ncols <= 64 or Mp <= 64 or (ENGINE == 1 and small)) else 0)
+    if ENGINE == 1 and 16 < Ncols <= 32:
+        tile = 2            # weight gradients with 17..32 columns: 64x64 split-engine tile, -26..-29 % (n32_bench_m31.log)
     if nb > 1 and ENGINE == 1 and Ncols > 32:
         tile = 2            # paired decoder layers (tools/pair_sweep.py): 64x64 tiles win at every measured shape
     bm, bn = _TILE_MN[tile]

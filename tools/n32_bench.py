@@ -32,3 +32,27 @@ for H, Cin, Cout, k in [(64, 32, 32, 3), (64, 32, 32, 1), (64, 64, 32, 1), (64, 
     dw = torch.empty(Cout, cpad, k, k, device=dev)
     t_plan = time_graph(lambda: ops._wgrad(x, dy, dw, M, k * k * cpad, Cout, cpad, Cout, geom, cpad, k * k, cpad))
     print('   wgrad planner %7.1f us %5.1f TF' % (t_plan, fl / t_plan), flush=True)
+    # explicit alternatives for the weight gradient: tile (engine) x number of K-slices
+    Mp = k * k * cpad
+    for tile, eng in ((3, 0), (2, 1), (2, 0)):
+        if tile == 3 and Cout > 32:
+            continue
+        out = []
+        for target in (256, 512, 1024):
+            bm, bn = ops._TILE_MN[tile]
+            tiles = -(-Mp // bm) * -(-Cout // bn)
+            sk = max(1, min(target // tiles, -(-M // 128)))
+            kc = -(-(-(-M // sk)) // 32) * 32
+            sk = -(-M // kc)
+            part = torch.empty(sk, Mp, Cout, device=dev)
+
+            def run():
+                ops.gemm(x, dy, part, Mp, Cout, M, cpad, Cout, Cout, a_mode=1, b_mode=0, splitk=sk, kchunk=kc, sCsplit=Mp * Cout,
+                         geom=geom, tile=tile, engine=eng)
+                ops.check(ops._L().rih_splitk_reduce(part.data_ptr(), sk, Mp, Cout, dw.data_ptr(), cpad, k * k, cpad, 0,
+                                                     ops._stream()), 'reduce')
+            try:
+                out.append('sk%d %6.1f us' % (sk, time_graph(run)))
+            except Exception as e:      # noqa: BLE001
+                out.append('sk%d failed' % sk)
+        print('   wgrad t%d e%d: %s' % (tile, eng, ' | '.join(out)), flush=True)
