@@ -58,8 +58,8 @@ def plan_gemm(M, N, K, batch=1, engine=None):
     if N <= 32:
         # 16 < N <= 32 (HRNet's 32-channel branch): a half-empty split-engine tile beats the 128x32 tile of the native-f32
         # engine by 6-9 % (profiles/r02/n32_bench_m31.log); below that the waste is too large
-        if e == 1 and N > 16 and _cdiv(M, 128) * batch >= 512:
-            return (1 if K >= 128 else 2), 1
+        if e == 1 and N > 16:
+            return (1 if (K >= 128 and _cdiv(M, 128) * batch >= 512) else 2), 1
         return 3, 1
     t0 = _cdiv(M, 128) * _cdiv(N, 128) * batch
     t1 = _cdiv(M, 128) * _cdiv(N, 64) * batch
