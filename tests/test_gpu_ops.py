@@ -45,6 +45,9 @@ CONV_CASES = [
     (1, 64, 64, 64, 256, 1, 1, 0, False, True),
     (2, 15, 17, 64, 96, 3, 2, 1, False, False),      # odd sizes: the parity classes of the strided dgrad differ in size
     (2, 13, 13, 32, 64, 1, 2, 0, False, False),
+    (2, 32, 32, 32, 32, 3, 1, 1, False, False),       # 17..32 output channels: half-empty split-engine tiles (HRNet's 32-channel branch)
+    (1, 9, 9, 64, 30, 1, 1, 0, True, True),           # ... and a column count that is not a multiple of 4 (general kernel)
+    (16, 64, 64, 32, 24, 3, 1, 1, True, False),       # many rows, K >= 128: the 128x64 tile
 ]
 
 
