@@ -96,7 +96,14 @@ typedef struct rih_gemm_desc {
      * (models/model_attn/DualGraph.py:83-89 runs them one after the other) execute as ONE launch on activations
      * stacked [2][rows][K].  0 = bias / R shared by all slices. */
     int64_t sBias1, sR1;
+    /* Optional statistics epilogue (split engine's fast path, a_mode 0, no split-K, no batch): per block of
+     * rih_gemm_stats_rows(desc) GEMM rows the column sums of the stored values and of their squares,
+     * stats[ceil(M / rows)][2][N] -- the training statistics of the BatchNorm behind a convolution without a pass over its
+     * output (rih_bn_stats_from_sums finishes them).  NULL = off.  rih_gemm returns RIH_EINVAL when stats is set and the
+     * descriptor does not take that path; rih_gemm_stats_rows (stats field ignored) returns 0 for such a descriptor. */
+    float* stats;
 } rih_gemm_desc;
+int rih_gemm_stats_rows(const rih_gemm_desc* d);
 
 int rih_gemm(const rih_gemm_desc* d, void* stream);
 
@@ -172,6 +179,12 @@ int rih_gemm_p3_tile_rows(int tile);
 int rih_p3_from_f32(const float* x, int64_t rows, int C, int ldx, void* out, int ldo, int layout, void* stream);
 int rih_p3_conv_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int CinPad, int for_dgrad, int kh0,
                        int kw0, int step, int Th, int Tw, int Kpad, int layout, void* stream);
+/* Training statistics (what rih_bn_stats produces, running buffers included) from the raw column sums that rih_gemm's
+ * statistics epilogue writes (rih_gemm_desc.stats: part[T][2][C], T = ceil(rows / rih_gemm_stats_rows(desc))): no pass over the
+ * convolution output.  One launch for T <= 256, two above (ws >= rih_bn_sums_ws_floats(T, C) floats). */
+int64_t rih_bn_sums_ws_floats(int T, int C);
+int rih_bn_stats_from_sums(const float* part, int T, int C, int rows, float eps, float momentum, float* mean, float* invstd,
+                           float* running_mean, float* running_var, float* ws, void* stream);
 /* part [T][C][2] from rih_gemm_p3 (tiles of rows_per_tile rows) -> what rih_bn_stats produces: mean[C],
  * invstd[C] = 1 / sqrt(biased var + eps) and, when running_mean / running_var != NULL, their momentum update with the unbiased
  * variance (nn.BatchNorm2d training forward).  Chan's merge in double, one wavefront per channel. */
@@ -425,7 +438,7 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
  * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of the by-pointer structs
  * (gemm desc, mano model, mesh topo, hconv desc), so a host binding can refuse a stale binary instead of handing it
  * mis-laid-out structs. */
-#define RIH_ABI_VERSION 6
+#define RIH_ABI_VERSION 7
 int rih_version(void);
 int rih_abi_sizes(int32_t* out4);
 const char* rih_arch(void);

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
                 ('KH', C.c_int32), ('KW', C.c_int32), ('strideA', C.c_int32), ('upS', C.c_int32),
                 ('padH', C.c_int32), ('padW', C.c_int32), ('tile', C.c_int32), ('engine', C.c_int32),
                 ('cS', C.c_int32), ('cOH', C.c_int32), ('cOW', C.c_int32), ('cH', C.c_int32), ('cW', C.c_int32), ('ones_row', C.c_int32),
-                ('reserved0', C.c_int32), ('sBias1', C.c_int64), ('sR1', C.c_int64)]
+                ('reserved0', C.c_int32), ('sBias1', C.c_int64), ('sR1', C.c_int64), ('stats', C.c_void_p)]
 
 
 class GemmP3Desc(C.Structure):
@@ -172,13 +172,16 @@ SIGNATURES = {
     'rih_p3_from_f32': (c_i, [c_f, c_l, c_i, c_i, C.c_void_p, c_i, c_i, C.c_void_p]),
     'rih_p3_conv_weight': (c_i, [c_f, C.c_void_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
     'rih_bn_stats_merge': (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),
+    'rih_gemm_stats_rows': (c_i, [C.POINTER(GemmDesc)]),
+    'rih_bn_sums_ws_floats': (c_l, [c_i, c_i]),
+    'rih_bn_stats_from_sums': (c_i, [c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f, C.c_void_p]),
     'rih_bn_stats_from_tiles': (c_i, [c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, C.c_void_p]),
     'rih_version': (c_i, []),
     'rih_abi_sizes': (c_i, [C.POINTER(C.c_int32)]),
     'rih_arch': (C.c_char_p, []),
 }
 
-ABI_VERSION = 6      # = RIH_ABI_VERSION of include/renderih_amd.h
+ABI_VERSION = 7      # = RIH_ABI_VERSION of include/renderih_amd.h
 
 _lib = None
 

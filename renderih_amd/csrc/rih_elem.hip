@@ -472,6 +472,37 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
     }
 }
 
+// Training statistics from raw column sums: ws[k][0..C) = partial sum x, ws[k][C..2C) = partial sum x^2 (k < nchunk rows of
+// pitch ld) -- the statistics epilogue of rih_gemm (rih_gemm_desc.stats), or its column-summed form.  One wavefront per channel,
+// double accumulation, var = E[x^2] - mean^2 in double.
+__global__ __launch_bounds__(TPB) void bn_sums_final_kernel(const float* __restrict__ ws, int ld, int nchunk, int rows, int C,
+                                                            float eps, float momentum, float* __restrict__ mean,
+                                                            float* __restrict__ invstd, float* __restrict__ rmean,
+                                                            float* __restrict__ rvar) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = lane; k < nchunk; k += 64) {
+        s1 += (double)ws[(long long)k * ld + c];
+        s2 += (double)ws[(long long)k * ld + C + c];
+    }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if (lane != 0) return;
+    const double n = (double)rows;
+    const double m = s1 / n;
+    double var = s2 / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean != nullptr) {
+        const double unb = (rows > 1) ? var * n / (n - 1.0) : var;
+        rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * m);
+        rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+    }
+}
+
 // BN backward pass 1: per-channel sum(dym), sum(dym * xhat), dym = dy * (y>0) when relu
 __global__ __launch_bounds__(TPB) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ y,
@@ -1625,6 +1656,26 @@ extern "C" int rih_bn_stats(const float* x, int rows, int C, float eps, float mo
                        g.rows_per_chunk, ws);
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 3) / 4), dim3(TPB), 0, STREAM, x, ws, rows, C, g.nchunk, eps,
                        momentum, mean, invstd, running_mean, running_var);
+    LAUNCH_RET();
+}
+extern "C" int64_t rih_bn_sums_ws_floats(int T, int C) { return (T > 256) ? (int64_t)64 * 2 * C : 0; }
+extern "C" int rih_bn_stats_from_sums(const float* part, int T, int C, int rows, float eps, float momentum, float* mean,
+                                      float* invstd, float* running_mean, float* running_var, float* ws, void* stream) {
+    if (!part || !mean || !invstd || T < 1 || C < 1 || rows < 1) return RIH_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return RIH_EINVAL;
+    if (T > 256 && !ws) return RIH_EINVAL;
+    const float* src = part;
+    int nchunk = T;
+    if (T > 256) {          // thousands of row blocks (layer1 / layer2 at B = 64): column-sum them into 64 chunks first
+        nchunk = 64;
+        const int rpc = (T + nchunk - 1) / nchunk;
+        nchunk = (T + rpc - 1) / rpc;
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((2 * C + 63) / 64, nchunk), dim3(TPB), 0, STREAM, part, T, 2 * C, 2 * C,
+                           rpc, ws);
+        src = ws;
+    }
+    hipLaunchKernelGGL(bn_sums_final_kernel, dim3((C + 3) / 4), dim3(TPB), 0, STREAM, src, 2 * C, nchunk, rows, C, eps, momentum,
+                       mean, invstd, running_mean, running_var);
     LAUNCH_RET();
 }
 extern "C" int rih_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean,

@@ -41,6 +41,7 @@ struct GemmArgs {
     int ones_row;                   // a_mode 1: A(ones_row, k) = 1 for every valid k (bias gradient row); 0 = off
     unsigned a_plane;               // a_mode 2: bytes per pre-split plane of A (last: keeps the older kernels' kernarg offsets)
     int epi_vec;                    // C, R, bias and every stride involved are 16-byte aligned: the epilogue may use 16-byte accesses
+    float* stats;                   // split fast path, a_mode 0, splitk 1: per wave-row-block column sums [M / WM][2][N] (or NULL)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -98,13 +99,21 @@ __device__ __forceinline__ int lds_swz(int m) { return (m >> 2) & 3; }
 // B = 64 step, GEMM family 24.0 -> 22.3 ms (profiles/r02/bench_m14_wide_epilogue.log).
 // `stg`: this wave's 32 x SLD floats of LDS; the caller guarantees a __syncthreads() since the last operand read.
 constexpr int SLD = 36;             // floats per staged row: 32 + pad, keeps float4 alignment
-template <int TM, int TN>
+// STATS: also sum the stored values and their squares per column over the wave's TM*32 rows (raw fp32 sums; the BatchNorm
+// that follows the convolution finishes them in double, rih_bn_stats_from_sums) and write them to p.stats[row block][2][N]:
+// the training statistics then cost no pass over the activation (csrc/rih_elem.hip: bn_stats_partial_kernel reads it once).
+template <int TM, int TN, bool STATS = false>
 __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&acc)[TM][TN], float* stg, float* __restrict__ C,
                                                  const float* __restrict__ biasp, const float* __restrict__ Rp, int mbase,
                                                  int nbase, int lane) {
     const bool raw = (p.splitk > 1);
     const bool vec = p.epi_vec != 0;
     const int l31 = lane & 31, lhi = lane >> 5;
+    float4 ssum[STATS ? TN : 1], ssq[STATS ? TN : 1];
+    if (STATS) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { ssum[j] = zero4(); ssq[j] = zero4(); }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -147,6 +156,37 @@ __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&a
                     if (n + 1 < p.N) crow[1] = v.y;
                     if (n + 2 < p.N) crow[2] = v.z;
                     if (n + 3 < p.N) crow[3] = v.w;
+                }
+                if (STATS) {        // (columns past N are never written out below)
+                    ssum[j].x += v.x; ssum[j].y += v.y; ssum[j].z += v.z; ssum[j].w += v.w;
+                    ssq[j].x += v.x * v.x; ssq[j].y += v.y * v.y; ssq[j].z += v.z * v.z; ssq[j].w += v.w * v.w;
+                }
+            }
+        }
+    }
+    if (STATS) {
+        // rows of a block are spread over lane >> 3 (and the q passes above): sum the eight row-lanes, lane >> 3 == 0 writes
+        const long long rb = mbase / (TM * 32);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                ssum[j].x += __shfl_xor(ssum[j].x, o, 64); ssum[j].y += __shfl_xor(ssum[j].y, o, 64);
+                ssum[j].z += __shfl_xor(ssum[j].z, o, 64); ssum[j].w += __shfl_xor(ssum[j].w, o, 64);
+                ssq[j].x += __shfl_xor(ssq[j].x, o, 64); ssq[j].y += __shfl_xor(ssq[j].y, o, 64);
+                ssq[j].z += __shfl_xor(ssq[j].z, o, 64); ssq[j].w += __shfl_xor(ssq[j].w, o, 64);
+            }
+            const int n = nbase + j * 32 + (lane & 7) * 4;
+            if ((lane >> 3) == 0 && n < p.N && mbase < p.M) {
+                float* s0 = p.stats + (rb * 2 + 0) * p.N + n;
+                float* s1 = p.stats + (rb * 2 + 1) * p.N + n;
+                if (vec && n + 3 < p.N) {
+                    *reinterpret_cast<float4*>(s0) = ssum[j];
+                    *reinterpret_cast<float4*>(s1) = ssq[j];
+                } else {
+                    const float a[4] = {ssum[j].x, ssum[j].y, ssum[j].z, ssum[j].w};
+                    const float b[4] = {ssq[j].x, ssq[j].y, ssq[j].z, ssq[j].w};
+                    for (int e = 0; e < 4 && n + e < p.N; ++e) { s0[e] = a[e]; s1[e] = b[e]; }
                 }
             }
         }
@@ -628,7 +668,7 @@ __device__ __forceinline__ uint4 bloadu4(__amdgpu_buffer_rsrc_t r, unsigned off)
 // APRE (a_mode 2): A arrives pre-split as well -- planes [hi | mid | lo][pixels][lda] bf16, channels contiguous, written
 // by rih_presplit_matrix on the NHWC activation; AMODE must be 0 (im2col / plain rows), the loader is the BMODE 2 one
 // plus the per-row window offsets and tap validity bits.  With both operands pre-split the kernel converts nothing.
-template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false>
+template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
     // global->register prefetch depth: k-tiles in flight.  The 64x64 tile (decoder-sized problems: a handful of
     // k-tiles, 12 MFMAs each) is bound by the load round trip per k-tile, so it keeps three tiles in flight.
@@ -1037,7 +1077,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
     }
 
     // ------------------------------------------------------------------ epilogue (store_tiles_wide; the main loop ended with a barrier)
-    store_tiles_wide<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp, m0 + wm * WM, n0 + wn * WN, lane);
+    store_tiles_wide<TM, TN, STATS>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp, m0 + wm * WM, n0 + wn * WN,
+                                    lane);
 }
 
 template <int BM, int BN>
@@ -1047,6 +1088,12 @@ int launch_split(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 gri
     if (a_mode == 2) {      // both operands pre-split (b_mode 2 enforced by rih_gemm)
         if (plain) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 2, true, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 2, false, true>), grid, block, 0, s, a);
+    }
+    else if (a.stats != nullptr) {      // statistics epilogue: forward-type GEMMs only (checked by the caller)
+#define RIH_LSS(BM_, PL_) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, BM_, PL_, false, true>), grid, block, 0, s, a)
+        if (b_mode == 0) { if (plain) RIH_LSS(0, true); else RIH_LSS(0, false); }
+        else { if (plain) RIH_LSS(1, true); else RIH_LSS(1, false); }
+#undef RIH_LSS
     }
     else if (a_mode == 0 && b_mode == 2) { if (plain) RIH_LS(0, 2, true); else RIH_LS(0, 2, false); }
     else if (a_mode == 0 && b_mode == 0) { if (plain) RIH_LS(0, 0, true); else RIH_LS(0, 0, false); }
@@ -1704,7 +1751,7 @@ extern "C" int rih_presplit_conv_weight(const float* w, void* dst, int Cout, int
     return launch_presplit(a, stream);
 }
 
-extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
+static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows) {
     if (!d || !d->A || !d->B || !d->C) return RIH_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K < 0) return RIH_EINVAL;
     if (d->splitk < 1 || d->nb1 < 1 || d->nb2 < 1) return RIH_EINVAL;
@@ -1750,6 +1797,7 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
     a.a_plane = 0;
     a.cS = d->cS; a.cOH = d->cOH; a.cOW = d->cOW; a.cH = d->cH; a.cW = d->cW;
     a.ones_row = d->ones_row;
+    a.stats = d->stats;
     {
         const auto al4 = [](long long v) { return (v & 3) == 0; };
         a.epi_vec = ((uintptr_t)d->C % 16 == 0) && al4(d->ldc) && al4(d->N) && al4(d->sC1) && al4(d->sC2) && al4(d->sCsplit) &&
@@ -1792,11 +1840,21 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
         if (d->a_mode == 1) ok = ok && (d->M % 4 == 0) && (plain || (d->Wo % 4 == 0 && d->Cin % 4 == 0));
         if (d->b_mode == 0) ok = ok && (d->N % 4 == 0);
         if (d->tile == 4) {     // 256x128 kernel: no general-kernel fallback, the caller must respect the preconditions
+            if (stats_rows != nullptr) { *stats_rows = 0; return 0; }
+            if (d->stats != nullptr) return RIH_EINVAL;
             ok = ok && !(d->a_mode == 1 && d->b_mode == 1);
             if (!ok) return RIH_EINVAL;
             a.a_bytes = (unsigned)a_bytes;
             a.b_bytes = (unsigned)b_bytes;
             return launch_split256(a, d->a_mode, d->b_mode, plain, grid, s);
+        }
+        if (d->stats != nullptr && !(ok && d->tile <= 2 && d->a_mode == 0 && d->b_mode <= 1 && d->splitk == 1 && gz == 1 &&
+                                     d->cS <= 1))
+            return RIH_EINVAL;      // the statistics epilogue exists on this path only (rih_gemm_stats_rows tells in advance)
+        if (stats_rows != nullptr) {
+            *stats_rows = (ok && d->tile <= 2 && d->a_mode == 0 && d->b_mode <= 1 && d->splitk == 1 && gz == 1 && d->cS <= 1)
+                              ? bm / 2 : 0;
+            return 0;
         }
         if (ok) {
             a.a_bytes = (unsigned)a_bytes;
@@ -1807,12 +1865,22 @@ extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) {
             return launch_split<64, 64>(a, d->a_mode, d->b_mode, plain, grid, s);
         }
     }
+    if (stats_rows != nullptr) { *stats_rows = 0; return 0; }
+    if (d->stats != nullptr) return RIH_EINVAL;
     if (d->b_mode == 2 || d->a_mode == 2) return RIH_EINVAL;  // the general kernels do not read pre-split operands
     if (d->tile == 4) return RIH_EINVAL;    // 256x128 exists only on the split engine's fast path
     if (d->tile == 0) return launch_tile<128, 128>(a, d->a_mode, d->b_mode, d->engine, grid, s);
     if (d->tile == 1) return launch_tile<128, 64>(a, d->a_mode, d->b_mode, d->engine, grid, s);
     if (d->tile == 3) return launch_tile<128, 32>(a, d->a_mode, d->b_mode, 0, grid, s);
     return launch_tile<64, 64>(a, d->a_mode, d->b_mode, d->engine, grid, s);
+}
+
+extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) { return gemm_impl(d, stream, nullptr); }
+
+extern "C" int rih_gemm_stats_rows(const rih_gemm_desc* d) {
+    int rows = 0;
+    if (gemm_impl(d, nullptr, &rows) != 0) return 0;
+    return rows;
 }
 
 extern "C" int rih_splitk_reduce_bias_batched(const float* P, int S, int Mp, int M, int N, float* dst, int Cin, int taps,

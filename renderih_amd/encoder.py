@@ -46,13 +46,19 @@ def conv(m, x, relu=False):
 def conv_bn(cm, bn, x, residual=None, relu=False, conv_relu=False, skip=False):
     """Conv2d followed by BatchNorm2d (Conv -> BN (-> ReLU) of the trunk, models/encoder.py:107-116, or Conv -> ReLU -> BN of
     the aux decoders / mid convs, :52-54 with conv_relu=True).  skip=True: also returns the alias of x for the block's skip
-    path (ops.conv2d_skip).  (Taking the BatchNorm statistics from the convolution's GEMM epilogue was built and measured in
-    round 2: 45.1 vs 44.95 ms per step -- the statistics epilogue costs the big GEMMs as much as the 0.95 ms pass it removes --
-    so only the P3 kernel keeps that epilogue; `bn_act(tile_stats=...)` is its consumer.)"""
+    path (ops.conv2d_skip).  In training the BatchNorm statistics come out of the convolution's GEMM epilogue when its
+    descriptor takes the split engine's fast path (ops.StatsHolder / rih_gemm_desc.stats): raw column sums per wave row block,
+    finished by rih_bn_stats_from_sums -- no statistics pass over the activation."""
     f = ops.conv2d_skip if skip else ops.conv2d
-    out = f(x, cm.weight, cm.bias, stride=cm.stride[0], pad=cm.padding[0], relu=conv_relu)
+    holder = ops.StatsHolder() if (ops.GEMM_STATS and bn.training) else None
+    ops._STATS_REQUEST = holder
+    try:
+        out = f(x, cm.weight, cm.bias, stride=cm.stride[0], pad=cm.padding[0], relu=conv_relu)
+    finally:
+        ops._STATS_REQUEST = None
     y, idt = out if skip else (out, None)
-    y = bn_act(bn, y, residual=residual, relu=relu)
+    stats = ('sums', holder.part, holder.T) if (holder is not None and holder.part is not None) else None
+    y = bn_act(bn, y, residual=residual, relu=relu, tile_stats=stats)
     return (y, idt) if skip else y
 
 

@@ -164,6 +164,21 @@ def _elem_profile(nbytes, tag, fn):
     return r
 
 
+# BatchNorm training statistics from the convolution's GEMM epilogue (rih_gemm_desc.stats): `conv_bn` of the encoder installs
+# a holder around its convolution; the forward-type GEMM of that convolution fills it when its descriptor takes the split
+# engine's fast path (rih_gemm_stats_rows), and the BatchNorm behind it finishes the sums instead of reading the activation.
+GEMM_STATS = os.environ.get('RIH_GEMM_STATS', '1') == '1'
+
+
+class StatsHolder:
+    def __init__(self):
+        self.part = None        # [T][2][N] raw column sums / sums of squares per row block
+        self.T = 0
+
+
+_STATS_REQUEST = None
+
+
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=None, ldr=0,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, kchunk=0, sCsplit=0, alpha=1.0, relu=False,
          geom=None, tile=None, engine=None, cstride=None, ones_row=0, sBias=0, sR=0):
@@ -211,6 +226,14 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
             check(_L().rih_splitk_finish(part.data_ptr(), sk, M, N, d.C, ldc, d.bias or 0, d.R or 0, ldr,
                                          alpha, 1 if relu else 0, _stream()), 'rih_splitk_finish')
             return
+    req = _STATS_REQUEST
+    if (req is not None and req.part is None and a_mode == 0 and splitk == 1 and nb1 * nb2 == 1 and cstride is None
+            and not isinstance(Cout, int)):
+        rows_per = int(_L().rih_gemm_stats_rows(C.byref(d)))
+        if rows_per > 0:
+            req.T = _cdiv(M, rows_per)
+            req.part = torch.empty((req.T, 2, N), device=Cout.device, dtype=torch.float32)
+            d.stats = req.part.data_ptr()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -870,7 +893,16 @@ class BatchNormFn(torch.autograd.Function):
         mask = torch.empty((x.numel() // 4,), device=x.device, dtype=torch.uint8) if relu else None
 
         def run():
-            if training and tile_stats is not None:       # statistics came out of the producing GEMM's epilogue
+            if training and tile_stats is not None and tile_stats[0] == 'sums':     # rih_gemm's statistics epilogue
+                _, part, T = tile_stats
+                assert part.shape[2] == Cc
+                ws2 = None
+                n2 = int(lib.rih_bn_sums_ws_floats(T, Cc))
+                if n2 > 0:
+                    ws2 = torch.empty((n2,), device=x.device, dtype=torch.float32)
+                check(lib.rih_bn_stats_from_sums(part.data_ptr(), T, Cc, rows, eps, momentum, mean.data_ptr(), invstd.data_ptr(),
+                                                 _p(rmean), _p(rvar), _p(ws2), _stream()), 'rih_bn_stats_from_sums')
+            elif training and tile_stats is not None:       # statistics came out of the producing GEMM's epilogue (P3)
                 part, T, bm = tile_stats
                 assert T * bm == rows and part.shape[1] == Cc
                 check(lib.rih_bn_stats_from_tiles(part.data_ptr(), T, Cc, bm, eps, momentum, mean.data_ptr(), invstd.data_ptr(),

@@ -139,6 +139,43 @@ class EmulatedLib:
                     out = np.maximum(out, 0)
                 mem = _f(Cb, int(crow.max()) * d.ldc + N)
                 mem[(cm * d.ldc + cn).ravel()] = out.astype(np.float32).ravel()
+                if d.stats:         # statistics epilogue: column sums / sums of squares per block of stats_rows GEMM rows
+                    rp = self.rih_gemm_stats_rows(dref)
+                    assert rp > 0, 'stats requested on a descriptor without the statistics path'
+                    T = -(-M // rp)
+                    st = _f(d.stats, T * 2 * N).reshape(T, 2, N)
+                    o32 = out.astype(np.float32)
+                    for t in range(T):
+                        blk = o32[t * rp:(t + 1) * rp]
+                        st[t, 0], st[t, 1] = blk.sum(0), (blk * blk).sum(0)
+        return 0
+
+    def rih_gemm_stats_rows(self, dref):
+        """The header's contract, restated: split engine's fast path, forward-type, no split-K, no batch, dense rows."""
+        d = dref._obj
+        plain = (d.KH == 1 and d.KW == 1 and d.strideA == 1 and d.padH == 0 and d.padW == 0 and d.H == d.Ho and d.W == d.Wo)
+        ok = (d.engine == 1 and d.tile in (0, 1, 2) and d.a_mode == 0 and d.b_mode in (0, 1) and d.splitk == 1
+              and d.nb1 * d.nb2 == 1 and d.cS <= 1 and d.upS == 1 and d.K % 4 == 0 and d.K >= 1
+              and d.A % 16 == 0 and d.B % 16 == 0 and d.lda % 4 == 0 and d.ldb % 4 == 0)
+        if not plain:
+            ok = ok and d.Cin % 32 == 0 and d.KH * d.KW <= 32
+        if d.b_mode == 0:
+            ok = ok and d.N % 4 == 0
+        return (64 if d.tile in (0, 1) else 32) if ok else 0
+
+    def rih_bn_sums_ws_floats(self, T, Cc):
+        return 64 * 2 * Cc if T > 256 else 0
+
+    def rih_bn_stats_from_sums(self, part, T, Cc, rows, eps, momentum, mean, invstd, rmean, rvar, ws, stream):
+        p = _f(part, T * 2 * Cc).reshape(T, 2, Cc).astype(np.float64)
+        m = p[:, 0].sum(0) / rows
+        var = np.maximum(p[:, 1].sum(0) / rows - m * m, 0.0)
+        _f(mean, Cc)[:] = m
+        _f(invstd, Cc)[:] = 1.0 / np.sqrt(var + eps)
+        if rmean:
+            unb = var * rows / (rows - 1.0) if rows > 1 else var
+            _f(rmean, Cc)[:] = (1.0 - momentum) * _f(rmean, Cc) + momentum * m
+            _f(rvar, Cc)[:] = (1.0 - momentum) * _f(rvar, Cc) + momentum * unb
         return 0
 
     def rih_bn_stats_from_tiles(self, part, T, Cc, rows_per_tile, eps, momentum, mean, invstd, rmean, rvar, stream):

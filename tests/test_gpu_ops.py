@@ -712,3 +712,67 @@ def test_pack_cache_one_launch_equals_per_call_packs():
     for a, b in zip(want2, third):
         assert torch.equal(a, b)
     assert not torch.equal(want[0], want2[0])
+
+
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, 128, 3, 1, 1, False), (3, 9, 7, 32, 72, 3, 2, 1, True),
+                                  (2, 16, 16, 64, 256, 1, 1, 0, False), (40, 32, 32, 64, 64, 1, 1, 0, True),
+                                  (1, 10, 10, 64, 36, 1, 1, 0, False), (2, 8, 8, 256, 256, 3, 1, 1, False)])
+def test_conv_bn_statistics_from_the_gemm_epilogue(case):
+    """encoder.conv_bn in training mode: the BatchNorm statistics come out of the convolution's GEMM epilogue (raw column sums
+    per wave row block, rih_gemm_desc.stats -> rih_bn_stats_from_sums) -- output, running buffers and all gradients equal the
+    separate statistics pass to fp32 round-off, and torch.  Cases: one tile, ragged M / N with a strided 3x3, 1x1 on the 128x128
+    tile, 40960 rows (640 row blocks -> the two-launch finish), N = 36 (ragged column tile), and a forward split-K
+    convolution (8x8, K = 2304: no statistics path -> the separate pass)."""
+    import torch.nn as nn
+    from renderih_amd import ops, encoder
+    N, H, W, Cin, Cout, k, s, p, conv_relu = case
+    d = dev()
+    x = rnd(N, Cin, H, W, seed=1)
+    cm = nn.Conv2d(Cin, Cout, k, s, p, bias=False)
+    bn = nn.BatchNorm2d(Cout)
+    with torch.no_grad():
+        cm.weight.copy_(rnd(Cout, Cin, k, k, seed=2, scale=1.0 / math.sqrt(Cin * k * k)))
+        bn.weight.copy_(torch.rand(Cout, generator=torch.Generator().manual_seed(3)) + 0.5)
+        bn.bias.copy_(rnd(Cout, seed=4) * 0.1)
+    # torch reference (Conv -> [ReLU] -> BN -> ReLU)
+    xr = x.clone().requires_grad_(True)
+    import copy
+    cm_r, bn_r = copy.deepcopy(cm), copy.deepcopy(bn)
+    t = cm_r(xr)
+    if conv_relu:
+        t = F.relu(t)
+    yr = F.relu(bn_r(t))
+    gy = rnd(*yr.shape, seed=5)
+    yr.backward(gy)
+    outs = []
+    for use_stats in (True, False):
+        cm_g, bn_g = copy.deepcopy(cm).to(d), copy.deepcopy(bn).to(d)
+        xg = nhwc(x).to(d).requires_grad_(True)
+        old = ops.GEMM_STATS
+        ops.GEMM_STATS = use_stats
+        try:
+            holder_seen = []
+            orig = ops.StatsHolder
+            if use_stats:
+                class Spy(orig):
+                    def __init__(self):
+                        super().__init__()
+                        holder_seen.append(self)
+                ops.StatsHolder = Spy
+            yg = encoder.conv_bn(cm_g, bn_g, xg, relu=True, conv_relu=conv_relu)
+        finally:
+            ops.GEMM_STATS = old
+            ops.StatsHolder = orig
+        if use_stats:
+            took = holder_seen and holder_seen[0].part is not None
+            assert bool(took) == (case != (2, 8, 8, 256, 256, 3, 1, 1, False)), 'statistics epilogue taken: %s' % took
+        yg.backward(nhwc(gy).to(d))
+        outs.append((yg.detach(), xg.grad, cm_g.weight.grad, bn_g.weight.grad, bn_g.bias.grad, bn_g.running_mean, bn_g.running_var))
+        assert_close(nchw(yg), yr, what='conv_bn y (stats=%s)' % use_stats)
+        assert_close(nchw(xg.grad), xr.grad, 1e-3, 1e-4, 'conv_bn dx')
+        assert_close(cm_g.weight.grad, cm_r.weight.grad, 1e-3, 1e-4, 'conv_bn dw')
+        assert_close(bn_g.weight.grad, bn_r.weight.grad, 1e-3, 1e-4, 'conv_bn dgamma')
+        assert_close(bn_g.running_mean, bn_r.running_mean, 1e-4, 1e-5, 'running_mean')
+        assert_close(bn_g.running_var, bn_r.running_var, 1e-4, 1e-5, 'running_var')
+    for a, b in zip(*outs):
+        assert_close(a, b, 1e-4, 1e-5, 'epilogue statistics vs separate pass')
