@@ -263,7 +263,9 @@ int rih_bn_apply(const float* x, const float* mean, const float* invstd, const f
  * The backward then reads one byte per quad instead of the 16 bytes of y (it needs nothing else of y).
  * backward of the above (training statistics): given dy and the ReLU pattern (relu_mask, or the forward output y when
  * relu_mask == NULL), produces dx, dgamma, dbeta and, when dres != NULL, the residual-branch gradient (= masked dy).
- * frozen_stats != 0: eval-mode backward (statistics are constants). */
+ * frozen_stats bit 0: eval-mode backward (statistics are constants).  Bit 1: the BatchNorm's input x is itself a ReLU output
+ * (Conv -> ReLU -> BN, models/encoder.py:52-54): dx is additionally gated by x > 0, so the convolution's backward needs no
+ * separate ReLU pass over it. */
 int rih_bn_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
                const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C,
                int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, void* stream);

@@ -622,9 +622,19 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
         if (dres != nullptr) reinterpret_cast<float4*>(dres)[i] = d;
         const float4 is = reinterpret_cast<const float4*>(invstd)[g];
         const float4 ga = reinterpret_cast<const float4*>(gamma)[g];
+        // `frozen` bit 1: the input of this BatchNorm is a ReLU output (Conv -> ReLU -> BN of models/encoder.py:52-54): the
+        // gradient leaves already gated by x > 0, and the convolution's backward skips its own ReLU pass over it
+        const bool in_relu = (frozen & 2) != 0;
         float4 o;
-        if (frozen) {
+        if (frozen & 1) {
             o.x = d.x * is.x * ga.x; o.y = d.y * is.y * ga.y; o.z = d.z * is.z * ga.z; o.w = d.w * is.w * ga.w;
+            if (in_relu) {
+                const float4 v = reinterpret_cast<const float4*>(x)[i];
+                if (!(v.x > 0.f)) o.x = 0.f;
+                if (!(v.y > 0.f)) o.y = 0.f;
+                if (!(v.z > 0.f)) o.z = 0.f;
+                if (!(v.w > 0.f)) o.w = 0.f;
+            }
         } else {
             const float4 v = reinterpret_cast<const float4*>(x)[i];
             const float4 m = reinterpret_cast<const float4*>(mean)[g];
@@ -634,6 +644,12 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
             o.y = (d.y - s1.y * inv_rows - ((v.y - m.y) * is.y) * (s2.y * inv_rows)) * (is.y * ga.y);
             o.z = (d.z - s1.z * inv_rows - ((v.z - m.z) * is.z) * (s2.z * inv_rows)) * (is.z * ga.z);
             o.w = (d.w - s1.w * inv_rows - ((v.w - m.w) * is.w) * (s2.w * inv_rows)) * (is.w * ga.w);
+            if (in_relu) {
+                if (!(v.x > 0.f)) o.x = 0.f;
+                if (!(v.y > 0.f)) o.y = 0.f;
+                if (!(v.z > 0.f)) o.z = 0.f;
+                if (!(v.w > 0.f)) o.w = 0.f;
+            }
         }
         reinterpret_cast<float4*>(dx)[i] = o;
     }

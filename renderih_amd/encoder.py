@@ -17,10 +17,11 @@ import torch.nn as nn
 from . import ops
 
 
-def bn_act(bn, x, residual=None, relu=False, tile_stats=None):
+def bn_act(bn, x, residual=None, relu=False, tile_stats=None, input_relu=False):
     """nn.BatchNorm2d semantics (train: batch stats + running update; eval: running stats) on NHWC."""
     y = ops.batchnorm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual=residual,
-                      training=bn.training, relu=relu, eps=bn.eps, momentum=bn.momentum, tile_stats=tile_stats)
+                      training=bn.training, relu=relu, eps=bn.eps, momentum=bn.momentum, tile_stats=tile_stats,
+                      input_relu=input_relu)
     if bn.training and bn.num_batches_tracked is not None:
         _PENDING_TRACKED.append(bn.num_batches_tracked)
     return y
@@ -48,17 +49,18 @@ def conv_bn(cm, bn, x, residual=None, relu=False, conv_relu=False, skip=False):
     the aux decoders / mid convs, :52-54 with conv_relu=True).  skip=True: also returns the alias of x for the block's skip
     path (ops.conv2d_skip).  In training the BatchNorm statistics come out of the convolution's GEMM epilogue when its
     descriptor takes the split engine's fast path (ops.StatsHolder / rih_gemm_desc.stats): raw column sums per wave row block,
-    finished by rih_bn_stats_from_sums -- no statistics pass over the activation."""
+    finished by rih_bn_stats_from_sums -- no statistics pass over the activation.  With conv_relu the ReLU's backward gate is
+    applied by the BatchNorm's backward kernel (it reads its input anyway): no separate relu_bwd pass."""
     f = ops.conv2d_skip if skip else ops.conv2d
     holder = ops.StatsHolder() if (ops.GEMM_STATS and bn.training) else None
     ops._STATS_REQUEST = holder
     try:
-        out = f(x, cm.weight, cm.bias, stride=cm.stride[0], pad=cm.padding[0], relu=conv_relu)
+        out = f(x, cm.weight, cm.bias, stride=cm.stride[0], pad=cm.padding[0], relu=conv_relu, grad_masked=conv_relu)
     finally:
         ops._STATS_REQUEST = None
     y, idt = out if skip else (out, None)
     stats = ('sums', holder.part, holder.T) if (holder is not None and holder.part is not None) else None
-    y = bn_act(bn, y, residual=residual, relu=relu, tile_stats=stats)
+    y = bn_act(bn, y, residual=residual, relu=relu, tile_stats=stats, input_relu=conv_relu)
     return (y, idt) if skip else y
 
 

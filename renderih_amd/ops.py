@@ -532,7 +532,7 @@ class Conv2dFn(torch.autograd.Function):
     x: [N,H,W,Cx] (Cx >= Cin, extra channels must be zero), w: [Cout,Cin,KH,KW] (the nn.Conv2d parameter)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, relu, skip=False):
+    def forward(ctx, x, w, bias, stride, pad, relu, skip=False, grad_masked=False):
         """skip=True: also return x itself (an alias).  A residual block feeds its skip path from that second output;
         the gradient arriving there is then added inside the data-gradient GEMM's epilogue (residual operand R)
         instead of by an autograd accumulation pass over the whole activation."""
@@ -558,8 +558,10 @@ class Conv2dFn(torch.autograd.Function):
         else:
             wp = _packed_weight(w, Cx, False)
             gemm(x, wp, y, M, Cout, K, Cx, Cout, Cout, a_mode=0, b_mode=0, bias=bias, relu=relu, geom=geom)
-        ctx.save_for_backward(x, w, y if relu else None)
-        ctx.cfg = (stride, pad, relu, bias is not None)
+        # grad_masked: the consumer (a BatchNorm with input_relu) hands back a gradient that is already zero where y <= 0
+        relu_bwd = relu and not grad_masked
+        ctx.save_for_backward(x, w, y if relu_bwd else None)
+        ctx.cfg = (stride, pad, relu_bwd, bias is not None)
         if skip:
             return y, x.view_as(x)
         return y
@@ -647,16 +649,16 @@ class Conv2dFn(torch.autograd.Function):
             db = colsum(dy, M, Cout)
         if dx is None and dskip is not None:
             dx = dskip
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, relu=False):
-    return Conv2dFn.apply(x, w, bias, stride, pad, relu, False)
+def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, grad_masked=False):
+    return Conv2dFn.apply(x, w, bias, stride, pad, relu, False, grad_masked)
 
 
-def conv2d_skip(x, w, bias=None, stride=1, pad=0, relu=False):
+def conv2d_skip(x, w, bias=None, stride=1, pad=0, relu=False, grad_masked=False):
     """(conv(x), x) -- see Conv2dFn.forward: use the second value for the block's skip path."""
-    return Conv2dFn.apply(x, w, bias, stride, pad, relu, True)
+    return Conv2dFn.apply(x, w, bias, stride, pad, relu, True, grad_masked)
 
 
 def pack_folded_conv(w, scale, cin_pad):
@@ -877,7 +879,7 @@ class BatchNormFn(torch.autograd.Function):
     in place (momentum 0.1, unbiased running_var) exactly like torch; eval: running statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, residual, training, relu, eps, momentum, tile_stats=None):
+    def forward(ctx, x, gamma, beta, rmean, rvar, residual, training, relu, eps, momentum, tile_stats=None, input_relu=False):
         _chk(x, gamma, beta, rmean, rvar, residual)
         x = _c(x)
         Cc = x.shape[-1]
@@ -919,13 +921,13 @@ class BatchNormFn(torch.autograd.Function):
         _elem_profile(x.numel() * (4.0 * ((1 if training and tile_stats is None else 0) + 2 + (1 if residual is not None else 0))
                                    + (0.25 if relu else 0.0)), 'bn_fwd', run)
         ctx.save_for_backward(x, mask, mean, invstd, gamma)
-        ctx.cfg = (training, relu, residual is not None)
+        ctx.cfg = (training, relu, residual is not None, bool(input_relu))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, mask, mean, invstd, gamma = ctx.saved_tensors
-        training, relu, has_res = ctx.cfg
+        training, relu, has_res, input_relu = ctx.cfg
         dy = _c(dy)
         Cc = x.shape[-1]
         rows = x.numel() // Cc
@@ -940,12 +942,15 @@ class BatchNormFn(torch.autograd.Function):
         _elem_profile(x.numel() * (4.0 * (2 * 2 + 1 + (1 if has_res else 0)) + (0.5 if relu else 0.0)), 'bn_bwd', lambda: check(
             lib.rih_bn_bwd(dy.data_ptr(), x.data_ptr(), 0, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                            dx.data_ptr(), _p(dres), dg.data_ptr(), db.data_ptr(), rows, Cc, 1 if relu else 0,
-                           0 if training else 1, ws.data_ptr(), _p(mask), _stream()), 'rih_bn_bwd'))
-        return dx, dg, db, None, None, dres, None, None, None, None, None
+                           (0 if training else 1) | (2 if input_relu else 0), ws.data_ptr(), _p(mask), _stream()),
+            'rih_bn_bwd'))
+        return dx, dg, db, None, None, dres, None, None, None, None, None, None
 
 
-def batchnorm(x, gamma, beta, rmean, rvar, residual=None, training=True, relu=False, eps=1e-5, momentum=0.1, tile_stats=None):
-    return BatchNormFn.apply(x, gamma, beta, rmean, rvar, residual, training, relu, eps, momentum, tile_stats)
+def batchnorm(x, gamma, beta, rmean, rvar, residual=None, training=True, relu=False, eps=1e-5, momentum=0.1, tile_stats=None,
+              input_relu=False):
+    """input_relu: x is the output of a ReLU (Conv -> ReLU -> BN); the gradient wrt x then leaves already gated by x > 0."""
+    return BatchNormFn.apply(x, gamma, beta, rmean, rvar, residual, training, relu, eps, momentum, tile_stats, input_relu)
 
 
 # --------------------------------------------------------------------------------------------- layout / pooling

@@ -913,10 +913,12 @@ class EmulatedLib:
         _f(dbeta, Cc)[:] = s1
         _f(dgamma, Cc)[:] = s2
         sc = _f(invstd, Cc) * _f(gamma, Cc)
-        if frozen:
+        if frozen & 1:
             o = D * sc
         else:
             o = (D - (s1 / rows).astype(np.float32) - xh * (s2 / rows).astype(np.float32)) * sc
+        if frozen & 2:          # the input is a ReLU output: dx gated by x > 0
+            o = np.where(X > 0, o, 0)
         _f(dx, rows * Cc)[:] = o.ravel()
         if dres:
             _f(dres, rows * Cc)[:] = D.ravel()
