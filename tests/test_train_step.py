@@ -80,3 +80,46 @@ def test_shared_parameters_turn_the_batched_reductions_off():
         assert not step.defer_reduce and any('used more than once' in str(i.message) for i in w)
         for k, p in m.named_parameters():
             assert torch.allclose(p.grad, want[k], rtol=1e-5, atol=1e-6), k
+
+
+def test_train_step_with_the_one_launch_adam_tracks_torch():
+    """TrainStep (deferred reductions on) + renderih_amd.optim.Adam over three steps == plain backward + torch.optim.Adam on a
+    copy of the module: same parameters afterwards (fp32 round-off), same optimizer state layout."""
+    import copy
+    import sys
+    import torch
+    sys.path.insert(0, HERE)
+    from abi_emulator import emulated_abi
+    from renderih_amd import ops, optim
+    from renderih_amd.train import TrainStep
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(24, 40)
+            self.n = torch.nn.LayerNorm(40, eps=1e-6)
+            self.b = torch.nn.Linear(40, 8)
+
+        def forward(self, x):
+            h = ops.layernorm(ops.linear(x, self.a.weight, self.a.bias, relu=True), self.n.weight, self.n.bias)
+            return ops.linear(h, self.b.weight, self.b.bias)
+
+    torch.manual_seed(1)
+    with emulated_abi():
+        m = Net()
+        ref = copy.deepcopy(m)
+        x = torch.randn(64, 24)
+        kw = dict(lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+        o_ref = torch.optim.Adam(ref.parameters(), **kw)
+        step = TrainStep(m, optim.Adam(m.parameters(), **kw), lambda out, lab: (out ** 2).mean(), (x, {}),
+                         process_group=False, use_graph=False)
+        for _ in range(3):
+            step(x, {})
+            o_ref.zero_grad(set_to_none=True)
+            (ref(x) ** 2).mean().backward()
+            o_ref.step()
+        assert step.defer_reduce
+        for (k, p), q in zip(m.named_parameters(), ref.parameters()):
+            assert torch.allclose(p, q, rtol=2e-5, atol=2e-6), k
+        st = step.opt.state[m.a.weight]
+        assert int(st['step']) == 3 and st['exp_avg'].shape == m.a.weight.shape
