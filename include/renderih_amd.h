@@ -97,9 +97,9 @@ typedef struct rih_gemm_desc {
      * stacked [2][rows][K].  0 = bias / R shared by all slices. */
     int64_t sBias1, sR1;
     /* Optional statistics epilogue (split engine's fast path, a_mode 0, no split-K, no batch): per block of
-     * rih_gemm_stats_rows(desc) GEMM rows the column sums of the stored values and of their squares,
+     * rih_gemm_stats_rows(desc) GEMM rows the per-column mean and centred sum of squares of the stored values,
      * stats[ceil(M / rows)][2][N] -- the training statistics of the BatchNorm behind a convolution without a pass over its
-     * output (rih_bn_stats_from_sums finishes them).  NULL = off.  rih_gemm returns RIH_EINVAL when stats is set and the
+     * output (rih_bn_stats_from_blocks merges them).  NULL = off.  rih_gemm returns RIH_EINVAL when stats is set and the
      * descriptor does not take that path; rih_gemm_stats_rows (stats field ignored) returns 0 for such a descriptor. */
     float* stats;
 } rih_gemm_desc;
@@ -179,12 +179,11 @@ int rih_gemm_p3_tile_rows(int tile);
 int rih_p3_from_f32(const float* x, int64_t rows, int C, int ldx, void* out, int ldo, int layout, void* stream);
 int rih_p3_conv_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int CinPad, int for_dgrad, int kh0,
                        int kw0, int step, int Th, int Tw, int Kpad, int layout, void* stream);
-/* Training statistics (what rih_bn_stats produces, running buffers included) from the raw column sums that rih_gemm's
- * statistics epilogue writes (rih_gemm_desc.stats: part[T][2][C], T = ceil(rows / rih_gemm_stats_rows(desc))): no pass over the
- * convolution output.  One launch for T <= 256, two above (ws >= rih_bn_sums_ws_floats(T, C) floats). */
-int64_t rih_bn_sums_ws_floats(int T, int C);
-int rih_bn_stats_from_sums(const float* part, int T, int C, int rows, float eps, float momentum, float* mean, float* invstd,
-                           float* running_mean, float* running_var, float* ws, void* stream);
+/* Training statistics (what rih_bn_stats produces, running buffers included) from the per-row-block (mean, M2) pairs that
+ * rih_gemm's statistics epilogue writes (rih_gemm_desc.stats: part[T][2][C], T = ceil(rows / rows_per_block),
+ * rows_per_block = rih_gemm_stats_rows(desc)): no pass over the convolution output; one launch. */
+int rih_bn_stats_from_blocks(const float* part, int T, int C, int rows, int rows_per_block, float eps, float momentum,
+                             float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
 /* part [T][C][2] from rih_gemm_p3 (tiles of rows_per_tile rows) -> what rih_bn_stats produces: mean[C],
  * invstd[C] = 1 / sqrt(biased var + eps) and, when running_mean / running_var != NULL, their momentum update with the unbiased
  * variance (nn.BatchNorm2d training forward).  Chan's merge in double, one wavefront per channel. */

@@ -173,8 +173,7 @@ SIGNATURES = {
     'rih_p3_conv_weight': (c_i, [c_f, C.c_void_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
     'rih_bn_stats_merge': (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),
     'rih_gemm_stats_rows': (c_i, [C.POINTER(GemmDesc)]),
-    'rih_bn_sums_ws_floats': (c_l, [c_i, c_i]),
-    'rih_bn_stats_from_sums': (c_i, [c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f, C.c_void_p]),
+    'rih_bn_stats_from_blocks': (c_i, [c_f, c_i, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, C.c_void_p]),
     'rih_bn_stats_from_tiles': (c_i, [c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, C.c_void_p]),
     'rih_version': (c_i, []),
     'rih_abi_sizes': (c_i, [C.POINTER(C.c_int32)]),

@@ -472,27 +472,34 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
     }
 }
 
-// Training statistics from raw column sums: ws[k][0..C) = partial sum x, ws[k][C..2C) = partial sum x^2 (k < nchunk rows of
-// pitch ld) -- the statistics epilogue of rih_gemm (rih_gemm_desc.stats), or its column-summed form.  One wavefront per channel,
-// double accumulation, var = E[x^2] - mean^2 in double.
-__global__ __launch_bounds__(TPB) void bn_sums_final_kernel(const float* __restrict__ ws, int ld, int nchunk, int rows, int C,
-                                                            float eps, float momentum, float* __restrict__ mean,
-                                                            float* __restrict__ invstd, float* __restrict__ rmean,
-                                                            float* __restrict__ rvar) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = lane; k < nchunk; k += 64) {
-        s1 += (double)ws[(long long)k * ld + c];
-        s2 += (double)ws[(long long)k * ld + C + c];
+// Training statistics from per-row-block (mean, M2) pairs -- the statistics epilogue of rih_gemm (rih_gemm_desc.stats:
+// part[T][2][C], block k covers rows [k*rpb, min(rows, (k+1)*rpb))).  One workgroup per channel; Chan's merge written as three
+// double sums: n*mean = sum n_k mean_k, M2 = sum M2_k + sum n_k mean_k^2 - n mean^2.
+__global__ __launch_bounds__(TPB) void bn_blocks_final_kernel(const float* __restrict__ part, int T, int C, int rows, int rpb,
+                                                              float eps, float momentum, float* __restrict__ mean,
+                                                              float* __restrict__ invstd, float* __restrict__ rmean,
+                                                              float* __restrict__ rvar) {
+    __shared__ double red[3][TPB / 64];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int k = threadIdx.x; k < T; k += TPB) {
+        const double nk = (double)((k == T - 1) ? rows - (T - 1) * rpb : rpb);
+        const double mk = (double)part[((long long)k * 2 + 0) * C + c];
+        s1 += nk * mk;
+        s2 += (double)part[((long long)k * 2 + 1) * C + c];
+        s3 += nk * mk * mk;
     }
     s1 = wave_sum_d(s1);
     s2 = wave_sum_d(s2);
-    if (lane != 0) return;
+    s3 = wave_sum_d(s3);
+    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; red[2][wave] = s3; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    s1 = s2 = s3 = 0.0;
+    for (int w = 0; w < TPB / 64; ++w) { s1 += red[0][w]; s2 += red[1][w]; s3 += red[2][w]; }
     const double n = (double)rows;
     const double m = s1 / n;
-    double var = s2 / n - m * m;
+    double var = (s2 + s3 - n * m * m) / n;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -1674,23 +1681,13 @@ extern "C" int rih_bn_stats(const float* x, int rows, int C, float eps, float mo
                        momentum, mean, invstd, running_mean, running_var);
     LAUNCH_RET();
 }
-extern "C" int64_t rih_bn_sums_ws_floats(int T, int C) { return (T > 256) ? (int64_t)64 * 2 * C : 0; }
-extern "C" int rih_bn_stats_from_sums(const float* part, int T, int C, int rows, float eps, float momentum, float* mean,
-                                      float* invstd, float* running_mean, float* running_var, float* ws, void* stream) {
-    if (!part || !mean || !invstd || T < 1 || C < 1 || rows < 1) return RIH_EINVAL;
+extern "C" int rih_bn_stats_from_blocks(const float* part, int T, int C, int rows, int rows_per_block, float eps,
+                                        float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                                        void* stream) {
+    if (!part || !mean || !invstd || T < 1 || C < 1 || rows < 1 || rows_per_block < 1) return RIH_EINVAL;
+    if ((long long)(T - 1) * rows_per_block >= rows || (long long)T * rows_per_block < rows) return RIH_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return RIH_EINVAL;
-    if (T > 256 && !ws) return RIH_EINVAL;
-    const float* src = part;
-    int nchunk = T;
-    if (T > 256) {          // thousands of row blocks (layer1 / layer2 at B = 64): column-sum them into 64 chunks first
-        nchunk = 64;
-        const int rpc = (T + nchunk - 1) / nchunk;
-        nchunk = (T + rpc - 1) / rpc;
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3((2 * C + 63) / 64, nchunk), dim3(TPB), 0, STREAM, part, T, 2 * C, 2 * C,
-                           rpc, ws);
-        src = ws;
-    }
-    hipLaunchKernelGGL(bn_sums_final_kernel, dim3((C + 3) / 4), dim3(TPB), 0, STREAM, src, 2 * C, nchunk, rows, C, eps, momentum,
+    hipLaunchKernelGGL(bn_blocks_final_kernel, dim3(C), dim3(TPB), 0, STREAM, part, T, C, rows, rows_per_block, eps, momentum,
                        mean, invstd, running_mean, running_var);
     LAUNCH_RET();
 }

@@ -99,9 +99,10 @@ __device__ __forceinline__ int lds_swz(int m) { return (m >> 2) & 3; }
 // B = 64 step, GEMM family 24.0 -> 22.3 ms (profiles/r02/bench_m14_wide_epilogue.log).
 // `stg`: this wave's 32 x SLD floats of LDS; the caller guarantees a __syncthreads() since the last operand read.
 constexpr int SLD = 36;             // floats per staged row: 32 + pad, keeps float4 alignment
-// STATS: also sum the stored values and their squares per column over the wave's TM*32 rows (raw fp32 sums; the BatchNorm
-// that follows the convolution finishes them in double, rih_bn_stats_from_sums) and write them to p.stats[row block][2][N]:
-// the training statistics then cost no pass over the activation (csrc/rih_elem.hip: bn_stats_partial_kernel reads it once).
+// STATS: also the per-column (mean, centred sum of squares M2) of the stored values over the wave's TM*32 rows -- shifted sums per
+// lane, Chan's pairwise merge across lanes: no E[x^2] - mean^2 cancellation -- written to p.stats[row block][2][N]; the BatchNorm
+// that follows the convolution merges the blocks in double (rih_bn_stats_from_blocks).  The training statistics then cost no
+// pass over the activation (csrc/rih_elem.hip: bn_stats_partial_kernel reads it once).
 template <int TM, int TN, bool STATS = false>
 __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&acc)[TM][TN], float* stg, float* __restrict__ C,
                                                  const float* __restrict__ biasp, const float* __restrict__ Rp, int mbase,
@@ -109,10 +110,12 @@ __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&a
     const bool raw = (p.splitk > 1);
     const bool vec = p.epi_vec != 0;
     const int l31 = lane & 31, lhi = lane >> 5;
-    float4 ssum[STATS ? TN : 1], ssq[STATS ? TN : 1];
+    // per lane and column block: shift (the lane's first stored row), sums of (v - shift) and of its square, row count
+    float4 ssh[STATS ? TN : 1], ssum[STATS ? TN : 1], ssq[STATS ? TN : 1];
+    float scnt[STATS ? TN : 1];
     if (STATS) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) { ssum[j] = zero4(); ssq[j] = zero4(); }
+        for (int j = 0; j < TN; ++j) { ssh[j] = zero4(); ssum[j] = zero4(); ssq[j] = zero4(); scnt[j] = 0.f; }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -158,35 +161,55 @@ __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&a
                     if (n + 3 < p.N) crow[3] = v.w;
                 }
                 if (STATS) {        // (columns past N are never written out below)
-                    ssum[j].x += v.x; ssum[j].y += v.y; ssum[j].z += v.z; ssum[j].w += v.w;
-                    ssq[j].x += v.x * v.x; ssq[j].y += v.y * v.y; ssq[j].z += v.z * v.z; ssq[j].w += v.w * v.w;
+                    if (scnt[j] == 0.f) ssh[j] = v;
+                    scnt[j] += 1.f;
+                    const float dx = v.x - ssh[j].x, dy = v.y - ssh[j].y, dz = v.z - ssh[j].z, dw = v.w - ssh[j].w;
+                    ssum[j].x += dx; ssum[j].y += dy; ssum[j].z += dz; ssum[j].w += dw;
+                    ssq[j].x += dx * dx; ssq[j].y += dy * dy; ssq[j].z += dz * dz; ssq[j].w += dw * dw;
                 }
             }
         }
     }
     if (STATS) {
-        // rows of a block are spread over lane >> 3 (and the q passes above): sum the eight row-lanes, lane >> 3 == 0 writes
+        // a lane holds (count, mean, centred sum of squares) of its <= 4*TM rows per column; the eight row-lanes (lane >> 3)
+        // are merged pairwise with Chan's formula (three xor-shuffle rounds), lane >> 3 == 0 writes the block's (mean, M2)
         const long long rb = mbase / (TM * 32);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
+            float n = scnt[j];
+            const float inv = n > 0.f ? 1.f / n : 0.f;
+            float4 mean = make_float4(ssh[j].x + ssum[j].x * inv, ssh[j].y + ssum[j].y * inv, ssh[j].z + ssum[j].z * inv,
+                                      ssh[j].w + ssum[j].w * inv);
+            float4 m2 = make_float4(ssq[j].x - ssum[j].x * ssum[j].x * inv, ssq[j].y - ssum[j].y * ssum[j].y * inv,
+                                    ssq[j].z - ssum[j].z * ssum[j].z * inv, ssq[j].w - ssum[j].w * ssum[j].w * inv);
 #pragma unroll
             for (int o = 8; o < 64; o <<= 1) {
-                ssum[j].x += __shfl_xor(ssum[j].x, o, 64); ssum[j].y += __shfl_xor(ssum[j].y, o, 64);
-                ssum[j].z += __shfl_xor(ssum[j].z, o, 64); ssum[j].w += __shfl_xor(ssum[j].w, o, 64);
-                ssq[j].x += __shfl_xor(ssq[j].x, o, 64); ssq[j].y += __shfl_xor(ssq[j].y, o, 64);
-                ssq[j].z += __shfl_xor(ssq[j].z, o, 64); ssq[j].w += __shfl_xor(ssq[j].w, o, 64);
+                const float nb = __shfl_xor(n, o, 64);
+                const float nt = n + nb;
+                const float wb = nt > 0.f ? nb / nt : 0.f;          // weight of the partner's mean
+                const float cf = n * wb;                            // n * nb / nt
+#define RIH_MERGE(c_)                                                        \
+    {                                                                        \
+        const float mb = __shfl_xor(mean.c_, o, 64), qb = __shfl_xor(m2.c_, o, 64); \
+        const float dl = mb - mean.c_;                                       \
+        mean.c_ += dl * wb;                                                  \
+        m2.c_ += qb + dl * dl * cf;                                          \
+    }
+                RIH_MERGE(x) RIH_MERGE(y) RIH_MERGE(z) RIH_MERGE(w)
+#undef RIH_MERGE
+                n = nt;
             }
-            const int n = nbase + j * 32 + (lane & 7) * 4;
-            if ((lane >> 3) == 0 && n < p.N && mbase < p.M) {
-                float* s0 = p.stats + (rb * 2 + 0) * p.N + n;
-                float* s1 = p.stats + (rb * 2 + 1) * p.N + n;
-                if (vec && n + 3 < p.N) {
-                    *reinterpret_cast<float4*>(s0) = ssum[j];
-                    *reinterpret_cast<float4*>(s1) = ssq[j];
+            const int nn = nbase + j * 32 + (lane & 7) * 4;
+            if ((lane >> 3) == 0 && nn < p.N && mbase < p.M) {
+                float* s0 = p.stats + (rb * 2 + 0) * p.N + nn;
+                float* s1 = p.stats + (rb * 2 + 1) * p.N + nn;
+                if (vec && nn + 3 < p.N) {
+                    *reinterpret_cast<float4*>(s0) = mean;
+                    *reinterpret_cast<float4*>(s1) = m2;
                 } else {
-                    const float a[4] = {ssum[j].x, ssum[j].y, ssum[j].z, ssum[j].w};
-                    const float b[4] = {ssq[j].x, ssq[j].y, ssq[j].z, ssq[j].w};
-                    for (int e = 0; e < 4 && n + e < p.N; ++e) { s0[e] = a[e]; s1[e] = b[e]; }
+                    const float a[4] = {mean.x, mean.y, mean.z, mean.w};
+                    const float b[4] = {m2.x, m2.y, m2.z, m2.w};
+                    for (int e = 0; e < 4 && nn + e < p.N; ++e) { s0[e] = a[e]; s1[e] = b[e]; }
                 }
             }
         }

@@ -48,8 +48,8 @@ def conv_bn(cm, bn, x, residual=None, relu=False, conv_relu=False, skip=False):
     """Conv2d followed by BatchNorm2d (Conv -> BN (-> ReLU) of the trunk, models/encoder.py:107-116, or Conv -> ReLU -> BN of
     the aux decoders / mid convs, :52-54 with conv_relu=True).  skip=True: also returns the alias of x for the block's skip
     path (ops.conv2d_skip).  In training the BatchNorm statistics come out of the convolution's GEMM epilogue when its
-    descriptor takes the split engine's fast path (ops.StatsHolder / rih_gemm_desc.stats): raw column sums per wave row block,
-    finished by rih_bn_stats_from_sums -- no statistics pass over the activation.  With conv_relu the ReLU's backward gate is
+    descriptor takes the split engine's fast path (ops.StatsHolder / rih_gemm_desc.stats): (mean, M2) per wave row block,
+    merged by rih_bn_stats_from_blocks -- no statistics pass over the activation.  With conv_relu the ReLU's backward gate is
     applied by the BatchNorm's backward kernel (it reads its input anyway): no separate relu_bwd pass."""
     f = ops.conv2d_skip if skip else ops.conv2d
     holder = ops.StatsHolder() if (ops.GEMM_STATS and bn.training) else None
@@ -59,7 +59,7 @@ def conv_bn(cm, bn, x, residual=None, relu=False, conv_relu=False, skip=False):
     finally:
         ops._STATS_REQUEST = None
     y, idt = out if skip else (out, None)
-    stats = ('sums', holder.part, holder.T) if (holder is not None and holder.part is not None) else None
+    stats = ('blocks', holder.part, holder.T, holder.rows) if (holder is not None and holder.part is not None) else None
     y = bn_act(bn, y, residual=residual, relu=relu, tile_stats=stats, input_relu=conv_relu)
     return (y, idt) if skip else y
 
@@ -328,7 +328,7 @@ class HRnet_encoder(nn.Module):
 
     @staticmethod
     def _head(seq, x):
-        return conv(seq[3], bn_act(seq[1], conv(seq[0], x), relu=True))
+        return conv(seq[3], conv_bn(seq[0], seq[1], x, relu=True))
 
     def forward(self, img):
         ys = self.hrnet(ops.nchw_to_nhwc(img, cpad=4))
@@ -368,13 +368,13 @@ class hrnet_mid(nn.Module):
 
     def forward(self, img_fmaps, hms_fmaps=None, dp_fmaps=None):
         """img_fmaps: branch maps, coarsest first (NHWC)."""
-        fmaps = [bn_act(seq[2], conv(seq[0], img_fmaps[i], relu=True)) for i, seq in enumerate(self.convs)]
+        fmaps = [conv_bn(seq[0], seq[2], img_fmaps[i], conv_relu=True) for i, seq in enumerate(self.convs)]
         fine_first = img_fmaps[::-1]
         y = self.incre_modules[0](fine_first[0])
         for i, ds in enumerate(self.downsamp_modules):
-            down = bn_act(ds[1], conv(ds[0], y), relu=True)
+            down = conv_bn(ds[0], ds[1], y, relu=True)
             y = ops.add_dropout(self.incre_modules[i + 1](fine_first[i + 1]), down)
-        y = bn_act(self.final_layer[1], conv(self.final_layer[0], y), relu=True)
+        y = conv_bn(self.final_layer[0], self.final_layer[1], y, relu=True)
         flush_batches_tracked()
         return ops.global_avgpool(y), fmaps
 

@@ -14,7 +14,7 @@ stride-2 3x3 conv+BN(+ReLU on all but the last) of every higher resolution j<i, 
 import torch.nn as nn
 
 from . import ops
-from .encoder import Bottleneck, bn_act, conv
+from .encoder import Bottleneck, conv, conv_bn
 
 # name -> (stage-1 bottlenecks, stage-1 width, [(modules, blocks per branch, widths), ...])   (hrnet.py:611-660)
 ARCH = {
@@ -36,7 +36,7 @@ def _cbr(cin, cout, k, stride, relu, bias=False):
 def run_cbr(seq, x, residual=None, relu=None):
     """Apply a Conv+BN(+ReLU) container; `residual` is added inside the BN kernel."""
     has_relu = len(seq) > 2 and isinstance(seq[2], nn.ReLU)
-    return bn_act(seq[1], conv(seq[0], x), residual=residual, relu=has_relu if relu is None else relu)
+    return conv_bn(seq[0], seq[1], x, residual=residual, relu=has_relu if relu is None else relu)
 
 
 class BasicBlock(nn.Module):
@@ -51,12 +51,10 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        c1 = self.conv1
-        out, idt = ops.conv2d_skip(x, c1.weight, c1.bias, stride=c1.stride[0], pad=c1.padding[0])
-        out = bn_act(self.bn1, out, relu=True)
+        out, idt = conv_bn(self.conv1, self.bn1, x, relu=True, skip=True)
         if self.downsample is not None:
-            idt = bn_act(self.downsample[1], conv(self.downsample[0], idt))
-        return bn_act(self.bn2, conv(self.conv2, out), residual=idt, relu=True)
+            idt = conv_bn(self.downsample[0], self.downsample[1], idt)
+        return conv_bn(self.conv2, self.bn2, out, residual=idt, relu=True)
 
 
 def make_layer(block, inplanes, planes, blocks, stride=1):
@@ -107,7 +105,7 @@ class HighResolutionModule(nn.Module):
                     acc = xs[j] if acc is None else ops.add_dropout(acc, xs[j])
                 elif j > i:
                     f = self.fuse_layers[i][j]
-                    low = bn_act(f[1], conv(f[0], xs[j]))
+                    low = conv_bn(f[0], f[1], xs[j])
                     acc = ops.nearest_up_add(low, acc, 2 ** (j - i))
                 else:
                     chain = self.fuse_layers[i][j]
@@ -158,8 +156,8 @@ class HighResolutionNet(nn.Module):
 
     def forward(self, x):
         """x: NHWC image (3 channels padded to 4).  Returns the four branch maps, finest first (NHWC)."""
-        x = bn_act(self.bn1, conv(self.conv1, x), relu=True)
-        x = bn_act(self.bn2, conv(self.conv2, x), relu=True)
+        x = conv_bn(self.conv1, self.bn1, x, relu=True)
+        x = conv_bn(self.conv2, self.bn2, x, relu=True)
         ys = [self.layer1(x)]
         for s in (2, 3, 4):
             trans = getattr(self, 'transition%d' % (s - 1))

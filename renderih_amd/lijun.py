@@ -23,7 +23,7 @@ from . import ops
 from .attn import DropCtx, MLP_res_block, SelfAttn, _drop_add, _lin_drop_res, _lin_pair, _xavier, img_ex
 from . import pose_head
 from .decoder import IMG_SIZE, decoder as _DecoderA
-from .encoder import FoldableTrunk, ResNetTrunk, bn_act, conv, conv1x1, flush_batches_tracked
+from .encoder import FoldableTrunk, ResNetTrunk, conv, conv1x1, conv_bn, flush_batches_tracked
 
 
 # ------------------------------------------------------------------------------------------------ encoder / mid
@@ -63,7 +63,7 @@ class resnet_mid(nn.Module):
 
     def forward(self, img_fmaps):
         gf = ops.global_avgpool(img_fmaps[0])
-        fmaps = [bn_act(seq[2], conv(seq[0], x, relu=True)) for seq, x in zip(self.convs, img_fmaps)]
+        fmaps = [conv_bn(seq[0], seq[2], x, conv_relu=True) for seq, x in zip(self.convs, img_fmaps)]
         flush_batches_tracked()
         return gf, fmaps
 

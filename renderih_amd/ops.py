@@ -172,8 +172,9 @@ GEMM_STATS = os.environ.get('RIH_GEMM_STATS', '1') == '1'
 
 class StatsHolder:
     def __init__(self):
-        self.part = None        # [T][2][N] raw column sums / sums of squares per row block
+        self.part = None        # [T][2][N]: (mean, centred sum of squares) per block of `rows` GEMM rows
         self.T = 0
+        self.rows = 0
 
 
 _STATS_REQUEST = None
@@ -231,7 +232,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
             and not isinstance(Cout, int)):
         rows_per = int(_L().rih_gemm_stats_rows(C.byref(d)))
         if rows_per > 0:
-            req.T = _cdiv(M, rows_per)
+            req.T, req.rows = _cdiv(M, rows_per), rows_per
             req.part = torch.empty((req.T, 2, N), device=Cout.device, dtype=torch.float32)
             d.stats = req.part.data_ptr()
     if PROFILE is not None:
@@ -895,15 +896,11 @@ class BatchNormFn(torch.autograd.Function):
         mask = torch.empty((x.numel() // 4,), device=x.device, dtype=torch.uint8) if relu else None
 
         def run():
-            if training and tile_stats is not None and tile_stats[0] == 'sums':     # rih_gemm's statistics epilogue
-                _, part, T = tile_stats
+            if training and tile_stats is not None and tile_stats[0] == 'blocks':   # rih_gemm's statistics epilogue
+                _, part, T, rpb = tile_stats
                 assert part.shape[2] == Cc
-                ws2 = None
-                n2 = int(lib.rih_bn_sums_ws_floats(T, Cc))
-                if n2 > 0:
-                    ws2 = torch.empty((n2,), device=x.device, dtype=torch.float32)
-                check(lib.rih_bn_stats_from_sums(part.data_ptr(), T, Cc, rows, eps, momentum, mean.data_ptr(), invstd.data_ptr(),
-                                                 _p(rmean), _p(rvar), _p(ws2), _stream()), 'rih_bn_stats_from_sums')
+                check(lib.rih_bn_stats_from_blocks(part.data_ptr(), T, Cc, rows, rpb, eps, momentum, mean.data_ptr(),
+                                                   invstd.data_ptr(), _p(rmean), _p(rvar), _stream()), 'rih_bn_stats_from_blocks')
             elif training and tile_stats is not None:       # statistics came out of the producing GEMM's epilogue (P3)
                 part, T, bm = tile_stats
                 assert T * bm == rows and part.shape[1] == Cc

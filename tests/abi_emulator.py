@@ -146,8 +146,8 @@ class EmulatedLib:
                     st = _f(d.stats, T * 2 * N).reshape(T, 2, N)
                     o32 = out.astype(np.float32)
                     for t in range(T):
-                        blk = o32[t * rp:(t + 1) * rp]
-                        st[t, 0], st[t, 1] = blk.sum(0), (blk * blk).sum(0)
+                        blk = o32[t * rp:(t + 1) * rp].astype(np.float64)
+                        st[t, 0], st[t, 1] = blk.mean(0), ((blk - blk.mean(0)) ** 2).sum(0)
         return 0
 
     def rih_gemm_stats_rows(self, dref):
@@ -163,13 +163,12 @@ class EmulatedLib:
             ok = ok and d.N % 4 == 0
         return (64 if d.tile in (0, 1) else 32) if ok else 0
 
-    def rih_bn_sums_ws_floats(self, T, Cc):
-        return 64 * 2 * Cc if T > 256 else 0
-
-    def rih_bn_stats_from_sums(self, part, T, Cc, rows, eps, momentum, mean, invstd, rmean, rvar, ws, stream):
+    def rih_bn_stats_from_blocks(self, part, T, Cc, rows, rpb, eps, momentum, mean, invstd, rmean, rvar, stream):
         p = _f(part, T * 2 * Cc).reshape(T, 2, Cc).astype(np.float64)
-        m = p[:, 0].sum(0) / rows
-        var = np.maximum(p[:, 1].sum(0) / rows - m * m, 0.0)
+        nk = np.full(T, rpb, np.float64)
+        nk[-1] = rows - (T - 1) * rpb
+        m = (nk[:, None] * p[:, 0]).sum(0) / rows
+        var = np.maximum((p[:, 1].sum(0) + (nk[:, None] * p[:, 0] ** 2).sum(0) - rows * m * m) / rows, 0.0)
         _f(mean, Cc)[:] = m
         _f(invstd, Cc)[:] = 1.0 / np.sqrt(var + eps)
         if rmean:

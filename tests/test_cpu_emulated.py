@@ -59,6 +59,7 @@ def test_paired_layers_host_logic():
     G.test_conv_bn_statistics_from_the_gemm_epilogue((2, 16, 16, 64, 128, 3, 1, 1, False))
     G.test_conv_bn_statistics_from_the_gemm_epilogue((3, 9, 7, 32, 72, 3, 2, 1, True))
     G.test_conv_bn_statistics_from_the_gemm_epilogue((1, 10, 10, 64, 36, 1, 1, 0, False))
+    G.test_conv_bn_epilogue_statistics_survive_a_large_mean()
     G.test_conv_bn_statistics_from_the_gemm_epilogue((2, 8, 8, 256, 256, 3, 1, 1, False))
     G.test_adam_one_launch_matches_torch(False, 1e-2)
     G.test_adam_one_launch_matches_torch(True, 1e-2)

@@ -719,7 +719,7 @@ def test_pack_cache_one_launch_equals_per_call_packs():
                                   (1, 10, 10, 64, 36, 1, 1, 0, False), (2, 8, 8, 256, 256, 3, 1, 1, False)])
 def test_conv_bn_statistics_from_the_gemm_epilogue(case):
     """encoder.conv_bn in training mode: the BatchNorm statistics come out of the convolution's GEMM epilogue (raw column sums
-    per wave row block, rih_gemm_desc.stats -> rih_bn_stats_from_sums) -- output, running buffers and all gradients equal the
+    per wave row block, rih_gemm_desc.stats -> rih_bn_stats_from_blocks) -- output, running buffers and all gradients equal the
     separate statistics pass to fp32 round-off, and torch.  Cases: one tile, ragged M / N with a strided 3x3, 1x1 on the 128x128
     tile, 40960 rows (640 row blocks -> the two-launch finish), N = 36 (ragged column tile), and a forward split-K
     convolution (8x8, K = 2304: no statistics path -> the separate pass)."""
@@ -776,3 +776,35 @@ def test_conv_bn_statistics_from_the_gemm_epilogue(case):
         assert_close(bn_g.running_var, bn_r.running_var, 1e-4, 1e-5, 'running_var')
     for a, b in zip(*outs):
         assert_close(a, b, 1e-4, 1e-5, 'epilogue statistics vs separate pass')
+
+
+def test_conv_bn_epilogue_statistics_survive_a_large_mean():
+    """Convolution outputs with |mean| / std ~ 2000: E[x^2] - mean^2 in fp32 would lose the variance entirely; the epilogue's
+    shifted sums + Chan merges (and the double-precision block merge) keep it: batch variance within 1e-3 of the fp64 value,
+    like the separate statistics pass."""
+    import copy
+    import torch.nn as nn
+    from renderih_amd import ops, encoder
+    d = dev()
+    g = torch.Generator().manual_seed(11)
+    x = 40.0 + 0.02 * torch.randn(2, 64, 16, 16, generator=g)
+    cm = nn.Conv2d(64, 128, 1, bias=False)
+    bn = nn.BatchNorm2d(128, momentum=1.0)           # running_var = this batch's (unbiased) variance
+    with torch.no_grad():
+        cm.weight.copy_((1.0 + 0.1 * torch.randn(128, 64, 1, 1, generator=g)) / 64.0)
+    y64 = F.conv2d(x.double(), cm.weight.double())
+    var64 = y64.var((0, 2, 3), unbiased=False).detach()
+    assert float((y64.mean((0, 2, 3)).abs() / var64.sqrt()).min().detach()) > 500
+    for use_stats in (True, False):
+        cm_g, bn_g = copy.deepcopy(cm).to(d), copy.deepcopy(bn).to(d)
+        old = ops.GEMM_STATS
+        ops.GEMM_STATS = use_stats
+        try:
+            with torch.no_grad():
+                encoder.conv_bn(cm_g, bn_g, nhwc(x).to(d))
+        finally:
+            ops.GEMM_STATS = old
+        n = x.numel() // 64
+        got_var = bn_g.running_var.cpu().double() * (n - 1) / n             # undo the unbiasing
+        # (the fp32 convolution output itself carries ~1e-6 * 40 of round-off per element against a std of 2.5e-3)
+        assert float(((got_var - var64).abs() / var64).max()) < 1e-2, (use_stats, float(((got_var - var64).abs() / var64).max()))
