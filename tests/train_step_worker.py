@@ -87,11 +87,10 @@ def main():
             zopt = ZeroRedundancyOptimizer([p for p in m.parameters() if p.requires_grad], optimizer_class=torch.optim.SGD,
                                            lr=1e-3)
             zstep = TrainStep(m, zopt, lambda out, lab: scalar_loss(out), (img, {}), use_graph=False)
-            zstep(img, {})
-            zstep(img, {})      # (the first call of a TrainStep learns the live set: two calls = two optimiser steps)
+            zstep(img, {})      # (the first call of a TrainStep learns the live set, then steps like every later call)
             for k, p in m.named_parameters():
                 p.data.copy_(before[k])
-            zstep(img, {})
+            zstep(img, {})      # plain SGD keeps no state: one step from `before` must land on `after_plain`
             flat = torch.cat([p.detach().flatten() for p in m.parameters()])
             ref = flat.clone()
             dist.broadcast(ref, 0)
@@ -99,10 +98,8 @@ def main():
             worst_z = max(float((p.detach() - after_plain[k]).abs().max() / (after_plain[k].abs().max() + 1e-30))
                           for k, p in m.named_parameters())
             assert worst_z < 1e-6, worst_z
-        # the model still works outside the helper (the trunk hook is inert there)
-        m.zero_grad(set_to_none=True)
-        scalar_loss(m(img)).backward()
-        assert m.encoder.resnet.conv1.weight.grad is not None
+        # (that the model still works outside the helper -- the trunk hook is inert there -- is checked on the GPU:
+        # tests/test_gpu_model.py::test_train_step_staged_graph_replay_matches_plain_backward)
     print('rank %d ok: %d live tensors in buckets of %s bytes, worst rel err %.1e' % (rank, n_live, sizes, worst))
     if world > 1:
         dist.barrier()
