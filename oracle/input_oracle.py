@@ -14,8 +14,13 @@ PARITY STATUS
     double precision, source coordinates are fixed point with 10 fractional bits (+ half of 1/32 for rounding) and reduced
     to 5 fractional bits, the four bilinear weights are 15-bit fixed point built from the 1/32-quantised fractions, the
     result is (sum + 2^14) >> 15, out-of-range taps read the border value 0.  In the golden generator the stub
-    `cv2.warpAffine` IS this function, so the warp itself is "parity unpinned" (no OpenCV to compare with); what the
-    fixtures pin is every step around it.
+    `cv2.warpAffine` IS this function, so the warp itself is "parity unpinned" against OpenCV (none to compare with); what the
+    fixtures pin is every step around it.  Its GEOMETRY (forward matrix inverted inside, axis order, pixel-centre convention,
+    border rule, bilinear weights) is cross-checked against an implementation that shares no code with it --
+    scipy.ndimage.affine_transform, order 1, 'grid-constant' -- on the reference's own augmentation matrices: equal to 1 grey
+    level wherever the four taps are inside the image (tests/test_input_pipeline.py::
+    test_warp_restatement_agrees_with_an_independent_bilinear_resampler).  What stays unpinned is OpenCV's exact fixed-point
+    rounding (1/32-pixel coordinates, 15-bit weights): a +-1 level question.
 """
 import math
 

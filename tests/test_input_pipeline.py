@@ -68,6 +68,41 @@ def test_warp_restatement_properties():
     assert (out[2:-2, 2:-2] == 200).all()
 
 
+def test_warp_restatement_agrees_with_an_independent_bilinear_resampler():
+    """The one unpinned piece (cv.warpAffine is not installable here) cross-checked against an implementation that shares no
+    code with it: scipy.ndimage.affine_transform (order 1, 'grid-constant' = taps outside the image read 0, like
+    BORDER_CONSTANT) on the reference's own augmentation matrices (`get_affine_mat`: rotation about the image centre, scale,
+    translation).  OpenCV quantises source coordinates to 1/32 pixel and its weights to 15 bits; on an image whose gradient is
+    <= 9 grey levels per pixel that is worth < 1 level, so the two must agree to 1 level wherever all four taps lie inside the
+    source image (and to 255/32 levels where a tap crosses its edge).  This
+    pins the matrix convention (forward matrix, inverted inside), the axis order, the centre convention (integer coordinates
+    = pixel centres) and the border rule; the exact fixed-point rounding of OpenCV stays unpinned."""
+    from scipy import ndimage
+    S = 96
+    yy, xx = np.mgrid[0:S, 0:S].astype(np.float64)
+    img = np.stack([127 + 90 * np.sin(xx / 11.0 + c) * np.cos(yy / 13.0 - c) for c in (0.0, 1.0, 2.0)], -1)
+    img = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    assert np.abs(np.diff(img.astype(np.int32), axis=0)).max() <= 9 and np.abs(np.diff(img.astype(np.int32), axis=1)).max() <= 9
+    rs = np.random.RandomState(3)
+    worst = 0
+    for _ in range(12):
+        theta, scale = rs.uniform(-60, 60), rs.uniform(0.7, 1.4)
+        u, v = rs.uniform(-12, 12), rs.uniform(-12, 12)
+        A = input_oracle.get_affine_mat(theta, scale, u, v, S, S)[:2]
+        got = input_oracle.warp_affine_u8(img, A, (S, S)).astype(np.int32)
+        m = input_oracle.invert_affine(A)               # destination (x, y) -> source (m0 x + m1 y + m2, m3 x + m4 y + m5)
+        mat = np.array([[m[4], m[3]], [m[1], m[0]]])    # scipy works in (row, col) = (y, x)
+        ref = np.stack([ndimage.affine_transform(img[..., c].astype(np.float64), mat, offset=[m[5], m[2]], output_shape=(S, S),
+                                                 order=1, mode='grid-constant', cval=0.0) for c in range(3)], -1)
+        diff = np.abs(got - np.rint(ref)).max(-1)
+        sx, sy = m[0] * xx + m[1] * yy + m[2], m[3] * xx + m[4] * yy + m[5]
+        inside = (sx >= 0) & (sx <= S - 1) & (sy >= 0) & (sy <= S - 1)       # all four taps inside the source image
+        worst = max(worst, int(diff[inside].max()))
+        # where a tap crosses the image edge the signal jumps to the border value: 1/32 pixel is worth up to 255/32 levels there
+        assert diff[inside].max() <= 1 and diff.max() <= 8 and diff.mean() < 0.25, (theta, scale, u, v, diff.max(), diff.mean())
+    assert worst <= 1
+
+
 def prepare_vs_fixtures(dev):
     """renderih_amd.input_pipeline.BatchPreparer against the reference's own outputs, one sample per call and the three
     64-pixel cases as one batch (per-sample matrices, flips and brightness in one launch)."""
