@@ -322,6 +322,124 @@ def test_gemm_descriptor_fuzz_against_emulator():
     assert checked >= 38
 
 
+def test_batched_entry_points_fuzz_against_emulator():
+    """Differential test of the descriptor-list entry points (descriptors by value in the kernel argument, several launches when
+    the list exceeds a pack): rih_splitk_reduce_multi (pack 60), rih_ln_param_final_multi (100), rih_pack_conv_weight_multi (56)
+    and rih_adam_multi -- list lengths on both sides of the pack sizes, ragged shapes, bias rows, accumulate, channel padding --
+    real kernels against the numpy restatement; and the statistics epilogue of rih_gemm (rih_gemm_desc.stats) incl. a ragged
+    last row block against per-block numpy means / M2."""
+    import ctypes as C
+    import numpy as np
+    from abi_emulator import EmulatedLib
+    from host_kernels import load
+    from renderih_amd._lib import GemmDesc, LnFinalDesc, PackDesc, ReduceDesc
+    host, emu = load(), EmulatedLib()
+    rs = np.random.RandomState(11)
+    f32 = np.float32
+
+    # ---- split-K reductions
+    for n in (1, 59, 61, 125):
+        keep, descs = [], []
+        for _ in range(n):
+            S, taps, cin, cv = int(rs.randint(1, 6)), int(rs.choice([1, 4, 9])), int(rs.choice([4, 8, 12])), 0
+            cv = cin if rs.rand() < 0.7 else cin - 1
+            M, N = taps * cin, int(rs.choice([3, 8, 33, 40]))
+            has_db, acc = rs.rand() < 0.4, int(rs.rand() < 0.3)
+            Mp = M + 4 if has_db else M
+            P = rs.randn(S, Mp, N).astype(f32)
+            init = rs.randn(N * cv * taps).astype(f32)
+            keep.append((P, init, has_db))
+            descs.append((S, Mp, M, N, cin, taps, cv, acc))
+        outs = []
+        for lib in (host, emu):
+            arr = (ReduceDesc * n)()
+            dst = [k[1].copy() for k in keep]
+            db = [np.full(d[3], 7.0, f32) for d in descs]
+            for a, (P, _, has_db), d, o, b in zip(arr, keep, descs, dst, db):
+                a.P, a.dst, a.db = P.ctypes.data, o.ctypes.data, (b.ctypes.data if has_db else 0)
+                a.S, a.Mp, a.M, a.N, a.Cin, a.taps, a.CinValid, a.accumulate = d
+            assert lib.rih_splitk_reduce_multi(arr, n, None) == 0
+            outs.append((dst, db))
+        for i in range(n):
+            assert np.allclose(outs[0][0][i], outs[1][0][i], rtol=1e-5, atol=1e-5), ('reduce', n, i, descs[i])
+            assert np.allclose(outs[0][1][i], outs[1][1][i], rtol=1e-5, atol=1e-5), ('bias gradient', n, i, descs[i])
+
+    # ---- LayerNorm parameter-gradient finals
+    for n in (1, 99, 101, 130):
+        shapes = [(int(rs.choice([5, 64, 200])), int(rs.randint(1, 40))) for _ in range(n)]      # (D, nblk)
+        ws = [rs.randn(nb, 2, D).astype(f32) for D, nb in shapes]
+        outs = []
+        for lib in (host, emu):
+            arr = (LnFinalDesc * n)()
+            dg = [np.zeros(D, f32) for D, _ in shapes]
+            db = [np.zeros(D, f32) for D, _ in shapes]
+            for a, w, g, b, (D, nb) in zip(arr, ws, dg, db, shapes):
+                a.ws, a.dg, a.db, a.D, a.nblk = w.ctypes.data, g.ctypes.data, b.ctypes.data, D, nb
+            assert lib.rih_ln_param_final_multi(arr, n, None) == 0
+            outs.append((dg, db))
+        for i in range(n):
+            assert np.allclose(outs[0][0][i], outs[1][0][i], rtol=1e-5, atol=1e-5) and \
+                np.allclose(outs[0][1][i], outs[1][1][i], rtol=1e-5, atol=1e-5), ('ln final', n, i, shapes[i])
+
+    # ---- weight packs
+    for n in (1, 55, 57, 115):
+        items = []
+        for _ in range(n):
+            Cout, Cin, KH = int(rs.choice([3, 8, 20])), int(rs.choice([3, 4, 9])), int(rs.choice([1, 2, 3, 4]))
+            KW = KH
+            cpad = (Cin + 3) // 4 * 4
+            mode = int(rs.randint(0, 2))
+            if mode == 0:
+                f = (Cout, Cin, KH, KW, cpad, 0, 0, 0, 1, KH, KW)
+                size = KH * KW * cpad * Cout
+            else:
+                step = int(rs.choice([1, 2])) if KH > 1 else 1
+                kh0, kw0 = int(rs.randint(0, step)), int(rs.randint(0, step))
+                Th, Tw = len(range(kh0, KH, step)), len(range(kw0, KW, step))
+                if Th == 0 or Tw == 0:
+                    kh0 = kw0 = 0
+                    Th, Tw = len(range(0, KH, step)), len(range(0, KW, step))
+                f = (Cout, Cin, KH, KW, cpad, 1, kh0, kw0, step, Th, Tw)
+                size = Th * Tw * Cout * cpad
+            items.append((rs.randn(Cout, Cin, KH, KW).astype(f32), f, size))
+        outs = []
+        for lib in (host, emu):
+            arr = (PackDesc * n)()
+            dst = [np.full(sz + 4, 7.0, f32) for _, _, sz in items]
+            for a, (w, f, _), o in zip(arr, items, dst):
+                a.w, a.dst = w.ctypes.data, o.ctypes.data
+                (a.Cout, a.Cin, a.KH, a.KW, a.CinPad, a.mode, a.kh0, a.kw0, a.step, a.Th, a.Tw) = f
+            assert lib.rih_pack_conv_weight_multi(arr, n, None) == 0
+            outs.append(dst)
+        for i in range(n):
+            assert np.array_equal(outs[0][i], outs[1][i]), ('pack', n, i, items[i][1])
+            assert (outs[0][i][items[i][2]:] == 7.0).all()
+
+    # ---- statistics epilogue: per-row-block (mean, M2) of the stored tile, ragged last block
+    for (M, N, K, tile, relu) in ((150, 72, 64, 2, 1), (300, 128, 96, 1, 0), (128, 40, 32, 0, 0)):
+        A, B = rs.randn(M, K).astype(f32) + 3.0, rs.randn(N, K).astype(f32)
+        d = GemmDesc()
+        Cc = np.zeros((M, N), f32)
+        d.A, d.B, d.C = A.ctypes.data, B.ctypes.data, Cc.ctypes.data
+        d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ldr = M, N, K, K, K, N, N
+        d.a_mode, d.b_mode, d.nb1, d.nb2, d.splitk, d.alpha, d.relu = 0, 1, 1, 1, 1, 1.0, relu
+        (d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.strideA, d.upS, d.padH, d.padW) = (1, 1, K, 1, 1, 1, 1, 1, 1, 0, 0)
+        d.tile, d.engine = tile, 1
+        rp = host.rih_gemm_stats_rows(C.byref(d))
+        assert rp == emu.rih_gemm_stats_rows(C.byref(d)) == (64 if tile < 2 else 32)
+        T = -(-M // rp)
+        st = np.full((T, 2, N), 7.0, f32)
+        d.stats = st.ctypes.data
+        assert host.rih_gemm(C.byref(d), None) == 0
+        ref = A.astype(np.float64) @ B.astype(np.float64).T
+        if relu:
+            ref = np.maximum(ref, 0)
+        for t in range(T):
+            blk = ref[t * rp:(t + 1) * rp]
+            assert np.allclose(st[t, 0], blk.mean(0), rtol=1e-5, atol=1e-5), ('block mean', M, N, t)
+            assert np.allclose(st[t, 1], ((blk - blk.mean(0)) ** 2).sum(0), rtol=2e-4, atol=1e-4), ('block M2', M, N, t)
+
+
 @pytest.mark.skipif(not os.environ.get('HIPCPU_MORE'), reason='set HIPCPU_MORE=1: ~1 min of extra scheduling runs')
 @pytest.mark.parametrize('sched', ['reverse', 'random'])
 def test_kernels_are_schedule_independent(sched):
