@@ -64,6 +64,7 @@ class Adam(torch.optim.Optimizer):
         """Validate, create state, and build the launch plan of a group for the current set of tensors: a list of
         (step counters, device table, block maps, nblocks) -- one entry per distinct step count (one, unless a checkpoint
         was loaded or parameters joined later: a launch has one bias correction)."""
+        ops._chk(*params)                   # HIP kernel: GPU tensors only (the CPU test emulation patches this check)
         for p in params:
             if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse:
                 raise RuntimeError('renderih_amd.optim: fp32 dense parameters and gradients only')

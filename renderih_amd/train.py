@@ -340,7 +340,15 @@ class TrainStep:
             for k, v in labels.items():
                 if v is not self.labels[k]:
                     self.labels[k].copy_(v, non_blocking=True)
-        return self._step_graph() if self.use_graph else self._step_eager()
+        try:
+            return self._step_graph() if self.use_graph else self._step_eager()
+        finally:
+            # whatever happened in the step (an exception included): no later forward pass may find this step's packed
+            # weights installed as fresh
+            if self.packs is not None:
+                self.packs.stale()
+                if ops._PACK is self.packs:
+                    ops._PACK = None
 
     def comm_ms_exposed(self):
         """Median over the recorded steps of the time the compute stream waited for the gradient exchange after the last

@@ -185,3 +185,13 @@ def test_checkpoint_conventions_round_trip(tmp_path):
     wrapped.module = src
     save_checkpoint(wrapped, p1, 1)
     assert set(torch.load(p1)['network']) == set(src.state_dict())
+
+
+def test_one_launch_adam_refuses_cpu_tensors():
+    """renderih_amd.optim.Adam drives a HIP kernel: CPU parameters raise (no fallback), like every op of the package."""
+    import pytest
+    from renderih_amd import optim
+    p = torch.zeros(8, requires_grad=True)
+    p.grad = torch.ones(8)
+    with pytest.raises(RuntimeError, match='GPU tensors'):
+        optim.Adam([p], lr=1e-3).step()
