@@ -63,10 +63,9 @@ def test_paired_layer_kernels():
     G.test_layernorm_pair(9, 200, True, True, False)
     G.test_patch_conv_pair(2, 8, 32, 16, 2)
     G.test_patch_conv_pair(1, 16, 64, 48, 4)                    # K = 1024: forward split-K + finish
-    G.test_deferred_reductions_equal_immediate()
-    G.test_pack_cache_one_launch_equals_per_call_packs()
-    G.test_conv_bn_statistics_from_the_gemm_epilogue((1, 8, 16, 64, 128, 3, 1, 1, False))      # one 128x128 tile
-    G.test_conv_bn_statistics_from_the_gemm_epilogue((3, 9, 7, 32, 72, 3, 2, 1, True))
+    # (the descriptor-list kernels behind ops.deferred_reductions / ops.PackCache are fuzzed at the ABI level below,
+    # test_batched_entry_points_fuzz_against_emulator; their host logic runs in tests/test_cpu_emulated.py)
+    G.test_conv_bn_statistics_from_the_gemm_epilogue((3, 9, 7, 32, 72, 3, 2, 1, True))          # statistics epilogue + ReLU gate
     G.test_conv_bn_epilogue_statistics_survive_a_large_mean()
     G.test_adam_one_launch_matches_torch(False, 1e-2)
 
