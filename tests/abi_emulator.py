@@ -75,7 +75,19 @@ class EmulatedLib:
                     pl = (raw.astype(np.uint32) << 16).view(np.float32)
                     self._a2 = np.ascontiguousarray(pl[0] + pl[1] + pl[2], np.float32)
                     Ab = self._a2.ctypes.data
-                if d.a_mode != 1:
+                plain = (taps == 1 and d.strideA == 1 and d.upS == 1 and d.padH == 0 and d.padW == 0 and d.H == d.Ho
+                         and d.W == d.Wo and d.a_mode != 2)
+                A = None
+                if plain and d.a_mode == 0 and K > 0:
+                    # fast path (the emulation's only optimisation): dense rows, no gather -- A[m, k] = mem[m * lda + k]
+                    A = np.lib.stride_tricks.as_strided(_f(Ab, (M - 1) * d.lda + K), (M, K), (4 * d.lda, 4)).copy()
+                elif plain and d.a_mode == 1 and K > 0:
+                    rows = d.ones_row if d.ones_row > 0 else M          # A[m, k] = mem[k * lda + m]; rows >= ones_row are not read
+                    A = np.zeros((M, K), np.float32)
+                    A[:rows] = np.lib.stride_tricks.as_strided(_f(Ab, (K - 1) * d.lda + rows), (rows, K), (4, 4 * d.lda))
+                if A is not None:
+                    pass
+                elif d.a_mode != 1:
                     m = np.arange(M)
                     wo, t = m % d.Wo, m // d.Wo
                     ho, img = t % d.Ho, t // d.Ho
@@ -101,44 +113,52 @@ class EmulatedLib:
                     idx = ((img[None, :] * d.H + hi) * d.W + wi) * d.lda + ci[:, None]
                     if d.ones_row > 0:      # rows >= ones_row are not read from memory
                         valid[d.ones_row:] = False
-                idx = np.where(valid, idx, 0)
-                A = self._gather(Ab, idx, valid)
+                if A is None:
+                    idx = np.where(valid, idx, 0)
+                    A = self._gather(Ab, idx, valid)
                 if d.a_mode == 1 and d.ones_row > 0:
                     A[d.ones_row, :] = 1.0
-                kk, nn = np.meshgrid(np.arange(K), np.arange(N), indexing='ij')
                 if d.b_mode == 2:       # pre-split planes [3][N][ldb] bf16: B = hi + mid + lo
                     raw = np.ctypeslib.as_array((C.c_uint16 * (3 * N * d.ldb)).from_address(int(d.B))).reshape(3, N, d.ldb)
                     planes = (raw.astype(np.uint32) << 16).view(np.float32)
                     Bm = (planes[0] + planes[1] + planes[2])[:, :K].T.astype(np.float32)
-                else:
-                    bidx = kk * d.ldb + nn if d.b_mode == 0 else nn * d.ldb + kk
-                    Bm = self._gather(Bb, bidx, np.ones_like(bidx, bool)) if K > 0 else np.zeros((0, N), np.float32)
+                elif K == 0:
+                    Bm = np.zeros((0, N), np.float32)
+                elif d.b_mode == 0:     # B[k, n] = mem[k * ldb + n]
+                    Bm = np.lib.stride_tricks.as_strided(_f(Bb, (K - 1) * d.ldb + N), (K, N), (4 * d.ldb, 4))
+                else:                   # B[k, n] = mem[n * ldb + k]
+                    Bm = np.lib.stride_tricks.as_strided(_f(Bb, (N - 1) * d.ldb + K), (K, N), (4, 4 * d.ldb))
                 crow = np.arange(M)
                 if d.cS > 1:        # strided output rows (parity class of a strided-conv data gradient)
                     assert d.a_mode != 1 and d.splitk == 1 and not d.R
                     cj, ct = crow % d.Wo, crow // d.Wo
                     ci_, cimg = ct % d.Ho, ct // d.Ho
                     crow = (cimg * d.cH + ci_ * d.cS + d.cOH) * d.cW + cj * d.cS + d.cOW
-                cm, cn = np.meshgrid(crow, np.arange(N), indexing='ij')
+                def c_window(base):     # the [M][N] window of C as a writable strided view (dense rows) or via row indices
+                    if d.cS > 1:
+                        return None
+                    return np.lib.stride_tricks.as_strided(_f(base, (M - 1) * d.ldc + N), (M, N), (4 * d.ldc, 4))
                 if d.splitk > 1:
                     assert d.kchunk % 32 == 0
                     for s in range(d.splitk):
                         k0, k1 = s * d.kchunk, min(K, (s + 1) * d.kchunk)
-                        part = A[:, k0:k1] @ Bm[k0:k1]
-                        mem = _f(Cb + 4 * s * d.sCsplit, (M - 1) * d.ldc + N)
-                        mem[(cm * d.ldc + cn).ravel()] = part.ravel()
+                        c_window(Cb + 4 * s * d.sCsplit)[:] = A[:, k0:k1] @ Bm[k0:k1]
                     continue
                 out = np.float32(d.alpha) * (A @ Bm)
                 if d.bias:
                     out = out + _f(d.bias + 4 * b1 * d.sBias1, N)[None, :]
                 if d.R:
-                    r = _f(d.R + 4 * b1 * d.sR1, (M - 1) * d.ldr + N)
-                    lm, ln = np.meshgrid(np.arange(M), np.arange(N), indexing='ij')
-                    out = out + r[(lm * d.ldr + ln).ravel()].reshape(M, N)
+                    out = out + np.lib.stride_tricks.as_strided(_f(d.R + 4 * b1 * d.sR1, (M - 1) * d.ldr + N), (M, N),
+                                                                (4 * d.ldr, 4))
                 if d.relu:
                     out = np.maximum(out, 0)
-                mem = _f(Cb, int(crow.max()) * d.ldc + N)
-                mem[(cm * d.ldc + cn).ravel()] = out.astype(np.float32).ravel()
+                win = c_window(Cb)
+                if win is not None:
+                    win[:] = out
+                else:
+                    cm, cn = np.meshgrid(crow, np.arange(N), indexing='ij')
+                    mem = _f(Cb, int(crow.max()) * d.ldc + N)
+                    mem[(cm * d.ldc + cn).ravel()] = out.astype(np.float32).ravel()
                 if d.stats:         # statistics epilogue: column sums / sums of squares per block of stats_rows GEMM rows
                     rp = self.rih_gemm_stats_rows(dref)
                     assert rp > 0, 'stats requested on a descriptor without the statistics path'
@@ -283,9 +303,9 @@ class EmulatedLib:
         m = np.arange(M)
         tap, ci = m // Cin, m % Cin
         ok = ci < CinValid
-        for n in range(N):
-            o = (n * CinValid + ci[ok]) * taps + tap[ok]
-            out[o] = (out[o] if accumulate else 0) + p[ok, n]
+        o = ((np.arange(N)[None, :] * CinValid + ci[ok][:, None]) * taps + tap[ok][:, None]).ravel()     # [rows ok][N], unique
+        v = p[ok].ravel()
+        out[o] = (out[o] + v) if accumulate else v
         return 0
 
     def rih_splitk_finish(self, P, S, M, N, Cp, ldc, bias, R, ldr, alpha, relu, stream):
