@@ -136,8 +136,8 @@ class FoldedTrunk:
     stays fp32, but the folded form computes v*s - m*s where the unfolded one computes (v - m)*s: both terms are rounded
     before they cancel, and the network output moves by a few 1e-5 relative (2.9e-5 on the test fixture) -- inside the 1e-4
     parity bar, yet a third of it, which is why this is not the default.  Opt-in
-    (`ResNetSimple.fold_batchnorm()` or RIH_FOLD_BN=1): not yet measured on a GPU.  Snapshot semantics: rebuild after
-    changing weights."""
+    (`ResNetSimple.fold_batchnorm()` or RIH_FOLD_BN=1); green on MI355X since round 2 (tests/test_gpu_paths.py).  Snapshot
+    semantics: rebuild after changing weights."""
 
     def __init__(self, trunk):
         if trunk.training:

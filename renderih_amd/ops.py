@@ -111,8 +111,8 @@ def _seed_dev():
 PAIR_HANDS = os.environ.get('RIH_PAIR_HANDS', '1') != '0'
 
 # Pre-split weight operands (rih_gemm b_mode 2): the bf16 hi/mid/lo planes of a convolution weight are produced once per
-# use by rih_presplit_conv_weight instead of inside the GEMM's loader.  OFF by default: written and verified on the
-# HIP-on-CPU harness (tests/test_kernels_on_cpu.py) after this round's GPU budget was spent -- not yet measured.
+# use by rih_presplit_conv_weight instead of inside the GEMM's loader.  OFF by default: measured in round 2 -- 45.9 ms per step
+# against 45.2 (=2: 50.1 ms); the split GEMMs are power-bound, not conversion-bound (profiles/r02/bench_m1_*).
 PRESPLIT = os.environ.get('RIH_PRESPLIT', '0') in ('1', '2')
 # RIH_PRESPLIT=2 additionally pre-splits the ACTIVATION operand of those GEMMs with a standalone pass (rih_gemm a_mode 2):
 # the experiment that tells whether producers (BatchNorm apply / backward) should emit bf16 planes themselves.
@@ -1233,8 +1233,8 @@ def layernorm_pair_skip(x, mL, mR):
     return LayerNormPairFn.apply(x, None, mL.weight, mR.weight, mL.bias, mR.bias, mL.eps, False, True)
 
 
-# One-launch attention forward (csrc/rih_attn.hip) instead of QK^T GEMM + softmax + PV GEMM.  OFF by default: verified on
-# the HIP-on-CPU harness only (written after the round's GPU budget was spent), not yet measured.
+# One-launch attention forward (csrc/rih_attn.hip) instead of QK^T GEMM + softmax + PV GEMM.  OFF by default: measured in
+# round 2 at 46.7 ms per step against 45.2 (profiles/r02/bench_m1_fusedattn.log).
 FUSED_ATTN = os.environ.get('RIH_FUSED_ATTN', '0') == '1'
 
 
