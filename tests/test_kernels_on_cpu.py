@@ -447,7 +447,8 @@ def test_kernels_are_schedule_independent(sched):
     its result.  Subset: implicit-GEMM fast path, the four-slot-ring kernel, wavefront-reduction kernels, MANO, loss."""
     import subprocess
     env = dict(os.environ, HIPCPU_SCHED=sched)
-    sel = 'conv2d_kernels or tile4 or mesh_loss or metrics_and_pose or mano_kernels or graph_and_resampling or paired_layer'
+    sel = ('conv2d_kernels or tile4 or mesh_loss or metrics_and_pose or mano_kernels or mano_fused or graph_and_resampling or '
+           'paired_layer or norm_softmax or batched_entry')
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k', sel, '-p', 'no:cacheprovider'],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
