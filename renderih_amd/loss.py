@@ -183,7 +183,9 @@ class FusedMeshLoss:
         when the trainer calls `set_epoch()` (or this loss eagerly) at a later epoch."""
         w, cnt = self.weights(B)
         vals = tuple(w) + tuple(cnt)
-        key = ('wdev', device)
+        # one slot per (device, batch size): evaluating this loss on another batch size between two replays of a captured
+        # step must not rewrite the weights / counts that the graph reads
+        key = ('wdev', device, B)
         if key not in self._dev:
             self._dev[key] = [torch.zeros(14, device=device, dtype=torch.float32), None]
         slot = self._dev[key]
@@ -199,8 +201,13 @@ class FusedMeshLoss:
         """Move the epoch gate (edge term on from NORM_EPOCH).  With a replayed hipGraph pass the captured batch size and
         device so that the device-resident weights are refreshed in place."""
         self.epoch = epoch
-        if B is not None and device is not None and self.Vc is not None:
+        if self.Vc is None:
+            return
+        if B is not None and device is not None:
             self.device_weights(B, torch.device(device))
+        else:                                       # refresh every slot that exists (all captured batch sizes / devices)
+            for key in [k for k in self._dev if k[0] == 'wdev']:
+                self.device_weights(key[2], key[1])
 
     def topo(self, side, device):
         from ._lib import MeshTopo
@@ -216,8 +223,11 @@ class FusedMeshLoss:
         return self._dev[key][1]
 
     def __call__(self, epoch, result, handDictList, v2d_l, v2d_r, v3d_l, v3d_r, root_rel):
-        """Returns (total, terms) with terms = [total, vert2d, vert3d, joint, norm, edge, coarse3d, coarse2d]."""
-        self.epoch = epoch
+        """Returns (total, terms) with terms = [total, vert2d, vert3d, joint, norm, edge, coarse3d, coarse2d].
+        epoch=None keeps the gate where `set_epoch()` put it (what a `loss_fn` handed to TrainStep should pass: a literal 0
+        there would switch the edge term off again on every eager step)."""
+        if epoch is not None:
+            self.epoch = epoch
         assert len(handDictList) == 1, 'one coarse level (the reference decoder emits exactly one)'
         hd = handDictList[0]
         Vc = hd['verts3d']['left'].shape[1]

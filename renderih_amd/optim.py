@@ -2,8 +2,9 @@
 
 Drop-in for the optimizer the reference's trainer builds (core/gcn_trainer.py:127 `torch.optim.Adam(optim_params, lr=...)`):
 same constructor arguments, same update rule (amsgrad / maximize / capturable / differentiable are not supported and raise),
-same `state_dict()` layout -- per parameter `step` (0-dim float tensor), `exp_avg`, `exp_avg_sq` -- so checkpoints move between
-the two in both directions.
+same `state_dict()` layout -- per parameter its OWN `step` (0-dim float tensor), `exp_avg`, `exp_avg_sq` -- so checkpoints move
+between the two in both directions and either optimizer can keep stepping after the load (tests/test_gpu_ops.py,
+tests/test_cpu_emulated.py).
 
 Why: torch's fused Adam walks the 843 gradient-carrying tensors of the pose network in 24 multi-tensor launches of ~37 us
 (0.89 ms per step on MI355X, profiles/r02); the update needs 4 reads + 3 writes per element = 1.0 GB, i.e. ~0.2 ms of HBM
@@ -53,10 +54,11 @@ class Adam(torch.optim.Optimizer):
         dev = new[0].device
         m = torch.zeros(max(n, 4), device=dev, dtype=torch.float32)
         v = torch.zeros(max(n, 4), device=dev, dtype=torch.float32)
-        step = torch.zeros((), dtype=torch.float32)     # ONE counter object shared by the parameters initialised together
         for p, o in zip(new, offs):
             st = self.state[p]
-            st['step'] = step
+            # a distinct 0-dim counter per parameter, as torch.optim.Adam keeps it: a state_dict() taken here and resumed in
+            # torch's own Adam advances every tensor once per parameter, so a shared object would run N times too fast there
+            st['step'] = torch.zeros((), dtype=torch.float32)
             st['exp_avg'] = m[o:o + p.numel()].view_as(p)
             st['exp_avg_sq'] = v[o:o + p.numel()].view_as(p)
 
@@ -75,15 +77,20 @@ class Adam(torch.optim.Optimizer):
             st = self.state[p]
             if not st['exp_avg'].is_contiguous() or not st['exp_avg_sq'].is_contiguous():      # e.g. a loaded checkpoint
                 st['exp_avg'], st['exp_avg_sq'] = st['exp_avg'].contiguous(), st['exp_avg_sq'].contiguous()
-        by_counter = {}
+        by_step, seen = {}, {}
         for p in params:
-            c = self.state[p]['step']
-            by_counter.setdefault(id(c), (c, []))[1].append(p)
-        by_step = {}
-        for c, ps in by_counter.values():
+            st = self.state[p]
+            c = st['step']
+            if not torch.is_tensor(c):              # checkpoints of old torch versions keep a Python number
+                c = st['step'] = torch.tensor(float(c), dtype=torch.float32)
+            elif c.device.type != 'cpu' or c.dim() != 0:
+                c = st['step'] = c.detach().to('cpu', torch.float32).reshape(())
+            if id(c) in seen:                       # a checkpoint written with ONE counter object for many parameters
+                c = st['step'] = c.clone()
+            seen[id(c)] = True
             e = by_step.setdefault(int(c), ([], []))
             e[0].append(c)
-            e[1].extend(ps)
+            e[1].append(p)
         chunk = int(_lib.load().rih_adam_chunk())
         dev = params[0].device
         plan = []
@@ -133,8 +140,7 @@ class Adam(torch.optim.Optimizer):
                                              float(group['lr']), float(b1), float(b2), float(group['eps']),
                                              float(group['weight_decay']), s + 1, 1 if self._decoupled else 0,
                                              ops._stream()), 'rih_adam_multi')
-                for c in counters:
-                    c += 1
+                torch._foreach_add_(counters, 1)     # every parameter's own counter, one host call
             if len(t.plan) > 1:
                 t.key = None            # distinct step counts: regroup next time (they may have converged or been reloaded)
         return loss

@@ -86,7 +86,6 @@ class TrainStep:
         self.cuda = dev.type == 'cuda'
         self._bounds = self._cut = None
         self._cutting = False
-        self._bound = False
         if self.nstage == 3:
             self._hook = _trunk(model).register_forward_hook(self._grab)
         self.live = None            # per stage: indices of the parameters that receive a gradient
@@ -196,8 +195,10 @@ class TrainStep:
         if self.order is not None:
             self.order.append(('reduce', i))
         if not self.exchange:
-            if not self._bound:
-                for j in live:
+            # (re-)bind every step: the reference loop's `optimizer.zero_grad()` sets `.grad` to None, and an optimizer
+            # silently skips such parameters -- an identity check per tensor costs ~0.1 ms of otherwise idle host time
+            for j in live:
+                if g[j].grad is not grads[j]:
                     g[j].grad = grads[j]
             return None
         src = [grads[j] for j in live]
@@ -211,8 +212,8 @@ class TrainStep:
             torch._foreach_copy_(self.views[i], src)
             self.flat[i].mul_(1.0 / self.world)
             dist.all_reduce(self.flat[i], op=dist.ReduceOp.SUM, group=self.group)
-        if not self._bound:
-            for j, v in zip(live, self.views[i]):
+        for j, v in zip(live, self.views[i]):
+            if g[j].grad is not v:
                 g[j].grad = v
         return None
 
@@ -286,11 +287,27 @@ class TrainStep:
         seed_word = ops.DROPOUT_SEED_TENSOR
         cap = torch.cuda.Stream(device=self.img.device)
         cap.wait_stream(torch.cuda.current_stream())
+        # The two warm-up steps below are REAL steps on `example_batch` (lazy tables, allocator, bucket setup, optimizer
+        # state allocation) -- a placeholder batch would otherwise perturb a freshly loaded checkpoint.  Everything they
+        # change is put back afterwards: parameters, buffers (BatchNorm running statistics, num_batches_tracked) and the
+        # optimizer state (moments, step counts), so construction leaves the training trajectory untouched.
+        import copy
+        with torch.no_grad():
+            saved_p = [p.detach().clone() for p in self.model.parameters()]
+            saved_b = [b.detach().clone() for b in self.model.buffers()]
+        saved_opt = copy.deepcopy(self.opt.state_dict())
         with torch.cuda.stream(cap):
-            for _ in range(2):                      # warm-up on the capture stream: lazy tables, allocator, bucket setup
+            for _ in range(2):                      # warm-up on the capture stream
                 self._step_eager()
+            with torch.no_grad():
+                for p, s_ in zip(self.model.parameters(), saved_p):
+                    p.copy_(s_)
+                for b, s_ in zip(self.model.buffers(), saved_b):
+                    b.copy_(s_)
         torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
+        self.opt.load_state_dict(saved_opt)
+        del saved_p, saved_b, saved_opt
         if self.exchange:
             import torch.distributed as dist
             dist.barrier(group=self.group)
@@ -328,7 +345,6 @@ class TrainStep:
                 self.order.append(('stage', i))
             gph.replay()
             self._reduce(i, self.static[i])
-        self._bound = True          # `.grad` now points at buffers that every replay / reduction rewrites in place
         self._finish()
         return self._static_loss
 

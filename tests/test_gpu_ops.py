@@ -549,6 +549,34 @@ def test_adam_one_launch_matches_torch(decoupled, wd):
     assert int(st['step']) == 4
     assert_close(st['exp_avg'], o_ref.state[ref[3]]['exp_avg'], 1e-5, 1e-6, 'exp_avg after round trip')
     assert_close(st['exp_avg_sq'], o_ref.state[ref[3]]['exp_avg_sq'], 1e-5, 1e-6, 'exp_avg_sq after round trip')
+    # ... and the loaded optimizer keeps STEPPING like the reference one: every parameter owns its step counter (one shared
+    # counter object would be advanced once per parameter by torch's loop, i.e. the bias corrections would run 7x too fast)
+    tp = o_t.param_groups[0]['params']
+    for i, (a, b) in enumerate(zip(ref[:-1], tp[:-1])):
+        g = rnd(*a.shape, seed=900 + i) * (10.0 ** (i - 3))
+        a.grad, b.grad = g.clone(), g.clone().to(b.device)
+    o_ref.step()
+    o_t.step()
+    for i, (a, b) in enumerate(zip(ref[:-1], tp[:-1])):
+        assert int(o_t.state[b]['step']) == 5, 'step counter of tensor %d after one torch step: %s' % (i, o_t.state[b]['step'])
+        assert_close(b.detach(), a.detach(), 2e-6, 1e-7, 'torch step after loading our state, tensor %d' % i)
+    # the other direction: torch's state (incl. a checkpoint of an old torch with Python-number steps) into this optimizer
+    sd_t = o_t.state_dict()
+    for k, st_ in sd_t['state'].items():
+        if k % 2 == 0:
+            st_['step'] = float(st_['step'])
+    o_back = (optim.AdamW if decoupled else optim.Adam)([t.detach().clone().to(d).requires_grad_(True) for t in tp], **kw)
+    o_back.load_state_dict(sd_t)
+    bp = o_back.param_groups[0]['params']
+    for step in range(2):
+        for i, (a, b) in enumerate(zip(ref[:-1], bp[:-1])):
+            g = rnd(*a.shape, seed=950 + 10 * step + i) * (10.0 ** (i - 3))
+            a.grad, b.grad = g.clone(), g.clone().to(d)
+        o_ref.step()
+        o_back.step()
+    for i, (a, b) in enumerate(zip(ref[:-1], bp[:-1])):
+        assert int(o_back.state[b]['step']) == 7
+        assert_close(b.detach(), a.detach(), 3e-6, 1e-7, 'our step after loading torch state, tensor %d' % i)
 
 
 def test_deferred_reductions_equal_immediate():
