@@ -341,8 +341,19 @@ def main():
         ops.PROFILE_ELEM = []
         for p_ in model.parameters():
             p_.grad = None
-        fwd_bwd(model)  # local forward + loss + backward on the bare module: the other ranks are not in this block, so
-        #                 no collective may be issued here (no reducer, no DDP wrapper)
+        if trainer is not None:
+            # one EAGER step of the same TrainStep configuration (staged backward, grouped weight-gradient launches, deferred
+            # reductions) with an event pair around every GEMM-family launch.  process_group=False: the other ranks are not
+            # in this block, so no collective may be issued here
+            from renderih_amd.train import TrainStep as _TS
+            prof = _TS(model, opt, loss_fn, (img, lab), use_graph=False, stages=not args.no_stages, process_group=False)
+            prof()
+            ops.PROFILE = []            # (the first eager step also walks the autograd graph once: profile the second)
+            ops.PROFILE_ELEM = []
+            prof()
+            del prof
+        else:
+            fwd_bwd(model)  # --ddp: local forward + loss + backward on the bare module (no reducer, no DDP wrapper)
         torch.cuda.synchronize()
         recs = ops.PROFILE
         erecs = ops.PROFILE_ELEM

@@ -107,6 +107,23 @@ int rih_gemm_stats_rows(const rih_gemm_desc* d);
 
 int rih_gemm(const rih_gemm_desc* d, void* stream);
 
+/* Grouped launch: n independent rih_gemm problems that take the SAME kernel variant run as ONE launch -- e.g. all weight
+ * gradients of the decoder's nn.Linear layers of a backward stage (models/model_attn/gcn.py:99-110, self_attn.py:17-33: 116
+ * GEMM launches of ~20 us per ResNet50 step, each a few hundred workgroups with short reductions) -- so that the chip stays
+ * full across problems and the dependent-launch floor is paid once.  Because the problems then fill the machine together,
+ * the caller can also use far fewer split-K slices per problem than a lone launch needs (less partial-slab traffic).
+ *   rih_gemm_multi_variant(d): >= 0 = the variant id of a descriptor that can ride in a grouped launch (split engine's fast
+ *     path; weight-gradient GEMMs a_mode 1 / b_mode 0 on 64x64 or 128x128 tiles), -1 otherwise.
+ *   rih_gemm_multi_table_bytes / rih_gemm_multi_pack: size of, and fill, the launch table in HOST memory for n descriptors of
+ *     one variant (returns the variant, or a negative error code; *total_blocks = grid size).  The table holds the prepared
+ *     kernel arguments of every problem and a block -> problem map.
+ *   rih_gemm_multi_launch(dev_table, variant, total_blocks, stream): the launch; `dev_table` = the packed table in DEVICE
+ *     memory (the caller's stream-ordered copy; it must stay unchanged until the kernel has run).  No allocation, no sync. */
+int rih_gemm_multi_variant(const rih_gemm_desc* d);
+int64_t rih_gemm_multi_table_bytes(const rih_gemm_desc* descs, int n);
+int rih_gemm_multi_pack(const rih_gemm_desc* descs, int n, void* host_table, int32_t* total_blocks);
+int rih_gemm_multi_launch(const void* dev_table, int variant, int total_blocks, void* stream);
+
 /* Sum split-K partials P[S][M][N] (M = taps*Cin rows ordered (tap,ci)) into a weight gradient laid out
  * like the parameter: dst[(n*CinValid + ci)*taps + tap]  (OIHW for convs, [out][in] for nn.Linear).
  * Rows with ci >= CinValid (channel padding) are dropped.  accumulate!=0 adds to dst.  One launch, fixed summation
@@ -436,12 +453,13 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
                         const float* counts, float* out, void* stream);
 
 /* library / device info.  RIH_ABI_VERSION is bumped whenever a struct layout or a signature of this header changes;
- * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of the by-pointer structs
- * (gemm desc, mano model, mesh topo, hconv desc), so a host binding can refuse a stale binary instead of handing it
- * mis-laid-out structs. */
-#define RIH_ABI_VERSION 7
+ * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of EVERY by-pointer struct, in
+ * this order: gemm desc, mano model, mesh topo, hconv desc, gemm p3 desc, reduce desc, pack desc, ln final desc, adam entry
+ * (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it mis-laid-out structs. */
+#define RIH_ABI_VERSION 8
+#define RIH_ABI_NSIZES 9
 int rih_version(void);
-int rih_abi_sizes(int32_t* out4);
+int rih_abi_sizes(int32_t* out9);
 const char* rih_arch(void);
 
 /* ------------------------------------------------------------------------------------------------

@@ -36,13 +36,27 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in _deps())
+    return any(os.path.getmtime(d) > t for d in _deps()) or _flags_changed()
+
+
+def _flags_stamp():
+    import hashlib
+    return hashlib.sha256(' '.join(FLAGS).encode()).hexdigest()[:16]
+
+
+def _flags_changed():
+    try:
+        with open(os.path.join(OBJ, 'flags.stamp')) as fh:
+            return fh.read().strip() != _flags_stamp()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     os.makedirs(OBJ, exist_ok=True)
+    force = force or _flags_changed()       # objects compiled with other FLAGS are stale whatever their mtime
     hdr_t = max(os.path.getmtime(d) for d in _deps()[len(SOURCES):])
     jobs = []
     for s in SOURCES:
@@ -57,6 +71,8 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     run([hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + [os.path.join(OBJ, s + '.o') for s in SOURCES])
+    with open(os.path.join(OBJ, 'flags.stamp'), 'w') as fh:
+        fh.write(_flags_stamp())
     return LIB
 
 

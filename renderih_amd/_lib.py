@@ -173,6 +173,10 @@ SIGNATURES = {
     'rih_p3_conv_weight': (c_i, [c_f, C.c_void_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
     'rih_bn_stats_merge': (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),
     'rih_gemm_stats_rows': (c_i, [C.POINTER(GemmDesc)]),
+    'rih_gemm_multi_variant': (c_i, [C.POINTER(GemmDesc)]),
+    'rih_gemm_multi_table_bytes': (c_l, [C.POINTER(GemmDesc), c_i]),
+    'rih_gemm_multi_pack': (c_i, [C.POINTER(GemmDesc), c_i, C.c_void_p, C.POINTER(C.c_int32)]),
+    'rih_gemm_multi_launch': (c_i, [C.c_void_p, c_i, c_i, C.c_void_p]),
     'rih_bn_stats_from_blocks': (c_i, [c_f, c_i, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, C.c_void_p]),
     'rih_bn_stats_from_tiles': (c_i, [c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, C.c_void_p]),
     'rih_version': (c_i, []),
@@ -180,7 +184,7 @@ SIGNATURES = {
     'rih_arch': (C.c_char_p, []),
 }
 
-ABI_VERSION = 7      # = RIH_ABI_VERSION of include/renderih_amd.h
+ABI_VERSION = 8      # = RIH_ABI_VERSION of include/renderih_amd.h
 
 _lib = None
 
@@ -213,12 +217,17 @@ def load():
         fn = getattr(lib, name)      # AttributeError => a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    sizes = (C.c_int32 * 4)()
-    if lib.rih_version() != ABI_VERSION or lib.rih_abi_sizes(sizes) != 0 or list(sizes) != [
-            C.sizeof(GemmDesc), C.sizeof(ManoModel), C.sizeof(MeshTopo), C.sizeof(HConvDesc)]:
-        raise RuntimeError('librenderih_amd.so does not match this binding (ABI %d vs %d, struct sizes %s vs %s): rebuild '
-                           'with `python -m renderih_amd._build`' % (lib.rih_version(), ABI_VERSION, list(sizes),
-                           [C.sizeof(GemmDesc), C.sizeof(ManoModel), C.sizeof(MeshTopo), C.sizeof(HConvDesc)]))
+    # every by-pointer struct of the header, in rih_abi_sizes' order; the last one (rih_adam_entry: four pointers + int64) is
+    # built by hand as int64 rows in renderih_amd/optim.py
+    mine = [C.sizeof(GemmDesc), C.sizeof(ManoModel), C.sizeof(MeshTopo), C.sizeof(HConvDesc), C.sizeof(GemmP3Desc),
+            C.sizeof(ReduceDesc), C.sizeof(PackDesc), C.sizeof(LnFinalDesc), 5 * 8]
+    if lib.rih_version() != ABI_VERSION:
+        raise RuntimeError('librenderih_amd.so does not match this binding (ABI %d vs %d): rebuild with '
+                           '`python -m renderih_amd._build`' % (lib.rih_version(), ABI_VERSION))
+    sizes = (C.c_int32 * len(mine))()
+    if lib.rih_abi_sizes(sizes) != 0 or list(sizes) != mine:
+        raise RuntimeError('librenderih_amd.so does not match this binding (struct sizes %s vs %s): rebuild with '
+                           '`python -m renderih_amd._build`' % (list(sizes), mine))
     _lib = lib
     return lib
 

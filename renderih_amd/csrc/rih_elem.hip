@@ -1961,12 +1961,17 @@ extern "C" int rih_project_bwd(const float* dout, const float* v, const float* s
 }
 
 extern "C" int rih_version(void) { return RIH_ABI_VERSION; }
-extern "C" int rih_abi_sizes(int32_t* out4) {
-    if (!out4) return RIH_EINVAL;
-    out4[0] = (int32_t)sizeof(rih_gemm_desc);
-    out4[1] = (int32_t)sizeof(rih_mano_model);
-    out4[2] = (int32_t)sizeof(rih_mesh_topo);
-    out4[3] = (int32_t)sizeof(rih_hconv_desc);
+extern "C" int rih_abi_sizes(int32_t* out9) {
+    if (!out9) return RIH_EINVAL;
+    out9[0] = (int32_t)sizeof(rih_gemm_desc);
+    out9[1] = (int32_t)sizeof(rih_mano_model);
+    out9[2] = (int32_t)sizeof(rih_mesh_topo);
+    out9[3] = (int32_t)sizeof(rih_hconv_desc);
+    out9[4] = (int32_t)sizeof(rih_gemm_p3_desc);
+    out9[5] = (int32_t)sizeof(rih_reduce_desc);
+    out9[6] = (int32_t)sizeof(rih_pack_desc);
+    out9[7] = (int32_t)sizeof(rih_ln_final_desc);
+    out9[8] = (int32_t)sizeof(rih_adam_entry);
     return 0;
 }
 extern "C" const char* rih_arch(void) { return "gfx950"; }

@@ -691,8 +691,11 @@ __device__ __forceinline__ uint4 bloadu4(__amdgpu_buffer_rsrc_t r, unsigned off)
 // APRE (a_mode 2): A arrives pre-split as well -- planes [hi | mid | lo][pixels][lda] bf16, channels contiguous, written
 // by rih_presplit_matrix on the NHWC activation; AMODE must be 0 (im2col / plain rows), the loader is the BMODE 2 one
 // plus the per-row window offsets and tap validity bits.  With both operands pre-split the kernel converts nothing.
+// The kernel body takes the block coordinates as arguments: gemm_split_kernel passes blockIdx / gridDim, the grouped launch
+// (gemm_split_multi_kernel, rih_gemm_multi) the coordinates of a block inside ITS problem of a descriptor table.
 template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false>
-__global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
+__device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk_x, const int blk_z, const int grid_x,
+                                                const int grid_z) {
     // global->register prefetch depth: k-tiles in flight.  The 64x64 tile (decoder-sized problems: a handful of
     // k-tiles, 12 MFMAs each) is bound by the load round trip per k-tile, so it keeps three tiles in flight.
     constexpr int PF = 1;     // (measured: 3 tiles in flight for the 64x64 tile changes nothing, the floor is elsewhere)
@@ -716,13 +719,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
     // Workgroups are dispatched x-fastest and round-robin over the 8 XCDs.  Remap so that each XCD (private L2) gets a
     // contiguous run of output tiles -- and, for a split-K launch, of (split, tile) pairs with the tile fastest, so
     // that all tiles reading one K-range of the operands sit on the same XCD instead of fetching it eight times.
-    int bid, z = blockIdx.z;
-    if (p.splitk > 1 && gridDim.z == (unsigned)p.splitk) {
-        const int c = xcd_remap(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z);
-        bid = c % gridDim.x;
-        z = c / gridDim.x;
+    int bid, z = blk_z;
+    if (p.splitk > 1 && grid_z == p.splitk) {
+        const int c = xcd_remap(blk_x + grid_x * blk_z, grid_x * grid_z);
+        bid = c % grid_x;
+        z = c / grid_x;
     } else {
-        bid = xcd_remap(blockIdx.x, gridDim.x);
+        bid = xcd_remap(blk_x, grid_x);
     }
     const int m0 = (bid / tilesN) * BM;
     const int n0 = (bid % tilesN) * BN;
@@ -1102,6 +1105,50 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
     // ------------------------------------------------------------------ epilogue (store_tiles_wide; the main loop ended with a barrier)
     store_tiles_wide<TM, TN, STATS>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp, m0 + wm * WM, n0 + wn * WN,
                                     lane);
+}
+
+template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false>
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
+    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, APRE, STATS>(p, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.z);
+}
+
+// ---- grouped launch (rih_gemm_multi): n independent problems of ONE kernel variant in one launch.  The table lives in device
+// memory (uploaded by the caller: the descriptors of e.g. all weight gradients of a backward stage do not fit the 4 KB kernel
+// argument): header, then per group of 8 consecutive blocks the problem it belongs to, then the problems.  Every problem's block
+// count is padded to a multiple of 8, so that the low three bits of a block's index inside its problem are still the XCD it
+// was dispatched to (xcd_remap); the padding blocks exit at once.  All table reads are wave-uniform scalar loads from the
+// constant address space, exactly like the kernel-argument reads of the single launch.
+struct MultiProb {
+    GemmArgs a;
+    int first;          // first block of the problem in the launch (multiple of 8)
+    int gx, gz;         // the problem's own grid (gx * gz <= its padded block count)
+    int pad;
+};
+struct MultiHeader {
+    int n, total_blocks, groups, pad;
+};
+#ifndef RIH_CONST_AS        /* (the host build of tests/hipcpu defines it empty) */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RIH_CONST_AS __attribute__((address_space(4)))
+#else
+#define RIH_CONST_AS        /* hipcc's host pass only parses the kernel */
+#endif
+#endif
+
+template <int BM, int BN, int AMODE, int BMODE, bool PLAIN>
+__global__ __launch_bounds__(256, 2) void gemm_split_multi_kernel(const unsigned char* __restrict__ table) {
+    const int b = (int)blockIdx.x;
+    const MultiHeader RIH_CONST_AS* hd = (const MultiHeader RIH_CONST_AS*)table;
+    const unsigned short RIH_CONST_AS* grp = (const unsigned short RIH_CONST_AS*)(table + sizeof(MultiHeader));
+    const int groups = hd->groups;
+    const int pi = (int)grp[b >> 3];
+    const MultiProb RIH_CONST_AS* pr =
+        (const MultiProb RIH_CONST_AS*)(table + sizeof(MultiHeader) + (((size_t)groups * 2 + 15) & ~(size_t)15)) + pi;
+    const int lb = b - pr->first;
+    const int gx = pr->gx, gz = pr->gz;
+    if (lb >= gx * gz) return;              // padding block
+    const GemmArgs p = pr->a;               // scalar loads; the copy lives in SGPRs like a kernel argument
+    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN>(p, lb % gx, lb / gx, gx, gz);
 }
 
 template <int BM, int BN>
@@ -1774,7 +1821,12 @@ extern "C" int rih_presplit_conv_weight(const float* w, void* dst, int Cout, int
     return launch_presplit(a, stream);
 }
 
-static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows) {
+struct PreparedGemm {       // what gemm_impl would launch on the split engine's fast path (tiles 0..2), for rih_gemm_multi
+    GemmArgs a;
+    int gx, gz, tile, a_mode, b_mode, plain;
+};
+
+static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, PreparedGemm* prep = nullptr) {
     if (!d || !d->A || !d->B || !d->C) return RIH_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K < 0) return RIH_EINVAL;
     if (d->splitk < 1 || d->nb1 < 1 || d->nb2 < 1) return RIH_EINVAL;
@@ -1864,6 +1916,7 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows) {
         if (d->b_mode == 0) ok = ok && (d->N % 4 == 0);
         if (d->tile == 4) {     // 256x128 kernel: no general-kernel fallback, the caller must respect the preconditions
             if (stats_rows != nullptr) { *stats_rows = 0; return 0; }
+            if (prep != nullptr) return RIH_EINVAL;
             if (d->stats != nullptr) return RIH_EINVAL;
             ok = ok && !(d->a_mode == 1 && d->b_mode == 1);
             if (!ok) return RIH_EINVAL;
@@ -1883,12 +1936,20 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows) {
             a.a_bytes = (unsigned)a_bytes;
             a.b_bytes = (unsigned)b_bytes;
             a.a_plane = (unsigned)a_plane;
+            if (prep != nullptr) {
+                if (d->stats != nullptr || d->a_mode > 1 || d->b_mode > 1) return RIH_EINVAL;
+                prep->a = a;
+                prep->gx = (int)grid.x; prep->gz = (int)grid.z;
+                prep->tile = d->tile; prep->a_mode = d->a_mode; prep->b_mode = d->b_mode; prep->plain = plain ? 1 : 0;
+                return 0;
+            }
             if (d->tile == 0) return launch_split<128, 128>(a, d->a_mode, d->b_mode, plain, grid, s);
             if (d->tile == 1) return launch_split<128, 64>(a, d->a_mode, d->b_mode, plain, grid, s);
             return launch_split<64, 64>(a, d->a_mode, d->b_mode, plain, grid, s);
         }
     }
     if (stats_rows != nullptr) { *stats_rows = 0; return 0; }
+    if (prep != nullptr) return RIH_EINVAL;                   // not a fast-path descriptor: no grouped launch
     if (d->stats != nullptr) return RIH_EINVAL;
     if (d->b_mode == 2 || d->a_mode == 2) return RIH_EINVAL;  // the general kernels do not read pre-split operands
     if (d->tile == 4) return RIH_EINVAL;    // 256x128 exists only on the split engine's fast path
@@ -1899,6 +1960,86 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows) {
 }
 
 extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) { return gemm_impl(d, stream, nullptr); }
+
+// ---- grouped launch.  Variant id = tile * 8 + a_mode * 4 + b_mode * 2 + plain of the split engine's fast path; the variants
+// instantiated for the grouped kernel are the weight-gradient ones (a_mode 1, b_mode 0; 64x64 and 128x128 tiles) and the
+// forward-type 64x64 ones.
+extern "C" int rih_gemm_multi_variant(const rih_gemm_desc* d) {
+    PreparedGemm pg;
+    if (gemm_impl(d, nullptr, nullptr, &pg) != 0) return -1;
+    const int v = pg.tile * 8 + pg.a_mode * 4 + pg.b_mode * 2 + pg.plain;
+    switch (v) {
+        case 2 * 8 + 4 + 0 + 1: case 2 * 8 + 4 + 0 + 0:         // 64x64 weight gradients (plain / conv gather)
+        case 0 * 8 + 4 + 0 + 1: case 0 * 8 + 4 + 0 + 0:         // 128x128 weight gradients
+            return v;
+        default: return -1;
+    }
+}
+
+extern "C" int64_t rih_gemm_multi_table_bytes(const rih_gemm_desc* descs, int n) {
+    if (n < 1 || !descs) return 0;
+    long long groups = 0;
+    for (int i = 0; i < n; ++i) {
+        PreparedGemm pg;
+        if (gemm_impl(&descs[i], nullptr, nullptr, &pg) != 0) return 0;
+        groups += ((long long)pg.gx * pg.gz + 7) / 8;
+    }
+    return (int64_t)(sizeof(MultiHeader) + ((groups * 2 + 15) & ~15ll) + (long long)n * sizeof(MultiProb));
+}
+
+// Fill `host_table` (rih_gemm_multi_table_bytes bytes of HOST memory) for n descriptors of one variant; returns the variant
+// (>= 0) and the launch's block count, or a negative error.  The caller copies the table to the device (any stream-ordered
+// copy in front of the launch; a pinned staging buffer under stream capture) and calls rih_gemm_multi_launch.
+extern "C" int rih_gemm_multi_pack(const rih_gemm_desc* descs, int n, void* host_table, int32_t* total_blocks) {
+    if (n < 1 || n > 65535 || !descs || !host_table || !total_blocks) return -RIH_EINVAL;
+    int variant = -1;
+    long long groups = 0;
+    for (int i = 0; i < n; ++i) {
+        const int v = rih_gemm_multi_variant(&descs[i]);
+        if (v < 0 || (variant >= 0 && v != variant)) return -RIH_EINVAL;
+        variant = v;
+        PreparedGemm pg;
+        gemm_impl(&descs[i], nullptr, nullptr, &pg);
+        groups += ((long long)pg.gx * pg.gz + 7) / 8;
+    }
+    if (groups * 8 > 0x7fffffffLL) return -RIH_EINVAL;
+    unsigned char* t = (unsigned char*)host_table;
+    MultiHeader* hd = (MultiHeader*)t;
+    unsigned short* grp = (unsigned short*)(t + sizeof(MultiHeader));
+    MultiProb* pr = (MultiProb*)(t + sizeof(MultiHeader) + ((groups * 2 + 15) & ~15ll));
+    long long g = 0;
+    for (int i = 0; i < n; ++i) {
+        PreparedGemm pg;
+        gemm_impl(&descs[i], nullptr, nullptr, &pg);
+        const long long ng = ((long long)pg.gx * pg.gz + 7) / 8;
+        pr[i].a = pg.a;
+        pr[i].first = (int)(g * 8);
+        pr[i].gx = pg.gx;
+        pr[i].gz = pg.gz;
+        pr[i].pad = 0;
+        for (long long k = 0; k < ng; ++k) grp[g + k] = (unsigned short)i;
+        g += ng;
+    }
+    for (long long k = g; k < ((groups * 2 + 15) & ~15ll) / 2; ++k) grp[k] = 0;
+    hd->n = n; hd->total_blocks = (int)(groups * 8); hd->groups = (int)groups; hd->pad = 0;
+    *total_blocks = (int)(groups * 8);
+    return variant;
+}
+
+extern "C" int rih_gemm_multi_launch(const void* dev_table, int variant, int total_blocks, void* stream) {
+    if (!dev_table || total_blocks < 8 || (total_blocks & 7)) return RIH_EINVAL;
+    const unsigned char* t = (const unsigned char*)dev_table;
+    dim3 grid((unsigned)total_blocks), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (variant) {
+        case 2 * 8 + 4 + 1: hipLaunchKernelGGL((gemm_split_multi_kernel<64, 64, 1, 0, true>), grid, block, 0, s, t); break;
+        case 2 * 8 + 4 + 0: hipLaunchKernelGGL((gemm_split_multi_kernel<64, 64, 1, 0, false>), grid, block, 0, s, t); break;
+        case 0 * 8 + 4 + 1: hipLaunchKernelGGL((gemm_split_multi_kernel<128, 128, 1, 0, true>), grid, block, 0, s, t); break;
+        case 0 * 8 + 4 + 0: hipLaunchKernelGGL((gemm_split_multi_kernel<128, 128, 1, 0, false>), grid, block, 0, s, t); break;
+        default: return RIH_EINVAL;
+    }
+    return (int)hipGetLastError();
+}
 
 extern "C" int rih_gemm_stats_rows(const rih_gemm_desc* d) {
     int rows = 0;

@@ -53,11 +53,7 @@ def conv_bn(cm, bn, x, residual=None, relu=False, conv_relu=False, skip=False):
     applied by the BatchNorm's backward kernel (it reads its input anyway): no separate relu_bwd pass."""
     f = ops.conv2d_skip if skip else ops.conv2d
     holder = ops.StatsHolder() if (ops.GEMM_STATS and bn.training) else None
-    ops._STATS_REQUEST = holder
-    try:
-        out = f(x, cm.weight, cm.bias, stride=cm.stride[0], pad=cm.padding[0], relu=conv_relu, grad_masked=conv_relu)
-    finally:
-        ops._STATS_REQUEST = None
+    out = f(x, cm.weight, cm.bias, stride=cm.stride[0], pad=cm.padding[0], relu=conv_relu, grad_masked=conv_relu, stats=holder)
     y, idt = out if skip else (out, None)
     stats = ('blocks', holder.part, holder.T, holder.rows) if (holder is not None and holder.part is not None) else None
     y = bn_act(bn, y, residual=residual, relu=relu, tile_stats=stats, input_relu=conv_relu)

@@ -177,14 +177,15 @@ class StatsHolder:
         self.rows = 0
 
 
-_STATS_REQUEST = None
-
-
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=None, ldr=0,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, kchunk=0, sCsplit=0, alpha=1.0, relu=False,
-         geom=None, tile=None, engine=None, cstride=None, ones_row=0, sBias=0, sR=0):
+         geom=None, tile=None, engine=None, cstride=None, ones_row=0, sBias=0, sR=0, collect=None, stats=None):
     """Enqueue one rih_gemm.  A/B/Cout/bias/R are tensors or raw device pointers.
-    cstride = (s, oh, ow, H, W): store GEMM row (img, i, j) to pixel (img, i*s+oh, j*s+ow) of a [*, H, W] tensor."""
+    cstride = (s, oh, ow, H, W): store GEMM row (img, i, j) to pixel (img, i*s+oh, j*s+ow) of a [*, H, W] tensor.
+    collect: a GroupedGemms -- the problem joins its next grouped launch (rih_gemm_multi) when its kernel variant can ride
+    in one, instead of being launched now; the operands are kept alive until then.
+    stats: a StatsHolder -- filled with the per-row-block BatchNorm statistics of the output when the descriptor takes the split
+    engine's statistics epilogue (left empty otherwise: the BatchNorm then runs its own statistics pass)."""
     d = GemmDesc()
     if cstride is not None:
         d.cS, d.cOH, d.cOW, d.cH, d.cW = cstride
@@ -227,7 +228,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
             check(_L().rih_splitk_finish(part.data_ptr(), sk, M, N, d.C, ldc, d.bias or 0, d.R or 0, ldr,
                                          alpha, 1 if relu else 0, _stream()), 'rih_splitk_finish')
             return
-    req = _STATS_REQUEST
+    req = stats
     if (req is not None and req.part is None and a_mode == 0 and splitk == 1 and nb1 * nb2 == 1 and cstride is None
             and not isinstance(Cout, int)):
         rows_per = int(_L().rih_gemm_stats_rows(C.byref(d)))
@@ -235,6 +236,8 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
             req.T, req.rows = _cdiv(M, rows_per), rows_per
             req.part = torch.empty((req.T, 2, N), device=Cout.device, dtype=torch.float32)
             d.stats = req.part.data_ptr()
+    if collect is not None and collect.add(d, (A, B, Cout), 2.0 * M * N * K * nb1 * nb2):
+        return
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -243,6 +246,67 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
         PROFILE.append((2.0 * M * N * K * nb1 * nb2, e0, e1, (M, N, K, nb1 * nb2, a_mode, b_mode, d.tile, splitk, d.engine)))
         return
     check(_L().rih_gemm(C.byref(d), _stream()), 'rih_gemm')
+
+
+# --------------------------------------------------------------------------------------------- grouped launches
+# rih_gemm_multi: the weight-gradient GEMMs of a backward stage -- independent of each other and of everything else until the
+# optimizer -- are collected inside `deferred_reductions()` and run as ONE launch per kernel variant at the end of the stage
+# (the decoder's 116 nn.Linear gradients per ResNet50 step were 116 launches of ~20 us with a few hundred short workgroups
+# each).  The launch table (prepared kernel arguments + block -> problem map) is packed on the host, staged in pinned memory
+# and copied to the device in stream order; under hipGraph capture the copy is a node of the graph, so the staging buffer must
+# outlive the graph: `TABLE_KEEP` (a list installed by the capturing code, renderih_amd.train.TrainStep) receives it.
+GROUP_WGRAD = int(os.environ.get('RIH_WGRAD_GROUP', '1'))        # 0: off, 1: decoder-sized gradients, 2: every weight gradient
+GROUP_KCHUNK = int(os.environ.get('RIH_WGRAD_GROUP_KCHUNK', '1024'))      # pixels per split-K slice in a grouped launch
+TABLE_KEEP = None
+
+
+class GroupedGemms:
+    def __init__(self):
+        self.items = []         # (variant, descriptor copy, operands kept alive, flops)
+
+    def add(self, d, keep, flops):
+        v = int(_L().rih_gemm_multi_variant(C.byref(d)))
+        if v < 0:
+            return False
+        c = GemmDesc()
+        C.memmove(C.byref(c), C.byref(d), C.sizeof(GemmDesc))
+        self.items.append((v, c, keep, flops))
+        return True
+
+    def flush(self):
+        items, self.items = self.items, []
+        by = {}
+        for v, d, keep, fl in items:
+            by.setdefault(v, []).append((d, keep, fl))
+        lib = _L()
+        for v, group in sorted(by.items()):
+            n = len(group)
+            arr = (GemmDesc * n)(*[g[0] for g in group])
+            nbytes = int(lib.rih_gemm_multi_table_bytes(arr, n))
+            if nbytes <= 0:
+                raise RuntimeError('renderih_amd: rih_gemm_multi_table_bytes rejected the group')
+            ref = next(t for t in group[0][1] if torch.is_tensor(t))
+            on_gpu = ref.is_cuda
+            host = torch.empty((nbytes,), dtype=torch.uint8, pin_memory=on_gpu)
+            total = C.c_int32(0)
+            got = int(lib.rih_gemm_multi_pack(arr, n, host.data_ptr(), C.byref(total)))
+            if got != v:
+                raise RuntimeError('renderih_amd: rih_gemm_multi_pack failed (%d)' % got)
+            if on_gpu:
+                dev = torch.empty((nbytes,), dtype=torch.uint8, device=ref.device)
+                dev.copy_(host, non_blocking=True)
+                if TABLE_KEEP is not None:
+                    TABLE_KEEP.append(host)
+            else:
+                dev = host
+            if PROFILE is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                check(lib.rih_gemm_multi_launch(dev.data_ptr(), v, total.value, _stream()), 'rih_gemm_multi_launch')
+                e1.record()
+                PROFILE.append((sum(g[2] for g in group), e0, e1, (0, 0, 0, n, (v >> 2) & 1, (v >> 1) & 1, 20 + (v >> 3), 0, 1)))
+            else:
+                check(lib.rih_gemm_multi_launch(dev.data_ptr(), v, total.value, _stream()), 'rih_gemm_multi_launch')
 
 
 # --------------------------------------------------------------------------------------------- P3 (pre-split) operands
@@ -370,19 +434,24 @@ def _pdiff(a, b):
 # AccumulateGrad may add a gradient into an existing .grad immediately.
 _DEFERRED = None
 _DEFERRED_LN = None         # same for the LayerNorm parameter gradients (rih_ln_param_final_multi)
+_DEFERRED_GEMM = None       # the weight-gradient GEMMs themselves (GroupedGemms, rih_gemm_multi) when GROUP_WGRAD is on
 
 
 class deferred_reductions:
     def __enter__(self):
-        global _DEFERRED, _DEFERRED_LN
+        global _DEFERRED, _DEFERRED_LN, _DEFERRED_GEMM
         assert _DEFERRED is None, 'deferred_reductions does not nest'
         _DEFERRED, _DEFERRED_LN = [], []
+        _DEFERRED_GEMM = GroupedGemms() if (GROUP_WGRAD and ENGINE == 1) else None
         return self
 
     def __exit__(self, et, ev, tb):
-        global _DEFERRED, _DEFERRED_LN
+        global _DEFERRED, _DEFERRED_LN, _DEFERRED_GEMM
         pending, _DEFERRED = _DEFERRED, None
         ln, _DEFERRED_LN = _DEFERRED_LN, None
+        gg, _DEFERRED_GEMM = _DEFERRED_GEMM, None
+        if et is None and gg is not None and gg.items:
+            gg.flush()              # the grouped weight-gradient GEMMs first: the reductions below read their slabs
         if et is None and ln:
             from ._lib import LnFinalDesc
             arr = (LnFinalDesc * len(ln))()
@@ -434,6 +503,12 @@ def _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin
         # measured optimum of resident split-K slices (tools/tile_sweep.py): ~512 workgroups, 256 for a single tile
         target = (256 if tiles == 1 else 512) if ENGINE == 1 else 1024
         splitk = max(1, min(target // max(tiles, 1), _cdiv(Kpix, 128)))
+    # grouped launch (rih_gemm_multi at the end of the backward stage): the problems fill the chip TOGETHER, so a problem needs
+    # only as many split-K slices as keep its own workgroups reasonably short -- fewer partial slabs to write and to sum
+    collect = None
+    if _DEFERRED_GEMM is not None and tile in (0, 2) and (GROUP_WGRAD >= 2 or nb > 1 or small):
+        collect = _DEFERRED_GEMM
+        splitk = max(1, min(splitk, _cdiv(Kpix, GROUP_KCHUNK)))
     kchunk = _cdiv(_cdiv(Kpix, splitk), 32) * 32
     splitk = _cdiv(Kpix, kchunk)
     part = torch.empty((nb, splitk, Mp, Ncols), device=x.device, dtype=torch.float32)
@@ -442,10 +517,10 @@ def _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin
     if splitk == 1:
         # a single slice still goes through the reduce kernel for the layout change; raw epilogue = alpha 1, no bias
         gemm(x, dy, part, Mp, Ncols, Kpix, ldx, ldy, Ncols, a_mode=1, b_mode=0, geom=geom, tile=tile, ones_row=ones,
-             **batch)
+             collect=collect, **batch)
     else:
         gemm(x, dy, part, Mp, Ncols, Kpix, ldx, ldy, Ncols, a_mode=1, b_mode=0, splitk=splitk, kchunk=kchunk,
-             sCsplit=Mp * Ncols, geom=geom, tile=tile, ones_row=ones, **batch)
+             sCsplit=Mp * Ncols, geom=geom, tile=tile, ones_row=ones, collect=collect, **batch)
     if _DEFERRED is not None:
         # summed at the end of the backward stage by ONE launch per 60 gradients (deferred_reductions below)
         per_dw, per_db = dw.numel() // nb, (Ncols if db is not None else 0)
@@ -533,7 +608,7 @@ class Conv2dFn(torch.autograd.Function):
     x: [N,H,W,Cx] (Cx >= Cin, extra channels must be zero), w: [Cout,Cin,KH,KW] (the nn.Conv2d parameter)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, relu, skip=False, grad_masked=False):
+    def forward(ctx, x, w, bias, stride, pad, relu, skip=False, grad_masked=False, stats=None):
         """skip=True: also return x itself (an alias).  A residual block feeds its skip path from that second output;
         the gradient arriving there is then added inside the data-gradient GEMM's epilogue (residual operand R)
         instead of by an autograd accumulation pass over the whole activation."""
@@ -555,10 +630,10 @@ class Conv2dFn(torch.autograd.Function):
             else:
                 gemm(x, wp, y, M, Cout, K, Cx, Kp, Cout, a_mode=0, b_mode=2, bias=bias, relu=relu, geom=geom)
         elif KH * KW == 1 and Cx == Cin:
-            gemm(x, w, y, M, Cout, K, Cx, Cin, Cout, a_mode=0, b_mode=1, bias=bias, relu=relu, geom=geom)
+            gemm(x, w, y, M, Cout, K, Cx, Cin, Cout, a_mode=0, b_mode=1, bias=bias, relu=relu, geom=geom, stats=stats)
         else:
             wp = _packed_weight(w, Cx, False)
-            gemm(x, wp, y, M, Cout, K, Cx, Cout, Cout, a_mode=0, b_mode=0, bias=bias, relu=relu, geom=geom)
+            gemm(x, wp, y, M, Cout, K, Cx, Cout, Cout, a_mode=0, b_mode=0, bias=bias, relu=relu, geom=geom, stats=stats)
         # grad_masked: the consumer (a BatchNorm with input_relu) hands back a gradient that is already zero where y <= 0
         relu_bwd = relu and not grad_masked
         ctx.save_for_backward(x, w, y if relu_bwd else None)
@@ -650,16 +725,17 @@ class Conv2dFn(torch.autograd.Function):
             db = colsum(dy, M, Cout)
         if dx is None and dskip is not None:
             dx = dskip
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, grad_masked=False):
-    return Conv2dFn.apply(x, w, bias, stride, pad, relu, False, grad_masked)
+def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, grad_masked=False, stats=None):
+    """stats: optional StatsHolder that receives the BatchNorm statistics of the output from the GEMM epilogue (see gemm)."""
+    return Conv2dFn.apply(x, w, bias, stride, pad, relu, False, grad_masked, stats)
 
 
-def conv2d_skip(x, w, bias=None, stride=1, pad=0, relu=False, grad_masked=False):
+def conv2d_skip(x, w, bias=None, stride=1, pad=0, relu=False, grad_masked=False, stats=None):
     """(conv(x), x) -- see Conv2dFn.forward: use the second value for the block's skip path."""
-    return Conv2dFn.apply(x, w, bias, stride, pad, relu, True, grad_masked)
+    return Conv2dFn.apply(x, w, bias, stride, pad, relu, True, grad_masked, stats)
 
 
 def pack_folded_conv(w, scale, cin_pad):

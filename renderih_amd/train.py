@@ -316,6 +316,9 @@ class TrainStep:
             p.grad = None
         self.graphs, self.static = [], []
         pool = None
+        # pinned staging buffers of captured host-to-device copies (launch tables of the grouped weight-gradient GEMMs): the
+        # graphs re-read them at every replay, so they live as long as this object
+        ops.TABLE_KEEP = self._table_keep = []
         with torch.cuda.stream(cap):
             carry, loss = None, None
             for i in range(self.nstage):
@@ -331,6 +334,7 @@ class TrainStep:
                 self.graphs.append(gph)
                 self.static.append(grads)
             self._static_loss = loss.detach()
+        ops.TABLE_KEEP = None
         if self.packs is not None:
             self.packs.stale()
             ops._PACK = None

@@ -170,6 +170,44 @@ class EmulatedLib:
                         st[t, 0], st[t, 1] = blk.mean(0), ((blk - blk.mean(0)) ** 2).sum(0)
         return 0
 
+    # grouped launch (rih_gemm_multi_*): the contract restated -- weight-gradient descriptors of one variant, a table in "device"
+    # memory that stands for the packed problems, one launch that runs them all
+    def rih_gemm_multi_variant(self, dref):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        plain = (d.KH == 1 and d.KW == 1 and d.strideA == 1 and d.padH == 0 and d.padW == 0 and d.H == d.Ho and d.W == d.Wo)
+        ok = (d.engine == 1 and d.tile in (0, 2) and d.a_mode == 1 and d.b_mode == 0 and d.upS == 1 and d.K % 4 == 0
+              and d.K >= 1 and d.A % 16 == 0 and d.B % 16 == 0 and d.lda % 4 == 0 and d.ldb % 4 == 0 and d.sA1 % 4 == 0
+              and d.sB1 % 4 == 0 and d.sA2 % 4 == 0 and d.sB2 % 4 == 0 and d.M % 4 == 0 and d.N % 4 == 0 and not d.stats)
+        if not plain:
+            ok = ok and d.Wo % 4 == 0 and d.Cin % 4 == 0
+        return (d.tile * 8 + 4 + (1 if plain else 0)) if ok else -1
+
+    def rih_gemm_multi_table_bytes(self, descs, n):
+        return 64 + 8 * n if n >= 1 else 0
+
+    def rih_gemm_multi_pack(self, descs, n, host_table, total_blocks):
+        vs = {self.rih_gemm_multi_variant(descs[i]) for i in range(n)}
+        if len(vs) != 1 or -1 in vs:
+            return -1
+        copies = []
+        for i in range(n):
+            c = type(descs[i])()
+            C.memmove(C.byref(c), C.byref(descs[i]), C.sizeof(c))
+            copies.append(c)
+        reg = self.__dict__.setdefault('_multi', {})
+        key = len(reg) + 1
+        reg[key] = copies
+        np.ctypeslib.as_array((C.c_int64 * 1).from_address(int(host_table)))[0] = key
+        total_blocks._obj.value = 8 * n
+        return vs.pop()
+
+    def rih_gemm_multi_launch(self, table, variant, total_blocks, stream):
+        key = int(np.ctypeslib.as_array((C.c_int64 * 1).from_address(int(table)))[0])
+        for c in self._multi[key]:
+            assert self.rih_gemm_multi_variant(c) == variant
+            self.rih_gemm(C.byref(c), stream)
+        return 0
+
     def rih_gemm_stats_rows(self, dref):
         """The header's contract, restated: split engine's fast path, forward-type, no split-K, no batch, dense rows."""
         d = dref._obj

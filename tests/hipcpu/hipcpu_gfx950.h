@@ -7,6 +7,8 @@
 #pragma once
 #include <cstdio>
 
+#define RIH_CONST_AS        /* the constant address space of the grouped GEMM's table reads: plain memory here */
+
 struct hipcpu_rsrc { const char* base; unsigned bytes; };
 #define __amdgpu_buffer_rsrc_t hipcpu_rsrc
 typedef unsigned hipcpu_u32x4 __attribute__((ext_vector_type(4)));

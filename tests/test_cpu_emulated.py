@@ -55,6 +55,8 @@ def test_paired_layers_host_logic():
     G.test_patch_conv_pair(3, 8, 32, 48, 1)
     G.test_patch_conv_pair(2, 16, 64, 48, 4)
     G.test_deferred_reductions_equal_immediate()
+    G.test_grouped_weight_gradients(1)
+    G.test_grouped_weight_gradients(2)
     G.test_pack_cache_one_launch_equals_per_call_packs()
     G.test_conv_bn_statistics_from_the_gemm_epilogue((2, 16, 16, 64, 128, 3, 1, 1, False))
     G.test_conv_bn_statistics_from_the_gemm_epilogue((3, 9, 7, 32, 72, 3, 2, 1, True))

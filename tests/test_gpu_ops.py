@@ -606,11 +606,70 @@ def test_deferred_reductions_equal_immediate():
 
     params = [w for w, _, _, _ in ws] + [ws[0][1], wl, bl] + wm + [p for gb in lns for p in gb]
     want = torch.autograd.grad([loss()], params)
-    with ops.deferred_reductions():
-        got = torch.autograd.grad([loss()], params)
-    assert ops._DEFERRED is None and ops._DEFERRED_LN is None
+    saved = ops.GROUP_WGRAD
+    ops.GROUP_WGRAD = 0             # same split-K plan as the immediate path: bit-identical sums (grouping: the test below)
+    try:
+        with ops.deferred_reductions():
+            got = torch.autograd.grad([loss()], params)
+    finally:
+        ops.GROUP_WGRAD = saved
+    assert ops._DEFERRED is None and ops._DEFERRED_LN is None and ops._DEFERRED_GEMM is None
     for a, b in zip(got, want):
         assert bool(torch.isfinite(b).all()) and torch.equal(a, b)
+
+
+@pytest.mark.parametrize('level', [1, 2])
+def test_grouped_weight_gradients(level):
+    """ops.GROUP_WGRAD: inside deferred_reductions() the weight-gradient GEMMs themselves are collected and run as ONE
+    rih_gemm_multi launch per kernel variant at the end of the block, with fewer split-K slices per problem (the problems fill the
+    chip together).  Decoder-like shapes -- paired nn.Linear (nb1 = 2, bias row), single nn.Linear, 3x3 / 1x1 convolutions with
+    and without bias, a gradient large enough for the 128x128 tile -- against the immediate path: equal to split-K round-off,
+    and bit-reproducible from run to run."""
+    from renderih_amd import ops
+    d = dev()
+    x = nhwc(rnd(2, 32, 8, 8, seed=1)).to(d)
+    x64 = nhwc(rnd(2, 64, 8, 8, seed=21)).to(d)
+    convs = [(x, rnd(64, 32, 3, 3, seed=2, scale=0.1).to(d).requires_grad_(True), rnd(64, seed=3).to(d).requires_grad_(True), 1, 1),
+             (x, rnd(40, 32, 1, 1, seed=4, scale=0.2).to(d).requires_grad_(True), None, 1, 0),
+             (x64, rnd(136, 64, 3, 3, seed=22, scale=0.1).to(d).requires_grad_(True), None, 1, 1)]        # 576 x 136: 128x128 tiles
+    xl = rnd(2, 4, 66, 40, seed=5).to(d)                   # 264 rows per hand
+    wl, bl = rnd(2, 72, 40, seed=6, scale=0.2).to(d).requires_grad_(True), rnd(2, 72, seed=7).to(d).requires_grad_(True)
+    wm = [rnd(36 + 4 * i, 40, seed=8 + i, scale=0.2).to(d).requires_grad_(True) for i in range(5)]
+    bm = [rnd(36 + 4 * i, seed=40 + i).to(d).requires_grad_(True) for i in range(5)]
+
+    def loss():
+        t = sum(ops.conv2d(xx, w, b, stride=s, pad=p).sum() * (i + 1) for i, (xx, w, b, s, p) in enumerate(convs))
+        t = t + (ops.LinearPairFn.apply(xl, wl, None, bl, None, None, False) ** 2).sum()
+        for i, (w, b) in enumerate(zip(wm, bm)):
+            t = t + (ops.linear(xl[i % 2], w, b) * (0.5 + i)).sum()
+        return t
+
+    params = [w for _, w, _, _, _ in convs] + [convs[0][2], wl, bl] + wm + bm
+    want = torch.autograd.grad([loss()], params)
+    seen = []
+    flush = ops.GroupedGemms.flush
+
+    def spy(self):
+        seen.extend(v for v, _, _, _ in self.items)
+        return flush(self)
+    saved = ops.GROUP_WGRAD
+    ops.GROUP_WGRAD = level
+    ops.GroupedGemms.flush = spy
+    try:
+        runs = []
+        for _ in range(2):
+            with ops.deferred_reductions():
+                runs.append(torch.autograd.grad([loss()], params))
+    finally:
+        ops.GROUP_WGRAD = saved
+        ops.GroupedGemms.flush = flush
+    if ops.ENGINE == 1:
+        # paired + 5 single Linears + the 3x3 / 1x1 convolutions rode in grouped launches; level 2 adds the 128x128-tile one
+        assert seen.count(2 * 8 + 4 + 1) >= 2 * 6 and seen.count(2 * 8 + 4 + 0) >= 2, seen
+        assert (seen.count(0 * 8 + 4 + 0) >= 2) == (level == 2), seen
+    for a, a2, b in zip(runs[0], runs[1], want):
+        assert torch.equal(a, a2)
+        assert_close(a, b, 2e-5, 2e-5, 'grouped weight gradient')
 
 
 @pytest.mark.parametrize('rows,D,relu,x2,skip', [(190, 128, False, False, True), (126, 256, True, True, False),

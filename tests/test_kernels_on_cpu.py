@@ -68,6 +68,7 @@ def test_paired_layer_kernels():
     G.test_conv_bn_statistics_from_the_gemm_epilogue((3, 9, 7, 32, 72, 3, 2, 1, True))          # statistics epilogue + ReLU gate
     G.test_conv_bn_epilogue_statistics_survive_a_large_mean()
     G.test_adam_one_launch_matches_torch(False, 1e-2)
+    G.test_grouped_weight_gradients(2)          # the grouped launch through the ops layer (ABI-level fuzz below)
 
 
 def test_norm_softmax_attention_kernels():
@@ -437,6 +438,84 @@ def test_batched_entry_points_fuzz_against_emulator():
             blk = ref[t * rp:(t + 1) * rp]
             assert np.allclose(st[t, 0], blk.mean(0), rtol=1e-5, atol=1e-5), ('block mean', M, N, t)
             assert np.allclose(st[t, 1], ((blk - blk.mean(0)) ** 2).sum(0), rtol=2e-4, atol=1e-4), ('block M2', M, N, t)
+
+
+def test_grouped_gemm_fuzz_against_emulator():
+    """Differential test of the grouped launch (rih_gemm_multi_pack / _launch: problems of one kernel variant in ONE launch, table
+    in "device" memory, block -> problem map, padding blocks): random weight-gradient problems -- plain and conv-gather A
+    operands, bias rows (ones_row), split-K with ragged last slices, paired batches (nb1 = 2) -- real kernel against the numpy
+    restatement of rih_gemm per problem; both tile classes."""
+    import ctypes as C
+    import numpy as np
+    from abi_emulator import EmulatedLib
+    from host_kernels import load
+    from renderih_amd._lib import GemmDesc
+    host, emu = load(), EmulatedLib()
+    rs = np.random.RandomState(23)
+    f32 = np.float32
+    for tile, plain, n in ((2, True, 9), (2, False, 5), (0, True, 3), (0, False, 2)):
+        probs = []
+        for _ in range(n):
+            nb = int(rs.choice([1, 2]))
+            N = int(rs.choice([36, 64, 72] if tile == 2 else [72, 136]))
+            if plain:
+                Kpix = int(rs.choice([32, 96, 132, 260]))
+                Cin = int(rs.choice([8, 40, 68] if tile == 2 else [132]))
+                geom = (1, 1, Cin, 1, 1, 1, 1, 1, 1, 0, 0)
+                taps, xrows = 1, Kpix
+            else:
+                H = W = int(rs.choice([4, 8]))
+                imgs, Cin, taps = int(rs.choice([1, 2])), int(rs.choice([8, 16] if tile == 2 else [16])), 9
+                geom = (H, W, Cin, H, W, 3, 3, 1, 1, 1, 1)
+                Kpix, xrows = imgs * H * W, imgs * H * W
+            M = taps * Cin
+            bias = bool(rs.rand() < 0.5)
+            Mp = M + 4 if bias else M
+            sk = int(rs.choice([1, 2, 3]))
+            kchunk = -(-(-(-Kpix // sk)) // 32) * 32
+            sk = -(-Kpix // kchunk)
+            x = rs.randn(nb, xrows, Cin).astype(f32)
+            dy = rs.randn(nb, Kpix, N).astype(f32)
+            probs.append((nb, M, Mp, N, Kpix, Cin, geom, bias, sk, kchunk, x, dy))
+        outs = []
+        for lib in (host, emu):
+            arr = (GemmDesc * n)()
+            parts = []
+            for d, (nb, M, Mp, N, Kpix, Cin, geom, bias, sk, kchunk, x, dy) in zip(arr, probs):
+                part = np.full((nb, sk, Mp, N), 7.0, f32)
+                parts.append(part)
+                d.A, d.B, d.C = x.ctypes.data, dy.ctypes.data, part.ctypes.data
+                d.M, d.N, d.K = Mp, N, Kpix
+                d.lda, d.ldb, d.ldc = Cin, N, N
+                d.a_mode, d.b_mode, d.nb1, d.nb2 = 1, 0, nb, 1
+                d.sA1, d.sB1, d.sC1 = x[0].size, dy[0].size, sk * Mp * N
+                d.splitk, d.kchunk, d.sCsplit = sk, (kchunk if sk > 1 else 0), Mp * N
+                d.alpha, d.tile, d.engine = 1.0, tile, 1
+                (d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.strideA, d.upS, d.padH, d.padW) = geom
+                d.ones_row = M if bias else 0
+                assert lib.rih_gemm_multi_variant(C.byref(d)) == tile * 8 + 4 + (1 if plain else 0), (tile, plain)
+            nbytes = int(lib.rih_gemm_multi_table_bytes(arr, n))
+            assert nbytes > 0
+            table = np.zeros(nbytes + 16, np.uint8)
+            tp = (table.ctypes.data + 15) & ~15
+            total = C.c_int32(0)
+            v = lib.rih_gemm_multi_pack(arr, n, tp, C.byref(total))
+            assert v == tile * 8 + 4 + (1 if plain else 0) and total.value % 8 == 0 and total.value >= 8
+            assert lib.rih_gemm_multi_launch(tp, v, total.value, None) == 0
+            outs.append(parts)
+        for i, (nb, M, Mp, N, Kpix, Cin, geom, bias, sk, kchunk, x, dy) in enumerate(probs):
+            a, b = outs[0][i], outs[1][i]
+            rows = M + 1 if bias else M          # rows past the all-ones row are junk by contract
+            scale = np.abs(b[:, :, :rows]).max() + 1e-6
+            assert np.abs(a[:, :, :rows] - b[:, :, :rows]).max() <= 2e-6 * scale * max(1.0, Kpix ** 0.5), \
+                ('grouped gemm', tile, plain, i, (nb, M, N, Kpix, sk))
+    # a descriptor of another variant, and a mixed list, are refused
+    d = GemmDesc()
+    assert emu.rih_gemm_multi_variant(d) == -1
+    arr = (GemmDesc * 2)()
+    for lib in (host,):
+        C.memmove(C.byref(arr[0]), C.byref(d), C.sizeof(d))
+        assert lib.rih_gemm_multi_table_bytes(arr, 2) == 0
 
 
 @pytest.mark.skipif(not os.environ.get('HIPCPU_MORE'), reason='set HIPCPU_MORE=1: ~1 min of extra scheduling runs')

@@ -56,6 +56,9 @@ def main():
         assert order == [('stage', 0), ('reduce', 0), ('stage', 1), ('reduce', 1), ('stage', 2), ('reduce', 2)], order
         n_live = 0
         worst = 0.0
+        # (a gradient that is mathematically zero -- the key bias of a softmax attention -- is pure round-off, whose value
+        # depends on the split-K partition of the weight-gradient GEMMs: errors are measured against the largest gradient too)
+        gmax = max(float(v.abs().max()) for v in local.values())
         for k, p in m.named_parameters():
             if k in local:
                 want = local[k].clone()
@@ -63,7 +66,7 @@ def main():
                     dist.all_reduce(want)
                     want /= world
                 assert p.grad is not None, k
-                err = float((p.grad - want).abs().max() / (want.abs().max() + 1e-30))
+                err = float((p.grad - want).abs().max() / (want.abs().max() + 1e-6 * gmax))
                 worst = max(worst, err)
                 assert err < 2e-5, (k, err)
                 n_live += 1
