@@ -463,7 +463,28 @@ int rih_abi_sizes(int32_t* out9);
 const char* rih_arch(void);
 
 /* ------------------------------------------------------------------------------------------------
- * Fused attention forward (models/model_attn/self_attn.py:70-76, inter_attn.py:93-107): out = softmax(alpha q k^T)
+ * Attention without a score matrix in memory (csrc/rih_flash.hip) -- the default path of SelfAttn / inter_attn
+ * (models/model_attn/self_attn.py:70-76: `attn = softmax(q k^T / sqrt(d_q)); attn = dropout(attn); out = attn v`;
+ * inter_attn.py:93-107: the two cross-hand directions).  q / k / v are head-sliced in place: row pitches q_ld / kv_ld floats,
+ * head h at column h*d, slice b at row b*Sq (b*Sk); d in {16, 32, 64}; B*heads <= 65535.
+ *   rih_flash_attention_fwd: out[b][i][h*d + c] = sum_j Pd[i][j] v[j][c], Pd = dropout(softmax_j(alpha q_i . k_j)); one launch;
+ *     lse[B*heads][Sq] receives log2(sum_j 2^(alpha log2(e) q_i . k_j)) -- all the backward needs besides q, k, v, out.
+ *     Dropout: element (row r = (b*heads + h)*Sq + i, column j) is kept iff hash(seed (+ *seed_dev), r*Sk + j) >= p * 2^32, kept
+ *     values scaled by 1/(1-p) -- the mask of rih_softmax_fwd, bit for bit.
+ *   rih_flash_attention_bwd: dq, dk, dv (row pitches dq_ld / dkv_ld, same head slicing) from dO [B][Sq][do_ld] and the saved
+ *     out / lse, recomputing the probabilities tile by tile; two launches (query side, then key side); Dws [B*heads][Sq] is
+ *     workspace (receives rowsum(dO o out)).  Every element of the dq / dk / dv head slices is written exactly once. */
+int rih_flash_attention_fwd(const float* q, int q_ld, const float* k, const float* v, int kv_ld, int B, int heads, int Sq,
+                            int Sk, int d, float alpha, float drop_p, uint64_t seed, const uint64_t* seed_dev, float* out,
+                            int ld_out, float* lse, void* stream);
+int rih_flash_attention_bwd(const float* dO, int do_ld, const float* O, int o_ld, const float* q, int q_ld, const float* k,
+                            const float* v, int kv_ld, int B, int heads, int Sq, int Sk, int d, float alpha, float drop_p,
+                            uint64_t seed, const uint64_t* seed_dev, const float* lse, float* Dws, float* dq, int dq_ld,
+                            float* dk, float* dv, int dkv_ld, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused attention forward, first generation (keeps P / Pd in memory; superseded by rih_flash_attention_*, kept as an opt-in
+ * experiment RIH_FUSED_ATTN=1): out = softmax(alpha q k^T)
  * [dropout] v per (image, head) in ONE launch; q / k / v are head-sliced in place (row pitches q_ld / kv_ld, head h at
  * column h*d), out [B][Sq][ld_out] at column h*d.  P and Pd [B][heads][Sq][ldP] receive the probabilities before / after
  * dropout for the backward (Pd may equal P when drop_p == 0).  d in {16, 32, 64}, Sk <= 320.  Dropout mask and seed as

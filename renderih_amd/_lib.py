@@ -179,6 +179,10 @@ SIGNATURES = {
     'rih_gemm_multi_launch': (c_i, [C.c_void_p, c_i, c_i, C.c_void_p]),
     'rih_bn_stats_from_blocks': (c_i, [c_f, c_i, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, C.c_void_p]),
     'rih_bn_stats_from_tiles': (c_i, [c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, C.c_void_p]),
+    'rih_flash_attention_fwd': (c_i, [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_u64, C.c_void_p, c_f,
+                                      c_i, c_f, C.c_void_p]),
+    'rih_flash_attention_bwd': (c_i, [c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl,
+                                      c_u64, C.c_void_p, c_f, c_f, c_f, c_i, c_f, c_f, c_i, C.c_void_p]),
     'rih_version': (c_i, []),
     'rih_abi_sizes': (c_i, [C.POINTER(C.c_int32)]),
     'rih_arch': (C.c_char_p, []),

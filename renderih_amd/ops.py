@@ -1314,11 +1314,43 @@ def layernorm_pair_skip(x, mL, mR):
 FUSED_ATTN = os.environ.get('RIH_FUSED_ATTN', '0') == '1'
 
 
+# Attention without a score matrix in memory (csrc/rih_flash.hip): forward one launch, backward two; what is kept for the
+# backward is the output and one log-sum-exp word per query row instead of two [B, heads, Sq, Sk] probability tensors.  The
+# default; RIH_FLASH_ATTN=0 = the three-kernel sequence (batched QK^T GEMM, softmax, batched PV GEMM; five launches backward).
+FLASH_ATTN = os.environ.get('RIH_FLASH_ATTN', '1') == '1'
+
+
+def _flash_ok(d, B, heads):
+    return FLASH_ATTN and not FUSED_ATTN and d in (16, 32, 64) and B * heads <= 65535
+
+
+def _profiled(flops, tag, fn):
+    """Run one MFMA-family launch; with ops.PROFILE set, bracket it with events like rih_gemm launches."""
+    if PROFILE is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    PROFILE.append((flops, e0, e1, tag))
+
+
 def _attn_forward(q, q_ld, k, v, kv_ld, B, Sq, Sk, D, heads, drop_p, seed, device, out=None):
-    """q/k/v: raw device pointers to the first element of [B,S,*] slices with row pitch q_ld / kv_ld."""
+    """q/k/v: raw device pointers to the first element of [B,S,*] slices with row pitch q_ld / kv_ld.
+    Returns (out, P, Pd) for _attn_backward: the probabilities before / after dropout, or -- on the flash path -- (out, lse, None)
+    with lse [B, heads, Sq]; the flash backward also needs `out`."""
     d = D // heads
     ldP = _cdiv(Sk, 4) * 4
     alpha = 1.0 / math.sqrt(d)
+    if _flash_ok(d, B, heads):
+        if out is None:
+            out = torch.empty((B, Sq, D), device=device, dtype=torch.float32)
+        lse = torch.empty((B, heads, Sq), device=device, dtype=torch.float32)
+        ptr = lambda t: t if isinstance(t, int) else t.data_ptr()
+        _profiled(4.0 * B * heads * Sq * Sk * d, (Sq, Sk, d, B * heads, 0, 1, 30, 1, 0), lambda: check(
+            _L().rih_flash_attention_fwd(ptr(q), q_ld, ptr(k), ptr(v), kv_ld, B, heads, Sq, Sk, d, alpha, drop_p, seed,
+                                         _seed_dev(), out.data_ptr(), D, lse.data_ptr(), _stream()), 'rih_flash_attention_fwd'))
+        return out, lse, None
     P = torch.empty((B, heads, Sq, ldP), device=device, dtype=torch.float32)
     if FUSED_ATTN and d in (16, 32, 64) and Sk <= 320 and B * heads <= 65535:
         Pd = torch.empty_like(P) if drop_p > 0 else P
@@ -1341,15 +1373,24 @@ def _attn_forward(q, q_ld, k, v, kv_ld, B, Sq, Sk, D, heads, drop_p, seed, devic
     return out, P, (Pd if drop_p > 0 else None)
 
 
-def _attn_backward(do, q, q_ld, k, v, kv_ld, dq, dq_ld, dk, dv, dkv_ld, P, Pd, B, Sq, Sk, D, heads, drop_p, seed):
-    """Writes dq / dk / dv (raw pointers, row pitches dq_ld / dkv_ld) given do [B,Sq,D] (contiguous tensor)."""
+def _attn_backward(do, q, q_ld, k, v, kv_ld, dq, dq_ld, dk, dv, dkv_ld, P, Pd, B, Sq, Sk, D, heads, drop_p, seed, out=None):
+    """Writes dq / dk / dv (raw pointers, row pitches dq_ld / dkv_ld) given do [B,Sq,D] (contiguous tensor).
+    P [B, heads, Sq] (3-d) = the log-sum-exp words of the flash forward, which also needs its output `out` [B,Sq,D]."""
+    d = D // heads
+    alpha = 1.0 / math.sqrt(d)
+    ptr = lambda t: t if isinstance(t, int) else t.data_ptr()
+    if P.dim() == 3:
+        assert out is not None and out.is_contiguous() and tuple(out.shape) == (B, Sq, D)
+        ws = torch.empty_like(P)
+        _profiled(14.0 * B * heads * Sq * Sk * d, (Sq, Sk, d, B * heads, 1, 1, 30, 1, 0), lambda: check(
+            _L().rih_flash_attention_bwd(do.data_ptr(), D, out.data_ptr(), D, ptr(q), q_ld, ptr(k), ptr(v), kv_ld, B, heads, Sq,
+                                         Sk, d, alpha, drop_p, seed, _seed_dev(), P.data_ptr(), ws.data_ptr(), ptr(dq), dq_ld,
+                                         ptr(dk), ptr(dv), dkv_ld, _stream()), 'rih_flash_attention_bwd'))
+        return
     if Pd is None:
         Pd = P
-    d = D // heads
     ldP = P.shape[-1]
-    alpha = 1.0 / math.sqrt(d)
     sP = (heads * Sq * ldP, Sq * ldP)
-    ptr = lambda t: t if isinstance(t, int) else t.data_ptr()
     if FUSED_ATTN and d in (16, 32, 64) and Sk <= 320 and B * heads <= 65535:
         dS = torch.empty_like(P)
         check(_L().rih_attention_bwd_dq_fused(do.data_ptr(), D, ptr(k), ptr(v), kv_ld, B, heads, Sq, Sk, d, alpha, drop_p,
@@ -1386,20 +1427,20 @@ class AttentionFn(torch.autograd.Function):
         Sk = k.shape[1]
         out, P, Pd = _attn_forward(q.data_ptr(), D, k.data_ptr(), v.data_ptr(), D, B, Sq, Sk, D, heads, drop_p, seed,
                                    q.device)
-        ctx.save_for_backward(q, k, v, P, Pd)
+        ctx.save_for_backward(q, k, v, P, Pd, out if P.dim() == 3 else None)
         ctx.cfg = (heads, drop_p, seed)
         return out
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, P, Pd = ctx.saved_tensors
+        q, k, v, P, Pd, out = ctx.saved_tensors
         heads, drop_p, seed = ctx.cfg
         do = _c(do)
         B, Sq, D = q.shape
         Sk = k.shape[1]
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         _attn_backward(do, q.data_ptr(), D, k.data_ptr(), v.data_ptr(), D, dq.data_ptr(), D, dk.data_ptr(),
-                       dv.data_ptr(), D, P, Pd, B, Sq, Sk, D, heads, drop_p, seed)
+                       dv.data_ptr(), D, P, Pd, B, Sq, Sk, D, heads, drop_p, seed, out=out)
         return dq, dk, dv, None, None, None
 
 
@@ -1419,13 +1460,13 @@ class SelfAttentionPackedFn(torch.autograd.Function):
         D = D3 // 3
         p0 = qkv.data_ptr()
         out, P, Pd = _attn_forward(p0, D3, p0 + 4 * D, p0 + 8 * D, D3, B, S, S, D, heads, drop_p, seed, qkv.device)
-        ctx.save_for_backward(qkv, P, Pd)
+        ctx.save_for_backward(qkv, P, Pd, out if P.dim() == 3 else None)
         ctx.cfg = (heads, drop_p, seed)
         return out
 
     @staticmethod
     def backward(ctx, do):
-        qkv, P, Pd = ctx.saved_tensors
+        qkv, P, Pd, out = ctx.saved_tensors
         heads, drop_p, seed = ctx.cfg
         do = _c(do)
         B, S, D3 = qkv.shape
@@ -1433,7 +1474,7 @@ class SelfAttentionPackedFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         p0, g0 = qkv.data_ptr(), dqkv.data_ptr()
         _attn_backward(do, p0, D3, p0 + 4 * D, p0 + 8 * D, D3, g0, D3, g0 + 4 * D, g0 + 8 * D, D3, P, Pd, B, S, S, D,
-                       heads, drop_p, seed)
+                       heads, drop_p, seed, out=out)
         return dqkv, None, None, None
 
 
@@ -1456,13 +1497,14 @@ class CrossAttentionPackedFn(torch.autograd.Function):
         l0, r0 = Lqkv.data_ptr(), Rqkv.data_ptr()
         o_r2l, P1, Pd1 = _attn_forward(l0, D3, r0 + 4 * D, r0 + 8 * D, D3, B, V, V, D, heads, drop_p, seed_r2l, Lqkv.device)
         o_l2r, P2, Pd2 = _attn_forward(r0, D3, l0 + 4 * D, l0 + 8 * D, D3, B, V, V, D, heads, drop_p, seed_l2r, Lqkv.device)
-        ctx.save_for_backward(Lqkv, Rqkv, P1, Pd1, P2, Pd2)
+        fl = P1.dim() == 3
+        ctx.save_for_backward(Lqkv, Rqkv, P1, Pd1, P2, Pd2, o_r2l if fl else None, o_l2r if fl else None)
         ctx.cfg = (heads, drop_p, seed_r2l, seed_l2r)
         return o_r2l, o_l2r
 
     @staticmethod
     def backward(ctx, d_r2l, d_l2r):
-        Lqkv, Rqkv, P1, Pd1, P2, Pd2 = ctx.saved_tensors
+        Lqkv, Rqkv, P1, Pd1, P2, Pd2, o1, o2 = ctx.saved_tensors
         heads, drop_p, seed_r2l, seed_l2r = ctx.cfg
         d_r2l, d_l2r = _c(d_r2l), _c(d_l2r)
         B, V, D3 = Lqkv.shape
@@ -1471,10 +1513,10 @@ class CrossAttentionPackedFn(torch.autograd.Function):
         l0, r0, gl, gr = Lqkv.data_ptr(), Rqkv.data_ptr(), dL.data_ptr(), dR.data_ptr()
         # R2L: q from L, k/v from R
         _attn_backward(d_r2l, l0, D3, r0 + 4 * D, r0 + 8 * D, D3, gl, D3, gr + 4 * D, gr + 8 * D, D3, P1, Pd1, B, V, V, D,
-                       heads, drop_p, seed_r2l)
+                       heads, drop_p, seed_r2l, out=o1)
         # L2R: q from R, k/v from L
         _attn_backward(d_l2r, r0, D3, l0 + 4 * D, l0 + 8 * D, D3, gr, D3, gl + 4 * D, gl + 8 * D, D3, P2, Pd2, B, V, V, D,
-                       heads, drop_p, seed_l2r)
+                       heads, drop_p, seed_l2r, out=o2)
         return dL, dR, None, None, None, None
 
 
@@ -1501,13 +1543,14 @@ class CrossAttentionStackedFn(torch.autograd.Function):
                                    out=out[0])
         _, P2, Pd2 = _attn_forward(r0, D3, kr + 4 * D, l0 + 8 * D, D3, B, V, V, D, heads, drop_p, seed_l2r, qkv.device,
                                    out=out[1])
-        ctx.save_for_backward(qkv, P1, Pd1, P2, Pd2)
+        ctx.save_for_backward(qkv, P1, Pd1, P2, Pd2, out if P1.dim() == 3 else None)
         ctx.cfg = (heads, drop_p, seed_r2l, seed_l2r, own_keys)
         return out
 
     @staticmethod
     def backward(ctx, do):
-        qkv, P1, Pd1, P2, Pd2 = ctx.saved_tensors
+        qkv, P1, Pd1, P2, Pd2, out = ctx.saved_tensors
+        o1, o2 = (out[0], out[1]) if out is not None else (None, None)
         heads, drop_p, seed_r2l, seed_l2r, own_keys = ctx.cfg
         do = _c(do)
         _, B, V, D3 = qkv.shape
@@ -1518,9 +1561,9 @@ class CrossAttentionStackedFn(torch.autograd.Function):
         # every slot of dqkv is written exactly once: q by its own direction, k by the direction that read it, v by
         # the other hand's direction
         _attn_backward(do[0], l0, D3, kl + 4 * D, r0 + 8 * D, D3, gl, D3, gkl + 4 * D, gr + 8 * D, D3, P1, Pd1, B, V, V, D,
-                       heads, drop_p, seed_r2l)
+                       heads, drop_p, seed_r2l, out=o1)
         _attn_backward(do[1], r0, D3, kr + 4 * D, l0 + 8 * D, D3, gr, D3, gkr + 4 * D, gl + 8 * D, D3, P2, Pd2, B, V, V, D,
-                       heads, drop_p, seed_l2r)
+                       heads, drop_p, seed_l2r, out=o2)
         return dqkv, None, None, None, None, None
 
 

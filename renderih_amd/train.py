@@ -303,7 +303,8 @@ class TrainStep:
                 for p, s_ in zip(self.model.parameters(), saved_p):
                     p.copy_(s_)
                 for b, s_ in zip(self.model.buffers(), saved_b):
-                    b.copy_(s_)
+                    if not torch.equal(b, s_):      # (untouched buffers keep their version: constants cached on it stay valid)
+                        b.copy_(s_)
         torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
         self.opt.load_state_dict(saved_opt)

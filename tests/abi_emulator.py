@@ -389,6 +389,73 @@ class EmulatedLib:
         return 0
 
     # ------------------------------------------------------------------ fused attention forward
+    # attention without a score matrix (rih_flash_attention_*): the header's contract restated per (image, head) slice
+    def _flash_slices(self, B, heads, S, ld, d):
+        cols = np.arange(d)
+        return lambda b, h: ((b * S + np.arange(S))[:, None] * ld + h * d + cols[None, :])
+
+    def _flash_probs(self, Qs, Ks, alpha, seed, drop_p, r0, Sq, Sk):
+        s = np.float64(alpha) * (Qs.astype(np.float64) @ Ks.astype(np.float64).T)
+        mx = s.max(1, keepdims=True)
+        e = np.exp(s - mx)
+        p = e / e.sum(1, keepdims=True)
+        lse2 = (mx[:, 0] + np.log(e.sum(1))) / np.log(2.0)
+        keep = np.ones((Sq, Sk))
+        if drop_p > 0:
+            idx = ((r0 + np.arange(Sq))[:, None] * Sk + np.arange(Sk)[None, :]).ravel()
+            thr = np.uint64(min(int(float(np.float32(drop_p)) * 4294967296.0), 4294967295))
+            keep = ((hash_np(seed, idx) >= thr).astype(np.float64) / (1.0 - float(np.float32(drop_p)))).reshape(Sq, Sk)
+        return p, keep, lse2
+
+    def rih_flash_attention_fwd(self, q, q_ld, k, v, kv_ld, B, heads, Sq, Sk, d, alpha, drop_p, seed, seed_dev, out, ld_out,
+                                lse, stream):
+        assert d in (16, 32, 64) and B * heads <= 65535
+        seed = self._seed(seed, seed_dev)
+        Q = _f(q, (B * Sq - 1) * q_ld + heads * d)
+        Kk = _f(k, (B * Sk - 1) * kv_ld + heads * d)
+        Vv = _f(v, (B * Sk - 1) * kv_ld + heads * d)
+        O = _f(out, (B * Sq - 1) * ld_out + heads * d)
+        L = _f(lse, B * heads * Sq)
+        qi, ki, oi = (self._flash_slices(B, heads, Sq, q_ld, d), self._flash_slices(B, heads, Sk, kv_ld, d),
+                      self._flash_slices(B, heads, Sq, ld_out, d))
+        for b in range(B):
+            for h in range(heads):
+                r0 = (b * heads + h) * Sq
+                p, keep, lse2 = self._flash_probs(Q[qi(b, h)], Kk[ki(b, h)], alpha, seed, drop_p, r0, Sq, Sk)
+                O[oi(b, h).ravel()] = ((p * keep) @ Vv[ki(b, h)].astype(np.float64)).astype(np.float32).ravel()
+                L[r0:r0 + Sq] = lse2.astype(np.float32)
+        return 0
+
+    def rih_flash_attention_bwd(self, dO, do_ld, O, o_ld, q, q_ld, k, v, kv_ld, B, heads, Sq, Sk, d, alpha, drop_p, seed,
+                                seed_dev, lse, Dws, dq, dq_ld, dk, dv, dkv_ld, stream):
+        seed = self._seed(seed, seed_dev)
+        G = _f(dO, (B * Sq - 1) * do_ld + heads * d)
+        Om = _f(O, (B * Sq - 1) * o_ld + heads * d)
+        Q = _f(q, (B * Sq - 1) * q_ld + heads * d)
+        Kk = _f(k, (B * Sk - 1) * kv_ld + heads * d)
+        Vv = _f(v, (B * Sk - 1) * kv_ld + heads * d)
+        dQ = _f(dq, (B * Sq - 1) * dq_ld + heads * d)
+        dK = _f(dk, (B * Sk - 1) * dkv_ld + heads * d)
+        dV = _f(dv, (B * Sk - 1) * dkv_ld + heads * d)
+        Dw = _f(Dws, B * heads * Sq)
+        sl = self._flash_slices
+        gi, oi, qi, ki = sl(B, heads, Sq, do_ld, d), sl(B, heads, Sq, o_ld, d), sl(B, heads, Sq, q_ld, d), sl(B, heads, Sk, kv_ld, d)
+        dqi, dki = sl(B, heads, Sq, dq_ld, d), sl(B, heads, Sk, dkv_ld, d)
+        for b in range(B):
+            for h in range(heads):
+                r0 = (b * heads + h) * Sq
+                Qs, Ks, Vs, Gs = (Q[qi(b, h)].astype(np.float64), Kk[ki(b, h)].astype(np.float64), Vv[ki(b, h)].astype(np.float64),
+                                  G[gi(b, h)].astype(np.float64))
+                p, keep, _ = self._flash_probs(Qs, Ks, alpha, seed, drop_p, r0, Sq, Sk)
+                dpd = (Gs @ Vs.T) * keep
+                D = (Gs * Om[oi(b, h)].astype(np.float64)).sum(1)
+                ds = np.float64(alpha) * p * (dpd - D[:, None])
+                Dw[r0:r0 + Sq] = D.astype(np.float32)
+                dQ[dqi(b, h).ravel()] = (ds @ Ks).astype(np.float32).ravel()
+                dK[dki(b, h).ravel()] = (ds.T @ Qs).astype(np.float32).ravel()
+                dV[dki(b, h).ravel()] = ((p * keep).T @ Gs).astype(np.float32).ravel()
+        return 0
+
     def rih_attention_fwd_fused(self, q, q_ld, k, v, kv_ld, B, heads, Sq, Sk, d, alpha, drop_p, seed, seed_dev, P, Pd, ldP,
                                 out, ld_out, stream):
         seed = self._seed(seed, seed_dev)

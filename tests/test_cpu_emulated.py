@@ -36,6 +36,7 @@ def test_other_ops_host_logic():
     G.test_attention(2, 127, 127, 256, 4)
     G.test_attention(2, 126, 252, 128, 4)
     G.test_attention_dropout_matches_hash_mask()
+    G.test_flash_attention_equals_three_kernel_path(2, 63, 252, 128, 4, 0.1)
     G.test_self_attention_packed(2, 190, 128, 4)
     G.test_cross_attention_packed(2, 63, 256, 4)
     G.test_add_dropout_and_bcast()

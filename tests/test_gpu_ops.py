@@ -202,6 +202,31 @@ def test_attention(B, Sq, Sk, D, h):
         assert_close(a.grad, bb.grad, 1e-3, 1e-4, 'attn ' + name)
 
 
+@pytest.mark.parametrize('B,Sq,Sk,D,h,p', [(2, 127, 127, 256, 4, 0.0), (1, 190, 190, 128, 4, 0.1), (1, 316, 316, 64, 4, 0.05),
+                                          (2, 63, 252, 128, 4, 0.0), (1, 33, 5, 64, 4, 0.2), (3, 1, 129, 32, 2, 0.0)])
+def test_flash_attention_equals_three_kernel_path(B, Sq, Sk, D, h, p):
+    """rih_flash_attention_* (no score matrix in memory: online softmax on transposed score tiles, probabilities recomputed in
+    the backward from one log-sum-exp word per row) against the three-kernel sequence (batched QK^T GEMM, softmax, batched PV
+    GEMM) it replaces, on the decoder's shapes -- head widths 64 / 32 / 16, ragged query and key counts, cross attention with
+    Sq != Sk, a single query row -- with the SAME dropout mask (same hash, same element index): outputs and dq / dk / dv."""
+    from renderih_amd import ops
+    d = dev()
+    q, k, v, gy = rnd(B, Sq, D, seed=1), rnd(B, Sk, D, seed=2) * 1.5, rnd(B, Sk, D, seed=3), rnd(B, Sq, D, seed=4)
+    res = []
+    saved = ops.FLASH_ATTN
+    try:
+        for flash in (False, True):
+            ops.FLASH_ATTN = flash
+            tg = [t.to(d).requires_grad_(True) for t in (q, k, v)]
+            y = ops.attention(tg[0], tg[1], tg[2], h, p, 987654321)
+            y.backward(gy.to(d))
+            res.append([y.detach()] + [t.grad for t in tg])
+    finally:
+        ops.FLASH_ATTN = saved
+    for name, a, b in zip(('out', 'dq', 'dk', 'dv'), res[1], res[0]):
+        assert_close(a, b, 2e-4, 2e-5, 'flash attention ' + name)
+
+
 def _hash_np(seed, idx):
     """numpy mirror of rih_hash (csrc/rih_elem.hip)."""
     M = np.uint64(0xFFFFFFFFFFFFFFFF)

@@ -89,6 +89,11 @@ def test_norm_softmax_attention_kernels():
     G.test_add_dropout_and_bcast()
 
 
+@pytest.mark.parametrize('case', [(2, 40, 40, 256, 4, 0.0), (1, 70, 33, 128, 4, 0.1), (1, 33, 130, 64, 4, 0.05), (2, 1, 5, 32, 2, 0.0)])
+def test_flash_attention_kernels(case):
+    G.test_flash_attention_equals_three_kernel_path(*case)
+
+
 def test_graph_and_resampling_kernels():
     G.test_cheby_gather_project()
     G.test_pool_upsample_layout()
