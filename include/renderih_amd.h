@@ -319,7 +319,8 @@ int rih_layernorm_bwd_grouped(const float* dy, const float* x, const float* x2, 
                               const float* mean, const float* rstd, const float* dres, float* dx, float* dg, float* db,
                               int groups, int rows, int D, int64_t sG, int relu, float* ws, void* stream);
 /* softmax over the last dim of [rows][ld] (first `cols` entries), optional inverted dropout with a
- * counter-based hash RNG: P (pre-dropout probabilities) and Pd (post-dropout, may alias P when p==0).
+ * counter-based hash RNG (csrc/rih_hash.h: element idx of stream `seed` is kept iff mix32(lo32(idx) ^ hi32(idx) * 0x85EBCA6B ^
+ * key(seed)) >= p * 2^32): P (pre-dropout probabilities) and Pd (post-dropout, may alias P when p==0).
  * Every dropout entry point takes the stream id of the mask as `seed` plus an optional DEVICE word `seed_dev` (may be
  * NULL) that is added to it on the GPU: a training step captured in a hipGraph advances that word inside the graph
  * and gets a fresh mask at every replay, with no host involvement. */

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/renderih_amd.h"
+#include "rih_hash.h"
 
 namespace {
 
@@ -26,15 +27,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int TPB = 256;
 constexpr int NTMAX = 10;           // key tiles of 32: Sk <= 320
 
-__device__ __forceinline__ uint32_t attn_hash(uint64_t seed, uint64_t idx) {       // = rih_hash of rih_elem.hip
-    uint64_t x = idx * 0x9E3779B97F4A7C15ull + seed;
-    x ^= x >> 32;
-    x *= 0xD6E8FEB86659FD93ull;
-    x ^= x >> 32;
-    x *= 0xD6E8FEB86659FD93ull;
-    x ^= x >> 32;
-    return (uint32_t)x;
-}
+__device__ __forceinline__ uint32_t attn_hash(uint64_t seed, uint64_t idx) { return rih_hash(seed, idx); }
 __device__ __forceinline__ uint32_t attn_thresh(float p) {
     double t = (double)p * 4294967296.0;
     if (t < 0.0) t = 0.0;

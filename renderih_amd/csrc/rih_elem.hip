@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <math.h>
 #include "../../include/renderih_amd.h"
+#include "rih_hash.h"
 
 namespace {
 
@@ -41,16 +42,7 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// counter-based RNG for dropout: 32 uniform bits from (seed, element index)
-__device__ __forceinline__ uint32_t rih_hash(uint64_t seed, uint64_t idx) {
-    uint64_t x = idx * 0x9E3779B97F4A7C15ull + seed;
-    x ^= x >> 32;
-    x *= 0xD6E8FEB86659FD93ull;
-    x ^= x >> 32;
-    x *= 0xD6E8FEB86659FD93ull;
-    x ^= x >> 32;
-    return (uint32_t)x;
-}
+// counter-based RNG for dropout: 32 uniform bits from (seed, element index) -- rih_hash.h
 __device__ __forceinline__ uint32_t drop_thresh(float p) {
     double t = (double)p * 4294967296.0;
     if (t < 0.0) t = 0.0;

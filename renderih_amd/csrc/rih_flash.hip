@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/renderih_amd.h"
+#include "rih_hash.h"
 
 namespace {
 
@@ -28,14 +29,10 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int TPB = 256;
 constexpr float LOG2E = 1.4426950408889634f;
 
-__device__ __forceinline__ uint32_t fl_hash(uint64_t seed, uint64_t idx) {       // = rih_hash of rih_elem.hip
-    uint64_t x = idx * 0x9E3779B97F4A7C15ull + seed;
-    x ^= x >> 32;
-    x *= 0xD6E8FEB86659FD93ull;
-    x ^= x >> 32;
-    x *= 0xD6E8FEB86659FD93ull;
-    x ^= x >> 32;
-    return (uint32_t)x;
+// mask word of element idx (rih_hash.h); `key` = rih_seed_key(seed), computed once per thread.  The element count of a score
+// tensor (B * heads * Sq * Sk) fits 32 bits for every decoder shape; the 64-bit form is the same function on wider indices.
+__device__ __forceinline__ uint32_t fl_hash(uint32_t key, long long idx, bool wide) {
+    return wide ? rih_hash_k64(key, (uint64_t)idx) : rih_hash_k32(key, (uint32_t)idx);
 }
 __device__ __forceinline__ uint32_t fl_thresh(float p) {
     double t = (double)p * 4294967296.0;
@@ -46,15 +43,48 @@ __device__ __forceinline__ uint32_t fl_thresh(float p) {
 // accumulator register r of lane (l31, lhi) holds row acc_row(r, lhi), column l31 of a 32x32 MFMA tile
 __device__ __forceinline__ int acc_row(int r, int lhi) { return (r & 3) + 8 * (r >> 2) + 4 * lhi; }
 
-// Two [32][DH] operand tiles (rows r0.. of a and of b, row pitches lda / ldb floats, rows >= nrows read as zero) into LDS.
+// Two [32][DH] operand tiles (rows r0.. of a and of b, row pitches lda / ldb floats, rows >= nrows read as zero) on their way
+// into LDS, in two halves so that the global loads of tile j+1 fly during the arithmetic of tile j: `issue` puts them into
+// registers (16-byte loads when the operands allow), `commit` writes the registers to the LDS tiles.
 template <int DH>
-__device__ __forceinline__ void load_tiles(float (*As)[DH + 1], const float* __restrict__ a, long long lda, float (*Bs)[DH + 1],
-                                           const float* __restrict__ b, long long ldb, int r0, int nrows, int tid) {
-    for (int i = tid; i < 32 * DH; i += TPB) {
-        const int rr = i / DH, c = i - rr * DH, row = r0 + rr;
-        const bool ok = row < nrows;
-        As[rr][c] = ok ? a[(long long)row * lda + c] : 0.f;
-        Bs[rr][c] = ok ? b[(long long)row * ldb + c] : 0.f;
+struct TileRegs {
+    static constexpr int NV = (32 * DH / 4 + TPB - 1) / TPB;        // float4 slots per thread and operand
+    float4 a[NV], b[NV];
+};
+template <int DH>
+__device__ __forceinline__ void issue_tiles(TileRegs<DH>& t, const float* __restrict__ a, long long lda,
+                                            const float* __restrict__ b, long long ldb, int r0, int nrows, int tid, bool vec) {
+    constexpr int Q = DH / 4;
+#pragma unroll
+    for (int i = 0; i < TileRegs<DH>::NV; ++i) {
+        const int idx = tid + i * TPB;
+        const int rr = idx / Q, c = 4 * (idx - rr * Q), row = r0 + rr;
+        t.a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        t.b[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < 32 * Q && row < nrows) {
+            const float* pa = a + (long long)row * lda + c;
+            const float* pb = b + (long long)row * ldb + c;
+            if (vec) {
+                t.a[i] = *reinterpret_cast<const float4*>(pa);
+                t.b[i] = *reinterpret_cast<const float4*>(pb);
+            } else {
+                t.a[i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
+                t.b[i] = make_float4(pb[0], pb[1], pb[2], pb[3]);
+            }
+        }
+    }
+}
+template <int DH>
+__device__ __forceinline__ void commit_tiles(const TileRegs<DH>& t, float (*As)[DH + 1], float (*Bs)[DH + 1], int tid) {
+    constexpr int Q = DH / 4;
+#pragma unroll
+    for (int i = 0; i < TileRegs<DH>::NV; ++i) {
+        const int idx = tid + i * TPB;
+        if (idx < 32 * Q) {
+            const int rr = idx / Q, c = 4 * (idx - rr * Q);
+            As[rr][c] = t.a[i].x; As[rr][c + 1] = t.a[i].y; As[rr][c + 2] = t.a[i].z; As[rr][c + 3] = t.a[i].w;
+            Bs[rr][c] = t.b[i].x; Bs[rr][c + 1] = t.b[i].y; Bs[rr][c + 2] = t.b[i].z; Bs[rr][c + 3] = t.b[i].w;
+        }
     }
 }
 
@@ -81,12 +111,14 @@ __global__ __launch_bounds__(TPB) void flash_fwd_kernel(const float* __restrict_
                                                         const float* __restrict__ v, int kv_ld, int heads, int Sq, int Sk,
                                                         float alpha, float drop_p, uint64_t seed,
                                                         const uint64_t* __restrict__ seed_dev, float* __restrict__ out,
-                                                        int ld_out, float* __restrict__ lse, int vec_out) {
+                                                        int ld_out, float* __restrict__ lse, int vec_out, int vec_in) {
     constexpr int CT = (DH + 31) / 32;
     __shared__ float Ks[32][DH + 1];
     __shared__ float Vs[32][DH + 1];
     __shared__ float Ps[TPB / 64][32][33];
     if (seed_dev != nullptr) seed += *seed_dev;
+    const uint32_t hkey = rih_seed_key(seed);
+    const bool wide = (long long)gridDim.y * Sq * Sk > 0xffffffffLL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
     const int qr = blockIdx.x * 128 + wave * 32 + l31;          // this lane's query
@@ -111,10 +143,13 @@ __global__ __launch_bounds__(TPB) void flash_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
 
+    TileRegs<DH> tr;
+    issue_tiles<DH>(tr, kb, kv_ld, vb, kv_ld, 0, Sk, tid, vec_in != 0);
     for (int j = 0; j < nt; ++j) {
         __syncthreads();                                        // the previous tile's operands have been consumed
-        load_tiles<DH>(Ks, kb, kv_ld, Vs, vb, kv_ld, 32 * j, Sk, tid);
+        commit_tiles<DH>(tr, Ks, Vs, tid);
         __syncthreads();
+        if (j + 1 < nt) issue_tiles<DH>(tr, kb, kv_ld, vb, kv_ld, 32 * (j + 1), Sk, tid, vec_in != 0);   // in flight during tile j
         floatx16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -137,7 +172,7 @@ __global__ __launch_bounds__(TPB) void flash_fwd_kernel(const float* __restrict_
             float p = exp2f(acc[r] - m_new);                    // 0 for keys past Sk
             psum += p;
             if (drop_p > 0.f) {
-                const bool keep = fl_hash(seed, (uint64_t)(ridx * Sk + 32 * j + kr)) >= thr;
+                const bool keep = fl_hash(hkey, ridx * Sk + 32 * j + kr, wide) >= thr;
                 p = keep ? p * keep_scale : 0.f;
             }
             Ps[wave][kr][l31] = p;
@@ -180,12 +215,14 @@ __global__ __launch_bounds__(TPB) void flash_bwd_dq_kernel(const float* __restri
                                                            int heads, int Sq, int Sk, float alpha, float drop_p, uint64_t seed,
                                                            const uint64_t* __restrict__ seed_dev, const float* __restrict__ lse,
                                                            float* __restrict__ Dout, float* __restrict__ dq, int dq_ld,
-                                                           int vec_out) {
+                                                           int vec_out, int vec_in) {
     constexpr int CT = (DH + 31) / 32;
     __shared__ float Ks[32][DH + 1];
     __shared__ float Vs[32][DH + 1];
     __shared__ float Ps[TPB / 64][32][33];
     if (seed_dev != nullptr) seed += *seed_dev;
+    const uint32_t hkey = rih_seed_key(seed);
+    const bool wide = (long long)gridDim.y * Sq * Sk > 0xffffffffLL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
     const int qr = blockIdx.x * 128 + wave * 32 + l31;
@@ -219,10 +256,13 @@ __global__ __launch_bounds__(TPB) void flash_bwd_dq_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[ct][r] = 0.f;
 
+    TileRegs<DH> tr;
+    issue_tiles<DH>(tr, kb, kv_ld, vb, kv_ld, 0, Sk, tid, vec_in != 0);
     for (int j = 0; j < nt; ++j) {
         __syncthreads();
-        load_tiles<DH>(Ks, kb, kv_ld, Vs, vb, kv_ld, 32 * j, Sk, tid);
+        commit_tiles<DH>(tr, Ks, Vs, tid);
         __syncthreads();
+        if (j + 1 < nt) issue_tiles<DH>(tr, kb, kv_ld, vb, kv_ld, 32 * (j + 1), Sk, tid, vec_in != 0);
         floatx16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -237,7 +277,7 @@ __global__ __launch_bounds__(TPB) void flash_bwd_dq_kernel(const float* __restri
             const int key = 32 * j + kr;
             const float p = (key < Sk) ? exp2f(s[r] * alpha2 - L2) : 0.f;
             float d = dp[r];
-            if (drop_p > 0.f) d = (fl_hash(seed, (uint64_t)(ridx * Sk + key)) >= thr) ? d * keep_scale : 0.f;
+            if (drop_p > 0.f) d = (fl_hash(hkey, ridx * Sk + key, wide) >= thr) ? d * keep_scale : 0.f;
             Ps[wave][kr][l31] = alpha * p * (d - D);            // dS^T
         }
         __syncthreads();
@@ -262,7 +302,8 @@ __global__ __launch_bounds__(TPB) void flash_bwd_dkv_kernel(const float* __restr
                                                             int kv_ld, int heads, int Sq, int Sk, float alpha, float drop_p,
                                                             uint64_t seed, const uint64_t* __restrict__ seed_dev,
                                                             const float* __restrict__ lse, const float* __restrict__ Din,
-                                                            float* __restrict__ dk, float* __restrict__ dv, int dkv_ld) {
+                                                            float* __restrict__ dk, float* __restrict__ dv, int dkv_ld,
+                                                            int vec_in) {
     constexpr int CT = (DH + 31) / 32;
     __shared__ float Qs[32][DH + 1];
     __shared__ float Os[32][DH + 1];
@@ -270,6 +311,8 @@ __global__ __launch_bounds__(TPB) void flash_bwd_dkv_kernel(const float* __restr
     __shared__ float Ss[TPB / 64][32][33];
     __shared__ float Ls[32], Ds[32];
     if (seed_dev != nullptr) seed += *seed_dev;
+    const uint32_t hkey = rih_seed_key(seed);
+    const bool wide = (long long)gridDim.y * Sq * Sk > 0xffffffffLL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
     const int key0 = blockIdx.x * 128 + wave * 32;
@@ -295,15 +338,26 @@ __global__ __launch_bounds__(TPB) void flash_bwd_dkv_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) { gv[ct][r] = 0.f; gk[ct][r] = 0.f; }
 
-    for (int q0 = 0; q0 < Sq; q0 += 32) {
-        __syncthreads();
-        load_tiles<DH>(Qs, qb, q_ld, Os, dob, do_ld, q0, Sq, tid);
+    TileRegs<DH> tr;
+    float lreg = 0.f, dreg = 0.f;       // threads 0..31: the tile's log-sum-exp / D words, prefetched like the operand tiles
+    auto issue_rows = [&](int q0) {
         if (tid < 32) {
             const bool ok = q0 + tid < Sq;
-            Ls[tid] = ok ? lse[(long long)bh * Sq + q0 + tid] : 0.f;
-            Ds[tid] = ok ? Din[(long long)bh * Sq + q0 + tid] : 0.f;
+            lreg = ok ? lse[(long long)bh * Sq + q0 + tid] : 0.f;
+            dreg = ok ? Din[(long long)bh * Sq + q0 + tid] : 0.f;
         }
+    };
+    issue_tiles<DH>(tr, qb, q_ld, dob, do_ld, 0, Sq, tid, vec_in != 0);
+    issue_rows(0);
+    for (int q0 = 0; q0 < Sq; q0 += 32) {
         __syncthreads();
+        commit_tiles<DH>(tr, Qs, Os, tid);
+        if (tid < 32) { Ls[tid] = lreg; Ds[tid] = dreg; }
+        __syncthreads();
+        if (q0 + 32 < Sq) {
+            issue_tiles<DH>(tr, qb, q_ld, dob, do_ld, q0 + 32, Sq, tid, vec_in != 0);
+            issue_rows(q0 + 32);
+        }
         floatx16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -321,7 +375,7 @@ __global__ __launch_bounds__(TPB) void flash_bwd_dkv_kernel(const float* __restr
             float d = dp[r];
             float pd = p;
             if (drop_p > 0.f) {
-                const bool keep = fl_hash(seed, (uint64_t)(((long long)bh * Sq + qq) * Sk + key)) >= thr;
+                const bool keep = fl_hash(hkey, ((long long)bh * Sq + qq) * Sk + key, wide) >= thr;
                 pd = keep ? p * keep_scale : 0.f;
                 d = keep ? d * keep_scale : 0.f;
             }
@@ -371,8 +425,9 @@ extern "C" int rih_flash_attention_fwd(const float* q, int q_ld, const float* k,
     const dim3 grid((Sq + 127) / 128, B * heads), block(TPB);
     hipStream_t s = (hipStream_t)stream;
     const int vec = (al16(out) && ld_out % 4 == 0 && d % 4 == 0) ? 1 : 0;
+    const int vin = (al16(k) && al16(v) && kv_ld % 4 == 0) ? 1 : 0;
 #define RIH_FL(D_) hipLaunchKernelGGL((flash_fwd_kernel<D_>), grid, block, 0, s, q, q_ld, k, v, kv_ld, heads, Sq, Sk, alpha,   \
-                                      drop_p, seed, seed_dev, out, ld_out, lse, vec)
+                                      drop_p, seed, seed_dev, out, ld_out, lse, vec, vin)
     if (d == 16) RIH_FL(16);
     else if (d == 32) RIH_FL(32);
     else if (d == 64) RIH_FL(64);
@@ -392,12 +447,14 @@ extern "C" int rih_flash_attention_bwd(const float* dO, int do_ld, const float* 
     const dim3 gq((Sq + 127) / 128, B * heads), gk((Sk + 127) / 128, B * heads), block(TPB);
     hipStream_t s = (hipStream_t)stream;
     const int vec = (al16(dq) && dq_ld % 4 == 0 && d % 4 == 0) ? 1 : 0;
+    const int vkv = (al16(k) && al16(v) && kv_ld % 4 == 0) ? 1 : 0;
+    const int vqo = (al16(q) && al16(dO) && q_ld % 4 == 0 && do_ld % 4 == 0) ? 1 : 0;
 #define RIH_FL(D_)                                                                                                             \
     {                                                                                                                          \
         hipLaunchKernelGGL((flash_bwd_dq_kernel<D_>), gq, block, 0, s, dO, do_ld, O, o_ld, q, q_ld, k, v, kv_ld, heads, Sq, Sk,  \
-                           alpha, drop_p, seed, seed_dev, lse, Dws, dq, dq_ld, vec);                                           \
+                           alpha, drop_p, seed, seed_dev, lse, Dws, dq, dq_ld, vec, vkv);                                      \
         hipLaunchKernelGGL((flash_bwd_dkv_kernel<D_>), gk, block, 0, s, dO, do_ld, q, q_ld, k, v, kv_ld, heads, Sq, Sk, alpha,   \
-                           drop_p, seed, seed_dev, lse, Dws, dk, dv, dkv_ld);                                                  \
+                           drop_p, seed, seed_dev, lse, Dws, dk, dv, dkv_ld, vqo);                                             \
     }
     if (d == 16) RIH_FL(16)
     else if (d == 32) RIH_FL(32)

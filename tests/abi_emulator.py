@@ -26,14 +26,20 @@ def _i8(ptr, n):
 
 
 def hash_np(seed, idx):
-    M = np.uint64(0xFFFFFFFFFFFFFFFF)
-    with np.errstate(over='ignore'):
-        x = (idx.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)) & M
-        for _ in range(2):
-            x ^= x >> np.uint64(32)
-            x = (x * np.uint64(0xD6E8FEB86659FD93)) & M
-        x ^= x >> np.uint64(32)
-    return x & np.uint64(0xFFFFFFFF)
+    """numpy mirror of rih_hash (csrc/rih_hash.h): mix32(lo32(idx) ^ hi32(idx) * 0x85EBCA6B ^ key(seed))."""
+    def mix(x):
+        x = x.astype(np.uint64) & np.uint64(0xFFFFFFFF)
+        x ^= x >> np.uint64(16)
+        x = (x * np.uint64(0x7feb352d)) & np.uint64(0xFFFFFFFF)
+        x ^= x >> np.uint64(15)
+        x = (x * np.uint64(0x846ca68b)) & np.uint64(0xFFFFFFFF)
+        x ^= x >> np.uint64(16)
+        return x
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    key = mix(np.array([seed & 0xFFFFFFFF], np.uint64)) ^ mix(np.array([(seed >> 32) ^ 0x9E3779B9], np.uint64))
+    idx = np.asarray(idx).astype(np.uint64)
+    lo, hi = idx & np.uint64(0xFFFFFFFF), idx >> np.uint64(32)
+    return mix(lo ^ key[0] ^ ((hi * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)))
 
 
 def keep_mask(seed, n, p):

@@ -430,7 +430,14 @@ def test_train_step_staged_graph_replay_matches_plain_backward(group, monkeypatc
                 if group == 0:
                     assert torch.equal(got[k], want[k]), 'replay %d: gradient of %s differs from the plain backward' % (rep, k)
                 else:
-                    testing.assert_close(got[k], want[k], 1e-4, 1e-4, 'replay %d: gradient of %s' % (rep, k))
+                    # (a bias gradient is a column sum of the dy that also forms the weight gradient; where it is mathematically
+                    # zero -- the key bias of a softmax attention -- it is pure round-off of that sum, so its error is measured
+                    # against the weight gradient's magnitude as well)
+                    wk = k[:-len('bias')] + 'weight'
+                    floor = 1e-5 * float(want[wk].abs().max()) if (k.endswith('.bias') and wk in want) else 0.0
+                    err = float((got[k] - want[k]).abs().max())
+                    assert err <= 1e-4 * float(want[k].abs().max()) + floor, \
+                        'replay %d: gradient of %s: max err %.3g (max |want| %.3g)' % (rep, k, err, float(want[k].abs().max()))
             if first is None:
                 first = {k: v.clone() for k, v in got.items()}
             else:

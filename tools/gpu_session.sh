@@ -18,8 +18,9 @@ for step in "$@"; do
     smoke) run smoke python __graft_entry__.py smoke ;;
     bench) run "bench$(echo "$arg" | tr -c 'A-Za-z0-9' _)" python bench.py --dump-gemm "$OUT/gemm_profile.json" $arg ;;
     ab) n=0; for v in base $(echo "$arg" | tr ',' ' '); do
-          if [ "$v" = base ]; then run "ab_base" python bench.py --steps 20 --warmup 5 $QUICK --no-roofline
-          else n=$((n+1)); run "ab_$(echo "$v" | tr -c 'A-Za-z0-9' _)" env $(echo "$v" | tr '+' ' ') python bench.py --steps 20 --warmup 5 $QUICK --no-roofline; fi
+          n=$((n+1))
+          if [ "$v" = base ]; then run "ab${n}_base" python bench.py --steps 20 --warmup 5 $QUICK --no-roofline
+          else run "ab${n}_$(echo "$v" | tr -c 'A-Za-z0-9' _)" env $(echo "$v" | tr '+' ' ') python bench.py --steps 20 --warmup 5 $QUICK --no-roofline; fi
         done ;;
     abroof) for v in base $(echo "$arg" | tr ',' ' '); do
           if [ "$v" = base ]; then run "abroof_base" python bench.py --steps 20 --warmup 5 $QUICK --dump-gemm "$OUT/gemm_base.json"
