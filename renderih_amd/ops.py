@@ -254,10 +254,29 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
 # (the decoder's 116 nn.Linear gradients per ResNet50 step were 116 launches of ~20 us with a few hundred short workgroups
 # each).  The launch table (prepared kernel arguments + block -> problem map) is packed on the host, staged in pinned memory
 # and copied to the device in stream order; under hipGraph capture the copy is a node of the graph, so the staging buffer must
-# outlive the graph: `TABLE_KEEP` (a list installed by the capturing code, renderih_amd.train.TrainStep) receives it.
+# outlive the graph AND must not be allocated while a stream captures (the pinned allocator's event bookkeeping is illegal
+# there): the capturing code (renderih_amd.train.TrainStep) installs a `TableArena` -- pinned memory allocated before the
+# capture, sized from the table bytes its warm-up steps used (`TABLE_BYTES_STEP`) -- and the tables are carved out of it.
 GROUP_WGRAD = int(os.environ.get('RIH_WGRAD_GROUP', '1'))        # 0: off, 1: decoder-sized gradients, 2: every weight gradient
 GROUP_KCHUNK = int(os.environ.get('RIH_WGRAD_GROUP_KCHUNK', '1024'))      # pixels per split-K slice in a grouped launch
-TABLE_KEEP = None
+TABLE_ARENA = None
+TABLE_BYTES_STEP = 0            # table bytes packed since the counter was last reset (TrainStep sizes its arena from it)
+
+
+class TableArena:
+    """Bump allocator over one pinned host buffer (256-byte granules); lives as long as the graphs that re-read it."""
+
+    def __init__(self, nbytes):
+        self.buf = torch.empty((max(int(nbytes), 4096),), dtype=torch.uint8, pin_memory=True)
+        self.used = 0
+
+    def take(self, nbytes):
+        a = (self.used + 255) // 256 * 256
+        if a + nbytes > self.buf.numel():
+            raise RuntimeError('renderih_amd: launch-table arena exhausted (%d + %d > %d bytes): the captured step packs '
+                               'more grouped launches than the warm-up steps did' % (a, nbytes, self.buf.numel()))
+        self.used = a + nbytes
+        return self.buf[a:a + nbytes]
 
 
 class GroupedGemms:
@@ -274,6 +293,7 @@ class GroupedGemms:
         return True
 
     def flush(self):
+        global TABLE_BYTES_STEP
         items, self.items = self.items, []
         by = {}
         for v, d, keep, fl in items:
@@ -287,7 +307,11 @@ class GroupedGemms:
                 raise RuntimeError('renderih_amd: rih_gemm_multi_table_bytes rejected the group')
             ref = next(t for t in group[0][1] if torch.is_tensor(t))
             on_gpu = ref.is_cuda
-            host = torch.empty((nbytes,), dtype=torch.uint8, pin_memory=on_gpu)
+            TABLE_BYTES_STEP += nbytes + 256
+            if on_gpu and TABLE_ARENA is not None:
+                host = TABLE_ARENA.take(nbytes)
+            else:
+                host = torch.empty((nbytes,), dtype=torch.uint8, pin_memory=on_gpu)
             total = C.c_int32(0)
             got = int(lib.rih_gemm_multi_pack(arr, n, host.data_ptr(), C.byref(total)))
             if got != v:
@@ -295,8 +319,6 @@ class GroupedGemms:
             if on_gpu:
                 dev = torch.empty((nbytes,), dtype=torch.uint8, device=ref.device)
                 dev.copy_(host, non_blocking=True)
-                if TABLE_KEEP is not None:
-                    TABLE_KEEP.append(host)
             else:
                 dev = host
             if PROFILE is not None:

@@ -298,6 +298,7 @@ class TrainStep:
         saved_opt = copy.deepcopy(self.opt.state_dict())
         with torch.cuda.stream(cap):
             for _ in range(2):                      # warm-up on the capture stream
+                ops.TABLE_BYTES_STEP = 0
                 self._step_eager()
             with torch.no_grad():
                 for p, s_ in zip(self.model.parameters(), saved_p):
@@ -317,9 +318,10 @@ class TrainStep:
             p.grad = None
         self.graphs, self.static = [], []
         pool = None
-        # pinned staging buffers of captured host-to-device copies (launch tables of the grouped weight-gradient GEMMs): the
-        # graphs re-read them at every replay, so they live as long as this object
-        ops.TABLE_KEEP = self._table_keep = []
+        # pinned staging memory of captured host-to-device copies (launch tables of the grouped weight-gradient GEMMs): the
+        # graphs re-read it at every replay, so it lives as long as this object; allocated HERE, before the capture (pinned
+        # allocations are illegal while a stream captures), twice the size one warm-up step packed
+        ops.TABLE_ARENA = self._table_arena = ops.TableArena(2 * ops.TABLE_BYTES_STEP + (1 << 16))
         with torch.cuda.stream(cap):
             carry, loss = None, None
             for i in range(self.nstage):
@@ -335,7 +337,7 @@ class TrainStep:
                 self.graphs.append(gph)
                 self.static.append(grads)
             self._static_loss = loss.detach()
-        ops.TABLE_KEEP = None
+        ops.TABLE_ARENA = None
         if self.packs is not None:
             self.packs.stale()
             ops._PACK = None
