@@ -455,12 +455,12 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
 
 /* library / device info.  RIH_ABI_VERSION is bumped whenever a struct layout or a signature of this header changes;
  * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of EVERY by-pointer struct, in
- * this order: gemm desc, mano model, mesh topo, hconv desc, gemm p3 desc, reduce desc, pack desc, ln final desc, adam entry
- * (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it mis-laid-out structs. */
-#define RIH_ABI_VERSION 8
-#define RIH_ABI_NSIZES 9
+ * this order: gemm desc, mano model, mesh topo, hconv desc, gemm p3 desc, reduce desc, pack desc, ln final desc, adam entry,
+ * chain desc (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it mis-laid-out structs. */
+#define RIH_ABI_VERSION 9
+#define RIH_ABI_NSIZES 10
 int rih_version(void);
-int rih_abi_sizes(int32_t* out9);
+int rih_abi_sizes(int32_t* out10);
 const char* rih_arch(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -482,6 +482,68 @@ int rih_flash_attention_bwd(const float* dO, int do_ld, const float* O, int o_ld
                             const float* v, int kv_ld, int B, int heads, int Sq, int Sk, int d, float alpha, float drop_p,
                             uint64_t seed, const uint64_t* seed_dev, const float* lse, float* Dws, float* dq, int dq_ld,
                             float* dk, float* dv, int dkv_ld, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * rih_chain: a chain of row-wise layers in ONE launch (csrc/rih_chain.hip) -- the Linear -> (dropout, add) -> LayerNorm ->
+ * ReLU -> Linear sequences of the mesh decoder (models/model_attn/self_attn.py:17-33 `MLP_res_block`, :66-85 the attention
+ * output projection + skip + `ff`; inter_attn.py:85-125; gcn.py:99-110 `GCN_ResBlock`) and their backward sequences.
+ * Every operator of such a chain maps token rows to token rows independently, so a workgroup keeps a block of `rblk` rows in
+ * LDS from the first load to the last store and runs the operators of `op[]` on it in order; the matrix products use the
+ * exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) with the weight operand streamed from L2.  What a standalone-launch sequence pays
+ * per operator -- a dependent launch (>= 4.5 us), a round trip of the activations through L2, a 64x64 GEMM tile with a
+ * 4-k-tile main loop -- is paid once per chain.
+ *
+ * Activations are [nhands][rows][*] row-major (hands stacked, renderih_amd/attn.py); the workgroup of (row block, hand h)
+ * addresses row r of a tensor with pitch `ld` at p + ((long long)h * rows + r) * ld, and parameters at p_i + h * s_i (s_i = the
+ * distance in floats from the left to the right hand's parameter; 0 = shared).  The block state is `cur` [rblk][width] (the
+ * running activation) and one optional second buffer `kept`.  Operators (kind, and what the other fields mean):
+ *   RIH_CH_LOAD      cur = p0 rows (n columns, pitch ld); width = n
+ *   RIH_CH_STORE     p0 rows (pitch ld) = cur
+ *   RIH_CH_ADD       cur += p0 rows (pitch ld)
+ *   RIH_CH_KEEP      kept = cur
+ *   RIH_CH_ADD_KEPT  cur += kept
+ *   RIH_CH_GEMM      cur[:, :n] = cur[:, :k] x B (+ p1[n] bias) (ReLU if flags & RIH_CHF_RELU); B(kk, j) = p0[j*k + kk] (an
+ *                    nn.Linear weight [n][k] as stored) or, with RIH_CHF_BT, p0[kk*n + j] ([k][n]: the same weight in the data
+ *                    gradient).  With RIH_CHF_OUT_GLOBAL the result goes to p2 rows (pitch ld) instead of `cur` (n is then not
+ *                    limited by the LDS block; cur keeps its value).  k % 8 == 0, n % 4 == 0.
+ *   RIH_CH_DROPOUT   cur = keep ? cur / (1 - f0) : 0, element (h, r, c) of the [nhands][rows][width] tensor kept iff
+ *                    hash(seed (+ *seed_dev), ((h*rows + r)*width + c)) >= f0 * 2^32 -- the mask of rih_add_dropout /
+ *                    rih_dropout_bwd on the same tensor, bit for bit
+ *   RIH_CH_MASKNZ    cur = (p0 rows (pitch ld) != 0) ? cur * f0 : 0   (backward of ReLU [+ dropout] through the saved output)
+ *   RIH_CH_LN        cur = LayerNorm(cur; gamma p0, beta p1, eps f0) (ReLU if RIH_CHF_RELU); mean / rstd of row (h, r) to
+ *                    p2[h*rows + r] / p3[...] when p2 != NULL
+ *   RIH_CH_LN_BWD    cur (= dy) -> dx of that LayerNorm: p0 = its input rows (pitch ld), p1 / p2 = mean / rstd, p3 = gamma;
+ *                    the block's partial parameter gradients go to p4 + h*s4 laid out [nblk][2][width] (nblk = ceil(rows/rblk);
+ *                    [.][0] = d gamma, [.][1] = d beta) for rih_ln_param_final_multi
+ * Limits: 1 <= nops <= RIH_CHAIN_MAXOPS; rblk in {32, 64}; ldw >= every width + 4, ldw % 4 == 0, rblk * ldw <= 12416 without
+ * a KEEP, <= 8448 with one; all widths % 4 == 0; row pitches % 4 == 0 and pointers 16-byte aligned. */
+#define RIH_CHAIN_MAXOPS 16
+enum {
+    RIH_CH_LOAD = 1, RIH_CH_STORE = 2, RIH_CH_ADD = 3, RIH_CH_KEEP = 4, RIH_CH_ADD_KEPT = 5, RIH_CH_GEMM = 6,
+    RIH_CH_DROPOUT = 7, RIH_CH_MASKNZ = 8, RIH_CH_LN = 9, RIH_CH_LN_BWD = 10
+};
+#define RIH_CHF_RELU 1
+#define RIH_CHF_BT 2
+#define RIH_CHF_OUT_GLOBAL 4
+typedef struct rih_chain_op {
+    int32_t kind, flags, n, k;
+    int32_t ld, reserved;
+    float f0, f1;
+    uint64_t seed;
+    const void* p0;
+    const void* p1;
+    void* p2;
+    void* p3;
+    void* p4;
+    int64_t s0, s1, s2, s3, s4;
+} rih_chain_op;
+typedef struct rih_chain_desc {
+    int32_t nops, rows, nhands, rblk;
+    int32_t ldw, reserved;
+    const uint64_t* seed_dev;
+    rih_chain_op op[RIH_CHAIN_MAXOPS];
+} rih_chain_desc;
+int rih_chain(const rih_chain_desc* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused attention forward, first generation (keeps P / Pd in memory; superseded by rih_flash_attention_*, kept as an opt-in

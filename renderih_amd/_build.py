@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'librenderih_amd.so')
 SOURCES = ['rih_gemm.hip', 'rih_gemm3.hip', 'rih_elem.hip', 'rih_mano.hip', 'rih_loss.hip', 'rih_metrics.hip',
-           'rih_pose.hip', 'rih_attn.hip', 'rih_flash.hip', 'rih_half.hip', 'rih_input.hip', 'rih_sdf.hip']
+           'rih_pose.hip', 'rih_attn.hip', 'rih_flash.hip', 'rih_chain.hip', 'rih_half.hip', 'rih_input.hip', 'rih_sdf.hip']
 HEADERS = ['rih_procrustes.h', 'rih_pose_math.h', 'rih_hash.h']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result',
          # hipcc's SLP pass packs neighbouring f32 adds into v_pk_add_f32, which issues at a fraction of the scalar

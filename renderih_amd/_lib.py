@@ -48,6 +48,21 @@ class LnFinalDesc(C.Structure):
     _fields_ = [('ws', C.c_void_p), ('dg', C.c_void_p), ('db', C.c_void_p), ('D', C.c_int32), ('nblk', C.c_int32)]
 
 
+class ChainOp(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('flags', C.c_int32), ('n', C.c_int32), ('k', C.c_int32),
+                ('ld', C.c_int32), ('reserved', C.c_int32), ('f0', C.c_float), ('f1', C.c_float), ('seed', C.c_uint64),
+                ('p0', C.c_void_p), ('p1', C.c_void_p), ('p2', C.c_void_p), ('p3', C.c_void_p), ('p4', C.c_void_p),
+                ('s0', C.c_int64), ('s1', C.c_int64), ('s2', C.c_int64), ('s3', C.c_int64), ('s4', C.c_int64)]
+
+
+CHAIN_MAXOPS = 16
+
+
+class ChainDesc(C.Structure):
+    _fields_ = [('nops', C.c_int32), ('rows', C.c_int32), ('nhands', C.c_int32), ('rblk', C.c_int32),
+                ('ldw', C.c_int32), ('reserved', C.c_int32), ('seed_dev', C.c_void_p), ('op', ChainOp * CHAIN_MAXOPS)]
+
+
 class PackDesc(C.Structure):
     _fields_ = [('w', C.c_void_p), ('dst', C.c_void_p)] + \
                [(n, C.c_int32) for n in ('Cout', 'Cin', 'KH', 'KW', 'CinPad', 'mode', 'kh0', 'kw0', 'step', 'Th', 'Tw',
@@ -183,12 +198,13 @@ SIGNATURES = {
                                       c_i, c_f, C.c_void_p]),
     'rih_flash_attention_bwd': (c_i, [c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl,
                                       c_u64, C.c_void_p, c_f, c_f, c_f, c_i, c_f, c_f, c_i, C.c_void_p]),
+    'rih_chain': (c_i, [C.POINTER(ChainDesc), C.c_void_p]),
     'rih_version': (c_i, []),
     'rih_abi_sizes': (c_i, [C.POINTER(C.c_int32)]),
     'rih_arch': (C.c_char_p, []),
 }
 
-ABI_VERSION = 8      # = RIH_ABI_VERSION of include/renderih_amd.h
+ABI_VERSION = 9      # = RIH_ABI_VERSION of include/renderih_amd.h
 
 _lib = None
 
@@ -224,7 +240,7 @@ def load():
     # every by-pointer struct of the header, in rih_abi_sizes' order; the last one (rih_adam_entry: four pointers + int64) is
     # built by hand as int64 rows in renderih_amd/optim.py
     mine = [C.sizeof(GemmDesc), C.sizeof(ManoModel), C.sizeof(MeshTopo), C.sizeof(HConvDesc), C.sizeof(GemmP3Desc),
-            C.sizeof(ReduceDesc), C.sizeof(PackDesc), C.sizeof(LnFinalDesc), 5 * 8]
+            C.sizeof(ReduceDesc), C.sizeof(PackDesc), C.sizeof(LnFinalDesc), 5 * 8, C.sizeof(ChainDesc)]
     if lib.rih_version() != ABI_VERSION:
         raise RuntimeError('librenderih_amd.so does not match this binding (ABI %d vs %d): rebuild with '
                            '`python -m renderih_amd._build`' % (lib.rih_version(), ABI_VERSION))

@@ -60,6 +60,11 @@ def _lin_drop_res(dc, m, x, res):
     return _lin(m, x, residual=res)
 
 
+def _seeds3(dc):
+    """The three mask streams of (output projection, MLP hidden, MLP output) in the order the standalone sequence draws them."""
+    return (dc.seed(), dc.seed(), dc.seed()) if dc.p > 0 else (0, 0, 0)
+
+
 def _lin_pair(mL, mR, X, residual=None, relu=False):
     return ops.linear_pair(X, mL, mR, residual=residual, relu=relu)
 
@@ -252,12 +257,18 @@ class SelfAttn(nn.Module):
     @staticmethod
     def forward_pair(L, R, X, dc):
         _, B, S, D = X.shape
-        y, X = ops.layernorm_pair_skip(X, L.layer_norm, R.layer_norm)
         # both hands' fused QKV operands stacked once into [2, 3D, D]
         w = torch.cat([L.w_qs.weight, L.w_ks.weight, L.w_vs.weight, R.w_qs.weight, R.w_ks.weight, R.w_vs.weight], 0)
         b = torch.cat([L.w_qs.bias, L.w_ks.bias, L.w_vs.bias, R.w_qs.bias, R.w_ks.bias, R.w_vs.bias], 0)
-        qkv = ops.LinearPairFn.apply(y, w.view(2, 3 * D, D), None, b.view(2, 3 * D), None, None, False)
+        chain = ops.chain_ok(D, L.ff.fc1.out_features)
+        if chain:       # LayerNorm -> QKV projection as one launch (csrc/rih_chain.hip)
+            qkv, X = ops.ln_linear_chain(X, L.layer_norm, R.layer_norm, w.view(2, 3 * D, D), b.view(2, 3 * D))
+        else:
+            y, X = ops.layernorm_pair_skip(X, L.layer_norm, R.layer_norm)
+            qkv = ops.LinearPairFn.apply(y, w.view(2, 3 * D, D), None, b.view(2, 3 * D), None, None, False)
         o = ops.self_attention_packed(qkv.view(2 * B, S, 3 * D), L.n_heads, dc.p, dc.seed() if dc.p > 0 else 0)
+        if chain:       # output projection, both skips and the MLP block as one launch
+            return ops.attn_tail_chain(o.view(2, B, S, D), X, L.fc, R.fc, L.ff, R.ff, dc.p, _seeds3(dc))
         X = _lin_drop_res_pair(dc, L.fc, R.fc, o.view(2, B, S, D), X)
         return MLP_res_block.forward_pair(L.ff, R.ff, X, dc)
 
@@ -378,12 +389,18 @@ class inter_attn(nn.Module):
 
     def forward_pair(self, X, dc):
         X = SelfAttn.forward_pair(self.L_self_attn_layer, self.R_self_attn_layer, X, dc)
-        X2 = ops.layernorm_pair(X, self.layer_norm1, self.layer_norm2)
         w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight], 0)
         b = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias], 0)
         sd = (lambda: dc.seed()) if dc.p > 0 else (lambda: 0)
+        chain = ops.chain_ok(X.shape[-1], self.ffL.fc1.out_features)
         # shared projections (N5): ONE fused QKV GEMM over both hands' rows, then the two cross-hand directions
-        feat = ops.cross_attention_stacked(ops.linear(X2, w, b), self.n_heads, dc.p, sd(), sd())
+        if chain:
+            qkv, X = ops.ln_linear_chain(X, self.layer_norm1, self.layer_norm2, w, b)
+        else:
+            qkv = ops.linear(ops.layernorm_pair(X, self.layer_norm1, self.layer_norm2), w, b)
+        feat = ops.cross_attention_stacked(qkv, self.n_heads, dc.p, sd(), sd())
+        if chain:
+            return ops.attn_tail_chain(feat, X, self.fc, None, self.ffL, self.ffR, dc.p, _seeds3(dc))
         return MLP_res_block.forward_pair(self.ffL, self.ffR, _lin_drop_res(dc, self.fc, feat, X), dc)
 
 

@@ -1,0 +1,427 @@
+// rih_chain.hip -- a chain of row-wise decoder layers in ONE launch (include/renderih_amd.h: rih_chain).
+//
+// The mesh decoder (models/model_attn/self_attn.py:17-33, :66-85; inter_attn.py:85-125; gcn.py:99-110) is a sequence of
+// small operators on token rows -- Linear (K, N <= 256), dropout, residual add, LayerNorm, ReLU -- that the standalone
+// kernels run as one dependent launch each: >= 4.5 us of launch floor per operator, the activations through L2 between any
+// two of them, and GEMMs whose main loop is 2..8 k-tiles long (20-60 TF on a 64x64 tile).  Every one of these operators maps
+// a token row to a token row independently, so here a workgroup owns a block of 32 or 64 rows, keeps it in LDS from the first
+// load to the last store and interprets the operator list of the descriptor on it.  The backward sequences are chains of the
+// same operators (data-gradient GEMMs on the transposed weight view, mask re-draws, LayerNorm backward), so one kernel serves
+// both directions; the weight gradients stay batched GEMMs over the tensors a chain stores on its way.
+//
+//   * state: `cur` [rblk][ldw] fp32 (the running activation) and an optional second buffer `kept` (skip connections);
+//     ldw = widest activation + 4 floats, so that the 16-byte operand reads of 32 consecutive rows spread over the banks.
+//   * matrix products: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), one 32x32 output block per wavefront and pass; the A operand
+//     is read from `cur` (one ds_read_b128 per four MFMAs), the B operand -- the weight -- goes from L2 straight into
+//     registers, a whole 128-deep slice of the reduction (16 x 16 bytes per lane) requested before the first MFMA, so that a
+//     product pays ONE memory round trip, not one per k-tile.  The k index is permuted inside a group of 8 (lane half h, step
+//     t <-> k = 8j + 4h + t) identically for both operands, which lets each operand fetch be one contiguous 16-byte access.
+//   * everything else (dropout masks from the counter hash of rih_hash.h, LayerNorm forward / backward with 4 or 8 lanes per
+//     row, residual adds) works on the block in LDS with 16-byte accesses.
+// Determinism: no atomics; the LayerNorm parameter gradients leave the kernel as per-block partial sums in a fixed order
+// (finished by rih_ln_param_final_multi like those of rih_layernorm_bwd).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/renderih_amd.h"
+#include "rih_hash.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+constexpr int TPB = 256;
+constexpr int MAXB = 3;           // 32x32 output blocks per wavefront and pass (12 per workgroup)
+constexpr int CAP_SOLO = 12416;   // floats of `cur` without a `kept` buffer (32 rows x (384 + 4))
+constexpr int CAP_PAIR = 8448;    // floats of `cur` and of `kept` (64 rows x (128 + 4), 32 rows x (256 + 4) fits too)
+constexpr int CAP_SMALL = 4224;   // 32 rows x (128 + 4): four workgroups per CU
+
+__device__ __forceinline__ int acc_row(int r, int lhi) { return (r & 3) + 8 * (r >> 2) + 4 * lhi; }
+__device__ __forceinline__ uint32_t ch_thresh(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t < 0.0) t = 0.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+
+struct Blk {
+    int h, row0, nrows, R, ldw;
+    long long rowbase;          // h * rows + row0: index of the block's first row in a hands-stacked tensor
+};
+
+// ---- cur[:, :n] = cur[:, :k] x B (+ bias) (ReLU), or the same product written to global rows ------------------------------
+__device__ __forceinline__ void ch_gemm(const rih_chain_op& op, float* __restrict__ cur, const Blk& b, int tid) {
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int K = op.k, N = op.n, ldw = b.ldw;
+    const float* __restrict__ W = reinterpret_cast<const float*>(op.p0) + b.h * op.s0;
+    const float* __restrict__ bias = op.p1 ? reinterpret_cast<const float*>(op.p1) + b.h * op.s1 : nullptr;
+    const bool bt = (op.flags & RIH_CHF_BT) != 0, outg = (op.flags & RIH_CHF_OUT_GLOBAL) != 0;
+    const bool relu = (op.flags & RIH_CHF_RELU) != 0;
+    const int nrb = b.R >> 5, ncb = (N + 31) >> 5, nblk = nrb * ncb;
+    float* __restrict__ dst = outg ? reinterpret_cast<float*>(op.p2) + b.rowbase * op.ld : nullptr;
+    for (int base = 0; base < nblk; base += 4 * MAXB) {
+        floatx16 acc[MAXB];
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            const int blk = base + wave + 4 * i;                // wave-uniform
+            if (blk >= nblk) continue;
+            const int rb = blk % nrb, cb = blk / nrb;
+            const int col = cb * 32 + l31;
+            const bool cok = col < N;
+            const float* arow = cur + (rb * 32 + l31) * ldw + 4 * lhi;
+            for (int k0 = 0; k0 < K; k0 += 128) {
+                const int nj = min(16, (K - k0) >> 3);
+                float4 bq[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    bq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (j < nj && cok) {
+                        const int kk = k0 + 8 * j + 4 * lhi;
+                        if (!bt) {
+                            bq[j] = *reinterpret_cast<const float4*>(W + (long long)col * K + kk);
+                        } else {
+                            const float* wp = W + (long long)kk * N + col;
+                            bq[j] = make_float4(wp[0], wp[N], wp[2 * (long long)N], wp[3 * (long long)N]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (j < nj) {
+                        const float4 a = *reinterpret_cast<const float4*>(arow + k0 + 8 * j);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[j].x, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[j].y, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[j].z, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[j].w, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (!outg) __syncthreads();         // every wavefront has read its A rows: `cur` may be overwritten (single pass)
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i) {
+            const int blk = base + wave + 4 * i;
+            if (blk >= nblk) continue;
+            const int rb = blk % nrb, cb = blk / nrb;
+            const int col = cb * 32 + l31;
+            if (col >= N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb * 32 + acc_row(r, lhi);
+                float v = acc[i][r] + bv;
+                if (relu) v = fmaxf(v, 0.f);
+                if (outg) {
+                    if (row < b.nrows) dst[(long long)row * op.ld + col] = v;
+                } else {
+                    cur[row * ldw + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- LayerNorm forward on the block: T = 256 / R lanes per row -----------------------------------------------------------------
+__device__ __forceinline__ float group_sum(float v, int T) {
+    for (int m = 1; m < T; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__device__ __forceinline__ void ch_ln(const rih_chain_op& op, float* __restrict__ cur, const Blk& b, int tid, int width) {
+    const int T = TPB / b.R, r = tid / T, sub = tid % T, w4 = width >> 2;
+    const float* __restrict__ g = reinterpret_cast<const float*>(op.p0) + b.h * op.s0;
+    const float* __restrict__ be = reinterpret_cast<const float*>(op.p1) + b.h * op.s1;
+    float4* row = reinterpret_cast<float4*>(cur + r * b.ldw);
+    float s = 0.f;
+    for (int c4 = sub; c4 < w4; c4 += T) {
+        const float4 v = row[c4];
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float m = group_sum(s, T) / (float)width;
+    float q = 0.f;
+    for (int c4 = sub; c4 < w4; c4 += T) {
+        const float4 v = row[c4];
+        const float a0 = v.x - m, a1 = v.y - m, a2 = v.z - m, a3 = v.w - m;
+        q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+    const float rs = 1.f / sqrtf(group_sum(q, T) / (float)width + op.f0);
+    const bool relu = (op.flags & RIH_CHF_RELU) != 0;
+    for (int c4 = sub; c4 < w4; c4 += T) {
+        const float4 v = row[c4];
+        const float4 gg = *reinterpret_cast<const float4*>(g + 4 * c4), bb = *reinterpret_cast<const float4*>(be + 4 * c4);
+        float4 o;
+        o.x = (v.x - m) * rs * gg.x + bb.x;
+        o.y = (v.y - m) * rs * gg.y + bb.y;
+        o.z = (v.z - m) * rs * gg.z + bb.z;
+        o.w = (v.w - m) * rs * gg.w + bb.w;
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        row[c4] = o;
+    }
+    if (op.p2 != nullptr && sub == 0 && r < b.nrows) {
+        reinterpret_cast<float*>(op.p2)[b.rowbase + r] = m;
+        reinterpret_cast<float*>(op.p3)[b.rowbase + r] = rs;
+    }
+}
+
+// ---- LayerNorm backward on the block: cur = dy -> dx; the block's d gamma / d beta partial sums to the workspace -------------
+__device__ __forceinline__ void ch_ln_bwd(const rih_chain_op& op, float* __restrict__ cur, float* __restrict__ stat,
+                                          const Blk& b, int tid, int width, int nblk) {
+    const float* __restrict__ x = reinterpret_cast<const float*>(op.p0) + b.rowbase * op.ld;
+    const float* __restrict__ g = reinterpret_cast<const float*>(op.p3) + b.h * op.s3;
+    float* smean = stat;
+    float* srstd = stat + 64;
+    if (tid < b.R) {
+        const bool ok = tid < b.nrows;
+        smean[tid] = ok ? reinterpret_cast<const float*>(op.p1)[b.rowbase + tid] : 0.f;
+        srstd[tid] = ok ? reinterpret_cast<const float*>(op.p2)[b.rowbase + tid] : 0.f;
+    }
+    __syncthreads();
+    // (1) parameter-gradient partial sums: a lane per column, the block's rows in order
+    float* ws = reinterpret_cast<float*>(op.p4) + b.h * op.s4 + (long long)blockIdx.x * 2 * width;
+    (void)nblk;
+    for (int c = tid; c < width; c += TPB) {
+        float sg = 0.f, sb = 0.f;
+        for (int r = 0; r < b.nrows; ++r) {
+            const float dy = cur[r * b.ldw + c];
+            const float xh = (x[(long long)r * op.ld + c] - smean[r]) * srstd[r];
+            sg += dy * xh;
+            sb += dy;
+        }
+        ws[c] = sg;
+        ws[width + c] = sb;
+    }
+    __syncthreads();
+    // (2) dx = rstd * (g dy - mean(g dy) - xhat mean(g dy xhat)), T lanes per row
+    const int T = TPB / b.R, r = tid / T, sub = tid % T, w4 = width >> 2;
+    float4* row = reinterpret_cast<float4*>(cur + r * b.ldw);
+    const float m = smean[r], rs = srstd[r];
+    const bool ok = r < b.nrows;
+    const float4* xr = reinterpret_cast<const float4*>(x + (long long)(ok ? r : 0) * op.ld);
+    float s1 = 0.f, s2 = 0.f;
+    for (int c4 = sub; c4 < w4; c4 += T) {
+        const float4 dy = row[c4], gg = *reinterpret_cast<const float4*>(g + 4 * c4);
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) xv = xr[c4];
+        const float h0 = (xv.x - m) * rs, h1 = (xv.y - m) * rs, h2 = (xv.z - m) * rs, h3 = (xv.w - m) * rs;
+        const float t0 = dy.x * gg.x, t1 = dy.y * gg.y, t2 = dy.z * gg.z, t3 = dy.w * gg.w;
+        s1 += (t0 + t1) + (t2 + t3);
+        s2 += (t0 * h0 + t1 * h1) + (t2 * h2 + t3 * h3);
+    }
+    s1 = group_sum(s1, T) / (float)width;
+    s2 = group_sum(s2, T) / (float)width;
+    for (int c4 = sub; c4 < w4; c4 += T) {
+        const float4 dy = row[c4], gg = *reinterpret_cast<const float4*>(g + 4 * c4);
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) xv = xr[c4];
+        float4 o;
+        o.x = rs * (dy.x * gg.x - s1 - (xv.x - m) * rs * s2);
+        o.y = rs * (dy.y * gg.y - s1 - (xv.y - m) * rs * s2);
+        o.z = rs * (dy.z * gg.z - s1 - (xv.z - m) * rs * s2);
+        o.w = rs * (dy.w * gg.w - s1 - (xv.w - m) * rs * s2);
+        row[c4] = o;
+    }
+}
+
+template <int CUR_F, int KEPT_F>
+__global__ __launch_bounds__(TPB) void chain_kernel(const rih_chain_desc d) {
+    __shared__ float4 cur4[CUR_F / 4];
+    __shared__ float4 kept4[(KEPT_F > 0 ? KEPT_F : 4) / 4];
+    __shared__ float stat[128];
+    float* cur = reinterpret_cast<float*>(cur4);
+    float* kept = reinterpret_cast<float*>(kept4);
+    const int tid = threadIdx.x;
+    Blk b;
+    b.h = blockIdx.y;
+    b.R = d.rblk;
+    b.ldw = d.ldw;
+    b.row0 = blockIdx.x * d.rblk;
+    b.nrows = min(d.rblk, d.rows - b.row0);
+    b.rowbase = (long long)b.h * d.rows + b.row0;
+    const int nblk = gridDim.x;
+    uint64_t seed_add = 0;
+    if (d.seed_dev != nullptr) seed_add = *d.seed_dev;
+    int width = 0;
+    for (int i = 0; i < d.nops; ++i) {
+        const rih_chain_op& op = d.op[i];
+        switch (op.kind) {
+        case RIH_CH_LOAD: {
+            width = op.n;
+            const int w4 = width >> 2;
+            const float* src = reinterpret_cast<const float*>(op.p0) + b.rowbase * op.ld;
+            for (int idx = tid; idx < b.R * w4; idx += TPB) {
+                const int r = idx / w4, c = (idx - r * w4) << 2;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < b.nrows) v = *reinterpret_cast<const float4*>(src + (long long)r * op.ld + c);
+                *reinterpret_cast<float4*>(cur + r * b.ldw + c) = v;
+            }
+            break;
+        }
+        case RIH_CH_STORE: {
+            const int w4 = width >> 2;
+            float* dst = reinterpret_cast<float*>(const_cast<void*>(op.p0)) + b.rowbase * op.ld;
+            for (int idx = tid; idx < b.R * w4; idx += TPB) {
+                const int r = idx / w4, c = (idx - r * w4) << 2;
+                if (r < b.nrows) *reinterpret_cast<float4*>(dst + (long long)r * op.ld + c) =
+                    *reinterpret_cast<const float4*>(cur + r * b.ldw + c);
+            }
+            break;
+        }
+        case RIH_CH_ADD: {
+            const int w4 = width >> 2;
+            const float* src = reinterpret_cast<const float*>(op.p0) + b.rowbase * op.ld;
+            for (int idx = tid; idx < b.R * w4; idx += TPB) {
+                const int r = idx / w4, c = (idx - r * w4) << 2;
+                if (r < b.nrows) {
+                    const float4 u = *reinterpret_cast<const float4*>(src + (long long)r * op.ld + c);
+                    float4* p = reinterpret_cast<float4*>(cur + r * b.ldw + c);
+                    float4 v = *p;
+                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                    *p = v;
+                }
+            }
+            break;
+        }
+        case RIH_CH_KEEP:
+        case RIH_CH_ADD_KEPT: {
+            const int w4 = width >> 2;
+            for (int idx = tid; idx < b.R * w4; idx += TPB) {
+                const int r = idx / w4, c = (idx - r * w4) << 2;
+                float4* pc = reinterpret_cast<float4*>(cur + r * b.ldw + c);
+                float4* pk = reinterpret_cast<float4*>(kept + r * b.ldw + c);
+                if (op.kind == RIH_CH_KEEP) {
+                    *pk = *pc;
+                } else {
+                    float4 v = *pc;
+                    const float4 u = *pk;
+                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                    *pc = v;
+                }
+            }
+            break;
+        }
+        case RIH_CH_GEMM:
+            ch_gemm(op, cur, b, tid);
+            if (!(op.flags & RIH_CHF_OUT_GLOBAL)) width = op.n;
+            break;
+        case RIH_CH_DROPOUT: {
+            const int w4 = width >> 2;
+            const uint32_t key = rih_seed_key(op.seed + seed_add), thr = ch_thresh(op.f0);
+            const float ks = 1.f / (1.f - op.f0);
+            for (int idx = tid; idx < b.R * w4; idx += TPB) {
+                const int r = idx / w4, c = (idx - r * w4) << 2;
+                const uint64_t e = (uint64_t)(b.rowbase + r) * (uint64_t)width + (uint64_t)c;
+                float4* p = reinterpret_cast<float4*>(cur + r * b.ldw + c);
+                float4 v = *p;
+                v.x = rih_hash_k64(key, e) >= thr ? v.x * ks : 0.f;
+                v.y = rih_hash_k64(key, e + 1) >= thr ? v.y * ks : 0.f;
+                v.z = rih_hash_k64(key, e + 2) >= thr ? v.z * ks : 0.f;
+                v.w = rih_hash_k64(key, e + 3) >= thr ? v.w * ks : 0.f;
+                *p = v;
+            }
+            break;
+        }
+        case RIH_CH_MASKNZ: {
+            const int w4 = width >> 2;
+            const float* src = reinterpret_cast<const float*>(op.p0) + b.rowbase * op.ld;
+            for (int idx = tid; idx < b.R * w4; idx += TPB) {
+                const int r = idx / w4, c = (idx - r * w4) << 2;
+                float4* p = reinterpret_cast<float4*>(cur + r * b.ldw + c);
+                float4 v = *p, u = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < b.nrows) u = *reinterpret_cast<const float4*>(src + (long long)r * op.ld + c);
+                v.x = u.x != 0.f ? v.x * op.f0 : 0.f;
+                v.y = u.y != 0.f ? v.y * op.f0 : 0.f;
+                v.z = u.z != 0.f ? v.z * op.f0 : 0.f;
+                v.w = u.w != 0.f ? v.w * op.f0 : 0.f;
+                *p = v;
+            }
+            break;
+        }
+        case RIH_CH_LN:
+            ch_ln(op, cur, b, tid, width);
+            break;
+        case RIH_CH_LN_BWD:
+            ch_ln_bwd(op, cur, stat, b, tid, width, nblk);
+            break;
+        default:
+            break;
+        }
+        __syncthreads();
+    }
+}
+
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" int rih_chain(const rih_chain_desc* desc, void* stream) {
+    if (!desc) return RIH_EINVAL;
+    const rih_chain_desc& d = *desc;
+    if (d.nops < 1 || d.nops > RIH_CHAIN_MAXOPS || d.rows < 1 || d.nhands < 1 || d.nhands > 65535) return RIH_EINVAL;
+    if ((d.rblk != 32 && d.rblk != 64) || d.ldw < 8 || d.ldw % 4 != 0) return RIH_EINVAL;
+    // static walk of the program: widths, buffer needs, pointer / pitch requirements
+    int width = 0;
+    bool keeps = false;
+    for (int i = 0; i < d.nops; ++i) {
+        const rih_chain_op& op = d.op[i];
+        switch (op.kind) {
+        case RIH_CH_LOAD:
+            if (!op.p0 || op.n < 4 || op.n % 4 != 0 || op.ld < op.n || op.ld % 4 != 0 || !al16(op.p0)) return RIH_EINVAL;
+            width = op.n;
+            break;
+        case RIH_CH_STORE:
+        case RIH_CH_ADD:
+        case RIH_CH_MASKNZ:
+            if (!op.p0 || width == 0 || op.ld < width || op.ld % 4 != 0 || !al16(op.p0)) return RIH_EINVAL;
+            break;
+        case RIH_CH_KEEP:
+            if (width == 0) return RIH_EINVAL;
+            keeps = true;
+            break;
+        case RIH_CH_ADD_KEPT:
+            if (!keeps || width == 0) return RIH_EINVAL;
+            break;
+        case RIH_CH_GEMM: {
+            if (!op.p0 || width == 0 || op.k != width || op.k % 8 != 0 || op.n < 4 || op.n % 4 != 0 || !al16(op.p0))
+                return RIH_EINVAL;
+            if (op.s0 % 4 != 0) return RIH_EINVAL;
+            const int blocks = (d.rblk / 32) * ((op.n + 31) / 32);
+            if (op.flags & RIH_CHF_OUT_GLOBAL) {
+                if (!op.p2 || op.ld < op.n) return RIH_EINVAL;
+            } else {
+                if (blocks > 4 * MAXB) return RIH_EINVAL;       // a single pass: the result overwrites the operand
+                width = op.n;
+            }
+            break;
+        }
+        case RIH_CH_DROPOUT:
+            if (width == 0 || !(op.f0 >= 0.f && op.f0 < 1.f)) return RIH_EINVAL;
+            break;
+        case RIH_CH_LN:
+            if (!op.p0 || !op.p1 || width == 0 || ((op.p2 == nullptr) != (op.p3 == nullptr)) || !al16(op.p0) || !al16(op.p1) ||
+                op.s0 % 4 != 0 || op.s1 % 4 != 0)
+                return RIH_EINVAL;
+            break;
+        case RIH_CH_LN_BWD:
+            if (!op.p0 || !op.p1 || !op.p2 || !op.p3 || !op.p4 || width == 0 || op.ld < width || op.ld % 4 != 0 ||
+                !al16(op.p0) || !al16(op.p3) || op.s3 % 4 != 0)
+                return RIH_EINVAL;
+            break;
+        default:
+            return RIH_EINVAL;
+        }
+        if (width + 4 > d.ldw) return RIH_EINVAL;
+    }
+    const int need = d.rblk * d.ldw;
+    const dim3 grid((d.rows + d.rblk - 1) / d.rblk, d.nhands), block(TPB);
+    hipStream_t s = (hipStream_t)stream;
+    if (!keeps) {
+        if (need <= CAP_SMALL) hipLaunchKernelGGL((chain_kernel<CAP_SMALL, 0>), grid, block, 0, s, d);
+        else if (need <= CAP_SOLO) hipLaunchKernelGGL((chain_kernel<CAP_SOLO, 0>), grid, block, 0, s, d);
+        else return RIH_EINVAL;
+    } else {
+        if (need <= CAP_SMALL) hipLaunchKernelGGL((chain_kernel<CAP_SMALL, CAP_SMALL>), grid, block, 0, s, d);
+        else if (need <= CAP_PAIR) hipLaunchKernelGGL((chain_kernel<CAP_PAIR, CAP_PAIR>), grid, block, 0, s, d);
+        else return RIH_EINVAL;
+    }
+    return (int)hipGetLastError();
+}

@@ -1953,7 +1953,7 @@ extern "C" int rih_project_bwd(const float* dout, const float* v, const float* s
 }
 
 extern "C" int rih_version(void) { return RIH_ABI_VERSION; }
-extern "C" int rih_abi_sizes(int32_t* out9) {
+extern "C" int rih_abi_sizes(int32_t* out9) {      // RIH_ABI_NSIZES values
     if (!out9) return RIH_EINVAL;
     out9[0] = (int32_t)sizeof(rih_gemm_desc);
     out9[1] = (int32_t)sizeof(rih_mano_model);
@@ -1964,6 +1964,7 @@ extern "C" int rih_abi_sizes(int32_t* out9) {
     out9[6] = (int32_t)sizeof(rih_pack_desc);
     out9[7] = (int32_t)sizeof(rih_ln_final_desc);
     out9[8] = (int32_t)sizeof(rih_adam_entry);
+    out9[9] = (int32_t)sizeof(rih_chain_desc);
     return 0;
 }
 extern "C" const char* rih_arch(void) { return "gfx950"; }

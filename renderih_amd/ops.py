@@ -1797,3 +1797,308 @@ class ProjectFn(torch.autograd.Function):
 
 def projection_batch(scale, trans2d, v, img_size=256):
     return ProjectFn.apply(v, scale, trans2d, img_size)
+
+
+# ------------------------------------------------------------------------------------------ rih_chain (csrc/rih_chain.hip)
+# The row-wise sequences of an attention block -- LayerNorm -> QKV projection, and output projection -> dropout -> skip ->
+# LayerNorm -> fc1 + ReLU -> dropout -> fc2 -> dropout -> skip -- as ONE launch each way instead of 2 and 7 (9 backward).  The
+# masks are those of the standalone kernels (same seeds, same element indices), the matrix products are exact fp32.
+# RIH_CHAIN=0 keeps the standalone sequence (the A/B partner; tests/test_gpu_ops.py pins the two against each other).
+CHAIN = os.environ.get('RIH_CHAIN', '1') == '1'
+CHAIN_RBLK = int(os.environ.get('RIH_CHAIN_RBLK', '0'))      # 0 = by size; 32 / 64 = forced (tuning aid)
+_CH = dict(LOAD=1, STORE=2, ADD=3, KEEP=4, ADD_KEPT=5, GEMM=6, DROPOUT=7, MASKNZ=8, LN=9, LN_BWD=10)
+
+
+class ChainProgram:
+    """Builder of one rih_chain launch over hands-stacked rows [nhands][rows][*]."""
+
+    def __init__(self, rows, nhands):
+        from ._lib import ChainDesc
+        self.d = ChainDesc()
+        self.d.rows, self.d.nhands = rows, nhands
+        self.n = 0
+        self.width = 0
+        self.maxw = 0
+        self.keeps = False
+        self.lds_n = 0              # widest product that is written back to the LDS block
+        self.flops = 0.0
+        self.alive = []
+
+    def _op(self, kind, **kw):
+        assert self.n < 16, 'rih_chain: more than RIH_CHAIN_MAXOPS operators'
+        op = self.d.op[self.n]
+        self.n += 1
+        op.kind = _CH[kind]
+        for k, v in kw.items():
+            if torch.is_tensor(v):
+                self.alive.append(v)
+                v = v.data_ptr()
+            setattr(op, k, v)
+        return op
+
+    def load(self, t, n):
+        self._op('LOAD', p0=t, n=n, ld=t.shape[-1])
+        self.width = n
+        self.maxw = max(self.maxw, n)
+
+    def store(self, t):
+        self._op('STORE', p0=t, ld=t.shape[-1])
+
+    def add(self, t):
+        self._op('ADD', p0=t, ld=t.shape[-1])
+
+    def keep(self):
+        self._op('KEEP')
+        self.keeps = True
+
+    def add_kept(self):
+        self._op('ADD_KEPT')
+
+    def gemm(self, w, bias, n, k, sw=0, sb=0, bt=False, relu=False, out=None):
+        assert k == self.width
+        fl = (1 if relu else 0) | (2 if bt else 0) | (4 if out is not None else 0)
+        op = self._op('GEMM', p0=w, n=n, k=k, s0=sw, flags=fl)
+        if bias is not None:
+            op.p1, op.s1 = bias.data_ptr(), sb
+            self.alive.append(bias)
+        if out is not None:
+            op.p2, op.ld = out.data_ptr(), out.shape[-1]
+            self.alive.append(out)
+        else:
+            self.width = n
+            self.maxw = max(self.maxw, n)
+            self.lds_n = max(self.lds_n, n)
+        self.flops += 2.0 * self.d.rows * self.d.nhands * n * k
+
+    def dropout(self, p, seed):
+        if p > 0:
+            self._op('DROPOUT', f0=p, seed=seed)
+
+    def masknz(self, t, scale):
+        self._op('MASKNZ', p0=t, ld=t.shape[-1], f0=scale)
+
+    def ln(self, g, b, sg, sb, eps, relu=False, mean=None, rstd=None):
+        op = self._op('LN', p0=g, p1=b, s0=sg, s1=sb, f0=eps, flags=1 if relu else 0)
+        if mean is not None:
+            op.p2, op.p3 = mean.data_ptr(), rstd.data_ptr()
+            self.alive.extend((mean, rstd))
+
+    def ln_bwd(self, x, mean, rstd, g, sg):
+        """The partial-sum workspace [nhands][nblk][2][width] is allocated by run(), once the row-block size is known
+        (self.ws, self.nblk)."""
+        self._lnb = (self._op('LN_BWD', p0=x, ld=x.shape[-1], p1=mean, p2=rstd, p3=g, s3=sg), self.width)
+
+    @staticmethod
+    def pick_rblk(rows, nhands, maxw, keeps, lds_n):
+        """64-row blocks halve the weight traffic per row but need >= 2 workgroups per CU to be worth it."""
+        cap = 8448 if keeps else 12416
+        ok64 = 64 * (maxw + 4) <= cap and 2 * _cdiv(max(lds_n, 1), 32) <= 12
+        if CHAIN_RBLK in (32, 64):
+            return CHAIN_RBLK if (CHAIN_RBLK == 32 or ok64) else 32
+        return 64 if (ok64 and nhands * _cdiv(rows, 64) >= 512) else 32
+
+    def run(self):
+        d = self.d
+        d.nops = self.n
+        d.rblk = self.pick_rblk(d.rows, d.nhands, self.maxw, self.keeps, self.lds_n)
+        d.ldw = self.maxw + 4
+        d.seed_dev = _seed_dev()
+        if getattr(self, '_lnb', None) is not None:
+            op, w = self._lnb
+            self.nblk = _cdiv(d.rows, d.rblk)
+            self.ws = torch.empty((d.nhands, self.nblk, 2, w), device=self.alive[0].device, dtype=torch.float32)
+            op.p4, op.s4 = self.ws.data_ptr(), self.nblk * 2 * w
+        _profiled(self.flops, (d.rows * d.nhands, self.maxw, self.n, 1, 0, 1, 40, 1, 0),
+                  lambda: check(_L().rih_chain(C.byref(d), _stream()), 'rih_chain'))
+
+
+def chain_ok(*dims):
+    """Widths a chain accepts: multiples of 8 (they are reduction lengths too), at most 256 as an LDS-resident activation."""
+    return CHAIN and all(d % 8 == 0 and 8 <= d <= 256 for d in dims)
+
+
+def _ln_partials_finish(ws, nblk, D, nh, dg, db):
+    """d gamma / d beta [nh, D] from the per-block partials ws [nh][nblk][2][D]: deferred to the end of the backward stage
+    (ops.deferred_reductions) or finished now by the same descriptor-list kernel."""
+    items = [(ws, ws.data_ptr() + 4 * h * nblk * 2 * D, dg, dg.data_ptr() + 4 * h * D, db, db.data_ptr() + 4 * h * D, D, nblk)
+             for h in range(nh)]
+    if _DEFERRED_LN is not None:
+        _DEFERRED_LN.extend(items)
+        return
+    from ._lib import LnFinalDesc
+    arr = (LnFinalDesc * len(items))()
+    for d, (_, wsp, _, dgp, _, dbp, D_, nb) in zip(arr, items):
+        d.ws, d.dg, d.db, d.D, d.nblk = wsp, dgp, dbp, D_, nb
+    check(_L().rih_ln_param_final_multi(arr, len(items), _stream()), 'rih_ln_param_final_multi')
+
+
+def _linear_wgrad(x, g, K, Nf, rows, paired, has_bias):
+    """Weight / bias gradient of y = x W^T + b from the saved input x [2, rows, K] and the output gradient g [2, rows, Nf]:
+    per hand (paired: dw [2, Nf, K]) or summed over both hands (a parameter shared by the hands: dw [Nf, K])."""
+    dev = x.device
+    geom = (1, 1, K, 1, 1, 1, 1, 1, 1, 0, 0)
+    if paired:
+        dw = torch.empty((2, Nf, K), device=dev, dtype=torch.float32)
+        db = torch.empty((2, Nf), device=dev, dtype=torch.float32) if has_bias else None
+        _wgrad(x, g, dw, rows, K, Nf, K, Nf, geom, K, 1, K, db=db, nb=2, sx=rows * K, sdy=rows * Nf)
+    else:
+        dw = torch.empty((Nf, K), device=dev, dtype=torch.float32)
+        db = torch.empty((Nf,), device=dev, dtype=torch.float32) if has_bias else None
+        _wgrad(x, g, dw, 2 * rows, K, Nf, K, Nf, geom, K, 1, K, db=db)
+    return dw, db
+
+
+class LnLinearChainFn(torch.autograd.Function):
+    """(Linear(LayerNorm_h(x[h])), x) for hands-stacked x [2, ..., D] in one launch: per-hand LayerNorm parameters, the Linear
+    either per hand (w [2, N, D], b [2, N]) or shared by the hands (w [N, D], b [N]).  The second output aliases x for the skip
+    connection around the branch; its gradient is added inside the backward chain (see LayerNormFn)."""
+
+    @staticmethod
+    def forward(ctx, x, gL, gR, bL, bR, w, b, eps):
+        _chk(x, gL, gR, bL, bR, w, b)
+        x, w, b = _c(x), _c(w), _c(b)
+        assert x.shape[0] == 2
+        D = x.shape[-1]
+        rows = x.numel() // (2 * D)
+        paired = w.dim() == 3
+        Nf = w.shape[-2]
+        sw, sb = (Nf * D, Nf) if paired else (0, 0)
+        y = torch.empty_like(x)
+        mean = torch.empty((2 * rows,), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        out = torch.empty(x.shape[:-1] + (Nf,), device=x.device, dtype=torch.float32)
+        pr = ChainProgram(rows, 2)
+        pr.load(x, D)
+        pr.ln(gL, bL, _pdiff(gL, gR), _pdiff(bL, bR), eps, mean=mean, rstd=rstd)
+        pr.store(y)
+        pr.gemm(w, b, Nf, D, sw, sb, out=out)
+        pr.alive.extend((gR, bR))
+        pr.run()
+        ctx.save_for_backward(x, y, mean, rstd, gL, gR, w)
+        ctx.cfg = (D, rows, Nf, paired, sw)
+        return out, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dout, dskip):
+        x, y, mean, rstd, gL, gR, w = ctx.saved_tensors
+        D, rows, Nf, paired, sw = ctx.cfg
+        dout = _c(dout)
+        dx = torch.empty_like(x)
+        pr = ChainProgram(rows, 2)
+        pr.load(dout, Nf)
+        pr.gemm(w, None, D, Nf, sw, 0, bt=True)
+        pr.ln_bwd(x, mean, rstd, gL, _pdiff(gL, gR))
+        if dskip is not None:
+            pr.add(_c(dskip))
+        pr.store(dx)
+        pr.alive.append(gR)
+        pr.run()
+        dg = torch.empty((2, D), device=x.device, dtype=torch.float32)
+        db_ = torch.empty((2, D), device=x.device, dtype=torch.float32)
+        _ln_partials_finish(pr.ws, pr.nblk, D, 2, dg, db_)
+        dw, dbias = _linear_wgrad(y, dout, D, Nf, rows, paired, True)
+        return dx, dg[0], dg[1], db_[0], db_[1], dw, dbias, None
+
+
+def ln_linear_chain(x, lnL, lnR, w, b):
+    return LnLinearChainFn.apply(x, lnL.weight, lnR.weight, lnL.bias, lnR.bias, w, b, lnL.eps)
+
+
+class AttnTailChainFn(torch.autograd.Function):
+    """The rest of an attention block behind the attention product, both hands, one launch each way
+    (models/model_attn/self_attn.py:76-85 + :17-33):
+        x1  = x + dropout(o fc^T + b)                       fc per hand (fcwL / fcwR) or shared by the hands (fcwR None)
+        out = x1 + dropout(relu-dropout(LN(x1) W1^T + b1) W2^T + b2)
+    `seeds` = the three mask streams in the order the standalone sequence draws them."""
+
+    @staticmethod
+    def forward(ctx, o, x, fcw, fcwR, fcb, fcbR, gL, gR, bL, bR, w1L, w1R, b1L, b1R, w2L, w2R, b2L, b2R, eps, p, seeds):
+        _chk(o, x, fcw, fcwR, fcb, fcbR, gL, gR, bL, bR, w1L, w1R, b1L, b1R, w2L, w2R, b2L, b2R)
+        o, x = _c(o), _c(x)
+        D = x.shape[-1]
+        rows = x.numel() // (2 * D)
+        hid = w1L.shape[0]
+        fc_paired = fcwR is not None
+        sfw, sfb = (_pdiff(fcw, fcwR), _pdiff(fcb, fcbR)) if fc_paired else (0, 0)
+        dev = x.device
+        x1 = torch.empty_like(x)
+        y2 = torch.empty_like(x)
+        h = torch.empty(x.shape[:-1] + (hid,), device=dev, dtype=torch.float32)
+        out = torch.empty_like(x)
+        mean = torch.empty((2 * rows,), device=dev, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        pr = ChainProgram(rows, 2)
+        pr.load(o, D)
+        pr.gemm(fcw, fcb, D, D, sfw, sfb)
+        pr.dropout(p, seeds[0])
+        pr.add(x)
+        pr.store(x1)
+        pr.keep()
+        pr.ln(gL, bL, _pdiff(gL, gR), _pdiff(bL, bR), eps, mean=mean, rstd=rstd)
+        pr.store(y2)
+        pr.gemm(w1L, b1L, hid, D, _pdiff(w1L, w1R), _pdiff(b1L, b1R), relu=True)
+        pr.dropout(p, seeds[1])
+        pr.store(h)
+        pr.gemm(w2L, b2L, D, hid, _pdiff(w2L, w2R), _pdiff(b2L, b2R))
+        pr.dropout(p, seeds[2])
+        pr.add_kept()
+        pr.store(out)
+        pr.alive.extend((gR, bR, w1R, b1R, w2R, b2R))
+        pr.run()
+        ctx.save_for_backward(o, x1, y2, h, mean, rstd, fcw, fcwR, gL, gR, w1L, w1R, w2L, w2R)
+        ctx.cfg = (D, rows, hid, fc_paired, sfw, p, seeds)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        o, x1, y2, h, mean, rstd, fcw, fcwR, gL, gR, w1L, w1R, w2L, w2R = ctx.saved_tensors
+        D, rows, hid, fc_paired, sfw, p, seeds = ctx.cfg
+        dev = dout.device
+        dout = _c(dout)
+        g3 = torch.empty_like(dout) if p > 0 else dout          # d (fc2 output)
+        g2 = torch.empty_like(h)                                # d (fc1 pre-activation)
+        dx = torch.empty_like(dout)                             # d x1 = d x
+        g1 = torch.empty_like(dout) if p > 0 else dx            # d (fc output)
+        do = torch.empty_like(o)
+        pr = ChainProgram(rows, 2)
+        pr.load(dout, D)
+        pr.keep()
+        if p > 0:
+            pr.dropout(p, seeds[2])
+            pr.store(g3)
+        pr.gemm(w2L, None, hid, D, _pdiff(w2L, w2R), 0, bt=True)
+        pr.masknz(h, 1.0 / (1.0 - p) if p > 0 else 1.0)
+        pr.store(g2)
+        pr.gemm(w1L, None, D, hid, _pdiff(w1L, w1R), 0, bt=True)
+        pr.ln_bwd(x1, mean, rstd, gL, _pdiff(gL, gR))
+        pr.add_kept()
+        pr.store(dx)
+        if p > 0:
+            pr.dropout(p, seeds[0])
+            pr.store(g1)
+        pr.gemm(fcw, None, D, D, sfw, 0, bt=True)
+        pr.store(do)
+        pr.alive.extend((gR, w1R, w2R))
+        pr.run()
+        dg = torch.empty((2, D), device=dev, dtype=torch.float32)
+        db_ = torch.empty((2, D), device=dev, dtype=torch.float32)
+        _ln_partials_finish(pr.ws, pr.nblk, D, 2, dg, db_)
+        dfw, dfb = _linear_wgrad(o, g1, D, D, rows, fc_paired, True)
+        dw1, db1 = _linear_wgrad(y2, g2, D, hid, rows, True, True)
+        dw2, db2 = _linear_wgrad(h, g3, hid, D, rows, True, True)
+        if fc_paired:
+            dfw, dfwR, dfb, dfbR = dfw[0], dfw[1], dfb[0], dfb[1]
+        else:
+            dfwR = dfbR = None
+        return (do, dx, dfw, dfwR, dfb, dfbR, dg[0], dg[1], db_[0], db_[1], dw1[0], dw1[1], db1[0], db1[1], dw2[0], dw2[1],
+                db2[0], db2[1], None, None, None)
+
+
+def attn_tail_chain(o, x, fcL, fcR, ffL, ffR, p, seeds):
+    """fcL / fcR: the attention output projection per hand (fcR None: one nn.Linear shared by the hands, inter_attn.py:85-90);
+    ffL / ffR: the hands' MLP_res_block modules (layer_norm, fc1, fc2)."""
+    ln = (ffL.layer_norm, ffR.layer_norm)
+    return AttnTailChainFn.apply(o, x, fcL.weight, None if fcR is None else fcR.weight, fcL.bias,
+                                 None if fcR is None else fcR.bias, ln[0].weight, ln[1].weight, ln[0].bias, ln[1].bias,
+                                 ffL.fc1.weight, ffR.fc1.weight, ffL.fc1.bias, ffR.fc1.bias,
+                                 ffL.fc2.weight, ffR.fc2.weight, ffL.fc2.bias, ffR.fc2.bias, ln[0].eps, p, tuple(seeds))

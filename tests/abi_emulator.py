@@ -1230,6 +1230,91 @@ class EmulatedLib:
         _f(dtrans, B * 2)[:] = (D.sum(1) * np.float32(img) / 2).ravel()
         return 0
 
+    # ------------------------------------------------------------------ rih_chain: a chain of row-wise layers in one call
+    def rih_chain(self, dref, stream):
+        """The header's operator list restated on whole [nhands][rows][*] tensors (no row blocks: the LayerNorm parameter
+        partials all land in block 0 of the workspace, the other blocks are zero)."""
+        d = dref._obj
+        H, rows = d.nhands, d.rows
+        assert 1 <= d.nops <= 16 and d.rblk in (32, 64)
+        nblk = -(-rows // d.rblk)
+        seed_add = 0
+        if d.seed_dev:
+            seed_add = int(np.ctypeslib.as_array((C.c_uint64 * 1).from_address(int(d.seed_dev)))[0])
+
+        def rowsview(p, ld, w):
+            """[H, rows, w] view of a hands-stacked tensor with row pitch ld."""
+            flat = _f(p, (H * rows - 1) * ld + w)
+            return np.lib.stride_tricks.as_strided(flat, (H, rows, w), (4 * rows * ld, 4 * ld, 4))
+
+        def param(p, stride, n):
+            return np.stack([_f(int(p) + 4 * h * int(stride), n).copy() for h in range(H)])
+
+        cur, kept = None, None
+        for i in range(d.nops):
+            op = d.op[i]
+            kind = op.kind
+            if kind == 1:       # LOAD
+                cur = rowsview(op.p0, op.ld, op.n).astype(np.float32).copy()
+            elif kind == 2:     # STORE
+                rowsview(op.p0, op.ld, cur.shape[2])[...] = cur
+            elif kind == 3:     # ADD
+                cur = cur + rowsview(op.p0, op.ld, cur.shape[2])
+            elif kind == 4:     # KEEP
+                kept = cur.copy()
+            elif kind == 5:     # ADD_KEPT
+                cur = cur + kept
+            elif kind == 6:     # GEMM
+                K, N = op.k, op.n
+                assert K == cur.shape[2] and K % 8 == 0 and N % 4 == 0
+                W = param(op.p0, op.s0, N * K)
+                W = W.reshape(H, K, N) if (op.flags & 2) else W.reshape(H, N, K).transpose(0, 2, 1)
+                out = np.einsum('hrk,hkn->hrn', cur.astype(np.float64), W.astype(np.float64)).astype(np.float32)
+                if op.p1:
+                    out = out + param(op.p1, op.s1, N)[:, None, :]
+                if op.flags & 1:
+                    out = np.maximum(out, 0)
+                if op.flags & 4:
+                    rowsview(op.p2, op.ld, N)[...] = out
+                else:
+                    cur = out.astype(np.float32)
+            elif kind == 7:     # DROPOUT
+                w = cur.shape[2]
+                seed = (int(op.seed) + seed_add) % (1 << 64)
+                cur = (cur.reshape(-1) * keep_mask(seed, H * rows * w, float(op.f0))).reshape(H, rows, w).astype(np.float32)
+            elif kind == 8:     # MASKNZ
+                cur = np.where(rowsview(op.p0, op.ld, cur.shape[2]) != 0, cur * np.float32(op.f0), 0).astype(np.float32)
+            elif kind == 9:     # LN
+                w = cur.shape[2]
+                g, b = param(op.p0, op.s0, w), param(op.p1, op.s1, w)
+                m = cur.mean(2, keepdims=True, dtype=np.float64)
+                v = ((cur - m) ** 2).mean(2, keepdims=True, dtype=np.float64)
+                rs = 1.0 / np.sqrt(v + np.float64(np.float32(op.f0)))
+                cur = ((cur - m) * rs * g[:, None, :] + b[:, None, :]).astype(np.float32)
+                if op.flags & 1:
+                    cur = np.maximum(cur, 0)
+                if op.p2:
+                    _f(op.p2, H * rows)[:] = m.reshape(-1)
+                    _f(op.p3, H * rows)[:] = rs.reshape(-1)
+            elif kind == 10:    # LN_BWD
+                w = cur.shape[2]
+                x = rowsview(op.p0, op.ld, w).astype(np.float64)
+                m = _f(op.p1, H * rows).reshape(H, rows, 1).astype(np.float64)
+                rs = _f(op.p2, H * rows).reshape(H, rows, 1).astype(np.float64)
+                g = param(op.p3, op.s3, w).astype(np.float64)[:, None, :]
+                dy = cur.astype(np.float64)
+                xh = (x - m) * rs
+                for h in range(H):
+                    ws = _f(int(op.p4) + 4 * h * int(op.s4), nblk * 2 * w).reshape(nblk, 2, w)
+                    ws[...] = 0
+                    ws[0, 0] = (dy[h] * xh[h]).sum(0)
+                    ws[0, 1] = dy[h].sum(0)
+                t = dy * g
+                cur = (rs * (t - t.mean(2, keepdims=True) - xh * (t * xh).mean(2, keepdims=True))).astype(np.float32)
+            else:
+                return -1
+        return 0
+
     def rih_version(self):
         return 1
 

@@ -43,6 +43,13 @@ def test_other_ops_host_logic():
     G.test_cheby_gather_project()
 
 
+def test_row_chain_host_logic():
+    """The operator programs that ops.LnLinearChainFn / AttnTailChainFn hand to rih_chain (per-hand and hand-shared
+    projections, mask seeds in the standalone sequence's order, lazily sized LayerNorm workspace)."""
+    G.test_attention_block_chains(2, 63, 128, 4, 0.1, False)
+    G.test_attention_block_chains(2, 63, 128, 4, 0.0, True)
+
+
 def test_paired_layers_host_logic():
     """Strides between separately allocated left/right parameters, stacked QKV operand, batched split-K reduce, grouped
     LayerNorm, shared-input patch conv: the descriptor plumbing of the hands-stacked decoder path."""

@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from renderih_amd.testing import assert_close
+from renderih_amd.testing import assert_close, is_null_gradient
 
 pytestmark = pytest.mark.gpu
 
@@ -926,3 +926,111 @@ def test_conv_bn_epilogue_statistics_survive_a_large_mean():
         got_var = bn_g.running_var.cpu().double() * (n - 1) / n             # undo the unbiasing
         # (the fp32 convolution output itself carries ~1e-6 * 40 of round-off per element against a std of 2.5e-3)
         assert float(((got_var - var64).abs() / var64).max()) < 1e-2, (use_stats, float(((got_var - var64).abs() / var64).max()))
+
+
+def _torch_attention_block(mods, x, heads, cross):
+    """Plain-torch restatement (no dropout) of SelfAttn.forward_pair / the cross-hand half of inter_attn.forward_pair on the
+    hands-stacked x [2, B, S, D] -- models/model_attn/self_attn.py:56-85, inter_attn.py:75-125."""
+    def ln(m, t):
+        return F.layer_norm(t, (t.shape[-1],), m.weight, m.bias, m.eps)
+
+    def mha(q, k, v):
+        B, S, D = q.shape
+        d = D // heads
+        sp = lambda t: t.view(B, -1, heads, d).transpose(1, 2)
+        a = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) / math.sqrt(d), -1)
+        return (a @ sp(v)).transpose(1, 2).reshape(B, S, D)
+
+    out = []
+    if not cross:
+        for h, m in enumerate(mods):
+            y = ln(m.layer_norm, x[h])
+            o = mha(F.linear(y, m.w_qs.weight, m.w_qs.bias), F.linear(y, m.w_ks.weight, m.w_ks.bias),
+                    F.linear(y, m.w_vs.weight, m.w_vs.bias))
+            x1 = x[h] + F.linear(o, m.fc.weight, m.fc.bias)
+            y2 = ln(m.ff.layer_norm, x1)
+            out.append(x1 + F.linear(F.relu(F.linear(y2, m.ff.fc1.weight, m.ff.fc1.bias)), m.ff.fc2.weight, m.ff.fc2.bias))
+    else:
+        m = mods
+        y = [ln(m.layer_norm1, x[0]), ln(m.layer_norm2, x[1])]
+        q = [F.linear(t, m.w_qs.weight, m.w_qs.bias) for t in y]
+        k = [F.linear(t, m.w_ks.weight, m.w_ks.bias) for t in y]
+        v = [F.linear(t, m.w_vs.weight, m.w_vs.bias) for t in y]
+        feat = [mha(q[0], k[1], v[1]), mha(q[1], k[0], v[0])]
+        for h, ff in enumerate((m.ffL, m.ffR)):
+            x1 = x[h] + F.linear(feat[h], m.fc.weight, m.fc.bias)
+            y2 = ln(ff.layer_norm, x1)
+            out.append(x1 + F.linear(F.relu(F.linear(y2, ff.fc1.weight, ff.fc1.bias)), ff.fc2.weight, ff.fc2.bias))
+    return torch.stack(out)
+
+
+@pytest.mark.parametrize('B,S,D,heads,p,cross', [(2, 63, 128, 4, 0.0, False), (1, 40, 64, 4, 0.1, False),
+                                                 (3, 33, 32, 2, 0.05, False), (2, 63, 128, 4, 0.0, True),
+                                                 (1, 70, 64, 4, 0.1, True)])
+def test_attention_block_chains(B, S, D, heads, p, cross):
+    """rih_chain (LayerNorm -> QKV projection; output projection -> dropout -> skip -> LayerNorm -> fc1 + ReLU -> dropout ->
+    fc2 -> dropout -> skip, one launch each, both directions) against the standalone launch sequence it replaces with the SAME
+    dropout masks: output, input gradient and every parameter gradient; without dropout also against plain torch.  Row counts
+    that are not multiples of the 32-row block, per-hand and hand-shared projections."""
+    from renderih_amd import attn, ops
+    d = dev()
+    torch.manual_seed(5)
+    if cross:
+        mod = attn.inter_attn(D, n_heads=heads, dropout=p)
+    else:
+        mod = torch.nn.ModuleList([attn.SelfAttn(D, n_heads=heads, dropout=p) for _ in range(2)])
+    g = torch.Generator().manual_seed(11)
+    for prm in mod.parameters():           # biases / LayerNorm parameters away from their 0 / 1 initial values
+        with torch.no_grad():
+            if prm.dim() == 1:
+                prm.add_(0.3 * torch.randn(prm.shape, generator=g))
+    x, gy = rnd(2, B, S, D, seed=1), rnd(2, B, S, D, seed=2)
+
+    def run_torch():
+        t = x.clone().requires_grad_(True)
+        y = _torch_attention_block(mod, t, heads, cross)
+        y.backward(gy)
+        grads = [q.grad.clone() if q.grad is not None else None for q in mod.parameters()]
+        mod.zero_grad(set_to_none=True)
+        return y.detach(), t.grad, grads
+
+    ref = run_torch() if p == 0 else None
+    mod = mod.to(d)
+    res = []
+    saved = ops.CHAIN
+    try:
+        for chain in (False, True):
+            ops.CHAIN = chain
+            torch.manual_seed(77)           # DropCtx draws its base seed from the host RNG
+            dc = attn.DropCtx(p, True)
+            t = x.to(d).clone().requires_grad_(True)
+            if cross:
+                # the cross-hand half only: its per-hand self-attention layers are the other parametrisations of this test
+                w = torch.cat([mod.w_qs.weight, mod.w_ks.weight, mod.w_vs.weight], 0)
+                b = torch.cat([mod.w_qs.bias, mod.w_ks.bias, mod.w_vs.bias], 0)
+                sd = (lambda: dc.seed()) if p > 0 else (lambda: 0)
+                if chain:
+                    qkv, X = ops.ln_linear_chain(t, mod.layer_norm1, mod.layer_norm2, w, b)
+                    feat = ops.cross_attention_stacked(qkv, heads, p, sd(), sd())
+                    y = ops.attn_tail_chain(feat, X, mod.fc, None, mod.ffL, mod.ffR, p, attn._seeds3(dc))
+                else:
+                    qkv = ops.linear(ops.layernorm_pair(t, mod.layer_norm1, mod.layer_norm2), w, b)
+                    feat = ops.cross_attention_stacked(qkv, heads, p, sd(), sd())
+                    y = attn.MLP_res_block.forward_pair(mod.ffL, mod.ffR, attn._lin_drop_res(dc, mod.fc, feat, t), dc)
+            else:
+                y = attn.SelfAttn.forward_pair(mod[0], mod[1], t, dc)
+            y.backward(gy.to(d))
+            res.append((y.detach(), t.grad, [q.grad.clone() if q.grad is not None else None for q in mod.parameters()]))
+            mod.zero_grad(set_to_none=True)
+    finally:
+        ops.CHAIN = saved
+    names = [n for n, _ in mod.named_parameters()]
+    for which, other in (('standalone', res[0]),) + ((('torch', ref),) if ref is not None else ()):
+        assert_close(res[1][0], other[0], 2e-4, 2e-5, 'chain out vs ' + which)
+        assert_close(res[1][1], other[1], 1e-3, 1e-4, 'chain dx vs ' + which)
+        for n, a, b_ in zip(names, res[1][2], other[2]):
+            if (cross and ('L_self_attn_layer' in n or 'R_self_attn_layer' in n)) or is_null_gradient(n):
+                continue        # (a key bias has no gradient in exact arithmetic: softmax is shift invariant)
+            assert (a is None) == (b_ is None), n
+            if a is not None:
+                assert_close(a, b_, 1e-3, 1e-4, 'chain d%s vs %s' % (n, which))
