@@ -505,7 +505,9 @@ int rih_flash_attention_bwd(const float* dO, int do_ld, const float* O, int o_ld
  *   RIH_CH_GEMM      cur[:, :n] = cur[:, :k] x B (+ p1[n] bias) (ReLU if flags & RIH_CHF_RELU); B(kk, j) = p0[j*k + kk] (an
  *                    nn.Linear weight [n][k] as stored) or, with RIH_CHF_BT, p0[kk*n + j] ([k][n]: the same weight in the data
  *                    gradient).  With RIH_CHF_OUT_GLOBAL the result goes to p2 rows (pitch ld) instead of `cur` (n is then not
- *                    limited by the LDS block; cur keeps its value).  k % 8 == 0, n % 4 == 0.
+ *                    limited by the LDS block; cur keeps its value).  With RIH_CHF_A_GLOBAL the left operand is read from
+ *                    p3 rows (pitch `lda`) instead of `cur` (k is then not limited by the block either: the QKV data gradient,
+ *                    k = 3 D).  k % 8 == 0, n % 4 == 0.
  *   RIH_CH_DROPOUT   cur = keep ? cur / (1 - f0) : 0, element (h, r, c) of the [nhands][rows][width] tensor kept iff
  *                    hash(seed (+ *seed_dev), ((h*rows + r)*width + c)) >= f0 * 2^32 -- the mask of rih_add_dropout /
  *                    rih_dropout_bwd on the same tensor, bit for bit
@@ -525,9 +527,10 @@ enum {
 #define RIH_CHF_RELU 1
 #define RIH_CHF_BT 2
 #define RIH_CHF_OUT_GLOBAL 4
+#define RIH_CHF_A_GLOBAL 8
 typedef struct rih_chain_op {
     int32_t kind, flags, n, k;
-    int32_t ld, reserved;
+    int32_t ld, lda;
     float f0, f1;
     uint64_t seed;
     const void* p0;
@@ -544,6 +547,10 @@ typedef struct rih_chain_desc {
     rih_chain_op op[RIH_CHAIN_MAXOPS];
 } rih_chain_desc;
 int rih_chain(const rih_chain_desc* desc, void* stream);
+/* The argument check of rih_chain on its own (no launch): 0 = launchable; -1 = a header field; -4 = the block does not fit the
+ * LDS; otherwise -(100 * (index of the offending operator + 1) + reason), reason 1 = a pointer is missing / misaligned (or a
+ * parameter stride is not a multiple of 4), 2 = a width / pitch / probability, 3 = operator order, 4 = too wide for the block. */
+int rih_chain_check(const rih_chain_desc* desc);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused attention forward, first generation (keeps P / Pd in memory; superseded by rih_flash_attention_*, kept as an opt-in

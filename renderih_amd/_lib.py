@@ -50,7 +50,7 @@ class LnFinalDesc(C.Structure):
 
 class ChainOp(C.Structure):
     _fields_ = [('kind', C.c_int32), ('flags', C.c_int32), ('n', C.c_int32), ('k', C.c_int32),
-                ('ld', C.c_int32), ('reserved', C.c_int32), ('f0', C.c_float), ('f1', C.c_float), ('seed', C.c_uint64),
+                ('ld', C.c_int32), ('lda', C.c_int32), ('f0', C.c_float), ('f1', C.c_float), ('seed', C.c_uint64),
                 ('p0', C.c_void_p), ('p1', C.c_void_p), ('p2', C.c_void_p), ('p3', C.c_void_p), ('p4', C.c_void_p),
                 ('s0', C.c_int64), ('s1', C.c_int64), ('s2', C.c_int64), ('s3', C.c_int64), ('s4', C.c_int64)]
 
@@ -199,6 +199,7 @@ SIGNATURES = {
     'rih_flash_attention_bwd': (c_i, [c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl,
                                       c_u64, C.c_void_p, c_f, c_f, c_f, c_i, c_f, c_f, c_i, C.c_void_p]),
     'rih_chain': (c_i, [C.POINTER(ChainDesc), C.c_void_p]),
+    'rih_chain_check': (c_i, [C.POINTER(ChainDesc)]),
     'rih_version': (c_i, []),
     'rih_abi_sizes': (c_i, [C.POINTER(C.c_int32)]),
     'rih_arch': (C.c_char_p, []),

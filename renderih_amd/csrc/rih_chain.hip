@@ -48,6 +48,9 @@ struct Blk {
 };
 
 // ---- cur[:, :n] = cur[:, :k] x B (+ bias) (ReLU), or the same product written to global rows ------------------------------
+// AG: the A operand comes from global rows p3 (pitch lda) instead of `cur` -- a reduction longer than the LDS
+// block is wide (the QKV data gradient: k = 3 D).
+template <bool AG>
 __device__ __forceinline__ void ch_gemm(const rih_chain_op& op, float* __restrict__ cur, const Blk& b, int tid) {
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
     const int K = op.k, N = op.n, ldw = b.ldw;
@@ -69,9 +72,19 @@ __device__ __forceinline__ void ch_gemm(const rih_chain_op& op, float* __restric
             const int col = cb * 32 + l31;
             const bool cok = col < N;
             const float* arow = cur + (rb * 32 + l31) * ldw + 4 * lhi;
+            if (AG) {       // rows behind the block's last one re-read it (finite values that nothing stores)
+                const int ar = min(rb * 32 + l31, b.nrows - 1);
+                arow = reinterpret_cast<const float*>(op.p3) + (b.rowbase + ar) * (long long)op.lda + 4 * lhi;
+            }
             for (int k0 = 0; k0 < K; k0 += 128) {
                 const int nj = min(16, (K - k0) >> 3);
                 float4 bq[16];
+                float4 aq[AG ? 16 : 1];
+                if (AG) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (j < nj) aq[AG ? j : 0] = *reinterpret_cast<const float4*>(arow + k0 + 8 * j);
+                }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     bq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -88,7 +101,7 @@ __device__ __forceinline__ void ch_gemm(const rih_chain_op& op, float* __restric
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     if (j < nj) {
-                        const float4 a = *reinterpret_cast<const float4*>(arow + k0 + 8 * j);
+                        const float4 a = AG ? aq[AG ? j : 0] : *reinterpret_cast<const float4*>(arow + k0 + 8 * j);
                         acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[j].x, acc[i], 0, 0, 0);
                         acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[j].y, acc[i], 0, 0, 0);
                         acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[j].z, acc[i], 0, 0, 0);
@@ -300,7 +313,8 @@ __global__ __launch_bounds__(TPB) void chain_kernel(const rih_chain_desc d) {
             break;
         }
         case RIH_CH_GEMM:
-            ch_gemm(op, cur, b, tid);
+            if (op.flags & RIH_CHF_A_GLOBAL) ch_gemm<true>(op, cur, b, tid);
+            else ch_gemm<false>(op, cur, b, tid);
             if (!(op.flags & RIH_CHF_OUT_GLOBAL)) width = op.n;
             break;
         case RIH_CH_DROPOUT: {
@@ -351,66 +365,98 @@ __global__ __launch_bounds__(TPB) void chain_kernel(const rih_chain_desc d) {
 
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-}  // namespace
-
-extern "C" int rih_chain(const rih_chain_desc* desc, void* stream) {
-    if (!desc) return RIH_EINVAL;
-    const rih_chain_desc& d = *desc;
+// Static walk of the program: widths, buffer needs, pointer / pitch requirements.  0 = launchable; otherwise -(100 * (index of
+// the offending operator + 1) + reason), reason 1 = pointer missing / misaligned, 2 = width or pitch, 3 = operator order,
+// 4 = does not fit the LDS block; -1 = header fields.  *keeps_out = the program uses the second buffer.
+static int chain_check(const rih_chain_desc& d, bool* keeps_out) {
     if (d.nops < 1 || d.nops > RIH_CHAIN_MAXOPS || d.rows < 1 || d.nhands < 1 || d.nhands > 65535) return RIH_EINVAL;
     if ((d.rblk != 32 && d.rblk != 64) || d.ldw < 8 || d.ldw % 4 != 0) return RIH_EINVAL;
-    // static walk of the program: widths, buffer needs, pointer / pitch requirements
     int width = 0;
     bool keeps = false;
+#define CH_BAD(reason) return -(100 * (i + 1) + (reason))
     for (int i = 0; i < d.nops; ++i) {
         const rih_chain_op& op = d.op[i];
         switch (op.kind) {
         case RIH_CH_LOAD:
-            if (!op.p0 || op.n < 4 || op.n % 4 != 0 || op.ld < op.n || op.ld % 4 != 0 || !al16(op.p0)) return RIH_EINVAL;
+            if (!op.p0 || !al16(op.p0)) CH_BAD(1);
+            if (op.n < 4 || op.n % 4 != 0 || op.ld < op.n || op.ld % 4 != 0) CH_BAD(2);
             width = op.n;
             break;
         case RIH_CH_STORE:
         case RIH_CH_ADD:
         case RIH_CH_MASKNZ:
-            if (!op.p0 || width == 0 || op.ld < width || op.ld % 4 != 0 || !al16(op.p0)) return RIH_EINVAL;
+            if (width == 0) CH_BAD(3);
+            if (!op.p0 || !al16(op.p0)) CH_BAD(1);
+            if (op.ld < width || op.ld % 4 != 0) CH_BAD(2);
             break;
         case RIH_CH_KEEP:
-            if (width == 0) return RIH_EINVAL;
+            if (width == 0) CH_BAD(3);
             keeps = true;
             break;
         case RIH_CH_ADD_KEPT:
-            if (!keeps || width == 0) return RIH_EINVAL;
+            if (!keeps || width == 0) CH_BAD(3);
             break;
         case RIH_CH_GEMM: {
-            if (!op.p0 || width == 0 || op.k != width || op.k % 8 != 0 || op.n < 4 || op.n % 4 != 0 || !al16(op.p0))
-                return RIH_EINVAL;
-            if (op.s0 % 4 != 0) return RIH_EINVAL;
+            if (op.flags & RIH_CHF_A_GLOBAL) {
+                if (!op.p3 || !al16(op.p3)) CH_BAD(1);
+                if (op.lda < op.k || op.lda % 4 != 0) CH_BAD(2);
+            } else {
+                if (width == 0) CH_BAD(3);
+                if (op.k != width) CH_BAD(2);
+            }
+            if (!op.p0 || !al16(op.p0) || op.s0 % 4 != 0) CH_BAD(1);
+            if (op.k % 8 != 0 || op.n < 4 || op.n % 4 != 0) CH_BAD(2);
             const int blocks = (d.rblk / 32) * ((op.n + 31) / 32);
             if (op.flags & RIH_CHF_OUT_GLOBAL) {
-                if (!op.p2 || op.ld < op.n) return RIH_EINVAL;
+                if (!op.p2) CH_BAD(1);
+                if (op.ld < op.n) CH_BAD(2);
             } else {
-                if (blocks > 4 * MAXB) return RIH_EINVAL;       // a single pass: the result overwrites the operand
+                if (blocks > 4 * MAXB) CH_BAD(4);       // a single pass: the result overwrites the operand
                 width = op.n;
             }
             break;
         }
         case RIH_CH_DROPOUT:
-            if (width == 0 || !(op.f0 >= 0.f && op.f0 < 1.f)) return RIH_EINVAL;
+            if (width == 0) CH_BAD(3);
+            if (!(op.f0 >= 0.f && op.f0 < 1.f)) CH_BAD(2);
             break;
         case RIH_CH_LN:
-            if (!op.p0 || !op.p1 || width == 0 || ((op.p2 == nullptr) != (op.p3 == nullptr)) || !al16(op.p0) || !al16(op.p1) ||
+            if (width == 0) CH_BAD(3);
+            if (!op.p0 || !op.p1 || ((op.p2 == nullptr) != (op.p3 == nullptr)) || !al16(op.p0) || !al16(op.p1) ||
                 op.s0 % 4 != 0 || op.s1 % 4 != 0)
-                return RIH_EINVAL;
+                CH_BAD(1);
             break;
         case RIH_CH_LN_BWD:
-            if (!op.p0 || !op.p1 || !op.p2 || !op.p3 || !op.p4 || width == 0 || op.ld < width || op.ld % 4 != 0 ||
-                !al16(op.p0) || !al16(op.p3) || op.s3 % 4 != 0)
-                return RIH_EINVAL;
+            if (width == 0) CH_BAD(3);
+            if (!op.p0 || !op.p1 || !op.p2 || !op.p3 || !op.p4 || !al16(op.p0) || !al16(op.p3) || op.s3 % 4 != 0) CH_BAD(1);
+            if (op.ld < width || op.ld % 4 != 0) CH_BAD(2);
             break;
         default:
-            return RIH_EINVAL;
+            CH_BAD(3);
         }
-        if (width + 4 > d.ldw) return RIH_EINVAL;
+        if (width + 4 > d.ldw) CH_BAD(4);
     }
+#undef CH_BAD
+    const int need = d.rblk * d.ldw;
+    if (need > (keeps ? CAP_PAIR : CAP_SOLO)) return -4;
+    *keeps_out = keeps;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int rih_chain_check(const rih_chain_desc* desc) {
+    if (!desc) return RIH_EINVAL;
+    bool keeps = false;
+    return chain_check(*desc, &keeps);
+}
+
+extern "C" int rih_chain(const rih_chain_desc* desc, void* stream) {
+    if (!desc) return RIH_EINVAL;
+    const rih_chain_desc& d = *desc;
+    bool keeps = false;
+    const int bad = chain_check(d, &keeps);
+    if (bad != 0) return bad;
     const int need = d.rblk * d.ldw;
     const dim3 grid((d.rows + d.rblk - 1) / d.rblk, d.nhands), block(TPB);
     hipStream_t s = (hipStream_t)stream;

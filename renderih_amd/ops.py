@@ -1854,10 +1854,15 @@ class ChainProgram:
     def add_kept(self):
         self._op('ADD_KEPT')
 
-    def gemm(self, w, bias, n, k, sw=0, sb=0, bt=False, relu=False, out=None):
-        assert k == self.width
-        fl = (1 if relu else 0) | (2 if bt else 0) | (4 if out is not None else 0)
+    def gemm(self, w, bias, n, k, sw=0, sb=0, bt=False, relu=False, out=None, a=None):
+        """a: the left operand as a tensor in memory (rows of pitch a.shape[-1]) instead of the block state -- a reduction
+        longer than the block is wide."""
+        assert a is not None or k == self.width
+        fl = (1 if relu else 0) | (2 if bt else 0) | (4 if out is not None else 0) | (8 if a is not None else 0)
         op = self._op('GEMM', p0=w, n=n, k=k, s0=sw, flags=fl)
+        if a is not None:
+            op.p3, op.lda = a.data_ptr(), a.shape[-1]
+            self.alive.append(a)
         if bias is not None:
             op.p1, op.s1 = bias.data_ptr(), sb
             self.alive.append(bias)
@@ -1985,8 +1990,7 @@ class LnLinearChainFn(torch.autograd.Function):
         dout = _c(dout)
         dx = torch.empty_like(x)
         pr = ChainProgram(rows, 2)
-        pr.load(dout, Nf)
-        pr.gemm(w, None, D, Nf, sw, 0, bt=True)
+        pr.gemm(w, None, D, Nf, sw, 0, bt=True, a=dout)       # (3 D wide: read from memory, not through the LDS block)
         pr.ln_bwd(x, mean, rstd, gL, _pdiff(gL, gR))
         if dskip is not None:
             pr.add(_c(dskip))

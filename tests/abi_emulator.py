@@ -49,6 +49,9 @@ def keep_mask(seed, n, p):
     return (hash_np(seed, np.arange(n)) >= thr).astype(np.float32) / np.float32(1.0 - p)
 
 
+_HOST_CHECK = None
+
+
 class EmulatedLib:
     @staticmethod
     def _seed(seed, seed_dev):
@@ -1237,6 +1240,9 @@ class EmulatedLib:
         d = dref._obj
         H, rows = d.nhands, d.rows
         assert 1 <= d.nops <= 16 and d.rblk in (32, 64)
+        bad = self.rih_chain_check(dref)
+        if bad != 0:
+            return bad
         nblk = -(-rows // d.rblk)
         seed_add = 0
         if d.seed_dev:
@@ -1266,10 +1272,15 @@ class EmulatedLib:
                 cur = cur + kept
             elif kind == 6:     # GEMM
                 K, N = op.k, op.n
-                assert K == cur.shape[2] and K % 8 == 0 and N % 4 == 0
+                if op.flags & 8:        # A operand from memory
+                    lhs = rowsview(op.p3, op.lda, K).astype(np.float64)
+                else:
+                    assert K == cur.shape[2]
+                    lhs = cur.astype(np.float64)
+                assert K % 8 == 0 and N % 4 == 0
                 W = param(op.p0, op.s0, N * K)
                 W = W.reshape(H, K, N) if (op.flags & 2) else W.reshape(H, N, K).transpose(0, 2, 1)
-                out = np.einsum('hrk,hkn->hrn', cur.astype(np.float64), W.astype(np.float64)).astype(np.float32)
+                out = np.einsum('hrk,hkn->hrn', lhs, W.astype(np.float64)).astype(np.float32)
                 if op.p1:
                     out = out + param(op.p1, op.s1, N)[:, None, :]
                 if op.flags & 1:
@@ -1314,6 +1325,21 @@ class EmulatedLib:
             else:
                 return -1
         return 0
+
+    def rih_chain_check(self, dref):
+        """The library's own argument check, from the host build of the kernels (tests/hipcpu) when that is available: a
+        descriptor the real entry point would refuse must not pass under emulation either."""
+        global _HOST_CHECK
+        if _HOST_CHECK is None:
+            try:
+                import sys
+                import os
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'hipcpu'))
+                from host_kernels import load
+                _HOST_CHECK = load().rih_chain_check
+            except Exception:       # noqa: BLE001  (no host compiler: the emulation stays usable without the check)
+                _HOST_CHECK = False
+        return int(_HOST_CHECK(dref)) if _HOST_CHECK else 0
 
     def rih_version(self):
         return 1
