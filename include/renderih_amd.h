@@ -507,7 +507,7 @@ int rih_flash_attention_bwd(const float* dO, int do_ld, const float* O, int o_ld
  *                    gradient).  With RIH_CHF_OUT_GLOBAL the result goes to p2 rows (pitch ld) instead of `cur` (n is then not
  *                    limited by the LDS block; cur keeps its value).  With RIH_CHF_A_GLOBAL the left operand is read from
  *                    p3 rows (pitch `lda`) instead of `cur` (k is then not limited by the block either: the QKV data gradient,
- *                    k = 3 D).  k % 8 == 0, n % 4 == 0.
+ *                    k = 3 D; data-gradient form only).  k % 64 == 0, n % 32 == 0.
  *   RIH_CH_DROPOUT   cur = keep ? cur / (1 - f0) : 0, element (h, r, c) of the [nhands][rows][width] tensor kept iff
  *                    hash(seed (+ *seed_dev), ((h*rows + r)*width + c)) >= f0 * 2^32 -- the mask of rih_add_dropout /
  *                    rih_dropout_bwd on the same tensor, bit for bit
@@ -517,8 +517,7 @@ int rih_flash_attention_bwd(const float* dO, int do_ld, const float* O, int o_ld
  *   RIH_CH_LN_BWD    cur (= dy) -> dx of that LayerNorm: p0 = its input rows (pitch ld), p1 / p2 = mean / rstd, p3 = gamma;
  *                    the block's partial parameter gradients go to p4 + h*s4 laid out [nblk][2][width] (nblk = ceil(rows/rblk);
  *                    [.][0] = d gamma, [.][1] = d beta) for rih_ln_param_final_multi
- * Limits: 1 <= nops <= RIH_CHAIN_MAXOPS; rblk in {32, 64}; ldw >= every width + 4, ldw % 4 == 0, rblk * ldw <= 12416 without
- * a KEEP, <= 8448 with one; all widths % 4 == 0; row pitches % 4 == 0 and pointers 16-byte aligned. */
+ * Limits: 1 <= nops <= RIH_CHAIN_MAXOPS; rblk in {32, 64}; ldw >= every width + 4, ldw % 4 == 0, rblk * ldw <= 8448; all widths % 4 == 0; row pitches % 4 == 0 and pointers 16-byte aligned. */
 #define RIH_CHAIN_MAXOPS 16
 enum {
     RIH_CH_LOAD = 1, RIH_CH_STORE = 2, RIH_CH_ADD = 3, RIH_CH_KEEP = 4, RIH_CH_ADD_KEPT = 5, RIH_CH_GEMM = 6,

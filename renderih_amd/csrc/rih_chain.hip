@@ -29,10 +29,8 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int TPB = 256;
-constexpr int MAXB = 3;           // 32x32 output blocks per wavefront and pass (12 per workgroup)
-constexpr int CAP_SOLO = 12416;   // floats of `cur` without a `kept` buffer (32 rows x (384 + 4))
-constexpr int CAP_PAIR = 8448;    // floats of `cur` and of `kept` (64 rows x (128 + 4), 32 rows x (256 + 4) fits too)
-constexpr int CAP_SMALL = 4224;   // 32 rows x (128 + 4): four workgroups per CU
+constexpr int CAP_BIG = 8448;     // floats of `cur` (and of `kept`): 64 rows x (128 + 4); 32 rows x (256 + 4) fits too
+constexpr int CAP_SMALL = 4224;   // 32 rows x (128 + 4): two workgroups per CU next to the weight tiles
 
 __device__ __forceinline__ int acc_row(int r, int lhi) { return (r & 3) + 8 * (r >> 2) + 4 * lhi; }
 __device__ __forceinline__ uint32_t ch_thresh(float p) {
@@ -47,90 +45,105 @@ struct Blk {
     long long rowbase;          // h * rows + row0: index of the block's first row in a hands-stacked tensor
 };
 
-// ---- cur[:, :n] = cur[:, :k] x B (+ bias) (ReLU), or the same product written to global rows ------------------------------
-// AG: the A operand comes from global rows p3 (pitch lda) instead of `cur` -- a reduction longer than the LDS
-// block is wide (the QKV data gradient: k = 3 D).
-template <bool AG>
-__device__ __forceinline__ void ch_gemm(const rih_chain_op& op, float* __restrict__ cur, const Blk& b, int tid) {
+// ---- nxt[:, :n] = cur[:, :k] x B (+ bias) (ReLU), or the same product written to global rows ------------------------------
+// A wavefront owns the 32-column blocks cb = wave, wave + 4, ... of the result and, per block, ALL row blocks of the workgroup
+// (one weight tile feeds one or two accumulators).  The weight streams in k-chunks of KC floats: a chunk of a column block is
+// 32 x KC, requested from L2 with fully used 128-byte lines (16 bytes per lane and request), parked in the wavefront's private
+// LDS tile and read back in MFMA operand order; the requests of the next chunk are issued before the MFMAs of the current one,
+// so the L2 round trip hides behind the arithmetic.  (Operand fetches straight from L2 -- each lane its own 16 bytes of a row
+// -- use a quarter of every line they pull through the CU's L1: measured 3.5 x the MFMA time on the decoder's D = 256 blocks.)
+//   NT weight ([n][k] as nn.Linear stores it): tile [32 columns][KC + 4], 16-byte writes and operand reads;
+//   BT weight ([k][n], the data gradient):     tile [KC][32 columns], 16-byte writes, four 4-byte operand reads per group.
+// The result goes to the block's OTHER activation buffer (the caller swaps the two), so a finished column block leaves the
+// registers at once and the loop body exists once.  AG: the A operand comes from global rows p3 (pitch lda) instead of `cur`.
+template <bool BT, int KC>
+__device__ __forceinline__ void wt_issue(float4 (&q)[32 * KC / 256], const float* __restrict__ W, int K, int N, int n0, int k0,
+                                         int lane) {
+#pragma unroll
+    for (int i = 0; i < 32 * KC / 256; ++i) {       // (n % 32 == 0 and k % KC == 0: every tile is full)
+        const int idx = lane + 64 * i;
+        if (!BT) q[i] = *reinterpret_cast<const float4*>(W + (long long)(n0 + idx / (KC / 4)) * K + k0 + 4 * (idx % (KC / 4)));
+        else q[i] = *reinterpret_cast<const float4*>(W + (long long)(k0 + (idx >> 3)) * N + n0 + 4 * (idx & 7));
+    }
+}
+template <bool BT, int KC>
+__device__ __forceinline__ void wt_commit(const float4 (&q)[32 * KC / 256], float* __restrict__ wt, int lane) {
+#pragma unroll
+    for (int i = 0; i < 32 * KC / 256; ++i) {
+        const int idx = lane + 64 * i;
+        if (!BT) *reinterpret_cast<float4*>(wt + (idx / (KC / 4)) * (KC + 4) + 4 * (idx % (KC / 4))) = q[i];
+        else *reinterpret_cast<float4*>(wt + 4 * idx) = q[i];       // [kr][32]: idx = kr * 8 + column quad
+    }
+}
+
+template <bool AG, bool BT, int NRB, int KC>
+__device__ __forceinline__ void ch_gemm(const rih_chain_op& op, const float* __restrict__ cur, float* __restrict__ nxt,
+                                        float* __restrict__ wtile, const Blk& b, int tid) {
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
     const int K = op.k, N = op.n, ldw = b.ldw;
     const float* __restrict__ W = reinterpret_cast<const float*>(op.p0) + b.h * op.s0;
     const float* __restrict__ bias = op.p1 ? reinterpret_cast<const float*>(op.p1) + b.h * op.s1 : nullptr;
-    const bool bt = (op.flags & RIH_CHF_BT) != 0, outg = (op.flags & RIH_CHF_OUT_GLOBAL) != 0;
-    const bool relu = (op.flags & RIH_CHF_RELU) != 0;
-    const int nrb = b.R >> 5, ncb = (N + 31) >> 5, nblk = nrb * ncb;
+    const bool outg = (op.flags & RIH_CHF_OUT_GLOBAL) != 0, relu = (op.flags & RIH_CHF_RELU) != 0;
+    const int ncb = N >> 5, nchunk = K / KC;
+    float* __restrict__ wt = wtile + wave * (32 * (KC + 4));
     float* __restrict__ dst = outg ? reinterpret_cast<float*>(op.p2) + b.rowbase * op.ld : nullptr;
-    for (int base = 0; base < nblk; base += 4 * MAXB) {
-        floatx16 acc[MAXB];
+    // A rows of this lane: LDS rows l31 (+32), or -- AG -- global rows (those behind the block's last one re-read it: finite
+    // values that nothing stores)
+    const float* a0 = cur + l31 * ldw + 4 * lhi;
+    long long astep = 32 * ldw;
+    if (AG) {
+        const float* A = reinterpret_cast<const float*>(op.p3) + 4 * lhi;
+        const int r0 = min(l31, b.nrows - 1), r1 = min(32 + l31, b.nrows - 1);
+        a0 = A + (b.rowbase + r0) * (long long)op.lda;
+        astep = (long long)(r1 - r0) * op.lda;
+    }
+    float4 q[32 * KC / 256];
+    if (wave < ncb) wt_issue<BT, KC>(q, W, K, N, wave * 32, 0, lane);
+    for (int cb = wave; cb < ncb; cb += 4) {
+        floatx16 acc[NRB];
 #pragma unroll
-        for (int i = 0; i < MAXB; ++i) {
+        for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-            const int blk = base + wave + 4 * i;                // wave-uniform
-            if (blk >= nblk) continue;
-            const int rb = blk % nrb, cb = blk / nrb;
-            const int col = cb * 32 + l31;
-            const bool cok = col < N;
-            const float* arow = cur + (rb * 32 + l31) * ldw + 4 * lhi;
-            if (AG) {       // rows behind the block's last one re-read it (finite values that nothing stores)
-                const int ar = min(rb * 32 + l31, b.nrows - 1);
-                arow = reinterpret_cast<const float*>(op.p3) + (b.rowbase + ar) * (long long)op.lda + 4 * lhi;
-            }
-            for (int k0 = 0; k0 < K; k0 += 128) {
-                const int nj = min(16, (K - k0) >> 3);
-                float4 bq[16];
-                float4 aq[AG ? 16 : 1];
-                if (AG) {
+            for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            wt_commit<BT, KC>(q, wt, lane);
+            __builtin_amdgcn_wave_barrier();        // (the tile is read by other lanes of this wavefront than wrote it)
+            if (ch + 1 < nchunk) wt_issue<BT, KC>(q, W, K, N, cb * 32, (ch + 1) * KC, lane);
+            else if (cb + 4 < ncb) wt_issue<BT, KC>(q, W, K, N, (cb + 4) * 32, 0, lane);
 #pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (j < nj) aq[AG ? j : 0] = *reinterpret_cast<const float4*>(arow + k0 + 8 * j);
+            for (int j = 0; j < KC / 8; ++j) {
+                float4 bv;
+                if (!BT) {
+                    bv = *reinterpret_cast<const float4*>(wt + l31 * (KC + 4) + 8 * j + 4 * lhi);
+                } else {
+                    const float* wp = wt + (8 * j + 4 * lhi) * 32 + l31;
+                    bv = make_float4(wp[0], wp[32], wp[64], wp[96]);
                 }
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    bq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (j < nj && cok) {
-                        const int kk = k0 + 8 * j + 4 * lhi;
-                        if (!bt) {
-                            bq[j] = *reinterpret_cast<const float4*>(W + (long long)col * K + kk);
-                        } else {
-                            const float* wp = W + (long long)kk * N + col;
-                            bq[j] = make_float4(wp[0], wp[N], wp[2 * (long long)N], wp[3 * (long long)N]);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    if (j < nj) {
-                        const float4 a = AG ? aq[AG ? j : 0] : *reinterpret_cast<const float4*>(arow + k0 + 8 * j);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[j].x, acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[j].y, acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[j].z, acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[j].w, acc[i], 0, 0, 0);
-                    }
+                for (int rb = 0; rb < NRB; ++rb) {
+                    const float4 a = *reinterpret_cast<const float4*>(a0 + rb * astep + ch * KC + 8 * j);
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv.x, acc[rb], 0, 0, 0);
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv.y, acc[rb], 0, 0, 0);
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv.z, acc[rb], 0, 0, 0);
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, acc[rb], 0, 0, 0);
                 }
             }
         }
-        if (!outg) __syncthreads();         // every wavefront has read its A rows: `cur` may be overwritten (single pass)
+        const int col = cb * 32 + l31;
+        const float bvs = bias ? bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXB; ++i) {
-            const int blk = base + wave + 4 * i;
-            if (blk >= nblk) continue;
-            const int rb = blk % nrb, cb = blk / nrb;
-            const int col = cb * 32 + l31;
-            if (col >= N) continue;
-            const float bv = bias ? bias[col] : 0.f;
+        for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rb * 32 + acc_row(r, lhi);
-                float v = acc[i][r] + bv;
+                float v = acc[rb][r] + bvs;
                 if (relu) v = fmaxf(v, 0.f);
                 if (outg) {
                     if (row < b.nrows) dst[(long long)row * op.ld + col] = v;
                 } else {
-                    cur[row * ldw + col] = v;
+                    nxt[row * ldw + col] = v;
                 }
             }
-        }
     }
 }
 
@@ -235,12 +248,16 @@ __device__ __forceinline__ void ch_ln_bwd(const rih_chain_op& op, float* __restr
     }
 }
 
-template <int CUR_F, int KEPT_F>
-__global__ __launch_bounds__(TPB) void chain_kernel(const rih_chain_desc d) {
+template <int CUR_F, int KEPT_F, int KC>
+__global__ __launch_bounds__(TPB, (CUR_F <= CAP_SMALL ? 2 : 1)) void chain_kernel(const rih_chain_desc d) {
     __shared__ float4 cur4[CUR_F / 4];
+    __shared__ float4 nxt4[CUR_F / 4];
     __shared__ float4 kept4[(KEPT_F > 0 ? KEPT_F : 4) / 4];
     __shared__ float stat[128];
+    __shared__ float4 wtile4[4 * 32 * (KC + 4) / 4];
+    float* wtile = reinterpret_cast<float*>(wtile4);
     float* cur = reinterpret_cast<float*>(cur4);
+    float* nxt = reinterpret_cast<float*>(nxt4);
     float* kept = reinterpret_cast<float*>(kept4);
     const int tid = threadIdx.x;
     Blk b;
@@ -313,8 +330,20 @@ __global__ __launch_bounds__(TPB) void chain_kernel(const rih_chain_desc d) {
             break;
         }
         case RIH_CH_GEMM:
-            if (op.flags & RIH_CHF_A_GLOBAL) ch_gemm<true>(op, cur, b, tid);
-            else ch_gemm<false>(op, cur, b, tid);
+            if (b.R == 32) {
+                if (op.flags & RIH_CHF_A_GLOBAL) ch_gemm<true, true, 1, KC>(op, cur, nxt, wtile, b, tid);
+                else if (op.flags & RIH_CHF_BT) ch_gemm<false, true, 1, KC>(op, cur, nxt, wtile, b, tid);
+                else ch_gemm<false, false, 1, KC>(op, cur, nxt, wtile, b, tid);
+            } else {
+                if (op.flags & RIH_CHF_A_GLOBAL) ch_gemm<true, true, 2, KC>(op, cur, nxt, wtile, b, tid);
+                else if (op.flags & RIH_CHF_BT) ch_gemm<false, true, 2, KC>(op, cur, nxt, wtile, b, tid);
+                else ch_gemm<false, false, 2, KC>(op, cur, nxt, wtile, b, tid);
+            }
+            if (!(op.flags & RIH_CHF_OUT_GLOBAL)) {     // the result is the new running activation
+                float* t = cur;
+                cur = nxt;
+                nxt = t;
+            }
             if (!(op.flags & RIH_CHF_OUT_GLOBAL)) width = op.n;
             break;
         case RIH_CH_DROPOUT: {
@@ -398,6 +427,7 @@ static int chain_check(const rih_chain_desc& d, bool* keeps_out) {
             break;
         case RIH_CH_GEMM: {
             if (op.flags & RIH_CHF_A_GLOBAL) {
+                if (!(op.flags & RIH_CHF_BT)) CH_BAD(3);       // (only the data-gradient form exists)
                 if (!op.p3 || !al16(op.p3)) CH_BAD(1);
                 if (op.lda < op.k || op.lda % 4 != 0) CH_BAD(2);
             } else {
@@ -405,13 +435,11 @@ static int chain_check(const rih_chain_desc& d, bool* keeps_out) {
                 if (op.k != width) CH_BAD(2);
             }
             if (!op.p0 || !al16(op.p0) || op.s0 % 4 != 0) CH_BAD(1);
-            if (op.k % 8 != 0 || op.n < 4 || op.n % 4 != 0) CH_BAD(2);
-            const int blocks = (d.rblk / 32) * ((op.n + 31) / 32);
+            if (op.k % 64 != 0 || op.n < 32 || op.n % 32 != 0) CH_BAD(2);
             if (op.flags & RIH_CHF_OUT_GLOBAL) {
                 if (!op.p2) CH_BAD(1);
                 if (op.ld < op.n) CH_BAD(2);
             } else {
-                if (blocks > 4 * MAXB) CH_BAD(4);       // a single pass: the result overwrites the operand
                 width = op.n;
             }
             break;
@@ -438,7 +466,7 @@ static int chain_check(const rih_chain_desc& d, bool* keeps_out) {
     }
 #undef CH_BAD
     const int need = d.rblk * d.ldw;
-    if (need > (keeps ? CAP_PAIR : CAP_SOLO)) return -4;
+    if (need > CAP_BIG) return -4;
     *keeps_out = keeps;
     return 0;
 }
@@ -460,14 +488,13 @@ extern "C" int rih_chain(const rih_chain_desc* desc, void* stream) {
     const int need = d.rblk * d.ldw;
     const dim3 grid((d.rows + d.rblk - 1) / d.rblk, d.nhands), block(TPB);
     hipStream_t s = (hipStream_t)stream;
+    // small blocks: 32-deep weight chunks (18 KB of tiles) keep two workgroups on a CU; big ones 64-deep
     if (!keeps) {
-        if (need <= CAP_SMALL) hipLaunchKernelGGL((chain_kernel<CAP_SMALL, 0>), grid, block, 0, s, d);
-        else if (need <= CAP_SOLO) hipLaunchKernelGGL((chain_kernel<CAP_SOLO, 0>), grid, block, 0, s, d);
-        else return RIH_EINVAL;
+        if (need <= CAP_SMALL) hipLaunchKernelGGL((chain_kernel<CAP_SMALL, 0, 32>), grid, block, 0, s, d);
+        else hipLaunchKernelGGL((chain_kernel<CAP_BIG, 0, 64>), grid, block, 0, s, d);
     } else {
-        if (need <= CAP_SMALL) hipLaunchKernelGGL((chain_kernel<CAP_SMALL, CAP_SMALL>), grid, block, 0, s, d);
-        else if (need <= CAP_PAIR) hipLaunchKernelGGL((chain_kernel<CAP_PAIR, CAP_PAIR>), grid, block, 0, s, d);
-        else return RIH_EINVAL;
+        if (need <= CAP_SMALL) hipLaunchKernelGGL((chain_kernel<CAP_SMALL, CAP_SMALL, 32>), grid, block, 0, s, d);
+        else hipLaunchKernelGGL((chain_kernel<CAP_BIG, CAP_BIG, 64>), grid, block, 0, s, d);
     }
     return (int)hipGetLastError();
 }

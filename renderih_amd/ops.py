@@ -1896,8 +1896,7 @@ class ChainProgram:
     @staticmethod
     def pick_rblk(rows, nhands, maxw, keeps, lds_n):
         """64-row blocks halve the weight traffic per row but need >= 2 workgroups per CU to be worth it."""
-        cap = 8448 if keeps else 12416
-        ok64 = 64 * (maxw + 4) <= cap and 2 * _cdiv(max(lds_n, 1), 32) <= 12
+        ok64 = 64 * (maxw + 4) <= 8448
         if CHAIN_RBLK in (32, 64):
             return CHAIN_RBLK if (CHAIN_RBLK == 32 or ok64) else 32
         return 64 if (ok64 and nhands * _cdiv(rows, 64) >= 512) else 32
@@ -1918,8 +1917,9 @@ class ChainProgram:
 
 
 def chain_ok(*dims):
-    """Widths a chain accepts: multiples of 8 (they are reduction lengths too), at most 256 as an LDS-resident activation."""
-    return CHAIN and all(d % 8 == 0 and 8 <= d <= 256 for d in dims)
+    """Widths a chain accepts: multiples of 64 (they are reduction lengths, streamed in 64-deep chunks, and output widths, made
+    of 32-column blocks), at most 256 as an LDS-resident activation."""
+    return CHAIN and all(d % 64 == 0 and 64 <= d <= 256 for d in dims)
 
 
 def _ln_partials_finish(ws, nblk, D, nh, dg, db):

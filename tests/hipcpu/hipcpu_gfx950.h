@@ -68,6 +68,9 @@ static inline hipcpu_f32x16 hipcpu_mfma_32x32x16_bf16(hipcpu_bf16x8 a, hipcpu_bf
     return c;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipcpu_mfma_32x32x2_f32((a), (b), (c))
+// scheduling barrier of a wavefront (no instruction on the hardware, where the lanes run in lock-step): here the point at which
+// every fiber of the wavefront has caught up -- LDS written by one lane and read by another needs it
+#define __builtin_amdgcn_wave_barrier() hipcpu::wave_barrier()
 // v_mfma_f32_16x16x4_f32: A (16 x 4): lane l holds row l%16, k = l/16; B (4 x 16): lane l holds column l%16, k = l/16;
 // C/D (16 x 16 fp32, 4 per lane): register r of lane l = row 4*(l>>4) + r, column l&15.  A k-ordered fmaf chain like the hardware.
 typedef float hipcpu_f32x4 __attribute__((ext_vector_type(4)));

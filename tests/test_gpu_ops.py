@@ -965,8 +965,9 @@ def _torch_attention_block(mods, x, heads, cross):
 
 
 @pytest.mark.parametrize('B,S,D,heads,p,cross', [(2, 63, 128, 4, 0.0, False), (1, 40, 64, 4, 0.1, False),
-                                                 (3, 33, 32, 2, 0.05, False), (2, 63, 128, 4, 0.0, True),
-                                                 (1, 70, 64, 4, 0.1, True), (1, 45, 256, 4, 0.1, False)])
+                                                 (3, 33, 64, 2, 0.05, False), (2, 63, 128, 4, 0.0, True),
+                                                 (1, 70, 64, 4, 0.1, True), (1, 45, 256, 4, 0.1, False),
+                                                 (9, 126, 128, 4, 0.1, False)])
 def test_attention_block_chains(B, S, D, heads, p, cross):
     """rih_chain (LayerNorm -> QKV projection; output projection -> dropout -> skip -> LayerNorm -> fc1 + ReLU -> dropout ->
     fc2 -> dropout -> skip, one launch each, both directions) against the standalone launch sequence it replaces with the SAME
@@ -974,6 +975,7 @@ def test_attention_block_chains(B, S, D, heads, p, cross):
     that are not multiples of the 32-row block, per-hand and hand-shared projections."""
     from renderih_amd import attn, ops
     d = dev()
+    assert ops.chain_ok(D), 'the case must take the chain path'
     torch.manual_seed(5)
     if cross:
         mod = attn.inter_attn(D, n_heads=heads, dropout=p)
