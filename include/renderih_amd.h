@@ -507,7 +507,12 @@ int rih_flash_attention_bwd(const float* dO, int do_ld, const float* O, int o_ld
  *                    gradient).  With RIH_CHF_OUT_GLOBAL the result goes to p2 rows (pitch ld) instead of `cur` (n is then not
  *                    limited by the LDS block; cur keeps its value).  With RIH_CHF_A_GLOBAL the left operand is read from
  *                    p3 rows (pitch `lda`) instead of `cur` (k is then not limited by the block either: the QKV data gradient,
- *                    k = 3 D; data-gradient form only).  k % 64 == 0, n % 32 == 0.
+ *                    k = 3 D; data-gradient form only).  k % 64 == 0, n % 32 == 0.  Fused epilogue of a product that stays in
+ *                    the block, applied in this order to v = acc + bias (ReLU): RIH_CHF_EPI_MASKNZ v = (p4 rows (pitch lde)
+ *                    != 0) ? v * f1 : 0; RIH_CHF_EPI_DROPOUT as RIH_CH_DROPOUT (f0, seed) on the [nhands][rows][n] result;
+ *                    RIH_CHF_EPI_ADD v += p4 rows (pitch lde; not together with MASKNZ); RIH_CHF_EPI_ADD_KEPT v += kept;
+ *                    RIH_CHF_EPI_STORE p2 rows (pitch ld) = v; RIH_CHF_EPI_KEEP kept = v.  (Each is what the separate operator
+ *                    does; fused, its memory operand is requested before the product starts instead of after it.)
  *   RIH_CH_DROPOUT   cur = keep ? cur / (1 - f0) : 0, element (h, r, c) of the [nhands][rows][width] tensor kept iff
  *                    hash(seed (+ *seed_dev), ((h*rows + r)*width + c)) >= f0 * 2^32 -- the mask of rih_add_dropout /
  *                    rih_dropout_bwd on the same tensor, bit for bit
@@ -527,9 +532,15 @@ enum {
 #define RIH_CHF_BT 2
 #define RIH_CHF_OUT_GLOBAL 4
 #define RIH_CHF_A_GLOBAL 8
+#define RIH_CHF_EPI_DROPOUT 16
+#define RIH_CHF_EPI_ADD 32
+#define RIH_CHF_EPI_ADD_KEPT 64
+#define RIH_CHF_EPI_STORE 128
+#define RIH_CHF_EPI_KEEP 256
+#define RIH_CHF_EPI_MASKNZ 512
 typedef struct rih_chain_op {
     int32_t kind, flags, n, k;
-    int32_t ld, lda;
+    int32_t ld, lda, lde, reserved;
     float f0, f1;
     uint64_t seed;
     const void* p0;

@@ -50,7 +50,7 @@ class LnFinalDesc(C.Structure):
 
 class ChainOp(C.Structure):
     _fields_ = [('kind', C.c_int32), ('flags', C.c_int32), ('n', C.c_int32), ('k', C.c_int32),
-                ('ld', C.c_int32), ('lda', C.c_int32), ('f0', C.c_float), ('f1', C.c_float), ('seed', C.c_uint64),
+                ('ld', C.c_int32), ('lda', C.c_int32), ('lde', C.c_int32), ('reserved', C.c_int32), ('f0', C.c_float), ('f1', C.c_float), ('seed', C.c_uint64),
                 ('p0', C.c_void_p), ('p1', C.c_void_p), ('p2', C.c_void_p), ('p3', C.c_void_p), ('p4', C.c_void_p),
                 ('s0', C.c_int64), ('s1', C.c_int64), ('s2', C.c_int64), ('s3', C.c_int64), ('s4', C.c_int64)]
 

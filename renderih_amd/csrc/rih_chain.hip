@@ -28,6 +28,7 @@
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));    // (register arrays of HIP's float4 -- a struct of unions -- end up in scratch memory)
 constexpr int TPB = 256;
 constexpr int CAP_BIG = 8448;     // floats of `cur` (and of `kept`): 64 rows x (128 + 4); 32 rows x (256 + 4) fits too
 constexpr int CAP_SMALL = 4224;   // 32 rows x (128 + 4): two workgroups per CU next to the weight tiles
@@ -56,25 +57,18 @@ struct Blk {
 //   BT weight ([k][n], the data gradient):     tile [KC][32 columns], 16-byte writes, four 4-byte operand reads per group.
 // The result goes to the block's OTHER activation buffer (the caller swaps the two), so a finished column block leaves the
 // registers at once and the loop body exists once.  AG: the A operand comes from global rows p3 (pitch lda) instead of `cur`.
-template <bool BT, int KC>
-__device__ __forceinline__ void wt_issue(float4 (&q)[32 * KC / 256], const float* __restrict__ W, int K, int N, int n0, int k0,
-                                         int lane) {
-#pragma unroll
-    for (int i = 0; i < 32 * KC / 256; ++i) {       // (n % 32 == 0 and k % KC == 0: every tile is full)
-        const int idx = lane + 64 * i;
-        if (!BT) q[i] = *reinterpret_cast<const float4*>(W + (long long)(n0 + idx / (KC / 4)) * K + k0 + 4 * (idx % (KC / 4)));
-        else q[i] = *reinterpret_cast<const float4*>(W + (long long)(k0 + (idx >> 3)) * N + n0 + 4 * (idx & 7));
+#define WT_ISSUE(n0_, k0_)                                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < NV; ++i_) {      /* n % 32 == 0 and k % KC == 0: every tile is full */       \
+        const int idx_ = lane + 64 * i_;                                                                                \
+        if (!BT) q[i_] = *reinterpret_cast<const f4*>(W + (long long)((n0_) + idx_ / (KC / 4)) * K + (k0_) + 4 * (idx_ % (KC / 4))); \
+        else q[i_] = *reinterpret_cast<const f4*>(W + (long long)((k0_) + (idx_ >> 3)) * N + (n0_) + 4 * (idx_ & 7)); \
     }
-}
-template <bool BT, int KC>
-__device__ __forceinline__ void wt_commit(const float4 (&q)[32 * KC / 256], float* __restrict__ wt, int lane) {
-#pragma unroll
-    for (int i = 0; i < 32 * KC / 256; ++i) {
-        const int idx = lane + 64 * i;
-        if (!BT) *reinterpret_cast<float4*>(wt + (idx / (KC / 4)) * (KC + 4) + 4 * (idx % (KC / 4))) = q[i];
-        else *reinterpret_cast<float4*>(wt + 4 * idx) = q[i];       // [kr][32]: idx = kr * 8 + column quad
+#define WT_COMMIT()                                                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < NV; ++i_) {                                                                 \
+        const int idx_ = lane + 64 * i_;                                                                                \
+        if (!BT) *reinterpret_cast<f4*>(wt + (idx_ / (KC / 4)) * (KC + 4) + 4 * (idx_ % (KC / 4))) = q[i_];          \
+        else *reinterpret_cast<f4*>(wt + 4 * idx_) = q[i_];       /* [kr][32]: idx = kr * 8 + column quad */         \
     }
-}
 
 template <bool AG, bool BT, int NRB, int KC>
 __device__ __forceinline__ void ch_gemm(const rih_chain_op& op, const float* __restrict__ cur, float* __restrict__ nxt,
@@ -97,19 +91,30 @@ __device__ __forceinline__ void ch_gemm(const rih_chain_op& op, const float* __r
         a0 = A + (b.rowbase + r0) * (long long)op.lda;
         astep = (long long)(r1 - r0) * op.lda;
     }
-    float4 q[32 * KC / 256];
-    if (wave < ncb) wt_issue<BT, KC>(q, W, K, N, wave * 32, 0, lane);
+    // Every workgroup streams the same weight: started at the same chunk, the CUs of an XCD would all ask the same few L2
+    // channels for the same lines at the same time (rows of a power-of-two pitch: a 32 x KC tile lives in 4 of 16 channels --
+    // measured 1.3 TB/s of weight traffic for the whole chip).  Each workgroup therefore walks the chunks of a column block
+    // from its own starting point (the k order of a row's sum depends on its block index, not on the run).
+    const int rot = (int)(blockIdx.x + blockIdx.y) % nchunk;
+    constexpr int NV = 32 * KC / 256;       // 16-byte requests per lane and chunk
+    f4 q[NV];
+    if (wave < ncb) WT_ISSUE(wave * 32, rot * KC)
     for (int cb = wave; cb < ncb; cb += 4) {
         floatx16 acc[NRB];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+        int kc = rot;                               // chunk being multiplied
         for (int ch = 0; ch < nchunk; ++ch) {
-            wt_commit<BT, KC>(q, wt, lane);
+            WT_COMMIT()
             __builtin_amdgcn_wave_barrier();        // (the tile is read by other lanes of this wavefront than wrote it)
-            if (ch + 1 < nchunk) wt_issue<BT, KC>(q, W, K, N, cb * 32, (ch + 1) * KC, lane);
-            else if (cb + 4 < ncb) wt_issue<BT, KC>(q, W, K, N, (cb + 4) * 32, 0, lane);
+            const int kn = (kc + 1 == nchunk) ? 0 : kc + 1;
+            if (ch + 1 < nchunk) {
+                WT_ISSUE(cb * 32, kn * KC)
+            } else if (cb + 4 < ncb) {
+                WT_ISSUE((cb + 4) * 32, rot * KC)
+            }
 #pragma unroll
             for (int j = 0; j < KC / 8; ++j) {
                 float4 bv;
@@ -121,13 +126,14 @@ __device__ __forceinline__ void ch_gemm(const rih_chain_op& op, const float* __r
                 }
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
-                    const float4 a = *reinterpret_cast<const float4*>(a0 + rb * astep + ch * KC + 8 * j);
+                    const float4 a = *reinterpret_cast<const float4*>(a0 + rb * astep + kc * KC + 8 * j);
                     acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv.x, acc[rb], 0, 0, 0);
                     acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv.y, acc[rb], 0, 0, 0);
                     acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv.z, acc[rb], 0, 0, 0);
                     acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, acc[rb], 0, 0, 0);
                 }
             }
+            kc = kn;
         }
         const int col = cb * 32 + l31;
         const float bvs = bias ? bias[col] : 0.f;
@@ -146,6 +152,9 @@ __device__ __forceinline__ void ch_gemm(const rih_chain_op& op, const float* __r
             }
     }
 }
+
+#undef WT_ISSUE
+#undef WT_COMMIT
 
 // ---- LayerNorm forward on the block: T = 256 / R lanes per row -----------------------------------------------------------------
 __device__ __forceinline__ float group_sum(float v, int T) {
@@ -248,7 +257,7 @@ __device__ __forceinline__ void ch_ln_bwd(const rih_chain_op& op, float* __restr
     }
 }
 
-template <int CUR_F, int KEPT_F, int KC>
+template <int CUR_F, int KEPT_F, int KC, int NRB>
 __global__ __launch_bounds__(TPB, (CUR_F <= CAP_SMALL ? 2 : 1)) void chain_kernel(const rih_chain_desc d) {
     __shared__ float4 cur4[CUR_F / 4];
     __shared__ float4 nxt4[CUR_F / 4];
@@ -329,15 +338,58 @@ __global__ __launch_bounds__(TPB, (CUR_F <= CAP_SMALL ? 2 : 1)) void chain_kerne
             }
             break;
         }
-        case RIH_CH_GEMM:
-            if (b.R == 32) {
-                if (op.flags & RIH_CHF_A_GLOBAL) ch_gemm<true, true, 1, KC>(op, cur, nxt, wtile, b, tid);
-                else if (op.flags & RIH_CHF_BT) ch_gemm<false, true, 1, KC>(op, cur, nxt, wtile, b, tid);
-                else ch_gemm<false, false, 1, KC>(op, cur, nxt, wtile, b, tid);
-            } else {
-                if (op.flags & RIH_CHF_A_GLOBAL) ch_gemm<true, true, 2, KC>(op, cur, nxt, wtile, b, tid);
-                else if (op.flags & RIH_CHF_BT) ch_gemm<false, true, 2, KC>(op, cur, nxt, wtile, b, tid);
-                else ch_gemm<false, false, 2, KC>(op, cur, nxt, wtile, b, tid);
+        case RIH_CH_GEMM: {
+            // the fused epilogue's memory operand (residual rows / the mask's saved activation) is requested BEFORE the product
+            // and consumed after it: its round trip hides behind the arithmetic
+            constexpr int PF = 8;               // 16-byte items per thread: rblk * n / 4 / 256 <= 8
+            const bool epi = (op.flags & (RIH_CHF_EPI_DROPOUT | RIH_CHF_EPI_ADD | RIH_CHF_EPI_ADD_KEPT | RIH_CHF_EPI_STORE |
+                                          RIH_CHF_EPI_KEEP | RIH_CHF_EPI_MASKNZ)) != 0;
+            const bool eload = (op.flags & (RIH_CHF_EPI_ADD | RIH_CHF_EPI_MASKNZ)) != 0;
+            const int n4 = op.n >> 2;
+            f4 pf[PF];
+            if (eload) {
+                const float* src = reinterpret_cast<const float*>(op.p4) + b.rowbase * op.lde;
+#pragma unroll
+                for (int t = 0; t < PF; ++t) {
+                    const int idx = tid + TPB * t, r = idx / n4, c = (idx - r * n4) << 2;
+                    pf[t] = f4{0.f, 0.f, 0.f, 0.f};
+                    if (idx < b.R * n4 && r < b.nrows) pf[t] = *reinterpret_cast<const f4*>(src + (long long)r * op.lde + c);
+                }
+            }
+            if (op.flags & RIH_CHF_A_GLOBAL) ch_gemm<true, true, NRB, KC>(op, cur, nxt, wtile, b, tid);
+            else if (op.flags & RIH_CHF_BT) ch_gemm<false, true, NRB, KC>(op, cur, nxt, wtile, b, tid);
+            else ch_gemm<false, false, NRB, KC>(op, cur, nxt, wtile, b, tid);
+            if (epi) {
+                __syncthreads();
+                const uint32_t key = rih_seed_key(op.seed + seed_add), thr = ch_thresh(op.f0);
+                const float ks = 1.f / (1.f - op.f0);
+                float* dst = (op.flags & RIH_CHF_EPI_STORE) ? reinterpret_cast<float*>(op.p2) + b.rowbase * op.ld : nullptr;
+#pragma unroll
+                for (int t = 0; t < PF; ++t) {
+                    const int idx = tid + TPB * t, r = idx / n4, c = (idx - r * n4) << 2;
+                    if (idx < b.R * n4) {
+                        f4* pn = reinterpret_cast<f4*>(nxt + r * b.ldw + c);
+                        f4 v = *pn;
+                        if (op.flags & RIH_CHF_EPI_MASKNZ) {
+                            v.x = pf[t].x != 0.f ? v.x * op.f1 : 0.f;
+                            v.y = pf[t].y != 0.f ? v.y * op.f1 : 0.f;
+                            v.z = pf[t].z != 0.f ? v.z * op.f1 : 0.f;
+                            v.w = pf[t].w != 0.f ? v.w * op.f1 : 0.f;
+                        }
+                        if (op.flags & RIH_CHF_EPI_DROPOUT) {
+                            const uint64_t e = (uint64_t)(b.rowbase + r) * (uint64_t)op.n + (uint64_t)c;
+                            v.x = rih_hash_k64(key, e) >= thr ? v.x * ks : 0.f;
+                            v.y = rih_hash_k64(key, e + 1) >= thr ? v.y * ks : 0.f;
+                            v.z = rih_hash_k64(key, e + 2) >= thr ? v.z * ks : 0.f;
+                            v.w = rih_hash_k64(key, e + 3) >= thr ? v.w * ks : 0.f;
+                        }
+                        if (op.flags & RIH_CHF_EPI_ADD) v += pf[t];
+                        if (op.flags & RIH_CHF_EPI_ADD_KEPT) v += *reinterpret_cast<const f4*>(kept + r * b.ldw + c);
+                        if (dst != nullptr && r < b.nrows) *reinterpret_cast<f4*>(dst + (long long)r * op.ld + c) = v;
+                        if (op.flags & RIH_CHF_EPI_KEEP) *reinterpret_cast<f4*>(kept + r * b.ldw + c) = v;
+                        *pn = v;
+                    }
+                }
             }
             if (!(op.flags & RIH_CHF_OUT_GLOBAL)) {     // the result is the new running activation
                 float* t = cur;
@@ -346,6 +398,7 @@ __global__ __launch_bounds__(TPB, (CUR_F <= CAP_SMALL ? 2 : 1)) void chain_kerne
             }
             if (!(op.flags & RIH_CHF_OUT_GLOBAL)) width = op.n;
             break;
+        }
         case RIH_CH_DROPOUT: {
             const int w4 = width >> 2;
             const uint32_t key = rih_seed_key(op.seed + seed_add), thr = ch_thresh(op.f0);
@@ -439,7 +492,22 @@ static int chain_check(const rih_chain_desc& d, bool* keeps_out) {
             if (op.flags & RIH_CHF_OUT_GLOBAL) {
                 if (!op.p2) CH_BAD(1);
                 if (op.ld < op.n) CH_BAD(2);
+                if (op.flags & (RIH_CHF_EPI_DROPOUT | RIH_CHF_EPI_ADD | RIH_CHF_EPI_ADD_KEPT | RIH_CHF_EPI_STORE | RIH_CHF_EPI_KEEP |
+                                RIH_CHF_EPI_MASKNZ))
+                    CH_BAD(3);
             } else {
+                if ((op.flags & RIH_CHF_EPI_ADD) && (op.flags & RIH_CHF_EPI_MASKNZ)) CH_BAD(3);
+                if (op.flags & (RIH_CHF_EPI_ADD | RIH_CHF_EPI_MASKNZ)) {
+                    if (!op.p4) CH_BAD(1);
+                    if (op.lde < op.n) CH_BAD(2);
+                }
+                if (op.flags & RIH_CHF_EPI_STORE) {
+                    if (!op.p2) CH_BAD(1);
+                    if (op.ld < op.n) CH_BAD(2);
+                }
+                if ((op.flags & RIH_CHF_EPI_DROPOUT) && !(op.f0 >= 0.f && op.f0 < 1.f)) CH_BAD(2);
+                if ((op.flags & RIH_CHF_EPI_ADD_KEPT) && !keeps) CH_BAD(3);
+                if (op.flags & RIH_CHF_EPI_KEEP) keeps = true;
                 width = op.n;
             }
             break;
@@ -489,12 +557,18 @@ extern "C" int rih_chain(const rih_chain_desc* desc, void* stream) {
     const dim3 grid((d.rows + d.rblk - 1) / d.rblk, d.nhands), block(TPB);
     hipStream_t s = (hipStream_t)stream;
     // small blocks: 32-deep weight chunks (18 KB of tiles) keep two workgroups on a CU; big ones 64-deep
-    if (!keeps) {
-        if (need <= CAP_SMALL) hipLaunchKernelGGL((chain_kernel<CAP_SMALL, 0, 32>), grid, block, 0, s, d);
-        else hipLaunchKernelGGL((chain_kernel<CAP_BIG, 0, 64>), grid, block, 0, s, d);
-    } else {
-        if (need <= CAP_SMALL) hipLaunchKernelGGL((chain_kernel<CAP_SMALL, CAP_SMALL, 32>), grid, block, 0, s, d);
-        else hipLaunchKernelGGL((chain_kernel<CAP_BIG, CAP_BIG, 64>), grid, block, 0, s, d);
+#define RIH_CHAIN_LAUNCH(C_, K_, KC_)                                                                     \
+    {                                                                                                    \
+        if (d.rblk == 32) hipLaunchKernelGGL((chain_kernel<C_, K_, KC_, 1>), grid, block, 0, s, d);       \
+        else hipLaunchKernelGGL((chain_kernel<C_, K_, KC_, 2>), grid, block, 0, s, d);                    \
     }
+    if (!keeps) {
+        if (need <= CAP_SMALL) RIH_CHAIN_LAUNCH(CAP_SMALL, 0, 32)
+        else RIH_CHAIN_LAUNCH(CAP_BIG, 0, 64)
+    } else {
+        if (need <= CAP_SMALL) RIH_CHAIN_LAUNCH(CAP_SMALL, CAP_SMALL, 32)
+        else RIH_CHAIN_LAUNCH(CAP_BIG, CAP_BIG, 64)
+    }
+#undef RIH_CHAIN_LAUNCH
     return (int)hipGetLastError();
 }

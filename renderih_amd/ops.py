@@ -1803,8 +1803,15 @@ def projection_batch(scale, trans2d, v, img_size=256):
 # The row-wise sequences of an attention block -- LayerNorm -> QKV projection, and output projection -> dropout -> skip ->
 # LayerNorm -> fc1 + ReLU -> dropout -> fc2 -> dropout -> skip -- as ONE launch each way instead of 2 and 7 (9 backward).  The
 # masks are those of the standalone kernels (same seeds, same element indices), the matrix products are exact fp32.
-# RIH_CHAIN=0 keeps the standalone sequence (the A/B partner; tests/test_gpu_ops.py pins the two against each other).
-CHAIN = os.environ.get('RIH_CHAIN', '1') == '1'
+# OFF by default (RIH_CHAIN=1 turns it on): correct on MI355X (tests/test_gpu_ops.py::test_attention_block_chains pins it
+# against the standalone sequence and plain torch), but measured SLOWER in round 3 -- the nine attention blocks of a step at
+# B = 64, hipGraph replays: forward 1.49 ms against 1.33 ms, forward + backward 5.11 ms against 4.42 ms
+# (profiles/r03/chain/chain_bench_v4_fused_epilogues.log); whole step 38.5 ms against 37.4 ms with the first version.  A dependent
+# launch inside a hipGraph costs ~4.5 us; a dependent L2 round trip + barrier inside the fused kernel costs ~2 us, and the fused
+# kernel runs them with one or two workgroups per CU (LDS: three activation buffers + weight tiles) where the standalone kernels
+# spread every operator over the whole chip; at D = 256 the exact-fp32 MFMA (157 TF peak) is also slower than the six-product
+# bf16 GEMM it replaces.  Kept as a tested opt-in; DESIGN.md section 3.13 has the measurements and what would have to change.
+CHAIN = os.environ.get('RIH_CHAIN', '0') == '1'
 CHAIN_RBLK = int(os.environ.get('RIH_CHAIN_RBLK', '0'))      # 0 = by size; 32 / 64 = forced (tuning aid)
 _CH = dict(LOAD=1, STORE=2, ADD=3, KEEP=4, ADD_KEPT=5, GEMM=6, DROPOUT=7, MASKNZ=8, LN=9, LN_BWD=10)
 
@@ -1854,10 +1861,14 @@ class ChainProgram:
     def add_kept(self):
         self._op('ADD_KEPT')
 
-    def gemm(self, w, bias, n, k, sw=0, sb=0, bt=False, relu=False, out=None, a=None):
+    def gemm(self, w, bias, n, k, sw=0, sb=0, bt=False, relu=False, out=None, a=None, drop=None, add=None, add_kept=False,
+             store=None, keep=False, masknz=None):
         """a: the left operand as a tensor in memory (rows of pitch a.shape[-1]) instead of the block state -- a reduction
-        longer than the block is wide."""
+        longer than the block is wide.  drop=(p, seed) / add=tensor / add_kept / store=tensor / keep / masknz=(tensor, scale):
+        the fused epilogue (header: RIH_CHF_EPI_*), each what the separate operator does, in the header's order."""
         assert a is not None or k == self.width
+        assert out is None or not (drop or add is not None or add_kept or store is not None or keep or masknz)
+        assert add is None or masknz is None
         fl = (1 if relu else 0) | (2 if bt else 0) | (4 if out is not None else 0) | (8 if a is not None else 0)
         op = self._op('GEMM', p0=w, n=n, k=k, s0=sw, flags=fl)
         if a is not None:
@@ -1873,6 +1884,26 @@ class ChainProgram:
             self.width = n
             self.maxw = max(self.maxw, n)
             self.lds_n = max(self.lds_n, n)
+            if drop is not None and drop[0] > 0:
+                op.flags |= 16
+                op.f0, op.seed = drop
+            if add is not None:
+                op.flags |= 32
+                op.p4, op.lde = add.data_ptr(), add.shape[-1]
+                self.alive.append(add)
+            if masknz is not None:
+                op.flags |= 512
+                op.p4, op.lde, op.f1 = masknz[0].data_ptr(), masknz[0].shape[-1], masknz[1]
+                self.alive.append(masknz[0])
+            if add_kept:
+                op.flags |= 64
+            if store is not None:
+                op.flags |= 128
+                op.p2, op.ld = store.data_ptr(), store.shape[-1]
+                self.alive.append(store)
+            if keep:
+                op.flags |= 256
+                self.keeps = True
         self.flops += 2.0 * self.d.rows * self.d.nhands * n * k
 
     def dropout(self, p, seed):
@@ -1916,10 +1947,14 @@ class ChainProgram:
                   lambda: check(_L().rih_chain(C.byref(d), _stream()), 'rih_chain'))
 
 
-def chain_ok(*dims):
+def chain_dims_ok(*dims):
     """Widths a chain accepts: multiples of 64 (they are reduction lengths, streamed in 64-deep chunks, and output widths, made
     of 32-column blocks), at most 256 as an LDS-resident activation."""
-    return CHAIN and all(d % 64 == 0 and 64 <= d <= 256 for d in dims)
+    return all(d % 64 == 0 and 64 <= d <= 256 for d in dims)
+
+
+def chain_ok(*dims):
+    return CHAIN and chain_dims_ok(*dims)
 
 
 def _ln_partials_finish(ws, nblk, D, nh, dg, db):
@@ -2033,20 +2068,11 @@ class AttnTailChainFn(torch.autograd.Function):
         rstd = torch.empty_like(mean)
         pr = ChainProgram(rows, 2)
         pr.load(o, D)
-        pr.gemm(fcw, fcb, D, D, sfw, sfb)
-        pr.dropout(p, seeds[0])
-        pr.add(x)
-        pr.store(x1)
-        pr.keep()
+        pr.gemm(fcw, fcb, D, D, sfw, sfb, drop=(p, seeds[0]), add=x, store=x1, keep=True)
         pr.ln(gL, bL, _pdiff(gL, gR), _pdiff(bL, bR), eps, mean=mean, rstd=rstd)
         pr.store(y2)
-        pr.gemm(w1L, b1L, hid, D, _pdiff(w1L, w1R), _pdiff(b1L, b1R), relu=True)
-        pr.dropout(p, seeds[1])
-        pr.store(h)
-        pr.gemm(w2L, b2L, D, hid, _pdiff(w2L, w2R), _pdiff(b2L, b2R))
-        pr.dropout(p, seeds[2])
-        pr.add_kept()
-        pr.store(out)
+        pr.gemm(w1L, b1L, hid, D, _pdiff(w1L, w1R), _pdiff(b1L, b1R), relu=True, drop=(p, seeds[1]), store=h)
+        pr.gemm(w2L, b2L, D, hid, _pdiff(w2L, w2R), _pdiff(b2L, b2R), drop=(p, seeds[2]), add_kept=True, store=out)
         pr.alive.extend((gR, bR, w1R, b1R, w2R, b2R))
         pr.run()
         ctx.save_for_backward(o, x1, y2, h, mean, rstd, fcw, fcwR, gL, gR, w1L, w1R, w2L, w2R)
@@ -2070,9 +2096,7 @@ class AttnTailChainFn(torch.autograd.Function):
         if p > 0:
             pr.dropout(p, seeds[2])
             pr.store(g3)
-        pr.gemm(w2L, None, hid, D, _pdiff(w2L, w2R), 0, bt=True)
-        pr.masknz(h, 1.0 / (1.0 - p) if p > 0 else 1.0)
-        pr.store(g2)
+        pr.gemm(w2L, None, hid, D, _pdiff(w2L, w2R), 0, bt=True, masknz=(h, 1.0 / (1.0 - p) if p > 0 else 1.0), store=g2)
         pr.gemm(w1L, None, D, hid, _pdiff(w1L, w1R), 0, bt=True)
         pr.ln_bwd(x1, mean, rstd, gL, _pdiff(gL, gR))
         pr.add_kept()

@@ -1288,6 +1288,20 @@ class EmulatedLib:
                 if op.flags & 4:
                     rowsview(op.p2, op.ld, N)[...] = out
                 else:
+                    out = out.astype(np.float32)
+                    if op.flags & 512:      # EPI_MASKNZ
+                        out = np.where(rowsview(op.p4, op.lde, N) != 0, out * np.float32(op.f1), 0).astype(np.float32)
+                    if op.flags & 16:       # EPI_DROPOUT
+                        seed = (int(op.seed) + seed_add) % (1 << 64)
+                        out = (out.reshape(-1) * keep_mask(seed, H * rows * N, float(op.f0))).reshape(H, rows, N).astype(np.float32)
+                    if op.flags & 32:       # EPI_ADD
+                        out = out + rowsview(op.p4, op.lde, N)
+                    if op.flags & 64:       # EPI_ADD_KEPT
+                        out = out + kept
+                    if op.flags & 128:      # EPI_STORE
+                        rowsview(op.p2, op.ld, N)[...] = out
+                    if op.flags & 256:      # EPI_KEEP
+                        kept = out.copy()
                     cur = out.astype(np.float32)
             elif kind == 7:     # DROPOUT
                 w = cur.shape[2]

@@ -975,7 +975,7 @@ def test_attention_block_chains(B, S, D, heads, p, cross):
     that are not multiples of the 32-row block, per-hand and hand-shared projections."""
     from renderih_amd import attn, ops
     d = dev()
-    assert ops.chain_ok(D), 'the case must take the chain path'
+    assert ops.chain_dims_ok(D), 'the case must take the chain path'
     torch.manual_seed(5)
     if cross:
         mod = attn.inter_attn(D, n_heads=heads, dropout=p)
