@@ -59,9 +59,37 @@ def _ref_conv_fp64(x_nchw, w, b, stride, pad, gy):
     return y.reshape(N, Cout, Ho, Ho), dx, dw, db
 
 
-@pytest.mark.parametrize('prob', CONV_PROBLEMS)
+# (e) HRNet-W32 (BASELINE configs[3], B = 32 per GPU): every distinct convolution problem of its training forward
+#     (tools/list_conv_problems.py --model hrnet32): 3x3 stems, the 32 / 64 / 128 / 256-channel branches at 64 / 32 / 16 / 8
+#     pixels, strided fuse-layer chains, 1x1 fuse / transition / head convolutions (480-channel heads with 7 / 42 outputs)
+HRNET_B = 32
+HRNET_PROBLEMS = [
+    (256, 3, 64, 3, 2, 1, False), (128, 64, 64, 3, 2, 1, False), (64, 32, 32, 3, 1, 1, False), (64, 32, 32, 3, 2, 1, False),
+    (64, 32, 64, 3, 2, 1, False), (64, 32, 128, 1, 1, 0, False), (64, 64, 64, 1, 1, 0, False), (64, 64, 64, 3, 1, 1, False),
+    (64, 64, 256, 1, 1, 0, False), (64, 128, 256, 3, 2, 1, True), (64, 256, 32, 1, 1, 0, False), (64, 256, 32, 3, 1, 1, False),
+    (64, 256, 64, 1, 1, 0, False), (64, 256, 64, 3, 2, 1, False), (64, 256, 128, 1, 1, 0, False), (64, 256, 256, 1, 1, 0, False),
+    (64, 480, 7, 1, 1, 0, True), (64, 480, 42, 1, 1, 0, True), (64, 480, 480, 1, 1, 0, True), (32, 32, 32, 3, 2, 1, False),
+    (32, 32, 128, 3, 2, 1, False), (32, 64, 32, 1, 1, 0, False), (32, 64, 64, 3, 1, 1, False), (32, 64, 64, 3, 2, 1, False),
+    (32, 64, 128, 3, 2, 1, False), (32, 64, 256, 1, 1, 0, False), (32, 256, 64, 1, 1, 0, False), (32, 256, 256, 1, 1, 0, False),
+    (32, 256, 512, 3, 2, 1, True), (16, 32, 256, 3, 2, 1, False), (16, 64, 256, 3, 2, 1, False), (16, 128, 32, 1, 1, 0, False),
+    (16, 128, 64, 1, 1, 0, False), (16, 128, 128, 3, 1, 1, False), (16, 128, 256, 3, 2, 1, False), (16, 128, 512, 1, 1, 0, False),
+    (16, 256, 128, 1, 1, 0, False), (16, 256, 256, 1, 1, 0, False), (16, 256, 512, 1, 1, 0, False), (16, 512, 1024, 3, 2, 1, True),
+    (8, 256, 32, 1, 1, 0, False), (8, 256, 64, 1, 1, 0, False), (8, 256, 128, 1, 1, 0, False), (8, 256, 256, 1, 1, 0, False),
+    (8, 256, 256, 3, 1, 1, False), (8, 256, 1024, 1, 1, 0, False), (8, 1024, 2048, 1, 1, 0, True),
+]
+# (f) the second model family (lijun_model_graph, B = 64): the convolution problems it has beyond the list above, and the
+#     Linear problems of its decoder (rows = 64 images x tokens; tools/list_conv_problems.py --model family_b)
+FAMILY_B_CONVS = [(64, 256, 256, 1, 1, 0, False), (8, 2048, 256, 1, 1, 0, False)]
+LINEAR_PROBLEMS = [(64, 2048, 509, True), (384, 252, 778, False), (8064, 256, 768, True), (16128, 128, 384, True),
+                   (32256, 64, 192, True), (32256, 64, 3, True), (8192, 252, 1, True)]
+
+
+@pytest.mark.parametrize('prob', CONV_PROBLEMS + FAMILY_B_CONVS + [(HRNET_B,) + q for q in HRNET_PROBLEMS])
 def test_conv_problem_at_bench_batch(prob):
     from renderih_amd import ops
+    B = 64
+    if len(prob) == 8:          # (batch, ...): an HRNet-W32 problem at its own bench batch
+        B, prob = prob[0], prob[1:]
     H, Cin, Cout, k, s, p, bias = prob
     d = torch.device('cuda:0')
     g = torch.Generator(device=d).manual_seed(1000 + H + 7 * Cin + 13 * Cout + k)
@@ -84,6 +112,31 @@ def test_conv_problem_at_bench_batch(prob):
     assert_close(wg.grad, dwr, 1e-3, 1e-4, 'dw %s' % (prob,))
     if Cin != 3:
         assert_close(xg.grad.permute(0, 3, 1, 2), dxr, 1e-3, 1e-4, 'dx %s' % (prob,))
+    if bias:
+        assert_close(bg.grad, dbr, 1e-3, 1e-4, 'db %s' % (prob,))
+
+
+@pytest.mark.parametrize('prob', LINEAR_PROBLEMS)
+def test_linear_problem_at_bench_batch(prob):
+    """nn.Linear problems of the decoders at B = 64 row counts through ops.linear: output, input / weight / bias gradients
+    against fp64 matmuls."""
+    from renderih_amd import ops
+    rows, K, N, bias = prob
+    d = torch.device('cuda:0')
+    g = torch.Generator(device=d).manual_seed(2000 + rows + 7 * K + 13 * N)
+    x = torch.randn(rows, K, device=d, generator=g)
+    w = torch.randn(N, K, device=d, generator=g) / math.sqrt(K)
+    b = torch.randn(N, device=d, generator=g) if bias else None
+    gy = torch.randn(rows, N, device=d, generator=g)
+    yr = x.double() @ w.double().t() + (b.double() if bias else 0.0)
+    dxr, dwr, dbr = gy.double() @ w.double(), gy.double().t() @ x.double(), gy.double().sum(0)
+    xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    bg = b.clone().requires_grad_(True) if bias else None
+    yg = ops.linear(xg, wg, bg)
+    assert_close(yg, yr, what='y %s' % (prob,))
+    yg.backward(gy)
+    assert_close(xg.grad, dxr, 1e-3, 1e-4, 'dx %s' % (prob,))
+    assert_close(wg.grad, dwr, 1e-3, 1e-4, 'dw %s' % (prob,))
     if bias:
         assert_close(bg.grad, dbr, 1e-3, 1e-4, 'db %s' % (prob,))
 
@@ -139,3 +192,51 @@ def test_training_step_at_bench_batch_is_finite_and_deterministic():
     for k, g in grads[0].items():
         assert bool(torch.isfinite(g).all()), k
         assert torch.equal(g, grads[1][k]), 'gradient of %s differs between two identical steps' % k
+
+
+def test_parameter_gradients_at_bench_batch_vs_fp64_anchor():
+    """(d) B = 64, the timed problem sizes: forward + scalar loss + backward of the HIP path against the fp64 run of the CPU
+    oracle, on a sample of parameters that touches every kernel family at its bench-size row counts -- stem, one convolution /
+    BatchNorm per trunk layer (statistics and backward over 16384 .. 1048576 samples per channel), aux decoders, mid convs,
+    and per decoder level a Chebyshev block, attention projections, LayerNorm, embeddings, plus the output heads.  The fp64
+    gradients come from tests/golden/b64_grads.npz (tests/golden/make_b64_grads.py: ~10 minutes of CPU, so committed as a
+    fixture together with the fp32 oracle's own distance from them; tensors of more than 16384 elements are compared on a seeded
+    random sample of 16384).  What an fp32 implementation can reach here is set by the network, not by the kernel: the fp32
+    ORACLE's gradients are up to 3.6e-2 (relative l2) from its own fp64 run on the trunk weights, cosine 0.9994 -- so the bar is
+    relative to that: per tensor, relative l2 distance from fp64 within 4 x the fp32 oracle's (floor 1e-4) and 1 - cosine
+    within 4 x the fp32 oracle's (floor 1e-6)."""
+    import os
+    import numpy as np
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'b64_grads.npz'))
+    seed_state, seed_img, bsz = (int(v) for v in fx['meta/seeds'])
+    assert bsz == B
+    from oracle import net_oracle
+    m, _ = _build(0.0, seed=seed_state)
+    m.train()
+    img = testing.seeded_image(B, seed_img).cuda()
+    net_oracle.scalar_loss(m(img)).backward()
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    names = [k[4:] for k in fx.files if k.startswith('g64/')]
+    assert len(names) >= 50
+    worst = (0.0, '')
+    for k in names:
+        assert k in grads, 'no gradient for %s' % k
+        g = grads[k].double().flatten().cpu()
+        assert bool(torch.isfinite(g).all()) and tuple(grads[k].shape) == tuple(int(v) for v in fx['shape/' + k]), k
+        r = torch.from_numpy(fx['g64/' + k]).double().flatten()
+        if g.numel() > r.numel():
+            import zlib
+            idx = np.sort(np.random.RandomState(zlib.crc32(k.encode()) & 0x7FFFFFFF).choice(g.numel(), r.numel(), replace=False))
+            g = g[torch.from_numpy(idx)]
+        cos = float(torch.dot(g, r) / (g.norm() * r.norm()).clamp_min(1e-300))
+        e = float((g - r).norm() / r.norm().clamp_min(1e-300))
+        e32 = float(fx['e32/' + k])
+        if testing.is_null_gradient(k):
+            continue
+        c32 = float(fx['c32/' + k])
+        assert 1.0 - cos <= 4.0 * (1.0 - c32) + 1e-6, '%s: cosine %.7f with the fp64 gradient (fp32 oracle: %.7f)' % (k, cos, c32)
+        assert e <= 4.0 * e32 + 1e-4, '%s: rel. l2 distance from fp64 %.2e, the fp32 oracle has %.2e' % (k, e, e32)
+        if e / max(e32, 1e-12) > worst[0]:
+            worst = (e / max(e32, 1e-12), k)
+    print('B=64 parameter gradients vs fp64: %d tensors, worst ratio to the fp32 oracle\'s own distance %.2f (%s)'
+          % (len(names), worst[0], worst[1]))

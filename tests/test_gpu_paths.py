@@ -43,22 +43,35 @@ def test_fp16_conv_kernels_register_staged():
 
 
 def test_fp16_backbone_close_to_fp32():
+    """fp16-storage inference backbone (BASELINE configs[4]): kernel-level checks, then the WHOLE model with the fp16 backbone
+    against the CPU ORACLE (the pinned restatement of the reference path, fp32 eval forward on the same seeded weights and
+    images) -- not against this package's own fp32 path.  Inference mode with fp16 storage is not the 1e-4 parity path
+    (DESIGN 3.9); measured 7e-4 of the mesh extent, bar 5e-3."""
     import test_half
-    from renderih_amd import testing
+    from oracle import net_oracle
+    from renderih_amd import assets, testing
     from renderih_amd.model import build_model
     d = dev()
     test_half.backbone_vs_fp32(d, B=2)
     test_half.backbone_b_vs_fp32(d, B=2)
-    m = build_model(0.0).to(d).eval()
-    img = testing.seeded_image(2, 3).to(d)
+    m = build_model(0.0)
+    sd = testing.deterministic_state(m.state_dict(), seed=1)
+    m.load_state_dict(sd)
+    m = m.to(d).eval()
+    img = testing.seeded_image(2, 3)
+    graph = net_oracle.graph_from_dicts(assets.load_graph_dict('left'), assets.load_graph_dict('right'))
     with torch.no_grad():
-        ref = testing.flatten_outputs(m(img))
+        want = testing.flatten_outputs(net_oracle.handnet_forward({k: v.clone() for k, v in sd.items()}, graph, img,
+                                                                  training=False))
         m.use_fp16_backbone()
-        got = testing.flatten_outputs(m(img))
-    for k in ('result.verts3d.left', 'result.verts3d.right'):
+        got = testing.flatten_outputs(m(img.to(d)))
+    worst = 0.0
+    for k in ('result.verts3d.left', 'result.verts3d.right', 'hand0.verts3d.left', 'hand0.verts3d.right'):
         assert bool(torch.isfinite(got[k]).all())
-        # inference mode with fp16 storage: not the 1e-4 parity path; measured 7e-4 at B=256
-        assert testing.rel_err(got[k], ref[k]) < 3e-2, k
+        e = testing.rel_err(got[k], want[k])
+        worst = max(worst, e)
+        assert e < 5e-3, (k, e)
+    print('fp16-storage backbone, whole model vs CPU oracle: worst rel. err %.2e' % worst)
 
 
 def test_graphed_inference_replay_is_bit_identical():
