@@ -203,8 +203,9 @@ def test_parameter_gradients_at_bench_batch_vs_fp64_anchor():
     fixture together with the fp32 oracle's own distance from them; tensors of more than 16384 elements are compared on a seeded
     random sample of 16384).  What an fp32 implementation can reach here is set by the network, not by the kernel: the fp32
     ORACLE's gradients are up to 3.6e-2 (relative l2) from its own fp64 run on the trunk weights, cosine 0.9994 -- so the bar is
-    relative to that: per tensor, relative l2 distance from fp64 within 4 x the fp32 oracle's (floor 1e-4) and 1 - cosine
-    within 4 x the fp32 oracle's (floor 1e-6)."""
+    relative to that: per tensor, relative l2 distance from fp64 within RATIO x the fp32 oracle's (floor 1e-4) and 1 - cosine
+    within RATIO^2 x the fp32 oracle's (1 - cos ~ e^2 / 2; floor 1e-6); the median ratio over the sample within 2."""
+    RATIO = 4.0
     import os
     import numpy as np
     fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'b64_grads.npz'))
@@ -218,7 +219,7 @@ def test_parameter_gradients_at_bench_batch_vs_fp64_anchor():
     grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
     names = [k[4:] for k in fx.files if k.startswith('g64/')]
     assert len(names) >= 50
-    worst = (0.0, '')
+    rows, bad = [], []
     for k in names:
         assert k in grads, 'no gradient for %s' % k
         g = grads[k].double().flatten().cpu()
@@ -228,15 +229,19 @@ def test_parameter_gradients_at_bench_batch_vs_fp64_anchor():
             import zlib
             idx = np.sort(np.random.RandomState(zlib.crc32(k.encode()) & 0x7FFFFFFF).choice(g.numel(), r.numel(), replace=False))
             g = g[torch.from_numpy(idx)]
-        cos = float(torch.dot(g, r) / (g.norm() * r.norm()).clamp_min(1e-300))
-        e = float((g - r).norm() / r.norm().clamp_min(1e-300))
-        e32 = float(fx['e32/' + k])
         if testing.is_null_gradient(k):
             continue
-        c32 = float(fx['c32/' + k])
-        assert 1.0 - cos <= 4.0 * (1.0 - c32) + 1e-6, '%s: cosine %.7f with the fp64 gradient (fp32 oracle: %.7f)' % (k, cos, c32)
-        assert e <= 4.0 * e32 + 1e-4, '%s: rel. l2 distance from fp64 %.2e, the fp32 oracle has %.2e' % (k, e, e32)
-        if e / max(e32, 1e-12) > worst[0]:
-            worst = (e / max(e32, 1e-12), k)
-    print('B=64 parameter gradients vs fp64: %d tensors, worst ratio to the fp32 oracle\'s own distance %.2f (%s)'
-          % (len(names), worst[0], worst[1]))
+        cos = float(torch.dot(g, r) / (g.norm() * r.norm()).clamp_min(1e-300))
+        e = float((g - r).norm() / r.norm().clamp_min(1e-300))
+        e32, c32 = float(fx['e32/' + k]), float(fx['c32/' + k])
+        rows.append((e / max(e32, 1e-12), k, e, e32, cos, c32))
+        if not (e <= RATIO * e32 + 1e-4 and 1.0 - cos <= RATIO * RATIO * (1.0 - c32) + 1e-6):
+            bad.append(k)
+    rows.sort(reverse=True)
+    print('B=64 parameter gradients vs the fp64 anchor (%d tensors); rel. l2 distance: HIP | fp32 oracle | ratio; cosines' % len(rows))
+    for ratio, k, e, e32, cos, c32 in rows[:12]:
+        print('  %-66s %.2e %.2e %5.2f   %.7f %.7f' % (k, e, e32, ratio, cos, c32))
+    med = sorted(r[0] for r in rows)[len(rows) // 2]
+    print('  median ratio %.2f' % med)
+    assert not bad, 'gradients further from fp64 than %g x the fp32 oracle: %s' % (RATIO, bad)
+    assert med <= 2.0, 'median distance ratio %.2f' % med
