@@ -177,7 +177,7 @@ SIGNATURES = {
     'rih_mano_pack': (c_i, [C.POINTER(ManoModel), c_f, C.c_void_p]),
     'rih_mano_fwd': (c_i, [C.POINTER(ManoModel), c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_i, c_i,
                            C.c_void_p]),
-    'rih_mano_bwd': (c_i, [C.POINTER(ManoModel), c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f,
+    'rih_mano_bwd': (c_i, [C.POINTER(ManoModel), c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f,
                            c_f, c_f, c_f, c_f, c_f, c_f, c_i, C.c_void_p]),
     'rih_mesh_loss': (c_i, [C.POINTER(MeshTopo), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_fl,
                             c_f, c_f, c_f, c_f, c_f, c_i, C.c_void_p]),
@@ -205,7 +205,7 @@ SIGNATURES = {
     'rih_arch': (C.c_char_p, []),
 }
 
-ABI_VERSION = 9      # = RIH_ABI_VERSION of include/renderih_amd.h
+ABI_VERSION = 10     # = RIH_ABI_VERSION of include/renderih_amd.h
 
 _lib = None
 

@@ -316,6 +316,7 @@ constexpr int NCP = NTILES * 192;       // 2496 padded coordinates
 constexpr int PK_JT = KP * NCP;         // Jt[16][3]
 constexpr int PK_JS = PK_JT + 48;       // Js[16][3][10]
 constexpr int PK_FLOATS = PK_JS + 480;
+constexpr int BW_STRIDE = NCP + 240;          // per-hand hand-off of the split backward: dv_tpose | dR[144] | (48 unused) | djt[48]
 
 __global__ void mano_pack_basis_kernel(Model m, float* __restrict__ pk) {
     const long long total = (long long)KP * NCP;
@@ -350,6 +351,45 @@ __global__ void mano_pack_joints_kernel(Model m, float* __restrict__ pk) {
 
 // ------------------------------------------------------------------------------------------------ fused forward
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+// A [rows][192] tile of a row-major matrix (row pitch src_ld floats) into LDS rows of pitch PITCH, by all 256 threads: the
+// 16-byte requests go out in batches of 12 per thread BEFORE the first LDS store (a load -> store loop waits one L2 round trip
+// per iteration: 28 dependent round trips per basis tile, ~26 us -- what the tile streaming of the hand-major forward and of
+// the backward blend kernel used to cost).  PITCH % 4 == 0: 16-byte stores; otherwise (even pitch) two 8-byte stores.
+template <int PITCH>
+__device__ __forceinline__ void load_tile_192(float* __restrict__ dst, const float* __restrict__ src, long long src_ld, int rows,
+                                              int t) {
+    constexpr int NB = 12;
+    const int total = rows * 48;
+    for (int base = 0; base < total; base += 256 * NB) {
+        floatx4 r[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int i = base + t + 256 * u;
+            r[u] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (i < total) {
+                const int k = i / 48, q = i - k * 48;
+                r[u] = *reinterpret_cast<const floatx4*>(src + (long long)k * src_ld + 4 * q);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int i = base + t + 256 * u;
+            if (i < total) {
+                const int k = i / 48, q = i - k * 48;
+                float* d = dst + k * PITCH + 4 * q;
+                if (PITCH % 4 == 0) {
+                    *reinterpret_cast<floatx4*>(d) = r[u];
+                } else {
+                    *reinterpret_cast<floatx2*>(d) = floatx2{r[u].x, r[u].y};
+                    *reinterpret_cast<floatx2*>(d + 2) = floatx2{r[u].z, r[u].w};
+                }
+            }
+        }
+    }
+}
+
 constexpr int HC = 16;                  // hands per chunk = one 16-row MFMA block
 constexpr int LDPF = 149;               // odd row stride of the pose-feature operand: conflict-free column reads
 constexpr int GST = 200;                // per-hand SE3s (16 x 12) + post (8)
@@ -389,13 +429,7 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
     const bool need_special = first_tile || centre_is_tip;
 
     // the basis tile: rows are 192 contiguous floats of Bmat
-    auto load_basis = [&](int tile) {
-        const int n0 = tile * 192;
-        for (int i = t; i < KP * 48; i += 256) {
-            const int k = i / 48, q = i - k * 48;
-            *reinterpret_cast<float4*>(s_B + k * 192 + 4 * q) = *reinterpret_cast<const float4*>(pk + (long long)k * NCP + n0 + 4 * q);
-        }
-    };
+    auto load_basis = [&](int tile) { load_tile_192<192>(s_B, pk + tile * 192, NCP, KP, t); };
     if (!HM) load_basis(tile_fixed);
     for (int i = t; i < 528; i += 256) s_J[i] = pk[PK_JT + i];
     if (t < NJ) {
@@ -598,7 +632,9 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
         }
         RIH_STAMP(5);
         for (int tl = 0; tl < (HM ? NTILES : 1); ++tl) {
-        const int tile = HM ? tl : tile_fixed;
+        // (hand-major: every workgroup streams the same 13 tiles -- each starts at its own, so that the CUs of an XCD do not
+        // all ask the same L2 channels for the same lines at the same time)
+        const int tile = HM ? (tl + (int)blockIdx.x) % NTILES : tile_fixed;
         const int v = tile * TILE_V + lane;
         const bool valid = v < NV;
         if (HM) {
@@ -684,17 +720,39 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(Model m, const float* __r
                                                        const float* __restrict__ dv, const float* __restrict__ dj,
                                                        const float* __restrict__ ws, float* __restrict__ d_root,
                                                        float* __restrict__ d_pose, float* __restrict__ d_shape,
-                                                       float* __restrict__ d_trans, float* __restrict__ d_scale) {
+                                                       float* __restrict__ d_trans, float* __restrict__ d_scale,
+                                                       float* __restrict__ wsb, long long* __restrict__ dbg) {
+    // phase timestamps of workgroup 0 (development aid, tools/mano_phases.py): slots 208.. of the rih_mano_debug_stamps buffer
+#define RIH_BSTAMP(i_) do { if (dbg != nullptr && threadIdx.x == 0 && blockIdx.x == 0) dbg[208 + (i_)] = clock64(); } while (0)
+    RIH_BSTAMP(0);
     __shared__ float s_dvs[NVC];           // dv_eff -> dv_skin -> dv_tpose -> dv_shaped (in place)
-    __shared__ float s_M[NV * 12];         // per-vertex outer products dv_skin x [v_t;1]
-    __shared__ float s_G[NJ * 12], s_R[NJ * 9], s_jt[NJ * 3];
+    __shared__ float s_M[NV * 6];          // per vertex: dv_skin (3) | v_tpose (3) -- the factors of M_v = dv_skin x [v_t;1]
+    __shared__ __attribute__((aligned(16))) float s_G[NJ * 12];
+    __shared__ float s_R[NJ * 9], s_jt[NJ * 3];
     __shared__ float s_dG[NJ * 12], s_dR[NJ * 9], s_djt[NJ * 3];
     __shared__ float s_djeff[63], s_dsrc[63];
     __shared__ float s_dpf[NPF];
     __shared__ float s_axis[48], s_dax[48];
     __shared__ float s_red[4];
     __shared__ float s_sh[250];
+    __shared__ float s_part[4 * NJ * 12];
+    __shared__ float s_red4[16];
+    __shared__ int s_depth[NJ + 1];        // tree depth of the joints, [16] = maximum
     const int b = blockIdx.x, t = threadIdx.x;
+    if (t < NJ) {
+        int d = 0;
+        for (int pp = m.parent[t]; pp >= 0; pp = m.parent[pp]) ++d;
+        s_depth[t] = d;
+    }
+    if (t == 0) {
+        int mx = 0;
+        for (int j = 1; j < NJ; ++j) {
+            int d = 0;
+            for (int pp = m.parent[j]; pp >= 0; pp = m.parent[pp]) ++d;
+            mx = max(mx, d);
+        }
+        s_depth[NJ] = mx;
+    }
     const float* w = ws + (long long)b * WS_STRIDE;
     const float* dvb = dv + (long long)b * NVC;
     const float* djb = dj + (long long)b * 63;
@@ -710,12 +768,13 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(Model m, const float* __r
         }
         s_djeff[t] = d;
     }
-    if (ncomp > 0 && t < 45) {
+    if (wsb == nullptr && ncomp > 0 && t < 45) {        // (split backward: the blend kernel computes the axis-angle vectors)
         float a = m.hands_mean[t];
         for (int c = 0; c < ncomp; ++c) a += pose[(long long)b * ncomp + c] * m.comps[c * 45 + t];
         s_axis[t] = a;
     }
     const float sc = w[OFF_POST + 3];
+    RIH_BSTAMP(1);
     // 1. effective vertex gradient (new_skel joints are averages of output vertices)
     float p_sv0 = 0.f, p_sv1 = 0.f, p_sv2 = 0.f, p_dot = 0.f;
     for (int i = t; i < NVC; i += 256) {
@@ -732,10 +791,21 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(Model m, const float* __r
     }
     __syncthreads();
     if (t < 63) p_dot += s_djeff[t] * w[OFF_J21C + t];
-    const float sv0 = block_sum_256(p_sv0, s_red);
-    const float sv1 = block_sum_256(p_sv1, s_red);
-    const float sv2 = block_sum_256(p_sv2, s_red);
-    const float dot = block_sum_256(p_dot, s_red);
+    float sv0, sv1, sv2, dot;               // four block sums behind ONE pair of barriers
+    {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            p_sv0 += __shfl_xor(p_sv0, o, 64); p_sv1 += __shfl_xor(p_sv1, o, 64);
+            p_sv2 += __shfl_xor(p_sv2, o, 64); p_dot += __shfl_xor(p_dot, o, 64);
+        }
+        __syncthreads();
+        if ((t & 63) == 0) { s_red4[(t >> 6) * 4] = p_sv0; s_red4[(t >> 6) * 4 + 1] = p_sv1; s_red4[(t >> 6) * 4 + 2] = p_sv2; s_red4[(t >> 6) * 4 + 3] = p_dot; }
+        __syncthreads();
+        sv0 = (s_red4[0] + s_red4[4]) + (s_red4[8] + s_red4[12]);
+        sv1 = (s_red4[1] + s_red4[5]) + (s_red4[9] + s_red4[13]);
+        sv2 = (s_red4[2] + s_red4[6]) + (s_red4[10] + s_red4[14]);
+        dot = (s_red4[3] + s_red4[7]) + (s_red4[11] + s_red4[15]);
+    }
     float sj[3] = {0.f, 0.f, 0.f};
     for (int k = 0; k < 21; ++k) { sj[0] += s_djeff[k * 3]; sj[1] += s_djeff[k * 3 + 1]; sj[2] += s_djeff[k * 3 + 2]; }
     const float st[3] = {sv0 + sj[0], sv1 + sj[1], sv2 + sj[2]};
@@ -743,6 +813,7 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(Model m, const float* __r
         if (d_trans) for (int c = 0; c < 3; ++c) d_trans[b * 3 + c] = st[c];
         if (d_scale && has_scale) d_scale[b] = dot;
     }
+    RIH_BSTAMP(2);
     // 3. joint-side gradients in `src` order (16 chain joints + 5 tips)
     if (t < 63) {
         const int k = t / 3, c = t % 3;
@@ -759,82 +830,159 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(Model m, const float* __r
         s_dvs[i] = d;                       // dv_skin
     }
     __syncthreads();
+    RIH_BSTAMP(3);
     // 4. through the skinning: dv_tpose = T_v^T dv_skin ; M_v = dv_skin x [v_t;1]
-    for (int v = t; v < NV; v += 256) {
+#pragma unroll
+    for (int vi = 0; vi < 4; ++vi) {        // (unrolled: the weight / v_tpose requests of a thread's vertices fly together)
+        const int v = t + 256 * vi;
+        if (v >= NV) continue;
         float Tr[9];
         for (int e = 0; e < 9; ++e) Tr[e] = 0.f;
+        float wv[NJ];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {       // the vertex's 16 weights: four 16-byte requests
+            const float4 w4 = *reinterpret_cast<const float4*>(m.weights + v * NJ + 4 * q);
+            wv[4 * q] = w4.x; wv[4 * q + 1] = w4.y; wv[4 * q + 2] = w4.z; wv[4 * q + 3] = w4.w;
+        }
+#pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const float wj = m.weights[v * NJ + j];
-            for (int r = 0; r < 3; ++r)
-                for (int c = 0; c < 3; ++c) Tr[r * 3 + c] += wj * s_G[j * 12 + r * 4 + c];
+            const float4 g0 = *reinterpret_cast<const float4*>(s_G + j * 12);
+            const float4 g1 = *reinterpret_cast<const float4*>(s_G + j * 12 + 4);
+            const float4 g2 = *reinterpret_cast<const float4*>(s_G + j * 12 + 8);
+            Tr[0] += wv[j] * g0.x; Tr[1] += wv[j] * g0.y; Tr[2] += wv[j] * g0.z;
+            Tr[3] += wv[j] * g1.x; Tr[4] += wv[j] * g1.y; Tr[5] += wv[j] * g1.z;
+            Tr[6] += wv[j] * g2.x; Tr[7] += wv[j] * g2.y; Tr[8] += wv[j] * g2.z;
         }
         const float d[3] = {s_dvs[v * 3], s_dvs[v * 3 + 1], s_dvs[v * 3 + 2]};
-        const float x[3] = {w[OFF_VT + v * 3], w[OFF_VT + v * 3 + 1], w[OFF_VT + v * 3 + 2]};
-        for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c) s_M[v * 12 + r * 4 + c] = d[r] * x[c];
-            s_M[v * 12 + r * 4 + 3] = d[r];
+        // M_v = dv_skin x [v_t; 1] is rank one: keep its two factors (19 KB for the mesh instead of 37 KB -- four workgroups
+        // per CU instead of two) and form the products in step 5
+        for (int c = 0; c < 3; ++c) {
+            s_M[v * 6 + c] = d[c];
+            s_M[v * 6 + 3 + c] = w[OFF_VT + v * 3 + c];
         }
         for (int c = 0; c < 3; ++c) s_dvs[v * 3 + c] = Tr[c] * d[0] + Tr[3 + c] * d[1] + Tr[6 + c] * d[2];
     }
     __syncthreads();
-    // 5. dG = W^T M
+    RIH_BSTAMP(4);
+    // 5. dG = W^T M: lane = (joint, three of the twelve elements), each wavefront a quarter of the vertices (the 64 bytes of a
+    //    vertex's weights are one coalesced request), partial sums joined through LDS in wavefront order
+    {
+        // lane group g = lane & 3: g < 3 owns row g of the 3 x 4 block (columns 0..2: d[g] x[c]), g == 3 its last column (d[r])
+        const int lane = t & 63, wave = t >> 6, j = lane >> 2, g = lane & 3;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int v0 = wave; v0 < NV; v0 += 4 * 8) {        // eight weight requests in flight per lane (one per iteration
+            float wj[8];                                   // would be a chain of 195 L2 round trips)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int v = v0 + 4 * u;
+                wj[u] = (v < NV) ? m.weights[v * NJ + j] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int v = min(v0 + 4 * u, NV - 1);
+                const float* f = &s_M[v * 6];
+                if (g < 3) {
+                    const float wd = wj[u] * f[g];
+                    a0 += wd * f[3]; a1 += wd * f[4]; a2 += wd * f[5];
+                } else {
+                    a0 += wj[u] * f[0]; a1 += wj[u] * f[1]; a2 += wj[u] * f[2];
+                }
+            }
+        }
+        const int e0 = (g < 3) ? 4 * g : 3, es = (g < 3) ? 1 : 4;       // element indices e0, e0 + es, e0 + 2 es of the 3 x 4 block
+        __syncthreads();                    // s_dvs is needed below; the partials go to a separate scratch
+        s_part[wave * 192 + j * 12 + e0] = a0;
+        s_part[wave * 192 + j * 12 + e0 + es] = a1;
+        s_part[wave * 192 + j * 12 + e0 + 2 * es] = a2;
+        __syncthreads();
+        if (t < NJ * 12) s_dG[t] = (s_part[t] + s_part[192 + t]) + (s_part[384 + t] + s_part[576 + t]);
+    }
+    __syncthreads();
+    RIH_BSTAMP(5);
+    // 6. joint-position gradients through the chain: dG_parent += d(joint i) x [jt_i; 1]^T (gathered per parent, children in
+    //    index order), djt_i += R_parent^T d(joint i).  (Rounds 1-2 ran steps 6-7 on ONE thread: ~2400 dependent LDS accesses,
+    //    ~80 us of the 150 us a workgroup took.)
     if (t < NJ * 12) {
-        const int j = t / 12, e = t % 12;
+        const int p = t / 12, e = t - p * 12, r = e >> 2, c = e & 3;
         float a = 0.f;
-        for (int v = 0; v < NV; ++v) a += m.weights[v * NJ + j] * s_M[v * 12 + e];
-        s_dG[t] = a;
-    }
-    __syncthreads();
-    // 6.-7. joints and kinematic chain, sequential (16 tiny steps)
-    if (t == 0) {
-        for (int c = 0; c < 3; ++c) s_djt[c] += s_dsrc[c];
-        for (int i = 1; i < NJ; ++i) {
-            const int p = m.parent[i];
+        for (int i = 1; i < NJ; ++i)
+            if (m.parent[i] == p) a += s_dsrc[i * 3 + r] * (c < 3 ? s_jt[i * 3 + c] : 1.f);
+        s_dG[t] += a;
+    } else if (t < NJ * 12 + NJ * 3) {
+        const int i = (t - NJ * 12) / 3, c = (t - NJ * 12) - i * 3;
+        if (i == 0) {
+            s_djt[c] += s_dsrc[c];
+        } else {
+            const float* P = &s_G[m.parent[i] * 12];
             const float* dji = &s_dsrc[i * 3];
-            const float* P = &s_G[p * 12];
-            for (int r = 0; r < 3; ++r) {
-                for (int c = 0; c < 3; ++c) s_dG[p * 12 + r * 4 + c] += dji[r] * s_jt[i * 3 + c];
-                s_dG[p * 12 + r * 4 + 3] += dji[r];
-            }
-            for (int c = 0; c < 3; ++c) s_djt[i * 3 + c] += P[c] * dji[0] + P[4 + c] * dji[1] + P[8 + c] * dji[2];
-        }
-        for (int i = NJ - 1; i >= 0; --i) {
-            const float* R = &s_R[i * 9];
-            const float* jv = &s_jt[i * 3];
-            const float* dGi = &s_dG[i * 12];
-            float dRl[9], dtl[3];
-            if (i > 0) {
-                const int p = m.parent[i];
-                const float* P = &s_G[p * 12];
-                float tl[3];
-                for (int r = 0; r < 3; ++r) tl[r] = jv[r] - (R[r * 3] * jv[0] + R[r * 3 + 1] * jv[1] + R[r * 3 + 2] * jv[2]);
-                for (int r = 0; r < 3; ++r) {
-                    for (int c = 0; c < 3; ++c) {
-                        // dRp += dRg * Ri^T + dtg x tl^T
-                        s_dG[p * 12 + r * 4 + c] += dGi[r * 4] * R[c * 3] + dGi[r * 4 + 1] * R[c * 3 + 1] +
-                                                    dGi[r * 4 + 2] * R[c * 3 + 2] + dGi[r * 4 + 3] * tl[c];
-                    }
-                    s_dG[p * 12 + r * 4 + 3] += dGi[r * 4 + 3];
-                }
-                for (int r = 0; r < 3; ++r) {
-                    for (int c = 0; c < 3; ++c)
-                        dRl[r * 3 + c] = P[r] * dGi[c] + P[4 + r] * dGi[4 + c] + P[8 + r] * dGi[8 + c];
-                    dtl[r] = P[r] * dGi[3] + P[4 + r] * dGi[7] + P[8 + r] * dGi[11];
-                }
-            } else {
-                for (int r = 0; r < 3; ++r) {
-                    for (int c = 0; c < 3; ++c) dRl[r * 3 + c] = dGi[r * 4 + c];
-                    dtl[r] = dGi[r * 4 + 3];
-                }
-            }
-            // local: t_l = (I - R) j  ->  dR -= dtl x j^T ; dj += dtl - R^T dtl
-            for (int r = 0; r < 3; ++r)
-                for (int c = 0; c < 3; ++c) s_dR[i * 9 + r * 3 + c] = dRl[r * 3 + c] - dtl[r] * jv[c];
-            for (int c = 0; c < 3; ++c)
-                s_djt[i * 3 + c] += dtl[c] - (R[c] * dtl[0] + R[3 + c] * dtl[1] + R[6 + c] * dtl[2]);
+            s_djt[i * 3 + c] += P[c] * dji[0] + P[4 + c] * dji[1] + P[8 + c] * dji[2];
         }
     }
     __syncthreads();
+    // 7a. global-transform gradients up the tree, one level at a time: a parent gathers dRg_i R_i^T + dtg_i tl_i^T (and dtg_i)
+    //     from its children, whose own gradients are complete by then
+    for (int L = s_depth[16]; L >= 1; --L) {
+        if (t < NJ * 12) {
+            const int p = t / 12, e = t - p * 12, r = e >> 2, c = e & 3;
+            if (s_depth[p] == L - 1) {
+                float a = 0.f;
+                for (int i = 1; i < NJ; ++i) {
+                    if (m.parent[i] != p) continue;
+                    const float* R = &s_R[i * 9];
+                    const float* jv = &s_jt[i * 3];
+                    const float* dGi = &s_dG[i * 12];
+                    if (c < 3) {
+                        const float tl = jv[c] - (R[c * 3] * jv[0] + R[c * 3 + 1] * jv[1] + R[c * 3 + 2] * jv[2]);
+                        a += dGi[r * 4] * R[c * 3] + dGi[r * 4 + 1] * R[c * 3 + 1] + dGi[r * 4 + 2] * R[c * 3 + 2] + dGi[r * 4 + 3] * tl;
+                    } else {
+                        a += dGi[r * 4 + 3];
+                    }
+                }
+                s_dG[t] += a;
+            }
+        }
+        __syncthreads();
+    }
+    // 7b. local terms of every joint in parallel: dR_i = dRl - dtl jt^T, djt_i += dtl - R_i^T dtl, with
+    //     dRl = P_rot^T dRg, dtl = P_rot^T dtg (P = the parent's global transform; identity for the root)
+    if (t < NJ * 12) {
+        const int i = t / 12, e = t - i * 12, r = e >> 2, c = e & 3;
+        const float* dGi = &s_dG[i * 12];
+        float dtl[3];
+        if (i > 0) {
+            const float* P = &s_G[m.parent[i] * 12];
+            for (int q = 0; q < 3; ++q) dtl[q] = P[q] * dGi[3] + P[4 + q] * dGi[7] + P[8 + q] * dGi[11];
+            if (c < 3) {
+                const float dRl = P[r] * dGi[c] + P[4 + r] * dGi[4 + c] + P[8 + r] * dGi[8 + c];
+                s_dR[i * 9 + r * 3 + c] = dRl - dtl[r] * s_jt[i * 3 + c];
+            }
+        } else {
+            for (int q = 0; q < 3; ++q) dtl[q] = dGi[q * 4 + 3];
+            if (c < 3) s_dR[r * 3 + c] = dGi[r * 4 + c] - dtl[r] * s_jt[c];
+        }
+        if (c == 3) {       // (three lanes per joint: r plays the coordinate)
+            const float* R = &s_R[i * 9];
+            s_djt[i * 3 + r] += dtl[r] - (R[r] * dtl[0] + R[3 + r] * dtl[1] + R[6 + r] * dtl[2]);
+        }
+    }
+    __syncthreads();
+    RIH_BSTAMP(6);
+    if (wsb != nullptr) {
+        // Split backward (rih_mano_bwd, default): the two contractions with the blend bases -- steps 8 and 10, 0.33 MFLOP per
+        // hand against 1.26 MB of basis that one workgroup per hand re-reads from L2 (5.2 GB for 4096 hands: the 1.17 ms of
+        // round 2) -- are left to mano_bwd_blend_kernel, which runs them as MFMA products of 16-hand chunks against basis
+        // tiles in LDS.  Step 9 disappears: d_shape = shapedirs^T (dv_tpose + J_reg^T djt) = shapedirs^T dv_tpose + Js^T djt with
+        // the folded regressor Js of the packed basis (480 MACs per hand instead of 37 k loads of J_reg).  Handed over per hand:
+        // dv_tpose (coordinates padded to the packed basis' 2496), the joint-rotation gradients before the pose-blend term, the
+        // axis-angle vector and the rest-joint gradients.
+        float* o = wsb + (long long)b * BW_STRIDE;
+        for (int i = t; i < NCP; i += 256) o[i] = (i < NVC) ? s_dvs[i] : 0.f;                       // dv_tpose
+        if (t < NJ * 9) o[NCP + t] = s_dR[t];
+        if (t < 48) o[NCP + 192 + t] = s_djt[t];
+        if (t < 9 && d_root) d_root[(long long)b * 9 + t] = s_dR[t];
+        RIH_BSTAMP(7);
+        return;
+    }
     // 8. pose-blend gradient: dpf[p] = sum_vc posedirs[vc][p] * dv_tpose[vc]
     if (t < NPF) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -888,6 +1036,124 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(Model m, const float* __r
     }
 }
 
+// ---- backward, part 2: the contractions with the blend bases for 16 hands at a time ---------------------------------------
+//   out[16 hands][148] = dv_tpose[16][2496] x Bmat^T: columns 0..134 = the pose-feature gradient, 135..144 = the vertex part
+//   of the shape gradient (the joint-regressor part is Js^T djt, added in the epilogue).
+// Hand-chunk major like the forward: a workgroup owns chunks of 16 hands and streams the 13 basis tiles ([148][192], zero rows
+// up to 160) from L2 through LDS; per tile ten 16 x 16 x 192 products on v_mfma_f32_16x16x4_f32 (column blocks of 16 basis
+// rows; two or three per wavefront), accumulated over the tiles in registers.  LDS rows have an even-but-not-multiple-of-32 pitch (194 floats) so that the k-strided operand reads of 16 rows
+// are bank-conflict free.  Epilogue per hand: pose-blend term into the joint-rotation gradients, Rodrigues backward, PCA
+// projection (or the rotation-matrix gradients as they are), shape gradient.
+constexpr int BL_P = 194;                       // LDS row pitch
+constexpr int BL_ROWS = 160;                    // basis rows incl. zero padding to ten 16-column blocks
+__global__ __launch_bounds__(256) void mano_bwd_blend_kernel(Model m, const float* __restrict__ pk, int ncomp,
+                                                             const float* __restrict__ pose, const float* __restrict__ wsb,
+                                                             float* __restrict__ d_pose, float* __restrict__ d_shape, int B) {
+    __shared__ __attribute__((aligned(16))) float s_B[BL_ROWS * BL_P];      // 124,160 B
+    __shared__ __attribute__((aligned(16))) float s_V[HC * BL_P];           //  12,416 B: dv_tpose tile
+    float* s_dR = s_B;                          // epilogue scratch in the (then dead) first basis rows: [HC][144] | 3 x [HC][48]
+    float* s_ax = s_B + HC * 144;
+    float* s_dax = s_ax + HC * 48;
+    float* s_djt = s_dax + HC * 48;
+    float* s_out = s_djt + HC * 48;              // [HC][160]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < (BL_ROWS - KP) * BL_P; i += 256) s_B[KP * BL_P + i] = 0.f;     // rows 148..159 stay zero
+    const int nchunks = (B + HC - 1) / HC;
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int h0 = chunk * HC;
+        floatx4 acc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int tl = 0; tl < NTILES; ++tl) {
+            __syncthreads();                    // the previous tile's products (and the previous chunk's epilogue) are done
+            const int tile = (tl + chunk) % NTILES;         // staggered start: see the forward's tile loop
+            const int n0 = tile * 192;
+            load_tile_192<BL_P>(s_B, pk + n0, NCP, KP, t);
+            {       // the gradient tile [16 hands][192]; rows of hands behind the end of the batch are zero
+                const int nh = min(HC, B - h0);
+                load_tile_192<BL_P>(s_V, wsb + (long long)h0 * BW_STRIDE + n0, BW_STRIDE, nh, t);
+                for (int i = t; i < (HC - nh) * 192; i += 256) s_V[(nh + i / 192) * BL_P + i % 192] = 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int blk = wave + 4 * j;                       // column block 0..9 (wave-uniform)
+                if (blk >= 10) continue;
+                const float* a_rd = s_V + (lane & 15) * BL_P + (lane >> 4);
+                const float* b_rd = s_B + (blk * 16 + (lane & 15)) * BL_P + (lane >> 4);
+#pragma unroll 8
+                for (int ks = 0; ks < 48; ++ks)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_rd[4 * ks], b_rd[4 * ks], acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        // C/D layout: column = lane & 15 (basis row within the block), row = 4 * (lane >> 4) + r (hand)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int blk = wave + 4 * j, col = blk * 16 + (lane & 15);
+            if (blk >= 10) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_out[(4 * (lane >> 4) + r) * BL_ROWS + col] = acc[j][r];
+        }
+        for (int i = t; i < HC * 192; i += 256) {
+            const int hl = i / 192, e = i - hl * 192;
+            if (e < 144) s_dR[hl * 144 + e] = (h0 + hl < B) ? wsb[(long long)(h0 + hl) * BW_STRIDE + NCP + e] : 0.f;
+        }
+        if (ncomp > 0) {        // axis-angle = hands_mean + pose x comps of the chunk's hands (for the Rodrigues backward)
+            for (int i = t; i < HC * 48; i += 256) {
+                const int hl = i / 48, e = i - hl * 48;
+                float a = 0.f;
+                if (e < 45 && h0 + hl < B) {
+                    a = m.hands_mean[e];
+                    const float* ph = pose + (long long)(h0 + hl) * ncomp;
+#pragma unroll 15
+                    for (int c = 0; c < ncomp; ++c) a += ph[c] * m.comps[c * 45 + e];      // (unrolled: the loads of 15 steps in flight)
+                }
+                s_ax[i] = a;
+            }
+        }
+        for (int i = t; i < HC * 48; i += 256) {
+            const int hl = i / 48, e = i - hl * 48;
+            s_djt[i] = (h0 + hl < B) ? wsb[(long long)(h0 + hl) * BW_STRIDE + NCP + 192 + e] : 0.f;
+        }
+        __syncthreads();
+        for (int i = t; i < HC * 10; i += 256) {
+            const int hl = i / 10, e = i - hl * 10;
+            if (h0 + hl < B && d_shape) {
+                float a = s_out[hl * BL_ROWS + NPF + e];
+                for (int q = 0; q < 48; ++q) a += s_djt[hl * 48 + q] * pk[PK_JS + q * 10 + e];     // + Js^T djt
+                d_shape[(long long)(h0 + hl) * 10 + e] = a;
+            }
+        }
+        if (d_pose) {
+            for (int i = t; i < HC * NPF; i += 256) {
+                const int hl = i / NPF, e = i - hl * NPF;
+                s_dR[hl * 144 + 9 + e] += s_out[hl * BL_ROWS + e];
+            }
+            __syncthreads();
+            if (ncomp > 0) {
+                if (t < HC * 15) {
+                    const int hl = t / 15, jn = t - hl * 15;
+                    rodrigues_bwd(&s_ax[hl * 48 + jn * 3], &s_dR[hl * 144 + (jn + 1) * 9], &s_dax[hl * 48 + jn * 3]);
+                }
+                __syncthreads();
+                for (int i = t; i < HC * ncomp; i += 256) {
+                    const int hl = i / ncomp, c = i - hl * ncomp;
+                    if (h0 + hl >= B) continue;
+                    float a = 0.f;
+                    for (int k = 0; k < 45; ++k) a += s_dax[hl * 48 + k] * m.comps[c * 45 + k];
+                    d_pose[(long long)(h0 + hl) * ncomp + c] = a;
+                }
+            } else {
+                for (int i = t; i < HC * NPF; i += 256) {
+                    const int hl = i / NPF, e = i - hl * NPF;
+                    if (h0 + hl < B) d_pose[(long long)(h0 + hl) * NPF + e] = s_dR[hl * 144 + 9 + e];
+                }
+            }
+        }
+    }
+}
+
 Model to_model(const rih_mano_model* m) {
     Model o;
     o.comps = m->comps; o.hands_mean = m->hands_mean; o.shapedirs = m->shapedirs; o.posedirs = m->posedirs;
@@ -907,7 +1173,7 @@ bool model_ok(const rih_mano_model* m) {
 }  // namespace
 
 extern "C" int64_t rih_mano_ws_floats(int B) { return B > 0 ? (int64_t)B * WS_STRIDE : 0; }
-extern "C" int64_t rih_mano_bwd_ws_floats(int B) { return B > 0 ? 4 : 0; }   // backward keeps its scratch in LDS
+extern "C" int64_t rih_mano_bwd_ws_floats(int B) { return B > 0 ? (int64_t)B * BW_STRIDE : 0; }
 
 static long long* g_mano_dbg = nullptr;
 // development aid: device buffer of 13 x 16 int64 that receives phase timestamps of the fused forward (NULL = off)
@@ -962,16 +1228,24 @@ extern "C" int rih_mano_fwd(const rih_mano_model* m, const float* packed, const 
     return (int)hipGetLastError();
 }
 
-extern "C" int rih_mano_bwd(const rih_mano_model* m, const float* root, const float* pose, int ncomp,
+extern "C" int rih_mano_bwd(const rih_mano_model* m, const float* packed, const float* root, const float* pose, int ncomp,
                             const float* shape, const float* trans, const float* scale, int center_idx, int new_skel,
                             const float* dv, const float* dj, const float* ws, float* d_root, float* d_pose,
                             float* d_shape, float* d_trans, float* d_scale, float* ws_bwd, int B, void* stream) {
-    (void)root; (void)shape; (void)trans; (void)ws_bwd;
+    (void)root; (void)shape; (void)trans;
     if (!model_ok(m) || !pose || !dv || !dj || !ws || B < 1) return RIH_EINVAL;
     if (ncomp < 0 || ncomp > 45 || center_idx >= 21) return RIH_EINVAL;
     if (ncomp > 0 && !m->comps) return RIH_EINVAL;
+    if (ws_bwd != nullptr && (!packed || ((uintptr_t)packed & 15) || ((uintptr_t)ws_bwd & 7))) return RIH_EINVAL;
     const Model mm = to_model(m);
-    hipLaunchKernelGGL(mano_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mm, pose, ncomp, center_idx,
-                       new_skel, scale ? 1 : 0, dv, dj, ws, d_root, d_pose, d_shape, d_trans, d_scale);
+    hipStream_t s = (hipStream_t)stream;
+    // ws_bwd == NULL: the one-kernel backward of round 1 (one workgroup per hand does everything; kept for A/B timing)
+    hipLaunchKernelGGL(mano_bwd_kernel, dim3(B), dim3(256), 0, s, mm, pose, ncomp, center_idx, new_skel, scale ? 1 : 0, dv, dj,
+                       ws, d_root, d_pose, d_shape, d_trans, d_scale, ws_bwd, g_mano_dbg);
+    if (ws_bwd != nullptr && (d_pose != nullptr || d_shape != nullptr)) {
+        const int nchunks = (B + HC - 1) / HC;
+        hipLaunchKernelGGL(mano_bwd_blend_kernel, dim3(nchunks < 512 ? nchunks : 512), dim3(256), 0, s, mm, packed, ncomp, pose,
+                           ws_bwd, d_pose, d_shape, B);
+    }
     return (int)hipGetLastError();
 }

@@ -14,7 +14,12 @@ import numpy as np
 import torch
 from torch.nn import Module
 
+import os
+
 from . import _lib, ops
+
+# RIH_MANO_BWD_SPLIT=0: the one-kernel backward of rounds 1-2 (A/B timing; tools/mano_bench.py)
+BWD_SPLIT = os.environ.get('RIH_MANO_BWD_SPLIT', '1') == '1'
 from ._lib import ManoModel, check
 
 
@@ -137,12 +142,17 @@ class _ManoFn(torch.autograd.Function):
         d_trans = torch.empty((B, 3), device=dev, dtype=torch.float32) if trans is not None else None
         d_scale = torch.empty((B,), device=dev, dtype=torch.float32) if scale is not None else None
         mm = ctx.layer._model_struct()
-        check(lib.rih_mano_bwd(C.byref(mm), root.data_ptr(), pose.data_ptr(), ncomp, shape.data_ptr(),
+        split = BWD_SPLIT
+        packed = ctx.layer._packed_basis(mm) if split else None
+        wsb = torch.empty((int(lib.rih_mano_bwd_ws_floats(B)),), device=dev, dtype=torch.float32) if split else None
+        check(lib.rih_mano_bwd(C.byref(mm), 0 if packed is None else packed.data_ptr(), root.data_ptr(), pose.data_ptr(), ncomp,
+                               shape.data_ptr(),
                                0 if trans is None else trans.data_ptr(), 0 if scale is None else scale.data_ptr(),
                                cidx, new_skel, dv.data_ptr(), dj.data_ptr(), ws.data_ptr(), d_root.data_ptr(),
                                d_pose.data_ptr(), d_shape.data_ptr(),
                                0 if d_trans is None else d_trans.data_ptr(),
-                               0 if d_scale is None else d_scale.data_ptr(), 0, B, ops._stream()), 'rih_mano_bwd')
+                               0 if d_scale is None else d_scale.data_ptr(), 0 if wsb is None else wsb.data_ptr(), B,
+                               ops._stream()), 'rih_mano_bwd')
         return None, d_root.view(root_shape), d_pose.view(pose_shape), d_shape, d_trans, d_scale
 
 

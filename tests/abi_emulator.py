@@ -717,7 +717,7 @@ class EmulatedLib:
         return 16 * B
 
     def rih_mano_bwd_ws_floats(self, B):
-        return 16
+        return B * (2496 + 240)
 
     def rih_mano_pack_floats(self):
         return 148 * 2496 + 528
@@ -732,7 +732,7 @@ class EmulatedLib:
         _f(j, B * 21 * 3)[:] = jj.numpy().ravel()
         return 0
 
-    def rih_mano_bwd(self, mref, root, pose, ncomp, shape, trans, scale, cidx, new_skel, dv, dj, ws, d_root, d_pose,
+    def rih_mano_bwd(self, mref, packed, root, pose, ncomp, shape, trans, scale, cidx, new_skel, dv, dj, ws, d_root, d_pose,
                      d_shape, d_trans, d_scale, ws_bwd, B, stream):
         with torch.enable_grad():
             ins, vv, jj = self._mano_run(mref, root, pose, ncomp, shape, trans, scale, cidx, new_skel, B, grad=True)
