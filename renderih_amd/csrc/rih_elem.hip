@@ -465,32 +465,32 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
 }
 
 // Training statistics from per-row-block (mean, M2) pairs -- the statistics epilogue of rih_gemm (rih_gemm_desc.stats:
-// part[T][2][C], block k covers rows [k*rpb, min(rows, (k+1)*rpb))).  Chan's merge written as three
+// part[T][2][C], block k covers rows [k*rpb, min(rows, (k+1)*rpb))).  One workgroup per channel; Chan's merge written as three
 // double sums: n*mean = sum n_k mean_k, M2 = sum M2_k + sum n_k mean_k^2 - n mean^2.
-// Workgroup = 16 channels x 16 block-lanes: a block's (mean, M2) of 16 consecutive channels is one 64-byte sector, so the
-// partials are read exactly once (one workgroup per CHANNEL read a 64-byte sector per value: 16 x the bytes, 10 us per launch
-// on the 2048-block layers of layer1); the 16 block-lanes of a channel are joined through LDS in lane order (fixed order).
+// (A 16-channel x 16-lane workgroup that reads each 64-byte sector of partials once was tried in round 3: 41 us per launch
+// against 10 us -- it has 16 x fewer threads in flight; one workgroup per channel stays.)
 __global__ __launch_bounds__(TPB) void bn_blocks_final_kernel(const float* __restrict__ part, int T, int C, int rows, int rpb,
                                                               float eps, float momentum, float* __restrict__ mean,
                                                               float* __restrict__ invstd, float* __restrict__ rmean,
                                                               float* __restrict__ rvar) {
-    __shared__ double red[3][16][17];
-    const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    __shared__ double red[3][TPB / 64];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    if (c < C) {
-        for (int k = kl; k < T; k += 16) {
-            const double nk = (double)((k == T - 1) ? rows - (T - 1) * rpb : rpb);
-            const double mk = (double)part[((long long)k * 2 + 0) * C + c];
-            s1 += nk * mk;
-            s2 += (double)part[((long long)k * 2 + 1) * C + c];
-            s3 += nk * mk * mk;
-        }
+    for (int k = threadIdx.x; k < T; k += TPB) {
+        const double nk = (double)((k == T - 1) ? rows - (T - 1) * rpb : rpb);
+        const double mk = (double)part[((long long)k * 2 + 0) * C + c];
+        s1 += nk * mk;
+        s2 += (double)part[((long long)k * 2 + 1) * C + c];
+        s3 += nk * mk * mk;
     }
-    red[0][kl][cl] = s1; red[1][kl][cl] = s2; red[2][kl][cl] = s3;
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    s3 = wave_sum_d(s3);
+    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; red[2][wave] = s3; }
     __syncthreads();
-    if (kl != 0 || c >= C) return;
+    if (threadIdx.x != 0) return;
     s1 = s2 = s3 = 0.0;
-    for (int w = 0; w < 16; ++w) { s1 += red[0][w][cl]; s2 += red[1][w][cl]; s3 += red[2][w][cl]; }
+    for (int w = 0; w < TPB / 64; ++w) { s1 += red[0][w]; s2 += red[1][w]; s3 += red[2][w]; }
     const double n = (double)rows;
     const double m = s1 / n;
     double var = (s2 + s3 - n * m * m) / n;
@@ -1681,7 +1681,7 @@ extern "C" int rih_bn_stats_from_blocks(const float* part, int T, int C, int row
     if (!part || !mean || !invstd || T < 1 || C < 1 || rows < 1 || rows_per_block < 1) return RIH_EINVAL;
     if ((long long)(T - 1) * rows_per_block >= rows || (long long)T * rows_per_block < rows) return RIH_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return RIH_EINVAL;
-    hipLaunchKernelGGL(bn_blocks_final_kernel, dim3((C + 15) / 16), dim3(TPB), 0, STREAM, part, T, C, rows, rows_per_block, eps, momentum,
+    hipLaunchKernelGGL(bn_blocks_final_kernel, dim3(C), dim3(TPB), 0, STREAM, part, T, C, rows, rows_per_block, eps, momentum,
                        mean, invstd, running_mean, running_var);
     LAUNCH_RET();
 }
