@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $R/gpurun_out/pmc/traffic_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph --no-reference-loop > $R/gpurun_out/pmc/traffic_$c.log 2>&1
   f=$(find /tmp/pmc_$c -name "*counter_collection*.csv" | head -1)
   python - "$f" "$c" <<'PY' > $R/gpurun_out/pmc/traffic_$c.txt
 import csv, sys, collections
@@ -17,14 +17,18 @@ for r in csv.DictReader(open(f)):
     if r['Counter_Name'] != c:
         continue
     k = r['Kernel_Name']
-    name = k[k.index('gemm'):k.index('>') + 1] if 'gemm_' in k else ('other: ' + k.split('(')[0][-60:])
+    if 'maxpool_fwd' in k:
+        steps = globals().get('steps', 0) + 1       # one launch per step: the number of steps the collection saw
+    name = k[k.index('gemm'):k.index('>') + 1] if 'gemm_' in k else (('gemm-family ' + k[k.index('flash'):k.index('>') + 1]) if 'flash_' in k else ('other: ' + k.split('(')[0][-60:]))
     a = agg.setdefault(name, [0, 0.0])
     a[0] += 1
     a[1] += float(r['Counter_Value'])
 tot_g = sum(v[1] for k, v in agg.items() if k.startswith('gemm'))
 n_g = sum(v[0] for k, v in agg.items() if k.startswith('gemm'))
-print('%s (raw counter units as reported by rocprofv3; 3 bench steps incl. warm-up)' % c)
-print('rih_gemm kernels: launches %d total %.6g per-launch %.6g' % (n_g, tot_g, tot_g / max(n_g, 1)))
+steps = globals().get('steps', 0)
+print('%s (raw counter units as reported by rocprofv3); steps seen: %d' % (c, steps))
+print('GEMM family (rih_gemm, grouped launch, flash attention): launches %d total %.6g per-launch %.6g per-step %.6g'
+      % (n_g, tot_g, tot_g / max(n_g, 1), tot_g / max(steps, 1)))
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
     print('%12.6g  n=%5d  per-launch %10.5g  %s' % (v[1], v[0], v[1] / v[0], k))
 PY
