@@ -94,11 +94,17 @@ def test_flash_attention_kernels(case):
     G.test_flash_attention_equals_three_kernel_path(*case)
 
 
-@pytest.mark.parametrize('case', [(1, 40, 64, 4, 0.1, False), (3, 33, 64, 2, 0.05, False), (1, 70, 64, 4, 0.1, True),
-                                  (1, 45, 256, 4, 0.1, False)])
+@pytest.mark.parametrize('case', [(1, 40, 64, 4, 0.1, False), (3, 33, 64, 2, 0.05, False), (1, 70, 64, 4, 0.1, True)])
 def test_row_chain_kernel(case):
-    """csrc/rih_chain.hip: the attention block's row-wise sequences as one launch each way, against the standalone kernels."""
+    """csrc/rih_chain.hip: the attention block's row-wise sequences as one launch each way, against the standalone kernels
+    (D = 64 here: the D = 128 / 256 cases, 40-60 s each on the fiber harness, run in the GPU suite and under HIPCPU_MORE=1)."""
     G.test_attention_block_chains(*case)
+
+
+@pytest.mark.skipif(os.environ.get('HIPCPU_MORE', '0') != '1', reason='slow on the fiber harness; HIPCPU_MORE=1')
+def test_row_chain_kernel_wide_blocks():
+    G.test_attention_block_chains(2, 63, 128, 4, 0.0, False)
+    G.test_attention_block_chains(1, 20, 256, 4, 0.1, False)
 
 
 def test_graph_and_resampling_kernels():
