@@ -145,6 +145,30 @@ def mano_roofline(device, hands=4096, iters=20):
             'fwdbwd_us': r['fwdbwd_us'], 'fwdbwd_hands_per_s': r['fwdbwd_hands_per_s']}
 
 
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio when a communicator comes up
+    (buffered: it lands at process exit, i.e. BEHIND the JSON line, and every rank prints one), so file descriptor 1 is pointed
+    at stderr for the whole process -- Python's and every library's writes -- and the JSON line alone goes to the saved
+    descriptor (`emit`)."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    data = (json.dumps(obj) + '\n').encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def config5(args):
     """BASELINE configs[4]: inference only, batch 256, fp16-storage backbone (BatchNorm folded, f16 MFMA, fp32 accumulate; the
     mesh decoder and the MANO layer stay fp32), encoder + attention decoder + MANO layer on 2 x 256 hands captured in ONE
@@ -192,7 +216,7 @@ def config5(args):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     del keep
-    print(json.dumps({'metric': 'images/sec inference (encoder + attention decoder + MANO layer), batch 256 fp16, hipGraph',
+    emit({'metric': 'images/sec inference (encoder + attention decoder + MANO layer), batch 256 fp16, hipGraph',
                       'value': round(B * args.steps / el, 2), 'unit': 'images/sec', 'n_gpus': 1, 'steps': args.steps,
                       'warmup': args.warmup, 'ms_per_step': round(1000.0 * el / args.steps, 3), 'higher_is_better': True,
                       'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16 storage / f32 accumulate (backbone); f32 (decoder, MANO)',
@@ -200,7 +224,7 @@ def config5(args):
                       'config': {'workload': 'BASELINE configs[4]: inference-only, batch=%d, hipGraph-captured encoder + attention '
                                              'decoder + MANO layer (2 x %d hands) on 1 x MI355X' % (B, B),
                                  'vertices_rel_deviation_from_fp32_path': dev_err,
-                                 'mpjpe': 'deferred: needs the pretrained checkpoint and InterHand2.6M (licence-gated)'}}))
+                                 'mpjpe': 'deferred: needs the pretrained checkpoint and InterHand2.6M (licence-gated)'}})
 
 
 def main():
@@ -233,6 +257,7 @@ def main():
                     help='BASELINE configs[4] instead of the training step: batch-256 fp16-storage inference in one hipGraph')
     args = ap.parse_args()
     if args.config5:
+        claim_stdout()
         return config5(args)
     if args.batch is None:
         args.batch = 32 if args.encoder == 'hrnet32' else 64
@@ -249,6 +274,7 @@ def main():
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
                '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
         os.execv(sys.executable, cmd)
+    claim_stdout()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -270,7 +296,7 @@ def main():
         else:
             ranks = 1
         if rank == 0:
-            print(json.dumps({'spawn_probe': True, 'n_gpus': world, 'ranks_seen': ranks, 'gpus_arg': args.gpus}), flush=True)
+            emit({'spawn_probe': True, 'n_gpus': world, 'ranks_seen': ranks, 'gpus_arg': args.gpus})
         return
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (HIP kernels only, no CPU fallback)')
@@ -525,7 +551,7 @@ def main():
                 'comm_ms_exposed': (None if comm_exposed is None else round(comm_exposed, 3)),
                 'eager_reference_loop': eager_ref,
                 'roofline': roof, 'roofline_hbm': roof_hbm, 'roofline_mano': roof_mano, 'cpu_baseline': cpu}
-        print(json.dumps(line), flush=True)
+        emit(line)
     if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
