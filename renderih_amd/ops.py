@@ -257,8 +257,10 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
 # outlive the graph AND must not be allocated while a stream captures (the pinned allocator's event bookkeeping is illegal
 # there): the capturing code (renderih_amd.train.TrainStep) installs a `TableArena` -- pinned memory allocated before the
 # capture, sized from the table bytes its warm-up steps used (`TABLE_BYTES_STEP`) -- and the tables are carved out of it.
-GROUP_WGRAD = int(os.environ.get('RIH_WGRAD_GROUP', '1'))        # 0: off, 1: decoder-sized gradients, 2: every weight gradient
+GROUP_WGRAD = int(os.environ.get('RIH_WGRAD_GROUP', '2'))        # 0: off, 1: decoder-sized gradients only, 2: every weight gradient (default:
+#                                                                   same-box +2.3 % over 1 on ResNet50, +6 % on HRNet-W32, profiles/r03/ab/h*)
 GROUP_KCHUNK = int(os.environ.get('RIH_WGRAD_GROUP_KCHUNK', '1024'))      # pixels per split-K slice in a grouped launch
+GROUP_SORT = os.environ.get('RIH_WGRAD_GROUP_SORT', '1') == '1'
 TABLE_ARENA = None
 TABLE_BYTES_STEP = 0            # table bytes packed since the counter was last reset (TrainStep sizes its arena from it)
 
@@ -300,6 +302,10 @@ class GroupedGemms:
             by.setdefault(v, []).append((d, keep, fl))
         lib = _L()
         for v, group in sorted(by.items()):
+            if GROUP_SORT:
+                # longest blocks first (a block's run time ~ its reduction length): the launch's tail is then made of short
+                # blocks.  The order of the problems does not touch any problem's own summation order.
+                group.sort(key=lambda g: -(g[0].kchunk if g[0].splitk > 1 else g[0].K))
             n = len(group)
             arr = (GemmDesc * n)(*[g[0] for g in group])
             nbytes = int(lib.rih_gemm_multi_table_bytes(arr, n))
