@@ -64,7 +64,8 @@ class TrainStep:
         every later call (static buffers of the graphs).  process_group: None = default group if torch.distributed is
         initialised, False = no exchange.  record_order: optional list that receives ('stage', i) / ('reduce', i) in
         issue order (tests).  force_exchange: run the bucket copies and collectives even at world size 1 (exercises the
-        N > 1 path on one GPU)."""
+        N > 1 path on one GPU).  stages: True = three backward stages, False = one, 'auto' = three only when gradients are
+        exchanged (bench.py's choice: one stage is +1.2 % on a single rank, same-box A/B in profiles/r03/ab/)."""
         import torch.distributed as dist
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
         self.order = record_order
@@ -73,13 +74,15 @@ class TrainStep:
         if process_group is not False and dist.is_available() and dist.is_initialized():
             self.group = process_group
             self.world = dist.get_world_size(process_group)
-        self.groups = stage_parameter_groups(model) if stages else [[p for p in model.parameters() if p.requires_grad]]
-        self.nstage = len(self.groups)
         import os
         self.side_wgrad = (os.environ.get('RIH_SIDE_WGRAD', '0') == '1') if side_wgrad is None else bool(side_wgrad)
         self.defer_reduce = (os.environ.get('RIH_DEFER_REDUCE', '1') == '1') if defer_reduce is None else bool(defer_reduce)
         self.packs = ops.PackCache() if os.environ.get('RIH_PACK_CACHE', '1') == '1' else None
         self.exchange = self.world > 1 or (force_exchange and dist.is_available() and dist.is_initialized())
+        if stages == 'auto':                        # the stages exist to overlap the exchange; without one a single stage
+            stages = self.exchange                  # groups every weight gradient of the step into 4 launches instead of 12
+        self.groups = stage_parameter_groups(model) if stages else [[p for p in model.parameters() if p.requires_grad]]
+        self.nstage = len(self.groups)
         self.overlap = overlap and self.exchange
         self.img, self.labels = example_batch
         dev = self.img.device

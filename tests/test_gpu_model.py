@@ -394,9 +394,10 @@ def test_family_b_matches_fp64_oracle(training):
 
 
 # ------------------------------------------------------------------------------------------------ TrainStep helper
-@pytest.mark.parametrize('group', [0, 1, 2])
-def test_train_step_staged_graph_replay_matches_plain_backward(group, monkeypatch):
-    """renderih_amd.train.TrainStep (three backward stages, three hipGraphs sharing a pool, fused optimizer outside): the
+@pytest.mark.parametrize('group,stages', [(0, True), (1, True), (2, True), (0, 'auto'), (2, 'auto')])
+def test_train_step_staged_graph_replay_matches_plain_backward(group, stages, monkeypatch):
+    """renderih_amd.train.TrainStep (three backward stages, three hipGraphs sharing a pool, fused optimizer outside -- or, with
+    stages='auto' and no gradient exchange, ONE stage and one graph: bench.py's single-rank configuration): the
     gradients it leaves in `.grad` equal those of a plain eager `loss.backward()` on the same state, for the first and for a
     replayed step, and the set of grad-less parameters is unchanged.  group 0 (weight-gradient GEMMs launched one by
     one, same split-K plan): bit for bit.  group 1 / 2 (ops.GROUP_WGRAD: the stage's weight gradients in grouped launches with
@@ -418,8 +419,8 @@ def test_train_step_staged_graph_replay_matches_plain_backward(group, monkeypatc
     m2.decoder.unsample_layer.weight.requires_grad_(False)
     opt = torch.optim.SGD([p for p in m2.parameters() if p.requires_grad], lr=0.0)      # lr 0: the state stays put
     try:
-        step = TrainStep(m2, opt, lambda out, lab: scalar_loss(out), (img.clone(), {}), process_group=False)
-        assert step.use_graph and step.nstage == 3 and step.defer_reduce and step.packs is not None
+        step = TrainStep(m2, opt, lambda out, lab: scalar_loss(out), (img.clone(), {}), process_group=False, stages=stages)
+        assert step.use_graph and step.nstage == (3 if stages is True else 1) and step.defer_reduce and step.packs is not None
         first = None
         for rep in range(3):
             loss = step(img, {})
