@@ -13,7 +13,7 @@ stride-2 3x3 conv+BN(+ReLU on all but the last) of every higher resolution j<i, 
 """
 import torch.nn as nn
 
-from . import ops
+from . import ops, streams
 from .encoder import Bottleneck, conv, conv_bn
 
 # name -> (stage-1 bottlenecks, stage-1 width, [(modules, blocks per branch, widths), ...])   (hrnet.py:611-660)
@@ -93,29 +93,31 @@ class HighResolutionModule(nn.Module):
         self.relu = nn.ReLU(False)
 
     def forward(self, xs):
-        xs = [b(x) for b, x in zip(self.branches, xs)]
+        # the branches are independent until the fuse, and so are the fuse layer's output rows: each set forks onto side
+        # streams (streams.fork_join; the finest resolution -- the longest -- stays in the calling stream)
+        xs = streams.fork_join([(lambda b=b, x=x: b(x)) for b, x in zip(self.branches, xs)], reads=xs)
         if self.fuse_layers is None:
             return xs
         nb = len(xs)
-        out = []
-        for i in range(nb):
-            acc = None
-            for j in range(nb):
-                if j == i:
-                    acc = xs[j] if acc is None else ops.add_dropout(acc, xs[j])
-                elif j > i:
-                    f = self.fuse_layers[i][j]
-                    low = conv_bn(f[0], f[1], xs[j])
-                    acc = ops.nearest_up_add(low, acc, 2 ** (j - i))
-                else:
-                    chain = self.fuse_layers[i][j]
-                    y = xs[j]
-                    for k, cb in enumerate(chain):
-                        last = (k == len(chain) - 1)
-                        y = run_cbr(cb, y, residual=acc if last else None)     # the running sum rides in the last BN
-                    acc = y
-            out.append(ops.relu(acc))
-        return out
+        return streams.fork_join([(lambda i=i: self._fuse_row(i, xs)) for i in range(nb)], reads=[xs] * nb)
+
+    def _fuse_row(self, i, xs):
+        acc = None
+        for j in range(len(xs)):
+            if j == i:
+                acc = xs[j] if acc is None else ops.add_dropout(acc, xs[j])
+            elif j > i:
+                f = self.fuse_layers[i][j]
+                low = conv_bn(f[0], f[1], xs[j])
+                acc = ops.nearest_up_add(low, acc, 2 ** (j - i))
+            else:
+                chain = self.fuse_layers[i][j]
+                y = xs[j]
+                for k, cb in enumerate(chain):
+                    last = (k == len(chain) - 1)
+                    y = run_cbr(cb, y, residual=acc if last else None)     # the running sum rides in the last BN
+                acc = y
+        return ops.relu(acc)
 
 
 class HighResolutionNet(nn.Module):

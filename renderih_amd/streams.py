@@ -1,0 +1,74 @@
+"""Fork / join of independent launch sequences onto side HIP streams.
+
+HRNet's exchange unit (models/model_zoo/hrnet.py:102-238) is two to four BasicBlock chains that do not see each other until
+the fuse layer, and most of their kernels are smaller than the chip (a 64x64-tile GEMM of the 8x8 branch at B = 32 has 128
+workgroups for 256 CUs) or sit at the dependent-launch floor.  Run in one stream they serialize; forked onto side streams they
+overlap -- eagerly, and as parallel branches of the hipGraph when `train.TrainStep` captures the step (the fork / join events
+are captured like the kernels).  The backward needs nothing extra: autograd runs every node on the stream its forward ran on
+and orders (and `record_stream`s) the gradients that cross streams.
+
+Allocator safety: a tensor that crosses streams is `record_stream`ed on the stream that reads it, so its block is not handed
+out again before that reader has finished (under capture: not before the capture has ended)."""
+import os
+
+import torch
+
+# side streams per device; 0 = everything in the calling stream.  1 = the finest branch in the calling stream beside all coarser
+# ones in ONE side stream: measured +5 % on the HRNet-W32 step (profiles/r03/ab/g2_hrnet_side_streams_*.log).  3 (one stream
+# per branch) runs eagerly but the captured step died with a host-side SIGSEGV inside the HIP runtime on ROCm 7.0.2
+# (profiles/r03/ab/g2_hrnet_side3_segv.log) -- not the default until that is understood.
+SIDE = int(os.environ.get('RIH_SIDE_STREAMS', '1'))
+_POOL = {}
+
+
+def side_streams(device, n):
+    key = (device.type, device.index)
+    pool = _POOL.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
+def _tensors(r):
+    if torch.is_tensor(r):
+        return [r]
+    return [t for t in r if torch.is_tensor(t)] if r is not None else []
+
+
+def fork_join(thunks, reads=None):
+    """[thunk() for thunk in thunks], thunk 0 in the calling stream and thunks 1.. each in a side stream that starts after
+    everything enqueued so far and is joined before this returns.  reads[k]: the tensors thunk k reads.  With SIDE == 0, on
+    CPU tensors, or with a single thunk: a plain loop."""
+    n = len(thunks)
+    first = None
+    if reads is not None:
+        for r in reads:
+            for t in _tensors(r):
+                first = t
+                break
+            if first is not None:
+                break
+    if n < 2 or SIDE <= 0 or first is None or not first.is_cuda:
+        return [f() for f in thunks]
+    main = torch.cuda.current_stream(first.device)
+    streams = side_streams(first.device, min(SIDE, n - 1))
+    out = [None] * n
+    used = []
+    for k in range(1, n):                   # every side stream starts at THIS point of the calling stream ...
+        s = streams[(k - 1) % len(streams)]
+        if s not in used:
+            s.wait_stream(main)
+            used.append(s)
+    out[0] = thunks[0]()                    # ... and the thunks are issued in list order, so autograd's node order (and with it
+    for k in range(1, n):                   # the order in which gradients of shared inputs are summed) is the single-stream one
+        s = streams[(k - 1) % len(streams)]
+        with torch.cuda.stream(s):
+            for t in _tensors(reads[k]):
+                t.record_stream(s)
+            out[k] = thunks[k]()
+    for s in used:
+        main.wait_stream(s)
+    for k in range(1, n):
+        for t in _tensors(out[k]):
+            t.record_stream(main)
+    return out

@@ -196,6 +196,73 @@ def test_hrnet_matches_fp64_oracle(training):
         assert int(m.encoder.hrnet.bn1.num_batches_tracked) == 1
 
 
+def test_hrnet_side_streams_change_nothing(monkeypatch):
+    """renderih_amd.streams.fork_join: the HRNet exchange units with their branches and fuse rows forked onto side streams give
+    the same outputs and parameter gradients, bit for bit, as the single-stream order -- eagerly (twice, so that recycled
+    allocator blocks are exercised) and replayed from TrainStep's hipGraph (parallel graph branches)."""
+    from oracle.net_oracle import scalar_loss
+    from renderih_amd import ops, streams
+    from renderih_amd.train import TrainStep
+    img = testing.seeded_image(2, 17).cuda()
+
+    def run(side):
+        monkeypatch.setattr(streams, 'SIDE', side)
+        m, _ = _build(0.0, seed=5, encoder='hrnet32')
+        m.train()
+        outs = None
+        for _ in range(2):
+            m.zero_grad(set_to_none=True)
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.reset_running_stats()
+            out = m(img)
+            scalar_loss(out).backward()
+            torch.cuda.synchronize()
+            now = ({k: v.detach().clone() for k, v in testing.flatten_outputs(out).items()},
+                   {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+            if outs is not None:
+                for a, b in zip(outs, now):
+                    for k in a:
+                        assert torch.equal(a[k], b[k]), 'side=%d: second eager pass differs (%s)' % (side, k)
+            outs = now
+        return m, outs
+
+    _, (o0, g0) = run(0)
+    m3, (o3, g3) = run(streams.SIDE if streams.SIDE > 0 else 1)
+    assert set(g0) == set(g3)
+    for k in o0:
+        assert torch.equal(o0[k], o3[k]), k
+    for k in g0:
+        # (issue order = single-stream order, so autograd sums the gradients of shared inputs in the same order; the bar below
+        # is what a different summation order could cost, far under anything a race would leave)
+        err = float((g0[k] - g3[k]).abs().max())
+        assert err <= 2e-5 * float(g0[k].abs().max()), (k, err)
+    # the same model under TrainStep's graph (weight gradients grouped: round-off differs from the eager order, replays agree)
+    m3.zero_grad(set_to_none=True)
+    opt = torch.optim.SGD([p for p in m3.parameters() if p.requires_grad], lr=0.0)
+    try:
+        step = TrainStep(m3, opt, lambda out, lab: scalar_loss(out), (img.clone(), {}), process_group=False, stages='auto')
+        assert step.use_graph
+        first = None
+        for rep in range(3):
+            step(img, {})
+            torch.cuda.synchronize()
+            got = {k: p.grad.clone() for k, p in m3.named_parameters() if p.grad is not None}
+            assert set(got) == set(g0)
+            if first is None:
+                first = got
+                for k in g0:
+                    wk = k[:-len('bias')] + 'weight'
+                    floor = 1e-5 * float(g0[wk].abs().max()) if (k.endswith('.bias') and wk in g0) else 0.0
+                    err = float((got[k] - g0[k]).abs().max())
+                    assert err <= 1e-4 * float(g0[k].abs().max()) + floor, (k, err)
+            else:
+                for k in g0:
+                    assert torch.equal(got[k], first[k]), 'replay %d differs (%s)' % (rep, k)
+    finally:
+        ops.DROPOUT_SEED_TENSOR = None
+
+
 # ------------------------------------------------------------------------------------------------ hipGraph capture
 def _sgd_losses(m, img, steps, capture, dropout_seed=None, reducer=None):
     """`steps` plain-SGD steps on the scalar loss; forward+backward either launched eagerly or replayed from a hipGraph.

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session: run a list of named steps, each with its own timeout, logs under gpurun_out/<tag>/.
 #   tools/gpu_session.sh <tag> <step> [<step> ...]
-# Steps: pytest[:<-k expr>]  smoke  bench[:<extra args>]  ab:<ENV=VAL>[,<ENV=VAL>...]  prof  mano  hrnet  famb  dist1  infer
+# Steps: pytest[:<-k expr>]  smoke  bench[:<extra args>]  ab:<ENV=VAL>[,<ENV=VAL>...]  hrab:<ENV=VAL>[,...]  prof  mano  hrnet  famb  dist1  infer
 # `ab:` runs bench.py twice in the SAME process environment apart from the given variables (baseline first), for same-box A/B.
 cd "$(dirname "$0")/.." || exit 1
 R=$(pwd)
@@ -28,6 +28,10 @@ for step in "$@"; do
         done ;;
     famb) run bench_b python bench.py --family b --steps 10 --warmup 3 $QUICK; run bench_bmano python bench.py --family b-mano --steps 10 --warmup 3 $QUICK ;;
     hrnet) run bench_hrnet python bench.py --encoder hrnet32 --steps 10 --warmup 3 $QUICK ;;
+    hrab) for v in base $(echo "$arg" | tr ',' ' '); do
+          if [ "$v" = base ]; then run "hrab_base" python bench.py --encoder hrnet32 --steps 10 --warmup 3 $QUICK
+          else run "hrab_$(echo "$v" | tr -c 'A-Za-z0-9' _)" env $(echo "$v" | tr '+' ' ') python bench.py --encoder hrnet32 --steps 10 --warmup 3 $QUICK; fi
+        done ;;
     dist1) run bench_dist1 python bench.py --steps 10 --warmup 3 --force-dist $QUICK --no-roofline ;;
     mano) run mano_bench python tools/mano_bench.py --hands 128 4096 --json "$OUT/mano_bench.json" ;;
     infer) run infer_f16 python tools/infer_bench.py --fp16; run infer_f32 python tools/infer_bench.py ;;
