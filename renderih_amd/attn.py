@@ -12,7 +12,15 @@ import scipy.sparse as sp
 import torch
 import torch.nn as nn
 
-from . import ops
+import os
+
+from . import ops, streams
+
+# the image-grid encoders of the decoder in a side stream (DualGraphLayer.forward_pair); needs streams.SIDE > 0 as well.
+# Built, parity-tested (tests/test_gpu_model.py::test_decoder_side_stream_changes_nothing) and REFUTED by measurement: the
+# ResNet50 step is 1.4 % slower with it (36.56 against 36.03 ms same-box, profiles/r03/ab/g4_decoder_fork_*.log) -- ten
+# launch-floor kernels per level hidden, a fork / join pair per level and direction added to the graph -- so it is opt-in.
+DECODER_FORK = os.environ.get('RIH_DECODER_FORK', '0') == '1'
 
 
 def _xavier(layer):
@@ -433,8 +441,17 @@ class DualGraphLayer(nn.Module):
         _, B, V, D = X.shape
         assert V == self.verts_num and D == self.verts_in_dim
         X = ops.add_rows_bcast(X.reshape(2 * B, V, D), self.position_embeddings.weight).view(2, B, V, D)
-        X = GraphLayer.forward_pair(self.graph_left, self.graph_right, X, dc)
-        X = img_ex.forward_pair(self.img_ex_left, self.img_ex_right, img_f, X, dc)
+        # the image-grid encoder (patch convolution + a SelfAttn block on 64 tokens) reads only the feature map: it runs in a
+        # side stream beside the graph convolutions (streams.fork_join; issue order -- and with it the dropout seeds -- unchanged)
+        L, R = self.img_ex_left, self.img_ex_right
+        if DECODER_FORK:
+            X, grid = streams.fork_join([lambda: GraphLayer.forward_pair(self.graph_left, self.graph_right, X, dc),
+                                         lambda: img_feat_to_grid.forward_pair(L.encoder, R.encoder, img_f, dc)],
+                                        reads=[X, img_f])
+        else:
+            X = GraphLayer.forward_pair(self.graph_left, self.graph_right, X, dc)
+            grid = img_feat_to_grid.forward_pair(L.encoder, R.encoder, img_f, dc)
+        X = img_attn.forward_pair(L.attn, R.attn, X, grid, dc)
         return self.attn.forward_pair(X, dc)
 
 

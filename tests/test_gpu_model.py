@@ -391,6 +391,35 @@ def test_paired_decoder_equals_sequential_on_gpu(monkeypatch):
         assert_close(outs[True][k], outs[False][k], 1e-4, 1e-5, 'paired vs sequential ' + k)
 
 
+def test_decoder_side_stream_changes_nothing(monkeypatch):
+    """attn.DECODER_FORK: the decoder's image-grid encoders in a side stream beside the graph convolutions.  Same issue order, so
+    the dropout seeds and autograd's summation order are the single-stream ones: training-mode outputs and every parameter
+    gradient equal bit for bit, with dropout on."""
+    from oracle.net_oracle import scalar_loss
+    from renderih_amd import attn, ops, streams
+    assert streams.SIDE > 0
+    img = testing.seeded_image(2, 9).to('cuda:0')
+    res = {}
+    for fork in (False, True):
+        monkeypatch.setattr(attn, 'DECODER_FORK', fork)
+        m, _ = _build(0.05, seed=3)
+        m.train()
+        ops.DROPOUT_SEED_TENSOR = None
+        torch.manual_seed(1234)
+        for _ in range(2):                      # twice: the second pass runs on recycled allocator blocks
+            m.zero_grad(set_to_none=True)
+            out = m(img)
+            scalar_loss(out).backward()
+        torch.cuda.synchronize()
+        res[fork] = ({k: v.detach().clone() for k, v in testing.flatten_outputs(out).items()},
+                     {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    for k in res[False][0]:
+        assert torch.equal(res[False][0][k], res[True][0][k]), k
+    assert set(res[False][1]) == set(res[True][1])
+    for k in res[False][1]:
+        assert torch.equal(res[False][1][k], res[True][1][k]), k
+
+
 # ------------------------------------------------------------------------------ second model family (SURVEY 8f rank 1)
 def _build_b(dropout=0.0, seed=4):
     from renderih_amd import _lib

@@ -15,6 +15,7 @@ for step in "$@"; do
   kind=${step%%:*}; arg=""; [ "$kind" != "$step" ] && arg=${step#*:}
   case $kind in
     pytest) if [ -n "$arg" ]; then T=1500 run "pytest_$(echo "$arg" | tr -c 'A-Za-z0-9' _)" python -m pytest tests -q -m gpu -x -k "$arg"; else T=1800 run pytest_gpu python -m pytest tests -q -m gpu; fi ;;
+    pytestf) T=1500 run "pytestf_$(echo "$arg" | tr -c 'A-Za-z0-9' _)" python -m pytest $arg -q -m gpu -x ;;
     smoke) run smoke python __graft_entry__.py smoke ;;
     bench) run "bench$(echo "$arg" | tr -c 'A-Za-z0-9' _)" python bench.py --dump-gemm "$OUT/gemm_profile.json" $arg ;;
     ab) n=0; for v in base $(echo "$arg" | tr ',' ' '); do
