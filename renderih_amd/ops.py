@@ -261,6 +261,7 @@ GROUP_WGRAD = int(os.environ.get('RIH_WGRAD_GROUP', '2'))        # 0: off, 1: de
 #                                                                   same-box +2.3 % over 1 on ResNet50, +6 % on HRNet-W32, profiles/r03/ab/h*)
 GROUP_KCHUNK = int(os.environ.get('RIH_WGRAD_GROUP_KCHUNK', '1024'))      # pixels per split-K slice in a grouped launch
 GROUP_SORT = os.environ.get('RIH_WGRAD_GROUP_SORT', '1') == '1'
+GROUP_T128 = int(os.environ.get('RIH_WGRAD_GROUP_T128', '0'))      # > 0: grouped gradients with both output dims >= this use 128x128 tiles
 TABLE_ARENA = None
 TABLE_BYTES_STEP = 0            # table bytes packed since the counter was last reset (TrainStep sizes its arena from it)
 
@@ -536,6 +537,11 @@ def _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin
     collect = None
     if _DEFERRED_GEMM is not None and tile in (0, 2) and (GROUP_WGRAD >= 2 or nb > 1 or small):
         collect = _DEFERRED_GEMM
+        if GROUP_T128 and tile == 2 and Ncols >= GROUP_T128 and Mrows >= GROUP_T128:
+            # the 64x64 choice above is a standalone-launch optimum (more resident slices); inside a grouped launch the chip is
+            # full anyway and a 128x128 tile reads half the operand bytes per product
+            tile = 0
+            bm, bn = _TILE_MN[tile]
         splitk = max(1, min(splitk, _cdiv(Kpix, GROUP_KCHUNK)))
     kchunk = _cdiv(_cdiv(Kpix, splitk), 32) * 32
     splitk = _cdiv(Kpix, kchunk)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session: run a list of named steps, each with its own timeout, logs under gpurun_out/<tag>/.
 #   tools/gpu_session.sh <tag> <step> [<step> ...]
-# Steps: pytest[:<-k expr>]  smoke  bench[:<extra args>]  ab:<ENV=VAL>[,<ENV=VAL>...]  hrab:<ENV=VAL>[,...]  prof  mano  hrnet  famb  dist1  infer
+# Steps: pytest[:<-k expr>]  pytestn[:<workers>] (whole GPU suite, pytest-xdist)  pytestf:<file>  smoke  bench[:<extra args>]  ab:<ENV=VAL>[,<ENV=VAL>...]  hrab:<ENV=VAL>[,...]  prof  mano  hrnet  famb  dist1  infer
 # `ab:` runs bench.py twice in the SAME process environment apart from the given variables (baseline first), for same-box A/B.
 cd "$(dirname "$0")/.." || exit 1
 R=$(pwd)
@@ -16,6 +16,9 @@ for step in "$@"; do
   case $kind in
     pytest) if [ -n "$arg" ]; then T=1500 run "pytest_$(echo "$arg" | tr -c 'A-Za-z0-9' _)" python -m pytest tests -q -m gpu -x -k "$arg"; else T=1800 run pytest_gpu python -m pytest tests -q -m gpu; fi ;;
     pytestf) T=1500 run "pytestf_$(echo "$arg" | tr -c 'A-Za-z0-9' _)" python -m pytest $arg -q -m gpu -x ;;
+    # (measured: 6 xdist workers on ONE GPU are SLOWER than the serial suite -- 141 of 295 tests in 540 s against 410-460 s for
+    # all of them -- the oracle's fp64 CPU runs oversubscribe the host threads; kept for boxes with more than one GPU)
+    pytestn) T=1500 run "pytest_gpu_n${arg:-6}" python -m pytest tests -q -m gpu -n "${arg:-6}" ;;
     smoke) run smoke python __graft_entry__.py smoke ;;
     bench) run "bench$(echo "$arg" | tr -c 'A-Za-z0-9' _)" python bench.py --dump-gemm "$OUT/gemm_profile.json" $arg ;;
     ab) n=0; for v in base $(echo "$arg" | tr ',' ' '); do
