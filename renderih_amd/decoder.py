@@ -38,6 +38,8 @@ class GCN_vert_convert():
 
 
 class decoder(nn.Module):
+    drops_last_fmap = True              # forward() never reads fmaps[-1] (models/decoder.py:130)
+
     def __init__(self, global_feature_dim=2048, f_in_Dim=[256, 256, 256, 256], f_out_Dim=[128, 64, 32],
                  gcn_in_dim=[256, 128, 128], gcn_out_dim=[128, 128, 64], graph_k=2, graph_layer_num=4,
                  left_graph_dict={}, right_graph_dict={}, vertex_num=778, dense_coor=None, num_attn_heads=4,

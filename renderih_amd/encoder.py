@@ -271,6 +271,7 @@ def conv1x1(in_channels, out_channels):
 
 class resnet_mid(nn.Module):
     """models/encoder.py:129-173."""
+    supports_drop_last = True           # forward(..., drop_last=True), see there
 
     def __init__(self, model_type='resnet50', in_fmapDim=(256, 256, 256, 256), out_fmapDim=(256, 256, 256, 256)):
         super().__init__()
@@ -286,13 +287,33 @@ class resnet_mid(nn.Module):
     def get_info(self):
         return {'global_feature_dim': self.global_feature_dim, 'fmaps_dim': self.fmaps_dim}
 
-    def forward(self, img_fmaps, hms_fmaps, dp_fmaps):
+    def forward(self, img_fmaps, hms_fmaps, dp_fmaps, drop_last=False):
+        """drop_last (not in the reference's signature; HandNET_GCN.forward passes it when RIH_SKIP_DEAD_MID=1): the caller
+        will not read fmaps[-1] -- `decoder.forward` drops it (models/decoder.py:130; SURVEY a4: 1.07 of the path's 17.7
+        GFLOP per image) and no gradient reaches `convs.3`.  What that branch still owes then is its BatchNorm's
+        running statistics in training mode (they are in the state_dict): the convolution and its statistics run, the apply
+        pass does not; in eval mode nothing runs.  The slot holds None."""
         gf = ops.global_avgpool(img_fmaps[0])
         fmaps = []
+        last = len(self.convs) - 1
         for i, seq in enumerate(self.convs):
+            bn = seq[2]
+            if drop_last and i == last and not bn.training:
+                fmaps.append(None)
+                continue
             parts = [hms_fmaps[i], dp_fmaps[i]] + ([img_fmaps[i]] if i > 0 else [])
             x = torch.cat(parts, dim=-1)                     # channel concat = last dim in NHWC (pure copy)
-            fmaps.append(conv_bn(seq[0], seq[2], x, conv_relu=True))
+            if drop_last and i == last:
+                with torch.no_grad():
+                    holder = ops.StatsHolder() if ops.GEMM_STATS else None
+                    y = ops.conv2d(x, seq[0].weight, seq[0].bias, stride=1, pad=0, relu=True, stats=holder)
+                    stats = ('blocks', holder.part, holder.T, holder.rows) if (holder is not None and holder.part is not None) else None
+                    ops.batchnorm_update_only(y, bn.running_mean, bn.running_var, eps=bn.eps, momentum=bn.momentum, tile_stats=stats)
+                if bn.num_batches_tracked is not None:
+                    _PENDING_TRACKED.append(bn.num_batches_tracked)
+                fmaps.append(None)
+                continue
+            fmaps.append(conv_bn(seq[0], bn, x, conv_relu=True))
         flush_batches_tracked()
         return gf, fmaps
 

@@ -249,6 +249,7 @@ class HalfBackbone:
             zero_page(encoder.resnet.conv1.weight.device)
         self.handNum = encoder.handNum
         self.fdim = [st[1].Cout for st in self.hms.stages]                       # 256 x 4
+        self.drop_last = False          # set by HandNET_GCN.use_fp16_backbone when its decoder never reads fmaps[-1]
 
     @torch.no_grad()
     def __call__(self, img):
@@ -265,7 +266,10 @@ class HalfBackbone:
         hms = self.hms(x1, [cats[i][..., :f[i]] for i in range(4)])
         out = self.dp(x1, [cats[i][..., f[i]:2 * f[i]] for i in range(4)])
         gf = global_avgpool(x1)
-        fmaps = [pc(cats[i], relu=True, out_f32=True) for i, pc in enumerate(self.mid)]
+        # (model.SKIP_DEAD_MID, opt-in: `decoder.forward` drops the finest map -- 275 GFLOP and a 1 GB fp32 store at B = 256)
+        from . import model as _model
+        last = len(self.mid) - 1 if (_model.SKIP_DEAD_MID and self.drop_last) else -1
+        fmaps = [None if i == last else pc(cats[i], relu=True, out_f32=True) for i, pc in enumerate(self.mid)]
         mask = ops.nhwc_to_nchw(out, 0, self.handNum)
         dp = ops.nhwc_to_nchw(out, self.handNum, out.shape[-1])
         return ops.nhwc_to_nchw(hms), mask, dp, gf, fmaps

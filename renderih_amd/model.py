@@ -14,6 +14,11 @@ from .encoder import load_encoder, flush_batches_tracked
 from .decoder import decoder as Decoder
 
 
+# Opt-in (built after the round's GPU budget was spent: parity-tested on the CPU harnesses, not yet on the GPU): leave out the
+# work of the finest mid convolution whose output `decoder.forward` drops (encoder.resnet_mid.forward, `drop_last`).
+SKIP_DEAD_MID = os.environ.get('RIH_SKIP_DEAD_MID', '0') == '1'
+
+
 class HandNET_GCN(nn.Module):
     def __init__(self, encoder, mid_model, decoder):
         super().__init__()
@@ -30,6 +35,7 @@ class HandNET_GCN(nn.Module):
         if enable:
             from .half import HalfBackbone
             self._half = HalfBackbone(self.encoder, self.mid_model)
+            self._half.drop_last = bool(getattr(self.decoder, 'drops_last_fmap', False))
         else:
             self._half = None
         return self
@@ -39,7 +45,10 @@ class HandNET_GCN(nn.Module):
             hms, mask, dp, global_feature, fmaps = self._half(img)
         else:
             hms, mask, dp, img_fmaps, hms_fmaps, dp_fmaps = self.encoder(img)
-            global_feature, fmaps = self.mid_model(img_fmaps, hms_fmaps, dp_fmaps)
+            if SKIP_DEAD_MID and getattr(self.mid_model, 'supports_drop_last', False) and getattr(self.decoder, 'drops_last_fmap', False):
+                global_feature, fmaps = self.mid_model(img_fmaps, hms_fmaps, dp_fmaps, drop_last=True)
+            else:
+                global_feature, fmaps = self.mid_model(img_fmaps, hms_fmaps, dp_fmaps)
             flush_batches_tracked()
         result, paramsDict, handDictList, otherInfo = self.decoder(global_feature, fmaps)
         if hms is not None:

@@ -1054,6 +1054,30 @@ class BatchNormFn(torch.autograd.Function):
         return dx, dg, db, None, None, dres, None, None, None, None, None, None
 
 
+def batchnorm_update_only(x, rmean, rvar, eps=1e-5, momentum=0.1, tile_stats=None):
+    """The side effect of a training-mode nn.BatchNorm2d WITHOUT its output: batch statistics of x (from the producing GEMM's
+    epilogue blocks when `tile_stats` carries them, by a statistics pass otherwise) folded into the running buffers exactly as
+    BatchNormFn.forward does.  For a BatchNorm whose output nobody reads (encoder.resnet_mid, `drop_last`)."""
+    _chk(x, rmean, rvar)
+    x = _c(x)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    lib = _L()
+    with torch.no_grad():
+        mean = torch.empty((Cc,), device=x.device, dtype=torch.float32)
+        invstd = torch.empty((Cc,), device=x.device, dtype=torch.float32)
+        if tile_stats is not None and tile_stats[0] == 'blocks':
+            _, part, T, rpb = tile_stats
+            assert part.shape[2] == Cc
+            check(lib.rih_bn_stats_from_blocks(part.data_ptr(), T, Cc, rows, rpb, eps, momentum, mean.data_ptr(),
+                                               invstd.data_ptr(), _p(rmean), _p(rvar), _stream()), 'rih_bn_stats_from_blocks')
+        else:
+            assert tile_stats is None
+            ws = torch.empty((int(lib.rih_bn_ws_floats(rows, Cc)),), device=x.device, dtype=torch.float32)
+            check(lib.rih_bn_stats(x.data_ptr(), rows, Cc, eps, momentum, mean.data_ptr(), invstd.data_ptr(),
+                                   _p(rmean), _p(rvar), ws.data_ptr(), _stream()), 'rih_bn_stats')
+
+
 def batchnorm(x, gamma, beta, rmean, rvar, residual=None, training=True, relu=False, eps=1e-5, momentum=0.1, tile_stats=None,
               input_relu=False):
     """input_relu: x is the output of a ReLU (Conv -> ReLU -> BN); the gradient wrt x then leaves already gated by x > 0."""

@@ -217,6 +217,46 @@ def test_model_host_logic_matches_oracle():
     assert int(m.encoder.resnet.bn1.num_batches_tracked) == 1
 
 
+def test_dead_mid_convolution_skip_host_logic():
+    """encoder.resnet_mid.forward(drop_last=True) (RIH_SKIP_DEAD_MID, see tests/test_gpu_model.py for the whole model on the
+    GPU) on the emulated ABI, module alone on small maps: the three live feature maps, the global feature, their gradients
+    and every buffer -- the dropped branch's BatchNorm running statistics included -- equal the full computation."""
+    from renderih_amd.encoder import resnet_mid
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    img_f = [torch.randn(B, s, s, c, generator=g) for s, c in zip((1, 2, 4, 8), (2048, 1024, 512, 256))]
+    hms_f = [torch.randn(B, s, s, 128, generator=g) for s in (1, 2, 4, 8)]
+    dp_f = [torch.randn(B, s, s, 128, generator=g) for s in (1, 2, 4, 8)]
+    ref = resnet_mid('resnet50', in_fmapDim=[128] * 4, out_fmapDim=[256] * 4)
+    sd = testing.deterministic_state(ref.state_dict(), seed=2)
+    res = {}
+    for drop in (False, True):
+        m = resnet_mid('resnet50', in_fmapDim=[128] * 4, out_fmapDim=[256] * 4)
+        m.load_state_dict(sd)
+        m.train()
+        ins = [[t.clone().requires_grad_() for t in lst] for lst in (img_f, hms_f, dp_f)]
+        gf, fm = m(*ins, drop_last=True) if drop else m(*ins)
+        assert len(fm) == 4 and (fm[3] is None) == drop
+        (gf.sum() + sum((f * f).sum() for f in fm[:3])).backward()
+        out = [gf.detach().clone()] + [f.detach().clone() for f in fm[:3]]
+        grads = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        dins = [t.grad.clone() for lst in ins for t in lst if t.grad is not None]
+        state = {k: v.clone() for k, v in m.state_dict().items()}
+        m.eval()
+        with torch.no_grad():
+            gf2, fm2 = m(img_f, hms_f, dp_f, drop_last=True) if drop else m(img_f, hms_f, dp_f)
+        assert (fm2[3] is None) == drop
+        res[drop] = (out, grads, dins, state, [gf2] + list(fm2[:3]))
+    full, lean = res[False], res[True]
+    assert int(full[3]['convs.3.2.num_batches_tracked']) == 1 and float(full[3]['convs.3.2.running_mean'].abs().max()) > 0
+    assert set(full[1]) == set(lean[1]) and not any(k.startswith('convs.3.') for k in full[1])      # SURVEY N4
+    for a, b in zip(full[0] + full[2] + full[4], lean[0] + lean[2] + lean[4]):
+        assert torch.equal(a, b)
+    for part in (1, 3):
+        for k in full[part]:
+            assert torch.equal(full[part][k], lean[part][k]), k
+
+
 def test_family_b_host_logic_matches_oracle():
     """Second model family (renderih_amd/lijun.py = common/myhand/lijun_model_graph.HandNET_GCN), B=2, train mode,
     dropout 0: forward outputs and all parameter gradients against the oracle, fp64-anchored like the first family."""

@@ -420,6 +420,46 @@ def test_decoder_side_stream_changes_nothing(monkeypatch):
         assert torch.equal(res[False][1][k], res[True][1][k]), k
 
 
+def _dead_mid_check(device, monkeypatch):
+    """model.SKIP_DEAD_MID (RIH_SKIP_DEAD_MID=1): the finest mid convolution, whose output `decoder.forward` drops
+    (models/decoder.py:130), reduced to what it still owes -- its BatchNorm's running statistics in training mode, nothing in
+    eval mode.  Outputs, parameter gradients and EVERY buffer of the state_dict equal the full computation bit for bit."""
+    from oracle.net_oracle import scalar_loss
+    from renderih_amd import model as model_mod
+    from renderih_amd.model import build_model
+    img = testing.seeded_image(2, 21).to(device)
+    res = {}
+    for skip in (False, True):
+        monkeypatch.setattr(model_mod, 'SKIP_DEAD_MID', skip)
+        m = build_model(0.0)
+        m.load_state_dict(testing.deterministic_state(m.state_dict(), seed=8))
+        m = m.to(device)
+        m.train()
+        out = m(img)
+        scalar_loss(out).backward()
+        train_out = {k: v.detach().clone() for k, v in testing.flatten_outputs(out).items()}
+        grads = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        m.eval()
+        with torch.no_grad():
+            eval_out = {k: v.clone() for k, v in testing.flatten_outputs(m(img)).items()}
+        res[skip] = (train_out, grads, state, eval_out)
+    full, lean = res[False], res[True]
+    assert int(full[2]['mid_model.convs.3.2.num_batches_tracked']) == 1
+    assert not torch.equal(full[2]['mid_model.convs.3.2.running_mean'], torch.zeros_like(full[2]['mid_model.convs.3.2.running_mean']))
+    for a, b, what in zip(full, lean, ('train output', 'gradient', 'state_dict entry', 'eval output')):
+        assert set(a) == set(b), what
+        for k in a:
+            assert torch.equal(a[k], b[k]), '%s %s differs with the dead mid convolution skipped' % (what, k)
+
+
+@pytest.mark.skipif(os.environ.get('RIH_SKIP_DEAD_MID', '0') != '1',
+                    reason='opt-in feature (RIH_SKIP_DEAD_MID=1), built after the round-3 GPU budget was spent: its host logic is '
+                           'covered on the emulated ABI (tests/test_cpu_emulated.py); run with the flag set to check it on the GPU')
+def test_dead_mid_convolution_skip_changes_nothing(monkeypatch):
+    _dead_mid_check('cuda:0', monkeypatch)
+
+
 # ------------------------------------------------------------------------------ second model family (SURVEY 8f rank 1)
 def _build_b(dropout=0.0, seed=4):
     from renderih_amd import _lib

@@ -192,6 +192,33 @@ def test_half_backbone_host_logic():
         backbone_vs_fp32(torch.device('cpu'))
 
 
+def test_half_backbone_dead_mid_skip_host_logic(monkeypatch):
+    """model.SKIP_DEAD_MID (opt-in) on the inference paths, emulated ABI: with the finest mid convolution left out (its slot
+    holds None; `decoder.forward` never reads it, models/decoder.py:130) the model's outputs are bit-identical -- through the
+    fp16-storage backbone and through the fp32 modules in eval mode."""
+    from abi_emulator import emulated_abi
+    from renderih_amd import model as model_mod, testing
+    with emulated_abi():
+        m = tiny_model()
+        img = testing.seeded_image(1, 6)
+        outs = {}
+        for skip in (False, True):
+            monkeypatch.setattr(model_mod, 'SKIP_DEAD_MID', skip)
+            with torch.no_grad():
+                fp32 = testing.flatten_outputs(m(img))
+                m.use_fp16_backbone()
+                assert m._half.drop_last
+                fmaps = m._half(img)[4]
+                assert (fmaps[3] is None) == skip and all(f is not None for f in fmaps[:3])
+                f16 = testing.flatten_outputs(m(img))
+                m.use_fp16_backbone(False)
+            outs[skip] = (fp32, f16)
+        for a, b in zip(outs[False], outs[True]):
+            assert set(a) == set(b)
+            for k in a:
+                assert torch.equal(a[k], b[k]), k
+
+
 @pytest.mark.skipif(os.environ.get('HIPCPU_MORE', '0') != '1', reason='3.5 min on the fiber harness: run with HIPCPU_MORE=1')
 def test_half_backbone_kernels_on_cpu():
     """The whole folded backbone dataflow with one bottleneck per stage (stem, pool, bottlenecks with in-place concat slices, aux decoders, mid convs,

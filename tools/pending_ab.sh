@@ -1,0 +1,21 @@
+#!/bin/bash
+# The experiments that were BUILT but not measured when round 3 ran out of GPU minutes, as one GPU-box session (~6 min):
+#   /usr/local/graft/bin/gpurun --timeout 600 -- 'bash tools/pending_ab.sh'
+# 1. RIH_SKIP_DEAD_MID=1 -- the finest mid convolution, whose output decoder.forward drops: the gated GPU
+#    parity test, then the training step and the fp16 inference step (--config5) with and without it.
+# 2. RIH_WGRAD_GROUP_T128=128 / 256 -- 128x128 tiles for the large grouped weight gradients (item 3b).
+# Each bench line is the last line of its log under gpurun_out/pending/.
+cd "$(dirname "$0")/.." || exit 1
+OUT=gpurun_out/pending
+mkdir -p "$OUT"
+Q="--steps 20 --warmup 5 --no-cpu-baseline --no-reference-loop --no-roofline"
+run() { name=$1; shift; echo "== $name: $*"; ( timeout 600 "$@" ) > "$OUT/$name.log" 2>&1; echo "   exit $?"; tail -n 1 "$OUT/$name.log" | cut -c1-260; }
+run pytest_dead_mid env RIH_SKIP_DEAD_MID=1 python -m pytest tests -q -m gpu -x -k "dead_mid or model_eval_matches or model_train_matches or fp16_backbone"
+run train_base python bench.py $Q
+run train_skip_dead_mid env RIH_SKIP_DEAD_MID=1 python bench.py $Q
+run train_t128 env RIH_WGRAD_GROUP_T128=128 python bench.py $Q
+run train_t256 env RIH_WGRAD_GROUP_T128=256 python bench.py $Q
+run train_base2 python bench.py $Q
+run config5_base python bench.py --config5
+run config5_skip_dead_mid env RIH_SKIP_DEAD_MID=1 python bench.py --config5
+echo done
