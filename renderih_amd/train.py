@@ -84,6 +84,12 @@ class TrainStep:
         self.groups = stage_parameter_groups(model) if stages else [[p for p in model.parameters() if p.requires_grad]]
         self.nstage = len(self.groups)
         self.overlap = overlap and self.exchange
+        if self.overlap and self.img_is_cuda(example_batch):
+            # the all-reduce already runs beside the backward in its own stream; a captured step with a THIRD concurrent branch
+            # (streams.fork_join's side stream, HRNet) died inside the HIP runtime on ROCm 7.0.2, so the model's own
+            # side streams are off in a process that exchanges gradients
+            from . import streams
+            streams.SIDE = 0
         self.img, self.labels = example_batch
         dev = self.img.device
         self.cuda = dev.type == 'cuda'
@@ -106,6 +112,10 @@ class TrainStep:
             self._capture()
 
     # ------------------------------------------------------------------ pieces
+    @staticmethod
+    def img_is_cuda(example_batch):
+        return bool(getattr(example_batch[0], 'is_cuda', False))
+
     def _grab(self, module, inputs, output):
         """Forward hook on the trunk, active only inside this helper's own forward: hands DETACHED aliases of the four
         feature maps to the rest of the network, so that stage 1 yields only the gradients that enter the trunk from
