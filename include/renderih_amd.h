@@ -286,6 +286,18 @@ int rih_bn_bwd(const float* dy, const float* x, const float* y, const float* mea
                const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C,
                int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, void* stream);
 
+/* One launch less per statistics pass and per backward ("last block done", ABI 11): the reduction pass publishes its partial sums
+ * and the last workgroup of each channel slice finishes the slice, with the arithmetic of the stand-alone finishing kernels
+ * (bit-identical results).  counters: >= rih_bn_ncounters(rows, C) uint32, ZERO before the first use; the kernels leave them
+ * zero, so a caller keeps one zero-initialised pool and hands every call that may run concurrently (other stream, other graph
+ * node) its own slice.  Everything else as rih_bn_stats / rih_bn_bwd. */
+int rih_bn_ncounters(int rows, int C);
+int rih_bn_stats_lastblock(const float* x, int rows, int C, float eps, float momentum, float* mean, float* invstd,
+                           float* running_mean, float* running_var, float* ws, uint32_t* counters, void* stream);
+int rih_bn_bwd_lastblock(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                         const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C,
+                         int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, uint32_t* counters, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Row-wise ops on [rows][D] matrices (decoder)                                                         */
 /* y = act(LayerNorm(x (+ x2)) * g + b); saves mean/rstd per row   (nn.LayerNorm eps=1e-6, gcn.py:91-97 ...) */
@@ -462,7 +474,7 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
  * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of EVERY by-pointer struct, in
  * this order: gemm desc, mano model, mesh topo, hconv desc, gemm p3 desc, reduce desc, pack desc, ln final desc, adam entry,
  * chain desc (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it mis-laid-out structs. */
-#define RIH_ABI_VERSION 10
+#define RIH_ABI_VERSION 11
 #define RIH_ABI_NSIZES 10
 int rih_version(void);
 int rih_abi_sizes(int32_t* out10);

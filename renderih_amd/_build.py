@@ -14,7 +14,7 @@ OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'librenderih_amd.so')
 SOURCES = ['rih_gemm.hip', 'rih_gemm3.hip', 'rih_elem.hip', 'rih_mano.hip', 'rih_loss.hip', 'rih_metrics.hip',
            'rih_pose.hip', 'rih_attn.hip', 'rih_flash.hip', 'rih_chain.hip', 'rih_half.hip', 'rih_input.hip', 'rih_sdf.hip']
-HEADERS = ['rih_procrustes.h', 'rih_pose_math.h', 'rih_hash.h']
+HEADERS = ['rih_procrustes.h', 'rih_pose_math.h', 'rih_hash.h', 'rih_bn_bwd_partial.inc']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result',
          # hipcc's SLP pass packs neighbouring f32 adds into v_pk_add_f32, which issues at a fraction of the scalar
          # rate next to MFMAs (MI355X_MICROARCH.md, cycle constants): keep the split arithmetic scalar

@@ -361,8 +361,8 @@ __device__ __forceinline__ void block_col_reduce(float4 (&v)[NV], int cg, int ry
 }
 
 // BN training statistics, pass 1: shifted sums  sum(x - x0), sum((x - x0)^2) per chunk, x0 = first row
-__global__ __launch_bounds__(TPB) void bn_stats_partial_kernel(const float* __restrict__ x, int rows, int C, int cgb,
-                                                               int rt, int rows_per_chunk, float* __restrict__ ws) {
+__device__ __forceinline__ void bn_stats_partial_body(const float* __restrict__ x, int rows, int C, int cgb,
+                                                      int rt, int rows_per_chunk, float* __restrict__ ws) {
     const int cg = threadIdx.x % cgb, ry = threadIdx.x / cgb;
     const int g = blockIdx.x * cgb + cg;
     const int CG = C / 4;
@@ -393,6 +393,30 @@ __global__ __launch_bounds__(TPB) void bn_stats_partial_kernel(const float* __re
         *reinterpret_cast<float4*>(ws + ((long long)0 * nchunk + chunk) * C + g * 4) = acc[0];
         *reinterpret_cast<float4*>(ws + ((long long)1 * nchunk + chunk) * C + g * 4) = acc[1];
     }
+}
+__global__ __launch_bounds__(TPB) void bn_stats_partial_kernel(const float* __restrict__ x, int rows, int C, int cgb,
+                                                               int rt, int rows_per_chunk, float* __restrict__ ws) {
+    bn_stats_partial_body(x, rows, C, cgb, rt, rows_per_chunk, ws);
+}
+
+// "Last block done" (rih_bn_stats_lastblock / rih_bn_bwd_lastblock): the grid of a column reduction is (channel slices, row
+// chunks); every block publishes its partial sums, takes a ticket on its slice's counter, and the block that draws the last
+// ticket finishes the slice -- the same per-channel arithmetic as the stand-alone finishing kernels, so the results are
+// bit-identical, without the second launch (~4.5 us of dependent-launch floor per BatchNorm and direction).  The counter
+// is left at zero for the next launch that is handed the slot.
+__device__ __forceinline__ bool column_slice_done(unsigned* __restrict__ counters) {
+    __shared__ int s_last;
+    __threadfence();                        // this block's partial sums are visible device-wide before its ticket
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = atomicAdd(&counters[blockIdx.x], 1u);
+        s_last = (t == gridDim.y - 1u) ? 1 : 0;
+        if (s_last) counters[blockIdx.x] = 0u;
+    }
+    __syncthreads();
+    const bool last = s_last != 0;
+    if (last) __threadfence();              // ... and the other blocks' sums are visible to this one after the last ticket
+    return last;
 }
 
 // one wavefront per channel: lanes stride over the chunk partials, fp64 xor-shuffle reduction
@@ -504,6 +528,41 @@ __global__ __launch_bounds__(TPB) void bn_blocks_final_kernel(const float* __res
     }
 }
 
+// statistics pass + finish in one launch: bn_stats_partial_kernel, then bn_stats_final_kernel's arithmetic for the channels of
+// this block's slice, done by the last block of the slice (waves take the slice's channels in turn)
+__global__ __launch_bounds__(TPB) void bn_stats_lastblock_kernel(const float* __restrict__ x, int rows, int C, int cgb, int rt,
+                                                                 int rows_per_chunk, float* __restrict__ ws,
+                                                                 unsigned* __restrict__ counters, float eps, float momentum,
+                                                                 float* __restrict__ mean, float* __restrict__ invstd,
+                                                                 float* __restrict__ rmean, float* __restrict__ rvar) {
+    bn_stats_partial_body(x, rows, C, cgb, rt, rows_per_chunk, ws);
+    if (!column_slice_done(counters)) return;
+    const int lane = threadIdx.x & 63, nchunk = gridDim.y;
+    const int c0 = blockIdx.x * cgb * 4, c1 = min(C, c0 + cgb * 4);
+    for (int c = c0 + (threadIdx.x >> 6); c < c1; c += TPB / 64) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = lane; k < nchunk; k += 64) {
+            s1 += (double)ws[((long long)0 * nchunk + k) * C + c];
+            s2 += (double)ws[((long long)1 * nchunk + k) * C + c];
+        }
+        s1 = wave_sum_d(s1);
+        s2 = wave_sum_d(s2);
+        if (lane != 0) continue;
+        const double n = (double)rows;
+        const double d = s1 / n;
+        const double m = (double)x[c] + d;
+        double var = s2 / n - d * d;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)m;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (rmean != nullptr) {
+            const double unb = (rows > 1) ? var * n / (n - 1.0) : var;
+            rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * m);
+            rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+        }
+    }
+}
+
 // BN backward pass 1: per-channel sum(dym), sum(dym * xhat), dym = dy * (y>0) when relu
 __global__ __launch_bounds__(TPB) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ y,
@@ -512,70 +571,33 @@ __global__ __launch_bounds__(TPB) void bn_bwd_partial_kernel(const float* __rest
                                                              int rt, int rows_per_chunk, int relu,
                                                              float* __restrict__ ws,
                                                              const unsigned char* __restrict__ mask) {
-    const int cg = threadIdx.x % cgb, ry = threadIdx.x / cgb;
-    const int g = blockIdx.x * cgb + cg;
-    const int CG = C / 4;
-    const int chunk = blockIdx.y, nchunk = gridDim.y;
-    float4 acc[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-    if (g < CG) {
-        const float4 m = reinterpret_cast<const float4*>(mean)[g];
-        const float4 is = reinterpret_cast<const float4*>(invstd)[g];
-        const int r0 = chunk * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
-        auto gate = [&](float4& d, const float4 yy, unsigned bits) {
-            if (mask != nullptr) {
-                if (!(bits & 1u)) d.x = 0.f;
-                if (!(bits & 2u)) d.y = 0.f;
-                if (!(bits & 4u)) d.z = 0.f;
-                if (!(bits & 8u)) d.w = 0.f;
-            } else {
-                if (!(yy.x > 0.f)) d.x = 0.f;
-                if (!(yy.y > 0.f)) d.y = 0.f;
-                if (!(yy.z > 0.f)) d.z = 0.f;
-                if (!(yy.w > 0.f)) d.w = 0.f;
-            }
-        };
-        auto add = [&](const float4 d, const float4 v) {
-            acc[0].x += d.x; acc[0].y += d.y; acc[0].z += d.z; acc[0].w += d.w;
-            acc[1].x += d.x * ((v.x - m.x) * is.x);
-            acc[1].y += d.y * ((v.y - m.y) * is.y);
-            acc[1].z += d.z * ((v.z - m.z) * is.z);
-            acc[1].w += d.w * ((v.w - m.w) * is.w);
-        };
-        const float4 z4 = make_float4(0, 0, 0, 0);
-        const bool use_y = relu && mask == nullptr;
-        int r = r0 + ry;
-        // four rows per iteration: eight 16-byte loads (+ the mask bytes) in flight per lane; one row per iteration keeps
-        // this two-stream reduction at ~3.5 TB/s (profiles/r02/bench_kernel_stats_final.csv: 2.5 ms per step)
-        for (; r + 3 * rt < r1; r += 4 * rt) {
-            float4 d[4], v[4], yy[4];
-            unsigned bits[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long long o = (long long)(r + u * rt) * C + g * 4;
-                d[u] = *reinterpret_cast<const float4*>(dy + o);
-                v[u] = *reinterpret_cast<const float4*>(x + o);
-                yy[u] = use_y ? *reinterpret_cast<const float4*>(y + o) : z4;
-                bits[u] = (relu && mask != nullptr) ? mask[(long long)(r + u * rt) * CG + g] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (relu) gate(d[u], yy[u], bits[u]);
-                add(d[u], v[u]);
-            }
-        }
-        for (; r < r1; r += rt) {
-            const long long o = (long long)r * C + g * 4;
-            float4 d = *reinterpret_cast<const float4*>(dy + o);
-            const float4 v = *reinterpret_cast<const float4*>(x + o);
-            if (relu)
-                gate(d, use_y ? *reinterpret_cast<const float4*>(y + o) : z4, mask != nullptr ? mask[(long long)r * CG + g] : 0u);
-            add(d, v);
-        }
+#include "rih_bn_bwd_partial.inc"
+}
+// the same pass with two_sum_final_kernel's arithmetic done by the last block of each channel slice (column_slice_done)
+__global__ __launch_bounds__(TPB) void bn_bwd_partial_lastblock_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                       const float* __restrict__ y,
+                                                                       const float* __restrict__ mean,
+                                                                       const float* __restrict__ invstd, int rows, int C,
+                                                                       int cgb, int rt, int rows_per_chunk, int relu,
+                                                                       float* __restrict__ ws,
+                                                                       const unsigned char* __restrict__ mask,
+                                                                       unsigned* __restrict__ counters,
+                                                                       float* __restrict__ out0, float* __restrict__ out1) {
+    {
+#include "rih_bn_bwd_partial.inc"
     }
-    block_col_reduce<2>(acc, cg, ry, cgb, rt);
-    if (ry == 0 && g < CG) {
-        *reinterpret_cast<float4*>(ws + ((long long)0 * nchunk + chunk) * C + g * 4) = acc[0];
-        *reinterpret_cast<float4*>(ws + ((long long)1 * nchunk + chunk) * C + g * 4) = acc[1];
+    if (!column_slice_done(counters)) return;
+    const int lane = threadIdx.x & 63, nslice = gridDim.y;
+    const int c0 = blockIdx.x * cgb * 4, c1 = min(C, c0 + cgb * 4);
+    for (int c = c0 + (threadIdx.x >> 6); c < c1; c += TPB / 64) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = lane; k < nslice; k += 64) {
+            s1 += (double)ws[((long long)0 * nslice + k) * C + c];
+            s2 += (double)ws[((long long)1 * nslice + k) * C + c];
+        }
+        s1 = wave_sum_d(s1);
+        s2 = wave_sum_d(s2);
+        if (lane == 0) { out0[c] = (float)s1; out1[c] = (float)s2; }
     }
 }
 
@@ -1675,6 +1697,19 @@ extern "C" int rih_bn_stats(const float* x, int rows, int C, float eps, float mo
                        momentum, mean, invstd, running_mean, running_var);
     LAUNCH_RET();
 }
+extern "C" int rih_bn_ncounters(int rows, int C) {
+    if (rows < 1 || C < 4 || (C % 4) != 0) return 0;
+    return col_geom(rows, C).gx;
+}
+extern "C" int rih_bn_stats_lastblock(const float* x, int rows, int C, float eps, float momentum, float* mean, float* invstd,
+                                      float* running_mean, float* running_var, float* ws, uint32_t* counters, void* stream) {
+    if (!x || !mean || !invstd || !ws || !counters || rows < 1 || C < 4 || (C % 4) != 0) return RIH_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return RIH_EINVAL;
+    const ColGeom g = col_geom(rows, C);
+    hipLaunchKernelGGL(bn_stats_lastblock_kernel, dim3(g.gx, g.nchunk), dim3(TPB), 0, STREAM, x, rows, C, g.cgb, g.rt,
+                       g.rows_per_chunk, ws, counters, eps, momentum, mean, invstd, running_mean, running_var);
+    LAUNCH_RET();
+}
 extern "C" int rih_bn_stats_from_blocks(const float* part, int T, int C, int rows, int rows_per_block, float eps,
                                         float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
                                         void* stream) {
@@ -1711,6 +1746,22 @@ extern "C" int rih_bn_bwd(const float* dy, const float* x, const float* y, const
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(g.gx, g.nchunk), dim3(TPB), 0, STREAM, dy, x, y, mean, invstd, rows, C,
                        g.cgb, g.rt, g.rows_per_chunk, relu, ws, relu_mask);
     hipLaunchKernelGGL(two_sum_final_kernel, dim3((C + 3) / 4), dim3(TPB), 0, STREAM, ws, C, g.nchunk, dbeta, dgamma);
+    const long long nq = (long long)rows * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nq)), dim3(TPB), 0, STREAM, dy, x, y, mean, invstd, gamma,
+                       dbeta, dgamma, dx, dres, nq, C, 1.f / (float)rows, relu, frozen_stats, relu_mask);
+    LAUNCH_RET();
+}
+
+extern "C" int rih_bn_bwd_lastblock(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                                    const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C,
+                                    int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, uint32_t* counters,
+                                    void* stream) {
+    if (!dy || !x || !mean || !invstd || !gamma || !dx || !dgamma || !dbeta || !ws || !counters) return RIH_EINVAL;
+    if (relu && !y && !relu_mask) return RIH_EINVAL;
+    if (rows < 1 || C < 4 || (C % 4) != 0) return RIH_EINVAL;
+    const ColGeom g = col_geom(rows, C);
+    hipLaunchKernelGGL(bn_bwd_partial_lastblock_kernel, dim3(g.gx, g.nchunk), dim3(TPB), 0, STREAM, dy, x, y, mean, invstd, rows,
+                       C, g.cgb, g.rt, g.rows_per_chunk, relu, ws, relu_mask, counters, dbeta, dgamma);
     const long long nq = (long long)rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nq)), dim3(TPB), 0, STREAM, dy, x, y, mean, invstd, gamma,
                        dbeta, dgamma, dx, dres, nq, C, 1.f / (float)rows, relu, frozen_stats, relu_mask);

@@ -985,6 +985,30 @@ def patch_conv_pair(x, cL, cR):
 
 
 # --------------------------------------------------------------------------------------------- batch norm
+# "Last block done" BatchNorm reductions (rih_bn_stats_lastblock / rih_bn_bwd_lastblock, ABI 11): the finishing launch of the
+# statistics pass and of the backward's reduction pass folded into the pass itself -- one dependent launch (~4.5 us) less per
+# BatchNorm and direction: 62 + 8 per ResNet50 step, ~630 per HRNet-W32 step.  Built after the round-3 GPU budget was spent:
+# bit-identical to the two-launch form on the HIP-on-CPU harness, NOT yet run on the GPU (device-scope fences across the XCDs'
+# L2s are what the harness cannot show) -- opt-in until it is: RIH_BN_LASTBLOCK=1.
+BN_LASTBLOCK = os.environ.get('RIH_BN_LASTBLOCK', '0') == '1'
+_BN_COUNTERS = {}
+_BN_COUNTER_POOL = 1 << 16
+
+
+def bn_counters(device, n):
+    """Pointer to n zero uint32 of the device's counter pool.  The kernels leave their counters zero, so the pool is zeroed
+    once; slices are handed out round-robin, far more of them than BatchNorm launches are ever in flight (or in one graph)."""
+    key = (device.type, device.index)
+    ent = _BN_COUNTERS.get(key)
+    if ent is None:
+        ent = _BN_COUNTERS[key] = [torch.zeros((_BN_COUNTER_POOL,), device=device, dtype=torch.int32), 0]
+    pool, off = ent
+    if off + n > _BN_COUNTER_POOL:
+        off = 0
+    ent[1] = off + n
+    return pool.data_ptr() + 4 * off
+
+
 class BatchNormFn(torch.autograd.Function):
     """nn.BatchNorm2d on NHWC rows (+ residual add + ReLU).  Training: batch statistics, running buffers updated
     in place (momentum 0.1, unbiased running_var) exactly like torch; eval: running statistics."""
@@ -1016,6 +1040,11 @@ class BatchNormFn(torch.autograd.Function):
                 assert T * bm == rows and part.shape[1] == Cc
                 check(lib.rih_bn_stats_from_tiles(part.data_ptr(), T, Cc, bm, eps, momentum, mean.data_ptr(), invstd.data_ptr(),
                                                   _p(rmean), _p(rvar), _stream()), 'rih_bn_stats_from_tiles')
+            elif training and BN_LASTBLOCK:
+                check(lib.rih_bn_stats_lastblock(x.data_ptr(), rows, Cc, eps, momentum, mean.data_ptr(), invstd.data_ptr(),
+                                                 _p(rmean), _p(rvar), ws.data_ptr(),
+                                                 bn_counters(x.device, int(lib.rih_bn_ncounters(rows, Cc))), _stream()),
+                      'rih_bn_stats_lastblock')
             elif training:
                 check(lib.rih_bn_stats(x.data_ptr(), rows, Cc, eps, momentum, mean.data_ptr(), invstd.data_ptr(),
                                        _p(rmean), _p(rvar), ws.data_ptr(), _stream()), 'rih_bn_stats')
@@ -1046,11 +1075,19 @@ class BatchNormFn(torch.autograd.Function):
         ws = torch.empty((int(lib.rih_bn_ws_floats(rows, Cc)),), device=x.device, dtype=torch.float32)
         # algorithmic bytes: reduction pass reads dy and x (+ 1 byte per quad of ReLU pattern), apply reads them again and
         # writes dx (+ dres)
-        _elem_profile(x.numel() * (4.0 * (2 * 2 + 1 + (1 if has_res else 0)) + (0.5 if relu else 0.0)), 'bn_bwd', lambda: check(
-            lib.rih_bn_bwd(dy.data_ptr(), x.data_ptr(), 0, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                           dx.data_ptr(), _p(dres), dg.data_ptr(), db.data_ptr(), rows, Cc, 1 if relu else 0,
-                           (0 if training else 1) | (2 if input_relu else 0), ws.data_ptr(), _p(mask), _stream()),
-            'rih_bn_bwd'))
+        flags = (0 if training else 1) | (2 if input_relu else 0)
+        if BN_LASTBLOCK:
+            cnt = bn_counters(x.device, int(lib.rih_bn_ncounters(rows, Cc)))
+            run = lambda: check(
+                lib.rih_bn_bwd_lastblock(dy.data_ptr(), x.data_ptr(), 0, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                         dx.data_ptr(), _p(dres), dg.data_ptr(), db.data_ptr(), rows, Cc, 1 if relu else 0,
+                                         flags, ws.data_ptr(), _p(mask), cnt, _stream()), 'rih_bn_bwd_lastblock')
+        else:
+            run = lambda: check(
+                lib.rih_bn_bwd(dy.data_ptr(), x.data_ptr(), 0, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                               dx.data_ptr(), _p(dres), dg.data_ptr(), db.data_ptr(), rows, Cc, 1 if relu else 0,
+                               flags, ws.data_ptr(), _p(mask), _stream()), 'rih_bn_bwd')
+        _elem_profile(x.numel() * (4.0 * (2 * 2 + 1 + (1 if has_res else 0)) + (0.5 if relu else 0.0)), 'bn_bwd', run)
         return dx, dg, db, None, None, dres, None, None, None, None, None, None
 
 

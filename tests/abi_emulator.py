@@ -1057,6 +1057,24 @@ class EmulatedLib:
             _f(dres, rows * Cc)[:] = D.ravel()
         return 0
 
+    # "last block done" forms: same results; the counters must arrive zero and are left zero
+    def rih_bn_ncounters(self, rows, Cc):
+        return 4
+
+    @staticmethod
+    def _counters_zero(counters, n=4):
+        assert counters, 'counters pointer missing'
+        assert not np.ctypeslib.as_array(C.cast(counters, C.POINTER(C.c_uint32)), shape=(n,)).any(), 'counter slice not zero'
+
+    def rih_bn_stats_lastblock(self, x, rows, Cc, eps, momentum, mean, invstd, rmean, rvar, ws, counters, stream):
+        self._counters_zero(counters)
+        return self.rih_bn_stats(x, rows, Cc, eps, momentum, mean, invstd, rmean, rvar, ws, stream)
+
+    def rih_bn_bwd_lastblock(self, dy, x, y, mean, invstd, gamma, dx, dres, dgamma, dbeta, rows, Cc, relu, frozen, ws, mask,
+                             counters, stream):
+        self._counters_zero(counters)
+        return self.rih_bn_bwd(dy, x, y, mean, invstd, gamma, dx, dres, dgamma, dbeta, rows, Cc, relu, frozen, ws, mask, stream)
+
     # ------------------------------------------------------------------ row-wise
     def rih_ln_nblk(self, rows):
         return 1

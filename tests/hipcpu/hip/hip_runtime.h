@@ -184,6 +184,10 @@ inline void launch(dim3 grid, dim3 block, F&& fn) {
 
 static inline void __syncthreads() { hipcpu::S().cur->land(); hipcpu::block_barrier(); }
 
+// blocks run one after the other and a block's fibers never run in parallel: a fence is a no-op, an atomic a plain update
+static inline void __threadfence() {}
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+
 template <typename T>
 static inline T __shfl_xor(T v, int mask, int width = 64) {
     static_assert(sizeof(T) <= 64, "exchange slot too small");

@@ -1,6 +1,7 @@
 """GPU parity tests of each HIP operator against plain PyTorch fp32 (CPU) of the same op -- forward and backward.
 Tolerance (fp32 bar of BASELINE.json): |a-b| <= 1e-4*|b| + 1e-5*max|b| for outputs, 1e-3 / 1e-4 for gradients."""
 import math
+import os
 import numpy as np
 import pytest
 import torch
@@ -148,6 +149,45 @@ def test_batchnorm(training, relu, res, shape):
         assert_close(nchw(rg.grad), rr.grad, 1e-3, 1e-4, 'bn dres')
     assert_close(rm_g, rm_r, 1e-4, 1e-5, 'bn running_mean')
     assert_close(rv_g, rv_r, 1e-4, 1e-5, 'bn running_var')
+
+
+def check_batchnorm_lastblock(shape, relu, res, monkeypatch=None):
+    """ops.BN_LASTBLOCK (rih_bn_stats_lastblock / rih_bn_bwd_lastblock): statistics, output, every gradient and the running
+    buffers bit-identical to the two-launch form; the counter pool is left zero."""
+    from renderih_amd import ops
+    N, H, W, Cc = shape
+    d = dev()
+    x = (rnd(N, H, W, Cc, seed=11) * 2 + 0.5).to(d)
+    r = rnd(N, H, W, Cc, seed=12).to(d) if res else None
+    g, b = (torch.rand(Cc) + 0.5).to(d), (rnd(Cc, seed=13) * 0.1).to(d)
+    gy = rnd(N, H, W, Cc, seed=15).to(d)
+    out = {}
+    saved = ops.BN_LASTBLOCK
+    try:
+        for last in (False, True):
+            ops.BN_LASTBLOCK = last
+            for rep in range(2 if last else 1):             # twice: the second call takes the next counter slice
+                xg, gg, bg = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+                rg = r.clone().requires_grad_(True) if res else None
+                rm, rv = (rnd(Cc, seed=14) * 0.1).to(d), torch.full((Cc,), 0.75).to(d)
+                y = ops.batchnorm(xg, gg, bg, rm, rv, residual=rg, training=True, relu=relu)
+                y.backward(gy)
+                out[last] = [y.detach(), xg.grad, gg.grad, bg.grad, rm, rv] + ([rg.grad] if res else [])
+    finally:
+        ops.BN_LASTBLOCK = saved
+    for a, bb in zip(out[False], out[True]):
+        assert torch.equal(a, bb)
+    pool = ops._BN_COUNTERS[(d.type, d.index)][0]
+    assert int(pool.abs().max()) == 0 and ops._BN_COUNTERS[(d.type, d.index)][1] > 0
+
+
+@pytest.mark.skipif(os.environ.get('RIH_BN_LASTBLOCK', '0') != '1',
+                    reason='opt-in feature (RIH_BN_LASTBLOCK=1) built after the round-3 GPU budget was spent: bit-identical on the '
+                           'HIP-on-CPU harness (tests/test_kernels_on_cpu.py); set the flag to check it on the GPU')
+@pytest.mark.parametrize('shape,relu,res', [((2, 16, 16, 64), True, True), ((3, 7, 9, 256), False, False),
+                                            ((64, 64, 64, 256), True, True), ((32, 8, 8, 2048), True, False)])
+def test_batchnorm_lastblock_is_bit_identical(shape, relu, res):
+    check_batchnorm_lastblock(shape, relu, res)
 
 
 @pytest.mark.parametrize('rows,D,x2,relu', [(126, 64, False, False), (4, 509, False, False), (300, 256, True, True),
