@@ -24,4 +24,12 @@ run hrnet_base python bench.py --encoder hrnet32 --steps 10 --warmup 3 --no-cpu-
 run hrnet_bn_lastblock env RIH_BN_LASTBLOCK=1 python bench.py --encoder hrnet32 --steps 10 --warmup 3 --no-cpu-baseline --no-reference-loop --no-roofline
 run config5_base python bench.py --config5
 run config5_skip_dead_mid env RIH_SKIP_DEAD_MID=1 python bench.py --config5
+# 4. where the HRNet-W32 step spends its time now that its branches overlap (no kernel trace of it exists for round 3)
+R=$(pwd); export TMPDIR=/tmp
+( cd /tmp && rm -rf /tmp/prof_hr && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_hr -o step -- \
+    python $R/bench.py --encoder hrnet32 --steps 5 --warmup 2 --no-cpu-baseline --no-reference-loop --no-roofline ) > "$OUT/prof_hrnet.log" 2>&1
+cp /tmp/prof_hr/step_kernel_stats.csv "$OUT/hrnet_kernel_stats.csv" 2>/dev/null
+cp /tmp/prof_hr/step_kernel_trace.csv "$OUT/hrnet_kernel_trace.csv" 2>/dev/null
+python tools/step_from_trace.py "$OUT/hrnet_kernel_trace.csv" --mark nchw_to_nhwc_kernel > "$OUT/step_trace_hrnet.txt" 2>&1
+rm -f "$OUT/hrnet_kernel_trace.csv"      # tens of MB: the summary above is what is kept
 echo done
