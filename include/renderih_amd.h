@@ -102,8 +102,20 @@ typedef struct rih_gemm_desc {
      * output (rih_bn_stats_from_blocks merges them).  NULL = off.  rih_gemm returns RIH_EINVAL when stats is set and the
      * descriptor does not take that path; rih_gemm_stats_rows (stats field ignored) returns 0 for such a descriptor. */
     float* stats;
+    /* Dropout in the epilogue (ABI 12; plain row-major GEMMs = nn.Linear on the split engine's fast path, no split-K, no stats):
+     * C = dropout(act(alpha A B + bias)) + R with the mask stream of rih_add_dropout over the output -- element e (offset from C
+     * in floats; the output is expected contiguous from C) is kept and scaled by 1 / (1 - drop_p) iff
+     * rih_hash(drop_seed + *drop_seed_dev, e) >= drop_p * 2^32 -- so that rih_gemm with drop_p equals rih_gemm followed by
+     * rih_add_dropout(R, ., drop_p, drop_seed, drop_seed_dev) bit for bit and rih_dropout_bwd re-draws the mask.  relu and R
+     * together are refused.  drop_p = 0: off.  rih_gemm_dropout_ok(desc) tells in advance whether a descriptor takes that path
+     * (rih_gemm returns RIH_EINVAL for drop_p != 0 otherwise). */
+    float drop_p;
+    int32_t reserved1;
+    uint64_t drop_seed;
+    const uint64_t* drop_seed_dev;
 } rih_gemm_desc;
 int rih_gemm_stats_rows(const rih_gemm_desc* d);
+int rih_gemm_dropout_ok(const rih_gemm_desc* d);
 
 int rih_gemm(const rih_gemm_desc* d, void* stream);
 
@@ -474,7 +486,7 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
  * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of EVERY by-pointer struct, in
  * this order: gemm desc, mano model, mesh topo, hconv desc, gemm p3 desc, reduce desc, pack desc, ln final desc, adam entry,
  * chain desc (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it mis-laid-out structs. */
-#define RIH_ABI_VERSION 11
+#define RIH_ABI_VERSION 12
 #define RIH_ABI_NSIZES 10
 int rih_version(void);
 int rih_abi_sizes(int32_t* out10);

@@ -28,7 +28,8 @@ class GemmDesc(C.Structure):
                 ('KH', C.c_int32), ('KW', C.c_int32), ('strideA', C.c_int32), ('upS', C.c_int32),
                 ('padH', C.c_int32), ('padW', C.c_int32), ('tile', C.c_int32), ('engine', C.c_int32),
                 ('cS', C.c_int32), ('cOH', C.c_int32), ('cOW', C.c_int32), ('cH', C.c_int32), ('cW', C.c_int32), ('ones_row', C.c_int32),
-                ('reserved0', C.c_int32), ('sBias1', C.c_int64), ('sR1', C.c_int64), ('stats', C.c_void_p)]
+                ('reserved0', C.c_int32), ('sBias1', C.c_int64), ('sR1', C.c_int64), ('stats', C.c_void_p),
+                ('drop_p', C.c_float), ('reserved1', C.c_int32), ('drop_seed', C.c_uint64), ('drop_seed_dev', C.c_void_p)]
 
 
 class GemmP3Desc(C.Structure):
@@ -192,6 +193,7 @@ SIGNATURES = {
     'rih_p3_conv_weight': (c_i, [c_f, C.c_void_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
     'rih_bn_stats_merge': (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),
     'rih_gemm_stats_rows': (c_i, [C.POINTER(GemmDesc)]),
+    'rih_gemm_dropout_ok': (c_i, [C.POINTER(GemmDesc)]),
     'rih_gemm_multi_variant': (c_i, [C.POINTER(GemmDesc)]),
     'rih_gemm_multi_table_bytes': (c_l, [C.POINTER(GemmDesc), c_i]),
     'rih_gemm_multi_pack': (c_i, [C.POINTER(GemmDesc), c_i, C.c_void_p, C.POINTER(C.c_int32)]),
@@ -209,7 +211,7 @@ SIGNATURES = {
     'rih_arch': (C.c_char_p, []),
 }
 
-ABI_VERSION = 11     # = RIH_ABI_VERSION of include/renderih_amd.h
+ABI_VERSION = 12     # = RIH_ABI_VERSION of include/renderih_amd.h
 
 _lib = None
 

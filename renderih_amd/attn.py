@@ -52,6 +52,21 @@ def _lin(m, x, residual=None, relu=False):
     return ops.linear(x, m.weight, m.bias, residual=residual, relu=relu)
 
 
+def _lin_drop(dc, m, x, relu=False):
+    """dropout(act(linear(x))): the dropout rides in the GEMM's epilogue when ops.GEMM_DROPOUT is set (same mask stream)."""
+    if dc.p > 0 and ops.GEMM_DROPOUT:
+        return ops.linear(x, m.weight, m.bias, relu=relu, drop=(dc.p, dc.seed()))
+    h = _lin(m, x, relu=relu)
+    return _drop_add(dc, None, h) if dc.p > 0 else h
+
+
+def _lin_drop_pair(dc, mL, mR, X, relu=False):
+    if dc.p > 0 and ops.GEMM_DROPOUT:
+        return ops.linear_pair(X, mL, mR, relu=relu, drop=(dc.p, dc.seed()))
+    h = ops.linear_pair(X, mL, mR, relu=relu)
+    return _drop_add(dc, None, h) if dc.p > 0 else h
+
+
 def _ln(m, x, x2=None, relu=False):
     return ops.layernorm(x, m.weight, m.bias, eps=m.eps, x2=x2, relu=relu)
 
@@ -63,6 +78,8 @@ def _drop_add(dc, a, b):
 
 def _lin_drop_res(dc, m, x, res):
     """res + dropout(linear(x)); the add is fused into the GEMM epilogue when dropout is off."""
+    if dc.p > 0 and ops.GEMM_DROPOUT:
+        return ops.linear(x, m.weight, m.bias, residual=res, drop=(dc.p, dc.seed()))
     if dc.p > 0:
         return _drop_add(dc, res, _lin(m, x))
     return _lin(m, x, residual=res)
@@ -78,6 +95,8 @@ def _lin_pair(mL, mR, X, residual=None, relu=False):
 
 
 def _lin_drop_res_pair(dc, mL, mR, X, res):
+    if dc.p > 0 and ops.GEMM_DROPOUT:
+        return ops.linear_pair(X, mL, mR, residual=res, drop=(dc.p, dc.seed()))
     if dc.p > 0:
         return _drop_add(dc, res, _lin_pair(mL, mR, X))
     return _lin_pair(mL, mR, X, residual=res)
@@ -163,7 +182,7 @@ class GCN_ResBlock(nn.Module):
         x1 = ops.layernorm_pair(x1, L.norm2, R.norm2, relu=True)
         x1c = cheb(x1)
         if dc.p > 0:
-            x1 = _drop_add(dc, None, _lin_pair(L.fc2, R.fc2, x1c))
+            x1 = _lin_drop_pair(dc, L.fc2, R.fc2, x1c)
             return ops.layernorm_pair(x1, L.norm3, R.norm3, x2=_lin_pair(L.shortcut, R.shortcut, X), relu=relu_out)
         x2 = _lin_pair(L.shortcut, R.shortcut, X)
         return ops.layernorm_pair(_lin_pair(L.fc2, R.fc2, x1c, residual=x2), L.norm3, R.norm3, relu=relu_out)
@@ -217,18 +236,14 @@ class MLP_res_block(nn.Module):
 
     def forward(self, x, dc):
         y, x = ops.layernorm_skip(x, self.layer_norm.weight, self.layer_norm.bias, eps=self.layer_norm.eps)
-        h = _lin(self.fc1, y, relu=True)
-        if dc.p > 0:
-            h = _drop_add(dc, None, h)
+        h = _lin_drop(dc, self.fc1, y, relu=True)
         return _lin_drop_res(dc, self.fc2, h, x)
 
 
     @staticmethod
     def forward_pair(L, R, X, dc):
         y, X = ops.layernorm_pair_skip(X, L.layer_norm, R.layer_norm)
-        h = _lin_pair(L.fc1, R.fc1, y, relu=True)
-        if dc.p > 0:
-            h = _drop_add(dc, None, h)
+        h = _lin_drop_pair(dc, L.fc1, R.fc1, y, relu=True)
         return _lin_drop_res_pair(dc, L.fc2, R.fc2, h, X)
 
 

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/renderih_amd.h"
+#include "rih_hash.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -42,6 +43,12 @@ struct GemmArgs {
     unsigned a_plane;               // a_mode 2: bytes per pre-split plane of A (last: keeps the older kernels' kernarg offsets)
     int epi_vec;                    // C, R, bias and every stride involved are 16-byte aligned: the epilogue may use 16-byte accesses
     float* stats;                   // split fast path, a_mode 0, splitk 1: per wave-row-block column sums [M / WM][2][N] (or NULL)
+    // dropout in the epilogue (DROP variants of the split fast path; appended last: the older kernels' kernarg offsets stay):
+    // element e of the output (offset from C in floats) is kept iff rih_hash(drop_seed + *drop_seed_dev, e) >= drop_thr
+    unsigned drop_thr;              // 0 = off
+    float drop_scale;               // 1 / (1 - p)
+    unsigned long long drop_seed;
+    const unsigned long long* drop_seed_dev;    // device-resident addend of the seed (hipGraph replay), or NULL
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -103,13 +110,18 @@ constexpr int SLD = 36;             // floats per staged row: 32 + pad, keeps fl
 // lane, Chan's pairwise merge across lanes: no E[x^2] - mean^2 cancellation -- written to p.stats[row block][2][N]; the BatchNorm
 // that follows the convolution merges the blocks in double (rih_bn_stats_from_blocks).  The training statistics then cost no
 // pass over the activation (csrc/rih_elem.hip: bn_stats_partial_kernel reads it once).
-template <int TM, int TN, bool STATS = false>
+// DROP (rih_gemm_desc.drop_p > 0; plain a_mode-0 GEMMs = nn.Linear): v = dropout(act(alpha acc + bias)) + R -- the mask stream
+// of rih_add_dropout over the output tensor (element index = offset from desc.C), so the fused form equals
+// rih_gemm followed by rih_add_dropout(R, ., p, seed) bit for bit and rih_dropout_bwd re-draws the same mask.
+template <int TM, int TN, bool STATS = false, bool DROP = false>
 __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&acc)[TM][TN], float* stg, float* __restrict__ C,
                                                  const float* __restrict__ biasp, const float* __restrict__ Rp, int mbase,
                                                  int nbase, int lane) {
     const bool raw = (p.splitk > 1);
     const bool vec = p.epi_vec != 0;
     const int l31 = lane & 31, lhi = lane >> 5;
+    unsigned drop_key = 0u;
+    if (DROP) drop_key = rih_seed_key(p.drop_seed + (p.drop_seed_dev != nullptr ? *p.drop_seed_dev : 0ull));
     // per lane and column block: shift (the lane's first stored row), sums of (v - shift) and of its square, row count
     float4 ssh[STATS ? TN : 1], ssum[STATS ? TN : 1], ssq[STATS ? TN : 1];
     float scnt[STATS ? TN : 1];
@@ -146,11 +158,25 @@ __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&a
                                 if (Rp != nullptr) set_elem(r4, e, Rp[(long long)m * p.ldr + n + e]);
                             }
                     }
+                    if (DROP) {
+                        v.x = v.x * p.alpha + b4.x;
+                        v.y = v.y * p.alpha + b4.y;
+                        v.z = v.z * p.alpha + b4.z;
+                        v.w = v.w * p.alpha + b4.w;
+                        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        const unsigned long long e0 = (unsigned long long)(crow - p.C);
+                        v.x = (rih_hash_k64(drop_key, e0) >= p.drop_thr) ? v.x * p.drop_scale : 0.f;
+                        v.y = (rih_hash_k64(drop_key, e0 + 1) >= p.drop_thr) ? v.y * p.drop_scale : 0.f;
+                        v.z = (rih_hash_k64(drop_key, e0 + 2) >= p.drop_thr) ? v.z * p.drop_scale : 0.f;
+                        v.w = (rih_hash_k64(drop_key, e0 + 3) >= p.drop_thr) ? v.w * p.drop_scale : 0.f;
+                        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                    } else {
                     v.x = v.x * p.alpha + b4.x + r4.x;
                     v.y = v.y * p.alpha + b4.y + r4.y;
                     v.z = v.z * p.alpha + b4.z + r4.z;
                     v.w = v.w * p.alpha + b4.w + r4.w;
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    }
                 }
                 if (full) {
                     *reinterpret_cast<float4*>(crow) = v;
@@ -693,7 +719,7 @@ __device__ __forceinline__ uint4 bloadu4(__amdgpu_buffer_rsrc_t r, unsigned off)
 // plus the per-row window offsets and tap validity bits.  With both operands pre-split the kernel converts nothing.
 // The kernel body takes the block coordinates as arguments: gemm_split_kernel passes blockIdx / gridDim, the grouped launch
 // (gemm_split_multi_kernel, rih_gemm_multi) the coordinates of a block inside ITS problem of a descriptor table.
-template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false>
+template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk_x, const int blk_z, const int grid_x,
                                                 const int grid_z) {
     // global->register prefetch depth: k-tiles in flight.  The 64x64 tile (decoder-sized problems: a handful of
@@ -1103,13 +1129,14 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
     }
 
     // ------------------------------------------------------------------ epilogue (store_tiles_wide; the main loop ended with a barrier)
-    store_tiles_wide<TM, TN, STATS>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp, m0 + wm * WM, n0 + wn * WN,
+    store_tiles_wide<TM, TN, STATS, DROP>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp, m0 + wm * WM, n0 + wn * WN,
                                     lane);
 }
 
-template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false>
+template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
-    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, APRE, STATS>(p, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.z);
+    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, APRE, STATS, DROP>(p, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.x,
+                                                                    (int)gridDim.z);
 }
 
 // ---- grouped launch (rih_gemm_multi): n independent problems of ONE kernel variant in one launch.  The table lives in device
@@ -1158,6 +1185,10 @@ int launch_split(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 gri
     if (a_mode == 2) {      // both operands pre-split (b_mode 2 enforced by rih_gemm)
         if (plain) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 2, true, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 2, false, true>), grid, block, 0, s, a);
+    }
+    else if (a.drop_thr != 0u) {        // dropout epilogue: plain a_mode-0 GEMMs only (checked by the caller)
+        if (b_mode == 0) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 0, true, false, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, false, true>), grid, block, 0, s, a);
     }
     else if (a.stats != nullptr) {      // statistics epilogue: forward-type GEMMs only (checked by the caller)
 #define RIH_LSS(BM_, PL_) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, BM_, PL_, false, true>), grid, block, 0, s, a)
@@ -1873,6 +1904,16 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
     a.cS = d->cS; a.cOH = d->cOH; a.cOW = d->cOW; a.cH = d->cH; a.cW = d->cW;
     a.ones_row = d->ones_row;
     a.stats = d->stats;
+    a.drop_thr = 0u; a.drop_scale = 1.f; a.drop_seed = 0ull; a.drop_seed_dev = nullptr;
+    if (d->drop_p != 0.f) {
+        if (!(d->drop_p > 0.f && d->drop_p < 1.f)) return RIH_EINVAL;
+        double t = (double)d->drop_p * 4294967296.0;            // = drop_thresh() of csrc/rih_elem.hip
+        if (t > 4294967295.0) t = 4294967295.0;
+        a.drop_thr = (unsigned)t;
+        a.drop_scale = 1.f / (1.f - d->drop_p);
+        a.drop_seed = d->drop_seed;
+        a.drop_seed_dev = (const unsigned long long*)d->drop_seed_dev;
+    }
     {
         const auto al4 = [](long long v) { return (v & 3) == 0; };
         a.epi_vec = ((uintptr_t)d->C % 16 == 0) && al4(d->ldc) && al4(d->N) && al4(d->sC1) && al4(d->sC2) && al4(d->sCsplit) &&
@@ -1917,7 +1958,7 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
         if (d->tile == 4) {     // 256x128 kernel: no general-kernel fallback, the caller must respect the preconditions
             if (stats_rows != nullptr) { *stats_rows = 0; return 0; }
             if (prep != nullptr) return RIH_EINVAL;
-            if (d->stats != nullptr) return RIH_EINVAL;
+            if (d->stats != nullptr || d->drop_p != 0.f) return RIH_EINVAL;
             ok = ok && !(d->a_mode == 1 && d->b_mode == 1);
             if (!ok) return RIH_EINVAL;
             a.a_bytes = (unsigned)a_bytes;
@@ -1927,6 +1968,10 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
         if (d->stats != nullptr && !(ok && d->tile <= 2 && d->a_mode == 0 && d->b_mode <= 1 && d->splitk == 1 && gz == 1 &&
                                      d->cS <= 1))
             return RIH_EINVAL;      // the statistics epilogue exists on this path only (rih_gemm_stats_rows tells in advance)
+        // the dropout epilogue exists for plain row-major GEMMs on this path only (rih_gemm_dropout_ok tells in advance)
+        if (d->drop_p != 0.f && !(ok && d->tile <= 2 && d->a_mode == 0 && d->b_mode <= 1 && plain && d->splitk == 1 &&
+                                  d->cS <= 1 && d->stats == nullptr && !(d->relu && d->R != nullptr) && prep == nullptr))
+            return RIH_EINVAL;
         if (stats_rows != nullptr) {
             *stats_rows = (ok && d->tile <= 2 && d->a_mode == 0 && d->b_mode <= 1 && d->splitk == 1 && gz == 1 && d->cS <= 1)
                               ? bm / 2 : 0;
@@ -1948,6 +1993,7 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
             return launch_split<64, 64>(a, d->a_mode, d->b_mode, plain, grid, s);
         }
     }
+    if (d->drop_p != 0.f) return RIH_EINVAL;                  // the general kernels have no dropout epilogue
     if (stats_rows != nullptr) { *stats_rows = 0; return 0; }
     if (prep != nullptr) return RIH_EINVAL;                   // not a fast-path descriptor: no grouped launch
     if (d->stats != nullptr) return RIH_EINVAL;
@@ -2039,6 +2085,16 @@ extern "C" int rih_gemm_multi_launch(const void* dev_table, int variant, int tot
         default: return RIH_EINVAL;
     }
     return (int)hipGetLastError();
+}
+
+// 1 when rih_gemm would run `d` with a dropout epilogue (drop_p of the descriptor is ignored: 0.5 is assumed when it is 0)
+extern "C" int rih_gemm_dropout_ok(const rih_gemm_desc* d) {
+    if (!d) return 0;
+    rih_gemm_desc c = *d;
+    if (c.drop_p == 0.f) c.drop_p = 0.5f;
+    c.stats = nullptr;
+    int rows = 0;
+    return gemm_impl(&c, nullptr, &rows) == 0 ? 1 : 0;
 }
 
 extern "C" int rih_gemm_stats_rows(const rih_gemm_desc* d) {

@@ -179,13 +179,16 @@ class StatsHolder:
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=None, ldr=0,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, kchunk=0, sCsplit=0, alpha=1.0, relu=False,
-         geom=None, tile=None, engine=None, cstride=None, ones_row=0, sBias=0, sR=0, collect=None, stats=None):
+         geom=None, tile=None, engine=None, cstride=None, ones_row=0, sBias=0, sR=0, collect=None, stats=None, drop=None):
     """Enqueue one rih_gemm.  A/B/Cout/bias/R are tensors or raw device pointers.
     cstride = (s, oh, ow, H, W): store GEMM row (img, i, j) to pixel (img, i*s+oh, j*s+ow) of a [*, H, W] tensor.
     collect: a GroupedGemms -- the problem joins its next grouped launch (rih_gemm_multi) when its kernel variant can ride
     in one, instead of being launched now; the operands are kept alive until then.
     stats: a StatsHolder -- filled with the per-row-block BatchNorm statistics of the output when the descriptor takes the split
-    engine's statistics epilogue (left empty otherwise: the BatchNorm then runs its own statistics pass)."""
+    engine's statistics epilogue (left empty otherwise: the BatchNorm then runs its own statistics pass).
+    drop = (p, seed): C = dropout(act(alpha A B + bias)) + R in the epilogue when the descriptor takes that path
+    (rih_gemm_dropout_ok) -- returns True; otherwise act(alpha A B + bias) is computed WITHOUT R and False is returned: the caller
+    finishes with rih_add_dropout(R, C, p, seed), which draws the same mask stream."""
     d = GemmDesc()
     if cstride is not None:
         d.cS, d.cOH, d.cOW, d.cH, d.cW = cstride
@@ -216,6 +219,16 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
         d.tile, auto_sk = plan_gemm(M, N, K, nb1 * nb2 * splitk, d.engine)
     else:
         d.tile = tile
+    fused_drop = False
+    if drop is not None and drop[0] > 0:
+        assert collect is None and stats is None and splitk == 1 and cstride is None
+        will_split = auto_sk > 1 and nb1 * nb2 == 1 and not isinstance(Cout, int) and _cdiv(K, _cdiv(_cdiv(K, auto_sk), 32) * 32) > 1
+        d.drop_p, d.drop_seed, d.drop_seed_dev = float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF, (_seed_dev() or None)
+        if not will_split and not (relu and R is not None) and int(_L().rih_gemm_dropout_ok(C.byref(d))) == 1:
+            fused_drop = True
+        else:
+            d.drop_p, d.drop_seed, d.drop_seed_dev = 0.0, 0, None
+            d.R, R = None, None             # the caller adds R behind its own dropout pass
     if auto_sk > 1 and splitk == 1 and nb1 * nb2 == 1 and not isinstance(Cout, int) and cstride is None:
         # few output tiles but a long reduction (e.g. the 8x8 3x3 convs, the 4x4 patch conv): split K over
         # workgroups and finish (bias / residual / ReLU) in a second pass
@@ -227,7 +240,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
                  sCsplit=M * N, geom=geom, tile=d.tile, engine=d.engine)
             check(_L().rih_splitk_finish(part.data_ptr(), sk, M, N, d.C, ldc, d.bias or 0, d.R or 0, ldr,
                                          alpha, 1 if relu else 0, _stream()), 'rih_splitk_finish')
-            return
+            return False
     req = stats
     if (req is not None and req.part is None and a_mode == 0 and splitk == 1 and nb1 * nb2 == 1 and cstride is None
             and not isinstance(Cout, int)):
@@ -244,8 +257,9 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
         check(_L().rih_gemm(C.byref(d), _stream()), 'rih_gemm')
         e1.record()
         PROFILE.append((2.0 * M * N * K * nb1 * nb2, e0, e1, (M, N, K, nb1 * nb2, a_mode, b_mode, d.tile, splitk, d.engine)))
-        return
+        return fused_drop
     check(_L().rih_gemm(C.byref(d), _stream()), 'rih_gemm')
+    return fused_drop
 
 
 # --------------------------------------------------------------------------------------------- grouped launches
@@ -803,11 +817,36 @@ def conv2d_packed(x, wp, KH, KW, bias=None, stride=1, pad=0, relu=False, residua
     return y
 
 
+# Dropout behind a Linear inside the GEMM's epilogue (rih_gemm_desc.drop_p, ABI 12) instead of an rih_add_dropout launch behind it
+# (57 launches of ~6.5 us per ResNet50 step): same mask stream, so outputs and gradients equal the two-launch form bit for bit
+# (tests/test_gpu_ops.py::check_linear_dropout_epilogue).  Built after the round-3 GPU budget was spent -- the plain kernels'
+# machine code is unchanged (diff of the device assembly), the DROP variants have run on the HIP-on-CPU harness only: opt-in.
+GEMM_DROPOUT = os.environ.get('RIH_GEMM_DROPOUT', '0') == '1'
+
+
+def _finish_dropout(fused, y, residual, drop):
+    """After gemm(..., drop=drop): nothing to do when the epilogue took the dropout, else residual + dropout(y) by the
+    stand-alone kernel (gemm left the residual out in that case)."""
+    if fused:
+        return y
+    out = torch.empty_like(y)
+    check(_L().rih_add_dropout(_p(residual), y.data_ptr(), out.data_ptr(), y.numel(), y.shape[-1], 0, drop[0], drop[1],
+                               _seed_dev(), _stream()), 'rih_add_dropout')
+    return out
+
+
+def _dropout_grad(dy, drop):
+    d = torch.empty_like(dy)
+    check(_L().rih_dropout_bwd(dy.data_ptr(), d.data_ptr(), dy.numel(), drop[0], drop[1], _seed_dev(), _stream()), 'rih_dropout_bwd')
+    return d
+
+
 class LinearFn(torch.autograd.Function):
-    """y = act(x @ w^T + bias + residual) for x [..., K], w [N, K] (the nn.Linear parameter, read in place)."""
+    """y = act(x @ w^T + bias + residual) for x [..., K], w [N, K] (the nn.Linear parameter, read in place).
+    drop = (p, seed): y = dropout(act(x @ w^T + bias)) + residual (relu and residual together are not supported)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, relu):
+    def forward(ctx, x, w, bias, residual, relu, drop=None):
         _chk(x, w, bias, residual)
         x = _c(x)
         w = _c(w)
@@ -816,19 +855,28 @@ class LinearFn(torch.autograd.Function):
         y = torch.empty(x.shape[:-1] + (Nf,), device=x.device, dtype=torch.float32)
         if residual is not None:
             residual = _c(residual)
-        gemm(x, w, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, bias=bias, R=residual, ldr=Nf, relu=relu)
+        if drop is not None and drop[0] > 0:
+            assert not (relu and residual is not None)
+            fused = gemm(x, w, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, bias=bias, R=residual, ldr=Nf, relu=relu, drop=drop)
+            y = _finish_dropout(fused, y, residual, drop)
+        else:
+            drop = None
+            gemm(x, w, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, bias=bias, R=residual, ldr=Nf, relu=relu)
         ctx.save_for_backward(x, w, y if relu else None)
-        ctx.cfg = (relu, bias is not None, residual is not None)
+        ctx.cfg = (relu, bias is not None, residual is not None, drop)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
-        relu, has_bias, has_res = ctx.cfg
+        relu, has_bias, has_res, drop = ctx.cfg
         Nf, K = w.shape
         M = x.numel() // K
         dy = _c(dy)
         lib = _L()
+        dres = dy if (has_res and ctx.needs_input_grad[3]) else None     # (with drop: the residual joins behind the dropout)
+        if drop is not None:
+            dy = _dropout_grad(dy, drop)
         if relu:
             dyr = torch.empty_like(dy)
             check(lib.rih_relu_bwd(dy.data_ptr(), y.data_ptr(), dyr.data_ptr(), dy.numel(), _stream()), 'rih_relu_bwd')
@@ -845,12 +893,13 @@ class LinearFn(torch.autograd.Function):
             _wgrad(x, dy, dw, M, K, Nf, K, Nf, (1, 1, K, 1, 1, 1, 1, 1, 1, 0, 0), K, 1, K, db=db)
         elif want_db:
             db = colsum(dy, M, Nf)
-        dres = dy if (has_res and ctx.needs_input_grad[3]) else None
-        return dx, dw, db, dres, None
+        if drop is None:
+            dres = dy if (has_res and ctx.needs_input_grad[3]) else None
+        return dx, dw, db, dres, None, None
 
 
-def linear(x, w, bias=None, residual=None, relu=False):
-    return LinearFn.apply(x, w, bias, residual, relu)
+def linear(x, w, bias=None, residual=None, relu=False, drop=None):
+    return LinearFn.apply(x, w, bias, residual, relu, drop)
 
 
 # ------------------------------------------------------------------------- paired left/right-hand layers
@@ -862,7 +911,7 @@ class LinearPairFn(torch.autograd.Function):
     wR / bR None: wL [2, N, K] and bL [2, N] hold both hands' parameters (the stacked fused QKV operand)."""
 
     @staticmethod
-    def forward(ctx, x, wL, wR, bL, bR, residual, relu):
+    def forward(ctx, x, wL, wR, bL, bR, residual, relu, drop=None):
         _chk(x, wL, wR, bL, bR, residual)
         x, wL = _c(x), _c(wL)
         assert x.shape[0] == 2
@@ -882,18 +931,28 @@ class LinearPairFn(torch.autograd.Function):
         y = torch.empty(x.shape[:-1] + (Nf,), device=x.device, dtype=torch.float32)
         if residual is not None:
             residual = _c(residual)
-        gemm(x, wL, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, bias=bL, R=residual, ldr=Nf, relu=relu, nb1=2,
-             sA=(M * K, 0), sB=(sW, 0), sC=(M * Nf, 0), sBias=sBias, sR=M * Nf)
+        if drop is not None and drop[0] > 0:
+            assert not (relu and residual is not None)
+            fused = gemm(x, wL, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, bias=bL, R=residual, ldr=Nf, relu=relu, nb1=2,
+                         sA=(M * K, 0), sB=(sW, 0), sC=(M * Nf, 0), sBias=sBias, sR=M * Nf, drop=drop)
+            y = _finish_dropout(fused, y, residual, drop)
+        else:
+            drop = None
+            gemm(x, wL, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, bias=bL, R=residual, ldr=Nf, relu=relu, nb1=2,
+                 sA=(M * K, 0), sB=(sW, 0), sC=(M * Nf, 0), sBias=sBias, sR=M * Nf)
         ctx.save_for_backward(x, wL, wR, y if relu else None)
-        ctx.cfg = (relu, bL is not None, residual is not None, stacked, Nf, K, sW)
+        ctx.cfg = (relu, bL is not None, residual is not None, stacked, Nf, K, sW, drop)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, wL, wR, y = ctx.saved_tensors
-        relu, has_bias, has_res, stacked, Nf, K, sW = ctx.cfg
+        relu, has_bias, has_res, stacked, Nf, K, sW, drop = ctx.cfg
         M = x.numel() // (2 * K)
         dy = _c(dy)
+        dres = dy if (has_res and ctx.needs_input_grad[5]) else None     # (with drop: the residual joins behind the dropout)
+        if drop is not None:
+            dy = _dropout_grad(dy, drop)
         if relu:
             dyr = torch.empty_like(dy)
             check(_L().rih_relu_bwd(dy.data_ptr(), y.data_ptr(), dyr.data_ptr(), dy.numel(), _stream()), 'rih_relu_bwd')
@@ -905,15 +964,16 @@ class LinearPairFn(torch.autograd.Function):
         dw = torch.empty((2, Nf, K), device=x.device, dtype=torch.float32)
         db = torch.empty((2, Nf), device=x.device, dtype=torch.float32) if has_bias else None
         _wgrad(x, dy, dw, M, K, Nf, K, Nf, (1, 1, K, 1, 1, 1, 1, 1, 1, 0, 0), K, 1, K, db=db, nb=2, sx=M * K, sdy=M * Nf)
-        dres = dy if (has_res and ctx.needs_input_grad[5]) else None
+        if drop is None:
+            dres = dy if (has_res and ctx.needs_input_grad[5]) else None
         if stacked:
-            return dx, dw, None, db, None, dres, None
-        return dx, dw[0], dw[1], (db[0] if has_bias else None), (db[1] if has_bias else None), dres, None
+            return dx, dw, None, db, None, dres, None, None
+        return dx, dw[0], dw[1], (db[0] if has_bias else None), (db[1] if has_bias else None), dres, None, None
 
 
-def linear_pair(x, mL, mR, residual=None, relu=False):
+def linear_pair(x, mL, mR, residual=None, relu=False, drop=None):
     """Both hands' nn.Linear (modules mL, mR) on the stacked activation x [2, ..., K]."""
-    return LinearPairFn.apply(x, mL.weight, mR.weight, mL.bias, mR.bias, residual, relu)
+    return LinearPairFn.apply(x, mL.weight, mR.weight, mL.bias, mR.bias, residual, relu, drop)
 
 
 class PatchConvPairFn(torch.autograd.Function):

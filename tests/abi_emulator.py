@@ -156,10 +156,21 @@ class EmulatedLib:
                 out = np.float32(d.alpha) * (A @ Bm)
                 if d.bias:
                     out = out + _f(d.bias + 4 * b1 * d.sBias1, N)[None, :]
+                if d.drop_p != 0:        # dropout epilogue: act -> mask stream over the output (offset from d.C) -> + R
+                    assert self.rih_gemm_dropout_ok(dref) == 1 and not (d.relu and d.R), 'descriptor without the dropout path'
+                    if d.relu:
+                        out = np.maximum(out, 0)
+                    e = ((Cb - d.C) // 4 + np.arange(M)[:, None] * d.ldc + np.arange(N)[None, :]).astype(np.uint64)
+                    seed = (int(d.drop_seed) + (int(np.ctypeslib.as_array((C.c_uint64 * 1).from_address(int(d.drop_seed_dev)))[0])
+                                                if d.drop_seed_dev else 0)) & 0xFFFFFFFFFFFFFFFF
+                    pf = np.float32(d.drop_p)
+                    thr = np.uint64(min(int(float(pf) * 4294967296.0), 4294967295))
+                    keep = hash_np(seed, e.ravel()).reshape(M, N) >= thr
+                    out = np.where(keep, out.astype(np.float32) * (np.float32(1.0) / (np.float32(1.0) - pf)), np.float32(0))
                 if d.R:
                     out = out + np.lib.stride_tricks.as_strided(_f(d.R + 4 * b1 * d.sR1, (M - 1) * d.ldr + N), (M, N),
                                                                 (4 * d.ldr, 4))
-                if d.relu:
+                if d.relu and d.drop_p == 0:
                     out = np.maximum(out, 0)
                 win = c_window(Cb)
                 if win is not None:
@@ -229,6 +240,18 @@ class EmulatedLib:
         if d.b_mode == 0:
             ok = ok and d.N % 4 == 0
         return (64 if d.tile in (0, 1) else 32) if ok else 0
+
+    def rih_gemm_dropout_ok(self, dref):
+        """The header's contract, restated: split engine's fast path, plain row-major A, no split-K, no stats, dense rows."""
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        plain = (d.KH == 1 and d.KW == 1 and d.strideA == 1 and d.padH == 0 and d.padW == 0 and d.H == d.Ho and d.W == d.Wo)
+        ok = (d.engine == 1 and d.tile in (0, 1, 2) and d.a_mode == 0 and d.b_mode in (0, 1) and d.splitk == 1 and plain
+              and d.cS <= 1 and d.upS == 1 and d.K % 4 == 0 and d.K >= 1 and d.A % 16 == 0 and d.B % 16 == 0
+              and d.lda % 4 == 0 and d.ldb % 4 == 0 and d.sA1 % 4 == 0 and d.sB1 % 4 == 0 and d.sA2 % 4 == 0 and d.sB2 % 4 == 0
+              and not (d.relu and d.R))
+        if d.b_mode == 0:
+            ok = ok and d.N % 4 == 0
+        return 1 if ok else 0
 
     def rih_bn_stats_from_blocks(self, part, T, Cc, rows, rpb, eps, momentum, mean, invstd, rmean, rvar, stream):
         p = _f(part, T * 2 * Cc).reshape(T, 2, Cc).astype(np.float64)

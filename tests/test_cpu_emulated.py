@@ -258,6 +258,30 @@ def test_dead_mid_convolution_skip_host_logic():
             assert torch.equal(full[part][k], lean[part][k]), k
 
 
+def test_gemm_dropout_epilogue_model_host_logic(monkeypatch):
+    """ops.GEMM_DROPOUT (RIH_GEMM_DROPOUT=1) through the whole network, training mode, dropout 0.1, emulated ABI: the dropout
+    sites behind the decoder's Linears ride in the GEMM epilogue and draw the same mask streams in the same order, so every
+    output and parameter gradient equals the two-launch form bit for bit."""
+    from oracle import net_oracle
+    from renderih_amd import ops
+    from renderih_amd.model import build_model
+    img = testing.seeded_image(1, 4)
+    res = {}
+    for fuse in (False, True):
+        monkeypatch.setattr(ops, 'GEMM_DROPOUT', fuse)
+        m = build_model(0.1)
+        m.load_state_dict(testing.deterministic_state(m.state_dict(), seed=3))
+        m.train()
+        torch.manual_seed(99)               # DropCtx draws its base seed from the host generator
+        out = m(img)
+        net_oracle.scalar_loss(out).backward()
+        res[fuse] = (testing.flatten_outputs(out), {k: p.grad for k, p in m.named_parameters() if p.grad is not None})
+    for a, b in zip(res[False], res[True]):
+        assert set(a) == set(b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
 def test_family_b_host_logic_matches_oracle():
     """Second model family (renderih_amd/lijun.py = common/myhand/lijun_model_graph.HandNET_GCN), B=2, train mode,
     dropout 0: forward outputs and all parameter gradients against the oracle, fp64-anchored like the first family."""

@@ -89,6 +89,14 @@ def test_norm_softmax_attention_kernels():
     G.test_add_dropout_and_bcast()
 
 
+@pytest.mark.parametrize('case', [(70, 64, 64, False, True, True), (33, 128, 96, True, False, True), (130, 32, 200, False, True, False),
+                                  (65, 64, 128, True, False, False), (40, 30, 64, False, True, False, 0.3, False)])
+def test_linear_dropout_epilogue_kernels(case):
+    """The DROP variants of the split engine's kernels (64x64 and, for 200 / 128 columns, wider tiles as the planner picks them)
+    against GEMM + rih_add_dropout: bit for bit, paired (batched) and single, ReLU or residual; K = 30 falls back."""
+    G.check_linear_dropout_epilogue(*case)
+
+
 @pytest.mark.parametrize('shape,relu,res', [((2, 4, 4, 64), True, True), ((3, 33, 7, 32), False, False), ((2, 9, 9, 512), True, False)])
 def test_batchnorm_lastblock_kernels(shape, relu, res):
     """The "last block done" reductions (one launch less per BatchNorm and direction) against the two-launch form: bit for bit,

@@ -1,11 +1,12 @@
 #!/bin/bash
-# The experiments that were BUILT but not measured when round 3 ran out of GPU minutes, as one GPU-box session (~10 min):
+# The experiments that were BUILT but not measured when round 3 ran out of GPU minutes, as one GPU-box session (~12 min):
 #   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/pending_ab.sh'
 # 1. RIH_SKIP_DEAD_MID=1 -- the finest mid convolution, whose output decoder.forward drops: the gated GPU
 #    parity test, then the training step and the fp16 inference step (--config5) with and without it.
 # 2. RIH_WGRAD_GROUP_T128=128 / 256 -- 128x128 tiles for the large grouped weight gradients (item 3b).
 # 3. RIH_BN_LASTBLOCK=1 -- BatchNorm reductions without their finishing launch (item 3c): parity tests with the flag set, then
 #    the ResNet50 and HRNet-W32 steps with and without it.
+# 3'. RIH_GEMM_DROPOUT=1 -- dropout behind the decoder's Linears in the GEMM epilogue (item 3d).
 # Each bench line is the last line of its log under gpurun_out/pending/.
 cd "$(dirname "$0")/.." || exit 1
 OUT=gpurun_out/pending
@@ -19,6 +20,9 @@ run train_t128 env RIH_WGRAD_GROUP_T128=128 python bench.py $Q
 run train_t256 env RIH_WGRAD_GROUP_T128=256 python bench.py $Q
 run pytest_bn_lastblock env RIH_BN_LASTBLOCK=1 python -m pytest tests -q -m gpu -x -k "batchnorm or conv_bn or model_train_matches or hrnet_matches"
 run train_bn_lastblock env RIH_BN_LASTBLOCK=1 python bench.py $Q
+run pytest_gemm_dropout env RIH_GEMM_DROPOUT=1 python -m pytest tests -q -m gpu -x -k "linear_dropout or dropout or model_train_matches or hipgraph"
+run train_gemm_dropout env RIH_GEMM_DROPOUT=1 python bench.py $Q
+run train_all_four env RIH_GEMM_DROPOUT=1 RIH_BN_LASTBLOCK=1 RIH_SKIP_DEAD_MID=1 RIH_WGRAD_GROUP_T128=128 python bench.py $Q
 run train_base2 python bench.py $Q
 run hrnet_base python bench.py --encoder hrnet32 --steps 10 --warmup 3 --no-cpu-baseline --no-reference-loop --no-roofline
 run hrnet_bn_lastblock env RIH_BN_LASTBLOCK=1 python bench.py --encoder hrnet32 --steps 10 --warmup 3 --no-cpu-baseline --no-reference-loop --no-roofline
