@@ -331,7 +331,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         a_ci = mm - tap * p.Cin;
         a_kh = tap / p.KW;
         a_kw = tap - a_kh * p.KW;
-        a_mvalid = max(0, min(4, p.M - mm));
+        // (rows from ones_row on are not in memory: the all-ones row is synthesised below, the rows behind it are padding)
+        a_mvalid = max(0, min(4, (p.ones_row > 0 ? p.ones_row : p.M) - mm));
         if (p.ones_row > 0 && p.ones_row >= mm && p.ones_row < mm + 4) a_one = p.ones_row - mm;
 #pragma unroll
         for (int i = 0; i < NPA; ++i) { a_base[i] = 0; a_hw0[i] = 0; }

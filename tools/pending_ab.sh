@@ -18,7 +18,7 @@ run train_base python bench.py $Q
 run train_skip_dead_mid env RIH_SKIP_DEAD_MID=1 python bench.py $Q
 run train_t128 env RIH_WGRAD_GROUP_T128=128 python bench.py $Q
 run train_t256 env RIH_WGRAD_GROUP_T128=256 python bench.py $Q
-run pytest_bn_lastblock env RIH_BN_LASTBLOCK=1 python -m pytest tests -q -m gpu -x -k "batchnorm or conv_bn or model_train_matches or hrnet_matches"
+run pytest_bn_lastblock env RIH_BN_LASTBLOCK=1 python -m pytest tests -q -m gpu -x -k "batchnorm or conv_bn or model_train_matches or hrnet_eval or side_streams"
 run train_bn_lastblock env RIH_BN_LASTBLOCK=1 python bench.py $Q
 run pytest_gemm_dropout env RIH_GEMM_DROPOUT=1 python -m pytest tests -q -m gpu -x -k "linear_dropout or dropout or model_train_matches or hipgraph"
 run train_gemm_dropout env RIH_GEMM_DROPOUT=1 python bench.py $Q
