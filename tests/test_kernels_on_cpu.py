@@ -283,10 +283,13 @@ def test_gemm_descriptor_fuzz_against_emulator():
     from host_kernels import load
     from renderih_amd._lib import GemmDesc
     host, emu = load(), EmulatedLib()
-    rs = np.random.RandomState(5)
+    # HIPCPU_FUZZ_SEED / HIPCPU_FUZZ_ITERS: other draws; HIPCPU_FUZZ_EXACT=1: operands allocated at their exact extent (no slack
+    # floats behind them), so that under AddressSanitizer (tests/hipcpu/README.md) a read past an operand's end is reported
+    rs = np.random.RandomState(int(os.environ.get('HIPCPU_FUZZ_SEED', '5')))
+    slack = 0 if os.environ.get('HIPCPU_FUZZ_EXACT', '0') == '1' else 8
     cdiv = lambda a, b: -(-a // b)
     checked = 0
-    for it in range(45):
+    for it in range(int(os.environ.get('HIPCPU_FUZZ_ITERS', '45'))):
         engine, a_mode, b_mode = int(rs.randint(0, 2)), int(rs.randint(0, 2)), int(rs.randint(0, 2))
         conv = rs.rand() < 0.5
         nb1 = 1
@@ -323,8 +326,8 @@ def test_gemm_descriptor_fuzz_against_emulator():
         if a_mode == 1 and rs.rand() < 0.4:
             Mp, ones_row = M + 4, M
         alpha = float(rs.choice([1.0, 0.5]))
-        A = rs.randn(nb1 * a_size + 8).astype(np.float32)
-        B = rs.randn(nb1 * b_size + 8).astype(np.float32)
+        A = rs.randn(nb1 * a_size + slack).astype(np.float32)
+        B = rs.randn(nb1 * b_size + slack).astype(np.float32)
         sB1 = int(rs.choice([0, b_size])) if nb1 > 1 else 0
         bias, R = rs.randn(nb1 * N).astype(np.float32), rs.randn(nb1 * Mp * (N + 4)).astype(np.float32)
         outs = []
