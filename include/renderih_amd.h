@@ -79,7 +79,13 @@ typedef struct rih_gemm_desc {
                             1: fp32 emulated on the bf16 MFMA pipe: each operand split into three bf16 terms
                                (hi+mid+lo, 24 significand bits), six v_mfma_f32_32x32x16_bf16 products, fp32
                                accumulate -- same accuracy as engine 0 (error <= ~2^-23 relative per product),
-                               2.5 PF / 6 = 417 TF peak.  Tiles 0,1,2 only (tile 3 always runs engine 0). */
+                               2.5 PF / 6 = 417 TF peak.  Tiles 0,1,2 only (tile 3 always runs engine 0).
+                            2: fp32 emulated on the fp16 MFMA pipe with THREE products: each operand is scaled by a power
+                               of two (from amax_a / amax_b below) and split into two fp16 terms hi + 2^-11 lo (22-23
+                               significand bits), hi*hi and hi*lo + lo*hi accumulate in two fp32 accumulators
+                               (v_mfma_f32_32x32x16_f16), combined and un-scaled in the epilogue; 2.5 PF / 3 = 833 TF
+                               peak.  Exists on the fast path of tiles 0,1,2 (a_mode / b_mode 0 or 1); a descriptor
+                               that asks for it elsewhere runs engine 1 (rih_gemm_engine tells which). */
     /* Strided output rows (cS > 1; a_mode 0, splitk 1, no residual): GEMM row m = (img, i, j) over (Ho, Wo) is stored
      * to pixel (img, i*cS + cOH, j*cS + cOW) of a [*, cH, cW, ldc] tensor.  Used to compute the data gradient of a
      * stride-s convolution as s*s dense sub-convolutions, one per output parity class (each with the kernel taps
@@ -113,9 +119,22 @@ typedef struct rih_gemm_desc {
     int32_t reserved1;
     uint64_t drop_seed;
     const uint64_t* drop_seed_dev;
+    /* Engine 2 only (ABI 13): DEVICE pointers to one float each, an upper bound of max|A| resp. max|B| over everything the
+     * launch reads (all batch slices).  The kernel derives the power-of-two operand scale from it (s * bound in [2^14, 2^15)),
+     * so the bound is read at run time -- a step captured in a hipGraph follows the data.  Any upper bound is correct: a
+     * bound 2^k too large costs k of the ~29 binades below the maximum that keep full precision; a bound that is too SMALL
+     * can overflow fp16 (inf / NaN in the result).  Written by rih_absmax or by the producing kernel (rih_bn_apply,
+     * rih_bn_bwd: `amax` arguments).  NULL = the operand is known to lie inside [-2^15, 2^15] (scale 1). */
+    const float* amax_a;
+    const float* amax_b;
 } rih_gemm_desc;
 int rih_gemm_stats_rows(const rih_gemm_desc* d);
 int rih_gemm_dropout_ok(const rih_gemm_desc* d);
+/* The engine rih_gemm would run `d` on (0 / 1 / 2), or -1 for an invalid descriptor. */
+int rih_gemm_engine(const rih_gemm_desc* d);
+/* out[0] = max(out[0], max_i |x[i]|) over n floats (out must hold a non-negative float, e.g. 0, beforehand; NaNs are ignored).
+ * One pass at streaming rate; several tensors can share one bound.  rih_fill_zero_f32 (or a memset) resets a bound. */
+int rih_absmax(const float* x, int64_t n, float* out, void* stream);
 
 int rih_gemm(const rih_gemm_desc* d, void* stream);
 
@@ -284,9 +303,10 @@ int rih_bn_stats(const float* x, int rows, int C, float eps, float momentum, flo
 /* eval statistics from running buffers */
 int rih_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean,
                       float* invstd, void* stream);
-/* y = act((x-mean)*invstd*gamma + beta + residual) */
+/* y = act((x-mean)*invstd*gamma + beta + residual).  amax (optional, ABI 13): *amax = max(*amax, max|y|) -- the operand bound of
+ * the convolution that reads y (rih_gemm_desc.amax_a, engine 2) at no extra pass; the caller zeroes it beforehand. */
 int rih_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                 const float* residual, float* y, int rows, int C, int relu, uint8_t* relu_mask, void* stream);
+                 const float* residual, float* y, int rows, int C, int relu, uint8_t* relu_mask, float* amax, void* stream);
 /* relu_mask (optional, relu != 0): rows*C/4 bytes, byte q = sign pattern of output quad q (bit e set: element 4q+e > 0).
  * The backward then reads one byte per quad instead of the 16 bytes of y (it needs nothing else of y).
  * backward of the above (training statistics): given dy and the ReLU pattern (relu_mask, or the forward output y when
@@ -296,7 +316,9 @@ int rih_bn_apply(const float* x, const float* mean, const float* invstd, const f
  * separate ReLU pass over it. */
 int rih_bn_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
                const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C,
-               int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, void* stream);
+               int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, float* amax_dx, void* stream);
+/* amax_dx (optional, ABI 13): *amax_dx = max(*amax_dx, max|dx|), as `amax` of rih_bn_apply -- dx is the gradient operand of the
+ * producing convolution's data- and weight-gradient GEMMs. */
 
 /* One launch less per statistics pass and per backward ("last block done", ABI 11): the reduction pass publishes its partial sums
  * and the last workgroup of each channel slice finishes the slice, with the arithmetic of the stand-alone finishing kernels
@@ -308,7 +330,8 @@ int rih_bn_stats_lastblock(const float* x, int rows, int C, float eps, float mom
                            float* running_mean, float* running_var, float* ws, uint32_t* counters, void* stream);
 int rih_bn_bwd_lastblock(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
                          const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C,
-                         int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, uint32_t* counters, void* stream);
+                         int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, uint32_t* counters, float* amax_dx,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row-wise ops on [rows][D] matrices (decoder)                                                         */
@@ -486,7 +509,7 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
  * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of EVERY by-pointer struct, in
  * this order: gemm desc, mano model, mesh topo, hconv desc, gemm p3 desc, reduce desc, pack desc, ln final desc, adam entry,
  * chain desc (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it mis-laid-out structs. */
-#define RIH_ABI_VERSION 12
+#define RIH_ABI_VERSION 13
 #define RIH_ABI_NSIZES 10
 int rih_version(void);
 int rih_abi_sizes(int32_t* out10);

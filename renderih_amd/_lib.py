@@ -29,7 +29,8 @@ class GemmDesc(C.Structure):
                 ('padH', C.c_int32), ('padW', C.c_int32), ('tile', C.c_int32), ('engine', C.c_int32),
                 ('cS', C.c_int32), ('cOH', C.c_int32), ('cOW', C.c_int32), ('cH', C.c_int32), ('cW', C.c_int32), ('ones_row', C.c_int32),
                 ('reserved0', C.c_int32), ('sBias1', C.c_int64), ('sR1', C.c_int64), ('stats', C.c_void_p),
-                ('drop_p', C.c_float), ('reserved1', C.c_int32), ('drop_seed', C.c_uint64), ('drop_seed_dev', C.c_void_p)]
+                ('drop_p', C.c_float), ('reserved1', C.c_int32), ('drop_seed', C.c_uint64), ('drop_seed_dev', C.c_void_p),
+                ('amax_a', C.c_void_p), ('amax_b', C.c_void_p)]
 
 
 class GemmP3Desc(C.Structure):
@@ -150,12 +151,12 @@ SIGNATURES = {
     'rih_bn_ws_floats': (c_l, [c_i, c_i]),
     'rih_bn_stats': (c_i, [c_f, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f, C.c_void_p]),
     'rih_bn_eval_stats': (c_i, [c_f, c_f, c_i, c_fl, c_f, c_f, C.c_void_p]),
-    'rih_bn_apply': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, C.c_void_p, C.c_void_p]),
-    'rih_bn_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, C.c_void_p, C.c_void_p]),
+    'rih_bn_apply': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, C.c_void_p, c_f, C.c_void_p]),
+    'rih_bn_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, C.c_void_p, c_f, C.c_void_p]),
     'rih_bn_ncounters': (c_i, [c_i, c_i]),
     'rih_bn_stats_lastblock': (c_i, [c_f, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f, C.c_void_p, C.c_void_p]),
     'rih_bn_bwd_lastblock': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, C.c_void_p, C.c_void_p,
-                                   C.c_void_p]),
+                                   c_f, C.c_void_p]),
     'rih_layernorm_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_i, C.c_void_p]),
     'rih_ln_nblk': (c_i, [c_i]),
     'rih_layernorm_fwd_grouped': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_l, c_l, c_fl, c_i, C.c_void_p]),
@@ -194,6 +195,8 @@ SIGNATURES = {
     'rih_bn_stats_merge': (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),
     'rih_gemm_stats_rows': (c_i, [C.POINTER(GemmDesc)]),
     'rih_gemm_dropout_ok': (c_i, [C.POINTER(GemmDesc)]),
+    'rih_gemm_engine': (c_i, [C.POINTER(GemmDesc)]),
+    'rih_absmax': (c_i, [c_f, c_l, c_f, C.c_void_p]),
     'rih_gemm_multi_variant': (c_i, [C.POINTER(GemmDesc)]),
     'rih_gemm_multi_table_bytes': (c_l, [C.POINTER(GemmDesc), c_i]),
     'rih_gemm_multi_pack': (c_i, [C.POINTER(GemmDesc), c_i, C.c_void_p, C.POINTER(C.c_int32)]),
@@ -211,7 +214,7 @@ SIGNATURES = {
     'rih_arch': (C.c_char_p, []),
 }
 
-ABI_VERSION = 12     # = RIH_ABI_VERSION of include/renderih_amd.h
+ABI_VERSION = 13     # = RIH_ABI_VERSION of include/renderih_amd.h
 
 _lib = None
 

@@ -50,6 +50,29 @@ __device__ __forceinline__ uint32_t drop_thresh(float p) {
     return (uint32_t)t;
 }
 
+// ------------------------------------------------------------------------------------------------ operand bounds (rih_gemm engine 2)
+// max|x| into a device word: non-negative floats order like their bit patterns, so the merge is an integer atomicMax (NaN
+// candidates are dropped by fmaxf before they get there).  One atomic per wavefront.
+__device__ __forceinline__ void amax_publish(float* out, float v) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(v));
+}
+__global__ __launch_bounds__(TPB) void absmax_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+    float m = 0.f;
+    const long long nq = n >> 2;
+    if (((uintptr_t)x & 15) == 0) {
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        GRID_STRIDE(i, nq) {
+            const float4 v = x4[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        GRID_STRIDE(i, n - 4 * nq) m = fmaxf(m, fabsf(x[4 * nq + i]));
+    } else {
+        GRID_STRIDE(i, n) m = fmaxf(m, fabsf(x[i]));
+    }
+    amax_publish(out, m);
+}
+
 // ------------------------------------------------------------------------------------------------ layout
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int H, int W,
                                     int Cpad) {
@@ -460,8 +483,10 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const floa
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ y,
-                                long long nquads, int C, int relu, unsigned char* __restrict__ mask) {
+                                long long nquads, int C, int relu, unsigned char* __restrict__ mask,
+                                float* __restrict__ amax) {
     const int CG = C / 4;
+    float am = 0.f;         // max |y| of this thread (-> *amax: the operand bound of the GEMM that reads y, rih_gemm engine 2)
     GRID_STRIDE(i, nquads) {
         const int g = (int)(i % CG);
         const float4 v = reinterpret_cast<const float4*>(x)[i];
@@ -485,7 +510,9 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
             o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
         }
         reinterpret_cast<float4*>(y)[i] = o;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
+    if (amax != nullptr) amax_publish(amax, am);
 }
 
 // Training statistics from per-row-block (mean, M2) pairs -- the statistics epilogue of rih_gemm (rih_gemm_desc.stats:
@@ -622,8 +649,10 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ sum_dy, const float* __restrict__ sum_dyxh,
                                     float* __restrict__ dx, float* __restrict__ dres, long long nquads, int C,
-                                    float inv_rows, int relu, int frozen, const unsigned char* __restrict__ mask) {
+                                    float inv_rows, int relu, int frozen, const unsigned char* __restrict__ mask,
+                                    float* __restrict__ amax) {
     const int CG = C / 4;
+    float am = 0.f;         // max |dx| of this thread (-> *amax, see bn_apply_kernel)
     GRID_STRIDE(i, nquads) {
         const int g = (int)(i % CG);
         float4 d = reinterpret_cast<const float4*>(dy)[i];
@@ -675,7 +704,9 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
             }
         }
         reinterpret_cast<float4*>(dx)[i] = o;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
+    if (amax != nullptr) amax_publish(amax, am);
 }
 
 // generic column sum (bias gradients): any C, scalar path; block = 64 channels x 4 row-threads
@@ -1729,16 +1760,16 @@ extern "C" int rih_bn_eval_stats(const float* running_mean, const float* running
 }
 extern "C" int rih_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
                             const float* beta, const float* residual, float* y, int rows, int C, int relu,
-                            uint8_t* relu_mask, void* stream) {
+                            uint8_t* relu_mask, float* amax, void* stream) {
     if (!x || !mean || !invstd || !gamma || !beta || !y || rows < 1 || C < 4 || (C % 4) != 0) return RIH_EINVAL;
     const long long nq = (long long)rows * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(nq)), dim3(TPB), 0, STREAM, x, mean, invstd, gamma, beta, residual,
-                       y, nq, C, relu, relu_mask);
+                       y, nq, C, relu, relu_mask, amax);
     LAUNCH_RET();
 }
 extern "C" int rih_bn_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
                           const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C,
-                          int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, void* stream) {
+                          int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, float* amax_dx, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !dx || !dgamma || !dbeta || !ws) return RIH_EINVAL;
     if (relu && !y && !relu_mask) return RIH_EINVAL;
     if (rows < 1 || C < 4 || (C % 4) != 0) return RIH_EINVAL;
@@ -1748,14 +1779,14 @@ extern "C" int rih_bn_bwd(const float* dy, const float* x, const float* y, const
     hipLaunchKernelGGL(two_sum_final_kernel, dim3((C + 3) / 4), dim3(TPB), 0, STREAM, ws, C, g.nchunk, dbeta, dgamma);
     const long long nq = (long long)rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nq)), dim3(TPB), 0, STREAM, dy, x, y, mean, invstd, gamma,
-                       dbeta, dgamma, dx, dres, nq, C, 1.f / (float)rows, relu, frozen_stats, relu_mask);
+                       dbeta, dgamma, dx, dres, nq, C, 1.f / (float)rows, relu, frozen_stats, relu_mask, amax_dx);
     LAUNCH_RET();
 }
 
 extern "C" int rih_bn_bwd_lastblock(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
                                     const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C,
                                     int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, uint32_t* counters,
-                                    void* stream) {
+                                    float* amax_dx, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !dx || !dgamma || !dbeta || !ws || !counters) return RIH_EINVAL;
     if (relu && !y && !relu_mask) return RIH_EINVAL;
     if (rows < 1 || C < 4 || (C % 4) != 0) return RIH_EINVAL;
@@ -1764,7 +1795,7 @@ extern "C" int rih_bn_bwd_lastblock(const float* dy, const float* x, const float
                        C, g.cgb, g.rt, g.rows_per_chunk, relu, ws, relu_mask, counters, dbeta, dgamma);
     const long long nq = (long long)rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nq)), dim3(TPB), 0, STREAM, dy, x, y, mean, invstd, gamma,
-                       dbeta, dgamma, dx, dres, nq, C, 1.f / (float)rows, relu, frozen_stats, relu_mask);
+                       dbeta, dgamma, dx, dres, nq, C, 1.f / (float)rows, relu, frozen_stats, relu_mask, amax_dx);
     LAUNCH_RET();
 }
 
@@ -2002,6 +2033,13 @@ extern "C" int rih_project_bwd(const float* dout, const float* v, const float* s
     if (!dout || !v || !scale || !dv || !dscale || !dtrans || B < 1 || V < 1) return RIH_EINVAL;
     hipLaunchKernelGGL(project_bwd_kernel, dim3(B), dim3(TPB), 0, STREAM, dout, v, scale, dv, dscale, dtrans, V,
                        img_size);
+    LAUNCH_RET();
+}
+
+extern "C" int rih_absmax(const float* x, int64_t n, float* out, void* stream) {
+    if (!x || !out || n < 0) return RIH_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n, 16)), dim3(TPB), 0, STREAM, x, (long long)n, out);
     LAUNCH_RET();
 }
 

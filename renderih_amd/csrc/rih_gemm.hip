@@ -17,6 +17,8 @@
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -49,6 +51,9 @@ struct GemmArgs {
     float drop_scale;               // 1 / (1 - p)
     unsigned long long drop_seed;
     const unsigned long long* drop_seed_dev;    // device-resident addend of the seed (hipGraph replay), or NULL
+    // engine 2 (two-term fp16 split): device-resident upper bounds of |A|, |B| (one float each), or NULL = 1.0
+    const float* amax_a;
+    const float* amax_b;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -99,6 +104,52 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& 
 __device__ __forceinline__ int lds_row(int m) { return (m ^ ((m >> 4) & 1)) * 16; }
 __device__ __forceinline__ int lds_swz(int m) { return (m >> 2) & 3; }
 
+// ---- split engine 2 (ENGINE 2): fp32 operands are scaled by a power of two s (so that s * max|x| lies in [2^14, 2^15), well
+// inside the fp16 range) and split on the way into LDS into TWO fp16 planes, hi = fp16(s x) and lo = fp16((s x - hi) * 2^11)
+// (round-to-nearest both; |s x - hi - 2^-11 lo| <= 2^-23 |s x|, and lo keeps its 11 bits down to |s x| = 2^-14 * 2^-11 thanks
+// to the 2^11 pre-scale -- the error-corrected tensor-core SGEMM scheme of Ootomo & Yokota).  The product is formed with THREE
+// v_mfma_f32_32x32x16_f16 per 32x32x16 block: hi*hi into one fp32 accumulator, hi*lo + lo*hi into a second one; the epilogue
+// combines acc0 + 2^-11 acc1 and undoes the operand scales (exact: powers of two).  The dropped lo*lo term is <= 2^-22
+// relative.  Half the matrix-pipe work (and energy) per fp32 FLOP of the six-product bf16 engine: 2.5 PF / 3 = 833 TF.
+// The scale comes from a device-resident upper bound of max|x| (GemmArgs.amax_a / amax_b: written by the kernel that produced
+// the operand, or by rih_absmax): any upper bound is correct, a loose one only costs range at the bottom (full 22-bit
+// precision for |x| >= 2^-29 * bound).
+__device__ __forceinline__ float e2_scale(const float* amax, bool at_least_one) {
+    if (amax == nullptr) return 1.f;
+    float a = *amax;
+    if (at_least_one) a = fmaxf(a, 1.f);            // the all-ones row of a weight-gradient's A operand must stay in range
+    const int e = (int)((__float_as_uint(a) >> 23) & 0xffu);
+    if (e == 0 || e == 255) return 1.f;             // zero / denormal bound (an all-zero operand), or inf / NaN (garbage either way)
+    int se = 268 - e;                               // 2^(14 - (e - 127)), biased
+    se = se > 253 ? 253 : se;                       // keep 1/s a normal number
+    return __uint_as_float((unsigned)se << 23);
+}
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {
+    const f16x2 v = {(_Float16)a, (_Float16)b};     // RNE; a in the low half
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void split2h(float a, float b, float s, unsigned& h, unsigned& l) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // six mixed-precision FMAs per pair (hipcc's own selection for the C form below takes ten): the f16 result of
+    // v_fma_mix{lo,hi}_f16 is the RNE conversion of the exact product (a power-of-two scaling), v_fma_mix_f32 reads the f16 half
+    // back as an addend, so the residual a*s - hi is one instruction and exact
+    float ra, rb;
+    const float k2048 = 2048.f;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a), "s"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(b), "s"(s));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(a), "s"(s), "v"(h));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(b), "s"(s), "v"(h));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(l) : "v"(ra), "s"(k2048));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l) : "v"(rb), "s"(k2048));
+#else       /* host build of tests/hipcpu: the same arithmetic in C */
+    a *= s;
+    b *= s;
+    const f16x2 hv = {(_Float16)a, (_Float16)b};
+    h = __builtin_bit_cast(unsigned, hv);
+    l = pk_f16((a - (float)hv.x) * 2048.f, (b - (float)hv.y) * 2048.f);        // the differences are exact in fp32
+#endif
+}
+
 // Epilogue shared by the kernels below.  Accumulators -> LDS (one 32x32 block per wave at a time; the operand tiles are dead
 // by then) -> each lane owns 4 consecutive columns of a row: one 16-byte residual load and one 16-byte store per lane, 8 lanes
 // per 128-byte row segment -- a quarter of the store instructions of the column-per-lane C/D layout.  The store phase of these
@@ -113,10 +164,13 @@ constexpr int SLD = 36;             // floats per staged row: 32 + pad, keeps fl
 // DROP (rih_gemm_desc.drop_p > 0; plain a_mode-0 GEMMs = nn.Linear): v = dropout(act(alpha acc + bias)) + R -- the mask stream
 // of rih_add_dropout over the output tensor (element index = offset from desc.C), so the fused form equals
 // rih_gemm followed by rih_add_dropout(R, ., p, seed) bit for bit and rih_dropout_bwd re-draws the same mask.
-template <int TM, int TN, bool STATS = false, bool DROP = false>
+// E2 (engine 2): the staged value is (acc + 2^-11 acc1) * inv_a * inv_b -- the correction accumulator folded in and the operand
+// scales undone (also for the raw split-K slabs, whose reduction knows nothing of scales).
+template <int TM, int TN, bool STATS = false, bool DROP = false, bool E2 = false>
 __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&acc)[TM][TN], float* stg, float* __restrict__ C,
                                                  const float* __restrict__ biasp, const float* __restrict__ Rp, int mbase,
-                                                 int nbase, int lane) {
+                                                 int nbase, int lane, floatx16 (*acc1)[TN] = nullptr, float inv_a = 1.f,
+                                                 float inv_b = 1.f) {
     const bool raw = (p.splitk > 1);
     const bool vec = p.epi_vec != 0;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -135,7 +189,11 @@ __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&a
         for (int j = 0; j < TN; ++j) {
             if (i + j > 0) __syncthreads();         // the previous block has been read back
 #pragma unroll
-            for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + l31] = acc[i][j][r];
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r];
+                if (E2) v = fmaf(acc1[i][j][r], 0x1p-11f, v) * inv_a * inv_b;
+                stg[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + l31] = v;
+            }
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -720,9 +778,13 @@ __device__ __forceinline__ uint4 bloadu4(__amdgpu_buffer_rsrc_t r, unsigned off)
 // plus the per-row window offsets and tap validity bits.  With both operands pre-split the kernel converts nothing.
 // The kernel body takes the block coordinates as arguments: gemm_split_kernel passes blockIdx / gridDim, the grouped launch
 // (gemm_split_multi_kernel, rih_gemm_multi) the coordinates of a block inside ITS problem of a descriptor table.
-template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false>
+// ENG 2: the two-term fp16 split (three MFMA products, see e2_scale / split2h above) instead of the three-term bf16 one; same
+// loaders, LDS layout (two planes instead of three) and epilogue.  Not with pre-split operands.
+template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false, int ENG = 1>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk_x, const int blk_z, const int grid_x,
                                                 const int grid_z) {
+    static_assert(ENG == 1 || (ENG == 2 && !APRE && BMODE != 2), "engine 2 converts both operands itself");
+    constexpr int NPL = (ENG == 2) ? 2 : 3;         // 16-bit planes per operand
     // global->register prefetch depth: k-tiles in flight.  The 64x64 tile (decoder-sized problems: a handful of
     // k-tiles, 12 MFMAs each) is bound by the load round trip per k-tile, so it keeps three tiles in flight.
     constexpr int PF = 1;     // (measured: 3 tiles in flight for the 64x64 tile changes nothing, the floor is elsewhere)
@@ -733,14 +795,23 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
     constexpr int NPA = BM / 32, NPB = BN / 32;
     constexpr int QA = BM / 4, QB = BN / 4;
 
-    __shared__ __attribute__((aligned(16))) unsigned smem[3 * (PLANE_A + PLANE_B)];
+    constexpr int OPER_DW = NPL * (PLANE_A + PLANE_B);
+    constexpr int SMEM_DW = OPER_DW > 4 * 32 * SLD ? OPER_DW : 4 * 32 * SLD;       // >= the epilogue's staging area
+    __shared__ __attribute__((aligned(16))) unsigned smem[SMEM_DW];
     unsigned* As = smem;
-    unsigned* Bs = smem + 3 * PLANE_A;
+    unsigned* Bs = smem + NPL * PLANE_A;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
+
+    // engine 2: power-of-two operand scales from the device-resident bounds (scalar loads, wave-uniform)
+    float e2_sa = 1.f, e2_sb = 1.f;
+    if (ENG == 2) {
+        e2_sa = e2_scale(p.amax_a, AMODE == 1 && p.ones_row > 0);
+        e2_sb = e2_scale(p.amax_b, false);
+    }
 
     const int tilesN = (p.N + BN - 1) / BN;
     // Workgroups are dispatched x-fastest and round-robin over the 8 XCDs.  Remap so that each XCD (private L2) gets a
@@ -1007,37 +1078,53 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
         }
     };
 
-    auto put4 = [](unsigned* u, int plane, float x0, float x1, float x2, float x3) {
-        unsigned h0, m0_, l0, h1, m1, l1;
-        split2(x0, x1, h0, m0_, l0);
-        split2(x2, x3, h1, m1, l1);
-        *reinterpret_cast<uint2*>(u) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(u + plane) = make_uint2(m0_, m1);
-        *reinterpret_cast<uint2*>(u + 2 * plane) = make_uint2(l0, l1);
+    // `sc`: engine 2's operand scale (unused by engine 1)
+    auto put4 = [](unsigned* u, int plane, float sc, float x0, float x1, float x2, float x3) {
+        if (ENG == 2) {
+            unsigned h0, l0, h1, l1;
+            split2h(x0, x1, sc, h0, l0);
+            split2h(x2, x3, sc, h1, l1);
+            *reinterpret_cast<uint2*>(u) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(u + plane) = make_uint2(l0, l1);
+        } else {
+            unsigned h0, m0_, l0, h1, m1, l1;
+            split2(x0, x1, h0, m0_, l0);
+            split2(x2, x3, h1, m1, l1);
+            *reinterpret_cast<uint2*>(u) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(u + plane) = make_uint2(m0_, m1);
+            *reinterpret_cast<uint2*>(u + 2 * plane) = make_uint2(l0, l1);
+        }
     };
-    auto put2 = [](unsigned* u, int plane, float x0, float x1) {
-        unsigned h, m, l;
-        split2(x0, x1, h, m, l);
-        u[0] = h;
-        u[plane] = m;
-        u[2 * plane] = l;
+    auto put2 = [](unsigned* u, int plane, float sc, float x0, float x1) {
+        if (ENG == 2) {
+            unsigned h, l;
+            split2h(x0, x1, sc, h, l);
+            u[0] = h;
+            u[plane] = l;
+        } else {
+            unsigned h, m, l;
+            split2(x0, x1, h, m, l);
+            u[0] = h;
+            u[plane] = m;
+            u[2 * plane] = l;
+        }
     };
-    auto store_kcontig = [&](unsigned* base, int plane, const float4* reg, const int* st, int npass) {
+    auto store_kcontig = [&](unsigned* base, int plane, float sc, const float4* reg, const int* st, int npass) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (i < npass) put4(base + st[i], plane, reg[i].x, reg[i].y, reg[i].z, reg[i].w);
+            if (i < npass) put4(base + st[i], plane, sc, reg[i].x, reg[i].y, reg[i].z, reg[i].w);
     };
-    auto store_kstrided = [&](unsigned* base, int plane, const float4* reg, const int* st, int np) {
+    auto store_kstrided = [&](unsigned* base, int plane, float sc, const float4* reg, const int* st, int np) {
         if (np == 4) {
-            put4(base + st[0], plane, reg[0].x, reg[1].x, reg[2].x, reg[3].x);
-            put4(base + st[1], plane, reg[0].y, reg[1].y, reg[2].y, reg[3].y);
-            put4(base + st[2], plane, reg[0].z, reg[1].z, reg[2].z, reg[3].z);
-            put4(base + st[3], plane, reg[0].w, reg[1].w, reg[2].w, reg[3].w);
+            put4(base + st[0], plane, sc, reg[0].x, reg[1].x, reg[2].x, reg[3].x);
+            put4(base + st[1], plane, sc, reg[0].y, reg[1].y, reg[2].y, reg[3].y);
+            put4(base + st[2], plane, sc, reg[0].z, reg[1].z, reg[2].z, reg[3].z);
+            put4(base + st[3], plane, sc, reg[0].w, reg[1].w, reg[2].w, reg[3].w);
         } else {
-            put2(base + st[0], plane, reg[0].x, reg[1].x);
-            put2(base + st[1], plane, reg[0].y, reg[1].y);
-            put2(base + st[2], plane, reg[0].z, reg[1].z);
-            put2(base + st[3], plane, reg[0].w, reg[1].w);
+            put2(base + st[0], plane, sc, reg[0].x, reg[1].x);
+            put2(base + st[1], plane, sc, reg[0].y, reg[1].y);
+            put2(base + st[2], plane, sc, reg[0].z, reg[1].z);
+            put2(base + st[3], plane, sc, reg[0].w, reg[1].w);
         }
     };
     auto store_A = [&](int st) {
@@ -1047,8 +1134,8 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
 #pragma unroll
                 for (int i = 0; i < APASS; ++i)
                     if ((tid >> 2) + 64 * i < BM) *reinterpret_cast<uint4*>(As + pl * PLANE_A + ap_st[i]) = apre[st][pl][i];
-        } else if (AMODE == 0) store_kcontig(As, PLANE_A, areg[st], a_st, NPA);
-        else store_kstrided(As, PLANE_A, areg[st], a_st, NPA);
+        } else if (AMODE == 0) store_kcontig(As, PLANE_A, e2_sa, areg[st], a_st, NPA);
+        else store_kstrided(As, PLANE_A, e2_sa, areg[st], a_st, NPA);
     };
     auto store_B = [&](int st) {
         if (BMODE == 2) {
@@ -1057,18 +1144,22 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
 #pragma unroll
                 for (int i = 0; i < BPASS; ++i)
                     if ((tid >> 2) + 64 * i < BN) *reinterpret_cast<uint4*>(Bs + pl * PLANE_B + bp_st[i]) = bpre[st][pl][i];
-        } else if (BMODE == 1) store_kcontig(Bs, PLANE_B, breg[st], b_st, NPB);
-        else store_kstrided(Bs, PLANE_B, breg[st], b_st, NPB);
+        } else if (BMODE == 1) store_kcontig(Bs, PLANE_B, e2_sb, breg[st], b_st, NPB);
+        else store_kstrided(Bs, PLANE_B, e2_sb, breg[st], b_st, NPB);
     };
 
     // ------------------------------------------------------------------ main loop
     floatx16 acc[TM][TN];
+    floatx16 acc1[ENG == 2 ? TM : 1][TN];           // engine 2: hi*lo + lo*hi (scaled by 2^11)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if (ENG == 2) acc1[i][j][r] = 0.f;
+            }
 
     // prologue: tiles 0..PF-1 in flight (a tile at or beyond kend arrives as zeros and is never multiplied)
 #pragma unroll
@@ -1101,6 +1192,28 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
                 load_A(kbeg + (t + j + PF) * BK, j);
                 load_B(kbeg + (t + j + PF) * BK, j);
                 __syncthreads();
+                if constexpr (ENG == 2) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        f16x8 av[2][TM], bv[2][TN];
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+                                av[pl][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(As + pl * PLANE_A + sa_off[s] + i * 512));
+#pragma unroll
+                            for (int jj = 0; jj < TN; ++jj)
+                                bv[pl][jj] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(Bs + pl * PLANE_B + sb_off[s] + jj * 512));
+                        }
+#define RIH_E2_TERM(ACC_, PA_, PB_)                                                                               \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int jj = 0; jj < TN; ++jj) ACC_[i][jj] = \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(av[PA_][i], bv[PB_][jj], ACC_[i][jj], 0, 0, 0);
+                        RIH_E2_TERM(acc1, 1, 0)
+                        RIH_E2_TERM(acc, 0, 0)
+                        RIH_E2_TERM(acc1, 0, 1)
+#undef RIH_E2_TERM
+                    }
+                } else {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     bf16x8 av[3][TM], bv[3][TN];
@@ -1124,20 +1237,26 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
                     RIH_SPLIT_TERM(0, 0)
 #undef RIH_SPLIT_TERM
                 }
+                }
                 __syncthreads();
             }
         }
     }
 
     // ------------------------------------------------------------------ epilogue (store_tiles_wide; the main loop ended with a barrier)
-    store_tiles_wide<TM, TN, STATS, DROP>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp, m0 + wm * WM, n0 + wn * WN,
-                                    lane);
+    if constexpr (ENG == 2) {
+        store_tiles_wide<TM, TN, STATS, DROP, true>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp,
+                                                    m0 + wm * WM, n0 + wn * WN, lane, acc1, 1.f / e2_sa, 1.f / e2_sb);
+    } else {
+        store_tiles_wide<TM, TN, STATS, DROP>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp, m0 + wm * WM, n0 + wn * WN,
+                                        lane);
+    }
 }
 
-template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false>
+template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false, int ENG = 1>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
-    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, APRE, STATS, DROP>(p, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.x,
-                                                                    (int)gridDim.z);
+    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, APRE, STATS, DROP, ENG>(p, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.x,
+                                                                         (int)gridDim.z);
 }
 
 // ---- grouped launch (rih_gemm_multi): n independent problems of ONE kernel variant in one launch.  The table lives in device
@@ -1163,7 +1282,7 @@ struct MultiHeader {
 #endif
 #endif
 
-template <int BM, int BN, int AMODE, int BMODE, bool PLAIN>
+template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, int ENG = 1>
 __global__ __launch_bounds__(256, 2) void gemm_split_multi_kernel(const unsigned char* __restrict__ table) {
     const int b = (int)blockIdx.x;
     const MultiHeader RIH_CONST_AS* hd = (const MultiHeader RIH_CONST_AS*)table;
@@ -1176,7 +1295,27 @@ __global__ __launch_bounds__(256, 2) void gemm_split_multi_kernel(const unsigned
     const int gx = pr->gx, gz = pr->gz;
     if (lb >= gx * gz) return;              // padding block
     const GemmArgs p = pr->a;               // scalar loads; the copy lives in SGPRs like a kernel argument
-    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN>(p, lb % gx, lb / gx, gx, gz);
+    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, false, false, false, ENG>(p, lb % gx, lb / gx, gx, gz);
+}
+
+template <int BM, int BN>
+int launch_split_e2(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 grid, hipStream_t s) {
+    dim3 block(256);
+#define RIH_L2(AM_, BM_, PL_, ST_, DR_) \
+    hipLaunchKernelGGL((gemm_split_kernel<BM, BN, AM_, BM_, PL_, false, ST_, DR_, 2>), grid, block, 0, s, a)
+    if (a_mode > 1 || b_mode > 1) return RIH_EINVAL;
+    if (a.drop_thr != 0u) {
+        if (b_mode == 0) RIH_L2(0, 0, true, false, true); else RIH_L2(0, 1, true, false, true);
+    } else if (a.stats != nullptr) {
+        if (b_mode == 0) { if (plain) RIH_L2(0, 0, true, true, false); else RIH_L2(0, 0, false, true, false); }
+        else { if (plain) RIH_L2(0, 1, true, true, false); else RIH_L2(0, 1, false, true, false); }
+    }
+    else if (a_mode == 0 && b_mode == 0) { if (plain) RIH_L2(0, 0, true, false, false); else RIH_L2(0, 0, false, false, false); }
+    else if (a_mode == 0 && b_mode == 1) { if (plain) RIH_L2(0, 1, true, false, false); else RIH_L2(0, 1, false, false, false); }
+    else if (a_mode == 1 && b_mode == 0) { if (plain) RIH_L2(1, 0, true, false, false); else RIH_L2(1, 0, false, false, false); }
+    else { if (plain) RIH_L2(1, 1, true, false, false); else RIH_L2(1, 1, false, false, false); }
+#undef RIH_L2
+    return (int)hipGetLastError();
 }
 
 template <int BM, int BN>
@@ -1855,10 +1994,10 @@ extern "C" int rih_presplit_conv_weight(const float* w, void* dst, int Cout, int
 
 struct PreparedGemm {       // what gemm_impl would launch on the split engine's fast path (tiles 0..2), for rih_gemm_multi
     GemmArgs a;
-    int gx, gz, tile, a_mode, b_mode, plain;
+    int gx, gz, tile, a_mode, b_mode, plain, engine;
 };
 
-static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, PreparedGemm* prep = nullptr) {
+static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, PreparedGemm* prep = nullptr, int* engine_out = nullptr) {
     if (!d || !d->A || !d->B || !d->C) return RIH_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K < 0) return RIH_EINVAL;
     if (d->splitk < 1 || d->nb1 < 1 || d->nb2 < 1) return RIH_EINVAL;
@@ -1906,6 +2045,7 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
     a.ones_row = d->ones_row;
     a.stats = d->stats;
     a.drop_thr = 0u; a.drop_scale = 1.f; a.drop_seed = 0ull; a.drop_seed_dev = nullptr;
+    a.amax_a = d->amax_a; a.amax_b = d->amax_b;
     if (d->drop_p != 0.f) {
         if (!(d->drop_p > 0.f && d->drop_p < 1.f)) return RIH_EINVAL;
         double t = (double)d->drop_p * 4294967296.0;            // = drop_thresh() of csrc/rih_elem.hip
@@ -1936,8 +2076,13 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
     if (tiles > 0x7fffffffLL || gz > 65535) return RIH_EINVAL;
     dim3 grid((unsigned)tiles, 1, (unsigned)gz);
     hipStream_t s = (hipStream_t)stream;
-    if (d->engine != 0 && d->engine != 1) return RIH_EINVAL;
-    if (d->engine == 1 && d->tile != 3 && a16 && b16 && d->upS == 1 && d->K % 4 == 0) {
+    if (d->engine < 0 || d->engine > 2) return RIH_EINVAL;
+    // engine 2 exists on the split engines' fast path only (tiles 0..2, operands converted by the kernel): anything else that
+    // asks for it runs engine 1 -- same fp32-grade result, the six-product arithmetic (rih_gemm_engine tells in advance)
+    const bool e2 = d->engine == 2 && d->tile <= 2 && d->a_mode <= 1 && d->b_mode <= 1;
+    const int engine = d->engine == 2 ? 1 : d->engine;
+    if (engine_out != nullptr) *engine_out = engine;
+    if (engine == 1 && d->tile != 3 && a16 && b16 && d->upS == 1 && d->K % 4 == 0) {
         // fast path of the split engine (see gemm_split_kernel for the preconditions)
         const bool plain = (d->KH == 1 && d->KW == 1 && d->strideA == 1 && d->padH == 0 && d->padW == 0 &&
                             d->H == d->Ho && d->W == d->Wo);
@@ -1962,6 +2107,7 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
             if (d->stats != nullptr || d->drop_p != 0.f) return RIH_EINVAL;
             ok = ok && !(d->a_mode == 1 && d->b_mode == 1);
             if (!ok) return RIH_EINVAL;
+            if (engine_out != nullptr) return 0;
             a.a_bytes = (unsigned)a_bytes;
             a.b_bytes = (unsigned)b_bytes;
             return launch_split256(a, d->a_mode, d->b_mode, plain, grid, s);
@@ -1982,12 +2128,20 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
             a.a_bytes = (unsigned)a_bytes;
             a.b_bytes = (unsigned)b_bytes;
             a.a_plane = (unsigned)a_plane;
+            if (engine_out != nullptr) *engine_out = e2 ? 2 : 1;
             if (prep != nullptr) {
                 if (d->stats != nullptr || d->a_mode > 1 || d->b_mode > 1) return RIH_EINVAL;
                 prep->a = a;
                 prep->gx = (int)grid.x; prep->gz = (int)grid.z;
                 prep->tile = d->tile; prep->a_mode = d->a_mode; prep->b_mode = d->b_mode; prep->plain = plain ? 1 : 0;
+                prep->engine = e2 ? 2 : 1;
                 return 0;
+            }
+            if (engine_out != nullptr) return 0;                       // rih_gemm_engine: a query, no launch
+            if (e2) {
+                if (d->tile == 0) return launch_split_e2<128, 128>(a, d->a_mode, d->b_mode, plain, grid, s);
+                if (d->tile == 1) return launch_split_e2<128, 64>(a, d->a_mode, d->b_mode, plain, grid, s);
+                return launch_split_e2<64, 64>(a, d->a_mode, d->b_mode, plain, grid, s);
             }
             if (d->tile == 0) return launch_split<128, 128>(a, d->a_mode, d->b_mode, plain, grid, s);
             if (d->tile == 1) return launch_split<128, 64>(a, d->a_mode, d->b_mode, plain, grid, s);
@@ -2000,10 +2154,14 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
     if (d->stats != nullptr) return RIH_EINVAL;
     if (d->b_mode == 2 || d->a_mode == 2) return RIH_EINVAL;  // the general kernels do not read pre-split operands
     if (d->tile == 4) return RIH_EINVAL;    // 256x128 exists only on the split engine's fast path
-    if (d->tile == 0) return launch_tile<128, 128>(a, d->a_mode, d->b_mode, d->engine, grid, s);
-    if (d->tile == 1) return launch_tile<128, 64>(a, d->a_mode, d->b_mode, d->engine, grid, s);
+    if (engine_out != nullptr) {                              // rih_gemm_engine: a query, no launch
+        if (d->tile == 3) *engine_out = 0;
+        return 0;
+    }
+    if (d->tile == 0) return launch_tile<128, 128>(a, d->a_mode, d->b_mode, engine, grid, s);
+    if (d->tile == 1) return launch_tile<128, 64>(a, d->a_mode, d->b_mode, engine, grid, s);
     if (d->tile == 3) return launch_tile<128, 32>(a, d->a_mode, d->b_mode, 0, grid, s);
-    return launch_tile<64, 64>(a, d->a_mode, d->b_mode, d->engine, grid, s);
+    return launch_tile<64, 64>(a, d->a_mode, d->b_mode, engine, grid, s);
 }
 
 extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) { return gemm_impl(d, stream, nullptr); }
@@ -2018,9 +2176,16 @@ extern "C" int rih_gemm_multi_variant(const rih_gemm_desc* d) {
     switch (v) {
         case 2 * 8 + 4 + 0 + 1: case 2 * 8 + 4 + 0 + 0:         // 64x64 weight gradients (plain / conv gather)
         case 0 * 8 + 4 + 0 + 1: case 0 * 8 + 4 + 0 + 0:         // 128x128 weight gradients
-            return v;
+            return v + (pg.engine == 2 ? 64 : 0);               // + 64: the same variant on engine 2
         default: return -1;
     }
+}
+
+// The engine rih_gemm would run `d` on: 0 / 1 / 2 (a descriptor asking for engine 2 off the fast path runs engine 1), or -1.
+extern "C" int rih_gemm_engine(const rih_gemm_desc* d) {
+    int e = -1;
+    if (gemm_impl(d, nullptr, nullptr, nullptr, &e) != 0) return -1;
+    return e;
 }
 
 extern "C" int64_t rih_gemm_multi_table_bytes(const rih_gemm_desc* descs, int n) {
@@ -2083,6 +2248,10 @@ extern "C" int rih_gemm_multi_launch(const void* dev_table, int variant, int tot
         case 2 * 8 + 4 + 0: hipLaunchKernelGGL((gemm_split_multi_kernel<64, 64, 1, 0, false>), grid, block, 0, s, t); break;
         case 0 * 8 + 4 + 1: hipLaunchKernelGGL((gemm_split_multi_kernel<128, 128, 1, 0, true>), grid, block, 0, s, t); break;
         case 0 * 8 + 4 + 0: hipLaunchKernelGGL((gemm_split_multi_kernel<128, 128, 1, 0, false>), grid, block, 0, s, t); break;
+        case 64 + 2 * 8 + 4 + 1: hipLaunchKernelGGL((gemm_split_multi_kernel<64, 64, 1, 0, true, 2>), grid, block, 0, s, t); break;
+        case 64 + 2 * 8 + 4 + 0: hipLaunchKernelGGL((gemm_split_multi_kernel<64, 64, 1, 0, false, 2>), grid, block, 0, s, t); break;
+        case 64 + 0 * 8 + 4 + 1: hipLaunchKernelGGL((gemm_split_multi_kernel<128, 128, 1, 0, true, 2>), grid, block, 0, s, t); break;
+        case 64 + 0 * 8 + 4 + 0: hipLaunchKernelGGL((gemm_split_multi_kernel<128, 128, 1, 0, false, 2>), grid, block, 0, s, t); break;
         default: return RIH_EINVAL;
     }
     return (int)hipGetLastError();

@@ -302,7 +302,7 @@ class resnet_mid(nn.Module):
                 fmaps.append(None)
                 continue
             parts = [hms_fmaps[i], dp_fmaps[i]] + ([img_fmaps[i]] if i > 0 else [])
-            x = torch.cat(parts, dim=-1)                     # channel concat = last dim in NHWC (pure copy)
+            x = ops.cat_channels(parts)                      # channel concat = last dim in NHWC (pure copy)
             if drop_last and i == last:
                 with torch.no_grad():
                     holder = ops.StatsHolder() if ops.GEMM_STATS else None

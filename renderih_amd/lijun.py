@@ -386,6 +386,8 @@ class HandNET_GCN(nn.Module):
         return self
 
     def forward(self, img):
+        if ops.ENGINE == 2:
+            ops.bounds_reset()          # see renderih_amd.model.HandNET_GCN.forward
         if self._half is not None and not self.training and not torch.is_grad_enabled():
             global_feature, fmaps = self._half(img)
         else:

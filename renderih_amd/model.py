@@ -8,7 +8,7 @@ import pickle
 import torch
 import torch.nn as nn
 
-from . import assets
+from . import assets, ops
 from .config import load_cfg
 from .encoder import load_encoder, flush_batches_tracked
 from .decoder import decoder as Decoder
@@ -41,6 +41,8 @@ class HandNET_GCN(nn.Module):
         return self
 
     def forward(self, img):
+        if ops.ENGINE == 2:
+            ops.bounds_reset()          # operand bounds of the three-product GEMM engine are per forward pass (ops.bound_of)
         if self._half is not None and not self.training and not torch.is_grad_enabled():
             hms, mask, dp, global_feature, fmaps = self._half(img)
         else:

@@ -55,6 +55,7 @@ def plan_gemm(M, N, K, batch=1, engine=None):
     blocks per CU and long k-loops (its per-block prologue/epilogue is expensive), so deep-K problems with few
     output tiles are split over K instead of shrinking the tile."""
     e = ENGINE if engine is None else engine
+    e = min(e, 1)            # engine 2 shares engine 1's kernels' structure: planned alike
     if N <= 32:
         # 16 < N <= 32 (HRNet's 32-channel branch): a half-empty split-engine tile beats the 128x32 tile of the native-f32
         # engine by 6-9 % (profiles/r02/n32_bench_m31.log); below that the waste is too large
@@ -96,6 +97,91 @@ _TILE_MN = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (256, 128
 # always runs engine 0.
 import os as _os
 ENGINE = int(_os.environ.get('RIH_GEMM_ENGINE', '1'))
+
+# Engine 2 (RIH_GEMM_ENGINE=2; rih_gemm_desc.engine 2): fp32 on THREE fp16 MFMA products.  Each operand needs a device-resident
+# upper bound of its largest magnitude (rih_gemm_desc.amax_a / amax_b) from which the kernel derives its power-of-two scale.
+# `bound_of(t)` returns that bound as a one-element tensor: the one the producing kernel left on the tensor (`set_bound`), the
+# one cached from an earlier use, or a fresh rih_absmax pass.  A call site that has no bounds for both operands runs engine 1.
+class _BoundPool:
+    """Zeroed one-float slots carved out of chunks (one fill launch per 1024 slots; a chunk allocated while a stream captures
+    is re-zeroed by every replay of the graph)."""
+    CHUNK = 1024
+
+    def __init__(self):
+        self.chunk = {}
+
+    def slot(self, device):
+        key = (device.type, device.index)
+        ent = self.chunk.get(key)
+        if ent is None or ent[1] >= self.CHUNK:
+            ent = self.chunk[key] = [torch.zeros((self.CHUNK,), device=device, dtype=torch.float32), 0]
+        i = ent[1]
+        ent[1] = i + 1
+        return ent[0][i:i + 1]
+
+    def reset(self):
+        self.chunk.clear()
+
+
+_BOUNDS = _BoundPool()
+_BOUND_EPOCH = 0            # cached bounds (tensor attribute `_rih_bound`) are valid inside one epoch only
+
+
+def bound_slot(device):
+    return _BOUNDS.slot(device)
+
+
+def bounds_reset():
+    """Forget every cached bound and start new slot chunks.  Called at the top of every model forward (HandNET_GCN.forward,
+    TrainStep): parameters are rewritten between steps by kernels torch's version counters do not see (rih_adam_multi), and
+    inside a captured step every bound must be (re)computed by a launch of the graph, into slots the graph zeroes."""
+    global _BOUND_EPOCH
+    _BOUND_EPOCH += 1
+    _BOUNDS.reset()
+
+
+def set_bound(t, slot):
+    t._rih_bound = (slot, t._version, _BOUND_EPOCH)
+    return t
+
+
+def cached_bound(t):
+    ent = getattr(t, '_rih_bound', None)
+    return ent[0] if (ent is not None and ent[1] == t._version and ent[2] == _BOUND_EPOCH) else None
+
+
+def inherit_bound(y, *xs):
+    """y's values are bounded by the largest magnitude among xs (selections / convex combinations / a concatenation of them):
+    hand their bound on when every x carries one (engine 2 only; a missing bound leaves y without one -- bound_of then
+    measures it)."""
+    if ENGINE != 2:
+        return y
+    slots = [cached_bound(x) for x in xs]
+    if any(s_ is None for s_ in slots):
+        return y
+    b = slots[0]
+    for s_ in slots[1:]:
+        b = torch.maximum(b, s_)
+    return set_bound(y, b)
+
+
+def cat_channels(parts):
+    """Channel concatenation of NHWC maps (models/encoder.py:165-173)."""
+    return inherit_bound(torch.cat(parts, dim=-1), *parts)
+
+
+def bound_of(t):
+    """One-element fp32 tensor >= max|t| (see above).  The cache entry dies with an in-place modification of t that torch
+    sees, and with the next bounds_reset()."""
+    ent = getattr(t, '_rih_bound', None)
+    if ent is not None and ent[1] == t._version and ent[2] == _BOUND_EPOCH:
+        return ent[0]
+    slot = bound_slot(t.device)
+    tc = _c(t)
+    check(_L().rih_absmax(tc.data_ptr(), tc.numel(), slot.data_ptr(), _stream()), 'rih_absmax')
+    t._rih_bound = (slot, t._version, _BOUND_EPOCH)
+    return slot
+
 
 # Optional device-resident dropout seed word (a 1-element int64 CUDA tensor): when set, every dropout kernel adds
 # *DROPOUT_SEED_TENSOR to its seed on the GPU.  A training step captured in a hipGraph advances the word inside the graph
@@ -179,7 +265,8 @@ class StatsHolder:
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=None, ldr=0,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, kchunk=0, sCsplit=0, alpha=1.0, relu=False,
-         geom=None, tile=None, engine=None, cstride=None, ones_row=0, sBias=0, sR=0, collect=None, stats=None, drop=None):
+         geom=None, tile=None, engine=None, cstride=None, ones_row=0, sBias=0, sR=0, collect=None, stats=None, drop=None,
+         amax_a=None, amax_b=None):
     """Enqueue one rih_gemm.  A/B/Cout/bias/R are tensors or raw device pointers.
     cstride = (s, oh, ow, H, W): store GEMM row (img, i, j) to pixel (img, i*s+oh, j*s+ow) of a [*, H, W] tensor.
     collect: a GroupedGemms -- the problem joins its next grouped launch (rih_gemm_multi) when its kernel variant can ride
@@ -188,13 +275,19 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
     engine's statistics epilogue (left empty otherwise: the BatchNorm then runs its own statistics pass).
     drop = (p, seed): C = dropout(act(alpha A B + bias)) + R in the epilogue when the descriptor takes that path
     (rih_gemm_dropout_ok) -- returns True; otherwise act(alpha A B + bias) is computed WITHOUT R and False is returned: the caller
-    finishes with rih_add_dropout(R, C, p, seed), which draws the same mask stream."""
+    finishes with rih_add_dropout(R, C, p, seed), which draws the same mask stream.
+    amax_a / amax_b (engine 2): one-element fp32 tensors (or raw device pointers) holding an upper bound of max|A| / max|B|
+    (rih_gemm_desc.amax_a); None = the operand is known to lie inside +-2^15."""
     d = GemmDesc()
+    d.amax_a = amax_a if isinstance(amax_a, int) else _p(amax_a)
+    d.amax_b = amax_b if isinstance(amax_b, int) else _p(amax_b)
     if cstride is not None:
         d.cS, d.cOH, d.cOW, d.cH, d.cW = cstride
     d.ones_row = ones_row
     d.sBias1, d.sR1 = sBias, sR
     d.engine = ENGINE if engine is None else engine
+    if d.engine == 2 and (amax_a is None or amax_b is None):
+        d.engine = 1            # no operand bounds at this call site: the six-product engine needs none
     d.A = A if isinstance(A, int) else A.data_ptr()
     d.B = B if isinstance(B, int) else B.data_ptr()
     d.C = Cout if isinstance(Cout, int) else Cout.data_ptr()
@@ -237,7 +330,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
         if sk > 1:
             part = torch.empty((sk, M, N), device=Cout.device, dtype=torch.float32)
             gemm(A, B, part, M, N, K, lda, ldb, N, a_mode=a_mode, b_mode=b_mode, splitk=sk, kchunk=kc,
-                 sCsplit=M * N, geom=geom, tile=d.tile, engine=d.engine)
+                 sCsplit=M * N, geom=geom, tile=d.tile, engine=d.engine, amax_a=amax_a, amax_b=amax_b)
             check(_L().rih_splitk_finish(part.data_ptr(), sk, M, N, d.C, ldc, d.bias or 0, d.R or 0, ldr,
                                          alpha, 1 if relu else 0, _stream()), 'rih_splitk_finish')
             return False
@@ -249,7 +342,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
             req.T, req.rows = _cdiv(M, rows_per), rows_per
             req.part = torch.empty((req.T, 2, N), device=Cout.device, dtype=torch.float32)
             d.stats = req.part.data_ptr()
-    if collect is not None and collect.add(d, (A, B, Cout), 2.0 * M * N * K * nb1 * nb2):
+    if collect is not None and collect.add(d, (A, B, Cout, amax_a, amax_b), 2.0 * M * N * K * nb1 * nb2):
         return
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -485,7 +578,7 @@ class deferred_reductions:
         global _DEFERRED, _DEFERRED_LN, _DEFERRED_GEMM
         assert _DEFERRED is None, 'deferred_reductions does not nest'
         _DEFERRED, _DEFERRED_LN = [], []
-        _DEFERRED_GEMM = GroupedGemms() if (GROUP_WGRAD and ENGINE == 1) else None
+        _DEFERRED_GEMM = GroupedGemms() if (GROUP_WGRAD and ENGINE >= 1) else None
         return self
 
     def __exit__(self, et, ev, tb):
@@ -511,18 +604,18 @@ class deferred_reductions:
         return False
 
 
-def _wgrad(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db=None, nb=1, sx=0, sdy=0):
+def _wgrad(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db=None, nb=1, sx=0, sdy=0, bounds=None):
     sw = SIDE_WGRAD
     if sw is None or not x.is_cuda:
-        return _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db, nb, sx, sdy)
+        return _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db, nb, sx, sdy, bounds)
     sw.stream.wait_stream(torch.cuda.current_stream())      # x, dy (and everything before them) are ready
     with torch.cuda.stream(sw.stream):
-        _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db, nb, sx, sdy)
+        _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db, nb, sx, sdy, bounds)
     sw.keep.extend((x, dy, dw, db))
     sw.used = True
 
 
-def _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db=None, nb=1, sx=0, sdy=0):
+def _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db=None, nb=1, sx=0, sdy=0, bounds=None):
     """dw (parameter layout) = im2col(x)^T @ dy with split-K over the Kpix pixels.  With `db` (bias gradient, [Ncols])
     the A operand gets an all-ones row behind its Mrows rows, so the same GEMM also produces the column sums of dy.
     nb > 1: that many independent gradients in one GEMM + one reduce launch (x / dy slices sx / sdy floats apart, sx = 0
@@ -532,19 +625,19 @@ def _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin
     # -- but only for short pixel reductions: from ~16k pixels on, 128x128 tiles with more K-slices win by 15-20%
     # (profiles/r02/tile_sweep_m15.log: 256->128 @64x64, 128<->512 @32x32)
     small = _cdiv(Mp, 128) * _cdiv(Ncols, 128) <= 4 and (Kpix < 16384 or nb > 1)
-    tile = 3 if Ncols <= 32 else (2 if (Ncols <= 64 or Mp <= 64 or (ENGINE == 1 and small)) else 0)
-    if ENGINE == 1 and 16 < Ncols <= 32:
+    tile = 3 if Ncols <= 32 else (2 if (Ncols <= 64 or Mp <= 64 or (ENGINE >= 1 and small)) else 0)
+    if ENGINE >= 1 and 16 < Ncols <= 32:
         tile = 2            # weight gradients with 17..32 columns: 64x64 split-engine tile, -26..-29 % (n32_bench_m31.log)
-    if nb > 1 and ENGINE == 1 and Ncols > 32:
+    if nb > 1 and ENGINE >= 1 and Ncols > 32:
         tile = 2            # paired decoder layers (tools/pair_sweep.py): 64x64 tiles win at every measured shape
     bm, bn = _TILE_MN[tile]
     tiles = _cdiv(Mp, bm) * _cdiv(Ncols, bn) * nb
-    if nb > 1 and ENGINE == 1:
+    if nb > 1 and ENGINE >= 1:
         # measured optimum (profiles/r01/pair_sweep_v15.log): k-chunks of ~320 pixels per slice, at most ~1024 workgroups
         splitk = max(1, min(int(round(Kpix / 320.0)), 1024 // max(tiles, 1), _cdiv(Kpix, 128)))
     else:
         # measured optimum of resident split-K slices (tools/tile_sweep.py): ~512 workgroups, 256 for a single tile
-        target = (256 if tiles == 1 else 512) if ENGINE == 1 else 1024
+        target = (256 if tiles == 1 else 512) if ENGINE >= 1 else 1024
         splitk = max(1, min(target // max(tiles, 1), _cdiv(Kpix, 128)))
     # grouped launch (rih_gemm_multi at the end of the backward stage): the problems fill the chip TOGETHER, so a problem needs
     # only as many split-K slices as keep its own workgroups reasonably short -- fewer partial slabs to write and to sum
@@ -562,6 +655,8 @@ def _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin
     part = torch.empty((nb, splitk, Mp, Ncols), device=x.device, dtype=torch.float32)
     ones = Mrows if db is not None else 0
     batch = dict(nb1=nb, sA=(sx, 0), sB=(sdy, 0), sC=(splitk * Mp * Ncols, 0)) if nb > 1 else {}
+    if bounds is not None:      # (bound of x, bound of dy): engine 2
+        batch = dict(batch, amax_a=bounds[0], amax_b=bounds[1])
     if splitk == 1:
         # a single slice still goes through the reduce kernel for the layout change; raw epilogue = alpha 1, no bias
         gemm(x, dy, part, Mp, Ncols, Kpix, ldx, ldy, Ncols, a_mode=1, b_mode=0, geom=geom, tile=tile, ones_row=ones,
@@ -670,6 +765,8 @@ class Conv2dFn(torch.autograd.Function):
         y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
         M, K = N * Ho * Wo, KH * KW * Cx
         geom = (H, W_, Cx, Ho, Wo, KH, KW, stride, 1, pad, pad)
+        # engine 2: operand bounds (kept for the backward: x is the weight gradient's A operand, w the data gradient's B)
+        bx, bw = (bound_of(x), bound_of(w)) if ENGINE == 2 else (None, None)
         if _presplit_ok(Cout, Cx, KH * KW):
             wp, Kp = _presplit_weight(w, Cx, False)
             if PRESPLIT_ACT:
@@ -678,14 +775,17 @@ class Conv2dFn(torch.autograd.Function):
             else:
                 gemm(x, wp, y, M, Cout, K, Cx, Kp, Cout, a_mode=0, b_mode=2, bias=bias, relu=relu, geom=geom)
         elif KH * KW == 1 and Cx == Cin:
-            gemm(x, w, y, M, Cout, K, Cx, Cin, Cout, a_mode=0, b_mode=1, bias=bias, relu=relu, geom=geom, stats=stats)
+            gemm(x, w, y, M, Cout, K, Cx, Cin, Cout, a_mode=0, b_mode=1, bias=bias, relu=relu, geom=geom, stats=stats,
+                 amax_a=bx, amax_b=bw)
         else:
             wp = _packed_weight(w, Cx, False)
-            gemm(x, wp, y, M, Cout, K, Cx, Cout, Cout, a_mode=0, b_mode=0, bias=bias, relu=relu, geom=geom, stats=stats)
+            gemm(x, wp, y, M, Cout, K, Cx, Cout, Cout, a_mode=0, b_mode=0, bias=bias, relu=relu, geom=geom, stats=stats,
+                 amax_a=bx, amax_b=bw)
         # grad_masked: the consumer (a BatchNorm with input_relu) hands back a gradient that is already zero where y <= 0
         relu_bwd = relu and not grad_masked
         ctx.save_for_backward(x, w, y if relu_bwd else None)
         ctx.cfg = (stride, pad, relu_bwd, bias is not None)
+        ctx.bounds = (bx, bw)
         if skip:
             return y, x.view_as(x)
         return y
@@ -702,6 +802,8 @@ class Conv2dFn(torch.autograd.Function):
         _, Ho, Wo, _ = dy.shape
         M = N * Ho * Wo
         lib = _L()
+        bx, bw = ctx.bounds
+        bdy = bound_of(dy) if bx is not None else None      # (also bounds the ReLU-gated gradient below)
         if relu:
             dyr = torch.empty_like(dy)
             check(lib.rih_relu_bwd(dy.data_ptr(), y.data_ptr(), dyr.data_ptr(), dy.numel(), _stream()), 'rih_relu_bwd')
@@ -743,7 +845,7 @@ class Conv2dFn(torch.autograd.Function):
                 else:
                     wd = _packed_weight(w, Cx, True, (kh0, kw0, stride, Th, Tw))
                 gemm(dy, wd, dx, N * Hc * Wc, Cx, Th * Tw * Cout, Cout, Cx, Cx, a_mode=0, b_mode=0, geom=geom,
-                     cstride=(stride, oh, ow, H, W_))
+                     cstride=(stride, oh, ow, H, W_), amax_a=bdy, amax_b=bw)
             if dskip is not None:
                 dx = dx + dskip
         elif ctx.needs_input_grad[0]:
@@ -758,17 +860,20 @@ class Conv2dFn(torch.autograd.Function):
                 else:
                     gemm(dy, wd, dx, Mx, Cx, KH * KW * Cout, Cout, Kp, Cx, a_mode=0, b_mode=2, geom=geom, R=dskip, ldr=Cx)
             elif KH * KW == 1 and Cx == Cin:
-                gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cin, Cx, a_mode=0, b_mode=0, geom=geom, R=dskip, ldr=Cx)
+                gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cin, Cx, a_mode=0, b_mode=0, geom=geom, R=dskip, ldr=Cx,
+                     amax_a=bdy, amax_b=bw)
             else:
                 wd = _packed_weight(w, Cx, True)
-                gemm(dy, wd, dx, Mx, Cx, KH * KW * Cout, Cout, Cx, Cx, a_mode=0, b_mode=0, geom=geom, R=dskip, ldr=Cx)
+                gemm(dy, wd, dx, Mx, Cx, KH * KW * Cout, Cout, Cx, Cx, a_mode=0, b_mode=0, geom=geom, R=dskip, ldr=Cx,
+                     amax_a=bdy, amax_b=bw)
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             if want_db:
                 db = torch.empty((Cout,), device=x.device, dtype=torch.float32)
             geom = (H, W_, Cx, Ho, Wo, KH, KW, stride, 1, pad, pad)
-            _wgrad(x, dy, dw, M, KH * KW * Cx, Cout, Cx, Cout, geom, Cx, KH * KW, Cin, db=db)
+            _wgrad(x, dy, dw, M, KH * KW * Cx, Cout, Cx, Cout, geom, Cx, KH * KW, Cin, db=db,
+                   bounds=(bx, bdy) if bx is not None else None)
         elif want_db:
             db = colsum(dy, M, Cout)
         if dx is None and dskip is not None:
@@ -1074,7 +1179,8 @@ class BatchNormFn(torch.autograd.Function):
     in place (momentum 0.1, unbiased running_var) exactly like torch; eval: running statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, residual, training, relu, eps, momentum, tile_stats=None, input_relu=False):
+    def forward(ctx, x, gamma, beta, rmean, rvar, residual, training, relu, eps, momentum, tile_stats=None, input_relu=False,
+                ybound=None):
         _chk(x, gamma, beta, rmean, rvar, residual)
         x = _c(x)
         Cc = x.shape[-1]
@@ -1088,6 +1194,7 @@ class BatchNormFn(torch.autograd.Function):
             residual = _c(residual)
         # the backward needs only the sign pattern of a ReLU'd output: one byte per quad (rih_bn_apply relu_mask)
         mask = torch.empty((x.numel() // 4,), device=x.device, dtype=torch.uint8) if relu else None
+        # ybound (engine 2): the apply pass leaves max|y| there -- the operand bound of the convolution that reads y (bound_of)
 
         def run():
             if training and tile_stats is not None and tile_stats[0] == 'blocks':   # rih_gemm's statistics epilogue
@@ -1112,7 +1219,8 @@ class BatchNormFn(torch.autograd.Function):
                 check(lib.rih_bn_eval_stats(rmean.data_ptr(), rvar.data_ptr(), Cc, eps, mean.data_ptr(),
                                             invstd.data_ptr(), _stream()), 'rih_bn_eval_stats')
             check(lib.rih_bn_apply(x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                   _p(residual), y.data_ptr(), rows, Cc, 1 if relu else 0, _p(mask), _stream()), 'rih_bn_apply')
+                                   _p(residual), y.data_ptr(), rows, Cc, 1 if relu else 0, _p(mask), _p(ybound), _stream()),
+                  'rih_bn_apply')
         # algorithmic bytes: statistics read x once (training), apply reads x (+ residual) and writes y
         _elem_profile(x.numel() * (4.0 * ((1 if training and tile_stats is None else 0) + 2 + (1 if residual is not None else 0))
                                    + (0.25 if relu else 0.0)), 'bn_fwd', run)
@@ -1136,19 +1244,22 @@ class BatchNormFn(torch.autograd.Function):
         # algorithmic bytes: reduction pass reads dy and x (+ 1 byte per quad of ReLU pattern), apply reads them again and
         # writes dx (+ dres)
         flags = (0 if training else 1) | (2 if input_relu else 0)
+        dxbound = bound_slot(x.device) if ENGINE == 2 else None     # max|dx|: the gradient operand's bound, as ybound above
         if BN_LASTBLOCK:
             cnt = bn_counters(x.device, int(lib.rih_bn_ncounters(rows, Cc)))
             run = lambda: check(
                 lib.rih_bn_bwd_lastblock(dy.data_ptr(), x.data_ptr(), 0, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                                          dx.data_ptr(), _p(dres), dg.data_ptr(), db.data_ptr(), rows, Cc, 1 if relu else 0,
-                                         flags, ws.data_ptr(), _p(mask), cnt, _stream()), 'rih_bn_bwd_lastblock')
+                                         flags, ws.data_ptr(), _p(mask), cnt, _p(dxbound), _stream()), 'rih_bn_bwd_lastblock')
         else:
             run = lambda: check(
                 lib.rih_bn_bwd(dy.data_ptr(), x.data_ptr(), 0, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                                dx.data_ptr(), _p(dres), dg.data_ptr(), db.data_ptr(), rows, Cc, 1 if relu else 0,
-                               flags, ws.data_ptr(), _p(mask), _stream()), 'rih_bn_bwd')
+                               flags, ws.data_ptr(), _p(mask), _p(dxbound), _stream()), 'rih_bn_bwd')
         _elem_profile(x.numel() * (4.0 * (2 * 2 + 1 + (1 if has_res else 0)) + (0.5 if relu else 0.0)), 'bn_bwd', run)
-        return dx, dg, db, None, None, dres, None, None, None, None, None, None
+        if dxbound is not None:
+            set_bound(dx, dxbound)
+        return dx, dg, db, None, None, dres, None, None, None, None, None, None, None
 
 
 def batchnorm_update_only(x, rmean, rvar, eps=1e-5, momentum=0.1, tile_stats=None):
@@ -1178,7 +1289,9 @@ def batchnorm_update_only(x, rmean, rvar, eps=1e-5, momentum=0.1, tile_stats=Non
 def batchnorm(x, gamma, beta, rmean, rvar, residual=None, training=True, relu=False, eps=1e-5, momentum=0.1, tile_stats=None,
               input_relu=False):
     """input_relu: x is the output of a ReLU (Conv -> ReLU -> BN); the gradient wrt x then leaves already gated by x > 0."""
-    return BatchNormFn.apply(x, gamma, beta, rmean, rvar, residual, training, relu, eps, momentum, tile_stats, input_relu)
+    ybound = bound_slot(x.device) if ENGINE == 2 else None
+    y = BatchNormFn.apply(x, gamma, beta, rmean, rvar, residual, training, relu, eps, momentum, tile_stats, input_relu, ybound)
+    return y if ybound is None else set_bound(y, ybound)
 
 
 # --------------------------------------------------------------------------------------------- layout / pooling
@@ -1253,7 +1366,7 @@ class MaxPoolFn(torch.autograd.Function):
 
 
 def maxpool3x3s2(x):
-    return MaxPoolFn.apply(x)
+    return inherit_bound(MaxPoolFn.apply(x), x)         # a maximum of window values
 
 
 class AvgPoolFn(torch.autograd.Function):
@@ -1305,11 +1418,11 @@ class UpsampleBilinearFn(torch.autograd.Function):
 
 
 def upsample_bilinear(x, factor):
-    return UpsampleBilinearFn.apply(x, factor)
+    return inherit_bound(UpsampleBilinearFn.apply(x, factor), x)        # convex combinations of input values
 
 
 def upsample_bilinear2x(x):
-    return UpsampleBilinearFn.apply(x, 2)
+    return inherit_bound(UpsampleBilinearFn.apply(x, 2), x)
 
 
 class NearestUpAddFn(torch.autograd.Function):

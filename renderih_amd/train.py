@@ -141,6 +141,8 @@ class TrainStep:
 
     def _forward_loss(self):
         self._bounds = self._cut = None
+        if ops.ENGINE == 2:
+            ops.bounds_reset()
         if self.packs is not None:
             # every packed weight operand the step needs (forward and data-gradient layouts of the k > 1 convolutions) in one
             # launch, before the first kernel of the forward pass; the per-call packs then find them ready (ops.PackCache)

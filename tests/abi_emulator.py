@@ -195,12 +195,37 @@ class EmulatedLib:
     def rih_gemm_multi_variant(self, dref):
         d = dref._obj if hasattr(dref, '_obj') else dref
         plain = (d.KH == 1 and d.KW == 1 and d.strideA == 1 and d.padH == 0 and d.padW == 0 and d.H == d.Ho and d.W == d.Wo)
-        ok = (d.engine == 1 and d.tile in (0, 2) and d.a_mode == 1 and d.b_mode == 0 and d.upS == 1 and d.K % 4 == 0
+        ok = (d.engine in (1, 2) and d.tile in (0, 2) and d.a_mode == 1 and d.b_mode == 0 and d.upS == 1 and d.K % 4 == 0
               and d.K >= 1 and d.A % 16 == 0 and d.B % 16 == 0 and d.lda % 4 == 0 and d.ldb % 4 == 0 and d.sA1 % 4 == 0
               and d.sB1 % 4 == 0 and d.sA2 % 4 == 0 and d.sB2 % 4 == 0 and d.M % 4 == 0 and d.N % 4 == 0 and not d.stats)
         if not plain:
             ok = ok and d.Wo % 4 == 0 and d.Cin % 4 == 0
-        return (d.tile * 8 + 4 + (1 if plain else 0)) if ok else -1
+        return (d.tile * 8 + 4 + (1 if plain else 0) + (64 if d.engine == 2 else 0)) if ok else -1
+
+    def rih_gemm_engine(self, dref):
+        """The header's contract, restated: engine 2 exists on the fast path of tiles 0..2 only, engine 1 runs otherwise."""
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        if d.engine == 0 or d.tile == 3:
+            return 0
+        plain = (d.KH == 1 and d.KW == 1 and d.strideA == 1 and d.padH == 0 and d.padW == 0 and d.H == d.Ho and d.W == d.Wo)
+        fast = (d.tile in (0, 1, 2) and d.upS == 1 and d.K % 4 == 0 and d.K >= 1 and d.A % 16 == 0 and d.B % 16 == 0
+                and d.lda % 4 == 0 and d.ldb % 4 == 0 and d.sA1 % 4 == 0 and d.sB1 % 4 == 0 and d.sA2 % 4 == 0 and d.sB2 % 4 == 0)
+        if d.a_mode != 1 and not plain:
+            fast = fast and d.Cin % 32 == 0 and d.KH * d.KW <= 32
+        if d.a_mode == 1:
+            fast = fast and d.M % 4 == 0 and (plain or (d.Wo % 4 == 0 and d.Cin % 4 == 0))
+        if d.b_mode == 0:
+            fast = fast and d.N % 4 == 0
+        return 2 if (d.engine == 2 and fast and d.a_mode <= 1 and d.b_mode <= 1) else 1
+
+    def rih_absmax(self, x, n, out, stream):
+        if n > 0:
+            o = _f(out, 1)
+            v = np.abs(_f(x, n))
+            v = v[~np.isnan(v)]
+            if v.size:
+                o[0] = max(float(o[0]), float(v.max()))
+        return 0
 
     def rih_gemm_multi_table_bytes(self, descs, n):
         return 64 + 8 * n if n >= 1 else 0
@@ -232,7 +257,7 @@ class EmulatedLib:
         """The header's contract, restated: split engine's fast path, forward-type, no split-K, no batch, dense rows."""
         d = dref._obj
         plain = (d.KH == 1 and d.KW == 1 and d.strideA == 1 and d.padH == 0 and d.padW == 0 and d.H == d.Ho and d.W == d.Wo)
-        ok = (d.engine == 1 and d.tile in (0, 1, 2) and d.a_mode == 0 and d.b_mode in (0, 1) and d.splitk == 1
+        ok = (d.engine in (1, 2) and d.tile in (0, 1, 2) and d.a_mode == 0 and d.b_mode in (0, 1) and d.splitk == 1
               and d.nb1 * d.nb2 == 1 and d.cS <= 1 and d.upS == 1 and d.K % 4 == 0 and d.K >= 1
               and d.A % 16 == 0 and d.B % 16 == 0 and d.lda % 4 == 0 and d.ldb % 4 == 0)
         if not plain:
@@ -245,7 +270,7 @@ class EmulatedLib:
         """The header's contract, restated: split engine's fast path, plain row-major A, no split-K, no stats, dense rows."""
         d = dref._obj if hasattr(dref, '_obj') else dref
         plain = (d.KH == 1 and d.KW == 1 and d.strideA == 1 and d.padH == 0 and d.padW == 0 and d.H == d.Ho and d.W == d.Wo)
-        ok = (d.engine == 1 and d.tile in (0, 1, 2) and d.a_mode == 0 and d.b_mode in (0, 1) and d.splitk == 1 and plain
+        ok = (d.engine in (1, 2) and d.tile in (0, 1, 2) and d.a_mode == 0 and d.b_mode in (0, 1) and d.splitk == 1 and plain
               and d.cS <= 1 and d.upS == 1 and d.K % 4 == 0 and d.K >= 1 and d.A % 16 == 0 and d.B % 16 == 0
               and d.lda % 4 == 0 and d.ldb % 4 == 0 and d.sA1 % 4 == 0 and d.sB1 % 4 == 0 and d.sA2 % 4 == 0 and d.sB2 % 4 == 0
               and not (d.relu and d.R))
@@ -1042,7 +1067,13 @@ class EmulatedLib:
     def _u8view(ptr, n):
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n,))
 
-    def rih_bn_apply(self, x, mean, invstd, gamma, beta, res, y, rows, Cc, relu, mask, stream):
+    @staticmethod
+    def _amax_into(slot, values):
+        if slot:
+            o = _f(slot, 1)
+            o[0] = max(float(o[0]), float(np.abs(values).max()))
+
+    def rih_bn_apply(self, x, mean, invstd, gamma, beta, res, y, rows, Cc, relu, mask, amax, stream):
         X = _f(x, rows * Cc).reshape(rows, Cc)
         o = (X - _f(mean, Cc)) * (_f(invstd, Cc) * _f(gamma, Cc)) + _f(beta, Cc)
         if res:
@@ -1053,9 +1084,10 @@ class EmulatedLib:
                 self._u8view(mask, rows * Cc // 4)[:] = bits[:, 0] | (bits[:, 1] << 1) | (bits[:, 2] << 2) | (bits[:, 3] << 3)
             o = np.maximum(o, 0)
         _f(y, rows * Cc)[:] = o.ravel()
+        self._amax_into(amax, o)
         return 0
 
-    def rih_bn_bwd(self, dy, x, y, mean, invstd, gamma, dx, dres, dgamma, dbeta, rows, Cc, relu, frozen, ws, mask, stream):
+    def rih_bn_bwd(self, dy, x, y, mean, invstd, gamma, dx, dres, dgamma, dbeta, rows, Cc, relu, frozen, ws, mask, amax_dx, stream):
         D = _f(dy, rows * Cc).reshape(rows, Cc).copy()
         if relu and mask:
             m = self._u8view(mask, rows * Cc // 4)
@@ -1076,6 +1108,7 @@ class EmulatedLib:
         if frozen & 2:          # the input is a ReLU output: dx gated by x > 0
             o = np.where(X > 0, o, 0)
         _f(dx, rows * Cc)[:] = o.ravel()
+        self._amax_into(amax_dx, o)
         if dres:
             _f(dres, rows * Cc)[:] = D.ravel()
         return 0
@@ -1094,9 +1127,10 @@ class EmulatedLib:
         return self.rih_bn_stats(x, rows, Cc, eps, momentum, mean, invstd, rmean, rvar, ws, stream)
 
     def rih_bn_bwd_lastblock(self, dy, x, y, mean, invstd, gamma, dx, dres, dgamma, dbeta, rows, Cc, relu, frozen, ws, mask,
-                             counters, stream):
+                             counters, amax_dx, stream):
         self._counters_zero(counters)
-        return self.rih_bn_bwd(dy, x, y, mean, invstd, gamma, dx, dres, dgamma, dbeta, rows, Cc, relu, frozen, ws, mask, stream)
+        return self.rih_bn_bwd(dy, x, y, mean, invstd, gamma, dx, dres, dgamma, dbeta, rows, Cc, relu, frozen, ws, mask, amax_dx,
+                               stream)
 
     # ------------------------------------------------------------------ row-wise
     def rih_ln_nblk(self, rows):

@@ -187,6 +187,7 @@ static inline void __syncthreads() { hipcpu::S().cur->land(); hipcpu::block_barr
 // blocks run one after the other and a block's fibers never run in parallel: a fence is a no-op, an atomic a plain update
 static inline void __threadfence() {}
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+static inline unsigned atomicMax(unsigned* p, unsigned v) { const unsigned o = *p; if (v > o) *p = v; return o; }
 
 template <typename T>
 static inline T __shfl_xor(T v, int mask, int width = 64) {

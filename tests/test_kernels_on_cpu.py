@@ -289,8 +289,8 @@ def test_gemm_descriptor_fuzz_against_emulator():
     slack = 0 if os.environ.get('HIPCPU_FUZZ_EXACT', '0') == '1' else 8
     cdiv = lambda a, b: -(-a // b)
     checked = 0
-    for it in range(int(os.environ.get('HIPCPU_FUZZ_ITERS', '45'))):
-        engine, a_mode, b_mode = int(rs.randint(0, 2)), int(rs.randint(0, 2)), int(rs.randint(0, 2))
+    for it in range(int(os.environ.get('HIPCPU_FUZZ_ITERS', '60'))):
+        engine, a_mode, b_mode = int(rs.randint(0, 3)), int(rs.randint(0, 2)), int(rs.randint(0, 2))
         conv = rs.rand() < 0.5
         nb1 = 1
         if conv:
@@ -320,6 +320,8 @@ def test_gemm_descriptor_fuzz_against_emulator():
             splitk = cdiv(K, kchunk)
         ldc = N + int(rs.choice([0, 0, 4]))
         tile = int(rs.choice([0, 1, 2, 3])) if (engine == 0 or N <= 32) else int(rs.choice([0, 1, 2]))
+        if engine == 2 and tile == 3:
+            tile = 2
         plain_ep = splitk == 1
         use_bias, use_R, relu = plain_ep and rs.rand() < 0.5, plain_ep and rs.rand() < 0.3, plain_ep and rs.rand() < 0.3
         Mp, ones_row = M, 0
@@ -330,6 +332,18 @@ def test_gemm_descriptor_fuzz_against_emulator():
         B = rs.randn(nb1 * b_size + slack).astype(np.float32)
         sB1 = int(rs.choice([0, b_size])) if nb1 > 1 else 0
         bias, R = rs.randn(nb1 * N).astype(np.float32), rs.randn(nb1 * Mp * (N + 4)).astype(np.float32)
+        amax = None
+        if engine == 2:
+            # engine 2 (two-term fp16 split): operand magnitudes far outside the fp16 range, bounds as rih_absmax would write
+            # them -- or a loose upper bound, or (values inside +-2^15 only) no bound at all
+            mode = int(rs.randint(0, 3))
+            if mode < 2:
+                A *= np.float32(rs.choice([1e-6, 1.0, 3e4, 1e7]))
+                B *= np.float32(rs.choice([1e-9, 1e-3, 1.0, 2e5]))
+                loose = np.float32(1.0 if mode == 0 else 37.0)
+                amax = (np.array([np.abs(A).max() * loose], np.float32), np.array([np.abs(B).max() * loose], np.float32))
+            bias *= np.float32(np.abs(A).max() * np.abs(B).max())
+            R *= np.float32(np.abs(A).max() * np.abs(B).max())
         outs = []
         for lib in (host, emu):
             Cc = np.full(nb1 * splitk * Mp * ldc + 8, 7.0, np.float32)
@@ -343,6 +357,10 @@ def test_gemm_descriptor_fuzz_against_emulator():
             d.splitk, d.kchunk, d.sCsplit, d.alpha, d.relu = splitk, kchunk, Mp * ldc, alpha, 1 if relu else 0
             (d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.strideA, d.upS, d.padH, d.padW) = geom
             d.tile, d.engine, d.ones_row = tile, engine, ones_row
+            if amax is not None:
+                d.amax_a, d.amax_b = amax[0].ctypes.data, amax[1].ctypes.data
+            if engine == 2:
+                assert host.rih_gemm_engine(C.byref(d)) == emu.rih_gemm_engine(C.byref(d)), it
             outs.append((lib.rih_gemm(C.byref(d), None), Cc))
         (rc0, c0), (rc1, c1) = outs
         assert rc0 == 0 and rc1 == 0, (it, rc0, rc1)
@@ -355,7 +373,7 @@ def test_gemm_descriptor_fuzz_against_emulator():
         assert np.allclose(v0[:, :rows, :N], v1[:, :rows, :N], rtol=2e-5, atol=2e-5 * sc), what
         assert (v0[:, :, N:] == 7.0).all() and (c0[nb1 * splitk * Mp * ldc:] == 7.0).all(), 'stray write, ' + what
         checked += 1
-    assert checked >= 38
+    assert checked >= 50
 
 
 def test_batched_entry_points_fuzz_against_emulator():

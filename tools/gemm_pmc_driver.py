@@ -10,14 +10,21 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from renderih_amd import ops  # noqa: E402
+from gemm_pmc_driver_shapes import SHAPES  # noqa: E402
 
 dev = torch.device('cuda:0')
 B, REP = 64, 10
-# (kind, H, Cin, Cout, k): fwd = forward / stride-1 data gradient (the same GEMM class), wgrad = weight gradient
-SHAPES = [('fwd', 16, 256, 256, 3), ('fwd', 32, 128, 128, 3), ('fwd', 64, 128, 128, 3), ('fwd', 64, 64, 64, 3),
-          ('wgrad', 16, 256, 256, 3), ('wgrad', 32, 128, 128, 3), ('fwd', 8, 512, 512, 3), ('fwd', 64, 64, 256, 1),
-          ('wgrad', 64, 64, 64, 3), ('fwd', 16, 1024, 256, 1), ('fwd', 16, 256, 1024, 1), ('fwd', 32, 128, 512, 1)]
+ENG = int(os.environ.get('RIH_PMC_ENGINE', '1'))        # 2: the three-product fp16 engine (operand bounds by rih_absmax)
+
+
+def amax(t):
+    a = torch.zeros(1, device=dev)
+    ops.check(ops._L().rih_absmax(t.data_ptr(), t.numel(), a.data_ptr(), ops._stream()), 'rih_absmax')
+    return a
+
+
 plan = []
 for kind, H, Cin, Cout, k in SHAPES:
     p = (k - 1) // 2
@@ -27,15 +34,16 @@ for kind, H, Cin, Cout, k in SHAPES:
     if kind == 'fwd':
         wp = torch.randn(K, Cout, device=dev) / K ** 0.5
         tile, sk = ops.plan_gemm(M, Cout, K, 1, 1)
+        kw = dict(amax_a=amax(x), amax_b=amax(wp)) if ENG == 2 else {}
         if sk > 1:
             kc = -(-(-(-K // sk)) // 32) * 32
             sk = -(-K // kc)
             part = torch.empty(sk, M, Cout, device=dev)
             fn = lambda: ops.gemm(x, wp, part, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=tile, splitk=sk,
-                                  kchunk=kc, sCsplit=M * Cout, engine=1)
+                                  kchunk=kc, sCsplit=M * Cout, engine=ENG, **kw)
         else:
             y = torch.empty(B, H, H, Cout, device=dev)
-            fn = lambda: ops.gemm(x, wp, y, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=tile, engine=1)
+            fn = lambda: ops.gemm(x, wp, y, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=tile, engine=ENG, **kw)
         label = 'fwd   %2dx%-2d %4d->%-4d k%d | M%-6d N%-4d K%-5d | tile %d sk %d' % (H, H, Cin, Cout, k, M, Cout, K, tile, sk)
     else:
         dy = torch.randn(B, H, H, Cout, device=dev)
@@ -48,8 +56,9 @@ for kind, H, Cin, Cout, k in SHAPES:
         kc = -(-(-(-M // sk)) // 32) * 32
         sk = -(-M // kc)
         part = torch.empty(sk, Mp, Cout, device=dev)
+        kw = dict(amax_a=amax(x), amax_b=amax(dy)) if ENG == 2 else {}
         fn = lambda: ops.gemm(x, dy, part, Mp, Cout, M, Cin, Cout, Cout, a_mode=1, b_mode=0, splitk=sk, kchunk=kc,
-                              sCsplit=Mp * Cout, geom=geom, tile=tile, engine=1)
+                              sCsplit=Mp * Cout, geom=geom, tile=tile, engine=ENG, **kw)
         label = 'wgrad %2dx%-2d %4d->%-4d k%d | M%-6d N%-4d K%-5d | tile %d sk %d' % (H, H, Cin, Cout, k, Mp, Cout, M, tile, sk)
     for _ in range(REP):
         fn()
