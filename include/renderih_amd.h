@@ -320,19 +320,6 @@ int rih_bn_bwd(const float* dy, const float* x, const float* y, const float* mea
 /* amax_dx (optional, ABI 13): *amax_dx = max(*amax_dx, max|dx|), as `amax` of rih_bn_apply -- dx is the gradient operand of the
  * producing convolution's data- and weight-gradient GEMMs. */
 
-/* One launch less per statistics pass and per backward ("last block done", ABI 11): the reduction pass publishes its partial sums
- * and the last workgroup of each channel slice finishes the slice, with the arithmetic of the stand-alone finishing kernels
- * (bit-identical results).  counters: >= rih_bn_ncounters(rows, C) uint32, ZERO before the first use; the kernels leave them
- * zero, so a caller keeps one zero-initialised pool and hands every call that may run concurrently (other stream, other graph
- * node) its own slice.  Everything else as rih_bn_stats / rih_bn_bwd. */
-int rih_bn_ncounters(int rows, int C);
-int rih_bn_stats_lastblock(const float* x, int rows, int C, float eps, float momentum, float* mean, float* invstd,
-                           float* running_mean, float* running_var, float* ws, uint32_t* counters, void* stream);
-int rih_bn_bwd_lastblock(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
-                         const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C,
-                         int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, uint32_t* counters, float* amax_dx,
-                         void* stream);
-
 /* ------------------------------------------------------------------------------------------------
  * Row-wise ops on [rows][D] matrices (decoder)                                                         */
 /* y = act(LayerNorm(x (+ x2)) * g + b); saves mean/rstd per row   (nn.LayerNorm eps=1e-6, gcn.py:91-97 ...) */
@@ -467,7 +454,7 @@ int rih_mano_fwd(const rih_mano_model* m, const float* packed, const float* root
  * Two launches: per hand the skinning / kinematic-chain part (one workgroup per hand), then -- round 3 -- the two contractions
  * with the blend bases (pose-blend and shape gradients: 0.33 MFLOP per hand against 1.26 MB of basis) as MFMA products of
  * 16-hand chunks against tiles of `packed` in LDS, with the Rodrigues / PCA epilogue; ws_bwd (>= rih_mano_bwd_ws_floats(B)
- * floats, 8-byte aligned) carries dv_tpose / dv_shaped / rotation gradients between the two.  ws_bwd == NULL runs the
+ * floats, 16-byte aligned: the blend kernel reads it with 16-byte vector loads) carries dv_tpose / dv_shaped / rotation gradients between the two.  ws_bwd == NULL runs the
  * one-kernel backward of rounds 1-2 (every workgroup re-reads the whole basis from L2: 1.17 ms for 4096 hands; A/B partner). */
 int rih_mano_bwd(const rih_mano_model* m, const float* packed, const float* root, const float* pose, int ncomp,
                  const float* shape, const float* trans, const float* scale, int center_idx, int new_skel, const float* dv,

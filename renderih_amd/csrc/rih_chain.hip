@@ -361,7 +361,8 @@ __global__ __launch_bounds__(TPB, (CUR_F <= CAP_SMALL ? 2 : 1)) void chain_kerne
             else ch_gemm<false, false, NRB, KC>(op, cur, nxt, wtile, b, tid);
             if (epi) {
                 __syncthreads();
-                const uint32_t key = rih_seed_key(op.seed + seed_add), thr = ch_thresh(op.f0);
+                const uint64_t key = rih_seed_key(op.seed + seed_add);
+                const uint32_t thr = ch_thresh(op.f0);
                 const float ks = 1.f / (1.f - op.f0);
                 float* dst = (op.flags & RIH_CHF_EPI_STORE) ? reinterpret_cast<float*>(op.p2) + b.rowbase * op.ld : nullptr;
 #pragma unroll
@@ -401,7 +402,8 @@ __global__ __launch_bounds__(TPB, (CUR_F <= CAP_SMALL ? 2 : 1)) void chain_kerne
         }
         case RIH_CH_DROPOUT: {
             const int w4 = width >> 2;
-            const uint32_t key = rih_seed_key(op.seed + seed_add), thr = ch_thresh(op.f0);
+            const uint64_t key = rih_seed_key(op.seed + seed_add);
+            const uint32_t thr = ch_thresh(op.f0);
             const float ks = 1.f / (1.f - op.f0);
             for (int idx = tid; idx < b.R * w4; idx += TPB) {
                 const int r = idx / w4, c = (idx - r * w4) << 2;

@@ -53,9 +53,23 @@ __device__ __forceinline__ uint32_t drop_thresh(float p) {
 // ------------------------------------------------------------------------------------------------ operand bounds (rih_gemm engine 2)
 // max|x| into a device word: non-negative floats order like their bit patterns, so the merge is an integer atomicMax (NaN
 // candidates are dropped by fmaxf before they get there).  One atomic per wavefront.
+// Every thread of the block must call it (one barrier).  One candidate per BLOCK, and the atomic only when the candidate exceeds
+// what the word already holds (a relaxed read: a stale, smaller value merely lets a redundant atomic through): same-address
+// device-scope atomics retire at ~10 ns each on this chip -- one per wavefront (65536 per BatchNorm launch) made the BatchNorm
+// family ten times slower (profiles/r04/ab/train_e2.log: 6.5 -> 60 ms per step).
 __device__ __forceinline__ void amax_publish(float* out, float v) {
+    __shared__ float amax_red[TPB / 64];
     v = wave_max(v);
-    if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(v));
+    if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = amax_red[0];
+#pragma unroll
+        for (int w = 1; w < TPB / 64; ++w) m = fmaxf(m, amax_red[w]);
+        const unsigned bits = __float_as_uint(m);
+        unsigned* o = reinterpret_cast<unsigned*>(out);
+        if (m > 0.f && bits > __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(o, bits);
+    }
 }
 __global__ __launch_bounds__(TPB) void absmax_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
     float m = 0.f;
@@ -422,26 +436,6 @@ __global__ __launch_bounds__(TPB) void bn_stats_partial_kernel(const float* __re
     bn_stats_partial_body(x, rows, C, cgb, rt, rows_per_chunk, ws);
 }
 
-// "Last block done" (rih_bn_stats_lastblock / rih_bn_bwd_lastblock): the grid of a column reduction is (channel slices, row
-// chunks); every block publishes its partial sums, takes a ticket on its slice's counter, and the block that draws the last
-// ticket finishes the slice -- the same per-channel arithmetic as the stand-alone finishing kernels, so the results are
-// bit-identical, without the second launch (~4.5 us of dependent-launch floor per BatchNorm and direction).  The counter
-// is left at zero for the next launch that is handed the slot.
-__device__ __forceinline__ bool column_slice_done(unsigned* __restrict__ counters) {
-    __shared__ int s_last;
-    __threadfence();                        // this block's partial sums are visible device-wide before its ticket
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned t = atomicAdd(&counters[blockIdx.x], 1u);
-        s_last = (t == gridDim.y - 1u) ? 1 : 0;
-        if (s_last) counters[blockIdx.x] = 0u;
-    }
-    __syncthreads();
-    const bool last = s_last != 0;
-    if (last) __threadfence();              // ... and the other blocks' sums are visible to this one after the last ticket
-    return last;
-}
-
 // one wavefront per channel: lanes stride over the chunk partials, fp64 xor-shuffle reduction
 __global__ __launch_bounds__(TPB) void bn_stats_final_kernel(const float* __restrict__ x, const float* __restrict__ ws,
                                                              int rows, int C, int nchunk, float eps, float momentum,
@@ -555,41 +549,6 @@ __global__ __launch_bounds__(TPB) void bn_blocks_final_kernel(const float* __res
     }
 }
 
-// statistics pass + finish in one launch: bn_stats_partial_kernel, then bn_stats_final_kernel's arithmetic for the channels of
-// this block's slice, done by the last block of the slice (waves take the slice's channels in turn)
-__global__ __launch_bounds__(TPB) void bn_stats_lastblock_kernel(const float* __restrict__ x, int rows, int C, int cgb, int rt,
-                                                                 int rows_per_chunk, float* __restrict__ ws,
-                                                                 unsigned* __restrict__ counters, float eps, float momentum,
-                                                                 float* __restrict__ mean, float* __restrict__ invstd,
-                                                                 float* __restrict__ rmean, float* __restrict__ rvar) {
-    bn_stats_partial_body(x, rows, C, cgb, rt, rows_per_chunk, ws);
-    if (!column_slice_done(counters)) return;
-    const int lane = threadIdx.x & 63, nchunk = gridDim.y;
-    const int c0 = blockIdx.x * cgb * 4, c1 = min(C, c0 + cgb * 4);
-    for (int c = c0 + (threadIdx.x >> 6); c < c1; c += TPB / 64) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = lane; k < nchunk; k += 64) {
-            s1 += (double)ws[((long long)0 * nchunk + k) * C + c];
-            s2 += (double)ws[((long long)1 * nchunk + k) * C + c];
-        }
-        s1 = wave_sum_d(s1);
-        s2 = wave_sum_d(s2);
-        if (lane != 0) continue;
-        const double n = (double)rows;
-        const double d = s1 / n;
-        const double m = (double)x[c] + d;
-        double var = s2 / n - d * d;
-        if (var < 0.0) var = 0.0;
-        mean[c] = (float)m;
-        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (rmean != nullptr) {
-            const double unb = (rows > 1) ? var * n / (n - 1.0) : var;
-            rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * m);
-            rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
-        }
-    }
-}
-
 // BN backward pass 1: per-channel sum(dym), sum(dym * xhat), dym = dy * (y>0) when relu
 __global__ __launch_bounds__(TPB) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ y,
@@ -599,33 +558,6 @@ __global__ __launch_bounds__(TPB) void bn_bwd_partial_kernel(const float* __rest
                                                              float* __restrict__ ws,
                                                              const unsigned char* __restrict__ mask) {
 #include "rih_bn_bwd_partial.inc"
-}
-// the same pass with two_sum_final_kernel's arithmetic done by the last block of each channel slice (column_slice_done)
-__global__ __launch_bounds__(TPB) void bn_bwd_partial_lastblock_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                       const float* __restrict__ y,
-                                                                       const float* __restrict__ mean,
-                                                                       const float* __restrict__ invstd, int rows, int C,
-                                                                       int cgb, int rt, int rows_per_chunk, int relu,
-                                                                       float* __restrict__ ws,
-                                                                       const unsigned char* __restrict__ mask,
-                                                                       unsigned* __restrict__ counters,
-                                                                       float* __restrict__ out0, float* __restrict__ out1) {
-    {
-#include "rih_bn_bwd_partial.inc"
-    }
-    if (!column_slice_done(counters)) return;
-    const int lane = threadIdx.x & 63, nslice = gridDim.y;
-    const int c0 = blockIdx.x * cgb * 4, c1 = min(C, c0 + cgb * 4);
-    for (int c = c0 + (threadIdx.x >> 6); c < c1; c += TPB / 64) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = lane; k < nslice; k += 64) {
-            s1 += (double)ws[((long long)0 * nslice + k) * C + c];
-            s2 += (double)ws[((long long)1 * nslice + k) * C + c];
-        }
-        s1 = wave_sum_d(s1);
-        s2 = wave_sum_d(s2);
-        if (lane == 0) { out0[c] = (float)s1; out1[c] = (float)s2; }
-    }
 }
 
 // finalize: out0[C] = sum dym, out1[C] = sum dym*xhat (also the dbeta / dgamma outputs); one wavefront per channel
@@ -1728,19 +1660,6 @@ extern "C" int rih_bn_stats(const float* x, int rows, int C, float eps, float mo
                        momentum, mean, invstd, running_mean, running_var);
     LAUNCH_RET();
 }
-extern "C" int rih_bn_ncounters(int rows, int C) {
-    if (rows < 1 || C < 4 || (C % 4) != 0) return 0;
-    return col_geom(rows, C).gx;
-}
-extern "C" int rih_bn_stats_lastblock(const float* x, int rows, int C, float eps, float momentum, float* mean, float* invstd,
-                                      float* running_mean, float* running_var, float* ws, uint32_t* counters, void* stream) {
-    if (!x || !mean || !invstd || !ws || !counters || rows < 1 || C < 4 || (C % 4) != 0) return RIH_EINVAL;
-    if ((running_mean == nullptr) != (running_var == nullptr)) return RIH_EINVAL;
-    const ColGeom g = col_geom(rows, C);
-    hipLaunchKernelGGL(bn_stats_lastblock_kernel, dim3(g.gx, g.nchunk), dim3(TPB), 0, STREAM, x, rows, C, g.cgb, g.rt,
-                       g.rows_per_chunk, ws, counters, eps, momentum, mean, invstd, running_mean, running_var);
-    LAUNCH_RET();
-}
 extern "C" int rih_bn_stats_from_blocks(const float* part, int T, int C, int rows, int rows_per_block, float eps,
                                         float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
                                         void* stream) {
@@ -1777,22 +1696,6 @@ extern "C" int rih_bn_bwd(const float* dy, const float* x, const float* y, const
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(g.gx, g.nchunk), dim3(TPB), 0, STREAM, dy, x, y, mean, invstd, rows, C,
                        g.cgb, g.rt, g.rows_per_chunk, relu, ws, relu_mask);
     hipLaunchKernelGGL(two_sum_final_kernel, dim3((C + 3) / 4), dim3(TPB), 0, STREAM, ws, C, g.nchunk, dbeta, dgamma);
-    const long long nq = (long long)rows * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nq)), dim3(TPB), 0, STREAM, dy, x, y, mean, invstd, gamma,
-                       dbeta, dgamma, dx, dres, nq, C, 1.f / (float)rows, relu, frozen_stats, relu_mask, amax_dx);
-    LAUNCH_RET();
-}
-
-extern "C" int rih_bn_bwd_lastblock(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
-                                    const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C,
-                                    int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, uint32_t* counters,
-                                    float* amax_dx, void* stream) {
-    if (!dy || !x || !mean || !invstd || !gamma || !dx || !dgamma || !dbeta || !ws || !counters) return RIH_EINVAL;
-    if (relu && !y && !relu_mask) return RIH_EINVAL;
-    if (rows < 1 || C < 4 || (C % 4) != 0) return RIH_EINVAL;
-    const ColGeom g = col_geom(rows, C);
-    hipLaunchKernelGGL(bn_bwd_partial_lastblock_kernel, dim3(g.gx, g.nchunk), dim3(TPB), 0, STREAM, dy, x, y, mean, invstd, rows,
-                       C, g.cgb, g.rt, g.rows_per_chunk, relu, ws, relu_mask, counters, dbeta, dgamma);
     const long long nq = (long long)rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nq)), dim3(TPB), 0, STREAM, dy, x, y, mean, invstd, gamma,
                        dbeta, dgamma, dx, dres, nq, C, 1.f / (float)rows, relu, frozen_stats, relu_mask, amax_dx);

@@ -31,7 +31,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 // mask word of element idx (rih_hash.h); `key` = rih_seed_key(seed), computed once per thread.  The element count of a score
 // tensor (B * heads * Sq * Sk) fits 32 bits for every decoder shape; the 64-bit form is the same function on wider indices.
-__device__ __forceinline__ uint32_t fl_hash(uint32_t key, long long idx, bool wide) {
+__device__ __forceinline__ uint32_t fl_hash(uint64_t key, long long idx, bool wide) {
     return wide ? rih_hash_k64(key, (uint64_t)idx) : rih_hash_k32(key, (uint32_t)idx);
 }
 __device__ __forceinline__ uint32_t fl_thresh(float p) {
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(TPB) void flash_fwd_kernel(const float* __restrict_
     __shared__ float Vs[32][DH + 1];
     __shared__ float Ps[TPB / 64][32][33];
     if (seed_dev != nullptr) seed += *seed_dev;
-    const uint32_t hkey = rih_seed_key(seed);
+    const uint64_t hkey = rih_seed_key(seed);
     const bool wide = (long long)gridDim.y * Sq * Sk > 0xffffffffLL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(TPB) void flash_bwd_dq_kernel(const float* __restri
     __shared__ float Vs[32][DH + 1];
     __shared__ float Ps[TPB / 64][32][33];
     if (seed_dev != nullptr) seed += *seed_dev;
-    const uint32_t hkey = rih_seed_key(seed);
+    const uint64_t hkey = rih_seed_key(seed);
     const bool wide = (long long)gridDim.y * Sq * Sk > 0xffffffffLL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(TPB) void flash_bwd_dkv_kernel(const float* __restr
     __shared__ float Ss[TPB / 64][32][33];
     __shared__ float Ls[32], Ds[32];
     if (seed_dev != nullptr) seed += *seed_dev;
-    const uint32_t hkey = rih_seed_key(seed);
+    const uint64_t hkey = rih_seed_key(seed);
     const bool wide = (long long)gridDim.y * Sq * Sk > 0xffffffffLL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;

@@ -174,7 +174,7 @@ __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&a
     const bool raw = (p.splitk > 1);
     const bool vec = p.epi_vec != 0;
     const int l31 = lane & 31, lhi = lane >> 5;
-    unsigned drop_key = 0u;
+    unsigned long long drop_key = 0ull;
     if (DROP) drop_key = rih_seed_key(p.drop_seed + (p.drop_seed_dev != nullptr ? *p.drop_seed_dev : 0ull));
     // per lane and column block: shift (the lane's first stored row), sums of (v - shift) and of its square, row count
     float4 ssh[STATS ? TN : 1], ssum[STATS ? TN : 1], ssq[STATS ? TN : 1];

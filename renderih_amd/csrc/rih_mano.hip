@@ -1236,7 +1236,7 @@ extern "C" int rih_mano_bwd(const rih_mano_model* m, const float* packed, const 
     if (!model_ok(m) || !pose || !dv || !dj || !ws || B < 1) return RIH_EINVAL;
     if (ncomp < 0 || ncomp > 45 || center_idx >= 21) return RIH_EINVAL;
     if (ncomp > 0 && !m->comps) return RIH_EINVAL;
-    if (ws_bwd != nullptr && (!packed || ((uintptr_t)packed & 15) || ((uintptr_t)ws_bwd & 7))) return RIH_EINVAL;
+    if (ws_bwd != nullptr && (!packed || ((uintptr_t)packed & 15) || ((uintptr_t)ws_bwd & 15))) return RIH_EINVAL;
     const Model mm = to_model(m);
     hipStream_t s = (hipStream_t)stream;
     // ws_bwd == NULL: the one-kernel backward of round 1 (one workgroup per hand does everything; kept for A/B timing)

@@ -349,7 +349,8 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
         e0.record()
         check(_L().rih_gemm(C.byref(d), _stream()), 'rih_gemm')
         e1.record()
-        PROFILE.append((2.0 * M * N * K * nb1 * nb2, e0, e1, (M, N, K, nb1 * nb2, a_mode, b_mode, d.tile, splitk, d.engine)))
+        PROFILE.append((2.0 * M * N * K * nb1 * nb2, e0, e1, (M, N, K, nb1 * nb2, a_mode, b_mode, d.tile, splitk,
+                                                              int(_L().rih_gemm_engine(C.byref(d))))))
         return fused_drop
     check(_L().rih_gemm(C.byref(d), _stream()), 'rih_gemm')
     return fused_drop
@@ -368,7 +369,6 @@ GROUP_WGRAD = int(os.environ.get('RIH_WGRAD_GROUP', '2'))        # 0: off, 1: de
 #                                                                   same-box +2.3 % over 1 on ResNet50, +6 % on HRNet-W32, profiles/r03/ab/h*)
 GROUP_KCHUNK = int(os.environ.get('RIH_WGRAD_GROUP_KCHUNK', '1024'))      # pixels per split-K slice in a grouped launch
 GROUP_SORT = os.environ.get('RIH_WGRAD_GROUP_SORT', '1') == '1'
-GROUP_T128 = int(os.environ.get('RIH_WGRAD_GROUP_T128', '0'))      # > 0: grouped gradients with both output dims >= this use 128x128 tiles
 TABLE_ARENA = None
 TABLE_BYTES_STEP = 0            # table bytes packed since the counter was last reset (TrainStep sizes its arena from it)
 
@@ -421,6 +421,15 @@ class GroupedGemms:
                 raise RuntimeError('renderih_amd: rih_gemm_multi_table_bytes rejected the group')
             ref = next(t for t in group[0][1] if torch.is_tensor(t))
             on_gpu = ref.is_cuda
+            if on_gpu:
+                # the collected operands (saved activations, gradients, split-K slabs) may have been allocated by backward nodes
+                # that ran on a streams.fork_join side stream; they are released right after this launch is enqueued on the
+                # CALLING stream, so their blocks must not go back to the side stream's pool before the launch has run
+                cur = torch.cuda.current_stream(ref.device)
+                for g in group:
+                    for t in g[1]:
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(cur)
             TABLE_BYTES_STEP += nbytes + 256
             if on_gpu and TABLE_ARENA is not None:
                 host = TABLE_ARENA.take(nbytes)
@@ -440,7 +449,8 @@ class GroupedGemms:
                 e0.record()
                 check(lib.rih_gemm_multi_launch(dev.data_ptr(), v, total.value, _stream()), 'rih_gemm_multi_launch')
                 e1.record()
-                PROFILE.append((sum(g[2] for g in group), e0, e1, (0, 0, 0, n, (v >> 2) & 1, (v >> 1) & 1, 20 + (v >> 3), 0, 1)))
+                PROFILE.append((sum(g[2] for g in group), e0, e1,
+                                (0, 0, 0, n, (v >> 2) & 1, (v >> 1) & 1, 20 + ((v & 63) >> 3), 0, 2 if v >= 64 else 1)))
             else:
                 check(lib.rih_gemm_multi_launch(dev.data_ptr(), v, total.value, _stream()), 'rih_gemm_multi_launch')
 
@@ -644,11 +654,8 @@ def _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin
     collect = None
     if _DEFERRED_GEMM is not None and tile in (0, 2) and (GROUP_WGRAD >= 2 or nb > 1 or small):
         collect = _DEFERRED_GEMM
-        if GROUP_T128 and tile == 2 and Ncols >= GROUP_T128 and Mrows >= GROUP_T128:
-            # the 64x64 choice above is a standalone-launch optimum (more resident slices); inside a grouped launch the chip is
-            # full anyway and a 128x128 tile reads half the operand bytes per product
-            tile = 0
-            bm, bn = _TILE_MN[tile]
+        # (128x128 tiles for the large grouped gradients -- half the operand bytes per product -- measured +0.25 % same-box in round 4,
+        # inside the noise: profiles/r04/ab/train_t128.log; the option was removed)
         splitk = max(1, min(splitk, _cdiv(Kpix, GROUP_KCHUNK)))
     kchunk = _cdiv(_cdiv(Kpix, splitk), 32) * 32
     splitk = _cdiv(Kpix, kchunk)
@@ -924,9 +931,9 @@ def conv2d_packed(x, wp, KH, KW, bias=None, stride=1, pad=0, relu=False, residua
 
 # Dropout behind a Linear inside the GEMM's epilogue (rih_gemm_desc.drop_p, ABI 12) instead of an rih_add_dropout launch behind it
 # (57 launches of ~6.5 us per ResNet50 step): same mask stream, so outputs and gradients equal the two-launch form bit for bit
-# (tests/test_gpu_ops.py::check_linear_dropout_epilogue).  Built after the round-3 GPU budget was spent -- the plain kernels'
-# machine code is unchanged (diff of the device assembly), the DROP variants have run on the HIP-on-CPU harness only: opt-in.
-GEMM_DROPOUT = os.environ.get('RIH_GEMM_DROPOUT', '0') == '1'
+# (tests/test_gpu_ops.py::test_linear_dropout_epilogue_is_bit_identical, green on MI355X in round 4).  Default since round 4:
+# same-box 1771.7 -> 1781.9 images/s (+0.6 %, profiles/r04/ab/train_gemm_dropout.log).  RIH_GEMM_DROPOUT=0: the two-launch form.
+GEMM_DROPOUT = os.environ.get('RIH_GEMM_DROPOUT', '1') == '1'
 
 
 def _finish_dropout(fused, y, residual, drop):
@@ -1150,30 +1157,6 @@ def patch_conv_pair(x, cL, cR):
 
 
 # --------------------------------------------------------------------------------------------- batch norm
-# "Last block done" BatchNorm reductions (rih_bn_stats_lastblock / rih_bn_bwd_lastblock, ABI 11): the finishing launch of the
-# statistics pass and of the backward's reduction pass folded into the pass itself -- one dependent launch (~4.5 us) less per
-# BatchNorm and direction: 62 + 8 per ResNet50 step, ~630 per HRNet-W32 step.  Built after the round-3 GPU budget was spent:
-# bit-identical to the two-launch form on the HIP-on-CPU harness, NOT yet run on the GPU (device-scope fences across the XCDs'
-# L2s are what the harness cannot show) -- opt-in until it is: RIH_BN_LASTBLOCK=1.
-BN_LASTBLOCK = os.environ.get('RIH_BN_LASTBLOCK', '0') == '1'
-_BN_COUNTERS = {}
-_BN_COUNTER_POOL = 1 << 16
-
-
-def bn_counters(device, n):
-    """Pointer to n zero uint32 of the device's counter pool.  The kernels leave their counters zero, so the pool is zeroed
-    once; slices are handed out round-robin, far more of them than BatchNorm launches are ever in flight (or in one graph)."""
-    key = (device.type, device.index)
-    ent = _BN_COUNTERS.get(key)
-    if ent is None:
-        ent = _BN_COUNTERS[key] = [torch.zeros((_BN_COUNTER_POOL,), device=device, dtype=torch.int32), 0]
-    pool, off = ent
-    if off + n > _BN_COUNTER_POOL:
-        off = 0
-    ent[1] = off + n
-    return pool.data_ptr() + 4 * off
-
-
 class BatchNormFn(torch.autograd.Function):
     """nn.BatchNorm2d on NHWC rows (+ residual add + ReLU).  Training: batch statistics, running buffers updated
     in place (momentum 0.1, unbiased running_var) exactly like torch; eval: running statistics."""
@@ -1207,11 +1190,6 @@ class BatchNormFn(torch.autograd.Function):
                 assert T * bm == rows and part.shape[1] == Cc
                 check(lib.rih_bn_stats_from_tiles(part.data_ptr(), T, Cc, bm, eps, momentum, mean.data_ptr(), invstd.data_ptr(),
                                                   _p(rmean), _p(rvar), _stream()), 'rih_bn_stats_from_tiles')
-            elif training and BN_LASTBLOCK:
-                check(lib.rih_bn_stats_lastblock(x.data_ptr(), rows, Cc, eps, momentum, mean.data_ptr(), invstd.data_ptr(),
-                                                 _p(rmean), _p(rvar), ws.data_ptr(),
-                                                 bn_counters(x.device, int(lib.rih_bn_ncounters(rows, Cc))), _stream()),
-                      'rih_bn_stats_lastblock')
             elif training:
                 check(lib.rih_bn_stats(x.data_ptr(), rows, Cc, eps, momentum, mean.data_ptr(), invstd.data_ptr(),
                                        _p(rmean), _p(rvar), ws.data_ptr(), _stream()), 'rih_bn_stats')
@@ -1245,15 +1223,8 @@ class BatchNormFn(torch.autograd.Function):
         # writes dx (+ dres)
         flags = (0 if training else 1) | (2 if input_relu else 0)
         dxbound = bound_slot(x.device) if ENGINE == 2 else None     # max|dx|: the gradient operand's bound, as ybound above
-        if BN_LASTBLOCK:
-            cnt = bn_counters(x.device, int(lib.rih_bn_ncounters(rows, Cc)))
-            run = lambda: check(
-                lib.rih_bn_bwd_lastblock(dy.data_ptr(), x.data_ptr(), 0, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                                         dx.data_ptr(), _p(dres), dg.data_ptr(), db.data_ptr(), rows, Cc, 1 if relu else 0,
-                                         flags, ws.data_ptr(), _p(mask), cnt, _p(dxbound), _stream()), 'rih_bn_bwd_lastblock')
-        else:
-            run = lambda: check(
-                lib.rih_bn_bwd(dy.data_ptr(), x.data_ptr(), 0, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+        run = lambda: check(
+            lib.rih_bn_bwd(dy.data_ptr(), x.data_ptr(), 0, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                                dx.data_ptr(), _p(dres), dg.data_ptr(), db.data_ptr(), rows, Cc, 1 if relu else 0,
                                flags, ws.data_ptr(), _p(mask), _p(dxbound), _stream()), 'rih_bn_bwd')
         _elem_profile(x.numel() * (4.0 * (2 * 2 + 1 + (1 if has_res else 0)) + (0.5 if relu else 0.0)), 'bn_bwd', run)

@@ -14,11 +14,59 @@ import os
 import torch
 
 # side streams per device; 0 = everything in the calling stream.  1 = the finest branch in the calling stream beside all coarser
-# ones in ONE side stream: measured +5 % on the HRNet-W32 step (profiles/r03/ab/g2_hrnet_side_streams_*.log).  3 (one stream
-# per branch) runs eagerly but the captured step died with a host-side SIGSEGV inside the HIP runtime on ROCm 7.0.2
-# (profiles/r03/ab/g2_hrnet_side3_segv.log) -- not the default until that is understood.
+# ones in ONE side stream: measured +5 % on the HRNet-W32 step (profiles/r03/ab/g2_hrnet_side_streams_*.log).  2 / 3 run eagerly
+# but a captured step died with a host-side SIGSEGV inside the HIP runtime on ROCm 7.0.2 (profiles/r03/ab/g2_hrnet_side3_segv.log)
+# -- `effective_side` clamps the value to 1 while a stream captures.
 SIDE = int(os.environ.get('RIH_SIDE_STREAMS', '1'))
 _POOL = {}
+_LIMIT = None           # `limit(n)`: an upper bound on SIDE for the code inside the context (renderih_amd.train.TrainStep)
+_OPEN = []              # side streams forked from the calling stream and not yet joined (assert_joined)
+_WARNED = False
+
+
+class limit:
+    """Context: at most n side streams inside (nests; None = no extra limit).  TrainStep uses it instead of rewriting the module
+    global, so that its choice dies with its own forward / backward and touches no other model of the process."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        global _LIMIT
+        self.prev = _LIMIT
+        if self.n is not None:
+            _LIMIT = self.n if _LIMIT is None else min(_LIMIT, self.n)
+        return self
+
+    def __exit__(self, *a):
+        global _LIMIT
+        _LIMIT = self.prev
+        return False
+
+
+def effective_side(device=None):
+    """Side streams fork_join may use right now: RIH_SIDE_STREAMS, the enclosing `limit`, and -- while a stream captures -- at
+    most ONE: a captured step with two or three concurrent side branches died with a host-side SIGSEGV inside the HIP runtime
+    (ROCm 7.0.2, profiles/r03/ab/g2_hrnet_side3_segv.log, g3_hrnet_side2_segv.log; no root cause), only one is evidenced to
+    work.  A larger request is clamped with one warning, not obeyed."""
+    global _WARNED
+    n = SIDE if _LIMIT is None else min(SIDE, _LIMIT)
+    if n > 1 and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        if not _WARNED:
+            import warnings
+            warnings.warn('renderih_amd.streams: RIH_SIDE_STREAMS=%d clamped to 1 while a hipGraph is being captured (captured '
+                          'steps with more than one side branch crash the HIP runtime)' % SIDE)
+            _WARNED = True
+        n = 1
+    return max(n, 0)
+
+
+def assert_joined():
+    """Raise if a side stream forked by fork_join has not been joined back yet.  TrainStep calls it before it ends a stage's
+    capture: ending a capture with an un-joined branch is an error the HIP runtime reports badly."""
+    if _OPEN:
+        raise RuntimeError('renderih_amd.streams: %d side stream(s) forked and not joined' % len(_OPEN))
+
 
 
 def side_streams(device, n):
@@ -48,10 +96,13 @@ def fork_join(thunks, reads=None):
                 break
             if first is not None:
                 break
-    if n < 2 or SIDE <= 0 or first is None or not first.is_cuda:
+    if n < 2 or first is None or not first.is_cuda:
+        return [f() for f in thunks]
+    side = effective_side()
+    if side <= 0:
         return [f() for f in thunks]
     main = torch.cuda.current_stream(first.device)
-    streams = side_streams(first.device, min(SIDE, n - 1))
+    streams = side_streams(first.device, min(side, n - 1))
     out = [None] * n
     used = []
     for k in range(1, n):                   # every side stream starts at THIS point of the calling stream ...
@@ -59,15 +110,19 @@ def fork_join(thunks, reads=None):
         if s not in used:
             s.wait_stream(main)
             used.append(s)
-    out[0] = thunks[0]()                    # ... and the thunks are issued in list order, so autograd's node order (and with it
-    for k in range(1, n):                   # the order in which gradients of shared inputs are summed) is the single-stream one
-        s = streams[(k - 1) % len(streams)]
-        with torch.cuda.stream(s):
-            for t in _tensors(reads[k]):
-                t.record_stream(s)
-            out[k] = thunks[k]()
-    for s in used:
-        main.wait_stream(s)
+            _OPEN.append(s)
+    try:
+        out[0] = thunks[0]()                # ... and the thunks are issued in list order, so autograd's node order (and with it
+        for k in range(1, n):               # the order in which gradients of shared inputs are summed) is the single-stream one
+            s = streams[(k - 1) % len(streams)]
+            with torch.cuda.stream(s):
+                for t in _tensors(reads[k]):
+                    t.record_stream(s)
+                out[k] = thunks[k]()
+    finally:
+        for s in used:                      # joined on every path out (an exception inside a thunk included)
+            main.wait_stream(s)
+            _OPEN.remove(s)
     for k in range(1, n):
         for t in _tensors(out[k]):
             t.record_stream(main)

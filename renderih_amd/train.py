@@ -35,7 +35,7 @@ updated by the kernels and are correct.
 """
 import torch
 
-from . import ops
+from . import ops, streams
 
 
 def _trunk(model):
@@ -84,12 +84,12 @@ class TrainStep:
         self.groups = stage_parameter_groups(model) if stages else [[p for p in model.parameters() if p.requires_grad]]
         self.nstage = len(self.groups)
         self.overlap = overlap and self.exchange
+        self.side_limit = None          # upper bound on streams.SIDE inside this object's forward / backward (streams.limit)
         if self.overlap and self.img_is_cuda(example_batch):
             # the all-reduce already runs beside the backward in its own stream; a captured step with a THIRD concurrent branch
             # (streams.fork_join's side stream, HRNet) died inside the HIP runtime on ROCm 7.0.2, so the model's own
             # side streams are off in a process that exchanges gradients
-            from . import streams
-            streams.SIDE = 0
+            self.side_limit = 0
         self.img, self.labels = example_batch
         dev = self.img.device
         self.cuda = dev.type == 'cuda'
@@ -150,7 +150,8 @@ class TrainStep:
             self.packs.refresh()
         self._cutting = True
         try:
-            out = self.model(self.img)
+            with streams.limit(self.side_limit):
+                out = self.model(self.img)
         finally:
             self._cutting = False
         return self.loss_fn(out, self.labels)
@@ -168,7 +169,8 @@ class TrainStep:
         if self.side_wgrad and self.cuda:
             ops.side_wgrad_begin(self.img.device)
         try:
-            return self._stage_body(i, loss, carry)
+            with streams.limit(self.side_limit):
+                return self._stage_body(i, loss, carry)
         finally:
             ops.side_wgrad_join()
 
@@ -348,6 +350,7 @@ class TrainStep:
                         seed_word.add_(0x9E3779B1)
                         loss = self._forward_loss()
                     grads, carry = self._stage(i, loss, carry)
+                    streams.assert_joined()         # no forked branch may be open when the capture ends
                 pool = gph.pool()
                 self.graphs.append(gph)
                 self.static.append(grads)

@@ -26,20 +26,27 @@ def _i8(ptr, n):
 
 
 def hash_np(seed, idx):
-    """numpy mirror of rih_hash (csrc/rih_hash.h): mix32(lo32(idx) ^ hi32(idx) * 0x85EBCA6B ^ key(seed))."""
-    def mix(x):
-        x = x.astype(np.uint64) & np.uint64(0xFFFFFFFF)
+    """numpy mirror of rih_hash (csrc/rih_hash.h): the lowbias32 finalizer of lo32(idx) ^ hi32(idx) * 0x85EBCA6B ^ keyA(seed) with
+    keyB(seed) added between its two multiplies."""
+    M32 = np.uint64(0xFFFFFFFF)
+
+    def mix(x, kb=None):
+        x = x.astype(np.uint64) & M32
         x ^= x >> np.uint64(16)
-        x = (x * np.uint64(0x7feb352d)) & np.uint64(0xFFFFFFFF)
+        x = (x * np.uint64(0x7feb352d)) & M32
         x ^= x >> np.uint64(15)
-        x = (x * np.uint64(0x846ca68b)) & np.uint64(0xFFFFFFFF)
+        if kb is not None:
+            x = (x + kb) & M32
+        x = (x * np.uint64(0x846ca68b)) & M32
         x ^= x >> np.uint64(16)
         return x
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-    key = mix(np.array([seed & 0xFFFFFFFF], np.uint64)) ^ mix(np.array([(seed >> 32) ^ 0x9E3779B9], np.uint64))
+    lo_s, hi_s = seed & 0xFFFFFFFF, seed >> 32
+    ka = mix(np.array([lo_s], np.uint64)) ^ mix(np.array([hi_s ^ 0x9E3779B9], np.uint64))
+    kb = (mix(np.array([lo_s ^ 0x85EBCA6B], np.uint64)) + mix(np.array([(hi_s + 0xC2B2AE35) & 0xFFFFFFFF], np.uint64))) & M32
     idx = np.asarray(idx).astype(np.uint64)
-    lo, hi = idx & np.uint64(0xFFFFFFFF), idx >> np.uint64(32)
-    return mix(lo ^ key[0] ^ ((hi * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)))
+    lo, hi = idx & M32, idx >> np.uint64(32)
+    return mix(lo ^ ka[0] ^ ((hi * np.uint64(0x85EBCA6B)) & M32), kb[0])
 
 
 def keep_mask(seed, n, p):
@@ -1112,25 +1119,6 @@ class EmulatedLib:
         if dres:
             _f(dres, rows * Cc)[:] = D.ravel()
         return 0
-
-    # "last block done" forms: same results; the counters must arrive zero and are left zero
-    def rih_bn_ncounters(self, rows, Cc):
-        return 4
-
-    @staticmethod
-    def _counters_zero(counters, n=4):
-        assert counters, 'counters pointer missing'
-        assert not np.ctypeslib.as_array(C.cast(counters, C.POINTER(C.c_uint32)), shape=(n,)).any(), 'counter slice not zero'
-
-    def rih_bn_stats_lastblock(self, x, rows, Cc, eps, momentum, mean, invstd, rmean, rvar, ws, counters, stream):
-        self._counters_zero(counters)
-        return self.rih_bn_stats(x, rows, Cc, eps, momentum, mean, invstd, rmean, rvar, ws, stream)
-
-    def rih_bn_bwd_lastblock(self, dy, x, y, mean, invstd, gamma, dx, dres, dgamma, dbeta, rows, Cc, relu, frozen, ws, mask,
-                             counters, amax_dx, stream):
-        self._counters_zero(counters)
-        return self.rih_bn_bwd(dy, x, y, mean, invstd, gamma, dx, dres, dgamma, dbeta, rows, Cc, relu, frozen, ws, mask, amax_dx,
-                               stream)
 
     # ------------------------------------------------------------------ row-wise
     def rih_ln_nblk(self, rows):

@@ -188,6 +188,7 @@ static inline void __syncthreads() { hipcpu::S().cur->land(); hipcpu::block_barr
 static inline void __threadfence() {}
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
 static inline unsigned atomicMax(unsigned* p, unsigned v) { const unsigned o = *p; if (v > o) *p = v; return o; }
+#define __hip_atomic_load(p, order, scope) (*(p))
 
 template <typename T>
 static inline T __shfl_xor(T v, int mask, int width = 64) {

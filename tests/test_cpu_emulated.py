@@ -31,7 +31,6 @@ def test_linear_host_logic(case):
 def test_other_ops_host_logic():
     G.test_batchnorm(True, True, True, (2, 16, 16, 64))
     G.test_batchnorm(False, True, False, (3, 7, 9, 256))
-    G.check_batchnorm_lastblock((2, 4, 4, 64), True, True)      # ops.BN_LASTBLOCK: counter-pool plumbing of the *_lastblock entry points
     G.test_layernorm(4, 509, False, False)
     G.test_layernorm(300, 256, True, True)
     G.test_attention(2, 127, 127, 256, 4)

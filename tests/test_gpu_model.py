@@ -47,7 +47,7 @@ def _grad_report(named_grads, g32, g64, k=6.0, floor=2e-4):
     by O(1/rows) (seen on CPU too: with train-mode BN at B=2..3 the fp32 oracle's trunk gradients are several % from
     its fp64 run).  So: at least 97% of the tensors must be within k x (the fp32 reference's own error vs fp64) +
     floor, and every tensor within max(5%, 20 x that reference error) of max|ref|."""
-    n, loose, gross = 0, [], []
+    n, loose, gross, worst = 0, [], [], (0.0, '', 0.0, 0.0)
     for name, g in named_grads:
         if testing.is_null_gradient(name):
             continue            # exactly zero in exact arithmetic: round-off noise only
@@ -56,10 +56,13 @@ def _grad_report(named_grads, g32, g64, k=6.0, floor=2e-4):
         e_got = float((g.detach().double().cpu() - ref64).abs().max()) / scale
         e_ref = float((ref32.double() - ref64).abs().max()) / scale
         n += 1
+        worst = max(worst, (e_got / max(e_ref, floor), name, e_got, e_ref))
         if not (e_got <= k * e_ref + floor):
             loose.append('%s: %.3g (fp32 ref %.3g)' % (name, e_got, e_ref))
         if not (e_got <= max(0.05, 20 * e_ref)):
             gross.append('%s: %.3g' % (name, e_got))
+    print('_grad_report: %d tensors, %d outside the %gx band; worst %s: %.3g vs fp32 ref %.3g (%.1fx)'
+          % (n, len(loose), k, worst[1], worst[2], worst[3], worst[0]))
     assert not gross, 'gradients grossly off:\n' + '\n'.join(gross[:20])
     assert len(loose) <= 0.03 * n, '%d/%d gradient tensors outside the fp64-anchored band:\n%s' % (
         len(loose), n, '\n'.join(loose[:20]))
@@ -421,7 +424,7 @@ def test_decoder_side_stream_changes_nothing(monkeypatch):
 
 
 def _dead_mid_check(device, monkeypatch):
-    """model.SKIP_DEAD_MID (RIH_SKIP_DEAD_MID=1): the finest mid convolution, whose output `decoder.forward` drops
+    """model.SKIP_DEAD_MID (the default since round 4): the finest mid convolution, whose output `decoder.forward` drops
     (models/decoder.py:130), reduced to what it still owes -- its BatchNorm's running statistics in training mode, nothing in
     eval mode.  Outputs, parameter gradients and EVERY buffer of the state_dict equal the full computation bit for bit."""
     from oracle.net_oracle import scalar_loss
@@ -453,9 +456,6 @@ def _dead_mid_check(device, monkeypatch):
             assert torch.equal(a[k], b[k]), '%s %s differs with the dead mid convolution skipped' % (what, k)
 
 
-@pytest.mark.skipif(os.environ.get('RIH_SKIP_DEAD_MID', '0') != '1',
-                    reason='opt-in feature (RIH_SKIP_DEAD_MID=1), built after the round-3 GPU budget was spent: its host logic is '
-                           'covered on the emulated ABI (tests/test_cpu_emulated.py); run with the flag set to check it on the GPU')
 def test_dead_mid_convolution_skip_changes_nothing(monkeypatch):
     _dead_mid_check('cuda:0', monkeypatch)
 

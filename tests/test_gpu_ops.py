@@ -204,53 +204,11 @@ def check_linear_dropout_epilogue(rows, K, Nf, relu, res, pair=False, p=0.3, exp
         assert torch.equal(a, b)
 
 
-def check_batchnorm_lastblock(shape, relu, res, monkeypatch=None):
-    """ops.BN_LASTBLOCK (rih_bn_stats_lastblock / rih_bn_bwd_lastblock): statistics, output, every gradient and the running
-    buffers bit-identical to the two-launch form; the counter pool is left zero."""
-    from renderih_amd import ops
-    N, H, W, Cc = shape
-    d = dev()
-    x = (rnd(N, H, W, Cc, seed=11) * 2 + 0.5).to(d)
-    r = rnd(N, H, W, Cc, seed=12).to(d) if res else None
-    g, b = (torch.rand(Cc) + 0.5).to(d), (rnd(Cc, seed=13) * 0.1).to(d)
-    gy = rnd(N, H, W, Cc, seed=15).to(d)
-    out = {}
-    saved = ops.BN_LASTBLOCK
-    try:
-        for last in (False, True):
-            ops.BN_LASTBLOCK = last
-            for rep in range(2 if last else 1):             # twice: the second call takes the next counter slice
-                xg, gg, bg = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
-                rg = r.clone().requires_grad_(True) if res else None
-                rm, rv = (rnd(Cc, seed=14) * 0.1).to(d), torch.full((Cc,), 0.75).to(d)
-                y = ops.batchnorm(xg, gg, bg, rm, rv, residual=rg, training=True, relu=relu)
-                y.backward(gy)
-                out[last] = [y.detach(), xg.grad, gg.grad, bg.grad, rm, rv] + ([rg.grad] if res else [])
-    finally:
-        ops.BN_LASTBLOCK = saved
-    for a, bb in zip(out[False], out[True]):
-        assert torch.equal(a, bb)
-    pool = ops._BN_COUNTERS[(d.type, d.index)][0]
-    assert int(pool.abs().max()) == 0 and ops._BN_COUNTERS[(d.type, d.index)][1] > 0
-
-
-@pytest.mark.skipif(os.environ.get('RIH_GEMM_DROPOUT', '0') != '1',
-                    reason='opt-in feature (RIH_GEMM_DROPOUT=1) built after the round-3 GPU budget was spent: bit-identical on the '
-                           'HIP-on-CPU harness (tests/test_kernels_on_cpu.py); set the flag to check it on the GPU')
 @pytest.mark.parametrize('case', [(8064, 256, 256, False, True, True), (40448, 64, 64, True, False, True),
                                   (8128, 128, 128, False, True, False), (300, 64, 509, False, True, False),
                                   (126, 30, 64, True, False, False, 0.3, False)])
 def test_linear_dropout_epilogue_is_bit_identical(case):
     check_linear_dropout_epilogue(*case)
-
-
-@pytest.mark.skipif(os.environ.get('RIH_BN_LASTBLOCK', '0') != '1',
-                    reason='opt-in feature (RIH_BN_LASTBLOCK=1) built after the round-3 GPU budget was spent: bit-identical on the '
-                           'HIP-on-CPU harness (tests/test_kernels_on_cpu.py); set the flag to check it on the GPU')
-@pytest.mark.parametrize('shape,relu,res', [((2, 16, 16, 64), True, True), ((3, 7, 9, 256), False, False),
-                                            ((64, 64, 64, 256), True, True), ((32, 8, 8, 2048), True, False)])
-def test_batchnorm_lastblock_is_bit_identical(shape, relu, res):
-    check_batchnorm_lastblock(shape, relu, res)
 
 
 @pytest.mark.parametrize('rows,D,x2,relu', [(126, 64, False, False), (4, 509, False, False), (300, 256, True, True),
@@ -331,20 +289,27 @@ def test_flash_attention_equals_three_kernel_path(B, Sq, Sk, D, h, p):
 
 
 def _hash_np(seed, idx):
-    """numpy mirror of rih_hash (csrc/rih_hash.h): mix32(lo32(idx) ^ hi32(idx) * 0x85EBCA6B ^ key(seed))."""
-    def mix(x):
-        x = x.astype(np.uint64) & np.uint64(0xFFFFFFFF)
+    """numpy mirror of rih_hash (csrc/rih_hash.h): the lowbias32 finalizer of lo32(idx) ^ hi32(idx) * 0x85EBCA6B ^ keyA(seed) with
+    keyB(seed) added between its two multiplies."""
+    M32 = np.uint64(0xFFFFFFFF)
+
+    def mix(x, kb=None):
+        x = x.astype(np.uint64) & M32
         x ^= x >> np.uint64(16)
-        x = (x * np.uint64(0x7feb352d)) & np.uint64(0xFFFFFFFF)
+        x = (x * np.uint64(0x7feb352d)) & M32
         x ^= x >> np.uint64(15)
-        x = (x * np.uint64(0x846ca68b)) & np.uint64(0xFFFFFFFF)
+        if kb is not None:
+            x = (x + kb) & M32
+        x = (x * np.uint64(0x846ca68b)) & M32
         x ^= x >> np.uint64(16)
         return x
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-    key = mix(np.array([seed & 0xFFFFFFFF], np.uint64)) ^ mix(np.array([(seed >> 32) ^ 0x9E3779B9], np.uint64))
+    lo_s, hi_s = seed & 0xFFFFFFFF, seed >> 32
+    ka = mix(np.array([lo_s], np.uint64)) ^ mix(np.array([hi_s ^ 0x9E3779B9], np.uint64))
+    kb = (mix(np.array([lo_s ^ 0x85EBCA6B], np.uint64)) + mix(np.array([(hi_s + 0xC2B2AE35) & 0xFFFFFFFF], np.uint64))) & M32
     idx = np.asarray(idx).astype(np.uint64)
-    lo, hi = idx & np.uint64(0xFFFFFFFF), idx >> np.uint64(32)
-    return mix(lo ^ key[0] ^ ((hi * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)))
+    lo, hi = idx & M32, idx >> np.uint64(32)
+    return mix(lo ^ ka[0] ^ ((hi * np.uint64(0x85EBCA6B)) & M32), kb[0])
 
 
 def test_attention_dropout_matches_hash_mask():

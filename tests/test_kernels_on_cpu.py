@@ -97,13 +97,6 @@ def test_linear_dropout_epilogue_kernels(case):
     G.check_linear_dropout_epilogue(*case)
 
 
-@pytest.mark.parametrize('shape,relu,res', [((2, 4, 4, 64), True, True), ((3, 33, 7, 32), False, False), ((2, 9, 9, 512), True, False)])
-def test_batchnorm_lastblock_kernels(shape, relu, res):
-    """The "last block done" reductions (one launch less per BatchNorm and direction) against the two-launch form: bit for bit,
-    several row chunks per channel slice (3 x 33 x 7 rows) and several slices (512 channels)."""
-    G.check_batchnorm_lastblock(shape, relu, res)
-
-
 @pytest.mark.parametrize('case', [(2, 40, 40, 256, 4, 0.0), (1, 70, 33, 128, 4, 0.1), (1, 33, 130, 64, 4, 0.05), (2, 1, 5, 32, 2, 0.0)])
 def test_flash_attention_kernels(case):
     G.test_flash_attention_equals_three_kernel_path(*case)

@@ -19,7 +19,7 @@ from gemm_pmc_driver_shapes import SHAPES  # noqa: E402
 
 dev = torch.device('cuda:0')
 B = 64
-BE = 4          # images of the error check (fp64 im2col products)
+BE = 8          # images of the error check (fp64 im2col products)
 
 
 def time_launch(fn, iters=20):
@@ -80,10 +80,20 @@ for kind, H, Cin, Cout, k in SHAPES:
                 y = torch.empty(B, H, H, Cout, device=dev)
                 fn = lambda: ops.gemm(x, wp, y, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=tile, engine=e, **kw)
             us = time_launch(fn)
-            # error on the first BE images, single launch (no split-K) so that the figure is the engine's, not the reduction's
-            ye = torch.empty(BE, H, H, Cout, device=dev)
-            ops.gemm(x[:BE].contiguous(), wp, ye, BE * H * H, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0,
-                     geom=geom, tile=tile, engine=e, **kw)
+            # error on the first BE images in the PRODUCTION configuration: same tile, same split-K chunk (the partial slabs
+            # summed in fp32 in slab order, as rih_splitk_finish does)
+            Me = BE * H * H
+            if sk > 1:
+                pe = torch.empty(skk, Me, Cout, device=dev)
+                ops.gemm(x[:BE].contiguous(), wp, pe, Me, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=tile,
+                         splitk=skk, kchunk=kc, sCsplit=Me * Cout, engine=e, **kw)
+                ye = pe[0].clone()
+                for i_ in range(1, skk):
+                    ye += pe[i_]
+            else:
+                ye = torch.empty(BE, H, H, Cout, device=dev)
+                ops.gemm(x[:BE].contiguous(), wp, ye, Me, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0,
+                         geom=geom, tile=tile, engine=e, **kw)
             er, e32 = errs(ye, im2col(x[:BE], k, p), wp)
             res[e] = (us, er, e32)
         label = 'fwd   %2dx%-2d %4d->%-4d k%d | M%-6d N%-4d K%-5d | tile %d sk %d' % (H, H, Cin, Cout, k, M, Cout, K, tile, sk)
@@ -106,12 +116,21 @@ for kind, H, Cin, Cout, k in SHAPES:
             fn = lambda: ops.gemm(x, dy, part, Mp, Cout, M, Cin, Cout, Cout, a_mode=1, b_mode=0, splitk=sk, kchunk=kc,
                                   sCsplit=Mp * Cout, geom=geom, tile=tile, engine=e, **kw)
             us = time_launch(fn)
-            # error: ONE k-chunk of the production split (what a workgroup accumulates), first BE images
+            # error on the first BE images in the PRODUCTION configuration: the same k-chunk per split-K slice as the timed launch,
+            # the partial slabs summed in fp32 in slab order (rih_splitk_reduce's order)
             Me = BE * H * H
-            pe = torch.empty(1, Mp, Cout, device=dev)
-            ops.gemm(x[:BE].contiguous(), dy[:BE].contiguous(), pe, Mp, Cout, Me, Cin, Cout, Cout, a_mode=1, b_mode=0,
-                     geom=geom, tile=tile, engine=e, **kw)
-            er, e32 = errs(pe[0], im2col(x[:BE], k, p).t().contiguous(), dy[:BE].reshape(Me, Cout))
+            ske = -(-Me // kc)
+            pe = torch.empty(ske, Mp, Cout, device=dev)
+            if ske > 1:
+                ops.gemm(x[:BE].contiguous(), dy[:BE].contiguous(), pe, Mp, Cout, Me, Cin, Cout, Cout, a_mode=1, b_mode=0,
+                         splitk=ske, kchunk=kc, sCsplit=Mp * Cout, geom=geom, tile=tile, engine=e, **kw)
+            else:
+                ops.gemm(x[:BE].contiguous(), dy[:BE].contiguous(), pe, Mp, Cout, Me, Cin, Cout, Cout, a_mode=1, b_mode=0,
+                         geom=geom, tile=tile, engine=e, **kw)
+            ge = pe[0].clone()
+            for i_ in range(1, ske):
+                ge += pe[i_]
+            er, e32 = errs(ge, im2col(x[:BE], k, p).t().contiguous(), dy[:BE].reshape(Me, Cout))
             res[e] = (us, er, e32)
         label = 'wgrad %2dx%-2d %4d->%-4d k%d | M%-6d N%-4d K%-5d | tile %d sk %d' % (H, H, Cin, Cout, k, Mp, Cout, M, tile, sk)
     fl = 2.0 * M * Cout * K
