@@ -119,12 +119,13 @@ typedef struct rih_gemm_desc {
     int32_t reserved1;
     uint64_t drop_seed;
     const uint64_t* drop_seed_dev;
-    /* Engine 2 only (ABI 13): DEVICE pointers to one float each, an upper bound of max|A| resp. max|B| over everything the
-     * launch reads (all batch slices).  The kernel derives the power-of-two operand scale from it (s * bound in [2^14, 2^15)),
-     * so the bound is read at run time -- a step captured in a hipGraph follows the data.  Any upper bound is correct: a
-     * bound 2^k too large costs k of the ~29 binades below the maximum that keep full precision; a bound that is too SMALL
-     * can overflow fp16 (inf / NaN in the result).  Written by rih_absmax or by the producing kernel (rih_bn_apply,
-     * rih_bn_bwd: `amax` arguments).  NULL = the operand is known to lie inside [-2^15, 2^15] (scale 1). */
+    /* Engine 2 only (ABI 13): DEVICE pointers to a BOUND BLOCK each (RIH_BOUND_FLOATS floats, see rih_absmax): an upper bound
+     * of max|A| resp. max|B| over everything the launch reads (all batch slices).  The kernel derives the power-of-two operand
+     * scale from it (s * bound in [2^14, 2^15)), so the bound is read at run time -- a step captured in a hipGraph follows the
+     * data.  Any upper bound is correct: a bound 2^k too large costs k of the ~29 binades below the maximum that keep full
+     * precision; a bound that is too SMALL can overflow fp16 (inf / NaN in the result).  Written by rih_absmax or by the
+     * producing kernel (rih_bn_apply, rih_bn_bwd: `amax` arguments).  NULL = the operand is known to lie inside
+     * [-2^15, 2^15] (scale 1). */
     const float* amax_a;
     const float* amax_b;
 } rih_gemm_desc;
@@ -132,9 +133,22 @@ int rih_gemm_stats_rows(const rih_gemm_desc* d);
 int rih_gemm_dropout_ok(const rih_gemm_desc* d);
 /* The engine rih_gemm would run `d` on (0 / 1 / 2), or -1 for an invalid descriptor. */
 int rih_gemm_engine(const rih_gemm_desc* d);
-/* out[0] = max(out[0], max_i |x[i]|) over n floats (out must hold a non-negative float, e.g. 0, beforehand; NaNs are ignored).
- * One pass at streaming rate; several tensors can share one bound.  rih_fill_zero_f32 (or a memset) resets a bound. */
+/* Bound block: RIH_BOUND_FLOATS floats = 64 partial maxima at a stride of 32 floats (one per 128-byte line; the other floats are
+ * unused); THE BOUND IS THE MAXIMUM OF THE 64.  A producer merges its candidates into the lines with atomic maxima (64 lines so
+ * that the same-address atomics of thousands of workgroups do not queue up behind one word), a consumer (rih_gemm engine 2) reads
+ * the 64 words with one vector load per wavefront.  The caller zeroes a block (all 2048 floats, or at least the 64 words) before
+ * its first producer runs; several producers may share a block.
+ * rih_absmax: block <- max(block, max_i |x[i]|) over n floats (NaNs are ignored); one pass at streaming rate.
+ * rih_absmax_multi: the same for n tensors in ceil(n / 120) launches (`descs` is HOST memory, read before the call returns):
+ * the convolution weights of a training step. */
+#define RIH_BOUND_FLOATS 2048
 int rih_absmax(const float* x, int64_t n, float* out, void* stream);
+typedef struct rih_absmax_desc {
+    const float* x;
+    float* out;             /* bound block */
+    int64_t n;
+} rih_absmax_desc;
+int rih_absmax_multi(const rih_absmax_desc* descs, int n, void* stream);
 
 int rih_gemm(const rih_gemm_desc* d, void* stream);
 
@@ -303,8 +317,8 @@ int rih_bn_stats(const float* x, int rows, int C, float eps, float momentum, flo
 /* eval statistics from running buffers */
 int rih_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean,
                       float* invstd, void* stream);
-/* y = act((x-mean)*invstd*gamma + beta + residual).  amax (optional, ABI 13): *amax = max(*amax, max|y|) -- the operand bound of
- * the convolution that reads y (rih_gemm_desc.amax_a, engine 2) at no extra pass; the caller zeroes it beforehand. */
+/* y = act((x-mean)*invstd*gamma + beta + residual).  amax (optional, ABI 13): a bound block (rih_absmax) that receives max|y| --
+ * the operand bound of the convolution that reads y (rih_gemm_desc.amax_a, engine 2) at no extra pass; zeroed by the caller. */
 int rih_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                  const float* residual, float* y, int rows, int C, int relu, uint8_t* relu_mask, float* amax, void* stream);
 /* relu_mask (optional, relu != 0): rows*C/4 bytes, byte q = sign pattern of output quad q (bit e set: element 4q+e > 0).
@@ -317,8 +331,8 @@ int rih_bn_apply(const float* x, const float* mean, const float* invstd, const f
 int rih_bn_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
                const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C,
                int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, float* amax_dx, void* stream);
-/* amax_dx (optional, ABI 13): *amax_dx = max(*amax_dx, max|dx|), as `amax` of rih_bn_apply -- dx is the gradient operand of the
- * producing convolution's data- and weight-gradient GEMMs. */
+/* amax_dx (optional, ABI 13): a bound block that receives max|dx|, as `amax` of rih_bn_apply -- dx is the gradient operand of
+ * the producing convolution's data- and weight-gradient GEMMs. */
 
 /* ------------------------------------------------------------------------------------------------
  * Row-wise ops on [rows][D] matrices (decoder)                                                         */
@@ -495,11 +509,11 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
 /* library / device info.  RIH_ABI_VERSION is bumped whenever a struct layout or a signature of this header changes;
  * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of EVERY by-pointer struct, in
  * this order: gemm desc, mano model, mesh topo, hconv desc, gemm p3 desc, reduce desc, pack desc, ln final desc, adam entry,
- * chain desc (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it mis-laid-out structs. */
+ * chain desc, absmax desc (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it mis-laid-out structs. */
 #define RIH_ABI_VERSION 13
-#define RIH_ABI_NSIZES 10
+#define RIH_ABI_NSIZES 11
 int rih_version(void);
-int rih_abi_sizes(int32_t* out10);
+int rih_abi_sizes(int32_t* out11);
 const char* rih_arch(void);
 
 /* ------------------------------------------------------------------------------------------------

@@ -46,6 +46,13 @@ class ReduceDesc(C.Structure):
                [(n, C.c_int32) for n in ('S', 'Mp', 'M', 'N', 'Cin', 'taps', 'CinValid', 'accumulate')]
 
 
+class AbsmaxDesc(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('out', C.c_void_p), ('n', C.c_int64)]
+
+
+BOUND_FLOATS = 2048     # = RIH_BOUND_FLOATS: a bound block (64 partial maxima, one per 128-byte line)
+
+
 class LnFinalDesc(C.Structure):
     _fields_ = [('ws', C.c_void_p), ('dg', C.c_void_p), ('db', C.c_void_p), ('D', C.c_int32), ('nblk', C.c_int32)]
 
@@ -193,6 +200,7 @@ SIGNATURES = {
     'rih_gemm_dropout_ok': (c_i, [C.POINTER(GemmDesc)]),
     'rih_gemm_engine': (c_i, [C.POINTER(GemmDesc)]),
     'rih_absmax': (c_i, [c_f, c_l, c_f, C.c_void_p]),
+    'rih_absmax_multi': (c_i, [C.POINTER(AbsmaxDesc), c_i, C.c_void_p]),
     'rih_gemm_multi_variant': (c_i, [C.POINTER(GemmDesc)]),
     'rih_gemm_multi_table_bytes': (c_l, [C.POINTER(GemmDesc), c_i]),
     'rih_gemm_multi_pack': (c_i, [C.POINTER(GemmDesc), c_i, C.c_void_p, C.POINTER(C.c_int32)]),
@@ -246,7 +254,7 @@ def load():
     # every by-pointer struct of the header, in rih_abi_sizes' order; the last one (rih_adam_entry: four pointers + int64) is
     # built by hand as int64 rows in renderih_amd/optim.py
     mine = [C.sizeof(GemmDesc), C.sizeof(ManoModel), C.sizeof(MeshTopo), C.sizeof(HConvDesc), C.sizeof(GemmP3Desc),
-            C.sizeof(ReduceDesc), C.sizeof(PackDesc), C.sizeof(LnFinalDesc), 5 * 8, C.sizeof(ChainDesc)]
+            C.sizeof(ReduceDesc), C.sizeof(PackDesc), C.sizeof(LnFinalDesc), 5 * 8, C.sizeof(ChainDesc), C.sizeof(AbsmaxDesc)]
     if lib.rih_version() != ABI_VERSION:
         raise RuntimeError('librenderih_amd.so does not match this binding (ABI %d vs %d): rebuild with '
                            '`python -m renderih_amd._build`' % (lib.rih_version(), ABI_VERSION))

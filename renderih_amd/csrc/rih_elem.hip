@@ -51,12 +51,16 @@ __device__ __forceinline__ uint32_t drop_thresh(float p) {
 }
 
 // ------------------------------------------------------------------------------------------------ operand bounds (rih_gemm engine 2)
-// max|x| into a device word: non-negative floats order like their bit patterns, so the merge is an integer atomicMax (NaN
-// candidates are dropped by fmaxf before they get there).  One atomic per wavefront.
-// Every thread of the block must call it (one barrier).  One candidate per BLOCK, and the atomic only when the candidate exceeds
-// what the word already holds (a relaxed read: a stale, smaller value merely lets a redundant atomic through): same-address
-// device-scope atomics retire at ~10 ns each on this chip -- one per wavefront (65536 per BatchNorm launch) made the BatchNorm
-// family ten times slower (profiles/r04/ab/train_e2.log: 6.5 -> 60 ms per step).
+// A bound block (include/renderih_amd.h: RIH_BOUND_FLOATS) = 64 partial maxima, one per 128-byte line; the bound is the maximum
+// of the 64.  Non-negative floats order like their bit patterns, so a merge is an integer atomicMax (NaN candidates are dropped
+// by fmaxf before they get there).  Why 64 lines: same-address device-scope atomics retire at ~7-10 ns each on this chip (they
+// are served behind the XCDs' L2s).  One word for the whole tensor cost the BatchNorm kernels dearly -- one atomic per wavefront
+// (65536 per launch): 6.5 -> 60 ms per step; one per block with a read in front of it: still +27 us on a 30 us launch
+// (profiles/r04/ab/train_e2.log, step_trace_c2_*.txt) -- because the blocks of a streaming kernel finish in herds that all
+// read the same stale word.  Spread over 64 lines (block b -> line b & 63) the herd is 64 short queues that drain in parallel.
+// Every thread of the block must call it (one barrier).
+constexpr int BOUND_SLOTS = 64, BOUND_STRIDE = 32;
+static_assert(BOUND_SLOTS * BOUND_STRIDE == RIH_BOUND_FLOATS, "bound block layout");
 __device__ __forceinline__ void amax_publish(float* out, float v) {
     __shared__ float amax_red[TPB / 64];
     v = wave_max(v);
@@ -67,24 +71,43 @@ __device__ __forceinline__ void amax_publish(float* out, float v) {
 #pragma unroll
         for (int w = 1; w < TPB / 64; ++w) m = fmaxf(m, amax_red[w]);
         const unsigned bits = __float_as_uint(m);
-        unsigned* o = reinterpret_cast<unsigned*>(out);
+        unsigned* o = reinterpret_cast<unsigned*>(out) + ((blockIdx.x + blockIdx.y * 7u) & (BOUND_SLOTS - 1)) * BOUND_STRIDE;
         if (m > 0.f && bits > __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(o, bits);
     }
 }
-__global__ __launch_bounds__(TPB) void absmax_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+__device__ __forceinline__ float absmax_span(const float* __restrict__ x, long long n, long long first, long long step) {
     float m = 0.f;
     const long long nq = n >> 2;
     if (((uintptr_t)x & 15) == 0) {
         const float4* x4 = reinterpret_cast<const float4*>(x);
-        GRID_STRIDE(i, nq) {
+        for (long long i = first; i < nq; i += step) {
             const float4 v = x4[i];
             m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         }
-        GRID_STRIDE(i, n - 4 * nq) m = fmaxf(m, fabsf(x[4 * nq + i]));
+        for (long long i = 4 * nq + first; i < n; i += step) m = fmaxf(m, fabsf(x[i]));
     } else {
-        GRID_STRIDE(i, n) m = fmaxf(m, fabsf(x[i]));
+        for (long long i = first; i < n; i += step) m = fmaxf(m, fabsf(x[i]));
     }
-    amax_publish(out, m);
+    return m;
+}
+__global__ __launch_bounds__(TPB) void absmax_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+    amax_publish(out, absmax_span(x, n, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x));
+}
+// many tensors in one launch (rih_absmax_multi: the convolution weights of a training step); descriptors by value
+constexpr int ABSMAX_PACK = 120;
+struct AbsmaxPack {
+    rih_absmax_desc d[ABSMAX_PACK];
+    int first[ABSMAX_PACK + 1];
+    int n;
+};
+static_assert(sizeof(AbsmaxPack) <= 4096, "kernel argument limit");
+__global__ __launch_bounds__(TPB) void absmax_multi_kernel(const AbsmaxPack pk) {
+    const int b = (int)blockIdx.x;
+    int k = 0;
+    while (k + 1 < pk.n && b >= pk.first[k + 1]) ++k;
+    const int nb = pk.first[k + 1] - pk.first[k];
+    const float m = absmax_span(pk.d[k].x, pk.d[k].n, (long long)(b - pk.first[k]) * TPB + threadIdx.x, (long long)nb * TPB);
+    amax_publish(pk.d[k].out, m);
 }
 
 // ------------------------------------------------------------------------------------------------ layout
@@ -1945,6 +1968,25 @@ extern "C" int rih_absmax(const float* x, int64_t n, float* out, void* stream) {
     hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n, 16)), dim3(TPB), 0, STREAM, x, (long long)n, out);
     LAUNCH_RET();
 }
+extern "C" int rih_absmax_multi(const rih_absmax_desc* descs, int n, void* stream) {
+    if (n < 0 || (n > 0 && !descs)) return RIH_EINVAL;
+    for (int i = 0; i < n; ++i)
+        if (!descs[i].x || !descs[i].out || descs[i].n < 1) return RIH_EINVAL;
+    for (int base = 0; base < n; base += ABSMAX_PACK) {
+        AbsmaxPack pk;
+        pk.n = (n - base < ABSMAX_PACK) ? n - base : ABSMAX_PACK;
+        int total = 0;
+        for (int i = 0; i < pk.n; ++i) {
+            pk.d[i] = descs[base + i];
+            pk.first[i] = total;
+            long long nb = (descs[base + i].n + 16 * TPB - 1) / (16 * TPB);     // 16 elements per thread
+            total += (int)(nb > 256 ? 256 : nb);
+        }
+        pk.first[pk.n] = total;
+        hipLaunchKernelGGL(absmax_multi_kernel, dim3(total), dim3(TPB), 0, STREAM, pk);
+    }
+    LAUNCH_RET();
+}
 
 extern "C" int rih_version(void) { return RIH_ABI_VERSION; }
 extern "C" int rih_abi_sizes(int32_t* out9) {      // RIH_ABI_NSIZES values
@@ -1959,6 +2001,7 @@ extern "C" int rih_abi_sizes(int32_t* out9) {      // RIH_ABI_NSIZES values
     out9[7] = (int32_t)sizeof(rih_ln_final_desc);
     out9[8] = (int32_t)sizeof(rih_adam_entry);
     out9[9] = (int32_t)sizeof(rih_chain_desc);
+    out9[10] = (int32_t)sizeof(rih_absmax_desc);
     return 0;
 }
 extern "C" const char* rih_arch(void) { return "gfx950"; }

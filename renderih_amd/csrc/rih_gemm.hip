@@ -13,6 +13,11 @@
 #include <stdint.h>
 #include "../../include/renderih_amd.h"
 #include "rih_hash.h"
+#include <type_traits>
+
+#ifndef RIH_E2_PIPE
+#define RIH_E2_PIPE 1       /* engine 2's main loop: 1 = two LDS stages, one barrier per k-tile, conversion interleaved with the MFMAs */
+#endif
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -51,7 +56,7 @@ struct GemmArgs {
     float drop_scale;               // 1 / (1 - p)
     unsigned long long drop_seed;
     const unsigned long long* drop_seed_dev;    // device-resident addend of the seed (hipGraph replay), or NULL
-    // engine 2 (two-term fp16 split): device-resident upper bounds of |A|, |B| (one float each), or NULL = 1.0
+    // engine 2 (two-term fp16 split): device-resident upper bounds of |A|, |B| (bound blocks, rih_absmax), or NULL = 1.0
     const float* amax_a;
     const float* amax_b;
 };
@@ -111,12 +116,17 @@ __device__ __forceinline__ int lds_swz(int m) { return (m >> 2) & 3; }
 // v_mfma_f32_32x32x16_f16 per 32x32x16 block: hi*hi into one fp32 accumulator, hi*lo + lo*hi into a second one; the epilogue
 // combines acc0 + 2^-11 acc1 and undoes the operand scales (exact: powers of two).  The dropped lo*lo term is <= 2^-22
 // relative.  Half the matrix-pipe work (and energy) per fp32 FLOP of the six-product bf16 engine: 2.5 PF / 3 = 833 TF.
-// The scale comes from a device-resident upper bound of max|x| (GemmArgs.amax_a / amax_b: written by the kernel that produced
-// the operand, or by rih_absmax): any upper bound is correct, a loose one only costs range at the bottom (full 22-bit
+// The scale comes from a device-resident upper bound of max|x| (GemmArgs.amax_a / amax_b: a bound block written by the kernel
+// that produced the operand, or by rih_absmax): any upper bound is correct, a loose one only costs range at the bottom (full 22-bit
 // precision for |x| >= 2^-29 * bound).
 __device__ __forceinline__ float e2_scale(const float* amax, bool at_least_one) {
     if (amax == nullptr) return 1.f;
-    float a = *amax;
+    // the bound block: 64 partial maxima, one per 128-byte line (include/renderih_amd.h: rih_absmax) -- one vector load per
+    // wavefront and an xor-shuffle maximum; the result is wave-uniform
+    float a = amax[(threadIdx.x & 63) * (RIH_BOUND_FLOATS / 64)];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
+    a = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(a)));
     if (at_least_one) a = fmaxf(a, 1.f);            // the all-ones row of a weight-gradient's A operand must stay in range
     const int e = (int)((__float_as_uint(a) >> 23) & 0xffu);
     if (e == 0 || e == 255) return 1.f;             // zero / denormal bound (an all-zero operand), or inf / NaN (garbage either way)
@@ -795,7 +805,11 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
     constexpr int NPA = BM / 32, NPB = BN / 32;
     constexpr int QA = BM / 4, QB = BN / 4;
 
-    constexpr int OPER_DW = NPL * (PLANE_A + PLANE_B);
+    // engine 2 runs a ONE-barrier main loop on two LDS stages (see the PIPE loop below); RIH_E2_PIPE=0 builds the two-barrier
+    // single-stage loop of engine 1 for it (A/B partner)
+    constexpr bool PIPE = (ENG == 2) && (RIH_E2_PIPE != 0);
+    constexpr int STAGE_DW = NPL * (PLANE_A + PLANE_B);
+    constexpr int OPER_DW = (PIPE ? 2 : 1) * STAGE_DW;
     constexpr int SMEM_DW = OPER_DW > 4 * 32 * SLD ? OPER_DW : 4 * 32 * SLD;       // >= the epilogue's staging area
     __shared__ __attribute__((aligned(16))) unsigned smem[SMEM_DW];
     unsigned* As = smem;
@@ -1162,11 +1176,13 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
             }
 
     // prologue: tiles 0..PF-1 in flight (a tile at or beyond kend arrives as zeros and is never multiplied)
+    if constexpr (!PIPE) {
 #pragma unroll
-    for (int j = 0; j < PF; ++j) {
-        if (j > 0) advance_A();
-        load_A(kbeg + j * BK, j);
-        load_B(kbeg + j * BK, j);
+        for (int j = 0; j < PF; ++j) {
+            if (j > 0) advance_A();
+            load_A(kbeg + j * BK, j);
+            load_B(kbeg + j * BK, j);
+        }
     }
 
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -1180,6 +1196,103 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
         }
     }
 
+    if constexpr (PIPE) {
+        // ---- engine 2, pipelined: LDS holds TWO k-tiles (stage t & 1 is multiplied while stage (t + 1) & 1 is filled), so a k-tile
+        // costs one barrier, and the conversion of tile t+1 (fp32 registers -> two fp16 planes: three mixed-precision FMAs per
+        // element) is cut into half-units of six VALU instructions that are issued one behind each MFMA of tile t -- they run in
+        // the shadow of the matrix pipe (32 cycles per v_mfma_f32_32x32x16_f16) instead of in a phase of their own between two
+        // barriers.  The global loads of tile t+2 go out when the registers of tile t+1 have been converted.
+        constexpr int UA = (AMODE == 0) ? NPA : 4, UB = (BMODE == 1) ? NPB : 4;      // conversion units (one LDS row segment each)
+        constexpr bool A4 = (AMODE == 0) || (NPA == 4), B4 = (BMODE == 1) || (NPB == 4);   // four values per unit (else two)
+        constexpr int HA = A4 ? 2 * UA : UA, HB = B4 ? 2 * UB : UB;                  // half-units: one pair of values each
+        constexpr int NH = HA + HB;
+        auto comp = [](const float4& v, int c) -> float { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
+        unsigned hu_h = 0, hu_l = 0;        // first pair of the unit in flight
+        // half-unit q of the registers in flight -> the stage at (sA, sB)
+        auto half_unit = [&](int q, unsigned* sA, unsigned* sB) {
+            const bool isA = q < HA;
+            const int r = isA ? q : q - HA;
+            const bool four = isA ? A4 : B4;
+            const int u = four ? (r >> 1) : r, h = four ? (r & 1) : 0;
+            const float sc = isA ? e2_sa : e2_sb;
+            const int plane = isA ? PLANE_A : PLANE_B;
+            unsigned* dst = isA ? sA + a_st[u] : sB + b_st[u];
+            float x0, x1;
+            const bool contig = isA ? (AMODE == 0) : (BMODE == 1);
+            if (contig) {       // unit u = register u: (x, y | z, w)
+                const float4& v = isA ? areg[0][isA ? u : 0] : breg[0][isA ? 0 : u];
+                x0 = h == 0 ? v.x : v.z;
+                x1 = h == 0 ? v.y : v.w;
+            } else {            // unit u = component u of the k-consecutive registers: (reg0, reg1 | reg2, reg3)
+                const float4* v = isA ? areg[0] : breg[0];
+                x0 = comp(v[2 * h], u);
+                x1 = comp(v[2 * h + 1], u);
+            }
+            unsigned hh, ll;
+            split2h(x0, x1, sc, hh, ll);
+            if (!four) {
+                dst[0] = hh;
+                dst[plane] = ll;
+            } else if (h == 0) {
+                hu_h = hh;
+                hu_l = ll;
+            } else {
+                *reinterpret_cast<uint2*>(dst) = make_uint2(hu_h, hh);
+                *reinterpret_cast<uint2*>(dst + plane) = make_uint2(hu_l, ll);
+            }
+        };
+        load_A(kbeg, 0);
+        load_B(kbeg, 0);
+#pragma unroll
+        for (int q = 0; q < NH; ++q) half_unit(q, As, Bs);
+        advance_A();
+        load_A(kbeg + BK, 0);
+        load_B(kbeg + BK, 0);
+        __syncthreads();
+        auto ktile = [&](const int t, auto more_c) {
+            constexpr bool MORE = decltype(more_c)::value;          // a tile t+1 exists: convert it while tile t is multiplied
+            const unsigned* cA = smem + (t & 1) * STAGE_DW;
+            const unsigned* cB = cA + NPL * PLANE_A;
+            unsigned* nA = smem + ((t & 1) ^ 1) * STAGE_DW;
+            unsigned* nB = nA + NPL * PLANE_A;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f16x8 av[2][TM], bv[2][TN];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        av[pl][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(cA + pl * PLANE_A + sa_off[s] + i * 512));
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj)
+                        bv[pl][jj] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(cB + pl * PLANE_B + sb_off[s] + jj * 512));
+                }
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < TN; ++jj) {
+                            if (term == 0) acc1[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[1][i], bv[0][jj], acc1[i][jj], 0, 0, 0);
+                            else if (term == 1) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][i], bv[0][jj], acc[i][jj], 0, 0, 0);
+                            else acc1[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][i], bv[1][jj], acc1[i][jj], 0, 0, 0);
+                            const int q = ((s * 3 + term) * TM + i) * TN + jj;      // this MFMA's slot
+                            if (MORE && q < NH) half_unit(q, nA, nB);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+            }
+            if (MORE) {
+#pragma unroll
+                for (int q = 6 * TM * TN; q < NH; ++q) half_unit(q, nA, nB);        // more half-units than MFMAs (64-wide tiles)
+                advance_A();
+                load_A(kbeg + (t + 2) * BK, 0);
+                load_B(kbeg + (t + 2) * BK, 0);
+            }
+            __syncthreads();
+        };
+        for (int t = 0; t + 1 < ntiles; ++t) ktile(t, std::true_type());
+        if (ntiles > 0) ktile(ntiles - 1, std::false_type());
+    } else
     for (int t = 0; t < ntiles; t += PF) {
 #pragma unroll
         for (int j = 0; j < PF; ++j) {

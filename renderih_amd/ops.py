@@ -103,9 +103,9 @@ ENGINE = int(_os.environ.get('RIH_GEMM_ENGINE', '1'))
 # `bound_of(t)` returns that bound as a one-element tensor: the one the producing kernel left on the tensor (`set_bound`), the
 # one cached from an earlier use, or a fresh rih_absmax pass.  A call site that has no bounds for both operands runs engine 1.
 class _BoundPool:
-    """Zeroed one-float slots carved out of chunks (one fill launch per 1024 slots; a chunk allocated while a stream captures
-    is re-zeroed by every replay of the graph)."""
-    CHUNK = 1024
+    """Zeroed bound blocks (_lib.BOUND_FLOATS floats each: rih_absmax in include/renderih_amd.h) carved out of chunks -- one
+    fill launch per 256 blocks; a chunk allocated while a stream captures is re-zeroed by every replay of the graph."""
+    CHUNK = 256
 
     def __init__(self):
         self.chunk = {}
@@ -114,10 +114,10 @@ class _BoundPool:
         key = (device.type, device.index)
         ent = self.chunk.get(key)
         if ent is None or ent[1] >= self.CHUNK:
-            ent = self.chunk[key] = [torch.zeros((self.CHUNK,), device=device, dtype=torch.float32), 0]
+            ent = self.chunk[key] = [torch.zeros((self.CHUNK * _lib.BOUND_FLOATS,), device=device, dtype=torch.float32), 0]
         i = ent[1]
         ent[1] = i + 1
-        return ent[0][i:i + 1]
+        return ent[0][i * _lib.BOUND_FLOATS:(i + 1) * _lib.BOUND_FLOATS]
 
     def reset(self):
         self.chunk.clear()
@@ -165,14 +165,43 @@ def inherit_bound(y, *xs):
     return set_bound(y, b)
 
 
+class LazyBound:
+    """bound_of(t) on first call (memoised): call sites hand these to gemm(), which asks for the value only when the launch
+    takes engine 2's kernels."""
+
+    def __init__(self, t):
+        self.t, self.value = t, None
+
+    def __call__(self):
+        if self.value is None:
+            self.value = bound_of(self.t)
+            self.t = None
+        return self.value
+
+
+def bound_weights(params):
+    """Bounds of many tensors (the convolution weights of a model) by ONE rih_absmax_multi launch; afterwards bound_of(p) finds
+    them cached.  Called at the top of a forward pass, behind bounds_reset()."""
+    ps = [p for p in params if p.is_contiguous()]
+    if not ps:
+        return
+    from ._lib import AbsmaxDesc
+    arr = (AbsmaxDesc * len(ps))()
+    for d, p in zip(arr, ps):
+        slot = bound_slot(p.device)
+        d.x, d.out, d.n = p.data_ptr(), slot.data_ptr(), p.numel()
+        set_bound(p, slot)
+    check(_L().rih_absmax_multi(arr, len(ps), _stream()), 'rih_absmax_multi')
+
+
 def cat_channels(parts):
     """Channel concatenation of NHWC maps (models/encoder.py:165-173)."""
     return inherit_bound(torch.cat(parts, dim=-1), *parts)
 
 
 def bound_of(t):
-    """One-element fp32 tensor >= max|t| (see above).  The cache entry dies with an in-place modification of t that torch
-    sees, and with the next bounds_reset()."""
+    """Bound block (fp32 tensor of _lib.BOUND_FLOATS floats whose maximum is >= max|t|, see above).  The cache entry dies with
+    an in-place modification of t that torch sees, and with the next bounds_reset()."""
     ent = getattr(t, '_rih_bound', None)
     if ent is not None and ent[1] == t._version and ent[2] == _BOUND_EPOCH:
         return ent[0]
@@ -276,11 +305,10 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
     drop = (p, seed): C = dropout(act(alpha A B + bias)) + R in the epilogue when the descriptor takes that path
     (rih_gemm_dropout_ok) -- returns True; otherwise act(alpha A B + bias) is computed WITHOUT R and False is returned: the caller
     finishes with rih_add_dropout(R, C, p, seed), which draws the same mask stream.
-    amax_a / amax_b (engine 2): one-element fp32 tensors (or raw device pointers) holding an upper bound of max|A| / max|B|
-    (rih_gemm_desc.amax_a); None = the operand is known to lie inside +-2^15."""
+    amax_a / amax_b (engine 2): bound blocks (bound_of; or raw device pointers, or thunks that return one -- called only when the
+    descriptor takes engine 2's kernels) holding an upper bound of max|A| / max|B| (rih_gemm_desc.amax_a); a call site that
+    passes none for either operand runs engine 1."""
     d = GemmDesc()
-    d.amax_a = amax_a if isinstance(amax_a, int) else _p(amax_a)
-    d.amax_b = amax_b if isinstance(amax_b, int) else _p(amax_b)
     if cstride is not None:
         d.cS, d.cOH, d.cOW, d.cH, d.cW = cstride
     d.ones_row = ones_row
@@ -312,6 +340,17 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
         d.tile, auto_sk = plan_gemm(M, N, K, nb1 * nb2 * splitk, d.engine)
     else:
         d.tile = tile
+    if d.engine == 2:
+        # bounds may be given as thunks (bound_of of a tensor nobody has measured yet costs a pass): resolved only when the
+        # descriptor really takes engine 2's kernels (rih_gemm_engine), else the launch runs engine 1 and needs none
+        if int(_L().rih_gemm_engine(C.byref(d))) == 2:
+            amax_a = amax_a() if callable(amax_a) else amax_a
+            amax_b = amax_b() if callable(amax_b) else amax_b
+            d.amax_a = amax_a if isinstance(amax_a, int) else _p(amax_a)
+            d.amax_b = amax_b if isinstance(amax_b, int) else _p(amax_b)
+        else:
+            d.engine = 1
+            amax_a = amax_b = None
     fused_drop = False
     if drop is not None and drop[0] > 0:
         assert collect is None and stats is None and splitk == 1 and cstride is None
@@ -773,7 +812,7 @@ class Conv2dFn(torch.autograd.Function):
         M, K = N * Ho * Wo, KH * KW * Cx
         geom = (H, W_, Cx, Ho, Wo, KH, KW, stride, 1, pad, pad)
         # engine 2: operand bounds (kept for the backward: x is the weight gradient's A operand, w the data gradient's B)
-        bx, bw = (bound_of(x), bound_of(w)) if ENGINE == 2 else (None, None)
+        bx, bw = (LazyBound(x), LazyBound(w)) if ENGINE == 2 else (None, None)
         if _presplit_ok(Cout, Cx, KH * KW):
             wp, Kp = _presplit_weight(w, Cx, False)
             if PRESPLIT_ACT:
@@ -810,7 +849,7 @@ class Conv2dFn(torch.autograd.Function):
         M = N * Ho * Wo
         lib = _L()
         bx, bw = ctx.bounds
-        bdy = bound_of(dy) if bx is not None else None      # (also bounds the ReLU-gated gradient below)
+        bdy = LazyBound(dy) if bx is not None else None     # (also bounds the ReLU-gated gradient below)
         if relu:
             dyr = torch.empty_like(dy)
             check(lib.rih_relu_bwd(dy.data_ptr(), y.data_ptr(), dyr.data_ptr(), dy.numel(), _stream()), 'rih_relu_bwd')

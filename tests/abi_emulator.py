@@ -225,6 +225,11 @@ class EmulatedLib:
             fast = fast and d.N % 4 == 0
         return 2 if (d.engine == 2 and fast and d.a_mode <= 1 and d.b_mode <= 1) else 1
 
+    def rih_absmax_multi(self, descs, n, stream):
+        for i in range(n):
+            self.rih_absmax(descs[i].x, descs[i].n, descs[i].out, stream)
+        return 0
+
     def rih_absmax(self, x, n, out, stream):
         if n > 0:
             o = _f(out, 1)

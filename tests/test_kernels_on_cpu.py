@@ -334,7 +334,11 @@ def test_gemm_descriptor_fuzz_against_emulator():
                 A *= np.float32(rs.choice([1e-6, 1.0, 3e4, 1e7]))
                 B *= np.float32(rs.choice([1e-9, 1e-3, 1.0, 2e5]))
                 loose = np.float32(1.0 if mode == 0 else 37.0)
-                amax = (np.array([np.abs(A).max() * loose], np.float32), np.array([np.abs(B).max() * loose], np.float32))
+                amax = (np.zeros(2048, np.float32), np.zeros(2048, np.float32))      # bound blocks: 64 partial maxima, stride 32
+                amax[0][32 * int(rs.randint(0, 64))] = np.abs(A).max() * loose
+                amax[1][32 * int(rs.randint(0, 64))] = np.abs(B).max() * loose
+                j = 32 * int(rs.randint(0, 64))                                       # a second, smaller partial maximum
+                amax[0][j] = max(amax[0][j], amax[0].max() * np.float32(rs.rand()))
             bias *= np.float32(np.abs(A).max() * np.abs(B).max())
             R *= np.float32(np.abs(A).max() * np.abs(B).max())
         outs = []

@@ -20,7 +20,7 @@ ENG = int(os.environ.get('RIH_PMC_ENGINE', '1'))        # 2: the three-product f
 
 
 def amax(t):
-    a = torch.zeros(1, device=dev)
+    a = torch.zeros(2048, device=dev)      # a bound block (include/renderih_amd.h: rih_absmax)
     ops.check(ops._L().rih_absmax(t.data_ptr(), t.numel(), a.data_ptr(), ops._stream()), 'rih_absmax')
     return a
 
