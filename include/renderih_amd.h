@@ -84,8 +84,10 @@ typedef struct rih_gemm_desc {
                                of two (from amax_a / amax_b below) and split into two fp16 terms hi + 2^-11 lo (22-23
                                significand bits), hi*hi and hi*lo + lo*hi accumulate in two fp32 accumulators
                                (v_mfma_f32_32x32x16_f16), combined and un-scaled in the epilogue; 2.5 PF / 3 = 833 TF
-                               peak.  Exists on the fast path of tiles 0,1,2 (a_mode / b_mode 0 or 1); a descriptor
-                               that asks for it elsewhere runs engine 1 (rih_gemm_engine tells which). */
+                               peak.  Exists on the fast path of tiles 0,1,2 (a_mode / b_mode 0 or 1, and a_mode 0 with
+                               b_mode 2 = B pre-split into two fp16 planes by rih_presplit_* with amax_e2 = amax_b); a
+                               descriptor that asks for it elsewhere runs engine 1 (rih_gemm_engine tells which; with
+                               b_mode 2 that is RIH_EINVAL: no other kernel reads two-plane operands). */
     /* Strided output rows (cS > 1; a_mode 0, splitk 1, no residual): GEMM row m = (img, i, j) over (Ho, Wo) is stored
      * to pixel (img, i*cS + cOH, j*cS + cOW) of a [*, cH, cW, ldc] tensor.  Used to compute the data gradient of a
      * stride-s convolution as s*s dense sub-convolutions, one per output parity class (each with the kernel taps
@@ -254,14 +256,26 @@ int rih_bn_stats_from_tiles(const float* part, int T, int C, int rows_per_tile, 
 /* part [T][C][2] (tiles of rows_per_tile rows) -> mean[C], biased variance var[C] */
 int rih_bn_stats_merge(const float* part, int T, int C, int rows_per_tile, float* mean, float* var, void* stream);
 
-/* Pre-split B operands for rih_gemm b_mode 2 (weights are constant within a training step, so their bf16 hi/mid/lo
- * planes are produced once instead of inside every GEMM): dst = 3 * N * Kpad bf16, Kpad % 32 == 0.
- * rih_presplit_matrix: from a plain b_mode 0 / 1 matrix.  rih_presplit_conv_weight: from an OIHW conv weight, as the
- * forward operand (for_dgrad 0: N = Cout, K = KH*KW*CinPad) or as the (flipped) data-gradient operand of the tap subset
- * kh0 + step*t, kw0 + step*t' (for_dgrad 1: N = CinPad, K = Th*Tw*Cout; the full gradient is 0, 0, 1, KH, KW). */
-int rih_presplit_matrix(const float* B, int b_mode, int K, int N, int ldb, void* dst, int Kpad, void* stream);
+/* Pre-split B operands for rih_gemm b_mode 2 (weights are constant within a training step, so their 16-bit planes are produced
+ * once instead of inside every GEMM's loader).  amax_e2 == NULL: three bf16 planes hi / mid / lo for engine 1,
+ * dst = 3 * N * Kpad bf16.  amax_e2 = the operand's bound block (rih_absmax): TWO fp16 planes for engine 2,
+ * dst = 2 * N * Kpad fp16 -- hi = fp16(s x), lo = fp16((s x - hi) 2^11) with the power-of-two scale s engine 2 derives from the
+ * SAME bound block (the descriptor of the GEMM that reads the planes passes it as amax_b, so that it undoes the same scale).
+ * Kpad % 32 == 0.  rih_presplit_matrix: from a plain b_mode 0 / 1 matrix.  rih_presplit_conv_weight: from an OIHW conv weight,
+ * as the forward operand (for_dgrad 0: N = Cout, K = KH*KW*CinPad) or as the (flipped) data-gradient operand of the tap subset
+ * kh0 + step*t, kw0 + step*t' (for_dgrad 1: N = CinPad, K = Th*Tw*Cout; the full gradient is 0, 0, 1, KH, KW).
+ * rih_presplit_multi: any number of conv-weight operands in ceil(n / 40) launches (`descs` is HOST memory, read before the call
+ * returns): every weight operand of a training step at its start. */
+int rih_presplit_matrix(const float* B, int b_mode, int K, int N, int ldb, void* dst, int Kpad, const float* amax_e2, void* stream);
 int rih_presplit_conv_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int CinPad, int for_dgrad,
-                             int kh0, int kw0, int step, int Th, int Tw, int Kpad, void* stream);
+                             int kh0, int kw0, int step, int Th, int Tw, int Kpad, const float* amax_e2, void* stream);
+typedef struct rih_presplit_desc {
+    const float* w;         /* OIHW parameter */
+    void* dst;
+    const float* amax_e2;   /* bound block of w (engine 2 planes) or NULL (engine 1 planes) */
+    int32_t Cout, Cin, KH, KW, CinPad, for_dgrad, kh0, kw0, step, Th, Tw, Kpad;
+} rih_presplit_desc;
+int rih_presplit_multi(const rih_presplit_desc* descs, int n, void* stream);
 
 /* Finish a forward split-K GEMM: C[m*ldc+n] = act(alpha * sum_s P[s][m][n] + bias[n] + R[m*ldr+n]). */
 int rih_splitk_finish(const float* P, int S, int M, int N, float* C, int ldc, const float* bias, const float* R,
@@ -509,11 +523,11 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
 /* library / device info.  RIH_ABI_VERSION is bumped whenever a struct layout or a signature of this header changes;
  * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of EVERY by-pointer struct, in
  * this order: gemm desc, mano model, mesh topo, hconv desc, gemm p3 desc, reduce desc, pack desc, ln final desc, adam entry,
- * chain desc, absmax desc (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it mis-laid-out structs. */
+ * chain desc, absmax desc, presplit desc (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it mis-laid-out structs. */
 #define RIH_ABI_VERSION 13
-#define RIH_ABI_NSIZES 11
+#define RIH_ABI_NSIZES 12
 int rih_version(void);
-int rih_abi_sizes(int32_t* out11);
+int rih_abi_sizes(int32_t* out12);
 const char* rih_arch(void);
 
 /* ------------------------------------------------------------------------------------------------

@@ -46,6 +46,11 @@ class ReduceDesc(C.Structure):
                [(n, C.c_int32) for n in ('S', 'Mp', 'M', 'N', 'Cin', 'taps', 'CinValid', 'accumulate')]
 
 
+class PresplitDesc(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('dst', C.c_void_p), ('amax_e2', C.c_void_p)] + \
+               [(n, C.c_int32) for n in ('Cout', 'Cin', 'KH', 'KW', 'CinPad', 'for_dgrad', 'kh0', 'kw0', 'step', 'Th', 'Tw', 'Kpad')]
+
+
 class AbsmaxDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('out', C.c_void_p), ('n', C.c_int64)]
 
@@ -117,8 +122,9 @@ SIGNATURES = {
                                          c_i, c_f, c_i, C.c_void_p]),
     'rih_attention_fwd_fused': (c_i, [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_u64, c_f, c_f, c_f, c_i,
                                       c_f, c_i, C.c_void_p]),
-    'rih_presplit_matrix': (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, C.c_void_p]),
-    'rih_presplit_conv_weight': (c_i, [c_f, c_f] + [c_i] * 12 + [C.c_void_p]),
+    'rih_presplit_matrix': (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_f, C.c_void_p]),
+    'rih_presplit_conv_weight': (c_i, [c_f, c_f] + [c_i] * 12 + [c_f, C.c_void_p]),
+    'rih_presplit_multi': (c_i, [C.POINTER(PresplitDesc), c_i, C.c_void_p]),
     'rih_hardswish_fwd': (c_i, [c_f, c_f, c_l, C.c_void_p]),
     'rih_hardswish_bwd': (c_i, [c_f, c_f, c_f, c_l, C.c_void_p]),
     'rih_tanh_scale_fwd': (c_i, [c_f, c_f, c_l, c_fl, C.c_void_p]),
@@ -254,7 +260,8 @@ def load():
     # every by-pointer struct of the header, in rih_abi_sizes' order; the last one (rih_adam_entry: four pointers + int64) is
     # built by hand as int64 rows in renderih_amd/optim.py
     mine = [C.sizeof(GemmDesc), C.sizeof(ManoModel), C.sizeof(MeshTopo), C.sizeof(HConvDesc), C.sizeof(GemmP3Desc),
-            C.sizeof(ReduceDesc), C.sizeof(PackDesc), C.sizeof(LnFinalDesc), 5 * 8, C.sizeof(ChainDesc), C.sizeof(AbsmaxDesc)]
+            C.sizeof(ReduceDesc), C.sizeof(PackDesc), C.sizeof(LnFinalDesc), 5 * 8, C.sizeof(ChainDesc), C.sizeof(AbsmaxDesc),
+            C.sizeof(PresplitDesc)]
     if lib.rih_version() != ABI_VERSION:
         raise RuntimeError('librenderih_amd.so does not match this binding (ABI %d vs %d): rebuild with '
                            '`python -m renderih_amd._build`' % (lib.rih_version(), ABI_VERSION))

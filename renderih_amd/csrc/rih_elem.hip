@@ -2002,6 +2002,7 @@ extern "C" int rih_abi_sizes(int32_t* out9) {      // RIH_ABI_NSIZES values
     out9[8] = (int32_t)sizeof(rih_adam_entry);
     out9[9] = (int32_t)sizeof(rih_chain_desc);
     out9[10] = (int32_t)sizeof(rih_absmax_desc);
+    out9[11] = (int32_t)sizeof(rih_presplit_desc);
     return 0;
 }
 extern "C" const char* rih_arch(void) { return "gfx950"; }

@@ -793,7 +793,7 @@ __device__ __forceinline__ uint4 bloadu4(__amdgpu_buffer_rsrc_t r, unsigned off)
 template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false, int ENG = 1>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk_x, const int blk_z, const int grid_x,
                                                 const int grid_z) {
-    static_assert(ENG == 1 || (ENG == 2 && !APRE && BMODE != 2), "engine 2 converts both operands itself");
+    static_assert(ENG == 1 || (ENG == 2 && !APRE), "engine 2: B may arrive as two pre-split fp16 planes (BMODE 2), A never");
     constexpr int NPL = (ENG == 2) ? 2 : 3;         // 16-bit planes per operand
     // global->register prefetch depth: k-tiles in flight.  The 64x64 tile (decoder-sized problems: a handful of
     // k-tiles, 12 MFMAs each) is bound by the load round trip per k-tile, so it keeps three tiles in flight.
@@ -1077,7 +1077,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
         if (BMODE == 2) {
             const unsigned ku = (ktile < kend) ? (unsigned)ktile * 2u : OOB;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
                 for (int i = 0; i < BPASS; ++i)
                     bpre[st][pl][i] = bloadu4(rB, (bp_off[i] == OOB || ku == OOB) ? OOB : bp_off[i] + (unsigned)pl * bp_plane + ku);
@@ -1154,7 +1154,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
     auto store_B = [&](int st) {
         if (BMODE == 2) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
                 for (int i = 0; i < BPASS; ++i)
                     if ((tid >> 2) + 64 * i < BN) *reinterpret_cast<uint4*>(Bs + pl * PLANE_B + bp_st[i]) = bpre[st][pl][i];
@@ -1204,7 +1204,9 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
         // barriers.  The global loads of tile t+2 go out when the registers of tile t+1 have been converted.
         constexpr int UA = (AMODE == 0) ? NPA : 4, UB = (BMODE == 1) ? NPB : 4;      // conversion units (one LDS row segment each)
         constexpr bool A4 = (AMODE == 0) || (NPA == 4), B4 = (BMODE == 1) || (NPB == 4);   // four values per unit (else two)
-        constexpr int HA = A4 ? 2 * UA : UA, HB = B4 ? 2 * UB : UB;                  // half-units: one pair of values each
+        // half-units: one pair of values each; a pre-split B (BMODE 2) has nothing to convert -- one 16-byte LDS store per plane
+        // and pass instead
+        constexpr int HA = A4 ? 2 * UA : UA, HB = (BMODE == 2) ? NPL * BPASS : (B4 ? 2 * UB : UB);
         constexpr int NH = HA + HB;
         auto comp = [](const float4& v, int c) -> float { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
         unsigned hu_h = 0, hu_l = 0;        // first pair of the unit in flight
@@ -1212,6 +1214,11 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
         auto half_unit = [&](int q, unsigned* sA, unsigned* sB) {
             const bool isA = q < HA;
             const int r = isA ? q : q - HA;
+            if (BMODE == 2 && !isA) {
+                const int pl = r / BPASS, i = r % BPASS;
+                if ((tid >> 2) + 64 * i < BN) *reinterpret_cast<uint4*>(sB + pl * PLANE_B + bp_st[i]) = bpre[0][pl][i];
+                return;
+            }
             const bool four = isA ? A4 : B4;
             const int u = four ? (r >> 1) : r, h = four ? (r & 1) : 0;
             const float sc = isA ? e2_sa : e2_sb;
@@ -1416,7 +1423,12 @@ int launch_split_e2(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 
     dim3 block(256);
 #define RIH_L2(AM_, BM_, PL_, ST_, DR_) \
     hipLaunchKernelGGL((gemm_split_kernel<BM, BN, AM_, BM_, PL_, false, ST_, DR_, 2>), grid, block, 0, s, a)
-    if (a_mode > 1 || b_mode > 1) return RIH_EINVAL;
+    if (a_mode > 1 || b_mode > 2 || (b_mode == 2 && a_mode != 0)) return RIH_EINVAL;
+    if (b_mode == 2) {          // B pre-split into two fp16 planes (weights, once per step)
+        if (a.drop_thr != 0u) return RIH_EINVAL;
+        if (a.stats != nullptr) { if (plain) RIH_L2(0, 2, true, true, false); else RIH_L2(0, 2, false, true, false); }
+        else { if (plain) RIH_L2(0, 2, true, false, false); else RIH_L2(0, 2, false, false, false); }
+    } else
     if (a.drop_thr != 0u) {
         if (b_mode == 0) RIH_L2(0, 0, true, false, true); else RIH_L2(0, 1, true, false, true);
     } else if (a.stats != nullptr) {
@@ -2005,6 +2017,7 @@ struct PresplitArgs {
     unsigned* dst;
     int N, K, Kpad, mode, ld;
     int Cout, Cin, KH, KW, CinPad, kh0, kw0, step, Th, Tw;
+    const float* amax;      // engine 2: the operand's bound block -> TWO fp16 planes [hi | lo] of the scaled values; NULL: three bf16 planes
 };
 __device__ __forceinline__ float presplit_fetch(const PresplitArgs& a, int n, int k) {
     if (k >= a.K) return 0.f;
@@ -2019,17 +2032,45 @@ __device__ __forceinline__ float presplit_fetch(const PresplitArgs& a, int n, in
     const int kh = a.kh0 + a.step * (a.Th - 1 - th), kw = a.kw0 + a.step * (a.Tw - 1 - tw);
     return n < a.Cin ? a.src[(((long long)co * a.Cin + n) * a.KH + kh) * a.KW + kw] : 0.f;
 }
-__global__ void presplit_kernel(const PresplitArgs a) {
+__device__ __forceinline__ void presplit_span(const PresplitArgs& a, long long first, long long stride) {
     const int half = a.Kpad / 2;
     const long long plane = (long long)a.N * half, total = plane;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    // engine 2: the same power-of-two scale the GEMM derives from the same bound block (e2_scale: every lane of the wave takes part)
+    const float sc = a.amax != nullptr ? e2_scale(a.amax, false) : 1.f;
+    for (long long i = first; i < total; i += stride) {
         const int n = (int)(i / half), j = (int)(i - (long long)n * half);
-        unsigned h, m, l;
-        split2(presplit_fetch(a, n, 2 * j), presplit_fetch(a, n, 2 * j + 1), h, m, l);
-        a.dst[i] = h;
-        a.dst[i + plane] = m;
-        a.dst[i + 2 * plane] = l;
+        const float x0 = presplit_fetch(a, n, 2 * j), x1 = presplit_fetch(a, n, 2 * j + 1);
+        if (a.amax != nullptr) {
+            unsigned h, l;
+            split2h(x0, x1, sc, h, l);
+            a.dst[i] = h;
+            a.dst[i + plane] = l;
+        } else {
+            unsigned h, m, l;
+            split2(x0, x1, h, m, l);
+            a.dst[i] = h;
+            a.dst[i + plane] = m;
+            a.dst[i + 2 * plane] = l;
+        }
     }
+}
+__global__ void presplit_kernel(const PresplitArgs a) {
+    presplit_span(a, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
+}
+// every pre-split weight operand of a step in one launch (rih_presplit_multi; descriptors by value)
+constexpr int PRESPLIT_PACK = 40;
+struct PresplitPack {
+    PresplitArgs d[PRESPLIT_PACK];
+    int first[PRESPLIT_PACK + 1];
+    int n;
+};
+static_assert(sizeof(PresplitPack) <= 4096, "kernel argument limit");
+__global__ __launch_bounds__(256) void presplit_multi_kernel(const PresplitPack pk) {
+    const int b = (int)blockIdx.x;
+    int k = 0;
+    while (k + 1 < pk.n && b >= pk.first[k + 1]) ++k;
+    const int nb = pk.first[k + 1] - pk.first[k];
+    presplit_span(pk.d[k], (long long)(b - pk.first[k]) * 256 + threadIdx.x, (long long)nb * 256);
 }
 
 }  // namespace
@@ -2080,18 +2121,19 @@ static int launch_presplit(const PresplitArgs& a, void* stream) {
     hipLaunchKernelGGL(presplit_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
-extern "C" int rih_presplit_matrix(const float* B, int b_mode, int K, int N, int ldb, void* dst, int Kpad, void* stream) {
+extern "C" int rih_presplit_matrix(const float* B, int b_mode, int K, int N, int ldb, void* dst, int Kpad, const float* amax_e2,
+                                   void* stream) {
     if (!B || !dst || (b_mode != 0 && b_mode != 1) || K < 1 || N < 1 || Kpad < K || Kpad % 32 != 0) return RIH_EINVAL;
     if (ldb < (b_mode == 0 ? N : K)) return RIH_EINVAL;
     PresplitArgs a = {};
-    a.src = B; a.dst = (unsigned*)dst; a.N = N; a.K = K; a.Kpad = Kpad; a.mode = b_mode; a.ld = ldb;
+    a.src = B; a.dst = (unsigned*)dst; a.N = N; a.K = K; a.Kpad = Kpad; a.mode = b_mode; a.ld = ldb; a.amax = amax_e2;
     return launch_presplit(a, stream);
 }
-extern "C" int rih_presplit_conv_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int CinPad,
-                                        int for_dgrad, int kh0, int kw0, int step, int Th, int Tw, int Kpad, void* stream) {
+static int presplit_conv_args(PresplitArgs& a, const float* w, void* dst, int Cout, int Cin, int KH, int KW, int CinPad,
+                              int for_dgrad, int kh0, int kw0, int step, int Th, int Tw, int Kpad, const float* amax_e2) {
     if (!w || !dst || Cout < 1 || Cin < 1 || KH < 1 || KW < 1 || CinPad < Cin || Kpad % 32 != 0) return RIH_EINVAL;
-    PresplitArgs a = {};
-    a.src = w; a.dst = (unsigned*)dst; a.Kpad = Kpad;
+    a = PresplitArgs{};
+    a.src = w; a.dst = (unsigned*)dst; a.Kpad = Kpad; a.amax = amax_e2;
     a.Cout = Cout; a.Cin = Cin; a.KH = KH; a.KW = KW; a.CinPad = CinPad;
     if (!for_dgrad) {
         a.mode = 2; a.N = Cout; a.K = KH * KW * CinPad;
@@ -2102,7 +2144,36 @@ extern "C" int rih_presplit_conv_weight(const float* w, void* dst, int Cout, int
         a.kh0 = kh0; a.kw0 = kw0; a.step = step; a.Th = Th; a.Tw = Tw;
     }
     if (Kpad < a.K) return RIH_EINVAL;
+    return 0;
+}
+extern "C" int rih_presplit_conv_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int CinPad,
+                                        int for_dgrad, int kh0, int kw0, int step, int Th, int Tw, int Kpad, const float* amax_e2,
+                                        void* stream) {
+    PresplitArgs a;
+    const int rc = presplit_conv_args(a, w, dst, Cout, Cin, KH, KW, CinPad, for_dgrad, kh0, kw0, step, Th, Tw, Kpad, amax_e2);
+    if (rc != 0) return rc;
     return launch_presplit(a, stream);
+}
+extern "C" int rih_presplit_multi(const rih_presplit_desc* descs, int n, void* stream) {
+    if (n < 0 || (n > 0 && !descs)) return RIH_EINVAL;
+    for (int base = 0; base < n; base += PRESPLIT_PACK) {
+        PresplitPack pk;
+        pk.n = (n - base < PRESPLIT_PACK) ? n - base : PRESPLIT_PACK;
+        int total = 0;
+        for (int i = 0; i < pk.n; ++i) {
+            const rih_presplit_desc& d = descs[base + i];
+            const int rc = presplit_conv_args(pk.d[i], d.w, d.dst, d.Cout, d.Cin, d.KH, d.KW, d.CinPad, d.for_dgrad, d.kh0, d.kw0,
+                                              d.step, d.Th, d.Tw, d.Kpad, d.amax_e2);
+            if (rc != 0) return rc;
+            const long long el = (long long)pk.d[i].N * (d.Kpad / 2);
+            long long nb = (el + 2047) / 2048;          // 8 dword pairs per thread
+            pk.first[i] = total;
+            total += (int)(nb > 512 ? 512 : nb);
+        }
+        pk.first[pk.n] = total;
+        hipLaunchKernelGGL(presplit_multi_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, pk);
+    }
+    return (int)hipGetLastError();
 }
 
 struct PreparedGemm {       // what gemm_impl would launch on the split engine's fast path (tiles 0..2), for rih_gemm_multi
@@ -2129,9 +2200,11 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
         if (d->a_mode == 2 && (d->b_mode != 2 || d->lda % 8 != 0 || d->sA1 != 0 || d->sA2 != 0 || d->nb1 * d->nb2 != 1 ||
                                d->K % 32 != 0 || d->Cin % 32 != 0))
             return RIH_EINVAL;      // pre-split A: im2col / plain rows of bf16 planes, together with pre-split B only
-        if (d->b_mode == 2 && (d->a_mode == 1 || d->engine != 1 || d->ldb % 32 != 0 || d->ldb < d->K || d->sB1 != 0 ||
+        if (d->b_mode == 2 && (d->a_mode == 1 || d->engine < 1 || d->ldb % 32 != 0 || d->ldb < d->K || d->sB1 != 0 ||
                                d->sB2 != 0 || d->tile > 2 || d->upS != 1))
-            return RIH_EINVAL;      // pre-split B: forward-type GEMMs on the split engine's fast path only
+            return RIH_EINVAL;      // pre-split B: forward-type GEMMs on the split engines' fast path only
+        if (d->b_mode == 2 && d->engine == 2 && (d->a_mode != 0 || d->drop_p != 0.f))
+            return RIH_EINVAL;      // engine 2: two fp16 planes scaled by amax_b's bound (rih_presplit_* with amax_e2), plain A
         if (d->H > 16000 || d->W > 16000 || d->Ho > 16000 || d->Wo > 16000 || d->strideA > 64 || d->padH > 64 ||
             d->padW > 64 || d->KH > 64 || d->KW > 64)
             return RIH_EINVAL;
@@ -2192,7 +2265,7 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
     if (d->engine < 0 || d->engine > 2) return RIH_EINVAL;
     // engine 2 exists on the split engines' fast path only (tiles 0..2, operands converted by the kernel): anything else that
     // asks for it runs engine 1 -- same fp32-grade result, the six-product arithmetic (rih_gemm_engine tells in advance)
-    const bool e2 = d->engine == 2 && d->tile <= 2 && d->a_mode <= 1 && d->b_mode <= 1;
+    const bool e2 = d->engine == 2 && d->tile <= 2 && d->a_mode <= 1 && (d->b_mode <= 1 || (d->b_mode == 2 && d->a_mode == 0));
     const int engine = d->engine == 2 ? 1 : d->engine;
     if (engine_out != nullptr) *engine_out = engine;
     if (engine == 1 && d->tile != 3 && a16 && b16 && d->upS == 1 && d->K % 4 == 0) {
@@ -2208,7 +2281,7 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
                                   : plain ? ((rowsA - 1) * d->lda + colsA) * 4ll
                                           : imgs * d->H * d->W * (long long)d->lda * 4ll;
         const long long rowsB = (d->b_mode == 0) ? (long long)d->K : (long long)d->N;
-        const long long b_bytes = (d->b_mode == 2) ? 3ll * d->N * d->ldb * 2ll
+        const long long b_bytes = (d->b_mode == 2) ? (e2 ? 2ll : 3ll) * d->N * d->ldb * 2ll
                                                    : ((rowsB - 1) * d->ldb + ((d->b_mode == 0) ? d->N : d->K)) * 4ll;
         bool ok = a_bytes < (1ll << 31) && b_bytes < (1ll << 31) && d->K >= 1;
         if (d->a_mode != 1 && !plain) ok = ok && (d->Cin % 32 == 0) && (d->KH * d->KW <= 32);
@@ -2225,7 +2298,8 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
             a.b_bytes = (unsigned)b_bytes;
             return launch_split256(a, d->a_mode, d->b_mode, plain, grid, s);
         }
-        if (d->stats != nullptr && !(ok && d->tile <= 2 && d->a_mode == 0 && d->b_mode <= 1 && d->splitk == 1 && gz == 1 &&
+        const bool b_stats_ok = d->b_mode <= 1 || (e2 && d->b_mode == 2);      // (engine 1's pre-split B path has no statistics variant)
+        if (d->stats != nullptr && !(ok && d->tile <= 2 && d->a_mode == 0 && b_stats_ok && d->splitk == 1 && gz == 1 &&
                                      d->cS <= 1))
             return RIH_EINVAL;      // the statistics epilogue exists on this path only (rih_gemm_stats_rows tells in advance)
         // the dropout epilogue exists for plain row-major GEMMs on this path only (rih_gemm_dropout_ok tells in advance)
@@ -2233,10 +2307,11 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
                                   d->cS <= 1 && d->stats == nullptr && !(d->relu && d->R != nullptr) && prep == nullptr))
             return RIH_EINVAL;
         if (stats_rows != nullptr) {
-            *stats_rows = (ok && d->tile <= 2 && d->a_mode == 0 && d->b_mode <= 1 && d->splitk == 1 && gz == 1 && d->cS <= 1)
+            *stats_rows = (ok && d->tile <= 2 && d->a_mode == 0 && b_stats_ok && d->splitk == 1 && gz == 1 && d->cS <= 1)
                               ? bm / 2 : 0;
             return 0;
         }
+        if (d->b_mode == 2 && d->engine == 2 && !(ok && e2)) return RIH_EINVAL;     // (no kernel reads two fp16 planes elsewhere)
         if (ok) {
             a.a_bytes = (unsigned)a_bytes;
             a.b_bytes = (unsigned)b_bytes;

@@ -44,9 +44,7 @@ class HandNET_GCN(nn.Module):
         return self
 
     def forward(self, img):
-        if ops.ENGINE == 2:
-            ops.bounds_reset()          # operand bounds of the three-product GEMM engine are per forward pass (ops.bound_of)
-            ops.bound_weights(p for p in self.parameters() if p.dim() == 4)     # every convolution weight, one launch
+        ops.begin_forward(self)         # operand bounds of the three-product GEMM engine are per forward pass
         if self._half is not None and not self.training and not torch.is_grad_enabled():
             hms, mask, dp, global_feature, fmaps = self._half(img)
         else:

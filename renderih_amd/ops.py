@@ -92,11 +92,14 @@ def plan_gemm(M, N, K, batch=1, engine=None):
 
 _TILE_MN = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (256, 128)}
 
-# MFMA engine of rih_gemm (include/renderih_amd.h): 1 = fp32 emulated on the bf16 pipe (three-term split, six
-# products, fp32 accumulate -- fp32-grade accuracy at up to 417 TF), 0 = native f32 MFMA (157 TF).  Tile 3 (N <= 32)
-# always runs engine 0.
+# MFMA engine of rih_gemm (include/renderih_amd.h): 2 (default since round 4) = fp32 on THREE fp16 MFMA products (scaled two-term
+# split, 833 TF ceiling) wherever a call site has operand bounds (the convolutions: bounds from the BatchNorm kernels), engine 1
+# elsewhere; 1 = fp32 emulated on the bf16 pipe (three-term split, six products, fp32 accumulate -- fp32-grade accuracy at up to
+# 417 TF); 0 = native f32 MFMA (157 TF).  Tile 3 (N <= 32) always runs engine 0.  Measured same-box (profiles/r04/ab/c3_*):
+# engine 1 1807 images/s, engine 2 1933-1946 (+7 %); its error against fp64 is half of engine 1's and at or below rocBLAS fp32
+# on every bench shape (profiles/r04/e2_bench_c2_production_config.log).
 import os as _os
-ENGINE = int(_os.environ.get('RIH_GEMM_ENGINE', '1'))
+ENGINE = int(_os.environ.get('RIH_GEMM_ENGINE', '2'))
 
 # Engine 2 (RIH_GEMM_ENGINE=2; rih_gemm_desc.engine 2): fp32 on THREE fp16 MFMA products.  Each operand needs a device-resident
 # upper bound of its largest magnitude (rih_gemm_desc.amax_a / amax_b) from which the kernel derives its power-of-two scale.
@@ -165,6 +168,31 @@ def inherit_bound(y, *xs):
     return set_bound(y, b)
 
 
+_FWD_PREPARED = False
+
+
+def begin_step(model):
+    """Top of a training step (TrainStep._forward_loss, before the weight operands are packed): new bound epoch, the bounds of
+    every convolution weight in one launch.  The forward pass that follows finds them (begin_forward skips its own reset)."""
+    global _FWD_PREPARED
+    if ENGINE == 2:
+        bounds_reset()
+        bound_weights(p for p in model.parameters() if p.dim() == 4)
+        _FWD_PREPARED = True
+
+
+def begin_forward(model):
+    """Top of a model's forward pass: operand bounds are per forward pass (see bounds_reset)."""
+    global _FWD_PREPARED
+    if ENGINE != 2:
+        return
+    if _FWD_PREPARED:
+        _FWD_PREPARED = False
+        return
+    bounds_reset()
+    bound_weights(p for p in model.parameters() if p.dim() == 4)
+
+
 class LazyBound:
     """bound_of(t) on first call (memoised): call sites hand these to gemm(), which asks for the value only when the launch
     takes engine 2's kernels."""
@@ -231,34 +259,58 @@ PAIR_HANDS = os.environ.get('RIH_PAIR_HANDS', '1') != '0'
 PRESPLIT = os.environ.get('RIH_PRESPLIT', '0') in ('1', '2')
 # RIH_PRESPLIT=2 additionally pre-splits the ACTIVATION operand of those GEMMs with a standalone pass (rih_gemm a_mode 2):
 # the experiment that tells whether producers (BatchNorm apply / backward) should emit bf16 planes themselves.
-PRESPLIT_ACT = os.environ.get('RIH_PRESPLIT', '0') == '2'
+PRESPLIT_ACT = os.environ.get('RIH_PRESPLIT', '0') == '2' and ENGINE == 1         # (an engine-1 experiment)
+
+
+# Engine 2: the two fp16 planes of every convolution WEIGHT operand (forward and data-gradient layouts) are produced once per
+# step -- rih_presplit_multi, one launch, through ops._PACK under TrainStep -- instead of inside every GEMM's loader: a weight
+# operand then costs the loader no conversion instructions at all (half of the conversion work on square tiles).  RIH_E2_PRESPLIT=0:
+# the loader converts B like A.
+E2_PRESPLIT = os.environ.get('RIH_E2_PRESPLIT', '1') == '1'
 
 
 def _presplit_weight(w, Cx, for_dgrad, sub=None):
     """(planes, Kpad) of an OIHW weight as forward operand (N = Cout) or as data-gradient operand of the tap subset
-    `sub` = (kh0, kw0, step, Th, Tw) (N = Cx)."""
+    `sub` = (kh0, kw0, step, Th, Tw) (N = Cx): three bf16 planes (engine 1, RIH_PRESPLIT) or two scaled fp16 planes (engine 2;
+    scale from bound_of(w), which the GEMM must be given as amax_b).  Through ops._PACK when one is installed."""
     Cout, Cin, KH, KW = w.shape
     kh0, kw0, step, Th, Tw = sub if sub is not None else (0, 0, 1, KH, KW)
     K = KH * KW * Cx if not for_dgrad else Th * Tw * Cout
     Nn = Cout if not for_dgrad else Cx
     Kp = _cdiv(K, 32) * 32
-    planes = torch.empty((3, Nn, Kp // 2), device=w.device, dtype=torch.float32)       # one float = two bf16
+    e2 = ENGINE == 2
+    fields = (Cout, Cin, KH, KW, Cx, 1 if for_dgrad else 0, kh0, kw0, step, Th, Tw, Kp)
+    pc = _PACK
+    if pc is not None:
+        key = ('presplit', e2, w.data_ptr()) + fields
+        e = pc.entries.get(key)
+        if e is not None and pc.fresh:
+            return e[1], Kp
+        if e is None:
+            planes = torch.empty((2 if e2 else 3, Nn, Kp // 2), device=w.device, dtype=torch.float32)   # one float = two halves
+            pc.entries[key] = (w if e2 else w.detach(), planes, ('presplit', e2) + fields)
+        else:
+            planes = e[1]
+    else:
+        planes = torch.empty((2 if e2 else 3, Nn, Kp // 2), device=w.device, dtype=torch.float32)
     check(_L().rih_presplit_conv_weight(w.data_ptr(), planes.data_ptr(), Cout, Cin, KH, KW, Cx, 1 if for_dgrad else 0,
-                                        kh0, kw0, step, Th, Tw, Kp, _stream()), 'rih_presplit_conv_weight')
+                                        kh0, kw0, step, Th, Tw, Kp, bound_of(w).data_ptr() if e2 else 0, _stream()),
+          'rih_presplit_conv_weight')
     return planes, Kp
 
 
 def _presplit_act(x2d_rows, C, x):
     """bf16 planes [3][rows][C] of an NHWC activation (rows = pixels, C % 32 == 0)."""
     planes = torch.empty((3, x2d_rows, C // 2), device=x.device, dtype=torch.float32)
-    check(_L().rih_presplit_matrix(x.data_ptr(), 1, C, x2d_rows, C, planes.data_ptr(), C, _stream()), 'rih_presplit_matrix')
+    check(_L().rih_presplit_matrix(x.data_ptr(), 1, C, x2d_rows, C, planes.data_ptr(), C, 0, _stream()), 'rih_presplit_matrix')
     return planes
 
 
-def _presplit_ok(Ngemm, Kchan, taps, engine=None):
-    """Preconditions of the b_mode 2 fast path: split engine, a 64-wide-or-larger tile, 32-channel-aligned gather."""
+def _presplit_ok(Ngemm, Kchan, taps, engine=None, abytes=0):
+    """Preconditions of the b_mode 2 fast path: a split engine, a 64-wide-or-larger tile, 32-channel-aligned gather."""
     e = ENGINE if engine is None else engine
-    return PRESPLIT and e == 1 and Ngemm > 32 and Kchan % 32 == 0 and taps <= 32
+    on = (PRESPLIT and e == 1) or (E2_PRESPLIT and e == 2)
+    return on and Ngemm > 32 and Kchan % 32 == 0 and taps <= 32 and abytes < (1 << 31)
 
 
 # When set to a list, every rih_gemm launch is bracketed by HIP events on the launch stream and
@@ -349,6 +401,9 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
             d.amax_a = amax_a if isinstance(amax_a, int) else _p(amax_a)
             d.amax_b = amax_b if isinstance(amax_b, int) else _p(amax_b)
         else:
+            if b_mode == 2:
+                raise RuntimeError('renderih_amd: a GEMM with a two-plane (engine 2) pre-split B operand does not take engine 2\'s '
+                                   'kernels (M %d N %d K %d): the caller must check _presplit_ok first' % (M, N, K))
             d.engine = 1
             amax_a = amax_b = None
     fused_drop = False
@@ -747,13 +802,24 @@ class PackCache:
         self.fresh = False
 
     def refresh(self):
-        if self.entries:
+        packs = [e for e in self.entries.values() if e[2][0] != 'presplit']
+        pres = [e for e in self.entries.values() if e[2][0] == 'presplit']
+        if packs:
             from ._lib import PackDesc
-            arr = (PackDesc * len(self.entries))()
-            for d, (w, dst, f) in zip(arr, self.entries.values()):
+            arr = (PackDesc * len(packs))()
+            for d, (w, dst, f) in zip(arr, packs):
                 d.w, d.dst = w.data_ptr(), dst.data_ptr()
                 (d.Cout, d.Cin, d.KH, d.KW, d.CinPad, d.mode, d.kh0, d.kw0, d.step, d.Th, d.Tw) = f
-            check(_L().rih_pack_conv_weight_multi(arr, len(self.entries), _stream()), 'rih_pack_conv_weight_multi')
+            check(_L().rih_pack_conv_weight_multi(arr, len(packs), _stream()), 'rih_pack_conv_weight_multi')
+        if pres:
+            # (engine 2 planes are scaled by the weight's bound: the bounds of this step must exist -- ops.begin_step runs first)
+            from ._lib import PresplitDesc
+            arr = (PresplitDesc * len(pres))()
+            for d, (w, dst, f) in zip(arr, pres):
+                d.w, d.dst = w.data_ptr(), dst.data_ptr()
+                d.amax_e2 = bound_of(w).data_ptr() if f[1] else None
+                (d.Cout, d.Cin, d.KH, d.KW, d.CinPad, d.for_dgrad, d.kh0, d.kw0, d.step, d.Th, d.Tw, d.Kpad) = f[2:]
+            check(_L().rih_presplit_multi(arr, len(pres), _stream()), 'rih_presplit_multi')
         self.fresh = True
 
     def stale(self):
@@ -813,13 +879,14 @@ class Conv2dFn(torch.autograd.Function):
         geom = (H, W_, Cx, Ho, Wo, KH, KW, stride, 1, pad, pad)
         # engine 2: operand bounds (kept for the backward: x is the weight gradient's A operand, w the data gradient's B)
         bx, bw = (LazyBound(x), LazyBound(w)) if ENGINE == 2 else (None, None)
-        if _presplit_ok(Cout, Cx, KH * KW):
+        if _presplit_ok(Cout, Cx, KH * KW, abytes=4 * x.numel()):
             wp, Kp = _presplit_weight(w, Cx, False)
             if PRESPLIT_ACT:
                 gemm(_presplit_act(N * H * W_, Cx, x), wp, y, M, Cout, K, Cx, Kp, Cout, a_mode=2, b_mode=2, bias=bias,
                      relu=relu, geom=geom)
             else:
-                gemm(x, wp, y, M, Cout, K, Cx, Kp, Cout, a_mode=0, b_mode=2, bias=bias, relu=relu, geom=geom)
+                gemm(x, wp, y, M, Cout, K, Cx, Kp, Cout, a_mode=0, b_mode=2, bias=bias, relu=relu, geom=geom,
+                     stats=stats if ENGINE == 2 else None, amax_a=bx, amax_b=bw)
         elif KH * KW == 1 and Cx == Cin:
             gemm(x, w, y, M, Cout, K, Cx, Cin, Cout, a_mode=0, b_mode=1, bias=bias, relu=relu, geom=geom, stats=stats,
                  amax_a=bx, amax_b=bw)
@@ -875,7 +942,7 @@ class Conv2dFn(torch.autograd.Function):
                     continue
                 padh, padw = Th - 1 - (oh + pad - kh0) // stride, Tw - 1 - (ow + pad - kw0) // stride
                 geom = (Ho, Wo, Cout, Hc, Wc, Th, Tw, 1, 1, padh, padw)
-                if _presplit_ok(Cx, Cout, Th * Tw):
+                if _presplit_ok(Cx, Cout, Th * Tw, abytes=4 * dy.numel()):
                     wd, Kp = _presplit_weight(w, Cx, True, (kh0, kw0, stride, Th, Tw))
                     if PRESPLIT_ACT:
                         if dyp is None:
@@ -884,7 +951,7 @@ class Conv2dFn(torch.autograd.Function):
                              cstride=(stride, oh, ow, H, W_))
                     else:
                         gemm(dy, wd, dx, N * Hc * Wc, Cx, Th * Tw * Cout, Cout, Kp, Cx, a_mode=0, b_mode=2, geom=geom,
-                             cstride=(stride, oh, ow, H, W_))
+                             cstride=(stride, oh, ow, H, W_), amax_a=bdy, amax_b=bw)
                     continue
                 if KH * KW == 1 and Cx == Cin:
                     wd = w
@@ -898,13 +965,14 @@ class Conv2dFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             Mx = N * H * W_
             geom = (Ho, Wo, Cout, H, W_, KH, KW, 1, stride, KH - 1 - pad, KW - 1 - pad)
-            if _presplit_ok(Cx, Cout, KH * KW):
+            if _presplit_ok(Cx, Cout, KH * KW, abytes=4 * dy.numel()):
                 wd, Kp = _presplit_weight(w, Cx, True)
                 if PRESPLIT_ACT:
                     gemm(_presplit_act(M, Cout, dy), wd, dx, Mx, Cx, KH * KW * Cout, Cout, Kp, Cx, a_mode=2, b_mode=2,
                          geom=geom, R=dskip, ldr=Cx)
                 else:
-                    gemm(dy, wd, dx, Mx, Cx, KH * KW * Cout, Cout, Kp, Cx, a_mode=0, b_mode=2, geom=geom, R=dskip, ldr=Cx)
+                    gemm(dy, wd, dx, Mx, Cx, KH * KW * Cout, Cout, Kp, Cx, a_mode=0, b_mode=2, geom=geom, R=dskip, ldr=Cx,
+                         amax_a=bdy, amax_b=bw)
             elif KH * KW == 1 and Cx == Cin:
                 gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cin, Cx, a_mode=0, b_mode=0, geom=geom, R=dskip, ldr=Cx,
                      amax_a=bdy, amax_b=bw)

@@ -141,8 +141,7 @@ class TrainStep:
 
     def _forward_loss(self):
         self._bounds = self._cut = None
-        if ops.ENGINE == 2:
-            ops.bounds_reset()
+        ops.begin_step(self.model)      # engine 2: this step's operand bounds (the packed weight planes below are scaled by them)
         if self.packs is not None:
             # every packed weight operand the step needs (forward and data-gradient layouts of the k > 1 convolutions) in one
             # launch, before the first kernel of the forward pass; the per-call packs then find them ready (ops.PackCache)
@@ -154,6 +153,7 @@ class TrainStep:
                 out = self.model(self.img)
         finally:
             self._cutting = False
+            ops._FWD_PREPARED = False       # (a model without ops.begin_forward leaves the flag set)
         return self.loss_fn(out, self.labels)
 
     def _stage(self, i, loss, carry):

@@ -134,7 +134,11 @@ class EmulatedLib:
                     A = self._gather(Ab, idx, valid)
                 if d.a_mode == 1 and d.ones_row > 0:
                     A[d.ones_row, :] = 1.0
-                if d.b_mode == 2:       # pre-split planes [3][N][ldb] bf16: B = hi + mid + lo
+                if d.b_mode == 2 and d.engine == 2:       # two fp16 planes of the scaled operand: B = (hi + 2^-11 lo) / s
+                    raw = np.ctypeslib.as_array((C.c_uint16 * (2 * N * d.ldb)).from_address(int(d.B))).reshape(2, N, d.ldb)
+                    pl = raw.view(np.float16).astype(np.float32)
+                    Bm = ((pl[0] + pl[1] * np.float32(2.0 ** -11)) / self._e2_scale(d.amax_b))[:, :K].T.astype(np.float32)
+                elif d.b_mode == 2:     # pre-split planes [3][N][ldb] bf16: B = hi + mid + lo
                     raw = np.ctypeslib.as_array((C.c_uint16 * (3 * N * d.ldb)).from_address(int(d.B))).reshape(3, N, d.ldb)
                     planes = (raw.astype(np.uint32) << 16).view(np.float32)
                     Bm = (planes[0] + planes[1] + planes[2])[:, :K].T.astype(np.float32)
@@ -223,7 +227,7 @@ class EmulatedLib:
             fast = fast and d.M % 4 == 0 and (plain or (d.Wo % 4 == 0 and d.Cin % 4 == 0))
         if d.b_mode == 0:
             fast = fast and d.N % 4 == 0
-        return 2 if (d.engine == 2 and fast and d.a_mode <= 1 and d.b_mode <= 1) else 1
+        return 2 if (d.engine == 2 and fast and d.a_mode <= 1 and (d.b_mode <= 1 or (d.b_mode == 2 and d.a_mode == 0))) else 1
 
     def rih_absmax_multi(self, descs, n, stream):
         for i in range(n):
@@ -269,7 +273,8 @@ class EmulatedLib:
         """The header's contract, restated: split engine's fast path, forward-type, no split-K, no batch, dense rows."""
         d = dref._obj
         plain = (d.KH == 1 and d.KW == 1 and d.strideA == 1 and d.padH == 0 and d.padW == 0 and d.H == d.Ho and d.W == d.Wo)
-        ok = (d.engine in (1, 2) and d.tile in (0, 1, 2) and d.a_mode == 0 and d.b_mode in (0, 1) and d.splitk == 1
+        ok = (d.engine in (1, 2) and d.tile in (0, 1, 2) and d.a_mode == 0
+              and (d.b_mode in (0, 1) or (d.b_mode == 2 and d.engine == 2)) and d.splitk == 1
               and d.nb1 * d.nb2 == 1 and d.cS <= 1 and d.upS == 1 and d.K % 4 == 0 and d.K >= 1
               and d.A % 16 == 0 and d.B % 16 == 0 and d.lda % 4 == 0 and d.ldb % 4 == 0)
         if not plain:
@@ -324,11 +329,32 @@ class EmulatedLib:
         r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
         return r.astype(np.uint16)
 
-    def _presplit_store(self, Bkn, dst, Kpad):
-        """Bkn [K][N] fp32 -> planes [3][N][Kpad] bf16 (hi, mid, lo; round to nearest even at every level)."""
+    @staticmethod
+    def _e2_scale(amax):
+        """The power of two rih_gemm engine 2 derives from a bound block: s * bound in [2^14, 2^15)."""
+        if not amax:
+            return np.float32(1.0)
+        a = float(_f(amax, 2048)[::32].max())
+        if not (a > 0 and np.isfinite(a)):
+            return np.float32(1.0)
+        e = int(np.floor(np.log2(a)))
+        if e < -126:
+            return np.float32(1.0)
+        return np.float32(2.0 ** min(14 - e, 126))
+
+    def _presplit_store(self, Bkn, dst, Kpad, amax_e2=0):
+        """Bkn [K][N] fp32 -> planes [3][N][Kpad] bf16 (hi, mid, lo; round to nearest even at every level), or with a bound
+        block (engine 2) -> planes [2][N][Kpad] fp16: hi = fp16(s x), lo = fp16((s x - hi) 2^11)."""
         K, N = Bkn.shape
         x = np.zeros((N, Kpad), np.float32)
         x[:, :K] = Bkn.T
+        if amax_e2:
+            xs = x * self._e2_scale(amax_e2)
+            out = np.ctypeslib.as_array((C.c_uint16 * (2 * N * Kpad)).from_address(int(dst))).reshape(2, N, Kpad)
+            hi = xs.astype(np.float16)
+            out[0] = hi.view(np.uint16)
+            out[1] = ((xs - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16).view(np.uint16)
+            return 0
         out = np.ctypeslib.as_array((C.c_uint16 * (3 * N * Kpad)).from_address(int(dst))).reshape(3, N, Kpad)
         for pl in range(3):
             h = self._bf16_rne(x)
@@ -336,12 +362,19 @@ class EmulatedLib:
             x = x - (h.astype(np.uint32) << 16).view(np.float32)
         return 0
 
-    def rih_presplit_matrix(self, B, b_mode, K, N, ldb, dst, Kpad, stream):
+    def rih_presplit_matrix(self, B, b_mode, K, N, ldb, dst, Kpad, amax_e2, stream):
         src = _f(B, (K - 1) * ldb + N if b_mode == 0 else (N - 1) * ldb + K)
         kk, nn = np.meshgrid(np.arange(K), np.arange(N), indexing='ij')
-        return self._presplit_store(src[kk * ldb + nn if b_mode == 0 else nn * ldb + kk], dst, Kpad)
+        return self._presplit_store(src[kk * ldb + nn if b_mode == 0 else nn * ldb + kk], dst, Kpad, amax_e2)
 
-    def rih_presplit_conv_weight(self, w, dst, Cout, Cin, KH, KW, CinPad, for_dgrad, kh0, kw0, step, Th, Tw, Kpad, stream):
+    def rih_presplit_multi(self, descs, n, stream):
+        for i in range(n):
+            d = descs[i]
+            self.rih_presplit_conv_weight(d.w, d.dst, d.Cout, d.Cin, d.KH, d.KW, d.CinPad, d.for_dgrad, d.kh0, d.kw0, d.step, d.Th,
+                                          d.Tw, d.Kpad, d.amax_e2, stream)
+        return 0
+
+    def rih_presplit_conv_weight(self, w, dst, Cout, Cin, KH, KW, CinPad, for_dgrad, kh0, kw0, step, Th, Tw, Kpad, amax_e2, stream):
         W = _f(w, Cout * Cin * KH * KW).reshape(Cout, Cin, KH, KW)
         Wp = np.zeros((Cout, CinPad, KH, KW), np.float32)
         Wp[:, :Cin] = W
@@ -350,7 +383,7 @@ class EmulatedLib:
         else:
             sel = Wp[:, :, [kh0 + step * (Th - 1 - t) for t in range(Th)]][:, :, :, [kw0 + step * (Tw - 1 - t) for t in range(Tw)]]
             Bkn = sel.transpose(2, 3, 0, 1).reshape(Th * Tw * Cout, CinPad)            # k = ((th, tw), co), n = ci
-        return self._presplit_store(Bkn, dst, Kpad)
+        return self._presplit_store(Bkn, dst, Kpad, amax_e2)
 
     def rih_splitk_reduce(self, P, S, M, N, dst, Cin, taps, CinValid, accumulate, stream):
         return self.rih_splitk_reduce_bias(P, S, M, M, N, dst, Cin, taps, CinValid, accumulate, 0, stream)

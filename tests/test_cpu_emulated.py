@@ -145,6 +145,7 @@ def test_paired_decoder_runs_with_dropout(monkeypatch):
 def test_presplit_weight_host_logic(monkeypatch):
     """ops.PRESPLIT (rih_gemm b_mode 2 + rih_presplit_conv_weight, off by default): descriptor / operand plumbing."""
     from renderih_amd import ops
+    monkeypatch.setattr(ops, 'ENGINE', 1)                       # (engine-1 experiments: three bf16 planes)
     monkeypatch.setattr(ops, 'PRESPLIT', True)
     G.test_conv2d((2, 8, 8, 64, 64, 3, 1, 1, True, True))
     G.test_conv2d((1, 8, 8, 64, 64, 3, 2, 1, False, False))

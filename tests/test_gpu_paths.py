@@ -118,8 +118,30 @@ def test_fused_attention_kernels(monkeypatch):
 def test_presplit_gemm_operands(monkeypatch, act):
     import test_gpu_ops as G
     from renderih_amd import ops
+    monkeypatch.setattr(ops, 'ENGINE', 1)                   # (engine-1 experiments: three bf16 planes per operand)
     monkeypatch.setattr(ops, 'PRESPLIT', True)
     monkeypatch.setattr(ops, 'PRESPLIT_ACT', act)
+    for case in G.CONV_CASES:
+        G.test_conv2d(case)
+
+
+@pytest.mark.parametrize('mode', ['per_call', 'pack_cache', 'loader_converts'])
+def test_engine2_weight_planes(monkeypatch, mode):
+    """Engine 2's weight operands: two scaled fp16 planes produced per call (rih_presplit_conv_weight), through a PackCache
+    refreshed in one rih_presplit_multi launch (second pass: every operand out of the cache), or converted by the GEMM's loader
+    (RIH_E2_PRESPLIT=0) -- all against F.conv2d at the suite's unchanged tolerance."""
+    import test_gpu_ops as G
+    from renderih_amd import ops
+    monkeypatch.setattr(ops, 'ENGINE', 2)
+    monkeypatch.setattr(ops, 'E2_PRESPLIT', mode != 'loader_converts')
+    if mode == 'pack_cache':
+        pc = ops.PackCache()
+        monkeypatch.setattr(ops, '_PACK', pc)
+        for case in G.CONV_CASES:
+            G.test_conv2d(case)
+        assert any(e[2][0] == 'presplit' for e in pc.entries.values())
+        ops.bounds_reset()
+        pc.refresh()
     for case in G.CONV_CASES:
         G.test_conv2d(case)
 

@@ -223,12 +223,45 @@ def test_presplit_weight_path(monkeypatch, case):
     from renderih_amd import ops
     calls = []
     real = ops._presplit_weight
+    monkeypatch.setattr(ops, 'ENGINE', 1)                   # (engine 2 pre-splits its weight operands by default: see below)
     monkeypatch.setattr(ops, 'PRESPLIT', True)
     monkeypatch.setattr(ops, '_presplit_weight', lambda *a, **k: (calls.append(a[2]), real(*a, **k))[1])
     G.test_conv2d(case)
     N_, H_, W_, Cin, Cout = case[:5]
     assert False in calls, calls                             # the forward operand went through it
     assert (True in calls) == (Cin > 32 and Cout % 32 == 0), calls      # ... and the data-gradient operand where eligible
+
+
+@pytest.mark.parametrize('case', [
+    (2, 8, 8, 32, 64, 3, 1, 1, False, True),
+    (1, 9, 7, 64, 96, 3, 2, 1, True, False),        # strided: parity-class data gradients from tap-subset planes
+    (2, 8, 8, 64, 128, 1, 1, 0, True, True),        # 1x1: planes of the raw [Cout][Cin] parameter
+    (2, 4, 4, 96, 40, 1, 2, 0, True, False),        # N = 40: a partial 64-wide tile of plane rows
+])
+@pytest.mark.parametrize('packed', [False, True])
+def test_engine2_presplit_weight_planes(monkeypatch, case, packed):
+    """Engine 2's default: weight operands as two scaled fp16 planes (rih_presplit_conv_weight / rih_presplit_multi with the
+    weight's bound block, rih_gemm b_mode 2 + engine 2, also with the statistics epilogue) against F.conv2d -- per call, and
+    through a PackCache refreshed in one launch (second pass over the same case: every operand comes out of the cache)."""
+    from renderih_amd import ops
+    calls = []
+    real = ops._presplit_weight
+    monkeypatch.setattr(ops, 'ENGINE', 2)
+    monkeypatch.setattr(ops, 'E2_PRESPLIT', True)
+    monkeypatch.setattr(ops, '_presplit_weight', lambda *a, **k: (calls.append(a[2]), real(*a, **k))[1])
+    if packed:
+        pc = ops.PackCache()
+        monkeypatch.setattr(ops, '_PACK', pc)
+        G.test_conv2d(case)                 # fills the cache (packed on the spot)
+        n = len(pc.entries)
+        assert n >= 1
+        ops.bounds_reset()
+        pc.refresh()                        # one rih_presplit_multi launch (bounds measured on demand)
+        G.test_conv2d(case)
+        assert len(pc.entries) >= n
+    else:
+        G.test_conv2d(case)
+    assert False in calls, calls
 
 
 @pytest.mark.parametrize('case', [
@@ -243,6 +276,7 @@ def test_presplit_activation_path(monkeypatch, case):
     from renderih_amd import ops
     acts = []
     real = ops._presplit_act
+    monkeypatch.setattr(ops, 'ENGINE', 1)                   # (an engine-1 experiment: three bf16 planes on both sides)
     monkeypatch.setattr(ops, 'PRESPLIT', True)
     monkeypatch.setattr(ops, 'PRESPLIT_ACT', True)
     monkeypatch.setattr(ops, '_presplit_act', lambda *a, **k: (acts.append(a[1]), real(*a, **k))[1])
@@ -259,7 +293,7 @@ def test_presplit_matrix_entry_point():
     x, w = G.rnd(M, K, seed=1), G.rnd(N, K, seed=2, scale=1 / math.sqrt(K))
     Kp = 128
     planes = torch.empty(3, N, Kp // 2)
-    check(ops._L().rih_presplit_matrix(w.data_ptr(), 1, K, N, K, planes.data_ptr(), Kp, 0), 'rih_presplit_matrix')
+    check(ops._L().rih_presplit_matrix(w.data_ptr(), 1, K, N, K, planes.data_ptr(), Kp, 0, 0), 'rih_presplit_matrix')
     y = torch.empty(M, N)
     ops.gemm(x, planes, y, M, N, K, K, Kp, N, a_mode=0, b_mode=2, engine=1)
     TMET.assert_close(y, (x.double() @ w.double().t()).float(), 1e-5, 1e-6, 'presplit matrix gemm')
@@ -616,8 +650,8 @@ def test_presplit_gemm_descriptor_fuzz_against_emulator():
         X, Bkn = rs.randn(pix, Cin).astype(np.float32), rs.randn(K, N).astype(np.float32)
         Kp = cdiv(K, 32) * 32
         pB, pA = np.zeros(3 * N * Kp, np.uint16), np.zeros(3 * pix * Cin, np.uint16)
-        assert host.rih_presplit_matrix(Bkn.ctypes.data, 0, K, N, N, pB.ctypes.data, Kp, None) == 0
-        assert host.rih_presplit_matrix(X.ctypes.data, 1, Cin, pix, Cin, pA.ctypes.data, Cin, None) == 0
+        assert host.rih_presplit_matrix(Bkn.ctypes.data, 0, K, N, N, pB.ctypes.data, Kp, None, None) == 0
+        assert host.rih_presplit_matrix(X.ctypes.data, 1, Cin, pix, Cin, pA.ctypes.data, Cin, None, None) == 0
         splitk, kchunk = 1, 0
         if rs.rand() < 0.3 and K >= 64:
             kchunk = cdiv(cdiv(K, 2), 32) * 32

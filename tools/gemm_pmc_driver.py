@@ -17,6 +17,16 @@ from gemm_pmc_driver_shapes import SHAPES  # noqa: E402
 dev = torch.device('cuda:0')
 B, REP = 64, 10
 ENG = int(os.environ.get('RIH_PMC_ENGINE', '1'))        # 2: the three-product fp16 engine (operand bounds by rih_absmax)
+PRE = os.environ.get('RIH_PMC_PRESPLIT', '0') == '1'    # engine 2: the weight operand as two pre-split fp16 planes (b_mode 2)
+
+
+def planes_of(wp, K, N, bound):
+    """two fp16 planes [2][N][Kpad] of a [K][N] weight operand, scaled by its bound block"""
+    Kp = -(-K // 32) * 32
+    pl = torch.empty(2, N, Kp // 2, device=dev)
+    ops.check(ops._L().rih_presplit_matrix(wp.data_ptr(), 0, K, N, N, pl.data_ptr(), Kp, bound.data_ptr(), ops._stream()),
+              'rih_presplit_matrix')
+    return pl, Kp
 
 
 def amax(t):
@@ -35,15 +45,19 @@ for kind, H, Cin, Cout, k in SHAPES:
         wp = torch.randn(K, Cout, device=dev) / K ** 0.5
         tile, sk = ops.plan_gemm(M, Cout, K, 1, 1)
         kw = dict(amax_a=amax(x), amax_b=amax(wp)) if ENG == 2 else {}
+        Bop, ldb, bm = wp, Cout, 0
+        if ENG == 2 and PRE:
+            Bop, ldb = planes_of(wp, K, Cout, kw['amax_b'])
+            bm = 2
         if sk > 1:
             kc = -(-(-(-K // sk)) // 32) * 32
             sk = -(-K // kc)
             part = torch.empty(sk, M, Cout, device=dev)
-            fn = lambda: ops.gemm(x, wp, part, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=tile, splitk=sk,
+            fn = lambda: ops.gemm(x, Bop, part, M, Cout, K, Cin, ldb, Cout, a_mode=0, b_mode=bm, geom=geom, tile=tile, splitk=sk,
                                   kchunk=kc, sCsplit=M * Cout, engine=ENG, **kw)
         else:
             y = torch.empty(B, H, H, Cout, device=dev)
-            fn = lambda: ops.gemm(x, wp, y, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=tile, engine=ENG, **kw)
+            fn = lambda: ops.gemm(x, Bop, y, M, Cout, K, Cin, ldb, Cout, a_mode=0, b_mode=bm, geom=geom, tile=tile, engine=ENG, **kw)
         label = 'fwd   %2dx%-2d %4d->%-4d k%d | M%-6d N%-4d K%-5d | tile %d sk %d' % (H, H, Cin, Cout, k, M, Cout, K, tile, sk)
     else:
         dy = torch.randn(B, H, H, Cout, device=dev)
