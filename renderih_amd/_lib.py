@@ -197,11 +197,6 @@ SIGNATURES = {
     'rih_mesh_loss': (c_i, [C.POINTER(MeshTopo), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_fl,
                             c_f, c_f, c_f, c_f, c_f, c_i, C.c_void_p]),
     'rih_mesh_loss_final': (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, C.c_void_p]),
-    'rih_gemm_p3': (c_i, [C.POINTER(GemmP3Desc), C.c_void_p]),
-    'rih_gemm_p3_tile_rows': (c_i, [c_i]),
-    'rih_p3_from_f32': (c_i, [c_f, c_l, c_i, c_i, C.c_void_p, c_i, c_i, C.c_void_p]),
-    'rih_p3_conv_weight': (c_i, [c_f, C.c_void_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
-    'rih_bn_stats_merge': (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),
     'rih_gemm_stats_rows': (c_i, [C.POINTER(GemmDesc)]),
     'rih_gemm_dropout_ok': (c_i, [C.POINTER(GemmDesc)]),
     'rih_gemm_engine': (c_i, [C.POINTER(GemmDesc)]),
@@ -212,17 +207,28 @@ SIGNATURES = {
     'rih_gemm_multi_pack': (c_i, [C.POINTER(GemmDesc), c_i, C.c_void_p, C.POINTER(C.c_int32)]),
     'rih_gemm_multi_launch': (c_i, [C.c_void_p, c_i, c_i, C.c_void_p]),
     'rih_bn_stats_from_blocks': (c_i, [c_f, c_i, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, C.c_void_p]),
-    'rih_bn_stats_from_tiles': (c_i, [c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, C.c_void_p]),
     'rih_flash_attention_fwd': (c_i, [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_u64, C.c_void_p, c_f,
                                       c_i, c_f, C.c_void_p]),
     'rih_flash_attention_bwd': (c_i, [c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl,
                                       c_u64, C.c_void_p, c_f, c_f, c_f, c_i, c_f, c_f, c_i, C.c_void_p]),
-    'rih_chain': (c_i, [C.POINTER(ChainDesc), C.c_void_p]),
-    'rih_chain_check': (c_i, [C.POINTER(ChainDesc)]),
     'rih_version': (c_i, []),
     'rih_abi_sizes': (c_i, [C.POINTER(C.c_int32)]),
     'rih_arch': (C.c_char_p, []),
 }
+
+# entry points of the two experiment sources (renderih_amd/_build.py: EXPERIMENT_SOURCES), bound only when the library was built
+# with RIH_BUILD_EXPERIMENTS=1
+EXPERIMENT_SIGNATURES = {
+    'rih_bn_stats_merge': (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),
+    'rih_bn_stats_from_tiles': (c_i, [c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, C.c_void_p]),
+    'rih_gemm_p3': (c_i, [C.POINTER(GemmP3Desc), C.c_void_p]),
+    'rih_gemm_p3_tile_rows': (c_i, [c_i]),
+    'rih_p3_from_f32': (c_i, [c_f, c_l, c_i, c_i, C.c_void_p, c_i, c_i, C.c_void_p]),
+    'rih_p3_conv_weight': (c_i, [c_f, C.c_void_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
+    'rih_chain': (c_i, [C.POINTER(ChainDesc), C.c_void_p]),
+    'rih_chain_check': (c_i, [C.POINTER(ChainDesc)]),
+}
+HAS_EXPERIMENTS = False
 
 ABI_VERSION = 13     # = RIH_ABI_VERSION of include/renderih_amd.h
 
@@ -257,11 +263,17 @@ def load():
         fn = getattr(lib, name)      # AttributeError => a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    global HAS_EXPERIMENTS
+    HAS_EXPERIMENTS = all(hasattr(lib, name) for name in EXPERIMENT_SIGNATURES)
+    if HAS_EXPERIMENTS:
+        for name, (res, args) in EXPERIMENT_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     # every by-pointer struct of the header, in rih_abi_sizes' order; the last one (rih_adam_entry: four pointers + int64) is
     # built by hand as int64 rows in renderih_amd/optim.py
-    mine = [C.sizeof(GemmDesc), C.sizeof(ManoModel), C.sizeof(MeshTopo), C.sizeof(HConvDesc), C.sizeof(GemmP3Desc),
-            C.sizeof(ReduceDesc), C.sizeof(PackDesc), C.sizeof(LnFinalDesc), 5 * 8, C.sizeof(ChainDesc), C.sizeof(AbsmaxDesc),
-            C.sizeof(PresplitDesc)]
+    mine = [C.sizeof(GemmDesc), C.sizeof(ManoModel), C.sizeof(MeshTopo), C.sizeof(HConvDesc),
+            C.sizeof(ReduceDesc), C.sizeof(PackDesc), C.sizeof(LnFinalDesc), 5 * 8, C.sizeof(AbsmaxDesc), C.sizeof(PresplitDesc)]
     if lib.rih_version() != ABI_VERSION:
         raise RuntimeError('librenderih_amd.so does not match this binding (ABI %d vs %d): rebuild with '
                            '`python -m renderih_amd._build`' % (lib.rih_version(), ABI_VERSION))

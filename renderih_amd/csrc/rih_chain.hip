@@ -22,7 +22,7 @@
 // (finished by rih_ln_param_final_multi like those of rih_layernorm_bwd).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "../../include/renderih_amd.h"
+#include "../../include/renderih_amd_experiments.h"
 #include "rih_hash.h"
 
 namespace {

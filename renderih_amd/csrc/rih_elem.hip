@@ -1995,14 +1995,12 @@ extern "C" int rih_abi_sizes(int32_t* out9) {      // RIH_ABI_NSIZES values
     out9[1] = (int32_t)sizeof(rih_mano_model);
     out9[2] = (int32_t)sizeof(rih_mesh_topo);
     out9[3] = (int32_t)sizeof(rih_hconv_desc);
-    out9[4] = (int32_t)sizeof(rih_gemm_p3_desc);
-    out9[5] = (int32_t)sizeof(rih_reduce_desc);
-    out9[6] = (int32_t)sizeof(rih_pack_desc);
-    out9[7] = (int32_t)sizeof(rih_ln_final_desc);
-    out9[8] = (int32_t)sizeof(rih_adam_entry);
-    out9[9] = (int32_t)sizeof(rih_chain_desc);
-    out9[10] = (int32_t)sizeof(rih_absmax_desc);
-    out9[11] = (int32_t)sizeof(rih_presplit_desc);
+    out9[4] = (int32_t)sizeof(rih_reduce_desc);
+    out9[5] = (int32_t)sizeof(rih_pack_desc);
+    out9[6] = (int32_t)sizeof(rih_ln_final_desc);
+    out9[7] = (int32_t)sizeof(rih_adam_entry);
+    out9[8] = (int32_t)sizeof(rih_absmax_desc);
+    out9[9] = (int32_t)sizeof(rih_presplit_desc);
     return 0;
 }
 extern "C" const char* rih_arch(void) { return "gfx950"; }

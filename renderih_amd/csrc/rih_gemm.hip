@@ -16,7 +16,11 @@
 #include <type_traits>
 
 #ifndef RIH_E2_PIPE
-#define RIH_E2_PIPE 1       /* engine 2's main loop: 1 = two LDS stages, one barrier per k-tile, conversion interleaved with the MFMAs */
+/* engine 2's main loop: 1 = two LDS stages, one barrier per k-tile, conversion half-units interleaved with the MFMAs.  Built,
+ * parity-tested and measured in round 4 (profiles/r04/ab/c3_*, c4_*): per shape within +-3 % of the two-barrier loop, whole step
+ * -0.5 % (1933-1935 against 1946 images/s) at twice the LDS footprint -- the kernel is bound by the SUM of its MFMA, VALU and LDS
+ * issue time on a SIMD (profiles/r04/gemm_pmc2_issue_breakdown_*), which re-ordering does not shrink.  Not compiled by default. */
+#define RIH_E2_PIPE 0
 #endif
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -1488,11 +1492,15 @@ int launch_split(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 gri
 __device__ __forceinline__ int hs_row(int m) { return (m ^ ((m >> 2) & 3)) * 8; }
 __device__ __forceinline__ int hs_swz(int m) { return (m >> 4) & 1; }
 
-template <int AMODE, int BMODE, bool PLAIN>
+// ENG 2 (round 4): the two-term fp16 split -- two planes per operand, three MFMA groups of eight per step (hi*lo and lo*hi into
+// the correction accumulators, hi*hi into the main ones: 256 accumulator registers per lane at one wavefront per SIMD), two
+// conversion units behind each group; STATS: the BatchNorm statistics epilogue of store_tiles_wide (rows per block = 128).
+template <int AMODE, int BMODE, bool PLAIN, int ENG = 1, bool STATS = false>
 __global__ __launch_bounds__(256, 1) void gemm_split256_kernel(const GemmArgs p) {
     constexpr int BM = 256, BN = 128;
+    constexpr int NPL = (ENG == 2) ? 2 : 3;             // 16-bit planes per operand
     constexpr int HPA = BM * 8, HPB = BN * 8;           // dwords per plane of a half-stage
-    constexpr int HSTAGE = 3 * (HPA + HPB);             // 9216 dwords = 36 KiB
+    constexpr int HSTAGE = NPL * (HPA + HPB);           // engine 1: 9216 dwords = 36 KiB; engine 2: 6144 dwords = 24 KiB
     constexpr int WM = 128, WN = 64, TM = 4, TN = 2;
 
     __shared__ __attribute__((aligned(16))) unsigned smem[4 * HSTAGE];
@@ -1531,6 +1539,11 @@ __global__ __launch_bounds__(256, 1) void gemm_split256_kernel(const GemmArgs p)
     const int kbeg = split * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
     const int ntiles = (kend - kbeg + BK - 1) / BK;
+    float e2_sa = 1.f, e2_sb = 1.f;
+    if (ENG == 2) {
+        e2_sa = e2_scale(p.amax_a, false);
+        e2_sb = e2_scale(p.amax_b, false);
+    }
 
     // ------------------------------------------------------------------ per-thread loader constants
     const int r4 = tid >> 2, qh = tid & 3;      // K-contiguous operands: row (+64 per pass), k-quad inside the half
@@ -1683,39 +1696,54 @@ __global__ __launch_bounds__(256, 1) void gemm_split256_kernel(const GemmArgs p)
         }
     };
 
-    auto put4 = [](unsigned* u, int plane, float x0, float x1, float x2, float x3) {
-        unsigned h0, m0_, l0, h1, m1, l1;
-        split2(x0, x1, h0, m0_, l0);
-        split2(x2, x3, h1, m1, l1);
-        *reinterpret_cast<uint2*>(u) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(u + plane) = make_uint2(m0_, m1);
-        *reinterpret_cast<uint2*>(u + 2 * plane) = make_uint2(l0, l1);
+    auto put4 = [](unsigned* u, int plane, float sc, float x0, float x1, float x2, float x3) {
+        if (ENG == 2) {
+            unsigned h0, l0, h1, l1;
+            split2h(x0, x1, sc, h0, l0);
+            split2h(x2, x3, sc, h1, l1);
+            *reinterpret_cast<uint2*>(u) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(u + plane) = make_uint2(l0, l1);
+        } else {
+            unsigned h0, m0_, l0, h1, m1, l1;
+            split2(x0, x1, h0, m0_, l0);
+            split2(x2, x3, h1, m1, l1);
+            *reinterpret_cast<uint2*>(u) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(u + plane) = make_uint2(m0_, m1);
+            *reinterpret_cast<uint2*>(u + 2 * plane) = make_uint2(l0, l1);
+        }
     };
-    auto put2 = [](unsigned* u, int plane, float x0, float x1) {
-        unsigned h, m, l;
-        split2(x0, x1, h, m, l);
-        u[0] = h;
-        u[plane] = m;
-        u[2 * plane] = l;
+    auto put2 = [](unsigned* u, int plane, float sc, float x0, float x1) {
+        if (ENG == 2) {
+            unsigned h, l;
+            split2h(x0, x1, sc, h, l);
+            u[0] = h;
+            u[plane] = l;
+        } else {
+            unsigned h, m, l;
+            split2(x0, x1, h, m, l);
+            u[0] = h;
+            u[plane] = m;
+            u[2 * plane] = l;
+        }
     };
     auto elem = [](const float4& v, int j) -> float { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); };
     // conversion unit u (0..3) of half s of the raw A registers -> half-stage `hs`
     auto conv_A = [&](unsigned* hs, int s, int u) {
         if (AMODE == 0) {
-            put4(hs + a_st + 512 * u, HPA, rawA[s][u].x, rawA[s][u].y, rawA[s][u].z, rawA[s][u].w);
+            put4(hs + a_st + 512 * u, HPA, e2_sa, rawA[s][u].x, rawA[s][u].y, rawA[s][u].z, rawA[s][u].w);
         } else {
-            put4(hs + a_st + 8 * (u ^ (amq & 3)), HPA, elem(rawA[s][0], u), elem(rawA[s][1], u), elem(rawA[s][2], u),
+            put4(hs + a_st + 8 * (u ^ (amq & 3)), HPA, e2_sa, elem(rawA[s][0], u), elem(rawA[s][1], u), elem(rawA[s][2], u),
                  elem(rawA[s][3], u));
         }
     };
     // conversion slot u (0..1) of half s of the raw B registers
     auto conv_B = [&](unsigned* hs, int s, int u) {
-        unsigned* bs = hs + 3 * HPA;
+        unsigned* bs = hs + NPL * HPA;
         if (BMODE == 1) {
-            put4(bs + b_st + 512 * u, HPB, rawB[s][u].x, rawB[s][u].y, rawB[s][u].z, rawB[s][u].w);
+            put4(bs + b_st + 512 * u, HPB, e2_sb, rawB[s][u].x, rawB[s][u].y, rawB[s][u].z, rawB[s][u].w);
         } else {
-            put2(bs + b_st + 8 * ((2 * u) ^ (bnq & 3)), HPB, elem(rawB[s][0], 2 * u), elem(rawB[s][1], 2 * u));
-            put2(bs + b_st + 8 * ((2 * u + 1) ^ (bnq & 3)), HPB, elem(rawB[s][0], 2 * u + 1), elem(rawB[s][1], 2 * u + 1));
+            put2(bs + b_st + 8 * ((2 * u) ^ (bnq & 3)), HPB, e2_sb, elem(rawB[s][0], 2 * u), elem(rawB[s][1], 2 * u));
+            put2(bs + b_st + 8 * ((2 * u + 1) ^ (bnq & 3)), HPB, e2_sb, elem(rawB[s][0], 2 * u + 1), elem(rawB[s][1], 2 * u + 1));
         }
     };
 
@@ -1723,37 +1751,57 @@ __global__ __launch_bounds__(256, 1) void gemm_split256_kernel(const GemmArgs p)
     const int l31 = lane & 31, lhi = lane >> 5;
     const int ma = wm * WM + l31, nb = wn * WN + l31;
     const int sa_rd = hs_row(ma) + 4 * (lhi ^ hs_swz(ma));
-    const int sb_rd = 3 * HPA + hs_row(nb) + 4 * (lhi ^ hs_swz(nb));
-    bf16x8 av[2][3][TM], bv[2][3][TN];
-    auto fetch = [&](const unsigned* hs, int set) {     // in order of first use: A.lo B.hi | A.hi B.lo | A.mid B.mid
+    const int sb_rd = NPL * HPA + hs_row(nb) + 4 * (lhi ^ hs_swz(nb));
+    typedef typename std::conditional<ENG == 2, f16x8, bf16x8>::type opnd_t;
+    opnd_t av[2][NPL][TM], bv[2][NPL][TN];
+    auto fetch = [&](const unsigned* hs, int set) {
+        if constexpr (ENG == 2) {       // in order of first use: A.lo B.hi | A.hi | B.lo
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-            av[set][2][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(hs + 2 * HPA + sa_rd + i * 256));
+            for (int i = 0; i < TM; ++i)
+                av[set][1][i] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + HPA + sa_rd + i * 256));
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-            bv[set][0][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(hs + sb_rd + j * 256));
+            for (int j = 0; j < TN; ++j)
+                bv[set][0][j] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + sb_rd + j * 256));
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-            av[set][0][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(hs + sa_rd + i * 256));
+            for (int i = 0; i < TM; ++i)
+                av[set][0][i] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + sa_rd + i * 256));
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-            bv[set][2][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(hs + 2 * HPB + sb_rd + j * 256));
+            for (int j = 0; j < TN; ++j)
+                bv[set][1][j] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + HPB + sb_rd + j * 256));
+        } else {                        // in order of first use: A.lo B.hi | A.hi B.lo | A.mid B.mid
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-            av[set][1][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(hs + HPA + sa_rd + i * 256));
+            for (int i = 0; i < TM; ++i)
+                av[set][NPL - 1][i] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + 2 * HPA + sa_rd + i * 256));
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-            bv[set][1][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(hs + HPB + sb_rd + j * 256));
+            for (int j = 0; j < TN; ++j)
+                bv[set][0][j] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + sb_rd + j * 256));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                av[set][0][i] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + sa_rd + i * 256));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bv[set][NPL - 1][j] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + 2 * HPB + sb_rd + j * 256));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                av[set][1][i] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + HPA + sa_rd + i * 256));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bv[set][1][j] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + HPB + sb_rd + j * 256));
+        }
     };
 
     // ------------------------------------------------------------------ prologue
     floatx16 acc[TM][TN];
+    floatx16 acc1[ENG == 2 ? TM : 1][TN];           // engine 2: hi*lo + lo*hi (scaled by 2^11)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if (ENG == 2) acc1[i][j][r] = 0.f;
+            }
 
 #pragma unroll
     for (int s = 0; s < 2; ++s) { load_A(kbeg, s); load_B(kbeg, s); }
@@ -1778,6 +1826,30 @@ __global__ __launch_bounds__(256, 1) void gemm_split256_kernel(const GemmArgs p)
         unsigned* slot_n0 = smem + ((2 * t + 2) & 3) * HSTAGE;
         unsigned* slot_n1 = smem + ((2 * t + 3) & 3) * HSTAGE;
         (void)slot_t0;
+        if constexpr (ENG == 2) {
+#define RIH_E2_TERM(ACC_, S_, PA_, PB_)                                                                           \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) ACC_[i][j] =    \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(av[S_][PA_][i], bv[S_][PB_][j], ACC_[i][j], 0, 0, 0);
+            // group G of step S: 8 MFMAs + two conversion units of step (t+1, S) (+ reload of their registers for t+2)
+#define RIH_E2_GROUP(S_, G_, ACC_, PA_, PB_, DST_)                                                                \
+    RIH_E2_TERM(ACC_, S_, PA_, PB_)                                                                               \
+    if ((G_) == 0) { conv_A(DST_, S_, 0); conv_A(DST_, S_, 1); }                                                  \
+    if ((G_) == 1) { conv_A(DST_, S_, 2); conv_A(DST_, S_, 3); if ((S_) == 0) advance_A(); load_A(k2, S_); }      \
+    if ((G_) == 2) { conv_B(DST_, S_, 0); conv_B(DST_, S_, 1); load_B(k2, S_); }                                  \
+    __builtin_amdgcn_sched_barrier(0);
+            fetch(slot_t1, 1);
+            RIH_E2_GROUP(0, 0, acc1, 1, 0, slot_n0)
+            RIH_E2_GROUP(0, 1, acc, 0, 0, slot_n0)
+            RIH_E2_GROUP(0, 2, acc1, 0, 1, slot_n0)
+            __syncthreads();
+            fetch(slot_n0, 0);
+            RIH_E2_GROUP(1, 0, acc1, 1, 0, slot_n1)
+            RIH_E2_GROUP(1, 1, acc, 0, 0, slot_n1)
+            RIH_E2_GROUP(1, 2, acc1, 0, 1, slot_n1)
+            __syncthreads();
+#undef RIH_E2_GROUP
+#undef RIH_E2_TERM
+        } else {
 #define RIH_SPLIT_TERM(S_, PA_, PB_)                                                                              \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =      \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[S_][PA_][i], bv[S_][PB_][j], acc[i][j], 0, 0, 0);
@@ -1809,14 +1881,34 @@ __global__ __launch_bounds__(256, 1) void gemm_split256_kernel(const GemmArgs p)
         __syncthreads();
 #undef RIH_GROUP
 #undef RIH_SPLIT_TERM
+        }
     }
 
     // ------------------------------------------------------------------ epilogue (store_tiles_wide; the main loop ended with a barrier)
-    store_tiles_wide<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp, m0 + wm * WM, n0 + wn * WN, lane);
+    if constexpr (ENG == 2) {
+        store_tiles_wide<TM, TN, STATS, false, true>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp, m0 + wm * WM,
+                                                     n0 + wn * WN, lane, acc1, 1.f / e2_sa, 1.f / e2_sb);
+    } else {
+        store_tiles_wide<TM, TN, STATS>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp, m0 + wm * WM, n0 + wn * WN, lane);
+    }
 }
 
-int launch_split256(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 grid, hipStream_t s) {
+int launch_split256(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 grid, hipStream_t s, int engine) {
     dim3 block(256);
+    if (a_mode == 1 && b_mode == 1) return RIH_EINVAL;
+    if (engine == 2) {
+#define RIH_LS(AM_, BM_, PL_, ST_) hipLaunchKernelGGL((gemm_split256_kernel<AM_, BM_, PL_, 2, ST_>), grid, block, 0, s, a)
+        if (a.stats != nullptr) {       // forward-type only (checked by the caller)
+            if (b_mode == 0) { if (plain) RIH_LS(0, 0, true, true); else RIH_LS(0, 0, false, true); }
+            else { if (plain) RIH_LS(0, 1, true, true); else RIH_LS(0, 1, false, true); }
+        }
+        else if (a_mode == 0 && b_mode == 0) { if (plain) RIH_LS(0, 0, true, false); else RIH_LS(0, 0, false, false); }
+        else if (a_mode == 0 && b_mode == 1) { if (plain) RIH_LS(0, 1, true, false); else RIH_LS(0, 1, false, false); }
+        else { if (plain) RIH_LS(1, 0, true, false); else RIH_LS(1, 0, false, false); }
+#undef RIH_LS
+        return (int)hipGetLastError();
+    }
+    if (a.stats != nullptr) return RIH_EINVAL;
 #define RIH_LS(AM_, BM_, PL_) hipLaunchKernelGGL((gemm_split256_kernel<AM_, BM_, PL_>), grid, block, 0, s, a)
     if (a_mode == 0 && b_mode == 0) { if (plain) RIH_LS(0, 0, true); else RIH_LS(0, 0, false); }
     else if (a_mode == 0 && b_mode == 1) { if (plain) RIH_LS(0, 1, true); else RIH_LS(0, 1, false); }
@@ -2288,15 +2380,18 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
         if (d->a_mode == 1) ok = ok && (d->M % 4 == 0) && (plain || (d->Wo % 4 == 0 && d->Cin % 4 == 0));
         if (d->b_mode == 0) ok = ok && (d->N % 4 == 0);
         if (d->tile == 4) {     // 256x128 kernel: no general-kernel fallback, the caller must respect the preconditions
-            if (stats_rows != nullptr) { *stats_rows = 0; return 0; }
+            const bool e2t4 = d->engine == 2 && d->a_mode <= 1 && d->b_mode <= 1 && d->ones_row == 0;
+            ok = ok && !(d->a_mode == 1 && d->b_mode == 1) && d->a_mode <= 1 && d->b_mode <= 1;
+            // the statistics epilogue exists in the engine-2 form only: forward-type, no split-K, no batch, dense rows
+            const bool st_ok = ok && e2t4 && d->a_mode == 0 && d->splitk == 1 && gz == 1 && d->cS <= 1;
+            if (stats_rows != nullptr) { *stats_rows = st_ok ? 128 : 0; return 0; }
             if (prep != nullptr) return RIH_EINVAL;
-            if (d->stats != nullptr || d->drop_p != 0.f) return RIH_EINVAL;
-            ok = ok && !(d->a_mode == 1 && d->b_mode == 1);
+            if (d->drop_p != 0.f || (d->stats != nullptr && !st_ok)) return RIH_EINVAL;
             if (!ok) return RIH_EINVAL;
-            if (engine_out != nullptr) return 0;
+            if (engine_out != nullptr) { *engine_out = e2t4 ? 2 : 1; return 0; }
             a.a_bytes = (unsigned)a_bytes;
             a.b_bytes = (unsigned)b_bytes;
-            return launch_split256(a, d->a_mode, d->b_mode, plain, grid, s);
+            return launch_split256(a, d->a_mode, d->b_mode, plain, grid, s, e2t4 ? 2 : 1);
         }
         const bool b_stats_ok = d->b_mode <= 1 || (e2 && d->b_mode == 2);      // (engine 1's pre-split B path has no statistics variant)
         if (d->stats != nullptr && !(ok && d->tile <= 2 && d->a_mode == 0 && b_stats_ok && d->splitk == 1 && gz == 1 &&

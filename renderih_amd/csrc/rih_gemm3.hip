@@ -37,7 +37,7 @@
 //     rih_bn_stats_merge with Chan's formula) -- the separate statistics pass over the activation disappears.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "../../include/renderih_amd.h"
+#include "../../include/renderih_amd_experiments.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -55,7 +55,11 @@ def plan_gemm(M, N, K, batch=1, engine=None):
     blocks per CU and long k-loops (its per-block prologue/epilogue is expensive), so deep-K problems with few
     output tiles are split over K instead of shrinking the tile."""
     e = ENGINE if engine is None else engine
-    e = min(e, 1)            # engine 2 shares engine 1's kernels' structure: planned alike
+    if e == 2 and E2_TILE4 and N >= 128 and K >= E2_TILE4_MINK and _cdiv(M, 256) * _cdiv(N, 128) * batch >= E2_TILE4_MIN:
+        # engine 2's 256x128 software-pipelined kernel (one workgroup per CU, conversion interleaved with the MFMAs by hand):
+        # large-M problems with at least E2_TILE4_MIN workgroups
+        return 4, 1
+    e = min(e, 1)            # otherwise engine 2 shares engine 1's kernels' structure: planned alike
     if N <= 32:
         # 16 < N <= 32 (HRNet's 32-channel branch): a half-empty split-engine tile beats the 128x32 tile of the native-f32
         # engine by 6-9 % (profiles/r02/n32_bench_m31.log); below that the waste is too large
@@ -91,6 +95,10 @@ def plan_gemm(M, N, K, batch=1, engine=None):
 
 
 _TILE_MN = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (256, 128)}
+# RIH_E2_TILE4=1: the planner may pick the 256x128 pipelined kernel for engine-2 launches (see plan_gemm)
+E2_TILE4 = os.environ.get('RIH_E2_TILE4', '0') == '1'
+E2_TILE4_MIN = int(os.environ.get('RIH_E2_TILE4_MIN', '192'))
+E2_TILE4_MINK = int(os.environ.get('RIH_E2_TILE4_MINK', '256'))
 
 # MFMA engine of rih_gemm (include/renderih_amd.h): 2 (default since round 4) = fp32 on THREE fp16 MFMA products (scaled two-term
 # split, 833 TF ceiling) wherever a call site has operand bounds (the convolutions: bounds from the BatchNorm kernels), engine 1
@@ -262,11 +270,12 @@ PRESPLIT = os.environ.get('RIH_PRESPLIT', '0') in ('1', '2')
 PRESPLIT_ACT = os.environ.get('RIH_PRESPLIT', '0') == '2' and ENGINE == 1         # (an engine-1 experiment)
 
 
-# Engine 2: the two fp16 planes of every convolution WEIGHT operand (forward and data-gradient layouts) are produced once per
-# step -- rih_presplit_multi, one launch, through ops._PACK under TrainStep -- instead of inside every GEMM's loader: a weight
-# operand then costs the loader no conversion instructions at all (half of the conversion work on square tiles).  RIH_E2_PRESPLIT=0:
-# the loader converts B like A.
-E2_PRESPLIT = os.environ.get('RIH_E2_PRESPLIT', '1') == '1'
+# Engine 2, optional (RIH_E2_PRESPLIT=1): the two fp16 planes of every convolution WEIGHT operand (forward and data-gradient
+# layouts) produced once per step -- rih_presplit_multi, one launch, through ops._PACK under TrainStep -- instead of inside every
+# GEMM's loader, which then converts nothing for B.  Measured in round 4 (profiles/r04/ab/c4_*, gemm_pmc_table_top12_engine2_
+# presplitB_c4.txt): the GEMMs themselves gain 2-8 % per shape, the whole step nothing (1921.9 against 1922.6 images/s: the
+# planes' own launch and traffic eat it).  Off by default; parity-tested in both settings (tests/test_gpu_paths.py).
+E2_PRESPLIT = os.environ.get('RIH_E2_PRESPLIT', '0') == '1'
 
 
 def _presplit_weight(w, Cx, for_dgrad, sub=None):
@@ -401,6 +410,8 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
             d.amax_a = amax_a if isinstance(amax_a, int) else _p(amax_a)
             d.amax_b = amax_b if isinstance(amax_b, int) else _p(amax_b)
         else:
+            if tile is None and d.tile == 4:        # the planner's engine-2 choice does not apply: plan again for engine 1
+                d.tile, auto_sk = plan_gemm(M, N, K, nb1 * nb2 * splitk, 1)
             if b_mode == 2:
                 raise RuntimeError('renderih_amd: a GEMM with a two-plane (engine 2) pre-split B operand does not take engine 2\'s '
                                    'kernels (M %d N %d K %d): the caller must check _presplit_ok first' % (M, N, K))
@@ -596,9 +607,19 @@ def plan_p3(M, N, K):
     return 2
 
 
+def need_experiments(what):
+    """The P3 GEMM and the row-chain kernel are not part of the default library (renderih_amd/_build.py: EXPERIMENT_SOURCES)."""
+    lib = _L()
+    if not hasattr(lib, 'rih_chain') or not hasattr(lib, 'rih_gemm_p3'):
+        raise RuntimeError('renderih_amd: %s needs the experiment kernels -- rebuild with RIH_BUILD_EXPERIMENTS=1 '
+                           '(python -m renderih_amd._build)' % what)
+    return lib
+
+
 def gemm_p3(A, B, Cout, M, N, K, lda, ldb, ldc, geom, bias=None, R=None, ldr=0, relu=False, cstride=None, stats=None,
             tile=None, layout=0):
     """Enqueue one rih_gemm_p3.  geom = (H, W, Cin, Ho, Wo, KH, KW, stride, padH, padW)."""
+    need_experiments('rih_gemm_p3')
     d = _lib.GemmP3Desc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
     d.zero = zero_page(Cout.device).data_ptr()

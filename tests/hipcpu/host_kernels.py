@@ -51,7 +51,10 @@ def build(force=False):
 def load():
     from renderih_amd import _lib
     lib = C.CDLL(build())
-    for name, (res, args) in _lib.SIGNATURES.items():
+    sigs = dict(_lib.SIGNATURES)
+    if all(hasattr(lib, n) for n in _lib.EXPERIMENT_SIGNATURES):     # built with RIH_BUILD_EXPERIMENTS=1
+        sigs.update(_lib.EXPERIMENT_SIGNATURES)
+    for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args

@@ -12,10 +12,15 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 
 def test_library_exports_every_declared_symbol():
     from renderih_amd import _lib
-    hdr = open(os.path.join(ROOT, 'include', 'renderih_amd.h')).read()
-    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
-    declared = set(re.findall(r'\b(rih_[a-z0-9_]+)\s*\(', hdr))
+
+    def declared_in(name):
+        hdr = open(os.path.join(ROOT, 'include', name)).read()
+        hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+        return set(re.findall(r'\b(rih_[a-z0-9_]+)\s*\(', hdr))
+    declared = declared_in('renderih_amd.h')
     assert declared, 'no declarations parsed'
+    # the experiment kernels (not in the default library) have their own header and their own binding table
+    assert declared_in('renderih_amd_experiments.h') == set(_lib.EXPERIMENT_SIGNATURES.keys())
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name

@@ -528,12 +528,16 @@ def test_cross_attention_packed(B, V, D, h):
     assert_close(gr.grad, tr.grad, 1e-3, 1e-4, 'cross dR')
 
 
+@pytest.mark.parametrize('engine', [1, 2])
 @pytest.mark.parametrize('case', [(2, 32, 32, 64, 128, 3, 1, 1), (1, 64, 64, 128, 256, 1, 1, 0), (2, 16, 16, 128, 128, 3, 1, 1)])
-def test_gemm_tile4_pipelined_kernel(case):
-    """The 256x128 software-pipelined split kernel (tile id 4) is not chosen by the planner yet; keep it honest against
-    the 128x128 kernel on conv forward, conv weight gradient (split-K) and a plain matrix product."""
+def test_gemm_tile4_pipelined_kernel(case, engine=1):
+    """The 256x128 software-pipelined split kernel (tile id 4), engine 1 (six bf16 products) and engine 2 (three fp16 products,
+    operand bounds from rih_absmax): honest against the 128x128 kernel of the same engine on conv forward, conv weight gradient
+    (split-K) and a plain matrix product, and -- engine 2 -- its statistics epilogue against the 128x128 kernel's."""
     from renderih_amd import ops
     d = dev()
+    if engine == 2:
+        return _tile4_engine2(case, d)
     N, H, W, Cin, Cout, k, s, p = case
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     x = rnd(N, H, W, Cin, seed=31).to(d)
@@ -563,6 +567,59 @@ def test_gemm_tile4_pipelined_kernel(case):
         zs.append(z)
     assert_close(zs[1], zs[0], 1e-5, 1e-6, 'tile4 linear')
     assert_close(zs[1], (a.double() @ b.double().t()).float(), 1e-5, 1e-6, 'tile4 linear vs fp64')
+
+
+def _tile4_engine2(case, d):
+    from renderih_amd import ops
+    N, H, W, Cin, Cout, k, s, p = case
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = (rnd(N, H, W, Cin, seed=31) * 37.0).to(d)               # magnitudes away from 1: the operand scales matter
+    wp = (rnd(k * k * Cin, Cout, seed=32) * 1e-3).to(d)
+    M, K = N * Ho * Wo, k * k * Cin
+    geom = (H, W, Cin, Ho, Wo, k, k, s, 1, p, p)
+    bx, bw = ops.bound_of(x), ops.bound_of(wp)
+    ys, sts = [], []
+    for t in (0, 4):
+        y = torch.empty(N, Ho, Wo, Cout, device=d)
+        h = ops.StatsHolder()
+        ops.gemm(x, wp, y, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=t, engine=2, amax_a=bx, amax_b=bw, stats=h)
+        assert h.part is not None and h.rows == (64 if t == 0 else 128), (t, h.rows)
+        ys.append(y)
+        # per-block (mean, M2) -> whole-tensor mean / variance per channel (Chan's merge, in double on the host)
+        part = h.part.double().cpu()
+        n = torch.full((h.T,), float(h.rows), dtype=torch.float64)
+        n[-1] = M - h.rows * (h.T - 1)
+        mean = (part[:, 0] * n[:, None]).sum(0) / M
+        var = (part[:, 1] + n[:, None] * (part[:, 0] - mean) ** 2).sum(0) / M
+        sts.append((mean, var))
+    ref = (x.view(M, -1).double().cpu() if k == 1 else None)
+    assert_close(ys[1], ys[0], 1e-5, 1e-6, 'tile4 e2 conv fwd')
+    assert_close(sts[1][0], sts[0][0], 1e-5, 1e-6, 'tile4 e2 stats mean')
+    assert_close(sts[1][1], sts[0][1], 1e-4, 1e-6, 'tile4 e2 stats var')
+    y2 = ys[1].double().view(M, Cout).cpu()
+    assert_close(sts[1][0], y2.mean(0), 1e-5, 1e-6, 'tile4 e2 stats mean vs output')
+    assert_close(sts[1][1], y2.var(0, unbiased=False), 1e-4, 1e-6, 'tile4 e2 stats var vs output')
+    if ref is not None:
+        assert_close(ys[1].view(M, Cout), (ref @ wp.double().cpu()).float(), 1e-5, 1e-6, 'tile4 e2 conv vs fp64')
+    dy = (rnd(N, Ho, Wo, Cout, seed=33) * 1e-4).to(d)
+    bdy = ops.bound_of(dy)
+    sk, kc = 2, -(-(-(-M // 2)) // 32) * 32
+    parts = []
+    for t in (0, 4):
+        part = torch.zeros(sk, K, Cout, device=d)
+        ops.gemm(x, dy, part, K, Cout, M, Cin, Cout, Cout, a_mode=1, b_mode=0, splitk=sk, kchunk=kc, sCsplit=K * Cout,
+                 geom=geom, tile=t, engine=2, amax_a=bx, amax_b=bdy)
+        parts.append(part.sum(0))
+    assert_close(parts[1], parts[0], 1e-5, 1e-6, 'tile4 e2 wgrad')
+    a, b = x.view(M if k == 1 else N * H * W, Cin), (rnd(Cout, Cin, seed=34) * 0.02).to(d)
+    bb = ops.bound_of(b)
+    zs = []
+    for t in (0, 4):
+        z = torch.empty(a.shape[0], Cout, device=d)
+        ops.gemm(a, b, z, a.shape[0], Cout, Cin, Cin, Cin, Cout, a_mode=0, b_mode=1, tile=t, engine=2, amax_a=bx, amax_b=bb)
+        zs.append(z)
+    assert_close(zs[1], zs[0], 1e-5, 1e-6, 'tile4 e2 linear')
+    assert_close(zs[1], (a.double() @ b.double().t()).float(), 1e-5, 1e-6, 'tile4 e2 linear vs fp64')
 
 
 # ------------------------------------------------------------------------------- hands-stacked (paired) layers
@@ -1037,6 +1094,9 @@ def _torch_attention_block(mods, x, heads, cross):
                                                  (1, 70, 64, 4, 0.1, True), (1, 45, 256, 4, 0.1, False),
                                                  (9, 126, 128, 4, 0.1, False)])
 def test_attention_block_chains(B, S, D, heads, p, cross):
+    from renderih_amd.testing import experiments_built
+    if not experiments_built() and dev().type == 'cuda':
+        pytest.skip('csrc/rih_chain.hip is an experiment outside the default library; build with RIH_BUILD_EXPERIMENTS=1')
     """rih_chain (LayerNorm -> QKV projection; output projection -> dropout -> skip -> LayerNorm -> fc1 + ReLU -> dropout ->
     fc2 -> dropout -> skip, one launch each, both directions) against the standalone launch sequence it replaces with the SAME
     dropout masks: output, input gradient and every parameter gradient; without dropout also against plain torch.  Row counts

@@ -102,6 +102,13 @@ def test_flash_attention_kernels(case):
     G.test_flash_attention_equals_three_kernel_path(*case)
 
 
+_EXPERIMENTS = os.environ.get('RIH_BUILD_EXPERIMENTS', '0') == '1'
+_needs_experiments = pytest.mark.skipif(not _EXPERIMENTS, reason='experiment kernels (rih_chain.hip, rih_gemm3.hip) are outside the '
+                                                                    'default library: RIH_BUILD_EXPERIMENTS=1 compiles them into the '
+                                                                    'host build too')
+
+
+@_needs_experiments
 @pytest.mark.parametrize('case', [(1, 40, 64, 4, 0.1, False), (3, 33, 64, 2, 0.05, False), (1, 70, 64, 4, 0.1, True)])
 def test_row_chain_kernel(case):
     """csrc/rih_chain.hip: the attention block's row-wise sequences as one launch each way, against the standalone kernels
@@ -109,6 +116,7 @@ def test_row_chain_kernel(case):
     G.test_attention_block_chains(*case)
 
 
+@_needs_experiments
 @pytest.mark.skipif(os.environ.get('HIPCPU_MORE', '0') != '1', reason='slow on the fiber harness; HIPCPU_MORE=1')
 def test_row_chain_kernel_wide_blocks():
     G.test_attention_block_chains(2, 63, 128, 4, 0.0, False)
@@ -121,6 +129,7 @@ def test_graph_and_resampling_kernels():
     G.test_resample_hrnet(2, 4, 4, 32)
 
 
+@_needs_experiments
 def test_p3_gemm_kernels():
     """csrc/rih_gemm3.hip: P3 format, LDS-DMA staged 6-product GEMM on all three tiles, epilogue, statistics, dgrad."""
     TP3.test_p3_format_round_trip()
@@ -135,8 +144,9 @@ def test_p3_gemm_kernels():
     TP3.test_p3_data_gradient((2, 8, 8, 64, 32, 3, 1, 1), 1)
 
 
-def test_tile4_pipelined_gemm_kernel():
-    G.test_gemm_tile4_pipelined_kernel((1, 16, 16, 32, 128, 3, 1, 1))        # M = 256: one 256x128 tile, 4-slot ring
+@pytest.mark.parametrize('engine', [1, 2])
+def test_tile4_pipelined_gemm_kernel(engine):
+    G.test_gemm_tile4_pipelined_kernel((1, 16, 16, 32, 128, 3, 1, 1), engine)    # M = 256: one 256x128 tile, 4-slot ring
 
 
 def test_fused_attention_forward(monkeypatch):

@@ -44,6 +44,8 @@ for kind, H, Cin, Cout, k in SHAPES:
     if kind == 'fwd':
         wp = torch.randn(K, Cout, device=dev) / K ** 0.5
         tile, sk = ops.plan_gemm(M, Cout, K, 1, 1)
+        if os.environ.get('RIH_PMC_TILE4', '0') == '1' and Cout >= 128 and K >= 128 and (-(-M // 256)) * (-(-Cout // 128)) >= 128:
+            tile, sk = 4, 1         # the 256x128 software-pipelined kernel on every shape it fits
         kw = dict(amax_a=amax(x), amax_b=amax(wp)) if ENG == 2 else {}
         Bop, ldb, bm = wp, Cout, 0
         if ENG == 2 and PRE:
