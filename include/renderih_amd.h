@@ -135,6 +135,11 @@ int rih_gemm_stats_rows(const rih_gemm_desc* d);
 int rih_gemm_dropout_ok(const rih_gemm_desc* d);
 /* The engine rih_gemm would run `d` on (0 / 1 / 2), or -1 for an invalid descriptor. */
 int rih_gemm_engine(const rih_gemm_desc* d);
+/* 1 when the library was built with the experiment variants of rih_gemm (pre-split operands: a_mode 2 / b_mode 2; the 256x128
+ * software-pipelined kernel: tile 4) and the experiment sources (renderih_amd_experiments.h); the default library returns 0 and
+ * answers RIH_EINVAL for such descriptors.  All of them were built, parity-tested and measured, and none is on a default path
+ * (DESIGN.md 8). */
+int rih_experiments(void);
 /* Bound block: RIH_BOUND_FLOATS floats = 64 partial maxima at a stride of 32 floats (one per 128-byte line; the other floats are
  * unused); THE BOUND IS THE MAXIMUM OF THE 64.  A producer merges its candidates into the lines with atomic maxima (64 lines so
  * that the same-address atomics of thousands of workgroups do not queue up behind one word), a consumer (rih_gemm engine 2) reads

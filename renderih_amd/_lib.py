@@ -200,6 +200,7 @@ SIGNATURES = {
     'rih_gemm_stats_rows': (c_i, [C.POINTER(GemmDesc)]),
     'rih_gemm_dropout_ok': (c_i, [C.POINTER(GemmDesc)]),
     'rih_gemm_engine': (c_i, [C.POINTER(GemmDesc)]),
+    'rih_experiments': (c_i, []),
     'rih_absmax': (c_i, [c_f, c_l, c_f, C.c_void_p]),
     'rih_absmax_multi': (c_i, [C.POINTER(AbsmaxDesc), c_i, C.c_void_p]),
     'rih_gemm_multi_variant': (c_i, [C.POINTER(GemmDesc)]),
@@ -264,7 +265,7 @@ def load():
         fn.restype = res
         fn.argtypes = args
     global HAS_EXPERIMENTS
-    HAS_EXPERIMENTS = all(hasattr(lib, name) for name in EXPERIMENT_SIGNATURES)
+    HAS_EXPERIMENTS = int(lib.rih_experiments()) == 1 and all(hasattr(lib, name) for name in EXPERIMENT_SIGNATURES)
     if HAS_EXPERIMENTS:
         for name, (res, args) in EXPERIMENT_SIGNATURES.items():
             fn = getattr(lib, name)

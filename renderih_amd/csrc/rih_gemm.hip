@@ -15,6 +15,12 @@
 #include "rih_hash.h"
 #include <type_traits>
 
+#ifndef RIH_EXPERIMENTS
+/* 1 (renderih_amd/_build.py: RIH_BUILD_EXPERIMENTS=1) also compiles the kernel variants that were built, parity-tested, measured and
+ * NOT adopted: pre-split operands (a_mode 2 / b_mode 2, engines 1 and 2) and the 256x128 software-pipelined kernel (tile 4, engines 1
+ * and 2).  The default library leaves them out; rih_gemm answers RIH_EINVAL for such a descriptor, rih_experiments() tells. */
+#define RIH_EXPERIMENTS 0
+#endif
 #ifndef RIH_E2_PIPE
 /* engine 2's main loop: 1 = two LDS stages, one barrier per k-tile, conversion half-units interleaved with the MFMAs.  Built,
  * parity-tested and measured in round 4 (profiles/r04/ab/c3_*, c4_*): per shape within +-3 % of the two-barrier loop, whole step
@@ -201,14 +207,24 @@ __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&a
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            if (i + j > 0) __syncthreads();         // the previous block has been read back
+            // (the staging rows are this wavefront's own: a wave-level ordering point is enough, the four waves of the workgroup
+            // store their blocks without waiting for each other -- round 4; before: two workgroup barriers per 32x32 block)
+#if defined(RIH_EPI_BLOCK_BARRIER)      /* A/B partner: the workgroup barriers of rounds 2-3 */
+            if (i + j > 0) __syncthreads();
+#else
+            if (i + j > 0) __builtin_amdgcn_wave_barrier();         // the previous block has been read back
+#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[i][j][r];
                 if (E2) v = fmaf(acc1[i][j][r], 0x1p-11f, v) * inv_a * inv_b;
                 stg[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + l31] = v;
             }
+#if defined(RIH_EPI_BLOCK_BARRIER)
             __syncthreads();
+#else
+            __builtin_amdgcn_wave_barrier();
+#endif
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = (lane >> 3) + 8 * q, c4 = (lane & 7) * 4;
@@ -1429,9 +1445,13 @@ int launch_split_e2(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 
     hipLaunchKernelGGL((gemm_split_kernel<BM, BN, AM_, BM_, PL_, false, ST_, DR_, 2>), grid, block, 0, s, a)
     if (a_mode > 1 || b_mode > 2 || (b_mode == 2 && a_mode != 0)) return RIH_EINVAL;
     if (b_mode == 2) {          // B pre-split into two fp16 planes (weights, once per step)
+#if RIH_EXPERIMENTS
         if (a.drop_thr != 0u) return RIH_EINVAL;
         if (a.stats != nullptr) { if (plain) RIH_L2(0, 2, true, true, false); else RIH_L2(0, 2, false, true, false); }
         else { if (plain) RIH_L2(0, 2, true, false, false); else RIH_L2(0, 2, false, false, false); }
+#else
+        return RIH_EINVAL;
+#endif
     } else
     if (a.drop_thr != 0u) {
         if (b_mode == 0) RIH_L2(0, 0, true, false, true); else RIH_L2(0, 1, true, false, true);
@@ -1451,11 +1471,17 @@ template <int BM, int BN>
 int launch_split(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 grid, hipStream_t s) {
     dim3 block(256);
 #define RIH_LS(AM_, BM_, PL_) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, AM_, BM_, PL_>), grid, block, 0, s, a)
+#if !RIH_EXPERIMENTS
+    if (a_mode == 2 || b_mode == 2) return RIH_EINVAL;      // pre-split operands: experiment builds only
+#endif
+#if RIH_EXPERIMENTS
     if (a_mode == 2) {      // both operands pre-split (b_mode 2 enforced by rih_gemm)
         if (plain) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 2, true, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 2, false, true>), grid, block, 0, s, a);
     }
-    else if (a.drop_thr != 0u) {        // dropout epilogue: plain a_mode-0 GEMMs only (checked by the caller)
+    else
+#endif
+    if (a.drop_thr != 0u) {        // dropout epilogue: plain a_mode-0 GEMMs only (checked by the caller)
         if (b_mode == 0) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 0, true, false, false, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, false, true>), grid, block, 0, s, a);
     }
@@ -1465,7 +1491,9 @@ int launch_split(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 gri
         else { if (plain) RIH_LSS(1, true); else RIH_LSS(1, false); }
 #undef RIH_LSS
     }
+#if RIH_EXPERIMENTS
     else if (a_mode == 0 && b_mode == 2) { if (plain) RIH_LS(0, 2, true); else RIH_LS(0, 2, false); }
+#endif
     else if (a_mode == 0 && b_mode == 0) { if (plain) RIH_LS(0, 0, true); else RIH_LS(0, 0, false); }
     else if (a_mode == 0 && b_mode == 1) { if (plain) RIH_LS(0, 1, true); else RIH_LS(0, 1, false); }
     else if (a_mode == 1 && b_mode == 0) { if (plain) RIH_LS(1, 0, true); else RIH_LS(1, 0, false); }
@@ -1474,6 +1502,7 @@ int launch_split(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 gri
     return (int)hipGetLastError();
 }
 
+#if RIH_EXPERIMENTS
 // ================================================================================================
 // Split engine, 256x128 block tile (tile id 4), software-pipelined in one instruction stream per SIMD.
 // Measured on MI355X: in the 128x128 kernels above the matrix pipe idles while (a) all waves of a block fetch their
@@ -1918,6 +1947,10 @@ int launch_split256(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 
     return (int)hipGetLastError();
 }
 
+#else
+int launch_split256(const GemmArgs&, int, int, bool, dim3, hipStream_t, int) { return RIH_EINVAL; }     // tile 4: experiment builds only
+#endif
+
 // One-launch split-K reduction for weight gradients: each 256-thread block sums an 8x32 tile of the S partial slabs
 // P[s][Mp][N] in a fixed order (deterministic) and writes it transposed into the parameter layout through LDS; blocks
 // past the tile range sum slab row M (the all-ones row of the A operand = column sums of dy) into the bias gradient.
@@ -2355,6 +2388,7 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
     dim3 grid((unsigned)tiles, 1, (unsigned)gz);
     hipStream_t s = (hipStream_t)stream;
     if (d->engine < 0 || d->engine > 2) return RIH_EINVAL;
+    if (!RIH_EXPERIMENTS && (d->tile == 4 || d->a_mode == 2 || d->b_mode == 2)) return RIH_EINVAL;     // (see RIH_EXPERIMENTS)
     // engine 2 exists on the split engines' fast path only (tiles 0..2, operands converted by the kernel): anything else that
     // asks for it runs engine 1 -- same fp32-grade result, the six-product arithmetic (rih_gemm_engine tells in advance)
     const bool e2 = d->engine == 2 && d->tile <= 2 && d->a_mode <= 1 && (d->b_mode <= 1 || (d->b_mode == 2 && d->a_mode == 0));
@@ -2448,6 +2482,7 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
 }
 
 extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) { return gemm_impl(d, stream, nullptr); }
+extern "C" int rih_experiments(void) { return RIH_EXPERIMENTS ? 1 : 0; }
 
 // ---- grouped launch.  Variant id = tile * 8 + a_mode * 4 + b_mode * 2 + plain of the split engine's fast path; the variants
 // instantiated for the grouped kernel are the weight-gradient ones (a_mode 1, b_mode 0; 64x64 and 128x128 tiles) and the

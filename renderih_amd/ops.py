@@ -55,7 +55,7 @@ def plan_gemm(M, N, K, batch=1, engine=None):
     blocks per CU and long k-loops (its per-block prologue/epilogue is expensive), so deep-K problems with few
     output tiles are split over K instead of shrinking the tile."""
     e = ENGINE if engine is None else engine
-    if e == 2 and E2_TILE4 and N >= 128 and K >= E2_TILE4_MINK and _cdiv(M, 256) * _cdiv(N, 128) * batch >= E2_TILE4_MIN:
+    if e == 2 and E2_TILE4 and experiments_built() and N >= 128 and K >= E2_TILE4_MINK and _cdiv(M, 256) * _cdiv(N, 128) * batch >= E2_TILE4_MIN:
         # engine 2's 256x128 software-pipelined kernel (one workgroup per CU, conversion interleaved with the MFMAs by hand):
         # large-M problems with at least E2_TILE4_MIN workgroups
         return 4, 1
@@ -95,7 +95,9 @@ def plan_gemm(M, N, K, batch=1, engine=None):
 
 
 _TILE_MN = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (256, 128)}
-# RIH_E2_TILE4=1: the planner may pick the 256x128 pipelined kernel for engine-2 launches (see plan_gemm)
+# RIH_E2_TILE4=1 (experiment builds): the planner may pick the 256x128 pipelined kernel for engine-2 launches (see plan_gemm).
+# Measured in round 4: 361 us against 293-318 on the 64x64 128->128 3x3 convolution, the whole step -3 % (profiles/r04/ab/c5_*,
+# gemm_pmc_table_top12_engine2_tile4_c5_NEGATIVE.txt): at one wavefront per SIMD the conversion work is not hidden.
 E2_TILE4 = os.environ.get('RIH_E2_TILE4', '0') == '1'
 E2_TILE4_MIN = int(os.environ.get('RIH_E2_TILE4_MIN', '192'))
 E2_TILE4_MINK = int(os.environ.get('RIH_E2_TILE4_MINK', '256'))
@@ -315,10 +317,25 @@ def _presplit_act(x2d_rows, C, x):
     return planes
 
 
+_EXPERIMENTS_BUILT = None
+
+
+def experiments_built():
+    """The loaded library contains the non-adopted kernel variants (rih_experiments(): pre-split operands, tile 4)."""
+    global _EXPERIMENTS_BUILT
+    lib = _L()
+    if _EXPERIMENTS_BUILT is None or _EXPERIMENTS_BUILT[0] is not lib:
+        _EXPERIMENTS_BUILT = (lib, int(lib.rih_experiments()) == 1)
+    return _EXPERIMENTS_BUILT[1]
+
+
 def _presplit_ok(Ngemm, Kchan, taps, engine=None, abytes=0):
-    """Preconditions of the b_mode 2 fast path: a split engine, a 64-wide-or-larger tile, 32-channel-aligned gather."""
+    """Preconditions of the b_mode 2 fast path: a split engine, a 64-wide-or-larger tile, 32-channel-aligned gather -- and a
+    library built with the experiment variants (RIH_PRESPLIT / RIH_E2_PRESPLIT raise otherwise: an explicit request)."""
     e = ENGINE if engine is None else engine
     on = (PRESPLIT and e == 1) or (E2_PRESPLIT and e == 2)
+    if on and not experiments_built():
+        raise RuntimeError('renderih_amd: RIH_PRESPLIT / RIH_E2_PRESPLIT need a library built with RIH_BUILD_EXPERIMENTS=1')
     return on and Ngemm > 32 and Kchan % 32 == 0 and taps <= 32 and abytes < (1 << 31)
 
 

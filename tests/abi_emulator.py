@@ -213,6 +213,9 @@ class EmulatedLib:
             ok = ok and d.Wo % 4 == 0 and d.Cin % 4 == 0
         return (d.tile * 8 + 4 + (1 if plain else 0) + (64 if d.engine == 2 else 0)) if ok else -1
 
+    def rih_experiments(self):
+        return 1            # the emulation restates every entry point, the experiment variants included
+
     def rih_gemm_engine(self, dref):
         """The header's contract, restated: engine 2 exists on the fast path of tiles 0..2 only, engine 1 runs otherwise."""
         d = dref._obj if hasattr(dref, '_obj') else dref

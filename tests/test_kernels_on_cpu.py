@@ -22,6 +22,12 @@ import test_pose_head as TP         # noqa: E402
 CPU = torch.device('cpu')
 
 
+_EXPERIMENTS = os.environ.get('RIH_BUILD_EXPERIMENTS', '0') == '1'
+_needs_experiments = pytest.mark.skipif(not _EXPERIMENTS, reason='experiment kernels (rih_chain.hip, rih_gemm3.hip) are outside the '
+                                                                    'default library: RIH_BUILD_EXPERIMENTS=1 compiles them into the '
+                                                                    'host build too')
+
+
 @pytest.fixture(autouse=True)
 def _host_kernels(monkeypatch):
     from host_kernels import host_kernels_abi
@@ -102,12 +108,6 @@ def test_flash_attention_kernels(case):
     G.test_flash_attention_equals_three_kernel_path(*case)
 
 
-_EXPERIMENTS = os.environ.get('RIH_BUILD_EXPERIMENTS', '0') == '1'
-_needs_experiments = pytest.mark.skipif(not _EXPERIMENTS, reason='experiment kernels (rih_chain.hip, rih_gemm3.hip) are outside the '
-                                                                    'default library: RIH_BUILD_EXPERIMENTS=1 compiles them into the '
-                                                                    'host build too')
-
-
 @_needs_experiments
 @pytest.mark.parametrize('case', [(1, 40, 64, 4, 0.1, False), (3, 33, 64, 2, 0.05, False), (1, 70, 64, 4, 0.1, True)])
 def test_row_chain_kernel(case):
@@ -144,6 +144,7 @@ def test_p3_gemm_kernels():
     TP3.test_p3_data_gradient((2, 8, 8, 64, 32, 3, 1, 1), 1)
 
 
+@_needs_experiments
 @pytest.mark.parametrize('engine', [1, 2])
 def test_tile4_pipelined_gemm_kernel(engine):
     G.test_gemm_tile4_pipelined_kernel((1, 16, 16, 32, 128, 3, 1, 1), engine)    # M = 256: one 256x128 tile, 4-slot ring
@@ -221,6 +222,7 @@ def test_metrics_and_pose_head_kernels():
     TP._pose_head_kernels_vs_oracle(CPU)
 
 
+@_needs_experiments
 @pytest.mark.parametrize('case', [
     (2, 8, 8, 64, 64, 3, 1, 1, True, True),         # 3x3: forward + stride-1 data gradient read pre-split weights
     (1, 8, 8, 64, 64, 3, 2, 1, False, False),       # strided: one pre-split tap subset per parity class
@@ -242,6 +244,7 @@ def test_presplit_weight_path(monkeypatch, case):
     assert (True in calls) == (Cin > 32 and Cout % 32 == 0), calls      # ... and the data-gradient operand where eligible
 
 
+@_needs_experiments
 @pytest.mark.parametrize('case', [
     (2, 8, 8, 32, 64, 3, 1, 1, False, True),
     (1, 9, 7, 64, 96, 3, 2, 1, True, False),        # strided: parity-class data gradients from tap-subset planes
@@ -274,6 +277,7 @@ def test_engine2_presplit_weight_planes(monkeypatch, case, packed):
     assert False in calls, calls
 
 
+@_needs_experiments
 @pytest.mark.parametrize('case', [
     (2, 8, 8, 64, 64, 3, 1, 1, True, True),
     (1, 8, 8, 64, 64, 3, 2, 1, False, False),
@@ -294,6 +298,7 @@ def test_presplit_activation_path(monkeypatch, case):
     assert len(acts) >= 1, 'the activation planes were never used'
 
 
+@_needs_experiments
 def test_presplit_matrix_entry_point():
     """rih_presplit_matrix on a plain [N][K] weight + b_mode 2 GEMM == the fp32 product."""
     import math
@@ -628,6 +633,7 @@ def test_kernels_are_schedule_independent(sched):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@_needs_experiments
 def test_presplit_gemm_descriptor_fuzz_against_emulator():
     """As the descriptor fuzz above, for the pre-split operand modes (b_mode 2 with a_mode 0 or 2): conv gathers with
     strides / padding / 2x2..3x3 taps, plain rows, split-K, all three tiles, partial N tiles."""

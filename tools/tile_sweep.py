@@ -11,6 +11,14 @@ from gemm_bench import time_launch  # noqa: E402
 
 dev = torch.device('cuda:0')
 B = 64
+ENG = int(os.environ.get('RIH_SWEEP_ENGINE', '1'))      # 2: engine 2 with operand bounds by rih_absmax
+
+
+def _bound(t):
+    a = torch.zeros(2048, device=dev)
+    ops.check(ops._L().rih_absmax(t.data_ptr(), t.numel(), a.data_ptr(), ops._stream()), 'rih_absmax')
+    return a
+
 # (H, Cin, Cout, k) stride-1 layers (count per step); the planner sees forward (Cin->Cout) and data-gradient (Cout->Cin)
 LAYERS = [(64, 64, 64, 1), (64, 64, 64, 3), (64, 64, 256, 1), (64, 256, 64, 1), (64, 256, 128, 1), (32, 128, 128, 3),
           (32, 128, 512, 1), (32, 512, 128, 1), (32, 512, 256, 1), (16, 256, 256, 3), (16, 256, 1024, 1),
@@ -26,14 +34,15 @@ def fwd(H, Cin, Cout, k):
     y = torch.empty(B, H, H, Cout, device=dev)
     M, K = B * H * H, k * k * Cin
     geom = (H, H, Cin, H, H, k, k, 1, 1, p, p)
-    pick, sk = ops.plan_gemm(M, Cout, K, 1, 1)
+    pick, sk = ops.plan_gemm(M, Cout, K, 1, ENG)
+    kw = dict(amax_a=_bound(x), amax_b=_bound(w)) if ENG == 2 else {}
     res = {}
     for t in (0, 1, 2, 4):
         try:
-            res[t] = time_launch(lambda: ops.gemm(x, w, y, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=t, engine=1), 10)
+            res[t] = time_launch(lambda: ops.gemm(x, w, y, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=t, engine=ENG, **kw), 10)
         except RuntimeError:
-            res[t] = float('inf')       # the 256x128 kernel has preconditions (Cin % 32, N % 4)
-    us_plan = time_launch(lambda: ops.gemm(x, w, y, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, engine=1), 10)
+            res[t] = float('inf')       # the 256x128 kernel has preconditions (Cin % 32, N % 4) and is an experiment variant
+    us_plan = time_launch(lambda: ops.gemm(x, w, y, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, engine=ENG, **kw), 10)
     best = min(res, key=res.get)
     flag = '' if us_plan <= 1.05 * res[best] else '   <-- planner loses %.0f%%' % (100 * (us_plan / res[best] - 1))
     print('fwd  %3dx%-3d %4d->%-4d k%d | M%-7d N%-5d K%-5d | t0 %7.1f t1 %7.1f t2 %7.1f t4 %7.1f | plan t%d sk%d %7.1f us%s'
@@ -74,5 +83,6 @@ if __name__ == '__main__':
         fwd(*L)
         if L[1] != L[2]:
             fwd(L[0], L[2], L[1], L[3])       # the data gradient of a stride-1 conv has the channels swapped
-    for L in LAYERS:
-        wgrad(*L)
+    if os.environ.get('RIH_SWEEP_WGRAD', '1') == '1':
+        for L in LAYERS:
+            wgrad(*L)
