@@ -130,6 +130,15 @@ typedef struct rih_gemm_desc {
      * [-2^15, 2^15] (scale 1). */
     const float* amax_a;
     const float* amax_b;
+    /* Segmented A (ABI 13): A = [A | a_seg[0] | a_seg[1] | a_seg[2]] along K -- columns [0, k_seg[0]) come from A (pitch lda),
+     * columns [k_seg[i], k_seg[i+1]) from a_seg[i] (pitch lda_seg[i]; the last piece ends at K); unused pieces NULL.  The
+     * channel concatenation in front of a 1x1 convolution (models/encoder.py:165-173: `torch.cat((hms_fmaps[i], dp_fmaps[i],
+     * img_fmaps[i]), dim=1)` -> conv1x1) is then read in place instead of being materialised.  Plain row-major pieces only
+     * (a_mode 0 without im2col geometry), b_mode 1, one batch slice, no split-K; every k_seg a multiple of 32, pieces 16-byte
+     * aligned; engines 1 and 2 on the fast path of tiles 0..2 (statistics epilogue available), RIH_EINVAL otherwise. */
+    const float* a_seg[3];
+    int32_t lda_seg[3];
+    int32_t k_seg[3];
 } rih_gemm_desc;
 int rih_gemm_stats_rows(const rih_gemm_desc* d);
 int rih_gemm_dropout_ok(const rih_gemm_desc* d);
@@ -186,7 +195,7 @@ int rih_splitk_reduce(float* P, int S, int M, int N, float* dst, int Cin, int ta
  * operand carries an all-ones row there (rih_gemm_desc.ones_row) -- is summed into the bias gradient db[N]. */
 int rih_splitk_reduce_bias(const float* P, int S, int Mp, int M, int N, float* dst, int Cin, int taps, int CinValid,
                            int accumulate, float* db, void* stream);
-/* Any number of independent reductions (each as rih_splitk_reduce_bias) in ceil(n/60) launches: the split-K partials of
+/* Any number of independent reductions (each as rih_splitk_reduce_bias) in ceil(n/56) launches: the split-K partials of
  * the weight gradients of a whole backward stage are summed at the END of the stage instead of one small launch behind
  * every weight-gradient GEMM (157 launches of ~8 us per ResNet50 step; a dependent kernel costs >= 4.5 us on this
  * platform whatever its size).  `descs` is HOST memory, read before the call returns.  Same fixed summation order. */
@@ -195,6 +204,9 @@ typedef struct rih_reduce_desc {
     float* dst;             /* parameter-layout gradient, see rih_splitk_reduce */
     float* db;              /* optional bias gradient [N] from slab row M, or NULL */
     int32_t S, Mp, M, N, Cin, taps, CinValid, accumulate;
+    int32_t CinPitch;       /* 0: dst is the whole parameter [N][CinValid][taps]; > 0: dst points at the first of CinValid columns of a
+                               wider parameter [N][CinPitch][taps] (the column slice of one part of a concatenated input, a_seg) */
+    int32_t reserved;
 } rih_reduce_desc;
 int rih_splitk_reduce_multi(const rih_reduce_desc* descs, int n, void* stream);
 /* nb independent reductions in one launch: slice b reads P + b*sP and writes dst + b*sDst, db + b*sDb (the split-K

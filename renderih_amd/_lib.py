@@ -30,7 +30,8 @@ class GemmDesc(C.Structure):
                 ('cS', C.c_int32), ('cOH', C.c_int32), ('cOW', C.c_int32), ('cH', C.c_int32), ('cW', C.c_int32), ('ones_row', C.c_int32),
                 ('reserved0', C.c_int32), ('sBias1', C.c_int64), ('sR1', C.c_int64), ('stats', C.c_void_p),
                 ('drop_p', C.c_float), ('reserved1', C.c_int32), ('drop_seed', C.c_uint64), ('drop_seed_dev', C.c_void_p),
-                ('amax_a', C.c_void_p), ('amax_b', C.c_void_p)]
+                ('amax_a', C.c_void_p), ('amax_b', C.c_void_p),
+                ('a_seg', C.c_void_p * 3), ('lda_seg', C.c_int32 * 3), ('k_seg', C.c_int32 * 3)]
 
 
 class GemmP3Desc(C.Structure):
@@ -43,7 +44,7 @@ class GemmP3Desc(C.Structure):
 
 class ReduceDesc(C.Structure):
     _fields_ = [('P', C.c_void_p), ('dst', C.c_void_p), ('db', C.c_void_p)] + \
-               [(n, C.c_int32) for n in ('S', 'Mp', 'M', 'N', 'Cin', 'taps', 'CinValid', 'accumulate')]
+               [(n, C.c_int32) for n in ('S', 'Mp', 'M', 'N', 'Cin', 'taps', 'CinValid', 'accumulate', 'CinPitch', 'reserved')]
 
 
 class PresplitDesc(C.Structure):

@@ -69,6 +69,12 @@ struct GemmArgs {
     // engine 2 (two-term fp16 split): device-resident upper bounds of |A|, |B| (bound blocks, rih_absmax), or NULL = 1.0
     const float* amax_a;
     const float* amax_b;
+    // segmented A (rih_gemm_desc.a_seg, plain a_mode 0 on the fast path): columns [kseg[i-1], kseg[i]) of A come from Aseg[i-1]
+    // (pitch ldaseg[i-1], extent aseg_bytes[i-1]); Aseg[0] == NULL: one operand
+    const float* Aseg[3];
+    int ldaseg[3];
+    int kseg[3];
+    unsigned aseg_bytes[3];
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -208,23 +214,16 @@ __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&a
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             // (the staging rows are this wavefront's own: a wave-level ordering point is enough, the four waves of the workgroup
-            // store their blocks without waiting for each other -- round 4; before: two workgroup barriers per 32x32 block)
-#if defined(RIH_EPI_BLOCK_BARRIER)      /* A/B partner: the workgroup barriers of rounds 2-3 */
-            if (i + j > 0) __syncthreads();
-#else
+            // store their blocks without waiting for each other -- round 4; before: two workgroup barriers per 32x32 block;
+            // same-box A/B 1936.8 / 1937.1 against 1937.2 / 1932.5 images/s: neutral, kept as the simpler form)
             if (i + j > 0) __builtin_amdgcn_wave_barrier();         // the previous block has been read back
-#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[i][j][r];
                 if (E2) v = fmaf(acc1[i][j][r], 0x1p-11f, v) * inv_a * inv_b;
                 stg[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + l31] = v;
             }
-#if defined(RIH_EPI_BLOCK_BARRIER)
-            __syncthreads();
-#else
             __builtin_amdgcn_wave_barrier();
-#endif
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = (lane >> 3) + 8 * q, c4 = (lane & 7) * 4;
@@ -810,10 +809,12 @@ __device__ __forceinline__ uint4 bloadu4(__amdgpu_buffer_rsrc_t r, unsigned off)
 // (gemm_split_multi_kernel, rih_gemm_multi) the coordinates of a block inside ITS problem of a descriptor table.
 // ENG 2: the two-term fp16 split (three MFMA products, see e2_scale / split2h above) instead of the three-term bf16 one; same
 // loaders, LDS layout (two planes instead of three) and epilogue.  Not with pre-split operands.
-template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false, int ENG = 1>
+template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false, int ENG = 1,
+          bool SEG = false>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk_x, const int blk_z, const int grid_x,
                                                 const int grid_z) {
     static_assert(ENG == 1 || (ENG == 2 && !APRE), "engine 2: B may arrive as two pre-split fp16 planes (BMODE 2), A never");
+    static_assert(!SEG || (AMODE == 0 && PLAIN && !APRE), "a segmented A operand is a plain row-major one");
     constexpr int NPL = (ENG == 2) ? 2 : 3;         // 16-bit planes per operand
     // global->register prefetch depth: k-tiles in flight.  The 64x64 tile (decoder-sized problems: a handful of
     // k-tiles, 12 MFMAs each) is bound by the load round trip per k-tile, so it keeps three tiles in flight.
@@ -872,6 +873,13 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + b1 * p.sA1 + b2 * p.sA2), (short)0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + b1 * p.sB1 + b2 * p.sB2), (short)0, (int)p.b_bytes, 0x00020000);
+    // segmented A: one more resource per further segment (never read when SEG is off; NULL segments get an empty extent)
+    const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)(SEG ? p.Aseg[0] : p.A), (short)0,
+                                                                         SEG ? (int)p.aseg_bytes[0] : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(SEG && p.Aseg[1] ? p.Aseg[1] : p.A), (short)0,
+                                                                         SEG && p.Aseg[1] ? (int)p.aseg_bytes[1] : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA3 = __builtin_amdgcn_make_buffer_rsrc((void*)(SEG && p.Aseg[2] ? p.Aseg[2] : p.A), (short)0,
+                                                                         SEG && p.Aseg[2] ? (int)p.aseg_bytes[2] : 0, 0x00020000);
 
     const int kbeg = split * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
@@ -1040,7 +1048,22 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
                     apre[st][pl][i] = bloadu4(rA, ok ? ap_off[i] + add + (unsigned)pl * p.a_plane : OOB);
                 }
         } else if (AMODE == 0) {
-            if (PLAIN) {
+            if (PLAIN && SEG) {
+                // the k-tile lies in ONE segment (boundaries are multiples of 32): wave-uniform choice of base, pitch and extent;
+                // a channel concatenation (models/encoder.py:165-173) is read in place, never materialised
+                const bool in_k = ktile + 4 * q8 < kend;
+                auto seg_load = [&](const __amdgpu_buffer_rsrc_t r, const int lda_s, const int k0) {
+                    const unsigned ku = in_k ? (unsigned)(ktile - k0 + 4 * q8) * 4u : OOB;
+#pragma unroll
+                    for (int i = 0; i < NPA; ++i)
+                        areg[st][i] = bload4(r, (a_off[i] == OOB || ku == OOB) ? OOB
+                                                    : (unsigned)(m0 + row8 + 32 * i) * (unsigned)lda_s * 4u + ku);
+                };
+                if (ktile < p.kseg[0]) seg_load(rA, p.lda, 0);
+                else if (p.Aseg[1] == nullptr || ktile < p.kseg[1]) seg_load(rA1, p.ldaseg[0], p.kseg[0]);
+                else if (p.Aseg[2] == nullptr || ktile < p.kseg[2]) seg_load(rA2, p.ldaseg[1], p.kseg[1]);
+                else seg_load(rA3, p.ldaseg[2], p.kseg[2]);
+            } else if (PLAIN) {
                 const unsigned ku = (ktile + 4 * q8 < kend) ? (unsigned)ktile * 4u : OOB;
 #pragma unroll
                 for (int i = 0; i < NPA; ++i) areg[st][i] = bload4(rA, a_off[i] + ku);
@@ -1393,10 +1416,11 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
     }
 }
 
-template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false, int ENG = 1>
+template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false, int ENG = 1,
+          bool SEG = false>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
-    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, APRE, STATS, DROP, ENG>(p, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.x,
-                                                                         (int)gridDim.z);
+    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, APRE, STATS, DROP, ENG, SEG>(p, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.x,
+                                                                              (int)gridDim.z);
 }
 
 // ---- grouped launch (rih_gemm_multi): n independent problems of ONE kernel variant in one launch.  The table lives in device
@@ -1444,6 +1468,11 @@ int launch_split_e2(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 
 #define RIH_L2(AM_, BM_, PL_, ST_, DR_) \
     hipLaunchKernelGGL((gemm_split_kernel<BM, BN, AM_, BM_, PL_, false, ST_, DR_, 2>), grid, block, 0, s, a)
     if (a_mode > 1 || b_mode > 2 || (b_mode == 2 && a_mode != 0)) return RIH_EINVAL;
+    if (a.Aseg[0] != nullptr) {         // segmented A: plain rows x [N][K] weight (checked by the caller), with / without statistics
+        if (a.stats != nullptr) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, true, false, 2, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, false, false, 2, true>), grid, block, 0, s, a);
+        return (int)hipGetLastError();
+    }
     if (b_mode == 2) {          // B pre-split into two fp16 planes (weights, once per step)
 #if RIH_EXPERIMENTS
         if (a.drop_thr != 0u) return RIH_EINVAL;
@@ -1474,6 +1503,11 @@ int launch_split(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 gri
 #if !RIH_EXPERIMENTS
     if (a_mode == 2 || b_mode == 2) return RIH_EINVAL;      // pre-split operands: experiment builds only
 #endif
+    if (a.Aseg[0] != nullptr) {         // segmented A (see launch_split_e2)
+        if (a.stats != nullptr) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, true, false, 1, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, false, false, 1, true>), grid, block, 0, s, a);
+        return (int)hipGetLastError();
+    }
 #if RIH_EXPERIMENTS
     if (a_mode == 2) {      // both operands pre-split (b_mode 2 enforced by rih_gemm)
         if (plain) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 2, true, true>), grid, block, 0, s, a);
@@ -1956,7 +1990,9 @@ int launch_split256(const GemmArgs&, int, int, bool, dim3, hipStream_t, int) { r
 // past the tile range sum slab row M (the all-ones row of the A operand = column sums of dy) into the bias gradient.
 __device__ __forceinline__ void splitk_reduce_block(const float* __restrict__ P, int S, int Mp, int M, int N,
                                                     float* __restrict__ dst, int Cin, int taps, int CinValid, int accumulate,
-                                                    float* __restrict__ db, int ntiles, int bx) {
+                                                    float* __restrict__ db, int ntiles, int bx, int CinPitch = 0) {
+    // CinPitch > 0: dst is a column slice of a wider [N][CinPitch][taps] parameter (rih_reduce_desc.CinPitch)
+    const int pitch = CinPitch > 0 ? CinPitch : CinValid;
     const long long slab = (long long)Mp * N;
     if (bx >= ntiles) {
         const int n = (bx - ntiles) * 256 + threadIdx.x;
@@ -1998,7 +2034,7 @@ __device__ __forceinline__ void splitk_reduce_block(const float* __restrict__ P,
         if (m < M && n < N) {
             const int tap = m / Cin, ci = m - tap * Cin;
             if (ci < CinValid) {
-                const long long o = ((long long)n * CinValid + ci) * taps + tap;
+                const long long o = ((long long)n * pitch + ci) * taps + tap;
                 const float v = tile[threadIdx.x & 7][threadIdx.x >> 3];
                 dst[o] = accumulate ? dst[o] + v : v;
             }
@@ -2020,7 +2056,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_fused_kernel(const float* _
 // Many independent reductions in ONE launch (rih_splitk_reduce_multi): the descriptors travel by value in the kernel
 // argument (<= 4 KB), so the launch is self-contained -- no device table to upload, and a hipGraph captures it as is.
 // A block finds its descriptor by scanning the exclusive prefix of block counts (<= REDUCE_PACK scalar compares).
-constexpr int REDUCE_PACK = 60;
+constexpr int REDUCE_PACK = 56;
 struct ReducePack {
     rih_reduce_desc d[REDUCE_PACK];
     int first[REDUCE_PACK + 1];         // first block of descriptor i; first[n] = total
@@ -2034,7 +2070,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(const ReducePa
     while (i + 1 < pk.n && b >= pk.first[i + 1]) ++i;
     const rih_reduce_desc& d = pk.d[i];
     splitk_reduce_block(d.P, d.S, d.Mp, d.M, d.N, d.dst, d.Cin, d.taps, d.CinValid, d.accumulate, d.db, pk.ntiles[i],
-                        b - pk.first[i]);
+                        b - pk.first[i], d.CinPitch);
 }
 
 // Forward split-K finish: C[m*ldc+n] = act(alpha * sum_s P[s][m][n] + bias[n] + R[m*ldr+n])
@@ -2357,6 +2393,32 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
     a.stats = d->stats;
     a.drop_thr = 0u; a.drop_scale = 1.f; a.drop_seed = 0ull; a.drop_seed_dev = nullptr;
     a.amax_a = d->amax_a; a.amax_b = d->amax_b;
+    for (int i = 0; i < 3; ++i) { a.Aseg[i] = nullptr; a.ldaseg[i] = 0; a.kseg[i] = 0; a.aseg_bytes[i] = 0; }
+    bool seg = false;
+    if (d->a_seg[0] != nullptr) {
+        // A = [A | a_seg[0] | a_seg[1] | a_seg[2]] along K: plain row-major pieces (a_mode 0, no im2col), b_mode 1, one batch slice,
+        // no split-K, every boundary a multiple of 32, 16-byte aligned pieces; the split engines' fast path only
+        seg = true;
+        int prev = 0;
+        for (int i = 0; i < 3; ++i) {
+            if (d->a_seg[i] == nullptr) {
+                for (int j = i; j < 3; ++j) if (d->a_seg[j] != nullptr) return RIH_EINVAL;
+                break;
+            }
+            const int k0 = d->k_seg[i], k1 = (i < 2 && d->a_seg[i + 1] != nullptr) ? d->k_seg[i + 1] : d->K;
+            if (k0 <= prev || k0 % 32 != 0 || k1 <= k0 || d->lda_seg[i] < k1 - k0 || d->lda_seg[i] % 4 != 0 ||
+                ((uintptr_t)d->a_seg[i] % 16) != 0)
+                return RIH_EINVAL;
+            const long long bytes = ((long long)(d->M - 1) * d->lda_seg[i] + (k1 - k0)) * 4ll;
+            if (bytes >= (1ll << 31)) return RIH_EINVAL;
+            a.Aseg[i] = d->a_seg[i]; a.ldaseg[i] = d->lda_seg[i]; a.kseg[i] = k0; a.aseg_bytes[i] = (unsigned)bytes;
+            prev = k0;
+        }
+        if (d->a_mode != 0 || d->b_mode != 1 || d->nb1 * d->nb2 != 1 || d->splitk != 1 || d->cS > 1 || d->drop_p != 0.f ||
+            d->tile > 2 || d->engine < 1 || d->lda < d->k_seg[0] ||
+            !(d->KH == 1 && d->KW == 1 && d->strideA == 1 && d->padH == 0 && d->padW == 0 && d->H == d->Ho && d->W == d->Wo))
+            return RIH_EINVAL;
+    }
     if (d->drop_p != 0.f) {
         if (!(d->drop_p > 0.f && d->drop_p < 1.f)) return RIH_EINVAL;
         double t = (double)d->drop_p * 4294967296.0;            // = drop_thresh() of csrc/rih_elem.hip
@@ -2400,7 +2462,7 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
                             d->H == d->Ho && d->W == d->Wo);
         const long long rowsA = (d->a_mode != 1) ? (long long)d->M : (long long)d->K;
         const long long imgs = (rowsA + (long long)d->Ho * d->Wo - 1) / ((long long)d->Ho * d->Wo);
-        const int colsA = (d->a_mode != 1) ? d->K : (d->ones_row > 0 ? d->ones_row : d->M);
+        const int colsA = seg ? d->k_seg[0] : (d->a_mode != 1) ? d->K : (d->ones_row > 0 ? d->ones_row : d->M);
         const long long a_rows = plain ? rowsA : imgs * d->H * d->W;
         const long long a_plane = a_rows * d->lda * 2ll;                   // a_mode 2: bytes per bf16 plane
         const long long a_bytes = (d->a_mode == 2) ? 3ll * a_plane
@@ -2441,6 +2503,7 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
             return 0;
         }
         if (d->b_mode == 2 && d->engine == 2 && !(ok && e2)) return RIH_EINVAL;     // (no kernel reads two fp16 planes elsewhere)
+        if (seg && (!ok || prep != nullptr)) return RIH_EINVAL;                      // (no other kernel reads a segmented A)
         if (ok) {
             a.a_bytes = (unsigned)a_bytes;
             a.b_bytes = (unsigned)b_bytes;
@@ -2465,7 +2528,7 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
             return launch_split<64, 64>(a, d->a_mode, d->b_mode, plain, grid, s);
         }
     }
-    if (d->drop_p != 0.f) return RIH_EINVAL;                  // the general kernels have no dropout epilogue
+    if (d->drop_p != 0.f || seg) return RIH_EINVAL;           // the general kernels have no dropout epilogue / segmented A
     if (stats_rows != nullptr) { *stats_rows = 0; return 0; }
     if (prep != nullptr) return RIH_EINVAL;                   // not a fast-path descriptor: no grouped launch
     if (d->stats != nullptr) return RIH_EINVAL;
@@ -2613,6 +2676,7 @@ extern "C" int rih_splitk_reduce_multi(const rih_reduce_desc* descs, int n, void
         if (!d.P || !d.dst || d.S < 1 || d.M < 1 || d.Mp < d.M || d.N < 1 || d.Cin < 1 || d.taps < 1 || d.CinValid < 1)
             return RIH_EINVAL;
         if (d.db && d.Mp < d.M + 1) return RIH_EINVAL;
+        if (d.CinPitch != 0 && d.CinPitch < d.CinValid) return RIH_EINVAL;
     }
     for (int base = 0; base < n; base += REDUCE_PACK) {
         ReducePack pk;

@@ -302,18 +302,23 @@ class resnet_mid(nn.Module):
                 fmaps.append(None)
                 continue
             parts = [hms_fmaps[i], dp_fmaps[i]] + ([img_fmaps[i]] if i > 0 else [])
-            x = ops.cat_channels(parts)                      # channel concat = last dim in NHWC (pure copy)
+            # the channel concatenation of models/encoder.py:165-173 is never materialised: the 1x1 convolution reads its parts in
+            # place (ops.conv1x1_cat: a segmented GEMM operand; data and weight gradients per part, no slice copies)
+            assert seq[0].bias is None
             if drop_last and i == last:
                 with torch.no_grad():
                     holder = ops.StatsHolder() if ops.GEMM_STATS else None
-                    y = ops.conv2d(x, seq[0].weight, seq[0].bias, stride=1, pad=0, relu=True, stats=holder)
+                    y = ops.conv1x1_cat(parts, seq[0].weight, relu=True, stats=holder)
                     stats = ('blocks', holder.part, holder.T, holder.rows) if (holder is not None and holder.part is not None) else None
                     ops.batchnorm_update_only(y, bn.running_mean, bn.running_var, eps=bn.eps, momentum=bn.momentum, tile_stats=stats)
                 if bn.num_batches_tracked is not None:
                     _PENDING_TRACKED.append(bn.num_batches_tracked)
                 fmaps.append(None)
                 continue
-            fmaps.append(conv_bn(seq[0], bn, x, conv_relu=True))
+            holder = ops.StatsHolder() if (ops.GEMM_STATS and bn.training) else None
+            y = ops.conv1x1_cat(parts, seq[0].weight, relu=True, stats=holder)
+            stats = ('blocks', holder.part, holder.T, holder.rows) if (holder is not None and holder.part is not None) else None
+            fmaps.append(bn_act(bn, y, tile_stats=stats, input_relu=True))
         flush_batches_tracked()
         return gf, fmaps
 

@@ -59,6 +59,10 @@ def plan_gemm(M, N, K, batch=1, engine=None):
         # engine 2's 256x128 software-pipelined kernel (one workgroup per CU, conversion interleaved with the MFMAs by hand):
         # large-M problems with at least E2_TILE4_MIN workgroups
         return 4, 1
+    if e == 2 and E2_SHORTK_T1 and K <= 256 and N >= 64 and _cdiv(M, 128) * _cdiv(N, 64) * batch >= 512:
+        # engine 2, short reductions on large maps (the 1x1 convolutions of layer1 / layer2 and their data gradients): 128x64
+        # tiles beat the 64x64 tiles of engine 1's rule by 5-15 % and the 128x128 ones by 3-8 % (profiles/r04/tile_sweep_engine2_c6.log)
+        return 1, 1
     e = min(e, 1)            # otherwise engine 2 shares engine 1's kernels' structure: planned alike
     if N <= 32:
         # 16 < N <= 32 (HRNet's 32-channel branch): a half-empty split-engine tile beats the 128x32 tile of the native-f32
@@ -98,6 +102,7 @@ _TILE_MN = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (256, 128
 # RIH_E2_TILE4=1 (experiment builds): the planner may pick the 256x128 pipelined kernel for engine-2 launches (see plan_gemm).
 # Measured in round 4: 361 us against 293-318 on the 64x64 128->128 3x3 convolution, the whole step -3 % (profiles/r04/ab/c5_*,
 # gemm_pmc_table_top12_engine2_tile4_c5_NEGATIVE.txt): at one wavefront per SIMD the conversion work is not hidden.
+E2_SHORTK_T1 = os.environ.get('RIH_E2_SHORTK_TILE1', '1') == '1'       # engine 2: 128x64 tiles for short reductions on large maps
 E2_TILE4 = os.environ.get('RIH_E2_TILE4', '0') == '1'
 E2_TILE4_MIN = int(os.environ.get('RIH_E2_TILE4_MIN', '192'))
 E2_TILE4_MINK = int(os.environ.get('RIH_E2_TILE4_MINK', '256'))
@@ -373,8 +378,10 @@ class StatsHolder:
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=None, ldr=0,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, kchunk=0, sCsplit=0, alpha=1.0, relu=False,
          geom=None, tile=None, engine=None, cstride=None, ones_row=0, sBias=0, sR=0, collect=None, stats=None, drop=None,
-         amax_a=None, amax_b=None):
+         amax_a=None, amax_b=None, a_seg=None):
     """Enqueue one rih_gemm.  A/B/Cout/bias/R are tensors or raw device pointers.
+    a_seg: [(tensor, pitch, first column), ...] -- up to three further pieces of a segmented A operand (rih_gemm_desc.a_seg);
+    `lda` / `A` describe the first piece.
     cstride = (s, oh, ow, H, W): store GEMM row (img, i, j) to pixel (img, i*s+oh, j*s+ow) of a [*, H, W] tensor.
     collect: a GroupedGemms -- the problem joins its next grouped launch (rih_gemm_multi) when its kernel variant can ride
     in one, instead of being launched now; the operands are kept alive until then.
@@ -387,6 +394,9 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
     descriptor takes engine 2's kernels) holding an upper bound of max|A| / max|B| (rih_gemm_desc.amax_a); a call site that
     passes none for either operand runs engine 1."""
     d = GemmDesc()
+    if a_seg:
+        for i, (t, ld, k0) in enumerate(a_seg):
+            d.a_seg[i], d.lda_seg[i], d.k_seg[i] = t.data_ptr(), ld, k0
     if cstride is not None:
         d.cS, d.cOH, d.cOW, d.cH, d.cW = cstride
     d.ones_row = ones_row
@@ -444,7 +454,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
         else:
             d.drop_p, d.drop_seed, d.drop_seed_dev = 0.0, 0, None
             d.R, R = None, None             # the caller adds R behind its own dropout pass
-    if auto_sk > 1 and splitk == 1 and nb1 * nb2 == 1 and not isinstance(Cout, int) and cstride is None:
+    if auto_sk > 1 and splitk == 1 and nb1 * nb2 == 1 and not isinstance(Cout, int) and cstride is None and not a_seg:
         # few output tiles but a long reduction (e.g. the 8x8 3x3 convs, the 4x4 patch conv): split K over
         # workgroups and finish (bias / residual / ReLU) in a second pass
         kc = _cdiv(_cdiv(K, auto_sk), 32) * 32
@@ -739,25 +749,29 @@ class deferred_reductions:
         if et is None and pending:
             from ._lib import ReduceDesc
             arr = (ReduceDesc * len(pending))()
-            for d, (_, P, _, dst, _, dbp, (S, Mp, M, N, Cin, taps, CinValid, acc)) in zip(arr, pending):
+            for d, (_, P, _, dst, _, dbp, (S, Mp, M, N, Cin, taps, CinValid, acc, *rest)) in zip(arr, pending):
                 d.P, d.dst, d.db = P, dst, dbp
                 d.S, d.Mp, d.M, d.N, d.Cin, d.taps, d.CinValid, d.accumulate = S, Mp, M, N, Cin, taps, CinValid, acc
+                d.CinPitch = rest[0] if rest else 0
             check(_L().rih_splitk_reduce_multi(arr, len(pending), _stream()), 'rih_splitk_reduce_multi')
         return False
 
 
-def _wgrad(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db=None, nb=1, sx=0, sdy=0, bounds=None):
+def _wgrad(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db=None, nb=1, sx=0, sdy=0, bounds=None,
+           dw_slice=None):
     sw = SIDE_WGRAD
     if sw is None or not x.is_cuda:
-        return _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db, nb, sx, sdy, bounds)
+        return _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db, nb, sx, sdy, bounds,
+                          dw_slice)
     sw.stream.wait_stream(torch.cuda.current_stream())      # x, dy (and everything before them) are ready
     with torch.cuda.stream(sw.stream):
-        _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db, nb, sx, sdy, bounds)
+        _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db, nb, sx, sdy, bounds, dw_slice)
     sw.keep.extend((x, dy, dw, db))
     sw.used = True
 
 
-def _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db=None, nb=1, sx=0, sdy=0, bounds=None):
+def _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin_valid, db=None, nb=1, sx=0, sdy=0, bounds=None,
+               dw_slice=None):
     """dw (parameter layout) = im2col(x)^T @ dy with split-K over the Kpix pixels.  With `db` (bias gradient, [Ncols])
     the A operand gets an all-ones row behind its Mrows rows, so the same GEMM also produces the column sums of dy.
     nb > 1: that many independent gradients in one GEMM + one reduce launch (x / dy slices sx / sdy floats apart, sx = 0
@@ -803,8 +817,23 @@ def _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin
     else:
         gemm(x, dy, part, Mp, Ncols, Kpix, ldx, ldy, Ncols, a_mode=1, b_mode=0, splitk=splitk, kchunk=kchunk,
              sCsplit=Mp * Ncols, geom=geom, tile=tile, ones_row=ones, collect=collect, **batch)
-    if _DEFERRED is not None:
-        # summed at the end of the backward stage by ONE launch per 60 gradients (deferred_reductions below)
+    if dw_slice is not None:
+        # the gradient lands in a column slice of a wider parameter: dw_slice = (first column, columns of the whole parameter);
+        # always through the descriptor form of the reduction (rih_reduce_desc.CinPitch)
+        assert nb == 1 and db is None
+        entry = (part, part.data_ptr(), dw, dw.data_ptr() + 4 * dw_slice[0] * taps, None, None,
+                 (splitk, Mp, Mrows, Ncols, Cin_pad, taps, Cin_valid, 0, dw_slice[1]))
+        if _DEFERRED is not None:
+            _DEFERRED.append(entry)
+        else:
+            from ._lib import ReduceDesc
+            arr = (ReduceDesc * 1)()
+            d = arr[0]
+            d.P, d.dst, d.db = entry[1], entry[3], None
+            d.S, d.Mp, d.M, d.N, d.Cin, d.taps, d.CinValid, d.accumulate, d.CinPitch = entry[6]
+            check(_L().rih_splitk_reduce_multi(arr, 1, _stream()), 'rih_splitk_reduce_multi')
+    elif _DEFERRED is not None:
+        # summed at the end of the backward stage by ONE launch per 56 gradients (deferred_reductions below)
         per_dw, per_db = dw.numel() // nb, (Ncols if db is not None else 0)
         for b in range(nb):
             _DEFERRED.append((part, part.data_ptr() + 4 * b * splitk * Mp * Ncols, dw, dw.data_ptr() + 4 * b * per_dw, db,
@@ -1041,6 +1070,82 @@ def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, grad_masked=False, stat
 def conv2d_skip(x, w, bias=None, stride=1, pad=0, relu=False, grad_masked=False, stats=None):
     """(conv(x), x) -- see Conv2dFn.forward: use the second value for the block's skip path."""
     return Conv2dFn.apply(x, w, bias, stride, pad, relu, True, grad_masked, stats)
+
+
+class ConvCat1x1Fn(torch.autograd.Function):
+    """1x1 convolution (no bias) of the channel concatenation of up to four NHWC maps WITHOUT materialising the concatenation
+    (models/encoder.py:165-173: `torch.cat((hms_fmaps[i], dp_fmaps[i], img_fmaps[i]), dim=1)` -> conv1x1 -> ReLU -> BN): the
+    forward GEMM reads its A operand piece by piece (rih_gemm_desc.a_seg), the backward writes each part's gradient with its own
+    data-gradient GEMM (no slice copies) and each part's weight-gradient columns with its own (grouped) weight-gradient GEMM.
+    forward(w, relu, stats, *parts); channel counts must be multiples of 32."""
+
+    @staticmethod
+    def forward(ctx, w, relu, stats, *parts):
+        _chk(w, *parts)
+        w = _c(w)
+        parts = [_c(p_) for p_ in parts]
+        N, H, W_, _ = parts[0].shape
+        Cs = [p_.shape[-1] for p_ in parts]
+        Cout, Cin = w.shape[0], w.shape[1]
+        assert sum(Cs) == Cin and w.shape[2] == w.shape[3] == 1 and 2 <= len(parts) <= 4 and all(c % 32 == 0 for c in Cs)
+        M = N * H * W_
+        y = torch.empty((N, H, W_, Cout), device=w.device, dtype=torch.float32)
+        starts = [sum(Cs[:i]) for i in range(len(Cs))]
+        b0 = bw = None
+        if ENGINE == 2:         # one bound for the whole operand: the largest of the parts'
+            bs = [bound_of(p_) for p_ in parts]
+            b0 = bs[0]
+            for b_ in bs[1:]:
+                b0 = torch.maximum(b0, b_)
+            bw = LazyBound(w)
+        gemm(parts[0], w, y, M, Cout, Cin, Cs[0], Cin, Cout, a_mode=0, b_mode=1, relu=relu, stats=stats, amax_a=b0, amax_b=bw,
+             a_seg=[(parts[i], Cs[i], starts[i]) for i in range(1, len(parts))])
+        ctx.save_for_backward(w, *parts)
+        ctx.cfg = (Cs, starts)
+        ctx.bounds = (bw,)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        w, *parts = ctx.saved_tensors
+        Cs, starts = ctx.cfg
+        (bw,) = ctx.bounds
+        dy = _c(dy)
+        N, H, W_, Cout = dy.shape
+        M = N * H * W_
+        Cin = w.shape[1]
+        bdy = LazyBound(dy) if bw is not None else None
+        wflat = w.view(Cout, Cin)
+        dparts = []
+        for i, p_ in enumerate(parts):
+            if ctx.needs_input_grad[3 + i]:
+                dx = torch.empty_like(p_)
+                # dx_i = dy W[:, slice]: B(k = co, n = ci) = w[co][start + ci] -- b_mode 0 with pitch Cin from the slice's first column
+                gemm(dy, wflat.data_ptr() + 4 * starts[i], dx, M, Cs[i], Cout, Cout, Cin, Cs[i], a_mode=0, b_mode=0,
+                     amax_a=bdy, amax_b=bw)
+                dparts.append(dx)
+            else:
+                dparts.append(None)
+        dw = None
+        if ctx.needs_input_grad[0]:
+            dw = torch.empty_like(w)
+            for i, p_ in enumerate(parts):
+                g = (H, W_, Cs[i], H, W_, 1, 1, 1, 1, 0, 0)
+                _wgrad(p_, dy, dw, M, Cs[i], Cout, Cs[i], Cout, g, Cs[i], 1, Cs[i],
+                       bounds=(LazyBound(p_), bdy) if bw is not None else None, dw_slice=(starts[i], Cin))
+        return (dw, None, None) + tuple(dparts)
+
+
+def conv1x1_cat(parts, w, relu=False, stats=None):
+    """conv1x1(torch.cat(parts, channel dim), w) without the concatenation (ConvCat1x1Fn); falls back to the concatenation when a
+    part's channel count is not a multiple of 32."""
+    if CAT_FREE and 2 <= len(parts) <= 4 and all(p_.shape[-1] % 32 == 0 for p_ in parts):
+        return ConvCat1x1Fn.apply(w, relu, stats, *parts)
+    return conv2d(cat_channels(list(parts)), w, None, stride=1, pad=0, relu=relu, grad_masked=relu, stats=stats)
+
+
+# the 1x1 convolutions behind channel concatenations (encoder.resnet_mid, HRnet_encoder heads) read their parts in place
+CAT_FREE = os.environ.get('RIH_CAT_FREE', '1') == '1'
 
 
 def pack_folded_conv(w, scale, cin_pad):

@@ -94,7 +94,17 @@ class EmulatedLib:
                 plain = (taps == 1 and d.strideA == 1 and d.upS == 1 and d.padH == 0 and d.padW == 0 and d.H == d.Ho
                          and d.W == d.Wo and d.a_mode != 2)
                 A = None
-                if plain and d.a_mode == 0 and K > 0:
+                if d.a_seg[0]:
+                    # segmented A: [A | a_seg[0] | a_seg[1] | a_seg[2]] along K, plain row-major pieces
+                    assert plain and d.a_mode == 0 and d.b_mode == 1 and d.nb1 * d.nb2 == 1 and d.splitk == 1
+                    starts = [0] + [d.k_seg[i] for i in range(3) if d.a_seg[i]] + [K]
+                    bases = [Ab] + [d.a_seg[i] for i in range(3) if d.a_seg[i]]
+                    ldas = [d.lda] + [d.lda_seg[i] for i in range(3) if d.a_seg[i]]
+                    A = np.empty((M, K), np.float32)
+                    for base, ld, k0, k1 in zip(bases, ldas, starts[:-1], starts[1:]):
+                        assert k0 % 32 == 0 and k1 > k0
+                        A[:, k0:k1] = np.lib.stride_tricks.as_strided(_f(base, (M - 1) * ld + (k1 - k0)), (M, k1 - k0), (4 * ld, 4))
+                elif plain and d.a_mode == 0 and K > 0:
                     # fast path (the emulation's only optimisation): dense rows, no gather -- A[m, k] = mem[m * lda + k]
                     A = np.lib.stride_tricks.as_strided(_f(Ab, (M - 1) * d.lda + K), (M, K), (4 * d.lda, 4)).copy()
                 elif plain and d.a_mode == 1 and K > 0:
@@ -434,19 +444,20 @@ class EmulatedLib:
         for i in range(n):
             d = descs[i]
             self.rih_splitk_reduce_bias(d.P, d.S, d.Mp, d.M, d.N, d.dst, d.Cin, d.taps, d.CinValid, d.accumulate, d.db or 0,
-                                        stream)
+                                        stream, pitch=d.CinPitch)
         return 0
 
-    def rih_splitk_reduce_bias(self, P, S, Mp, M, N, dst, Cin, taps, CinValid, accumulate, db, stream):
+    def rih_splitk_reduce_bias(self, P, S, Mp, M, N, dst, Cin, taps, CinValid, accumulate, db, stream, pitch=0):
         p = _f(P, S * Mp * N).reshape(S, Mp, N).sum(0)
         if db:
             _f(db, N)[:] = p[M]
         p = p[:M]
-        out = _f(dst, N * CinValid * taps)
+        pitch = pitch or CinValid           # > CinValid: dst is a column slice of a wider parameter
+        out = _f(dst, ((N - 1) * pitch + CinValid) * taps)
         m = np.arange(M)
         tap, ci = m // Cin, m % Cin
         ok = ci < CinValid
-        o = ((np.arange(N)[None, :] * CinValid + ci[ok][:, None]) * taps + tap[ok][:, None]).ravel()     # [rows ok][N], unique
+        o = ((np.arange(N)[None, :] * pitch + ci[ok][:, None]) * taps + tap[ok][:, None]).ravel()     # [rows ok][N], unique
         v = p[ok].ravel()
         out[o] = (out[o] + v) if accumulate else v
         return 0

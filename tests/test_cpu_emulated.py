@@ -142,6 +142,13 @@ def test_paired_decoder_runs_with_dropout(monkeypatch):
     assert torch.isfinite(s) and all(torch.isfinite(p.grad).all() for p in dec.parameters() if p.grad is not None)
 
 
+def test_conv1x1_cat_host_logic():
+    """ops.conv1x1_cat on the emulated ABI: segment descriptors, per-part data gradients, column-slice weight gradients."""
+    for eng in (1, 2):
+        G.test_conv1x1_cat((2, 8, 8, (64, 32, 96), 128, True), eng)
+        G.test_conv1x1_cat((1, 5, 7, (32, 64), 40, False), eng)
+
+
 def test_presplit_weight_host_logic(monkeypatch):
     """ops.PRESPLIT (rih_gemm b_mode 2 + rih_presplit_conv_weight, off by default): descriptor / operand plumbing."""
     from renderih_amd import ops

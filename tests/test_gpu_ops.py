@@ -84,6 +84,54 @@ def test_conv2d(case):
         assert_close(bg.grad, br.grad, 1e-3, 1e-4, 'conv db %s' % (case,))
 
 
+@pytest.mark.parametrize('engine', [1, 2])
+@pytest.mark.parametrize('case', [(2, 16, 16, (128, 128, 256), 256, True), (3, 9, 7, (32, 64), 40, False),
+                                  (2, 8, 8, (128, 128, 1024, 32), 256, True), (1, 33, 5, (64, 32, 96), 128, False)])
+def test_conv1x1_cat(case, engine, monkeypatch=None):
+    """ops.conv1x1_cat (segmented GEMM operand, rih_gemm_desc.a_seg): the 1x1 convolution of a channel concatenation read in place
+    -- output, the statistics epilogue, every part's gradient and the weight gradient (written as column slices by the reduction)
+    against F.conv2d on the materialised concatenation; engines 1 and 2, two to four parts, ragged row counts, N tails."""
+    from renderih_amd import ops
+    N, H, W, Cs, Cout, relu = case
+    saved = ops.ENGINE
+    ops.ENGINE = engine
+    try:
+        parts = [rnd(N, c, H, W, seed=11 + i) * (1.0 + 3.0 * i) for i, c in enumerate(Cs)]
+        Cin = sum(Cs)
+        w = rnd(Cout, Cin, 1, 1, seed=2, scale=1.0 / math.sqrt(Cin))
+        pr = [t.clone().requires_grad_(True) for t in parts]
+        wr = w.clone().requires_grad_(True)
+        yr = F.conv2d(torch.cat(pr, dim=1), wr)
+        if relu:
+            yr = F.relu(yr)
+        gy = rnd(*yr.shape, seed=4)
+        if relu:
+            gy = gy * (yr > 0).float()          # the consumer (BatchNorm with input_relu) hands back a gradient gated by y > 0
+        yr.backward(gy)
+        d = dev()
+        pg = [nhwc(t).contiguous().to(d).requires_grad_(True) for t in parts]
+        wg = w.to(d).requires_grad_(True)
+        holder = ops.StatsHolder()
+        yg = ops.conv1x1_cat(pg, wg, relu=relu, stats=holder)
+        assert_close(nchw(yg), yr, what='cat conv y %s' % (case,))
+        if holder.part is not None:             # per-block (mean, M2) -> mean / variance per channel
+            M = N * H * W
+            part = holder.part.double().cpu()
+            n = torch.full((holder.T,), float(holder.rows), dtype=torch.float64)
+            n[-1] = M - holder.rows * (holder.T - 1)
+            mean = (part[:, 0] * n[:, None]).sum(0) / M
+            var = (part[:, 1] + n[:, None] * (part[:, 0] - mean) ** 2).sum(0) / M
+            y2 = nhwc(yr.detach()).reshape(M, Cout).double()
+            assert_close(mean, y2.mean(0), 1e-4, 1e-5, 'cat conv stats mean')
+            assert_close(var, y2.var(0, unbiased=False), 1e-3, 1e-5, 'cat conv stats var')
+        yg.backward(nhwc(gy).contiguous().to(d))
+        assert_close(wg.grad, wr.grad, 1e-3, 1e-4, 'cat conv dw %s' % (case,))
+        for i, (a, b) in enumerate(zip(pg, pr)):
+            assert_close(nchw(a.grad), b.grad, 1e-3, 1e-4, 'cat conv dx%d %s' % (i, case))
+    finally:
+        ops.ENGINE = saved
+
+
 LIN_CASES = [(126, 512, 256, True, False, False), (126, 2048, 509, True, False, False), (100, 64, 3, True, False, False),
              (128, 252, 1, True, False, False), (6, 252, 778, False, False, False), (4032, 128, 128, True, True, True),
              (300, 256, 256, True, False, True), (8064, 64, 64, True, True, False)]

@@ -56,6 +56,12 @@ def test_conv2d_kernels(case):
     G.test_conv2d(case)
 
 
+@pytest.mark.parametrize('engine', [1, 2])
+@pytest.mark.parametrize('case', [(1, 8, 8, (32, 64), 40, False), (2, 4, 4, (64, 32, 96), 128, True), (1, 5, 7, (32, 32, 64, 32), 64, True)])
+def test_conv1x1_cat_kernels(case, engine):
+    G.test_conv1x1_cat(case, engine)
+
+
 @pytest.mark.parametrize('case', [(33, 64, 24, True, True, True), (64, 128, 64, True, False, False),
                                   (20, 36, 6, False, False, False)])
 def test_linear_kernels(case):
