@@ -204,6 +204,48 @@ def config5(args):
     with torch.cuda.stream(side):
         forward()
     torch.cuda.current_stream().wait_stream(side)
+    roof = None
+    if not args.no_roofline:
+        # one EAGER forward with an event pair around every matrix-pipe launch (rih_hconv of the fp16-storage backbone, rih_gemm
+        # and flash attention of the fp32 decoder); the empty-pair cost is calibrated and taken off as in the training bench
+        from renderih_amd import ops
+        torch.cuda.synchronize()
+        ops.PROFILE = []
+        forward()
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+        pairs = []
+        for _ in range(64):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            b.record()
+            pairs.append((a, b))
+        torch.cuda.synchronize()
+        empty = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
+        fam = {}
+        for f, e0, e1, tag in recs:
+            eng = tag[8] if len(tag) > 8 else 'other'
+            if tag[6] == 30:
+                eng = 'flash'
+            k = ('backbone f16 (rih_hconv)' if eng == 'f16' else 'decoder attention (rih_flash_fwd, split-bf16 products)'
+                 if eng == 'flash' else 'decoder f32 (rih_gemm engine %s)' % eng)
+            a = fam.setdefault(k, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += max(e0.elapsed_time(e1) - empty, 0.0)
+            a[2] += f
+        # ceilings: one f16 product per MAC on the fp16-storage backbone (2500 TF/s dense); the fp32 decoder runs the split
+        # engines: six bf16 products (2500 / 6) or, where operand bounds exist, three fp16 products (2500 / 3)
+        peaks = {'f16': PEAK_BF16_MFMA_TF, '1': PEAK_BF16_MFMA_TF / 6.0, '2': PEAK_BF16_MFMA_TF / 3.0, '0': PEAK_FP32_MFMA_TF}
+        fams = {}
+        for k, (n_, ms_, fl) in sorted(fam.items()):
+            key = 'f16' if 'rih_hconv' in k else '1' if 'flash' in k else k.split('engine ')[-1].rstrip(')')
+            pk = peaks.get(key, PEAK_BF16_MFMA_TF / 6.0)
+            fams[k] = {'launches': n_, 'ms': round(ms_, 3), 'achieved': round(fl / max(ms_, 1e-9) / 1e9, 1), 'peak': round(pk, 1),
+                       'frac': round(fl / max(ms_, 1e-9) / 1e9 / pk, 4)}
+        top = max(fams.items(), key=lambda kv: kv[1]['ms'])
+        roof = {'bound': 'mfma', 'achieved': top[1]['achieved'], 'peak': top[1]['peak'], 'unit': 'TFLOP/s', 'frac': top[1]['frac'],
+                'traffic': None, 'kernel': top[0] + ': the matrix-pipe family with the most time in one eager forward',
+                'families': fams, 'event_pair_overhead_us': round(1000.0 * empty, 2)}
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         keep = forward()
@@ -224,7 +266,8 @@ def config5(args):
                       'config': {'workload': 'BASELINE configs[4]: inference-only, batch=%d, hipGraph-captured encoder + attention '
                                              'decoder + MANO layer (2 x %d hands) on 1 x MI355X' % (B, B),
                                  'vertices_rel_deviation_from_fp32_path': dev_err,
-                                 'mpjpe': 'deferred: needs the pretrained checkpoint and InterHand2.6M (licence-gated)'}})
+                                 'mpjpe': 'deferred: needs the pretrained checkpoint and InterHand2.6M (licence-gated)'},
+          'roofline': roof, 'cpu_baseline': None})
 
 
 def main():

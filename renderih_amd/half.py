@@ -124,11 +124,16 @@ class PackedConv:
         d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = N, H, W, self.Cin, self.Cout, self.KH, self.KW
         d.stride, d.pad, d.Ho, d.Wo, d.ldx, d.ldy, d.Kpad = self.stride, self.pad, Ho, Wo, ldx, ldy, self.Kpad
         d.relu, d.out_f32 = int(relu), int(out_f32)
-        check(ops._L().rih_hconv(C.byref(d), ops._stream()), 'rih_hconv')
-        if TALLY is not None:               # algorithmic work of this launch (true Cin of the weights, no padding)
-            TALLY['flop'] += 2.0 * N * Ho * Wo * self.Cout * self.KH * self.KW * self.Cin_w
-            TALLY['bytes'] += 2.0 * (N * H * W * self.Cin_w + self.Cout * self.KH * self.KW * self.Cin_w) + \
-                (4.0 if out_f32 else 2.0) * N * Ho * Wo * self.Cout + (2.0 * N * Ho * Wo * self.Cout if res is not None else 0.0)
+        # algorithmic work of this launch (true Cin of the weights, no padding)
+        flop = 2.0 * N * Ho * Wo * self.Cout * self.KH * self.KW * self.Cin_w
+        nbytes = 2.0 * (N * H * W * self.Cin_w + self.Cout * self.KH * self.KW * self.Cin_w) + \
+            (4.0 if out_f32 else 2.0) * N * Ho * Wo * self.Cout + (2.0 * N * Ho * Wo * self.Cout if res is not None else 0.0)
+        ops._profiled(flop, (N * Ho * Wo, self.Cout, self.KH * self.KW * self.Cin_w, 1, 1, 0, 0, 1, 'f16', nbytes,
+                             (H, W, self.KH, self.stride, int(res is not None), int(out_f32))),
+                      lambda: check(ops._L().rih_hconv(C.byref(d), ops._stream()), 'rih_hconv'))
+        if TALLY is not None:
+            TALLY['flop'] += flop
+            TALLY['bytes'] += nbytes
             TALLY['launches'] += 1
         return out
 

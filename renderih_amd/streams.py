@@ -18,6 +18,10 @@ import torch
 # but a captured step died with a host-side SIGSEGV inside the HIP runtime on ROCm 7.0.2 (profiles/r03/ab/g2_hrnet_side3_segv.log)
 # -- `effective_side` clamps the value to 1 while a stream captures.
 SIDE = int(os.environ.get('RIH_SIDE_STREAMS', '1'))
+# the clamp under capture; raised only by tools/capture_fork_repro.sh to reproduce the crash under a debugger
+CAPTURE_MAX = int(os.environ.get('RIH_SIDE_CAPTURE_MAX', '1'))
+# side-stream results re-enter the autograd graph through a node on the calling stream (see _Hop); 0 only to reproduce the crash
+HOP = os.environ.get('RIH_FORK_HOP', '1') != '0'
 _POOL = {}
 _LIMIT = None           # `limit(n)`: an upper bound on SIDE for the code inside the context (renderih_amd.train.TrainStep)
 _OPEN = []              # side streams forked from the calling stream and not yet joined (assert_joined)
@@ -51,13 +55,13 @@ def effective_side(device=None):
     work.  A larger request is clamped with one warning, not obeyed."""
     global _WARNED
     n = SIDE if _LIMIT is None else min(SIDE, _LIMIT)
-    if n > 1 and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+    if n > CAPTURE_MAX and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
         if not _WARNED:
             import warnings
-            warnings.warn('renderih_amd.streams: RIH_SIDE_STREAMS=%d clamped to 1 while a hipGraph is being captured (captured '
-                          'steps with more than one side branch crash the HIP runtime)' % SIDE)
+            warnings.warn('renderih_amd.streams: RIH_SIDE_STREAMS=%d clamped to %d while a hipGraph is being captured (captured '
+                          'steps with more than one side branch crash the HIP runtime)' % (SIDE, CAPTURE_MAX))
             _WARNED = True
-        n = 1
+        n = CAPTURE_MAX
     return max(n, 0)
 
 
@@ -75,6 +79,33 @@ def side_streams(device, n):
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=device))
     return pool[:n]
+
+
+class _Hop(torch.autograd.Function):
+    """Identity whose autograd node lives on the CALLING stream.  fork_join passes every tensor a side stream produced through
+    it after the join, so that in the backward a gradient never travels from one side stream straight to another: it is
+    handed side -> calling stream -> side.  Why that matters: hipStreamWaitEvent on a capturing, non-origin stream appends the
+    waiting stream to the EVENT stream's parallel-capture list (every time, not only when it first joins the capture), and
+    hipStreamEndCapture walks those lists recursively before clearing them -- two side streams that each waited on the other
+    once form a cycle and hip::Stream::EndCapture() recurses until the stack overflows (ROCm 7.0.2; root cause of the SIGSEGV
+    of captured steps with more than one side stream: profiles/r04/capture_segv_rocgdb_backtrace_c8.txt).  With the
+    hop every event wait of a captured step has the origin stream on one side, and the origin stream is never listed."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _hop(r):
+    if torch.is_tensor(r):
+        return _Hop.apply(r) if r.requires_grad else r
+    if isinstance(r, (list, tuple)):
+        return type(r)(_hop(t) for t in r)
+    return r
 
 
 def _tensors(r):
@@ -126,4 +157,6 @@ def fork_join(thunks, reads=None):
     for k in range(1, n):
         for t in _tensors(out[k]):
             t.record_stream(main)
+    if HOP and len(used) > 1 and torch.is_grad_enabled():
+        out = [out[0]] + [_hop(o) for o in out[1:]]
     return out

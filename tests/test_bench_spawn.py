@@ -37,3 +37,23 @@ def test_default_is_one_rank_without_a_launcher():
 def test_world_size_and_gpus_flag_must_agree():
     r = _run(['--gpus', '4'], extra_env={'WORLD_SIZE': '2', 'RANK': '0', 'LOCAL_RANK': '0'})
     assert r.returncode != 0 and 'must agree' in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_config5_line_carries_a_roofline():
+    """BASELINE configs[4] (`bench.py --config5`): the line names its workload, reports the deviation from the fp32 path and a
+    `roofline` object with the matrix-pipe families of one forward (fp16-storage backbone, fp32 decoder, attention)."""
+    env = dict(os.environ)
+    env.pop('RIH_BENCH_SPAWN_PROBE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config5', '--batch', '16', '--steps', '2', '--warmup', '1'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['unit'] == 'images/sec' and d['value'] > 0 and 'configs[4]' in d['config']['workload']
+    assert d['config']['vertices_rel_deviation_from_fp32_path'] < 5e-3
+    roof = d['roofline']
+    assert roof['bound'] == 'mfma' and 0.0 < roof['frac'] < 1.0 and roof['unit'] == 'TFLOP/s'
+    fams = roof['families']
+    assert any('rih_hconv' in k for k in fams) and any('rih_gemm' in k for k in fams)
+    for v in fams.values():
+        assert v['launches'] > 0 and v['ms'] > 0 and 0.0 < v['frac'] < 1.0
