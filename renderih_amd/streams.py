@@ -13,15 +13,14 @@ import os
 
 import torch
 
-# side streams per device; 0 = everything in the calling stream.  1 = the finest branch in the calling stream beside all coarser
-# ones in ONE side stream: measured +5 % on the HRNet-W32 step (profiles/r03/ab/g2_hrnet_side_streams_*.log).  2 / 3 run eagerly
-# but a captured step died with a host-side SIGSEGV inside the HIP runtime on ROCm 7.0.2 (profiles/r03/ab/g2_hrnet_side3_segv.log)
-# -- `effective_side` clamps the value to 1 while a stream captures.
-SIDE = int(os.environ.get('RIH_SIDE_STREAMS', '1'))
-# the clamp under capture; raised only by tools/capture_fork_repro.sh to reproduce the crash under a debugger
-CAPTURE_MAX = int(os.environ.get('RIH_SIDE_CAPTURE_MAX', '1'))
+# side streams per device; 0 = everything in the calling stream.  HRNet-W32 step, one box (profiles/r04/ab/c10_hr_side*.log):
+# 0: 627, 1: 671-673, 2: 737, 3: 774 images/s.  More than one side stream inside a captured step needs the autograd hop of
+# fork_join (HOP below): without it hipStreamEndCapture overflows the stack (ROCm 7.0.2, see _Hop).
+SIDE = int(os.environ.get('RIH_SIDE_STREAMS', '3'))
 # side-stream results re-enter the autograd graph through a node on the calling stream (see _Hop); 0 only to reproduce the crash
 HOP = os.environ.get('RIH_FORK_HOP', '1') != '0'
+# the clamp on SIDE while a stream captures: none with the hop, 1 without it (tools/capture_fork_min.py raises it to reproduce)
+CAPTURE_MAX = int(os.environ.get('RIH_SIDE_CAPTURE_MAX', '64' if HOP else '1'))
 _POOL = {}
 _LIMIT = None           # `limit(n)`: an upper bound on SIDE for the code inside the context (renderih_amd.train.TrainStep)
 _OPEN = []              # side streams forked from the calling stream and not yet joined (assert_joined)
@@ -49,17 +48,17 @@ class limit:
 
 
 def effective_side(device=None):
-    """Side streams fork_join may use right now: RIH_SIDE_STREAMS, the enclosing `limit`, and -- while a stream captures -- at
-    most ONE: a captured step with two or three concurrent side branches died with a host-side SIGSEGV inside the HIP runtime
-    (ROCm 7.0.2, profiles/r03/ab/g2_hrnet_side3_segv.log, g3_hrnet_side2_segv.log; no root cause), only one is evidenced to
-    work.  A larger request is clamped with one warning, not obeyed."""
+    """Side streams fork_join may use right now: RIH_SIDE_STREAMS under the enclosing `limit`.  While a stream captures AND the
+    autograd hop is switched off (RIH_FORK_HOP=0), at most ONE: two side streams that wait on each other's events -- the
+    backward of an all-to-all exchange does -- make hipStreamEndCapture recurse without end (see _Hop).  A larger request is
+    then clamped with one warning, not obeyed."""
     global _WARNED
     n = SIDE if _LIMIT is None else min(SIDE, _LIMIT)
     if n > CAPTURE_MAX and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
         if not _WARNED:
             import warnings
             warnings.warn('renderih_amd.streams: RIH_SIDE_STREAMS=%d clamped to %d while a hipGraph is being captured (captured '
-                          'steps with more than one side branch crash the HIP runtime)' % (SIDE, CAPTURE_MAX))
+                          'steps with more than one side branch and RIH_FORK_HOP=0 crash the HIP runtime)' % (SIDE, CAPTURE_MAX))
             _WARNED = True
         n = CAPTURE_MAX
     return max(n, 0)

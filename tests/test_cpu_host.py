@@ -200,3 +200,22 @@ def test_one_launch_adam_refuses_cpu_tensors():
     p.grad = torch.ones(8)
     with pytest.raises(RuntimeError, match='GPU tensors'):
         optim.Adam([p], lr=1e-3).step()
+
+
+def test_fork_join_hop_is_an_identity_with_a_node_of_its_own():
+    """streams._hop (the autograd node fork_join puts on the calling stream behind every side-stream result): values and
+    gradients pass unchanged, nested results keep their structure, tensors outside the autograd graph are returned as they are."""
+    import torch
+    from renderih_amd import streams
+    x = torch.randn(5, requires_grad=True)
+    c = torch.randn(5)
+    a, (b, k), n = streams._hop([x * 2.0, (x + 1.0, c), None])
+    assert k is c and n is None
+    assert type(a.grad_fn).__name__ == '_HopBackward' and type(b.grad_fn).__name__ == '_HopBackward'
+    assert torch.equal(a, x.detach() * 2.0) and torch.equal(b, x.detach() + 1.0)
+    (a.sum() + 3.0 * b.sum()).backward()
+    assert torch.equal(x.grad, torch.full((5,), 5.0))
+    # CPU tensors: fork_join is a plain loop and adds no node
+    outs = streams.fork_join([lambda: x * 2.0, lambda: x * 3.0], reads=[[x], [x]])
+    assert [type(o.grad_fn).__name__ for o in outs] == ['MulBackward0', 'MulBackward0']
+    assert streams.SIDE == int(os.environ.get('RIH_SIDE_STREAMS', '3')) and streams.HOP

@@ -199,6 +199,20 @@ def test_hrnet_matches_fp64_oracle(training):
         assert int(m.encoder.hrnet.bn1.num_batches_tracked) == 1
 
 
+def test_captured_all_to_all_fork_join_with_three_side_streams():
+    """Two fork_joins, the second reading every output of the first, forward + backward captured in one hipGraph on three side
+    streams (tools/capture_fork_min.py a2a3): without the autograd hop of streams.fork_join the backward makes side streams wait
+    on each other and hipStreamEndCapture overflows the stack (ROCm 7.0.2); with it the capture ends and replays."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'capture_fork_min.py')
+    env = dict(os.environ)
+    env.pop('RIH_FORK_HOP', None)
+    r = subprocess.run([sys.executable, '-X', 'faulthandler', tool, 'a2a3'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.strip().splitlines()[-1].startswith('ok ')
+
+
 def test_hrnet_side_streams_change_nothing(monkeypatch):
     """renderih_amd.streams.fork_join: the HRNet exchange units with their branches and fuse rows forked onto side streams give
     the same outputs and parameter gradients, bit for bit, as the single-stream order -- eagerly (twice, so that recycled
