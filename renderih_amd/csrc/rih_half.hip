@@ -48,7 +48,7 @@ struct HConvArgs {
     void* y;
     int M, Cout, Kpad;
     int H, W, Cin, KH, KW, stride, pad, Ho, Wo;
-    int ldx, ldr, ldy, relu, out_f32, vec;
+    int ldx, ldr, ldy, relu, out_f32, vec, cvec;
 };
 
 __device__ __forceinline__ int xcd_chunk(int bid, int nwg) {       // each XCD (private L2) gets a contiguous run of tiles
@@ -171,6 +171,42 @@ __global__ __launch_bounds__(TPB, 2) void hconv_kernel(const HConvArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     stage(0);
+    // ------------------------------------------------------------ what the epilogue will need from memory, requested NOW: the
+    // lane's 8 output channels per column block j (bias, post scale / shift) and the residual of every element it will write
+    // (4 pixels per j).  They land while the k-loop runs; issued in the epilogue they cost one exposed memory latency each
+    // (measured: the 1x1 convolutions with a residual ran at 0.25 of their HBM roofline, profiles/r04/hconv_sweep_c10.log)
+    const int ech = lane & 3, erow = lane >> 2;             // item = lane + 64 q: channel block ech, row erow + 16 q of the wave's 64
+    const int em0 = m0 + wm * 64 + erow, en0 = n0 + wn * WN + 8 * ech;
+    float bia[TN][8], psc[TN][8], psh[TN][8];
+    half8 rres[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = en0 + j * 32;
+        if (p.cvec && n + 8 <= p.Cout) {                      // 16-byte loads (the build does not merge scalar ones)
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f), o = make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 b0 = p.bias ? *(const float4*)(p.bias + n) : z, b1 = p.bias ? *(const float4*)(p.bias + n + 4) : z;
+            const float4 s0 = p.post_scale ? *(const float4*)(p.post_scale + n) : o, s1 = p.post_scale ? *(const float4*)(p.post_scale + n + 4) : o;
+            const float4 t0 = p.post_scale ? *(const float4*)(p.post_shift + n) : z, t1 = p.post_scale ? *(const float4*)(p.post_shift + n + 4) : z;
+            bia[j][0] = b0.x; bia[j][1] = b0.y; bia[j][2] = b0.z; bia[j][3] = b0.w; bia[j][4] = b1.x; bia[j][5] = b1.y; bia[j][6] = b1.z; bia[j][7] = b1.w;
+            psc[j][0] = s0.x; psc[j][1] = s0.y; psc[j][2] = s0.z; psc[j][3] = s0.w; psc[j][4] = s1.x; psc[j][5] = s1.y; psc[j][6] = s1.z; psc[j][7] = s1.w;
+            psh[j][0] = t0.x; psh[j][1] = t0.y; psh[j][2] = t0.z; psh[j][3] = t0.w; psh[j][4] = t1.x; psh[j][5] = t1.y; psh[j][6] = t1.z; psh[j][7] = t1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = n + e < p.Cout;
+                bia[j][e] = (p.bias != nullptr && ok) ? p.bias[n + e] : 0.f;
+                psc[j][e] = (p.post_scale != nullptr && ok) ? p.post_scale[n + e] : 1.f;
+                psh[j][e] = (p.post_scale != nullptr && ok) ? p.post_shift[n + e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = em0 + 16 * q;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rres[j][q][e] = (half_t)0.f;
+            if (p.res != nullptr && p.vec && m < p.M && n + 8 <= p.Cout) rres[j][q] = *(const half8*)(p.res + (long long)m * p.ldr + n);
+        }
+    }
     land(0);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
@@ -211,53 +247,57 @@ __global__ __launch_bounds__(TPB, 2) void hconv_kernel(const HConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * STAGE_LD + l31] = acc[i][j][r];
         __syncthreads();
+        const int n = en0 + j * 32;
+        const bool full = p.vec && n + 8 <= p.Cout;
+        const int cnt = n >= p.Cout ? 0 : (full ? 8 : min(8, p.Cout - n));
+        // pass 1: every value of this lane for this j is finished in registers before its first store -- a store through y may
+        // alias any later load as far as the compiler knows, and a load issued after it waits out a full memory latency
+        float v[4][8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int item = lane + 64 * q, row = item >> 2, ch = item & 3;
-            const int m = m0 + wm * 64 + row, n = n0 + wn * WN + j * 32 + 8 * ch;
-            if (m >= p.M || n >= p.Cout) continue;
-            const float4 v0 = *(const float4*)(st + row * STAGE_LD + 8 * ch), v1 = *(const float4*)(st + row * STAGE_LD + 8 * ch + 4);
-            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            const bool full = p.vec && n + 8 <= p.Cout;
-            const int cnt = full ? 8 : min(8, p.Cout - n);
+            const int row = erow + 16 * q;
+            const float4 v0 = *(const float4*)(st + row * STAGE_LD + 8 * ech), v1 = *(const float4*)(st + row * STAGE_LD + 8 * ech + 4);
+            const float t[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            const int m = em0 + 16 * q;
             float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (p.res != nullptr) {
-                const half_t* rp = p.res + (long long)m * p.ldr + n;
+            if (p.res != nullptr && m < p.M && cnt > 0) {
                 if (full) {
-                    const half8 h = *(const half8*)rp;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) rv[e] = (float)h[e];
+                    for (int e = 0; e < 8; ++e) rv[e] = (float)rres[j][q][e];
                 } else {
+                    const half_t* rp = p.res + (long long)m * p.ldr + n;
                     for (int e = 0; e < cnt; ++e) rv[e] = (float)rp[e];
                 }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                if (e < cnt) {
-                    float u = v[e] + rv[e];
-                    if (p.bias != nullptr) u += p.bias[n + e];
-                    if (p.relu) u = fmaxf(u, 0.f);
-                    if (p.post_scale != nullptr) u = u * p.post_scale[n + e] + p.post_shift[n + e];
-                    v[e] = u;
-                }
+                float u = t[e] + rv[e] + bia[j][e];
+                if (p.relu) u = fmaxf(u, 0.f);
+                v[q][e] = u * psc[j][e] + psh[j][e];
             }
+        }
+        // pass 2: the stores
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = em0 + 16 * q;
+            if (m >= p.M || cnt == 0) continue;
             if (p.out_f32) {
                 float* yp = (float*)p.y + (long long)m * p.ldy + n;
                 if (full) {
-                    *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
-                    *(float4*)(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    *(float4*)yp = make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
+                    *(float4*)(yp + 4) = make_float4(v[q][4], v[q][5], v[q][6], v[q][7]);
                 } else {
-                    for (int e = 0; e < cnt; ++e) yp[e] = v[e];
+                    for (int e = 0; e < cnt; ++e) yp[e] = v[q][e];
                 }
             } else {
                 half_t* yp = (half_t*)p.y + (long long)m * p.ldy + n;
                 if (full) {
                     half8 h;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) h[e] = (half_t)clamp_h(v[e]);
+                    for (int e = 0; e < 8; ++e) h[e] = (half_t)clamp_h(v[q][e]);
                     *(half8*)yp = h;
                 } else {
-                    for (int e = 0; e < cnt; ++e) yp[e] = (half_t)clamp_h(v[e]);
+                    for (int e = 0; e < cnt; ++e) yp[e] = (half_t)clamp_h(v[q][e]);
                 }
             }
         }
@@ -412,6 +452,7 @@ extern "C" int rih_hconv(const rih_hconv_desc* d, void* stream) {
     a.Ho = d->Ho; a.Wo = d->Wo; a.ldx = d->ldx; a.ldr = d->ldr; a.ldy = d->ldy; a.relu = d->relu; a.out_f32 = d->out_f32;
     // 16-byte epilogue accesses need aligned rows on every tensor they touch
     a.vec = al16(d->y) && d->ldy % (d->out_f32 ? 4 : 8) == 0 && (d->res == nullptr || (al16(d->res) && d->ldr % 8 == 0));
+    a.cvec = (d->bias == nullptr || al16(d->bias)) && (d->post_scale == nullptr || (al16(d->post_scale) && al16(d->post_shift)));
     hipStream_t s = (hipStream_t)stream;
     const long long tilesM = (M + BM - 1) / BM;
     static const bool glds = [] { const char* e = getenv("RIH_HCONV_GLDS"); return !(e && e[0] == '0'); }();

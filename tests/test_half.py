@@ -101,6 +101,11 @@ def kernels_vs_torch(dev):
     conv_case(dev, 1, 4, 4, 192, 64, 1, 1, 0, 'conv-relu-bn', True, False, True, seed=7)
     conv_case(dev, 1, 5, 5, 64, 42, 1, 1, 0, None, False, False, True, seed=8)
     conv_case(dev, 1, 5, 5, 64, 10, 1, 1, 0, None, False, False, False, seed=9)      # fp16, ld not a multiple of 8
+    # residual prefetch (round 4): two pixel tiles with a ragged second one; ragged channel count (scalar residual path);
+    # 128-wide tile with a partly filled last 8-channel block, fp32 output
+    conv_case(dev, 2, 9, 9, 64, 128, 1, 1, 0, 'conv-bn', True, True, False, seed=10)
+    conv_case(dev, 1, 7, 7, 64, 20, 1, 1, 0, 'conv-bn', True, True, False, seed=11)
+    conv_case(dev, 1, 6, 6, 64, 72, 3, 1, 1, 'conv-relu-bn', True, True, True, seed=12)
     # pooling / resampling
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, 9, 10, 16, generator=g).to(F16)
