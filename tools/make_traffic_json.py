@@ -1,0 +1,34 @@
+"""profiles/rNN/traffic_vMM.json from the two text summaries tools/pmc_traffic.sh writes (FETCH_SIZE / WRITE_SIZE passes).
+    python tools/make_traffic_json.py gpurun_out/pmc profiles/r04/traffic_v5.json "<what ran>" """
+import json
+import re
+import sys
+
+
+def per_step(path):
+    txt = open(path).read()
+    m = re.search(r'GEMM family.*launches (\d+) total ([0-9.e+]+) per-launch ([0-9.e+]+) per-step ([0-9.e+]+)', txt)
+    steps = int(re.search(r'steps seen: (\d+)', txt).group(1))
+    return int(m.group(1)) // max(steps, 1), float(m.group(4)), steps
+
+
+def main():
+    src, dst, what = sys.argv[1], sys.argv[2], sys.argv[3]
+    n, fetch_kb, steps = per_step(src + '/traffic_FETCH_SIZE.txt')
+    _, write_kb, _ = per_step(src + '/traffic_WRITE_SIZE.txt')
+    d = {'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace, counters only) over `bench.py --steps 2 '
+                   '--warmup 1 --no-graph --no-reference-loop` = %d eager TrainStep steps; tools/pmc_traffic.sh; %s' % (steps, what),
+         'kernels': 'GEMM family: rih_gemm launches (gemm_kernel / gemm_split_kernel, engines 0 / 1 / 2), the grouped weight-gradient '
+                    'launches (gemm_split_multi_kernel) and the flash-attention kernels',
+         'launches_per_step': n,
+         'fetch_KB_raw_per_step': fetch_kb, 'write_KB_raw_per_step': write_kb,
+         'fetch_GB_per_step_corrected': round(2.0 * fetch_kb * 1000 / 1e9, 2),
+         'write_GB_per_step': round(write_kb * 1000 / 1e9, 2),
+         'correction': 'FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B for wide coalesced reads, MI355X_MICROARCH.md HBM '
+                       'section); WRITE_SIZE as reported (uncalibrated)'}
+    json.dump(d, open(dst, 'w'), indent=1)
+    print(json.dumps(d))
+
+
+if __name__ == '__main__':
+    main()
