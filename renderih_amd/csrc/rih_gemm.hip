@@ -11,6 +11,7 @@
 // blockIdx.x is remapped so that each XCD (private L2) works on a contiguous run of tiles.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/renderih_amd.h"
 #include "rih_hash.h"
 #include <type_traits>
@@ -810,7 +811,7 @@ __device__ __forceinline__ uint4 bloadu4(__amdgpu_buffer_rsrc_t r, unsigned off)
 // ENG 2: the two-term fp16 split (three MFMA products, see e2_scale / split2h above) instead of the three-term bf16 one; same
 // loaders, LDS layout (two planes instead of three) and epilogue.  Not with pre-split operands.
 template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false, int ENG = 1,
-          bool SEG = false>
+          bool SEG = false, int PFD = 1>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk_x, const int blk_z, const int grid_x,
                                                 const int grid_z) {
     static_assert(ENG == 1 || (ENG == 2 && !APRE), "engine 2: B may arrive as two pre-split fp16 planes (BMODE 2), A never");
@@ -818,7 +819,11 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
     constexpr int NPL = (ENG == 2) ? 2 : 3;         // 16-bit planes per operand
     // global->register prefetch depth: k-tiles in flight.  The 64x64 tile (decoder-sized problems: a handful of
     // k-tiles, 12 MFMAs each) is bound by the load round trip per k-tile, so it keeps three tiles in flight.
-    constexpr int PF = 1;     // (measured: 3 tiles in flight for the 64x64 tile changes nothing, the floor is elsewhere)
+    // (measured in round 2: 3 tiles in flight for the 64x64 tile changes nothing on decoder-sized problems, the floor is elsewhere.)
+    // PFD = 2 (round 4, engine 2, plain rows, short reductions -- the 1x1 convolutions with K <= 256 and a million rows): such a
+    // workgroup is a chain of dependent memory round trips (bound, k-tile, k-tile, ..., store) with a few MFMAs between them; a
+    // second k-tile in flight takes one round trip out of every two.
+    constexpr int PF = PFD;
     constexpr int PLANE_A = BM * 16, PLANE_B = BN * 16;
     constexpr int WGN = 2, WGM = 2;
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -1417,9 +1422,9 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
 }
 
 template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false, int ENG = 1,
-          bool SEG = false>
+          bool SEG = false, int PFD = 1>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
-    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, APRE, STATS, DROP, ENG, SEG>(p, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.x,
+    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, APRE, STATS, DROP, ENG, SEG, PFD>(p, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.x,
                                                                               (int)gridDim.z);
 }
 
@@ -1471,6 +1476,16 @@ int launch_split_e2(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 
     if (a.Aseg[0] != nullptr) {         // segmented A: plain rows x [N][K] weight (checked by the caller), with / without statistics
         if (a.stats != nullptr) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, true, false, 2, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, false, false, 2, true>), grid, block, 0, s, a);
+        return (int)hipGetLastError();
+    }
+    // short reductions on plain rows: two k-tiles in flight (RIH_E2_DEEP_K = largest K that takes this path, 0 = off)
+    static const int deep_k = [] { const char* e = getenv("RIH_E2_DEEP_K"); return e ? atoi(e) : 256; }();
+    if (plain && a_mode == 0 && b_mode < 2 && a.drop_thr == 0u && a.splitk == 1 && a.K <= deep_k && a.K > 32) {
+#define RIH_L2D(BM_, ST_) \
+    hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, BM_, true, false, ST_, false, 2, false, 2>), grid, block, 0, s, a)
+        if (a.stats != nullptr) { if (b_mode == 0) RIH_L2D(0, true); else RIH_L2D(1, true); }
+        else { if (b_mode == 0) RIH_L2D(0, false); else RIH_L2D(1, false); }
+#undef RIH_L2D
         return (int)hipGetLastError();
     }
     if (b_mode == 2) {          // B pre-split into two fp16 planes (weights, once per step)
