@@ -820,9 +820,9 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
     // global->register prefetch depth: k-tiles in flight.  The 64x64 tile (decoder-sized problems: a handful of
     // k-tiles, 12 MFMAs each) is bound by the load round trip per k-tile, so it keeps three tiles in flight.
     // (measured in round 2: 3 tiles in flight for the 64x64 tile changes nothing on decoder-sized problems, the floor is elsewhere.)
-    // PFD = 2 (round 4, engine 2, plain rows, short reductions -- the 1x1 convolutions with K <= 256 and a million rows): such a
-    // workgroup is a chain of dependent memory round trips (bound, k-tile, k-tile, ..., store) with a few MFMAs between them; a
-    // second k-tile in flight takes one round trip out of every two.
+    // PFD = 2 (round 4 experiment, engine 2, plain rows, short reductions -- the 1x1 convolutions with K <= 256 and a million
+    // rows): such a workgroup is a chain of dependent memory round trips (bound, k-tile, k-tile, ..., store) with a few MFMAs
+    // between them; a second k-tile in flight was meant to take one round trip out of every two.  Measured slower (launch_split_e2).
     constexpr int PF = PFD;
     constexpr int PLANE_A = BM * 16, PLANE_B = BN * 16;
     constexpr int WGN = 2, WGM = 2;
@@ -1478,8 +1478,12 @@ int launch_split_e2(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 
         else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, false, false, 2, true>), grid, block, 0, s, a);
         return (int)hipGetLastError();
     }
-    // short reductions on plain rows: two k-tiles in flight (RIH_E2_DEEP_K = largest K that takes this path, 0 = off)
-    static const int deep_k = [] { const char* e = getenv("RIH_E2_DEEP_K"); return e ? atoi(e) : 256; }();
+#if RIH_EXPERIMENTS
+    // short reductions on plain rows: two k-tiles in flight (RIH_E2_DEEP_K = largest K that takes this path, default 0 = off).
+    // REFUTED (round 4, session 12, one box): 1942.5 / 1937.3 images/s against 1960.2 / 1961.3 without it (-1.1 %); for every K
+    // (4096) 1940.2 -- the second register set costs 128x64 tiles one workgroup per CU (126 -> 146-152 VGPRs, 4 -> 3), and the
+    // workgroups a CU holds hide the round trips better than a deeper pipeline inside each of them.
+    static const int deep_k = [] { const char* e = getenv("RIH_E2_DEEP_K"); return e ? atoi(e) : 0; }();
     if (plain && a_mode == 0 && b_mode < 2 && a.drop_thr == 0u && a.splitk == 1 && a.K <= deep_k && a.K > 32) {
 #define RIH_L2D(BM_, ST_) \
     hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, BM_, true, false, ST_, false, 2, false, 2>), grid, block, 0, s, a)
@@ -1488,6 +1492,7 @@ int launch_split_e2(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 
 #undef RIH_L2D
         return (int)hipGetLastError();
     }
+#endif
     if (b_mode == 2) {          // B pre-split into two fp16 planes (weights, once per step)
 #if RIH_EXPERIMENTS
         if (a.drop_thr != 0u) return RIH_EINVAL;

@@ -41,12 +41,14 @@ def test_native_library_is_loaded_and_has_no_fallback():
     assert lib.rih_arch() == b'gfx950'
 
 
-def _grad_report(named_grads, g32, g64, k=6.0, floor=2e-4):
+def _grad_report(named_grads, g32, g64, k=6.0, floor=2e-4, max_loose=0.03):
     """Per-tensor gradient check anchored on the fp64 oracle.  ReLU / max-pool decisions are discontinuous: an
     activation within round-off of zero can flip between two fp32 implementations and move a small decoder gradient
     by O(1/rows) (seen on CPU too: with train-mode BN at B=2..3 the fp32 oracle's trunk gradients are several % from
-    its fp64 run).  So: at least 97% of the tensors must be within k x (the fp32 reference's own error vs fp64) +
-    floor, and every tensor within max(5%, 20 x that reference error) of max|ref|."""
+    its fp64 run).  So: all but a fraction `max_loose` of the tensors must be within k x (the fp32 reference's own error vs fp64) +
+    floor, and every tensor within max(5%, 20 x that reference error) of max|ref|.  `max_loose` per caller follows what the GPU
+    prints (profiles/r04/ab/c12_pytest_grad_reports.log, engine 2): ResNet50 model 0 of 823 tensors outside the 6x band (worst
+    3.0x) -> 0.5 %; second family 2 of 843 (worst 17x, one layer4 convolution at B = 2) -> 1 %; HRNet-W32 31 / 14 of 1621 -> 3 %."""
     n, loose, gross, worst = 0, [], [], (0.0, '', 0.0, 0.0)
     for name, g in named_grads:
         if testing.is_null_gradient(name):
@@ -64,7 +66,7 @@ def _grad_report(named_grads, g32, g64, k=6.0, floor=2e-4):
     print('_grad_report: %d tensors, %d outside the %gx band; worst %s: %.3g vs fp32 ref %.3g (%.1fx)'
           % (n, len(loose), k, worst[1], worst[2], worst[3], worst[0]))
     assert not gross, 'gradients grossly off:\n' + '\n'.join(gross[:20])
-    assert len(loose) <= 0.03 * n, '%d/%d gradient tensors outside the fp64-anchored band:\n%s' % (
+    assert len(loose) <= max_loose * n, '%d/%d gradient tensors outside the fp64-anchored band:\n%s' % (
         len(loose), n, '\n'.join(loose[:20]))
     return len(loose), n
 
@@ -126,7 +128,7 @@ def test_model_matches_fp64_oracle(training):
     net_oracle.scalar_loss(out).backward()
     params = [(k, p.grad) for k, p in m.named_parameters() if p.grad is not None]
     assert {k for k, _ in params} == set(g64.keys())
-    nloose, n = _grad_report(params, g32, g64)
+    nloose, n = _grad_report(params, g32, g64, max_loose=0.005)
     print('fp64-anchored: outputs worst %.3g (fp32 ref %.3g); grads %d/%d outside band'
           % (max(v[0] for v in report.values()), max(v[1] for v in report.values()), nloose, n))
 
@@ -540,7 +542,7 @@ def test_family_b_matches_fp64_oracle(training):
     net_oracle.scalar_loss(out).backward()
     params = [(k, p.grad) for k, p in m.named_parameters() if p.grad is not None]
     assert {k for k, _ in params} == set(g64.keys())
-    _grad_report(params, g32, g64)
+    _grad_report(params, g32, g64, max_loose=0.01)
 
 
 # ------------------------------------------------------------------------------------------------ TrainStep helper
