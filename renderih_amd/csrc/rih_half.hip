@@ -456,14 +456,22 @@ extern "C" int rih_hconv(const rih_hconv_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const long long tilesM = (M + BM - 1) / BM;
     static const bool glds = [] { const char* e = getenv("RIH_HCONV_GLDS"); return !(e && e[0] == '0'); }();
-    if (d->Cout > 64) {
+    // 128x64 tiles (three workgroups per CU instead of two; A is re-read per 64 columns) also for wide outputs when the reduction
+    // is ONE k-tile: measured per shape at B = 256 (profiles/r04/c13_hconv_sweep_*.log) 1x1 64 -> 256 at 64x64 297 -> 272 us with
+    // the residual, 279 -> 254 without; everywhere (RIH_HCONV_BN=64) the 3x3 convolutions lose 14-45 % and a forward 8 %.
+    // RIH_HCONV_BN=128 switches the rule off.
+    static const int force_bn = [] { const char* e = getenv("RIH_HCONV_BN"); return e ? atoi(e) : 0; }();
+    const bool narrow = force_bn == 64 || (force_bn != 128 && d->Kpad <= BKH);
+    if (d->Cout > 64 && !narrow) {
         const long long tiles = tilesM * ((d->Cout + 127) / 128);
         if (tiles > 0x7fffffffLL) return RIH_EINVAL;
         if (glds) hipLaunchKernelGGL((hconv_kernel<128, true>), dim3((unsigned)tiles), dim3(TPB), 0, s, a);
         else hipLaunchKernelGGL((hconv_kernel<128, false>), dim3((unsigned)tiles), dim3(TPB), 0, s, a);
     } else {
-        if (glds) hipLaunchKernelGGL((hconv_kernel<64, true>), dim3((unsigned)tilesM), dim3(TPB), 0, s, a);
-        else hipLaunchKernelGGL((hconv_kernel<64, false>), dim3((unsigned)tilesM), dim3(TPB), 0, s, a);
+        const long long tiles = tilesM * ((d->Cout + 63) / 64);
+        if (tiles > 0x7fffffffLL) return RIH_EINVAL;
+        if (glds) hipLaunchKernelGGL((hconv_kernel<64, true>), dim3((unsigned)tiles), dim3(TPB), 0, s, a);
+        else hipLaunchKernelGGL((hconv_kernel<64, false>), dim3((unsigned)tiles), dim3(TPB), 0, s, a);
     }
     return (int)hipGetLastError();
 }
