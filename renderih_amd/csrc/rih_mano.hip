@@ -631,75 +631,128 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
             __syncthreads();            // the scratch (src / sp) is overwritten by the v_tpose tile below
         }
         RIH_STAMP(5);
-        for (int tl = 0; tl < (HM ? NTILES : 1); ++tl) {
-        // (hand-major: every workgroup streams the same 13 tiles -- each starts at its own, so that the CUs of an XCD do not
-        // all ask the same L2 channels for the same lines at the same time)
-        const int tile = HM ? (tl + (int)blockIdx.x) % NTILES : tile_fixed;
-        const int v = tile * TILE_V + lane;
-        const bool valid = v < NV;
-        if (HM) {
-            __syncthreads();        // the previous tile's skinning is done with the v_tpose tile; phase 1 with its scratch
-            load_basis(tile);
-            load_weights(tile);
-            __syncthreads();
-        }
-        // ---- phase 2: v_tpose[16][192] = operand[16][148] x Bmat tile; wave w owns coordinate blocks 3w .. 3w+2
+        // ---- phase 2: v_tpose[16][192] = operand[16][148] x Bmat tile; wave w owns coordinate blocks 3w .. 3w+2 (k-steps of 4)
         floatx4 acc[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-        {
+        auto blend_steps = [&](int ks0, int ks1) {
             const float* a_rd = s_pf + (lane & 15) * LDPF + (lane >> 4);
             const float* b_rd = s_B + (lane >> 4) * 192 + wave * 48 + (lane & 15);
 #pragma unroll 4
-            for (int ks = 0; ks < KP / 4; ++ks) {
+            for (int ks = ks0; ks < ks1; ++ks) {
                 const float a = a_rd[4 * ks];
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b_rd[4 * ks * 192 + 16 * j], acc[j], 0, 0, 0);
             }
-        }
+        };
         // C/D layout: column = lane & 15 (coordinate), row = 4 * (lane >> 4) + r (hand)
+        auto park_vtpose = [&]() {
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s_scr[(4 * (lane >> 4) + r) * 192 + wave * 48 + 16 * j + (lane & 15)] = acc[j][r];
-        __syncthreads();
-        RIH_STAMP(6);
+                for (int r = 0; r < 4; ++r) s_scr[(4 * (lane >> 4) + r) * 192 + wave * 48 + 16 * j + (lane & 15)] = acc[j][r];
+        };
         // ---- phase 3: skinning, lane = vertex, wave w takes hands w, w+4, ...
-        for (int hl = wave; hl < HC; hl += 4) {
-            const int h = h0 + hl;
-            if (h >= B) break;                                  // wave-uniform
-            const float* G = &s_G[hl * GST];
-            float T[12];
+        auto skin = [&](int tile) {
+            const int v = tile * TILE_V + lane;
+            const bool valid = v < NV;
+            for (int hl = wave; hl < HC; hl += 4) {
+                const int h = h0 + hl;
+                if (h >= B) break;                                  // wave-uniform
+                const float* G = &s_G[hl * GST];
+                float T[12];
 #pragma unroll
-            for (int e = 0; e < 12; ++e) T[e] = 0.f;
+                for (int e = 0; e < 12; ++e) T[e] = 0.f;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const float4 g0 = *reinterpret_cast<const float4*>(G + j * 12);
-                const float4 g1 = *reinterpret_cast<const float4*>(G + j * 12 + 4);
-                const float4 g2 = *reinterpret_cast<const float4*>(G + j * 12 + 8);
-                T[0] += wgt[j] * g0.x; T[1] += wgt[j] * g0.y; T[2] += wgt[j] * g0.z; T[3] += wgt[j] * g0.w;
-                T[4] += wgt[j] * g1.x; T[5] += wgt[j] * g1.y; T[6] += wgt[j] * g1.z; T[7] += wgt[j] * g1.w;
-                T[8] += wgt[j] * g2.x; T[9] += wgt[j] * g2.y; T[10] += wgt[j] * g2.z; T[11] += wgt[j] * g2.w;
-            }
-            const float* post = G + 192;
-            const float vt0 = s_scr[hl * 192 + lane * 3], vt1 = s_scr[hl * 192 + lane * 3 + 1], vt2 = s_scr[hl * 192 + lane * 3 + 2];
-            if (valid) {
-                const float x = T[0] * vt0 + T[1] * vt1 + T[2] * vt2 + T[3] - post[0];
-                const float y = T[4] * vt0 + T[5] * vt1 + T[6] * vt2 + T[7] - post[1];
-                const float z = T[8] * vt0 + T[9] * vt1 + T[10] * vt2 + T[11] - post[2];
-                float* o = vout + ((long long)h * NV + v) * 3;
-                o[0] = x * post[3] + post[4];
-                o[1] = y * post[3] + post[5];
-                o[2] = z * post[3] + post[6];
-                if (ws != nullptr) {
-                    float* w = ws + (long long)h * WS_STRIDE;
-                    w[OFF_VT + v * 3 + 0] = vt0; w[OFF_VT + v * 3 + 1] = vt1; w[OFF_VT + v * 3 + 2] = vt2;
-                    w[OFF_VSC + v * 3 + 0] = x; w[OFF_VSC + v * 3 + 1] = y; w[OFF_VSC + v * 3 + 2] = z;
+                for (int j = 0; j < NJ; ++j) {
+                    const float4 g0 = *reinterpret_cast<const float4*>(G + j * 12);
+                    const float4 g1 = *reinterpret_cast<const float4*>(G + j * 12 + 4);
+                    const float4 g2 = *reinterpret_cast<const float4*>(G + j * 12 + 8);
+                    T[0] += wgt[j] * g0.x; T[1] += wgt[j] * g0.y; T[2] += wgt[j] * g0.z; T[3] += wgt[j] * g0.w;
+                    T[4] += wgt[j] * g1.x; T[5] += wgt[j] * g1.y; T[6] += wgt[j] * g1.z; T[7] += wgt[j] * g1.w;
+                    T[8] += wgt[j] * g2.x; T[9] += wgt[j] * g2.y; T[10] += wgt[j] * g2.z; T[11] += wgt[j] * g2.w;
+                }
+                const float* post = G + 192;
+                const float vt0 = s_scr[hl * 192 + lane * 3], vt1 = s_scr[hl * 192 + lane * 3 + 1], vt2 = s_scr[hl * 192 + lane * 3 + 2];
+                if (valid) {
+                    const float x = T[0] * vt0 + T[1] * vt1 + T[2] * vt2 + T[3] - post[0];
+                    const float y = T[4] * vt0 + T[5] * vt1 + T[6] * vt2 + T[7] - post[1];
+                    const float z = T[8] * vt0 + T[9] * vt1 + T[10] * vt2 + T[11] - post[2];
+                    float* o = vout + ((long long)h * NV + v) * 3;
+                    o[0] = x * post[3] + post[4];
+                    o[1] = y * post[3] + post[5];
+                    o[2] = z * post[3] + post[6];
+                    if (ws != nullptr) {
+                        float* w = ws + (long long)h * WS_STRIDE;
+                        w[OFF_VT + v * 3 + 0] = vt0; w[OFF_VT + v * 3 + 1] = vt1; w[OFF_VT + v * 3 + 2] = vt2;
+                        w[OFF_VSC + v * 3 + 0] = x; w[OFF_VSC + v * 3 + 1] = y; w[OFF_VSC + v * 3 + 2] = z;
+                    }
                 }
             }
+        };
+        if (!HM) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+            blend_steps(0, KP / 4);
+            park_vtpose();
+            __syncthreads();
+            RIH_STAMP(6);
+            skin(tile_fixed);
+        } else {
+            // Hand-major: every workgroup streams the same 13 tiles (each starts at its own, so that the CUs of an XCD do not all
+            // ask the same L2 channels for the same lines at the same time).  Round 4: the tile arrives in two halves of its
+            // k-range (rows 0..75 = 19 k-steps, rows 76..147 = 18), and the NEXT half is always in flight -- global -> registers
+            // -- while the MFMAs (and, for the first half of the next tile, the skinning) of the current one run; it lands in the
+            // LDS rows its predecessor has finished with.  One basis tile of LDS as before (two would be 222 KB); the chain of
+            // round trips load -> blend -> skin per tile (13 x ~9 us of a 127 us forward at 4096 hands) loses its load link.
+            constexpr int H0 = 76, KS0 = H0 / 4, NHR = 15;          // 76 x 48 = 3648 16-byte items = 14.25 per thread
+            floatx4 hr[NHR];
+            auto issue_half = [&](int tile, int half) {
+                const int r0 = half ? H0 : 0, total = (half ? KP - H0 : H0) * 48;
+#pragma unroll
+                for (int u = 0; u < NHR; ++u) {
+                    const int i = t + 256 * u;
+                    hr[u] = floatx4{0.f, 0.f, 0.f, 0.f};
+                    if (i < total) {
+                        const int k = i / 48, q = i - k * 48;
+                        hr[u] = *reinterpret_cast<const floatx4*>(pk + (long long)(r0 + k) * NCP + tile * 192 + 4 * q);
+                    }
+                }
+            };
+            auto land_half = [&](int half) {
+                const int r0 = half ? H0 : 0, total = (half ? KP - H0 : H0) * 48;
+#pragma unroll
+                for (int u = 0; u < NHR; ++u) {
+                    const int i = t + 256 * u;
+                    if (i < total) {
+                        const int k = i / 48, q = i - k * 48;
+                        *reinterpret_cast<floatx4*>(s_B + (r0 + k) * 192 + 4 * q) = hr[u];
+                    }
+                }
+            };
+            const int tile0 = (int)blockIdx.x % NTILES;
+            issue_half(tile0, 0);
+            __syncthreads();            // phase 1 is done with its scratch; the previous chunk's last blend with the basis rows
+            land_half(0);
+            __syncthreads();
+            for (int tl = 0; tl < NTILES; ++tl) {
+                const int tile = (tl + (int)blockIdx.x) % NTILES;
+                issue_half(tile, 1);
+                load_weights(tile);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+                blend_steps(0, KS0);
+                land_half(1);           // rows 76..147: the previous tile's second half was finished before its skinning
+                __syncthreads();
+                if (tl + 1 < NTILES) issue_half((tile + 1) % NTILES, 0);
+                blend_steps(KS0, KP / 4);
+                park_vtpose();
+                __syncthreads();        // v_tpose complete; every wave is done with rows 0..75
+                if (tl == 0) RIH_STAMP(6);
+                skin(tile);
+                if (tl + 1 < NTILES) land_half(0);
+                __syncthreads();        // next tile's first half landed; the skinning is done with the v_tpose tile
+            }
         }
-        }   // tiles
         RIH_STAMP(7);
     }
 #undef RIH_STAMP
@@ -1064,17 +1117,57 @@ __global__ __launch_bounds__(256) void mano_bwd_blend_kernel(Model m, const floa
         floatx4 acc[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-        for (int tl = 0; tl < NTILES; ++tl) {
-            __syncthreads();                    // the previous tile's products (and the previous chunk's epilogue) are done
-            const int tile = (tl + chunk) % NTILES;         // staggered start: see the forward's tile loop
-            const int n0 = tile * 192;
-            load_tile_192<BL_P>(s_B, pk + n0, NCP, KP, t);
-            {       // the gradient tile [16 hands][192]; rows of hands behind the end of the batch are zero
-                const int nh = min(HC, B - h0);
-                load_tile_192<BL_P>(s_V, wsb + (long long)h0 * BW_STRIDE + n0, BW_STRIDE, nh, t);
-                for (int i = t; i < (HC - nh) * 192; i += 256) s_V[(nh + i / 192) * BL_P + i % 192] = 0.f;
+        // Round 4: a tile arrives in two halves of its 192 columns (the k-range of these products), and the NEXT half is always
+        // in flight -- global -> registers -- while the MFMAs of the current one run; it lands in the columns its predecessor has
+        // finished with (same LDS, same order of the fp32 sums).  Before: load -> sync -> multiply per tile, 13 exposed round trips.
+        const int nh = min(HC, B - h0);
+        constexpr int NHB = 14, NHV = 2;            // 148 x 24 = 3552 16-byte items of a basis half, 16 x 24 = 384 of a gradient half
+        floatx4 hb[NHB], hv[NHV];
+        auto issue_half = [&](int tile, int half) {
+            const float* src = pk + tile * 192 + 96 * half;
+#pragma unroll
+            for (int u = 0; u < NHB; ++u) {
+                const int i = t + 256 * u;
+                hb[u] = floatx4{0.f, 0.f, 0.f, 0.f};
+                if (i < KP * 24) {
+                    const int k = i / 24, q = i - k * 24;
+                    hb[u] = *reinterpret_cast<const floatx4*>(src + (long long)k * NCP + 4 * q);
+                }
             }
-            __syncthreads();
+            const float* vsrc = wsb + (long long)h0 * BW_STRIDE + tile * 192 + 96 * half;
+#pragma unroll
+            for (int u = 0; u < NHV; ++u) {
+                const int i = t + 256 * u;
+                hv[u] = floatx4{0.f, 0.f, 0.f, 0.f};        // rows of hands behind the end of the batch are zero
+                if (i < HC * 24) {
+                    const int k = i / 24, q = i - k * 24;
+                    if (k < nh) hv[u] = *reinterpret_cast<const floatx4*>(vsrc + (long long)k * BW_STRIDE + 4 * q);
+                }
+            }
+        };
+        auto land_half = [&](int half) {            // (pitch 194: 8-byte stores)
+#pragma unroll
+            for (int u = 0; u < NHB; ++u) {
+                const int i = t + 256 * u;
+                if (i < KP * 24) {
+                    const int k = i / 24, q = i - k * 24;
+                    float* d = s_B + k * BL_P + 96 * half + 4 * q;
+                    *reinterpret_cast<floatx2*>(d) = floatx2{hb[u].x, hb[u].y};
+                    *reinterpret_cast<floatx2*>(d + 2) = floatx2{hb[u].z, hb[u].w};
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NHV; ++u) {
+                const int i = t + 256 * u;
+                if (i < HC * 24) {
+                    const int k = i / 24, q = i - k * 24;
+                    float* d = s_V + k * BL_P + 96 * half + 4 * q;
+                    *reinterpret_cast<floatx2*>(d) = floatx2{hv[u].x, hv[u].y};
+                    *reinterpret_cast<floatx2*>(d + 2) = floatx2{hv[u].z, hv[u].w};
+                }
+            }
+        };
+        auto products = [&](int ks0, int ks1) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int blk = wave + 4 * j;                       // column block 0..9 (wave-uniform)
@@ -1082,9 +1175,24 @@ __global__ __launch_bounds__(256) void mano_bwd_blend_kernel(Model m, const floa
                 const float* a_rd = s_V + (lane & 15) * BL_P + (lane >> 4);
                 const float* b_rd = s_B + (blk * 16 + (lane & 15)) * BL_P + (lane >> 4);
 #pragma unroll 8
-                for (int ks = 0; ks < 48; ++ks)
+                for (int ks = ks0; ks < ks1; ++ks)
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_rd[4 * ks], b_rd[4 * ks], acc[j], 0, 0, 0);
             }
+        };
+        issue_half(chunk % NTILES, 0);              // staggered start: see the forward's tile loop
+        __syncthreads();                            // the previous chunk's epilogue is done with its scratch in the basis rows
+        land_half(0);
+        __syncthreads();
+        for (int tl = 0; tl < NTILES; ++tl) {
+            const int tile = (tl + chunk) % NTILES;
+            issue_half(tile, 1);
+            products(0, 24);
+            land_half(1);               // columns 96..191: the previous tile's second half was multiplied before the last barrier
+            __syncthreads();
+            if (tl + 1 < NTILES) issue_half((tile + 1) % NTILES, 0);
+            products(24, 48);
+            if (tl + 1 < NTILES) land_half(0);      // columns 0..95: every wave left them before the barrier above
+            __syncthreads();
         }
         __syncthreads();
         // C/D layout: column = lane & 15 (basis row within the block), row = 4 * (lane >> 4) + r (hand)

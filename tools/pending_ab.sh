@@ -1,4 +1,6 @@
 #!/bin/bash
+# EXECUTED in round 4, session 1 (logs: profiles/r04/ab/{train,hrnet,config5,pytest}_*.log); RIH_WGRAD_GROUP_T128 and RIH_BN_LASTBLOCK
+# were removed after it (measured neutral / slower) -- kept as the record of what produced those logs, not runnable any more.
 # The experiments that were BUILT but not measured when round 3 ran out of GPU minutes, as one GPU-box session (~12 min):
 #   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/pending_ab.sh'
 # 1. RIH_SKIP_DEAD_MID=1 -- the finest mid convolution, whose output decoder.forward drops: the gated GPU
