@@ -357,7 +357,10 @@ typedef float floatx2 __attribute__((ext_vector_type(2)));
 // 16-byte requests go out in batches of 12 per thread BEFORE the first LDS store (a load -> store loop waits one L2 round trip
 // per iteration: 28 dependent round trips per basis tile, ~26 us -- what the tile streaming of the hand-major forward and of
 // the backward blend kernel used to cost).  PITCH % 4 == 0: 16-byte stores; otherwise (even pitch) two 8-byte stores.
-template <int PITCH>
+// SWZ (the forward's basis tile, pitch 192 = 3 x 64 banks): the 16-float column block of row k is stored at block ^ (k & 3), so
+// that the blend GEMM's operand read -- 4 consecutive rows x 16 consecutive columns per wave instruction -- hits 64 different
+// banks instead of 16 four times (round 4; a padded pitch does not fit: the kernel uses 162.7 of 163.8 KB).
+template <int PITCH, bool SWZ = false>
 __device__ __forceinline__ void load_tile_192(float* __restrict__ dst, const float* __restrict__ src, long long src_ld, int rows,
                                               int t) {
     constexpr int NB = 12;
@@ -378,7 +381,7 @@ __device__ __forceinline__ void load_tile_192(float* __restrict__ dst, const flo
             const int i = base + t + 256 * u;
             if (i < total) {
                 const int k = i / 48, q = i - k * 48;
-                float* d = dst + k * PITCH + 4 * q;
+                float* d = dst + k * PITCH + (SWZ ? ((4 * q) ^ ((k & 3) << 4)) : 4 * q);
                 if (PITCH % 4 == 0) {
                     *reinterpret_cast<floatx4*>(d) = r[u];
                 } else {
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
     const bool need_special = first_tile || centre_is_tip;
 
     // the basis tile: rows are 192 contiguous floats of Bmat
-    auto load_basis = [&](int tile) { load_tile_192<192>(s_B, pk + tile * 192, NCP, KP, t); };
+    auto load_basis = [&](int tile) { load_tile_192<192, true>(s_B, pk + tile * 192, NCP, KP, t); };
     if (!HM) load_basis(tile_fixed);
     for (int i = t; i < 528; i += 256) s_J[i] = pk[PK_JT + i];
     if (t < NJ) {
@@ -634,14 +637,18 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
         // ---- phase 2: v_tpose[16][192] = operand[16][148] x Bmat tile; wave w owns coordinate blocks 3w .. 3w+2 (k-steps of 4)
         floatx4 acc[3];
         auto blend_steps = [&](int ks0, int ks1) {
-            const float* a_rd = s_pf + (lane & 15) * LDPF + (lane >> 4);
-            const float* b_rd = s_B + (lane >> 4) * 192 + wave * 48 + (lane & 15);
+            const int kq = lane >> 4;                       // row 4 ks + kq: its column blocks sit at block ^ kq (load_tile_192 SWZ)
+            const float* a_rd = s_pf + (lane & 15) * LDPF + kq;
+            const float* b_rd = s_B + kq * 192 + (lane & 15);
+            int cb[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) cb[j] = (wave * 48 + 16 * j) ^ (kq << 4);
 #pragma unroll 4
             for (int ks = ks0; ks < ks1; ++ks) {
                 const float a = a_rd[4 * ks];
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b_rd[4 * ks * 192 + 16 * j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b_rd[4 * ks * 192 + cb[j]], acc[j], 0, 0, 0);
             }
         };
         // C/D layout: column = lane & 15 (coordinate), row = 4 * (lane >> 4) + r (hand)
@@ -659,6 +666,8 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
                 const int h = h0 + hl;
                 if (h >= B) break;                                  // wave-uniform
                 const float* G = &s_G[hl * GST];
+                // (six two-component FMAs per joint -- v_pk_fma_f32 -- instead of these twelve were measured in round 4:
+                // 121 -> 128.6 us at 4096 hands; the scalar form stays)
                 float T[12];
 #pragma unroll
                 for (int e = 0; e < 12; ++e) T[e] = 0.f;
@@ -673,6 +682,9 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
                 }
                 const float* post = G + 192;
                 const float vt0 = s_scr[hl * 192 + lane * 3], vt1 = s_scr[hl * 192 + lane * 3 + 1], vt2 = s_scr[hl * 192 + lane * 3 + 2];
+                // (the three dword stores per output at a 12-byte stride stay: sending the 192 consecutive floats of a tile back
+                // through LDS to leave as 8-byte stores of consecutive lanes was measured in round 4 -- 121 -> 184 us at 4096
+                // hands: three dependent LDS round trips per hand cost far more than the scattered stores)
                 if (valid) {
                     const float x = T[0] * vt0 + T[1] * vt1 + T[2] * vt2 + T[3] - post[0];
                     const float y = T[4] * vt0 + T[5] * vt1 + T[6] * vt2 + T[7] - post[1];
@@ -725,7 +737,7 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
                     const int i = t + 256 * u;
                     if (i < total) {
                         const int k = i / 48, q = i - k * 48;
-                        *reinterpret_cast<floatx4*>(s_B + (r0 + k) * 192 + 4 * q) = hr[u];
+                        *reinterpret_cast<floatx4*>(s_B + (r0 + k) * 192 + ((4 * q) ^ (((r0 + k) & 3) << 4))) = hr[u];
                     }
                 }
             };
@@ -1094,16 +1106,17 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(Model m, const float* __r
 //   of the shape gradient (the joint-regressor part is Js^T djt, added in the epilogue).
 // Hand-chunk major like the forward: a workgroup owns chunks of 16 hands and streams the 13 basis tiles ([148][192], zero rows
 // up to 160) from L2 through LDS; per tile ten 16 x 16 x 192 products on v_mfma_f32_16x16x4_f32 (column blocks of 16 basis
-// rows; two or three per wavefront), accumulated over the tiles in registers.  LDS rows have an even-but-not-multiple-of-32 pitch (194 floats) so that the k-strided operand reads of 16 rows
-// are bank-conflict free.  Epilogue per hand: pose-blend term into the joint-rotation gradients, Rodrigues backward, PCA
+// rows; two or three per wavefront), accumulated over the tiles in registers.  LDS row pitch 196 floats: the k-strided operand
+// reads of 16 rows are bank-conflict free.  Epilogue per hand: pose-blend term into the joint-rotation gradients, Rodrigues backward, PCA
 // projection (or the rotation-matrix gradients as they are), shape gradient.
-constexpr int BL_P = 194;                       // LDS row pitch
+constexpr int BL_P = 196;                       // LDS row pitch: 196 mod 64 = 4, so the 16 rows x 4 k of an operand read (bank =
+                                                // 4 row + k) hit 64 different banks (194, rounds 2-3: pairs of lanes collided)
 constexpr int BL_ROWS = 160;                    // basis rows incl. zero padding to ten 16-column blocks
 __global__ __launch_bounds__(256) void mano_bwd_blend_kernel(Model m, const float* __restrict__ pk, int ncomp,
                                                              const float* __restrict__ pose, const float* __restrict__ wsb,
                                                              float* __restrict__ d_pose, float* __restrict__ d_shape, int B) {
-    __shared__ __attribute__((aligned(16))) float s_B[BL_ROWS * BL_P];      // 124,160 B
-    __shared__ __attribute__((aligned(16))) float s_V[HC * BL_P];           //  12,416 B: dv_tpose tile
+    __shared__ __attribute__((aligned(16))) float s_B[BL_ROWS * BL_P];      // 125,440 B
+    __shared__ __attribute__((aligned(16))) float s_V[HC * BL_P];           //  12,544 B: dv_tpose tile
     float* s_dR = s_B;                          // epilogue scratch in the (then dead) first basis rows: [HC][144] | 3 x [HC][48]
     float* s_ax = s_B + HC * 144;
     float* s_dax = s_ax + HC * 48;
@@ -1145,15 +1158,13 @@ __global__ __launch_bounds__(256) void mano_bwd_blend_kernel(Model m, const floa
                 }
             }
         };
-        auto land_half = [&](int half) {            // (pitch 194: 8-byte stores)
+        auto land_half = [&](int half) {            // (pitch 196: rows stay 16-byte aligned)
 #pragma unroll
             for (int u = 0; u < NHB; ++u) {
                 const int i = t + 256 * u;
                 if (i < KP * 24) {
                     const int k = i / 24, q = i - k * 24;
-                    float* d = s_B + k * BL_P + 96 * half + 4 * q;
-                    *reinterpret_cast<floatx2*>(d) = floatx2{hb[u].x, hb[u].y};
-                    *reinterpret_cast<floatx2*>(d + 2) = floatx2{hb[u].z, hb[u].w};
+                    *reinterpret_cast<floatx4*>(s_B + k * BL_P + 96 * half + 4 * q) = hb[u];
                 }
             }
 #pragma unroll
@@ -1161,9 +1172,7 @@ __global__ __launch_bounds__(256) void mano_bwd_blend_kernel(Model m, const floa
                 const int i = t + 256 * u;
                 if (i < HC * 24) {
                     const int k = i / 24, q = i - k * 24;
-                    float* d = s_V + k * BL_P + 96 * half + 4 * q;
-                    *reinterpret_cast<floatx2*>(d) = floatx2{hv[u].x, hv[u].y};
-                    *reinterpret_cast<floatx2*>(d + 2) = floatx2{hv[u].z, hv[u].w};
+                    *reinterpret_cast<floatx4*>(s_V + k * BL_P + 96 * half + 4 * q) = hv[u];
                 }
             }
         };
