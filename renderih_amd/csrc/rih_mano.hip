@@ -667,7 +667,9 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
                 if (h >= B) break;                                  // wave-uniform
                 const float* G = &s_G[hl * GST];
                 // (six two-component FMAs per joint -- v_pk_fma_f32 -- instead of these twelve were measured in round 4:
-                // 121 -> 128.6 us at 4096 hands; the scalar form stays)
+                // 121 -> 128.6 us at 4096 hands; and T as a [64 vertices x 16 joints] x [16 x 12] product on the f32 MFMA with a
+                // quad transpose-reduce behind it, which takes the 48 broadcast ds_read_b128 per hand away: 121 -> 147-150 us
+                // (profiles/r04/c19, c20).  The scalar form stays.)
                 float T[12];
 #pragma unroll
                 for (int e = 0; e < 12; ++e) T[e] = 0.f;
