@@ -420,6 +420,16 @@ def main():
         for _ in range(2):
             ref_step()
         torch.cuda.synchronize()
+        if os.environ.get('RIH_PROFILE_REF_LOOP'):          # host-side profile of the eager loop (it is launch-bound)
+            import cProfile
+            import pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            for _ in range(3):
+                ref_step()
+            torch.cuda.synchronize()
+            pr.disable()
+            pstats.Stats(pr, stream=sys.stderr).sort_stats('tottime').print_stats(45)
         t0 = time.perf_counter()
         for _ in range(5):
             ref_step()
