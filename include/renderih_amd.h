@@ -139,8 +139,26 @@ typedef struct rih_gemm_desc {
     const float* a_seg[3];
     int32_t lda_seg[3];
     int32_t k_seg[3];
+    /* BatchNorm-backward sums in the epilogue (ABI 14; engine 2 on the fast path of tiles 0..2, a_mode 0, no split-K, no batch,
+     * no statistics / dropout / segmented A, N % 4 == 0): the GEMM output C[M][N] is the gradient dy arriving at a BatchNorm
+     * whose input was x (same [M][N] geometry, row pitch bnb_ldx) -- a convolution's data gradient flowing into the
+     * Conv -> BN -> ReLU in front of it (models/encoder.py:107-116 in reverse).  The epilogue gates the values it stores with the
+     * ReLU pattern bnb_mask (rih_bn_apply's relu_mask; NULL = no ReLU) and leaves, per block of rih_gemm_bnb_rows(desc) rows,
+     * the column sums bnb_part[0][block][n] = sum dy and bnb_part[1][block][n] = sum dy * (x - mean) * invstd
+     * (bnb_part[2][bnb_T][N], bnb_T = ceil(M / rows)): the reduction pass of rih_bn_bwd without its pass over dy and x
+     * (rih_bn_bwd_partials finishes).  The stored C is the un-gated dy, as without the fold.  NULL = off; RIH_EINVAL when set on a
+     * descriptor that does not take that path (rih_gemm_bnb_rows returns 0 for it). */
+    const float* bnb_x;
+    const uint8_t* bnb_mask;
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    float* bnb_part;
+    int32_t bnb_ldx;
+    int32_t bnb_T;
 } rih_gemm_desc;
 int rih_gemm_stats_rows(const rih_gemm_desc* d);
+/* rows per block of the bnb_* epilogue for this descriptor (bnb fields ignored), 0 when it would not take that path */
+int rih_gemm_bnb_rows(const rih_gemm_desc* d);
 int rih_gemm_dropout_ok(const rih_gemm_desc* d);
 /* The engine rih_gemm would run `d` on (0 / 1 / 2), or -1 for an invalid descriptor. */
 int rih_gemm_engine(const rih_gemm_desc* d);
@@ -309,6 +327,11 @@ int rih_bn_apply(const float* x, const float* mean, const float* invstd, const f
 int rih_bn_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
                const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C,
                int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, float* amax_dx, void* stream);
+/* rih_bn_bwd without its reduction pass (ABI 14): `part`[2][T][C] holds per-row-block column sums of the ReLU-gated dy and of
+ * dy * xhat, written by the epilogue of the GEMM that produced dy (rih_gemm_desc.bnb_*).  One finishing launch + the apply pass. */
+int rih_bn_bwd_partials(const float* part, int T, const float* dy, const float* x, const float* mean, const float* invstd,
+                        const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C, int relu,
+                        int frozen_stats, const uint8_t* relu_mask, float* amax_dx, void* stream);
 /* amax_dx (optional, ABI 13): a bound block that receives max|dx|, as `amax` of rih_bn_apply -- dx is the gradient operand of
  * the producing convolution's data- and weight-gradient GEMMs. */
 
@@ -488,7 +511,7 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
  * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of EVERY by-pointer struct, in
  * this order: gemm desc, mano model, mesh topo, hconv desc, reduce desc, pack desc, ln final desc, adam entry, absmax desc,
  * presplit desc (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it mis-laid-out structs. */
-#define RIH_ABI_VERSION 13
+#define RIH_ABI_VERSION 14
 #define RIH_ABI_NSIZES 10
 int rih_version(void);
 int rih_abi_sizes(int32_t* out10);

@@ -31,7 +31,9 @@ class GemmDesc(C.Structure):
                 ('reserved0', C.c_int32), ('sBias1', C.c_int64), ('sR1', C.c_int64), ('stats', C.c_void_p),
                 ('drop_p', C.c_float), ('reserved1', C.c_int32), ('drop_seed', C.c_uint64), ('drop_seed_dev', C.c_void_p),
                 ('amax_a', C.c_void_p), ('amax_b', C.c_void_p),
-                ('a_seg', C.c_void_p * 3), ('lda_seg', C.c_int32 * 3), ('k_seg', C.c_int32 * 3)]
+                ('a_seg', C.c_void_p * 3), ('lda_seg', C.c_int32 * 3), ('k_seg', C.c_int32 * 3),
+                ('bnb_x', C.c_void_p), ('bnb_mask', C.c_void_p), ('bnb_mean', C.c_void_p), ('bnb_invstd', C.c_void_p),
+                ('bnb_part', C.c_void_p), ('bnb_ldx', C.c_int32), ('bnb_T', C.c_int32)]
 
 
 class GemmP3Desc(C.Structure):
@@ -167,6 +169,8 @@ SIGNATURES = {
     'rih_bn_eval_stats': (c_i, [c_f, c_f, c_i, c_fl, c_f, c_f, C.c_void_p]),
     'rih_bn_apply': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, C.c_void_p, c_f, C.c_void_p]),
     'rih_bn_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, C.c_void_p, c_f, C.c_void_p]),
+    'rih_bn_bwd_partials': (c_i, [c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, C.c_void_p, c_f,
+                                  C.c_void_p]),
     'rih_layernorm_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_i, C.c_void_p]),
     'rih_ln_nblk': (c_i, [c_i]),
     'rih_layernorm_fwd_grouped': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_l, c_l, c_fl, c_i, C.c_void_p]),
@@ -199,6 +203,7 @@ SIGNATURES = {
                             c_f, c_f, c_f, c_f, c_f, c_i, C.c_void_p]),
     'rih_mesh_loss_final': (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, C.c_void_p]),
     'rih_gemm_stats_rows': (c_i, [C.POINTER(GemmDesc)]),
+    'rih_gemm_bnb_rows': (c_i, [C.POINTER(GemmDesc)]),
     'rih_gemm_dropout_ok': (c_i, [C.POINTER(GemmDesc)]),
     'rih_gemm_engine': (c_i, [C.POINTER(GemmDesc)]),
     'rih_experiments': (c_i, []),
@@ -232,7 +237,7 @@ EXPERIMENT_SIGNATURES = {
 }
 HAS_EXPERIMENTS = False
 
-ABI_VERSION = 13     # = RIH_ABI_VERSION of include/renderih_amd.h
+ABI_VERSION = 14     # = RIH_ABI_VERSION of include/renderih_amd.h
 
 _lib = None
 

@@ -61,6 +61,10 @@ struct GemmArgs {
     unsigned a_plane;               // a_mode 2: bytes per pre-split plane of A (last: keeps the older kernels' kernarg offsets)
     int epi_vec;                    // C, R, bias and every stride involved are 16-byte aligned: the epilogue may use 16-byte accesses
     float* stats;                   // split fast path, a_mode 0, splitk 1: per wave-row-block column sums [M / WM][2][N] (or NULL)
+    // BatchNorm-backward sums in the epilogue (rih_gemm_desc.bnb_*; engine 2): x / ReLU pattern / statistics of the BatchNorm
+    // whose output gradient this GEMM produces, part[2][bnb_T][N]
+    const float* bnb_x; const unsigned char* bnb_mask; const float* bnb_mean; const float* bnb_invstd; float* bnb_part;
+    int bnb_ldx, bnb_T;
     // dropout in the epilogue (DROP variants of the split fast path; appended last: the older kernels' kernarg offsets stay):
     // element e of the output (offset from C in floats) is kept iff rih_hash(drop_seed + *drop_seed_dev, e) >= drop_thr
     unsigned drop_thr;              // 0 = off
@@ -193,7 +197,10 @@ constexpr int SLD = 36;             // floats per staged row: 32 + pad, keeps fl
 // rih_gemm followed by rih_add_dropout(R, ., p, seed) bit for bit and rih_dropout_bwd re-draws the same mask.
 // E2 (engine 2): the staged value is (acc + 2^-11 acc1) * inv_a * inv_b -- the correction accumulator folded in and the operand
 // scales undone (also for the raw split-K slabs, whose reduction knows nothing of scales).
-template <int TM, int TN, bool STATS = false, bool DROP = false, bool E2 = false>
+// BNB (rih_gemm_desc.bnb_*, round 4): the stored values are the gradient dy arriving at a BatchNorm; per column and wave row
+// block the sums of the ReLU-gated dy and of dy * xhat are left in p.bnb_part -- the reduction pass of rih_bn_bwd without its
+// reads of dy and x from memory (x and the ReLU pattern of the wave's whole tile are requested before the first store).
+template <int TM, int TN, bool STATS = false, bool DROP = false, bool E2 = false, bool BNB = false>
 __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&acc)[TM][TN], float* stg, float* __restrict__ C,
                                                  const float* __restrict__ biasp, const float* __restrict__ Rp, int mbase,
                                                  int nbase, int lane, floatx16 (*acc1)[TN] = nullptr, float inv_a = 1.f,
@@ -209,6 +216,33 @@ __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&a
     if (STATS) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) { ssh[j] = zero4(); ssum[j] = zero4(); ssq[j] = zero4(); scnt[j] = 0.f; }
+    }
+    float4 bs1[BNB ? TN : 1], bs2[BNB ? TN : 1], bmu[BNB ? TN : 1], bis[BNB ? TN : 1];
+    float4 bxv[BNB ? TM : 1][BNB ? TN : 1][4];
+    unsigned bbits[BNB ? TM : 1][BNB ? TN : 1][4];
+    if (BNB) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nbase + j * 32 + (lane & 7) * 4;
+            bs1[j] = zero4(); bs2[j] = zero4(); bmu[j] = zero4(); bis[j] = zero4();
+            if (n < p.N) {                  // (N % 4 == 0: a quad is inside or outside)
+                bmu[j] = *reinterpret_cast<const float4*>(p.bnb_mean + n);
+                bis[j] = *reinterpret_cast<const float4*>(p.bnb_invstd + n);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = mbase + i * 32 + (lane >> 3) + 8 * q;
+                    bxv[i][j][q] = zero4();
+                    bbits[i][j][q] = 0xFu;
+                    if (m < p.M && n < p.N) {
+                        const long long o = (long long)m * p.bnb_ldx + n;
+                        bxv[i][j][q] = *reinterpret_cast<const float4*>(p.bnb_x + o);
+                        if (p.bnb_mask != nullptr) bbits[i][j][q] = p.bnb_mask[o >> 2];
+                    }
+                }
+        }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -274,6 +308,17 @@ __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&a
                     if (n + 2 < p.N) crow[2] = v.z;
                     if (n + 3 < p.N) crow[3] = v.w;
                 }
+                if (BNB) {          // gate with the ReLU pattern, add to the two column sums of this lane
+                    const unsigned bits = bbits[i][j][q];
+                    const float4 xv = bxv[i][j][q];
+                    const float dx_ = (bits & 1u) ? v.x : 0.f, dy_ = (bits & 2u) ? v.y : 0.f;
+                    const float dz_ = (bits & 4u) ? v.z : 0.f, dw_ = (bits & 8u) ? v.w : 0.f;
+                    bs1[j].x += dx_; bs1[j].y += dy_; bs1[j].z += dz_; bs1[j].w += dw_;
+                    bs2[j].x += dx_ * ((xv.x - bmu[j].x) * bis[j].x);
+                    bs2[j].y += dy_ * ((xv.y - bmu[j].y) * bis[j].y);
+                    bs2[j].z += dz_ * ((xv.z - bmu[j].z) * bis[j].z);
+                    bs2[j].w += dw_ * ((xv.w - bmu[j].w) * bis[j].w);
+                }
                 if (STATS) {        // (columns past N are never written out below)
                     if (scnt[j] == 0.f) ssh[j] = v;
                     scnt[j] += 1.f;
@@ -281,6 +326,27 @@ __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&a
                     ssum[j].x += dx; ssum[j].y += dy; ssum[j].z += dz; ssum[j].w += dw;
                     ssq[j].x += dx * dx; ssq[j].y += dy * dy; ssq[j].z += dz * dz; ssq[j].w += dw * dw;
                 }
+            }
+        }
+    }
+    if (BNB) {
+        // the eight row-lanes (lane >> 3) of a column quad are added up (three xor-shuffle rounds, fixed order); lane >> 3 == 0
+        // writes the wave row block's two sums
+        const long long rb = mbase / (TM * 32);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float4 a1 = bs1[j], a2 = bs2[j];
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                a1.x += __shfl_xor(a1.x, o, 64); a1.y += __shfl_xor(a1.y, o, 64);
+                a1.z += __shfl_xor(a1.z, o, 64); a1.w += __shfl_xor(a1.w, o, 64);
+                a2.x += __shfl_xor(a2.x, o, 64); a2.y += __shfl_xor(a2.y, o, 64);
+                a2.z += __shfl_xor(a2.z, o, 64); a2.w += __shfl_xor(a2.w, o, 64);
+            }
+            const int n = nbase + j * 32 + (lane & 7) * 4;
+            if ((lane >> 3) == 0 && n < p.N && rb < p.bnb_T) {
+                *reinterpret_cast<float4*>(p.bnb_part + ((long long)0 * p.bnb_T + rb) * p.N + n) = a1;
+                *reinterpret_cast<float4*>(p.bnb_part + ((long long)1 * p.bnb_T + rb) * p.N + n) = a2;
             }
         }
     }
@@ -811,7 +877,7 @@ __device__ __forceinline__ uint4 bloadu4(__amdgpu_buffer_rsrc_t r, unsigned off)
 // ENG 2: the two-term fp16 split (three MFMA products, see e2_scale / split2h above) instead of the three-term bf16 one; same
 // loaders, LDS layout (two planes instead of three) and epilogue.  Not with pre-split operands.
 template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false, int ENG = 1,
-          bool SEG = false, int PFD = 1>
+          bool SEG = false, int PFD = 1, bool BNB = false>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk_x, const int blk_z, const int grid_x,
                                                 const int grid_z) {
     static_assert(ENG == 1 || (ENG == 2 && !APRE), "engine 2: B may arrive as two pre-split fp16 planes (BMODE 2), A never");
@@ -1413,7 +1479,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
 
     // ------------------------------------------------------------------ epilogue (store_tiles_wide; the main loop ended with a barrier)
     if constexpr (ENG == 2) {
-        store_tiles_wide<TM, TN, STATS, DROP, true>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp,
+        store_tiles_wide<TM, TN, STATS, DROP, true, BNB>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp,
                                                     m0 + wm * WM, n0 + wn * WN, lane, acc1, 1.f / e2_sa, 1.f / e2_sb);
     } else {
         store_tiles_wide<TM, TN, STATS, DROP>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp, m0 + wm * WM, n0 + wn * WN,
@@ -1422,9 +1488,9 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
 }
 
 template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false, int ENG = 1,
-          bool SEG = false, int PFD = 1>
+          bool SEG = false, int PFD = 1, bool BNB = false>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
-    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, APRE, STATS, DROP, ENG, SEG, PFD>(p, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.x,
+    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, APRE, STATS, DROP, ENG, SEG, PFD, BNB>(p, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.x,
                                                                               (int)gridDim.z);
 }
 
@@ -1476,6 +1542,14 @@ int launch_split_e2(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 
     if (a.Aseg[0] != nullptr) {         // segmented A: plain rows x [N][K] weight (checked by the caller), with / without statistics
         if (a.stats != nullptr) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, true, false, 2, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, false, false, 2, true>), grid, block, 0, s, a);
+        return (int)hipGetLastError();
+    }
+    if (a.bnb_part != nullptr) {        // BatchNorm-backward sums in the epilogue (gemm_impl checked the preconditions)
+#define RIH_L2B(BM_, PL_) \
+    hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, BM_, PL_, false, false, false, 2, false, 1, true>), grid, block, 0, s, a)
+        if (b_mode == 0) { if (plain) RIH_L2B(0, true); else RIH_L2B(0, false); }
+        else { if (plain) RIH_L2B(1, true); else RIH_L2B(1, false); }
+#undef RIH_L2B
         return (int)hipGetLastError();
     }
 #if RIH_EXPERIMENTS
@@ -2362,7 +2436,8 @@ struct PreparedGemm {       // what gemm_impl would launch on the split engine's
     int gx, gz, tile, a_mode, b_mode, plain, engine;
 };
 
-static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, PreparedGemm* prep = nullptr, int* engine_out = nullptr) {
+static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, PreparedGemm* prep = nullptr, int* engine_out = nullptr,
+                     int* bnb_rows = nullptr) {
     if (!d || !d->A || !d->B || !d->C) return RIH_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K < 0) return RIH_EINVAL;
     if (d->splitk < 1 || d->nb1 < 1 || d->nb2 < 1) return RIH_EINVAL;
@@ -2411,6 +2486,11 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
     a.cS = d->cS; a.cOH = d->cOH; a.cOW = d->cOW; a.cH = d->cH; a.cW = d->cW;
     a.ones_row = d->ones_row;
     a.stats = d->stats;
+    // (rih_gemm_bnb_rows asks about the path only: the bnb fields of its descriptor are ignored)
+    const bool bnb = d->bnb_part != nullptr && bnb_rows == nullptr && stats_rows == nullptr && engine_out == nullptr;
+    a.bnb_x = bnb ? d->bnb_x : nullptr; a.bnb_mask = bnb ? d->bnb_mask : nullptr; a.bnb_mean = bnb ? d->bnb_mean : nullptr;
+    a.bnb_invstd = bnb ? d->bnb_invstd : nullptr; a.bnb_part = bnb ? d->bnb_part : nullptr;
+    a.bnb_ldx = d->bnb_ldx; a.bnb_T = d->bnb_T;
     a.drop_thr = 0u; a.drop_scale = 1.f; a.drop_seed = 0ull; a.drop_seed_dev = nullptr;
     a.amax_a = d->amax_a; a.amax_b = d->amax_b;
     for (int i = 0; i < 3; ++i) { a.Aseg[i] = nullptr; a.ldaseg[i] = 0; a.kseg[i] = 0; a.aseg_bytes[i] = 0; }
@@ -2501,7 +2581,8 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
             // the statistics epilogue exists in the engine-2 form only: forward-type, no split-K, no batch, dense rows
             const bool st_ok = ok && e2t4 && d->a_mode == 0 && d->splitk == 1 && gz == 1 && d->cS <= 1;
             if (stats_rows != nullptr) { *stats_rows = st_ok ? 128 : 0; return 0; }
-            if (prep != nullptr) return RIH_EINVAL;
+            if (bnb_rows != nullptr) { *bnb_rows = 0; return 0; }
+            if (prep != nullptr || bnb) return RIH_EINVAL;
             if (d->drop_p != 0.f || (d->stats != nullptr && !st_ok)) return RIH_EINVAL;
             if (!ok) return RIH_EINVAL;
             if (engine_out != nullptr) { *engine_out = e2t4 ? 2 : 1; return 0; }
@@ -2521,6 +2602,18 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
             *stats_rows = (ok && d->tile <= 2 && d->a_mode == 0 && b_stats_ok && d->splitk == 1 && gz == 1 && d->cS <= 1)
                               ? bm / 2 : 0;
             return 0;
+        }
+        // BatchNorm-backward sums in the epilogue: engine 2, forward-type operand forms, one launch slice, whole quads
+        const bool bnb_ok = ok && e2 && d->tile <= 2 && d->a_mode == 0 && d->b_mode <= 1 && d->splitk == 1 && gz == 1 &&
+                            d->cS <= 1 && d->stats == nullptr && d->drop_p == 0.f && !seg && prep == nullptr && d->N % 4 == 0 &&
+                            a.epi_vec;
+        if (bnb_rows != nullptr) { *bnb_rows = bnb_ok ? bm / 2 : 0; return 0; }
+        if (bnb) {
+            const int rows_per = bm / 2;
+            if (!bnb_ok || !d->bnb_x || !d->bnb_mean || !d->bnb_invstd || d->bnb_ldx < d->N || d->bnb_ldx % 4 != 0 ||
+                d->bnb_T != (d->M + rows_per - 1) / rows_per || ((uintptr_t)d->bnb_x % 16) != 0 ||
+                ((uintptr_t)d->bnb_mean % 16) != 0 || ((uintptr_t)d->bnb_invstd % 16) != 0 || ((uintptr_t)d->bnb_part % 16) != 0)
+                return RIH_EINVAL;
         }
         if (d->b_mode == 2 && d->engine == 2 && !(ok && e2)) return RIH_EINVAL;     // (no kernel reads two fp16 planes elsewhere)
         if (seg && (!ok || prep != nullptr)) return RIH_EINVAL;                      // (no other kernel reads a segmented A)
@@ -2550,6 +2643,8 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
     }
     if (d->drop_p != 0.f || seg) return RIH_EINVAL;           // the general kernels have no dropout epilogue / segmented A
     if (stats_rows != nullptr) { *stats_rows = 0; return 0; }
+    if (bnb_rows != nullptr) { *bnb_rows = 0; return 0; }
+    if (bnb) return RIH_EINVAL;                               // no BatchNorm-backward epilogue outside engine 2's fast path
     if (prep != nullptr) return RIH_EINVAL;                   // not a fast-path descriptor: no grouped launch
     if (d->stats != nullptr) return RIH_EINVAL;
     if (d->b_mode == 2 || d->a_mode == 2) return RIH_EINVAL;  // the general kernels do not read pre-split operands
@@ -2671,6 +2766,11 @@ extern "C" int rih_gemm_dropout_ok(const rih_gemm_desc* d) {
 extern "C" int rih_gemm_stats_rows(const rih_gemm_desc* d) {
     int rows = 0;
     if (gemm_impl(d, nullptr, &rows) != 0) return 0;
+    return rows;
+}
+extern "C" int rih_gemm_bnb_rows(const rih_gemm_desc* d) {
+    int rows = 0;
+    if (gemm_impl(d, nullptr, nullptr, nullptr, nullptr, &rows) != 0) return 0;
     return rows;
 }
 

@@ -378,7 +378,7 @@ class StatsHolder:
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=None, ldr=0,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, kchunk=0, sCsplit=0, alpha=1.0, relu=False,
          geom=None, tile=None, engine=None, cstride=None, ones_row=0, sBias=0, sR=0, collect=None, stats=None, drop=None,
-         amax_a=None, amax_b=None, a_seg=None):
+         amax_a=None, amax_b=None, a_seg=None, bnb=None):
     """Enqueue one rih_gemm.  A/B/Cout/bias/R are tensors or raw device pointers.
     a_seg: [(tensor, pitch, first column), ...] -- up to three further pieces of a segmented A operand (rih_gemm_desc.a_seg);
     `lda` / `A` describe the first piece.
@@ -392,7 +392,9 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
     finishes with rih_add_dropout(R, C, p, seed), which draws the same mask stream.
     amax_a / amax_b (engine 2): bound blocks (bound_of; or raw device pointers, or thunks that return one -- called only when the
     descriptor takes engine 2's kernels) holding an upper bound of max|A| / max|B| (rih_gemm_desc.amax_a); a call site that
-    passes none for either operand runs engine 1."""
+    passes none for either operand runs engine 1.
+    bnb: a BnFold -- the output is the gradient arriving at that BatchNorm; when the descriptor takes the epilogue of
+    rih_gemm_desc.bnb_* the reduction sums of its backward are left in bnb.part (BatchNormFn.backward then skips its own pass)."""
     d = GemmDesc()
     if a_seg:
         for i, (t, ld, k0) in enumerate(a_seg):
@@ -466,6 +468,15 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
             check(_L().rih_splitk_finish(part.data_ptr(), sk, M, N, d.C, ldc, d.bias or 0, d.R or 0, ldr,
                                          alpha, 1 if relu else 0, _stream()), 'rih_splitk_finish')
             return False
+    if (bnb is not None and collect is None and stats is None and not fused_drop and splitk == 1 and nb1 * nb2 == 1
+            and cstride is None and not isinstance(Cout, int) and M == bnb.rows and N == bnb.C and ldc == bnb.C):
+        rows_per = int(_L().rih_gemm_bnb_rows(C.byref(d)))
+        if rows_per > 0:
+            T = _cdiv(M, rows_per)
+            part = torch.empty((2, T, N), device=Cout.device, dtype=torch.float32)
+            d.bnb_x, d.bnb_mask, d.bnb_mean, d.bnb_invstd = bnb.x.data_ptr(), _p(bnb.mask), bnb.mean.data_ptr(), bnb.invstd.data_ptr()
+            d.bnb_part, d.bnb_ldx, d.bnb_T = part.data_ptr(), bnb.C, T
+            bnb.part = (part, T, Cout.data_ptr(), Cout._version)
     req = stats
     if (req is not None and req.part is None and a_mode == 0 and splitk == 1 and nb1 * nb2 == 1 and cstride is None
             and not isinstance(Cout, int)):
@@ -966,6 +977,7 @@ class Conv2dFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, y if relu_bwd else None)
         ctx.cfg = (stride, pad, relu_bwd, bias is not None)
         ctx.bounds = (bx, bw)
+        ctx.bnfold = getattr(x, '_rih_bnfold', None) if BN_FOLD else None
         if skip:
             return y, x.view_as(x)
         return y
@@ -1042,11 +1054,11 @@ class Conv2dFn(torch.autograd.Function):
                          amax_a=bdy, amax_b=bw)
             elif KH * KW == 1 and Cx == Cin:
                 gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cin, Cx, a_mode=0, b_mode=0, geom=geom, R=dskip, ldr=Cx,
-                     amax_a=bdy, amax_b=bw)
+                     amax_a=bdy, amax_b=bw, bnb=ctx.bnfold)
             else:
                 wd = _packed_weight(w, Cx, True)
                 gemm(dy, wd, dx, Mx, Cx, KH * KW * Cout, Cout, Cx, Cx, a_mode=0, b_mode=0, geom=geom, R=dskip, ldr=Cx,
-                     amax_a=bdy, amax_b=bw)
+                     amax_a=bdy, amax_b=bw, bnb=ctx.bnfold)
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
@@ -1407,6 +1419,21 @@ def patch_conv_pair(x, cL, cR):
 
 
 # --------------------------------------------------------------------------------------------- batch norm
+# The reduction pass of a BatchNorm's backward folded into the epilogue of the data-gradient GEMM that produces its dy
+# (rih_gemm_desc.bnb_*): BatchNormFn.forward leaves a BnFold on its output, the convolution that reads that output hands it to its
+# data-gradient GEMM, BatchNormFn.backward finds the sums and skips its own pass over dy and x.  Round 4; see DESIGN 3.2.
+BN_FOLD = os.environ.get('RIH_BN_FOLD', '0') == '1'
+BN_FOLD_TAKEN = 0       # BatchNorm backwards that found their sums in the data-gradient GEMM's epilogue (tests read it)
+_LAST_FOLD = [None]
+
+
+class BnFold:
+    __slots__ = ('x', 'mask', 'mean', 'invstd', 'rows', 'C', 'part')
+
+    def __init__(self, x, mask, mean, invstd, rows, C_):
+        self.x, self.mask, self.mean, self.invstd, self.rows, self.C, self.part = x, mask, mean, invstd, rows, C_, None
+
+
 class BatchNormFn(torch.autograd.Function):
     """nn.BatchNorm2d on NHWC rows (+ residual add + ReLU).  Training: batch statistics, running buffers updated
     in place (momentum 0.1, unbiased running_var) exactly like torch; eval: running statistics."""
@@ -1454,6 +1481,9 @@ class BatchNormFn(torch.autograd.Function):
                                    + (0.25 if relu else 0.0)), 'bn_fwd', run)
         ctx.save_for_backward(x, mask, mean, invstd, gamma)
         ctx.cfg = (training, relu, residual is not None, bool(input_relu))
+        ctx.fold = None
+        if BN_FOLD and training and ENGINE == 2 and Cc % 4 == 0:
+            ctx.fold = _LAST_FOLD[0] = BnFold(x, mask, mean, invstd, rows, Cc)
         return y
 
     @staticmethod
@@ -1473,8 +1503,24 @@ class BatchNormFn(torch.autograd.Function):
         # writes dx (+ dres)
         flags = (0 if training else 1) | (2 if input_relu else 0)
         dxbound = bound_slot(x.device) if ENGINE == 2 else None     # max|dx|: the gradient operand's bound, as ybound above
-        run = lambda: check(
-            lib.rih_bn_bwd(dy.data_ptr(), x.data_ptr(), 0, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+        fold = ctx.fold.part if ctx.fold is not None else None
+        if fold is not None:
+            ctx.fold.part = None
+            # the sums are of the GEMM's output: usable only if THAT is the gradient that arrived -- the same memory, and not
+            # touched since (autograd adds the gradients of several consumers of y in place into the first one: version bump)
+            if fold[2] != dy.data_ptr() or fold[3] != dy._version:
+                fold = None
+        if fold is not None:
+            global BN_FOLD_TAKEN
+            BN_FOLD_TAKEN += 1
+            run = lambda: check(
+                lib.rih_bn_bwd_partials(fold[0].data_ptr(), fold[1], dy.data_ptr(), x.data_ptr(), mean.data_ptr(),
+                                        invstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(), _p(dres), dg.data_ptr(),
+                                        db.data_ptr(), rows, Cc, 1 if relu else 0, flags, _p(mask), _p(dxbound), _stream()),
+                'rih_bn_bwd_partials')
+        else:
+            run = lambda: check(
+                lib.rih_bn_bwd(dy.data_ptr(), x.data_ptr(), 0, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                                dx.data_ptr(), _p(dres), dg.data_ptr(), db.data_ptr(), rows, Cc, 1 if relu else 0,
                                flags, ws.data_ptr(), _p(mask), _p(dxbound), _stream()), 'rih_bn_bwd')
         _elem_profile(x.numel() * (4.0 * (2 * 2 + 1 + (1 if has_res else 0)) + (0.5 if relu else 0.0)), 'bn_bwd', run)
@@ -1511,7 +1557,10 @@ def batchnorm(x, gamma, beta, rmean, rvar, residual=None, training=True, relu=Fa
               input_relu=False):
     """input_relu: x is the output of a ReLU (Conv -> ReLU -> BN); the gradient wrt x then leaves already gated by x > 0."""
     ybound = bound_slot(x.device) if ENGINE == 2 else None
+    _LAST_FOLD[0] = None
     y = BatchNormFn.apply(x, gamma, beta, rmean, rvar, residual, training, relu, eps, momentum, tile_stats, input_relu, ybound)
+    if _LAST_FOLD[0] is not None:       # (set by BatchNormFn.forward when the fold is on: the consumer finds it on the tensor)
+        y._rih_bnfold, _LAST_FOLD[0] = _LAST_FOLD[0], None
     return y if ybound is None else set_bound(y, ybound)
 
 

@@ -200,6 +200,24 @@ class EmulatedLib:
                     cm, cn = np.meshgrid(crow, np.arange(N), indexing='ij')
                     mem = _f(Cb, int(crow.max()) * d.ldc + N)
                     mem[(cm * d.ldc + cn).ravel()] = out.astype(np.float32).ravel()
+                if d.bnb_part:      # BatchNorm-backward sums of the stored (un-gated) values, gated by the ReLU pattern
+                    rp = self.rih_gemm_bnb_rows(dref)
+                    assert rp > 0, 'bnb requested on a descriptor without that path'
+                    T = -(-M // rp)
+                    assert d.bnb_T == T and d.bnb_ldx >= N
+                    o32 = out.astype(np.float32)
+                    X = np.lib.stride_tricks.as_strided(_f(d.bnb_x, (M - 1) * d.bnb_ldx + N), (M, N), (4 * d.bnb_ldx, 4))
+                    D = o32.copy()
+                    if d.bnb_mask:
+                        assert d.bnb_ldx == N
+                        mk = self._u8view(d.bnb_mask, M * N // 4)
+                        keep = np.stack([(mk >> e) & 1 for e in range(4)], 1).reshape(M, N).astype(bool)
+                        D[~keep] = 0
+                    xh = (X - _f(d.bnb_mean, N)) * _f(d.bnb_invstd, N)
+                    pt = _f(d.bnb_part, 2 * T * N).reshape(2, T, N)
+                    for t in range(T):
+                        pt[0, t] = D[t * rp:(t + 1) * rp].sum(0, dtype=np.float64)
+                        pt[1, t] = (D[t * rp:(t + 1) * rp] * xh[t * rp:(t + 1) * rp]).sum(0, dtype=np.float64)
                 if d.stats:         # statistics epilogue: column sums / sums of squares per block of stats_rows GEMM rows
                     rp = self.rih_gemm_stats_rows(dref)
                     assert rp > 0, 'stats requested on a descriptor without the statistics path'
@@ -294,6 +312,15 @@ class EmulatedLib:
             ok = ok and d.Cin % 32 == 0 and d.KH * d.KW <= 32
         if d.b_mode == 0:
             ok = ok and d.N % 4 == 0
+        return (64 if d.tile in (0, 1) else 32) if ok else 0
+
+    def rih_gemm_bnb_rows(self, dref):
+        """The header's contract, restated: engine 2's fast path, forward-type operand forms, one slice, whole quads."""
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        ok = (self.rih_gemm_engine(dref) == 2 and d.tile in (0, 1, 2) and d.a_mode == 0 and d.b_mode in (0, 1) and d.splitk == 1
+              and d.nb1 * d.nb2 == 1 and d.cS <= 1 and not d.stats and d.drop_p == 0 and not d.a_seg[0] and d.N % 4 == 0
+              and d.C % 16 == 0 and d.ldc % 4 == 0 and (not d.R or (d.R % 16 == 0 and d.ldr % 4 == 0))
+              and (not d.bias or d.bias % 16 == 0))
         return (64 if d.tile in (0, 1) else 32) if ok else 0
 
     def rih_gemm_dropout_ok(self, dref):
@@ -1165,6 +1192,34 @@ class EmulatedLib:
         else:
             o = (D - (s1 / rows).astype(np.float32) - xh * (s2 / rows).astype(np.float32)) * sc
         if frozen & 2:          # the input is a ReLU output: dx gated by x > 0
+            o = np.where(X > 0, o, 0)
+        _f(dx, rows * Cc)[:] = o.ravel()
+        self._amax_into(amax_dx, o)
+        if dres:
+            _f(dres, rows * Cc)[:] = D.ravel()
+        return 0
+
+    def rih_bn_bwd_partials(self, part, T, dy, x, mean, invstd, gamma, dx, dres, dgamma, dbeta, rows, Cc, relu, frozen, mask,
+                            amax_dx, stream):
+        """rih_bn_bwd with the two reduction sums taken from `part`[2][T][C] (written by rih_gemm's bnb epilogue)."""
+        pt = _f(part, 2 * T * Cc).reshape(2, T, Cc)
+        s1, s2 = pt[0].sum(0, dtype=np.float64), pt[1].sum(0, dtype=np.float64)
+        D = _f(dy, rows * Cc).reshape(rows, Cc).copy()
+        if relu:
+            assert mask
+            m = self._u8view(mask, rows * Cc // 4)
+            keep = np.stack([(m >> e) & 1 for e in range(4)], 1).reshape(rows, Cc).astype(bool)
+            D[~keep] = 0
+        X = _f(x, rows * Cc).reshape(rows, Cc)
+        xh = (X - _f(mean, Cc)) * _f(invstd, Cc)
+        _f(dbeta, Cc)[:] = s1
+        _f(dgamma, Cc)[:] = s2
+        sc = _f(invstd, Cc) * _f(gamma, Cc)
+        if frozen & 1:
+            o = D * sc
+        else:
+            o = (D - (s1 / rows).astype(np.float32) - xh * (s2 / rows).astype(np.float32)) * sc
+        if frozen & 2:
             o = np.where(X > 0, o, 0)
         _f(dx, rows * Cc)[:] = o.ravel()
         self._amax_into(amax_dx, o)

@@ -149,6 +149,14 @@ def test_conv1x1_cat_host_logic():
         G.test_conv1x1_cat((1, 5, 7, (32, 64), 40, False), eng)
 
 
+def test_bn_fold_host_logic(monkeypatch):
+    """ops.BN_FOLD on the emulated ABI: the BnFold hand-over from BatchNorm to the convolution behind it, the bnb descriptor
+    fields, rih_bn_bwd_partials, and the pointer check that refuses sums of a gradient that is not the one that arrived."""
+    for case in [(2, 16, 16, 64, 64, 64, 3, True, False), (2, 8, 8, 64, 64, 32, 1, True, True), (3, 9, 7, 32, 64, 96, 3, False, False),
+                 (2, 8, 8, 64, 64, 64, 1, True, 'fanout')]:
+        G.test_bn_backward_sums_in_the_data_gradient_epilogue(case, monkeypatch)
+
+
 def test_presplit_weight_host_logic(monkeypatch):
     """ops.PRESPLIT (rih_gemm b_mode 2 + rih_presplit_conv_weight, off by default): descriptor / operand plumbing."""
     from renderih_amd import ops

@@ -199,6 +199,65 @@ def test_batchnorm(training, relu, res, shape):
     assert_close(rv_g, rv_r, 1e-4, 1e-5, 'bn running_var')
 
 
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, 64, 64, 3, True, False), (2, 16, 16, 64, 128, 64, 1, True, False),
+                                  (3, 9, 7, 32, 64, 96, 3, False, False), (2, 8, 8, 64, 64, 32, 1, True, True),
+                                  (1, 20, 12, 32, 32, 32, 3, True, True), (2, 8, 8, 64, 64, 64, 1, True, 'fanout')])
+def test_bn_backward_sums_in_the_data_gradient_epilogue(case, monkeypatch):
+    """RIH_BN_FOLD (rih_gemm_desc.bnb_*, rih_bn_bwd_partials): conv_a -> BatchNorm(-> ReLU) -> conv_b; the data gradient of conv_b is
+    the gradient arriving at the BatchNorm, and its GEMM's epilogue leaves the two reduction sums of the BatchNorm's backward.
+    Every gradient agrees with the unfolded path (the sums are fp32 in another order: 1e-5 of the largest value) and with
+    torch; the fold was really taken; with a skip path (conv_b's input also feeds a residual add) the gradient the skip carries
+    joins inside the GEMM and the fold still holds; with a second consumer that autograd adds in behind the GEMM ('fanout': in
+    place, into the GEMM's own output buffer) the sums are refused and the BatchNorm runs its own pass."""
+    from renderih_amd import ops
+    N, H, W, C0, C1, C2, kb, relu, skip = case
+    d = dev()
+    monkeypatch.setattr(ops, 'ENGINE', 2)
+    x0 = rnd(N, C0, H, W, seed=1)
+    wa = rnd(C1, C0, 3, 3, seed=2) * (2.0 / (C0 * 9)) ** 0.5
+    wb = rnd(C2, C1, kb, kb, seed=3) * (2.0 / (C1 * kb * kb)) ** 0.5
+    g, b = torch.rand(C1) + 0.5, rnd(C1, seed=4) * 0.1
+    gy = rnd(N, C2, H, W, seed=5)
+    gs = rnd(N, C1, H, W, seed=6) if skip else None
+
+    def torch_ref():
+        x, a, bb, gg, be = [t.clone().double().requires_grad_(True) for t in (x0, wa, wb, g, b)]
+        y = F.batch_norm(F.conv2d(x, a, None, 1, 1), None, None, gg, be, True, 0.1, 1e-5)
+        y = F.relu(y) if relu else y
+        z = F.conv2d(y, bb, None, 1, kb // 2)
+        loss = (z * gy.double()).sum() + ((y * gs.double()).sum() if skip else 0.0)
+        loss.backward()
+        return [t.grad.float() for t in (x, a, bb, gg, be)]
+
+    def ours(fold):
+        monkeypatch.setattr(ops, 'BN_FOLD', fold)
+        taken = ops.BN_FOLD_TAKEN
+        x = nhwc(x0).to(d).requires_grad_(True)
+        a, bb, gg, be = [t.clone().to(d).requires_grad_(True) for t in (wa, wb, g, b)]
+        ops.bounds_reset()
+        h = ops.conv2d(x, a, stride=1, pad=1)
+        y = ops.batchnorm(h, gg, be, torch.zeros(C1, device=d), torch.ones(C1, device=d), training=True, relu=relu)
+        if skip == 'fanout':
+            z = ops.conv2d(y, bb, stride=1, pad=kb // 2)
+            loss = (z * nhwc(gy).to(d)).sum() + (y * nhwc(gs).to(d)).sum()
+        elif skip:
+            z, yv = ops.conv2d_skip(y, bb, stride=1, pad=kb // 2)
+            loss = (z * nhwc(gy).to(d)).sum() + (yv * nhwc(gs).to(d)).sum()
+        else:
+            z = ops.conv2d(y, bb, stride=1, pad=kb // 2)
+            loss = (z * nhwc(gy).to(d)).sum()
+        loss.backward()
+        return [nchw(x.grad), a.grad, bb.grad, gg.grad, be.grad], ops.BN_FOLD_TAKEN - taken
+
+    ref = torch_ref()
+    plain, t0 = ours(False)
+    folded, t1 = ours(True)
+    assert t0 == 0 and t1 == (0 if skip == 'fanout' else 1), (t0, t1)
+    for name, r, p_, f_ in zip(('dx', 'dwa', 'dwb', 'dgamma', 'dbeta'), ref, plain, folded):
+        assert_close(f_, p_, 1e-5, 1e-5 * float(p_.abs().max()), 'fold vs plain ' + name)
+        assert_close(f_, r, 2e-3, 2e-4 * float(r.abs().max()), 'fold vs torch ' + name)
+
+
 def check_linear_dropout_epilogue(rows, K, Nf, relu, res, pair=False, p=0.3, expect_fused=True):
     """rih_gemm_desc.drop_p (ops.linear / ops.linear_pair with drop=): dropout in the GEMM's epilogue against the GEMM followed by
     rih_add_dropout -- the same mask stream, so the output and every gradient are bit-identical; shapes the epilogue does not
