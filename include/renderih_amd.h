@@ -147,7 +147,9 @@ typedef struct rih_gemm_desc {
      * the column sums bnb_part[0][block][n] = sum dy and bnb_part[1][block][n] = sum dy * (x - mean) * invstd
      * (bnb_part[2][bnb_T][N], bnb_T = ceil(M / rows)): the reduction pass of rih_bn_bwd without its pass over dy and x
      * (rih_bn_bwd_partials finishes).  The stored C is the un-gated dy, as without the fold.  NULL = off; RIH_EINVAL when set on a
-     * descriptor that does not take that path (rih_gemm_bnb_rows returns 0 for it). */
+     * descriptor that does not take that path (rih_gemm_bnb_rows returns 0 for it).  Built, parity-tested and measured 1.4 %
+     * SLOWER on the training step in round 4: the kernels are compiled only with RIH_BUILD_EXPERIMENTS=1 -- the default library
+     * answers 0 rows / RIH_EINVAL. */
     const float* bnb_x;
     const uint8_t* bnb_mask;
     const float* bnb_mean;

@@ -1544,7 +1544,11 @@ int launch_split_e2(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 
         else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, false, false, 2, true>), grid, block, 0, s, a);
         return (int)hipGetLastError();
     }
-    if (a.bnb_part != nullptr) {        // BatchNorm-backward sums in the epilogue (gemm_impl checked the preconditions)
+#if RIH_EXPERIMENTS
+    // BatchNorm-backward sums in the epilogue (gemm_impl checked the preconditions).  MEASURED SLOWER (round 4, session 23, one
+    // box): 1948.4 / 1950.8 images/s with RIH_BN_FOLD=1 against 1975.7 / 1976.4 without (-1.4 %) -- the epilogue's reads of x and
+    // of the ReLU pattern plus 48 shuffles per wave cost more than the reduction pass they replace (which streams at 5 TB/s).
+    if (a.bnb_part != nullptr) {
 #define RIH_L2B(BM_, PL_) \
     hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, BM_, PL_, false, false, false, 2, false, 1, true>), grid, block, 0, s, a)
         if (b_mode == 0) { if (plain) RIH_L2B(0, true); else RIH_L2B(0, false); }
@@ -1552,7 +1556,6 @@ int launch_split_e2(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 
 #undef RIH_L2B
         return (int)hipGetLastError();
     }
-#if RIH_EXPERIMENTS
     // short reductions on plain rows: two k-tiles in flight (RIH_E2_DEEP_K = largest K that takes this path, default 0 = off).
     // REFUTED (round 4, session 12, one box): 1942.5 / 1937.3 images/s against 1960.2 / 1961.3 without it (-1.1 %); for every K
     // (4096) 1940.2 -- the second register set costs 128x64 tiles one workgroup per CU (126 -> 146-152 VGPRs, 4 -> 3), and the
@@ -2604,7 +2607,7 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
             return 0;
         }
         // BatchNorm-backward sums in the epilogue: engine 2, forward-type operand forms, one launch slice, whole quads
-        const bool bnb_ok = ok && e2 && d->tile <= 2 && d->a_mode == 0 && d->b_mode <= 1 && d->splitk == 1 && gz == 1 &&
+        const bool bnb_ok = RIH_EXPERIMENTS && ok && e2 && d->tile <= 2 && d->a_mode == 0 && d->b_mode <= 1 && d->splitk == 1 && gz == 1 &&
                             d->cS <= 1 && d->stats == nullptr && d->drop_p == 0.f && !seg && prep == nullptr && d->N % 4 == 0 &&
                             a.epi_vec;
         if (bnb_rows != nullptr) { *bnb_rows = bnb_ok ? bm / 2 : 0; return 0; }

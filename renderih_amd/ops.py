@@ -1421,7 +1421,10 @@ def patch_conv_pair(x, cL, cR):
 # --------------------------------------------------------------------------------------------- batch norm
 # The reduction pass of a BatchNorm's backward folded into the epilogue of the data-gradient GEMM that produces its dy
 # (rih_gemm_desc.bnb_*): BatchNormFn.forward leaves a BnFold on its output, the convolution that reads that output hands it to its
-# data-gradient GEMM, BatchNormFn.backward finds the sums and skips its own pass over dy and x.  Round 4; see DESIGN 3.2.
+# data-gradient GEMM, BatchNormFn.backward finds the sums and skips its own pass over dy and x.  Round 4: correct on the GPU
+# (profiles/r04/ab/c23_pytest_fold_*.log) and 1.4 % SLOWER on the step (c23_train_*.log: 1948 / 1951 against 1976 / 1976
+# images/s) -- the kernels are in the experiment build only; in the default library rih_gemm_bnb_rows answers 0 and this switch
+# changes nothing.
 BN_FOLD = os.environ.get('RIH_BN_FOLD', '0') == '1'
 BN_FOLD_TAKEN = 0       # BatchNorm backwards that found their sums in the data-gradient GEMM's epilogue (tests read it)
 _LAST_FOLD = [None]

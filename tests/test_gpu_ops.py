@@ -210,8 +210,11 @@ def test_bn_backward_sums_in_the_data_gradient_epilogue(case, monkeypatch):
     joins inside the GEMM and the fold still holds; with a second consumer that autograd adds in behind the GEMM ('fanout': in
     place, into the GEMM's own output buffer) the sums are refused and the BatchNorm runs its own pass."""
     from renderih_amd import ops
+    from renderih_amd.testing import experiments_built
     N, H, W, C0, C1, C2, kb, relu, skip = case
     d = dev()
+    if d.type == 'cuda' and not experiments_built():
+        pytest.skip('the bnb epilogue was measured slower and is compiled only with RIH_BUILD_EXPERIMENTS=1')
     monkeypatch.setattr(ops, 'ENGINE', 2)
     x0 = rnd(N, C0, H, W, seed=1)
     wa = rnd(C1, C0, 3, 3, seed=2) * (2.0 / (C0 * 9)) ** 0.5

@@ -64,6 +64,7 @@ def test_conv1x1_cat_kernels(case, engine):
 
 @pytest.mark.parametrize('case', [(2, 8, 8, 64, 64, 64, 3, True, False), (1, 8, 8, 64, 128, 64, 1, True, True),
                                   (1, 9, 7, 32, 64, 96, 3, False, False)])
+@_needs_experiments
 def test_bn_fold_kernels(case, monkeypatch):
     """The bnb epilogue of gemm_split_kernel and rih_bn_bwd_partials (the real kernels) against the unfolded path and torch."""
     G.test_bn_backward_sums_in_the_data_gradient_epilogue(case, monkeypatch)
