@@ -18,9 +18,10 @@ Prints ONE JSON line (rank 0).  `roofline`: the GEMM/implicit-conv kernel family
 on the launch stream; achieved = SURVEY 8d algorithmic FLOPs (53.2 GFLOP/img fwd+bwd) x images per step / GEMM-family
 time per step (`achieved_launched` = the FLOPs actually launched: dead branches are skipped).  `roofline_hbm`: the BatchNorm
 kernel family (largest HBM-bound group) the same way in GB/s against 8 TB/s; `roofline_mano`: the MANO layer micro-benchmark
-(4096 hands, PCA-45) in GB/s of its algorithmic bytes.  The default engine computes every fp32 product as six bf16 MFMA products (three-term operand split,
-fp32 accumulate; DESIGN.md 3.1), so its peak is the dense bf16 MFMA peak / 6 = 416.7 TFLOP/s of fp32-equivalent work;
-the native f32 MFMA peak (157.3 TFLOP/s, engine 0, RIH_GEMM_ENGINE=0) is reported next to it.  `cpu_baseline`: the CPU oracle (a port of the
+(4096 hands, PCA-45) in GB/s of its algorithmic bytes.  The default engine (2) computes every fp32 product as THREE fp16 MFMA products (scaled two-term
+operand split, fp32 accumulate): ceiling 2500 / 3 = 833 TFLOP/s of fp32-equivalent work; engine 1 (six bf16 products, the
+decoder's Linears) 416.7; engine 0 / flash attention the native f32 MFMA peak 157.3.  `roofline.peak` is the ceiling of the engine that
+produced most of the family's time, `by_engine` carries every engine's own fraction.  `cpu_baseline`: the CPU oracle (a port of the
 reference's PyTorch-CPU path) timed on this box's host cores on a bounded sample (rank 0, N=1 only).
 """
 import argparse
@@ -70,13 +71,15 @@ def synth_batch(B, device, seed):
     return img.to(device), {k: v.to(device) for k, v in lab.items()}
 
 
-def cpu_baseline(seconds=40.0, batch=16, family='a', threads=(16, 32, 64)):
+def cpu_baseline(seconds=40.0, batch=16, family='a', threads=(16, 32, 64), inference=False):
     """The CPU baseline of SURVEY 8d -- the reference's PyTorch-CPU path, forward + backward at B = 16 -- on THIS box's host
     cores.  kind = "port": /root/reference does not exist on the GPU box, so the timed code is oracle/net_oracle.py, the
     functional restatement of the reference modules (same torch CPU operators in the same order, pinned to the real modules by
     tests/golden).  torch's intra-op thread count is swept (one iteration each after one warm-up: 128 threads on a 128-core
     host oversubscribe the small decoder operators), then >= 3 iterations are timed at the best setting; bounded to about
-    `seconds` of CPU work."""
+    `seconds` of CPU work.  inference=True (configs[4]): eval-mode forward under no_grad only.
+    `reference_ratio`: port images/s divided by the REAL reference modules' images/s, measured where both can run (the build
+    container, same weights / image / threads: tools/cpu_port_vs_reference.py -> profiles/r05/cpu_port_vs_reference.json)."""
     from oracle import net_oracle
     from renderih_amd import assets
     from renderih_amd.model import build_model
@@ -95,6 +98,10 @@ def cpu_baseline(seconds=40.0, batch=16, family='a', threads=(16, 32, 64)):
 
     def one():
         t0 = time.time()
+        if inference:
+            with torch.no_grad():
+                net_oracle.handnet_forward(sd, graph, img, training=False)
+            return time.time() - t0
         out = net_oracle.handnet_forward(sd, graph, img, training=True)
         net_oracle.scalar_loss(out).backward()
         for v in sd.values():
@@ -119,11 +126,24 @@ def cpu_baseline(seconds=40.0, batch=16, family='a', threads=(16, 32, 64)):
         times.append(one())
     torch.set_num_threads(before)
     t_total = sum(times)
-    return {'value': round(batch * len(times) / t_total, 3), 'unit': 'images/sec', 'cores': best, 'host_cores': ncpu,
-            'kind': 'port', 'thread_sweep_s_per_iter': {str(k): round(v, 2) for k, v in sweep.items()},
-            'sample': 'oracle (CPU restatement of the reference path; the reference modules cannot travel to the GPU box) '
-                      'fwd+bwd, batch %d, %d timed iterations (%.0f s) at %d threads after 1 warm-up + a %d-point thread sweep'
-                      % (batch, len(times), t_total, best, len(sweep))}
+    ratio = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r05', 'cpu_port_vs_reference.json')) as fh:
+            rr = json.load(fh)
+        ratio = {'reference_ratio': rr['reference_ratio'],
+                 'reference_ratio_source': 'profiles/r05/cpu_port_vs_reference.json: fwd+bwd B = %d on %d threads of the build '
+                                           'container, port %.2f vs reference modules %.2f images/s'
+                                           % (rr['batch'], rr['threads'], rr['port_images_per_sec'], rr['reference_images_per_sec'])}
+    except (OSError, KeyError, ValueError):
+        pass
+    out = {'value': round(batch * len(times) / t_total, 3), 'unit': 'images/sec', 'cores': best, 'host_cores': ncpu,
+           'kind': 'port', 'thread_sweep_s_per_iter': {str(k): round(v, 2) for k, v in sweep.items()},
+           'sample': 'oracle (CPU restatement of the reference path; the reference modules cannot travel to the GPU box) '
+                     '%s, batch %d, %d timed iterations (%.0f s) at %d threads after 1 warm-up + a %d-point thread sweep'
+                     % ('eval-mode forward' if inference else 'fwd+bwd', batch, len(times), t_total, best, len(sweep))}
+    if ratio is not None:
+        out.update(ratio)
+    return out
 
 
 def mano_roofline(device, hands=4096, iters=20):
@@ -267,7 +287,8 @@ def config5(args):
                                              'decoder + MANO layer (2 x %d hands) on 1 x MI355X' % (B, B),
                                  'vertices_rel_deviation_from_fp32_path': dev_err,
                                  'mpjpe': 'deferred: needs the pretrained checkpoint and InterHand2.6M (licence-gated)'},
-          'roofline': roof, 'cpu_baseline': None})
+          'roofline': roof,
+          'cpu_baseline': None if args.no_cpu_baseline else cpu_baseline(seconds=25.0, inference=True)})
 
 
 def main():
@@ -545,15 +566,22 @@ def main():
             #                         MANO head of b-mano adds 0.01)
         achieved = gflop_img * B / ms            # GFLOP / ms = TFLOP/s
         split = (ops.ENGINE >= 1)
-        # the ceiling the fraction is quoted against stays the six-product one (2500 / 6), whichever engine ran, so that the
-        # line compares across rounds; with engine 2 (three fp16 products) the fraction of ITS ceiling (2500 / 3) is added
-        peak = PEAK_BF16_MFMA_TF / 6.0 if split else PEAK_FP32_MFMA_TF
         by_engine = {}
         for f, e0, e1, tag in recs:
-            a = by_engine.setdefault('engine%d' % tag[8], [0, 0.0, 0.0])
+            # flash attention (tag[6] 30) and the row-chain kernel (40) run exact-fp32 MFMA but are their own families; the fp16
+            # convolution of configs[4] carries tag[8] 'f16'
+            key = 'flash_attention' if tag[6] == 30 else 'row_chain' if tag[6] == 40 else 'engine%s' % (tag[8],)
+            a = by_engine.setdefault(key, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += max(e0.elapsed_time(e1) - empty, 0.0)
             a[2] += f
+        # `peak` = the ceiling of the arithmetic that produced MOST of the family's time (round-5: the line used to divide by the
+        # six-product ceiling 2500 / 6 whichever engine ran, which overstated engine 2's fraction twofold); the six-product
+        # fraction of rounds 2-4 stays beside it for comparison across rounds
+        ceilings = {'engine2': PEAK_BF16_MFMA_TF / 3.0, 'engine1': PEAK_BF16_MFMA_TF / 6.0, 'engine0': PEAK_FP32_MFMA_TF,
+                    'flash_attention': PEAK_FP32_MFMA_TF, 'row_chain': PEAK_FP32_MFMA_TF}
+        dominant = max(by_engine.items(), key=lambda kv: kv[1][1])[0] if by_engine else ('engine1' if split else 'engine0')
+        peak = ceilings.get(dominant, PEAK_BF16_MFMA_TF / 6.0)
         ems = sum(max(e0.elapsed_time(e1) - empty, 0.0) for _, e0, e1, _ in erecs)
         ebytes = sum(b_ for b_, _, _, _ in erecs)
         roof_hbm = {'bound': 'hbm', 'achieved': round(ebytes / max(ems, 1e-9) / 1e6, 1), 'peak': 8000.0, 'unit': 'GB/s',
@@ -566,13 +594,18 @@ def main():
                 'traffic': measured_traffic() if args.encoder == 'resnet50' and B == 64 and args.family == 'a' else None,
                 'kernel': ('rih_gemm engine 2 where operand bounds exist (gemm_split_kernel<..., ENG 2>: fp32 = 3 x '
                            'v_mfma_f32_32x32x16_f16 on a scaled two-term fp16 split, ceiling 2500 / 3 = 833 TF/s), engine 1 elsewhere; '
-                           '`peak` / `frac` are quoted against the six-product ceiling 2500 / 6 of engine 1 for comparability'
+                           '`peak` / `frac` = the ceiling of the engine with the most time; `frac_of_six_product_peak` is the figure '
+                           'rounds 2-4 quoted'
                            if ops.ENGINE == 2 else
                            'rih_gemm engine 1 (gemm_split_kernel / gemm_split256_kernel: fp32 = 6 x '
                            'v_mfma_f32_32x32x16_bf16 on a 3-term bf16 split; peak = 2500 TF/s bf16 dense / 6)'
                            if split else 'rih_gemm engine 0 (gemm_kernel, v_mfma_f32_32x32x2_f32)'),
-                'frac_of_three_product_peak': (round(achieved / (PEAK_BF16_MFMA_TF / 3.0), 4) if ops.ENGINE == 2 else None),
-                'by_engine': {k: {'launches': v[0], 'ms': round(v[1], 3), 'launched_tflops': round(v[2] / max(v[1], 1e-9) / 1e9, 1)}
+                'peak_is': 'ceiling of %s, the arithmetic with the most GEMM-family time of the step' % dominant,
+                'frac_of_six_product_peak': round(achieved / (PEAK_BF16_MFMA_TF / 6.0), 4),
+                'frac_of_three_product_peak': round(achieved / (PEAK_BF16_MFMA_TF / 3.0), 4),
+                'by_engine': {k: {'launches': v[0], 'ms': round(v[1], 3), 'launched_tflops': round(v[2] / max(v[1], 1e-9) / 1e9, 1),
+                                  'ceiling': round(ceilings.get(k, 0.0), 1),
+                                  'frac_of_ceiling': (round(v[2] / max(v[1], 1e-9) / 1e9 / ceilings[k], 4) if k in ceilings else None)}
                               for k, v in sorted(by_engine.items())},
                 'native_f32_mfma_peak': PEAK_FP32_MFMA_TF,
                 'frac_of_native_f32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TF, 4),

@@ -44,6 +44,10 @@ class HandNET_GCN(nn.Module):
         return self
 
     def forward(self, img):
+        with ops.owned_bounds():        # (parameter bounds measured at the top stay valid until the forward returns)
+            return self._forward(img)
+
+    def _forward(self, img):
         ops.begin_forward(self)         # operand bounds of the three-product GEMM engine are per forward pass
         if self._half is not None and not self.training and not torch.is_grad_enabled():
             hms, mask, dp, global_feature, fmaps = self._half(img)

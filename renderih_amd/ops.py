@@ -143,6 +143,34 @@ class _BoundPool:
 
 _BOUNDS = _BoundPool()
 _BOUND_EPOCH = 0            # cached bounds (tensor attribute `_rih_bound`) are valid inside one epoch only
+# > 0 inside `owned_bounds()`: a model forward (HandNET_GCN.forward) or a whole training step (TrainStep) owns the current epoch --
+# it measured every convolution weight at its top and nothing rewrites a weight before it ends.  Only then is the cached bound
+# of a PARAMETER trusted: outside such a scope (ops.conv2d / conv_bn called on their own, a sub-module run standalone, a user
+# module) a parameter may have been rewritten by something torch's version counter does not see (rih_adam_multi, `w.data.mul_`)
+# since it was measured, and a stale, too small bound overflows engine 2's fp16 planes (round-4 advisor finding) -- there a
+# parameter's bound is measured again at every use.
+_OWNED = 0
+
+
+class owned_bounds:
+    """Context: the enclosed code owns the bound epoch (see _OWNED).  Nests."""
+
+    def __enter__(self):
+        global _OWNED
+        _OWNED += 1
+        return self
+
+    def __exit__(self, *a):
+        global _OWNED
+        _OWNED -= 1
+        return False
+
+
+def bounds_invalidate():
+    """Every cached bound dies (new epoch; the slot chunks stay).  Called by whatever rewrites parameters behind torch's back:
+    renderih_amd.optim.Adam after rih_adam_multi."""
+    global _BOUND_EPOCH
+    _BOUND_EPOCH += 1
 
 
 def bound_slot(device):
@@ -244,9 +272,11 @@ def cat_channels(parts):
 
 def bound_of(t):
     """Bound block (fp32 tensor of _lib.BOUND_FLOATS floats whose maximum is >= max|t|, see above).  The cache entry dies with
-    an in-place modification of t that torch sees, and with the next bounds_reset()."""
+    an in-place modification of t that torch sees, and with the next bounds_reset() / bounds_invalidate(); a parameter's entry is
+    used only inside owned_bounds() (see _OWNED)."""
     ent = getattr(t, '_rih_bound', None)
-    if ent is not None and ent[1] == t._version and ent[2] == _BOUND_EPOCH:
+    if (ent is not None and ent[1] == t._version and ent[2] == _BOUND_EPOCH
+            and (_OWNED > 0 or not isinstance(t, torch.nn.Parameter))):
         return ent[0]
     slot = bound_slot(t.device)
     tc = _c(t)
@@ -1089,10 +1119,13 @@ class ConvCat1x1Fn(torch.autograd.Function):
     (models/encoder.py:165-173: `torch.cat((hms_fmaps[i], dp_fmaps[i], img_fmaps[i]), dim=1)` -> conv1x1 -> ReLU -> BN): the
     forward GEMM reads its A operand piece by piece (rih_gemm_desc.a_seg), the backward writes each part's gradient with its own
     data-gradient GEMM (no slice copies) and each part's weight-gradient columns with its own (grouped) weight-gradient GEMM.
-    forward(w, relu, stats, *parts); channel counts must be multiples of 32."""
+    forward(w, relu, stats, grad_masked, *parts); channel counts must be multiples of 32 (conv1x1_cat checks the preconditions and
+    falls back to the concatenation)."""
 
     @staticmethod
-    def forward(ctx, w, relu, stats, *parts):
+    def forward(ctx, w, relu, stats, grad_masked, *parts):
+        """grad_masked: the consumer (a BatchNorm with input_relu) hands back a gradient that is already zero where y <= 0; without
+        it the backward gates dy by y > 0 itself (rih_relu_bwd), like Conv2dFn."""
         _chk(w, *parts)
         w = _c(w)
         parts = [_c(p_) for p_ in parts]
@@ -1112,25 +1145,30 @@ class ConvCat1x1Fn(torch.autograd.Function):
             bw = LazyBound(w)
         gemm(parts[0], w, y, M, Cout, Cin, Cs[0], Cin, Cout, a_mode=0, b_mode=1, relu=relu, stats=stats, amax_a=b0, amax_b=bw,
              a_seg=[(parts[i], Cs[i], starts[i]) for i in range(1, len(parts))])
-        ctx.save_for_backward(w, *parts)
-        ctx.cfg = (Cs, starts)
+        relu_bwd = relu and not grad_masked
+        ctx.save_for_backward(w, y if relu_bwd else None, *parts)
+        ctx.cfg = (Cs, starts, relu_bwd)
         ctx.bounds = (bw,)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        w, *parts = ctx.saved_tensors
-        Cs, starts = ctx.cfg
+        w, y, *parts = ctx.saved_tensors
+        Cs, starts, relu_bwd = ctx.cfg
         (bw,) = ctx.bounds
         dy = _c(dy)
         N, H, W_, Cout = dy.shape
         M = N * H * W_
         Cin = w.shape[1]
+        if relu_bwd:
+            dyr = torch.empty_like(dy)
+            check(_L().rih_relu_bwd(dy.data_ptr(), y.data_ptr(), dyr.data_ptr(), dy.numel(), _stream()), 'rih_relu_bwd')
+            dy = dyr
         bdy = LazyBound(dy) if bw is not None else None
         wflat = w.view(Cout, Cin)
         dparts = []
         for i, p_ in enumerate(parts):
-            if ctx.needs_input_grad[3 + i]:
+            if ctx.needs_input_grad[4 + i]:
                 dx = torch.empty_like(p_)
                 # dx_i = dy W[:, slice]: B(k = co, n = ci) = w[co][start + ci] -- b_mode 0 with pitch Cin from the slice's first column
                 gemm(dy, wflat.data_ptr() + 4 * starts[i], dx, M, Cs[i], Cout, Cout, Cin, Cs[i], a_mode=0, b_mode=0,
@@ -1145,15 +1183,40 @@ class ConvCat1x1Fn(torch.autograd.Function):
                 g = (H, W_, Cs[i], H, W_, 1, 1, 1, 1, 0, 0)
                 _wgrad(p_, dy, dw, M, Cs[i], Cout, Cs[i], Cout, g, Cs[i], 1, Cs[i],
                        bounds=(LazyBound(p_), bdy) if bw is not None else None, dw_slice=(starts[i], Cin))
-        return (dw, None, None) + tuple(dparts)
+        return (dw, None, None, None) + tuple(dparts)
 
 
-def conv1x1_cat(parts, w, relu=False, stats=None):
-    """conv1x1(torch.cat(parts, channel dim), w) without the concatenation (ConvCat1x1Fn); falls back to the concatenation when a
-    part's channel count is not a multiple of 32."""
-    if CAT_FREE and 2 <= len(parts) <= 4 and all(p_.shape[-1] % 32 == 0 for p_ in parts):
-        return ConvCat1x1Fn.apply(w, relu, stats, *parts)
-    return conv2d(cat_channels(list(parts)), w, None, stride=1, pad=0, relu=relu, grad_masked=relu, stats=stats)
+def _cat_seg_ok(parts, w):
+    """Preconditions of rih_gemm's segmented A operand (csrc/rih_gemm.hip gemm_impl: the split engines' fast path only): a split
+    engine, 2..4 contiguous 16-byte aligned parts of one pixel grid whose channel counts are multiples of 32, every part and the
+    weight below 2 GiB, K and N multiples of 4."""
+    if ENGINE < 1 or not (2 <= len(parts) <= 4):
+        return False
+    shape = parts[0].shape[:-1]
+    rows = 1
+    for s_ in shape:
+        rows *= int(s_)
+    for p_ in parts:
+        c = p_.shape[-1]
+        if (p_.shape[:-1] != shape or c % 32 != 0 or not p_.is_contiguous() or p_.data_ptr() % 16 != 0
+                or 4 * rows * c >= (1 << 31)):
+            return False
+    return (w.dim() == 4 and w.shape[2] == w.shape[3] == 1 and w.shape[0] % 4 == 0 and w.data_ptr() % 16 == 0
+            and 4 * w.numel() < (1 << 31))
+
+
+def conv1x1_cat(parts, w, relu=False, stats=None, grad_masked=None):
+    """conv1x1(torch.cat(parts, channel dim), w) without the concatenation (ConvCat1x1Fn) when rih_gemm's segmented operand applies
+    (_cat_seg_ok: a split engine, aligned parts with channel counts that are multiples of 32, below 2 GiB each); the concatenation
+    followed by conv2d otherwise (engine 0, odd channel counts, giant maps).
+    grad_masked: the consumer is a BatchNorm with input_relu, whose backward hands back a gradient already gated by y > 0 (the
+    mid convolutions of models/encoder.py:165-173); default = `relu`, the only use inside this package.  With relu=True and
+    grad_masked=False the backward applies the ReLU gate itself."""
+    if grad_masked is None:
+        grad_masked = relu
+    if CAT_FREE and _cat_seg_ok(parts, w):
+        return ConvCat1x1Fn.apply(w, relu, stats, bool(grad_masked), *parts)
+    return conv2d(cat_channels(list(parts)), w, None, stride=1, pad=0, relu=relu, grad_masked=bool(grad_masked and relu), stats=stats)
 
 
 # the 1x1 convolutions behind channel concatenations (encoder.resnet_mid, HRnet_encoder heads) read their parts in place
@@ -1215,6 +1278,23 @@ def _dropout_grad(dy, drop):
     return d
 
 
+# EXPERIMENT (round 5, verdict item 6: "engine 2 for the decoder's Linears"): RIH_DECODER_E2=1 hands every nn.Linear GEMM of the
+# decoder (forward, data gradient, weight gradient; LinearFn and LinearPairFn) operand bounds MEASURED ON DEMAND (bound_of: one
+# rih_absmax launch per operand that nobody has measured) so that they take engine 2's kernels.  The extra launches make the
+# step slower; what the switch is for is the per-launch GEMM profile (bench.py by_engine): the time those GEMMs would take on
+# three fp16 products, i.e. what producer-published bounds (LayerNorm / GEMM / attention epilogues) could buy at most.
+DECODER_E2 = os.environ.get('RIH_DECODER_E2', '0') == '1'
+
+
+def _lin_bounds(x, w, w2=None):
+    """(bound thunk of the activation, bound thunk of the weight or of a left / right weight pair) or (None, None)."""
+    if not (DECODER_E2 and ENGINE == 2):
+        return None, None
+    if w2 is None:
+        return LazyBound(x), LazyBound(w)
+    return LazyBound(x), (lambda: torch.maximum(bound_of(w), bound_of(w2)))
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x @ w^T + bias + residual) for x [..., K], w [N, K] (the nn.Linear parameter, read in place).
     drop = (p, seed): y = dropout(act(x @ w^T + bias)) + residual (relu and residual together are not supported)."""
@@ -1229,15 +1309,18 @@ class LinearFn(torch.autograd.Function):
         y = torch.empty(x.shape[:-1] + (Nf,), device=x.device, dtype=torch.float32)
         if residual is not None:
             residual = _c(residual)
+        bx, bw = _lin_bounds(x, w)
         if drop is not None and drop[0] > 0:
             assert not (relu and residual is not None)
-            fused = gemm(x, w, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, bias=bias, R=residual, ldr=Nf, relu=relu, drop=drop)
+            fused = gemm(x, w, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, bias=bias, R=residual, ldr=Nf, relu=relu, drop=drop,
+                         amax_a=bx, amax_b=bw)
             y = _finish_dropout(fused, y, residual, drop)
         else:
             drop = None
-            gemm(x, w, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, bias=bias, R=residual, ldr=Nf, relu=relu)
+            gemm(x, w, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, bias=bias, R=residual, ldr=Nf, relu=relu, amax_a=bx, amax_b=bw)
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.cfg = (relu, bias is not None, residual is not None, drop)
+        ctx.bounds = (bx, bw)
         return y
 
     @staticmethod
@@ -1256,15 +1339,18 @@ class LinearFn(torch.autograd.Function):
             check(lib.rih_relu_bwd(dy.data_ptr(), y.data_ptr(), dyr.data_ptr(), dy.numel(), _stream()), 'rih_relu_bwd')
             dy = dyr
         dx = dw = db = None
+        bx, bw = ctx.bounds
+        bdy = LazyBound(dy) if bx is not None else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            gemm(dy, w, dx, M, K, Nf, Nf, K, K, a_mode=0, b_mode=0)
+            gemm(dy, w, dx, M, K, Nf, Nf, K, K, a_mode=0, b_mode=0, amax_a=bdy, amax_b=bw)
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             if want_db:
                 db = torch.empty((Nf,), device=x.device, dtype=torch.float32)
-            _wgrad(x, dy, dw, M, K, Nf, K, Nf, (1, 1, K, 1, 1, 1, 1, 1, 1, 0, 0), K, 1, K, db=db)
+            _wgrad(x, dy, dw, M, K, Nf, K, Nf, (1, 1, K, 1, 1, 1, 1, 1, 1, 0, 0), K, 1, K, db=db,
+                   bounds=(bx, bdy) if bx is not None else None)
         elif want_db:
             db = colsum(dy, M, Nf)
         if drop is None:
@@ -1305,17 +1391,19 @@ class LinearPairFn(torch.autograd.Function):
         y = torch.empty(x.shape[:-1] + (Nf,), device=x.device, dtype=torch.float32)
         if residual is not None:
             residual = _c(residual)
+        bx, bw = _lin_bounds(x, wL, None if stacked else wR)
         if drop is not None and drop[0] > 0:
             assert not (relu and residual is not None)
             fused = gemm(x, wL, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, bias=bL, R=residual, ldr=Nf, relu=relu, nb1=2,
-                         sA=(M * K, 0), sB=(sW, 0), sC=(M * Nf, 0), sBias=sBias, sR=M * Nf, drop=drop)
+                         sA=(M * K, 0), sB=(sW, 0), sC=(M * Nf, 0), sBias=sBias, sR=M * Nf, drop=drop, amax_a=bx, amax_b=bw)
             y = _finish_dropout(fused, y, residual, drop)
         else:
             drop = None
             gemm(x, wL, y, M, Nf, K, K, K, Nf, a_mode=0, b_mode=1, bias=bL, R=residual, ldr=Nf, relu=relu, nb1=2,
-                 sA=(M * K, 0), sB=(sW, 0), sC=(M * Nf, 0), sBias=sBias, sR=M * Nf)
+                 sA=(M * K, 0), sB=(sW, 0), sC=(M * Nf, 0), sBias=sBias, sR=M * Nf, amax_a=bx, amax_b=bw)
         ctx.save_for_backward(x, wL, wR, y if relu else None)
         ctx.cfg = (relu, bL is not None, residual is not None, stacked, Nf, K, sW, drop)
+        ctx.bounds = (bx, bw)
         return y
 
     @staticmethod
@@ -1332,12 +1420,16 @@ class LinearPairFn(torch.autograd.Function):
             check(_L().rih_relu_bwd(dy.data_ptr(), y.data_ptr(), dyr.data_ptr(), dy.numel(), _stream()), 'rih_relu_bwd')
             dy = dyr
         dx = None
+        bx, bw = ctx.bounds
+        bdy = LazyBound(dy) if bx is not None else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            gemm(dy, wL, dx, M, K, Nf, Nf, K, K, a_mode=0, b_mode=0, nb1=2, sA=(M * Nf, 0), sB=(sW, 0), sC=(M * K, 0))
+            gemm(dy, wL, dx, M, K, Nf, Nf, K, K, a_mode=0, b_mode=0, nb1=2, sA=(M * Nf, 0), sB=(sW, 0), sC=(M * K, 0),
+                 amax_a=bdy, amax_b=bw)
         dw = torch.empty((2, Nf, K), device=x.device, dtype=torch.float32)
         db = torch.empty((2, Nf), device=x.device, dtype=torch.float32) if has_bias else None
-        _wgrad(x, dy, dw, M, K, Nf, K, Nf, (1, 1, K, 1, 1, 1, 1, 1, 1, 0, 0), K, 1, K, db=db, nb=2, sx=M * K, sdy=M * Nf)
+        _wgrad(x, dy, dw, M, K, Nf, K, Nf, (1, 1, K, 1, 1, 1, 1, 1, 1, 0, 0), K, 1, K, db=db, nb=2, sx=M * K, sdy=M * Nf,
+               bounds=(bx, bdy) if bx is not None else None)
         if drop is None:
             dres = dy if (has_res and ctx.needs_input_grad[5]) else None
         if stacked:

@@ -143,6 +143,9 @@ class Adam(torch.optim.Optimizer):
                 torch._foreach_add_(counters, 1)     # every parameter's own counter, one host call
             if len(t.plan) > 1:
                 t.key = None            # distinct step counts: regroup next time (they may have converged or been reloaded)
+        # the kernel rewrote the parameters through raw pointers: torch's version counters did not move, so every operand bound
+        # cached on a parameter (engine 2, ops.bound_of) is stale from here on
+        ops.bounds_invalidate()
         return loss
 
 

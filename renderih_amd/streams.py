@@ -101,7 +101,18 @@ class _Hop(torch.autograd.Function):
 
 def _hop(r):
     if torch.is_tensor(r):
-        return _Hop.apply(r) if r.requires_grad else r
+        if not r.requires_grad:
+            return r
+        y = _Hop.apply(r)
+        # the hop's output is a fresh view: hand on what the producing kernels left on the tensor -- its operand bound (engine 2:
+        # without it every consumer pays an rih_absmax pass) and the BatchNorm-backward fold record
+        b = getattr(r, '_rih_bound', None)
+        if b is not None:
+            y._rih_bound = (b[0], y._version, b[2])
+        f = getattr(r, '_rih_bnfold', None)
+        if f is not None:
+            y._rih_bnfold = f
+        return y
     if isinstance(r, (list, tuple)):
         return type(r)(_hop(t) for t in r)
     return r

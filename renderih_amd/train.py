@@ -84,12 +84,15 @@ class TrainStep:
         self.groups = stage_parameter_groups(model) if stages else [[p for p in model.parameters() if p.requires_grad]]
         self.nstage = len(self.groups)
         self.overlap = overlap and self.exchange
-        self.side_limit = None          # upper bound on streams.SIDE inside this object's forward / backward (streams.limit)
-        if self.overlap and self.img_is_cuda(example_batch):
-            # the all-reduce already runs beside the backward in its own stream; a captured step with a THIRD concurrent branch
-            # (streams.fork_join's side stream, HRNet) died inside the HIP runtime on ROCm 7.0.2, so the model's own
-            # side streams are off in a process that exchanges gradients
-            self.side_limit = 0
+        # upper bound on streams.SIDE inside this object's forward / backward (streams.limit).  None = no extra limit, also in a
+        # process that exchanges gradients: rounds 3-4 switched the model's own side streams off there (a captured step with more
+        # than one concurrent branch died inside hipStreamEndCapture), which cost HRNet-W32 its three side streams under data
+        # parallelism (627 against 774 images/s on one rank).  The crash was root-caused in round 4 -- side streams that wait on each
+        # other's events inside a capture -- and is avoided by streams._Hop (every cross-stream gradient travels through the
+        # origin stream); the all-reduce itself is never captured (it runs eagerly on `self.side` between the stage replays), so
+        # it adds no branch to any capture.  RIH_DP_SIDE_LIMIT=n restores a clamp.
+        lim = os.environ.get('RIH_DP_SIDE_LIMIT', '')
+        self.side_limit = int(lim) if (lim != '' and self.overlap and self.img_is_cuda(example_batch)) else None
         self.img, self.labels = example_batch
         dev = self.img.device
         self.cuda = dev.type == 'cuda'
@@ -259,6 +262,12 @@ class TrainStep:
         return sum(1 for n in uses.values() if n > 1)
 
     def _step_eager(self):
+        with ops.owned_bounds():        # forward + every backward stage: nothing rewrites a weight before _finish()
+            loss = self._step_eager_body()
+        self._finish()
+        return loss
+
+    def _step_eager_body(self):
         loss = self._forward_loss()
         if self.defer_reduce and self.live is None:
             shared = self._shared_parameters([loss] + list(self._bounds or ()))
@@ -279,7 +288,6 @@ class TrainStep:
             self._setup_buckets(per_stage)
             for i, grads in enumerate(per_stage):
                 self._reduce(i, grads)
-        self._finish()
         return loss.detach()
 
     def _finish(self):
@@ -339,7 +347,7 @@ class TrainStep:
         # graphs re-read it at every replay, so it lives as long as this object; allocated HERE, before the capture (pinned
         # allocations are illegal while a stream captures), twice the size one warm-up step packed
         ops.TABLE_ARENA = self._table_arena = ops.TableArena(2 * ops.TABLE_BYTES_STEP + (1 << 16))
-        with torch.cuda.stream(cap):
+        with torch.cuda.stream(cap), ops.owned_bounds():
             carry, loss = None, None
             for i in range(self.nstage):
                 gph = torch.cuda.CUDAGraph()

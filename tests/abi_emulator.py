@@ -80,6 +80,8 @@ class EmulatedLib:
         M, N, K = d.M, d.N, d.K
         taps = d.KH * d.KW
         assert d.splitk >= 1 and (taps == 1 or d.Cin % 4 == 0)
+        if d.a_seg[0] and (d.engine < 1 or d.tile > 2 or d.a_mode != 0 or d.b_mode != 1 or d.nb1 * d.nb2 != 1 or d.splitk != 1):
+            return -1           # RIH_EINVAL: only the split engines' fast path reads a segmented A (csrc/rih_gemm.hip gemm_impl)
         for b1 in range(d.nb1):
             for b2 in range(d.nb2):
                 Ab = d.A + 4 * (b1 * d.sA1 + b2 * d.sA2)

@@ -147,6 +147,11 @@ def test_conv1x1_cat_host_logic():
     for eng in (1, 2):
         G.test_conv1x1_cat((2, 8, 8, (64, 32, 96), 128, True), eng)
         G.test_conv1x1_cat((1, 5, 7, (32, 64), 40, False), eng)
+    # engine 0 (no segmented operand in rih_gemm: the emulator answers RIH_EINVAL like the library) and ragged channel counts fall
+    # back to the concatenation; a consumer without gradient pre-gating gets the ReLU gate from the function
+    G.test_conv1x1_cat((1, 5, 7, (32, 64), 40, True), 0)
+    G.test_conv1x1_cat((1, 4, 4, (32, 40), 32, True), 2)
+    G.test_conv1x1_cat((1, 4, 4, (64, 32), 64, 'ungated'), 1)
 
 
 def test_bn_fold_host_logic(monkeypatch):

@@ -84,15 +84,21 @@ def test_conv2d(case):
         assert_close(bg.grad, br.grad, 1e-3, 1e-4, 'conv db %s' % (case,))
 
 
-@pytest.mark.parametrize('engine', [1, 2])
+@pytest.mark.parametrize('engine', [0, 1, 2])
 @pytest.mark.parametrize('case', [(2, 16, 16, (128, 128, 256), 256, True), (3, 9, 7, (32, 64), 40, False),
-                                  (2, 8, 8, (128, 128, 1024, 32), 256, True), (1, 33, 5, (64, 32, 96), 128, False)])
+                                  (2, 8, 8, (128, 128, 1024, 32), 256, True), (1, 33, 5, (64, 32, 96), 128, False),
+                                  (2, 8, 8, (64, 32), 64, 'ungated'), (1, 6, 6, (32, 40), 32, True)])
 def test_conv1x1_cat(case, engine, monkeypatch=None):
     """ops.conv1x1_cat (segmented GEMM operand, rih_gemm_desc.a_seg): the 1x1 convolution of a channel concatenation read in place
     -- output, the statistics epilogue, every part's gradient and the weight gradient (written as column slices by the reduction)
-    against F.conv2d on the materialised concatenation; engines 1 and 2, two to four parts, ragged row counts, N tails."""
+    against F.conv2d on the materialised concatenation; engines 1 and 2, two to four parts, ragged row counts, N tails.  Engine 0
+    (rih_gemm reads no segmented operand there) and a channel count that is not a multiple of 32 take the concatenation
+    fall-back (round-4 advisor finding: the documented RIH_GEMM_ENGINE=0 broke the mid convolutions).  relu == 'ungated': a
+    consumer that does NOT pre-gate the gradient (grad_masked=False) -- the backward applies the ReLU gate itself."""
     from renderih_amd import ops
     N, H, W, Cs, Cout, relu = case
+    ungated = relu == 'ungated'
+    relu = bool(relu)
     saved = ops.ENGINE
     ops.ENGINE = engine
     try:
@@ -105,14 +111,14 @@ def test_conv1x1_cat(case, engine, monkeypatch=None):
         if relu:
             yr = F.relu(yr)
         gy = rnd(*yr.shape, seed=4)
-        if relu:
+        if relu and not ungated:
             gy = gy * (yr > 0).float()          # the consumer (BatchNorm with input_relu) hands back a gradient gated by y > 0
         yr.backward(gy)
         d = dev()
         pg = [nhwc(t).contiguous().to(d).requires_grad_(True) for t in parts]
         wg = w.to(d).requires_grad_(True)
         holder = ops.StatsHolder()
-        yg = ops.conv1x1_cat(pg, wg, relu=relu, stats=holder)
+        yg = ops.conv1x1_cat(pg, wg, relu=relu, stats=holder, grad_masked=(False if ungated else None))
         assert_close(nchw(yg), yr, what='cat conv y %s' % (case,))
         if holder.part is not None:             # per-block (mean, M2) -> mean / variance per channel
             M = N * H * W

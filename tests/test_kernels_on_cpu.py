@@ -62,6 +62,52 @@ def test_conv1x1_cat_kernels(case, engine):
     G.test_conv1x1_cat(case, engine)
 
 
+@pytest.mark.parametrize('case,engine', [((1, 8, 8, (32, 64), 40, True), 0), ((1, 4, 4, (32, 40), 32, True), 2),
+                                         ((1, 4, 4, (64, 32), 64, 'ungated'), 2), ((1, 4, 4, (64, 32), 64, 'ungated'), 0)])
+def test_conv1x1_cat_fallback_and_ungated_relu_kernels(case, engine):
+    """Round-4 advisor findings on ops.conv1x1_cat: engine 0 (RIH_GEMM_ENGINE=0 is a documented switch; rih_gemm reads a segmented A
+    on the split engines only) and channel counts off the 32-grid fall back to the concatenation instead of failing with
+    RIH_EINVAL; a consumer that does not pre-gate the gradient gets the ReLU's backward gate from the function itself."""
+    G.test_conv1x1_cat(case, engine)
+
+
+def test_parameter_bounds_are_not_trusted_outside_an_owning_scope():
+    """Round-4 advisor finding: engine 2 derives its fp16 operand scale from a cached bound of the weight; outside a model forward /
+    TrainStep nothing invalidates that cache when the weight is rewritten behind torch's version counter (rih_adam_multi through
+    raw pointers, `w.data.mul_`) -- a conv2d after an 8-fold growth overflowed the fp16 planes (inf / NaN).  Parameters are now
+    measured again at every use outside ops.owned_bounds(), and renderih_amd.optim.Adam starts a new bound epoch."""
+    import torch.nn.functional as F
+    from renderih_amd import ops, optim
+    saved = ops.ENGINE
+    ops.ENGINE = 2
+    try:
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(1, 8, 8, 32, generator=g)
+        w = torch.nn.Parameter(torch.randn(32, 32, 3, 3, generator=g) * 0.1)
+
+        def check(what):
+            y = ops.conv2d(x, w, None, stride=1, pad=1)
+            want = F.conv2d(x.permute(0, 3, 1, 2), w.detach(), padding=1).permute(0, 2, 3, 1)
+            assert torch.isfinite(y).all(), what
+            G.assert_close(y, want, 1e-4, 1e-5, what)
+        check('first call')
+        w.data.mul_(64.0)                       # invisible to w._version
+        check('after w.data.mul_(64)')
+        # the one-launch Adam rewrites the weights through raw pointers: a bound cached INSIDE an owning scope dies with its step
+        with ops.owned_bounds():
+            ops.bounds_reset()
+            ops.bound_weights([w])
+            cached = ops.bound_of(w)
+            assert ops.bound_of(w) is cached                    # trusted inside the scope
+            opt = optim.Adam([w], lr=50.0)
+            ops.conv2d(x, w, None, stride=1, pad=1).sum().backward()
+            opt.step()
+            assert ops.bound_of(w) is not cached                # new epoch: measured again
+        check('after an Adam step with a huge learning rate')
+    finally:
+        ops.ENGINE = saved
+
+
 @pytest.mark.parametrize('case', [(2, 8, 8, 64, 64, 64, 3, True, False), (1, 8, 8, 64, 128, 64, 1, True, True),
                                   (1, 9, 7, 32, 64, 96, 3, False, False)])
 @_needs_experiments
