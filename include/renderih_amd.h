@@ -261,6 +261,41 @@ typedef struct rih_presplit_desc {
 } rih_presplit_desc;
 int rih_presplit_multi(const rih_presplit_desc* descs, int n, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Halo-resident 3x3 convolution, stride 1, padding 1 (csrc/rih_conv3.hip, ABI 15) -- the 3x3 convolutions of the trunk's
+ * Bottlenecks and of the aux decoders (torchvision Bottleneck.conv2 via models/encoder.py:81-83; models/encoder.py:44-54) and
+ * their data gradients, on engine 2's arithmetic (fp32 = three fp16 MFMA products, see rih_gemm_desc.engine).  A workgroup owns
+ * an 8 x 32 pixel patch and 128 (64) output channels, loads and converts each 32-channel chunk of the (8+2) x (32+2) input
+ * halo ONCE and runs the nine taps on shifted windows of that LDS image; the weights arrive as two pre-split fp16 planes
+ * ("H2": dst[n][k / 8][plane][8 halves], k = (tap, channel), written once per training step by rih_h2_multi) through LDS-DMA.
+ *   y[img][i][j][n] = act(sum_{kh,kw,c} x[img][i+kh-1][j+kw-1][c] * W(n, (kh*3+kw)*C + c))        (zero padding)
+ * Forward: W from rih_h2_desc.for_dgrad 0 (n = co).  Data gradient: x = dy, C = Cout, N = CinPad, for_dgrad 1 (flipped taps).
+ * Preconditions (rih_conv3x3_ok returns 1): C % 32 == 0, N % 64 == 0, H % 8 == 0, W % 32 == 0, Kpad == 9 * C, 16-byte aligned
+ * x / w_h2 / y / stats, ldx / ldy % 4 == 0, one image below 2 GiB.  amax_x / amax_w: bound blocks (rih_absmax) -- amax_w must be
+ * the block the H2 planes were scaled with.  stats (optional): [imgs * H * W / 64][2][N] (mean, M2) per 64-row block, the format
+ * of rih_gemm_desc.stats with rows_per_block = rih_conv3x3_stats_rows() = 64 (a block is a quarter of a patch, every block full).
+ * Not bit-identical to rih_gemm on the same convolution: the reduction runs chunk-major, (c / 32, tap, c % 32). */
+typedef struct rih_conv3_desc {
+    const float* x;         /* NHWC [imgs][H][W][ldx] */
+    const void* w_h2;       /* [N][Kpad / 8][2][8] fp16 */
+    float* y;               /* NHWC [imgs][H][W][ldy] */
+    float* stats;           /* or NULL */
+    const float* amax_x;
+    const float* amax_w;
+    int32_t imgs, H, W, C, N, ldx, ldy, Kpad, relu;
+} rih_conv3_desc;
+int rih_conv3x3_ok(const rih_conv3_desc* d);
+int rih_conv3x3_stats_rows(void);
+int rih_conv3x3(const rih_conv3_desc* d, void* stream);
+typedef struct rih_h2_desc {
+    const float* w;         /* OIHW parameter */
+    void* dst;              /* [N][Kpad / 8][2][8] fp16: N = Cout (for_dgrad 0) or CinPad (1), Kpad >= KH*KW*CinPad (resp. *Cout), % 32 */
+    const float* amax;      /* bound block of w */
+    int32_t Cout, Cin, KH, KW, CinPad, for_dgrad, Kpad;
+} rih_h2_desc;
+/* any number of H2 weight operands in ceil(n / 48) launches (`descs` is HOST memory, read before the call returns) */
+int rih_h2_multi(const rih_h2_desc* descs, int n, void* stream);
+
 /* Finish a forward split-K GEMM: C[m*ldc+n] = act(alpha * sum_s P[s][m][n] + bias[n] + R[m*ldr+n]). */
 int rih_splitk_finish(const float* P, int S, int M, int N, float* C, int ldc, const float* bias, const float* R,
                       int ldr, float alpha, int relu, void* stream);
@@ -512,9 +547,10 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
 /* library / device info.  RIH_ABI_VERSION is bumped whenever a struct layout or a signature of this header changes;
  * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of EVERY by-pointer struct, in
  * this order: gemm desc, mano model, mesh topo, hconv desc, reduce desc, pack desc, ln final desc, adam entry, absmax desc,
- * presplit desc (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it mis-laid-out structs. */
-#define RIH_ABI_VERSION 14
-#define RIH_ABI_NSIZES 10
+ * presplit desc, conv3 desc, h2 desc (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it
+ * mis-laid-out structs. */
+#define RIH_ABI_VERSION 15
+#define RIH_ABI_NSIZES 12
 int rih_version(void);
 int rih_abi_sizes(int32_t* out10);
 const char* rih_arch(void);

@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, 'librenderih_amd.so')
 # opt-in paths RIH_CHAIN=1 / ops.gemm_p3 and their tests then work as before).
 EXPERIMENTS = os.environ.get('RIH_BUILD_EXPERIMENTS', '0') == '1'
 EXPERIMENT_SOURCES = ['rih_gemm3.hip', 'rih_chain.hip']
-SOURCES = ['rih_gemm.hip', 'rih_elem.hip', 'rih_mano.hip', 'rih_loss.hip', 'rih_metrics.hip',
+SOURCES = ['rih_gemm.hip', 'rih_conv3.hip', 'rih_elem.hip', 'rih_mano.hip', 'rih_loss.hip', 'rih_metrics.hip',
            'rih_pose.hip', 'rih_attn.hip', 'rih_flash.hip', 'rih_half.hip', 'rih_input.hip', 'rih_sdf.hip'] + \
           (EXPERIMENT_SOURCES if EXPERIMENTS else [])
 HEADERS = ['rih_procrustes.h', 'rih_pose_math.h', 'rih_hash.h', 'rih_bn_bwd_partial.inc']

@@ -54,6 +54,17 @@ class PresplitDesc(C.Structure):
                [(n, C.c_int32) for n in ('Cout', 'Cin', 'KH', 'KW', 'CinPad', 'for_dgrad', 'kh0', 'kw0', 'step', 'Th', 'Tw', 'Kpad')]
 
 
+class Conv3Desc(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('w_h2', C.c_void_p), ('y', C.c_void_p), ('stats', C.c_void_p), ('amax_x', C.c_void_p),
+                ('amax_w', C.c_void_p)] + \
+               [(n, C.c_int32) for n in ('imgs', 'H', 'W', 'C', 'N', 'ldx', 'ldy', 'Kpad', 'relu')]
+
+
+class H2Desc(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('dst', C.c_void_p), ('amax', C.c_void_p)] + \
+               [(n, C.c_int32) for n in ('Cout', 'Cin', 'KH', 'KW', 'CinPad', 'for_dgrad', 'Kpad')]
+
+
 class AbsmaxDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('out', C.c_void_p), ('n', C.c_int64)]
 
@@ -128,6 +139,10 @@ SIGNATURES = {
     'rih_presplit_matrix': (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_f, C.c_void_p]),
     'rih_presplit_conv_weight': (c_i, [c_f, c_f] + [c_i] * 12 + [c_f, C.c_void_p]),
     'rih_presplit_multi': (c_i, [C.POINTER(PresplitDesc), c_i, C.c_void_p]),
+    'rih_conv3x3_ok': (c_i, [C.POINTER(Conv3Desc)]),
+    'rih_conv3x3_stats_rows': (c_i, []),
+    'rih_conv3x3': (c_i, [C.POINTER(Conv3Desc), C.c_void_p]),
+    'rih_h2_multi': (c_i, [C.POINTER(H2Desc), c_i, C.c_void_p]),
     'rih_hardswish_fwd': (c_i, [c_f, c_f, c_l, C.c_void_p]),
     'rih_hardswish_bwd': (c_i, [c_f, c_f, c_f, c_l, C.c_void_p]),
     'rih_tanh_scale_fwd': (c_i, [c_f, c_f, c_l, c_fl, C.c_void_p]),
@@ -237,7 +252,7 @@ EXPERIMENT_SIGNATURES = {
 }
 HAS_EXPERIMENTS = False
 
-ABI_VERSION = 14     # = RIH_ABI_VERSION of include/renderih_amd.h
+ABI_VERSION = 15     # = RIH_ABI_VERSION of include/renderih_amd.h
 
 _lib = None
 
@@ -280,7 +295,8 @@ def load():
     # every by-pointer struct of the header, in rih_abi_sizes' order; the last one (rih_adam_entry: four pointers + int64) is
     # built by hand as int64 rows in renderih_amd/optim.py
     mine = [C.sizeof(GemmDesc), C.sizeof(ManoModel), C.sizeof(MeshTopo), C.sizeof(HConvDesc),
-            C.sizeof(ReduceDesc), C.sizeof(PackDesc), C.sizeof(LnFinalDesc), 5 * 8, C.sizeof(AbsmaxDesc), C.sizeof(PresplitDesc)]
+            C.sizeof(ReduceDesc), C.sizeof(PackDesc), C.sizeof(LnFinalDesc), 5 * 8, C.sizeof(AbsmaxDesc), C.sizeof(PresplitDesc),
+            C.sizeof(Conv3Desc), C.sizeof(H2Desc)]
     if lib.rih_version() != ABI_VERSION:
         raise RuntimeError('librenderih_amd.so does not match this binding (ABI %d vs %d): rebuild with '
                            '`python -m renderih_amd._build`' % (lib.rih_version(), ABI_VERSION))

@@ -1,0 +1,466 @@
+// rih_conv3.hip -- halo-resident 3x3 convolution (stride 1, padding 1) for gfx950 on rih_gemm's engine-2 arithmetic.
+//
+// Why (round-5).  The implicit-GEMM kernels of rih_gemm.hip walk a 3x3 convolution tap by tap: every one of the nine
+// k-tiles of a 32-channel chunk fetches the 128 (or 256) A rows of the workgroup again from L2 -- the same input pixels, shifted by
+// one -- and converts them again (fp32 -> two scaled fp16 planes, six VALU instructions per pair).  Round 4 measured those
+// kernels bound by the SUM of MFMA, conversion VALU and LDS issue plus ~8 TB/s of L2 -> LDS operand traffic (2.4 GB per launch for
+// 268 MB of compulsory bytes on the 64x64 128 -> 128 convolution).  Here a workgroup owns an 8 x 32 pixel patch of one image
+// and BN output channels; per 32-channel chunk it loads the (8+2) x (32+2) input halo ONCE, converts it ONCE into the two fp16
+// planes in LDS, and runs the nine taps' MFMAs on shifted windows of that LDS image: A traffic and A conversion per FLOP drop
+// 6.8-fold (340 halo pixels for 9 x 256 operand rows).  The weights arrive PRE-SPLIT (two fp16 planes, interleaved per 8 k:
+// "H2", written once per step by rih_h2_conv_weight / rih_h2_multi) and are staged global -> LDS by LDS-DMA: no VGPR round
+// trip, no ds_write, no conversion for B at all.  One barrier per k-tile; B double-buffered, A double-buffered per chunk.
+//
+// Arithmetic = engine 2 of rih_gemm.hip, bit for bit per product: operands scaled by powers of two derived from device-resident
+// bound blocks (e2_scale), x = hi + 2^-11 lo with fp16 hi / lo, three v_mfma_f32_32x32x16_f16 per 32x32x16 block (hi*hi into
+// acc0, lo*hi + hi*lo into acc1), result (acc0 + 2^-11 acc1) / (s_a s_b).  The summation ORDER over k differs from the tap-major
+// implicit GEMM (here chunk-major: (c / 32, tap, c % 32)), so results agree to fp32 round-off, not bitwise.
+//
+// Geometry: 512 threads = 8 wavefronts as 4 (M) x 2 (N); wave tile 64 x BN/2 (two image rows of 32 pixels x TN 32-column
+// blocks); BN = 128 or 64.  LDS: A 2 x 340 x 128 B = 85 KB, B 2 x BN x 128 B <= 32 KB: one workgroup (two waves per SIMD) per CU.
+// LDS images: a pixel (or a weight row) is 8 units of 16 bytes -- unit j = (k / 8) * 2 + plane -- stored at position
+// j ^ ((index >> 1) & 7): the ds_read_b128 operand fetches (32 consecutive pixels of ONE image row, resp. 32 consecutive weight
+// rows, one unit index per half wave) touch 16 distinct bank groups per 16-lane group for every tap shift (checked exhaustively
+// by tests/test_kernels_on_cpu.py::test_conv3_lds_image_is_conflict_free).
+//
+// Preconditions (rih_conv3x3_ok): C % 32 == 0, N % 64 == 0, H % 8 == 0, W % 32 == 0, 16-byte aligned operands, pitches % 4 == 0,
+// one image < 2 GiB.  Epilogue: optional ReLU, optional BatchNorm statistics per 64-row wave block ((mean, M2), the format of
+// rih_gemm_desc.stats: rih_bn_stats_from_blocks merges them).  No bias / residual (no 3x3 convolution of the network has one
+// on the training path); callers with either use rih_gemm.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/renderih_amd.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int TH = 8, TW = 32, HW_ = TW + 2, HP = (TH + 2) * HW_;       // halo: 10 x 34 = 340 pixels
+constexpr int A_STAGE = HP * 128;                                        // bytes: 8 units of 16 B per pixel
+constexpr int NT = 512;
+constexpr unsigned OOB = 0x80000000u;
+constexpr int SLD = 36;                                                  // epilogue staging pitch (floats)
+
+struct C3Args {
+    const float* x;
+    const unsigned char* w;     // H2 planes [N][Kp / 8][2][8 halves]
+    float* y;
+    float* stats;
+    const float* amax_x;
+    const float* amax_w;
+    int imgs, H, W, C, N, ldx, ldy, Kp, relu;
+    int tiles_x, tiles_y, nblk;
+};
+
+__device__ __forceinline__ int xcd_remap_c3(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+// the same scale derivation as rih_gemm.hip's e2_scale (bound block: 64 partial maxima, one per 128-byte line)
+__device__ __forceinline__ float c3_scale(const float* amax) {
+    if (amax == nullptr) return 1.f;
+    float a = amax[(threadIdx.x & 63) * (RIH_BOUND_FLOATS / 64)];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
+    a = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(a)));
+    const int e = (int)((__float_as_uint(a) >> 23) & 0xffu);
+    if (e == 0 || e == 255) return 1.f;
+    int se = 268 - e;
+    se = se > 253 ? 253 : se;
+    return __uint_as_float((unsigned)se << 23);
+}
+
+__device__ __forceinline__ unsigned c3_pk_f16(float a, float b) {
+    const f16x2 v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+// (a, b) * s -> packed fp16 hi pair and packed fp16 pair of the 2^11-scaled residuals (rih_gemm.hip split2h)
+__device__ __forceinline__ void c3_split2h(float a, float b, float s, unsigned& h, unsigned& l) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float ra, rb;
+    const float k2048 = 2048.f;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a), "s"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(b), "s"(s));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(a), "s"(s), "v"(h));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(b), "s"(s), "v"(h));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(l) : "v"(ra), "s"(k2048));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l) : "v"(rb), "s"(k2048));
+#else
+    a *= s;
+    b *= s;
+    const f16x2 hv = {(_Float16)a, (_Float16)b};
+    h = __builtin_bit_cast(unsigned, hv);
+    l = c3_pk_f16((a - (float)hv.x) * 2048.f, (b - (float)hv.y) * 2048.f);
+#endif
+}
+
+__device__ __forceinline__ void c3_glds16(const unsigned char* src, unsigned char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+__device__ __forceinline__ float4 c3_bload4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+template <int BN, bool STATS>
+__global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
+    constexpr int TN = BN / 64;                         // 32-column blocks per wave (waves 4 x 2, wave tile 64 x BN / 2)
+    constexpr int B_STAGE = BN * 128;
+    constexpr int NPA = (HP * 8 + NT - 1) / NT;         // float4 quads of a halo chunk per thread: 6 (the last pass partial)
+    constexpr int NPB = (BN * 8) / NT;                  // LDS-DMA units of a weight k-tile per thread: 2 (BN 128) / 1 (BN 64)
+    static_assert((BN * 8) % NT == 0, "whole LDS-DMA instructions");
+    constexpr int SMEM = 2 * A_STAGE + 2 * B_STAGE;
+    static_assert(SMEM >= 8 * 32 * SLD * 4, "epilogue staging fits");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    unsigned char* const Abuf = smem;
+    unsigned char* const Bbuf = smem + 2 * A_STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // workgroup -> (image, patch, channel block); channel blocks fastest so that workgroups sharing a halo are neighbours
+    const int bid = xcd_remap_c3((int)blockIdx.x, (int)gridDim.x);
+    const int nb = bid % p.nblk;
+    int rest = bid / p.nblk;
+    const int tx_t = rest % p.tiles_x;
+    rest /= p.tiles_x;
+    const int ty_t = rest % p.tiles_y;
+    const int img = rest / p.tiles_y;
+    const int y0 = ty_t * TH, x0 = tx_t * TW, n0 = nb * BN;
+
+    const float sa = c3_scale(p.amax_x), sb = c3_scale(p.amax_w);
+
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x + (long long)img * p.H * p.W * p.ldx), (short)0, (int)((long long)p.H * p.W * p.ldx * 4), 0x00020000);
+
+    // ---------------------------------------------------------------- loader constants
+    // A: quad q = pass * NT + tid -> halo pixel hp = q / 8, channel quad cq = q % 8 of the 32-channel chunk
+    unsigned a_goff[NPA];       // byte offset of (pixel, channel quad) in the image, OOB for the zero padding / idle lanes
+    int a_lds[NPA];             // LDS byte offset of the hi half-unit (the lo half-unit is at offset ^ 16), -1: idle lane
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        const int q = i * NT + tid;
+        const int hp = q >> 3, cq = q & 7;
+        a_goff[i] = OOB;
+        a_lds[i] = -1;
+        if (hp < HP) {
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+                a_goff[i] = (unsigned)(((y * p.W + x) * p.ldx + 4 * cq) * 4);
+            a_lds[i] = hp * 128 + ((((cq >> 1) * 2) ^ ((hp >> 1) & 7)) << 4) + (cq & 1) * 8;
+        }
+    }
+    // B: unit U = pass * NT + tid -> weight row n = U / 8, LDS position U % 8 holds source unit j = pos ^ ((n >> 1) & 7)
+    const unsigned char* b_src[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int U = i * NT + tid;
+        const int n = U >> 3, j = (U & 7) ^ ((n >> 1) & 7);
+        b_src[i] = p.w + ((long long)(n0 + n) * (p.Kp >> 3)) * 32 + j * 16;         // + (k / 8) * 32 per k-tile
+    }
+    // operand fetch: A pixel rows of this wave: image rows ty = 2 wm + i (i < 2), pixel tx = l31; B rows wn * BN/2 + jj * 32 + l31
+    int b_rd[2][2][TN];         // [k-step][plane][block]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) {
+                const int n = wn * (BN / 2) + jj * 32 + l31;
+                b_rd[s][pl][jj] = n * 128 + (((((2 * s + lhi) * 2) + pl) ^ ((n >> 1) & 7)) << 4);
+            }
+    const int a_hp0 = (2 * wm) * HW_ + l31;             // halo pixel of (row 2 wm, pixel l31) at tap (0, 0)
+
+    float4 areg[NPA];
+    auto load_A = [&](int c0) {                         // global -> registers: the halo of channels [c0, c0 + 32)
+        const unsigned add = (unsigned)c0 * 4u;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) areg[i] = c3_bload4(rX, a_goff[i] == OOB ? OOB : a_goff[i] + add);
+    };
+    auto store_A = [&](unsigned char* dst) {            // registers -> two fp16 planes in LDS
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            if (a_lds[i] < 0) continue;
+            unsigned h0, l0, h1, l1;
+            c3_split2h(areg[i].x, areg[i].y, sa, h0, l0);
+            c3_split2h(areg[i].z, areg[i].w, sa, h1, l1);
+            *reinterpret_cast<uint2*>(dst + a_lds[i]) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(dst + (a_lds[i] ^ 16)) = make_uint2(l0, l1);
+        }
+    };
+    auto issue_B = [&](int kofs, unsigned char* dst) {  // LDS-DMA: weight rows [n0, n0 + BN) x k [kofs, kofs + 32)
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) c3_glds16(b_src[i] + (long long)(kofs >> 3) * 32, dst + (i * NT + tid) * 16);
+    };
+
+    floatx16 acc[2][TN], acc1[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
+
+    const int nchunk = p.C / 32;
+    const int ntile = nchunk * 9;
+    // prologue: halo of chunk 0 converted into A stage 0, weights of k-tile 0 in flight into B stage 0
+    load_A(0);
+    issue_B(0, Bbuf);
+    store_A(Abuf);
+    __syncthreads();                                    // (waits for the LDS-DMA too: hipcc drains vmcnt before a barrier)
+    int kt = 0;
+    for (int c = 0; c < nchunk; ++c) {
+        const unsigned char* As = Abuf + (c & 1) * A_STAGE;
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t, ++kt) {
+            // k-tile kt = (chunk c, tap t): its weights have landed in B stage kt & 1, the halo of chunk c is in A stage c & 1
+            if (kt + 1 < ntile) {
+                const int t1 = (t == 8) ? 0 : t + 1, c1 = (t == 8) ? c + 1 : c;
+                issue_B(t1 * p.C + c1 * 32, Bbuf + ((kt + 1) & 1) * B_STAGE);
+            }
+            if (t == 0 && c + 1 < nchunk) load_A((c + 1) * 32);          // lands during this chunk's taps
+            const unsigned char* Bs = Bbuf + (kt & 1) * B_STAGE;
+            const int kh = t / 3, kw = t - kh * 3;
+            const int hp_t = a_hp0 + kh * HW_ + kw;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f16x8 av[2][2], bv[2][TN];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int hp = hp_t + i * HW_;
+                    const int base = hp * 128, sw = (hp >> 1) & 7;
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        av[pl][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(
+                                                                  As + base + (((((2 * s + lhi) * 2) + pl) ^ sw) << 4)));
+                }
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj)
+                        bv[pl][jj] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(Bs + b_rd[s][pl][jj]));
+#define RIH_C3_TERM(ACC_, PA_, PB_)                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int jj = 0; jj < TN; ++jj) ACC_[i][jj] = \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(av[PA_][i], bv[PB_][jj], ACC_[i][jj], 0, 0, 0);
+                RIH_C3_TERM(acc1, 1, 0)
+                RIH_C3_TERM(acc, 0, 0)
+                RIH_C3_TERM(acc1, 0, 1)
+#undef RIH_C3_TERM
+            }
+            if (t == 8 && c + 1 < nchunk) store_A(Abuf + ((c + 1) & 1) * A_STAGE);   // (that stage was last read in chunk c - 1)
+            __syncthreads();
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue (the loop ended with a barrier: LDS is free)
+    // accumulators -> this wave's 32 x SLD floats of LDS -> each lane owns 4 consecutive columns of a row: 16-byte stores
+    float* stg = reinterpret_cast<float*>(smem) + wave * (32 * SLD);
+    const float inv_a = 1.f / sa, inv_b = 1.f / sb;     // (applied one after the other, like rih_gemm: exact powers of two)
+    float4 ssh[STATS ? TN : 1], ssum[STATS ? TN : 1], ssq[STATS ? TN : 1];
+    float scnt[STATS ? TN : 1];
+    if (STATS) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            ssh[j] = make_float4(0, 0, 0, 0); ssum[j] = make_float4(0, 0, 0, 0); ssq[j] = make_float4(0, 0, 0, 0); scnt[j] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int y = y0 + 2 * wm + i;
+        float* yrow = p.y + (((long long)img * p.H + y) * p.W + x0) * p.ldy + n0 + wn * (BN / 2);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (i + j > 0) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = fmaf(acc1[i][j][r], 0x1p-11f, acc[i][j][r]) * inv_a * inv_b;
+                stg[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + l31] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = (lane >> 3) + 8 * q, c4 = (lane & 7) * 4;       // row = pixel tx of this image row
+                float4 v = *reinterpret_cast<const float4*>(stg + row * SLD + c4);
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(yrow + (long long)row * p.ldy + j * 32 + c4) = v;
+                if (STATS) {
+                    if (scnt[j] == 0.f) ssh[j] = v;
+                    scnt[j] += 1.f;
+                    const float dx = v.x - ssh[j].x, dy = v.y - ssh[j].y, dz = v.z - ssh[j].z, dw = v.w - ssh[j].w;
+                    ssum[j].x += dx; ssum[j].y += dy; ssum[j].z += dz; ssum[j].w += dw;
+                    ssq[j].x += dx * dx; ssq[j].y += dy * dy; ssq[j].z += dz * dz; ssq[j].w += dw * dw;
+                }
+            }
+        }
+    }
+    if (STATS) {
+        // per column: (mean, centred sum of squares) of this wave's 64 rows; a lane holds 8 rows, the eight row-lanes merge
+        // pairwise with Chan's formula (store_tiles_wide of rih_gemm.hip); row block index = 4 * patch + wm
+        const long long rb = (((long long)img * p.tiles_y + ty_t) * p.tiles_x + tx_t) * 4 + wm;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float n = scnt[j];
+            const float in = n > 0.f ? 1.f / n : 0.f;
+            float4 mean = make_float4(ssh[j].x + ssum[j].x * in, ssh[j].y + ssum[j].y * in, ssh[j].z + ssum[j].z * in,
+                                      ssh[j].w + ssum[j].w * in);
+            float4 m2 = make_float4(ssq[j].x - ssum[j].x * ssum[j].x * in, ssq[j].y - ssum[j].y * ssum[j].y * in,
+                                    ssq[j].z - ssum[j].z * ssum[j].z * in, ssq[j].w - ssum[j].w * ssum[j].w * in);
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                const float nbr = __shfl_xor(n, o, 64);
+                const float nt = n + nbr;
+                const float wb = nt > 0.f ? nbr / nt : 0.f;
+                const float cf = n * wb;
+#define RIH_C3_MERGE(c_)                                                              \
+    {                                                                                 \
+        const float mb = __shfl_xor(mean.c_, o, 64), qb = __shfl_xor(m2.c_, o, 64);   \
+        const float dl = mb - mean.c_;                                                \
+        mean.c_ += dl * wb;                                                           \
+        m2.c_ += qb + dl * dl * cf;                                                   \
+    }
+                RIH_C3_MERGE(x) RIH_C3_MERGE(y) RIH_C3_MERGE(z) RIH_C3_MERGE(w)
+#undef RIH_C3_MERGE
+                n = nt;
+            }
+            if ((lane >> 3) == 0) {
+                const int nn = n0 + wn * (BN / 2) + j * 32 + (lane & 7) * 4;
+                *reinterpret_cast<float4*>(p.stats + (rb * 2 + 0) * p.N + nn) = mean;
+                *reinterpret_cast<float4*>(p.stats + (rb * 2 + 1) * p.N + nn) = m2;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ H2 weight operand
+// OIHW conv weight -> two scaled fp16 planes interleaved per 8 k: dst[n][k / 8][plane][8 halves] (row pitch Kp * 4 bytes), zero
+// padded to Kp.  for_dgrad 0: n = co, k = (tap, ci < CinPad) -- the forward operand; for_dgrad 1: n = ci < CinPad,
+// k = ((th, tw), co), taps flipped -- the data-gradient operand (stride-1 gradient: all KH x KW taps).  Scale from the weight's
+// bound block, derived like the consuming kernel derives it.
+struct H2WArgs {
+    const float* w;
+    unsigned char* dst;
+    const float* amax;
+    int N, K, Kp, for_dgrad;
+    int Cout, Cin, KH, KW, CinPad;
+};
+__device__ __forceinline__ float h2w_fetch(const H2WArgs& a, int n, int k) {
+    if (k >= a.K) return 0.f;
+    if (!a.for_dgrad) {
+        const int tap = k / a.CinPad, ci = k - tap * a.CinPad;
+        return ci < a.Cin ? a.w[((long long)n * a.Cin + ci) * (a.KH * a.KW) + tap] : 0.f;
+    }
+    const int co = k % a.Cout, t = k / a.Cout;
+    const int tw = t % a.KW, th = t / a.KW;
+    const int kh = a.KH - 1 - th, kw = a.KW - 1 - tw;
+    return n < a.Cin ? a.w[(((long long)co * a.Cin + n) * a.KH + kh) * a.KW + kw] : 0.f;
+}
+__device__ __forceinline__ void h2w_span(const H2WArgs& a, long long first, long long stride) {
+    const int G = a.Kp / 8;
+    const long long total = (long long)a.N * G;
+    const float sc = c3_scale(a.amax);
+    for (long long i = first; i < total; i += stride) {
+        const int n = (int)(i / G), g = (int)(i - (long long)n * G);
+        uint4 h, l;
+        c3_split2h(h2w_fetch(a, n, 8 * g + 0), h2w_fetch(a, n, 8 * g + 1), sc, h.x, l.x);
+        c3_split2h(h2w_fetch(a, n, 8 * g + 2), h2w_fetch(a, n, 8 * g + 3), sc, h.y, l.y);
+        c3_split2h(h2w_fetch(a, n, 8 * g + 4), h2w_fetch(a, n, 8 * g + 5), sc, h.z, l.z);
+        c3_split2h(h2w_fetch(a, n, 8 * g + 6), h2w_fetch(a, n, 8 * g + 7), sc, h.w, l.w);
+        uint4* d = reinterpret_cast<uint4*>(a.dst + i * 32);
+        d[0] = h;
+        d[1] = l;
+    }
+}
+constexpr int H2_PACK = 48;
+struct H2Pack {
+    H2WArgs d[H2_PACK];
+    int first[H2_PACK + 1];
+    int n;
+};
+static_assert(sizeof(H2Pack) <= 4096, "kernel argument limit");
+__global__ __launch_bounds__(256) void h2_weight_multi_kernel(const H2Pack pk) {
+    const int b = (int)blockIdx.x;
+    int k = 0;
+    while (k + 1 < pk.n && b >= pk.first[k + 1]) ++k;
+    const int nb = pk.first[k + 1] - pk.first[k];
+    h2w_span(pk.d[k], (long long)(b - pk.first[k]) * 256 + threadIdx.x, (long long)nb * 256);
+}
+
+int h2_args(H2WArgs& a, const rih_h2_desc& d) {
+    if (!d.w || !d.dst || !d.amax || d.Cout < 1 || d.Cin < 1 || d.KH < 1 || d.KW < 1 || d.CinPad < d.Cin || d.Kpad < 32 ||
+        d.Kpad % 32 != 0 || ((uintptr_t)d.dst % 16) != 0)
+        return RIH_EINVAL;
+    a.w = d.w; a.dst = (unsigned char*)d.dst; a.amax = d.amax; a.Kp = d.Kpad; a.for_dgrad = d.for_dgrad ? 1 : 0;
+    a.Cout = d.Cout; a.Cin = d.Cin; a.KH = d.KH; a.KW = d.KW; a.CinPad = d.CinPad;
+    if (!a.for_dgrad) { a.N = d.Cout; a.K = d.KH * d.KW * d.CinPad; }
+    else { a.N = d.CinPad; a.K = d.KH * d.KW * d.Cout; }
+    return a.Kp < a.K ? RIH_EINVAL : RIH_OK;
+}
+
+bool c3_ok(const rih_conv3_desc* d) {
+    if (!d || !d->x || !d->w_h2 || !d->y || !d->amax_x || !d->amax_w) return false;
+    if (d->imgs < 1 || d->H < TH || d->W < TW || d->H % TH != 0 || d->W % TW != 0) return false;
+    if (d->C < 32 || d->C % 32 != 0 || d->N < 64 || d->N % 64 != 0) return false;
+    if (d->ldx < d->C || d->ldx % 4 != 0 || d->ldy < d->N || d->ldy % 4 != 0 || d->Kpad != 9 * d->C) return false;
+    if ((((uintptr_t)d->x | (uintptr_t)d->w_h2 | (uintptr_t)d->y | (uintptr_t)d->stats) % 16) != 0) return false;
+    if ((long long)d->H * d->W * d->ldx * 4 >= (1ll << 31)) return false;
+    const long long wg = (long long)d->imgs * (d->H / TH) * (d->W / TW) * (d->N / ((d->N % 128 == 0) ? 128 : 64));
+    return wg < (1ll << 31);
+}
+
+}  // namespace
+
+extern "C" int rih_conv3x3_ok(const rih_conv3_desc* d) { return c3_ok(d) ? 1 : 0; }
+
+/* rows of the output per BatchNorm statistics block (rih_bn_stats_from_blocks' rows_per_block); the blocks are 64-row pieces of
+ * the 8 x 32 pixel patches, not of consecutive rows -- the merge only needs their row counts, and every block is full */
+extern "C" int rih_conv3x3_stats_rows(void) { return 64; }
+
+extern "C" int rih_conv3x3(const rih_conv3_desc* d, void* stream) {
+    if (!c3_ok(d)) return RIH_EINVAL;
+    C3Args a;
+    a.x = d->x; a.w = (const unsigned char*)d->w_h2; a.y = d->y; a.stats = d->stats; a.amax_x = d->amax_x; a.amax_w = d->amax_w;
+    a.imgs = d->imgs; a.H = d->H; a.W = d->W; a.C = d->C; a.N = d->N; a.ldx = d->ldx; a.ldy = d->ldy; a.Kp = d->Kpad;
+    a.relu = d->relu ? 1 : 0;
+    a.tiles_x = d->W / TW; a.tiles_y = d->H / TH;
+    const int bn = (d->N % 128 == 0) ? 128 : 64;
+    a.nblk = d->N / bn;
+    const unsigned grid = (unsigned)((long long)d->imgs * a.tiles_x * a.tiles_y * a.nblk);
+    hipStream_t s = (hipStream_t)stream;
+    if (bn == 128) {
+        if (d->stats) hipLaunchKernelGGL((conv3x3_halo_kernel<128, true>), dim3(grid), dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<128, false>), dim3(grid), dim3(NT), 0, s, a);
+    } else {
+        if (d->stats) hipLaunchKernelGGL((conv3x3_halo_kernel<64, true>), dim3(grid), dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<64, false>), dim3(grid), dim3(NT), 0, s, a);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int rih_h2_multi(const rih_h2_desc* descs, int n, void* stream) {
+    if (n < 0 || (n > 0 && !descs)) return RIH_EINVAL;
+    for (int i0 = 0; i0 < n; i0 += H2_PACK) {
+        H2Pack pk;
+        pk.n = (n - i0 < H2_PACK) ? n - i0 : H2_PACK;
+        int total = 0;
+        for (int i = 0; i < pk.n; ++i) {
+            const int rc = h2_args(pk.d[i], descs[i0 + i]);
+            if (rc != RIH_OK) return rc;
+            const long long units = (long long)pk.d[i].N * (pk.d[i].Kp / 8);
+            long long nb = (units + 255) / 256;
+            if (nb > 512) nb = 512;
+            pk.first[i] = total;
+            total += (int)nb;
+        }
+        pk.first[pk.n] = total;
+        hipLaunchKernelGGL(h2_weight_multi_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, pk);
+    }
+    return (int)hipGetLastError();
+}

@@ -2015,6 +2015,8 @@ extern "C" int rih_abi_sizes(int32_t* out9) {      // RIH_ABI_NSIZES values
     out9[7] = (int32_t)sizeof(rih_adam_entry);
     out9[8] = (int32_t)sizeof(rih_absmax_desc);
     out9[9] = (int32_t)sizeof(rih_presplit_desc);
+    out9[10] = (int32_t)sizeof(rih_conv3_desc);
+    out9[11] = (int32_t)sizeof(rih_h2_desc);
     return 0;
 }
 extern "C" const char* rih_arch(void) { return "gfx950"; }

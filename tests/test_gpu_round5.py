@@ -35,7 +35,7 @@ def _graph():
 @pytest.mark.parametrize('bn_mode', ['train', 'frozen'])
 def test_captured_step_follows_the_data_magnitude(bn_mode, monkeypatch):
     """TrainStep captured on batch A (engine 2: every GEMM's power-of-two operand scales come from bound blocks written by
-    kernels INSIDE the graph) and replayed on A, 1000 A, A / 1000 and A with one pixel at 1e4: outputs and every parameter
+    kernels INSIDE the graph) and replayed on A, 1000 A, A / 1000 (A / 100 with batch statistics) and A with one pixel at 1e4: outputs and every parameter
     gradient of each replay against an eager engine-0 (native f32 MFMA) run of the same model on the same data, inside the
     suite's fp64-anchored bands (testing.assert_fp32_equivalent k = 4 + 2e-5 for outputs, _grad_report's 6x band for
     gradients with at most 1 % of the tensors outside, the allowance of the second family's B = 2 test: a dry run of this test on
@@ -54,7 +54,11 @@ def test_captured_step_follows_the_data_magnitude(bn_mode, monkeypatch):
     A = testing.seeded_image(2, 51)
     spike = A.clone()
     spike[0, 1, 100, 37] = 1e4
-    variants = [('A', A), ('1e3 A', 1e3 * A), ('1e-3 A', 1e-3 * A), ('A + one 1e4 pixel', spike)]
+    # (train mode: A / 100, not A / 1000 -- at A / 1000 the stem's batch variance (2e-6) drops below BatchNorm's eps (1e-5), the
+    # backward through that BatchNorm amplifies round-off ~300-fold and even the exact-fp32 engine's gradients are 3 % from fp64:
+    # a degenerate operating point that says nothing about operand scales.  With frozen statistics the full 1e-3 is used.)
+    small = 1e-2 if training else 1e-3
+    variants = [('A', A), ('1e3 A', 1e3 * A), ('%g A' % small, small * A), ('A + one 1e4 pixel', spike)]
     m2, sd = _build(0.0, seed=13)
     m2.train(training)
     m2.decoder.unsample_layer.weight.requires_grad_(False)

@@ -7,7 +7,7 @@ O=gpurun_out/r5c1; mkdir -p $O
 run() { n=$1; shift; echo "== $n: $*"; ( time timeout ${T:-600} "$@" ) > $O/$n.log 2>&1; echo "   exit $?"; grep '^{' $O/$n.log | tail -1 | cut -c1-400; }
 T=1500 run pytest_r5 python -m pytest tests/test_gpu_round5.py -q -s -x
 grep -n "passed\|failed\|replay on\|gradient tensors\|configs\[0\]\|outside\|worst" $O/pytest_r5.log | cut -c1-260 | tail -60
-T=900 run pytest_grads python -m pytest tests/test_gpu_model.py -q -s -k "matches_fp64_oracle or train_matches_reference_golden"
+T=900 run pytest_grads python -m pytest tests/test_gpu_model.py -q -s -k "hrnet_matches_fp64_oracle"
 grep -n "passed\|failed\|_grad_report\|outside the" $O/pytest_grads.log | cut -c1-260 | tail -80
 run bench_base python bench.py --no-cpu-baseline --no-reference-loop
 run hr_plain python bench.py --encoder hrnet32 --no-cpu-baseline --no-reference-loop --no-roofline

@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Diagnostic (round 5): are the replays of a captured HRNet-W32 step bit-identical?  tests/test_gpu_round5.py::
+test_hrnet_side_streams_survive_the_gradient_exchange saw replay 1 differ from replay 0 with three side streams and the RCCL
+exchange on.  Runs one configuration per process invocation: --exchange 0/1, --side N, --group G (ops.GROUP_WGRAD), --reps R;
+prints, per replay pair, how many gradient tensors differ, the largest relative difference and the first names."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--exchange', type=int, default=1)
+    ap.add_argument('--side', type=int, default=3)
+    ap.add_argument('--group', type=int, default=2)
+    ap.add_argument('--reps', type=int, default=6)
+    ap.add_argument('--encoder', default='hrnet32')
+    a = ap.parse_args()
+    torch.cuda.set_device(0)
+    if a.exchange:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29543')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    from oracle.net_oracle import scalar_loss
+    from renderih_amd import testing, streams, ops
+    from renderih_amd.model import build_model
+    from renderih_amd.train import TrainStep
+    streams.SIDE = a.side
+    ops.GROUP_WGRAD = a.group
+    m = build_model(0.0, a.encoder)
+    m.load_state_dict(testing.deterministic_state(m.state_dict(), seed=5))
+    m = m.cuda().train()
+    m.decoder.unsample_layer.weight.requires_grad_(False)
+    img = testing.seeded_image(2, 17).cuda()
+    opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.0)
+    step = TrainStep(m, opt, lambda out, lab: scalar_loss(out), (img.clone(), {}), force_exchange=bool(a.exchange),
+                     process_group=None if a.exchange else False)
+    print('config: exchange %d side %d group %d; use_graph %s stages %d side_limit %s' %
+          (a.exchange, a.side, a.group, step.use_graph, step.nstage, step.side_limit), flush=True)
+    first, losses = None, []
+    for rep in range(a.reps):
+        loss = step(img, {})
+        torch.cuda.synchronize()
+        losses.append(float(loss))
+        got = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        if first is None:
+            first = got
+            continue
+        bad = []
+        for k in first:
+            if not torch.equal(got[k], first[k]):
+                d = float((got[k] - first[k]).abs().max()) / max(float(first[k].abs().max()), 1e-30)
+                bad.append((d, k))
+        print('replay %d vs 0: %d of %d tensors differ%s' % (rep, len(bad), len(first),
+              ('; largest relative %.3g; first in parameter order: %s; largest: %s' %
+               (max(bad)[0], ', '.join(k for _, k in bad[:4]), max(bad)[1])) if bad else ''), flush=True)
+    print('losses', ' '.join('%.9g' % v for v in losses))
+    if a.exchange:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
