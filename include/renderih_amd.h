@@ -270,10 +270,11 @@ int rih_presplit_multi(const rih_presplit_desc* descs, int n, void* stream);
  * ("H2": dst[n][k / 8][plane][8 halves], k = (tap, channel), written once per training step by rih_h2_multi) through LDS-DMA.
  *   y[img][i][j][n] = act(sum_{kh,kw,c} x[img][i+kh-1][j+kw-1][c] * W(n, (kh*3+kw)*C + c))        (zero padding)
  * Forward: W from rih_h2_desc.for_dgrad 0 (n = co).  Data gradient: x = dy, C = Cout, N = CinPad, for_dgrad 1 (flipped taps).
- * Preconditions (rih_conv3x3_ok returns 1): C % 32 == 0, N % 64 == 0, H % 8 == 0, W % 32 == 0, Kpad == 9 * C, 16-byte aligned
- * x / w_h2 / y / stats, ldx / ldy % 4 == 0, one image below 2 GiB.  amax_x / amax_w: bound blocks (rih_absmax) -- amax_w must be
- * the block the H2 planes were scaled with.  stats (optional): [imgs * H * W / 64][2][N] (mean, M2) per 64-row block, the format
- * of rih_gemm_desc.stats with rows_per_block = rih_conv3x3_stats_rows() = 64 (a block is a quarter of a patch, every block full).
+ * Preconditions (rih_conv3x3_ok returns 1): C % 32 == 0, N % 32 == 0, (H % 8 == 0 and W % 32 == 0: patches of 8 x 32 pixels) or
+ * (H % 16 == 0 and W % 16 == 0: 16 x 16), Kpad == 9 * C, 16-byte aligned x / w_h2 / y / stats, ldx / ldy % 4 == 0, one image
+ * below 2 GiB.  amax_x / amax_w: bound blocks (rih_absmax) -- amax_w must be the block the H2 planes were scaled with.  stats
+ * (optional): [imgs * H * W / rows][2][N] (mean, M2) per block of rows = rih_conv3x3_stats_rows(desc) output rows (64; 32 when
+ * N is not a multiple of 64), the format of rih_gemm_desc.stats (a block is a piece of a patch, every block full).
  * Not bit-identical to rih_gemm on the same convolution: the reduction runs chunk-major, (c / 32, tap, c % 32). */
 typedef struct rih_conv3_desc {
     const float* x;         /* NHWC [imgs][H][W][ldx] */
@@ -285,7 +286,7 @@ typedef struct rih_conv3_desc {
     int32_t imgs, H, W, C, N, ldx, ldy, Kpad, relu;
 } rih_conv3_desc;
 int rih_conv3x3_ok(const rih_conv3_desc* d);
-int rih_conv3x3_stats_rows(void);
+int rih_conv3x3_stats_rows(const rih_conv3_desc* d);
 int rih_conv3x3(const rih_conv3_desc* d, void* stream);
 typedef struct rih_h2_desc {
     const float* w;         /* OIHW parameter */

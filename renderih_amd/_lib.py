@@ -140,7 +140,7 @@ SIGNATURES = {
     'rih_presplit_conv_weight': (c_i, [c_f, c_f] + [c_i] * 12 + [c_f, C.c_void_p]),
     'rih_presplit_multi': (c_i, [C.POINTER(PresplitDesc), c_i, C.c_void_p]),
     'rih_conv3x3_ok': (c_i, [C.POINTER(Conv3Desc)]),
-    'rih_conv3x3_stats_rows': (c_i, []),
+    'rih_conv3x3_stats_rows': (c_i, [C.POINTER(Conv3Desc)]),
     'rih_conv3x3': (c_i, [C.POINTER(Conv3Desc), C.c_void_p]),
     'rih_h2_multi': (c_i, [C.POINTER(H2Desc), c_i, C.c_void_p]),
     'rih_hardswish_fwd': (c_i, [c_f, c_f, c_l, C.c_void_p]),

@@ -16,15 +16,17 @@
 // acc0, lo*hi + hi*lo into acc1), result (acc0 + 2^-11 acc1) / (s_a s_b).  The summation ORDER over k differs from the tap-major
 // implicit GEMM (here chunk-major: (c / 32, tap, c % 32)), so results agree to fp32 round-off, not bitwise.
 //
-// Geometry: 512 threads = 8 wavefronts as 4 (M) x 2 (N); wave tile 64 x BN/2 (two image rows of 32 pixels x TN 32-column
-// blocks); BN = 128 or 64.  LDS: A 2 x 340 x 128 B = 85 KB, B 2 x BN x 128 B <= 32 KB: one workgroup (two waves per SIMD) per CU.
+// Geometry: 512 threads = 8 wavefronts; a patch is 256 pixels of one image -- 8 rows x 32 pixels (W % 32 == 0) or 16 x 16 (maps
+// whose width is a multiple of 16 only: the 16 x 16 maps of ResNet layer3 / HRNet branch 2) -- times BN = 128 / 64 / 32 output
+// channels: waves 4 (M) x 2 (N) with wave tile 64 x BN/2 for BN >= 64, waves 8 x 1 with wave tile 32 x 32 for BN = 32 (HRNet's
+// 32-channel branch).  LDS: A 2 x 340 x 128 B = 85 KB, B 2 x BN x 128 B <= 32 KB: one workgroup (two waves per SIMD) per CU.
 // LDS images: a pixel (or a weight row) is 8 units of 16 bytes -- unit j = (k / 8) * 2 + plane -- stored at position
-// j ^ ((index >> 1) & 7): the ds_read_b128 operand fetches (32 consecutive pixels of ONE image row, resp. 32 consecutive weight
-// rows, one unit index per half wave) touch 16 distinct bank groups per 16-lane group for every tap shift (checked exhaustively
-// by tests/test_kernels_on_cpu.py::test_conv3_lds_image_is_conflict_free).
+// j ^ ((halo column >> 1) & 7) (weights: j ^ ((row >> 1) & 7)): the ds_read_b128 operand fetches (32 consecutive pixels of one
+// image row, or 2 x 16 of two rows; 32 consecutive weight rows; one unit index per half wave) touch 16 distinct bank groups per
+// 16-lane group for every tap shift (checked exhaustively by tests/test_kernels_on_cpu.py::test_conv3_lds_image_is_conflict_free).
 //
-// Preconditions (rih_conv3x3_ok): C % 32 == 0, N % 64 == 0, H % 8 == 0, W % 32 == 0, 16-byte aligned operands, pitches % 4 == 0,
-// one image < 2 GiB.  Epilogue: optional ReLU, optional BatchNorm statistics per 64-row wave block ((mean, M2), the format of
+// Preconditions (rih_conv3x3_ok): C % 32 == 0, N % 32 == 0, (H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0),
+// 16-byte aligned operands, pitches % 4 == 0, one image < 2 GiB.  Epilogue: optional ReLU, optional BatchNorm statistics per 64-row wave block ((mean, M2), the format of
 // rih_gemm_desc.stats: rih_bn_stats_from_blocks merges them).  No bias / residual (no 3x3 convolution of the network has one
 // on the training path); callers with either use rih_gemm.
 #include <hip/hip_runtime.h>
@@ -37,8 +39,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int TH = 8, TW = 32, HW_ = TW + 2, HP = (TH + 2) * HW_;       // halo: 10 x 34 = 340 pixels
-constexpr int A_STAGE = HP * 128;                                        // bytes: 8 units of 16 B per pixel
+constexpr int A_STAGE = 340 * 128;                                       // bytes: the larger halo (10 x 34), 8 units of 16 B per pixel
 constexpr int NT = 512;
 constexpr unsigned OOB = 0x80000000u;
 constexpr int SLD = 36;                                                  // epilogue staging pitch (floats)
@@ -109,13 +110,16 @@ __device__ __forceinline__ float4 c3_bload4(__amdgpu_buffer_rsrc_t r, unsigned o
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int BN, bool STATS>
+template <int TW, int BN, bool STATS>
 __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
-    constexpr int TN = BN / 64;                         // 32-column blocks per wave (waves 4 x 2, wave tile 64 x BN / 2)
+    constexpr int TH = 256 / TW, HW_ = TW + 2, HP = (TH + 2) * HW_;     // patch 8 x 32 (halo 340 pixels) or 16 x 16 (324)
+    constexpr int WGN = BN >= 64 ? 2 : 1, WGM = 8 / WGN;                // waves 4 x 2, or 8 x 1 for 32 output channels
+    constexpr int TM = 8 / WGM;                                         // 32-row blocks per wave: 2 / 1
+    constexpr int TN = BN / (32 * WGN);                                 // 32-column blocks per wave: 2 / 1 / 1
     constexpr int B_STAGE = BN * 128;
     constexpr int NPA = (HP * 8 + NT - 1) / NT;         // float4 quads of a halo chunk per thread: 6 (the last pass partial)
-    constexpr int NPB = (BN * 8) / NT;                  // LDS-DMA units of a weight k-tile per thread: 2 (BN 128) / 1 (BN 64)
-    static_assert((BN * 8) % NT == 0, "whole LDS-DMA instructions");
+    constexpr int NPB = (BN * 8 + NT - 1) / NT;         // LDS-DMA units of a weight k-tile per thread: 2 / 1 / 1 (BN 32: waves 0-3 only)
+    static_assert((BN * 8) % 64 == 0 && HP * 128 <= A_STAGE, "whole wave instructions; the halo fits its stage");
     constexpr int SMEM = 2 * A_STAGE + 2 * B_STAGE;
     static_assert(SMEM >= 8 * 32 * SLD * 4, "epilogue staging fits");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
     unsigned char* const Bbuf = smem + 2 * A_STAGE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
 
     // workgroup -> (image, patch, channel block); channel blocks fastest so that workgroups sharing a halo are neighbours
     const int bid = xcd_remap_c3((int)blockIdx.x, (int)gridDim.x);
@@ -134,6 +138,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
     const int ty_t = rest % p.tiles_y;
     const int img = rest / p.tiles_y;
     const int y0 = ty_t * TH, x0 = tx_t * TW, n0 = nb * BN;
+    // 32-row MFMA block blk (0..7) of the patch, lane l31 -> pixel (ty, tx): one image row of 32, or two rows of 16
+    const int lty = (TW == 32) ? 0 : (l31 >> 4), ltx = l31 & (TW - 1);
 
     const float sa = c3_scale(p.amax_x), sb = c3_scale(p.amax_w);
 
@@ -155,18 +161,18 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
             if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
                 a_goff[i] = (unsigned)(((y * p.W + x) * p.ldx + 4 * cq) * 4);
-            a_lds[i] = hp * 128 + ((((cq >> 1) * 2) ^ ((hp >> 1) & 7)) << 4) + (cq & 1) * 8;
+            a_lds[i] = hp * 128 + ((((cq >> 1) * 2) ^ ((hx >> 1) & 7)) << 4) + (cq & 1) * 8;
         }
     }
     // B: unit U = pass * NT + tid -> weight row n = U / 8, LDS position U % 8 holds source unit j = pos ^ ((n >> 1) & 7)
     const unsigned char* b_src[NPB];
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
-        const int U = i * NT + tid;
+        const int U = (i * NT + tid) % (BN * 8);                                    // (BN 32: the idle upper half never issues)
         const int n = U >> 3, j = (U & 7) ^ ((n >> 1) & 7);
         b_src[i] = p.w + ((long long)(n0 + n) * (p.Kp >> 3)) * 32 + j * 16;         // + (k / 8) * 32 per k-tile
     }
-    // operand fetch: A pixel rows of this wave: image rows ty = 2 wm + i (i < 2), pixel tx = l31; B rows wn * BN/2 + jj * 32 + l31
+    // operand fetch: A pixel rows of this wave: blocks blk = wm * TM + i; B rows wn * (BN / WGN) + jj * 32 + l31
     int b_rd[2][2][TN];         // [k-step][plane][block]
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -174,10 +180,12 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
             for (int jj = 0; jj < TN; ++jj) {
-                const int n = wn * (BN / 2) + jj * 32 + l31;
+                const int n = wn * (BN / WGN) + jj * 32 + l31;
                 b_rd[s][pl][jj] = n * 128 + (((((2 * s + lhi) * 2) + pl) ^ ((n >> 1) & 7)) << 4);
             }
-    const int a_hp0 = (2 * wm) * HW_ + l31;             // halo pixel of (row 2 wm, pixel l31) at tap (0, 0)
+    // halo pixel of block 0 of this wave, lane l31, at tap (0, 0); block i adds i * BLKROWS * HW_
+    constexpr int BLKROWS = 32 / TW;                    // image rows per 32-row block: 1 / 2
+    const int a_hp0 = (wm * TM * BLKROWS + lty) * HW_ + ltx;
 
     float4 areg[NPA];
     auto load_A = [&](int c0) {                         // global -> registers: the halo of channels [c0, c0 + 32)
@@ -198,12 +206,14 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
     };
     auto issue_B = [&](int kofs, unsigned char* dst) {  // LDS-DMA: weight rows [n0, n0 + BN) x k [kofs, kofs + 32)
 #pragma unroll
-        for (int i = 0; i < NPB; ++i) c3_glds16(b_src[i] + (long long)(kofs >> 3) * 32, dst + (i * NT + tid) * 16);
+        for (int i = 0; i < NPB; ++i)
+            if ((i + 1) * NT <= BN * 8 || i * NT + tid < BN * 8)                    // (wave-uniform: BN * 8 is a multiple of 64)
+                c3_glds16(b_src[i] + (long long)(kofs >> 3) * 32, dst + (i * NT + tid) * 16);
     };
 
-    floatx16 acc[2][TN], acc1[2][TN];
+    floatx16 acc[TM][TN], acc1[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -232,11 +242,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
             const int hp_t = a_hp0 + kh * HW_ + kw;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                f16x8 av[2][2], bv[2][TN];
+                f16x8 av[2][TM], bv[2][TN];
+                const int sw = ((ltx + kw) >> 1) & 7;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int hp = hp_t + i * HW_;
-                    const int base = hp * 128, sw = (hp >> 1) & 7;
+                for (int i = 0; i < TM; ++i) {
+                    const int base = (hp_t + i * BLKROWS * HW_) * 128;
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl)
                         av[pl][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(
@@ -248,7 +258,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
                     for (int jj = 0; jj < TN; ++jj)
                         bv[pl][jj] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(Bs + b_rd[s][pl][jj]));
 #define RIH_C3_TERM(ACC_, PA_, PB_)                                                                               \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int jj = 0; jj < TN; ++jj) ACC_[i][jj] = \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int jj = 0; jj < TN; ++jj) ACC_[i][jj] = \
         __builtin_amdgcn_mfma_f32_32x32x16_f16(av[PA_][i], bv[PB_][jj], ACC_[i][jj], 0, 0, 0);
                 RIH_C3_TERM(acc1, 1, 0)
                 RIH_C3_TERM(acc, 0, 0)
@@ -273,9 +283,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
         }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int y = y0 + 2 * wm + i;
-        float* yrow = p.y + (((long long)img * p.H + y) * p.W + x0) * p.ldy + n0 + wn * (BN / 2);
+    for (int i = 0; i < TM; ++i) {
+        const int blk = wm * TM + i;                    // 32-row block of the patch: image row blk (TW 32) or rows 2 blk, 2 blk + 1
+        float* ypatch = p.y + (((long long)img * p.H + y0) * p.W + x0) * p.ldy + n0 + wn * (BN / WGN);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             if (i + j > 0) __builtin_amdgcn_wave_barrier();
@@ -287,10 +297,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int row = (lane >> 3) + 8 * q, c4 = (lane & 7) * 4;       // row = pixel tx of this image row
+                const int row = (lane >> 3) + 8 * q, c4 = (lane & 7) * 4;       // row of the 32-row block -> pixel (ty, tx)
+                const int ty = (TW == 32) ? blk : 2 * blk + (row >> 4), tx = row & (TW - 1);
                 float4 v = *reinterpret_cast<const float4*>(stg + row * SLD + c4);
                 if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *reinterpret_cast<float4*>(yrow + (long long)row * p.ldy + j * 32 + c4) = v;
+                *reinterpret_cast<float4*>(ypatch + ((long long)ty * p.W + tx) * p.ldy + j * 32 + c4) = v;
                 if (STATS) {
                     if (scnt[j] == 0.f) ssh[j] = v;
                     scnt[j] += 1.f;
@@ -302,9 +313,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
         }
     }
     if (STATS) {
-        // per column: (mean, centred sum of squares) of this wave's 64 rows; a lane holds 8 rows, the eight row-lanes merge
-        // pairwise with Chan's formula (store_tiles_wide of rih_gemm.hip); row block index = 4 * patch + wm
-        const long long rb = (((long long)img * p.tiles_y + ty_t) * p.tiles_x + tx_t) * 4 + wm;
+        // per column: (mean, centred sum of squares) of this wave's 32 TM rows; a lane holds 4 TM rows, the eight row-lanes merge
+        // pairwise with Chan's formula (store_tiles_wide of rih_gemm.hip); row block index = WGM * patch + wm
+        const long long rb = (((long long)img * p.tiles_y + ty_t) * p.tiles_x + tx_t) * WGM + wm;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float n = scnt[j];
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
                 n = nt;
             }
             if ((lane >> 3) == 0) {
-                const int nn = n0 + wn * (BN / 2) + j * 32 + (lane & 7) * 4;
+                const int nn = n0 + wn * (BN / WGN) + j * 32 + (lane & 7) * 4;
                 *reinterpret_cast<float4*>(p.stats + (rb * 2 + 0) * p.N + nn) = mean;
                 *reinterpret_cast<float4*>(p.stats + (rb * 2 + 1) * p.N + nn) = m2;
             }
@@ -404,24 +415,47 @@ int h2_args(H2WArgs& a, const rih_h2_desc& d) {
     return a.Kp < a.K ? RIH_EINVAL : RIH_OK;
 }
 
+// patch width: 32 when the map allows it (one image row per 32-row block), else 16 (two rows per block); 0: not a shape of this kernel
+int c3_tw(const rih_conv3_desc* d) {
+    if (d->H % 8 == 0 && d->W % 32 == 0) return 32;
+    if (d->H % 16 == 0 && d->W % 16 == 0) return 16;
+    return 0;
+}
+// output-channel block: the widest that divides N; 128 -> 64 when the 128-wide grid would leave CUs without a workgroup
+int c3_bn(const rih_conv3_desc* d, int tw) {
+    const long long patches = (long long)d->imgs * (d->H / (256 / tw)) * (d->W / tw);
+    if (d->N % 128 == 0 && patches * (d->N / 128) >= 256) return 128;
+    if (d->N % 64 == 0) return 64;
+    return 32;
+}
 bool c3_ok(const rih_conv3_desc* d) {
     if (!d || !d->x || !d->w_h2 || !d->y || !d->amax_x || !d->amax_w) return false;
-    if (d->imgs < 1 || d->H < TH || d->W < TW || d->H % TH != 0 || d->W % TW != 0) return false;
-    if (d->C < 32 || d->C % 32 != 0 || d->N < 64 || d->N % 64 != 0) return false;
+    if (d->imgs < 1 || d->H < 8 || d->W < 16 || c3_tw(d) == 0) return false;
+    if (d->C < 32 || d->C % 32 != 0 || d->N < 32 || d->N % 32 != 0) return false;
     if (d->ldx < d->C || d->ldx % 4 != 0 || d->ldy < d->N || d->ldy % 4 != 0 || d->Kpad != 9 * d->C) return false;
     if ((((uintptr_t)d->x | (uintptr_t)d->w_h2 | (uintptr_t)d->y | (uintptr_t)d->stats) % 16) != 0) return false;
     if ((long long)d->H * d->W * d->ldx * 4 >= (1ll << 31)) return false;
-    const long long wg = (long long)d->imgs * (d->H / TH) * (d->W / TW) * (d->N / ((d->N % 128 == 0) ? 128 : 64));
+    const long long wg = (long long)d->imgs * (d->H / 8) * (d->W / 16) * (d->N / 32);        // (an upper bound of the grid)
     return wg < (1ll << 31);
+}
+
+template <int TW, int BN>
+void c3_launch(const C3Args& a, unsigned grid, bool stats, hipStream_t s) {
+    if (stats) hipLaunchKernelGGL((conv3x3_halo_kernel<TW, BN, true>), dim3(grid), dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<TW, BN, false>), dim3(grid), dim3(NT), 0, s, a);
 }
 
 }  // namespace
 
 extern "C" int rih_conv3x3_ok(const rih_conv3_desc* d) { return c3_ok(d) ? 1 : 0; }
 
-/* rows of the output per BatchNorm statistics block (rih_bn_stats_from_blocks' rows_per_block); the blocks are 64-row pieces of
- * the 8 x 32 pixel patches, not of consecutive rows -- the merge only needs their row counts, and every block is full */
-extern "C" int rih_conv3x3_stats_rows(void) { return 64; }
+/* rows of the output per BatchNorm statistics block (rih_bn_stats_from_blocks' rows_per_block) for this descriptor: 64, or 32
+ * with 32-channel blocks; the blocks are pieces of the 256-pixel patches, not of consecutive rows -- the merge only needs
+ * their row counts, and every block is full.  0: not a shape of this kernel. */
+extern "C" int rih_conv3x3_stats_rows(const rih_conv3_desc* d) {
+    if (!c3_ok(d)) return 0;
+    return c3_bn(d, c3_tw(d)) >= 64 ? 64 : 32;
+}
 
 extern "C" int rih_conv3x3(const rih_conv3_desc* d, void* stream) {
     if (!c3_ok(d)) return RIH_EINVAL;
@@ -429,17 +463,20 @@ extern "C" int rih_conv3x3(const rih_conv3_desc* d, void* stream) {
     a.x = d->x; a.w = (const unsigned char*)d->w_h2; a.y = d->y; a.stats = d->stats; a.amax_x = d->amax_x; a.amax_w = d->amax_w;
     a.imgs = d->imgs; a.H = d->H; a.W = d->W; a.C = d->C; a.N = d->N; a.ldx = d->ldx; a.ldy = d->ldy; a.Kp = d->Kpad;
     a.relu = d->relu ? 1 : 0;
-    a.tiles_x = d->W / TW; a.tiles_y = d->H / TH;
-    const int bn = (d->N % 128 == 0) ? 128 : 64;
+    const int tw = c3_tw(d), bn = c3_bn(d, tw);
+    a.tiles_x = d->W / tw; a.tiles_y = d->H / (256 / tw);
     a.nblk = d->N / bn;
     const unsigned grid = (unsigned)((long long)d->imgs * a.tiles_x * a.tiles_y * a.nblk);
     hipStream_t s = (hipStream_t)stream;
-    if (bn == 128) {
-        if (d->stats) hipLaunchKernelGGL((conv3x3_halo_kernel<128, true>), dim3(grid), dim3(NT), 0, s, a);
-        else hipLaunchKernelGGL((conv3x3_halo_kernel<128, false>), dim3(grid), dim3(NT), 0, s, a);
+    const bool st = d->stats != nullptr;
+    if (tw == 32) {
+        if (bn == 128) c3_launch<32, 128>(a, grid, st, s);
+        else if (bn == 64) c3_launch<32, 64>(a, grid, st, s);
+        else c3_launch<32, 32>(a, grid, st, s);
     } else {
-        if (d->stats) hipLaunchKernelGGL((conv3x3_halo_kernel<64, true>), dim3(grid), dim3(NT), 0, s, a);
-        else hipLaunchKernelGGL((conv3x3_halo_kernel<64, false>), dim3(grid), dim3(NT), 0, s, a);
+        if (bn == 128) c3_launch<16, 128>(a, grid, st, s);
+        else if (bn == 64) c3_launch<16, 64>(a, grid, st, s);
+        else c3_launch<16, 32>(a, grid, st, s);
     }
     return (int)hipGetLastError();
 }

@@ -122,14 +122,22 @@ ENGINE = int(_os.environ.get('RIH_GEMM_ENGINE', '2'))
 # one cached from an earlier use, or a fresh rih_absmax pass.  A call site that has no bounds for both operands runs engine 1.
 class _BoundPool:
     """Zeroed bound blocks (_lib.BOUND_FLOATS floats each: rih_absmax in include/renderih_amd.h) carved out of chunks -- one
-    fill launch per 256 blocks; a chunk allocated while a stream captures is re-zeroed by every replay of the graph."""
+    fill launch per 256 blocks; a chunk allocated while a stream captures is re-zeroed by every replay of the graph.
+    Chunks are PER STREAM (round 5): a block is handed out on the stream whose next launch writes it (the producing BatchNorm /
+    rih_absmax kernel), so its zero fill must be ordered before that launch -- which stream order gives only if the fill ran on
+    the SAME stream.  One chunk shared by all streams had its fill on whichever stream happened to exhaust the previous chunk
+    (inside a streams.fork_join side branch, say) with nothing ordering it against the other branches: a bound published early
+    could be zeroed afterwards, the consuming GEMM then scaled by 1 instead of 2^k -- finite but differently rounded results that
+    changed from replay to replay (seen on the captured HRNet-W32 step with three side streams, profiles/r05/ab/c1_pytest_r5.log)
+    and an fp16 overflow waiting to happen on large activations."""
     CHUNK = 256
 
     def __init__(self):
         self.chunk = {}
 
     def slot(self, device):
-        key = (device.type, device.index)
+        stream = torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0
+        key = (device.type, device.index, stream)
         ent = self.chunk.get(key)
         if ent is None or ent[1] >= self.CHUNK:
             ent = self.chunk[key] = [torch.zeros((self.CHUNK * _lib.BOUND_FLOATS,), device=device, dtype=torch.float32), 0]
@@ -910,8 +918,11 @@ class PackCache:
         self.fresh = False
 
     def refresh(self):
-        packs = [e for e in self.entries.values() if e[2][0] != 'presplit']
+        packs = [e for e in self.entries.values() if e[2][0] not in ('presplit', 'h2')]
         pres = [e for e in self.entries.values() if e[2][0] == 'presplit']
+        h2 = [e for e in self.entries.values() if e[2][0] == 'h2']
+        if h2:          # H2 weight operands of the halo-resident 3x3 convolutions (rih_conv3x3): one launch per 48
+            _h2_launch([(w, dst, f[1:]) for w, dst, f in h2])
         if packs:
             from ._lib import PackDesc
             arr = (PackDesc * len(packs))()
@@ -966,6 +977,89 @@ def _packed_weight(w, Cx, for_dgrad, sub=None, out=None):
     return dst
 
 
+# --------------------------------------------------------------------------------------------- halo-resident 3x3 convolution
+# csrc/rih_conv3.hip (round 5): stride-1 3x3 convolutions -- forward and data gradient -- on engine 2's arithmetic with the input
+# halo of an 8 x 32 pixel patch loaded and converted ONCE per 32-channel chunk and the weights as pre-split fp16 planes ("H2",
+# one rih_h2_multi launch per step through ops._PACK) staged by LDS-DMA.  RIH_HALO3=0: the tap-by-tap implicit GEMM (rih_gemm).
+HALO3 = os.environ.get('RIH_HALO3', '1') == '1'
+
+
+def _h2_launch(items):
+    """items: [(weight, planes tensor, (Cout, Cin, KH, KW, CinPad, for_dgrad, Kpad)), ...] -> rih_h2_multi."""
+    from ._lib import H2Desc
+    arr = (H2Desc * len(items))()
+    for d, (w, dst, f) in zip(arr, items):
+        d.w, d.dst, d.amax = w.data_ptr(), dst.data_ptr(), bound_of(w).data_ptr()
+        (d.Cout, d.Cin, d.KH, d.KW, d.CinPad, d.for_dgrad, d.Kpad) = f
+    check(_L().rih_h2_multi(arr, len(items), _stream()), 'rih_h2_multi')
+
+
+def _h2_weight(w, Cx, for_dgrad):
+    """H2 planes ([N][Kpad / 8][2][8] fp16 as a float32 tensor [N][Kpad]) of an OIHW weight: forward operand (N = Cout,
+    k = (tap, ci < Cx)) or flipped data-gradient operand (N = Cx, k = (tap, co)); scaled by bound_of(w).  Through ops._PACK when
+    one is installed (TrainStep: every H2 operand of the step in one launch at its start)."""
+    Cout, Cin, KH, KW = w.shape
+    K = KH * KW * (Cx if not for_dgrad else Cout)
+    Nn = Cout if not for_dgrad else Cx
+    Kp = _cdiv(K, 32) * 32
+    f = (Cout, Cin, KH, KW, Cx, 1 if for_dgrad else 0, Kp)
+    pc = _PACK
+    if pc is not None:
+        key = ('h2', w.data_ptr()) + f
+        e = pc.entries.get(key)
+        if e is not None and pc.fresh:
+            return e[1], Kp
+        if e is None:
+            planes = torch.empty((Nn, Kp), device=w.device, dtype=torch.float32)
+            pc.entries[key] = (w, planes, ('h2',) + f)
+        else:
+            planes = e[1]
+    else:
+        planes = torch.empty((Nn, Kp), device=w.device, dtype=torch.float32)
+    _h2_launch([(w, planes, f)])
+    return planes, Kp
+
+
+def _halo3_ok(x, Cch, Nout, KH, KW, stride, pad, bias=None, residual=None):
+    """Shapes rih_conv3x3 takes (csrc/rih_conv3.hip): engine 2, 3x3 / 1 / 1, no bias or residual, 8 x 32 or 16 x 16 pixel patches,
+    whole 32-channel chunks, 32-column blocks; the kernel itself re-checks (rih_conv3x3_ok)."""
+    if not (HALO3 and ENGINE == 2) or KH != 3 or KW != 3 or stride != 1 or pad != 1 or bias is not None or residual is not None:
+        return False
+    N, H, W_, Cx = x.shape
+    return (Cx == Cch and Cch % 32 == 0 and Nout % 32 == 0 and ((H % 8 == 0 and W_ % 32 == 0) or (H % 16 == 0 and W_ % 16 == 0))
+            and x.is_contiguous() and x.data_ptr() % 16 == 0 and 4 * H * W_ * Cx < (1 << 31))
+
+
+def conv3x3_halo(x, w, y, for_dgrad, relu=False, stats=None, bx=None, bw=None):
+    """Enqueue rih_conv3x3: y = act(conv3x3(x, w)) (for_dgrad False; x [N,H,W,Cin], y [N,H,W,Cout]) or the data gradient
+    y = conv3x3(x = dy, flipped w) (for_dgrad True; x [N,H,W,Cout], y [N,H,W,Cin]).  stats: a StatsHolder, filled.  bx / bw: bound
+    thunks (LazyBound) of x and w."""
+    from ._lib import Conv3Desc
+    N, H, W_, Cch = x.shape
+    Nout = y.shape[-1]
+    planes, Kp = _h2_weight(w, (Cch if not for_dgrad else Nout), for_dgrad)
+    d = Conv3Desc()
+    d.x, d.w_h2, d.y = x.data_ptr(), planes.data_ptr(), y.data_ptr()
+    d.amax_x = (bx() if callable(bx) else bx).data_ptr()
+    d.amax_w = (bw() if callable(bw) else bw).data_ptr()
+    d.imgs, d.H, d.W, d.C, d.N, d.ldx, d.ldy, d.Kpad, d.relu = N, H, W_, Cch, Nout, Cch, Nout, Kp, 1 if relu else 0
+    if stats is not None and stats.part is None:
+        stats.rows = int(_L().rih_conv3x3_stats_rows(C.byref(d)))
+        assert stats.rows > 0
+        stats.T = (N * H * W_) // stats.rows
+        stats.part = torch.empty((stats.T, 2, Nout), device=x.device, dtype=torch.float32)
+        d.stats = stats.part.data_ptr()
+    flops = 2.0 * N * H * W_ * Nout * 9 * Cch
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_L().rih_conv3x3(C.byref(d), _stream()), 'rih_conv3x3')
+        e1.record()
+        PROFILE.append((flops, e0, e1, (N * H * W_, Nout, 9 * Cch, 1, 0, 3, 50, 1, 2)))
+        return
+    check(_L().rih_conv3x3(C.byref(d), _stream()), 'rih_conv3x3')
+
+
 class Conv2dFn(torch.autograd.Function):
     """NHWC conv2d (+bias, +ReLU epilogue) = implicit GEMM on the fp32 MFMA pipe.
     x: [N,H,W,Cx] (Cx >= Cin, extra channels must be zero), w: [Cout,Cin,KH,KW] (the nn.Conv2d parameter)."""
@@ -987,7 +1081,9 @@ class Conv2dFn(torch.autograd.Function):
         geom = (H, W_, Cx, Ho, Wo, KH, KW, stride, 1, pad, pad)
         # engine 2: operand bounds (kept for the backward: x is the weight gradient's A operand, w the data gradient's B)
         bx, bw = (LazyBound(x), LazyBound(w)) if ENGINE == 2 else (None, None)
-        if _presplit_ok(Cout, Cx, KH * KW, abytes=4 * x.numel()):
+        if Cx == Cin and _halo3_ok(x, Cx, Cout, KH, KW, stride, pad, bias):
+            conv3x3_halo(x, w, y, False, relu=relu, stats=stats, bx=bx, bw=bw)
+        elif _presplit_ok(Cout, Cx, KH * KW, abytes=4 * x.numel()):
             wp, Kp = _presplit_weight(w, Cx, False)
             if PRESPLIT_ACT:
                 gemm(_presplit_act(N * H * W_, Cx, x), wp, y, M, Cout, K, Cx, Kp, Cout, a_mode=2, b_mode=2, bias=bias,
@@ -1074,7 +1170,9 @@ class Conv2dFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             Mx = N * H * W_
             geom = (Ho, Wo, Cout, H, W_, KH, KW, 1, stride, KH - 1 - pad, KW - 1 - pad)
-            if _presplit_ok(Cx, Cout, KH * KW, abytes=4 * dy.numel()):
+            if Cx == Cin and ctx.bnfold is None and _halo3_ok(dy, Cout, Cx, KH, KW, stride, pad, None, dskip):
+                conv3x3_halo(dy, w, dx, True, bx=bdy, bw=bw)
+            elif _presplit_ok(Cx, Cout, KH * KW, abytes=4 * dy.numel()):
                 wd, Kp = _presplit_weight(w, Cx, True)
                 if PRESPLIT_ACT:
                     gemm(_presplit_act(M, Cout, dy), wd, dx, Mx, Cx, KH * KW * Cout, Cout, Kp, Cx, a_mode=2, b_mode=2,

@@ -427,6 +427,93 @@ class EmulatedLib:
             Bkn = sel.transpose(2, 3, 0, 1).reshape(Th * Tw * Cout, CinPad)            # k = ((th, tw), co), n = ci
         return self._presplit_store(Bkn, dst, Kpad, amax_e2)
 
+    # ------------------------------------------------------------------ halo-resident 3x3 convolution (csrc/rih_conv3.hip)
+    def rih_h2_multi(self, descs, n, stream):
+        """OIHW weight -> H2 planes dst[n][k / 8][plane][8 halves] (hi = fp16(s w), lo = fp16((s w - hi) 2^11))."""
+        for i in range(n):
+            d = descs[i]
+            if not (d.w and d.dst and d.amax) or d.Kpad % 32 != 0 or d.CinPad < d.Cin:
+                return -1
+            W = _f(d.w, d.Cout * d.Cin * d.KH * d.KW).reshape(d.Cout, d.Cin, d.KH, d.KW)
+            Wp = np.zeros((d.Cout, d.CinPad, d.KH, d.KW), np.float32)
+            Wp[:, :d.Cin] = W
+            if not d.for_dgrad:
+                Bnk = Wp.transpose(0, 2, 3, 1).reshape(d.Cout, d.KH * d.KW * d.CinPad)           # n = co, k = (tap, ci)
+            else:
+                Bnk = Wp[:, :, ::-1, ::-1].transpose(1, 2, 3, 0).reshape(d.CinPad, d.KH * d.KW * d.Cout)   # n = ci, k = (flipped tap, co)
+            N, K = Bnk.shape
+            if d.Kpad < K:
+                return -1
+            x = np.zeros((N, d.Kpad), np.float32)
+            x[:, :K] = Bnk
+            xs = x * self._e2_scale(d.amax)
+            hi = xs.astype(np.float16)
+            lo = ((xs - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+            out = np.ctypeslib.as_array((C.c_uint16 * (2 * N * d.Kpad)).from_address(int(d.dst))).reshape(N, d.Kpad // 8, 2, 8)
+            out[:, :, 0, :] = hi.view(np.uint16).reshape(N, d.Kpad // 8, 8)
+            out[:, :, 1, :] = lo.view(np.uint16).reshape(N, d.Kpad // 8, 8)
+        return 0
+
+    @staticmethod
+    def _conv3_ok(d):
+        return bool(d.x and d.w_h2 and d.y and d.amax_x and d.amax_w and d.imgs >= 1
+                    and ((d.H % 8 == 0 and d.W % 32 == 0) or (d.H % 16 == 0 and d.W % 16 == 0)) and d.H >= 8 and d.W >= 16
+                    and d.C >= 32 and d.C % 32 == 0 and d.N >= 32 and d.N % 32 == 0 and d.ldx >= d.C
+                    and d.ldx % 4 == 0 and d.ldy >= d.N and d.ldy % 4 == 0 and d.Kpad == 9 * d.C
+                    and d.x % 16 == 0 and d.w_h2 % 16 == 0 and d.y % 16 == 0 and (not d.stats or d.stats % 16 == 0))
+
+    def rih_conv3x3_ok(self, dref):
+        return 1 if self._conv3_ok(dref._obj if hasattr(dref, '_obj') else dref) else 0
+
+    @staticmethod
+    def _conv3_geom(d):
+        """(patch rows, patch width, channel block) as csrc/rih_conv3.hip chooses them."""
+        tw = 32 if (d.H % 8 == 0 and d.W % 32 == 0) else 16
+        patches = d.imgs * (d.H // (256 // tw)) * (d.W // tw)
+        bn = 128 if (d.N % 128 == 0 and patches * (d.N // 128) >= 256) else 64 if d.N % 64 == 0 else 32
+        return 256 // tw, tw, bn
+
+    def rih_conv3x3_stats_rows(self, dref):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        if not self._conv3_ok(d):
+            return 0
+        return 64 if self._conv3_geom(d)[2] >= 64 else 32
+
+    def rih_conv3x3(self, dref, stream):
+        d = dref._obj
+        if not self._conv3_ok(d):
+            return -1
+        sw = self._e2_scale(d.amax_w)
+        pl = np.ctypeslib.as_array((C.c_uint16 * (2 * d.N * d.Kpad)).from_address(int(d.w_h2))).reshape(d.N, d.Kpad // 8, 2, 8)
+        hi = pl[:, :, 0, :].reshape(d.N, d.Kpad).view(np.float16).astype(np.float32)
+        lo = pl[:, :, 1, :].reshape(d.N, d.Kpad).view(np.float16).astype(np.float32)
+        Wnk = ((hi + lo * np.float32(2.0 ** -11)) / sw).astype(np.float32)           # [N][(tap, c)]
+        x = np.lib.stride_tricks.as_strided(_f(d.x, ((d.imgs * d.H * d.W) - 1) * d.ldx + d.C), (d.imgs, d.H, d.W, d.C),
+                                            (4 * d.H * d.W * d.ldx, 4 * d.W * d.ldx, 4 * d.ldx, 4))
+        xp = np.zeros((d.imgs, d.H + 2, d.W + 2, d.C), np.float32)
+        xp[:, 1:-1, 1:-1] = x
+        y = np.zeros((d.imgs, d.H, d.W, d.N), np.float32)
+        for kh in range(3):
+            for kw in range(3):
+                t = kh * 3 + kw
+                y += xp[:, kh:kh + d.H, kw:kw + d.W].reshape(-1, d.C).dot(Wnk[:, t * d.C:(t + 1) * d.C].T).reshape(y.shape)
+        if d.relu:
+            y = np.maximum(y, 0)
+        out = np.lib.stride_tricks.as_strided(_f(d.y, ((d.imgs * d.H * d.W) - 1) * d.ldy + d.N), (d.imgs, d.H, d.W, d.N),
+                                              (4 * d.H * d.W * d.ldy, 4 * d.W * d.ldy, 4 * d.ldy, 4))
+        out[...] = y
+        if d.stats:
+            # blocks = consecutive runs of `rows` pixels of a patch in patch-row-major order: block ((img, ty, tx), wm)
+            th, tw, bn = self._conv3_geom(d)
+            rows = 64 if bn >= 64 else 32
+            T = d.imgs * d.H * d.W // rows
+            st = _f(d.stats, T * 2 * d.N).reshape(T, 2, d.N)
+            blk = y.reshape(d.imgs, d.H // th, th, d.W // tw, tw, d.N).transpose(0, 1, 3, 2, 4, 5).reshape(T, rows, d.N)
+            m = blk.astype(np.float64).mean(1)
+            st[:, 0] = m
+            st[:, 1] = ((blk - m[:, None]) ** 2).sum(1)
+        return 0
+
     def rih_splitk_reduce(self, P, S, M, N, dst, Cin, taps, CinValid, accumulate, stream):
         return self.rih_splitk_reduce_bias(P, S, M, M, N, dst, Cin, taps, CinValid, accumulate, 0, stream)
 

@@ -142,6 +142,15 @@ def test_paired_decoder_runs_with_dropout(monkeypatch):
     assert torch.isfinite(s) and all(torch.isfinite(p.grad).all() for p in dec.parameters() if p.grad is not None)
 
 
+def test_conv3x3_halo_host_logic():
+    """ops.conv3x3_halo / _h2_weight on the emulated ABI: descriptor fields, H2 operand for forward and data gradient, statistics
+    blocks in patch order, the fall-back for shapes the kernel does not take."""
+    G.test_conv3x3_halo((2, 16, 32, 64, 128, False, True))
+    G.test_conv3x3_halo((1, 8, 64, 32, 64, True, True))
+    G.test_conv3x3_halo((2, 16, 16, 64, 96, True, True))           # 16 x 16 patches, 32-channel blocks (32-row statistics blocks)
+    G.test_conv2d((2, 8, 8, 32, 32, 3, 1, 1, False, True))         # W = 8: not a whole 32-pixel patch -> rih_gemm
+
+
 def test_conv1x1_cat_host_logic():
     """ops.conv1x1_cat on the emulated ABI: segment descriptors, per-part data gradients, column-slice weight gradients."""
     for eng in (1, 2):

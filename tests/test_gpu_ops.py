@@ -138,6 +138,60 @@ def test_conv1x1_cat(case, engine, monkeypatch=None):
         ops.ENGINE = saved
 
 
+HALO_CASES = [(2, 16, 32, 64, 128, False, True), (1, 8, 64, 32, 64, True, True), (3, 8, 32, 96, 192, False, False),
+              (2, 64, 64, 128, 128, True, True), (1, 32, 32, 64, 64, False, True),
+              (2, 16, 16, 64, 128, True, True), (1, 32, 16, 32, 64, False, True),           # 16 x 16 patches (W % 32 != 0)
+              (2, 16, 32, 32, 32, False, True), (1, 16, 16, 64, 96, True, True),            # 32-channel blocks
+              (64, 16, 16, 32, 128, False, False)]                                        # 128-wide blocks on 16 x 16 patches
+
+
+@pytest.mark.parametrize('case', HALO_CASES)
+def test_conv3x3_halo(case, monkeypatch=None):
+    """csrc/rih_conv3.hip through ops.conv2d (ops.HALO3, engine 2): stride-1 3x3 convolution with the input halo resident in LDS
+    and pre-split (H2) weights -- output (+ ReLU), the BatchNorm statistics of its epilogue, the data gradient (the same kernel on
+    flipped weights) and the weight gradient (rih_gemm) against F.conv2d in fp64; and equal to the tap-by-tap implicit GEMM
+    (HALO3 off) to fp32 round-off.  (N, H, W, Cin, Cout, relu, stats)."""
+    from renderih_amd import ops
+    N, H, W, Cin, Cout, relu, want_stats = case
+    saved = (ops.ENGINE, ops.HALO3)
+    ops.ENGINE = 2
+    try:
+        x = rnd(N, Cin, H, W, seed=21) * 3.0
+        w = rnd(Cout, Cin, 3, 3, seed=22, scale=1.0 / math.sqrt(9 * Cin))
+        xr, wr = x.double().clone().requires_grad_(True), w.double().clone().requires_grad_(True)
+        yr = F.conv2d(xr, wr, padding=1)
+        if relu:
+            yr = F.relu(yr)
+        gy = rnd(*yr.shape, seed=23)
+        yr.backward(gy.double())
+        d = dev()
+        outs = {}
+        for halo in (True, False):
+            ops.HALO3 = halo
+            xg = nhwc(x).contiguous().to(d).requires_grad_(True)
+            wg = w.clone().to(d).requires_grad_(True)        # (a fresh leaf per pass: on the CPU harness .to() is the identity)
+            holder = ops.StatsHolder() if want_stats else None
+            yg = ops.conv2d(xg, wg, None, stride=1, pad=1, relu=relu, stats=holder)
+            yg.backward(nhwc(gy).contiguous().to(d))
+            outs[halo] = (nchw(yg).detach().cpu(), nchw(xg.grad).cpu(), wg.grad.cpu())
+            assert_close(outs[halo][0], yr.float(), 1e-4, 1e-5, 'halo %s y %s' % (halo, case,))
+            assert_close(outs[halo][1], xr.grad.float(), 1e-4, 2e-5, 'halo %s dx %s' % (halo, case,))
+            assert_close(outs[halo][2], wr.grad.float(), 1e-3, 1e-4, 'halo %s dw %s' % (halo, case,))
+            if halo and want_stats:
+                assert holder.part is not None and holder.rows in (32, 64) and holder.T == N * H * W // holder.rows
+                M = N * H * W
+                part = holder.part.double().cpu()
+                mean = part[:, 0].mean(0)
+                var = (part[:, 1] + float(holder.rows) * (part[:, 0] - mean) ** 2).sum(0) / M
+                y2 = nhwc(yr.detach()).reshape(M, Cout)
+                assert_close(mean, y2.mean(0), 1e-4, 1e-5, 'halo stats mean')
+                assert_close(var, y2.var(0, unbiased=False), 1e-3, 1e-5, 'halo stats var')
+        for a, b, what in zip(outs[True], outs[False], ('y', 'dx', 'dw')):
+            assert_close(a, b, 1e-4, 1e-5, 'halo vs implicit GEMM ' + what)
+    finally:
+        ops.ENGINE, ops.HALO3 = saved
+
+
 LIN_CASES = [(126, 512, 256, True, False, False), (126, 2048, 509, True, False, False), (100, 64, 3, True, False, False),
              (128, 252, 1, True, False, False), (6, 252, 778, False, False, False), (4032, 128, 128, True, True, True),
              (300, 256, 256, True, False, True), (8064, 64, 64, True, True, False)]

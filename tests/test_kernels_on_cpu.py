@@ -71,6 +71,38 @@ def test_conv1x1_cat_fallback_and_ungated_relu_kernels(case, engine):
     G.test_conv1x1_cat(case, engine)
 
 
+@pytest.mark.parametrize('case', [(1, 8, 32, 32, 64, False, True), (2, 8, 32, 64, 128, True, True), (1, 16, 64, 32, 64, True, False),
+                                  (1, 16, 16, 32, 64, True, True), (1, 16, 32, 32, 32, False, True), (2, 16, 16, 64, 96, True, True)])
+def test_conv3x3_halo_kernels(case):
+    """csrc/rih_conv3.hip on the host harness (LDS-DMA lands at the barrier that publishes it, 512 fibers per block): halo staging,
+    tap windows, H2 weight planes, statistics epilogue, data gradient."""
+    G.test_conv3x3_halo(case)
+
+
+def test_conv3_lds_image_is_conflict_free():
+    """The LDS images of csrc/rih_conv3.hip: a pixel / weight row = 8 units of 16 bytes at position j ^ ((index >> 1) & 7).  A
+    ds_read_b128 is served in 16-lane groups (MI355X_MICROARCH.md, LDS table); within a group every lane must hit its own 16-byte
+    bank group (64 banks x 4 B = 16 groups).  Checked for every tap shift of the A window (any halo origin) and for the weight
+    rows."""
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    for tw in (32, 16):                         # patch width; halo row pitch tw + 2; a 32-lane block = 32 / tw image rows
+        pitch = tw + 2
+        for row0 in range(0, 256 // tw, 32 // tw):
+            for kh in range(3):
+                for kw in range(3):
+                    for j in range(8):
+                        for g in groups:
+                            banks = set()
+                            for l in g:
+                                row, col = row0 + (0 if tw == 32 else l >> 4) + kh, (l & (tw - 1)) + kw
+                                banks.add(((row * pitch + col) * 8 + (j ^ ((col >> 1) & 7))) % 16)
+                            assert len(banks) == 16, (tw, row0, kh, kw, j)
+    for n0 in range(0, 128, 32):                # weight rows: position j ^ ((n >> 1) & 7)
+        for j in range(8):
+            for g in groups:
+                assert len({(((n0 + l) * 8 + (j ^ (((n0 + l) >> 1) & 7))) % 16) for l in g}) == 16
+
+
 def test_parameter_bounds_are_not_trusted_outside_an_owning_scope():
     """Round-4 advisor finding: engine 2 derives its fp16 operand scale from a cached bound of the weight; outside a model forward /
     TrainStep nothing invalidates that cache when the weight is rewritten behind torch's version counter (rih_adam_multi through

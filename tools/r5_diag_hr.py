@@ -39,19 +39,30 @@ def main():
     m.decoder.unsample_layer.weight.requires_grad_(False)
     img = testing.seeded_image(2, 17).cuda()
     opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.0)
-    step = TrainStep(m, opt, lambda out, lab: scalar_loss(out), (img.clone(), {}), force_exchange=bool(a.exchange),
+    holder = {}
+
+    def loss_fn(out, lab):
+        holder['out'] = out
+        return scalar_loss(out)
+    step = TrainStep(m, opt, loss_fn, (img.clone(), {}), force_exchange=bool(a.exchange),
                      process_group=None if a.exchange else False)
     print('config: exchange %d side %d group %d; use_graph %s stages %d side_limit %s' %
           (a.exchange, a.side, a.group, step.use_graph, step.nstage, step.side_limit), flush=True)
-    first, losses = None, []
+    first, losses, first_out = None, [], None
     for rep in range(a.reps):
         loss = step(img, {})
         torch.cuda.synchronize()
         losses.append(float(loss))
         got = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        outs = {k: v.detach().clone() for k, v in testing.flatten_outputs(holder['out']).items()}
         if first is None:
-            first = got
+            first, first_out = got, outs
             continue
+        obad = [(float((outs[k] - first_out[k]).abs().max()) / max(float(first_out[k].abs().max()), 1e-30), k)
+                for k in outs if not torch.equal(outs[k], first_out[k])]
+        if obad:
+            print('replay %d vs 0: OUTPUTS differ: %s' % (rep, ', '.join('%s %.3g' % (k, d) for d, k in sorted(obad, reverse=True)[:8])),
+                  flush=True)
         bad = []
         for k in first:
             if not torch.equal(got[k], first[k]):
