@@ -41,8 +41,21 @@ def main():
     opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.0)
     holder = {}
 
+    def terms_of(out):
+        """The addends of oracle.net_oracle.scalar_loss, one tensor each (same order)."""
+        result, params, hd, other = out
+        t = []
+        for side in ('left', 'right'):
+            t += [('v3d.' + side, result['verts3d'][side].abs().sum()), ('v2d.' + side, 1e-2 * result['verts2d'][side].abs().sum()),
+                  ('c3d.' + side, hd[0]['verts3d'][side].pow(2).sum()), ('c2d.' + side, 1e-4 * hd[0]['verts2d'][side].pow(2).sum()),
+                  ('scale.' + side, params['scale'][side].sum()), ('trans.' + side, params['trans2d'][side].pow(2).sum())]
+        t += [('hms', 1e-3 * other['hms'].pow(2).sum()), ('mask', 1e-3 * other['mask'].abs().sum()),
+              ('dense', 1e-3 * other['dense'].pow(2).sum())]
+        return t
+
     def loss_fn(out, lab):
         holder['out'] = out
+        holder['terms'] = terms_of(out)             # (extra nodes of the captured graph: they do not feed the loss)
         return scalar_loss(out)
     step = TrainStep(m, opt, loss_fn, (img.clone(), {}), force_exchange=bool(a.exchange),
                      process_group=None if a.exchange else False)
@@ -55,6 +68,14 @@ def main():
         losses.append(float(loss))
         got = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
         outs = {k: v.detach().clone() for k, v in testing.flatten_outputs(holder['out']).items()}
+        with torch.no_grad():
+            eager = float(scalar_loss(holder['out']))
+            et = terms_of(holder['out'])
+        torch.cuda.synchronize()
+        tdiff = ['%s graph %.9g eager %.9g' % (n, float(a), float(b)) for (n, a), (_, b) in zip(holder['terms'], et)
+                 if float(a) != float(b)]
+        print('replay %d: loss in graph %.9g, recomputed eagerly from the replay\'s outputs %.9g%s' %
+              (rep, float(loss), eager, ('; terms that differ: ' + '; '.join(tdiff)) if tdiff else ''), flush=True)
         if first is None:
             first, first_out = got, outs
             continue

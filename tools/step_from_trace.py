@@ -55,6 +55,27 @@ def main():
     print('GEMM kernels %.3f ms, everything else %.3f ms' % (g / 1e6, (busy - g) / 1e6))
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
         print('%8.3f ms %5d x %8.1f us  %s' % (v[1] / 1e6, v[0], v[1] / v[0] / 1e3, k))
+    if '--torch' in sys.argv:
+        # every launch of the step that is not a kernel of this package (torch element-wise glue, fills, copies), in launch
+        # order with its grid size and the package kernels before / after it: enough to find the line of Python that issued it
+        ours = ('gemm', 'bn_', 'flash', 'layernorm', 'cheby', 'dropout', 'relu_', 'splitk', 'absmax', 'pack_', 'mesh_loss',
+                'adam', 'conv3x3', 'h2_', 'maxpool', 'avgpool', 'upsample', 'nchw', 'nhwc', 'gather', 'scatter', 'project',
+                'add_', 'two_sum', 'colsum', 'ln_', 'nearest', 'softmax', 'presplit')
+        names = [short(r['Kernel_Name']) for r in step]
+        tot = 0
+        print('launches that are not kernels of this package:')
+        for i, r in enumerate(step):
+            n = names[i]
+            if n.startswith(ours):
+                continue
+            d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+            tot += d
+            prev = next((names[j] for j in range(i - 1, -1, -1) if names[j].startswith(ours)), '-')
+            nxt = next((names[j] for j in range(i + 1, len(step)) if names[j].startswith(ours)), '-')
+            print('  #%4d %6.1f us grid %8s wg %4s  %-58s  after %-28s before %s'
+                  % (i, d, r.get('Grid_Size_X', r.get('Grid_Size', '?')), r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?')),
+                     n[:58], prev[:28], nxt[:28]))
+        print('  total %.3f ms' % (tot / 1e3))
 
 
 if __name__ == '__main__':
