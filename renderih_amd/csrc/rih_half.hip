@@ -427,6 +427,203 @@ __global__ void havgpool_kernel(const half_t* __restrict__ x, float* __restrict_
 }
 
 inline int hgrid(long long n) { return (int)((n + 255) / 256 < 65535 * 16 ? (n + 255) / 256 : 65535 * 16); }
+
+// ------------------------------------------------------------------------------------------------ halo-resident 3x3 (round 5)
+// hconv3_halo_kernel: the stride-1 / pad-1 3x3 convolutions of the fp16 backbone with the input halo resident in LDS -- the
+// fp16 sibling of csrc/rih_conv3.hip.  A workgroup (512 threads, 8 wavefronts as 4 x 2, wave tile 64 x BN/2) owns a patch of 256
+// pixels of one image (8 x 32, or 16 x 16 where the width is a multiple of 16 only) and BN = 128 / 64 output channels; per
+// 64-channel chunk the (rows + 2) x (width + 2) halo (128 bytes per pixel) is fetched ONCE by LDS-DMA and the nine taps run on
+// shifted windows of it -- the implicit GEMM above fetches every pixel nine times per chunk (its 3x3 launches sat at 0.23-0.36 of
+// their rooflines, LDS-DMA bound at an occupancy of two: profiles/r04/c11_hconv_sweep.log).  Weights: the same [Cout][Kpad] fp16
+// operand (k = (tap, ci)), one 128-byte row segment per output channel and k-tile, LDS-DMA, double-buffered; one barrier per
+// k-tile.  LDS images: unit j (8 halves) of a pixel at position j ^ ((halo column >> 1) & 7), of a weight row at
+// j ^ ((row >> 1) & 7), applied on the SOURCE address (the LDS-DMA destination is lane-linear): conflict-free ds_read_b128
+// operand fetches for every tap shift (tests/test_kernels_on_cpu.py::test_conv3_lds_image_is_conflict_free).
+// Epilogue as hconv_kernel (bias, ReLU, post scale / shift, fp16 or fp32 output); no residual (no 3x3 convolution has one).
+// Preconditions (hconv3_ok): KH = KW = 3, stride 1, pad 1, Cin % 64 == 0, Cout % 64 == 0, (H % 8 == 0 and W % 32 == 0) or
+// (H % 16 == 0 and W % 16 == 0), no residual, 16-byte aligned output rows.
+constexpr int H3_NT = 512;
+constexpr int H3_ASTAGE = 2752 * 16;        // 340 pixels x 8 units, rounded up to whole wave instructions (43 x 64 units)
+
+template <int TW, int BN>
+__global__ __launch_bounds__(H3_NT, 2) void hconv3_halo_kernel(const HConvArgs p) {
+    constexpr int TH = 256 / TW, HWP = TW + 2, HP = (TH + 2) * HWP;
+    constexpr int TN = BN / 64;
+    constexpr int B_STAGE = BN * ROWB;
+    constexpr int NPA = (HP * 8 + H3_NT - 1) / H3_NT;       // 6: the last instruction of the last issuing wave lands in the padding
+    constexpr int NPB = (BN * 8) / H3_NT;                   // 2 / 1
+    static_assert(((HP * 8 + 63) / 64) * 64 * 16 <= H3_ASTAGE && (BN * 8) % H3_NT == 0, "stage sizes");
+    constexpr int SMEM = 2 * H3_ASTAGE + 2 * B_STAGE;
+    static_assert(SMEM >= 8 * 32 * STAGE_LD * 4, "epilogue staging fits");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    unsigned char* const Abuf = smem;
+    unsigned char* const Bbuf = smem + 2 * H3_ASTAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_x = p.W / TW, tiles_y = p.H / TH, nblk = p.Cout / BN;
+    const int bid = xcd_chunk(blockIdx.x, gridDim.x);
+    const int nb = bid % nblk;
+    int rest = bid / nblk;
+    const int tx_t = rest % tiles_x;
+    rest /= tiles_x;
+    const int ty_t = rest % tiles_y;
+    const int img = rest / tiles_y;
+    const int y0 = ty_t * TH, x0 = tx_t * TW, n0 = nb * BN;
+    const int lty = (TW == 32) ? 0 : (l31 >> 4), ltx = l31 & (TW - 1);
+
+    // A: LDS unit U = pass * NT + tid (halo pixel hp = U / 8, position U % 8) holds source unit j = pos ^ ((hx >> 1) & 7)
+    const half_t* a_src[NPA];
+    bool a_on[NPA];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        const int U = i * H3_NT + tid;
+        const int hp = U >> 3, pos = U & 7;
+        a_src[i] = p.zero;
+        a_on[i] = (i * H3_NT + (tid & ~63)) < HP * 8;       // wave-uniform: this wave's instruction starts inside the halo
+        if (hp < HP) {
+            const int hy = hp / HWP, hx = hp - hy * HWP;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+                a_src[i] = p.x + ((long long)(img * p.H + y) * p.W + x) * p.ldx + 8 * (pos ^ ((hx >> 1) & 7));
+        }
+    }
+    const half_t* b_src[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int U = i * H3_NT + tid;
+        const int n = U >> 3, j = (U & 7) ^ ((n >> 1) & 7);
+        b_src[i] = p.w + (long long)(n0 + n) * p.Kpad + 8 * j;
+    }
+    auto issue_A = [&](int c0, unsigned char* dst) {        // the halo of channels [c0, c0 + 64); padding lanes read the zero page
+#pragma unroll
+        for (int i = 0; i < NPA; ++i)
+            if (a_on[i]) glds16(pick(a_src[i] != p.zero, a_src[i] + c0, p.zero), dst + (i * H3_NT + tid) * 16);
+    };
+    auto issue_B = [&](int kofs, unsigned char* dst) {
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) glds16(b_src[i] + kofs, dst + (i * H3_NT + tid) * 16);
+    };
+    int b_rd[4][TN];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj) {
+            const int n = wn * (BN / 2) + jj * 32 + l31;
+            b_rd[s][jj] = n * ROWB + (((2 * s + lhi) ^ ((n >> 1) & 7)) << 4);
+        }
+    constexpr int BLKROWS = 32 / TW;
+    const int a_hp0 = (wm * 2 * BLKROWS + lty) * HWP + ltx;
+
+    floatx16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // epilogue constants, requested before the k-loop (see hconv_kernel): lane -> 8 output channels of a 32-column block
+    const int ech = lane & 3, erow = lane >> 2;
+    const int en0 = n0 + wn * (BN / 2) + 8 * ech;
+    float bia[TN][8], psc[TN][8], psh[TN][8];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = en0 + j * 32;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bia[j][e] = p.bias != nullptr ? p.bias[n + e] : 0.f;
+            psc[j][e] = p.post_scale != nullptr ? p.post_scale[n + e] : 1.f;
+            psh[j][e] = p.post_scale != nullptr ? p.post_shift[n + e] : 0.f;
+        }
+    }
+
+    const int nchunk = p.Cin / 64, ntile = nchunk * 9;
+    issue_A(0, Abuf);
+    issue_B(0, Bbuf);
+    __syncthreads();
+    int kt = 0;
+    for (int c = 0; c < nchunk; ++c) {
+        const unsigned char* As = Abuf + (c & 1) * H3_ASTAGE;
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t, ++kt) {
+            if (kt + 1 < ntile) {
+                const int t1 = (t == 8) ? 0 : t + 1, c1 = (t == 8) ? c + 1 : c;
+                issue_B(t1 * p.Cin + c1 * 64, Bbuf + ((kt + 1) & 1) * B_STAGE);
+            }
+            if (t == 0 && c + 1 < nchunk) issue_A((c + 1) * 64, Abuf + ((c + 1) & 1) * H3_ASTAGE);   // (last read in chunk c - 1)
+            const unsigned char* Bs = Bbuf + (kt & 1) * B_STAGE;
+            const int kh = t / 3, kw = t - kh * 3;
+            const int hp_t = a_hp0 + kh * HWP + kw;
+            const int sw = ((ltx + kw) >> 1) & 7;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                half8 a[2], b[TN];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    a[i] = *(const half8*)(As + (hp_t + i * BLKROWS * HWP) * ROWB + (((2 * s + lhi) ^ sw) << 4));
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) b[jj] = *(const half8*)(Bs + b_rd[s][jj]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[jj], acc[i][jj], 0, 0, 0);
+            }
+            __syncthreads();        // k-tile kt + 1 (and, at t == 0, the next chunk's halo) has landed; nobody still reads kt's stages
+        }
+    }
+
+    // ------------------------------------------------------------ epilogue: 32 x 32 blocks through this wave's LDS slice
+    float* st = (float*)smem + wave * 32 * STAGE_LD;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int blk = wm * 2 + i;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (i + j > 0) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * lhi) * STAGE_LD + l31] = acc[i][j][r];
+            __builtin_amdgcn_wave_barrier();
+            const int n = en0 + j * 32;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int row = erow + 16 * q;                  // row of the 32-row block -> pixel (ty, tx) of the patch
+                const int ty = (TW == 32) ? blk : 2 * blk + (row >> 4), tx = row & (TW - 1);
+                const float4 v0 = *(const float4*)(st + row * STAGE_LD + 8 * ech), v1 = *(const float4*)(st + row * STAGE_LD + 8 * ech + 4);
+                const float t8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float u = t8[e] + bia[j][e];
+                    if (p.relu) u = fmaxf(u, 0.f);
+                    v[e] = u * psc[j][e] + psh[j][e];
+                }
+                const long long m = ((long long)img * p.H + y0 + ty) * p.W + x0 + tx;
+                if (p.out_f32) {
+                    float* yp = (float*)p.y + m * p.ldy + n;
+                    *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    half8 h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = (half_t)clamp_h(v[e]);
+                    *(half8*)((half_t*)p.y + m * p.ldy + n) = h;
+                }
+            }
+        }
+    }
+}
+
+// 0: not a shape of hconv3_halo_kernel; else the patch width (32 / 16)
+inline int hconv3_tw(const rih_hconv_desc* d) {
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->res != nullptr) return 0;
+    if (d->Cin % 64 != 0 || d->Cout % 64 != 0 || d->Kpad < 9 * d->Cin) return 0;
+    if (d->ldy % (d->out_f32 ? 4 : 8) != 0 || ((uintptr_t)d->y & 15) != 0) return 0;
+    if (d->H % 8 == 0 && d->W % 32 == 0) return 32;
+    if (d->H % 16 == 0 && d->W % 16 == 0) return 16;
+    return 0;
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -454,6 +651,20 @@ extern "C" int rih_hconv(const rih_hconv_desc* d, void* stream) {
     a.vec = al16(d->y) && d->ldy % (d->out_f32 ? 4 : 8) == 0 && (d->res == nullptr || (al16(d->res) && d->ldr % 8 == 0));
     a.cvec = (d->bias == nullptr || al16(d->bias)) && (d->post_scale == nullptr || (al16(d->post_scale) && al16(d->post_shift)));
     hipStream_t s = (hipStream_t)stream;
+    // stride-1 3x3 convolutions on whole patches: the halo-resident kernel (RIH_HCONV_HALO=0: the implicit GEMM below)
+    static const bool halo = [] { const char* e = getenv("RIH_HCONV_HALO"); return !(e && e[0] == '0'); }();
+    const int tw = halo ? hconv3_tw(d) : 0;
+    if (tw != 0) {
+        const long long patches = (long long)d->N * (d->H / (256 / tw)) * (d->W / tw);
+        const int bn = (d->Cout % 128 == 0 && patches * (d->Cout / 128) >= 256) ? 128 : 64;
+        const long long grid = patches * (d->Cout / bn);
+        if (grid > 0x7fffffffLL) return RIH_EINVAL;
+        if (tw == 32 && bn == 128) hipLaunchKernelGGL((hconv3_halo_kernel<32, 128>), dim3((unsigned)grid), dim3(H3_NT), 0, s, a);
+        else if (tw == 32) hipLaunchKernelGGL((hconv3_halo_kernel<32, 64>), dim3((unsigned)grid), dim3(H3_NT), 0, s, a);
+        else if (bn == 128) hipLaunchKernelGGL((hconv3_halo_kernel<16, 128>), dim3((unsigned)grid), dim3(H3_NT), 0, s, a);
+        else hipLaunchKernelGGL((hconv3_halo_kernel<16, 64>), dim3((unsigned)grid), dim3(H3_NT), 0, s, a);
+        return (int)hipGetLastError();
+    }
     const long long tilesM = (M + BM - 1) / BM;
     static const bool glds = [] { const char* e = getenv("RIH_HCONV_GLDS"); return !(e && e[0] == '0'); }();
     // 128x64 tiles (three workgroups per CU instead of two; A is re-read per 64 columns) also for wide outputs when the reduction

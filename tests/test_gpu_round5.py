@@ -37,11 +37,15 @@ def test_captured_step_follows_the_data_magnitude(bn_mode, monkeypatch):
     """TrainStep captured on batch A (engine 2: every GEMM's power-of-two operand scales come from bound blocks written by
     kernels INSIDE the graph) and replayed on A, 1000 A, A / 1000 (A / 100 with batch statistics) and A with one pixel at 1e4: outputs and every parameter
     gradient of each replay against an eager engine-0 (native f32 MFMA) run of the same model on the same data, inside the
-    suite's fp64-anchored bands (testing.assert_fp32_equivalent k = 4 + 2e-5 for outputs, _grad_report's 6x band for
-    gradients with at most 1 % of the tensors outside, the allowance of the second family's B = 2 test: a dry run of this test on
-    the numpy ABI emulator showed ONE ReLU decision of a decoder patch convolution flipping between two fp32 summation orders
-    and moving five tensors at once -- that convolution's weight and bias and the mid convolution feeding it -- by 3e-4 ... 1e-3,
-    i.e. 0.5 % = four tensors is less than one such event); nothing may be inf / NaN.  A stale or capture-time bound would overflow the fp16 planes at 1000 A (inf) or
+    suite's fp64-anchored bands: testing.assert_fp32_equivalent (k = 4 + 2e-5) for every output; for the gradients
+    _grad_report's 6x band with the allowance of the HRNet B = 2 test (at most 3 % of the tensors outside, none beyond
+    max(5 %, 20 x the exact-fp32 engine's own distance from fp64)).  Why not the 0.5 % of the B = 3 ResNet test: at B = 2 a single
+    ReLU decision that differs between two fp32 summation orders moves a whole backward path at once -- on MI355X the excursions
+    came in clusters of five tensors (profiles/r05/ab/c1_pytest_r5.log and c5_pytest_gpu.log: `layers.0.img_ex_left.encoder.
+    {position_embeddings, proj, self_attn.w_qs, ff.fc1.*}` together, `layers.2.attn.{layer_norm2, ffL.*}` together), 0-2 clusters
+    per variant, and WHICH clusters changed when the 3x3 convolutions moved to the halo kernel (another summation order).  What
+    this test is after -- a stale bound -- shows as inf / NaN or as errors of order one, which the gross bound catches.  Nothing
+    may be inf / NaN.  A stale or capture-time bound would overflow the fp16 planes at 1000 A (inf) or
     flush A / 1000 to zero.  bn_mode 'frozen' = eval-mode BatchNorm (running statistics) with autograd on: the magnitude then
     travels through the whole trunk instead of being normalised away by the stem's batch statistics."""
     from oracle import net_oracle
@@ -105,7 +109,7 @@ def test_captured_step_follows_the_data_magnitude(bn_mode, monkeypatch):
             for k in w64:
                 worst = max(worst, testing.assert_fp32_equivalent(got_out[k], w0[k], w64[k], k=4.0, floor=2e-5,
                                                                   what='%s (%s): %s' % (name, bn_mode, k)))
-            nloose, n = _grad_report(got, g0, g64, max_loose=0.01)
+            nloose, n = _grad_report(got, g0, g64, max_loose=0.03)
             print('replay on %-18s (%s): outputs worst %.3g vs fp64 (engine 0: %.3g); gradients %d/%d outside the band'
                   % (name, bn_mode, worst[0], worst[1], nloose, n))
     finally:

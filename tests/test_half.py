@@ -106,6 +106,12 @@ def kernels_vs_torch(dev):
     conv_case(dev, 2, 9, 9, 64, 128, 1, 1, 0, 'conv-bn', True, True, False, seed=10)
     conv_case(dev, 1, 7, 7, 64, 20, 1, 1, 0, 'conv-bn', True, True, False, seed=11)
     conv_case(dev, 1, 6, 6, 64, 72, 3, 1, 1, 'conv-relu-bn', True, True, True, seed=12)
+    # halo-resident 3x3 (hconv3_halo_kernel: whole 8 x 32 / 16 x 16 patches, Cin % 64 == 0, Cout % 64 == 0): both patch shapes,
+    # 64- and 128-wide channel blocks, two channel chunks, pixel pitches on both sides, fp32 output, Conv -> ReLU -> BN order
+    conv_case(dev, 1, 8, 32, 64, 64, 3, 1, 1, 'conv-bn', True, False, False, seed=13)
+    conv_case(dev, 2, 16, 16, 128, 128, 3, 1, 1, 'conv-relu-bn', True, False, False, x_pad=8, y_pad=64, seed=14)
+    conv_case(dev, 1, 16, 32, 64, 192, 3, 1, 1, 'conv-bn', False, False, False, seed=15)
+    conv_case(dev, 1, 8, 32, 128, 64, 3, 1, 1, 'conv-relu-bn', True, False, True, seed=16)
     # pooling / resampling
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, 9, 10, 16, generator=g).to(F16)
