@@ -297,6 +297,28 @@ typedef struct rih_h2_desc {
 /* any number of H2 weight operands in ceil(n / 48) launches (`descs` is HOST memory, read before the call returns) */
 int rih_h2_multi(const rih_h2_desc* descs, int n, void* stream);
 
+/* Short-reduction streaming GEMM (csrc/rih_conv3.hip `panel_kernel`, ABI 16): C[M][N] = act(A[M][K] W[N][K]^T (+ R)) for the 1x1
+ * convolutions with K = 64 or 128 on large maps (torchvision Bottleneck.conv3 of layer1 / layer2 forward, conv1's data
+ * gradient) -- HBM streams that the tiled kernels of rih_gemm ran at 2-3 TB/s.  Persistent workgroups (one per CU) keep their
+ * column block of the H2 weight planes (rih_h2_multi with KH = KW = 1: forward n = co, k = ci; data gradient for_dgrad 1: n = ci,
+ * k = co) in LDS and walk over row tiles with the next tile's rows in flight.  Engine-2 arithmetic (amax_a / amax_w as
+ * rih_conv3_desc).  Preconditions (rih_panel_ok returns 1): K in {64, 128}, N % 64 == 0 (% 128 at K = 128), M % 128 == 0,
+ * 16-byte aligned a / w_h2 / c / r / stats, lda / ldc / ldr % 4 == 0, M * lda * 4 < 2^31, not stats and r together.
+ * stats (optional): [M / rows][2][N] per block of rows = rih_panel_stats_rows(desc) consecutive rows (rih_gemm_desc.stats format). */
+typedef struct rih_panel_desc {
+    const float* a;         /* [M][lda] */
+    const void* w_h2;       /* [N][K / 8][2][8] fp16 */
+    float* c;               /* [M][ldc] */
+    const float* r;         /* [M][ldr] or NULL */
+    float* stats;           /* or NULL */
+    const float* amax_a;
+    const float* amax_w;
+    int32_t M, N, K, lda, ldc, ldr, relu;
+} rih_panel_desc;
+int rih_panel_ok(const rih_panel_desc* d);
+int rih_panel_stats_rows(const rih_panel_desc* d);
+int rih_panel(const rih_panel_desc* d, void* stream);
+
 /* Finish a forward split-K GEMM: C[m*ldc+n] = act(alpha * sum_s P[s][m][n] + bias[n] + R[m*ldr+n]). */
 int rih_splitk_finish(const float* P, int S, int M, int N, float* C, int ldc, const float* bias, const float* R,
                       int ldr, float alpha, int relu, void* stream);
@@ -548,10 +570,10 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
 /* library / device info.  RIH_ABI_VERSION is bumped whenever a struct layout or a signature of this header changes;
  * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of EVERY by-pointer struct, in
  * this order: gemm desc, mano model, mesh topo, hconv desc, reduce desc, pack desc, ln final desc, adam entry, absmax desc,
- * presplit desc, conv3 desc, h2 desc (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it
+ * presplit desc, conv3 desc, h2 desc, panel desc (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it
  * mis-laid-out structs. */
-#define RIH_ABI_VERSION 15
-#define RIH_ABI_NSIZES 12
+#define RIH_ABI_VERSION 16
+#define RIH_ABI_NSIZES 13
 int rih_version(void);
 int rih_abi_sizes(int32_t* out10);
 const char* rih_arch(void);

@@ -60,6 +60,12 @@ class Conv3Desc(C.Structure):
                [(n, C.c_int32) for n in ('imgs', 'H', 'W', 'C', 'N', 'ldx', 'ldy', 'Kpad', 'relu')]
 
 
+class PanelDesc(C.Structure):
+    _fields_ = [('a', C.c_void_p), ('w_h2', C.c_void_p), ('c', C.c_void_p), ('r', C.c_void_p), ('stats', C.c_void_p),
+                ('amax_a', C.c_void_p), ('amax_w', C.c_void_p)] + \
+               [(n, C.c_int32) for n in ('M', 'N', 'K', 'lda', 'ldc', 'ldr', 'relu')]
+
+
 class H2Desc(C.Structure):
     _fields_ = [('w', C.c_void_p), ('dst', C.c_void_p), ('amax', C.c_void_p)] + \
                [(n, C.c_int32) for n in ('Cout', 'Cin', 'KH', 'KW', 'CinPad', 'for_dgrad', 'Kpad')]
@@ -143,6 +149,9 @@ SIGNATURES = {
     'rih_conv3x3_stats_rows': (c_i, [C.POINTER(Conv3Desc)]),
     'rih_conv3x3': (c_i, [C.POINTER(Conv3Desc), C.c_void_p]),
     'rih_h2_multi': (c_i, [C.POINTER(H2Desc), c_i, C.c_void_p]),
+    'rih_panel_ok': (c_i, [C.POINTER(PanelDesc)]),
+    'rih_panel_stats_rows': (c_i, [C.POINTER(PanelDesc)]),
+    'rih_panel': (c_i, [C.POINTER(PanelDesc), C.c_void_p]),
     'rih_hardswish_fwd': (c_i, [c_f, c_f, c_l, C.c_void_p]),
     'rih_hardswish_bwd': (c_i, [c_f, c_f, c_f, c_l, C.c_void_p]),
     'rih_tanh_scale_fwd': (c_i, [c_f, c_f, c_l, c_fl, C.c_void_p]),
@@ -252,7 +261,7 @@ EXPERIMENT_SIGNATURES = {
 }
 HAS_EXPERIMENTS = False
 
-ABI_VERSION = 15     # = RIH_ABI_VERSION of include/renderih_amd.h
+ABI_VERSION = 16     # = RIH_ABI_VERSION of include/renderih_amd.h
 
 _lib = None
 
@@ -296,7 +305,7 @@ def load():
     # built by hand as int64 rows in renderih_amd/optim.py
     mine = [C.sizeof(GemmDesc), C.sizeof(ManoModel), C.sizeof(MeshTopo), C.sizeof(HConvDesc),
             C.sizeof(ReduceDesc), C.sizeof(PackDesc), C.sizeof(LnFinalDesc), 5 * 8, C.sizeof(AbsmaxDesc), C.sizeof(PresplitDesc),
-            C.sizeof(Conv3Desc), C.sizeof(H2Desc)]
+            C.sizeof(Conv3Desc), C.sizeof(H2Desc), C.sizeof(PanelDesc)]
     if lib.rih_version() != ABI_VERSION:
         raise RuntimeError('librenderih_amd.so does not match this binding (ABI %d vs %d): rebuild with '
                            '`python -m renderih_amd._build`' % (lib.rih_version(), ABI_VERSION))

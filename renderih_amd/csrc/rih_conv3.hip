@@ -415,6 +415,261 @@ int h2_args(H2WArgs& a, const rih_h2_desc& d) {
     return a.Kp < a.K ? RIH_EINVAL : RIH_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ short-K streaming GEMM ("panel")
+// rih_panel: C[M][N] = act(A[M][K] W[N][K]^T (+ R)) for the 1x1 convolutions with a SHORT reduction (K = 64 or 128) and a large
+// map -- layer1 / layer2's conv3 (64 -> 256, 128 -> 512) forward and conv1's data gradient.  These launches move 3-5 bytes per
+// FLOP: they are HBM streams, and on the tiled kernels of rih_gemm.hip they ran at 1.9-2.9 TB/s inside the captured step
+// (profiles/r05/step_by_grid_c7.txt: 64 -> 256 at 64x64 115 us forward, 176 us as a data gradient, for 335 / 603 MB) where the
+// BatchNorm kernels beside them stream at 5.3-6.6 TB/s -- every workgroup pays its own prologue (bound blocks, first operand
+// round trip, weights re-staged and re-converted per tile) for two k-tiles of work.  Here a workgroup is PERSISTENT: it keeps
+// its BN-column slice of the weights (pre-split "H2" planes, 64 KB, staged once by LDS-DMA) in LDS and walks over row tiles;
+// the fp32 rows of tile t + 2 are in flight (global -> registers) and tile t + 1 is being converted into the other LDS stage
+// while tile t is multiplied, and the accumulators leave through the consumed stage as 16-byte stores -- nothing but two
+// barriers per tile between one tile's stores and the next tile's loads.  Arithmetic: engine 2 (see conv3x3_halo_kernel).
+// Geometry: 512 threads = 8 wavefronts; tile BM x BN with BM * K = 8192 (128 rows at K = 64, 64 rows at K = 128) and
+// BN = 256 / 128 / 64 (BN * K <= 16384); LDS = weights 64 KB + two row stages of 32 KB; the epilogue staging aliases the stage
+// that was just multiplied.  LDS images: unit j = (k / 8) * 2 + plane of a row at position j ^ (row & 15) inside its 16-unit
+// group (conflict-free ds_read_b128 for 32 consecutive rows).  Epilogue: optional residual, ReLU, BatchNorm statistics per
+// 32 TM rows of a wave (rih_gemm_desc.stats format).  Preconditions (rih_panel_ok): K in {64, 128}, N % 64 == 0, M % 128 == 0,
+// at least 256 (tile, column block) items, 16-byte aligned operands and pitches.
+struct PanelArgs {
+    const float* a;
+    const unsigned char* w;
+    float* c;
+    const float* r;
+    float* stats;
+    const float* amax_a;
+    const float* amax_w;
+    int M, N, K, lda, ldc, ldr, relu;
+    int nblk, mtiles;
+};
+
+template <int KT, int BN, bool STATS, bool RES>
+__global__ __launch_bounds__(NT, 2) void panel_kernel(const PanelArgs p) {
+    constexpr int K = 32 * KT;                          // 64 / 128
+    constexpr int BM = 8192 / K;                        // 128 / 64
+    constexpr int WGN = BN >= 128 ? 4 : 2, WGM = 8 / WGN;
+    constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+    static_assert(TM >= 1 && TN >= 1 && BN * K <= 16384, "tile shape");
+    constexpr int ROWB = K * 4;                         // bytes per LDS row: K / 8 groups x 2 planes x 16 B
+    constexpr int UPR = K / 4;                          // 16-byte units per row
+    constexpr int A_ST = BM * ROWB;                     // 32 KB
+    constexpr int B_BYTES = BN * ROWB;
+    constexpr int NPA = (BM * K / 4) / NT;              // float4 of a row tile per thread: 4
+    constexpr int NPB = (BN * UPR) / NT;                // LDS-DMA units of the weight slice per thread
+    static_assert((BM * K / 4) % NT == 0 && (BN * UPR) % NT == 0 && 8 * 32 * 32 * 4 <= A_ST, "loader / staging geometry");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[B_BYTES + 2 * A_ST];
+    unsigned char* const Bs = smem;
+    unsigned char* const Abuf = smem + B_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int G = (int)gridDim.x;
+    const int id = xcd_remap_c3((int)blockIdx.x, G);   // neighbours on one XCD share the row tiles (their column blocks differ)
+    const int nb = id % p.nblk, n0 = nb * BN;
+    const int mstep = G / p.nblk;
+    int mt = id / p.nblk;
+    if (mt >= p.mtiles) return;                         // (whole workgroup: before any barrier)
+
+    const float sa = c3_scale(p.amax_a), sb = c3_scale(p.amax_w);
+    const float inv_a = 1.f / sa, inv_b = 1.f / sb;
+
+    // weights: LDS unit U = (row n, position pos) holds source unit j = (pos & ~15) | ((pos & 15) ^ (n & 15)); staged once
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int U = i * NT + tid;
+        const int n = U / UPR, pos = U % UPR;
+        const int j = (pos & ~15) | ((pos & 15) ^ (n & 15));
+        c3_glds16(p.w + ((long long)(n0 + n) * UPR + j) * 16, Bs + U * 16);
+    }
+    // rows: float4 q = pass * NT + tid of a tile -> row q / (K / 4), channel quad q % (K / 4)
+    int a_row[NPA], a_lds[NPA];
+    unsigned a_col[NPA];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        const int q = i * NT + tid;
+        const int row = q / (K / 4), cq = q % (K / 4);
+        a_row[i] = row;
+        a_col[i] = (unsigned)cq * 16u;
+        const int j = (cq >> 1) * 2;                    // hi unit of the 8-channel group; lo = j + 1
+        a_lds[i] = row * ROWB + (((j & ~15) | ((j & 15) ^ (row & 15))) << 4) + (cq & 1) * 8;
+    }
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, (short)0, (int)0x7fffffff, 0x00020000);
+    float4 areg[NPA];
+    auto load_A = [&](int tile) {                       // (a tile past the end arrives as zeros and is never multiplied)
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const long long off = ((long long)tile * BM + a_row[i]) * p.lda * 4 + a_col[i];
+            areg[i] = c3_bload4(rA, (tile < p.mtiles && off < 0x7fffffffLL) ? (unsigned)off : OOB);
+        }
+    };
+    auto store_A = [&](unsigned char* dst) {
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            unsigned h0, l0, h1, l1;
+            c3_split2h(areg[i].x, areg[i].y, sa, h0, l0);
+            c3_split2h(areg[i].z, areg[i].w, sa, h1, l1);
+            *reinterpret_cast<uint2*>(dst + a_lds[i]) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(dst + (a_lds[i] ^ 16)) = make_uint2(l0, l1);
+        }
+    };
+    // operand fetch offsets per (k-tile, k-step, plane): unit j = 8 kt + (2 s + lhi) * 2 + pl of rows (wave base + 32 i + l31)
+    const int ra = wm * (32 * TM) + l31, rb = wn * (32 * TN) + l31;
+
+    load_A(mt);
+    store_A(Abuf);
+    load_A(mt + mstep);
+    __syncthreads();                                    // weights landed (LDS-DMA drained before the barrier), stage 0 complete
+    int st = 0;
+    for (; mt < p.mtiles; mt += mstep, st ^= 1) {
+        const unsigned char* As = Abuf + st * A_ST;
+        // tile t + 1 (in registers since the last iteration) -> the other stage; tile t + 2 -> registers
+        store_A(Abuf + (st ^ 1) * A_ST);
+        load_A(mt + 2 * mstep);
+        floatx16 acc[TM][TN], acc1[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f16x8 av[2][TM], bv[2][TN];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const int j = 8 * kt + (2 * s + lhi) * 2 + pl;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int row = ra + 32 * i;
+                        av[pl][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(
+                                                                  As + row * ROWB + (((j & ~15) | ((j & 15) ^ (row & 15))) << 4)));
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj) {
+                        const int n = rb + 32 * jj;
+                        bv[pl][jj] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(
+                                                                   Bs + n * ROWB + (((j & ~15) | ((j & 15) ^ (n & 15))) << 4)));
+                    }
+                }
+#define RIH_PN_TERM(ACC_, PA_, PB_)                                                                               \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int jj = 0; jj < TN; ++jj) ACC_[i][jj] = \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(av[PA_][i], bv[PB_][jj], ACC_[i][jj], 0, 0, 0);
+                RIH_PN_TERM(acc1, 1, 0)
+                RIH_PN_TERM(acc, 0, 0)
+                RIH_PN_TERM(acc1, 0, 1)
+#undef RIH_PN_TERM
+            }
+        __syncthreads();                                // stage st is consumed by every wave; stage st ^ 1 is complete
+        // ---- epilogue through this wave's 32 x 32 floats of the consumed stage
+        float* stg = reinterpret_cast<float*>(Abuf + st * A_ST) + wave * (32 * 32);
+        const int mbase = mt * BM + wm * (32 * TM), nbase = n0 + wn * (32 * TN);
+        float4 ssh[STATS ? TN : 1], ssum[STATS ? TN : 1], ssq[STATS ? TN : 1];
+        float scnt[STATS ? TN : 1];
+        if (STATS) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                ssh[j] = make_float4(0, 0, 0, 0); ssum[j] = make_float4(0, 0, 0, 0); ssq[j] = make_float4(0, 0, 0, 0); scnt[j] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float4 rv[RES ? 4 : 1];
+                if (RES) {                              // the block's residual, requested before the staging round trip
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        rv[q] = *reinterpret_cast<const float4*>(p.r + (long long)(mbase + i * 32 + (lane >> 3) + 8 * q) * p.ldr + nbase +
+                                                                 j * 32 + (lane & 7) * 4);
+                }
+                if (i + j > 0) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stg[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 32 + l31] = fmaf(acc1[i][j][r], 0x1p-11f, acc[i][j][r]) * inv_a * inv_b;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = (lane >> 3) + 8 * q, c4 = (lane & 7) * 4;
+                    float4 v = *reinterpret_cast<const float4*>(stg + row * 32 + c4);
+                    if (RES) { v.x += rv[q].x; v.y += rv[q].y; v.z += rv[q].z; v.w += rv[q].w; }
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *reinterpret_cast<float4*>(p.c + (long long)(mbase + i * 32 + row) * p.ldc + nbase + j * 32 + c4) = v;
+                    if (STATS) {
+                        if (scnt[j] == 0.f) ssh[j] = v;
+                        scnt[j] += 1.f;
+                        const float dx = v.x - ssh[j].x, dy = v.y - ssh[j].y, dz = v.z - ssh[j].z, dw = v.w - ssh[j].w;
+                        ssum[j].x += dx; ssum[j].y += dy; ssum[j].z += dz; ssum[j].w += dw;
+                        ssq[j].x += dx * dx; ssq[j].y += dy * dy; ssq[j].z += dz * dz; ssq[j].w += dw * dw;
+                    }
+                }
+            }
+        }
+        if (STATS) {
+            const long long rblk = mbase / (32 * TM);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float n = scnt[j];
+                const float in = n > 0.f ? 1.f / n : 0.f;
+                float4 mean = make_float4(ssh[j].x + ssum[j].x * in, ssh[j].y + ssum[j].y * in, ssh[j].z + ssum[j].z * in,
+                                          ssh[j].w + ssum[j].w * in);
+                float4 m2 = make_float4(ssq[j].x - ssum[j].x * ssum[j].x * in, ssq[j].y - ssum[j].y * ssum[j].y * in,
+                                        ssq[j].z - ssum[j].z * ssum[j].z * in, ssq[j].w - ssum[j].w * ssum[j].w * in);
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+                    const float nbr = __shfl_xor(n, o, 64);
+                    const float nt = n + nbr;
+                    const float wb = nt > 0.f ? nbr / nt : 0.f;
+                    const float cf = n * wb;
+#define RIH_PN_MERGE(c_)                                                              \
+    {                                                                                 \
+        const float mb = __shfl_xor(mean.c_, o, 64), qb = __shfl_xor(m2.c_, o, 64);   \
+        const float dl = mb - mean.c_;                                                \
+        mean.c_ += dl * wb;                                                           \
+        m2.c_ += qb + dl * dl * cf;                                                   \
+    }
+                    RIH_PN_MERGE(x) RIH_PN_MERGE(y) RIH_PN_MERGE(z) RIH_PN_MERGE(w)
+#undef RIH_PN_MERGE
+                    n = nt;
+                }
+                if ((lane >> 3) == 0) {
+                    const int nn = nbase + j * 32 + (lane & 7) * 4;
+                    *reinterpret_cast<float4*>(p.stats + (rblk * 2 + 0) * p.N + nn) = mean;
+                    *reinterpret_cast<float4*>(p.stats + (rblk * 2 + 1) * p.N + nn) = m2;
+                }
+            }
+        }
+        __syncthreads();                                // the staging reads are done: the next iteration overwrites this stage
+    }
+}
+
+int panel_bn(const rih_panel_desc* d) {
+    const int cap = 16384 / d->K;                       // 256 (K = 64) / 128 (K = 128)
+    if (d->N % 256 == 0 && cap >= 256) return 256;
+    if (d->N % 128 == 0 && cap >= 128) return 128;
+    return 64;
+}
+bool panel_ok(const rih_panel_desc* d) {
+    if (!d || !d->a || !d->w_h2 || !d->c || !d->amax_a || !d->amax_w) return false;
+    if ((d->K != 64 && d->K != 128) || d->N < 64 || d->N % 64 != 0 || d->M < 128 || d->M % 128 != 0) return false;
+    if (d->K == 128 && d->N % 128 != 0) return false;   // (64-row tiles leave no 8-wave arrangement for a 64-column block)
+    if (d->lda < d->K || d->lda % 4 != 0 || d->ldc < d->N || d->ldc % 4 != 0) return false;
+    if (d->r != nullptr && (d->ldr < d->N || d->ldr % 4 != 0)) return false;
+    if ((((uintptr_t)d->a | (uintptr_t)d->w_h2 | (uintptr_t)d->c | (uintptr_t)d->r | (uintptr_t)d->stats) % 16) != 0) return false;
+    if ((long long)d->M * d->lda * 4 >= (1ll << 31)) return false;     // 31-bit byte offsets into A
+    return true;        // (whether the launch has enough (tile, column block) items to fill the chip is the caller's planning)
+}
+
+template <int KT, int BN>
+void panel_launch(const PanelArgs& a, unsigned grid, bool stats, bool res, hipStream_t s) {
+    if (stats && !res) hipLaunchKernelGGL((panel_kernel<KT, BN, true, false>), dim3(grid), dim3(NT), 0, s, a);
+    else if (!stats && res) hipLaunchKernelGGL((panel_kernel<KT, BN, false, true>), dim3(grid), dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((panel_kernel<KT, BN, false, false>), dim3(grid), dim3(NT), 0, s, a);
+}
+
 // patch width: 32 when the map allows it (one image row per 32-row block), else 16 (two rows per block); 0: not a shape of this kernel
 int c3_tw(const rih_conv3_desc* d) {
     if (d->H % 8 == 0 && d->W % 32 == 0) return 32;
@@ -477,6 +732,51 @@ extern "C" int rih_conv3x3(const rih_conv3_desc* d, void* stream) {
         if (bn == 128) c3_launch<16, 128>(a, grid, st, s);
         else if (bn == 64) c3_launch<16, 64>(a, grid, st, s);
         else c3_launch<16, 32>(a, grid, st, s);
+    }
+    return (int)hipGetLastError();
+}
+
+
+extern "C" int rih_panel_ok(const rih_panel_desc* d) { return panel_ok(d) && !(d->stats && d->r) ? 1 : 0; }
+
+/* rows per BatchNorm statistics block of rih_panel for this descriptor (32 or 64), 0: not a shape of the kernel */
+extern "C" int rih_panel_stats_rows(const rih_panel_desc* d) {
+    if (!panel_ok(d)) return 0;
+    const int bn = panel_bn(d), bm = 8192 / d->K;
+    const int wgm = bn >= 128 ? 2 : 4;
+    return bm / wgm;
+}
+
+extern "C" int rih_panel(const rih_panel_desc* d, void* stream) {
+    if (!panel_ok(d) || (d->stats && d->r)) return RIH_EINVAL;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RIH_EINVAL;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    PanelArgs a;
+    a.a = d->a; a.w = (const unsigned char*)d->w_h2; a.c = d->c; a.r = d->r; a.stats = d->stats;
+    a.amax_a = d->amax_a; a.amax_w = d->amax_w;
+    a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr; a.relu = d->relu ? 1 : 0;
+    const int bn = panel_bn(d), bm = 8192 / d->K;
+    a.nblk = d->N / bn;
+    a.mtiles = d->M / bm;
+    // one persistent workgroup per CU (128 KB of LDS), a multiple of the column-block count so that a workgroup keeps ONE block
+    long long g = (long long)cus / a.nblk * a.nblk;
+    if (g < a.nblk) g = a.nblk;
+    const long long items = (long long)a.mtiles * a.nblk;
+    if (g > items) g = items;
+    const unsigned grid = (unsigned)g;
+    hipStream_t s = (hipStream_t)stream;
+    const bool st = d->stats != nullptr, rs = d->r != nullptr;
+    if (d->K == 64) {
+        if (bn == 256) panel_launch<2, 256>(a, grid, st, rs, s);
+        else if (bn == 128) panel_launch<2, 128>(a, grid, st, rs, s);
+        else panel_launch<2, 64>(a, grid, st, rs, s);
+    } else {
+        panel_launch<4, 128>(a, grid, st, rs, s);
     }
     return (int)hipGetLastError();
 }

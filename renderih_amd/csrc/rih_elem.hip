@@ -2017,6 +2017,7 @@ extern "C" int rih_abi_sizes(int32_t* out9) {      // RIH_ABI_NSIZES values
     out9[9] = (int32_t)sizeof(rih_presplit_desc);
     out9[10] = (int32_t)sizeof(rih_conv3_desc);
     out9[11] = (int32_t)sizeof(rih_h2_desc);
+    out9[12] = (int32_t)sizeof(rih_panel_desc);
     return 0;
 }
 extern "C" const char* rih_arch(void) { return "gfx950"; }

@@ -1060,6 +1060,53 @@ def conv3x3_halo(x, w, y, for_dgrad, relu=False, stats=None, bx=None, bw=None):
     check(_L().rih_conv3x3(C.byref(d), _stream()), 'rih_conv3x3')
 
 
+# --------------------------------------------------------------------------------------------- short-K streaming GEMM
+# csrc/rih_conv3.hip panel_kernel (round 5): the 1x1 convolutions with K = 64 / 128 on large maps (layer1 / layer2 conv3 forward,
+# conv1 data gradient) as persistent workgroups that keep their slice of the H2 weight planes in LDS and stream the rows.
+# RIH_PANEL=0: rih_gemm's tiled kernels.
+PANEL = os.environ.get('RIH_PANEL', '1') == '1'
+
+
+def _panel_ok(a2d_rows, K, N, lda, a, bias=None):
+    """Launches rih_panel takes and that are worth it: engine 2, K in {64, 128}, N % 64 (128 at K = 128), whole 128-row tiles, at
+    least 256 (row tile, column block) items so that every CU's persistent workgroup has work."""
+    if not (PANEL and ENGINE == 2) or bias is not None or K not in (64, 128) or N % 64 != 0 or (K == 128 and N % 128 != 0):
+        return False
+    if a2d_rows % 128 != 0 or lda % 4 != 0 or a.data_ptr() % 16 != 0 or 4 * a2d_rows * lda >= (1 << 31):
+        return False
+    cap = 16384 // K
+    bn = 256 if (N % 256 == 0 and cap >= 256) else 128 if (N % 128 == 0 and cap >= 128) else 64
+    return (a2d_rows // (8192 // K)) * (N // bn) >= 256
+
+
+def panel_gemm(a, w, c, M, N, K, lda, ldc, for_dgrad, relu=False, stats=None, R=None, ldr=0, ba=None, bw=None):
+    """Enqueue rih_panel: c[M][N] = act(a[M][K] W^T (+ R)) with W = the OIHW 1x1 weight `w` as forward (n = co, k = ci) or
+    data-gradient (n = ci, k = co) H2 operand.  stats: a StatsHolder, filled.  ba / bw: bound thunks of a and w."""
+    from ._lib import PanelDesc
+    Cout, Cin = w.shape[0], w.shape[1]
+    planes, Kp = _h2_weight(w, Cin, for_dgrad)
+    assert Kp == K and (N, K) == ((Cin, Cout) if for_dgrad else (Cout, Cin))
+    d = PanelDesc()
+    d.a, d.w_h2, d.c, d.r = a.data_ptr(), planes.data_ptr(), c.data_ptr(), _p(R)
+    d.amax_a = (ba() if callable(ba) else ba).data_ptr()
+    d.amax_w = (bw() if callable(bw) else bw).data_ptr()
+    d.M, d.N, d.K, d.lda, d.ldc, d.ldr, d.relu = M, N, K, lda, ldc, ldr, 1 if relu else 0
+    if stats is not None and stats.part is None and R is None:
+        stats.rows = int(_L().rih_panel_stats_rows(C.byref(d)))
+        assert stats.rows > 0
+        stats.T = M // stats.rows
+        stats.part = torch.empty((stats.T, 2, N), device=a.device, dtype=torch.float32)
+        d.stats = stats.part.data_ptr()
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_L().rih_panel(C.byref(d), _stream()), 'rih_panel')
+        e1.record()
+        PROFILE.append((2.0 * M * N * K, e0, e1, (M, N, K, 1, 0, 3, 51, 1, 2)))
+        return
+    check(_L().rih_panel(C.byref(d), _stream()), 'rih_panel')
+
+
 class Conv2dFn(torch.autograd.Function):
     """NHWC conv2d (+bias, +ReLU epilogue) = implicit GEMM on the fp32 MFMA pipe.
     x: [N,H,W,Cx] (Cx >= Cin, extra channels must be zero), w: [Cout,Cin,KH,KW] (the nn.Conv2d parameter)."""
@@ -1091,6 +1138,8 @@ class Conv2dFn(torch.autograd.Function):
             else:
                 gemm(x, wp, y, M, Cout, K, Cx, Kp, Cout, a_mode=0, b_mode=2, bias=bias, relu=relu, geom=geom,
                      stats=stats if ENGINE == 2 else None, amax_a=bx, amax_b=bw)
+        elif KH * KW == 1 and Cx == Cin and stride == 1 and pad == 0 and _panel_ok(M, Cin, Cout, Cx, x, bias):
+            panel_gemm(x, w, y, M, Cout, Cin, Cx, Cout, False, relu=relu, stats=stats, ba=bx, bw=bw)
         elif KH * KW == 1 and Cx == Cin:
             gemm(x, w, y, M, Cout, K, Cx, Cin, Cout, a_mode=0, b_mode=1, bias=bias, relu=relu, geom=geom, stats=stats,
                  amax_a=bx, amax_b=bw)
@@ -1180,6 +1229,9 @@ class Conv2dFn(torch.autograd.Function):
                 else:
                     gemm(dy, wd, dx, Mx, Cx, KH * KW * Cout, Cout, Kp, Cx, a_mode=0, b_mode=2, geom=geom, R=dskip, ldr=Cx,
                          amax_a=bdy, amax_b=bw)
+            elif (KH * KW == 1 and Cx == Cin and stride == 1 and pad == 0 and ctx.bnfold is None
+                  and _panel_ok(Mx, Cout, Cin, Cout, dy)):
+                panel_gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cx, True, R=dskip, ldr=Cx, ba=bdy, bw=bw)
             elif KH * KW == 1 and Cx == Cin:
                 gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cin, Cx, a_mode=0, b_mode=0, geom=geom, R=dskip, ldr=Cx,
                      amax_a=bdy, amax_b=bw, bnb=ctx.bnfold)

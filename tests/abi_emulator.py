@@ -514,6 +514,51 @@ class EmulatedLib:
             st[:, 1] = ((blk - m[:, None]) ** 2).sum(1)
         return 0
 
+    # ------------------------------------------------------------------ short-K streaming GEMM (csrc/rih_conv3.hip panel_kernel)
+    @staticmethod
+    def _panel_ok(d):
+        return bool(d.a and d.w_h2 and d.c and d.amax_a and d.amax_w and d.K in (64, 128) and d.N >= 64 and d.N % 64 == 0
+                    and not (d.K == 128 and d.N % 128 != 0) and d.M >= 128 and d.M % 128 == 0 and d.lda >= d.K and d.lda % 4 == 0
+                    and d.ldc >= d.N and d.ldc % 4 == 0 and (not d.r or (d.ldr >= d.N and d.ldr % 4 == 0))
+                    and all(int(x or 0) % 16 == 0 for x in (d.a, d.w_h2, d.c, d.r, d.stats)) and not (d.stats and d.r))
+
+    def rih_panel_ok(self, dref):
+        return 1 if self._panel_ok(dref._obj if hasattr(dref, '_obj') else dref) else 0
+
+    def rih_panel_stats_rows(self, dref):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        if not self._panel_ok(d):
+            return 0
+        cap = 16384 // d.K
+        bn = 256 if (d.N % 256 == 0 and cap >= 256) else 128 if (d.N % 128 == 0 and cap >= 128) else 64
+        return (8192 // d.K) // (2 if bn >= 128 else 4)
+
+    def rih_panel(self, dref, stream):
+        d = dref._obj
+        if not self._panel_ok(d):
+            return -1
+        sw = self._e2_scale(d.amax_w)
+        pl = np.ctypeslib.as_array((C.c_uint16 * (2 * d.N * d.K)).from_address(int(d.w_h2))).reshape(d.N, d.K // 8, 2, 8)
+        hi = pl[:, :, 0, :].reshape(d.N, d.K).view(np.float16).astype(np.float32)
+        lo = pl[:, :, 1, :].reshape(d.N, d.K).view(np.float16).astype(np.float32)
+        Wnk = ((hi + lo * np.float32(2.0 ** -11)) / sw).astype(np.float32)
+        A = np.lib.stride_tricks.as_strided(_f(d.a, (d.M - 1) * d.lda + d.K), (d.M, d.K), (4 * d.lda, 4))
+        y = A.dot(Wnk.T)
+        if d.r:
+            y = y + np.lib.stride_tricks.as_strided(_f(d.r, (d.M - 1) * d.ldr + d.N), (d.M, d.N), (4 * d.ldr, 4))
+        if d.relu:
+            y = np.maximum(y, 0)
+        np.lib.stride_tricks.as_strided(_f(d.c, (d.M - 1) * d.ldc + d.N), (d.M, d.N), (4 * d.ldc, 4))[...] = y
+        if d.stats:
+            rows = self.rih_panel_stats_rows(d)
+            T = d.M // rows
+            st = _f(d.stats, T * 2 * d.N).reshape(T, 2, d.N)
+            blk = y.reshape(T, rows, d.N)
+            m = blk.astype(np.float64).mean(1)
+            st[:, 0] = m
+            st[:, 1] = ((blk - m[:, None]) ** 2).sum(1)
+        return 0
+
     def rih_splitk_reduce(self, P, S, M, N, dst, Cin, taps, CinValid, accumulate, stream):
         return self.rih_splitk_reduce_bias(P, S, M, M, N, dst, Cin, taps, CinValid, accumulate, 0, stream)
 

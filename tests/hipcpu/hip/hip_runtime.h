@@ -214,6 +214,15 @@ static inline int __builtin_amdgcn_readfirstlane_emul(int v) {
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipcpu::launch(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); })
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+// device query of the persistent kernels (csrc/rih_conv3.hip rih_panel sizes its grid by the CU count): a "device" of HIPCPU_CUS
+// compute units (default 6, not a divisor-friendly number on purpose), so that workgroups walk over several tiles on small tests
+struct hipDeviceProp_t { int multiProcessorCount; };
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    const char* e = std::getenv("HIPCPU_CUS");
+    p->multiProcessorCount = e ? std::atoi(e) : 6;
+    return hipSuccess;
+}
 #include "../hipcpu_gfx950.h"
 
 // shader-clock read of the phase-stamp development aid (csrc/rih_mano.hip): no meaning on the host

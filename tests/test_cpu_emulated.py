@@ -151,6 +151,14 @@ def test_conv3x3_halo_host_logic():
     G.test_conv2d((2, 8, 8, 32, 32, 3, 1, 1, False, True))         # W = 8: not a whole 32-pixel patch -> rih_gemm
 
 
+def test_panel_host_logic():
+    """ops.panel_gemm on the emulated ABI: forward and data-gradient H2 operands of a 1x1 weight, the skip path's gradient as
+    residual, statistics blocks of 32 / 64 rows."""
+    G.test_panel_1x1((1, 16, 16, 64, 256, False, True))
+    G.test_panel_1x1((1, 16, 16, 128, 128, True, True))
+    G.test_panel_1x1((1, 16, 8, 64, 64, False, True))
+
+
 def test_conv1x1_cat_host_logic():
     """ops.conv1x1_cat on the emulated ABI: segment descriptors, per-part data gradients, column-slice weight gradients."""
     for eng in (1, 2):

@@ -192,6 +192,63 @@ def test_conv3x3_halo(case, monkeypatch=None):
         ops.ENGINE, ops.HALO3 = saved
 
 
+PANEL_CASES = [(2, 64, 64, 64, 256, False, True), (1, 64, 64, 128, 512, False, True), (2, 64, 32, 64, 64, True, True),
+               (2, 64, 64, 64, 128, False, False), (4, 64, 64, 128, 128, True, True)]
+
+
+@pytest.mark.parametrize('case', PANEL_CASES)
+def test_panel_1x1(case, monkeypatch=None):
+    """csrc/rih_conv3.hip panel_kernel through ops.conv2d / ops.conv2d_skip (ops.PANEL, engine 2): 1x1 convolutions with K = 64 / 128
+    as persistent streaming workgroups -- forward (+ ReLU, + BatchNorm statistics), the data gradient WITH the skip path's gradient
+    as residual (conv2d_skip: Bottleneck.conv1), the weight gradient (rih_gemm) -- against fp64, and against the tiled kernels
+    (PANEL off).  (N, H, W, Cin, Cout, relu, stats); the planning threshold (>= 256 work items) is lifted for the small shapes."""
+    from renderih_amd import ops
+    N, H, W, Cin, Cout, relu, want_stats = case
+    saved = (ops.ENGINE, ops.PANEL, ops._panel_ok)
+    ops.ENGINE = 2
+    ok0 = ops._panel_ok
+
+    def ok_small(rows, K, Nn, lda, a, bias=None):            # the kernel's own preconditions without the fill-the-chip rule
+        return (ops.PANEL and bias is None and K in (64, 128) and Nn % 64 == 0 and not (K == 128 and Nn % 128 != 0) and rows % 128 == 0
+                and lda % 4 == 0)
+    ops._panel_ok = ok_small
+    try:
+        x = rnd(N, Cin, H, W, seed=31) * 2.0
+        w = rnd(Cout, Cin, 1, 1, seed=32, scale=1.0 / math.sqrt(Cin))
+        xr, wr = x.double().clone().requires_grad_(True), w.double().clone().requires_grad_(True)
+        yr = F.conv2d(xr, wr)
+        if relu:
+            yr = F.relu(yr)
+        gy, gs = rnd(*yr.shape, seed=33), rnd(*x.shape, seed=34)
+        (yr * gy.double()).sum().add((xr * gs.double()).sum()).backward()     # the skip path contributes gs to dx
+        d = dev()
+        outs = {}
+        for panel in (True, False):
+            ops.PANEL = panel
+            xg = nhwc(x).contiguous().to(d).requires_grad_(True)
+            wg = w.clone().to(d).requires_grad_(True)
+            holder = ops.StatsHolder() if want_stats else None
+            yg, idt = ops.conv2d_skip(xg, wg, None, stride=1, pad=0, relu=relu, stats=holder)
+            ((yg * nhwc(gy).contiguous().to(d)).sum() + (idt * nhwc(gs).contiguous().to(d)).sum()).backward()
+            outs[panel] = (nchw(yg).detach().cpu(), nchw(xg.grad).cpu(), wg.grad.cpu())
+            assert_close(outs[panel][0], yr.float(), 1e-4, 1e-5, 'panel %s y %s' % (panel, case,))
+            assert_close(outs[panel][1], xr.grad.float(), 1e-4, 2e-5, 'panel %s dx %s' % (panel, case,))
+            assert_close(outs[panel][2], wr.grad.float(), 1e-3, 1e-4, 'panel %s dw %s' % (panel, case,))
+            if panel and want_stats:
+                assert holder.part is not None and holder.rows in (32, 64)
+                M = N * H * W
+                part = holder.part.double().cpu()
+                mean = part[:, 0].mean(0)
+                var = (part[:, 1] + float(holder.rows) * (part[:, 0] - mean) ** 2).sum(0) / M
+                y2 = nhwc(yr.detach()).reshape(M, Cout)
+                assert_close(mean, y2.mean(0), 1e-4, 1e-5, 'panel stats mean')
+                assert_close(var, y2.var(0, unbiased=False), 1e-3, 1e-5, 'panel stats var')
+        for a, b, what in zip(outs[True], outs[False], ('y', 'dx', 'dw')):
+            assert_close(a, b, 1e-4, 1e-5, 'panel vs tiled GEMM ' + what)
+    finally:
+        ops.ENGINE, ops.PANEL, ops._panel_ok = saved
+
+
 LIN_CASES = [(126, 512, 256, True, False, False), (126, 2048, 509, True, False, False), (100, 64, 3, True, False, False),
              (128, 252, 1, True, False, False), (6, 252, 778, False, False, False), (4032, 128, 128, True, True, True),
              (300, 256, 256, True, False, True), (8064, 64, 64, True, True, False)]

@@ -79,6 +79,14 @@ def test_conv3x3_halo_kernels(case):
     G.test_conv3x3_halo(case)
 
 
+@pytest.mark.parametrize('case', [(1, 16, 16, 64, 256, False, True), (1, 16, 16, 128, 128, True, True), (1, 16, 8, 64, 64, False, True),
+                                  (1, 32, 16, 64, 128, True, False)])
+def test_panel_kernels(case):
+    """csrc/rih_conv3.hip panel_kernel on the host harness (a "device" of 6 CUs: persistent workgroups walk over several row tiles,
+    ragged trip counts): resident weight planes, two row stages, the epilogue through the consumed stage, residual, statistics."""
+    G.test_panel_1x1(case)
+
+
 def test_conv3_lds_image_is_conflict_free():
     """The LDS images of csrc/rih_conv3.hip: a pixel / weight row = 8 units of 16 bytes at position j ^ ((index >> 1) & 7).  A
     ds_read_b128 is served in 16-lane groups (MI355X_MICROARCH.md, LDS table); within a group every lane must hit its own 16-byte
@@ -97,6 +105,11 @@ def test_conv3_lds_image_is_conflict_free():
                                 row, col = row0 + (0 if tw == 32 else l >> 4) + kh, (l & (tw - 1)) + kw
                                 banks.add(((row * pitch + col) * 8 + (j ^ ((col >> 1) & 7))) % 16)
                             assert len(banks) == 16, (tw, row0, kh, kw, j)
+    for r0 in range(0, 128, 32):                # rows of the panel kernel: unit j at (j & ~15) | ((j & 15) ^ (row & 15)), 16 / 32 units per row
+        for upr in (16, 32):
+            for j in range(upr):
+                for g in groups:
+                    assert len({(((r0 + l) * upr + ((j & ~15) | ((j & 15) ^ ((r0 + l) & 15)))) % 16) for l in g}) == 16
     for n0 in range(0, 128, 32):                # weight rows: position j ^ ((n >> 1) & 7)
         for j in range(8):
             for g in groups:

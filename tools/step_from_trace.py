@@ -55,6 +55,19 @@ def main():
     print('GEMM kernels %.3f ms, everything else %.3f ms' % (g / 1e6, (busy - g) / 1e6))
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
         print('%8.3f ms %5d x %8.1f us  %s' % (v[1] / 1e6, v[0], v[1] / v[0] / 1e3, k))
+    if '--by-grid' in sys.argv:
+        # the GEMM-family launches of the step by (kernel, grid): a shape is a grid size, so per-shape durations inside the replay
+        byg = collections.OrderedDict()
+        for r in step:
+            n = short(r['Kernel_Name'])
+            if not (n.startswith('gemm') or n.startswith('conv3x3')):
+                continue
+            k = byg.setdefault((n[:70], r.get('Grid_Size_X', r.get('Grid_Size', '?'))), [0, 0])
+            k[0] += 1
+            k[1] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+        print('GEMM-family launches by (kernel, grid threads):')
+        for (n, g), v in sorted(byg.items(), key=lambda kv: -kv[1][1]):
+            print('%8.3f ms %4d x %8.1f us  grid %9s  %s' % (v[1] / 1e6, v[0], v[1] / v[0] / 1e3, g, n))
     if '--torch' in sys.argv:
         # every launch of the step that is not a kernel of this package (torch element-wise glue, fills, copies), in launch
         # order with its grid size and the package kernels before / after it: enough to find the line of Python that issued it
