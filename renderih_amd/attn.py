@@ -270,8 +270,8 @@ class SelfAttn(nn.Module):
     def forward(self, x, dc):
         y, x = ops.layernorm_skip(x, self.layer_norm.weight, self.layer_norm.bias, eps=self.layer_norm.eps)
         # one fused QKV projection: the three nn.Linear parameters are stacked (a copy) into a [3D, D] operand
-        w = ops.stacked([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight])
-        b = ops.stacked([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias])
+        w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight], 0)
+        b = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias], 0)
         o = ops.self_attention_packed(ops.linear(y, w, b), self.n_heads, dc.p, dc.seed() if dc.p > 0 else 0)
         x = _lin_drop_res(dc, self.fc, o, x)
         return self.ff(x, dc)
@@ -281,8 +281,8 @@ class SelfAttn(nn.Module):
     def forward_pair(L, R, X, dc):
         _, B, S, D = X.shape
         # both hands' fused QKV operands stacked once into [2, 3D, D]
-        w = ops.stacked([L.w_qs.weight, L.w_ks.weight, L.w_vs.weight, R.w_qs.weight, R.w_ks.weight, R.w_vs.weight])
-        b = ops.stacked([L.w_qs.bias, L.w_ks.bias, L.w_vs.bias, R.w_qs.bias, R.w_ks.bias, R.w_vs.bias])
+        w = torch.cat([L.w_qs.weight, L.w_ks.weight, L.w_vs.weight, R.w_qs.weight, R.w_ks.weight, R.w_vs.weight], 0)
+        b = torch.cat([L.w_qs.bias, L.w_ks.bias, L.w_vs.bias, R.w_qs.bias, R.w_ks.bias, R.w_vs.bias], 0)
         chain = ops.chain_ok(D, L.ff.fc1.out_features)
         if chain:       # LayerNorm -> QKV projection as one launch (csrc/rih_chain.hip)
             qkv, X = ops.ln_linear_chain(X, L.layer_norm, R.layer_norm, w.view(2, 3 * D, D), b.view(2, 3 * D))
@@ -399,8 +399,8 @@ class inter_attn(nn.Module):
         L2 = _ln(self.layer_norm1, Lf)
         R2 = _ln(self.layer_norm2, Rf)
         # shared projections (N5): stacked once into a [3D, D] operand, one fused QKV GEMM per hand
-        w = ops.stacked([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight])
-        b = ops.stacked([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias])
+        w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight], 0)
+        b = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias], 0)
         sd = (lambda: dc.seed()) if dc.p > 0 else (lambda: 0)
         # feat_R2L = softmax(Lq Rk^T) Rv, feat_L2R = softmax(Rq Lk^T) Lv  (inter_attn.py:93-104)
         feat_R2L, feat_L2R = ops.cross_attention_packed(ops.linear(L2, w, b), ops.linear(R2, w, b), self.n_heads,
@@ -412,8 +412,8 @@ class inter_attn(nn.Module):
 
     def forward_pair(self, X, dc):
         X = SelfAttn.forward_pair(self.L_self_attn_layer, self.R_self_attn_layer, X, dc)
-        w = ops.stacked([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight])
-        b = ops.stacked([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias])
+        w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight], 0)
+        b = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias], 0)
         sd = (lambda: dc.seed()) if dc.p > 0 else (lambda: 0)
         chain = ops.chain_ok(X.shape[-1], self.ffL.fc1.out_features)
         # shared projections (N5): ONE fused QKV GEMM over both hands' rows, then the two cross-hand directions

@@ -156,8 +156,8 @@ class inter_attn(nn.Module):
         X = SelfAttn.forward_pair(self.L_self_attn_layer, self.R_self_attn_layer, X, dc)
         # Lf2 = LN1(Lf + Rf), Rf2 = LN2(Rf + Lf): the other hand is the second (fused-add) input of the norm
         X2 = ops.layernorm_pair(X, self.layer_norm1, self.layer_norm2, x2=torch.flip(X, (0,)))
-        w = ops.stacked([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight])
-        b = ops.stacked([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias])
+        w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight], 0)
+        b = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias], 0)
         sd = (lambda: dc.seed()) if dc.p > 0 else (lambda: 0)
         # feat_R2L = softmax(Lq Lk^T) Rv, feat_L2R = softmax(Rq Rk^T) Lv  (inter_attn_lijun.py:94-112)
         feat = ops.cross_attention_stacked(ops.linear(X2, w, b), self.n_heads, dc.p, sd(), sd(), own_keys=True)

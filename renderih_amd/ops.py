@@ -918,11 +918,7 @@ class PackCache:
         self.fresh = False
 
     def refresh(self):
-        packs = [e for e in self.entries.values() if e[2][0] not in ('presplit', 'h2', 'stack')]
-        stacks = [e for e in self.entries.values() if e[2][0] == 'stack']
-        if stacks:      # stacked parameter operands (the fused QKV weights / biases of the attention blocks): one multi-tensor copy
-            with torch.no_grad():
-                torch._foreach_copy_([v for e in stacks for v in e[2][1]], [p_ for e in stacks for p_ in e[0]])
+        packs = [e for e in self.entries.values() if e[2][0] not in ('presplit', 'h2')]
         pres = [e for e in self.entries.values() if e[2][0] == 'presplit']
         h2 = [e for e in self.entries.values() if e[2][0] == 'h2']
         if h2:          # H2 weight operands of the halo-resident 3x3 convolutions (rih_conv3x3): one launch per 48
@@ -950,47 +946,6 @@ class PackCache:
 
 
 _PACK = None
-
-
-STACK_CACHE = os.environ.get('RIH_STACK_CACHE', '1') == '1'      # 0: torch.cat per attention block and step (A/B partner)
-
-
-class _StackFn(torch.autograd.Function):
-    """cat(params, dim 0) whose value already sits in a persistent buffer (ops.stacked): forward hands the buffer on, backward cuts
-    the gradient of the stacked operand into the parameters' gradients (views, no copies)."""
-
-    @staticmethod
-    def forward(ctx, buf, *params):
-        ctx.sizes = [int(p_.shape[0]) for p_ in params]
-        return buf.view_as(buf)
-
-    @staticmethod
-    def backward(ctx, g):
-        return (None,) + tuple(torch.split(g, ctx.sizes, 0))
-
-
-def stacked(params):
-    """torch.cat(params, 0) of parameters (the q / k / v projections of an attention block as ONE GEMM operand, models/model_attn/
-    self_attn.py:62-64).  Under a TrainStep (ops._PACK installed) the concatenation lives in a persistent buffer that ONE
-    multi-tensor copy per step refreshes for all attention blocks (PackCache.refresh) instead of two `cat` launches per block and
-    step (24 launch-floor kernels of ~5 us in the captured ResNet50 step, profiles/r05/step_trace_c4_halo.txt)."""
-    params = list(params)
-    pc = _PACK
-    if pc is None or not STACK_CACHE or not all(p_.is_contiguous() for p_ in params):
-        return torch.cat(params, 0)
-    key = ('stack',) + tuple(p_.data_ptr() for p_ in params)
-    e = pc.entries.get(key)
-    if e is None:
-        with torch.no_grad():
-            buf = torch.cat([p_.detach() for p_ in params], 0)
-        views = list(torch.split(buf, [int(p_.shape[0]) for p_ in params], 0))
-        pc.entries[key] = (params, buf, ('stack', views))
-    else:
-        buf = e[1]
-        if not pc.fresh:        # (a request outside a refreshed step: bring this buffer up to date now)
-            with torch.no_grad():
-                torch._foreach_copy_(e[2][1], params)
-    return _StackFn.apply(buf, *params)
 
 
 def _packed_weight(w, Cx, for_dgrad, sub=None, out=None):
