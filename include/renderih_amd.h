@@ -525,12 +525,16 @@ int rih_mano_pack(const rih_mano_model* m, float* packed, void* stream);
 int rih_mano_fwd(const rih_mano_model* m, const float* packed, const float* root, const float* pose, int ncomp,
                  const float* shape, const float* trans, const float* scale, int center_idx, int new_skel, float* v,
                  float* j, float* ws, int B, int variant, void* stream);
-/* gradients wrt root/pose/shape/trans/scale (any may be NULL) given dv[B][778][3], dj[B][21][3] and the forward's ws.
- * Two launches: per hand the skinning / kinematic-chain part (one workgroup per hand), then -- round 3 -- the two contractions
- * with the blend bases (pose-blend and shape gradients: 0.33 MFLOP per hand against 1.26 MB of basis) as MFMA products of
- * 16-hand chunks against tiles of `packed` in LDS, with the Rodrigues / PCA epilogue; ws_bwd (>= rih_mano_bwd_ws_floats(B)
- * floats, 16-byte aligned: the blend kernel reads it with 16-byte vector loads) carries dv_tpose / dv_shaped / rotation gradients between the two.  ws_bwd == NULL runs the
- * one-kernel backward of rounds 1-2 (every workgroup re-reads the whole basis from L2: 1.17 ms for 4096 hands; A/B partner). */
+/* gradients wrt root/pose/shape/trans/scale (any may be NULL) given dv[B][778][3], dj[B][21][3] and the forward's ws (16-byte
+ * aligned: the hand's SE3s are read with 16-byte scalar loads).
+ * Three launches (round 5): (1) per hand the skinning / kinematic-chain part -- one workgroup per hand; the SE3s as wave-uniform
+ * scalar operands, dG = W^T M on v_mfma_f32_16x16x4_f32; (2) the two contractions with the blend bases (pose-blend and shape
+ * gradients: 0.33 MFLOP per hand against 1.26 MB of basis) TILE major: a workgroup pins one of the 13 tiles of `packed` in LDS
+ * and walks over 16-hand chunks of dv_tpose, writing partial sums; (3) per hand (one wavefront) the sum of the 13 partials in
+ * tile order, the pose-blend term, Rodrigues backward, PCA projection, shape gradient.  ws_bwd (>= rih_mano_bwd_ws_floats(B)
+ * floats, 16-byte aligned) carries dv_tpose / rotation and rest-joint gradients / the partial sums between them.
+ * 4096 hands: 175 us (rounds 3-4: 362); 128 hands: 39 us (174).  ws_bwd == NULL runs the one-kernel backward of rounds 1-2
+ * (every workgroup re-reads the whole basis from L2: 1.17 ms for 4096 hands; A/B partner). */
 int rih_mano_bwd(const rih_mano_model* m, const float* packed, const float* root, const float* pose, int ncomp,
                  const float* shape, const float* trans, const float* scale, int center_idx, int new_skel, const float* dv,
                  const float* dj, const float* ws, float* d_root, float* d_pose, float* d_shape, float* d_trans,

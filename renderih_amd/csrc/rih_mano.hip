@@ -50,7 +50,18 @@ struct Model {
     const float* J_reg;
     const float* weights;
     int parent[16];
+    // derived on the host (to_model): tree depth of every joint ([16] = maximum) and the children of every joint in index order
+    // (CSR) -- the backward used to rebuild both with chains of dependent loads from the kernel argument at its start
+    int depth[17];
+    int cstart[17];
+    int child[16];
 };
+
+// Wave-uniform operands that an EARLIER kernel wrote: reading them through the constant address space makes the compiler use
+// scalar loads (s_load_dwordx*) into SGPRs instead of per-lane requests.  (The host build of the test harness defines it empty.)
+#ifndef RIH_CONST_AS
+#define RIH_CONST_AS __attribute__((address_space(4)))
+#endif
 
 __device__ __forceinline__ void rodrigues_fwd(const float* ax, float* R) {
     // manolayer.py:32-48: angle = ||axis|| + 1e-8, R = I + sin K + (1-cos) K^2
@@ -435,17 +446,8 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
     auto load_basis = [&](int tile) { load_tile_192<192, true>(s_B, pk + tile * 192, NCP, KP, t); };
     if (!HM) load_basis(tile_fixed);
     for (int i = t; i < 528; i += 256) s_J[i] = pk[PK_JT + i];
-    if (t < NJ) {
-        int d = 0;
-        for (int pp = m.parent[t]; pp >= 0; pp = m.parent[pp]) ++d;
-        s_depth[t] = d;
-    }
+    if (t <= NJ) s_depth[t] = m.depth[t];
     __syncthreads();
-    if (t == 0) {
-        int mx = 0;
-        for (int j = 0; j < NJ; ++j) mx = max(mx, s_depth[j]);
-        s_depth[16] = mx;
-    }
     float wgt[NJ];
     auto load_weights = [&](int tile) {
         const int vv = tile * TILE_V + lane;
@@ -805,22 +807,11 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(Model m, const float* __r
     __shared__ float s_part[4 * NJ * 12];
     __shared__ float s_red4[16];
     __shared__ int s_depth[NJ + 1];        // tree depth of the joints, [16] = maximum
+    __shared__ int s_par[NJ], s_cstart[NJ + 1], s_child[NJ];
     const int b = blockIdx.x, t = threadIdx.x;
-    if (t < NJ) {
-        int d = 0;
-        for (int pp = m.parent[t]; pp >= 0; pp = m.parent[pp]) ++d;
-        s_depth[t] = d;
-    }
-    if (t == 0) {
-        int mx = 0;
-        for (int j = 1; j < NJ; ++j) {
-            int d = 0;
-            for (int pp = m.parent[j]; pp >= 0; pp = m.parent[pp]) ++d;
-            mx = max(mx, d);
-        }
-        s_depth[NJ] = mx;
-    }
-    const float* w = ws + (long long)b * WS_STRIDE;
+    if (t <= NJ) { s_depth[t] = m.depth[t]; s_cstart[t] = m.cstart[t]; }
+    if (t < NJ) { s_par[t] = m.parent[t]; s_child[t] = m.child[t]; }
+    const float* w = (const float*)__builtin_assume_aligned(ws + (long long)b * WS_STRIDE, 16);     // (WS_STRIDE % 4 == 0)
     const float* dvb = dv + (long long)b * NVC;
     const float* djb = dj + (long long)b * 63;
 
@@ -835,26 +826,39 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(Model m, const float* __r
         }
         s_djeff[t] = d;
     }
-    if (wsb == nullptr && ncomp > 0 && t < 45) {        // (split backward: the blend kernel computes the axis-angle vectors)
+    if (wsb == nullptr && ncomp > 0 && t < 45) {        // (split backward: the finish kernel computes the axis-angle vectors)
         float a = m.hands_mean[t];
         for (int c = 0; c < ncomp; ++c) a += pose[(long long)b * ncomp + c] * m.comps[c * 45 + t];
         s_axis[t] = a;
     }
     const float sc = w[OFF_POST + 3];
     RIH_BSTAMP(1);
-    // 1. effective vertex gradient (new_skel joints are averages of output vertices)
+    // 1. effective vertex gradient (new_skel joints are averages of output vertices).  Round 5: the 2 x 10 global requests of a
+    //    thread go out together (the loop used to wait one round trip per iteration: 17 k of the workgroup's 120 k cycles)
     float p_sv0 = 0.f, p_sv1 = 0.f, p_sv2 = 0.f, p_dot = 0.f;
-    for (int i = t; i < NVC; i += 256) {
-        float d = dvb[i];
-        if (new_skel) {
-            const int v = i / 3, c = i - v * 3;
-            for (int q = 0; q < 8; ++q)
-                if (c_special[5 + q] == v) d += 0.5f * djb[c_ns_joint[q >> 1] * 3 + c];
+    {
+        constexpr int NIT = (NVC + 255) / 256;
+        float dreg[NIT], wreg[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = t + 256 * u;
+            dreg[u] = (i < NVC) ? dvb[i] : 0.f;
+            wreg[u] = (i < NVC) ? w[OFF_VSC + i] : 0.f;
         }
-        s_dvs[i] = d;
-        const int c = i % 3;
-        if (c == 0) p_sv0 += d; else if (c == 1) p_sv1 += d; else p_sv2 += d;
-        p_dot += d * w[OFF_VSC + i];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = t + 256 * u;
+            if (i >= NVC) continue;
+            float d = dreg[u];
+            const int v = i / 3, c = i - v * 3;
+            if (new_skel) {
+                for (int q = 0; q < 8; ++q)
+                    if (c_special[5 + q] == v) d += 0.5f * djb[c_ns_joint[q >> 1] * 3 + c];
+            }
+            s_dvs[i] = d;
+            if (c == 0) p_sv0 += d; else if (c == 1) p_sv1 += d; else p_sv2 += d;
+            p_dot += d * wreg[u];
+        }
     }
     __syncthreads();
     if (t < 63) p_dot += s_djeff[t] * w[OFF_J21C + t];
@@ -889,78 +893,105 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(Model m, const float* __r
         s_dsrc[c_new_order[k] * 3 + c] = d;
     }
     __syncthreads();
-    for (int i = t; i < NVC; i += 256) {
-        float d = sc * s_dvs[i];
-        const int v = i / 3, c = i - v * 3;
-        for (int q = 0; q < 5; ++q)
-            if (c_special[q] == v) d += s_dsrc[(16 + q) * 3 + c];
-        s_dvs[i] = d;                       // dv_skin
-    }
-    __syncthreads();
     RIH_BSTAMP(3);
-    // 4. through the skinning: dv_tpose = T_v^T dv_skin ; M_v = dv_skin x [v_t;1]
+    // 4. through the skinning: dv_skin = sc dv_eff (+ the tip joints' gradients at their vertices); dv_tpose = T_v^T dv_skin;
+    //    M_v = dv_skin x [v_t;1].  Round 5: the sixteen SE3s of the hand are WAVE-UNIFORM operands read from the workspace by
+    //    scalar loads (constant address space: the forward wrote them, nobody writes them here) -- lane = vertex used to fetch
+    //    each of them from LDS with 48 broadcast ds_read_b128 per vertex, and with four workgroups per CU the LDS pipe (8
+    //    cycles per such instruction) was what the phase waited for: 65 k of the workgroup's 120 k cycles.  The separate
+    //    dv_skin pass over the coordinates (14 k cycles) is folded in: a thread scales its own vertices.
+    {
+        const RIH_CONST_AS float* gG = (const RIH_CONST_AS float*)(w + OFF_G);
+        float wv[4][NJ], Tr[4][9], d[4][3];
 #pragma unroll
-    for (int vi = 0; vi < 4; ++vi) {        // (unrolled: the weight / v_tpose requests of a thread's vertices fly together)
-        const int v = t + 256 * vi;
-        if (v >= NV) continue;
-        float Tr[9];
-        for (int e = 0; e < 9; ++e) Tr[e] = 0.f;
-        float wv[NJ];
+        for (int vi = 0; vi < 4; ++vi) {
+            const int v = min(t + 256 * vi, NV - 1);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {       // the vertex's 16 weights: four 16-byte requests
-            const float4 w4 = *reinterpret_cast<const float4*>(m.weights + v * NJ + 4 * q);
-            wv[4 * q] = w4.x; wv[4 * q + 1] = w4.y; wv[4 * q + 2] = w4.z; wv[4 * q + 3] = w4.w;
+            for (int q = 0; q < 4; ++q) {       // the vertex's 16 weights: four 16-byte requests
+                const float4 w4 = *reinterpret_cast<const float4*>(m.weights + v * NJ + 4 * q);
+                wv[vi][4 * q] = w4.x; wv[vi][4 * q + 1] = w4.y; wv[vi][4 * q + 2] = w4.z; wv[vi][4 * q + 3] = w4.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 9; ++e) Tr[vi][e] = 0.f;
+        }
+#pragma unroll
+        for (int vi = 0; vi < 4; ++vi) {
+            const int v = t + 256 * vi;
+            if (v >= NV) continue;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float x = sc * s_dvs[v * 3 + c];
+#pragma unroll
+                for (int q = 0; q < 5; ++q)
+                    if (c_special[q] == v) x += s_dsrc[(16 + q) * 3 + c];
+                d[vi][c] = x;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const float4 g0 = *reinterpret_cast<const float4*>(s_G + j * 12);
-            const float4 g1 = *reinterpret_cast<const float4*>(s_G + j * 12 + 4);
-            const float4 g2 = *reinterpret_cast<const float4*>(s_G + j * 12 + 8);
-            Tr[0] += wv[j] * g0.x; Tr[1] += wv[j] * g0.y; Tr[2] += wv[j] * g0.z;
-            Tr[3] += wv[j] * g1.x; Tr[4] += wv[j] * g1.y; Tr[5] += wv[j] * g1.z;
-            Tr[6] += wv[j] * g2.x; Tr[7] += wv[j] * g2.y; Tr[8] += wv[j] * g2.z;
+            float g[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) g[e] = gG[j * 12 + e];
+#pragma unroll
+            for (int vi = 0; vi < 4; ++vi) {
+                Tr[vi][0] += wv[vi][j] * g[0]; Tr[vi][1] += wv[vi][j] * g[1]; Tr[vi][2] += wv[vi][j] * g[2];
+                Tr[vi][3] += wv[vi][j] * g[4]; Tr[vi][4] += wv[vi][j] * g[5]; Tr[vi][5] += wv[vi][j] * g[6];
+                Tr[vi][6] += wv[vi][j] * g[8]; Tr[vi][7] += wv[vi][j] * g[9]; Tr[vi][8] += wv[vi][j] * g[10];
+            }
         }
-        const float d[3] = {s_dvs[v * 3], s_dvs[v * 3 + 1], s_dvs[v * 3 + 2]};
-        // M_v = dv_skin x [v_t; 1] is rank one: keep its two factors (19 KB for the mesh instead of 37 KB -- four workgroups
-        // per CU instead of two) and form the products in step 5
-        for (int c = 0; c < 3; ++c) {
-            s_M[v * 6 + c] = d[c];
-            s_M[v * 6 + 3 + c] = w[OFF_VT + v * 3 + c];
+#pragma unroll
+        for (int vi = 0; vi < 4; ++vi) {
+            const int v = t + 256 * vi;
+            if (v >= NV) continue;
+            // M_v = dv_skin x [v_t; 1] is rank one: keep its two factors (19 KB for the mesh instead of 37 KB -- four workgroups
+            // per CU instead of two) and form the products in step 5
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                s_M[v * 6 + c] = d[vi][c];
+                s_M[v * 6 + 3 + c] = w[OFF_VT + v * 3 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                s_dvs[v * 3 + c] = Tr[vi][c] * d[vi][0] + Tr[vi][3 + c] * d[vi][1] + Tr[vi][6 + c] * d[vi][2];     // dv_tpose
         }
-        for (int c = 0; c < 3; ++c) s_dvs[v * 3 + c] = Tr[c] * d[0] + Tr[3 + c] * d[1] + Tr[6 + c] * d[2];
     }
     __syncthreads();
     RIH_BSTAMP(4);
-    // 5. dG = W^T M: lane = (joint, three of the twelve elements), each wavefront a quarter of the vertices (the 64 bytes of a
-    //    vertex's weights are one coalesced request), partial sums joined through LDS in wavefront order
+    // 5. dG = W^T M, [16 joints] x [778 vertices] x [12 elements], on v_mfma_f32_16x16x4_f32: A = four rows of the skinning
+    //    weights (lane = (joint, vertex k): 256 contiguous bytes per instruction, ALL 49 requests of a lane issued before the
+    //    first product), B = M_v = dv_skin x [v_t; 1] formed from its two factors in LDS (lane = (element, vertex k)); each
+    //    wavefront takes every fourth group of four vertices, the four partial sums are joined through LDS in wavefront order.
+    //    (Rounds 2-4: lane = (joint, three elements) with eight weight requests in flight -- 25 dependent L2 round trips per
+    //    wavefront, 63 k of the workgroup's 104 k cycles; the phase timings of round 4 had this phase under the skinning's label.)
     {
-        // lane group g = lane & 3: g < 3 owns row g of the 3 x 4 block (columns 0..2: d[g] x[c]), g == 3 its last column (d[r])
-        const int lane = t & 63, wave = t >> 6, j = lane >> 2, g = lane & 3;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int v0 = wave; v0 < NV; v0 += 4 * 8) {        // eight weight requests in flight per lane (one per iteration
-            float wj[8];                                   // would be a chain of 195 L2 round trips)
+        const int lane = t & 63, wave = t >> 6, kq = lane >> 4, col = lane & 15;
+        constexpr int NKS = (NV + 3) / 4;               // 195 groups of four vertices
+        constexpr int PER = (NKS + 3) / 4;              // 49 per wavefront
+        float wa[PER];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int v = v0 + 4 * u;
-                wj[u] = (v < NV) ? m.weights[v * NJ + j] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int v = min(v0 + 4 * u, NV - 1);
-                const float* f = &s_M[v * 6];
-                if (g < 3) {
-                    const float wd = wj[u] * f[g];
-                    a0 += wd * f[3]; a1 += wd * f[4]; a2 += wd * f[5];
-                } else {
-                    a0 += wj[u] * f[0]; a1 += wj[u] * f[1]; a2 += wj[u] * f[2];
-                }
-            }
+        for (int i = 0; i < PER; ++i) {
+            const int v = 4 * (wave + 4 * i) + kq;
+            wa[i] = (v < NV) ? m.weights[v * NJ + col] : 0.f;
         }
-        const int e0 = (g < 3) ? 4 * g : 3, es = (g < 3) ? 1 : 4;       // element indices e0, e0 + es, e0 + 2 es of the 3 x 4 block
+        const int r = col >> 2, c = col & 3;            // element (r, c) of the 3 x 4 block; columns 12..15 of the product are unused
+        floatx4 acc0 = floatx4{0.f, 0.f, 0.f, 0.f}, acc1 = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int v = 4 * (wave + 4 * i) + kq;
+            float bv = 0.f;
+            if (v < NV && col < 12) {
+                const float* f = &s_M[v * 6];
+                bv = (c < 3) ? f[r] * f[3 + c] : f[r];
+            }
+            if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], bv, acc1, 0, 0, 0);
+            else       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], bv, acc0, 0, 0, 0);
+        }
+        // C/D layout: column = lane & 15 (element), row = 4 * (lane >> 4) + q (joint)
         __syncthreads();                    // s_dvs is needed below; the partials go to a separate scratch
-        s_part[wave * 192 + j * 12 + e0] = a0;
-        s_part[wave * 192 + j * 12 + e0 + es] = a1;
-        s_part[wave * 192 + j * 12 + e0 + 2 * es] = a2;
+        if (col < 12) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_part[wave * 192 + (4 * kq + q) * 12 + col] = acc0[q] + acc1[q];
+        }
         __syncthreads();
         if (t < NJ * 12) s_dG[t] = (s_part[t] + s_part[192 + t]) + (s_part[384 + t] + s_part[576 + t]);
     }
@@ -972,29 +1003,31 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(Model m, const float* __r
     if (t < NJ * 12) {
         const int p = t / 12, e = t - p * 12, r = e >> 2, c = e & 3;
         float a = 0.f;
-        for (int i = 1; i < NJ; ++i)
-            if (m.parent[i] == p) a += s_dsrc[i * 3 + r] * (c < 3 ? s_jt[i * 3 + c] : 1.f);
+        for (int q = s_cstart[p]; q < s_cstart[p + 1]; ++q) {
+            const int i = s_child[q];
+            a += s_dsrc[i * 3 + r] * (c < 3 ? s_jt[i * 3 + c] : 1.f);
+        }
         s_dG[t] += a;
     } else if (t < NJ * 12 + NJ * 3) {
         const int i = (t - NJ * 12) / 3, c = (t - NJ * 12) - i * 3;
         if (i == 0) {
             s_djt[c] += s_dsrc[c];
         } else {
-            const float* P = &s_G[m.parent[i] * 12];
+            const float* P = &s_G[s_par[i] * 12];
             const float* dji = &s_dsrc[i * 3];
             s_djt[i * 3 + c] += P[c] * dji[0] + P[4 + c] * dji[1] + P[8 + c] * dji[2];
         }
     }
     __syncthreads();
     // 7a. global-transform gradients up the tree, one level at a time: a parent gathers dRg_i R_i^T + dtg_i tl_i^T (and dtg_i)
-    //     from its children, whose own gradients are complete by then
+    //     from its children (index order), whose own gradients are complete by then
     for (int L = s_depth[16]; L >= 1; --L) {
         if (t < NJ * 12) {
             const int p = t / 12, e = t - p * 12, r = e >> 2, c = e & 3;
             if (s_depth[p] == L - 1) {
                 float a = 0.f;
-                for (int i = 1; i < NJ; ++i) {
-                    if (m.parent[i] != p) continue;
+                for (int q = s_cstart[p]; q < s_cstart[p + 1]; ++q) {
+                    const int i = s_child[q];
                     const float* R = &s_R[i * 9];
                     const float* jv = &s_jt[i * 3];
                     const float* dGi = &s_dG[i * 12];
@@ -1017,7 +1050,7 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(Model m, const float* __r
         const float* dGi = &s_dG[i * 12];
         float dtl[3];
         if (i > 0) {
-            const float* P = &s_G[m.parent[i] * 12];
+            const float* P = &s_G[s_par[i] * 12];
             for (int q = 0; q < 3; ++q) dtl[q] = P[q] * dGi[3] + P[4 + q] * dGi[7] + P[8 + q] * dGi[11];
             if (c < 3) {
                 const float dRl = P[r] * dGi[c] + P[4 + r] * dGi[4 + c] + P[8 + r] * dGi[8 + c];
@@ -1103,172 +1136,202 @@ __global__ __launch_bounds__(256) void mano_bwd_kernel(Model m, const float* __r
     }
 }
 
-// ---- backward, part 2: the contractions with the blend bases for 16 hands at a time ---------------------------------------
-//   out[16 hands][148] = dv_tpose[16][2496] x Bmat^T: columns 0..134 = the pose-feature gradient, 135..144 = the vertex part
-//   of the shape gradient (the joint-regressor part is Js^T djt, added in the epilogue).
-// Hand-chunk major like the forward: a workgroup owns chunks of 16 hands and streams the 13 basis tiles ([148][192], zero rows
-// up to 160) from L2 through LDS; per tile ten 16 x 16 x 192 products on v_mfma_f32_16x16x4_f32 (column blocks of 16 basis
-// rows; two or three per wavefront), accumulated over the tiles in registers.  LDS row pitch 196 floats: the k-strided operand
-// reads of 16 rows are bank-conflict free.  Epilogue per hand: pose-blend term into the joint-rotation gradients, Rodrigues backward, PCA
-// projection (or the rotation-matrix gradients as they are), shape gradient.
+// ---- backward, parts 2 and 3: the contractions with the blend bases ----------------------------------------------------------
+//   out[hand][148] = dv_tpose[hand][2496] x Bmat^T: columns 0..134 = the pose-feature gradient, 135..144 = the vertex part of
+//   the shape gradient (the joint-regressor part is Js^T djt, added in the epilogue).
+// Round 5 -- TILE major: a workgroup pins ONE of the 13 basis tiles ([148][192], zero rows up to 160; LDS pitch 196: the
+// k-strided operand reads of 16 rows are bank-conflict free) and walks over chunks of 16 hands; what streams is the chunk's
+// 12 KB tile of dv_tpose (the next one in flight in registers), not the 111 KB basis tile.  Rounds 3-4 ran this hand-chunk major
+// like the large-batch forward -- every workgroup streamed all 13 basis tiles from L2, ~11 us per tile of which the ten
+// 16 x 16 x 192 products on v_mfma_f32_16x16x4_f32 are 2.2: 145 us for 4096 hands, and 8 workgroups x 13 serial tiles for 128
+// hands.  (The forward has a reason to be hand major there -- its pose chain would be repeated per tile; this product has none.)
+// The price is that a hand's 148 sums now come from 13 workgroups: each writes its partial [16 hands][160] and
+// mano_bwd_finish_kernel adds them in tile order (deterministic) in front of the epilogue it took over: pose-blend term into the
+// joint-rotation gradients, Rodrigues backward, PCA projection (or the rotation-matrix gradients as they are), shape gradient.
 constexpr int BL_P = 196;                       // LDS row pitch: 196 mod 64 = 4, so the 16 rows x 4 k of an operand read (bank =
                                                 // 4 row + k) hit 64 different banks (194, rounds 2-3: pairs of lanes collided)
 constexpr int BL_ROWS = 160;                    // basis rows incl. zero padding to ten 16-column blocks
-__global__ __launch_bounds__(256) void mano_bwd_blend_kernel(Model m, const float* __restrict__ pk, int ncomp,
-                                                             const float* __restrict__ pose, const float* __restrict__ wsb,
-                                                             float* __restrict__ d_pose, float* __restrict__ d_shape, int B) {
+constexpr int PART_W = 256;                     // floats of a (tile, hand) partial row: 128 whole sums + 4 k-quarters x 32
+__global__ __launch_bounds__(256) void mano_bwd_blend_kernel(const float* __restrict__ pk, const float* __restrict__ wsb,
+                                                             float* __restrict__ part, int B) {
     __shared__ __attribute__((aligned(16))) float s_B[BL_ROWS * BL_P];      // 125,440 B
-    __shared__ __attribute__((aligned(16))) float s_V[HC * BL_P];           //  12,544 B: dv_tpose tile
-    float* s_dR = s_B;                          // epilogue scratch in the (then dead) first basis rows: [HC][144] | 3 x [HC][48]
-    float* s_ax = s_B + HC * 144;
-    float* s_dax = s_ax + HC * 48;
-    float* s_djt = s_dax + HC * 48;
-    float* s_out = s_djt + HC * 48;              // [HC][160]
+    __shared__ __attribute__((aligned(16))) float s_V[2][HC * BL_P];        //  25,088 B: dv_tpose tiles of two chunks
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    for (int i = t; i < (BL_ROWS - KP) * BL_P; i += 256) s_B[KP * BL_P + i] = 0.f;     // rows 148..159 stay zero
+    const int tile = blockIdx.x, group = blockIdx.y, ngroups = gridDim.y;
     const int nchunks = (B + HC - 1) / HC;
-    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    floatx4 hv[3];                              // 16 hands x 48 sixteen-byte items = 3 per thread
+    auto issue = [&](int chunk) {
         const int h0 = chunk * HC;
-        floatx4 acc[3];
+        const float* vsrc = wsb + (long long)h0 * BW_STRIDE + tile * 192;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-        // Round 4: a tile arrives in two halves of its 192 columns (the k-range of these products), and the NEXT half is always
-        // in flight -- global -> registers -- while the MFMAs of the current one run; it lands in the columns its predecessor has
-        // finished with (same LDS, same order of the fp32 sums).  Before: load -> sync -> multiply per tile, 13 exposed round trips.
-        const int nh = min(HC, B - h0);
-        constexpr int NHB = 14, NHV = 2;            // 148 x 24 = 3552 16-byte items of a basis half, 16 x 24 = 384 of a gradient half
-        floatx4 hb[NHB], hv[NHV];
-        auto issue_half = [&](int tile, int half) {
-            const float* src = pk + tile * 192 + 96 * half;
+        for (int u = 0; u < 3; ++u) {
+            const int i = t + 256 * u, k = i / 48, q = i - k * 48;
+            hv[u] = floatx4{0.f, 0.f, 0.f, 0.f};        // rows of hands behind the end of the batch are zero
+            if (h0 + k < B) hv[u] = *reinterpret_cast<const floatx4*>(vsrc + (long long)k * BW_STRIDE + 4 * q);
+        }
+    };
+    auto land = [&](int buf) {
 #pragma unroll
-            for (int u = 0; u < NHB; ++u) {
-                const int i = t + 256 * u;
-                hb[u] = floatx4{0.f, 0.f, 0.f, 0.f};
-                if (i < KP * 24) {
-                    const int k = i / 24, q = i - k * 24;
-                    hb[u] = *reinterpret_cast<const floatx4*>(src + (long long)k * NCP + 4 * q);
+        for (int u = 0; u < 3; ++u) {
+            const int i = t + 256 * u, k = i / 48, q = i - k * 48;
+            *reinterpret_cast<floatx4*>(&s_V[buf][k * BL_P + 4 * q]) = hv[u];
+        }
+    };
+    if (group < nchunks) issue(group);
+    load_tile_192<BL_P>(s_B, pk + tile * 192, NCP, KP, t);
+    for (int i = t; i < (BL_ROWS - KP) * BL_P; i += 256) s_B[KP * BL_P + i] = 0.f;     // rows 148..159 are zero
+    if (group < nchunks) land(0);
+    __syncthreads();
+    int buf = 0;
+    for (int chunk = group; chunk < nchunks; chunk += ngroups, buf ^= 1) {
+        const bool more = chunk + ngroups < nchunks;
+        if (more) issue(chunk + ngroups);
+        // The ten column blocks of 16 basis rows over four wavefronts: blocks w and w + 4 whole, and the k-quarter w of blocks 8
+        // and 9 (120 products each; 3 + 3 + 2 + 2 whole blocks left two wavefronts waiting at the barrier) -- four independent
+        // accumulation chains that share the A operand read.
+        floatx4 acc0 = floatx4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+        {
+            const float* a_rd = &s_V[buf][(lane & 15) * BL_P + (lane >> 4)];
+            const float* b0 = s_B + (wave * 16 + (lane & 15)) * BL_P + (lane >> 4);
+            const float* b1 = b0 + 64 * BL_P;
+            const float* b8 = s_B + (128 + (lane & 15)) * BL_P + (lane >> 4) + 48 * wave;       // the wavefront's k-quarter
+            const float* b9 = b8 + 16 * BL_P;
+            // operands of twelve k-steps at a time in registers, the NEXT twelve requested before the products of the current
+            // ones (the compiler's own schedule asked LDS two k-steps ahead and waited out its latency every four products)
+            float av[2][12], bv0[2][12], bv1[2][12], bv8[12], bv9[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { av[0][i] = a_rd[4 * i]; bv0[0][i] = b0[4 * i]; bv1[0][i] = b1[4 * i]; }
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { bv8[i] = b8[4 * i]; bv9[i] = b9[4 * i]; }
+#pragma unroll
+            for (int seg = 0; seg < 4; ++seg) {
+                const int cur = seg & 1, nxt = cur ^ 1;
+                if (seg < 3) {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        const int k = 4 * (12 * (seg + 1) + i);
+                        av[nxt][i] = a_rd[k]; bv0[nxt][i] = b0[k]; bv1[nxt][i] = b1[k];
+                    }
                 }
-            }
-            const float* vsrc = wsb + (long long)h0 * BW_STRIDE + tile * 192 + 96 * half;
+                __builtin_amdgcn_sched_barrier(0);
+                if (seg == wave) {
 #pragma unroll
-            for (int u = 0; u < NHV; ++u) {
-                const int i = t + 256 * u;
-                hv[u] = floatx4{0.f, 0.f, 0.f, 0.f};        // rows of hands behind the end of the batch are zero
-                if (i < HC * 24) {
-                    const int k = i / 24, q = i - k * 24;
-                    if (k < nh) hv[u] = *reinterpret_cast<const floatx4*>(vsrc + (long long)k * BW_STRIDE + 4 * q);
+                    for (int i = 0; i < 12; ++i) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][i], bv0[cur][i], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][i], bv1[cur][i], acc1, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][i], bv8[i], acc2, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][i], bv9[i], acc3, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][i], bv0[cur][i], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][i], bv1[cur][i], acc1, 0, 0, 0);
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-        };
-        auto land_half = [&](int half) {            // (pitch 196: rows stay 16-byte aligned)
+        }
+        // C/D layout: column = lane & 15 (basis row within the block), row = 4 * (lane >> 4) + r (hand).  Partial row of a hand:
+        // [0..127] the whole blocks, [128 + 32 q + c] the k-quarter q of columns 128 + c
+        const int h0 = chunk * HC;
 #pragma unroll
-            for (int u = 0; u < NHB; ++u) {
-                const int i = t + 256 * u;
-                if (i < KP * 24) {
-                    const int k = i / 24, q = i - k * 24;
-                    *reinterpret_cast<floatx4*>(s_B + k * BL_P + 96 * half + 4 * q) = hb[u];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < NHV; ++u) {
-                const int i = t + 256 * u;
-                if (i < HC * 24) {
-                    const int k = i / 24, q = i - k * 24;
-                    *reinterpret_cast<floatx4*>(s_V + k * BL_P + 96 * half + 4 * q) = hv[u];
-                }
-            }
-        };
-        auto products = [&](int ks0, int ks1) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int blk = wave + 4 * j;                       // column block 0..9 (wave-uniform)
-                if (blk >= 10) continue;
-                const float* a_rd = s_V + (lane & 15) * BL_P + (lane >> 4);
-                const float* b_rd = s_B + (blk * 16 + (lane & 15)) * BL_P + (lane >> 4);
-#pragma unroll 8
-                for (int ks = ks0; ks < ks1; ++ks)
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_rd[4 * ks], b_rd[4 * ks], acc[j], 0, 0, 0);
-            }
-        };
-        issue_half(chunk % NTILES, 0);              // staggered start: see the forward's tile loop
-        __syncthreads();                            // the previous chunk's epilogue is done with its scratch in the basis rows
-        land_half(0);
+        for (int r = 0; r < 4; ++r) {
+            const int h = h0 + 4 * (lane >> 4) + r;
+            if (h >= B) continue;
+            float* pr = part + ((long long)tile * B + h) * PART_W;
+            pr[wave * 16 + (lane & 15)] = acc0[r];
+            pr[64 + wave * 16 + (lane & 15)] = acc1[r];
+            pr[128 + 32 * wave + (lane & 15)] = acc2[r];
+            pr[144 + 32 * wave + (lane & 15)] = acc3[r];
+        }
+        if (more) land(buf ^ 1);        // the other buffer: its last readers passed the barrier of the previous iteration
         __syncthreads();
-        for (int tl = 0; tl < NTILES; ++tl) {
-            const int tile = (tl + chunk) % NTILES;
-            issue_half(tile, 1);
-            products(0, 24);
-            land_half(1);               // columns 96..191: the previous tile's second half was multiplied before the last barrier
-            __syncthreads();
-            if (tl + 1 < NTILES) issue_half((tile + 1) % NTILES, 0);
-            products(24, 48);
-            if (tl + 1 < NTILES) land_half(0);      // columns 0..95: every wave left them before the barrier above
-            __syncthreads();
-        }
+    }
+}
+
+// One WAVEFRONT per hand, four hands per workgroup: every global request of a hand (3 x 13 partial sums, rotation gradients, axis,
+// rest-joint gradients) leaves in one batch, the PCA basis and the folded regressor are staged in LDS by the whole workgroup.
+// (First version of this round: a workgroup per 16 hands looping ten times over 13 requests, then 45-step loops on global
+// memory -- 24 us for 8 workgroups, 28 us for 256: a chain of round trips.)
+constexpr int FH = 4;
+__global__ __launch_bounds__(256) void mano_bwd_finish_kernel(Model m, const float* __restrict__ pk, int ncomp,
+                                                              const float* __restrict__ pose, const float* __restrict__ wsb,
+                                                              const float* __restrict__ part,
+                                                              float* __restrict__ d_pose, float* __restrict__ d_shape, int B) {
+    __shared__ float s_comps[45 * 45], s_js[480];
+    __shared__ float s_dR[FH][144], s_ax[FH][48], s_dax[FH][48], s_djt[FH][48], s_out[FH][BL_ROWS], s_pose[FH][48];
+    const int t = threadIdx.x, lane = t & 63, hl = t >> 6, h = blockIdx.x * FH + hl;
+    const bool live = h < B;
+    const float* o = wsb + (long long)(live ? h : 0) * BW_STRIDE + NCP;
+    // partial sums of the hand: columns lane and 64 + lane whole (13 tiles); columns 128 + (lane & 31) in four k-quarters, of
+    // which the lane's half wave takes two
+    float p[2][NTILES], pq[2][NTILES], rr[3], ps = 0.f, hm = 0.f, dj = 0.f;
+    const int c32 = lane & 31, qh = lane >> 5;
+#pragma unroll
+    for (int tl = 0; tl < NTILES; ++tl) {
+        const float* pr = part + ((long long)tl * B + (live ? h : 0)) * PART_W;
+        p[0][tl] = live ? pr[lane] : 0.f;
+        p[1][tl] = live ? pr[64 + lane] : 0.f;
+        pq[0][tl] = live ? pr[128 + 32 * (2 * qh) + c32] : 0.f;
+        pq[1][tl] = live ? pr[128 + 32 * (2 * qh + 1) + c32] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) rr[u] = (live && lane + 64 * u < 144) ? o[lane + 64 * u] : 0.f;
+    if (live && lane < 48) dj = o[192 + lane];
+    if (ncomp > 0) {
+        if (live && lane < ncomp) ps = pose[(long long)h * ncomp + lane];
+        if (lane < 45) hm = m.hands_mean[lane];
+        for (int i = t; i < ncomp * 45; i += 256) s_comps[i] = m.comps[i];
+    }
+    for (int i = t; i < 480; i += 256) s_js[i] = pk[PK_JS + i];
+    {       // tile order, then quarter order: deterministic
+        float a0 = p[0][0], a1 = p[1][0], q0 = pq[0][0], q1 = pq[1][0];
+#pragma unroll
+        for (int tl = 1; tl < NTILES; ++tl) { a0 += p[0][tl]; a1 += p[1][tl]; q0 += pq[0][tl]; q1 += pq[1][tl]; }
+        float q = q0 + q1;
+        q += __shfl_xor(q, 32, 64);
+        s_out[hl][lane] = a0;
+        s_out[hl][64 + lane] = a1;
+        if (qh == 0) s_out[hl][128 + c32] = q;
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+        if (lane + 64 * u < 144) s_dR[hl][lane + 64 * u] = rr[u];
+    if (lane < 48) { s_pose[hl][lane] = ps; s_djt[hl][lane] = dj; }
+    __syncthreads();
+    if (ncomp > 0 && lane < 48) {       // axis-angle = hands_mean + pose x comps (for the Rodrigues backward; ready at the next barrier)
+        float a = hm;
+        if (lane < 45)
+            for (int c = 0; c < ncomp; ++c) a += s_pose[hl][c] * s_comps[c * 45 + lane];
+        s_ax[hl][lane] = a;
+    }
+    if (lane < 10 && live && d_shape) {
+        float a = s_out[hl][NPF + lane];
+        for (int q = 0; q < 48; ++q) a += s_djt[hl][q] * s_js[q * 10 + lane];      // + Js^T djt
+        d_shape[(long long)h * 10 + lane] = a;
+    }
+    if (d_pose == nullptr) return;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int e = lane + 64 * u;
+        if (e < NPF) s_dR[hl][9 + e] += s_out[hl][e];
+    }
+    __syncthreads();
+    if (ncomp > 0) {
+        if (lane < 15) rodrigues_bwd(&s_ax[hl][lane * 3], &s_dR[hl][(lane + 1) * 9], &s_dax[hl][lane * 3]);
         __syncthreads();
-        // C/D layout: column = lane & 15 (basis row within the block), row = 4 * (lane >> 4) + r (hand)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int blk = wave + 4 * j, col = blk * 16 + (lane & 15);
-            if (blk >= 10) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s_out[(4 * (lane >> 4) + r) * BL_ROWS + col] = acc[j][r];
-        }
-        for (int i = t; i < HC * 192; i += 256) {
-            const int hl = i / 192, e = i - hl * 192;
-            if (e < 144) s_dR[hl * 144 + e] = (h0 + hl < B) ? wsb[(long long)(h0 + hl) * BW_STRIDE + NCP + e] : 0.f;
-        }
-        if (ncomp > 0) {        // axis-angle = hands_mean + pose x comps of the chunk's hands (for the Rodrigues backward)
-            for (int i = t; i < HC * 48; i += 256) {
-                const int hl = i / 48, e = i - hl * 48;
-                float a = 0.f;
-                if (e < 45 && h0 + hl < B) {
-                    a = m.hands_mean[e];
-                    const float* ph = pose + (long long)(h0 + hl) * ncomp;
+        if (lane < ncomp && live) {
+            float a = 0.f;
 #pragma unroll 15
-                    for (int c = 0; c < ncomp; ++c) a += ph[c] * m.comps[c * 45 + e];      // (unrolled: the loads of 15 steps in flight)
-                }
-                s_ax[i] = a;
-            }
+            for (int k = 0; k < 45; ++k) a += s_dax[hl][k] * s_comps[lane * 45 + k];
+            d_pose[(long long)h * ncomp + lane] = a;
         }
-        for (int i = t; i < HC * 48; i += 256) {
-            const int hl = i / 48, e = i - hl * 48;
-            s_djt[i] = (h0 + hl < B) ? wsb[(long long)(h0 + hl) * BW_STRIDE + NCP + 192 + e] : 0.f;
-        }
-        __syncthreads();
-        for (int i = t; i < HC * 10; i += 256) {
-            const int hl = i / 10, e = i - hl * 10;
-            if (h0 + hl < B && d_shape) {
-                float a = s_out[hl * BL_ROWS + NPF + e];
-                for (int q = 0; q < 48; ++q) a += s_djt[hl * 48 + q] * pk[PK_JS + q * 10 + e];     // + Js^T djt
-                d_shape[(long long)(h0 + hl) * 10 + e] = a;
-            }
-        }
-        if (d_pose) {
-            for (int i = t; i < HC * NPF; i += 256) {
-                const int hl = i / NPF, e = i - hl * NPF;
-                s_dR[hl * 144 + 9 + e] += s_out[hl * BL_ROWS + e];
-            }
-            __syncthreads();
-            if (ncomp > 0) {
-                if (t < HC * 15) {
-                    const int hl = t / 15, jn = t - hl * 15;
-                    rodrigues_bwd(&s_ax[hl * 48 + jn * 3], &s_dR[hl * 144 + (jn + 1) * 9], &s_dax[hl * 48 + jn * 3]);
-                }
-                __syncthreads();
-                for (int i = t; i < HC * ncomp; i += 256) {
-                    const int hl = i / ncomp, c = i - hl * ncomp;
-                    if (h0 + hl >= B) continue;
-                    float a = 0.f;
-                    for (int k = 0; k < 45; ++k) a += s_dax[hl * 48 + k] * m.comps[c * 45 + k];
-                    d_pose[(long long)(h0 + hl) * ncomp + c] = a;
-                }
-            } else {
-                for (int i = t; i < HC * NPF; i += 256) {
-                    const int hl = i / NPF, e = i - hl * NPF;
-                    if (h0 + hl < B) d_pose[(long long)(h0 + hl) * NPF + e] = s_dR[hl * 144 + 9 + e];
-                }
-            }
+    } else if (live) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int e = lane + 64 * u;
+            if (e < NPF) d_pose[(long long)h * NPF + e] = s_dR[hl][9 + e];
         }
     }
 }
@@ -1278,6 +1341,22 @@ Model to_model(const rih_mano_model* m) {
     o.comps = m->comps; o.hands_mean = m->hands_mean; o.shapedirs = m->shapedirs; o.posedirs = m->posedirs;
     o.v_template = m->v_template; o.J_reg = m->J_reg; o.weights = m->weights;
     for (int i = 0; i < 16; ++i) o.parent[i] = m->parent[i];
+    // (model_ok: parent[0] < 0, 0 <= parent[i] < i -- the loops below end)
+    int mx = 0, n = 0;
+    for (int i = 0; i < 16; ++i) {
+        int d = 0;
+        for (int pp = o.parent[i]; pp >= 0 && d < 16; pp = o.parent[pp]) ++d;
+        o.depth[i] = d;
+        if (i > 0 && d > mx) mx = d;
+    }
+    o.depth[16] = mx;
+    for (int p = 0; p < 16; ++p) {
+        o.cstart[p] = n;
+        for (int i = 1; i < 16; ++i)
+            if (o.parent[i] == p && n < 15) o.child[n++] = i;
+    }
+    o.cstart[16] = n;
+    for (int q = n; q < 16; ++q) o.child[q] = 0;
     return o;
 }
 
@@ -1292,7 +1371,8 @@ bool model_ok(const rih_mano_model* m) {
 }  // namespace
 
 extern "C" int64_t rih_mano_ws_floats(int B) { return B > 0 ? (int64_t)B * WS_STRIDE : 0; }
-extern "C" int64_t rih_mano_bwd_ws_floats(int B) { return B > 0 ? (int64_t)B * BW_STRIDE : 0; }
+// per hand: the hand-off of the per-hand kernel (BW_STRIDE) + the 13 tiles' partial sums of the blend products
+extern "C" int64_t rih_mano_bwd_ws_floats(int B) { return B > 0 ? (int64_t)B * (BW_STRIDE + NTILES * PART_W) : 0; }
 
 static long long* g_mano_dbg = nullptr;
 // development aid: device buffer of 13 x 16 int64 that receives phase timestamps of the fused forward (NULL = off)
@@ -1356,6 +1436,7 @@ extern "C" int rih_mano_bwd(const rih_mano_model* m, const float* packed, const 
     if (ncomp < 0 || ncomp > 45 || center_idx >= 21) return RIH_EINVAL;
     if (ncomp > 0 && !m->comps) return RIH_EINVAL;
     if (ws_bwd != nullptr && (!packed || ((uintptr_t)packed & 15) || ((uintptr_t)ws_bwd & 15))) return RIH_EINVAL;
+    if ((uintptr_t)ws & 15) return RIH_EINVAL;          // the per-hand kernel reads the hand's SE3s with 16-byte scalar loads
     const Model mm = to_model(m);
     hipStream_t s = (hipStream_t)stream;
     // ws_bwd == NULL: the one-kernel backward of round 1 (one workgroup per hand does everything; kept for A/B timing)
@@ -1363,8 +1444,19 @@ extern "C" int rih_mano_bwd(const rih_mano_model* m, const float* packed, const 
                        ws, d_root, d_pose, d_shape, d_trans, d_scale, ws_bwd, g_mano_dbg);
     if (ws_bwd != nullptr && (d_pose != nullptr || d_shape != nullptr)) {
         const int nchunks = (B + HC - 1) / HC;
-        hipLaunchKernelGGL(mano_bwd_blend_kernel, dim3(nchunks < 512 ? nchunks : 512), dim3(256), 0, s, mm, packed, ncomp, pose,
-                           ws_bwd, d_pose, d_shape, B);
+        // 13 tiles x groups of chunks: as many groups as keep the launch within one workgroup per CU (LDS: one fits) -- 19 on
+        // 256 CUs; a 20th would put four workgroups into a second round
+        int cus = 0, dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus < 1)
+            cus = 256;
+        int groups = cus / NTILES;
+        if (groups < 1) groups = 1;
+        if (groups > nchunks) groups = nchunks;
+        float* part = ws_bwd + (long long)B * BW_STRIDE;
+        hipLaunchKernelGGL(mano_bwd_blend_kernel, dim3(NTILES, groups), dim3(256), 0, s, packed, ws_bwd, part, B);
+        hipLaunchKernelGGL(mano_bwd_finish_kernel, dim3((B + FH - 1) / FH), dim3(256), 0, s, mm, packed, ncomp, pose, ws_bwd, part,
+                           d_pose, d_shape, B);
     }
     return (int)hipGetLastError();
 }

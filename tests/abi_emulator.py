@@ -985,7 +985,7 @@ class EmulatedLib:
         return 16 * B
 
     def rih_mano_bwd_ws_floats(self, B):
-        return B * (2496 + 240)
+        return B * (2496 + 240 + 13 * 256)
 
     def rih_mano_pack_floats(self):
         return 148 * 2496 + 528

@@ -223,6 +223,12 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     p->multiProcessorCount = e ? std::atoi(e) : 6;
     return hipSuccess;
 }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {
+    const char* e = std::getenv("HIPCPU_CUS");
+    *v = e ? std::atoi(e) : 6;
+    return hipSuccess;
+}
 #include "../hipcpu_gfx950.h"
 
 // shader-clock read of the phase-stamp development aid (csrc/rih_mano.hip): no meaning on the host

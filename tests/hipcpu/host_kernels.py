@@ -41,7 +41,7 @@ def build(force=False):
         o = os.path.join(os.path.dirname(OUT), os.path.basename(s) + ('.exp' if EXPERIMENTS else '') + ('.asan.o' if ASAN else '.o'))
         objs.append(o)
         procs.append(subprocess.Popen([clangxx(), '-x', 'c++', '-std=c++20', '-O1', '-fPIC', '-c', '-I', HERE,
-                                       '-DRIH_EXPERIMENTS=%d' % (1 if EXPERIMENTS else 0)] +
+                                       '-DRIH_EXPERIMENTS=%d' % (1 if EXPERIMENTS else 0), '-DRIH_CONST_AS='] +
                                       (['-fsanitize=address', '-fno-omit-frame-pointer', '-g'] if ASAN else []) + [
                                        '-I', os.path.join(ROOT, 'include'), '-Wno-unused-value', '-Wno-pass-failed', '-o', o, s]))
     for p in procs:

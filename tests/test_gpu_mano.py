@@ -91,6 +91,32 @@ def test_mano_properties_large_batch():
     assert float(j0[:, 9].abs().max()) < 1e-6          # centred on joint 9
 
 
+@pytest.mark.parametrize('B', [300, 4096])
+def test_mano_backward_batch_independence(B):
+    """Backward at the micro-benchmark size through a size-independent property: the gradients of a few hands inside a large batch
+    equal those of the same hands run alone (the tile-major blend kernel walks chunks in groups, the finish kernel adds 13
+    partial sums per hand: a chunk mixed up with another, or a partial of the wrong hand, shows here).  300 hands = 19 chunks = one
+    per group on 256 CUs; 4096 = 14 chunks per group, ragged."""
+    from renderih_amd.manolayer import rodrigues_batch
+    layer = _layer('right', 9, True, False)
+    g = torch.Generator().manual_seed(5)
+    root = rodrigues_batch(torch.randn(B, 3, generator=g)).to(dev())
+    pose, shape = (torch.randn(B, 45, generator=g) * 0.7).to(dev()), torch.randn(B, 10, generator=g).to(dev())
+    wv, wj = torch.randn(B, 778, 3, generator=g).to(dev()), torch.randn(B, 21, 3, generator=g).to(dev())
+    sel = torch.tensor(sorted({0, 15, 16, B // 2 + 1, B - 17, B - 1}))
+
+    def grads(idx):
+        ins = [t[idx].clone().requires_grad_(True) for t in (root, pose, shape)]
+        v, j = layer(*ins)
+        ((v * wv[idx]).sum() + (j * wj[idx]).sum()).backward()
+        return [t.grad for t in ins]
+    full = grads(torch.arange(B))
+    alone = grads(sel)
+    for nm, a, b in zip(('root', 'pose', 'shape'), full, alone):
+        assert torch.isfinite(a).all()
+        assert_close(a[sel.to(a.device)], b, 1e-5, 1e-6, 'grad ' + nm)
+
+
 def test_mano_reads_mutated_shapedirs():
     """Callers flip shapedirs in place after construction (dataset/interhand.py:22-25); forward must see it."""
     from renderih_amd.manolayer import rodrigues_batch

@@ -305,6 +305,12 @@ def test_mano_kernels(B):
     TMANO.test_mano_matches_oracle(B)
 
 
+def test_mano_backward_chunk_groups(monkeypatch):
+    """The tile-major blend kernel with more than one chunk group and a chunk loop: 40 hands = 3 chunks on '26 CUs' = 2 groups."""
+    monkeypatch.setenv('HIPCPU_CUS', '26')
+    TMANO.test_mano_backward_batch_independence(40)
+
+
 def test_mano_kernels_reference_golden():
     TMANO.test_mano_matches_reference_golden('left')
 

@@ -38,5 +38,5 @@ for tile in (0, 1, 12):
 
 raw = buf.cpu()
 b = [int(raw[208 + i]) for i in range(8)]
-bn = ['0 loads/axis', '1 dv_eff+sums', '3 joint side', '3b dv_skin', '4 skinning', '5 dG=W^T M', '6-7 chain', 'hand-off']
+bn = ['0 loads/axis', '1 dv_eff+sums', '3 joint side', '4 skinning', '5 dG=W^T M', '6-7 chain', 'hand-off']      # (until round 4 an extra label shifted the last four)
 print('backward, per-hand kernel (workgroup 0): ' + ' | '.join('%s %d' % (n, b[i + 1] - b[i]) for i, n in enumerate(bn[:7])) + ' | total %d cycles' % (b[7] - b[0]))
