@@ -638,19 +638,44 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
         RIH_STAMP(5);
         // ---- phase 2: v_tpose[16][192] = operand[16][148] x Bmat tile; wave w owns coordinate blocks 3w .. 3w+2 (k-steps of 4)
         floatx4 acc[3];
+        // Round 5: the operands of several k-steps at a time in registers, the next group requested before the products of the
+        // current one.  The compiler's own schedule read ONE k-step ahead -- ds_read, s_waitcnt, v_mfma, 111 times per tile: every
+        // product waited out an LDS round trip (the workgroup is alone on its CU, one wavefront per SIMD, nothing else to run).
         auto blend_steps = [&](int ks0, int ks1) {
+            constexpr int GS = 7;
             const int kq = lane >> 4;                       // row 4 ks + kq: its column blocks sit at block ^ kq (load_tile_192 SWZ)
             const float* a_rd = s_pf + (lane & 15) * LDPF + kq;
             const float* b_rd = s_B + kq * 192 + (lane & 15);
             int cb[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) cb[j] = (wave * 48 + 16 * j) ^ (kq << 4);
-#pragma unroll 4
-            for (int ks = ks0; ks < ks1; ++ks) {
-                const float a = a_rd[4 * ks];
+            float av[2][GS], bv[2][GS][3];
+            auto fetch = [&](int buf, int g0) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b_rd[4 * ks * 192 + cb[j]], acc[j], 0, 0, 0);
+                for (int i = 0; i < GS; ++i) {
+                    const int ks = g0 + i;
+                    if (ks < ks1) {
+                        av[buf][i] = a_rd[4 * ks];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) bv[buf][i][j] = b_rd[4 * ks * 192 + cb[j]];
+                    }
+                }
+            };
+            fetch(0, ks0);
+            int buf = 0;
+#pragma unroll
+            for (int g0 = ks0; g0 < ks1; g0 += GS, buf ^= 1) {
+                if (g0 + GS < ks1) fetch(buf ^ 1, g0 + GS);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < GS; ++i) {
+                    if (g0 + i < ks1) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][i], bv[buf][i][j], acc[j], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
         // C/D layout: column = lane & 15 (coordinate), row = 4 * (lane >> 4) + r (hand)
@@ -752,21 +777,29 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
             __syncthreads();
             for (int tl = 0; tl < NTILES; ++tl) {
                 const int tile = (tl + (int)blockIdx.x) % NTILES;
+                // (stamps 8..14: the steps of the third tile, tools/mano_phases.py)
+                if (tl == 2) RIH_STAMP(8);
                 issue_half(tile, 1);
                 load_weights(tile);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
                 blend_steps(0, KS0);
+                if (tl == 2) RIH_STAMP(9);
                 land_half(1);           // rows 76..147: the previous tile's second half was finished before its skinning
                 __syncthreads();
+                if (tl == 2) RIH_STAMP(10);
                 if (tl + 1 < NTILES) issue_half((tile + 1) % NTILES, 0);
                 blend_steps(KS0, KP / 4);
+                if (tl == 2) RIH_STAMP(11);
                 park_vtpose();
                 __syncthreads();        // v_tpose complete; every wave is done with rows 0..75
                 if (tl == 0) RIH_STAMP(6);
+                if (tl == 2) RIH_STAMP(12);
                 skin(tile);
+                if (tl == 2) RIH_STAMP(13);
                 if (tl + 1 < NTILES) land_half(0);
                 __syncthreads();        // next tile's first half landed; the skinning is done with the v_tpose tile
+                if (tl == 2) RIH_STAMP(14);
             }
         }
         RIH_STAMP(7);

@@ -36,6 +36,10 @@ for tile in (0, 1, 12):
     d = [int(s[tile, i + 1] - s[tile, i]) for i in range(7)]
     print('tile %2d: ' % tile + ' | '.join('%s %d' % (n, x) for n, x in zip(names, d)) + ' | chunk total %d cycles' % (int(s[tile, 7] - s[tile, 0])))
 
+tn = ['issue + weights + blend 1st half', 'land 2nd half + barrier', 'issue next + blend 2nd half', 'park + barrier', 'skin', 'land next 1st half + barrier']
+d = [int(s[0, 9 + i] - s[0, 8 + i]) for i in range(6)]
+print('hand-major forward, third tile of workgroup 0: ' + ' | '.join('%s %d' % (n, x) for n, x in zip(tn, d)) + ' | tile total %d cycles' % (int(s[0, 14] - s[0, 8])))
+
 raw = buf.cpu()
 b = [int(raw[208 + i]) for i in range(8)]
 bn = ['0 loads/axis', '1 dv_eff+sums', '3 joint side', '4 skinning', '5 dG=W^T M', '6-7 chain', 'hand-off']      # (until round 4 an extra label shifted the last four)
