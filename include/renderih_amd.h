@@ -576,7 +576,7 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
  * this order: gemm desc, mano model, mesh topo, hconv desc, reduce desc, pack desc, ln final desc, adam entry, absmax desc,
  * presplit desc, conv3 desc, h2 desc, panel desc (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it
  * mis-laid-out structs. */
-#define RIH_ABI_VERSION 16
+#define RIH_ABI_VERSION 17
 #define RIH_ABI_NSIZES 13
 int rih_version(void);
 int rih_abi_sizes(int32_t* out10);

@@ -261,7 +261,7 @@ EXPERIMENT_SIGNATURES = {
 }
 HAS_EXPERIMENTS = False
 
-ABI_VERSION = 16     # = RIH_ABI_VERSION of include/renderih_amd.h
+ABI_VERSION = 17     # = RIH_ABI_VERSION of include/renderih_amd.h
 
 _lib = None
 
