@@ -498,7 +498,8 @@ int rih_cheby_bwd(const float* dy, const int32_t* t_indptr, const int32_t* t_ind
  *   shape[B][10], trans[B][3] or NULL, scale[B] or NULL.  Outputs v[B][778][3], j[B][21][3].
  * packed: >= rih_mano_pack_floats() floats (16-byte aligned) written by rih_mano_pack from the model buffers: the blend
  *   bases as one k-major matrix [148][2496] (posedirs | shapedirs | v_template, coordinates padded to 13 tiles of 192) and
- *   the joint regressor folded onto template and shape basis.  Re-pack whenever a model buffer changes (the reference's
+ *   the joint regressor folded onto template and shape basis, and (ABI 17) a compact [148][48] copy of the basis columns of the
+ *   13 special vertices (finger tips, new_skel).  Re-pack whenever a model buffer changes (the reference's
  *   callers mutate shapedirs in place, dataset/interhand.py:22-25).
  * rih_mano_fwd variant 0: ONE fused launch (workgroup = 64-vertex tile of the packed basis pinned in LDS x group of hand
  *   chunks; pose chain per chunk, blend GEMM on v_mfma_f32_16x16x4_f32, skinning).  ws may be NULL (inference: only v and j

@@ -326,7 +326,8 @@ constexpr int KP = 148;                 // 135 pose features + 10 betas + 1 (tem
 constexpr int NCP = NTILES * 192;       // 2496 padded coordinates
 constexpr int PK_JT = KP * NCP;         // Jt[16][3]
 constexpr int PK_JS = PK_JT + 48;       // Js[16][3][10]
-constexpr int PK_FLOATS = PK_JS + 480;
+constexpr int PK_SP = PK_JS + 480;      // [KP][48]: the basis columns of the 13 special vertices' 39 coordinates, compact (9 zero columns)
+constexpr int PK_FLOATS = PK_SP + KP * 48;
 constexpr int BW_STRIDE = NCP + 240;          // per-hand hand-off of the split backward: dv_tpose | dR[144] | (48 unused) | djt[48]
 
 __global__ void mano_pack_basis_kernel(Model m, float* __restrict__ pk) {
@@ -343,6 +344,15 @@ __global__ void mano_pack_basis_kernel(Model m, float* __restrict__ pk) {
     }
 }
 // one wavefront per output: Jt[j][c] = sum_v J_reg[j][v] v_template[v][c];  Js[j][c][s] = sum_v J_reg[j][v] shapedirs[v][c][s]
+// the basis columns of the special vertices gathered into a compact [KP][48] matrix (after mano_pack_basis_kernel): phase 1d of the
+// fused forward used to gather them from the big matrix -- 37 requests per lane at a 10 KB stride, ~24 cache lines per instruction
+__global__ void mano_pack_special_kernel(float* __restrict__ pk) {
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < KP * 48; idx += gridDim.x * blockDim.x) {
+        const int k = idx / 48, n = idx - k * 48;
+        pk[PK_SP + idx] = (n < 39) ? pk[(long long)k * NCP + c_special[n / 3] * 3 + n % 3] : 0.f;
+    }
+}
+
 __global__ void mano_pack_joints_kernel(Model m, float* __restrict__ pk) {
     const int o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -404,6 +414,69 @@ __device__ __forceinline__ void load_tile_192(float* __restrict__ dst, const flo
     }
 }
 
+// Skinning FMAs with the SE3 element as a ROW-BROADCAST operand (DPP row_newbcast: every row of 16 lanes reads lane K of its own
+// row): T[c] += G[(j, c)] * w[j] for four joints j and the twelve elements c, where the 48 values G[(j, c)] of the four joints sit in
+// three registers G0..G2 whose lane l holds flat element 16 r + (l & 15) -- the same sixteen values in each of the four rows.  One
+// v_fmac_f32_dpp per product: no LDS read, no move.  (The compiler does not fold __builtin_amdgcn_update_dpp into the FMA -- it
+// emits v_mov_b32_dpp + v_fma -- so the block is inline assembly; the leading s_nop covers the two wait states a DPP read needs
+// after a VALU write of its source, which the hazard recognizer cannot see inside an asm statement.)  The host build of the test
+// harness supplies the same arithmetic with an emulated lane exchange.
+#ifndef RIH_SKIN_GROUP
+#define RIH_SKIN_GROUP(T, G0, G1, G2, W0, W1, W2, W3)                                                                             \
+    asm("s_nop 1\n"                                                                                                               \
+        "v_fmac_f32_dpp %0, %12, %15 row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %1, %12, %15 row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %2, %12, %15 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %3, %12, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %4, %12, %15 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %5, %12, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %6, %12, %15 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %7, %12, %15 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %8, %12, %15 row_newbcast:8 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %9, %12, %15 row_newbcast:9 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %10, %12, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %11, %12, %15 row_newbcast:11 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %0, %12, %16 row_newbcast:12 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %1, %12, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %2, %12, %16 row_newbcast:14 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %3, %12, %16 row_newbcast:15 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %4, %13, %16 row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %5, %13, %16 row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %6, %13, %16 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %7, %13, %16 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %8, %13, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %9, %13, %16 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %10, %13, %16 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %11, %13, %16 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %0, %13, %17 row_newbcast:8 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %1, %13, %17 row_newbcast:9 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %2, %13, %17 row_newbcast:10 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %3, %13, %17 row_newbcast:11 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %4, %13, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %5, %13, %17 row_newbcast:13 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %6, %13, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %7, %13, %17 row_newbcast:15 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %8, %14, %17 row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %9, %14, %17 row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %10, %14, %17 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %11, %14, %17 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %0, %14, %18 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %1, %14, %18 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %2, %14, %18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %3, %14, %18 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %4, %14, %18 row_newbcast:8 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %5, %14, %18 row_newbcast:9 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %6, %14, %18 row_newbcast:10 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %7, %14, %18 row_newbcast:11 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %8, %14, %18 row_newbcast:12 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %9, %14, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %10, %14, %18 row_newbcast:14 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %11, %14, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n"                                                                                                                         \
+        : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5]), "+v"(T[6]), "+v"(T[7]), "+v"(T[8]), "+v"(T[9]),   \
+          "+v"(T[10]), "+v"(T[11])                                                                                                 \
+        : "v"(G0), "v"(G1), "v"(G2), "v"(W0), "v"(W1), "v"(W2), "v"(W3))
+#endif
+
 constexpr int HC = 16;                  // hands per chunk = one 16-row MFMA block
 constexpr int LDPF = 149;               // odd row stride of the pose-feature operand: conflict-free column reads
 constexpr int GST = 200;                // per-hand SE3s (16 x 12) + post (8)
@@ -424,6 +497,7 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
     __shared__ __attribute__((aligned(16))) float smem[FUSED_LDS_FLOATS];
     // phase timestamps (shader clock) of the first chunk of the workgroups (tile, group 0): development aid, dbg == NULL otherwise
 #define RIH_STAMP(i_) do { if (dbg != nullptr && threadIdx.x == 0 && blockIdx.y == 0 && chunk == 0) dbg[blockIdx.x * 16 + (i_)] = clock64(); } while (0)
+#define RIH_STAMP2(i_) do { if (dbg != nullptr && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && chunk == 0) dbg[16 + (i_)] = clock64(); } while (0)
     float* s_B = smem;                          // [KP][192] basis tile
     float* s_pf = s_B + KP * 192;               // [HC][LDPF] pose feature | beta | 1 | 0 0
     float* s_G = s_pf + HC * LDPF;              // [HC][GST]
@@ -452,13 +526,24 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
     auto load_weights = [&](int tile) {
         const int vv = tile * TILE_V + lane;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) wgt[j] = (vv < NV) ? m.weights[vv * NJ + j] : 0.f;
+        for (int q = 0; q < 4; ++q) {       // the vertex's 16 weights: four 16-byte requests (rounds 1-4: sixteen dword loads)
+            const floatx4 w4 = (vv < NV) ? *reinterpret_cast<const floatx4*>(m.weights + vv * NJ + 4 * q) : floatx4{0.f, 0.f, 0.f, 0.f};
+            wgt[4 * q] = w4.x; wgt[4 * q + 1] = w4.y; wgt[4 * q + 2] = w4.z; wgt[4 * q + 3] = w4.w;
+        }
     };
     if (!HM) load_weights(tile_fixed);
 
     const int nchunks = (B + HC - 1) / HC;
     for (int chunk = HM ? blockIdx.x : blockIdx.y; chunk < nchunks; chunk += HM ? gridDim.x : gridDim.y) {
         const int h0 = chunk * HC;
+        // the basis columns of the special vertices (phase 1d) are requested NOW: they depend on nothing, and behind phases 1a-1c
+        // their (cold) round trip is hidden -- issued in 1d itself they were 14 k of the 20 k cycles of that phase
+        float bv_sp[KP / 4];
+        if (need_special && wave < 3) {
+            const int kq = lane >> 4, n = wave * 16 + (lane & 15);
+#pragma unroll
+            for (int ks = 0; ks < KP / 4; ++ks) bv_sp[ks] = pk[PK_SP + (4 * ks + kq) * 48 + n];       // (compact copy: rih_mano_pack)
+        }
         __syncthreads();                        // previous chunk's skinning is done with s_G / s_scr
         RIH_STAMP(0);
         // ---- phase 1a: axis-angle = hands_mean + pose x comps as a 16 x 48 x 48 product on the f32 MFMA (waves 0..2 own 16
@@ -562,36 +647,53 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
         __syncthreads();
         RIH_STAMP(3);
         // ---- phase 1d: the 13 special vertices (5 tips + 8 new_skel): blend on the MFMA with the basis columns read straight
-        //      from the packed matrix (waves 0..2 own 16 of the 39 coordinates each), then skinning
+        //      from their compact copy in the packed buffer (waves 0..2 own 16 of the 39 coordinates each), then skinning
         if (need_special) {
             if (wave < 3) {
                 const int kq = lane >> 4, n = wave * 16 + (lane & 15);
-                const int vc = (n < 39) ? c_special[n / 3] * 3 + n % 3 : 0;
-                float bv[KP / 4];
-#pragma unroll
-                for (int ks = 0; ks < KP / 4; ++ks) bv[ks] = pk[(long long)(4 * ks + kq) * NCP + vc];
                 const float* a_rd = s_pf + (lane & 15) * LDPF + kq;
+                float av[KP / 4];
+#pragma unroll
+                for (int ks = 0; ks < KP / 4; ++ks) av[ks] = a_rd[4 * ks];      // (all LDS reads first: see blend_steps)
                 floatx4 sp = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < KP / 4; ++ks) sp = __builtin_amdgcn_mfma_f32_16x16x4f32(a_rd[4 * ks], bv[ks], sp, 0, 0, 0);
+                for (int ks = 0; ks < KP / 4; ++ks) sp = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv_sp[ks], sp, 0, 0, 0);
                 if (n < 39)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s_scr[(4 * kq + r) * SCR + S_SPT + n] = sp[r];
             }
+            RIH_STAMP2(0);
             __syncthreads();
+            RIH_STAMP2(1);
             for (int i = t; i < HC * 13; i += 256) {
                 const int hl = i / 13, q = i - hl * 13, vv = c_special[q];
+                // the vertex's sixteen weights in four 16-byte requests up front (the joint loop used to wait for one dword load
+                // per joint: sixteen L2 round trips in a row, most of the 20 k cycles this phase took), the SE3s as 16-byte LDS reads
+                float wv[NJ];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const floatx4 w4 = *reinterpret_cast<const floatx4*>(m.weights + vv * NJ + 4 * u);
+                    wv[4 * u] = w4.x; wv[4 * u + 1] = w4.y; wv[4 * u + 2] = w4.z; wv[4 * u + 3] = w4.w;
+                }
                 float T[12];
+#pragma unroll
                 for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const float wj = m.weights[vv * NJ + j];
-                    for (int e = 0; e < 12; ++e) T[e] += wj * s_G[hl * GST + j * 12 + e];
+                    const float* Gj = &s_G[hl * GST + j * 12];
+                    const float4 g0 = *reinterpret_cast<const float4*>(Gj), g1 = *reinterpret_cast<const float4*>(Gj + 4),
+                                 g2 = *reinterpret_cast<const float4*>(Gj + 8);
+                    T[0] += wv[j] * g0.x; T[1] += wv[j] * g0.y; T[2] += wv[j] * g0.z; T[3] += wv[j] * g0.w;
+                    T[4] += wv[j] * g1.x; T[5] += wv[j] * g1.y; T[6] += wv[j] * g1.z; T[7] += wv[j] * g1.w;
+                    T[8] += wv[j] * g2.x; T[9] += wv[j] * g2.y; T[10] += wv[j] * g2.z; T[11] += wv[j] * g2.w;
                 }
                 const float* x = &s_scr[hl * SCR + S_SPT + q * 3];
                 for (int r = 0; r < 3; ++r)
                     s_scr[hl * SCR + S_SP + q * 3 + r] = T[r * 4] * x[0] + T[r * 4 + 1] * x[1] + T[r * 4 + 2] * x[2] + T[r * 4 + 3];
             }
+            RIH_STAMP2(2);
             __syncthreads();
+            RIH_STAMP2(3);
             for (int i = t; i < HC * 15; i += 256) {
                 const int hl = i / 15, e = i - hl * 15;
                 s_scr[hl * SCR + S_SRC + 48 + e] = s_scr[hl * SCR + S_SP + e];       // tips = special[0..4]
@@ -689,45 +791,63 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
         auto skin = [&](int tile) {
             const int v = tile * TILE_V + lane;
             const bool valid = v < NV;
-            for (int hl = wave; hl < HC; hl += 4) {
-                const int h = h0 + hl;
-                if (h >= B) break;                                  // wave-uniform
+            // Round 5: the hand's 192 SE3 elements in twelve registers (lane l holds element 16 r + (l & 15)); the products take
+            // them as DPP row-broadcast operands (RIH_SKIN_GROUP).  Rounds 1-4 fetched every element for every lane from LDS --
+            // 48 broadcast ds_read_b128 per hand, 192 per wavefront and tile at 8 cycles of the CU's one LDS pipe each: 6.1 k of
+            // the 7.8 k cycles the skinning of a tile took (tools/mano_phases.py).
+            // (measured and not kept on the LDS form in round 4: v_pk_fma_f32 121 -> 128.6 us at 4096 hands; T as a
+            // [64 vertices x 16 joints] x [16 x 12] product on the f32 MFMA with a quad transpose-reduce 147-150 us
+            // (profiles/r04/c19, c20); round 5: SE3 reads pipelined through registers / lane = (hand, vertex) with the SE3s in
+            // registers: both beyond 512 registers, 128-130 us (profiles/r05/mano/c15_forward_experiments_stdout.txt))
+            // The operands of the NEXT hand (twelve SE3 registers, three v_tpose coordinates, seven post-transform scalars) are
+            // requested before the products of the current one: one wavefront per SIMD, nothing else hides an LDS round trip.
+            float g[2][12], vt[2][3], post[2][7];
+            auto fetch = [&](int buf, int hl) {
                 const float* G = &s_G[hl * GST];
-                // (six two-component FMAs per joint -- v_pk_fma_f32 -- instead of these twelve were measured in round 4:
-                // 121 -> 128.6 us at 4096 hands; and T as a [64 vertices x 16 joints] x [16 x 12] product on the f32 MFMA with a
-                // quad transpose-reduce behind it, which takes the 48 broadcast ds_read_b128 per hand away: 121 -> 147-150 us
-                // (profiles/r04/c19, c20).  The scalar form stays.)
+#pragma unroll
+                for (int r = 0; r < 12; ++r) g[buf][r] = G[16 * r + (lane & 15)];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) vt[buf][k] = s_scr[hl * 192 + lane * 3 + k];
+#pragma unroll
+                for (int e = 0; e < 7; ++e) post[buf][e] = G[192 + e];
+            };
+            auto hand = [&](int buf, int hl) {
+                const int h = h0 + hl;
                 float T[12];
 #pragma unroll
                 for (int e = 0; e < 12; ++e) T[e] = 0.f;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const float4 g0 = *reinterpret_cast<const float4*>(G + j * 12);
-                    const float4 g1 = *reinterpret_cast<const float4*>(G + j * 12 + 4);
-                    const float4 g2 = *reinterpret_cast<const float4*>(G + j * 12 + 8);
-                    T[0] += wgt[j] * g0.x; T[1] += wgt[j] * g0.y; T[2] += wgt[j] * g0.z; T[3] += wgt[j] * g0.w;
-                    T[4] += wgt[j] * g1.x; T[5] += wgt[j] * g1.y; T[6] += wgt[j] * g1.z; T[7] += wgt[j] * g1.w;
-                    T[8] += wgt[j] * g2.x; T[9] += wgt[j] * g2.y; T[10] += wgt[j] * g2.z; T[11] += wgt[j] * g2.w;
-                }
-                const float* post = G + 192;
-                const float vt0 = s_scr[hl * 192 + lane * 3], vt1 = s_scr[hl * 192 + lane * 3 + 1], vt2 = s_scr[hl * 192 + lane * 3 + 2];
+                RIH_SKIN_GROUP(T, g[buf][0], g[buf][1], g[buf][2], wgt[0], wgt[1], wgt[2], wgt[3]);
+                RIH_SKIN_GROUP(T, g[buf][3], g[buf][4], g[buf][5], wgt[4], wgt[5], wgt[6], wgt[7]);
+                RIH_SKIN_GROUP(T, g[buf][6], g[buf][7], g[buf][8], wgt[8], wgt[9], wgt[10], wgt[11]);
+                RIH_SKIN_GROUP(T, g[buf][9], g[buf][10], g[buf][11], wgt[12], wgt[13], wgt[14], wgt[15]);
+                const float vt0 = vt[buf][0], vt1 = vt[buf][1], vt2 = vt[buf][2];
+                const float* ps = post[buf];
                 // (the three dword stores per output at a 12-byte stride stay: sending the 192 consecutive floats of a tile back
                 // through LDS to leave as 8-byte stores of consecutive lanes was measured in round 4 -- 121 -> 184 us at 4096
                 // hands: three dependent LDS round trips per hand cost far more than the scattered stores)
-                if (valid) {
-                    const float x = T[0] * vt0 + T[1] * vt1 + T[2] * vt2 + T[3] - post[0];
-                    const float y = T[4] * vt0 + T[5] * vt1 + T[6] * vt2 + T[7] - post[1];
-                    const float z = T[8] * vt0 + T[9] * vt1 + T[10] * vt2 + T[11] - post[2];
+                if (valid && h < B) {
+                    const float x = T[0] * vt0 + T[1] * vt1 + T[2] * vt2 + T[3] - ps[0];
+                    const float y = T[4] * vt0 + T[5] * vt1 + T[6] * vt2 + T[7] - ps[1];
+                    const float z = T[8] * vt0 + T[9] * vt1 + T[10] * vt2 + T[11] - ps[2];
                     float* o = vout + ((long long)h * NV + v) * 3;
-                    o[0] = x * post[3] + post[4];
-                    o[1] = y * post[3] + post[5];
-                    o[2] = z * post[3] + post[6];
+                    o[0] = x * ps[3] + ps[4];
+                    o[1] = y * ps[3] + ps[5];
+                    o[2] = z * ps[3] + ps[6];
                     if (ws != nullptr) {
                         float* w = ws + (long long)h * WS_STRIDE;
                         w[OFF_VT + v * 3 + 0] = vt0; w[OFF_VT + v * 3 + 1] = vt1; w[OFF_VT + v * 3 + 2] = vt2;
                         w[OFF_VSC + v * 3 + 0] = x; w[OFF_VSC + v * 3 + 1] = y; w[OFF_VSC + v * 3 + 2] = z;
                     }
                 }
+            };
+            fetch(0, wave);
+#pragma unroll 1
+            for (int hp = 0; hp < HC / 8; ++hp) {           // two hands per iteration: the register sets alternate statically
+                const int hl = wave + 8 * hp;
+                fetch(1, hl + 4);
+                hand(0, hl);
+                if (hp + 1 < HC / 8) fetch(0, hl + 8);
+                hand(1, hl + 4);
             }
         };
         if (!HM) {
@@ -747,16 +867,22 @@ __global__ __launch_bounds__(256) void mano_fused_kernel(Model m, const float* _
             // round trips load -> blend -> skin per tile (13 x ~9 us of a 127 us forward at 4096 hands) loses its load link.
             constexpr int H0 = 76, KS0 = H0 / 4, NHR = 15;          // 76 x 48 = 3648 16-byte items = 14.25 per thread
             floatx4 hr[NHR];
+            // a thread's items of a half tile: item i = t + 256 u -> row i / 48, 16-byte column i % 48 -- the same for every
+            // tile and both halves, so the source offsets are computed once per chunk (they were recomputed, with their 64-bit
+            // address arithmetic, 30 times per tile)
+            int src_off[NHR];
+#pragma unroll
+            for (int u = 0; u < NHR; ++u) {
+                const int i = t + 256 * u, k = i / 48, q = i - k * 48;
+                src_off[u] = k * NCP + 4 * q;
+            }
             auto issue_half = [&](int tile, int half) {
-                const int r0 = half ? H0 : 0, total = (half ? KP - H0 : H0) * 48;
+                const int total = (half ? KP - H0 : H0) * 48;
+                const float* src = pk + (half ? H0 : 0) * NCP + tile * 192;
 #pragma unroll
                 for (int u = 0; u < NHR; ++u) {
-                    const int i = t + 256 * u;
                     hr[u] = floatx4{0.f, 0.f, 0.f, 0.f};
-                    if (i < total) {
-                        const int k = i / 48, q = i - k * 48;
-                        hr[u] = *reinterpret_cast<const floatx4*>(pk + (long long)(r0 + k) * NCP + tile * 192 + 4 * q);
-                    }
+                    if (t + 256 * u < total) hr[u] = *reinterpret_cast<const floatx4*>(src + src_off[u]);
                 }
             };
             auto land_half = [&](int half) {
@@ -1419,6 +1545,7 @@ extern "C" int rih_mano_pack(const rih_mano_model* m, float* packed, void* strea
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(mano_pack_basis_kernel, dim3(1024), dim3(256), 0, s, mm, packed);
     hipLaunchKernelGGL(mano_pack_joints_kernel, dim3(132), dim3(256), 0, s, mm, packed);
+    hipLaunchKernelGGL(mano_pack_special_kernel, dim3(28), dim3(256), 0, s, packed);
     return (int)hipGetLastError();
 }
 

@@ -988,7 +988,7 @@ class EmulatedLib:
         return B * (2496 + 240 + 13 * 256)
 
     def rih_mano_pack_floats(self):
-        return 148 * 2496 + 528
+        return 148 * 2496 + 528 + 148 * 48
 
     def rih_mano_pack(self, mref, packed, stream):
         return 0            # the emulator evaluates the layer from the model buffers directly

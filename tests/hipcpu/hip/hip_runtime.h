@@ -201,6 +201,24 @@ static inline T __shfl_xor(T v, int mask, int width = 64) {
     hipcpu::wave_barrier();
     return r;
 }
+// DPP row_newbcast:K of csrc/rih_mano.hip's skinning block: every lane reads lane K of its own row of 16
+static inline float hipcpu_row_newbcast(float v, int k) {
+    std::memcpy(hipcpu::xchg_slot(hipcpu::S().cur->flat), &v, sizeof(float));
+    hipcpu::wave_barrier();
+    float r;
+    std::memcpy(&r, hipcpu::xchg_slot(hipcpu::wave_base() + ((hipcpu::lane() & ~15) | k)), sizeof(float));
+    hipcpu::wave_barrier();
+    return r;
+}
+#define RIH_SKIN_GROUP(T, G0, G1, G2, W0, W1, W2, W3)                                                  \
+    do {                                                                                               \
+        const float g_[3] = {G0, G1, G2}, w_[4] = {W0, W1, W2, W3};                                    \
+        for (int jj_ = 0; jj_ < 4; ++jj_)                                                              \
+            for (int c_ = 0; c_ < 12; ++c_) {                                                          \
+                const int f_ = jj_ * 12 + c_;                                                          \
+                T[c_] = __builtin_fmaf(hipcpu_row_newbcast(g_[f_ >> 4], f_ & 15), w_[jj_], T[c_]);     \
+            }                                                                                          \
+    } while (0)
 static inline int __builtin_amdgcn_readfirstlane_emul(int v) {
     std::memcpy(hipcpu::xchg_slot(hipcpu::S().cur->flat), &v, sizeof(int));
     hipcpu::wave_barrier();

@@ -36,6 +36,8 @@ for tile in (0, 1, 12):
     d = [int(s[tile, i + 1] - s[tile, i]) for i in range(7)]
     print('tile %2d: ' % tile + ' | '.join('%s %d' % (n, x) for n, x in zip(names, d)) + ' | chunk total %d cycles' % (int(s[tile, 7] - s[tile, 0])))
 
+d1 = [int(s[1, i]) for i in range(4)]
+print('phase 1d of workgroup 0: blend of the special coordinates %d | barrier %d | their skinning %d | barrier %d | tips copy + barrier %d' % (d1[0] - int(s[0, 3]), d1[1] - d1[0], d1[2] - d1[1], d1[3] - d1[2], int(s[0, 4]) - d1[3]))
 tn = ['issue + weights + blend 1st half', 'land 2nd half + barrier', 'issue next + blend 2nd half', 'park + barrier', 'skin', 'land next 1st half + barrier']
 d = [int(s[0, 9 + i] - s[0, 8 + i]) for i in range(6)]
 print('hand-major forward, third tile of workgroup 0: ' + ' | '.join('%s %d' % (n, x) for n, x in zip(tn, d)) + ' | tile total %d cycles' % (int(s[0, 14] - s[0, 8])))
