@@ -4,7 +4,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 R=$(pwd)
-O=gpurun_out/r5final; mkdir -p $O
+O=gpurun_out/${OUT:-r5final}; mkdir -p $O
 run() { n=$1; shift; echo "== $n: $*"; ( time timeout ${T:-900} "$@" ) > $O/$n.log 2>&1; echo "   exit $?"; grep '^{' $O/$n.log | tail -1 | cut -c1-260; }
 T=1500 run pytest_gpu python -m pytest tests -q -m gpu -x
 tail -4 $O/pytest_gpu.log | cut -c1-200
