@@ -201,24 +201,23 @@ static inline T __shfl_xor(T v, int mask, int width = 64) {
     hipcpu::wave_barrier();
     return r;
 }
-// DPP row_newbcast:K of csrc/rih_mano.hip's skinning block: every lane reads lane K of its own row of 16
-static inline float hipcpu_row_newbcast(float v, int k) {
-    std::memcpy(hipcpu::xchg_slot(hipcpu::S().cur->flat), &v, sizeof(float));
+// DPP row_newbcast:K of csrc/rih_mano.hip's skinning block: every lane reads lane K of its own row of 16.  One exchange per
+// block of 48 products (the three registers of the block published together), not one per product.
+static inline void hipcpu_skin_group(float* T, float g0, float g1, float g2, float w0, float w1, float w2, float w3) {
+    const float mine[3] = {g0, g1, g2}, w_[4] = {w0, w1, w2, w3};
+    std::memcpy(hipcpu::xchg_slot(hipcpu::S().cur->flat), mine, sizeof(mine));
     hipcpu::wave_barrier();
-    float r;
-    std::memcpy(&r, hipcpu::xchg_slot(hipcpu::wave_base() + ((hipcpu::lane() & ~15) | k)), sizeof(float));
+    const int row0 = hipcpu::wave_base() + (hipcpu::lane() & ~15);
+    for (int jj = 0; jj < 4; ++jj)
+        for (int c = 0; c < 12; ++c) {
+            const int f = jj * 12 + c;
+            float g[3];
+            std::memcpy(g, hipcpu::xchg_slot(row0 + (f & 15)), sizeof(g));
+            T[c] = __builtin_fmaf(g[f >> 4], w_[jj], T[c]);
+        }
     hipcpu::wave_barrier();
-    return r;
 }
-#define RIH_SKIN_GROUP(T, G0, G1, G2, W0, W1, W2, W3)                                                  \
-    do {                                                                                               \
-        const float g_[3] = {G0, G1, G2}, w_[4] = {W0, W1, W2, W3};                                    \
-        for (int jj_ = 0; jj_ < 4; ++jj_)                                                              \
-            for (int c_ = 0; c_ < 12; ++c_) {                                                          \
-                const int f_ = jj_ * 12 + c_;                                                          \
-                T[c_] = __builtin_fmaf(hipcpu_row_newbcast(g_[f_ >> 4], f_ & 15), w_[jj_], T[c_]);     \
-            }                                                                                          \
-    } while (0)
+#define RIH_SKIN_GROUP(T, G0, G1, G2, W0, W1, W2, W3) hipcpu_skin_group(T, G0, G1, G2, W0, W1, W2, W3)
 static inline int __builtin_amdgcn_readfirstlane_emul(int v) {
     std::memcpy(hipcpu::xchg_slot(hipcpu::S().cur->flat), &v, sizeof(int));
     hipcpu::wave_barrier();
