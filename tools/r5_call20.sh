@@ -8,6 +8,6 @@ cd /tmp; rm -rf /tmp/trh
 cd $R
 T=$(find /tmp/trh -name "*kernel_trace.csv" | head -1); S=$(find /tmp/trh -name "*kernel_stats.csv" | head -1)
 cp "$S" $O/hrnet_kernel_stats.csv 2>/dev/null
-python tools/step_from_trace.py "$T" --top 45 --mark nchw_to_nhwc > $O/step_trace_hrnet.txt 2>&1
+python tools/step_from_trace.py "$T" --top 70 --mark nchw_to_nhwc --by-grid > $O/step_trace_hrnet.txt 2>&1
 head -50 $O/step_trace_hrnet.txt | cut -c1-150
 grep '^{' $O/prof_bench_hrnet.log | tail -1 | cut -c1-160
