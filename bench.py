@@ -570,7 +570,7 @@ def main():
         for f, e0, e1, tag in recs:
             # flash attention (tag[6] 30) and the row-chain kernel (40) run exact-fp32 MFMA but are their own families; the fp16
             # convolution of configs[4] carries tag[8] 'f16'
-            key = 'flash_attention' if tag[6] == 30 else 'row_chain' if tag[6] == 40 else 'engine%s' % (tag[8],)
+            key = 'flash_attention' if tag[6] == 30 else 'engine%s' % (tag[8],)
             a = by_engine.setdefault(key, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += max(e0.elapsed_time(e1) - empty, 0.0)
@@ -579,7 +579,7 @@ def main():
         # six-product ceiling 2500 / 6 whichever engine ran, which overstated engine 2's fraction twofold); the six-product
         # fraction of rounds 2-4 stays beside it for comparison across rounds
         ceilings = {'engine2': PEAK_BF16_MFMA_TF / 3.0, 'engine1': PEAK_BF16_MFMA_TF / 6.0, 'engine0': PEAK_FP32_MFMA_TF,
-                    'flash_attention': PEAK_FP32_MFMA_TF, 'row_chain': PEAK_FP32_MFMA_TF}
+                    'flash_attention': PEAK_FP32_MFMA_TF}
         dominant = max(by_engine.items(), key=lambda kv: kv[1][1])[0] if by_engine else ('engine1' if split else 'engine0')
         peak = ceilings.get(dominant, PEAK_BF16_MFMA_TF / 6.0)
         ems = sum(max(e0.elapsed_time(e1) - empty, 0.0) for _, e0, e1, _ in erecs)
@@ -651,7 +651,7 @@ def main():
                                               'per-stage buckets on a side stream, overlapped with the next backward stage'
                                               if not args.no_overlap else 'per-stage buckets on the compute stream'),
                            'optimizer': 'torch.optim.Adam(fused=True)' if args.torch_adam else 'renderih_amd.optim.Adam (rih_adam_multi, one launch)',
-                           'presplit_weights': bool(ops.PRESPLIT), 'presplit_activations': bool(ops.PRESPLIT_ACT), 'flash_attention': bool(ops.FLASH_ATTN), 'one_kernel_attention_rih_fused_attn': bool(ops.FUSED_ATTN),
+                           'flash_attention': bool(ops.FLASH_ATTN), 'one_kernel_attention_rih_fused_attn': bool(ops.FUSED_ATTN),
                            'gemm_engine': ('engine 2: fp32 via a scaled two-term fp16 split, 3 MFMA products, fp32 accumulate, on the '
                                            'convolutions (operand bounds from the BatchNorm kernels); engine 1 elsewhere'
                                            if ops.ENGINE == 2 else

@@ -28,7 +28,9 @@ extern "C" {
 #define RIH_EINVAL (-1)
 
 /* ------------------------------------------------------------------------------------------------
- * rih_gemm: C = epilogue(alpha * A (*) B) on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32).
+ * rih_gemm: C = epilogue(alpha * A (*) B), fp32 in / fp32 out / fp32 accumulate on one of three MFMA engines (field `engine`):
+ * 0 = native v_mfma_f32_32x32x2_f32, 1 = six bf16 products (v_mfma_f32_32x32x16_bf16), 2 (default where both operands have bounds) =
+ * three fp16 products on a scaled two-term split (v_mfma_f32_32x32x16_f16).
  *
  * One kernel family covers every dense contraction of the path:
  *   conv2d forward / data-gradient (A gathered im2col-style from an NHWC tensor)
@@ -43,13 +45,8 @@ extern "C" {
  *           X[img][(ho*strideA - padH + kh)/upS][(wo*strideA - padW + kw)/upS][ci]  (0 when out of range or
  *           not divisible by upS; upS>1 expresses the data-gradient of a strided conv).  K-contiguous.
  * a_mode 1: A(m,k): m = (kh,kw,ci), k = (img,ho,wo) -- the transpose gather, M-contiguous (weight grad).
- * a_mode 2: a_mode 0 on a PRE-SPLIT activation: A points to three bf16 planes [hi|mid|lo][pixels][lda] written by
- *           rih_presplit_matrix(x, b_mode 1, K = channels, N = pixels); lda in bf16 elements (% 8), Cin % 32 == 0,
- *           together with b_mode 2 only -- the kernel then converts nothing at all (engine 1 fast path).
  * b_mode 0: B(k,n) = Bp[k*ldb + n]   (row-major [K][N])
  * b_mode 1: B(k,n) = Bp[n*ldb + k]   ([N][K], e.g. an nn.Linear / 1x1-conv weight as stored)
- * b_mode 2: B pre-split by rih_presplit_*: three bf16 planes [hi|mid|lo][N][ldb] (ldb = K rounded up to 32, zero padded);
- *           engine 1 fast path with a_mode 0 only -- the kernel then spends no conversion instructions on B
  * Epilogue (splitk==1): C[m*ldc+n] = act(alpha*acc + bias[n] + R[m*ldr+n]); with splitk>1 raw partial sums
  *           go to C + split*sCsplit and rih_splitk_reduce finishes.
  */
@@ -84,10 +81,8 @@ typedef struct rih_gemm_desc {
                                of two (from amax_a / amax_b below) and split into two fp16 terms hi + 2^-11 lo (22-23
                                significand bits), hi*hi and hi*lo + lo*hi accumulate in two fp32 accumulators
                                (v_mfma_f32_32x32x16_f16), combined and un-scaled in the epilogue; 2.5 PF / 3 = 833 TF
-                               peak.  Exists on the fast path of tiles 0,1,2 (a_mode / b_mode 0 or 1, and a_mode 0 with
-                               b_mode 2 = B pre-split into two fp16 planes by rih_presplit_* with amax_e2 = amax_b); a
-                               descriptor that asks for it elsewhere runs engine 1 (rih_gemm_engine tells which; with
-                               b_mode 2 that is RIH_EINVAL: no other kernel reads two-plane operands). */
+                               peak.  Exists on the fast path of tiles 0,1,2 (a_mode / b_mode 0 or 1); a descriptor that asks
+                               for it elsewhere runs engine 1 (rih_gemm_engine tells which). */
     /* Strided output rows (cS > 1; a_mode 0, splitk 1, no residual): GEMM row m = (img, i, j) over (Ho, Wo) is stored
      * to pixel (img, i*cS + cOH, j*cS + cOW) of a [*, cH, cW, ldc] tensor.  Used to compute the data gradient of a
      * stride-s convolution as s*s dense sub-convolutions, one per output parity class (each with the kernel taps
@@ -139,36 +134,11 @@ typedef struct rih_gemm_desc {
     const float* a_seg[3];
     int32_t lda_seg[3];
     int32_t k_seg[3];
-    /* BatchNorm-backward sums in the epilogue (ABI 14; engine 2 on the fast path of tiles 0..2, a_mode 0, no split-K, no batch,
-     * no statistics / dropout / segmented A, N % 4 == 0): the GEMM output C[M][N] is the gradient dy arriving at a BatchNorm
-     * whose input was x (same [M][N] geometry, row pitch bnb_ldx) -- a convolution's data gradient flowing into the
-     * Conv -> BN -> ReLU in front of it (models/encoder.py:107-116 in reverse).  The epilogue gates the values it stores with the
-     * ReLU pattern bnb_mask (rih_bn_apply's relu_mask; NULL = no ReLU) and leaves, per block of rih_gemm_bnb_rows(desc) rows,
-     * the column sums bnb_part[0][block][n] = sum dy and bnb_part[1][block][n] = sum dy * (x - mean) * invstd
-     * (bnb_part[2][bnb_T][N], bnb_T = ceil(M / rows)): the reduction pass of rih_bn_bwd without its pass over dy and x
-     * (rih_bn_bwd_partials finishes).  The stored C is the un-gated dy, as without the fold.  NULL = off; RIH_EINVAL when set on a
-     * descriptor that does not take that path (rih_gemm_bnb_rows returns 0 for it).  Built, parity-tested and measured 1.4 %
-     * SLOWER on the training step in round 4: the kernels are compiled only with RIH_BUILD_EXPERIMENTS=1 -- the default library
-     * answers 0 rows / RIH_EINVAL. */
-    const float* bnb_x;
-    const uint8_t* bnb_mask;
-    const float* bnb_mean;
-    const float* bnb_invstd;
-    float* bnb_part;
-    int32_t bnb_ldx;
-    int32_t bnb_T;
 } rih_gemm_desc;
 int rih_gemm_stats_rows(const rih_gemm_desc* d);
-/* rows per block of the bnb_* epilogue for this descriptor (bnb fields ignored), 0 when it would not take that path */
-int rih_gemm_bnb_rows(const rih_gemm_desc* d);
 int rih_gemm_dropout_ok(const rih_gemm_desc* d);
 /* The engine rih_gemm would run `d` on (0 / 1 / 2), or -1 for an invalid descriptor. */
 int rih_gemm_engine(const rih_gemm_desc* d);
-/* 1 when the library was built with the experiment variants of rih_gemm (pre-split operands: a_mode 2 / b_mode 2; the 256x128
- * software-pipelined kernel: tile 4) and the experiment sources (renderih_amd_experiments.h); the default library returns 0 and
- * answers RIH_EINVAL for such descriptors.  All of them were built, parity-tested and measured, and none is on a default path
- * (DESIGN.md 8). */
-int rih_experiments(void);
 /* Bound block: RIH_BOUND_FLOATS floats = 64 partial maxima at a stride of 32 floats (one per 128-byte line; the other floats are
  * unused); THE BOUND IS THE MAXIMUM OF THE 64.  A producer merges its candidates into the lines with atomic maxima (64 lines so
  * that the same-address atomics of thousands of workgroups do not queue up behind one word), a consumer (rih_gemm engine 2) reads
@@ -240,26 +210,6 @@ int rih_splitk_reduce_bias_batched(const float* P, int S, int Mp, int M, int N, 
  * rows_per_block = rih_gemm_stats_rows(desc)): no pass over the convolution output; one launch. */
 int rih_bn_stats_from_blocks(const float* part, int T, int C, int rows, int rows_per_block, float eps, float momentum,
                              float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
-/* Pre-split B operands for rih_gemm b_mode 2 (weights are constant within a training step, so their 16-bit planes are produced
- * once instead of inside every GEMM's loader).  amax_e2 == NULL: three bf16 planes hi / mid / lo for engine 1,
- * dst = 3 * N * Kpad bf16.  amax_e2 = the operand's bound block (rih_absmax): TWO fp16 planes for engine 2,
- * dst = 2 * N * Kpad fp16 -- hi = fp16(s x), lo = fp16((s x - hi) 2^11) with the power-of-two scale s engine 2 derives from the
- * SAME bound block (the descriptor of the GEMM that reads the planes passes it as amax_b, so that it undoes the same scale).
- * Kpad % 32 == 0.  rih_presplit_matrix: from a plain b_mode 0 / 1 matrix.  rih_presplit_conv_weight: from an OIHW conv weight,
- * as the forward operand (for_dgrad 0: N = Cout, K = KH*KW*CinPad) or as the (flipped) data-gradient operand of the tap subset
- * kh0 + step*t, kw0 + step*t' (for_dgrad 1: N = CinPad, K = Th*Tw*Cout; the full gradient is 0, 0, 1, KH, KW).
- * rih_presplit_multi: any number of conv-weight operands in ceil(n / 40) launches (`descs` is HOST memory, read before the call
- * returns): every weight operand of a training step at its start. */
-int rih_presplit_matrix(const float* B, int b_mode, int K, int N, int ldb, void* dst, int Kpad, const float* amax_e2, void* stream);
-int rih_presplit_conv_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int CinPad, int for_dgrad,
-                             int kh0, int kw0, int step, int Th, int Tw, int Kpad, const float* amax_e2, void* stream);
-typedef struct rih_presplit_desc {
-    const float* w;         /* OIHW parameter */
-    void* dst;
-    const float* amax_e2;   /* bound block of w (engine 2 planes) or NULL (engine 1 planes) */
-    int32_t Cout, Cin, KH, KW, CinPad, for_dgrad, kh0, kw0, step, Th, Tw, Kpad;
-} rih_presplit_desc;
-int rih_presplit_multi(const rih_presplit_desc* descs, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Halo-resident 3x3 convolution, stride 1, padding 1 (csrc/rih_conv3.hip, ABI 15) -- the 3x3 convolutions of the trunk's
@@ -387,11 +337,6 @@ int rih_bn_apply(const float* x, const float* mean, const float* invstd, const f
 int rih_bn_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
                const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C,
                int relu, int frozen_stats, float* ws, const uint8_t* relu_mask, float* amax_dx, void* stream);
-/* rih_bn_bwd without its reduction pass (ABI 14): `part`[2][T][C] holds per-row-block column sums of the ReLU-gated dy and of
- * dy * xhat, written by the epilogue of the GEMM that produced dy (rih_gemm_desc.bnb_*).  One finishing launch + the apply pass. */
-int rih_bn_bwd_partials(const float* part, int T, const float* dy, const float* x, const float* mean, const float* invstd,
-                        const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta, int rows, int C, int relu,
-                        int frozen_stats, const uint8_t* relu_mask, float* amax_dx, void* stream);
 /* amax_dx (optional, ABI 13): a bound block that receives max|dx|, as `amax` of rih_bn_apply -- dx is the gradient operand of
  * the producing convolution's data- and weight-gradient GEMMs. */
 
@@ -575,10 +520,10 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
 /* library / device info.  RIH_ABI_VERSION is bumped whenever a struct layout or a signature of this header changes;
  * rih_version() returns the value the library was compiled with and rih_abi_sizes() the sizeof of EVERY by-pointer struct, in
  * this order: gemm desc, mano model, mesh topo, hconv desc, reduce desc, pack desc, ln final desc, adam entry, absmax desc,
- * presplit desc, conv3 desc, h2 desc, panel desc (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it
+ * conv3 desc, h2 desc, panel desc (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it
  * mis-laid-out structs. */
-#define RIH_ABI_VERSION 17
-#define RIH_ABI_NSIZES 13
+#define RIH_ABI_VERSION 18
+#define RIH_ABI_NSIZES 12
 int rih_version(void);
 int rih_abi_sizes(int32_t* out10);
 const char* rih_arch(void);

@@ -12,17 +12,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'librenderih_amd.so')
-# Two experiments of rounds 2-3 that no default path uses are NOT part of the product library (round-3 verdict): the P3 GEMM on
-# pre-split bf16 operands (rih_gemm3.hip: power-bound like engine 1) and the row-chain kernel (rih_chain.hip: 1.1 ms
-# per step slower than the launches it fuses).  RIH_BUILD_EXPERIMENTS=1 compiles them in (their entry points, the
-# opt-in paths RIH_CHAIN=1 / ops.gemm_p3 and their tests then work as before).
-EXPERIMENTS = os.environ.get('RIH_BUILD_EXPERIMENTS', '0') == '1'
-EXPERIMENT_SOURCES = ['rih_gemm3.hip', 'rih_chain.hip']
+# Kernel variants that were measured and refuted in rounds 2-5 (P3 GEMM, row chain, tile 4, pre-split operands, the BatchNorm-backward
+# epilogue) live on the git branch `experiments-r05`, not in this tree.
 SOURCES = ['rih_gemm.hip', 'rih_conv3.hip', 'rih_elem.hip', 'rih_mano.hip', 'rih_loss.hip', 'rih_metrics.hip',
-           'rih_pose.hip', 'rih_attn.hip', 'rih_flash.hip', 'rih_half.hip', 'rih_input.hip', 'rih_sdf.hip'] + \
-          (EXPERIMENT_SOURCES if EXPERIMENTS else [])
+           'rih_pose.hip', 'rih_attn.hip', 'rih_flash.hip', 'rih_half.hip', 'rih_input.hip', 'rih_sdf.hip']
 HEADERS = ['rih_procrustes.h', 'rih_pose_math.h', 'rih_hash.h', 'rih_bn_bwd_partial.inc']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-DRIH_EXPERIMENTS=%d' % (1 if EXPERIMENTS else 0),
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result',
          # hipcc's SLP pass packs neighbouring f32 adds into v_pk_add_f32, which issues at a fraction of the scalar
          # rate next to MFMAs (MI355X_MICROARCH.md, cycle constants): keep the split arithmetic scalar
          '-fno-slp-vectorize']

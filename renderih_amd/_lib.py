@@ -31,27 +31,12 @@ class GemmDesc(C.Structure):
                 ('reserved0', C.c_int32), ('sBias1', C.c_int64), ('sR1', C.c_int64), ('stats', C.c_void_p),
                 ('drop_p', C.c_float), ('reserved1', C.c_int32), ('drop_seed', C.c_uint64), ('drop_seed_dev', C.c_void_p),
                 ('amax_a', C.c_void_p), ('amax_b', C.c_void_p),
-                ('a_seg', C.c_void_p * 3), ('lda_seg', C.c_int32 * 3), ('k_seg', C.c_int32 * 3),
-                ('bnb_x', C.c_void_p), ('bnb_mask', C.c_void_p), ('bnb_mean', C.c_void_p), ('bnb_invstd', C.c_void_p),
-                ('bnb_part', C.c_void_p), ('bnb_ldx', C.c_int32), ('bnb_T', C.c_int32)]
-
-
-class GemmP3Desc(C.Structure):
-    _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('zero', C.c_void_p), ('C', C.c_void_p), ('bias', C.c_void_p),
-                ('R', C.c_void_p), ('stats', C.c_void_p)] + \
-               [(n, C.c_int32) for n in ('M', 'N', 'K', 'lda', 'ldb', 'ldc', 'ldr', 'H', 'W', 'Cin', 'Ho', 'Wo', 'KH', 'KW',
-                                         'stride', 'padH', 'padW', 'cS', 'cOH', 'cOW', 'cH', 'cW', 'relu', 'tile',
-                                         'layout')]
+                ('a_seg', C.c_void_p * 3), ('lda_seg', C.c_int32 * 3), ('k_seg', C.c_int32 * 3)]
 
 
 class ReduceDesc(C.Structure):
     _fields_ = [('P', C.c_void_p), ('dst', C.c_void_p), ('db', C.c_void_p)] + \
                [(n, C.c_int32) for n in ('S', 'Mp', 'M', 'N', 'Cin', 'taps', 'CinValid', 'accumulate', 'CinPitch', 'reserved')]
-
-
-class PresplitDesc(C.Structure):
-    _fields_ = [('w', C.c_void_p), ('dst', C.c_void_p), ('amax_e2', C.c_void_p)] + \
-               [(n, C.c_int32) for n in ('Cout', 'Cin', 'KH', 'KW', 'CinPad', 'for_dgrad', 'kh0', 'kw0', 'step', 'Th', 'Tw', 'Kpad')]
 
 
 class Conv3Desc(C.Structure):
@@ -80,21 +65,6 @@ BOUND_FLOATS = 2048     # = RIH_BOUND_FLOATS: a bound block (64 partial maxima, 
 
 class LnFinalDesc(C.Structure):
     _fields_ = [('ws', C.c_void_p), ('dg', C.c_void_p), ('db', C.c_void_p), ('D', C.c_int32), ('nblk', C.c_int32)]
-
-
-class ChainOp(C.Structure):
-    _fields_ = [('kind', C.c_int32), ('flags', C.c_int32), ('n', C.c_int32), ('k', C.c_int32),
-                ('ld', C.c_int32), ('lda', C.c_int32), ('lde', C.c_int32), ('reserved', C.c_int32), ('f0', C.c_float), ('f1', C.c_float), ('seed', C.c_uint64),
-                ('p0', C.c_void_p), ('p1', C.c_void_p), ('p2', C.c_void_p), ('p3', C.c_void_p), ('p4', C.c_void_p),
-                ('s0', C.c_int64), ('s1', C.c_int64), ('s2', C.c_int64), ('s3', C.c_int64), ('s4', C.c_int64)]
-
-
-CHAIN_MAXOPS = 16
-
-
-class ChainDesc(C.Structure):
-    _fields_ = [('nops', C.c_int32), ('rows', C.c_int32), ('nhands', C.c_int32), ('rblk', C.c_int32),
-                ('ldw', C.c_int32), ('reserved', C.c_int32), ('seed_dev', C.c_void_p), ('op', ChainOp * CHAIN_MAXOPS)]
 
 
 class PackDesc(C.Structure):
@@ -142,9 +112,6 @@ SIGNATURES = {
                                          c_i, c_f, c_i, C.c_void_p]),
     'rih_attention_fwd_fused': (c_i, [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_u64, c_f, c_f, c_f, c_i,
                                       c_f, c_i, C.c_void_p]),
-    'rih_presplit_matrix': (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_f, C.c_void_p]),
-    'rih_presplit_conv_weight': (c_i, [c_f, c_f] + [c_i] * 12 + [c_f, C.c_void_p]),
-    'rih_presplit_multi': (c_i, [C.POINTER(PresplitDesc), c_i, C.c_void_p]),
     'rih_conv3x3_ok': (c_i, [C.POINTER(Conv3Desc)]),
     'rih_conv3x3_stats_rows': (c_i, [C.POINTER(Conv3Desc)]),
     'rih_conv3x3': (c_i, [C.POINTER(Conv3Desc), C.c_void_p]),
@@ -193,8 +160,6 @@ SIGNATURES = {
     'rih_bn_eval_stats': (c_i, [c_f, c_f, c_i, c_fl, c_f, c_f, C.c_void_p]),
     'rih_bn_apply': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, C.c_void_p, c_f, C.c_void_p]),
     'rih_bn_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, C.c_void_p, c_f, C.c_void_p]),
-    'rih_bn_bwd_partials': (c_i, [c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, C.c_void_p, c_f,
-                                  C.c_void_p]),
     'rih_layernorm_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_i, C.c_void_p]),
     'rih_ln_nblk': (c_i, [c_i]),
     'rih_layernorm_fwd_grouped': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_l, c_l, c_fl, c_i, C.c_void_p]),
@@ -227,10 +192,8 @@ SIGNATURES = {
                             c_f, c_f, c_f, c_f, c_f, c_i, C.c_void_p]),
     'rih_mesh_loss_final': (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, C.c_void_p]),
     'rih_gemm_stats_rows': (c_i, [C.POINTER(GemmDesc)]),
-    'rih_gemm_bnb_rows': (c_i, [C.POINTER(GemmDesc)]),
     'rih_gemm_dropout_ok': (c_i, [C.POINTER(GemmDesc)]),
     'rih_gemm_engine': (c_i, [C.POINTER(GemmDesc)]),
-    'rih_experiments': (c_i, []),
     'rih_absmax': (c_i, [c_f, c_l, c_f, C.c_void_p]),
     'rih_absmax_multi': (c_i, [C.POINTER(AbsmaxDesc), c_i, C.c_void_p]),
     'rih_gemm_multi_variant': (c_i, [C.POINTER(GemmDesc)]),
@@ -247,21 +210,8 @@ SIGNATURES = {
     'rih_arch': (C.c_char_p, []),
 }
 
-# entry points of the two experiment sources (renderih_amd/_build.py: EXPERIMENT_SOURCES), bound only when the library was built
-# with RIH_BUILD_EXPERIMENTS=1
-EXPERIMENT_SIGNATURES = {
-    'rih_bn_stats_merge': (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),
-    'rih_bn_stats_from_tiles': (c_i, [c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, C.c_void_p]),
-    'rih_gemm_p3': (c_i, [C.POINTER(GemmP3Desc), C.c_void_p]),
-    'rih_gemm_p3_tile_rows': (c_i, [c_i]),
-    'rih_p3_from_f32': (c_i, [c_f, c_l, c_i, c_i, C.c_void_p, c_i, c_i, C.c_void_p]),
-    'rih_p3_conv_weight': (c_i, [c_f, C.c_void_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
-    'rih_chain': (c_i, [C.POINTER(ChainDesc), C.c_void_p]),
-    'rih_chain_check': (c_i, [C.POINTER(ChainDesc)]),
-}
-HAS_EXPERIMENTS = False
 
-ABI_VERSION = 17     # = RIH_ABI_VERSION of include/renderih_amd.h
+ABI_VERSION = 18     # = RIH_ABI_VERSION of include/renderih_amd.h
 
 _lib = None
 
@@ -294,17 +244,10 @@ def load():
         fn = getattr(lib, name)      # AttributeError => a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    global HAS_EXPERIMENTS
-    HAS_EXPERIMENTS = int(lib.rih_experiments()) == 1 and all(hasattr(lib, name) for name in EXPERIMENT_SIGNATURES)
-    if HAS_EXPERIMENTS:
-        for name, (res, args) in EXPERIMENT_SIGNATURES.items():
-            fn = getattr(lib, name)
-            fn.restype = res
-            fn.argtypes = args
     # every by-pointer struct of the header, in rih_abi_sizes' order; the last one (rih_adam_entry: four pointers + int64) is
     # built by hand as int64 rows in renderih_amd/optim.py
     mine = [C.sizeof(GemmDesc), C.sizeof(ManoModel), C.sizeof(MeshTopo), C.sizeof(HConvDesc),
-            C.sizeof(ReduceDesc), C.sizeof(PackDesc), C.sizeof(LnFinalDesc), 5 * 8, C.sizeof(AbsmaxDesc), C.sizeof(PresplitDesc),
+            C.sizeof(ReduceDesc), C.sizeof(PackDesc), C.sizeof(LnFinalDesc), 5 * 8, C.sizeof(AbsmaxDesc),
             C.sizeof(Conv3Desc), C.sizeof(H2Desc), C.sizeof(PanelDesc)]
     if lib.rih_version() != ABI_VERSION:
         raise RuntimeError('librenderih_amd.so does not match this binding (ABI %d vs %d): rebuild with '

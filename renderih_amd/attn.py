@@ -283,15 +283,9 @@ class SelfAttn(nn.Module):
         # both hands' fused QKV operands stacked once into [2, 3D, D]
         w = torch.cat([L.w_qs.weight, L.w_ks.weight, L.w_vs.weight, R.w_qs.weight, R.w_ks.weight, R.w_vs.weight], 0)
         b = torch.cat([L.w_qs.bias, L.w_ks.bias, L.w_vs.bias, R.w_qs.bias, R.w_ks.bias, R.w_vs.bias], 0)
-        chain = ops.chain_ok(D, L.ff.fc1.out_features)
-        if chain:       # LayerNorm -> QKV projection as one launch (csrc/rih_chain.hip)
-            qkv, X = ops.ln_linear_chain(X, L.layer_norm, R.layer_norm, w.view(2, 3 * D, D), b.view(2, 3 * D))
-        else:
-            y, X = ops.layernorm_pair_skip(X, L.layer_norm, R.layer_norm)
-            qkv = ops.LinearPairFn.apply(y, w.view(2, 3 * D, D), None, b.view(2, 3 * D), None, None, False)
+        y, X = ops.layernorm_pair_skip(X, L.layer_norm, R.layer_norm)
+        qkv = ops.LinearPairFn.apply(y, w.view(2, 3 * D, D), None, b.view(2, 3 * D), None, None, False)
         o = ops.self_attention_packed(qkv.view(2 * B, S, 3 * D), L.n_heads, dc.p, dc.seed() if dc.p > 0 else 0)
-        if chain:       # output projection, both skips and the MLP block as one launch
-            return ops.attn_tail_chain(o.view(2, B, S, D), X, L.fc, R.fc, L.ff, R.ff, dc.p, _seeds3(dc))
         X = _lin_drop_res_pair(dc, L.fc, R.fc, o.view(2, B, S, D), X)
         return MLP_res_block.forward_pair(L.ff, R.ff, X, dc)
 
@@ -415,15 +409,9 @@ class inter_attn(nn.Module):
         w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight], 0)
         b = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias], 0)
         sd = (lambda: dc.seed()) if dc.p > 0 else (lambda: 0)
-        chain = ops.chain_ok(X.shape[-1], self.ffL.fc1.out_features)
         # shared projections (N5): ONE fused QKV GEMM over both hands' rows, then the two cross-hand directions
-        if chain:
-            qkv, X = ops.ln_linear_chain(X, self.layer_norm1, self.layer_norm2, w, b)
-        else:
-            qkv = ops.linear(ops.layernorm_pair(X, self.layer_norm1, self.layer_norm2), w, b)
+        qkv = ops.linear(ops.layernorm_pair(X, self.layer_norm1, self.layer_norm2), w, b)
         feat = ops.cross_attention_stacked(qkv, self.n_heads, dc.p, sd(), sd())
-        if chain:
-            return ops.attn_tail_chain(feat, X, self.fc, None, self.ffL, self.ffR, dc.p, _seeds3(dc))
         return MLP_res_block.forward_pair(self.ffL, self.ffR, _lin_drop_res(dc, self.fc, feat, X), dc)
 
 

@@ -1725,20 +1725,6 @@ extern "C" int rih_bn_bwd(const float* dy, const float* x, const float* y, const
     LAUNCH_RET();
 }
 
-extern "C" int rih_bn_bwd_partials(const float* part, int T, const float* dy, const float* x, const float* mean,
-                                   const float* invstd, const float* gamma, float* dx, float* dres, float* dgamma,
-                                   float* dbeta, int rows, int C, int relu, int frozen_stats, const uint8_t* relu_mask,
-                                   float* amax_dx, void* stream) {
-    if (!part || T < 1 || !dy || !x || !mean || !invstd || !gamma || !dx || !dgamma || !dbeta) return RIH_EINVAL;
-    if (relu && !relu_mask) return RIH_EINVAL;
-    if (rows < 1 || C < 4 || (C % 4) != 0) return RIH_EINVAL;
-    hipLaunchKernelGGL(two_sum_final_kernel, dim3((C + 3) / 4), dim3(TPB), 0, STREAM, part, C, T, dbeta, dgamma);
-    const long long nq = (long long)rows * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nq)), dim3(TPB), 0, STREAM, dy, x, (const float*)nullptr, mean, invstd,
-                       gamma, dbeta, dgamma, dx, dres, nq, C, 1.f / (float)rows, relu, frozen_stats, relu_mask, amax_dx);
-    LAUNCH_RET();
-}
-
 extern "C" int rih_ln_nblk(int rows) {
     // 4 rows (wavefronts) per block pass; enough blocks that a wavefront walks only a few rows: each row is a
     // load -> shuffle-reduce -> store dependency chain (~1.5 us), so few resident waves means latency-bound
@@ -2014,10 +2000,9 @@ extern "C" int rih_abi_sizes(int32_t* out9) {      // RIH_ABI_NSIZES values
     out9[6] = (int32_t)sizeof(rih_ln_final_desc);
     out9[7] = (int32_t)sizeof(rih_adam_entry);
     out9[8] = (int32_t)sizeof(rih_absmax_desc);
-    out9[9] = (int32_t)sizeof(rih_presplit_desc);
-    out9[10] = (int32_t)sizeof(rih_conv3_desc);
-    out9[11] = (int32_t)sizeof(rih_h2_desc);
-    out9[12] = (int32_t)sizeof(rih_panel_desc);
+    out9[9] = (int32_t)sizeof(rih_conv3_desc);
+    out9[10] = (int32_t)sizeof(rih_h2_desc);
+    out9[11] = (int32_t)sizeof(rih_panel_desc);
     return 0;
 }
 extern "C" const char* rih_arch(void) { return "gfx950"; }

@@ -16,12 +16,6 @@
 #include "rih_hash.h"
 #include <type_traits>
 
-#ifndef RIH_EXPERIMENTS
-/* 1 (renderih_amd/_build.py: RIH_BUILD_EXPERIMENTS=1) also compiles the kernel variants that were built, parity-tested, measured and
- * NOT adopted: pre-split operands (a_mode 2 / b_mode 2, engines 1 and 2) and the 256x128 software-pipelined kernel (tile 4, engines 1
- * and 2).  The default library leaves them out; rih_gemm answers RIH_EINVAL for such a descriptor, rih_experiments() tells. */
-#define RIH_EXPERIMENTS 0
-#endif
 #ifndef RIH_E2_PIPE
 /* engine 2's main loop: 1 = two LDS stages, one barrier per k-tile, conversion half-units interleaved with the MFMAs.  Built,
  * parity-tested and measured in round 4 (profiles/r04/ab/c3_*, c4_*): per shape within +-3 % of the two-barrier loop, whole step
@@ -61,10 +55,6 @@ struct GemmArgs {
     unsigned a_plane;               // a_mode 2: bytes per pre-split plane of A (last: keeps the older kernels' kernarg offsets)
     int epi_vec;                    // C, R, bias and every stride involved are 16-byte aligned: the epilogue may use 16-byte accesses
     float* stats;                   // split fast path, a_mode 0, splitk 1: per wave-row-block column sums [M / WM][2][N] (or NULL)
-    // BatchNorm-backward sums in the epilogue (rih_gemm_desc.bnb_*; engine 2): x / ReLU pattern / statistics of the BatchNorm
-    // whose output gradient this GEMM produces, part[2][bnb_T][N]
-    const float* bnb_x; const unsigned char* bnb_mask; const float* bnb_mean; const float* bnb_invstd; float* bnb_part;
-    int bnb_ldx, bnb_T;
     // dropout in the epilogue (DROP variants of the split fast path; appended last: the older kernels' kernarg offsets stay):
     // element e of the output (offset from C in floats) is kept iff rih_hash(drop_seed + *drop_seed_dev, e) >= drop_thr
     unsigned drop_thr;              // 0 = off
@@ -197,10 +187,7 @@ constexpr int SLD = 36;             // floats per staged row: 32 + pad, keeps fl
 // rih_gemm followed by rih_add_dropout(R, ., p, seed) bit for bit and rih_dropout_bwd re-draws the same mask.
 // E2 (engine 2): the staged value is (acc + 2^-11 acc1) * inv_a * inv_b -- the correction accumulator folded in and the operand
 // scales undone (also for the raw split-K slabs, whose reduction knows nothing of scales).
-// BNB (rih_gemm_desc.bnb_*, round 4): the stored values are the gradient dy arriving at a BatchNorm; per column and wave row
-// block the sums of the ReLU-gated dy and of dy * xhat are left in p.bnb_part -- the reduction pass of rih_bn_bwd without its
-// reads of dy and x from memory (x and the ReLU pattern of the wave's whole tile are requested before the first store).
-template <int TM, int TN, bool STATS = false, bool DROP = false, bool E2 = false, bool BNB = false>
+template <int TM, int TN, bool STATS = false, bool DROP = false, bool E2 = false>
 __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&acc)[TM][TN], float* stg, float* __restrict__ C,
                                                  const float* __restrict__ biasp, const float* __restrict__ Rp, int mbase,
                                                  int nbase, int lane, floatx16 (*acc1)[TN] = nullptr, float inv_a = 1.f,
@@ -216,33 +203,6 @@ __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&a
     if (STATS) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) { ssh[j] = zero4(); ssum[j] = zero4(); ssq[j] = zero4(); scnt[j] = 0.f; }
-    }
-    float4 bs1[BNB ? TN : 1], bs2[BNB ? TN : 1], bmu[BNB ? TN : 1], bis[BNB ? TN : 1];
-    float4 bxv[BNB ? TM : 1][BNB ? TN : 1][4];
-    unsigned bbits[BNB ? TM : 1][BNB ? TN : 1][4];
-    if (BNB) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = nbase + j * 32 + (lane & 7) * 4;
-            bs1[j] = zero4(); bs2[j] = zero4(); bmu[j] = zero4(); bis[j] = zero4();
-            if (n < p.N) {                  // (N % 4 == 0: a quad is inside or outside)
-                bmu[j] = *reinterpret_cast<const float4*>(p.bnb_mean + n);
-                bis[j] = *reinterpret_cast<const float4*>(p.bnb_invstd + n);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int m = mbase + i * 32 + (lane >> 3) + 8 * q;
-                    bxv[i][j][q] = zero4();
-                    bbits[i][j][q] = 0xFu;
-                    if (m < p.M && n < p.N) {
-                        const long long o = (long long)m * p.bnb_ldx + n;
-                        bxv[i][j][q] = *reinterpret_cast<const float4*>(p.bnb_x + o);
-                        if (p.bnb_mask != nullptr) bbits[i][j][q] = p.bnb_mask[o >> 2];
-                    }
-                }
-        }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -308,17 +268,6 @@ __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&a
                     if (n + 2 < p.N) crow[2] = v.z;
                     if (n + 3 < p.N) crow[3] = v.w;
                 }
-                if (BNB) {          // gate with the ReLU pattern, add to the two column sums of this lane
-                    const unsigned bits = bbits[i][j][q];
-                    const float4 xv = bxv[i][j][q];
-                    const float dx_ = (bits & 1u) ? v.x : 0.f, dy_ = (bits & 2u) ? v.y : 0.f;
-                    const float dz_ = (bits & 4u) ? v.z : 0.f, dw_ = (bits & 8u) ? v.w : 0.f;
-                    bs1[j].x += dx_; bs1[j].y += dy_; bs1[j].z += dz_; bs1[j].w += dw_;
-                    bs2[j].x += dx_ * ((xv.x - bmu[j].x) * bis[j].x);
-                    bs2[j].y += dy_ * ((xv.y - bmu[j].y) * bis[j].y);
-                    bs2[j].z += dz_ * ((xv.z - bmu[j].z) * bis[j].z);
-                    bs2[j].w += dw_ * ((xv.w - bmu[j].w) * bis[j].w);
-                }
                 if (STATS) {        // (columns past N are never written out below)
                     if (scnt[j] == 0.f) ssh[j] = v;
                     scnt[j] += 1.f;
@@ -326,27 +275,6 @@ __device__ __forceinline__ void store_tiles_wide(const GemmArgs& p, floatx16 (&a
                     ssum[j].x += dx; ssum[j].y += dy; ssum[j].z += dz; ssum[j].w += dw;
                     ssq[j].x += dx * dx; ssq[j].y += dy * dy; ssq[j].z += dz * dz; ssq[j].w += dw * dw;
                 }
-            }
-        }
-    }
-    if (BNB) {
-        // the eight row-lanes (lane >> 3) of a column quad are added up (three xor-shuffle rounds, fixed order); lane >> 3 == 0
-        // writes the wave row block's two sums
-        const long long rb = mbase / (TM * 32);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float4 a1 = bs1[j], a2 = bs2[j];
-#pragma unroll
-            for (int o = 8; o < 64; o <<= 1) {
-                a1.x += __shfl_xor(a1.x, o, 64); a1.y += __shfl_xor(a1.y, o, 64);
-                a1.z += __shfl_xor(a1.z, o, 64); a1.w += __shfl_xor(a1.w, o, 64);
-                a2.x += __shfl_xor(a2.x, o, 64); a2.y += __shfl_xor(a2.y, o, 64);
-                a2.z += __shfl_xor(a2.z, o, 64); a2.w += __shfl_xor(a2.w, o, 64);
-            }
-            const int n = nbase + j * 32 + (lane & 7) * 4;
-            if ((lane >> 3) == 0 && n < p.N && rb < p.bnb_T) {
-                *reinterpret_cast<float4*>(p.bnb_part + ((long long)0 * p.bnb_T + rb) * p.N + n) = a1;
-                *reinterpret_cast<float4*>(p.bnb_part + ((long long)1 * p.bnb_T + rb) * p.N + n) = a2;
             }
         }
     }
@@ -877,7 +805,7 @@ __device__ __forceinline__ uint4 bloadu4(__amdgpu_buffer_rsrc_t r, unsigned off)
 // ENG 2: the two-term fp16 split (three MFMA products, see e2_scale / split2h above) instead of the three-term bf16 one; same
 // loaders, LDS layout (two planes instead of three) and epilogue.  Not with pre-split operands.
 template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false, int ENG = 1,
-          bool SEG = false, int PFD = 1, bool BNB = false>
+          bool SEG = false, int PFD = 1>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk_x, const int blk_z, const int grid_x,
                                                 const int grid_z) {
     static_assert(ENG == 1 || (ENG == 2 && !APRE), "engine 2: B may arrive as two pre-split fp16 planes (BMODE 2), A never");
@@ -1479,7 +1407,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
 
     // ------------------------------------------------------------------ epilogue (store_tiles_wide; the main loop ended with a barrier)
     if constexpr (ENG == 2) {
-        store_tiles_wide<TM, TN, STATS, DROP, true, BNB>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp,
+        store_tiles_wide<TM, TN, STATS, DROP, true>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp,
                                                     m0 + wm * WM, n0 + wn * WN, lane, acc1, 1.f / e2_sa, 1.f / e2_sb);
     } else {
         store_tiles_wide<TM, TN, STATS, DROP>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp, m0 + wm * WM, n0 + wn * WN,
@@ -1488,9 +1416,9 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
 }
 
 template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false, int ENG = 1,
-          bool SEG = false, int PFD = 1, bool BNB = false>
+          bool SEG = false, int PFD = 1>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
-    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, APRE, STATS, DROP, ENG, SEG, PFD, BNB>(p, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.x,
+    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, APRE, STATS, DROP, ENG, SEG, PFD>(p, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.x,
                                                                               (int)gridDim.z);
 }
 
@@ -1544,40 +1472,8 @@ int launch_split_e2(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 
         else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, false, false, 2, true>), grid, block, 0, s, a);
         return (int)hipGetLastError();
     }
-#if RIH_EXPERIMENTS
-    // BatchNorm-backward sums in the epilogue (gemm_impl checked the preconditions).  MEASURED SLOWER (round 4, session 23, one
-    // box): 1948.4 / 1950.8 images/s with RIH_BN_FOLD=1 against 1975.7 / 1976.4 without (-1.4 %) -- the epilogue's reads of x and
-    // of the ReLU pattern plus 48 shuffles per wave cost more than the reduction pass they replace (which streams at 5 TB/s).
-    if (a.bnb_part != nullptr) {
-#define RIH_L2B(BM_, PL_) \
-    hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, BM_, PL_, false, false, false, 2, false, 1, true>), grid, block, 0, s, a)
-        if (b_mode == 0) { if (plain) RIH_L2B(0, true); else RIH_L2B(0, false); }
-        else { if (plain) RIH_L2B(1, true); else RIH_L2B(1, false); }
-#undef RIH_L2B
-        return (int)hipGetLastError();
-    }
-    // short reductions on plain rows: two k-tiles in flight (RIH_E2_DEEP_K = largest K that takes this path, default 0 = off).
-    // REFUTED (round 4, session 12, one box): 1942.5 / 1937.3 images/s against 1960.2 / 1961.3 without it (-1.1 %); for every K
-    // (4096) 1940.2 -- the second register set costs 128x64 tiles one workgroup per CU (126 -> 146-152 VGPRs, 4 -> 3), and the
-    // workgroups a CU holds hide the round trips better than a deeper pipeline inside each of them.
-    static const int deep_k = [] { const char* e = getenv("RIH_E2_DEEP_K"); return e ? atoi(e) : 0; }();
-    if (plain && a_mode == 0 && b_mode < 2 && a.drop_thr == 0u && a.splitk == 1 && a.K <= deep_k && a.K > 32) {
-#define RIH_L2D(BM_, ST_) \
-    hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, BM_, true, false, ST_, false, 2, false, 2>), grid, block, 0, s, a)
-        if (a.stats != nullptr) { if (b_mode == 0) RIH_L2D(0, true); else RIH_L2D(1, true); }
-        else { if (b_mode == 0) RIH_L2D(0, false); else RIH_L2D(1, false); }
-#undef RIH_L2D
-        return (int)hipGetLastError();
-    }
-#endif
     if (b_mode == 2) {          // B pre-split into two fp16 planes (weights, once per step)
-#if RIH_EXPERIMENTS
-        if (a.drop_thr != 0u) return RIH_EINVAL;
-        if (a.stats != nullptr) { if (plain) RIH_L2(0, 2, true, true, false); else RIH_L2(0, 2, false, true, false); }
-        else { if (plain) RIH_L2(0, 2, true, false, false); else RIH_L2(0, 2, false, false, false); }
-#else
         return RIH_EINVAL;
-#endif
     } else
     if (a.drop_thr != 0u) {
         if (b_mode == 0) RIH_L2(0, 0, true, false, true); else RIH_L2(0, 1, true, false, true);
@@ -1597,21 +1493,12 @@ template <int BM, int BN>
 int launch_split(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 grid, hipStream_t s) {
     dim3 block(256);
 #define RIH_LS(AM_, BM_, PL_) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, AM_, BM_, PL_>), grid, block, 0, s, a)
-#if !RIH_EXPERIMENTS
     if (a_mode == 2 || b_mode == 2) return RIH_EINVAL;      // pre-split operands: experiment builds only
-#endif
     if (a.Aseg[0] != nullptr) {         // segmented A (see launch_split_e2)
         if (a.stats != nullptr) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, true, false, 1, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, false, false, 1, true>), grid, block, 0, s, a);
         return (int)hipGetLastError();
     }
-#if RIH_EXPERIMENTS
-    if (a_mode == 2) {      // both operands pre-split (b_mode 2 enforced by rih_gemm)
-        if (plain) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 2, true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 2, false, true>), grid, block, 0, s, a);
-    }
-    else
-#endif
     if (a.drop_thr != 0u) {        // dropout epilogue: plain a_mode-0 GEMMs only (checked by the caller)
         if (b_mode == 0) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 0, true, false, false, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, false, true>), grid, block, 0, s, a);
@@ -1622,9 +1509,6 @@ int launch_split(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 gri
         else { if (plain) RIH_LSS(1, true); else RIH_LSS(1, false); }
 #undef RIH_LSS
     }
-#if RIH_EXPERIMENTS
-    else if (a_mode == 0 && b_mode == 2) { if (plain) RIH_LS(0, 2, true); else RIH_LS(0, 2, false); }
-#endif
     else if (a_mode == 0 && b_mode == 0) { if (plain) RIH_LS(0, 0, true); else RIH_LS(0, 0, false); }
     else if (a_mode == 0 && b_mode == 1) { if (plain) RIH_LS(0, 1, true); else RIH_LS(0, 1, false); }
     else if (a_mode == 1 && b_mode == 0) { if (plain) RIH_LS(1, 0, true); else RIH_LS(1, 0, false); }
@@ -1633,454 +1517,6 @@ int launch_split(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 gri
     return (int)hipGetLastError();
 }
 
-#if RIH_EXPERIMENTS
-// ================================================================================================
-// Split engine, 256x128 block tile (tile id 4), software-pipelined in one instruction stream per SIMD.
-// Measured on MI355X: in the 128x128 kernels above the matrix pipe idles while (a) all waves of a block fetch their
-// MFMA operands from LDS at the same moment after each barrier and (b) late global loads are waited for.  Here:
-//   * 4 wavefronts (2x2), wave tile 128x64 = 4x2 MFMA tiles; a pipeline step is ONE k16 half-tile = 48 MFMAs;
-//   * LDS is a ring of four k16 half-stages (4 x 36 KiB): step h multiplies operands that are already in registers,
-//     prefetches the operands of step h+1 from slot (h+1)%4 (18 ds_read_b128), converts the raw fp32 registers of
-//     step h+2 (one k-tile ahead) into slot (h+2)%4 and re-issues the global loads of those registers for step h+4
-//     (two k-tiles ahead); one barrier per step;
-//   * the conversion units and loads are spread over the six 8-MFMA groups of the step so that VALU / LDS / VMEM
-//     instructions issue in the shadow of the matrix pipe (~4.5 of them per MFMA).
-// Half-stage layout per bf16 plane: [rows][8 dwords]; logical row m, 16-byte chunk c (8 k) -> physical row
-// m ^ ((m>>2)&3), chunk c ^ ((m>>4)&1): conflict-free b128 operand reads and K-contiguous b64 stores, 2-way (b64) /
-// 4-way (b32) conflicts on the transposing stores (the minimum for 16/32 lanes writing one k-column).
-// Preconditions as gemm_split_kernel.
-__device__ __forceinline__ int hs_row(int m) { return (m ^ ((m >> 2) & 3)) * 8; }
-__device__ __forceinline__ int hs_swz(int m) { return (m >> 4) & 1; }
-
-// ENG 2 (round 4): the two-term fp16 split -- two planes per operand, three MFMA groups of eight per step (hi*lo and lo*hi into
-// the correction accumulators, hi*hi into the main ones: 256 accumulator registers per lane at one wavefront per SIMD), two
-// conversion units behind each group; STATS: the BatchNorm statistics epilogue of store_tiles_wide (rows per block = 128).
-template <int AMODE, int BMODE, bool PLAIN, int ENG = 1, bool STATS = false>
-__global__ __launch_bounds__(256, 1) void gemm_split256_kernel(const GemmArgs p) {
-    constexpr int BM = 256, BN = 128;
-    constexpr int NPL = (ENG == 2) ? 2 : 3;             // 16-bit planes per operand
-    constexpr int HPA = BM * 8, HPB = BN * 8;           // dwords per plane of a half-stage
-    constexpr int HSTAGE = NPL * (HPA + HPB);           // engine 1: 9216 dwords = 36 KiB; engine 2: 6144 dwords = 24 KiB
-    constexpr int WM = 128, WN = 64, TM = 4, TN = 2;
-
-    __shared__ __attribute__((aligned(16))) unsigned smem[4 * HSTAGE];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int tilesN = (p.N + BN - 1) / BN;
-    // Workgroups are dispatched x-fastest and round-robin over the 8 XCDs.  Remap so that each XCD (private L2) gets a
-    // contiguous run of output tiles -- and, for a split-K launch, of (split, tile) pairs with the tile fastest, so
-    // that all tiles reading one K-range of the operands sit on the same XCD instead of fetching it eight times.
-    int bid, z = blockIdx.z;
-    if (p.splitk > 1 && gridDim.z == (unsigned)p.splitk) {
-        const int c = xcd_remap(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z);
-        bid = c % gridDim.x;
-        z = c / gridDim.x;
-    } else {
-        bid = xcd_remap(blockIdx.x, gridDim.x);
-    }
-    const int m0 = (bid / tilesN) * BM;
-    const int n0 = (bid % tilesN) * BN;
-
-    const int split = z % p.splitk;
-    const int bz = z / p.splitk;
-    const int b2 = bz % p.nb2, b1 = bz / p.nb2;
-    float* __restrict__ C = p.C + b1 * p.sC1 + b2 * p.sC2 + split * p.sCsplit;
-    const float* __restrict__ biasp = p.bias != nullptr ? p.bias + b1 * p.sBias1 : nullptr;
-    const float* __restrict__ Rp = p.R != nullptr ? p.R + b1 * p.sR1 : nullptr;
-    const __amdgpu_buffer_rsrc_t rA =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + b1 * p.sA1 + b2 * p.sA2), (short)0, (int)p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + b1 * p.sB1 + b2 * p.sB2), (short)0, (int)p.b_bytes, 0x00020000);
-
-    const int kbeg = split * p.kchunk;
-    const int kend = min(p.K, kbeg + p.kchunk);
-    const int ntiles = (kend - kbeg + BK - 1) / BK;
-    float e2_sa = 1.f, e2_sb = 1.f;
-    if (ENG == 2) {
-        e2_sa = e2_scale(p.amax_a, false);
-        e2_sb = e2_scale(p.amax_b, false);
-    }
-
-    // ------------------------------------------------------------------ per-thread loader constants
-    const int r4 = tid >> 2, qh = tid & 3;      // K-contiguous operands: row (+64 per pass), k-quad inside the half
-    unsigned a_off[4], a_val[4];
-    int a_st;                                   // LDS store offset (dwords) inside a half-stage
-    const int amq = tid & 63, akr = tid >> 6;   // AMODE 1: m-quad (64), k-quad inside the half (4)
-    int a1_wo[2] = {0, 0}, a1_ho[2] = {0, 0}, a1_img[2] = {0, 0};
-    int a1_kh = 0, a1_kw = 0;
-    unsigned a1_base = 0;
-    if (AMODE == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + r4 + 64 * i;
-            a_val[i] = 0;
-            if (m >= p.M) {
-                a_off[i] = OOB;
-            } else if (PLAIN) {
-                a_off[i] = ((unsigned)m * (unsigned)p.lda + 4u * qh) * 4u;
-            } else {
-                const int wo = m % p.Wo;
-                const int t = m / p.Wo;
-                const int ho = t % p.Ho;
-                const int img = t / p.Ho;
-                const int hi0 = ho * p.strideA - p.padH, wi0 = wo * p.strideA - p.padW;
-                a_off[i] = (unsigned)((((img * p.H + hi0) * p.W + wi0) * p.lda + 4 * qh) * 4);
-                unsigned bits = 0;
-                for (int kh = 0; kh < p.KH; ++kh)
-                    for (int kw = 0; kw < p.KW; ++kw)
-                        if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W)
-                            bits |= 1u << (kh * p.KW + kw);
-                a_val[i] = bits;
-            }
-        }
-        a_st = hs_row(r4) + 4 * ((qh >> 1) ^ hs_swz(r4)) + 2 * (qh & 1);      // + 512 per pass (64 rows)
-    } else {
-        const int mm = m0 + 4 * amq;
-        if (mm >= p.M) {
-            a1_base = OOB;
-        } else if (PLAIN) {
-            a1_base = ((unsigned)(akr * 4) * (unsigned)p.lda + (unsigned)mm) * 4u;
-        } else {
-            const int tap = mm / p.Cin;
-            a1_base = (unsigned)(mm - tap * p.Cin) * 4u;
-            a1_kh = tap / p.KW;
-            a1_kw = tap - a1_kh * p.KW;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int k0 = kbeg + 16 * s + akr * 4;
-                a1_wo[s] = k0 % p.Wo;
-                const int t = k0 / p.Wo;
-                a1_ho[s] = t % p.Ho;
-                a1_img[s] = t / p.Ho;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { a_off[i] = 0; a_val[i] = 0; }
-        // row 4*amq + j -> physical row 4*amq + (j ^ (amq&3)); chunk (akr>>1) ^ ((amq>>2)&1), quad-half akr&1
-        a_st = (4 * amq) * 8 + 4 * ((akr >> 1) ^ ((amq >> 2) & 1)) + 2 * (akr & 1);
-    }
-
-    unsigned b_off[2];
-    int b_st;
-    const int bnq = tid & 31, bkr = tid >> 5;   // BMODE 0: n-quad (32), k-pair inside the half (8)
-    if (BMODE == 1) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int n = n0 + r4 + 64 * i;
-            b_off[i] = (n < p.N) ? ((unsigned)n * (unsigned)p.ldb + 4u * qh) * 4u : OOB;
-        }
-        b_st = hs_row(r4) + 4 * ((qh >> 1) ^ hs_swz(r4)) + 2 * (qh & 1);
-    } else {
-        const int n = n0 + 4 * bnq;
-        const unsigned base = (n < p.N) ? ((unsigned)(bkr * 2) * (unsigned)p.ldb + (unsigned)n) * 4u : OOB;
-        b_off[0] = base;
-        b_off[1] = base + (unsigned)p.ldb * 4u;
-        b_st = (4 * bnq) * 8 + 4 * ((bkr >> 2) ^ ((bnq >> 2) & 1)) + (bkr & 3);
-    }
-
-    // wave-uniform (tap, channel) walk of the conv A-gather; stands on the k-tile whose loads are issued next
-    int u_tap = 0, u_ci = 0, u_kh = 0, u_kw = 0;
-    if (AMODE == 0 && !PLAIN) {
-        u_tap = kbeg / p.Cin;
-        u_ci = kbeg - u_tap * p.Cin;
-        u_kh = u_tap / p.KW;
-        u_kw = u_tap - u_kh * p.KW;
-    }
-
-    float4 rawA[2][4], rawB[2][2];
-
-    // loads of half `s` (k16) of the k-tile starting at `ktile`; a tile at or beyond kend arrives as zeros
-    auto load_A = [&](int ktile, int s) {
-        if (AMODE == 0) {
-            if (PLAIN) {
-                const unsigned ku = (ktile + 16 * s + 4 * qh < kend) ? (unsigned)(ktile + 16 * s) * 4u : OOB;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rawA[s][i] = bload4(rA, a_off[i] + ku);
-            } else {
-                const unsigned tapoff = (unsigned)(((u_kh * p.W + u_kw) * p.lda + u_ci + 16 * s) * 4);
-                const unsigned tapbit = (ktile < kend) ? (1u << (u_tap & 31)) : 0u;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rawA[s][i] = bload4(rA, (a_val[i] & tapbit) ? a_off[i] + tapoff : OOB);
-            }
-        } else {
-            if (PLAIN) {
-                const unsigned ku =
-                    (ktile + 16 * s + akr * 4 < kend) ? (unsigned)(ktile + 16 * s) * (unsigned)p.lda * 4u : OOB;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rawA[s][i] = bload4(rA, a1_base + ku + (unsigned)i * (unsigned)p.lda * 4u);
-            } else {
-                const int hi = a1_ho[s] * p.strideA - p.padH + a1_kh;
-                const int wi = a1_wo[s] * p.strideA - p.padW + a1_kw;
-                const bool rowok = (ktile + 16 * s + akr * 4 < kend) && (unsigned)hi < (unsigned)p.H;
-                const unsigned rowoff = (unsigned)((((a1_img[s] * p.H + hi) * p.W + wi) * p.lda) * 4) + a1_base;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bool ok = rowok && (unsigned)(wi + i * p.strideA) < (unsigned)p.W;
-                    rawA[s][i] = bload4(rA, ok ? rowoff + (unsigned)(i * p.strideA * p.lda * 4) : OOB);
-                }
-            }
-        }
-    };
-    auto advance_A = [&]() {        // once per k-tile, before the loads of its first half
-        if (AMODE == 0 && !PLAIN) {
-            u_ci += BK;
-            if (u_ci >= p.Cin) {
-                u_ci = 0;
-                ++u_tap;
-                if (++u_kw == p.KW) { u_kw = 0; ++u_kh; }
-            }
-        }
-        if (AMODE == 1 && !PLAIN) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                a1_wo[s] += BK;
-                while (a1_wo[s] >= p.Wo) { a1_wo[s] -= p.Wo; ++a1_ho[s]; }
-                while (a1_ho[s] >= p.Ho) { a1_ho[s] -= p.Ho; ++a1_img[s]; }
-            }
-        }
-    };
-    auto load_B = [&](int ktile, int s) {
-        if (BMODE == 1) {
-            const unsigned ku = (ktile + 16 * s + 4 * qh < kend) ? (unsigned)(ktile + 16 * s) * 4u : OOB;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) rawB[s][i] = bload4(rB, b_off[i] + ku);
-        } else {
-            const unsigned ku =
-                (ktile + 16 * s + bkr * 2 < kend) ? (unsigned)(ktile + 16 * s) * (unsigned)p.ldb * 4u : OOB;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) rawB[s][i] = bload4(rB, b_off[i] + ku);
-        }
-    };
-
-    auto put4 = [](unsigned* u, int plane, float sc, float x0, float x1, float x2, float x3) {
-        if (ENG == 2) {
-            unsigned h0, l0, h1, l1;
-            split2h(x0, x1, sc, h0, l0);
-            split2h(x2, x3, sc, h1, l1);
-            *reinterpret_cast<uint2*>(u) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(u + plane) = make_uint2(l0, l1);
-        } else {
-            unsigned h0, m0_, l0, h1, m1, l1;
-            split2(x0, x1, h0, m0_, l0);
-            split2(x2, x3, h1, m1, l1);
-            *reinterpret_cast<uint2*>(u) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(u + plane) = make_uint2(m0_, m1);
-            *reinterpret_cast<uint2*>(u + 2 * plane) = make_uint2(l0, l1);
-        }
-    };
-    auto put2 = [](unsigned* u, int plane, float sc, float x0, float x1) {
-        if (ENG == 2) {
-            unsigned h, l;
-            split2h(x0, x1, sc, h, l);
-            u[0] = h;
-            u[plane] = l;
-        } else {
-            unsigned h, m, l;
-            split2(x0, x1, h, m, l);
-            u[0] = h;
-            u[plane] = m;
-            u[2 * plane] = l;
-        }
-    };
-    auto elem = [](const float4& v, int j) -> float { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); };
-    // conversion unit u (0..3) of half s of the raw A registers -> half-stage `hs`
-    auto conv_A = [&](unsigned* hs, int s, int u) {
-        if (AMODE == 0) {
-            put4(hs + a_st + 512 * u, HPA, e2_sa, rawA[s][u].x, rawA[s][u].y, rawA[s][u].z, rawA[s][u].w);
-        } else {
-            put4(hs + a_st + 8 * (u ^ (amq & 3)), HPA, e2_sa, elem(rawA[s][0], u), elem(rawA[s][1], u), elem(rawA[s][2], u),
-                 elem(rawA[s][3], u));
-        }
-    };
-    // conversion slot u (0..1) of half s of the raw B registers
-    auto conv_B = [&](unsigned* hs, int s, int u) {
-        unsigned* bs = hs + NPL * HPA;
-        if (BMODE == 1) {
-            put4(bs + b_st + 512 * u, HPB, e2_sb, rawB[s][u].x, rawB[s][u].y, rawB[s][u].z, rawB[s][u].w);
-        } else {
-            put2(bs + b_st + 8 * ((2 * u) ^ (bnq & 3)), HPB, e2_sb, elem(rawB[s][0], 2 * u), elem(rawB[s][1], 2 * u));
-            put2(bs + b_st + 8 * ((2 * u + 1) ^ (bnq & 3)), HPB, e2_sb, elem(rawB[s][0], 2 * u + 1), elem(rawB[s][1], 2 * u + 1));
-        }
-    };
-
-    // ------------------------------------------------------------------ operand fetch
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const int ma = wm * WM + l31, nb = wn * WN + l31;
-    const int sa_rd = hs_row(ma) + 4 * (lhi ^ hs_swz(ma));
-    const int sb_rd = NPL * HPA + hs_row(nb) + 4 * (lhi ^ hs_swz(nb));
-    typedef typename std::conditional<ENG == 2, f16x8, bf16x8>::type opnd_t;
-    opnd_t av[2][NPL][TM], bv[2][NPL][TN];
-    auto fetch = [&](const unsigned* hs, int set) {
-        if constexpr (ENG == 2) {       // in order of first use: A.lo B.hi | A.hi | B.lo
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                av[set][1][i] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + HPA + sa_rd + i * 256));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bv[set][0][j] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + sb_rd + j * 256));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                av[set][0][i] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + sa_rd + i * 256));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bv[set][1][j] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + HPB + sb_rd + j * 256));
-        } else {                        // in order of first use: A.lo B.hi | A.hi B.lo | A.mid B.mid
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                av[set][NPL - 1][i] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + 2 * HPA + sa_rd + i * 256));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bv[set][0][j] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + sb_rd + j * 256));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                av[set][0][i] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + sa_rd + i * 256));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bv[set][NPL - 1][j] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + 2 * HPB + sb_rd + j * 256));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                av[set][1][i] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + HPA + sa_rd + i * 256));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bv[set][1][j] = __builtin_bit_cast(opnd_t, *reinterpret_cast<const uint4*>(hs + HPB + sb_rd + j * 256));
-        }
-    };
-
-    // ------------------------------------------------------------------ prologue
-    floatx16 acc[TM][TN];
-    floatx16 acc1[ENG == 2 ? TM : 1][TN];           // engine 2: hi*lo + lo*hi (scaled by 2^11)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[i][j][r] = 0.f;
-                if (ENG == 2) acc1[i][j][r] = 0.f;
-            }
-
-#pragma unroll
-    for (int s = 0; s < 2; ++s) { load_A(kbeg, s); load_B(kbeg, s); }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) conv_A(smem + s * HSTAGE, s, u);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) conv_B(smem + s * HSTAGE, s, u);
-    }
-    advance_A();
-#pragma unroll
-    for (int s = 0; s < 2; ++s) { load_A(kbeg + BK, s); load_B(kbeg + BK, s); }
-    __syncthreads();
-    fetch(smem, 0);
-
-    // ------------------------------------------------------------------ main loop: step h = 2t + s
-    for (int t = 0; t < ntiles; ++t) {
-        const int k2 = kbeg + (t + 2) * BK;         // k-tile whose loads are issued during this iteration
-        unsigned* slot_t0 = smem + ((2 * t) & 3) * HSTAGE;      // slots of steps (t,0), (t,1); (t+1, s) = slot (t, s) ^ 2
-        unsigned* slot_t1 = smem + ((2 * t + 1) & 3) * HSTAGE;
-        unsigned* slot_n0 = smem + ((2 * t + 2) & 3) * HSTAGE;
-        unsigned* slot_n1 = smem + ((2 * t + 3) & 3) * HSTAGE;
-        (void)slot_t0;
-        if constexpr (ENG == 2) {
-#define RIH_E2_TERM(ACC_, S_, PA_, PB_)                                                                           \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) ACC_[i][j] =    \
-        __builtin_amdgcn_mfma_f32_32x32x16_f16(av[S_][PA_][i], bv[S_][PB_][j], ACC_[i][j], 0, 0, 0);
-            // group G of step S: 8 MFMAs + two conversion units of step (t+1, S) (+ reload of their registers for t+2)
-#define RIH_E2_GROUP(S_, G_, ACC_, PA_, PB_, DST_)                                                                \
-    RIH_E2_TERM(ACC_, S_, PA_, PB_)                                                                               \
-    if ((G_) == 0) { conv_A(DST_, S_, 0); conv_A(DST_, S_, 1); }                                                  \
-    if ((G_) == 1) { conv_A(DST_, S_, 2); conv_A(DST_, S_, 3); if ((S_) == 0) advance_A(); load_A(k2, S_); }      \
-    if ((G_) == 2) { conv_B(DST_, S_, 0); conv_B(DST_, S_, 1); load_B(k2, S_); }                                  \
-    __builtin_amdgcn_sched_barrier(0);
-            fetch(slot_t1, 1);
-            RIH_E2_GROUP(0, 0, acc1, 1, 0, slot_n0)
-            RIH_E2_GROUP(0, 1, acc, 0, 0, slot_n0)
-            RIH_E2_GROUP(0, 2, acc1, 0, 1, slot_n0)
-            __syncthreads();
-            fetch(slot_n0, 0);
-            RIH_E2_GROUP(1, 0, acc1, 1, 0, slot_n1)
-            RIH_E2_GROUP(1, 1, acc, 0, 0, slot_n1)
-            RIH_E2_GROUP(1, 2, acc1, 0, 1, slot_n1)
-            __syncthreads();
-#undef RIH_E2_GROUP
-#undef RIH_E2_TERM
-        } else {
-#define RIH_SPLIT_TERM(S_, PA_, PB_)                                                                              \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =      \
-        __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[S_][PA_][i], bv[S_][PB_][j], acc[i][j], 0, 0, 0);
-        // group G of step S: 8 MFMAs + one conversion unit of step (t+1, S) (+ reload of its registers for t+2)
-#define RIH_GROUP(S_, G_, PA_, PB_, DST_)                                                                         \
-    RIH_SPLIT_TERM(S_, PA_, PB_)                                                                                  \
-    if ((G_) < 4) conv_A(DST_, S_, (G_));                                                                         \
-    if ((G_) == 3) { if ((S_) == 0) advance_A(); load_A(k2, S_); }                                                \
-    if ((G_) >= 4) conv_B(DST_, S_, (G_) - 4);                                                                    \
-    if ((G_) == 5) load_B(k2, S_);                                                                                \
-    __builtin_amdgcn_sched_barrier(0);
-        // ---- step (t, 0): operands in set 0; prefetch step (t, 1) into set 1
-        fetch(slot_t1, 1);
-        RIH_GROUP(0, 0, 2, 0, slot_n0)
-        RIH_GROUP(0, 1, 0, 2, slot_n0)
-        RIH_GROUP(0, 2, 1, 1, slot_n0)
-        RIH_GROUP(0, 3, 1, 0, slot_n0)
-        RIH_GROUP(0, 4, 0, 1, slot_n0)
-        RIH_GROUP(0, 5, 0, 0, slot_n0)
-        __syncthreads();
-        // ---- step (t, 1): operands in set 1; prefetch step (t+1, 0) into set 0
-        fetch(slot_n0, 0);
-        RIH_GROUP(1, 0, 2, 0, slot_n1)
-        RIH_GROUP(1, 1, 0, 2, slot_n1)
-        RIH_GROUP(1, 2, 1, 1, slot_n1)
-        RIH_GROUP(1, 3, 1, 0, slot_n1)
-        RIH_GROUP(1, 4, 0, 1, slot_n1)
-        RIH_GROUP(1, 5, 0, 0, slot_n1)
-        __syncthreads();
-#undef RIH_GROUP
-#undef RIH_SPLIT_TERM
-        }
-    }
-
-    // ------------------------------------------------------------------ epilogue (store_tiles_wide; the main loop ended with a barrier)
-    if constexpr (ENG == 2) {
-        store_tiles_wide<TM, TN, STATS, false, true>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp, m0 + wm * WM,
-                                                     n0 + wn * WN, lane, acc1, 1.f / e2_sa, 1.f / e2_sb);
-    } else {
-        store_tiles_wide<TM, TN, STATS>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * SLD), C, biasp, Rp, m0 + wm * WM, n0 + wn * WN, lane);
-    }
-}
-
-int launch_split256(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 grid, hipStream_t s, int engine) {
-    dim3 block(256);
-    if (a_mode == 1 && b_mode == 1) return RIH_EINVAL;
-    if (engine == 2) {
-#define RIH_LS(AM_, BM_, PL_, ST_) hipLaunchKernelGGL((gemm_split256_kernel<AM_, BM_, PL_, 2, ST_>), grid, block, 0, s, a)
-        if (a.stats != nullptr) {       // forward-type only (checked by the caller)
-            if (b_mode == 0) { if (plain) RIH_LS(0, 0, true, true); else RIH_LS(0, 0, false, true); }
-            else { if (plain) RIH_LS(0, 1, true, true); else RIH_LS(0, 1, false, true); }
-        }
-        else if (a_mode == 0 && b_mode == 0) { if (plain) RIH_LS(0, 0, true, false); else RIH_LS(0, 0, false, false); }
-        else if (a_mode == 0 && b_mode == 1) { if (plain) RIH_LS(0, 1, true, false); else RIH_LS(0, 1, false, false); }
-        else { if (plain) RIH_LS(1, 0, true, false); else RIH_LS(1, 0, false, false); }
-#undef RIH_LS
-        return (int)hipGetLastError();
-    }
-    if (a.stats != nullptr) return RIH_EINVAL;
-#define RIH_LS(AM_, BM_, PL_) hipLaunchKernelGGL((gemm_split256_kernel<AM_, BM_, PL_>), grid, block, 0, s, a)
-    if (a_mode == 0 && b_mode == 0) { if (plain) RIH_LS(0, 0, true); else RIH_LS(0, 0, false); }
-    else if (a_mode == 0 && b_mode == 1) { if (plain) RIH_LS(0, 1, true); else RIH_LS(0, 1, false); }
-    else if (a_mode == 1 && b_mode == 0) { if (plain) RIH_LS(1, 0, true); else RIH_LS(1, 0, false); }
-    else return RIH_EINVAL;
-#undef RIH_LS
-    return (int)hipGetLastError();
-}
-
-#else
-int launch_split256(const GemmArgs&, int, int, bool, dim3, hipStream_t, int) { return RIH_EINVAL; }     // tile 4: experiment builds only
-#endif
 
 // One-launch split-K reduction for weight gradients: each 256-thread block sums an 8x32 tile of the S partial slabs
 // P[s][Mp][N] in a fixed order (deterministic) and writes it transposed into the parameter layout through LDS; blocks
@@ -2264,73 +1700,6 @@ __global__ __launch_bounds__(256) void pack_conv_weight_multi_kernel(const PackP
     }
 }
 
-// Pre-split B operands for gemm_split_kernel<..., BMODE 2>: dst = three bf16 planes [hi | mid | lo][N][Kpad] (as dwords
-// [3][N][Kpad/2], k even in the low half), B(k, n) taken from
-//   mode 0 / 1: a plain matrix in b_mode 0 / 1 layout (src[k*ld + n] / src[n*ld + k]);
-//   mode 2: an OIHW conv weight as the forward operand, k = (tap, ci < CinPad), n = co;
-//   mode 3: an OIHW conv weight as the data-gradient operand of the tap subset (kh0 + step*t, kw0 + step*t'), flipped:
-//           k = ((th, tw), co), n = ci < CinPad  (the full stride-1 gradient is kh0 = kw0 = 0, step 1, Th x Tw = KH x KW).
-struct PresplitArgs {
-    const float* src;
-    unsigned* dst;
-    int N, K, Kpad, mode, ld;
-    int Cout, Cin, KH, KW, CinPad, kh0, kw0, step, Th, Tw;
-    const float* amax;      // engine 2: the operand's bound block -> TWO fp16 planes [hi | lo] of the scaled values; NULL: three bf16 planes
-};
-__device__ __forceinline__ float presplit_fetch(const PresplitArgs& a, int n, int k) {
-    if (k >= a.K) return 0.f;
-    if (a.mode == 0) return a.src[(long long)k * a.ld + n];
-    if (a.mode == 1) return a.src[(long long)n * a.ld + k];
-    if (a.mode == 2) {
-        const int tap = k / a.CinPad, ci = k - tap * a.CinPad;
-        return ci < a.Cin ? a.src[((long long)n * a.Cin + ci) * (a.KH * a.KW) + tap] : 0.f;
-    }
-    const int co = k % a.Cout, t = k / a.Cout;
-    const int tw = t % a.Tw, th = t / a.Tw;
-    const int kh = a.kh0 + a.step * (a.Th - 1 - th), kw = a.kw0 + a.step * (a.Tw - 1 - tw);
-    return n < a.Cin ? a.src[(((long long)co * a.Cin + n) * a.KH + kh) * a.KW + kw] : 0.f;
-}
-__device__ __forceinline__ void presplit_span(const PresplitArgs& a, long long first, long long stride) {
-    const int half = a.Kpad / 2;
-    const long long plane = (long long)a.N * half, total = plane;
-    // engine 2: the same power-of-two scale the GEMM derives from the same bound block (e2_scale: every lane of the wave takes part)
-    const float sc = a.amax != nullptr ? e2_scale(a.amax, false) : 1.f;
-    for (long long i = first; i < total; i += stride) {
-        const int n = (int)(i / half), j = (int)(i - (long long)n * half);
-        const float x0 = presplit_fetch(a, n, 2 * j), x1 = presplit_fetch(a, n, 2 * j + 1);
-        if (a.amax != nullptr) {
-            unsigned h, l;
-            split2h(x0, x1, sc, h, l);
-            a.dst[i] = h;
-            a.dst[i + plane] = l;
-        } else {
-            unsigned h, m, l;
-            split2(x0, x1, h, m, l);
-            a.dst[i] = h;
-            a.dst[i + plane] = m;
-            a.dst[i + 2 * plane] = l;
-        }
-    }
-}
-__global__ void presplit_kernel(const PresplitArgs a) {
-    presplit_span(a, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
-}
-// every pre-split weight operand of a step in one launch (rih_presplit_multi; descriptors by value)
-constexpr int PRESPLIT_PACK = 40;
-struct PresplitPack {
-    PresplitArgs d[PRESPLIT_PACK];
-    int first[PRESPLIT_PACK + 1];
-    int n;
-};
-static_assert(sizeof(PresplitPack) <= 4096, "kernel argument limit");
-__global__ __launch_bounds__(256) void presplit_multi_kernel(const PresplitPack pk) {
-    const int b = (int)blockIdx.x;
-    int k = 0;
-    while (k + 1 < pk.n && b >= pk.first[k + 1]) ++k;
-    const int nb = pk.first[k + 1] - pk.first[k];
-    presplit_span(pk.d[k], (long long)(b - pk.first[k]) * 256 + threadIdx.x, (long long)nb * 256);
-}
-
 }  // namespace
 
 extern "C" int rih_pack_conv_weight_multi(const rih_pack_desc* descs, int n, void* stream) {
@@ -2373,74 +1742,14 @@ extern "C" int rih_pack_conv_weight_sub(const float* w, float* dst, int Cout, in
     return (int)hipGetLastError();
 }
 
-static int launch_presplit(const PresplitArgs& a, void* stream) {
-    const long long total = (long long)a.N * (a.Kpad / 2);
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(presplit_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
-}
-extern "C" int rih_presplit_matrix(const float* B, int b_mode, int K, int N, int ldb, void* dst, int Kpad, const float* amax_e2,
-                                   void* stream) {
-    if (!B || !dst || (b_mode != 0 && b_mode != 1) || K < 1 || N < 1 || Kpad < K || Kpad % 32 != 0) return RIH_EINVAL;
-    if (ldb < (b_mode == 0 ? N : K)) return RIH_EINVAL;
-    PresplitArgs a = {};
-    a.src = B; a.dst = (unsigned*)dst; a.N = N; a.K = K; a.Kpad = Kpad; a.mode = b_mode; a.ld = ldb; a.amax = amax_e2;
-    return launch_presplit(a, stream);
-}
-static int presplit_conv_args(PresplitArgs& a, const float* w, void* dst, int Cout, int Cin, int KH, int KW, int CinPad,
-                              int for_dgrad, int kh0, int kw0, int step, int Th, int Tw, int Kpad, const float* amax_e2) {
-    if (!w || !dst || Cout < 1 || Cin < 1 || KH < 1 || KW < 1 || CinPad < Cin || Kpad % 32 != 0) return RIH_EINVAL;
-    a = PresplitArgs{};
-    a.src = w; a.dst = (unsigned*)dst; a.Kpad = Kpad; a.amax = amax_e2;
-    a.Cout = Cout; a.Cin = Cin; a.KH = KH; a.KW = KW; a.CinPad = CinPad;
-    if (!for_dgrad) {
-        a.mode = 2; a.N = Cout; a.K = KH * KW * CinPad;
-    } else {
-        if (step < 1 || Th < 1 || Tw < 1 || kh0 < 0 || kw0 < 0 || kh0 + step * (Th - 1) >= KH || kw0 + step * (Tw - 1) >= KW)
-            return RIH_EINVAL;
-        a.mode = 3; a.N = CinPad; a.K = Th * Tw * Cout;
-        a.kh0 = kh0; a.kw0 = kw0; a.step = step; a.Th = Th; a.Tw = Tw;
-    }
-    if (Kpad < a.K) return RIH_EINVAL;
-    return 0;
-}
-extern "C" int rih_presplit_conv_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int CinPad,
-                                        int for_dgrad, int kh0, int kw0, int step, int Th, int Tw, int Kpad, const float* amax_e2,
-                                        void* stream) {
-    PresplitArgs a;
-    const int rc = presplit_conv_args(a, w, dst, Cout, Cin, KH, KW, CinPad, for_dgrad, kh0, kw0, step, Th, Tw, Kpad, amax_e2);
-    if (rc != 0) return rc;
-    return launch_presplit(a, stream);
-}
-extern "C" int rih_presplit_multi(const rih_presplit_desc* descs, int n, void* stream) {
-    if (n < 0 || (n > 0 && !descs)) return RIH_EINVAL;
-    for (int base = 0; base < n; base += PRESPLIT_PACK) {
-        PresplitPack pk;
-        pk.n = (n - base < PRESPLIT_PACK) ? n - base : PRESPLIT_PACK;
-        int total = 0;
-        for (int i = 0; i < pk.n; ++i) {
-            const rih_presplit_desc& d = descs[base + i];
-            const int rc = presplit_conv_args(pk.d[i], d.w, d.dst, d.Cout, d.Cin, d.KH, d.KW, d.CinPad, d.for_dgrad, d.kh0, d.kw0,
-                                              d.step, d.Th, d.Tw, d.Kpad, d.amax_e2);
-            if (rc != 0) return rc;
-            const long long el = (long long)pk.d[i].N * (d.Kpad / 2);
-            long long nb = (el + 2047) / 2048;          // 8 dword pairs per thread
-            pk.first[i] = total;
-            total += (int)(nb > 512 ? 512 : nb);
-        }
-        pk.first[pk.n] = total;
-        hipLaunchKernelGGL(presplit_multi_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, pk);
-    }
-    return (int)hipGetLastError();
-}
+
 
 struct PreparedGemm {       // what gemm_impl would launch on the split engine's fast path (tiles 0..2), for rih_gemm_multi
     GemmArgs a;
     int gx, gz, tile, a_mode, b_mode, plain, engine;
 };
 
-static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, PreparedGemm* prep = nullptr, int* engine_out = nullptr,
-                     int* bnb_rows = nullptr) {
+static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, PreparedGemm* prep = nullptr, int* engine_out = nullptr) {
     if (!d || !d->A || !d->B || !d->C) return RIH_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K < 0) return RIH_EINVAL;
     if (d->splitk < 1 || d->nb1 < 1 || d->nb2 < 1) return RIH_EINVAL;
@@ -2489,11 +1798,6 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
     a.cS = d->cS; a.cOH = d->cOH; a.cOW = d->cOW; a.cH = d->cH; a.cW = d->cW;
     a.ones_row = d->ones_row;
     a.stats = d->stats;
-    // (rih_gemm_bnb_rows asks about the path only: the bnb fields of its descriptor are ignored)
-    const bool bnb = d->bnb_part != nullptr && bnb_rows == nullptr && stats_rows == nullptr && engine_out == nullptr;
-    a.bnb_x = bnb ? d->bnb_x : nullptr; a.bnb_mask = bnb ? d->bnb_mask : nullptr; a.bnb_mean = bnb ? d->bnb_mean : nullptr;
-    a.bnb_invstd = bnb ? d->bnb_invstd : nullptr; a.bnb_part = bnb ? d->bnb_part : nullptr;
-    a.bnb_ldx = d->bnb_ldx; a.bnb_T = d->bnb_T;
     a.drop_thr = 0u; a.drop_scale = 1.f; a.drop_seed = 0ull; a.drop_seed_dev = nullptr;
     a.amax_a = d->amax_a; a.amax_b = d->amax_b;
     for (int i = 0; i < 3; ++i) { a.Aseg[i] = nullptr; a.ldaseg[i] = 0; a.kseg[i] = 0; a.aseg_bytes[i] = 0; }
@@ -2537,23 +1841,22 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
                     (d->R == nullptr || (((uintptr_t)d->R % 16 == 0) && al4(d->ldr) && al4(d->sR1))) &&
                     (d->bias == nullptr || (((uintptr_t)d->bias % 16 == 0) && al4(d->sBias1)));
     }
-    if (d->ones_row != 0 && (d->a_mode != 1 || d->ones_row < 0 || d->ones_row >= d->M || d->tile == 4)) return RIH_EINVAL;
+    if (d->ones_row != 0 && (d->a_mode != 1 || d->ones_row < 0 || d->ones_row >= d->M)) return RIH_EINVAL;
     if (d->cS > 1 && (d->splitk != 1 || d->a_mode == 1 || d->R != nullptr || d->cH < 1 || d->cW < 1 || d->cOH < 0 ||
                       d->cOW < 0 || d->nb1 * d->nb2 != 1))
         return RIH_EINVAL;
     int bm = 128, bn = 128;
-    if (d->tile == 4) { bm = 256; bn = 128; }
-    else if (d->tile == 1) { bm = 128; bn = 64; }
+    if (d->tile == 1) { bm = 128; bn = 64; }
     else if (d->tile == 2) { bm = 64; bn = 64; }
     else if (d->tile == 3) { bm = 128; bn = 32; }
-    else if (d->tile != 0 && d->tile != 4) return RIH_EINVAL;
+    else if (d->tile != 0) return RIH_EINVAL;
     const long long tiles = (long long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn);
     const long long gz = (long long)d->nb1 * d->nb2 * d->splitk;
     if (tiles > 0x7fffffffLL || gz > 65535) return RIH_EINVAL;
     dim3 grid((unsigned)tiles, 1, (unsigned)gz);
     hipStream_t s = (hipStream_t)stream;
     if (d->engine < 0 || d->engine > 2) return RIH_EINVAL;
-    if (!RIH_EXPERIMENTS && (d->tile == 4 || d->a_mode == 2 || d->b_mode == 2)) return RIH_EINVAL;     // (see RIH_EXPERIMENTS)
+    if (d->a_mode > 1 || d->b_mode > 1) return RIH_EINVAL;
     // engine 2 exists on the split engines' fast path only (tiles 0..2, operands converted by the kernel): anything else that
     // asks for it runs engine 1 -- same fp32-grade result, the six-product arithmetic (rih_gemm_engine tells in advance)
     const bool e2 = d->engine == 2 && d->tile <= 2 && d->a_mode <= 1 && (d->b_mode <= 1 || (d->b_mode == 2 && d->a_mode == 0));
@@ -2578,21 +1881,6 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
         if (d->a_mode != 1 && !plain) ok = ok && (d->Cin % 32 == 0) && (d->KH * d->KW <= 32);
         if (d->a_mode == 1) ok = ok && (d->M % 4 == 0) && (plain || (d->Wo % 4 == 0 && d->Cin % 4 == 0));
         if (d->b_mode == 0) ok = ok && (d->N % 4 == 0);
-        if (d->tile == 4) {     // 256x128 kernel: no general-kernel fallback, the caller must respect the preconditions
-            const bool e2t4 = d->engine == 2 && d->a_mode <= 1 && d->b_mode <= 1 && d->ones_row == 0;
-            ok = ok && !(d->a_mode == 1 && d->b_mode == 1) && d->a_mode <= 1 && d->b_mode <= 1;
-            // the statistics epilogue exists in the engine-2 form only: forward-type, no split-K, no batch, dense rows
-            const bool st_ok = ok && e2t4 && d->a_mode == 0 && d->splitk == 1 && gz == 1 && d->cS <= 1;
-            if (stats_rows != nullptr) { *stats_rows = st_ok ? 128 : 0; return 0; }
-            if (bnb_rows != nullptr) { *bnb_rows = 0; return 0; }
-            if (prep != nullptr || bnb) return RIH_EINVAL;
-            if (d->drop_p != 0.f || (d->stats != nullptr && !st_ok)) return RIH_EINVAL;
-            if (!ok) return RIH_EINVAL;
-            if (engine_out != nullptr) { *engine_out = e2t4 ? 2 : 1; return 0; }
-            a.a_bytes = (unsigned)a_bytes;
-            a.b_bytes = (unsigned)b_bytes;
-            return launch_split256(a, d->a_mode, d->b_mode, plain, grid, s, e2t4 ? 2 : 1);
-        }
         const bool b_stats_ok = d->b_mode <= 1 || (e2 && d->b_mode == 2);      // (engine 1's pre-split B path has no statistics variant)
         if (d->stats != nullptr && !(ok && d->tile <= 2 && d->a_mode == 0 && b_stats_ok && d->splitk == 1 && gz == 1 &&
                                      d->cS <= 1))
@@ -2605,18 +1893,6 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
             *stats_rows = (ok && d->tile <= 2 && d->a_mode == 0 && b_stats_ok && d->splitk == 1 && gz == 1 && d->cS <= 1)
                               ? bm / 2 : 0;
             return 0;
-        }
-        // BatchNorm-backward sums in the epilogue: engine 2, forward-type operand forms, one launch slice, whole quads
-        const bool bnb_ok = RIH_EXPERIMENTS && ok && e2 && d->tile <= 2 && d->a_mode == 0 && d->b_mode <= 1 && d->splitk == 1 && gz == 1 &&
-                            d->cS <= 1 && d->stats == nullptr && d->drop_p == 0.f && !seg && prep == nullptr && d->N % 4 == 0 &&
-                            a.epi_vec;
-        if (bnb_rows != nullptr) { *bnb_rows = bnb_ok ? bm / 2 : 0; return 0; }
-        if (bnb) {
-            const int rows_per = bm / 2;
-            if (!bnb_ok || !d->bnb_x || !d->bnb_mean || !d->bnb_invstd || d->bnb_ldx < d->N || d->bnb_ldx % 4 != 0 ||
-                d->bnb_T != (d->M + rows_per - 1) / rows_per || ((uintptr_t)d->bnb_x % 16) != 0 ||
-                ((uintptr_t)d->bnb_mean % 16) != 0 || ((uintptr_t)d->bnb_invstd % 16) != 0 || ((uintptr_t)d->bnb_part % 16) != 0)
-                return RIH_EINVAL;
         }
         if (d->b_mode == 2 && d->engine == 2 && !(ok && e2)) return RIH_EINVAL;     // (no kernel reads two fp16 planes elsewhere)
         if (seg && (!ok || prep != nullptr)) return RIH_EINVAL;                      // (no other kernel reads a segmented A)
@@ -2646,12 +1922,9 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
     }
     if (d->drop_p != 0.f || seg) return RIH_EINVAL;           // the general kernels have no dropout epilogue / segmented A
     if (stats_rows != nullptr) { *stats_rows = 0; return 0; }
-    if (bnb_rows != nullptr) { *bnb_rows = 0; return 0; }
-    if (bnb) return RIH_EINVAL;                               // no BatchNorm-backward epilogue outside engine 2's fast path
     if (prep != nullptr) return RIH_EINVAL;                   // not a fast-path descriptor: no grouped launch
     if (d->stats != nullptr) return RIH_EINVAL;
     if (d->b_mode == 2 || d->a_mode == 2) return RIH_EINVAL;  // the general kernels do not read pre-split operands
-    if (d->tile == 4) return RIH_EINVAL;    // 256x128 exists only on the split engine's fast path
     if (engine_out != nullptr) {                              // rih_gemm_engine: a query, no launch
         if (d->tile == 3) *engine_out = 0;
         return 0;
@@ -2663,7 +1936,6 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
 }
 
 extern "C" int rih_gemm(const rih_gemm_desc* d, void* stream) { return gemm_impl(d, stream, nullptr); }
-extern "C" int rih_experiments(void) { return RIH_EXPERIMENTS ? 1 : 0; }
 
 // ---- grouped launch.  Variant id = tile * 8 + a_mode * 4 + b_mode * 2 + plain of the split engine's fast path; the variants
 // instantiated for the grouped kernel are the weight-gradient ones (a_mode 1, b_mode 0; 64x64 and 128x128 tiles) and the
@@ -2771,12 +2043,6 @@ extern "C" int rih_gemm_stats_rows(const rih_gemm_desc* d) {
     if (gemm_impl(d, nullptr, &rows) != 0) return 0;
     return rows;
 }
-extern "C" int rih_gemm_bnb_rows(const rih_gemm_desc* d) {
-    int rows = 0;
-    if (gemm_impl(d, nullptr, nullptr, nullptr, nullptr, &rows) != 0) return 0;
-    return rows;
-}
-
 extern "C" int rih_splitk_reduce_bias_batched(const float* P, int S, int Mp, int M, int N, float* dst, int Cin, int taps,
                                               int CinValid, int accumulate, float* db, int nb, int64_t sP, int64_t sDst,
                                               int64_t sDb, void* stream) {

@@ -55,10 +55,6 @@ def plan_gemm(M, N, K, batch=1, engine=None):
     blocks per CU and long k-loops (its per-block prologue/epilogue is expensive), so deep-K problems with few
     output tiles are split over K instead of shrinking the tile."""
     e = ENGINE if engine is None else engine
-    if e == 2 and E2_TILE4 and experiments_built() and N >= 128 and K >= E2_TILE4_MINK and _cdiv(M, 256) * _cdiv(N, 128) * batch >= E2_TILE4_MIN:
-        # engine 2's 256x128 software-pipelined kernel (one workgroup per CU, conversion interleaved with the MFMAs by hand):
-        # large-M problems with at least E2_TILE4_MIN workgroups
-        return 4, 1
     if e == 2 and E2_SHORTK_T1 and K <= 256 and N >= 64 and _cdiv(M, 128) * _cdiv(N, 64) * batch >= 512:
         # engine 2, short reductions on large maps (the 1x1 convolutions of layer1 / layer2 and their data gradients): 128x64
         # tiles beat the 64x64 tiles of engine 1's rule by 5-15 % and the 128x128 ones by 3-8 % (profiles/r04/tile_sweep_engine2_c6.log)
@@ -98,14 +94,8 @@ def plan_gemm(M, N, K, batch=1, engine=None):
     return tile, 1
 
 
-_TILE_MN = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (256, 128)}
-# RIH_E2_TILE4=1 (experiment builds): the planner may pick the 256x128 pipelined kernel for engine-2 launches (see plan_gemm).
-# Measured in round 4: 361 us against 293-318 on the 64x64 128->128 3x3 convolution, the whole step -3 % (profiles/r04/ab/c5_*,
-# gemm_pmc_table_top12_engine2_tile4_c5_NEGATIVE.txt): at one wavefront per SIMD the conversion work is not hidden.
+_TILE_MN = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32)}
 E2_SHORTK_T1 = os.environ.get('RIH_E2_SHORTK_TILE1', '1') == '1'       # engine 2: 128x64 tiles for short reductions on large maps
-E2_TILE4 = os.environ.get('RIH_E2_TILE4', '0') == '1'
-E2_TILE4_MIN = int(os.environ.get('RIH_E2_TILE4_MIN', '192'))
-E2_TILE4_MINK = int(os.environ.get('RIH_E2_TILE4_MINK', '256'))
 
 # MFMA engine of rih_gemm (include/renderih_amd.h): 2 (default since round 4) = fp32 on THREE fp16 MFMA products (scaled two-term
 # split, 833 TF ceiling) wherever a call site has operand bounds (the convolutions: bounds from the BatchNorm kernels), engine 1
@@ -306,82 +296,6 @@ def _seed_dev():
 # Run the per-hand decoder layers as paired launches on hands-stacked activations (LinearPairFn & co. below).
 PAIR_HANDS = os.environ.get('RIH_PAIR_HANDS', '1') != '0'
 
-# Pre-split weight operands (rih_gemm b_mode 2): the bf16 hi/mid/lo planes of a convolution weight are produced once per
-# use by rih_presplit_conv_weight instead of inside the GEMM's loader.  OFF by default: measured in round 2 -- 45.9 ms per step
-# against 45.2 (=2: 50.1 ms); the split GEMMs are power-bound, not conversion-bound (profiles/r02/bench_m1_*).
-PRESPLIT = os.environ.get('RIH_PRESPLIT', '0') in ('1', '2')
-# RIH_PRESPLIT=2 additionally pre-splits the ACTIVATION operand of those GEMMs with a standalone pass (rih_gemm a_mode 2):
-# the experiment that tells whether producers (BatchNorm apply / backward) should emit bf16 planes themselves.
-PRESPLIT_ACT = os.environ.get('RIH_PRESPLIT', '0') == '2' and ENGINE == 1         # (an engine-1 experiment)
-
-
-# Engine 2, optional (RIH_E2_PRESPLIT=1): the two fp16 planes of every convolution WEIGHT operand (forward and data-gradient
-# layouts) produced once per step -- rih_presplit_multi, one launch, through ops._PACK under TrainStep -- instead of inside every
-# GEMM's loader, which then converts nothing for B.  Measured in round 4 (profiles/r04/ab/c4_*, gemm_pmc_table_top12_engine2_
-# presplitB_c4.txt): the GEMMs themselves gain 2-8 % per shape, the whole step nothing (1921.9 against 1922.6 images/s: the
-# planes' own launch and traffic eat it).  Off by default; parity-tested in both settings (tests/test_gpu_paths.py).
-E2_PRESPLIT = os.environ.get('RIH_E2_PRESPLIT', '0') == '1'
-
-
-def _presplit_weight(w, Cx, for_dgrad, sub=None):
-    """(planes, Kpad) of an OIHW weight as forward operand (N = Cout) or as data-gradient operand of the tap subset
-    `sub` = (kh0, kw0, step, Th, Tw) (N = Cx): three bf16 planes (engine 1, RIH_PRESPLIT) or two scaled fp16 planes (engine 2;
-    scale from bound_of(w), which the GEMM must be given as amax_b).  Through ops._PACK when one is installed."""
-    Cout, Cin, KH, KW = w.shape
-    kh0, kw0, step, Th, Tw = sub if sub is not None else (0, 0, 1, KH, KW)
-    K = KH * KW * Cx if not for_dgrad else Th * Tw * Cout
-    Nn = Cout if not for_dgrad else Cx
-    Kp = _cdiv(K, 32) * 32
-    e2 = ENGINE == 2
-    fields = (Cout, Cin, KH, KW, Cx, 1 if for_dgrad else 0, kh0, kw0, step, Th, Tw, Kp)
-    pc = _PACK
-    if pc is not None:
-        key = ('presplit', e2, w.data_ptr()) + fields
-        e = pc.entries.get(key)
-        if e is not None and pc.fresh:
-            return e[1], Kp
-        if e is None:
-            planes = torch.empty((2 if e2 else 3, Nn, Kp // 2), device=w.device, dtype=torch.float32)   # one float = two halves
-            pc.entries[key] = (w if e2 else w.detach(), planes, ('presplit', e2) + fields)
-        else:
-            planes = e[1]
-    else:
-        planes = torch.empty((2 if e2 else 3, Nn, Kp // 2), device=w.device, dtype=torch.float32)
-    check(_L().rih_presplit_conv_weight(w.data_ptr(), planes.data_ptr(), Cout, Cin, KH, KW, Cx, 1 if for_dgrad else 0,
-                                        kh0, kw0, step, Th, Tw, Kp, bound_of(w).data_ptr() if e2 else 0, _stream()),
-          'rih_presplit_conv_weight')
-    return planes, Kp
-
-
-def _presplit_act(x2d_rows, C, x):
-    """bf16 planes [3][rows][C] of an NHWC activation (rows = pixels, C % 32 == 0)."""
-    planes = torch.empty((3, x2d_rows, C // 2), device=x.device, dtype=torch.float32)
-    check(_L().rih_presplit_matrix(x.data_ptr(), 1, C, x2d_rows, C, planes.data_ptr(), C, 0, _stream()), 'rih_presplit_matrix')
-    return planes
-
-
-_EXPERIMENTS_BUILT = None
-
-
-def experiments_built():
-    """The loaded library contains the non-adopted kernel variants (rih_experiments(): pre-split operands, tile 4)."""
-    global _EXPERIMENTS_BUILT
-    lib = _L()
-    if _EXPERIMENTS_BUILT is None or _EXPERIMENTS_BUILT[0] is not lib:
-        _EXPERIMENTS_BUILT = (lib, int(lib.rih_experiments()) == 1)
-    return _EXPERIMENTS_BUILT[1]
-
-
-def _presplit_ok(Ngemm, Kchan, taps, engine=None, abytes=0):
-    """Preconditions of the b_mode 2 fast path: a split engine, a 64-wide-or-larger tile, 32-channel-aligned gather -- and a
-    library built with the experiment variants (RIH_PRESPLIT / RIH_E2_PRESPLIT raise otherwise: an explicit request)."""
-    e = ENGINE if engine is None else engine
-    on = (PRESPLIT and e == 1) or (E2_PRESPLIT and e == 2)
-    if on and not experiments_built():
-        raise RuntimeError('renderih_amd: RIH_PRESPLIT / RIH_E2_PRESPLIT need a library built with RIH_BUILD_EXPERIMENTS=1')
-    return on and Ngemm > 32 and Kchan % 32 == 0 and taps <= 32 and abytes < (1 << 31)
-
-
 # When set to a list, every rih_gemm launch is bracketed by HIP events on the launch stream and
 # (flops, start, end, tag) is appended -- bench.py uses this for the live roofline measurement.
 PROFILE = None
@@ -416,7 +330,7 @@ class StatsHolder:
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=None, ldr=0,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, kchunk=0, sCsplit=0, alpha=1.0, relu=False,
          geom=None, tile=None, engine=None, cstride=None, ones_row=0, sBias=0, sR=0, collect=None, stats=None, drop=None,
-         amax_a=None, amax_b=None, a_seg=None, bnb=None):
+         amax_a=None, amax_b=None, a_seg=None):
     """Enqueue one rih_gemm.  A/B/Cout/bias/R are tensors or raw device pointers.
     a_seg: [(tensor, pitch, first column), ...] -- up to three further pieces of a segmented A operand (rih_gemm_desc.a_seg);
     `lda` / `A` describe the first piece.
@@ -430,9 +344,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
     finishes with rih_add_dropout(R, C, p, seed), which draws the same mask stream.
     amax_a / amax_b (engine 2): bound blocks (bound_of; or raw device pointers, or thunks that return one -- called only when the
     descriptor takes engine 2's kernels) holding an upper bound of max|A| / max|B| (rih_gemm_desc.amax_a); a call site that
-    passes none for either operand runs engine 1.
-    bnb: a BnFold -- the output is the gradient arriving at that BatchNorm; when the descriptor takes the epilogue of
-    rih_gemm_desc.bnb_* the reduction sums of its backward are left in bnb.part (BatchNormFn.backward then skips its own pass)."""
+    passes none for either operand runs engine 1."""
     d = GemmDesc()
     if a_seg:
         for i, (t, ld, k0) in enumerate(a_seg):
@@ -477,11 +389,6 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
             d.amax_a = amax_a if isinstance(amax_a, int) else _p(amax_a)
             d.amax_b = amax_b if isinstance(amax_b, int) else _p(amax_b)
         else:
-            if tile is None and d.tile == 4:        # the planner's engine-2 choice does not apply: plan again for engine 1
-                d.tile, auto_sk = plan_gemm(M, N, K, nb1 * nb2 * splitk, 1)
-            if b_mode == 2:
-                raise RuntimeError('renderih_amd: a GEMM with a two-plane (engine 2) pre-split B operand does not take engine 2\'s '
-                                   'kernels (M %d N %d K %d): the caller must check _presplit_ok first' % (M, N, K))
             d.engine = 1
             amax_a = amax_b = None
     fused_drop = False
@@ -506,15 +413,6 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, bias=None, R=No
             check(_L().rih_splitk_finish(part.data_ptr(), sk, M, N, d.C, ldc, d.bias or 0, d.R or 0, ldr,
                                          alpha, 1 if relu else 0, _stream()), 'rih_splitk_finish')
             return False
-    if (bnb is not None and collect is None and stats is None and not fused_drop and splitk == 1 and nb1 * nb2 == 1
-            and cstride is None and not isinstance(Cout, int) and M == bnb.rows and N == bnb.C and ldc == bnb.C):
-        rows_per = int(_L().rih_gemm_bnb_rows(C.byref(d)))
-        if rows_per > 0:
-            T = _cdiv(M, rows_per)
-            part = torch.empty((2, T, N), device=Cout.device, dtype=torch.float32)
-            d.bnb_x, d.bnb_mask, d.bnb_mean, d.bnb_invstd = bnb.x.data_ptr(), _p(bnb.mask), bnb.mean.data_ptr(), bnb.invstd.data_ptr()
-            d.bnb_part, d.bnb_ldx, d.bnb_T = part.data_ptr(), bnb.C, T
-            bnb.part = (part, T, Cout.data_ptr(), Cout._version)
     req = stats
     if (req is not None and req.part is None and a_mode == 0 and splitk == 1 and nb1 * nb2 == 1 and cstride is None
             and not isinstance(Cout, int)):
@@ -634,88 +532,6 @@ class GroupedGemms:
                                 (0, 0, 0, n, (v >> 2) & 1, (v >> 1) & 1, 20 + ((v & 63) >> 3), 0, 2 if v >= 64 else 1)))
             else:
                 check(lib.rih_gemm_multi_launch(dev.data_ptr(), v, total.value, _stream()), 'rih_gemm_multi_launch')
-
-
-# --------------------------------------------------------------------------------------------- P3 (pre-split) operands
-# csrc/rih_gemm3.hip: activations / weights stored as three bf16 planes interleaved per 8 channels (6 bytes per element);
-# the GEMM stages them by LDS-DMA and converts nothing.  A P3 tensor is a torch.uint8 tensor [..., 6 * C].
-_ZERO_PAGE = {}
-P3_TILES = {0: (256, 128), 1: (128, 128), 2: (128, 64)}
-
-
-def zero_page(device):
-    z = _ZERO_PAGE.get(device)
-    if z is None:
-        z = _ZERO_PAGE[device] = torch.zeros(256, device=device, dtype=torch.uint8)
-    return z
-
-
-def p3_from_f32(x2d_rows, C_, x, ldx=None, out=None, layout=0):
-    """fp32 [rows][C_] (row pitch ldx) -> P3 [rows][6*C_] bytes (layout 0) or slab-major P3S [C_/32][rows][192] (layout 1)."""
-    ldx = C_ if ldx is None else ldx
-    if out is None:
-        out = torch.empty((x2d_rows, 6 * C_), device=x.device, dtype=torch.uint8)
-    check(_L().rih_p3_from_f32(x.data_ptr(), x2d_rows, C_, ldx, out.data_ptr(), C_, layout, _stream()), 'rih_p3_from_f32')
-    return out
-
-
-def p3_weight(w, Cx, for_dgrad, sub=None, layout=0):
-    """(P3 tensor [N][6*Kpad], Kpad) of an OIHW weight as forward operand (N = Cout) or as data-gradient operand of the tap
-    subset `sub` = (kh0, kw0, step, Th, Tw) (N = Cx)."""
-    Cout, Cin, KH, KW = w.shape
-    kh0, kw0, step, Th, Tw = sub if sub is not None else (0, 0, 1, KH, KW)
-    K = KH * KW * Cx if not for_dgrad else Th * Tw * Cout
-    Nn = Cout if not for_dgrad else Cx
-    Kp = _cdiv(K, 32) * 32
-    out = torch.empty((Nn, 6 * Kp), device=w.device, dtype=torch.uint8)
-    check(_L().rih_p3_conv_weight(w.data_ptr(), out.data_ptr(), Cout, Cin, KH, KW, Cx, 1 if for_dgrad else 0,
-                                  kh0, kw0, step, Th, Tw, Kp, layout, _stream()), 'rih_p3_conv_weight')
-    return out, Kp
-
-
-def plan_p3(M, N, K):
-    """Tile of a P3 GEMM: the largest tile that still gives every CU a workgroup."""
-    for t in (0, 1, 2):
-        bm, bn = P3_TILES[t]
-        if N > 64 or t == 2:
-            if _cdiv(M, bm) * _cdiv(N, bn) >= 256 or t == 2:
-                return t
-    return 2
-
-
-def need_experiments(what):
-    """The P3 GEMM and the row-chain kernel are not part of the default library (renderih_amd/_build.py: EXPERIMENT_SOURCES)."""
-    lib = _L()
-    if not hasattr(lib, 'rih_chain') or not hasattr(lib, 'rih_gemm_p3'):
-        raise RuntimeError('renderih_amd: %s needs the experiment kernels -- rebuild with RIH_BUILD_EXPERIMENTS=1 '
-                           '(python -m renderih_amd._build)' % what)
-    return lib
-
-
-def gemm_p3(A, B, Cout, M, N, K, lda, ldb, ldc, geom, bias=None, R=None, ldr=0, relu=False, cstride=None, stats=None,
-            tile=None, layout=0):
-    """Enqueue one rih_gemm_p3.  geom = (H, W, Cin, Ho, Wo, KH, KW, stride, padH, padW)."""
-    need_experiments('rih_gemm_p3')
-    d = _lib.GemmP3Desc()
-    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
-    d.zero = zero_page(Cout.device).data_ptr()
-    d.bias, d.R, d.stats = _p(bias), _p(R), _p(stats)
-    d.M, d.N, d.K = M, N, K
-    d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
-    (d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.stride, d.padH, d.padW) = geom
-    if cstride is not None:
-        d.cS, d.cOH, d.cOW, d.cH, d.cW = cstride
-    d.relu = 1 if relu else 0
-    d.tile = plan_p3(M, N, K) if tile is None else tile
-    d.layout = layout               # 0: interleaved P3, 1: slab-major P3S (both operands)
-    if PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(_L().rih_gemm_p3(C.byref(d), _stream()), 'rih_gemm_p3')
-        e1.record()
-        PROFILE.append((2.0 * M * N * K, e0, e1, (M, N, K, 1, 3, 3, 10 + d.tile, 1, 1)))
-        return
-    check(_L().rih_gemm_p3(C.byref(d), _stream()), 'rih_gemm_p3')
 
 
 # --------------------------------------------------------------------------------------------- weight gradients off the
@@ -918,8 +734,7 @@ class PackCache:
         self.fresh = False
 
     def refresh(self):
-        packs = [e for e in self.entries.values() if e[2][0] not in ('presplit', 'h2')]
-        pres = [e for e in self.entries.values() if e[2][0] == 'presplit']
+        packs = [e for e in self.entries.values() if e[2][0] != 'h2']
         h2 = [e for e in self.entries.values() if e[2][0] == 'h2']
         if h2:          # H2 weight operands of the halo-resident 3x3 convolutions (rih_conv3x3): one launch per 48
             _h2_launch([(w, dst, f[1:]) for w, dst, f in h2])
@@ -930,15 +745,6 @@ class PackCache:
                 d.w, d.dst = w.data_ptr(), dst.data_ptr()
                 (d.Cout, d.Cin, d.KH, d.KW, d.CinPad, d.mode, d.kh0, d.kw0, d.step, d.Th, d.Tw) = f
             check(_L().rih_pack_conv_weight_multi(arr, len(packs), _stream()), 'rih_pack_conv_weight_multi')
-        if pres:
-            # (engine 2 planes are scaled by the weight's bound: the bounds of this step must exist -- ops.begin_step runs first)
-            from ._lib import PresplitDesc
-            arr = (PresplitDesc * len(pres))()
-            for d, (w, dst, f) in zip(arr, pres):
-                d.w, d.dst = w.data_ptr(), dst.data_ptr()
-                d.amax_e2 = bound_of(w).data_ptr() if f[1] else None
-                (d.Cout, d.Cin, d.KH, d.KW, d.CinPad, d.for_dgrad, d.kh0, d.kw0, d.step, d.Th, d.Tw, d.Kpad) = f[2:]
-            check(_L().rih_presplit_multi(arr, len(pres), _stream()), 'rih_presplit_multi')
         self.fresh = True
 
     def stale(self):
@@ -1130,14 +936,6 @@ class Conv2dFn(torch.autograd.Function):
         bx, bw = (LazyBound(x), LazyBound(w)) if ENGINE == 2 else (None, None)
         if Cx == Cin and _halo3_ok(x, Cx, Cout, KH, KW, stride, pad, bias):
             conv3x3_halo(x, w, y, False, relu=relu, stats=stats, bx=bx, bw=bw)
-        elif _presplit_ok(Cout, Cx, KH * KW, abytes=4 * x.numel()):
-            wp, Kp = _presplit_weight(w, Cx, False)
-            if PRESPLIT_ACT:
-                gemm(_presplit_act(N * H * W_, Cx, x), wp, y, M, Cout, K, Cx, Kp, Cout, a_mode=2, b_mode=2, bias=bias,
-                     relu=relu, geom=geom)
-            else:
-                gemm(x, wp, y, M, Cout, K, Cx, Kp, Cout, a_mode=0, b_mode=2, bias=bias, relu=relu, geom=geom,
-                     stats=stats if ENGINE == 2 else None, amax_a=bx, amax_b=bw)
         elif KH * KW == 1 and Cx == Cin and stride == 1 and pad == 0 and _panel_ok(M, Cin, Cout, Cx, x, bias):
             panel_gemm(x, w, y, M, Cout, Cin, Cx, Cout, False, relu=relu, stats=stats, ba=bx, bw=bw)
         elif KH * KW == 1 and Cx == Cin:
@@ -1152,7 +950,6 @@ class Conv2dFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, y if relu_bwd else None)
         ctx.cfg = (stride, pad, relu_bwd, bias is not None)
         ctx.bounds = (bx, bw)
-        ctx.bnfold = getattr(x, '_rih_bnfold', None) if BN_FOLD else None
         if skip:
             return y, x.view_as(x)
         return y
@@ -1190,23 +987,11 @@ class Conv2dFn(torch.autograd.Function):
                         classes.append((oh, ow, kh0, kw0, Th, Tw, Hc, Wc))
             dense = all(c[4] > 0 and c[5] > 0 for c in classes)
             dx = torch.empty_like(x) if dense else torch.zeros_like(x)
-            dyp = None
             for oh, ow, kh0, kw0, Th, Tw, Hc, Wc in classes:
                 if Th == 0 or Tw == 0:
                     continue
                 padh, padw = Th - 1 - (oh + pad - kh0) // stride, Tw - 1 - (ow + pad - kw0) // stride
                 geom = (Ho, Wo, Cout, Hc, Wc, Th, Tw, 1, 1, padh, padw)
-                if _presplit_ok(Cx, Cout, Th * Tw, abytes=4 * dy.numel()):
-                    wd, Kp = _presplit_weight(w, Cx, True, (kh0, kw0, stride, Th, Tw))
-                    if PRESPLIT_ACT:
-                        if dyp is None:
-                            dyp = _presplit_act(N * Ho * Wo, Cout, dy)
-                        gemm(dyp, wd, dx, N * Hc * Wc, Cx, Th * Tw * Cout, Cout, Kp, Cx, a_mode=2, b_mode=2, geom=geom,
-                             cstride=(stride, oh, ow, H, W_))
-                    else:
-                        gemm(dy, wd, dx, N * Hc * Wc, Cx, Th * Tw * Cout, Cout, Kp, Cx, a_mode=0, b_mode=2, geom=geom,
-                             cstride=(stride, oh, ow, H, W_), amax_a=bdy, amax_b=bw)
-                    continue
                 if KH * KW == 1 and Cx == Cin:
                     wd = w
                 else:
@@ -1219,26 +1004,17 @@ class Conv2dFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             Mx = N * H * W_
             geom = (Ho, Wo, Cout, H, W_, KH, KW, 1, stride, KH - 1 - pad, KW - 1 - pad)
-            if Cx == Cin and ctx.bnfold is None and _halo3_ok(dy, Cout, Cx, KH, KW, stride, pad, None, dskip):
+            if Cx == Cin and _halo3_ok(dy, Cout, Cx, KH, KW, stride, pad, None, dskip):
                 conv3x3_halo(dy, w, dx, True, bx=bdy, bw=bw)
-            elif _presplit_ok(Cx, Cout, KH * KW, abytes=4 * dy.numel()):
-                wd, Kp = _presplit_weight(w, Cx, True)
-                if PRESPLIT_ACT:
-                    gemm(_presplit_act(M, Cout, dy), wd, dx, Mx, Cx, KH * KW * Cout, Cout, Kp, Cx, a_mode=2, b_mode=2,
-                         geom=geom, R=dskip, ldr=Cx)
-                else:
-                    gemm(dy, wd, dx, Mx, Cx, KH * KW * Cout, Cout, Kp, Cx, a_mode=0, b_mode=2, geom=geom, R=dskip, ldr=Cx,
-                         amax_a=bdy, amax_b=bw)
-            elif (KH * KW == 1 and Cx == Cin and stride == 1 and pad == 0 and ctx.bnfold is None
-                  and _panel_ok(Mx, Cout, Cin, Cout, dy)):
+            elif KH * KW == 1 and Cx == Cin and stride == 1 and pad == 0 and _panel_ok(Mx, Cout, Cin, Cout, dy):
                 panel_gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cx, True, R=dskip, ldr=Cx, ba=bdy, bw=bw)
             elif KH * KW == 1 and Cx == Cin:
                 gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cin, Cx, a_mode=0, b_mode=0, geom=geom, R=dskip, ldr=Cx,
-                     amax_a=bdy, amax_b=bw, bnb=ctx.bnfold)
+                     amax_a=bdy, amax_b=bw)
             else:
                 wd = _packed_weight(w, Cx, True)
                 gemm(dy, wd, dx, Mx, Cx, KH * KW * Cout, Cout, Cx, Cx, a_mode=0, b_mode=0, geom=geom, R=dskip, ldr=Cx,
-                     amax_a=bdy, amax_b=bw, bnb=ctx.bnfold)
+                     amax_a=bdy, amax_b=bw)
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
@@ -1661,24 +1437,6 @@ def patch_conv_pair(x, cL, cR):
 
 
 # --------------------------------------------------------------------------------------------- batch norm
-# The reduction pass of a BatchNorm's backward folded into the epilogue of the data-gradient GEMM that produces its dy
-# (rih_gemm_desc.bnb_*): BatchNormFn.forward leaves a BnFold on its output, the convolution that reads that output hands it to its
-# data-gradient GEMM, BatchNormFn.backward finds the sums and skips its own pass over dy and x.  Round 4: correct on the GPU
-# (profiles/r04/ab/c23_pytest_fold_*.log) and 1.4 % SLOWER on the step (c23_train_*.log: 1948 / 1951 against 1976 / 1976
-# images/s) -- the kernels are in the experiment build only; in the default library rih_gemm_bnb_rows answers 0 and this switch
-# changes nothing.
-BN_FOLD = os.environ.get('RIH_BN_FOLD', '0') == '1'
-BN_FOLD_TAKEN = 0       # BatchNorm backwards that found their sums in the data-gradient GEMM's epilogue (tests read it)
-_LAST_FOLD = [None]
-
-
-class BnFold:
-    __slots__ = ('x', 'mask', 'mean', 'invstd', 'rows', 'C', 'part')
-
-    def __init__(self, x, mask, mean, invstd, rows, C_):
-        self.x, self.mask, self.mean, self.invstd, self.rows, self.C, self.part = x, mask, mean, invstd, rows, C_, None
-
-
 class BatchNormFn(torch.autograd.Function):
     """nn.BatchNorm2d on NHWC rows (+ residual add + ReLU).  Training: batch statistics, running buffers updated
     in place (momentum 0.1, unbiased running_var) exactly like torch; eval: running statistics."""
@@ -1726,9 +1484,6 @@ class BatchNormFn(torch.autograd.Function):
                                    + (0.25 if relu else 0.0)), 'bn_fwd', run)
         ctx.save_for_backward(x, mask, mean, invstd, gamma)
         ctx.cfg = (training, relu, residual is not None, bool(input_relu))
-        ctx.fold = None
-        if BN_FOLD and training and ENGINE == 2 and Cc % 4 == 0:
-            ctx.fold = _LAST_FOLD[0] = BnFold(x, mask, mean, invstd, rows, Cc)
         return y
 
     @staticmethod
@@ -1748,26 +1503,10 @@ class BatchNormFn(torch.autograd.Function):
         # writes dx (+ dres)
         flags = (0 if training else 1) | (2 if input_relu else 0)
         dxbound = bound_slot(x.device) if ENGINE == 2 else None     # max|dx|: the gradient operand's bound, as ybound above
-        fold = ctx.fold.part if ctx.fold is not None else None
-        if fold is not None:
-            ctx.fold.part = None
-            # the sums are of the GEMM's output: usable only if THAT is the gradient that arrived -- the same memory, and not
-            # touched since (autograd adds the gradients of several consumers of y in place into the first one: version bump)
-            if fold[2] != dy.data_ptr() or fold[3] != dy._version:
-                fold = None
-        if fold is not None:
-            global BN_FOLD_TAKEN
-            BN_FOLD_TAKEN += 1
-            run = lambda: check(
-                lib.rih_bn_bwd_partials(fold[0].data_ptr(), fold[1], dy.data_ptr(), x.data_ptr(), mean.data_ptr(),
-                                        invstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(), _p(dres), dg.data_ptr(),
-                                        db.data_ptr(), rows, Cc, 1 if relu else 0, flags, _p(mask), _p(dxbound), _stream()),
-                'rih_bn_bwd_partials')
-        else:
-            run = lambda: check(
-                lib.rih_bn_bwd(dy.data_ptr(), x.data_ptr(), 0, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                               dx.data_ptr(), _p(dres), dg.data_ptr(), db.data_ptr(), rows, Cc, 1 if relu else 0,
-                               flags, ws.data_ptr(), _p(mask), _p(dxbound), _stream()), 'rih_bn_bwd')
+        run = lambda: check(
+            lib.rih_bn_bwd(dy.data_ptr(), x.data_ptr(), 0, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                           dx.data_ptr(), _p(dres), dg.data_ptr(), db.data_ptr(), rows, Cc, 1 if relu else 0,
+                           flags, ws.data_ptr(), _p(mask), _p(dxbound), _stream()), 'rih_bn_bwd')
         _elem_profile(x.numel() * (4.0 * (2 * 2 + 1 + (1 if has_res else 0)) + (0.5 if relu else 0.0)), 'bn_bwd', run)
         if dxbound is not None:
             set_bound(dx, dxbound)
@@ -1802,10 +1541,7 @@ def batchnorm(x, gamma, beta, rmean, rvar, residual=None, training=True, relu=Fa
               input_relu=False):
     """input_relu: x is the output of a ReLU (Conv -> ReLU -> BN); the gradient wrt x then leaves already gated by x > 0."""
     ybound = bound_slot(x.device) if ENGINE == 2 else None
-    _LAST_FOLD[0] = None
     y = BatchNormFn.apply(x, gamma, beta, rmean, rvar, residual, training, relu, eps, momentum, tile_stats, input_relu, ybound)
-    if _LAST_FOLD[0] is not None:       # (set by BatchNormFn.forward when the fold is on: the consumer finds it on the tensor)
-        y._rih_bnfold, _LAST_FOLD[0] = _LAST_FOLD[0], None
     return y if ybound is None else set_bound(y, ybound)
 
 
@@ -2560,164 +2296,6 @@ def projection_batch(scale, trans2d, v, img_size=256):
     return ProjectFn.apply(v, scale, trans2d, img_size)
 
 
-# ------------------------------------------------------------------------------------------ rih_chain (csrc/rih_chain.hip)
-# The row-wise sequences of an attention block -- LayerNorm -> QKV projection, and output projection -> dropout -> skip ->
-# LayerNorm -> fc1 + ReLU -> dropout -> fc2 -> dropout -> skip -- as ONE launch each way instead of 2 and 7 (9 backward).  The
-# masks are those of the standalone kernels (same seeds, same element indices), the matrix products are exact fp32.
-# OFF by default (RIH_CHAIN=1 turns it on): correct on MI355X (tests/test_gpu_ops.py::test_attention_block_chains pins it
-# against the standalone sequence and plain torch), but measured SLOWER in round 3 -- the nine attention blocks of a step at
-# B = 64, hipGraph replays: forward 1.49 ms against 1.33 ms, forward + backward 5.11 ms against 4.42 ms
-# (profiles/r03/chain/chain_bench_v4_fused_epilogues.log); whole step 38.5 ms against 37.4 ms with the first version.  A dependent
-# launch inside a hipGraph costs ~4.5 us; a dependent L2 round trip + barrier inside the fused kernel costs ~2 us, and the fused
-# kernel runs them with one or two workgroups per CU (LDS: three activation buffers + weight tiles) where the standalone kernels
-# spread every operator over the whole chip; at D = 256 the exact-fp32 MFMA (157 TF peak) is also slower than the six-product
-# bf16 GEMM it replaces.  Kept as a tested opt-in; DESIGN.md section 3.13 has the measurements and what would have to change.
-CHAIN = os.environ.get('RIH_CHAIN', '0') == '1'
-CHAIN_RBLK = int(os.environ.get('RIH_CHAIN_RBLK', '0'))      # 0 = by size; 32 / 64 = forced (tuning aid)
-_CH = dict(LOAD=1, STORE=2, ADD=3, KEEP=4, ADD_KEPT=5, GEMM=6, DROPOUT=7, MASKNZ=8, LN=9, LN_BWD=10)
-
-
-class ChainProgram:
-    """Builder of one rih_chain launch over hands-stacked rows [nhands][rows][*]."""
-
-    def __init__(self, rows, nhands):
-        from ._lib import ChainDesc
-        self.d = ChainDesc()
-        self.d.rows, self.d.nhands = rows, nhands
-        self.n = 0
-        self.width = 0
-        self.maxw = 0
-        self.keeps = False
-        self.lds_n = 0              # widest product that is written back to the LDS block
-        self.flops = 0.0
-        self.alive = []
-
-    def _op(self, kind, **kw):
-        assert self.n < 16, 'rih_chain: more than RIH_CHAIN_MAXOPS operators'
-        op = self.d.op[self.n]
-        self.n += 1
-        op.kind = _CH[kind]
-        for k, v in kw.items():
-            if torch.is_tensor(v):
-                self.alive.append(v)
-                v = v.data_ptr()
-            setattr(op, k, v)
-        return op
-
-    def load(self, t, n):
-        self._op('LOAD', p0=t, n=n, ld=t.shape[-1])
-        self.width = n
-        self.maxw = max(self.maxw, n)
-
-    def store(self, t):
-        self._op('STORE', p0=t, ld=t.shape[-1])
-
-    def add(self, t):
-        self._op('ADD', p0=t, ld=t.shape[-1])
-
-    def keep(self):
-        self._op('KEEP')
-        self.keeps = True
-
-    def add_kept(self):
-        self._op('ADD_KEPT')
-
-    def gemm(self, w, bias, n, k, sw=0, sb=0, bt=False, relu=False, out=None, a=None, drop=None, add=None, add_kept=False,
-             store=None, keep=False, masknz=None):
-        """a: the left operand as a tensor in memory (rows of pitch a.shape[-1]) instead of the block state -- a reduction
-        longer than the block is wide.  drop=(p, seed) / add=tensor / add_kept / store=tensor / keep / masknz=(tensor, scale):
-        the fused epilogue (header: RIH_CHF_EPI_*), each what the separate operator does, in the header's order."""
-        assert a is not None or k == self.width
-        assert out is None or not (drop or add is not None or add_kept or store is not None or keep or masknz)
-        assert add is None or masknz is None
-        fl = (1 if relu else 0) | (2 if bt else 0) | (4 if out is not None else 0) | (8 if a is not None else 0)
-        op = self._op('GEMM', p0=w, n=n, k=k, s0=sw, flags=fl)
-        if a is not None:
-            op.p3, op.lda = a.data_ptr(), a.shape[-1]
-            self.alive.append(a)
-        if bias is not None:
-            op.p1, op.s1 = bias.data_ptr(), sb
-            self.alive.append(bias)
-        if out is not None:
-            op.p2, op.ld = out.data_ptr(), out.shape[-1]
-            self.alive.append(out)
-        else:
-            self.width = n
-            self.maxw = max(self.maxw, n)
-            self.lds_n = max(self.lds_n, n)
-            if drop is not None and drop[0] > 0:
-                op.flags |= 16
-                op.f0, op.seed = drop
-            if add is not None:
-                op.flags |= 32
-                op.p4, op.lde = add.data_ptr(), add.shape[-1]
-                self.alive.append(add)
-            if masknz is not None:
-                op.flags |= 512
-                op.p4, op.lde, op.f1 = masknz[0].data_ptr(), masknz[0].shape[-1], masknz[1]
-                self.alive.append(masknz[0])
-            if add_kept:
-                op.flags |= 64
-            if store is not None:
-                op.flags |= 128
-                op.p2, op.ld = store.data_ptr(), store.shape[-1]
-                self.alive.append(store)
-            if keep:
-                op.flags |= 256
-                self.keeps = True
-        self.flops += 2.0 * self.d.rows * self.d.nhands * n * k
-
-    def dropout(self, p, seed):
-        if p > 0:
-            self._op('DROPOUT', f0=p, seed=seed)
-
-    def masknz(self, t, scale):
-        self._op('MASKNZ', p0=t, ld=t.shape[-1], f0=scale)
-
-    def ln(self, g, b, sg, sb, eps, relu=False, mean=None, rstd=None):
-        op = self._op('LN', p0=g, p1=b, s0=sg, s1=sb, f0=eps, flags=1 if relu else 0)
-        if mean is not None:
-            op.p2, op.p3 = mean.data_ptr(), rstd.data_ptr()
-            self.alive.extend((mean, rstd))
-
-    def ln_bwd(self, x, mean, rstd, g, sg):
-        """The partial-sum workspace [nhands][nblk][2][width] is allocated by run(), once the row-block size is known
-        (self.ws, self.nblk)."""
-        self._lnb = (self._op('LN_BWD', p0=x, ld=x.shape[-1], p1=mean, p2=rstd, p3=g, s3=sg), self.width)
-
-    @staticmethod
-    def pick_rblk(rows, nhands, maxw, keeps, lds_n):
-        """64-row blocks halve the weight traffic per row but need >= 2 workgroups per CU to be worth it."""
-        ok64 = 64 * (maxw + 4) <= 8448
-        if CHAIN_RBLK in (32, 64):
-            return CHAIN_RBLK if (CHAIN_RBLK == 32 or ok64) else 32
-        return 64 if (ok64 and nhands * _cdiv(rows, 64) >= 512) else 32
-
-    def run(self):
-        d = self.d
-        d.nops = self.n
-        d.rblk = self.pick_rblk(d.rows, d.nhands, self.maxw, self.keeps, self.lds_n)
-        d.ldw = self.maxw + 4
-        d.seed_dev = _seed_dev()
-        if getattr(self, '_lnb', None) is not None:
-            op, w = self._lnb
-            self.nblk = _cdiv(d.rows, d.rblk)
-            self.ws = torch.empty((d.nhands, self.nblk, 2, w), device=self.alive[0].device, dtype=torch.float32)
-            op.p4, op.s4 = self.ws.data_ptr(), self.nblk * 2 * w
-        _profiled(self.flops, (d.rows * d.nhands, self.maxw, self.n, 1, 0, 1, 40, 1, 0),
-                  lambda: check(_L().rih_chain(C.byref(d), _stream()), 'rih_chain'))
-
-
-def chain_dims_ok(*dims):
-    """Widths a chain accepts: multiples of 64 (they are reduction lengths, streamed in 64-deep chunks, and output widths, made
-    of 32-column blocks), at most 256 as an LDS-resident activation."""
-    return all(d % 64 == 0 and 64 <= d <= 256 for d in dims)
-
-
-def chain_ok(*dims):
-    return CHAIN and chain_dims_ok(*dims)
-
-
 def _ln_partials_finish(ws, nblk, D, nh, dg, db):
     """d gamma / d beta [nh, D] from the per-block partials ws [nh][nblk][2][D]: deferred to the end of the backward stage
     (ops.deferred_reductions) or finished now by the same descriptor-list kernel."""
@@ -2747,147 +2325,3 @@ def _linear_wgrad(x, g, K, Nf, rows, paired, has_bias):
         db = torch.empty((Nf,), device=dev, dtype=torch.float32) if has_bias else None
         _wgrad(x, g, dw, 2 * rows, K, Nf, K, Nf, geom, K, 1, K, db=db)
     return dw, db
-
-
-class LnLinearChainFn(torch.autograd.Function):
-    """(Linear(LayerNorm_h(x[h])), x) for hands-stacked x [2, ..., D] in one launch: per-hand LayerNorm parameters, the Linear
-    either per hand (w [2, N, D], b [2, N]) or shared by the hands (w [N, D], b [N]).  The second output aliases x for the skip
-    connection around the branch; its gradient is added inside the backward chain (see LayerNormFn)."""
-
-    @staticmethod
-    def forward(ctx, x, gL, gR, bL, bR, w, b, eps):
-        _chk(x, gL, gR, bL, bR, w, b)
-        x, w, b = _c(x), _c(w), _c(b)
-        assert x.shape[0] == 2
-        D = x.shape[-1]
-        rows = x.numel() // (2 * D)
-        paired = w.dim() == 3
-        Nf = w.shape[-2]
-        sw, sb = (Nf * D, Nf) if paired else (0, 0)
-        y = torch.empty_like(x)
-        mean = torch.empty((2 * rows,), device=x.device, dtype=torch.float32)
-        rstd = torch.empty_like(mean)
-        out = torch.empty(x.shape[:-1] + (Nf,), device=x.device, dtype=torch.float32)
-        pr = ChainProgram(rows, 2)
-        pr.load(x, D)
-        pr.ln(gL, bL, _pdiff(gL, gR), _pdiff(bL, bR), eps, mean=mean, rstd=rstd)
-        pr.store(y)
-        pr.gemm(w, b, Nf, D, sw, sb, out=out)
-        pr.alive.extend((gR, bR))
-        pr.run()
-        ctx.save_for_backward(x, y, mean, rstd, gL, gR, w)
-        ctx.cfg = (D, rows, Nf, paired, sw)
-        return out, x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, dout, dskip):
-        x, y, mean, rstd, gL, gR, w = ctx.saved_tensors
-        D, rows, Nf, paired, sw = ctx.cfg
-        dout = _c(dout)
-        dx = torch.empty_like(x)
-        pr = ChainProgram(rows, 2)
-        pr.gemm(w, None, D, Nf, sw, 0, bt=True, a=dout)       # (3 D wide: read from memory, not through the LDS block)
-        pr.ln_bwd(x, mean, rstd, gL, _pdiff(gL, gR))
-        if dskip is not None:
-            pr.add(_c(dskip))
-        pr.store(dx)
-        pr.alive.append(gR)
-        pr.run()
-        dg = torch.empty((2, D), device=x.device, dtype=torch.float32)
-        db_ = torch.empty((2, D), device=x.device, dtype=torch.float32)
-        _ln_partials_finish(pr.ws, pr.nblk, D, 2, dg, db_)
-        dw, dbias = _linear_wgrad(y, dout, D, Nf, rows, paired, True)
-        return dx, dg[0], dg[1], db_[0], db_[1], dw, dbias, None
-
-
-def ln_linear_chain(x, lnL, lnR, w, b):
-    return LnLinearChainFn.apply(x, lnL.weight, lnR.weight, lnL.bias, lnR.bias, w, b, lnL.eps)
-
-
-class AttnTailChainFn(torch.autograd.Function):
-    """The rest of an attention block behind the attention product, both hands, one launch each way
-    (models/model_attn/self_attn.py:76-85 + :17-33):
-        x1  = x + dropout(o fc^T + b)                       fc per hand (fcwL / fcwR) or shared by the hands (fcwR None)
-        out = x1 + dropout(relu-dropout(LN(x1) W1^T + b1) W2^T + b2)
-    `seeds` = the three mask streams in the order the standalone sequence draws them."""
-
-    @staticmethod
-    def forward(ctx, o, x, fcw, fcwR, fcb, fcbR, gL, gR, bL, bR, w1L, w1R, b1L, b1R, w2L, w2R, b2L, b2R, eps, p, seeds):
-        _chk(o, x, fcw, fcwR, fcb, fcbR, gL, gR, bL, bR, w1L, w1R, b1L, b1R, w2L, w2R, b2L, b2R)
-        o, x = _c(o), _c(x)
-        D = x.shape[-1]
-        rows = x.numel() // (2 * D)
-        hid = w1L.shape[0]
-        fc_paired = fcwR is not None
-        sfw, sfb = (_pdiff(fcw, fcwR), _pdiff(fcb, fcbR)) if fc_paired else (0, 0)
-        dev = x.device
-        x1 = torch.empty_like(x)
-        y2 = torch.empty_like(x)
-        h = torch.empty(x.shape[:-1] + (hid,), device=dev, dtype=torch.float32)
-        out = torch.empty_like(x)
-        mean = torch.empty((2 * rows,), device=dev, dtype=torch.float32)
-        rstd = torch.empty_like(mean)
-        pr = ChainProgram(rows, 2)
-        pr.load(o, D)
-        pr.gemm(fcw, fcb, D, D, sfw, sfb, drop=(p, seeds[0]), add=x, store=x1, keep=True)
-        pr.ln(gL, bL, _pdiff(gL, gR), _pdiff(bL, bR), eps, mean=mean, rstd=rstd)
-        pr.store(y2)
-        pr.gemm(w1L, b1L, hid, D, _pdiff(w1L, w1R), _pdiff(b1L, b1R), relu=True, drop=(p, seeds[1]), store=h)
-        pr.gemm(w2L, b2L, D, hid, _pdiff(w2L, w2R), _pdiff(b2L, b2R), drop=(p, seeds[2]), add_kept=True, store=out)
-        pr.alive.extend((gR, bR, w1R, b1R, w2R, b2R))
-        pr.run()
-        ctx.save_for_backward(o, x1, y2, h, mean, rstd, fcw, fcwR, gL, gR, w1L, w1R, w2L, w2R)
-        ctx.cfg = (D, rows, hid, fc_paired, sfw, p, seeds)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        o, x1, y2, h, mean, rstd, fcw, fcwR, gL, gR, w1L, w1R, w2L, w2R = ctx.saved_tensors
-        D, rows, hid, fc_paired, sfw, p, seeds = ctx.cfg
-        dev = dout.device
-        dout = _c(dout)
-        g3 = torch.empty_like(dout) if p > 0 else dout          # d (fc2 output)
-        g2 = torch.empty_like(h)                                # d (fc1 pre-activation)
-        dx = torch.empty_like(dout)                             # d x1 = d x
-        g1 = torch.empty_like(dout) if p > 0 else dx            # d (fc output)
-        do = torch.empty_like(o)
-        pr = ChainProgram(rows, 2)
-        pr.load(dout, D)
-        pr.keep()
-        if p > 0:
-            pr.dropout(p, seeds[2])
-            pr.store(g3)
-        pr.gemm(w2L, None, hid, D, _pdiff(w2L, w2R), 0, bt=True, masknz=(h, 1.0 / (1.0 - p) if p > 0 else 1.0), store=g2)
-        pr.gemm(w1L, None, D, hid, _pdiff(w1L, w1R), 0, bt=True)
-        pr.ln_bwd(x1, mean, rstd, gL, _pdiff(gL, gR))
-        pr.add_kept()
-        pr.store(dx)
-        if p > 0:
-            pr.dropout(p, seeds[0])
-            pr.store(g1)
-        pr.gemm(fcw, None, D, D, sfw, 0, bt=True)
-        pr.store(do)
-        pr.alive.extend((gR, w1R, w2R))
-        pr.run()
-        dg = torch.empty((2, D), device=dev, dtype=torch.float32)
-        db_ = torch.empty((2, D), device=dev, dtype=torch.float32)
-        _ln_partials_finish(pr.ws, pr.nblk, D, 2, dg, db_)
-        dfw, dfb = _linear_wgrad(o, g1, D, D, rows, fc_paired, True)
-        dw1, db1 = _linear_wgrad(y2, g2, D, hid, rows, True, True)
-        dw2, db2 = _linear_wgrad(h, g3, hid, D, rows, True, True)
-        if fc_paired:
-            dfw, dfwR, dfb, dfbR = dfw[0], dfw[1], dfb[0], dfb[1]
-        else:
-            dfwR = dfbR = None
-        return (do, dx, dfw, dfwR, dfb, dfbR, dg[0], dg[1], db_[0], db_[1], dw1[0], dw1[1], db1[0], db1[1], dw2[0], dw2[1],
-                db2[0], db2[1], None, None, None)
-
-
-def attn_tail_chain(o, x, fcL, fcR, ffL, ffR, p, seeds):
-    """fcL / fcR: the attention output projection per hand (fcR None: one nn.Linear shared by the hands, inter_attn.py:85-90);
-    ffL / ffR: the hands' MLP_res_block modules (layer_norm, fc1, fc2)."""
-    ln = (ffL.layer_norm, ffR.layer_norm)
-    return AttnTailChainFn.apply(o, x, fcL.weight, None if fcR is None else fcR.weight, fcL.bias,
-                                 None if fcR is None else fcR.bias, ln[0].weight, ln[1].weight, ln[0].bias, ln[1].bias,
-                                 ffL.fc1.weight, ffR.fc1.weight, ffL.fc1.bias, ffR.fc1.bias,
-                                 ffL.fc2.weight, ffR.fc2.weight, ffL.fc2.bias, ffR.fc2.bias, ln[0].eps, p, tuple(seeds))

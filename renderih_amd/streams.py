@@ -105,13 +105,10 @@ def _hop(r):
             return r
         y = _Hop.apply(r)
         # the hop's output is a fresh view: hand on what the producing kernels left on the tensor -- its operand bound (engine 2:
-        # without it every consumer pays an rih_absmax pass) and the BatchNorm-backward fold record
+        # without it every consumer pays an rih_absmax pass)
         b = getattr(r, '_rih_bound', None)
         if b is not None:
             y._rih_bound = (b[0], y._version, b[2])
-        f = getattr(r, '_rih_bnfold', None)
-        if f is not None:
-            y._rih_bnfold = f
         return y
     if isinstance(r, (list, tuple)):
         return type(r)(_hop(t) for t in r)

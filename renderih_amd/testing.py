@@ -129,14 +129,3 @@ def is_null_gradient(name):
         return True
     return name in ('encoder.hms_decoder.0.bias', 'encoder.dp_decoder.0.bias', 'mid_model.final_layer.0.bias') or \
         (name.startswith('mid_model.downsamp_modules.') and name.endswith('.0.bias'))
-
-
-def experiments_built():
-    """True when the loaded kernel library contains the experiment sources (renderih_amd/_build.py: RIH_BUILD_EXPERIMENTS=1):
-    the P3 GEMM and the row-chain kernel, which the default library leaves out.  Tests of those kernels skip otherwise."""
-    from . import _lib
-    try:
-        lib = _lib.load()
-    except Exception:       # noqa: BLE001 -- no library at all: the caller's own test will say so
-        return False
-    return hasattr(lib, 'rih_gemm_p3') and hasattr(lib, 'rih_chain')

@@ -56,7 +56,6 @@ def keep_mask(seed, n, p):
     return (hash_np(seed, np.arange(n)) >= thr).astype(np.float32) / np.float32(1.0 - p)
 
 
-_HOST_CHECK = None
 
 
 class EmulatedLib:
@@ -202,24 +201,6 @@ class EmulatedLib:
                     cm, cn = np.meshgrid(crow, np.arange(N), indexing='ij')
                     mem = _f(Cb, int(crow.max()) * d.ldc + N)
                     mem[(cm * d.ldc + cn).ravel()] = out.astype(np.float32).ravel()
-                if d.bnb_part:      # BatchNorm-backward sums of the stored (un-gated) values, gated by the ReLU pattern
-                    rp = self.rih_gemm_bnb_rows(dref)
-                    assert rp > 0, 'bnb requested on a descriptor without that path'
-                    T = -(-M // rp)
-                    assert d.bnb_T == T and d.bnb_ldx >= N
-                    o32 = out.astype(np.float32)
-                    X = np.lib.stride_tricks.as_strided(_f(d.bnb_x, (M - 1) * d.bnb_ldx + N), (M, N), (4 * d.bnb_ldx, 4))
-                    D = o32.copy()
-                    if d.bnb_mask:
-                        assert d.bnb_ldx == N
-                        mk = self._u8view(d.bnb_mask, M * N // 4)
-                        keep = np.stack([(mk >> e) & 1 for e in range(4)], 1).reshape(M, N).astype(bool)
-                        D[~keep] = 0
-                    xh = (X - _f(d.bnb_mean, N)) * _f(d.bnb_invstd, N)
-                    pt = _f(d.bnb_part, 2 * T * N).reshape(2, T, N)
-                    for t in range(T):
-                        pt[0, t] = D[t * rp:(t + 1) * rp].sum(0, dtype=np.float64)
-                        pt[1, t] = (D[t * rp:(t + 1) * rp] * xh[t * rp:(t + 1) * rp]).sum(0, dtype=np.float64)
                 if d.stats:         # statistics epilogue: column sums / sums of squares per block of stats_rows GEMM rows
                     rp = self.rih_gemm_stats_rows(dref)
                     assert rp > 0, 'stats requested on a descriptor without the statistics path'
@@ -242,9 +223,6 @@ class EmulatedLib:
         if not plain:
             ok = ok and d.Wo % 4 == 0 and d.Cin % 4 == 0
         return (d.tile * 8 + 4 + (1 if plain else 0) + (64 if d.engine == 2 else 0)) if ok else -1
-
-    def rih_experiments(self):
-        return 1            # the emulation restates every entry point, the experiment variants included
 
     def rih_gemm_engine(self, dref):
         """The header's contract, restated: engine 2 exists on the fast path of tiles 0..2 only, engine 1 runs otherwise."""
@@ -316,15 +294,6 @@ class EmulatedLib:
             ok = ok and d.N % 4 == 0
         return (64 if d.tile in (0, 1) else 32) if ok else 0
 
-    def rih_gemm_bnb_rows(self, dref):
-        """The header's contract, restated: engine 2's fast path, forward-type operand forms, one slice, whole quads."""
-        d = dref._obj if hasattr(dref, '_obj') else dref
-        ok = (self.rih_gemm_engine(dref) == 2 and d.tile in (0, 1, 2) and d.a_mode == 0 and d.b_mode in (0, 1) and d.splitk == 1
-              and d.nb1 * d.nb2 == 1 and d.cS <= 1 and not d.stats and d.drop_p == 0 and not d.a_seg[0] and d.N % 4 == 0
-              and d.C % 16 == 0 and d.ldc % 4 == 0 and (not d.R or (d.R % 16 == 0 and d.ldr % 4 == 0))
-              and (not d.bias or d.bias % 16 == 0))
-        return (64 if d.tile in (0, 1) else 32) if ok else 0
-
     def rih_gemm_dropout_ok(self, dref):
         """The header's contract, restated: split engine's fast path, plain row-major A, no split-K, no stats, dense rows."""
         d = dref._obj if hasattr(dref, '_obj') else dref
@@ -383,49 +352,6 @@ class EmulatedLib:
         if e < -126:
             return np.float32(1.0)
         return np.float32(2.0 ** min(14 - e, 126))
-
-    def _presplit_store(self, Bkn, dst, Kpad, amax_e2=0):
-        """Bkn [K][N] fp32 -> planes [3][N][Kpad] bf16 (hi, mid, lo; round to nearest even at every level), or with a bound
-        block (engine 2) -> planes [2][N][Kpad] fp16: hi = fp16(s x), lo = fp16((s x - hi) 2^11)."""
-        K, N = Bkn.shape
-        x = np.zeros((N, Kpad), np.float32)
-        x[:, :K] = Bkn.T
-        if amax_e2:
-            xs = x * self._e2_scale(amax_e2)
-            out = np.ctypeslib.as_array((C.c_uint16 * (2 * N * Kpad)).from_address(int(dst))).reshape(2, N, Kpad)
-            hi = xs.astype(np.float16)
-            out[0] = hi.view(np.uint16)
-            out[1] = ((xs - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16).view(np.uint16)
-            return 0
-        out = np.ctypeslib.as_array((C.c_uint16 * (3 * N * Kpad)).from_address(int(dst))).reshape(3, N, Kpad)
-        for pl in range(3):
-            h = self._bf16_rne(x)
-            out[pl] = h
-            x = x - (h.astype(np.uint32) << 16).view(np.float32)
-        return 0
-
-    def rih_presplit_matrix(self, B, b_mode, K, N, ldb, dst, Kpad, amax_e2, stream):
-        src = _f(B, (K - 1) * ldb + N if b_mode == 0 else (N - 1) * ldb + K)
-        kk, nn = np.meshgrid(np.arange(K), np.arange(N), indexing='ij')
-        return self._presplit_store(src[kk * ldb + nn if b_mode == 0 else nn * ldb + kk], dst, Kpad, amax_e2)
-
-    def rih_presplit_multi(self, descs, n, stream):
-        for i in range(n):
-            d = descs[i]
-            self.rih_presplit_conv_weight(d.w, d.dst, d.Cout, d.Cin, d.KH, d.KW, d.CinPad, d.for_dgrad, d.kh0, d.kw0, d.step, d.Th,
-                                          d.Tw, d.Kpad, d.amax_e2, stream)
-        return 0
-
-    def rih_presplit_conv_weight(self, w, dst, Cout, Cin, KH, KW, CinPad, for_dgrad, kh0, kw0, step, Th, Tw, Kpad, amax_e2, stream):
-        W = _f(w, Cout * Cin * KH * KW).reshape(Cout, Cin, KH, KW)
-        Wp = np.zeros((Cout, CinPad, KH, KW), np.float32)
-        Wp[:, :Cin] = W
-        if not for_dgrad:
-            Bkn = Wp.transpose(2, 3, 1, 0).reshape(KH * KW * CinPad, Cout)            # k = (tap, ci), n = co
-        else:
-            sel = Wp[:, :, [kh0 + step * (Th - 1 - t) for t in range(Th)]][:, :, :, [kw0 + step * (Tw - 1 - t) for t in range(Tw)]]
-            Bkn = sel.transpose(2, 3, 0, 1).reshape(Th * Tw * Cout, CinPad)            # k = ((th, tw), co), n = ci
-        return self._presplit_store(Bkn, dst, Kpad, amax_e2)
 
     # ------------------------------------------------------------------ halo-resident 3x3 convolution (csrc/rih_conv3.hip)
     def rih_h2_multi(self, descs, n, stream):
@@ -1333,35 +1259,6 @@ class EmulatedLib:
             _f(dres, rows * Cc)[:] = D.ravel()
         return 0
 
-    def rih_bn_bwd_partials(self, part, T, dy, x, mean, invstd, gamma, dx, dres, dgamma, dbeta, rows, Cc, relu, frozen, mask,
-                            amax_dx, stream):
-        """rih_bn_bwd with the two reduction sums taken from `part`[2][T][C] (written by rih_gemm's bnb epilogue)."""
-        pt = _f(part, 2 * T * Cc).reshape(2, T, Cc)
-        s1, s2 = pt[0].sum(0, dtype=np.float64), pt[1].sum(0, dtype=np.float64)
-        D = _f(dy, rows * Cc).reshape(rows, Cc).copy()
-        if relu:
-            assert mask
-            m = self._u8view(mask, rows * Cc // 4)
-            keep = np.stack([(m >> e) & 1 for e in range(4)], 1).reshape(rows, Cc).astype(bool)
-            D[~keep] = 0
-        X = _f(x, rows * Cc).reshape(rows, Cc)
-        xh = (X - _f(mean, Cc)) * _f(invstd, Cc)
-        _f(dbeta, Cc)[:] = s1
-        _f(dgamma, Cc)[:] = s2
-        sc = _f(invstd, Cc) * _f(gamma, Cc)
-        if frozen & 1:
-            o = D * sc
-        else:
-            o = (D - (s1 / rows).astype(np.float32) - xh * (s2 / rows).astype(np.float32)) * sc
-        if frozen & 2:
-            o = np.where(X > 0, o, 0)
-        _f(dx, rows * Cc)[:] = o.ravel()
-        self._amax_into(amax_dx, o)
-        if dres:
-            _f(dres, rows * Cc)[:] = D.ravel()
-        return 0
-
-    # ------------------------------------------------------------------ row-wise
     def rih_ln_nblk(self, rows):
         return 1
 
@@ -1536,128 +1433,6 @@ class EmulatedLib:
         _f(dscale, B)[:] = (D * Vv[..., :2]).sum((1, 2)) * np.float32(img)
         _f(dtrans, B * 2)[:] = (D.sum(1) * np.float32(img) / 2).ravel()
         return 0
-
-    # ------------------------------------------------------------------ rih_chain: a chain of row-wise layers in one call
-    def rih_chain(self, dref, stream):
-        """The header's operator list restated on whole [nhands][rows][*] tensors (no row blocks: the LayerNorm parameter
-        partials all land in block 0 of the workspace, the other blocks are zero)."""
-        d = dref._obj
-        H, rows = d.nhands, d.rows
-        assert 1 <= d.nops <= 16 and d.rblk in (32, 64)
-        bad = self.rih_chain_check(dref)
-        if bad != 0:
-            return bad
-        nblk = -(-rows // d.rblk)
-        seed_add = 0
-        if d.seed_dev:
-            seed_add = int(np.ctypeslib.as_array((C.c_uint64 * 1).from_address(int(d.seed_dev)))[0])
-
-        def rowsview(p, ld, w):
-            """[H, rows, w] view of a hands-stacked tensor with row pitch ld."""
-            flat = _f(p, (H * rows - 1) * ld + w)
-            return np.lib.stride_tricks.as_strided(flat, (H, rows, w), (4 * rows * ld, 4 * ld, 4))
-
-        def param(p, stride, n):
-            return np.stack([_f(int(p) + 4 * h * int(stride), n).copy() for h in range(H)])
-
-        cur, kept = None, None
-        for i in range(d.nops):
-            op = d.op[i]
-            kind = op.kind
-            if kind == 1:       # LOAD
-                cur = rowsview(op.p0, op.ld, op.n).astype(np.float32).copy()
-            elif kind == 2:     # STORE
-                rowsview(op.p0, op.ld, cur.shape[2])[...] = cur
-            elif kind == 3:     # ADD
-                cur = cur + rowsview(op.p0, op.ld, cur.shape[2])
-            elif kind == 4:     # KEEP
-                kept = cur.copy()
-            elif kind == 5:     # ADD_KEPT
-                cur = cur + kept
-            elif kind == 6:     # GEMM
-                K, N = op.k, op.n
-                if op.flags & 8:        # A operand from memory
-                    lhs = rowsview(op.p3, op.lda, K).astype(np.float64)
-                else:
-                    assert K == cur.shape[2]
-                    lhs = cur.astype(np.float64)
-                assert K % 8 == 0 and N % 4 == 0
-                W = param(op.p0, op.s0, N * K)
-                W = W.reshape(H, K, N) if (op.flags & 2) else W.reshape(H, N, K).transpose(0, 2, 1)
-                out = np.einsum('hrk,hkn->hrn', lhs, W.astype(np.float64)).astype(np.float32)
-                if op.p1:
-                    out = out + param(op.p1, op.s1, N)[:, None, :]
-                if op.flags & 1:
-                    out = np.maximum(out, 0)
-                if op.flags & 4:
-                    rowsview(op.p2, op.ld, N)[...] = out
-                else:
-                    out = out.astype(np.float32)
-                    if op.flags & 512:      # EPI_MASKNZ
-                        out = np.where(rowsview(op.p4, op.lde, N) != 0, out * np.float32(op.f1), 0).astype(np.float32)
-                    if op.flags & 16:       # EPI_DROPOUT
-                        seed = (int(op.seed) + seed_add) % (1 << 64)
-                        out = (out.reshape(-1) * keep_mask(seed, H * rows * N, float(op.f0))).reshape(H, rows, N).astype(np.float32)
-                    if op.flags & 32:       # EPI_ADD
-                        out = out + rowsview(op.p4, op.lde, N)
-                    if op.flags & 64:       # EPI_ADD_KEPT
-                        out = out + kept
-                    if op.flags & 128:      # EPI_STORE
-                        rowsview(op.p2, op.ld, N)[...] = out
-                    if op.flags & 256:      # EPI_KEEP
-                        kept = out.copy()
-                    cur = out.astype(np.float32)
-            elif kind == 7:     # DROPOUT
-                w = cur.shape[2]
-                seed = (int(op.seed) + seed_add) % (1 << 64)
-                cur = (cur.reshape(-1) * keep_mask(seed, H * rows * w, float(op.f0))).reshape(H, rows, w).astype(np.float32)
-            elif kind == 8:     # MASKNZ
-                cur = np.where(rowsview(op.p0, op.ld, cur.shape[2]) != 0, cur * np.float32(op.f0), 0).astype(np.float32)
-            elif kind == 9:     # LN
-                w = cur.shape[2]
-                g, b = param(op.p0, op.s0, w), param(op.p1, op.s1, w)
-                m = cur.mean(2, keepdims=True, dtype=np.float64)
-                v = ((cur - m) ** 2).mean(2, keepdims=True, dtype=np.float64)
-                rs = 1.0 / np.sqrt(v + np.float64(np.float32(op.f0)))
-                cur = ((cur - m) * rs * g[:, None, :] + b[:, None, :]).astype(np.float32)
-                if op.flags & 1:
-                    cur = np.maximum(cur, 0)
-                if op.p2:
-                    _f(op.p2, H * rows)[:] = m.reshape(-1)
-                    _f(op.p3, H * rows)[:] = rs.reshape(-1)
-            elif kind == 10:    # LN_BWD
-                w = cur.shape[2]
-                x = rowsview(op.p0, op.ld, w).astype(np.float64)
-                m = _f(op.p1, H * rows).reshape(H, rows, 1).astype(np.float64)
-                rs = _f(op.p2, H * rows).reshape(H, rows, 1).astype(np.float64)
-                g = param(op.p3, op.s3, w).astype(np.float64)[:, None, :]
-                dy = cur.astype(np.float64)
-                xh = (x - m) * rs
-                for h in range(H):
-                    ws = _f(int(op.p4) + 4 * h * int(op.s4), nblk * 2 * w).reshape(nblk, 2, w)
-                    ws[...] = 0
-                    ws[0, 0] = (dy[h] * xh[h]).sum(0)
-                    ws[0, 1] = dy[h].sum(0)
-                t = dy * g
-                cur = (rs * (t - t.mean(2, keepdims=True) - xh * (t * xh).mean(2, keepdims=True))).astype(np.float32)
-            else:
-                return -1
-        return 0
-
-    def rih_chain_check(self, dref):
-        """The library's own argument check, from the host build of the kernels (tests/hipcpu) when that is available: a
-        descriptor the real entry point would refuse must not pass under emulation either."""
-        global _HOST_CHECK
-        if _HOST_CHECK is None:
-            try:
-                import sys
-                import os
-                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'hipcpu'))
-                from host_kernels import load
-                _HOST_CHECK = load().rih_chain_check
-            except Exception:       # noqa: BLE001  (no host compiler: the emulation stays usable without the check)
-                _HOST_CHECK = False
-        return int(_HOST_CHECK(dref)) if _HOST_CHECK else 0
 
     def rih_version(self):
         return 1

@@ -14,9 +14,7 @@ CSRC = os.path.join(ROOT, 'renderih_amd', 'csrc')
 # and ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0): out-of-bounds reads / writes of the kernels on the
 # caller's buffers, which plain host execution would silently tolerate, abort the test
 ASAN = os.environ.get('HIPCPU_ASAN', '0') == '1'
-# RIH_BUILD_EXPERIMENTS=1: the experiment sources / kernel variants too (renderih_amd/_build.py), into a library of its own name
-EXPERIMENTS = os.environ.get('RIH_BUILD_EXPERIMENTS', '0') == '1'
-OUT = os.path.join(HERE, '_build', 'librenderih_cpu%s%s.so' % ('_exp' if EXPERIMENTS else '', '_asan' if ASAN else ''))
+OUT = os.path.join(HERE, '_build', 'librenderih_cpu%s.so' % ('_asan' if ASAN else '',))
 
 
 def clangxx():
@@ -38,10 +36,10 @@ def build(force=False):
     objs = []
     procs = []
     for s in srcs:                                   # one translation unit per process: the GEMM file dominates
-        o = os.path.join(os.path.dirname(OUT), os.path.basename(s) + ('.exp' if EXPERIMENTS else '') + ('.asan.o' if ASAN else '.o'))
+        o = os.path.join(os.path.dirname(OUT), os.path.basename(s) + ('.asan.o' if ASAN else '.o'))
         objs.append(o)
         procs.append(subprocess.Popen([clangxx(), '-x', 'c++', '-std=c++20', '-O1', '-fPIC', '-c', '-I', HERE,
-                                       '-DRIH_EXPERIMENTS=%d' % (1 if EXPERIMENTS else 0), '-DRIH_CONST_AS='] +
+                                       '-DRIH_CONST_AS='] +
                                       (['-fsanitize=address', '-fno-omit-frame-pointer', '-g'] if ASAN else []) + [
                                        '-I', os.path.join(ROOT, 'include'), '-Wno-unused-value', '-Wno-pass-failed', '-o', o, s]))
     for p in procs:
@@ -55,8 +53,6 @@ def load():
     from renderih_amd import _lib
     lib = C.CDLL(build())
     sigs = dict(_lib.SIGNATURES)
-    if all(hasattr(lib, n) for n in _lib.EXPERIMENT_SIGNATURES):     # built with RIH_BUILD_EXPERIMENTS=1
-        sigs.update(_lib.EXPERIMENT_SIGNATURES)
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -43,13 +43,6 @@ def test_other_ops_host_logic():
     G.test_cheby_gather_project()
 
 
-def test_row_chain_host_logic():
-    """The operator programs that ops.LnLinearChainFn / AttnTailChainFn hand to rih_chain (per-hand and hand-shared
-    projections, mask seeds in the standalone sequence's order, lazily sized LayerNorm workspace)."""
-    G.test_attention_block_chains(2, 63, 128, 4, 0.1, False)
-    G.test_attention_block_chains(2, 63, 128, 4, 0.0, True)
-
-
 def test_paired_layers_host_logic():
     """Strides between separately allocated left/right parameters, stacked QKV operand, batched split-K reduce, grouped
     LayerNorm, shared-input patch conv: the descriptor plumbing of the hands-stacked decoder path."""
@@ -169,27 +162,6 @@ def test_conv1x1_cat_host_logic():
     G.test_conv1x1_cat((1, 5, 7, (32, 64), 40, True), 0)
     G.test_conv1x1_cat((1, 4, 4, (32, 40), 32, True), 2)
     G.test_conv1x1_cat((1, 4, 4, (64, 32), 64, 'ungated'), 1)
-
-
-def test_bn_fold_host_logic(monkeypatch):
-    """ops.BN_FOLD on the emulated ABI: the BnFold hand-over from BatchNorm to the convolution behind it, the bnb descriptor
-    fields, rih_bn_bwd_partials, and the pointer check that refuses sums of a gradient that is not the one that arrived."""
-    for case in [(2, 16, 16, 64, 64, 64, 3, True, False), (2, 8, 8, 64, 64, 32, 1, True, True), (3, 9, 7, 32, 64, 96, 3, False, False),
-                 (2, 8, 8, 64, 64, 64, 1, True, 'fanout')]:
-        G.test_bn_backward_sums_in_the_data_gradient_epilogue(case, monkeypatch)
-
-
-def test_presplit_weight_host_logic(monkeypatch):
-    """ops.PRESPLIT (rih_gemm b_mode 2 + rih_presplit_conv_weight, off by default): descriptor / operand plumbing."""
-    from renderih_amd import ops
-    monkeypatch.setattr(ops, 'ENGINE', 1)                       # (engine-1 experiments: three bf16 planes)
-    monkeypatch.setattr(ops, 'PRESPLIT', True)
-    G.test_conv2d((2, 8, 8, 64, 64, 3, 1, 1, True, True))
-    G.test_conv2d((1, 8, 8, 64, 64, 3, 2, 1, False, False))
-    G.test_conv2d((2, 8, 8, 64, 128, 1, 1, 0, False, True))
-    monkeypatch.setattr(ops, 'PRESPLIT_ACT', True)              # + pre-split activations (a_mode 2)
-    G.test_conv2d((2, 8, 8, 64, 64, 3, 1, 1, True, True))
-    G.test_conv2d((1, 8, 8, 64, 64, 3, 2, 1, False, False))
 
 
 def test_fused_attention_host_logic(monkeypatch):

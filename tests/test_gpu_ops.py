@@ -316,68 +316,6 @@ def test_batchnorm(training, relu, res, shape):
     assert_close(rv_g, rv_r, 1e-4, 1e-5, 'bn running_var')
 
 
-@pytest.mark.parametrize('case', [(2, 16, 16, 64, 64, 64, 3, True, False), (2, 16, 16, 64, 128, 64, 1, True, False),
-                                  (3, 9, 7, 32, 64, 96, 3, False, False), (2, 8, 8, 64, 64, 32, 1, True, True),
-                                  (1, 20, 12, 32, 32, 32, 3, True, True), (2, 8, 8, 64, 64, 64, 1, True, 'fanout')])
-def test_bn_backward_sums_in_the_data_gradient_epilogue(case, monkeypatch):
-    """RIH_BN_FOLD (rih_gemm_desc.bnb_*, rih_bn_bwd_partials): conv_a -> BatchNorm(-> ReLU) -> conv_b; the data gradient of conv_b is
-    the gradient arriving at the BatchNorm, and its GEMM's epilogue leaves the two reduction sums of the BatchNorm's backward.
-    Every gradient agrees with the unfolded path (the sums are fp32 in another order: 1e-5 of the largest value) and with
-    torch; the fold was really taken; with a skip path (conv_b's input also feeds a residual add) the gradient the skip carries
-    joins inside the GEMM and the fold still holds; with a second consumer that autograd adds in behind the GEMM ('fanout': in
-    place, into the GEMM's own output buffer) the sums are refused and the BatchNorm runs its own pass."""
-    from renderih_amd import ops
-    from renderih_amd.testing import experiments_built
-    N, H, W, C0, C1, C2, kb, relu, skip = case
-    d = dev()
-    if d.type == 'cuda' and not experiments_built():
-        pytest.skip('the bnb epilogue was measured slower and is compiled only with RIH_BUILD_EXPERIMENTS=1')
-    monkeypatch.setattr(ops, 'ENGINE', 2)
-    x0 = rnd(N, C0, H, W, seed=1)
-    wa = rnd(C1, C0, 3, 3, seed=2) * (2.0 / (C0 * 9)) ** 0.5
-    wb = rnd(C2, C1, kb, kb, seed=3) * (2.0 / (C1 * kb * kb)) ** 0.5
-    g, b = torch.rand(C1) + 0.5, rnd(C1, seed=4) * 0.1
-    gy = rnd(N, C2, H, W, seed=5)
-    gs = rnd(N, C1, H, W, seed=6) if skip else None
-
-    def torch_ref():
-        x, a, bb, gg, be = [t.clone().double().requires_grad_(True) for t in (x0, wa, wb, g, b)]
-        y = F.batch_norm(F.conv2d(x, a, None, 1, 1), None, None, gg, be, True, 0.1, 1e-5)
-        y = F.relu(y) if relu else y
-        z = F.conv2d(y, bb, None, 1, kb // 2)
-        loss = (z * gy.double()).sum() + ((y * gs.double()).sum() if skip else 0.0)
-        loss.backward()
-        return [t.grad.float() for t in (x, a, bb, gg, be)]
-
-    def ours(fold):
-        monkeypatch.setattr(ops, 'BN_FOLD', fold)
-        taken = ops.BN_FOLD_TAKEN
-        x = nhwc(x0).to(d).requires_grad_(True)
-        a, bb, gg, be = [t.clone().to(d).requires_grad_(True) for t in (wa, wb, g, b)]
-        ops.bounds_reset()
-        h = ops.conv2d(x, a, stride=1, pad=1)
-        y = ops.batchnorm(h, gg, be, torch.zeros(C1, device=d), torch.ones(C1, device=d), training=True, relu=relu)
-        if skip == 'fanout':
-            z = ops.conv2d(y, bb, stride=1, pad=kb // 2)
-            loss = (z * nhwc(gy).to(d)).sum() + (y * nhwc(gs).to(d)).sum()
-        elif skip:
-            z, yv = ops.conv2d_skip(y, bb, stride=1, pad=kb // 2)
-            loss = (z * nhwc(gy).to(d)).sum() + (yv * nhwc(gs).to(d)).sum()
-        else:
-            z = ops.conv2d(y, bb, stride=1, pad=kb // 2)
-            loss = (z * nhwc(gy).to(d)).sum()
-        loss.backward()
-        return [nchw(x.grad), a.grad, bb.grad, gg.grad, be.grad], ops.BN_FOLD_TAKEN - taken
-
-    ref = torch_ref()
-    plain, t0 = ours(False)
-    folded, t1 = ours(True)
-    assert t0 == 0 and t1 == (0 if skip == 'fanout' else 1), (t0, t1)
-    for name, r, p_, f_ in zip(('dx', 'dwa', 'dwb', 'dgamma', 'dbeta'), ref, plain, folded):
-        assert_close(f_, p_, 1e-5, 1e-5 * float(p_.abs().max()), 'fold vs plain ' + name)
-        assert_close(f_, r, 2e-3, 2e-4 * float(r.abs().max()), 'fold vs torch ' + name)
-
-
 def check_linear_dropout_epilogue(rows, K, Nf, relu, res, pair=False, p=0.3, expect_fused=True):
     """rih_gemm_desc.drop_p (ops.linear / ops.linear_pair with drop=): dropout in the GEMM's epilogue against the GEMM followed by
     rih_add_dropout -- the same mask stream, so the output and every gradient are bit-identical; shapes the epilogue does not
@@ -753,49 +691,6 @@ def test_cross_attention_packed(B, V, D, h):
     ((a * g1.to(d)).sum() + (b * g2.to(d)).sum()).backward()
     assert_close(gl.grad, tl.grad, 1e-3, 1e-4, 'cross dL')
     assert_close(gr.grad, tr.grad, 1e-3, 1e-4, 'cross dR')
-
-
-@pytest.mark.parametrize('engine', [1, 2])
-@pytest.mark.parametrize('case', [(2, 32, 32, 64, 128, 3, 1, 1), (1, 64, 64, 128, 256, 1, 1, 0), (2, 16, 16, 128, 128, 3, 1, 1)])
-def test_gemm_tile4_pipelined_kernel(case, engine):
-    """The 256x128 software-pipelined split kernel (tile id 4), engine 1 (six bf16 products) and engine 2 (three fp16 products,
-    operand bounds from rih_absmax): honest against the 128x128 kernel of the same engine on conv forward, conv weight gradient
-    (split-K) and a plain matrix product, and -- engine 2 -- its statistics epilogue against the 128x128 kernel's."""
-    from renderih_amd import ops
-    d = dev()
-    if not ops.experiments_built():
-        pytest.skip('tile 4 is an experiment variant outside the default library (RIH_BUILD_EXPERIMENTS=1)')
-    if engine == 2:
-        return _tile4_engine2(case, d)
-    N, H, W, Cin, Cout, k, s, p = case
-    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
-    x = rnd(N, H, W, Cin, seed=31).to(d)
-    wp = rnd(k * k * Cin, Cout, seed=32).to(d)
-    M, K = N * Ho * Wo, k * k * Cin
-    geom = (H, W, Cin, Ho, Wo, k, k, s, 1, p, p)
-    ys = []
-    for t in (0, 4):
-        y = torch.empty(N, Ho, Wo, Cout, device=d)
-        ops.gemm(x, wp, y, M, Cout, K, Cin, Cout, Cout, a_mode=0, b_mode=0, geom=geom, tile=t, engine=1)
-        ys.append(y)
-    assert_close(ys[1], ys[0], 1e-5, 1e-6, 'tile4 conv fwd')
-    dy = rnd(N, Ho, Wo, Cout, seed=33).to(d)
-    sk, kc = 2, -(-(-(-M // 2)) // 32) * 32
-    parts = []
-    for t in (0, 4):
-        part = torch.zeros(sk, K, Cout, device=d)
-        ops.gemm(x, dy, part, K, Cout, M, Cin, Cout, Cout, a_mode=1, b_mode=0, splitk=sk, kchunk=kc, sCsplit=K * Cout,
-                 geom=geom, tile=t, engine=1)
-        parts.append(part.sum(0))
-    assert_close(parts[1], parts[0], 1e-5, 1e-6, 'tile4 wgrad')
-    a, b = x.view(M if k == 1 else N * H * W, Cin), rnd(Cout, Cin, seed=34).to(d)
-    zs = []
-    for t in (0, 4):
-        z = torch.empty(a.shape[0], Cout, device=d)
-        ops.gemm(a, b, z, a.shape[0], Cout, Cin, Cin, Cin, Cout, a_mode=0, b_mode=1, tile=t, engine=1)
-        zs.append(z)
-    assert_close(zs[1], zs[0], 1e-5, 1e-6, 'tile4 linear')
-    assert_close(zs[1], (a.double() @ b.double().t()).float(), 1e-5, 1e-6, 'tile4 linear vs fp64')
 
 
 def _tile4_engine2(case, d):
@@ -1317,79 +1212,3 @@ def _torch_attention_block(mods, x, heads, cross):
             out.append(x1 + F.linear(F.relu(F.linear(y2, ff.fc1.weight, ff.fc1.bias)), ff.fc2.weight, ff.fc2.bias))
     return torch.stack(out)
 
-
-@pytest.mark.parametrize('B,S,D,heads,p,cross', [(2, 63, 128, 4, 0.0, False), (1, 40, 64, 4, 0.1, False),
-                                                 (3, 33, 64, 2, 0.05, False), (2, 63, 128, 4, 0.0, True),
-                                                 (1, 70, 64, 4, 0.1, True), (1, 45, 256, 4, 0.1, False),
-                                                 (9, 126, 128, 4, 0.1, False)])
-def test_attention_block_chains(B, S, D, heads, p, cross):
-    from renderih_amd.testing import experiments_built
-    if not experiments_built() and dev().type == 'cuda':
-        pytest.skip('csrc/rih_chain.hip is an experiment outside the default library; build with RIH_BUILD_EXPERIMENTS=1')
-    """rih_chain (LayerNorm -> QKV projection; output projection -> dropout -> skip -> LayerNorm -> fc1 + ReLU -> dropout ->
-    fc2 -> dropout -> skip, one launch each, both directions) against the standalone launch sequence it replaces with the SAME
-    dropout masks: output, input gradient and every parameter gradient; without dropout also against plain torch.  Row counts
-    that are not multiples of the 32-row block, per-hand and hand-shared projections."""
-    from renderih_amd import attn, ops
-    d = dev()
-    assert ops.chain_dims_ok(D), 'the case must take the chain path'
-    torch.manual_seed(5)
-    if cross:
-        mod = attn.inter_attn(D, n_heads=heads, dropout=p)
-    else:
-        mod = torch.nn.ModuleList([attn.SelfAttn(D, n_heads=heads, dropout=p) for _ in range(2)])
-    g = torch.Generator().manual_seed(11)
-    for prm in mod.parameters():           # biases / LayerNorm parameters away from their 0 / 1 initial values
-        with torch.no_grad():
-            if prm.dim() == 1:
-                prm.add_(0.3 * torch.randn(prm.shape, generator=g))
-    x, gy = rnd(2, B, S, D, seed=1), rnd(2, B, S, D, seed=2)
-
-    def run_torch():
-        t = x.clone().requires_grad_(True)
-        y = _torch_attention_block(mod, t, heads, cross)
-        y.backward(gy)
-        grads = [q.grad.clone() if q.grad is not None else None for q in mod.parameters()]
-        mod.zero_grad(set_to_none=True)
-        return y.detach(), t.grad, grads
-
-    ref = run_torch() if p == 0 else None
-    mod = mod.to(d)
-    res = []
-    saved = ops.CHAIN
-    try:
-        for chain in (False, True):
-            ops.CHAIN = chain
-            torch.manual_seed(77)           # DropCtx draws its base seed from the host RNG
-            dc = attn.DropCtx(p, True)
-            t = x.to(d).clone().requires_grad_(True)
-            if cross:
-                # the cross-hand half only: its per-hand self-attention layers are the other parametrisations of this test
-                w = torch.cat([mod.w_qs.weight, mod.w_ks.weight, mod.w_vs.weight], 0)
-                b = torch.cat([mod.w_qs.bias, mod.w_ks.bias, mod.w_vs.bias], 0)
-                sd = (lambda: dc.seed()) if p > 0 else (lambda: 0)
-                if chain:
-                    qkv, X = ops.ln_linear_chain(t, mod.layer_norm1, mod.layer_norm2, w, b)
-                    feat = ops.cross_attention_stacked(qkv, heads, p, sd(), sd())
-                    y = ops.attn_tail_chain(feat, X, mod.fc, None, mod.ffL, mod.ffR, p, attn._seeds3(dc))
-                else:
-                    qkv = ops.linear(ops.layernorm_pair(t, mod.layer_norm1, mod.layer_norm2), w, b)
-                    feat = ops.cross_attention_stacked(qkv, heads, p, sd(), sd())
-                    y = attn.MLP_res_block.forward_pair(mod.ffL, mod.ffR, attn._lin_drop_res(dc, mod.fc, feat, t), dc)
-            else:
-                y = attn.SelfAttn.forward_pair(mod[0], mod[1], t, dc)
-            y.backward(gy.to(d))
-            res.append((y.detach(), t.grad, [q.grad.clone() if q.grad is not None else None for q in mod.parameters()]))
-            mod.zero_grad(set_to_none=True)
-    finally:
-        ops.CHAIN = saved
-    names = [n for n, _ in mod.named_parameters()]
-    for which, other in (('standalone', res[0]),) + ((('torch', ref),) if ref is not None else ()):
-        assert_close(res[1][0], other[0], 2e-4, 2e-5, 'chain out vs ' + which)
-        assert_close(res[1][1], other[1], 1e-3, 1e-4, 'chain dx vs ' + which)
-        for n, a, b_ in zip(names, res[1][2], other[2]):
-            if (cross and ('L_self_attn_layer' in n or 'R_self_attn_layer' in n)) or is_null_gradient(n):
-                continue        # (a key bias has no gradient in exact arithmetic: softmax is shift invariant)
-            assert (a is None) == (b_ is None), n
-            if a is not None:
-                assert_close(a, b_, 1e-3, 1e-4, 'chain d%s vs %s' % (n, which))

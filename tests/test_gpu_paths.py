@@ -114,42 +114,6 @@ def test_fused_attention_kernels(monkeypatch):
     G.test_cross_attention_stacked_and_rows_pair()
 
 
-@pytest.mark.parametrize('act', [False, True])
-def test_presplit_gemm_operands(monkeypatch, act):
-    import test_gpu_ops as G
-    from renderih_amd import ops
-    if not ops.experiments_built():
-        pytest.skip('pre-split operands are an experiment variant outside the default library (RIH_BUILD_EXPERIMENTS=1)')
-    monkeypatch.setattr(ops, 'ENGINE', 1)                   # (engine-1 experiments: three bf16 planes per operand)
-    monkeypatch.setattr(ops, 'PRESPLIT', True)
-    monkeypatch.setattr(ops, 'PRESPLIT_ACT', act)
-    for case in G.CONV_CASES:
-        G.test_conv2d(case)
-
-
-@pytest.mark.parametrize('mode', ['per_call', 'pack_cache', 'loader_converts'])
-def test_engine2_weight_planes(monkeypatch, mode):
-    """Engine 2's weight operands: two scaled fp16 planes produced per call (rih_presplit_conv_weight), through a PackCache
-    refreshed in one rih_presplit_multi launch (second pass: every operand out of the cache), or converted by the GEMM's loader
-    (RIH_E2_PRESPLIT=0) -- all against F.conv2d at the suite's unchanged tolerance."""
-    import test_gpu_ops as G
-    from renderih_amd import ops
-    if mode != 'loader_converts' and not ops.experiments_built():
-        pytest.skip('pre-split operands are an experiment variant outside the default library (RIH_BUILD_EXPERIMENTS=1)')
-    monkeypatch.setattr(ops, 'ENGINE', 2)
-    monkeypatch.setattr(ops, 'E2_PRESPLIT', mode != 'loader_converts')
-    if mode == 'pack_cache':
-        pc = ops.PackCache()
-        monkeypatch.setattr(ops, '_PACK', pc)
-        for case in G.CONV_CASES:
-            G.test_conv2d(case)
-        assert any(e[2][0] == 'presplit' for e in pc.entries.values())
-        ops.bounds_reset()
-        pc.refresh()
-    for case in G.CONV_CASES:
-        G.test_conv2d(case)
-
-
 def test_batch_input_preparation_matches_reference_fixtures():
     import test_input_pipeline
     test_input_pipeline.prepare_vs_fixtures(dev())

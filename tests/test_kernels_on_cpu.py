@@ -15,23 +15,18 @@ sys.path.insert(0, os.path.join(HERE, 'hipcpu'))
 import test_gpu_loss as TL          # noqa: E402
 import test_gpu_mano as TMANO       # noqa: E402
 import test_gpu_ops as G            # noqa: E402
-import test_gpu_p3 as TP3          # noqa: E402
 import test_metrics as TMET         # noqa: E402
 import test_pose_head as TP         # noqa: E402
 
 CPU = torch.device('cpu')
 
 
-_EXPERIMENTS = os.environ.get('RIH_BUILD_EXPERIMENTS', '0') == '1'
-_needs_experiments = pytest.mark.skipif(not _EXPERIMENTS, reason='experiment kernels (rih_chain.hip, rih_gemm3.hip) are outside the '
-                                                                    'default library: RIH_BUILD_EXPERIMENTS=1 compiles them into the '
-                                                                    'host build too')
 
 
 @pytest.fixture(autouse=True)
 def _host_kernels(monkeypatch):
     from host_kernels import host_kernels_abi
-    for mod in (G, TL, TMANO, TP3):
+    for mod in (G, TL, TMANO):
         monkeypatch.setattr(mod, 'dev', lambda: CPU)
     with host_kernels_abi():
         yield
@@ -153,14 +148,6 @@ def test_parameter_bounds_are_not_trusted_outside_an_owning_scope():
         ops.ENGINE = saved
 
 
-@pytest.mark.parametrize('case', [(2, 8, 8, 64, 64, 64, 3, True, False), (1, 8, 8, 64, 128, 64, 1, True, True),
-                                  (1, 9, 7, 32, 64, 96, 3, False, False)])
-@_needs_experiments
-def test_bn_fold_kernels(case, monkeypatch):
-    """The bnb epilogue of gemm_split_kernel and rih_bn_bwd_partials (the real kernels) against the unfolded path and torch."""
-    G.test_bn_backward_sums_in_the_data_gradient_epilogue(case, monkeypatch)
-
-
 @pytest.mark.parametrize('case', [(33, 64, 24, True, True, True), (64, 128, 64, True, False, False),
                                   (20, 36, 6, False, False, False)])
 def test_linear_kernels(case):
@@ -213,46 +200,10 @@ def test_flash_attention_kernels(case):
     G.test_flash_attention_equals_three_kernel_path(*case)
 
 
-@_needs_experiments
-@pytest.mark.parametrize('case', [(1, 40, 64, 4, 0.1, False), (3, 33, 64, 2, 0.05, False), (1, 70, 64, 4, 0.1, True)])
-def test_row_chain_kernel(case):
-    """csrc/rih_chain.hip: the attention block's row-wise sequences as one launch each way, against the standalone kernels
-    (D = 64 here: the D = 128 / 256 cases, 40-60 s each on the fiber harness, run in the GPU suite and under HIPCPU_MORE=1)."""
-    G.test_attention_block_chains(*case)
-
-
-@_needs_experiments
-@pytest.mark.skipif(os.environ.get('HIPCPU_MORE', '0') != '1', reason='slow on the fiber harness; HIPCPU_MORE=1')
-def test_row_chain_kernel_wide_blocks():
-    G.test_attention_block_chains(2, 63, 128, 4, 0.0, False)
-    G.test_attention_block_chains(1, 20, 256, 4, 0.1, False)
-
-
 def test_graph_and_resampling_kernels():
     G.test_cheby_gather_project()
     G.test_pool_upsample_layout()
     G.test_resample_hrnet(2, 4, 4, 32)
-
-
-@_needs_experiments
-def test_p3_gemm_kernels():
-    """csrc/rih_gemm3.hip: P3 format, LDS-DMA staged 6-product GEMM on all three tiles, epilogue, statistics, dgrad."""
-    TP3.test_p3_format_round_trip()
-    for case in TP3.P3_CONV_CASES:
-        TP3.test_p3_conv_forward(case, 0)
-        TP3.test_p3_conv_forward(case, 1)
-    TP3.test_p3_epilogue_bias_residual_relu()
-    TP3.test_p3_tile_statistics_and_merge(0, (1, 16, 16, 32, 128))
-    TP3.test_p3_tile_statistics_and_merge(2, (2, 8, 8, 32, 64))
-    TP3.test_p3_data_gradient((2, 9, 7, 32, 64, 3, 2, 1), 0)
-    TP3.test_p3_data_gradient((2, 9, 7, 32, 64, 3, 2, 1), 1)
-    TP3.test_p3_data_gradient((2, 8, 8, 64, 32, 3, 1, 1), 1)
-
-
-@_needs_experiments
-@pytest.mark.parametrize('engine', [1, 2])
-def test_tile4_pipelined_gemm_kernel(engine):
-    G.test_gemm_tile4_pipelined_kernel((1, 16, 16, 32, 128, 3, 1, 1), engine)    # M = 256: one 256x128 tile, 4-slot ring
 
 
 def test_fused_attention_forward(monkeypatch):
@@ -331,98 +282,6 @@ def test_mesh_loss_kernel():
 def test_metrics_and_pose_head_kernels():
     TMET._check_against_oracle(CPU)
     TP._pose_head_kernels_vs_oracle(CPU)
-
-
-@_needs_experiments
-@pytest.mark.parametrize('case', [
-    (2, 8, 8, 64, 64, 3, 1, 1, True, True),         # 3x3: forward + stride-1 data gradient read pre-split weights
-    (1, 8, 8, 64, 64, 3, 2, 1, False, False),       # strided: one pre-split tap subset per parity class
-    (2, 8, 8, 64, 128, 1, 1, 0, False, True),       # 1x1
-    (2, 4, 4, 96, 40, 1, 2, 0, True, False),        # N = 40: a partial 64-wide tile of plane rows
-])
-def test_presplit_weight_path(monkeypatch, case):
-    """rih_gemm b_mode 2 (B as pre-split bf16 planes from rih_presplit_conv_weight) against F.conv2d; off by default in
-    the product (ops.PRESPLIT), enabled here on the host-compiled kernels."""
-    from renderih_amd import ops
-    calls = []
-    real = ops._presplit_weight
-    monkeypatch.setattr(ops, 'ENGINE', 1)                   # (engine 2 pre-splits its weight operands by default: see below)
-    monkeypatch.setattr(ops, 'PRESPLIT', True)
-    monkeypatch.setattr(ops, '_presplit_weight', lambda *a, **k: (calls.append(a[2]), real(*a, **k))[1])
-    G.test_conv2d(case)
-    N_, H_, W_, Cin, Cout = case[:5]
-    assert False in calls, calls                             # the forward operand went through it
-    assert (True in calls) == (Cin > 32 and Cout % 32 == 0), calls      # ... and the data-gradient operand where eligible
-
-
-@_needs_experiments
-@pytest.mark.parametrize('case', [
-    (2, 8, 8, 32, 64, 3, 1, 1, False, True),
-    (1, 9, 7, 64, 96, 3, 2, 1, True, False),        # strided: parity-class data gradients from tap-subset planes
-    (2, 8, 8, 64, 128, 1, 1, 0, True, True),        # 1x1: planes of the raw [Cout][Cin] parameter
-    (2, 4, 4, 96, 40, 1, 2, 0, True, False),        # N = 40: a partial 64-wide tile of plane rows
-])
-@pytest.mark.parametrize('packed', [False, True])
-def test_engine2_presplit_weight_planes(monkeypatch, case, packed):
-    """Engine 2's default: weight operands as two scaled fp16 planes (rih_presplit_conv_weight / rih_presplit_multi with the
-    weight's bound block, rih_gemm b_mode 2 + engine 2, also with the statistics epilogue) against F.conv2d -- per call, and
-    through a PackCache refreshed in one launch (second pass over the same case: every operand comes out of the cache)."""
-    from renderih_amd import ops
-    calls = []
-    real = ops._presplit_weight
-    monkeypatch.setattr(ops, 'ENGINE', 2)
-    monkeypatch.setattr(ops, 'E2_PRESPLIT', True)
-    monkeypatch.setattr(ops, '_presplit_weight', lambda *a, **k: (calls.append(a[2]), real(*a, **k))[1])
-    if packed:
-        pc = ops.PackCache()
-        monkeypatch.setattr(ops, '_PACK', pc)
-        G.test_conv2d(case)                 # fills the cache (packed on the spot)
-        n = len(pc.entries)
-        assert n >= 1
-        ops.bounds_reset()
-        pc.refresh()                        # one rih_presplit_multi launch (bounds measured on demand)
-        G.test_conv2d(case)
-        assert len(pc.entries) >= n
-    else:
-        G.test_conv2d(case)
-    assert False in calls, calls
-
-
-@_needs_experiments
-@pytest.mark.parametrize('case', [
-    (2, 8, 8, 64, 64, 3, 1, 1, True, True),
-    (1, 8, 8, 64, 64, 3, 2, 1, False, False),
-    (2, 8, 8, 64, 128, 1, 1, 0, False, True),
-    (1, 9, 7, 32, 96, 3, 1, 1, True, False),        # odd sizes: partial row passes, halo taps
-])
-def test_presplit_activation_path(monkeypatch, case):
-    """RIH_PRESPLIT=2: both GEMM operands pre-split (rih_gemm a_mode 2 + b_mode 2, activation planes from a standalone
-    rih_presplit_matrix pass) -- forward, stride-1 and parity-class data gradients against F.conv2d."""
-    from renderih_amd import ops
-    acts = []
-    real = ops._presplit_act
-    monkeypatch.setattr(ops, 'ENGINE', 1)                   # (an engine-1 experiment: three bf16 planes on both sides)
-    monkeypatch.setattr(ops, 'PRESPLIT', True)
-    monkeypatch.setattr(ops, 'PRESPLIT_ACT', True)
-    monkeypatch.setattr(ops, '_presplit_act', lambda *a, **k: (acts.append(a[1]), real(*a, **k))[1])
-    G.test_conv2d(case)
-    assert len(acts) >= 1, 'the activation planes were never used'
-
-
-@_needs_experiments
-def test_presplit_matrix_entry_point():
-    """rih_presplit_matrix on a plain [N][K] weight + b_mode 2 GEMM == the fp32 product."""
-    import math
-    from renderih_amd import ops
-    from renderih_amd._lib import check
-    M, K, N = 70, 100, 72
-    x, w = G.rnd(M, K, seed=1), G.rnd(N, K, seed=2, scale=1 / math.sqrt(K))
-    Kp = 128
-    planes = torch.empty(3, N, Kp // 2)
-    check(ops._L().rih_presplit_matrix(w.data_ptr(), 1, K, N, K, planes.data_ptr(), Kp, 0, 0), 'rih_presplit_matrix')
-    y = torch.empty(M, N)
-    ops.gemm(x, planes, y, M, N, K, K, Kp, N, a_mode=0, b_mode=2, engine=1)
-    TMET.assert_close(y, (x.double() @ w.double().t()).float(), 1e-5, 1e-6, 'presplit matrix gemm')
 
 
 def test_gemm_descriptor_fuzz_against_emulator():
@@ -743,67 +602,3 @@ def test_kernels_are_schedule_independent(sched):
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
-
-@_needs_experiments
-def test_presplit_gemm_descriptor_fuzz_against_emulator():
-    """As the descriptor fuzz above, for the pre-split operand modes (b_mode 2 with a_mode 0 or 2): conv gathers with
-    strides / padding / 2x2..3x3 taps, plain rows, split-K, all three tiles, partial N tiles."""
-    import ctypes as C
-    import numpy as np
-    from abi_emulator import EmulatedLib
-    from host_kernels import load
-    from renderih_amd._lib import GemmDesc
-    host, emu = load(), EmulatedLib()
-    rs = np.random.RandomState(3)
-    cdiv = lambda a, b: -(-a // b)
-    checked = 0
-    for it in range(28):
-        conv = rs.rand() < 0.6
-        Cin = int(rs.choice([32, 64, 96]))
-        if conv:
-            Nimg, H, W = int(rs.randint(1, 3)), int(rs.randint(3, 9)), int(rs.randint(3, 9))
-            KH, KW, stride, pad = int(rs.choice([1, 2, 3])), int(rs.choice([1, 2, 3])), int(rs.choice([1, 2])), int(rs.randint(0, 2))
-            Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-            if Ho < 1 or Wo < 1:
-                continue
-            M, K, pix = Nimg * Ho * Wo, KH * KW * Cin, Nimg * H * W
-            geom = (H, W, Cin, Ho, Wo, KH, KW, stride, 1, pad, pad)
-        else:
-            M = int(rs.randint(1, 200))
-            K = Cin * int(rs.choice([1, 2]))
-            pix, Cin = M, K
-            geom = (1, 1, K, 1, 1, 1, 1, 1, 1, 0, 0)
-        N, a_pre = int(rs.choice([33, 40, 64, 72, 130])), rs.rand() < 0.5
-        X, Bkn = rs.randn(pix, Cin).astype(np.float32), rs.randn(K, N).astype(np.float32)
-        Kp = cdiv(K, 32) * 32
-        pB, pA = np.zeros(3 * N * Kp, np.uint16), np.zeros(3 * pix * Cin, np.uint16)
-        assert host.rih_presplit_matrix(Bkn.ctypes.data, 0, K, N, N, pB.ctypes.data, Kp, None, None) == 0
-        assert host.rih_presplit_matrix(X.ctypes.data, 1, Cin, pix, Cin, pA.ctypes.data, Cin, None, None) == 0
-        splitk, kchunk = 1, 0
-        if rs.rand() < 0.3 and K >= 64:
-            kchunk = cdiv(cdiv(K, 2), 32) * 32
-            splitk = cdiv(K, kchunk)
-        tile, ldc = int(rs.choice([0, 1, 2])), N + int(rs.choice([0, 4]))
-        use_bias, relu = splitk == 1 and rs.rand() < 0.5, splitk == 1 and rs.rand() < 0.3
-        bias = rs.randn(N).astype(np.float32)
-        outs = []
-        for lib in (host, emu):
-            Cc = np.full(splitk * M * ldc + 8, 7.0, np.float32)
-            d = GemmDesc()
-            d.A, d.B, d.C = (pA if a_pre else X).ctypes.data, pB.ctypes.data, Cc.ctypes.data
-            d.bias, d.R = (bias.ctypes.data if use_bias else 0), 0
-            d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, Cin, Kp, ldc
-            d.a_mode, d.b_mode, d.nb1, d.nb2 = (2 if a_pre else 0), 2, 1, 1
-            d.splitk, d.kchunk, d.sCsplit, d.alpha, d.relu = splitk, kchunk, M * ldc, 1.0, 1 if relu else 0
-            (d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.strideA, d.upS, d.padH, d.padW) = geom
-            d.tile, d.engine = tile, 1
-            outs.append((lib.rih_gemm(C.byref(d), None), Cc))
-        (r0, c0), (r1, c1) = outs
-        what = 'case %d conv=%s a_pre=%s M%d N%d K%d sk%d tile%d geom=%s' % (it, conv, a_pre, M, N, K, splitk, tile, geom)
-        assert r0 == 0 and r1 == 0, what
-        v0, v1 = c0[:splitk * M * ldc].reshape(splitk, M, ldc), c1[:splitk * M * ldc].reshape(splitk, M, ldc)
-        sc = max(float(np.abs(v1[:, :, :N]).max()), 1e-6)
-        assert np.allclose(v0[:, :, :N], v1[:, :, :N], rtol=2e-5, atol=2e-5 * sc), what
-        assert (v0[:, :, N:] == 7.0).all() and (c0[splitk * M * ldc:] == 7.0).all(), 'stray write, ' + what
-        checked += 1
-    assert checked >= 22
