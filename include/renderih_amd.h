@@ -268,6 +268,15 @@ typedef struct rih_panel_desc {
 int rih_panel_ok(const rih_panel_desc* d);
 int rih_panel_stats_rows(const rih_panel_desc* d);
 int rih_panel(const rih_panel_desc* d, void* stream);
+/* Long-K plain-row GEMM (csrc/rih_conv3.hip rows_kernel, ABI 18) -- the 1x1 convolutions with K >= 256 of Bottleneck.conv1 / conv3
+ * and their data gradients (torchvision Bottleneck via models/encoder.py:75-89,107-126): the same descriptor and the same
+ * arithmetic as rih_panel (engine 2, H2 weight planes), as 512-thread workgroups on 256 x 128 / 128 x 128 / 256 x 64 / 128 x 64 tiles
+ * with the weights staged by LDS-DMA and three A stages in LDS.  Preconditions (rih_rows_ok returns 1): K % 32 == 0, K >= 64,
+ * N % 64 == 0, M % 128 == 0, pitches % 4 == 0, 16-byte aligned operands, M * lda * 4 < 2^31, not both stats and r.
+ * stats (optional): [M / rows][2][N] per block of rows = rih_rows_stats_rows(desc) consecutive rows (64 or 32). */
+int rih_rows_ok(const rih_panel_desc* d);
+int rih_rows_stats_rows(const rih_panel_desc* d);
+int rih_rows(const rih_panel_desc* d, void* stream);
 
 /* Finish a forward split-K GEMM: C[m*ldc+n] = act(alpha * sum_s P[s][m][n] + bias[n] + R[m*ldr+n]). */
 int rih_splitk_finish(const float* P, int S, int M, int N, float* C, int ldc, const float* bias, const float* R,

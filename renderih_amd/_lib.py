@@ -119,6 +119,9 @@ SIGNATURES = {
     'rih_panel_ok': (c_i, [C.POINTER(PanelDesc)]),
     'rih_panel_stats_rows': (c_i, [C.POINTER(PanelDesc)]),
     'rih_panel': (c_i, [C.POINTER(PanelDesc), C.c_void_p]),
+    'rih_rows_ok': (c_i, [C.POINTER(PanelDesc)]),
+    'rih_rows_stats_rows': (c_i, [C.POINTER(PanelDesc)]),
+    'rih_rows': (c_i, [C.POINTER(PanelDesc), C.c_void_p]),
     'rih_hardswish_fwd': (c_i, [c_f, c_f, c_l, C.c_void_p]),
     'rih_hardswish_bwd': (c_i, [c_f, c_f, c_f, c_l, C.c_void_p]),
     'rih_tanh_scale_fwd': (c_i, [c_f, c_f, c_l, c_fl, C.c_void_p]),

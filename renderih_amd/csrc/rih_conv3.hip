@@ -104,6 +104,15 @@ __device__ __forceinline__ void c3_glds16(const unsigned char* src, unsigned cha
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// LDS-DMA data is published to the other wavefronts by a barrier only once the requesting wavefront's vmcnt has drained: hipcc
+// places that wait in front of __syncthreads() today, but nothing guarantees it -- every barrier that publishes
+// DMA data is preceded by this explicit wait (CK's block_sync_lds_direct_load does the same).
+__device__ __forceinline__ void c3_dma_wait() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 __device__ __forceinline__ float4 c3_bload4(__amdgpu_buffer_rsrc_t r, unsigned off) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
@@ -225,7 +234,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
     load_A(0);
     issue_B(0, Bbuf);
     store_A(Abuf);
-    __syncthreads();                                    // (waits for the LDS-DMA too: hipcc drains vmcnt before a barrier)
+    c3_dma_wait();
+    __syncthreads();
     int kt = 0;
     for (int c = 0; c < nchunk; ++c) {
         const unsigned char* As = Abuf + (c & 1) * A_STAGE;
@@ -266,6 +276,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
 #undef RIH_C3_TERM
             }
             if (t == 8 && c + 1 < nchunk) store_A(Abuf + ((c + 1) & 1) * A_STAGE);   // (that stage was last read in chunk c - 1)
+            c3_dma_wait();                              // the weights of k-tile kt + 1 have landed before the barrier publishes them
             __syncthreads();
         }
     }
@@ -519,8 +530,9 @@ __global__ __launch_bounds__(NT, 2) void panel_kernel(const PanelArgs p) {
 
     load_A(mt);
     store_A(Abuf);
+    c3_dma_wait();                                      // the weight slice has landed
     load_A(mt + mstep);
-    __syncthreads();                                    // weights landed (LDS-DMA drained before the barrier), stage 0 complete
+    __syncthreads();                                    // weights published, stage 0 complete
     int st = 0;
     for (; mt < p.mtiles; mt += mstep, st ^= 1) {
         const unsigned char* As = Abuf + st * A_ST;
@@ -670,6 +682,282 @@ void panel_launch(const PanelArgs& a, unsigned grid, bool stats, bool res, hipSt
     else hipLaunchKernelGGL((panel_kernel<KT, BN, false, false>), dim3(grid), dim3(NT), 0, s, a);
 }
 
+// ------------------------------------------------------------------------------------------------ long-K plain-row GEMM ("rows")
+// rih_rows: C[M][N] = act(A[M][K] W[N][K]^T (+ R)) for the 1x1 convolutions with a LONG reduction (K >= 256: Bottleneck.conv1 /
+// conv3 of layer2-4 forward, their data gradients, the downsample branches' data gradients) -- round 6.  On the tiled kernels of
+// rih_gemm.hip these launches ran at 105-200 TF/s (profiles/r05/gemm_dump_c5.json: 16x16 1024 -> 256 51 us = 169 TF/s, 256 -> 1024
+// 55-67 us = 128-156 TF/s, 64x64 256 -> 64 82 us = 105 TF/s) where the halo-resident 3x3 kernel reaches 285-350: 256-thread
+// workgroups with 128 x 64 tiles move 22 FLOP per operand byte out of L2, convert BOTH operands in every workgroup and have one
+// k-tile in flight.  Here the recipe of conv3x3_halo_kernel is applied to plain rows: 512 threads, a BM x BN tile of 256 x 128
+// (128 x 128, 256 x 64, 128 x 64 for problems that would not fill the chip otherwise), the weights as pre-split H2 planes staged
+// global -> LDS by LDS-DMA (no conversion, no VGPR round trip for B), the A rows global -> registers -> converted ONCE per tile ->
+// LDS, THREE A stages and two B stages so that the loads of k-tile t + 2 are issued at the top of k-tile t and stored at its
+// end: every request has a whole k-tile of MFMAs to land, one barrier per k-tile, and nothing is in flight across a barrier
+// except what that barrier publishes.  Arithmetic: engine 2, product for product (see conv3x3_halo_kernel); k-order identical to
+// the tiled kernel's (k ascending in 32-deep tiles), so the two agree to the last bit wherever their accumulation order inside a
+// tile agrees, and to fp32 round-off in general.
+// LDS images: a row (of A or of W) is 8 units of 16 bytes, unit j = (k / 8) * 2 + plane at position j ^ ((row >> 1) & 7) -- the
+// weight image of conv3x3_halo_kernel for both operands (conflict-free ds_read_b128 for 32 consecutive rows).
+// Epilogue: optional residual (requested before the staging round trip), ReLU, BatchNorm statistics per 32 TM rows of a wave
+// (rih_gemm_desc.stats format).  Preconditions (rih_rows_ok): K % 32 == 0, K >= 64, N % 64 == 0, M % 128 == 0, 16-byte aligned
+// operands, pitches % 4 == 0, A < 2 GiB.
+struct RowsArgs {
+    const float* a;
+    const unsigned char* w;     // H2 planes [N][K / 8][2][8 halves]
+    float* c;
+    const float* r;
+    float* stats;
+    const float* amax_a;
+    const float* amax_w;
+    int M, N, K, lda, ldc, ldr, relu;
+    int nblk, mtiles;
+};
+
+template <int BM, int BN, bool STATS, bool RES>
+__global__ __launch_bounds__(NT, (3 * BM + 2 * BN) * 128 <= 80 * 1024 ? 4 : 2) void rows_kernel(const RowsArgs p) {
+    constexpr int WGN = 2, WGM = 4;                     // waves 4 (M) x 2 (N)
+    constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;               // 2 x 2, 1 x 2, 2 x 1, 1 x 1
+    static_assert(TM >= 1 && TN >= 1, "wave tile");
+    constexpr int A_ST = BM * 128, B_ST = BN * 128;     // bytes per stage: 32-deep k-tile, two fp16 planes
+    constexpr int NPA = (BM * 8) / NT;                  // float4 quads of an A k-tile per thread: 4 / 2
+    constexpr int NPB = (BN * 8 + NT - 1) / NT;         // LDS-DMA units of a W k-tile per thread: 2 / 1
+    static_assert((BM * 8) % NT == 0 && (BN * 8) % 64 == 0, "loader geometry");
+    constexpr int SMEM = 3 * A_ST + 2 * B_ST;
+    static_assert(SMEM >= 8 * 32 * SLD * 4, "epilogue staging fits");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    unsigned char* const Bbuf = smem + 3 * A_ST;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int wm = wave / WGN, wn = wave % WGN;
+    // workgroup -> (row tile, column block); column blocks fastest: the workgroups that share A rows are neighbours on one XCD
+    const int id = xcd_remap_c3((int)blockIdx.x, (int)gridDim.x);
+    const int nb = id % p.nblk, mt = id / p.nblk;
+    const int m0 = mt * BM, n0 = nb * BN;
+
+    const float sa = c3_scale(p.amax_a), sb = c3_scale(p.amax_w);
+
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, (short)0, (int)0x7fffffff, 0x00020000);
+    // A: quad q = pass * NT + tid -> row q / 8, channel quad q % 8 of the 32-deep k-tile
+    unsigned a_goff[NPA];
+    int a_lds[NPA];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        const int q = i * NT + tid;
+        const int row = q >> 3, cq = q & 7;
+        const long long off = ((long long)(m0 + row) * p.lda + 4 * cq) * 4;
+        a_goff[i] = (m0 + row < p.M && off < 0x7fffffffLL - 4 * p.K) ? (unsigned)off : OOB;
+        a_lds[i] = row * 128 + ((((cq >> 1) * 2) ^ ((row >> 1) & 7)) << 4) + (cq & 1) * 8;
+    }
+    // W: unit U = pass * NT + tid -> row n = U / 8, LDS position U % 8 holds source unit j = pos ^ ((n >> 1) & 7)
+    const unsigned char* b_src[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int U = (i * NT + tid) % (BN * 8);
+        const int n = U >> 3, j = (U & 7) ^ ((n >> 1) & 7);
+        b_src[i] = p.w + ((long long)(n0 + n) * (p.K >> 3)) * 32 + j * 16;          // + (k / 8) * 32 per k-tile
+    }
+    // operand fetch offsets [k-step][plane][block]: rows wm * 32 TM + 32 i + l31 of A, wn * 32 TN + 32 jj + l31 of W
+    int a_rd[2][2][TM], b_rd[2][2][TN];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm * (32 * TM) + 32 * i + l31;
+                a_rd[s][pl][i] = r * 128 + (((((2 * s + lhi) * 2) + pl) ^ ((r >> 1) & 7)) << 4);
+            }
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) {
+                const int n = wn * (32 * TN) + 32 * jj + l31;
+                b_rd[s][pl][jj] = n * 128 + (((((2 * s + lhi) * 2) + pl) ^ ((n >> 1) & 7)) << 4);
+            }
+        }
+
+    float4 areg[NPA];
+    auto load_A = [&](int k0) {                         // global -> registers: columns [k0, k0 + 32) of the tile's rows
+        const unsigned add = (unsigned)k0 * 4u;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) areg[i] = c3_bload4(rA, a_goff[i] == OOB ? OOB : a_goff[i] + add);
+    };
+    auto store_A = [&](unsigned char* dst) {            // registers -> two fp16 planes in LDS
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            unsigned h0, l0, h1, l1;
+            c3_split2h(areg[i].x, areg[i].y, sa, h0, l0);
+            c3_split2h(areg[i].z, areg[i].w, sa, h1, l1);
+            *reinterpret_cast<uint2*>(dst + a_lds[i]) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(dst + (a_lds[i] ^ 16)) = make_uint2(l0, l1);
+        }
+    };
+    auto issue_B = [&](int k0, unsigned char* dst) {    // LDS-DMA: weight rows [n0, n0 + BN) x k [k0, k0 + 32)
+#pragma unroll
+        for (int i = 0; i < NPB; ++i)
+            if ((i + 1) * NT <= BN * 8 || i * NT + tid < BN * 8)                    // (wave-uniform: BN * 8 is a multiple of 64)
+                c3_glds16(b_src[i] + (long long)(k0 >> 3) * 32, dst + (i * NT + tid) * 16);
+    };
+
+    floatx16 acc[TM][TN], acc1[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
+
+    const int nk = p.K >> 5;
+    // prologue: k-tiles 0 and 1 of A converted into stages 0 and 1, the weights of k-tile 0 in flight into B stage 0
+    unsigned char* As0 = smem;                          // the stage multiplied in this iteration
+    unsigned char* As1 = smem + A_ST;                   // complete, multiplied next
+    unsigned char* As2 = smem + 2 * A_ST;               // written at the end of this iteration
+    load_A(0);
+    issue_B(0, Bbuf);
+    store_A(As0);
+    if (nk > 1) { load_A(32); store_A(As1); }
+    c3_dma_wait();
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        // k-tile kt: A in stage As0, W in B stage kt & 1.  Requests of this iteration: W of kt + 1 (read after the barrier below),
+        // A of kt + 2 (converted at the end of this iteration into the stage that was multiplied in iteration kt - 1)
+        if (kt + 1 < nk) issue_B((kt + 1) * 32, Bbuf + ((kt + 1) & 1) * B_ST);
+        if (kt + 2 < nk) load_A((kt + 2) * 32);
+        const unsigned char* Bs = Bbuf + (kt & 1) * B_ST;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 av[2][TM], bv[2][TN];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    av[pl][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(As0 + a_rd[s][pl][i]));
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj)
+                    bv[pl][jj] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(Bs + b_rd[s][pl][jj]));
+            }
+#define RIH_RW_TERM(ACC_, PA_, PB_)                                                                               \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int jj = 0; jj < TN; ++jj) ACC_[i][jj] = \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(av[PA_][i], bv[PB_][jj], ACC_[i][jj], 0, 0, 0);
+            RIH_RW_TERM(acc1, 1, 0)
+            RIH_RW_TERM(acc, 0, 0)
+            RIH_RW_TERM(acc1, 0, 1)
+#undef RIH_RW_TERM
+        }
+        if (kt + 2 < nk) store_A(As2);
+        c3_dma_wait();                                  // the LDS-DMA of this iteration has landed before the barrier publishes it
+        __syncthreads();
+        unsigned char* const t = As0;
+        As0 = As1; As1 = As2; As2 = t;
+    }
+
+    // ---------------------------------------------------------------- epilogue (the loop ended with a barrier: LDS is free)
+    float* stg = reinterpret_cast<float*>(smem) + wave * (32 * SLD);
+    const float inv_a = 1.f / sa, inv_b = 1.f / sb;
+    const int mbase = m0 + wm * (32 * TM), nbase = n0 + wn * (32 * TN);
+    float4 ssh[STATS ? TN : 1], ssum[STATS ? TN : 1], ssq[STATS ? TN : 1];
+    float scnt[STATS ? TN : 1];
+    if (STATS) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            ssh[j] = make_float4(0, 0, 0, 0); ssum[j] = make_float4(0, 0, 0, 0); ssq[j] = make_float4(0, 0, 0, 0); scnt[j] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float4 rv[RES ? 4 : 1];
+            if (RES) {                                  // the block's residual, requested before the staging round trip
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    rv[q] = *reinterpret_cast<const float4*>(p.r + (long long)(mbase + i * 32 + (lane >> 3) + 8 * q) * p.ldr + nbase +
+                                                             j * 32 + (lane & 7) * 4);
+            }
+            if (i + j > 0) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stg[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + l31] = fmaf(acc1[i][j][r], 0x1p-11f, acc[i][j][r]) * inv_a * inv_b;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = (lane >> 3) + 8 * q, c4 = (lane & 7) * 4;
+                float4 v = *reinterpret_cast<const float4*>(stg + row * SLD + c4);
+                if (RES) { v.x += rv[q].x; v.y += rv[q].y; v.z += rv[q].z; v.w += rv[q].w; }
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(p.c + (long long)(mbase + i * 32 + row) * p.ldc + nbase + j * 32 + c4) = v;
+                if (STATS) {
+                    if (scnt[j] == 0.f) ssh[j] = v;
+                    scnt[j] += 1.f;
+                    const float dx = v.x - ssh[j].x, dy = v.y - ssh[j].y, dz = v.z - ssh[j].z, dw = v.w - ssh[j].w;
+                    ssum[j].x += dx; ssum[j].y += dy; ssum[j].z += dz; ssum[j].w += dw;
+                    ssq[j].x += dx * dx; ssq[j].y += dy * dy; ssq[j].z += dz * dz; ssq[j].w += dw * dw;
+                }
+            }
+        }
+    }
+    if (STATS) {
+        const long long rblk = mbase / (32 * TM);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float n = scnt[j];
+            const float in = n > 0.f ? 1.f / n : 0.f;
+            float4 mean = make_float4(ssh[j].x + ssum[j].x * in, ssh[j].y + ssum[j].y * in, ssh[j].z + ssum[j].z * in,
+                                      ssh[j].w + ssum[j].w * in);
+            float4 m2 = make_float4(ssq[j].x - ssum[j].x * ssum[j].x * in, ssq[j].y - ssum[j].y * ssum[j].y * in,
+                                    ssq[j].z - ssum[j].z * ssum[j].z * in, ssq[j].w - ssum[j].w * ssum[j].w * in);
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                const float nbr = __shfl_xor(n, o, 64);
+                const float nt = n + nbr;
+                const float wb = nt > 0.f ? nbr / nt : 0.f;
+                const float cf = n * wb;
+#define RIH_RW_MERGE(c_)                                                              \
+    {                                                                                 \
+        const float mb = __shfl_xor(mean.c_, o, 64), qb = __shfl_xor(m2.c_, o, 64);   \
+        const float dl = mb - mean.c_;                                                \
+        mean.c_ += dl * wb;                                                           \
+        m2.c_ += qb + dl * dl * cf;                                                   \
+    }
+                RIH_RW_MERGE(x) RIH_RW_MERGE(y) RIH_RW_MERGE(z) RIH_RW_MERGE(w)
+#undef RIH_RW_MERGE
+                n = nt;
+            }
+            if ((lane >> 3) == 0) {
+                const int nn = nbase + j * 32 + (lane & 7) * 4;
+                *reinterpret_cast<float4*>(p.stats + (rblk * 2 + 0) * p.N + nn) = mean;
+                *reinterpret_cast<float4*>(p.stats + (rblk * 2 + 1) * p.N + nn) = m2;
+            }
+        }
+    }
+}
+
+// tile of a rows launch: the largest of 256 x 128, 128 x 128 (256 x 64 for N = 64), 128 x 64 that still gives every CU a workgroup
+void rows_tile(const rih_panel_desc* d, int& bm, int& bn) {
+    const bool n128 = d->N % 128 == 0, m256 = d->M % 256 == 0;
+    const auto wgs = [&](int m, int n) { return (long long)(d->M / m) * (d->N / n); };
+    if (n128 && m256 && wgs(256, 128) >= 256) { bm = 256; bn = 128; return; }
+    if (n128 && wgs(128, 128) >= 256) { bm = 128; bn = 128; return; }
+    if (m256 && wgs(256, 64) >= 256) { bm = 256; bn = 64; return; }
+    if (wgs(128, 64) >= 256 || !n128) { bm = 128; bn = 64; return; }
+    bm = 128; bn = 128;         // a small problem: fewer, larger tiles (the caller's planning decides whether it comes here at all)
+}
+bool rows_ok(const rih_panel_desc* d) {
+    if (!d || !d->a || !d->w_h2 || !d->c || !d->amax_a || !d->amax_w) return false;
+    if (d->K < 64 || d->K % 32 != 0 || d->N < 64 || d->N % 64 != 0 || d->M < 128 || d->M % 128 != 0) return false;
+    if (d->lda < d->K || d->lda % 4 != 0 || d->ldc < d->N || d->ldc % 4 != 0) return false;
+    if (d->r != nullptr && (d->ldr < d->N || d->ldr % 4 != 0)) return false;
+    if ((((uintptr_t)d->a | (uintptr_t)d->w_h2 | (uintptr_t)d->c | (uintptr_t)d->r | (uintptr_t)d->stats) % 16) != 0) return false;
+    if ((long long)d->M * d->lda * 4 >= (1ll << 31)) return false;     // 31-bit byte offsets into A
+    return true;
+}
+
+template <int BM, int BN>
+void rows_launch(const RowsArgs& a, unsigned grid, bool stats, bool res, hipStream_t s) {
+    if (stats && !res) hipLaunchKernelGGL((rows_kernel<BM, BN, true, false>), dim3(grid), dim3(NT), 0, s, a);
+    else if (!stats && res) hipLaunchKernelGGL((rows_kernel<BM, BN, false, true>), dim3(grid), dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((rows_kernel<BM, BN, false, false>), dim3(grid), dim3(NT), 0, s, a);
+}
+
 // patch width: 32 when the map allows it (one image row per 32-row block), else 16 (two rows per block); 0: not a shape of this kernel
 int c3_tw(const rih_conv3_desc* d) {
     if (d->H % 8 == 0 && d->W % 32 == 0) return 32;
@@ -778,6 +1066,37 @@ extern "C" int rih_panel(const rih_panel_desc* d, void* stream) {
     } else {
         panel_launch<4, 128>(a, grid, st, rs, s);
     }
+    return (int)hipGetLastError();
+}
+
+extern "C" int rih_rows_ok(const rih_panel_desc* d) { return rows_ok(d) && !(d->stats && d->r) ? 1 : 0; }
+
+/* rows per BatchNorm statistics block of rih_rows for this descriptor (64 with 256-row tiles, 32 with 128-row tiles), 0: not a
+ * shape of the kernel */
+extern "C" int rih_rows_stats_rows(const rih_panel_desc* d) {
+    if (!rows_ok(d)) return 0;
+    int bm, bn;
+    rows_tile(d, bm, bn);
+    return bm / 4;
+}
+
+extern "C" int rih_rows(const rih_panel_desc* d, void* stream) {
+    if (!rows_ok(d) || (d->stats && d->r)) return RIH_EINVAL;
+    RowsArgs a;
+    a.a = d->a; a.w = (const unsigned char*)d->w_h2; a.c = d->c; a.r = d->r; a.stats = d->stats;
+    a.amax_a = d->amax_a; a.amax_w = d->amax_w;
+    a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr; a.relu = d->relu ? 1 : 0;
+    int bm, bn;
+    rows_tile(d, bm, bn);
+    a.nblk = d->N / bn;
+    a.mtiles = d->M / bm;
+    const unsigned grid = (unsigned)((long long)a.mtiles * a.nblk);
+    hipStream_t s = (hipStream_t)stream;
+    const bool st = d->stats != nullptr, rs = d->r != nullptr;
+    if (bm == 256 && bn == 128) rows_launch<256, 128>(a, grid, st, rs, s);
+    else if (bm == 128 && bn == 128) rows_launch<128, 128>(a, grid, st, rs, s);
+    else if (bm == 256) rows_launch<256, 64>(a, grid, st, rs, s);
+    else rows_launch<128, 64>(a, grid, st, rs, s);
     return (int)hipGetLastError();
 }
 

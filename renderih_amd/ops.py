@@ -794,13 +794,15 @@ def _h2_launch(items):
     """items: [(weight, planes tensor, (Cout, Cin, KH, KW, CinPad, for_dgrad, Kpad)), ...] -> rih_h2_multi."""
     from ._lib import H2Desc
     arr = (H2Desc * len(items))()
-    for d, (w, dst, f) in zip(arr, items):
-        d.w, d.dst, d.amax = w.data_ptr(), dst.data_ptr(), bound_of(w).data_ptr()
+    for d, (w, dst, f, *bound) in zip(arr, items):
+        # the planes are scaled with ONE bound block, and that block is what the consuming kernel un-scales with: a caller that has
+        # already resolved the weight's bound hands it in (outside owned_bounds() a Parameter is re-measured by every bound_of)
+        d.w, d.dst, d.amax = w.data_ptr(), dst.data_ptr(), (bound[0] if bound and bound[0] is not None else bound_of(w)).data_ptr()
         (d.Cout, d.Cin, d.KH, d.KW, d.CinPad, d.for_dgrad, d.Kpad) = f
     check(_L().rih_h2_multi(arr, len(items), _stream()), 'rih_h2_multi')
 
 
-def _h2_weight(w, Cx, for_dgrad):
+def _h2_weight(w, Cx, for_dgrad, bound=None):
     """H2 planes ([N][Kpad / 8][2][8] fp16 as a float32 tensor [N][Kpad]) of an OIHW weight: forward operand (N = Cout,
     k = (tap, ci < Cx)) or flipped data-gradient operand (N = Cx, k = (tap, co)); scaled by bound_of(w).  Through ops._PACK when
     one is installed (TrainStep: every H2 operand of the step in one launch at its start)."""
@@ -822,7 +824,7 @@ def _h2_weight(w, Cx, for_dgrad):
             planes = e[1]
     else:
         planes = torch.empty((Nn, Kp), device=w.device, dtype=torch.float32)
-    _h2_launch([(w, planes, f)])
+    _h2_launch([(w, planes, f, bound)])
     return planes, Kp
 
 
@@ -839,16 +841,22 @@ def _halo3_ok(x, Cch, Nout, KH, KW, stride, pad, bias=None, residual=None):
 def conv3x3_halo(x, w, y, for_dgrad, relu=False, stats=None, bx=None, bw=None):
     """Enqueue rih_conv3x3: y = act(conv3x3(x, w)) (for_dgrad False; x [N,H,W,Cin], y [N,H,W,Cout]) or the data gradient
     y = conv3x3(x = dy, flipped w) (for_dgrad True; x [N,H,W,Cout], y [N,H,W,Cin]).  stats: a StatsHolder, filled.  bx / bw: bound
-    thunks (LazyBound) of x and w."""
+    thunks (LazyBound) of x and w.  Returns False (nothing enqueued) when the library refuses the descriptor (rih_conv3x3_ok)."""
     from ._lib import Conv3Desc
     N, H, W_, Cch = x.shape
     Nout = y.shape[-1]
-    planes, Kp = _h2_weight(w, (Cch if not for_dgrad else Nout), for_dgrad)
     d = Conv3Desc()
-    d.x, d.w_h2, d.y = x.data_ptr(), planes.data_ptr(), y.data_ptr()
+    d.x, d.y = x.data_ptr(), y.data_ptr()
+    d.imgs, d.H, d.W, d.C, d.N, d.ldx, d.ldy, d.Kpad, d.relu = N, H, W_, Cch, Nout, Cch, Nout, 9 * Cch, 1 if relu else 0
+    d.w_h2 = d.amax_x = d.amax_w = x.data_ptr()         # (placeholders for the library's own precondition check)
+    if int(_L().rih_conv3x3_ok(C.byref(d))) != 1:       # e.g. an output view that is not 16-byte aligned: the caller takes rih_gemm
+        return False
+    bwv = bw() if callable(bw) else bw      # ONE bound block of w: the planes are scaled with it and the kernel un-scales with it
+    planes, Kp = _h2_weight(w, (Cch if not for_dgrad else Nout), for_dgrad, bound=bwv)
+    assert Kp == 9 * Cch
+    d.w_h2 = planes.data_ptr()
     d.amax_x = (bx() if callable(bx) else bx).data_ptr()
-    d.amax_w = (bw() if callable(bw) else bw).data_ptr()
-    d.imgs, d.H, d.W, d.C, d.N, d.ldx, d.ldy, d.Kpad, d.relu = N, H, W_, Cch, Nout, Cch, Nout, Kp, 1 if relu else 0
+    d.amax_w = bwv.data_ptr()
     if stats is not None and stats.part is None:
         stats.rows = int(_L().rih_conv3x3_stats_rows(C.byref(d)))
         assert stats.rows > 0
@@ -862,8 +870,9 @@ def conv3x3_halo(x, w, y, for_dgrad, relu=False, stats=None, bx=None, bw=None):
         check(_L().rih_conv3x3(C.byref(d), _stream()), 'rih_conv3x3')
         e1.record()
         PROFILE.append((flops, e0, e1, (N * H * W_, Nout, 9 * Cch, 1, 0, 3, 50, 1, 2)))
-        return
+        return True
     check(_L().rih_conv3x3(C.byref(d), _stream()), 'rih_conv3x3')
+    return True
 
 
 # --------------------------------------------------------------------------------------------- short-K streaming GEMM
@@ -887,16 +896,22 @@ def _panel_ok(a2d_rows, K, N, lda, a, bias=None):
 
 def panel_gemm(a, w, c, M, N, K, lda, ldc, for_dgrad, relu=False, stats=None, R=None, ldr=0, ba=None, bw=None):
     """Enqueue rih_panel: c[M][N] = act(a[M][K] W^T (+ R)) with W = the OIHW 1x1 weight `w` as forward (n = co, k = ci) or
-    data-gradient (n = ci, k = co) H2 operand.  stats: a StatsHolder, filled.  ba / bw: bound thunks of a and w."""
+    data-gradient (n = ci, k = co) H2 operand.  stats: a StatsHolder, filled.  ba / bw: bound thunks of a and w.  Returns False
+    (nothing enqueued) when the library refuses the descriptor (rih_panel_ok)."""
     from ._lib import PanelDesc
     Cout, Cin = w.shape[0], w.shape[1]
-    planes, Kp = _h2_weight(w, Cin, for_dgrad)
-    assert Kp == K and (N, K) == ((Cin, Cout) if for_dgrad else (Cout, Cin))
     d = PanelDesc()
-    d.a, d.w_h2, d.c, d.r = a.data_ptr(), planes.data_ptr(), c.data_ptr(), _p(R)
-    d.amax_a = (ba() if callable(ba) else ba).data_ptr()
-    d.amax_w = (bw() if callable(bw) else bw).data_ptr()
+    d.a, d.c, d.r = a.data_ptr(), c.data_ptr(), _p(R)
     d.M, d.N, d.K, d.lda, d.ldc, d.ldr, d.relu = M, N, K, lda, ldc, ldr, 1 if relu else 0
+    d.w_h2 = d.amax_a = d.amax_w = a.data_ptr()         # (placeholders for the library's own precondition check)
+    if int(_L().rih_panel_ok(C.byref(d))) != 1:         # e.g. a dskip view that is not 16-byte aligned: the caller takes rih_gemm
+        return False
+    bwv = bw() if callable(bw) else bw
+    planes, Kp = _h2_weight(w, Cin, for_dgrad, bound=bwv)
+    assert Kp == K and (N, K) == ((Cin, Cout) if for_dgrad else (Cout, Cin))
+    d.w_h2 = planes.data_ptr()
+    d.amax_a = (ba() if callable(ba) else ba).data_ptr()
+    d.amax_w = bwv.data_ptr()
     if stats is not None and stats.part is None and R is None:
         stats.rows = int(_L().rih_panel_stats_rows(C.byref(d)))
         assert stats.rows > 0
@@ -909,8 +924,65 @@ def panel_gemm(a, w, c, M, N, K, lda, ldc, for_dgrad, relu=False, stats=None, R=
         check(_L().rih_panel(C.byref(d), _stream()), 'rih_panel')
         e1.record()
         PROFILE.append((2.0 * M * N * K, e0, e1, (M, N, K, 1, 0, 3, 51, 1, 2)))
-        return
+        return True
     check(_L().rih_panel(C.byref(d), _stream()), 'rih_panel')
+    return True
+
+
+# --------------------------------------------------------------------------------------------- long-K plain-row GEMM
+# csrc/rih_conv3.hip rows_kernel (round 6): the 1x1 convolutions with K >= ROWS_MINK on plain rows (Bottleneck.conv1 / conv3 of layer1-4
+# forward, their data gradients) as 512-thread workgroups on up to 256 x 128 tiles with the H2 weight planes staged by LDS-DMA and three
+# A stages.  RIH_ROWS=0: rih_gemm's tiled kernels.  RIH_ROWS_MINK: smallest reduction that goes there (shorter ones: rih_panel / tiled).
+ROWS = os.environ.get('RIH_ROWS', '1') == '1'
+ROWS_MINK = int(os.environ.get('RIH_ROWS_MINK', '256'))
+ROWS_MIN_WGS = int(os.environ.get('RIH_ROWS_MIN_WGS', '128'))
+
+
+def _rows_ok(a2d_rows, K, N, lda, a, bias=None, c=None, R=None):
+    """Launches rih_rows takes and that are worth it: engine 2, K >= ROWS_MINK in whole 32-deep tiles, N % 64, whole 128-row tiles, at
+    least ROWS_MIN_WGS workgroups of the smallest tile; the library re-checks (rih_rows_ok) before the launch."""
+    if not (ROWS and ENGINE == 2) or bias is not None or K < ROWS_MINK or K % 32 != 0 or N % 64 != 0 or a2d_rows % 128 != 0:
+        return False
+    if lda % 4 != 0 or a.data_ptr() % 16 != 0 or 4 * a2d_rows * lda >= (1 << 31):
+        return False
+    if (c is not None and c.data_ptr() % 16 != 0) or (R is not None and R.data_ptr() % 16 != 0):
+        return False
+    return (a2d_rows // 128) * (N // 64) >= ROWS_MIN_WGS
+
+
+def rows_gemm(a, w, c, M, N, K, lda, ldc, for_dgrad, relu=False, stats=None, R=None, ldr=0, ba=None, bw=None):
+    """Enqueue rih_rows: c[M][N] = act(a[M][K] W^T (+ R)) with W = the OIHW 1x1 weight `w` as forward (n = co, k = ci) or
+    data-gradient (n = ci, k = co) H2 operand.  stats: a StatsHolder, filled.  ba / bw: bound thunks of a and w.  Returns False
+    (nothing enqueued) when the library refuses the descriptor: the caller then takes rih_gemm."""
+    from ._lib import PanelDesc
+    Cout, Cin = w.shape[0], w.shape[1]
+    d = PanelDesc()
+    d.a, d.c, d.r = a.data_ptr(), c.data_ptr(), _p(R)
+    d.M, d.N, d.K, d.lda, d.ldc, d.ldr, d.relu = M, N, K, lda, ldc, ldr, 1 if relu else 0
+    d.w_h2 = d.amax_a = d.amax_w = a.data_ptr()         # (placeholders for the library's own precondition check)
+    if int(_L().rih_rows_ok(C.byref(d))) != 1:
+        return False
+    bwv = bw() if callable(bw) else bw                  # ONE bound block of w: the planes are scaled with it and the kernel unscales with it
+    planes, Kp = _h2_weight(w, Cin, for_dgrad, bound=bwv)
+    assert Kp == K and (N, K) == ((Cin, Cout) if for_dgrad else (Cout, Cin))
+    d.w_h2 = planes.data_ptr()
+    d.amax_a = (ba() if callable(ba) else ba).data_ptr()
+    d.amax_w = bwv.data_ptr()
+    if stats is not None and stats.part is None and R is None:
+        stats.rows = int(_L().rih_rows_stats_rows(C.byref(d)))
+        assert stats.rows > 0
+        stats.T = M // stats.rows
+        stats.part = torch.empty((stats.T, 2, N), device=a.device, dtype=torch.float32)
+        d.stats = stats.part.data_ptr()
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_L().rih_rows(C.byref(d), _stream()), 'rih_rows')
+        e1.record()
+        PROFILE.append((2.0 * M * N * K, e0, e1, (M, N, K, 1, 0, 3, 52, 1, 2)))
+        return True
+    check(_L().rih_rows(C.byref(d), _stream()), 'rih_rows')
+    return True
 
 
 class Conv2dFn(torch.autograd.Function):
@@ -934,10 +1006,16 @@ class Conv2dFn(torch.autograd.Function):
         geom = (H, W_, Cx, Ho, Wo, KH, KW, stride, 1, pad, pad)
         # engine 2: operand bounds (kept for the backward: x is the weight gradient's A operand, w the data gradient's B)
         bx, bw = (LazyBound(x), LazyBound(w)) if ENGINE == 2 else (None, None)
-        if Cx == Cin and _halo3_ok(x, Cx, Cout, KH, KW, stride, pad, bias):
-            conv3x3_halo(x, w, y, False, relu=relu, stats=stats, bx=bx, bw=bw)
-        elif KH * KW == 1 and Cx == Cin and stride == 1 and pad == 0 and _panel_ok(M, Cin, Cout, Cx, x, bias):
-            panel_gemm(x, w, y, M, Cout, Cin, Cx, Cout, False, relu=relu, stats=stats, ba=bx, bw=bw)
+        rows1x1 = KH * KW == 1 and Cx == Cin and stride == 1 and pad == 0       # a plain-row GEMM on the stored [Cout][Cin] weight
+        if (Cx == Cin and _halo3_ok(x, Cx, Cout, KH, KW, stride, pad, bias)
+                and conv3x3_halo(x, w, y, False, relu=relu, stats=stats, bx=bx, bw=bw)):
+            pass
+        elif (rows1x1 and _panel_ok(M, Cin, Cout, Cx, x, bias)
+              and panel_gemm(x, w, y, M, Cout, Cin, Cx, Cout, False, relu=relu, stats=stats, ba=bx, bw=bw)):
+            pass
+        elif (rows1x1 and _rows_ok(M, Cin, Cout, Cx, x, bias)
+              and rows_gemm(x, w, y, M, Cout, Cin, Cx, Cout, False, relu=relu, stats=stats, ba=bx, bw=bw)):
+            pass
         elif KH * KW == 1 and Cx == Cin:
             gemm(x, w, y, M, Cout, K, Cx, Cin, Cout, a_mode=0, b_mode=1, bias=bias, relu=relu, geom=geom, stats=stats,
                  amax_a=bx, amax_b=bw)
@@ -1004,10 +1082,16 @@ class Conv2dFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             Mx = N * H * W_
             geom = (Ho, Wo, Cout, H, W_, KH, KW, 1, stride, KH - 1 - pad, KW - 1 - pad)
-            if Cx == Cin and _halo3_ok(dy, Cout, Cx, KH, KW, stride, pad, None, dskip):
-                conv3x3_halo(dy, w, dx, True, bx=bdy, bw=bw)
-            elif KH * KW == 1 and Cx == Cin and stride == 1 and pad == 0 and _panel_ok(Mx, Cout, Cin, Cout, dy):
-                panel_gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cx, True, R=dskip, ldr=Cx, ba=bdy, bw=bw)
+            rows1x1 = KH * KW == 1 and Cx == Cin and stride == 1 and pad == 0
+            if (Cx == Cin and _halo3_ok(dy, Cout, Cx, KH, KW, stride, pad, None, dskip)
+                    and conv3x3_halo(dy, w, dx, True, bx=bdy, bw=bw)):
+                pass
+            elif (rows1x1 and _panel_ok(Mx, Cout, Cin, Cout, dy)
+                  and panel_gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cx, True, R=dskip, ldr=Cx, ba=bdy, bw=bw)):
+                pass
+            elif (rows1x1 and _rows_ok(Mx, Cout, Cin, Cout, dy)
+                  and rows_gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cx, True, R=dskip, ldr=Cx, ba=bdy, bw=bw)):
+                pass
             elif KH * KW == 1 and Cx == Cin:
                 gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cin, Cx, a_mode=0, b_mode=0, geom=geom, R=dskip, ldr=Cx,
                      amax_a=bdy, amax_b=bw)

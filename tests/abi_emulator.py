@@ -463,6 +463,44 @@ class EmulatedLib:
         d = dref._obj
         if not self._panel_ok(d):
             return -1
+        return self._panel_like(d, self.rih_panel_stats_rows)
+
+    # ------------------------------------------------------------------ long-K plain-row GEMM (csrc/rih_conv3.hip rows_kernel)
+    @staticmethod
+    def _rows_ok(d):
+        return bool(d.a and d.w_h2 and d.c and d.amax_a and d.amax_w and d.K >= 64 and d.K % 32 == 0 and d.N >= 64 and d.N % 64 == 0
+                    and d.M >= 128 and d.M % 128 == 0 and d.lda >= d.K and d.lda % 4 == 0 and d.ldc >= d.N and d.ldc % 4 == 0
+                    and (not d.r or (d.ldr >= d.N and d.ldr % 4 == 0)) and 4 * d.M * d.lda < (1 << 31)
+                    and all(int(x or 0) % 16 == 0 for x in (d.a, d.w_h2, d.c, d.r, d.stats)) and not (d.stats and d.r))
+
+    @staticmethod
+    def _rows_tile(d):
+        n128, m256 = d.N % 128 == 0, d.M % 256 == 0
+        wgs = lambda m, n: (d.M // m) * (d.N // n)
+        if n128 and m256 and wgs(256, 128) >= 256:
+            return 256, 128
+        if n128 and wgs(128, 128) >= 256:
+            return 128, 128
+        if m256 and wgs(256, 64) >= 256:
+            return 256, 64
+        if wgs(128, 64) >= 256 or not n128:
+            return 128, 64
+        return 128, 128
+
+    def rih_rows_ok(self, dref):
+        return 1 if self._rows_ok(dref._obj if hasattr(dref, '_obj') else dref) else 0
+
+    def rih_rows_stats_rows(self, dref):
+        d = dref._obj if hasattr(dref, '_obj') else dref
+        return self._rows_tile(d)[0] // 4 if self._rows_ok(d) else 0
+
+    def rih_rows(self, dref, stream):
+        d = dref._obj
+        if not self._rows_ok(d):
+            return -1
+        return self._panel_like(d, self.rih_rows_stats_rows)
+
+    def _panel_like(self, d, stats_rows):
         sw = self._e2_scale(d.amax_w)
         pl = np.ctypeslib.as_array((C.c_uint16 * (2 * d.N * d.K)).from_address(int(d.w_h2))).reshape(d.N, d.K // 8, 2, 8)
         hi = pl[:, :, 0, :].reshape(d.N, d.K).view(np.float16).astype(np.float32)
@@ -476,7 +514,7 @@ class EmulatedLib:
             y = np.maximum(y, 0)
         np.lib.stride_tricks.as_strided(_f(d.c, (d.M - 1) * d.ldc + d.N), (d.M, d.N), (4 * d.ldc, 4))[...] = y
         if d.stats:
-            rows = self.rih_panel_stats_rows(d)
+            rows = stats_rows(d)
             T = d.M // rows
             st = _f(d.stats, T * 2 * d.N).reshape(T, 2, d.N)
             blk = y.reshape(T, rows, d.N)

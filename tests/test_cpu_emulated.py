@@ -152,6 +152,14 @@ def test_panel_host_logic():
     G.test_panel_1x1((1, 16, 8, 64, 64, False, True))
 
 
+def test_rows_host_logic(monkeypatch):
+    """ops.rows_gemm on the emulated ABI: dispatch from Conv2dFn (forward and data gradient with the skip residual), H2 operands,
+    statistics blocks of 32 / 64 rows, the library-side precondition check with its rih_gemm fallback."""
+    G.test_rows_1x1((2, 16, 16, 256, 64, False, True))
+    G.test_rows_1x1((1, 16, 8, 96, 128, True, True))
+    G.test_rows_kernel_is_taken_and_falls_back(monkeypatch)
+
+
 def test_conv1x1_cat_host_logic():
     """ops.conv1x1_cat on the emulated ABI: segment descriptors, per-part data gradients, column-slice weight gradients."""
     for eng in (1, 2):

@@ -82,6 +82,14 @@ def test_panel_kernels(case):
     G.test_panel_1x1(case)
 
 
+@pytest.mark.parametrize('case', [(2, 16, 16, 256, 64, False, True), (1, 16, 8, 96, 128, True, True), (1, 8, 16, 64, 256, False, True),
+                                  (3, 16, 8, 160, 320, True, False)])
+def test_rows_kernels(case):
+    """csrc/rih_conv3.hip rows_kernel on the host harness: LDS-DMA-staged weight planes on two stages, three A stages rotating,
+    tiles 128 x 64 / 128 x 128 / 256 x 64, one to eight k-tiles, residual and statistics epilogues."""
+    G.test_rows_1x1(case)
+
+
 def test_conv3_lds_image_is_conflict_free():
     """The LDS images of csrc/rih_conv3.hip: a pixel / weight row = 8 units of 16 bytes at position j ^ ((index >> 1) & 7).  A
     ds_read_b128 is served in 16-lane groups (MI355X_MICROARCH.md, LDS table); within a group every lane must hit its own 16-byte
