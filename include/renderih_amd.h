@@ -274,6 +274,13 @@ int rih_panel(const rih_panel_desc* d, void* stream);
  * with the weights staged by LDS-DMA and three A stages in LDS.  Preconditions (rih_rows_ok returns 1): K % 32 == 0, K >= 64,
  * N % 64 == 0, M % 128 == 0, pitches % 4 == 0, 16-byte aligned operands, M * lda * 4 < 2^31, not both stats and r.
  * stats (optional): [M / rows][2][N] per block of rows = rih_rows_stats_rows(desc) consecutive rows (64 or 32). */
+/* The stem convolution (ABI 18): 7 x 7 / stride 2 / padding 3 over a FOUR-channel NHWC image batch (encoder.resnet.conv1 of
+ * torchvision ResNet-50 via models/encoder.py:107-116, on the 3 -> 4 channel padded input of rih_nchw_to_nhwc) on the rows kernel with
+ * an im2col loader (one tap of one output pixel = one float4).  Descriptor = rih_conv3_desc: x [imgs][H][W][4] (C = ldx = 4), w_h2 =
+ * H2 planes of the OIHW weight with CinPad 4 (rih_h2_desc: KH = KW = 7, Kpad = 224), y [imgs][H/2][W/2][ldy], N = 64, stats per 64
+ * rows.  Preconditions (rih_stem_ok returns 1): H, W even, imgs * H/2 * W/2 % 256 == 0, the image batch < 2 GiB, 16-byte aligned. */
+int rih_stem_ok(const rih_conv3_desc* d);
+int rih_stem(const rih_conv3_desc* d, void* stream);
 int rih_rows_ok(const rih_panel_desc* d);
 int rih_rows_stats_rows(const rih_panel_desc* d);
 int rih_rows(const rih_panel_desc* d, void* stream);

@@ -119,6 +119,8 @@ SIGNATURES = {
     'rih_panel_ok': (c_i, [C.POINTER(PanelDesc)]),
     'rih_panel_stats_rows': (c_i, [C.POINTER(PanelDesc)]),
     'rih_panel': (c_i, [C.POINTER(PanelDesc), C.c_void_p]),
+    'rih_stem_ok': (c_i, [C.POINTER(Conv3Desc)]),
+    'rih_stem': (c_i, [C.POINTER(Conv3Desc), C.c_void_p]),
     'rih_rows_ok': (c_i, [C.POINTER(PanelDesc)]),
     'rih_rows_stats_rows': (c_i, [C.POINTER(PanelDesc)]),
     'rih_rows': (c_i, [C.POINTER(PanelDesc), C.c_void_p]),

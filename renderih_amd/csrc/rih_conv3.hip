@@ -99,6 +99,24 @@ __device__ __forceinline__ void c3_split2h(float a, float b, float s, unsigned& 
 #endif
 }
 
+// c3_split2h pinned in program order (volatile): rows_kernel converts the rows of k-tile j + 1 BEHIND its counted wait -- hoisted
+// into the MFMA phase (where the scheduler likes to put it) the conversion needs those rows at the top of the iteration and the
+// prefetch is one k-tile deep again
+__device__ __forceinline__ void c3_split2h_pinned(float a, float b, float s, unsigned& h, unsigned& l) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float ra, rb;
+    const float k2048 = 2048.f;
+    asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a), "s"(s));
+    asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(b), "s"(s));
+    asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(a), "s"(s), "v"(h));
+    asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(b), "s"(s), "v"(h));
+    asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(l) : "v"(ra), "s"(k2048));
+    asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l) : "v"(rb), "s"(k2048));
+#else
+    c3_split2h(a, b, s, h, l);
+#endif
+}
+
 __device__ __forceinline__ void c3_glds16(const unsigned char* src, unsigned char* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
@@ -113,10 +131,46 @@ __device__ __forceinline__ void c3_dma_wait() {
 #endif
 }
 
+// The same LDS-DMA instruction issued OUTSIDE hipcc's wait-count bookkeeping (rows_kernel): behind the builtin the compiler puts
+// `s_waitcnt vmcnt(0)` in front of the next barrier / LDS read that may alias the destination, which also drains every register
+// load in flight -- a prefetch of A rows two k-tiles ahead would be cut back to one.  Here the kernel waits itself, with a COUNTED
+// c3_vm_wait<N>() (memory operations retire in order: "at most N outstanding" = everything but the N youngest has landed).  The
+// compiler's own waits for register loads stay correct: operations it does not know of can only make its counts conservative.
+__device__ __forceinline__ void c3_glds16_raw(const unsigned char* src, unsigned char* lds_dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned base = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_dst);      // lane 0's address; lane l lands at + 16 l
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(base), "v"(src) : "memory");      // (m0: nothing else in rows_kernel uses it; hipcc rejects it as a clobber)
+#else
+    c3_glds16(src, lds_dst);
+#endif
+}
+template <int N>
+__device__ __forceinline__ void c3_vm_wait() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+
 __device__ __forceinline__ float4 c3_bload4(__amdgpu_buffer_rsrc_t r, unsigned off) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// A 16-byte buffer load outside hipcc's wait-count bookkeeping, like c3_glds16_raw: the destination registers are the kernel's to
+// wait for (c3_vm_wait) before their first use.  `rs` = the four words of a raw buffer resource (base, base_hi, num_records, flags);
+// an offset beyond num_records returns zeros (the hardware range check, as with the builtin).
+typedef float c3_f32x4 __attribute__((ext_vector_type(4)));
+typedef int c3_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 c3_bload4_raw(c3_i32x4 rs, __amdgpu_buffer_rsrc_t r, unsigned off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    c3_f32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(off), "s"(rs) : "memory");
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return c3_bload4(r, off);
+#endif
 }
 
 template <int TW, int BN, bool STATS>
@@ -711,21 +765,27 @@ struct RowsArgs {
     const float* amax_w;
     int M, N, K, lda, ldc, ldr, relu;
     int nblk, mtiles;
+    int H, W, Ho, Wo;           // STEM: the 4-channel input image and the output map
 };
 
-template <int BM, int BN, bool STATS, bool RES>
-__global__ __launch_bounds__(NT, (3 * BM + 2 * BN) * 128 <= 80 * 1024 ? 4 : 2) void rows_kernel(const RowsArgs p) {
+// STEM (rih_stem): the A operand is the im2col of a 7 x 7 / stride 2 / padding 3 convolution over a FOUR-channel NHWC image
+// (encoder.resnet.conv1 on the 3 -> 4 padded input, models/encoder.py:107-116): k = (tap, channel), a 32-deep k-tile = eight taps, and
+// one tap of one output pixel is ONE float4 -- the loader's quad (row, cq) reads the pixel under tap 8 kt + cq of output pixel `row`
+// (zero outside the image, zero for the taps 49..55 that pad K = 196 to 224); everything behind the loader is the rows kernel.
+template <int BM, int BN, bool STATS, bool RES, bool STEM = false>
+__global__ __launch_bounds__(NT, BM == 128 ? 4 : 2) void rows_kernel(const RowsArgs p) {      // (128-row tiles: two workgroups per CU)
     constexpr int WGN = 2, WGM = 4;                     // waves 4 (M) x 2 (N)
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;               // 2 x 2, 1 x 2, 2 x 1, 1 x 1
     static_assert(TM >= 1 && TN >= 1, "wave tile");
     constexpr int A_ST = BM * 128, B_ST = BN * 128;     // bytes per stage: 32-deep k-tile, two fp16 planes
     constexpr int NPA = (BM * 8) / NT;                  // float4 quads of an A k-tile per thread: 4 / 2
-    constexpr int NPB = (BN * 8 + NT - 1) / NT;         // LDS-DMA units of a W k-tile per thread: 2 / 1
-    static_assert((BM * 8) % NT == 0 && (BN * 8) % 64 == 0, "loader geometry");
-    constexpr int SMEM = 3 * A_ST + 2 * B_ST;
+    constexpr int NPB = (BN * 8) / NT;                  // LDS-DMA units of a W k-tile per thread: 2 / 1
+    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "loader geometry: every thread issues the same number of requests");
+    constexpr int SMEM = 2 * A_ST + 3 * B_ST;          // two A stages, three W stages
     static_assert(SMEM >= 8 * 32 * SLD * 4, "epilogue staging fits");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
-    unsigned char* const Bbuf = smem + 3 * A_ST;
+    unsigned char* const Abuf = smem;
+    unsigned char* const Bbuf = smem + 2 * A_ST;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -740,19 +800,28 @@ __global__ __launch_bounds__(NT, (3 * BM + 2 * BN) * 128 <= 80 * 1024 ? 4 : 2) v
     // A: quad q = pass * NT + tid -> row q / 8, channel quad q % 8 of the 32-deep k-tile
     unsigned a_goff[NPA];
     int a_lds[NPA];
+    int s_ih0[STEM ? NPA : 1], s_iw0[STEM ? NPA : 1];   // STEM: input coordinates under tap (0, 0) of the row's output pixel
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
         const int q = i * NT + tid;
         const int row = q >> 3, cq = q & 7;
-        const long long off = ((long long)(m0 + row) * p.lda + 4 * cq) * 4;
-        a_goff[i] = (m0 + row < p.M && off < 0x7fffffffLL - 4 * p.K) ? (unsigned)off : OOB;
+        if (STEM) {
+            const int m = m0 + row, hw = p.Ho * p.Wo;
+            const int img = m / hw, pix = m - img * hw, oh = pix / p.Wo, ow = pix - oh * p.Wo;
+            s_ih0[i] = 2 * oh - 3;
+            s_iw0[i] = 2 * ow - 3;
+            // (wraps for negative coordinates; only used where the coordinates are inside the image)
+            a_goff[i] = (m < p.M) ? (unsigned)((((long long)img * p.H + s_ih0[i]) * p.W + s_iw0[i]) * 16) : OOB;
+        } else {
+            a_goff[i] = (m0 + row < p.M) ? (unsigned)(((long long)(m0 + row) * p.lda + 4 * cq) * 4) : OOB;   // (M * lda * 4 < 2^31)
+        }
         a_lds[i] = row * 128 + ((((cq >> 1) * 2) ^ ((row >> 1) & 7)) << 4) + (cq & 1) * 8;
     }
     // W: unit U = pass * NT + tid -> row n = U / 8, LDS position U % 8 holds source unit j = pos ^ ((n >> 1) & 7)
     const unsigned char* b_src[NPB];
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
-        const int U = (i * NT + tid) % (BN * 8);
+        const int U = i * NT + tid;
         const int n = U >> 3, j = (U & 7) ^ ((n >> 1) & 7);
         b_src[i] = p.w + ((long long)(n0 + n) * (p.K >> 3)) * 32 + j * 16;          // + (k / 8) * 32 per k-tile
     }
@@ -774,27 +843,50 @@ __global__ __launch_bounds__(NT, (3 * BM + 2 * BN) * 128 <= 80 * 1024 ? 4 : 2) v
             }
         }
 
-    float4 areg[NPA];
-    auto load_A = [&](int k0) {                         // global -> registers: columns [k0, k0 + 32) of the tile's rows
-        const unsigned add = (unsigned)k0 * 4u;
+    float4 areg[2][NPA];                                // two k-tiles of A rows in flight / landed (indexed by literal parity below)
+    // Every request of the main loop -- the A rows (buffer loads) and the weights (LDS-DMA) -- is issued through inline assembly,
+    // OUTSIDE hipcc's wait-count bookkeeping, and waited for with counted waits: the compiler's own placement drains vmcnt to 0 in
+    // front of every barrier behind an LDS-DMA and in front of every conversion behind a conditional request, which leaves each
+    // request ONE k-tile of MFMAs to land -- and a round trip to L2 / HBM on this part (0.7-2 us under load) is longer than a
+    // k-tile (0.5-1 us).  Requests past the last k-tile are issued all the same (out-of-range offset: zeros, no memory access; the
+    // weights of the last k-tile again into a free stage), so that the number of requests per iteration is a compile-time constant.
+    const c3_i32x4 rsA = {(int)(unsigned)(uintptr_t)p.a, (int)((unsigned long long)(uintptr_t)p.a >> 32), (int)0x7fffffff, (int)0x00020000};
+#define RIH_RW_LOAD_A(SET_, KT_)                        /* global -> registers: columns [32 KT_, 32 KT_ + 32) of the tile's rows */ \
+    {                                                                                                                        \
+        const bool in_ = (KT_) < nk;                                                                                          \
+        if (STEM) {                                     /* this lane's tap of the k-tile: (kh, kw) = divmod(8 KT_ + cq, 7) */   \
+            const int tap_ = 8 * (KT_) + (tid & 7), kh_ = (tap_ * 37) >> 8, kw_ = tap_ - 7 * kh_;                             \
+            const unsigned add_ = (unsigned)((kh_ * p.W + kw_) * 16);                                                         \
+            unsigned off_[NPA];                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < NPA; ++i) {                                                                \
+                const bool ok_ = in_ && tap_ < 49 && a_goff[i] != OOB && (unsigned)(s_ih0[i] + kh_) < (unsigned)p.H &&        \
+                                 (unsigned)(s_iw0[i] + kw_) < (unsigned)p.W;                                                  \
+                off_[i] = ok_ ? a_goff[i] + add_ : OOB;                                                                       \
+            }                                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < NPA; ++i) areg[SET_][i] = c3_bload4_raw(rsA, rA, off_[i]);                  \
+        } else {                                                                                                             \
+            const unsigned add_ = (unsigned)(KT_) * 128u;                                                                     \
+            unsigned off_[NPA];                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < NPA; ++i) off_[i] = (a_goff[i] == OOB || !in_) ? OOB : a_goff[i] + add_;    \
+            _Pragma("unroll") for (int i = 0; i < NPA; ++i) areg[SET_][i] = c3_bload4_raw(rsA, rA, off_[i]);                  \
+        }                                                                                                                    \
+    }
+#define RIH_RW_STORE_A(SET_, DST_)                      /* registers -> two fp16 planes in LDS */                            \
+    {                                                                                                                        \
+        unsigned char* const dst_ = (DST_);                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NPA; ++i) {                                                                    \
+            unsigned h0, l0, h1, l1;                                                                                         \
+            c3_split2h_pinned(areg[SET_][i].x, areg[SET_][i].y, sa, h0, l0);                                                 \
+            c3_split2h_pinned(areg[SET_][i].z, areg[SET_][i].w, sa, h1, l1);                                                 \
+            *reinterpret_cast<uint2*>(dst_ + a_lds[i]) = make_uint2(h0, h1);                                                 \
+            *reinterpret_cast<uint2*>(dst_ + (a_lds[i] ^ 16)) = make_uint2(l0, l1);                                          \
+        }                                                                                                                    \
+    }
+    const int nk = p.K >> 5;
+    auto issue_B = [&](int kt, unsigned char* dst) {    // LDS-DMA: weight rows [n0, n0 + BN) x k-tile kt (clamped to the last one)
+        const long long ko = (long long)(kt < nk ? kt : nk - 1) * 128;
 #pragma unroll
-        for (int i = 0; i < NPA; ++i) areg[i] = c3_bload4(rA, a_goff[i] == OOB ? OOB : a_goff[i] + add);
-    };
-    auto store_A = [&](unsigned char* dst) {            // registers -> two fp16 planes in LDS
-#pragma unroll
-        for (int i = 0; i < NPA; ++i) {
-            unsigned h0, l0, h1, l1;
-            c3_split2h(areg[i].x, areg[i].y, sa, h0, l0);
-            c3_split2h(areg[i].z, areg[i].w, sa, h1, l1);
-            *reinterpret_cast<uint2*>(dst + a_lds[i]) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(dst + (a_lds[i] ^ 16)) = make_uint2(l0, l1);
-        }
-    };
-    auto issue_B = [&](int k0, unsigned char* dst) {    // LDS-DMA: weight rows [n0, n0 + BN) x k [k0, k0 + 32)
-#pragma unroll
-        for (int i = 0; i < NPB; ++i)
-            if ((i + 1) * NT <= BN * 8 || i * NT + tid < BN * 8)                    // (wave-uniform: BN * 8 is a multiple of 64)
-                c3_glds16(b_src[i] + (long long)(k0 >> 3) * 32, dst + (i * NT + tid) * 16);
+        for (int i = 0; i < NPB; ++i) c3_glds16_raw(b_src[i] + ko, dst + (i * NT + tid) * 16);
     };
 
     floatx16 acc[TM][TN], acc1[TM][TN];
@@ -805,24 +897,7 @@ __global__ __launch_bounds__(NT, (3 * BM + 2 * BN) * 128 <= 80 * 1024 ? 4 : 2) v
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
 
-    const int nk = p.K >> 5;
-    // prologue: k-tiles 0 and 1 of A converted into stages 0 and 1, the weights of k-tile 0 in flight into B stage 0
-    unsigned char* As0 = smem;                          // the stage multiplied in this iteration
-    unsigned char* As1 = smem + A_ST;                   // complete, multiplied next
-    unsigned char* As2 = smem + 2 * A_ST;               // written at the end of this iteration
-    load_A(0);
-    issue_B(0, Bbuf);
-    store_A(As0);
-    if (nk > 1) { load_A(32); store_A(As1); }
-    c3_dma_wait();
-    __syncthreads();
-#pragma unroll 1
-    for (int kt = 0; kt < nk; ++kt) {
-        // k-tile kt: A in stage As0, W in B stage kt & 1.  Requests of this iteration: W of kt + 1 (read after the barrier below),
-        // A of kt + 2 (converted at the end of this iteration into the stage that was multiplied in iteration kt - 1)
-        if (kt + 1 < nk) issue_B((kt + 1) * 32, Bbuf + ((kt + 1) & 1) * B_ST);
-        if (kt + 2 < nk) load_A((kt + 2) * 32);
-        const unsigned char* Bs = Bbuf + (kt & 1) * B_ST;
+    auto multiply = [&](const unsigned char* As, const unsigned char* Bs) {         // one 32-deep k-tile out of LDS
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f16x8 av[2][TM], bv[2][TN];
@@ -830,7 +905,7 @@ __global__ __launch_bounds__(NT, (3 * BM + 2 * BN) * 128 <= 80 * 1024 ? 4 : 2) v
             for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    av[pl][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(As0 + a_rd[s][pl][i]));
+                    av[pl][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(As + a_rd[s][pl][i]));
 #pragma unroll
                 for (int jj = 0; jj < TN; ++jj)
                     bv[pl][jj] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(Bs + b_rd[s][pl][jj]));
@@ -843,12 +918,48 @@ __global__ __launch_bounds__(NT, (3 * BM + 2 * BN) * 128 <= 80 * 1024 ? 4 : 2) v
             RIH_RW_TERM(acc1, 0, 1)
 #undef RIH_RW_TERM
         }
-        if (kt + 2 < nk) store_A(As2);
-        c3_dma_wait();                                  // the LDS-DMA of this iteration has landed before the barrier publishes it
-        __syncthreads();
-        unsigned char* const t = As0;
-        As0 = As1; As1 = As2; As2 = t;
+    };
+
+    // Schedule.  Iteration j multiplies k-tile j (A in LDS stage j & 1, W in stage j % 3).  At its top it requests the weights AND the
+    // A rows of k-tile j + 2 (weights: LDS-DMA into the stage read in iteration j - 1; rows: into the register set converted at the
+    // end of iteration j - 1).  After the MFMAs it waits until only THIS iteration's NPB + NPA requests are outstanding -- everything
+    // requested at the top of iteration j - 1, i.e. the weights and the rows of k-tile j + 1, has then had TWO k-tiles of MFMAs to
+    // land --, converts those rows into the other A stage and meets the barrier that publishes both.
+    unsigned char* Bc = Bbuf;                           // W stage of k-tile j, j + 1, j + 2 (rotating)
+    unsigned char* Bn = Bbuf + B_ST;
+    unsigned char* Bf = Bbuf + 2 * B_ST;
+    issue_B(0, Bc);
+    issue_B(1, Bn);
+    RIH_RW_LOAD_A(0, 0)
+    RIH_RW_LOAD_A(1, 1)
+    c3_vm_wait<NPA>();                                  // the weights of k-tiles 0 and 1 and the rows of k-tile 0 have landed
+    RIH_RW_STORE_A(0, Abuf)
+    __syncthreads();
+    int j = 0;
+#define RIH_RW_ITER(PAR_)                               /* PAR_ = j & 1 (a literal: the register sets are not indexable) */     \
+    {                                                                                                                        \
+        issue_B(j + 2, Bf);                                                                                                  \
+        RIH_RW_LOAD_A(PAR_, j + 2)                                                                                           \
+        multiply(Abuf + PAR_ * A_ST, Bc);                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        c3_vm_wait<NPB + NPA>();                                                                                             \
+        if (j + 1 < nk) RIH_RW_STORE_A(1 - PAR_, Abuf + (1 - PAR_) * A_ST)                                                   \
+        __syncthreads();                                                                                                     \
+        unsigned char* const t_ = Bc;                                                                                        \
+        Bc = Bn; Bn = Bf; Bf = t_;                                                                                           \
+        ++j;                                                                                                                 \
     }
+#pragma unroll 1
+    while (j + 1 < nk) {
+        RIH_RW_ITER(0)
+        RIH_RW_ITER(1)
+    }
+    if (j < nk) RIH_RW_ITER(0)                          // (an odd trip count ends on an even k-tile)
+    c3_vm_wait<0>();                                    // (the tail's surplus requests: nothing may land in LDS behind the epilogue's staging)
+    __syncthreads();
+#undef RIH_RW_ITER
+#undef RIH_RW_LOAD_A
+#undef RIH_RW_STORE_A
 
     // ---------------------------------------------------------------- epilogue (the loop ended with a barrier: LDS is free)
     float* stg = reinterpret_cast<float*>(smem) + wave * (32 * SLD);
@@ -949,6 +1060,16 @@ bool rows_ok(const rih_panel_desc* d) {
     if ((((uintptr_t)d->a | (uintptr_t)d->w_h2 | (uintptr_t)d->c | (uintptr_t)d->r | (uintptr_t)d->stats) % 16) != 0) return false;
     if ((long long)d->M * d->lda * 4 >= (1ll << 31)) return false;     // 31-bit byte offsets into A
     return true;
+}
+
+bool stem_ok(const rih_conv3_desc* d) {
+    if (!d || !d->x || !d->w_h2 || !d->y || !d->amax_x || !d->amax_w) return false;
+    if (d->imgs < 1 || d->H < 8 || d->W < 8 || d->H % 2 != 0 || d->W % 2 != 0 || d->C != 4 || d->ldx != 4) return false;
+    if (d->N != 64 || d->ldy < d->N || d->ldy % 4 != 0 || d->Kpad != 224) return false;
+    if ((((uintptr_t)d->x | (uintptr_t)d->w_h2 | (uintptr_t)d->y | (uintptr_t)d->stats) % 16) != 0) return false;
+    const long long M = (long long)d->imgs * (d->H / 2) * (d->W / 2);
+    if (M % 256 != 0 || M >= (1ll << 31)) return false;
+    return (long long)d->imgs * d->H * d->W * 16 < (1ll << 31);         // 31-bit byte offsets into the image batch
 }
 
 template <int BM, int BN>
@@ -1086,6 +1207,7 @@ extern "C" int rih_rows(const rih_panel_desc* d, void* stream) {
     a.a = d->a; a.w = (const unsigned char*)d->w_h2; a.c = d->c; a.r = d->r; a.stats = d->stats;
     a.amax_a = d->amax_a; a.amax_w = d->amax_w;
     a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr; a.relu = d->relu ? 1 : 0;
+    a.H = a.W = a.Ho = a.Wo = 0;
     int bm, bn;
     rows_tile(d, bm, bn);
     a.nblk = d->N / bn;
@@ -1097,6 +1219,23 @@ extern "C" int rih_rows(const rih_panel_desc* d, void* stream) {
     else if (bm == 128 && bn == 128) rows_launch<128, 128>(a, grid, st, rs, s);
     else if (bm == 256) rows_launch<256, 64>(a, grid, st, rs, s);
     else rows_launch<128, 64>(a, grid, st, rs, s);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rih_stem_ok(const rih_conv3_desc* d) { return stem_ok(d) ? 1 : 0; }
+
+extern "C" int rih_stem(const rih_conv3_desc* d, void* stream) {
+    if (!stem_ok(d)) return RIH_EINVAL;
+    RowsArgs a;
+    a.a = d->x; a.w = (const unsigned char*)d->w_h2; a.c = d->y; a.r = nullptr; a.stats = d->stats;
+    a.amax_a = d->amax_x; a.amax_w = d->amax_w;
+    a.H = d->H; a.W = d->W; a.Ho = d->H / 2; a.Wo = d->W / 2;
+    a.M = d->imgs * a.Ho * a.Wo; a.N = d->N; a.K = d->Kpad; a.lda = 4; a.ldc = d->ldy; a.ldr = 0; a.relu = d->relu ? 1 : 0;
+    a.nblk = 1;
+    a.mtiles = a.M / 256;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->stats != nullptr) hipLaunchKernelGGL((rows_kernel<256, 64, true, false, true>), dim3((unsigned)a.mtiles), dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((rows_kernel<256, 64, false, false, true>), dim3((unsigned)a.mtiles), dim3(NT), 0, s, a);
     return (int)hipGetLastError();
 }
 

@@ -1948,6 +1948,8 @@ extern "C" int rih_gemm_multi_variant(const rih_gemm_desc* d) {
         case 2 * 8 + 4 + 0 + 1: case 2 * 8 + 4 + 0 + 0:         // 64x64 weight gradients (plain / conv gather)
         case 0 * 8 + 4 + 0 + 1: case 0 * 8 + 4 + 0 + 0:         // 128x128 weight gradients
             return v + (pg.engine == 2 ? 64 : 0);               // + 64: the same variant on engine 2
+        case 1 * 8 + 4 + 0 + 1: case 1 * 8 + 4 + 0 + 0:         // 128x64 weight gradients (round 6: <= 64 output channels), engine 2 only
+            return pg.engine == 2 ? v + 64 : -1;
         default: return -1;
     }
 }
@@ -2023,6 +2025,8 @@ extern "C" int rih_gemm_multi_launch(const void* dev_table, int variant, int tot
         case 64 + 2 * 8 + 4 + 0: hipLaunchKernelGGL((gemm_split_multi_kernel<64, 64, 1, 0, false, 2>), grid, block, 0, s, t); break;
         case 64 + 0 * 8 + 4 + 1: hipLaunchKernelGGL((gemm_split_multi_kernel<128, 128, 1, 0, true, 2>), grid, block, 0, s, t); break;
         case 64 + 0 * 8 + 4 + 0: hipLaunchKernelGGL((gemm_split_multi_kernel<128, 128, 1, 0, false, 2>), grid, block, 0, s, t); break;
+        case 64 + 1 * 8 + 4 + 1: hipLaunchKernelGGL((gemm_split_multi_kernel<128, 64, 1, 0, true, 2>), grid, block, 0, s, t); break;
+        case 64 + 1 * 8 + 4 + 0: hipLaunchKernelGGL((gemm_split_multi_kernel<128, 64, 1, 0, false, 2>), grid, block, 0, s, t); break;
         default: return RIH_EINVAL;
     }
     return (int)hipGetLastError();

@@ -448,6 +448,9 @@ GROUP_WGRAD = int(os.environ.get('RIH_WGRAD_GROUP', '2'))        # 0: off, 1: de
 #                                                                   same-box +2.3 % over 1 on ResNet50, +6 % on HRNet-W32, profiles/r03/ab/h*)
 GROUP_KCHUNK = int(os.environ.get('RIH_WGRAD_GROUP_KCHUNK', '1024'))      # pixels per split-K slice in a grouped launch
 GROUP_SORT = os.environ.get('RIH_WGRAD_GROUP_SORT', '1') == '1'
+# 128x64 tiles for weight gradients with 33..64 output channels and >= WGRAD_T1_MINK pixels (64x64 tiles otherwise): round 6, A/B below
+WGRAD_T1 = os.environ.get('RIH_WGRAD_T1', '0') == '1'
+WGRAD_T1_MINK = int(os.environ.get('RIH_WGRAD_T1_MINK', '16384'))
 TABLE_ARENA = None
 TABLE_BYTES_STEP = 0            # table bytes packed since the counter was last reset (TrainStep sizes its arena from it)
 
@@ -651,6 +654,8 @@ def _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin
         tile = 2            # weight gradients with 17..32 columns: 64x64 split-engine tile, -26..-29 % (n32_bench_m31.log)
     if nb > 1 and ENGINE >= 1 and Ncols > 32:
         tile = 2            # paired decoder layers (tools/pair_sweep.py): 64x64 tiles win at every measured shape
+    if WGRAD_T1 and ENGINE == 2 and nb == 1 and bounds is not None and 32 < Ncols <= 64 and Mp >= 128 and Kpix >= WGRAD_T1_MINK:
+        tile = 1            # <= 64 output channels on a large map (layer1's 64-channel convolutions, the stem): 128x64 tiles
     bm, bn = _TILE_MN[tile]
     tiles = _cdiv(Mp, bm) * _cdiv(Ncols, bn) * nb
     if nb > 1 and ENGINE >= 1:
@@ -663,7 +668,7 @@ def _wgrad_now(x, dy, dw, Kpix, Mrows, Ncols, ldx, ldy, geom, Cin_pad, taps, Cin
     # grouped launch (rih_gemm_multi at the end of the backward stage): the problems fill the chip TOGETHER, so a problem needs
     # only as many split-K slices as keep its own workgroups reasonably short -- fewer partial slabs to write and to sum
     collect = None
-    if _DEFERRED_GEMM is not None and tile in (0, 2) and (GROUP_WGRAD >= 2 or nb > 1 or small):
+    if _DEFERRED_GEMM is not None and tile in (0, 1, 2) and (GROUP_WGRAD >= 2 or nb > 1 or small):
         collect = _DEFERRED_GEMM
         # (128x128 tiles for the large grouped gradients -- half the operand bytes per product -- measured +0.25 % same-box in round 4,
         # inside the noise: profiles/r04/ab/train_t128.log; the option was removed)
@@ -936,12 +941,18 @@ def panel_gemm(a, w, c, M, N, K, lda, ldc, for_dgrad, relu=False, stats=None, R=
 ROWS = os.environ.get('RIH_ROWS', '1') == '1'
 ROWS_MINK = int(os.environ.get('RIH_ROWS_MINK', '256'))
 ROWS_MIN_WGS = int(os.environ.get('RIH_ROWS_MIN_WGS', '128'))
+# smallest row count: the H2 planes of a weight cost a conversion pass per step that grows with the WEIGHT (rih_h2_multi: 0.14 ms per
+# step for every 1x1 weight of ResNet50 in both forms, 70 % of it layer4's), the kernel's advantage grows with rows x weight -- on the
+# 8 x 8 maps (4096 rows at B = 64) it is 3-7 us per launch against ~10 us of plane conversion per weight (profiles/r06/rows/)
+ROWS_MIN_M = int(os.environ.get('RIH_ROWS_MIN_M', '8192'))
 
 
 def _rows_ok(a2d_rows, K, N, lda, a, bias=None, c=None, R=None):
     """Launches rih_rows takes and that are worth it: engine 2, K >= ROWS_MINK in whole 32-deep tiles, N % 64, whole 128-row tiles, at
     least ROWS_MIN_WGS workgroups of the smallest tile; the library re-checks (rih_rows_ok) before the launch."""
     if not (ROWS and ENGINE == 2) or bias is not None or K < ROWS_MINK or K % 32 != 0 or N % 64 != 0 or a2d_rows % 128 != 0:
+        return False
+    if a2d_rows < ROWS_MIN_M:
         return False
     if lda % 4 != 0 or a.data_ptr() % 16 != 0 or 4 * a2d_rows * lda >= (1 << 31):
         return False
@@ -985,6 +996,47 @@ def rows_gemm(a, w, c, M, N, K, lda, ldc, for_dgrad, relu=False, stats=None, R=N
     return True
 
 
+# --------------------------------------------------------------------------------------------- stem convolution
+# csrc/rih_conv3.hip rows_kernel<STEM> (round 6): encoder.resnet.conv1 -- 7 x 7 / 2 / 3 on the 4-channel padded image -- on engine 2 with an
+# im2col loader.  Before: rih_gemm's GENERAL kernel on engine 1 (Cin = 4 is not a multiple of 32: no fast path), 270-280 us per step at
+# 96 TF/s.  RIH_STEM=0 restores that.
+STEM = os.environ.get('RIH_STEM', '1') == '1'
+
+
+def stem_conv(x, w, y, relu=False, stats=None, bx=None, bw=None):
+    """Enqueue rih_stem: y [N, H/2, W/2, 64] = act(conv7x7/2/3(x [N, H, W, 4], w [64, <= 4, 7, 7])).  Returns False (nothing enqueued)
+    when the shape is not the kernel's (rih_stem_ok): the caller takes rih_gemm."""
+    from ._lib import Conv3Desc
+    N, H, W_, Cx = x.shape
+    Cout = w.shape[0]
+    d = Conv3Desc()
+    d.x, d.y = x.data_ptr(), y.data_ptr()
+    d.imgs, d.H, d.W, d.C, d.N, d.ldx, d.ldy, d.Kpad, d.relu = N, H, W_, Cx, Cout, Cx, Cout, 224, 1 if relu else 0
+    d.w_h2 = d.amax_x = d.amax_w = x.data_ptr()         # (placeholders for the library's own precondition check)
+    if int(_L().rih_stem_ok(C.byref(d))) != 1:
+        return False
+    bwv = bw() if callable(bw) else bw
+    planes, Kp = _h2_weight(w, Cx, False, bound=bwv)
+    assert Kp == 224
+    d.w_h2 = planes.data_ptr()
+    d.amax_x = (bx() if callable(bx) else bx).data_ptr()
+    d.amax_w = bwv.data_ptr()
+    M = N * (H // 2) * (W_ // 2)
+    if stats is not None and stats.part is None:
+        stats.rows, stats.T = 64, M // 64
+        stats.part = torch.empty((stats.T, 2, Cout), device=x.device, dtype=torch.float32)
+        d.stats = stats.part.data_ptr()
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_L().rih_stem(C.byref(d), _stream()), 'rih_stem')
+        e1.record()
+        PROFILE.append((2.0 * M * Cout * 49 * Cx, e0, e1, (M, Cout, 49 * Cx, 1, 0, 3, 53, 1, 2)))
+        return True
+    check(_L().rih_stem(C.byref(d), _stream()), 'rih_stem')
+    return True
+
+
 class Conv2dFn(torch.autograd.Function):
     """NHWC conv2d (+bias, +ReLU epilogue) = implicit GEMM on the fp32 MFMA pipe.
     x: [N,H,W,Cx] (Cx >= Cin, extra channels must be zero), w: [Cout,Cin,KH,KW] (the nn.Conv2d parameter)."""
@@ -1009,6 +1061,9 @@ class Conv2dFn(torch.autograd.Function):
         rows1x1 = KH * KW == 1 and Cx == Cin and stride == 1 and pad == 0       # a plain-row GEMM on the stored [Cout][Cin] weight
         if (Cx == Cin and _halo3_ok(x, Cx, Cout, KH, KW, stride, pad, bias)
                 and conv3x3_halo(x, w, y, False, relu=relu, stats=stats, bx=bx, bw=bw)):
+            pass
+        elif (STEM and ENGINE == 2 and KH == 7 and KW == 7 and stride == 2 and pad == 3 and Cx == 4 and Cout == 64 and bias is None
+              and x.is_contiguous() and stem_conv(x, w, y, relu=relu, stats=stats, bx=bx, bw=bw)):
             pass
         elif (rows1x1 and _panel_ok(M, Cin, Cout, Cx, x, bias)
               and panel_gemm(x, w, y, M, Cout, Cin, Cx, Cout, False, relu=relu, stats=stats, ba=bx, bw=bw)):

@@ -217,7 +217,7 @@ class EmulatedLib:
     def rih_gemm_multi_variant(self, dref):
         d = dref._obj if hasattr(dref, '_obj') else dref
         plain = (d.KH == 1 and d.KW == 1 and d.strideA == 1 and d.padH == 0 and d.padW == 0 and d.H == d.Ho and d.W == d.Wo)
-        ok = (d.engine in (1, 2) and d.tile in (0, 2) and d.a_mode == 1 and d.b_mode == 0 and d.upS == 1 and d.K % 4 == 0
+        ok = (d.engine in (1, 2) and (d.tile in (0, 2) or (d.tile == 1 and d.engine == 2)) and d.a_mode == 1 and d.b_mode == 0 and d.upS == 1 and d.K % 4 == 0
               and d.K >= 1 and d.A % 16 == 0 and d.B % 16 == 0 and d.lda % 4 == 0 and d.ldb % 4 == 0 and d.sA1 % 4 == 0
               and d.sB1 % 4 == 0 and d.sA2 % 4 == 0 and d.sB2 % 4 == 0 and d.M % 4 == 0 and d.N % 4 == 0 and not d.stats)
         if not plain:
@@ -435,6 +435,49 @@ class EmulatedLib:
             T = d.imgs * d.H * d.W // rows
             st = _f(d.stats, T * 2 * d.N).reshape(T, 2, d.N)
             blk = y.reshape(d.imgs, d.H // th, th, d.W // tw, tw, d.N).transpose(0, 1, 3, 2, 4, 5).reshape(T, rows, d.N)
+            m = blk.astype(np.float64).mean(1)
+            st[:, 0] = m
+            st[:, 1] = ((blk - m[:, None]) ** 2).sum(1)
+        return 0
+
+    # ------------------------------------------------------------------ stem convolution (csrc/rih_conv3.hip rows_kernel<STEM>)
+    @staticmethod
+    def _stem_ok(d):
+        M = d.imgs * (d.H // 2) * (d.W // 2)
+        return bool(d.x and d.w_h2 and d.y and d.amax_x and d.amax_w and d.imgs >= 1 and d.H >= 8 and d.W >= 8 and d.H % 2 == 0
+                    and d.W % 2 == 0 and d.C == 4 and d.ldx == 4 and d.N == 64 and d.ldy >= d.N and d.ldy % 4 == 0 and d.Kpad == 224
+                    and all(int(v or 0) % 16 == 0 for v in (d.x, d.w_h2, d.y, d.stats)) and M % 256 == 0
+                    and d.imgs * d.H * d.W * 16 < (1 << 31))
+
+    def rih_stem_ok(self, dref):
+        return 1 if self._stem_ok(dref._obj if hasattr(dref, '_obj') else dref) else 0
+
+    def rih_stem(self, dref, stream):
+        d = dref._obj
+        if not self._stem_ok(d):
+            return -1
+        sw = self._e2_scale(d.amax_w)
+        pl = np.ctypeslib.as_array((C.c_uint16 * (2 * d.N * d.Kpad)).from_address(int(d.w_h2))).reshape(d.N, d.Kpad // 8, 2, 8)
+        hi = pl[:, :, 0, :].reshape(d.N, d.Kpad).view(np.float16).astype(np.float32)
+        lo = pl[:, :, 1, :].reshape(d.N, d.Kpad).view(np.float16).astype(np.float32)
+        Wnk = ((hi + lo * np.float32(2.0 ** -11)) / sw).astype(np.float32)           # [N][(tap, c)], taps 49..55 zero
+        x = _f(d.x, d.imgs * d.H * d.W * 4).reshape(d.imgs, d.H, d.W, 4)
+        xp = np.zeros((d.imgs, d.H + 6, d.W + 6, 4), np.float32)
+        xp[:, 3:-3, 3:-3] = x
+        Ho, Wo = d.H // 2, d.W // 2
+        y = np.zeros((d.imgs, Ho, Wo, d.N), np.float32)
+        for kh in range(7):
+            for kw in range(7):
+                t = kh * 7 + kw
+                y += xp[:, kh:kh + d.H:2, kw:kw + d.W:2].reshape(-1, 4).dot(Wnk[:, t * 4:(t + 1) * 4].T).reshape(y.shape)
+        if d.relu:
+            y = np.maximum(y, 0)
+        M = d.imgs * Ho * Wo
+        np.lib.stride_tricks.as_strided(_f(d.y, (M - 1) * d.ldy + d.N), (M, d.N), (4 * d.ldy, 4))[...] = y.reshape(M, d.N)
+        if d.stats:
+            T = M // 64
+            st = _f(d.stats, T * 2 * d.N).reshape(T, 2, d.N)
+            blk = y.reshape(T, 64, d.N)
             m = blk.astype(np.float64).mean(1)
             st[:, 0] = m
             st[:, 1] = ((blk - m[:, None]) ** 2).sum(1)

@@ -158,6 +158,7 @@ def test_rows_host_logic(monkeypatch):
     G.test_rows_1x1((2, 16, 16, 256, 64, False, True))
     G.test_rows_1x1((1, 16, 8, 96, 128, True, True))
     G.test_rows_kernel_is_taken_and_falls_back(monkeypatch)
+    G.test_stem_conv((2, 32, 32, True, True))
 
 
 def test_conv1x1_cat_host_logic():

@@ -265,8 +265,8 @@ def test_rows_1x1(case, monkeypatch=None):
     thresholds (K >= 256, >= 128 workgroups) are lifted for the small shapes; the panel kernel is off so that K = 64 / 128 come here."""
     from renderih_amd import ops
     N, H, W, Cin, Cout, relu, want_stats = case
-    saved = (ops.ENGINE, ops.ROWS, ops.ROWS_MINK, ops.ROWS_MIN_WGS, ops.PANEL)
-    ops.ENGINE, ops.ROWS_MINK, ops.ROWS_MIN_WGS, ops.PANEL = 2, 64, 1, False
+    saved = (ops.ENGINE, ops.ROWS, ops.ROWS_MINK, ops.ROWS_MIN_WGS, ops.PANEL, ops.ROWS_MIN_M)
+    ops.ENGINE, ops.ROWS_MINK, ops.ROWS_MIN_WGS, ops.PANEL, ops.ROWS_MIN_M = 2, 64, 1, False, 1
     try:
         x = rnd(N, Cin, H, W, seed=41) * 2.0
         w = rnd(Cout, Cin, 1, 1, seed=42, scale=1.0 / math.sqrt(Cin))
@@ -302,7 +302,7 @@ def test_rows_1x1(case, monkeypatch=None):
         for a, b, what in zip(outs[True], outs[False], ('y', 'dx', 'dw')):
             assert_close(a, b, 1e-4, 1e-5, 'rows vs tiled GEMM ' + what)
     finally:
-        ops.ENGINE, ops.ROWS, ops.ROWS_MINK, ops.ROWS_MIN_WGS, ops.PANEL = saved
+        ops.ENGINE, ops.ROWS, ops.ROWS_MINK, ops.ROWS_MIN_WGS, ops.PANEL, ops.ROWS_MIN_M = saved
 
 
 def test_rows_kernel_is_taken_and_falls_back(monkeypatch):
@@ -312,6 +312,7 @@ def test_rows_kernel_is_taken_and_falls_back(monkeypatch):
     from renderih_amd import ops
     monkeypatch.setattr(ops, 'ENGINE', 2)
     monkeypatch.setattr(ops, 'ROWS_MIN_WGS', 1)
+    monkeypatch.setattr(ops, 'ROWS_MIN_M', 1)
     calls = []
     real = ops.rows_gemm
     monkeypatch.setattr(ops, 'rows_gemm', lambda *a, **k: (calls.append(real(*a, **k)) or calls[-1]))
@@ -332,6 +333,97 @@ def test_rows_kernel_is_taken_and_falls_back(monkeypatch):
     assert int(ops._L().rih_rows_ok(C.byref(pd))) == 0
     pd.c = x.data_ptr()
     assert int(ops._L().rih_rows_ok(C.byref(pd))) == 1
+
+
+def test_grouped_weight_gradients_on_128x64_tiles(monkeypatch):
+    """ops.WGRAD_T1 (round 6): weight gradients with 33..64 output channels on a large map ride in the grouped launch on 128 x 64
+    tiles of engine 2 (rih_gemm_multi variant 64 + 8 + 4 + plain) -- 3 x 3 and 1 x 1 convolutions, with the 64 x 64-tile path and fp64
+    as references; bit-reproducible from run to run."""
+    from renderih_amd import ops
+    monkeypatch.setattr(ops, 'ENGINE', 2)
+    monkeypatch.setattr(ops, 'WGRAD_T1_MINK', 512)
+    d = dev()
+    xs = [rnd(2, 64, 16, 32, seed=61), rnd(2, 128, 16, 32, seed=66)]
+    gys = [rnd(2, 64, 16, 32, seed=62), rnd(2, 48, 16, 32, seed=63)]
+    ws = [rnd(64, 64, 3, 3, seed=64, scale=0.05), rnd(48, 128, 1, 1, seed=65, scale=0.1)]
+    refs = []
+    for x, w, gy, pad in zip(xs, ws, gys, (1, 0)):
+        wr = w.double().clone().requires_grad_(True)
+        F.conv2d(x.double(), wr, padding=pad).backward(gy.double())
+        refs.append(wr.grad.float())
+    seen = []
+    flush = ops.GroupedGemms.flush
+
+    def spy(self):
+        seen.extend(v for v, _, _, _ in self.items)
+        return flush(self)
+    monkeypatch.setattr(ops.GroupedGemms, 'flush', spy)
+    got = {}
+    for t1 in (True, False, True):
+        monkeypatch.setattr(ops, 'WGRAD_T1', t1)
+        del seen[:]
+        xg = [nhwc(x).contiguous().to(d) for x in xs]
+        wg = [w.clone().to(d).requires_grad_(True) for w in ws]
+        with ops.deferred_reductions():
+            ys = [ops.conv2d(xg[0], wg[0], None, stride=1, pad=1), ops.conv2d(xg[1], wg[1], None, stride=1, pad=0)]
+            g = torch.autograd.grad([(y * nhwc(gy).contiguous().to(d)).sum() for y, gy in zip(ys, gys)], wg)
+        g = [t.cpu() for t in g]
+        if t1:
+            assert sorted(seen) == [64 + 8 + 4 + 0, 64 + 8 + 4 + 1], seen
+            if True in got:
+                assert all(torch.equal(a, b) for a, b in zip(g, got[True])), 'grouped 128x64 launch is not reproducible'
+        else:
+            assert all((v & 63) >> 3 == 2 for v in seen), seen
+        got[t1] = g
+        for a, r in zip(g, refs):
+            assert_close(a, r, 1e-4, 1e-5, 'wgrad T1=%s vs fp64' % t1)
+
+
+@pytest.mark.parametrize('case', [(2, 32, 32, True, True), (16, 24, 40, False, True), (4, 16, 16, True, False)])
+def test_stem_conv(case, monkeypatch=None):
+    """csrc/rih_conv3.hip rows_kernel<STEM> through ops.conv2d (ops.STEM, engine 2): encoder.resnet.conv1 -- 7 x 7 / stride 2 / padding 3
+    on the 4-channel padded image -- with the im2col loader (one tap of one output pixel = one float4; zero padding and the K = 196 ->
+    224 tail by predication): output (+ ReLU), the BatchNorm statistics of its epilogue, the weight gradient (rih_gemm) against
+    F.conv2d in fp64, and equal to rih_gemm's general kernel (STEM off) to fp32 round-off.  (N, H, W, relu, stats)."""
+    from renderih_amd import ops
+    N, H, W, relu, want_stats = case
+    saved = (ops.ENGINE, ops.STEM)
+    ops.ENGINE = 2
+    try:
+        x = rnd(N, 3, H, W, seed=51) * 2.0
+        w = rnd(64, 3, 7, 7, seed=52, scale=1.0 / math.sqrt(147.0))
+        xr, wr = x.double(), w.double().clone().requires_grad_(True)
+        yr = F.conv2d(xr, wr, stride=2, padding=3)
+        if relu:
+            yr = F.relu(yr)
+        gy = rnd(*yr.shape, seed=53)
+        yr.backward(gy.double())
+        d = dev()
+        outs = {}
+        for stem in (True, False):
+            ops.STEM = stem
+            xg = torch.zeros(N, H, W, 4)
+            xg[..., :3] = nhwc(x)
+            xg = xg.to(d)
+            wg = w.clone().to(d).requires_grad_(True)
+            holder = ops.StatsHolder() if want_stats else None
+            yg = ops.conv2d(xg, wg, None, stride=2, pad=3, relu=relu, stats=holder)
+            yg.backward(nhwc(gy).contiguous().to(d))
+            outs[stem] = (nchw(yg).detach().cpu(), wg.grad.cpu())
+            assert_close(outs[stem][0], yr.float(), 1e-4, 1e-5, 'stem %s y %s' % (stem, case,))
+            assert_close(outs[stem][1], wr.grad.float(), 1e-4, 1e-5, 'stem %s dw %s' % (stem, case,))
+            if stem and want_stats:
+                M = N * (H // 2) * (W // 2)
+                assert holder.part is not None and holder.rows == 64 and holder.T == M // 64
+                part = holder.part.double().cpu()
+                mean = part[:, 0].mean(0)
+                var = (part[:, 1] + 64.0 * (part[:, 0] - mean) ** 2).sum(0) / M
+                y2 = nhwc(yr.detach()).reshape(M, 64)
+                assert_close(mean, y2.mean(0), 1e-4, 1e-5, 'stem stats mean')
+                assert_close(var, y2.var(0, unbiased=False), 1e-3, 1e-5, 'stem stats var')
+        assert_close(outs[True][0], outs[False][0], 1e-4, 1e-5, 'stem kernel vs general GEMM y')
+    finally:
+        ops.ENGINE, ops.STEM = saved
 
 
 LIN_CASES = [(126, 512, 256, True, False, False), (126, 2048, 509, True, False, False), (100, 64, 3, True, False, False),

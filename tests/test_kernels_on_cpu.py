@@ -90,6 +90,18 @@ def test_rows_kernels(case):
     G.test_rows_1x1(case)
 
 
+@pytest.mark.parametrize('case', [(2, 32, 32, True, True), (4, 16, 16, True, False)])
+def test_stem_kernel(case):
+    """csrc/rih_conv3.hip rows_kernel<STEM> on the host harness: the im2col loader's predication (image border, the seven padding
+    taps of the last k-tile), seven k-tiles through the two-stage pipeline, statistics epilogue."""
+    G.test_stem_conv(case)
+
+
+def test_grouped_wgrad_128x64_kernels(monkeypatch):
+    """gemm_split_multi_kernel<128, 64, 1, 0, *, 2> (round 6) on the host harness."""
+    G.test_grouped_weight_gradients_on_128x64_tiles(monkeypatch)
+
+
 def test_conv3_lds_image_is_conflict_free():
     """The LDS images of csrc/rih_conv3.hip: a pixel / weight row = 8 units of 16 bytes at position j ^ ((index >> 1) & 7).  A
     ds_read_b128 is served in 16-lane groups (MI355X_MICROARCH.md, LDS table); within a group every lane must hit its own 16-byte

@@ -51,9 +51,9 @@ def main():
         prev_end = max(prev_end or e, e)
     print('step: %d launches, wall %.3f ms, sum of kernel durations %.3f ms, idle between kernels %.3f ms'
           % (len(step), (t1 - t0) / 1e6, busy / 1e6, gaps / 1e6))
-    fam = ('gemm', 'conv3x3_halo', 'panel_kernel')      # the GEMM family: rih_gemm's kernels, the halo-resident 3x3 and the streaming 1x1
+    fam = ('gemm', 'conv3x3_halo', 'panel_kernel', 'rows_kernel', 'stem_kernel', 'wgrad')   # the GEMM family: rih_gemm's kernels, halo 3x3, panel / rows 1x1, stem
     g = sum(v[1] for k, v in agg.items() if k.startswith(fam))
-    print('GEMM-family kernels (gemm_*, conv3x3_halo_kernel, panel_kernel) %.3f ms, everything else %.3f ms' % (g / 1e6, (busy - g) / 1e6))
+    print('GEMM-family kernels (gemm_*, conv3x3_halo_kernel, panel_kernel, rows_kernel, stem_kernel) %.3f ms, everything else %.3f ms' % (g / 1e6, (busy - g) / 1e6))
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
         print('%8.3f ms %5d x %8.1f us  %s' % (v[1] / 1e6, v[0], v[1] / v[0] / 1e3, k))
     if '--by-grid' in sys.argv:
@@ -61,7 +61,7 @@ def main():
         byg = collections.OrderedDict()
         for r in step:
             n = short(r['Kernel_Name'])
-            if not n.startswith(('gemm', 'conv3x3', 'panel_kernel')):
+            if not n.startswith(('gemm', 'conv3x3', 'panel_kernel', 'rows_kernel', 'stem_kernel', 'wgrad')):
                 continue
             k = byg.setdefault((n[:70], r.get('Grid_Size_X', r.get('Grid_Size', '?'))), [0, 0])
             k[0] += 1
