@@ -31,6 +31,7 @@
 // on the training path); callers with either use rih_gemm.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/renderih_amd.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));

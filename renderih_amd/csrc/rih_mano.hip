@@ -418,12 +418,14 @@ __device__ __forceinline__ void load_tile_192(float* __restrict__ dst, const flo
 // row): T[c] += G[(j, c)] * w[j] for four joints j and the twelve elements c, where the 48 values G[(j, c)] of the four joints sit in
 // three registers G0..G2 whose lane l holds flat element 16 r + (l & 15) -- the same sixteen values in each of the four rows.  One
 // v_fmac_f32_dpp per product: no LDS read, no move.  (The compiler does not fold __builtin_amdgcn_update_dpp into the FMA -- it
-// emits v_mov_b32_dpp + v_fma -- so the block is inline assembly; the leading s_nop covers the two wait states a DPP read needs
-// after a VALU write of its source, which the hazard recognizer cannot see inside an asm statement.)  The host build of the test
+// emits v_mov_b32_dpp + v_fma -- so the block is inline assembly; the leading `s_nop 4` covers what the hazard recognizer cannot see
+// inside an asm statement: the two wait states a DPP read needs after a VALU write of its source AND the five a DPP instruction needs
+// after a VALU write of EXEC (v_cmpx; ADVICE round 5 -- the compiler emits no such sequence in front of the block today, but that is
+// code generation, not a guarantee).)  The host build of the test
 // harness supplies the same arithmetic with an emulated lane exchange.
 #ifndef RIH_SKIN_GROUP
 #define RIH_SKIN_GROUP(T, G0, G1, G2, W0, W1, W2, W3)                                                                             \
-    asm("s_nop 1\n"                                                                                                               \
+    asm("s_nop 4\n"                                                                                                               \
         "v_fmac_f32_dpp %0, %12, %15 row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
         "v_fmac_f32_dpp %1, %12, %15 row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
         "v_fmac_f32_dpp %2, %12, %15 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \

@@ -27,7 +27,10 @@ What it does that the plain loop does not:
   support), so the host cost per step is three graph launches + three collectives + one fused optimizer launch instead of
   ~2700 kernel launches.  Dropout masks stay fresh through the device-resident seed word (`ops.DROPOUT_SEED_TENSOR`).
 
-Stages need the ResNet trunk (`model.encoder.resnet`); other encoders run as one stage (still bucketed + graphed).
+Stages need a trunk that `stage_plan` knows: the ResNet trunk (`model.encoder.resnet`: three stages, cut at its four feature maps and
+at layer2's output) or HRNet (`model.encoder.hrnet`, round 6: four stages, cut at the trunk's branch maps and behind its stage 3 and
+stage 2 -- the reference's DDP buckets ANY model at 25 MB, core/gcn_trainer.py:110-115; until round 6 HRNet-W32 was one stage and one
+202 MB bucket whose all-reduce could overlap nothing); other encoders run as one stage (still bucketed + graphed).
 Host-side bookkeeping of the forward that is not a kernel does not happen on a replay: `BatchNorm2d.num_batches_tracked` stays
 at its capture-time value (it only matters for `momentum=None`, which the reference never uses); running statistics are
 updated by the kernels and are correct.
@@ -43,10 +46,33 @@ def _trunk(model):
     return getattr(enc, 'resnet', None)
 
 
+def _hr_trunk(model):
+    enc = getattr(model, 'encoder', None)
+    t = getattr(enc, 'hrnet', None)
+    return t if (t is not None and all(hasattr(t, n) for n in ('stage2', 'stage3', 'stage4', 'transition3'))) else None
+
+
+def hrnet_cut_modules(model):
+    """HRNet: the modules whose outputs cut the backward pass, in FORWARD order -- the last HighResolutionModule of stage 2 and of
+    stage 3 (each returns the list of branch maps that everything downstream is computed from) and the trunk itself."""
+    t = _hr_trunk(model)
+    return None if t is None else [t.stage2[-1], t.stage3[-1], t]
+
+
 def stage_parameter_groups(model):
-    """Trainable parameters in reverse-autograd order: [after-trunk, layer4+layer3, layer2+layer1+stem] (or one group)."""
+    """Trainable parameters in reverse-autograd order: ResNet [after-trunk, layer4+layer3, layer2+layer1+stem]; HRNet
+    [after-trunk, stage4+transition3, stage3+transition2, stage2+transition1+layer1+stem]; anything else one group."""
     trunk = _trunk(model)
     allp = [p for p in model.parameters() if p.requires_grad]
+    hr = _hr_trunk(model)
+    if hr is not None:
+        s4 = [p for m in (hr.stage4, hr.transition3) for p in m.parameters() if p.requires_grad]
+        s3 = [p for m in (hr.stage3, hr.transition2) for p in m.parameters() if p.requires_grad]
+        ids = {id(p) for p in s4 + s3}
+        early = [p for p in hr.parameters() if p.requires_grad and id(p) not in ids]
+        ids |= {id(p) for p in early}
+        rest = [p for p in allp if id(p) not in ids]
+        return [rest, s4, s3, early]
     if trunk is None or not all(hasattr(trunk, n) for n in ('layer1', 'layer2', 'layer3', 'layer4')):
         return [allp]
     late = [p for m in (trunk.layer4, trunk.layer3) for p in m.parameters() if p.requires_grad]
@@ -98,8 +124,14 @@ class TrainStep:
         self.cuda = dev.type == 'cuda'
         self._bounds = self._cut = None
         self._cutting = False
+        self._chain = None          # HRNet: the cut modules in forward order; _att / _det = their attached / detached outputs
+        self._att = self._det = None
         if self.nstage == 3:
             self._hook = _trunk(model).register_forward_hook(self._grab)
+        elif self.nstage == 4:
+            self._chain = hrnet_cut_modules(model)
+            self._hooks = [m.register_forward_hook(lambda mod, inp, out, k=k: self._grab_chain(k, out))
+                           for k, m in enumerate(self._chain)]
         self.live = None            # per stage: indices of the parameters that receive a gradient
         self.flat = None            # per stage: flat bucket
         self.views = None
@@ -129,6 +161,16 @@ class TrainStep:
         self._cut = tuple(t.detach().requires_grad_(True) for t in output)
         return self._cut
 
+    def _grab_chain(self, k, output):
+        """Forward hook on cut module k of a chain (HRNet), active only inside this helper's own forward: keeps the attached list of
+        branch maps and hands detached aliases downstream, so that each backward stage stops at the cut in front of it."""
+        if not self._cutting:
+            return None
+        outs = list(output)
+        self._att[k] = outs
+        self._det[k] = [t.detach().requires_grad_(True) for t in outs]
+        return type(output)(self._det[k]) if isinstance(output, (list, tuple)) else self._det[k]
+
     def _broadcast_state(self):
         import torch.distributed as dist
         every = list(self.model.parameters())
@@ -144,6 +186,8 @@ class TrainStep:
 
     def _forward_loss(self):
         self._bounds = self._cut = None
+        if self._chain is not None:
+            self._att, self._det = [None] * len(self._chain), [None] * len(self._chain)
         ops.begin_step(self.model)      # engine 2: this step's operand bounds (the packed weight planes below are scaled by them)
         if self.packs is not None:
             # every packed weight operand the step needs (forward and data-gradient layouts of the k > 1 convolutions) in one
@@ -182,6 +226,17 @@ class TrainStep:
         g = self.groups[i]
         if self.nstage == 1:
             return list(torch.autograd.grad([loss], g, allow_unused=True)), None
+        if self._chain is not None:
+            # chain of cuts c_0 .. c_{n-1} (forward order), n + 1 stages: stage 0 runs from the loss to the last cut, stage i from the
+            # attached outputs of cut n - i (seeded with the gradients that arrived at their detached aliases) to cut n - i - 1
+            n = len(self._chain)
+            roots, seeds = ([loss], None) if i == 0 else (self._att[n - i], list(carry))
+            stop = self._det[n - i - 1] if i < n else []
+            if i > 0:           # (a branch map that nothing downstream read has no gradient: it contributes nothing)
+                keep = [k for k, (r, sd) in enumerate(zip(roots, seeds)) if sd is not None and r.requires_grad]
+                roots, seeds = [roots[k] for k in keep], [seeds[k] for k in keep]
+            r = torch.autograd.grad(roots, g + stop, grad_outputs=seeds, allow_unused=True)
+            return list(r[:len(g)]), (tuple(r[len(g):]) if stop else None)
         x4, x3, x2, x1 = self._bounds
         if i == 0:
             c4, c3, c2, c1 = self._cut
@@ -270,7 +325,7 @@ class TrainStep:
     def _step_eager_body(self):
         loss = self._forward_loss()
         if self.defer_reduce and self.live is None:
-            shared = self._shared_parameters([loss] + list(self._bounds or ()))
+            shared = self._shared_parameters([loss] + list(self._bounds or ()) + [t for a in (self._att or ()) for t in (a or ())])
             if shared:
                 import warnings
                 warnings.warn('TrainStep: %d parameters are used more than once in the forward pass; the batched split-K / '

@@ -109,11 +109,13 @@ def test_conv_problem_at_bench_batch(prob):
     yg = ops.conv2d(xg, wg, bg, stride=s, pad=p)
     assert_close(yg.permute(0, 3, 1, 2), yr, what='y %s' % (prob,))
     yg.backward(gy.permute(0, 2, 3, 1).contiguous())
-    assert_close(wg.grad, dwr, 1e-3, 1e-4, 'dw %s' % (prob,))
+    # (round 6: gradients at north_star's 1e-4 + 1e-5 max -- ten times what the engines measure against fp64, 2-8e-7 of the maximum;
+    # until round 5 these bars were 1e-3 + 1e-4 max and would have let a hundredfold regression pass)
+    assert_close(wg.grad, dwr, 1e-4, 1e-5, 'dw %s' % (prob,))
     if Cin != 3:
-        assert_close(xg.grad.permute(0, 3, 1, 2), dxr, 1e-3, 1e-4, 'dx %s' % (prob,))
+        assert_close(xg.grad.permute(0, 3, 1, 2), dxr, 1e-4, 1e-5, 'dx %s' % (prob,))
     if bias:
-        assert_close(bg.grad, dbr, 1e-3, 1e-4, 'db %s' % (prob,))
+        assert_close(bg.grad, dbr, 1e-4, 1e-5, 'db %s' % (prob,))
 
 
 @pytest.mark.parametrize('prob', LINEAR_PROBLEMS)
@@ -135,10 +137,10 @@ def test_linear_problem_at_bench_batch(prob):
     yg = ops.linear(xg, wg, bg)
     assert_close(yg, yr, what='y %s' % (prob,))
     yg.backward(gy)
-    assert_close(xg.grad, dxr, 1e-3, 1e-4, 'dx %s' % (prob,))
-    assert_close(wg.grad, dwr, 1e-3, 1e-4, 'dw %s' % (prob,))
+    assert_close(xg.grad, dxr, 1e-4, 1e-5, 'dx %s' % (prob,))
+    assert_close(wg.grad, dwr, 1e-4, 1e-5, 'dw %s' % (prob,))
     if bias:
-        assert_close(bg.grad, dbr, 1e-3, 1e-4, 'db %s' % (prob,))
+        assert_close(bg.grad, dbr, 1e-4, 1e-5, 'db %s' % (prob,))
 
 
 def _build(dropout=0.0, seed=0):
@@ -245,3 +247,76 @@ def test_parameter_gradients_at_bench_batch_vs_fp64_anchor():
     print('  median ratio %.2f' % med)
     assert not bad, 'gradients further from fp64 than %g x the fp32 oracle: %s' % (RATIO, bad)
     assert med <= 2.0, 'median distance ratio %.2f' % med
+
+
+def test_b64_matches_the_reference_fixture_directly():
+    """tests/golden/net_train_b64_ref.npz (make_b64_ref.py, round 6 -- round-5 verdict item 3 iv): the REAL reference modules
+    (`models.model.HandNET_GCN`, train mode, fp32) at the BENCHMARK batch B = 64 on the seeds of b64_grads.npz.  Until round 6 the
+    largest batch the reference itself pinned was B = 16 and the B = 64 anchor was the oracle's.  Here the HIP path meets reference
+    output directly, no oracle in between:
+      * every output of the 4-tuple (signature samples): there is no fp64 anchor for the outputs at this size, so the bar is direct,
+        |HIP - reference| <= 2e-3 of the tensor's maximum (two fp32 evaluation orders of this 50-layer batch-statistics network
+        land 1e-4 .. 8e-4 apart, DESIGN 4), and the loss within 1e-3 relative;
+      * the sampled parameter gradients: |HIP - fp64 anchor| (relative l2 on the 16384-element sample) within 4 x the REFERENCE's
+        own distance e32ref from that anchor (floor 1e-4), cosine likewise, median ratio <= 2 -- test_parameter_gradients_at_
+        bench_batch_vs_fp64_anchor's band with the reference's fp32 run in the role of the oracle's;
+      * the direct distance |HIP - reference| / |reference| on the same samples <= 5 x e32ref + 1e-4 (triangle inequality);
+      * BatchNorm running buffers after the step at 1e-3."""
+    import os
+    import zlib
+    import numpy as np
+    from oracle import net_oracle
+    here = os.path.dirname(os.path.abspath(__file__))
+    z = np.load(os.path.join(here, 'golden', 'net_train_b64_ref.npz'))
+    fx = np.load(os.path.join(here, 'golden', 'b64_grads.npz'))
+    seed_state, seed_img, bsz = (int(v) for v in z['meta/seeds'])
+    assert bsz == B and [int(v) for v in fx['meta/seeds']] == [seed_state, seed_img, bsz]
+    m, _ = _build(0.0, seed=seed_state)
+    m.train()
+    out = m(testing.seeded_image(B, seed_img).cuda())
+    worst = (0.0, '')
+    for k, v in testing.flatten_outputs(out).items():
+        st, sa = testing.signature(v)
+        assert int(st[4]) == int(z['out/' + k + '#stats'][4]), k
+        ref = z['out/' + k + '#samp'].astype(np.float64)
+        scale = max(float(z['out/' + k + '#stats'][3]), 1e-30)
+        assert np.isfinite(sa).all(), k
+        e = float(np.abs(sa.astype(np.float64) - ref).max()) / scale
+        worst = max(worst, (e, k))
+        assert e <= 2e-3, '%s: %.3g of the tensor maximum from the reference' % (k, e)
+    loss = net_oracle.scalar_loss(out)
+    assert abs(loss.item() - float(z['loss'])) <= 1e-3 * abs(float(z['loss'])), (loss.item(), float(z['loss']))
+    loss.backward()
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    names = [k[4:] for k in z.files if k.startswith('g32/')]
+    assert len(names) >= 50
+    rows, bad = [], []
+    for k in names:
+        g = grads[k].double().flatten().cpu()
+        r64 = torch.from_numpy(fx['g64/' + k]).double().flatten()
+        r32 = torch.from_numpy(z['g32/' + k]).double().flatten()
+        if g.numel() > r64.numel():
+            idx = np.sort(np.random.RandomState(zlib.crc32(k.encode()) & 0x7FFFFFFF).choice(g.numel(), r64.numel(), replace=False))
+            g = g[torch.from_numpy(idx)]
+        if testing.is_null_gradient(k):
+            continue
+        e = float((g - r64).norm() / r64.norm().clamp_min(1e-300))
+        cos = float(torch.dot(g, r64) / (g.norm() * r64.norm()).clamp_min(1e-300))
+        edir = float((g - r32).norm() / r32.norm().clamp_min(1e-300))
+        eref, cref = float(z['e32ref/' + k]), float(z['c32ref/' + k])
+        rows.append((e / max(eref, 1e-12), k, e, eref, edir))
+        if not (e <= 4.0 * eref + 1e-4 and 1.0 - cos <= 16.0 * (1.0 - cref) + 1e-6 and edir <= 5.0 * eref + 1e-4):
+            bad.append('%s: vs fp64 %.3g (reference %.3g), vs reference %.3g' % (k, e, eref, edir))
+    rows.sort(reverse=True)
+    print('B = 64 against the REFERENCE fixture: outputs worst %.3g of max (%s); %d gradient tensors; rel. l2: HIP vs fp64 | reference vs '
+          'fp64 | ratio | HIP vs reference' % (worst[0], worst[1], len(rows)))
+    for ratio, k, e, eref, edir in rows[:10]:
+        print('  %-66s %.2e %.2e %5.2f  %.2e' % (k, e, eref, ratio, edir))
+    med = sorted(r[0] for r in rows)[len(rows) // 2]
+    print('  median ratio %.2f' % med)
+    assert not bad, 'gradients further from fp64 / from the reference than the band allows:\n' + '\n'.join(bad)
+    assert med <= 2.0, 'median distance ratio %.2f' % med
+    sd = m.state_dict()
+    for k in z.files:
+        if k.startswith('bnstat/'):
+            testing.assert_close(sd[k[7:]].float(), torch.from_numpy(np.asarray(z[k])).float(), 1e-3, 1e-4, k)

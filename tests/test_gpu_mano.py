@@ -43,31 +43,34 @@ def test_mano_matches_reference_golden(side):
         ((v * torch.from_numpy(z[key + 'wv']).to(dev())).sum() + (j * torch.from_numpy(z[key + 'wj']).to(dev())).sum()).backward()
         for nm, t in (('root', root), ('pose', pose), ('shape', shape), ('trans', trans), ('scale', scale)):
             if t is not None:
-                assert_close(t.grad, torch.from_numpy(z[key + 'grad_' + nm]), 1e-3, 1e-4, key + 'grad_' + nm)
+                assert_close(t.grad, torch.from_numpy(z[key + 'grad_' + nm]), 1e-4, 1e-5, key + 'grad_' + nm)
 
 
-@pytest.mark.parametrize('B', [1, 2, 17, 64, 257])
+@pytest.mark.parametrize('B', [1, 2, 17, 64, 257, 4096])
 def test_mano_matches_oracle(B):
+    """Values and input gradients against the CPU oracle evaluated in fp64 (its constants promoted: the same restatement of
+    models/manolayer.py:250-322 that tests/test_oracle_golden.py pins to the reference) at north_star's 1e-4 -- up to the
+    micro-benchmark's 4096 hands (round-5 verdict item 3 iii: until round 6 that size was only covered by invariances)."""
     from oracle import mano_oracle
     from renderih_amd.manolayer import rodrigues_batch
     d = assets.synthetic_mano_dict('right', seed=0)
-    c = mano_oracle.constants_from_dict(d)
+    c = {k: (v.double() if torch.is_tensor(v) else v) for k, v in mano_oracle.constants_from_dict(d).items()}
     layer = _layer('right', 9, True, False)
     g = torch.Generator().manual_seed(B)
     root = rodrigues_batch(torch.randn(B, 3, generator=g))
     pose, shape = torch.randn(B, 45, generator=g) * 0.7, torch.randn(B, 10, generator=g)
     trans, scale = torch.randn(B, 3, generator=g) * 0.1, torch.rand(B, generator=g) + 0.5
-    ins = [t.clone().requires_grad_(True) for t in (root, pose, shape, trans, scale)]
+    ins = [t.double().clone().requires_grad_(True) for t in (root, pose, shape, trans, scale)]
     vr, jr = mano_oracle.mano_forward(c, *ins)
     wv, wj = torch.randn(vr.shape, generator=g), torch.randn(jr.shape, generator=g)
-    ((vr * wv).sum() + (jr * wj).sum()).backward()
+    ((vr * wv.double()).sum() + (jr * wj.double()).sum()).backward()
     gin = [t.clone().to(dev()).requires_grad_(True) for t in (root, pose, shape, trans, scale)]
     v, j = layer(gin[0], gin[1], gin[2], trans=gin[3], scale=gin[4])
     assert_close(v, vr, 1e-4, 1e-5, 'v')
     assert_close(j, jr, 1e-4, 1e-5, 'j')
     ((v * wv.to(dev())).sum() + (j * wj.to(dev())).sum()).backward()
     for nm, a, b in zip(('root', 'pose', 'shape', 'trans', 'scale'), gin, ins):
-        assert_close(a.grad, b.grad, 1e-3, 1e-4, 'grad ' + nm)
+        assert_close(a.grad, b.grad, 1e-4, 1e-5, 'grad ' + nm)
 
 
 def test_mano_properties_large_batch():

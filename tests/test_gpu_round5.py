@@ -32,8 +32,8 @@ def _graph():
 
 
 # ------------------------------------------------------------------------------------------------ captured step, other magnitudes
-@pytest.mark.parametrize('bn_mode', ['train', 'frozen'])
-def test_captured_step_follows_the_data_magnitude(bn_mode, monkeypatch):
+@pytest.mark.parametrize('bn_mode,bsz', [('train', 2), ('frozen', 2), ('train', 16)])
+def test_captured_step_follows_the_data_magnitude(bn_mode, bsz, monkeypatch):
     """TrainStep captured on batch A (engine 2: every GEMM's power-of-two operand scales come from bound blocks written by
     kernels INSIDE the graph) and replayed on A, 1000 A, A / 1000 (A / 100 with batch statistics) and A with one pixel at 1e4: outputs and every parameter
     gradient of each replay against an eager engine-0 (native f32 MFMA) run of the same model on the same data, inside the
@@ -47,7 +47,12 @@ def test_captured_step_follows_the_data_magnitude(bn_mode, monkeypatch):
     this test is after -- a stale bound -- shows as inf / NaN or as errors of order one, which the gross bound catches.  Nothing
     may be inf / NaN.  A stale or capture-time bound would overflow the fp16 planes at 1000 A (inf) or
     flush A / 1000 to zero.  bn_mode 'frozen' = eval-mode BatchNorm (running statistics) with autograd on: the magnitude then
-    travels through the whole trunk instead of being normalised away by the stem's batch statistics."""
+    travels through the whole trunk instead of being normalised away by the stem's batch statistics.
+    Round 6 (verdict item 3 i): the B = 2 probe is ill conditioned (128 statistics samples at the 8 x 8 level), so (a) the same test
+    runs at B = 16 -- 1024 samples, where the reference pinned a fixture (net_train_b16.npz) -- with the ResNet test's own 0.5 %
+    allowance, and (b) at B = 2 the 3 % allowance of round 5 is no longer taken on faith: the CPU fp32 ORACLE's gradients on the same
+    data (another fp32 summation order of the same network, pinned to the reference) go through the same band, and the HIP path
+    may have at most 1 % of its tensors outside OR no more than that independent fp32 implementation has (+ 2)."""
     from oracle import net_oracle
     from renderih_amd import ops
     from renderih_amd.train import TrainStep
@@ -55,7 +60,7 @@ def test_captured_step_follows_the_data_magnitude(bn_mode, monkeypatch):
     if ops.ENGINE != 2:
         pytest.skip('engine 2 is not the configured engine')
     training = bn_mode == 'train'
-    A = testing.seeded_image(2, 51)
+    A = testing.seeded_image(bsz, 51)
     spike = A.clone()
     spike[0, 1, 100, 37] = 1e4
     # (train mode: A / 100, not A / 1000 -- at A / 1000 the stem's batch variance (2e-6) drops below BatchNorm's eps (1e-5), the
@@ -63,6 +68,8 @@ def test_captured_step_follows_the_data_magnitude(bn_mode, monkeypatch):
     # a degenerate operating point that says nothing about operand scales.  With frozen statistics the full 1e-3 is used.)
     small = 1e-2 if training else 1e-3
     variants = [('A', A), ('1e3 A', 1e3 * A), ('%g A' % small, small * A), ('A + one 1e4 pixel', spike)]
+    if bsz > 2:
+        variants = variants[:3]         # (the fp64 oracle run per variant is the cost of this test: ~1 min each at B = 16)
     m2, sd = _build(0.0, seed=13)
     m2.train(training)
     m2.decoder.unsample_layer.weight.requires_grad_(False)
@@ -109,9 +116,18 @@ def test_captured_step_follows_the_data_magnitude(bn_mode, monkeypatch):
             for k in w64:
                 worst = max(worst, testing.assert_fp32_equivalent(got_out[k], w0[k], w64[k], k=4.0, floor=2e-5,
                                                                   what='%s (%s): %s' % (name, bn_mode, k)))
-            nloose, n = _grad_report(got, g0, g64, max_loose=0.03)
-            print('replay on %-18s (%s): outputs worst %.3g vs fp64 (engine 0: %.3g); gradients %d/%d outside the band'
-                  % (name, bn_mode, worst[0], worst[1], nloose, n))
+            if bsz > 2:
+                nloose, n = _grad_report(got, g0, g64, max_loose=0.005)
+                nctl = -1
+            else:
+                nloose, n = _grad_report(got, g0, g64, max_loose=0.03)      # (gross bound + the round-5 ceiling)
+                # control: the CPU fp32 oracle through the same band
+                _, g32o = net_oracle.run(sd, graph, X, training, torch.float32, True)
+                nctl, _ = _grad_report([(k, g32o[k]) for k, _ in got], g0, g64, max_loose=None)
+                assert nloose <= max(0.01 * n, nctl + 2), (
+                    '%s: %d of %d HIP gradient tensors outside the band, the independent fp32 oracle has %d' % (name, nloose, n, nctl))
+            print('replay on %-18s (%s, B = %d): outputs worst %.3g vs fp64 (engine 0: %.3g); gradients %d/%d outside the band '
+                  '(fp32 oracle control: %d)' % (name, bn_mode, bsz, worst[0], worst[1], nloose, n, nctl))
     finally:
         ops.DROPOUT_SEED_TENSOR = None
 

@@ -24,8 +24,10 @@ def main():
     from renderih_amd import testing
     from renderih_amd.model import build_model
     from renderih_amd.train import TrainStep
+    enc = os.environ.get('RIH_TEST_ENCODER', 'resnet50')
+    nstage = 4 if enc.startswith('hrnet') else 3        # HRNet (round 6): cuts behind stage 2, stage 3 and the trunk
     with emulated_abi():
-        m = build_model(0.0)
+        m = build_model(0.0, enc)
         m.load_state_dict(testing.deterministic_state(m.state_dict(), seed=2 + rank))      # ranks start DIFFERENT
         m.decoder.unsample_layer.weight.requires_grad_(False)          # core/gcn_trainer.py:102-103
         m.train()
@@ -53,7 +55,7 @@ def main():
         for k, p in m.named_parameters():
             p.data.copy_(before[k])
         step(img, {})
-        assert order == [('stage', 0), ('reduce', 0), ('stage', 1), ('reduce', 1), ('stage', 2), ('reduce', 2)], order
+        assert order == [(w, i) for i in range(nstage) for w in ('stage', 'reduce')], order
         n_live = 0
         worst = 0.0
         # (a gradient that is mathematically zero -- the key bias of a softmax attention -- is pure round-off, whose value
@@ -67,13 +69,14 @@ def main():
                     want /= world
                 assert p.grad is not None, k
                 err = float((p.grad - want).abs().max() / (want.abs().max() + 1e-6 * gmax))
-                worst = max(worst, err)
-                assert err < 2e-5, (k, err)
+                if not testing.is_null_gradient(k):      # (mathematically zero gradients are round-off only, see above)
+                    worst = max(worst, err)
+                    assert err < 2e-5, (k, err)
                 n_live += 1
             else:
                 assert p.grad is None, k
         sizes = step.bucket_bytes()
-        assert len(sizes) == 3 and sum(len(v) for v in step.live) == n_live
+        assert len(sizes) == nstage and sum(len(v) for v in step.live) == n_live and all(b > 0 for b in sizes)
         if world > 1:
             flat = torch.cat([p.detach().flatten() for p in m.parameters()])
             ref = flat.clone()
@@ -82,7 +85,7 @@ def main():
         # ZeRO-1 as the reference's trainer builds it for distributed runs (core/gcn_trainer.py:121-125: torch's
         # ZeroRedundancyOptimizer shards the optimiser state over the ranks): TrainStep only calls optimizer.step(), so the
         # sharded optimiser drops in -- same parameters on every rank afterwards, and the same update as the plain optimiser
-        if world > 1:
+        if world > 1 and nstage == 3:
             from torch.distributed.optim import ZeroRedundancyOptimizer
             after_plain = {k: p.detach().clone() for k, p in m.named_parameters()}
             for k, p in m.named_parameters():
