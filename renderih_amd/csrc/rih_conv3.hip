@@ -756,6 +756,9 @@ void panel_launch(const PanelArgs& a, unsigned grid, bool stats, bool res, hipSt
 // Epilogue: optional residual (requested before the staging round trip), ReLU, BatchNorm statistics per 32 TM rows of a wave
 // (rih_gemm_desc.stats format).  Preconditions (rih_rows_ok): K % 32 == 0, K >= 64, N % 64 == 0, M % 128 == 0, 16-byte aligned
 // operands, pitches % 4 == 0, A < 2 GiB.
+#ifndef RIH_ROWS_COUNTED_WAITS
+#define RIH_ROWS_COUNTED_WAITS 0
+#endif
 struct RowsArgs {
     const float* a;
     const unsigned char* w;     // H2 planes [N][K / 8][2][8 halves]
@@ -774,7 +777,9 @@ struct RowsArgs {
 // one tap of one output pixel is ONE float4 -- the loader's quad (row, cq) reads the pixel under tap 8 kt + cq of output pixel `row`
 // (zero outside the image, zero for the taps 49..55 that pad K = 196 to 224); everything behind the loader is the rows kernel.
 template <int BM, int BN, bool STATS, bool RES, bool STEM = false>
-__global__ __launch_bounds__(NT, BM == 128 ? 4 : 2) void rows_kernel(const RowsArgs p) {      // (128-row tiles: two workgroups per CU)
+__global__ __launch_bounds__(NT, 2) void rows_kernel(const RowsArgs p) {
+    // (two wavefronts per SIMD = 256 registers for every tile: a SPILL of a register that an inline-assembly load is still writing
+    // would store garbage -- at the 128-register budget of two 128-row workgroups per CU two variants spilled 2-5 registers)
     constexpr int WGN = 2, WGM = 4;                     // waves 4 (M) x 2 (N)
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;               // 2 x 2, 1 x 2, 2 x 1, 1 x 1
     static_assert(TM >= 1 && TN >= 1, "wave tile");
@@ -923,9 +928,15 @@ __global__ __launch_bounds__(NT, BM == 128 ? 4 : 2) void rows_kernel(const RowsA
 
     // Schedule.  Iteration j multiplies k-tile j (A in LDS stage j & 1, W in stage j % 3).  At its top it requests the weights AND the
     // A rows of k-tile j + 2 (weights: LDS-DMA into the stage read in iteration j - 1; rows: into the register set converted at the
-    // end of iteration j - 1).  After the MFMAs it waits until only THIS iteration's NPB + NPA requests are outstanding -- everything
-    // requested at the top of iteration j - 1, i.e. the weights and the rows of k-tile j + 1, has then had TWO k-tiles of MFMAs to
-    // land --, converts those rows into the other A stage and meets the barrier that publishes both.
+    // end of iteration j - 1); after the MFMAs it waits, converts the rows of k-tile j + 1 into the other A stage and meets the
+    // barrier that publishes both.
+    // THE WAIT IS vmcnt(0).  The design was a counted wait -- vmcnt(NPB + NPA): "only this iteration's requests may be outstanding",
+    // which leaves every request two k-tiles of MFMAs to land -- and it is WRONG on this part: with LDS-DMA requests and buffer
+    // loads in one queue a counted wait does not guarantee that the OLDER buffer loads have returned.  Measured (round 6,
+    // tools/r6_stress_rows.py, profiles/r06/rows/c14_*): 6 of 800 launches wrote rows computed from registers whose load had not
+    // landed (always whole load instructions: 32 rows at a stride of 8), only on the HBM-bound 262144 x 256 -> 64 shapes; with
+    // vmcnt(0) 0 of 800, and the step's gradients are bit-reproducible again.  The counted form (RIH_ROWS_COUNTED_WAITS=1) was 2.4 %
+    // faster on the rows launches, 0.4 % on the step.  hipcc never emits a counted wait across an LDS-DMA request either.
     unsigned char* Bc = Bbuf;                           // W stage of k-tile j, j + 1, j + 2 (rotating)
     unsigned char* Bn = Bbuf + B_ST;
     unsigned char* Bf = Bbuf + 2 * B_ST;
@@ -933,7 +944,7 @@ __global__ __launch_bounds__(NT, BM == 128 ? 4 : 2) void rows_kernel(const RowsA
     issue_B(1, Bn);
     RIH_RW_LOAD_A(0, 0)
     RIH_RW_LOAD_A(1, 1)
-    c3_vm_wait<NPA>();                                  // the weights of k-tiles 0 and 1 and the rows of k-tile 0 have landed
+    c3_vm_wait<RIH_ROWS_COUNTED_WAITS ? NPA : 0>();     // the weights of k-tiles 0 and 1 and the rows of k-tile 0 have landed
     RIH_RW_STORE_A(0, Abuf)
     __syncthreads();
     int j = 0;
@@ -943,7 +954,7 @@ __global__ __launch_bounds__(NT, BM == 128 ? 4 : 2) void rows_kernel(const RowsA
         RIH_RW_LOAD_A(PAR_, j + 2)                                                                                           \
         multiply(Abuf + PAR_ * A_ST, Bc);                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
-        c3_vm_wait<NPB + NPA>();                                                                                             \
+        c3_vm_wait<RIH_ROWS_COUNTED_WAITS ? NPB + NPA : 0>();                                                                \
         if (j + 1 < nk) RIH_RW_STORE_A(1 - PAR_, Abuf + (1 - PAR_) * A_ST)                                                   \
         __syncthreads();                                                                                                     \
         unsigned char* const t_ = Bc;                                                                                        \
@@ -955,8 +966,22 @@ __global__ __launch_bounds__(NT, BM == 128 ? 4 : 2) void rows_kernel(const RowsA
         RIH_RW_ITER(0)
         RIH_RW_ITER(1)
     }
-    if (j < nk) RIH_RW_ITER(0)                          // (an odd trip count ends on an even k-tile)
-    c3_vm_wait<0>();                                    // (the tail's surplus requests: nothing may land in LDS behind the epilogue's staging)
+    // The compiler does not know that the registers of an inline-assembly load are written LATER: a request whose result nothing
+    // reads is a dead definition to it, and it may hand the destination registers to the next instruction that needs some -- the
+    // load then lands on top of a live value.  (Found on the GPU in round 6: with an odd trip count the last iteration, a separate
+    // copy of the loop body, issued its surplus out-of-range requests into dead registers that the MFMA operand fetches re-used;
+    // results were wrong and changed from run to run, the host harness -- where a load completes at once -- passed.)  So: every
+    // request of the loop has a consumer in the next iteration's conversion (possibly never executed, but live for the register
+    // allocator), the odd trip count's last k-tile issues NO request, and everything still in flight is drained behind a scheduling
+    // barrier before the first instruction of the epilogue.
+    if (j < nk) {                                       // (an odd trip count ends on an even k-tile: A stage 0)
+        c3_vm_wait<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(Abuf, Bc);
+        __syncthreads();
+    }
+    c3_vm_wait<0>();                                    // (the surplus requests of the last iterations: nothing may land behind this line)
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
 #undef RIH_RW_ITER
 #undef RIH_RW_LOAD_A
