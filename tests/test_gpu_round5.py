@@ -120,8 +120,11 @@ def test_captured_step_follows_the_data_magnitude(bn_mode, bsz, monkeypatch):
                 nloose, n = _grad_report(got, g0, g64, max_loose=0.005)
                 nctl = -1
             else:
-                nloose, n = _grad_report(got, g0, g64, max_loose=0.03)      # (gross bound + the round-5 ceiling)
-                # control: the CPU fp32 oracle through the same band
+                nloose, n = _grad_report(got, g0, g64, max_loose=1.0)       # (the gross bound: nothing beyond max(5 %, 20 x))
+                # control: the CPU fp32 oracle through the same band.  (Round 6: with the stem convolution on engine 2 the outlier
+                # variant of the frozen-statistics run has 146 tensors outside the band -- and the fp32 oracle 300: one pixel of
+                # 1e4 in an image of unit variance makes every product of its receptive field ill conditioned in ANY fp32
+                # arithmetic, tools-side check in DESIGN 4.)
                 _, g32o = net_oracle.run(sd, graph, X, training, torch.float32, True)
                 nctl, _ = _grad_report([(k, g32o[k]) for k, _ in got], g0, g64, max_loose=None)
                 assert nloose <= max(0.01 * n, nctl + 2), (
