@@ -21,8 +21,8 @@ for r in csv.DictReader(open(f)):
         steps = globals().get('steps', 0) + 1       # one launch per step: the number of steps the collection saw
     if 'gemm_' in k:
         name = k[k.index('gemm'):k.index('>') + 1]
-    elif 'conv3x3_halo_kernel' in k or 'panel_kernel' in k:         # round 5: the halo-resident 3x3 and the streaming 1x1 kernels
-        i0 = k.index('conv3x3_halo') if 'conv3x3_halo' in k else k.index('panel_kernel')
+    elif 'conv3x3_halo_kernel' in k or 'panel_kernel' in k or 'rows_kernel' in k:   # rounds 5-6: halo 3x3, streaming 1x1, long-K rows / stem
+        i0 = k.index('conv3x3_halo') if 'conv3x3_halo' in k else k.index('panel_kernel') if 'panel_kernel' in k else k.index('rows_kernel')
         name = 'gemm-family ' + k[i0:k.index('>') + 1]
     elif 'flash_' in k:
         name = 'gemm-family ' + k[k.index('flash'):k.index('>') + 1]
