@@ -397,11 +397,26 @@ class TrainStep:
         for p in self.model.parameters():
             p.grad = None
         self.graphs, self.static = [], []
-        pool = None
         # pinned staging memory of captured host-to-device copies (launch tables of the grouped weight-gradient GEMMs): the
         # graphs re-read it at every replay, so it lives as long as this object; allocated HERE, before the capture (pinned
         # allocations are illegal while a stream captures), twice the size one warm-up step packed
         ops.TABLE_ARENA = self._table_arena = ops.TableArena(2 * ops.TABLE_BYTES_STEP + (1 << 16))
+        # No cyclic garbage collection while a stream captures: a collection that happens to run inside the capture finalises
+        # whatever garbage earlier code left behind (another TrainStep's graphs, pinned arenas, streams, tensors with recorded
+        # streams) and their destructors call HIP functions that are illegal during a capture -- the process aborts (seen once in
+        # round 6: "Fatal Python error: Aborted ... Garbage-collecting" inside BatchNormFn.forward of the first captured stage).
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            self._capture_stages(cap, seed_word)
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def _capture_stages(self, cap, seed_word):
+        pool = None
         with torch.cuda.stream(cap), ops.owned_bounds():
             carry, loss = None, None
             for i in range(self.nstage):

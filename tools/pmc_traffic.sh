@@ -19,13 +19,17 @@ for r in csv.DictReader(open(f)):
     k = r['Kernel_Name']
     if 'maxpool_fwd' in k:
         steps = globals().get('steps', 0) + 1       # one launch per step: the number of steps the collection saw
+    def upto(i0):       # the kernel's name from position i0 up to the end of its template arguments (or its parameter list)
+        j = k.find('>', i0)
+        j = j if j >= 0 else (k.find('(', i0) if k.find('(', i0) >= 0 else len(k)) - 1
+        return k[i0:j + 1]
     if 'gemm_' in k:
-        name = k[k.index('gemm'):k.index('>') + 1]
+        name = upto(k.index('gemm'))
     elif 'conv3x3_halo_kernel' in k or 'panel_kernel' in k or 'rows_kernel' in k:   # rounds 5-6: halo 3x3, streaming 1x1, long-K rows / stem
         i0 = k.index('conv3x3_halo') if 'conv3x3_halo' in k else k.index('panel_kernel') if 'panel_kernel' in k else k.index('rows_kernel')
-        name = 'gemm-family ' + k[i0:k.index('>') + 1]
+        name = 'gemm-family ' + upto(i0)
     elif 'flash_' in k:
-        name = 'gemm-family ' + k[k.index('flash'):k.index('>') + 1]
+        name = 'gemm-family ' + upto(k.index('flash'))
     else:
         name = 'other: ' + k.split('(')[0][-60:]
     a = agg.setdefault(name, [0, 0.0])
