@@ -62,12 +62,18 @@ def test_captured_step_follows_the_data_magnitude(bn_mode, bsz, monkeypatch):
     training = bn_mode == 'train'
     A = testing.seeded_image(bsz, 51)
     spike = A.clone()
-    spike[0, 1, 100, 37] = 1e4
+    # the outlier: 1e4 with batch statistics (the stem's BatchNorm normalises it away), 1e3 with frozen statistics -- there a pixel of
+    # 1e4 makes the probe itself ill conditioned: the fp64 oracle's gradients move by up to 3.3e-3 of their maximum (ten tensors by more
+    # than 2e-4) when the IMAGE is perturbed by 2^-22 relative, against 1.2e-4 / none at 1e3 and 1.8e-4 / none without an outlier
+    # (tools/r6_spike_conditioning.py, profiles/r06/spike_conditioning.txt).  1e3 is still 185 x the image's maximum: a bound left over
+    # from the capture batch would scale it to 4e6 and overflow the fp16 planes.
+    spike_mag = 1e4 if training else 1e3
+    spike[0, 1, 100, 37] = spike_mag
     # (train mode: A / 100, not A / 1000 -- at A / 1000 the stem's batch variance (2e-6) drops below BatchNorm's eps (1e-5), the
     # backward through that BatchNorm amplifies round-off ~300-fold and even the exact-fp32 engine's gradients are 3 % from fp64:
     # a degenerate operating point that says nothing about operand scales.  With frozen statistics the full 1e-3 is used.)
     small = 1e-2 if training else 1e-3
-    variants = [('A', A), ('1e3 A', 1e3 * A), ('%g A' % small, small * A), ('A + one 1e4 pixel', spike)]
+    variants = [('A', A), ('1e3 A', 1e3 * A), ('%g A' % small, small * A), ('A + one %g pixel' % spike_mag, spike)]
     if bsz > 2:
         variants = variants[:3]         # (the fp64 oracle run per variant is the cost of this test: ~1 min each at B = 16)
     m2, sd = _build(0.0, seed=13)
@@ -121,10 +127,7 @@ def test_captured_step_follows_the_data_magnitude(bn_mode, bsz, monkeypatch):
                 nctl = -1
             else:
                 nloose, n = _grad_report(got, g0, g64, max_loose=1.0)       # (the gross bound: nothing beyond max(5 %, 20 x))
-                # control: the CPU fp32 oracle through the same band.  (Round 6: with the stem convolution on engine 2 the outlier
-                # variant of the frozen-statistics run has 146 tensors outside the band -- and the fp32 oracle 300: one pixel of
-                # 1e4 in an image of unit variance makes every product of its receptive field ill conditioned in ANY fp32
-                # arithmetic, tools-side check in DESIGN 4.)
+                # control: the CPU fp32 oracle through the same band
                 _, g32o = net_oracle.run(sd, graph, X, training, torch.float32, True)
                 nctl, _ = _grad_report([(k, g32o[k]) for k, _ in got], g0, g64, max_loose=None)
                 assert nloose <= max(0.01 * n, nctl + 2), (

@@ -19,7 +19,7 @@ def main():
     d = {'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace, counters only) over `bench.py --steps 2 '
                    '--warmup 1 --no-graph --no-reference-loop` = %d eager TrainStep steps; tools/pmc_traffic.sh; %s' % (steps, what),
          'kernels': 'GEMM family: rih_gemm launches (gemm_kernel / gemm_split_kernel, engines 0 / 1 / 2), the grouped weight-gradient '
-                    'launches (gemm_split_multi_kernel) and the flash-attention kernels',
+                    'launches (gemm_split_multi_kernel) , the halo 3x3 / panel / rows / stem kernels (conv3x3_halo_kernel, panel_kernel, rows_kernel) and the flash-attention kernels',
          'launches_per_step': n,
          'fetch_KB_raw_per_step': fetch_kb, 'write_KB_raw_per_step': write_kb,
          'fetch_GB_per_step_corrected': round(2.0 * fetch_kb * 1000 / 1e9, 2),

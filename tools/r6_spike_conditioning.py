@@ -13,7 +13,8 @@ torch.set_num_threads(8)
 m = build_model(0.0); sd = testing.deterministic_state(m.state_dict(), seed=13)
 graph = net_oracle.graph_from_dicts(assets.load_graph_dict('left'), assets.load_graph_dict('right'))
 A = testing.seeded_image(2, 51); spike = A.clone(); spike[0,1,100,37] = 1e4
-for name, X in (('A', A), ('spike', spike)):
+s3 = A.clone(); s3[0,1,100,37] = 1e3
+for name, X in (('A', A), ('spike 1e3', s3), ('spike 1e4', spike)):
     _, g64 = net_oracle.run(sd, graph, X, False, torch.float64, True)
     _, g32 = net_oracle.run(sd, graph, X, False, torch.float32, True)
     # perturb the stem input representation like engine 2 would: relative error 2^-22 on the image -> how far do gradients move (fp64 run)?
