@@ -52,7 +52,6 @@ struct GemmArgs {
     unsigned a_bytes, b_bytes;      // extent of one batch slice of A / B (split fast path: buffer range check)
     int cS, cOH, cOW, cH, cW;       // strided output rows (parity classes of a strided-conv data gradient)
     int ones_row;                   // a_mode 1: A(ones_row, k) = 1 for every valid k (bias gradient row); 0 = off
-    unsigned a_plane;               // a_mode 2: bytes per pre-split plane of A (last: keeps the older kernels' kernarg offsets)
     int epi_vec;                    // C, R, bias and every stride involved are 16-byte aligned: the epilogue may use 16-byte accesses
     float* stats;                   // split fast path, a_mode 0, splitk 1: per wave-row-block column sums [M / WM][2][N] (or NULL)
     // dropout in the epilogue (DROP variants of the split fast path; appended last: the older kernels' kernarg offsets stay):
@@ -787,29 +786,16 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off)
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-__device__ __forceinline__ uint4 bloadu4(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-
-// BMODE 2: B arrives PRE-SPLIT -- three bf16 planes [hi | mid | lo][N][ldb] (k contiguous, ldb = K rounded up to 32,
-// zero padded), written once per step by rih_presplit_* because weights are constant within a step.  The B loader
-// is then a plain 16-byte copy global -> LDS (one 8-k chunk per lane and plane): no conversion instructions for B,
-// which is half of the split engine's VALU work on square tiles (see the plateau analysis above).
-// APRE (a_mode 2): A arrives pre-split as well -- planes [hi | mid | lo][pixels][lda] bf16, channels contiguous, written
-// by rih_presplit_matrix on the NHWC activation; AMODE must be 0 (im2col / plain rows), the loader is the BMODE 2 one
-// plus the per-row window offsets and tap validity bits.  With both operands pre-split the kernel converts nothing.
 // The kernel body takes the block coordinates as arguments: gemm_split_kernel passes blockIdx / gridDim, the grouped launch
 // (gemm_split_multi_kernel, rih_gemm_multi) the coordinates of a block inside ITS problem of a descriptor table.
 // ENG 2: the two-term fp16 split (three MFMA products, see e2_scale / split2h above) instead of the three-term bf16 one; same
-// loaders, LDS layout (two planes instead of three) and epilogue.  Not with pre-split operands.
-template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false, int ENG = 1,
+// loaders, LDS layout (two planes instead of three) and epilogue.
+template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool STATS = false, bool DROP = false, int ENG = 1,
           bool SEG = false, int PFD = 1>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk_x, const int blk_z, const int grid_x,
                                                 const int grid_z) {
-    static_assert(ENG == 1 || (ENG == 2 && !APRE), "engine 2: B may arrive as two pre-split fp16 planes (BMODE 2), A never");
-    static_assert(!SEG || (AMODE == 0 && PLAIN && !APRE), "a segmented A operand is a plain row-major one");
+    static_assert(BMODE == 0 || BMODE == 1, "B is row-major [K][N] (0) or [N][K] (1)");
+    static_assert(!SEG || (AMODE == 0 && PLAIN), "a segmented A operand is a plain row-major one");
     constexpr int NPL = (ENG == 2) ? 2 : 3;         // 16-bit planes per operand
     // global->register prefetch depth: k-tiles in flight.  The 64x64 tile (decoder-sized problems: a handful of
     // k-tiles, 12 MFMAs each) is bound by the load round trip per k-tile, so it keeps three tiles in flight.
@@ -958,7 +944,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
         }
         const int o = lds_row(row8) + 4 * ((q8 >> 1) ^ lds_swz(row8)) + 2 * (q8 & 1);
         b_st[0] = o; b_st[1] = o + 512; b_st[2] = o + 1024; b_st[3] = o + 1536;
-    } else {        // BMODE 0 (for BMODE 2 these values are dead)
+    } else {        // BMODE 0
         const int n = n0 + 4 * bnq;
         const unsigned base = (n < p.N) ? ((unsigned)(bkr * NPB) * (unsigned)p.ldb + (unsigned)n) * 4u : OOB;
 #pragma unroll
@@ -967,53 +953,6 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
         const int sw = (NPB == 4) ? 4 * ((bkr >> 1) ^ (bnq & 3)) + 2 * (bkr & 1) : 4 * ((bkr >> 2) ^ (bnq & 3)) + (bkr & 3);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b_st[j] = (4 * bnq + (j ^ fl)) * 16 + sw;
-    }
-
-    // APRE: lane = (row tid>>2 (+64 per pass), 8-channel chunk tid&3) of every plane
-    constexpr int APASS = (BM + 63) / 64;
-    unsigned ap_off[APASS], ap_val[APASS];
-    int ap_st[APASS];
-    if (APRE) {
-#pragma unroll
-        for (int i = 0; i < APASS; ++i) {
-            const int r = (tid >> 2) + 64 * i;
-            const int m = m0 + r;
-            ap_val[i] = 0;
-            ap_st[i] = lds_row(r) + 4 * ((tid & 3) ^ lds_swz(r));
-            if (m >= p.M || r >= BM) {
-                ap_off[i] = OOB;
-            } else if (PLAIN) {
-                ap_off[i] = ((unsigned)m * (unsigned)p.lda + 8u * (tid & 3)) * 2u;
-            } else {
-                const int wo = m % p.Wo;
-                const int t = m / p.Wo;
-                const int ho = t % p.Ho;
-                const int img = t / p.Ho;
-                const int hi0 = ho * p.strideA - p.padH, wi0 = wo * p.strideA - p.padW;
-                ap_off[i] = (unsigned)((((img * p.H + hi0) * p.W + wi0) * p.lda + 8 * (tid & 3)) * 2);
-                unsigned bits = 0;
-                for (int kh = 0; kh < p.KH; ++kh)
-                    for (int kw = 0; kw < p.KW; ++kw)
-                        if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W)
-                            bits |= 1u << (kh * p.KW + kw);
-                ap_val[i] = bits;
-            }
-        }
-    }
-
-    // BMODE 2 (pre-split planes): lane = (row tid>>2 (+64 per pass), 8-k chunk tid&3)
-    constexpr int BPASS = (BN + 63) / 64;
-    unsigned bp_off[BPASS];
-    int bp_st[BPASS];
-    const unsigned bp_plane = (unsigned)p.N * (unsigned)p.ldb * 2u;      // bytes per plane
-    if (BMODE == 2) {
-#pragma unroll
-        for (int i = 0; i < BPASS; ++i) {
-            const int r = (tid >> 2) + 64 * i;
-            const int n = n0 + r;
-            bp_off[i] = (n < p.N && r < BN) ? ((unsigned)n * (unsigned)p.ldb + 8u * (tid & 3)) * 2u : OOB;
-            bp_st[i] = lds_row(r) + 4 * ((tid & 3) ^ lds_swz(r));
-        }
     }
 
     // wave-uniform walk over (tap, channel) for the conv A-gather: one tap per k-tile (Cin % 32 == 0)
@@ -1026,27 +965,9 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
     }
 
     float4 areg[PF][NPA], breg[PF][NPB];
-    uint4 bpre[PF][3][BPASS];
-    uint4 apre[PF][3][APASS];
 
     auto load_A = [&](int ktile, int st) {
-        if (APRE) {
-            unsigned add, bit;
-            if (PLAIN) {
-                add = (unsigned)ktile * 2u;
-                bit = (ktile < kend) ? 1u : 0u;
-            } else {
-                add = (unsigned)(((u_kh * p.W + u_kw) * p.lda + u_ci) * 2);
-                bit = (ktile < kend) ? (1u << (u_tap & 31)) : 0u;
-            }
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int i = 0; i < APASS; ++i) {
-                    const bool ok = PLAIN ? (bit != 0u && ap_off[i] != OOB) : ((ap_val[i] & bit) != 0u);
-                    apre[st][pl][i] = bloadu4(rA, ok ? ap_off[i] + add + (unsigned)pl * p.a_plane : OOB);
-                }
-        } else if (AMODE == 0) {
+        if (AMODE == 0) {
             if (PLAIN && SEG) {
                 // the k-tile lies in ONE segment (boundaries are multiples of 32): wave-uniform choice of base, pitch and extent;
                 // a channel concatenation (models/encoder.py:165-173) is read in place, never materialised
@@ -1116,14 +1037,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
         }
     };
     auto load_B = [&](int ktile, int st) {
-        if (BMODE == 2) {
-            const unsigned ku = (ktile < kend) ? (unsigned)ktile * 2u : OOB;
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl)
-#pragma unroll
-                for (int i = 0; i < BPASS; ++i)
-                    bpre[st][pl][i] = bloadu4(rB, (bp_off[i] == OOB || ku == OOB) ? OOB : bp_off[i] + (unsigned)pl * bp_plane + ku);
-        } else if (BMODE == 1) {
+        if (BMODE == 1) {
             const unsigned ku = (ktile + 4 * q8 < kend) ? (unsigned)ktile * 4u : OOB;
 #pragma unroll
             for (int i = 0; i < NPB; ++i) breg[st][i] = bload4(rB, b_off[i] + ku);
@@ -1184,23 +1098,11 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
         }
     };
     auto store_A = [&](int st) {
-        if (APRE) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int i = 0; i < APASS; ++i)
-                    if ((tid >> 2) + 64 * i < BM) *reinterpret_cast<uint4*>(As + pl * PLANE_A + ap_st[i]) = apre[st][pl][i];
-        } else if (AMODE == 0) store_kcontig(As, PLANE_A, e2_sa, areg[st], a_st, NPA);
+        if (AMODE == 0) store_kcontig(As, PLANE_A, e2_sa, areg[st], a_st, NPA);
         else store_kstrided(As, PLANE_A, e2_sa, areg[st], a_st, NPA);
     };
     auto store_B = [&](int st) {
-        if (BMODE == 2) {
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl)
-#pragma unroll
-                for (int i = 0; i < BPASS; ++i)
-                    if ((tid >> 2) + 64 * i < BN) *reinterpret_cast<uint4*>(Bs + pl * PLANE_B + bp_st[i]) = bpre[st][pl][i];
-        } else if (BMODE == 1) store_kcontig(Bs, PLANE_B, e2_sb, breg[st], b_st, NPB);
+        if (BMODE == 1) store_kcontig(Bs, PLANE_B, e2_sb, breg[st], b_st, NPB);
         else store_kstrided(Bs, PLANE_B, e2_sb, breg[st], b_st, NPB);
     };
 
@@ -1246,9 +1148,8 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
         // barriers.  The global loads of tile t+2 go out when the registers of tile t+1 have been converted.
         constexpr int UA = (AMODE == 0) ? NPA : 4, UB = (BMODE == 1) ? NPB : 4;      // conversion units (one LDS row segment each)
         constexpr bool A4 = (AMODE == 0) || (NPA == 4), B4 = (BMODE == 1) || (NPB == 4);   // four values per unit (else two)
-        // half-units: one pair of values each; a pre-split B (BMODE 2) has nothing to convert -- one 16-byte LDS store per plane
-        // and pass instead
-        constexpr int HA = A4 ? 2 * UA : UA, HB = (BMODE == 2) ? NPL * BPASS : (B4 ? 2 * UB : UB);
+        // half-units: one pair of values each
+        constexpr int HA = A4 ? 2 * UA : UA, HB = B4 ? 2 * UB : UB;
         constexpr int NH = HA + HB;
         auto comp = [](const float4& v, int c) -> float { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
         unsigned hu_h = 0, hu_l = 0;        // first pair of the unit in flight
@@ -1256,11 +1157,6 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
         auto half_unit = [&](int q, unsigned* sA, unsigned* sB) {
             const bool isA = q < HA;
             const int r = isA ? q : q - HA;
-            if (BMODE == 2 && !isA) {
-                const int pl = r / BPASS, i = r % BPASS;
-                if ((tid >> 2) + 64 * i < BN) *reinterpret_cast<uint4*>(sB + pl * PLANE_B + bp_st[i]) = bpre[0][pl][i];
-                return;
-            }
             const bool four = isA ? A4 : B4;
             const int u = four ? (r >> 1) : r, h = four ? (r & 1) : 0;
             const float sc = isA ? e2_sa : e2_sb;
@@ -1415,10 +1311,10 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
     }
 }
 
-template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool APRE = false, bool STATS = false, bool DROP = false, int ENG = 1,
+template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool STATS = false, bool DROP = false, int ENG = 1,
           bool SEG = false, int PFD = 1>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
-    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, APRE, STATS, DROP, ENG, SEG, PFD>(p, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.x,
+    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, STATS, DROP, ENG, SEG, PFD>(p, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.x,
                                                                               (int)gridDim.z);
 }
 
@@ -1458,23 +1354,20 @@ __global__ __launch_bounds__(256, 2) void gemm_split_multi_kernel(const unsigned
     const int gx = pr->gx, gz = pr->gz;
     if (lb >= gx * gz) return;              // padding block
     const GemmArgs p = pr->a;               // scalar loads; the copy lives in SGPRs like a kernel argument
-    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, false, false, false, ENG>(p, lb % gx, lb / gx, gx, gz);
+    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, false, false, ENG>(p, lb % gx, lb / gx, gx, gz);
 }
 
 template <int BM, int BN>
 int launch_split_e2(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 grid, hipStream_t s) {
     dim3 block(256);
 #define RIH_L2(AM_, BM_, PL_, ST_, DR_) \
-    hipLaunchKernelGGL((gemm_split_kernel<BM, BN, AM_, BM_, PL_, false, ST_, DR_, 2>), grid, block, 0, s, a)
-    if (a_mode > 1 || b_mode > 2 || (b_mode == 2 && a_mode != 0)) return RIH_EINVAL;
+    hipLaunchKernelGGL((gemm_split_kernel<BM, BN, AM_, BM_, PL_, ST_, DR_, 2>), grid, block, 0, s, a)
+    if (a_mode > 1 || b_mode > 1) return RIH_EINVAL;
     if (a.Aseg[0] != nullptr) {         // segmented A: plain rows x [N][K] weight (checked by the caller), with / without statistics
-        if (a.stats != nullptr) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, true, false, 2, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, false, false, 2, true>), grid, block, 0, s, a);
+        if (a.stats != nullptr) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, true, false, 2, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, false, 2, true>), grid, block, 0, s, a);
         return (int)hipGetLastError();
     }
-    if (b_mode == 2) {          // B pre-split into two fp16 planes (weights, once per step)
-        return RIH_EINVAL;
-    } else
     if (a.drop_thr != 0u) {
         if (b_mode == 0) RIH_L2(0, 0, true, false, true); else RIH_L2(0, 1, true, false, true);
     } else if (a.stats != nullptr) {
@@ -1493,18 +1386,18 @@ template <int BM, int BN>
 int launch_split(const GemmArgs& a, int a_mode, int b_mode, bool plain, dim3 grid, hipStream_t s) {
     dim3 block(256);
 #define RIH_LS(AM_, BM_, PL_) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, AM_, BM_, PL_>), grid, block, 0, s, a)
-    if (a_mode == 2 || b_mode == 2) return RIH_EINVAL;      // pre-split operands: experiment builds only
+    if (a_mode > 1 || b_mode > 1) return RIH_EINVAL;
     if (a.Aseg[0] != nullptr) {         // segmented A (see launch_split_e2)
-        if (a.stats != nullptr) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, true, false, 1, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, false, false, 1, true>), grid, block, 0, s, a);
+        if (a.stats != nullptr) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, true, false, 1, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, false, 1, true>), grid, block, 0, s, a);
         return (int)hipGetLastError();
     }
     if (a.drop_thr != 0u) {        // dropout epilogue: plain a_mode-0 GEMMs only (checked by the caller)
-        if (b_mode == 0) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 0, true, false, false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, false, true>), grid, block, 0, s, a);
+        if (b_mode == 0) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 0, true, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, 1, true, false, true>), grid, block, 0, s, a);
     }
     else if (a.stats != nullptr) {      // statistics epilogue: forward-type GEMMs only (checked by the caller)
-#define RIH_LSS(BM_, PL_) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, BM_, PL_, false, true>), grid, block, 0, s, a)
+#define RIH_LSS(BM_, PL_) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, 0, BM_, PL_, true>), grid, block, 0, s, a)
         if (b_mode == 0) { if (plain) RIH_LSS(0, true); else RIH_LSS(0, false); }
         else { if (plain) RIH_LSS(1, true); else RIH_LSS(1, false); }
 #undef RIH_LSS
@@ -1764,15 +1657,7 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
         if (imgs * d->H * d->W * (long long)d->lda >= (1ll << 31)) return RIH_EINVAL;
         const long long rowsB = (d->b_mode == 0) ? (long long)d->K : (long long)d->N;
         if (rowsB * (long long)d->ldb >= (1ll << 31)) return RIH_EINVAL;
-        if (d->b_mode < 0 || d->b_mode > 2 || d->a_mode < 0 || d->a_mode > 2) return RIH_EINVAL;
-        if (d->a_mode == 2 && (d->b_mode != 2 || d->lda % 8 != 0 || d->sA1 != 0 || d->sA2 != 0 || d->nb1 * d->nb2 != 1 ||
-                               d->K % 32 != 0 || d->Cin % 32 != 0))
-            return RIH_EINVAL;      // pre-split A: im2col / plain rows of bf16 planes, together with pre-split B only
-        if (d->b_mode == 2 && (d->a_mode == 1 || d->engine < 1 || d->ldb % 32 != 0 || d->ldb < d->K || d->sB1 != 0 ||
-                               d->sB2 != 0 || d->tile > 2 || d->upS != 1))
-            return RIH_EINVAL;      // pre-split B: forward-type GEMMs on the split engines' fast path only
-        if (d->b_mode == 2 && d->engine == 2 && (d->a_mode != 0 || d->drop_p != 0.f))
-            return RIH_EINVAL;      // engine 2: two fp16 planes scaled by amax_b's bound (rih_presplit_* with amax_e2), plain A
+        if (d->b_mode < 0 || d->b_mode > 1 || d->a_mode < 0 || d->a_mode > 1) return RIH_EINVAL;
         if (d->H > 16000 || d->W > 16000 || d->Ho > 16000 || d->Wo > 16000 || d->strideA > 64 || d->padH > 64 ||
             d->padW > 64 || d->KH > 64 || d->KW > 64)
             return RIH_EINVAL;
@@ -1794,7 +1679,6 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
     a.vecA = a16 ? 1 : 0;
     a.vecB = b16 ? 1 : 0;
     a.a_bytes = a.b_bytes = 0;
-    a.a_plane = 0;
     a.cS = d->cS; a.cOH = d->cOH; a.cOW = d->cOW; a.cH = d->cH; a.cW = d->cW;
     a.ones_row = d->ones_row;
     a.stats = d->stats;
@@ -1856,10 +1740,9 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
     dim3 grid((unsigned)tiles, 1, (unsigned)gz);
     hipStream_t s = (hipStream_t)stream;
     if (d->engine < 0 || d->engine > 2) return RIH_EINVAL;
-    if (d->a_mode > 1 || d->b_mode > 1) return RIH_EINVAL;
     // engine 2 exists on the split engines' fast path only (tiles 0..2, operands converted by the kernel): anything else that
     // asks for it runs engine 1 -- same fp32-grade result, the six-product arithmetic (rih_gemm_engine tells in advance)
-    const bool e2 = d->engine == 2 && d->tile <= 2 && d->a_mode <= 1 && (d->b_mode <= 1 || (d->b_mode == 2 && d->a_mode == 0));
+    const bool e2 = d->engine == 2 && d->tile <= 2;
     const int engine = d->engine == 2 ? 1 : d->engine;
     if (engine_out != nullptr) *engine_out = engine;
     if (engine == 1 && d->tile != 3 && a16 && b16 && d->upS == 1 && d->K % 4 == 0) {
@@ -1870,39 +1753,32 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
         const long long imgs = (rowsA + (long long)d->Ho * d->Wo - 1) / ((long long)d->Ho * d->Wo);
         const int colsA = seg ? d->k_seg[0] : (d->a_mode != 1) ? d->K : (d->ones_row > 0 ? d->ones_row : d->M);
         const long long a_rows = plain ? rowsA : imgs * d->H * d->W;
-        const long long a_plane = a_rows * d->lda * 2ll;                   // a_mode 2: bytes per bf16 plane
-        const long long a_bytes = (d->a_mode == 2) ? 3ll * a_plane
-                                  : plain ? ((rowsA - 1) * d->lda + colsA) * 4ll
-                                          : imgs * d->H * d->W * (long long)d->lda * 4ll;
+        const long long a_bytes = plain ? ((rowsA - 1) * d->lda + colsA) * 4ll : a_rows * (long long)d->lda * 4ll;
         const long long rowsB = (d->b_mode == 0) ? (long long)d->K : (long long)d->N;
-        const long long b_bytes = (d->b_mode == 2) ? (e2 ? 2ll : 3ll) * d->N * d->ldb * 2ll
-                                                   : ((rowsB - 1) * d->ldb + ((d->b_mode == 0) ? d->N : d->K)) * 4ll;
+        const long long b_bytes = ((rowsB - 1) * d->ldb + ((d->b_mode == 0) ? d->N : d->K)) * 4ll;
         bool ok = a_bytes < (1ll << 31) && b_bytes < (1ll << 31) && d->K >= 1;
         if (d->a_mode != 1 && !plain) ok = ok && (d->Cin % 32 == 0) && (d->KH * d->KW <= 32);
         if (d->a_mode == 1) ok = ok && (d->M % 4 == 0) && (plain || (d->Wo % 4 == 0 && d->Cin % 4 == 0));
         if (d->b_mode == 0) ok = ok && (d->N % 4 == 0);
-        const bool b_stats_ok = d->b_mode <= 1 || (e2 && d->b_mode == 2);      // (engine 1's pre-split B path has no statistics variant)
-        if (d->stats != nullptr && !(ok && d->tile <= 2 && d->a_mode == 0 && b_stats_ok && d->splitk == 1 && gz == 1 &&
+        if (d->stats != nullptr && !(ok && d->tile <= 2 && d->a_mode == 0 && d->splitk == 1 && gz == 1 &&
                                      d->cS <= 1))
             return RIH_EINVAL;      // the statistics epilogue exists on this path only (rih_gemm_stats_rows tells in advance)
         // the dropout epilogue exists for plain row-major GEMMs on this path only (rih_gemm_dropout_ok tells in advance)
-        if (d->drop_p != 0.f && !(ok && d->tile <= 2 && d->a_mode == 0 && d->b_mode <= 1 && plain && d->splitk == 1 &&
+        if (d->drop_p != 0.f && !(ok && d->tile <= 2 && d->a_mode == 0 && plain && d->splitk == 1 &&
                                   d->cS <= 1 && d->stats == nullptr && !(d->relu && d->R != nullptr) && prep == nullptr))
             return RIH_EINVAL;
         if (stats_rows != nullptr) {
-            *stats_rows = (ok && d->tile <= 2 && d->a_mode == 0 && b_stats_ok && d->splitk == 1 && gz == 1 && d->cS <= 1)
+            *stats_rows = (ok && d->tile <= 2 && d->a_mode == 0 && d->splitk == 1 && gz == 1 && d->cS <= 1)
                               ? bm / 2 : 0;
             return 0;
         }
-        if (d->b_mode == 2 && d->engine == 2 && !(ok && e2)) return RIH_EINVAL;     // (no kernel reads two fp16 planes elsewhere)
         if (seg && (!ok || prep != nullptr)) return RIH_EINVAL;                      // (no other kernel reads a segmented A)
         if (ok) {
             a.a_bytes = (unsigned)a_bytes;
             a.b_bytes = (unsigned)b_bytes;
-            a.a_plane = (unsigned)a_plane;
             if (engine_out != nullptr) *engine_out = e2 ? 2 : 1;
             if (prep != nullptr) {
-                if (d->stats != nullptr || d->a_mode > 1 || d->b_mode > 1) return RIH_EINVAL;
+                if (d->stats != nullptr) return RIH_EINVAL;
                 prep->a = a;
                 prep->gx = (int)grid.x; prep->gz = (int)grid.z;
                 prep->tile = d->tile; prep->a_mode = d->a_mode; prep->b_mode = d->b_mode; prep->plain = plain ? 1 : 0;
@@ -1924,7 +1800,6 @@ static int gemm_impl(const rih_gemm_desc* d, void* stream, int* stats_rows, Prep
     if (stats_rows != nullptr) { *stats_rows = 0; return 0; }
     if (prep != nullptr) return RIH_EINVAL;                   // not a fast-path descriptor: no grouped launch
     if (d->stats != nullptr) return RIH_EINVAL;
-    if (d->b_mode == 2 || d->a_mode == 2) return RIH_EINVAL;  // the general kernels do not read pre-split operands
     if (engine_out != nullptr) {                              // rih_gemm_engine: a query, no launch
         if (d->tile == 3) *engine_out = 0;
         return 0;

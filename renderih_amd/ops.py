@@ -1604,12 +1604,8 @@ class BatchNormFn(torch.autograd.Function):
                 assert part.shape[2] == Cc
                 check(lib.rih_bn_stats_from_blocks(part.data_ptr(), T, Cc, rows, rpb, eps, momentum, mean.data_ptr(),
                                                    invstd.data_ptr(), _p(rmean), _p(rvar), _stream()), 'rih_bn_stats_from_blocks')
-            elif training and tile_stats is not None:       # statistics came out of the producing GEMM's epilogue (P3)
-                part, T, bm = tile_stats
-                assert T * bm == rows and part.shape[1] == Cc
-                check(lib.rih_bn_stats_from_tiles(part.data_ptr(), T, Cc, bm, eps, momentum, mean.data_ptr(), invstd.data_ptr(),
-                                                  _p(rmean), _p(rvar), _stream()), 'rih_bn_stats_from_tiles')
             elif training:
+                assert tile_stats is None
                 check(lib.rih_bn_stats(x.data_ptr(), rows, Cc, eps, momentum, mean.data_ptr(), invstd.data_ptr(),
                                        _p(rmean), _p(rvar), ws.data_ptr(), _stream()), 'rih_bn_stats')
             else:

@@ -81,19 +81,15 @@ class EmulatedLib:
         assert d.splitk >= 1 and (taps == 1 or d.Cin % 4 == 0)
         if d.a_seg[0] and (d.engine < 1 or d.tile > 2 or d.a_mode != 0 or d.b_mode != 1 or d.nb1 * d.nb2 != 1 or d.splitk != 1):
             return -1           # RIH_EINVAL: only the split engines' fast path reads a segmented A (csrc/rih_gemm.hip gemm_impl)
+        if d.a_mode not in (0, 1) or d.b_mode not in (0, 1):
+            return -1           # RIH_EINVAL (gemm_impl): fp32 operands only, row-major either way
         for b1 in range(d.nb1):
             for b2 in range(d.nb2):
                 Ab = d.A + 4 * (b1 * d.sA1 + b2 * d.sA2)
                 Bb = d.B + 4 * (b1 * d.sB1 + b2 * d.sB2)
                 Cb = d.C + 4 * (b1 * d.sC1 + b2 * d.sC2)
-                if d.a_mode == 2:       # a_mode 0 on pre-split planes [3][pixels][lda] bf16: rebuild the fp32 activation
-                    pix = (-(-M // (d.Ho * d.Wo))) * d.H * d.W
-                    raw = np.ctypeslib.as_array((C.c_uint16 * (3 * pix * d.lda)).from_address(int(d.A))).reshape(3, -1)
-                    pl = (raw.astype(np.uint32) << 16).view(np.float32)
-                    self._a2 = np.ascontiguousarray(pl[0] + pl[1] + pl[2], np.float32)
-                    Ab = self._a2.ctypes.data
                 plain = (taps == 1 and d.strideA == 1 and d.upS == 1 and d.padH == 0 and d.padW == 0 and d.H == d.Ho
-                         and d.W == d.Wo and d.a_mode != 2)
+                         and d.W == d.Wo)
                 A = None
                 if d.a_seg[0]:
                     # segmented A: [A | a_seg[0] | a_seg[1] | a_seg[2]] along K, plain row-major pieces
@@ -145,15 +141,7 @@ class EmulatedLib:
                     A = self._gather(Ab, idx, valid)
                 if d.a_mode == 1 and d.ones_row > 0:
                     A[d.ones_row, :] = 1.0
-                if d.b_mode == 2 and d.engine == 2:       # two fp16 planes of the scaled operand: B = (hi + 2^-11 lo) / s
-                    raw = np.ctypeslib.as_array((C.c_uint16 * (2 * N * d.ldb)).from_address(int(d.B))).reshape(2, N, d.ldb)
-                    pl = raw.view(np.float16).astype(np.float32)
-                    Bm = ((pl[0] + pl[1] * np.float32(2.0 ** -11)) / self._e2_scale(d.amax_b))[:, :K].T.astype(np.float32)
-                elif d.b_mode == 2:     # pre-split planes [3][N][ldb] bf16: B = hi + mid + lo
-                    raw = np.ctypeslib.as_array((C.c_uint16 * (3 * N * d.ldb)).from_address(int(d.B))).reshape(3, N, d.ldb)
-                    planes = (raw.astype(np.uint32) << 16).view(np.float32)
-                    Bm = (planes[0] + planes[1] + planes[2])[:, :K].T.astype(np.float32)
-                elif K == 0:
+                if K == 0:
                     Bm = np.zeros((0, N), np.float32)
                 elif d.b_mode == 0:     # B[k, n] = mem[k * ldb + n]
                     Bm = np.lib.stride_tricks.as_strided(_f(Bb, (K - 1) * d.ldb + N), (K, N), (4 * d.ldb, 4))
@@ -238,7 +226,7 @@ class EmulatedLib:
             fast = fast and d.M % 4 == 0 and (plain or (d.Wo % 4 == 0 and d.Cin % 4 == 0))
         if d.b_mode == 0:
             fast = fast and d.N % 4 == 0
-        return 2 if (d.engine == 2 and fast and d.a_mode <= 1 and (d.b_mode <= 1 or (d.b_mode == 2 and d.a_mode == 0))) else 1
+        return 2 if (d.engine == 2 and fast) else 1
 
     def rih_absmax_multi(self, descs, n, stream):
         for i in range(n):
@@ -285,7 +273,7 @@ class EmulatedLib:
         d = dref._obj
         plain = (d.KH == 1 and d.KW == 1 and d.strideA == 1 and d.padH == 0 and d.padW == 0 and d.H == d.Ho and d.W == d.Wo)
         ok = (d.engine in (1, 2) and d.tile in (0, 1, 2) and d.a_mode == 0
-              and (d.b_mode in (0, 1) or (d.b_mode == 2 and d.engine == 2)) and d.splitk == 1
+              and d.b_mode in (0, 1) and d.splitk == 1
               and d.nb1 * d.nb2 == 1 and d.cS <= 1 and d.upS == 1 and d.K % 4 == 0 and d.K >= 1
               and d.A % 16 == 0 and d.B % 16 == 0 and d.lda % 4 == 0 and d.ldb % 4 == 0)
         if not plain:
@@ -319,26 +307,6 @@ class EmulatedLib:
             _f(rmean, Cc)[:] = (1.0 - momentum) * _f(rmean, Cc) + momentum * m
             _f(rvar, Cc)[:] = (1.0 - momentum) * _f(rvar, Cc) + momentum * unb
         return 0
-
-    def rih_bn_stats_from_tiles(self, part, T, Cc, rows_per_tile, eps, momentum, mean, invstd, rmean, rvar, stream):
-        p_ = _f(part, T * Cc * 2).reshape(T, Cc, 2).astype(np.float64)
-        m = p_[:, :, 0].mean(0)
-        m2 = (p_[:, :, 1] + rows_per_tile * (p_[:, :, 0] - m) ** 2).sum(0)
-        n = float(T * rows_per_tile)
-        var = m2 / n
-        _f(mean, Cc)[:] = m
-        _f(invstd, Cc)[:] = 1.0 / np.sqrt(var + eps)
-        if rmean:
-            unb = var * n / (n - 1.0) if n > 1 else var
-            _f(rmean, Cc)[:] = (1.0 - momentum) * _f(rmean, Cc) + momentum * m
-            _f(rvar, Cc)[:] = (1.0 - momentum) * _f(rvar, Cc) + momentum * unb
-        return 0
-
-    @staticmethod
-    def _bf16_rne(x):
-        u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
-        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
-        return r.astype(np.uint16)
 
     @staticmethod
     def _e2_scale(amax):

@@ -1,5 +1,5 @@
 """GPU tests of the opt-in / secondary code paths: fp16-storage inference backbone (csrc/rih_half.hip; LDS-DMA and
-register-staged loaders), fused attention kernels (csrc/rih_attn.hip), pre-split GEMM operands (rih_gemm a/b_mode 2), batch
+register-staged loaders), fused attention kernels (csrc/rih_attn.hip), batch
 input preparation (csrc/rih_input.hip), SDF voxeliser (csrc/rih_sdf.hip), contact deviation, hipGraph-replayed inference and
 the BatchNorm-folded fp32 trunk.  All of them passed their first hardware run in round 1's driver suite (they were wrapped as
 xfail-on-failure then); they are ordinary tests now: a failure fails the suite."""

@@ -17,16 +17,6 @@ from gemm_pmc_driver_shapes import SHAPES  # noqa: E402
 dev = torch.device('cuda:0')
 B, REP = 64, 10
 ENG = int(os.environ.get('RIH_PMC_ENGINE', '1'))        # 2: the three-product fp16 engine (operand bounds by rih_absmax)
-PRE = os.environ.get('RIH_PMC_PRESPLIT', '0') == '1'    # engine 2: the weight operand as two pre-split fp16 planes (b_mode 2)
-
-
-def planes_of(wp, K, N, bound):
-    """two fp16 planes [2][N][Kpad] of a [K][N] weight operand, scaled by its bound block"""
-    Kp = -(-K // 32) * 32
-    pl = torch.empty(2, N, Kp // 2, device=dev)
-    ops.check(ops._L().rih_presplit_matrix(wp.data_ptr(), 0, K, N, N, pl.data_ptr(), Kp, bound.data_ptr(), ops._stream()),
-              'rih_presplit_matrix')
-    return pl, Kp
 
 
 def amax(t):
@@ -44,13 +34,8 @@ for kind, H, Cin, Cout, k in SHAPES:
     if kind == 'fwd':
         wp = torch.randn(K, Cout, device=dev) / K ** 0.5
         tile, sk = ops.plan_gemm(M, Cout, K, 1, 1)
-        if os.environ.get('RIH_PMC_TILE4', '0') == '1' and Cout >= 128 and K >= 128 and (-(-M // 256)) * (-(-Cout // 128)) >= 128:
-            tile, sk = 4, 1         # the 256x128 software-pipelined kernel on every shape it fits
         kw = dict(amax_a=amax(x), amax_b=amax(wp)) if ENG == 2 else {}
         Bop, ldb, bm = wp, Cout, 0
-        if ENG == 2 and PRE:
-            Bop, ldb = planes_of(wp, K, Cout, kw['amax_b'])
-            bm = 2
         if sk > 1:
             kc = -(-(-(-K // sk)) // 32) * 32
             sk = -(-K // kc)
