@@ -14,15 +14,6 @@
 #include <stdlib.h>
 #include "../../include/renderih_amd.h"
 #include "rih_hash.h"
-#include <type_traits>
-
-#ifndef RIH_E2_PIPE
-/* engine 2's main loop: 1 = two LDS stages, one barrier per k-tile, conversion half-units interleaved with the MFMAs.  Built,
- * parity-tested and measured in round 4 (profiles/r04/ab/c3_*, c4_*): per shape within +-3 % of the two-barrier loop, whole step
- * -0.5 % (1933-1935 against 1946 images/s) at twice the LDS footprint -- the kernel is bound by the SUM of its MFMA, VALU and LDS
- * issue time on a SIMD (profiles/r04/gemm_pmc2_issue_breakdown_*), which re-ordering does not shrink.  Not compiled by default. */
-#define RIH_E2_PIPE 0
-#endif
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -791,7 +782,7 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off)
 // ENG 2: the two-term fp16 split (three MFMA products, see e2_scale / split2h above) instead of the three-term bf16 one; same
 // loaders, LDS layout (two planes instead of three) and epilogue.
 template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool STATS = false, bool DROP = false, int ENG = 1,
-          bool SEG = false, int PFD = 1>
+          bool SEG = false>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk_x, const int blk_z, const int grid_x,
                                                 const int grid_z) {
     static_assert(BMODE == 0 || BMODE == 1, "B is row-major [K][N] (0) or [N][K] (1)");
@@ -800,10 +791,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
     // global->register prefetch depth: k-tiles in flight.  The 64x64 tile (decoder-sized problems: a handful of
     // k-tiles, 12 MFMAs each) is bound by the load round trip per k-tile, so it keeps three tiles in flight.
     // (measured in round 2: 3 tiles in flight for the 64x64 tile changes nothing on decoder-sized problems, the floor is elsewhere.)
-    // PFD = 2 (round 4 experiment, engine 2, plain rows, short reductions -- the 1x1 convolutions with K <= 256 and a million
-    // rows): such a workgroup is a chain of dependent memory round trips (bound, k-tile, k-tile, ..., store) with a few MFMAs
-    // between them; a second k-tile in flight was meant to take one round trip out of every two.  Measured slower (launch_split_e2).
-    constexpr int PF = PFD;
+    constexpr int PF = 1;
     constexpr int PLANE_A = BM * 16, PLANE_B = BN * 16;
     constexpr int WGN = 2, WGM = 2;
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -811,11 +799,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
     constexpr int NPA = BM / 32, NPB = BN / 32;
     constexpr int QA = BM / 4, QB = BN / 4;
 
-    // engine 2 runs a ONE-barrier main loop on two LDS stages (see the PIPE loop below); RIH_E2_PIPE=0 builds the two-barrier
-    // single-stage loop of engine 1 for it (A/B partner)
-    constexpr bool PIPE = (ENG == 2) && (RIH_E2_PIPE != 0);
-    constexpr int STAGE_DW = NPL * (PLANE_A + PLANE_B);
-    constexpr int OPER_DW = (PIPE ? 2 : 1) * STAGE_DW;
+    constexpr int OPER_DW = NPL * (PLANE_A + PLANE_B);
     constexpr int SMEM_DW = OPER_DW > 4 * 32 * SLD ? OPER_DW : 4 * 32 * SLD;       // >= the epilogue's staging area
     __shared__ __attribute__((aligned(16))) unsigned smem[SMEM_DW];
     unsigned* As = smem;
@@ -1120,13 +1104,11 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
             }
 
     // prologue: tiles 0..PF-1 in flight (a tile at or beyond kend arrives as zeros and is never multiplied)
-    if constexpr (!PIPE) {
 #pragma unroll
-        for (int j = 0; j < PF; ++j) {
-            if (j > 0) advance_A();
-            load_A(kbeg + j * BK, j);
-            load_B(kbeg + j * BK, j);
-        }
+    for (int j = 0; j < PF; ++j) {
+        if (j > 0) advance_A();
+        load_A(kbeg + j * BK, j);
+        load_B(kbeg + j * BK, j);
     }
 
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -1140,104 +1122,6 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
         }
     }
 
-    if constexpr (PIPE) {
-        // ---- engine 2, pipelined: LDS holds TWO k-tiles (stage t & 1 is multiplied while stage (t + 1) & 1 is filled), so a k-tile
-        // costs one barrier, and the conversion of tile t+1 (fp32 registers -> two fp16 planes: three mixed-precision FMAs per
-        // element) is cut into half-units of six VALU instructions that are issued one behind each MFMA of tile t -- they run in
-        // the shadow of the matrix pipe (32 cycles per v_mfma_f32_32x32x16_f16) instead of in a phase of their own between two
-        // barriers.  The global loads of tile t+2 go out when the registers of tile t+1 have been converted.
-        constexpr int UA = (AMODE == 0) ? NPA : 4, UB = (BMODE == 1) ? NPB : 4;      // conversion units (one LDS row segment each)
-        constexpr bool A4 = (AMODE == 0) || (NPA == 4), B4 = (BMODE == 1) || (NPB == 4);   // four values per unit (else two)
-        // half-units: one pair of values each
-        constexpr int HA = A4 ? 2 * UA : UA, HB = B4 ? 2 * UB : UB;
-        constexpr int NH = HA + HB;
-        auto comp = [](const float4& v, int c) -> float { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
-        unsigned hu_h = 0, hu_l = 0;        // first pair of the unit in flight
-        // half-unit q of the registers in flight -> the stage at (sA, sB)
-        auto half_unit = [&](int q, unsigned* sA, unsigned* sB) {
-            const bool isA = q < HA;
-            const int r = isA ? q : q - HA;
-            const bool four = isA ? A4 : B4;
-            const int u = four ? (r >> 1) : r, h = four ? (r & 1) : 0;
-            const float sc = isA ? e2_sa : e2_sb;
-            const int plane = isA ? PLANE_A : PLANE_B;
-            unsigned* dst = isA ? sA + a_st[u] : sB + b_st[u];
-            float x0, x1;
-            const bool contig = isA ? (AMODE == 0) : (BMODE == 1);
-            if (contig) {       // unit u = register u: (x, y | z, w)
-                const float4& v = isA ? areg[0][isA ? u : 0] : breg[0][isA ? 0 : u];
-                x0 = h == 0 ? v.x : v.z;
-                x1 = h == 0 ? v.y : v.w;
-            } else {            // unit u = component u of the k-consecutive registers: (reg0, reg1 | reg2, reg3)
-                const float4* v = isA ? areg[0] : breg[0];
-                x0 = comp(v[2 * h], u);
-                x1 = comp(v[2 * h + 1], u);
-            }
-            unsigned hh, ll;
-            split2h(x0, x1, sc, hh, ll);
-            if (!four) {
-                dst[0] = hh;
-                dst[plane] = ll;
-            } else if (h == 0) {
-                hu_h = hh;
-                hu_l = ll;
-            } else {
-                *reinterpret_cast<uint2*>(dst) = make_uint2(hu_h, hh);
-                *reinterpret_cast<uint2*>(dst + plane) = make_uint2(hu_l, ll);
-            }
-        };
-        load_A(kbeg, 0);
-        load_B(kbeg, 0);
-#pragma unroll
-        for (int q = 0; q < NH; ++q) half_unit(q, As, Bs);
-        advance_A();
-        load_A(kbeg + BK, 0);
-        load_B(kbeg + BK, 0);
-        __syncthreads();
-        auto ktile = [&](const int t, auto more_c) {
-            constexpr bool MORE = decltype(more_c)::value;          // a tile t+1 exists: convert it while tile t is multiplied
-            const unsigned* cA = smem + (t & 1) * STAGE_DW;
-            const unsigned* cB = cA + NPL * PLANE_A;
-            unsigned* nA = smem + ((t & 1) ^ 1) * STAGE_DW;
-            unsigned* nB = nA + NPL * PLANE_A;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                f16x8 av[2][TM], bv[2][TN];
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        av[pl][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(cA + pl * PLANE_A + sa_off[s] + i * 512));
-#pragma unroll
-                    for (int jj = 0; jj < TN; ++jj)
-                        bv[pl][jj] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(cB + pl * PLANE_B + sb_off[s] + jj * 512));
-                }
-#pragma unroll
-                for (int term = 0; term < 3; ++term)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int jj = 0; jj < TN; ++jj) {
-                            if (term == 0) acc1[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[1][i], bv[0][jj], acc1[i][jj], 0, 0, 0);
-                            else if (term == 1) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][i], bv[0][jj], acc[i][jj], 0, 0, 0);
-                            else acc1[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0][i], bv[1][jj], acc1[i][jj], 0, 0, 0);
-                            const int q = ((s * 3 + term) * TM + i) * TN + jj;      // this MFMA's slot
-                            if (MORE && q < NH) half_unit(q, nA, nB);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-            }
-            if (MORE) {
-#pragma unroll
-                for (int q = 6 * TM * TN; q < NH; ++q) half_unit(q, nA, nB);        // more half-units than MFMAs (64-wide tiles)
-                advance_A();
-                load_A(kbeg + (t + 2) * BK, 0);
-                load_B(kbeg + (t + 2) * BK, 0);
-            }
-            __syncthreads();
-        };
-        for (int t = 0; t + 1 < ntiles; ++t) ktile(t, std::true_type());
-        if (ntiles > 0) ktile(ntiles - 1, std::false_type());
-    } else
     for (int t = 0; t < ntiles; t += PF) {
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
@@ -1312,9 +1196,9 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& p, const int blk
 }
 
 template <int BM, int BN, int AMODE, int BMODE, bool PLAIN, bool STATS = false, bool DROP = false, int ENG = 1,
-          bool SEG = false, int PFD = 1>
+          bool SEG = false>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
-    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, STATS, DROP, ENG, SEG, PFD>(p, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.x,
+    gemm_split_body<BM, BN, AMODE, BMODE, PLAIN, STATS, DROP, ENG, SEG>(p, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.x,
                                                                               (int)gridDim.z);
 }
 
