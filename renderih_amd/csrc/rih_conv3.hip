@@ -134,9 +134,12 @@ __device__ __forceinline__ void c3_dma_wait() {
 
 // The same LDS-DMA instruction issued OUTSIDE hipcc's wait-count bookkeeping (rows_kernel): behind the builtin the compiler puts
 // `s_waitcnt vmcnt(0)` in front of the next barrier / LDS read that may alias the destination, which also drains every register
-// load in flight -- a prefetch of A rows two k-tiles ahead would be cut back to one.  Here the kernel waits itself, with a COUNTED
-// c3_vm_wait<N>() (memory operations retire in order: "at most N outstanding" = everything but the N youngest has landed).  The
-// compiler's own waits for register loads stay correct: operations it does not know of can only make its counts conservative.
+// load in flight -- a prefetch of A rows two k-tiles ahead would be cut back to one.  Here the kernel places its waits itself
+// (c3_vm_wait<N>()).  N = 0 everywhere since round 6: the design counted ("at most N outstanding" = everything but the N youngest
+// has landed), which holds among register loads but NOT between register loads and LDS-DMA requests on gfx950 -- see the schedule
+// comment in rows_kernel.  What the explicit placement still buys is ONE wait per k-tile, behind the MFMAs, instead of one in
+// front of every barrier and LDS read the compiler cannot prove independent.  The compiler's own waits for register loads stay
+// correct: operations it does not know of can only make its counts conservative.
 __device__ __forceinline__ void c3_glds16_raw(const unsigned char* src, unsigned char* lds_dst) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const unsigned base = __builtin_amdgcn_readfirstlane(
