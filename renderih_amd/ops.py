@@ -945,14 +945,18 @@ ROWS_MIN_WGS = int(os.environ.get('RIH_ROWS_MIN_WGS', '128'))
 # step for every 1x1 weight of ResNet50 in both forms, 70 % of it layer4's), the kernel's advantage grows with rows x weight -- on the
 # 8 x 8 maps (4096 rows at B = 64) it is 3-7 us per launch against ~10 us of plane conversion per weight (profiles/r06/rows/)
 ROWS_MIN_M = int(os.environ.get('RIH_ROWS_MIN_M', '8192'))
+# narrowest output: on N = 64 (layer1's conv1 forward and conv3 data gradient, 262144 x 256 -> 64: HBM-bound, 335 MB per launch) the tiled
+# 128 x 64 kernel is the faster one -- 80 us against 91-95 us on 256 x 64 tiles (88 KB of LDS: one workgroup per CU) and 86-90 us on
+# 128 x 64 tiles (two per CU); profiles/r06/rows/c18_rows_bench_n64.log, final/rows_bench.log
+ROWS_MIN_N = int(os.environ.get('RIH_ROWS_MIN_N', '128'))
 
 
 def _rows_ok(a2d_rows, K, N, lda, a, bias=None, c=None, R=None):
-    """Launches rih_rows takes and that are worth it: engine 2, K >= ROWS_MINK in whole 32-deep tiles, N % 64, whole 128-row tiles, at
-    least ROWS_MIN_WGS workgroups of the smallest tile; the library re-checks (rih_rows_ok) before the launch."""
+    """Launches rih_rows takes and that are worth it: engine 2, K >= ROWS_MINK in whole 32-deep tiles, N % 64, N >= ROWS_MIN_N, whole
+    128-row tiles, at least ROWS_MIN_WGS workgroups of the smallest tile; the library re-checks (rih_rows_ok) before the launch."""
     if not (ROWS and ENGINE == 2) or bias is not None or K < ROWS_MINK or K % 32 != 0 or N % 64 != 0 or a2d_rows % 128 != 0:
         return False
-    if a2d_rows < ROWS_MIN_M:
+    if a2d_rows < ROWS_MIN_M or N < ROWS_MIN_N:
         return False
     if lda % 4 != 0 or a.data_ptr() % 16 != 0 or 4 * a2d_rows * lda >= (1 << 31):
         return False

@@ -262,11 +262,11 @@ def test_rows_1x1(case, monkeypatch=None):
     as 512-thread workgroups with LDS-DMA-staged H2 weight planes and three A stages -- forward (+ ReLU, + BatchNorm statistics), the
     data gradient WITH the skip path's gradient as residual (conv2d_skip: Bottleneck.conv1), the weight gradient (rih_gemm) --
     against fp64 (gradients at rtol 1e-4 + 1e-5 max: north_star's bar), and against the tiled kernels (ROWS off).  The planning
-    thresholds (K >= 256, >= 128 workgroups) are lifted for the small shapes; the panel kernel is off so that K = 64 / 128 come here."""
+    thresholds (K >= 256, N >= 128, >= 128 workgroups) are lifted for the small shapes; the panel kernel is off so that K = 64 / 128 come here."""
     from renderih_amd import ops
     N, H, W, Cin, Cout, relu, want_stats = case
-    saved = (ops.ENGINE, ops.ROWS, ops.ROWS_MINK, ops.ROWS_MIN_WGS, ops.PANEL, ops.ROWS_MIN_M)
-    ops.ENGINE, ops.ROWS_MINK, ops.ROWS_MIN_WGS, ops.PANEL, ops.ROWS_MIN_M = 2, 64, 1, False, 1
+    saved = (ops.ENGINE, ops.ROWS, ops.ROWS_MINK, ops.ROWS_MIN_WGS, ops.PANEL, ops.ROWS_MIN_M, ops.ROWS_MIN_N)
+    ops.ENGINE, ops.ROWS_MINK, ops.ROWS_MIN_WGS, ops.PANEL, ops.ROWS_MIN_M, ops.ROWS_MIN_N = 2, 64, 1, False, 1, 64
     try:
         x = rnd(N, Cin, H, W, seed=41) * 2.0
         w = rnd(Cout, Cin, 1, 1, seed=42, scale=1.0 / math.sqrt(Cin))
@@ -302,7 +302,7 @@ def test_rows_1x1(case, monkeypatch=None):
         for a, b, what in zip(outs[True], outs[False], ('y', 'dx', 'dw')):
             assert_close(a, b, 1e-4, 1e-5, 'rows vs tiled GEMM ' + what)
     finally:
-        ops.ENGINE, ops.ROWS, ops.ROWS_MINK, ops.ROWS_MIN_WGS, ops.PANEL, ops.ROWS_MIN_M = saved
+        ops.ENGINE, ops.ROWS, ops.ROWS_MINK, ops.ROWS_MIN_WGS, ops.PANEL, ops.ROWS_MIN_M, ops.ROWS_MIN_N = saved
 
 
 def test_rows_and_stem_kernels_are_reproducible_at_bench_size():
