@@ -138,8 +138,8 @@ class _MeshLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_total, _g_terms):
-        grads = [g.clone() for g in ctx.saved_tensors]      # the saved gradients may be read again (retain_graph)
-        torch._foreach_mul_(grads, g_total)
+        # out of place: the saved gradients may be read again (retain_graph); ONE multi-tensor launch instead of a clone per tensor
+        grads = torch._foreach_mul(list(ctx.saved_tensors), g_total)
         return (None,) + tuple(grads) + (None,) * 5
 
 
