@@ -49,6 +49,8 @@ class Count(TorchDispatchMode):
                 site = '%s:%d %s' % (os.path.relpath(fr.filename, ROOT), fr.lineno, fr.name)
                 break
         n = out.numel() if isinstance(out, torch.Tensor) else 0
+        if site is None and name == 'add' and isinstance(out, torch.Tensor):
+            self.sites[('shape', tuple(out.shape))] += 1       # gradient accumulation: the shape names the two-consumer tensor
         self.sites[(self.phase, name, site or '(autograd engine)')] += 1
         self.sites[('bytes', self.phase, name, site or '(autograd engine)')] += 4 * n
         return out
@@ -90,7 +92,8 @@ def main():
         c = Count()
         with c:
             step(c)
-    rows = [(k, v) for k, v in c.sites.items() if k[0] != 'bytes']
+    shapes = sorted(((k[1], v) for k, v in c.sites.items() if k[0] == 'shape'), key=lambda kv: -kv[1])
+    rows = [(k, v) for k, v in c.sites.items() if k[0] not in ('bytes', 'shape')]
     tot = collections.Counter()
     for (ph, name, site), v in rows:
         tot[ph] += v
@@ -101,6 +104,7 @@ def main():
     print('by op:', ', '.join('%s %d' % kv for kv in by_op.most_common()))
     for (ph, name, site), v in sorted(rows, key=lambda kv: -kv[1]):
         print('%4d  %-9s %-28s %s   (%.1f KB per call at B = 2)' % (v, ph, name, site, c.sites[('bytes', ph, name, site)] / v / 1024.0))
+    print('gradient accumulations of the autograd engine by tensor shape:', ', '.join('%d x %s' % (v, list(k)) for k, v in shapes))
 
 
 if __name__ == '__main__':
