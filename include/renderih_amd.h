@@ -218,7 +218,7 @@ int rih_bn_stats_from_blocks(const float* part, int T, int C, int rows, int rows
  * an 8 x 32 pixel patch and 128 (64) output channels, loads and converts each 32-channel chunk of the (8+2) x (32+2) input
  * halo ONCE and runs the nine taps on shifted windows of that LDS image; the weights arrive as two pre-split fp16 planes
  * ("H2": dst[n][k / 8][plane][8 halves], k = (tap, channel), written once per training step by rih_h2_multi) through LDS-DMA.
- *   y[img][i][j][n] = act(sum_{kh,kw,c} x[img][i+kh-1][j+kw-1][c] * W(n, (kh*3+kw)*C + c))        (zero padding)
+ *   y[img][i][j][n] = act(sum_{kh,kw,c} x[img][i+kh-1][j+kw-1][c] * W(n, (kh*3+kw)*C + c) (+ r[img][i][j][n]))        (zero padding)
  * Forward: W from rih_h2_desc.for_dgrad 0 (n = co).  Data gradient: x = dy, C = Cout, N = CinPad, for_dgrad 1 (flipped taps).
  * Preconditions (rih_conv3x3_ok returns 1): C % 32 == 0, N % 32 == 0, (H % 8 == 0 and W % 32 == 0: patches of 8 x 32 pixels) or
  * (H % 16 == 0 and W % 16 == 0: 16 x 16), Kpad == 9 * C, 16-byte aligned x / w_h2 / y / stats, ldx / ldy % 4 == 0, one image
@@ -234,6 +234,11 @@ typedef struct rih_conv3_desc {
     const float* amax_x;
     const float* amax_w;
     int32_t imgs, H, W, C, N, ldx, ldy, Kpad, relu;
+    int32_t ldr;            /* (ABI 19) pitch of r */
+    const float* r;         /* (ABI 19) optional residual NHWC [imgs][H][W][ldr], added before the ReLU: the skip gradient that joins the
+                             * data gradient of a residual block's first 3x3 convolution (torchvision BasicBlock.conv1; reference
+                             * models/hrnet: BasicBlock.forward `out += residual`).  16-byte aligned, ldr >= N, ldr % 4 == 0; not
+                             * together with stats; rih_stem takes none.  NULL: none */
 } rih_conv3_desc;
 int rih_conv3x3_ok(const rih_conv3_desc* d);
 int rih_conv3x3_stats_rows(const rih_conv3_desc* d);
@@ -538,7 +543,7 @@ int rih_mesh_loss_final(const float* partial_left, const float* partial_right, i
  * this order: gemm desc, mano model, mesh topo, hconv desc, reduce desc, pack desc, ln final desc, adam entry, absmax desc,
  * conv3 desc, h2 desc, panel desc (RIH_ABI_NSIZES values), so a host binding can refuse a stale binary instead of handing it
  * mis-laid-out structs. */
-#define RIH_ABI_VERSION 18
+#define RIH_ABI_VERSION 19
 #define RIH_ABI_NSIZES 12
 int rih_version(void);
 int rih_abi_sizes(int32_t* out10);

@@ -42,7 +42,7 @@ class ReduceDesc(C.Structure):
 class Conv3Desc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('w_h2', C.c_void_p), ('y', C.c_void_p), ('stats', C.c_void_p), ('amax_x', C.c_void_p),
                 ('amax_w', C.c_void_p)] + \
-               [(n, C.c_int32) for n in ('imgs', 'H', 'W', 'C', 'N', 'ldx', 'ldy', 'Kpad', 'relu')]
+               [(n, C.c_int32) for n in ('imgs', 'H', 'W', 'C', 'N', 'ldx', 'ldy', 'Kpad', 'relu', 'ldr')] + [('r', C.c_void_p)]
 
 
 class PanelDesc(C.Structure):
@@ -216,7 +216,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 18     # = RIH_ABI_VERSION of include/renderih_amd.h
+ABI_VERSION = 19     # = RIH_ABI_VERSION of include/renderih_amd.h
 
 _lib = None
 

@@ -27,8 +27,9 @@
 //
 // Preconditions (rih_conv3x3_ok): C % 32 == 0, N % 32 == 0, (H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0),
 // 16-byte aligned operands, pitches % 4 == 0, one image < 2 GiB.  Epilogue: optional ReLU, optional BatchNorm statistics per 64-row wave block ((mean, M2), the format of
-// rih_gemm_desc.stats: rih_bn_stats_from_blocks merges them).  No bias / residual (no 3x3 convolution of the network has one
-// on the training path); callers with either use rih_gemm.
+// rih_gemm_desc.stats: rih_bn_stats_from_blocks merges them), or an optional residual added before the ReLU (RES variants, ABI 19:
+// the skip gradient in the data gradient of a BasicBlock's first convolution).  No bias (no 3x3 convolution of the network has one
+// on the training path); callers with one use rih_gemm.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -54,6 +55,8 @@ struct C3Args {
     const float* amax_w;
     int imgs, H, W, C, N, ldx, ldy, Kp, relu;
     int tiles_x, tiles_y, nblk;
+    const float* r;             // RES: residual [imgs][H][W][ldr], added before the ReLU (the skip gradient of a BasicBlock's first conv)
+    int ldr;
 };
 
 __device__ __forceinline__ int xcd_remap_c3(int bid, int nwg) {
@@ -177,8 +180,9 @@ __device__ __forceinline__ float4 c3_bload4_raw(c3_i32x4 rs, __amdgpu_buffer_rsr
 #endif
 }
 
-template <int TW, int BN, bool STATS>
+template <int TW, int BN, bool STATS, bool RES = false>
 __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
+    static_assert(!(STATS && RES), "a launch has statistics (forward) or a residual (data gradient), not both");
     constexpr int TH = 256 / TW, HW_ = TW + 2, HP = (TH + 2) * HW_;     // patch 8 x 32 (halo 340 pixels) or 16 x 16 (324)
     constexpr int WGN = BN >= 64 ? 2 : 1, WGM = 8 / WGN;                // waves 4 x 2, or 8 x 1 for 32 output channels
     constexpr int TM = 8 / WGM;                                         // 32-row blocks per wave: 2 / 1
@@ -355,6 +359,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
     for (int i = 0; i < TM; ++i) {
         const int blk = wm * TM + i;                    // 32-row block of the patch: image row blk (TW 32) or rows 2 blk, 2 blk + 1
         float* ypatch = p.y + (((long long)img * p.H + y0) * p.W + x0) * p.ldy + n0 + wn * (BN / WGN);
+        const float* rpatch = RES ? p.r + (((long long)img * p.H + y0) * p.W + x0) * p.ldr + n0 + wn * (BN / WGN) : nullptr;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             if (i + j > 0) __builtin_amdgcn_wave_barrier();
@@ -369,6 +374,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(const C3Args p) {
                 const int row = (lane >> 3) + 8 * q, c4 = (lane & 7) * 4;       // row of the 32-row block -> pixel (ty, tx)
                 const int ty = (TW == 32) ? blk : 2 * blk + (row >> 4), tx = row & (TW - 1);
                 float4 v = *reinterpret_cast<const float4*>(stg + row * SLD + c4);
+                if (RES) {
+                    const float4 rr = *reinterpret_cast<const float4*>(rpatch + ((long long)ty * p.W + tx) * p.ldr + j * 32 + c4);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
                 if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 *reinterpret_cast<float4*>(ypatch + ((long long)ty * p.W + tx) * p.ldy + j * 32 + c4) = v;
                 if (STATS) {
@@ -1094,7 +1103,7 @@ bool rows_ok(const rih_panel_desc* d) {
 bool stem_ok(const rih_conv3_desc* d) {
     if (!d || !d->x || !d->w_h2 || !d->y || !d->amax_x || !d->amax_w) return false;
     if (d->imgs < 1 || d->H < 8 || d->W < 8 || d->H % 2 != 0 || d->W % 2 != 0 || d->C != 4 || d->ldx != 4) return false;
-    if (d->N != 64 || d->ldy < d->N || d->ldy % 4 != 0 || d->Kpad != 224) return false;
+    if (d->N != 64 || d->ldy < d->N || d->ldy % 4 != 0 || d->Kpad != 224 || d->r != nullptr) return false;
     if ((((uintptr_t)d->x | (uintptr_t)d->w_h2 | (uintptr_t)d->y | (uintptr_t)d->stats) % 16) != 0) return false;
     const long long M = (long long)d->imgs * (d->H / 2) * (d->W / 2);
     if (M % 256 != 0 || M >= (1ll << 31)) return false;
@@ -1128,6 +1137,7 @@ bool c3_ok(const rih_conv3_desc* d) {
     if (d->ldx < d->C || d->ldx % 4 != 0 || d->ldy < d->N || d->ldy % 4 != 0 || d->Kpad != 9 * d->C) return false;
     if ((((uintptr_t)d->x | (uintptr_t)d->w_h2 | (uintptr_t)d->y | (uintptr_t)d->stats) % 16) != 0) return false;
     if ((long long)d->H * d->W * d->ldx * 4 >= (1ll << 31)) return false;
+    if (d->r != nullptr && (d->stats != nullptr || d->ldr < d->N || d->ldr % 4 != 0 || ((uintptr_t)d->r % 16) != 0)) return false;
     const long long wg = (long long)d->imgs * (d->H / 8) * (d->W / 16) * (d->N / 32);        // (an upper bound of the grid)
     return wg < (1ll << 31);
 }
@@ -1135,6 +1145,7 @@ bool c3_ok(const rih_conv3_desc* d) {
 template <int TW, int BN>
 void c3_launch(const C3Args& a, unsigned grid, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL((conv3x3_halo_kernel<TW, BN, true>), dim3(grid), dim3(NT), 0, s, a);
+    else if (a.r != nullptr) hipLaunchKernelGGL((conv3x3_halo_kernel<TW, BN, false, true>), dim3(grid), dim3(NT), 0, s, a);
     else hipLaunchKernelGGL((conv3x3_halo_kernel<TW, BN, false>), dim3(grid), dim3(NT), 0, s, a);
 }
 
@@ -1156,6 +1167,7 @@ extern "C" int rih_conv3x3(const rih_conv3_desc* d, void* stream) {
     a.x = d->x; a.w = (const unsigned char*)d->w_h2; a.y = d->y; a.stats = d->stats; a.amax_x = d->amax_x; a.amax_w = d->amax_w;
     a.imgs = d->imgs; a.H = d->H; a.W = d->W; a.C = d->C; a.N = d->N; a.ldx = d->ldx; a.ldy = d->ldy; a.Kp = d->Kpad;
     a.relu = d->relu ? 1 : 0;
+    a.r = d->r; a.ldr = d->ldr;
     const int tw = c3_tw(d), bn = c3_bn(d, tw);
     a.tiles_x = d->W / tw; a.tiles_y = d->H / (256 / tw);
     a.nblk = d->N / bn;

@@ -793,6 +793,9 @@ def _packed_weight(w, Cx, for_dgrad, sub=None, out=None):
 # halo of an 8 x 32 pixel patch loaded and converted ONCE per 32-channel chunk and the weights as pre-split fp16 planes ("H2",
 # one rih_h2_multi launch per step through ops._PACK) staged by LDS-DMA.  RIH_HALO3=0: the tap-by-tap implicit GEMM (rih_gemm).
 HALO3 = os.environ.get('RIH_HALO3', '1') == '1'
+# the data gradient of a residual block's FIRST 3x3 convolution (BasicBlock.conv1 of HRNet: conv2d_skip) with the skip gradient
+# added in the halo kernel's epilogue (rih_conv3_desc.r, ABI 19); RIH_HALO3_RES=0: those launches on rih_gemm's tiled kernel
+HALO3_RES = os.environ.get('RIH_HALO3_RES', '1') == '1'
 
 
 def _h2_launch(items):
@@ -834,24 +837,31 @@ def _h2_weight(w, Cx, for_dgrad, bound=None):
 
 
 def _halo3_ok(x, Cch, Nout, KH, KW, stride, pad, bias=None, residual=None):
-    """Shapes rih_conv3x3 takes (csrc/rih_conv3.hip): engine 2, 3x3 / 1 / 1, no bias or residual, 8 x 32 or 16 x 16 pixel patches,
-    whole 32-channel chunks, 32-column blocks; the kernel itself re-checks (rih_conv3x3_ok)."""
-    if not (HALO3 and ENGINE == 2) or KH != 3 or KW != 3 or stride != 1 or pad != 1 or bias is not None or residual is not None:
+    """Shapes rih_conv3x3 takes (csrc/rih_conv3.hip): engine 2, 3x3 / 1 / 1, no bias, 8 x 32 or 16 x 16 pixel patches, whole
+    32-channel chunks, 32-column blocks; a residual (the skip gradient of a BasicBlock's first convolution) when HALO3_RES; the
+    kernel itself re-checks (rih_conv3x3_ok)."""
+    if not (HALO3 and ENGINE == 2) or KH != 3 or KW != 3 or stride != 1 or pad != 1 or bias is not None:
+        return False
+    if residual is not None and not (HALO3_RES and residual.is_contiguous() and residual.data_ptr() % 16 == 0):
         return False
     N, H, W_, Cx = x.shape
     return (Cx == Cch and Cch % 32 == 0 and Nout % 32 == 0 and ((H % 8 == 0 and W_ % 32 == 0) or (H % 16 == 0 and W_ % 16 == 0))
             and x.is_contiguous() and x.data_ptr() % 16 == 0 and 4 * H * W_ * Cx < (1 << 31))
 
 
-def conv3x3_halo(x, w, y, for_dgrad, relu=False, stats=None, bx=None, bw=None):
+def conv3x3_halo(x, w, y, for_dgrad, relu=False, stats=None, bx=None, bw=None, R=None):
     """Enqueue rih_conv3x3: y = act(conv3x3(x, w)) (for_dgrad False; x [N,H,W,Cin], y [N,H,W,Cout]) or the data gradient
     y = conv3x3(x = dy, flipped w) (for_dgrad True; x [N,H,W,Cout], y [N,H,W,Cin]).  stats: a StatsHolder, filled.  bx / bw: bound
-    thunks (LazyBound) of x and w.  Returns False (nothing enqueued) when the library refuses the descriptor (rih_conv3x3_ok)."""
+    thunks (LazyBound) of x and w.  R: a dense [N,H,W,Nout] tensor added before the ReLU (not together with stats).  Returns False
+    (nothing enqueued) when the library refuses the descriptor (rih_conv3x3_ok)."""
     from ._lib import Conv3Desc
     N, H, W_, Cch = x.shape
     Nout = y.shape[-1]
     d = Conv3Desc()
     d.x, d.y = x.data_ptr(), y.data_ptr()
+    if R is not None:
+        assert stats is None and tuple(R.shape) == tuple(y.shape)
+        d.r, d.ldr = R.data_ptr(), Nout
     d.imgs, d.H, d.W, d.C, d.N, d.ldx, d.ldy, d.Kpad, d.relu = N, H, W_, Cch, Nout, Cch, Nout, 9 * Cch, 1 if relu else 0
     d.w_h2 = d.amax_x = d.amax_w = x.data_ptr()         # (placeholders for the library's own precondition check)
     if int(_L().rih_conv3x3_ok(C.byref(d))) != 1:       # e.g. an output view that is not 16-byte aligned: the caller takes rih_gemm
@@ -1143,7 +1153,7 @@ class Conv2dFn(torch.autograd.Function):
             geom = (Ho, Wo, Cout, H, W_, KH, KW, 1, stride, KH - 1 - pad, KW - 1 - pad)
             rows1x1 = KH * KW == 1 and Cx == Cin and stride == 1 and pad == 0
             if (Cx == Cin and _halo3_ok(dy, Cout, Cx, KH, KW, stride, pad, None, dskip)
-                    and conv3x3_halo(dy, w, dx, True, bx=bdy, bw=bw)):
+                    and conv3x3_halo(dy, w, dx, True, bx=bdy, bw=bw, R=dskip)):
                 pass
             elif (rows1x1 and _panel_ok(Mx, Cout, Cin, Cout, dy)
                   and panel_gemm(dy, w, dx, Mx, Cin, Cout, Cout, Cx, True, R=dskip, ldr=Cx, ba=bdy, bw=bw)):

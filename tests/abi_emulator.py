@@ -354,7 +354,8 @@ class EmulatedLib:
                     and ((d.H % 8 == 0 and d.W % 32 == 0) or (d.H % 16 == 0 and d.W % 16 == 0)) and d.H >= 8 and d.W >= 16
                     and d.C >= 32 and d.C % 32 == 0 and d.N >= 32 and d.N % 32 == 0 and d.ldx >= d.C
                     and d.ldx % 4 == 0 and d.ldy >= d.N and d.ldy % 4 == 0 and d.Kpad == 9 * d.C
-                    and d.x % 16 == 0 and d.w_h2 % 16 == 0 and d.y % 16 == 0 and (not d.stats or d.stats % 16 == 0))
+                    and d.x % 16 == 0 and d.w_h2 % 16 == 0 and d.y % 16 == 0 and (not d.stats or d.stats % 16 == 0)
+                    and (not d.r or (not d.stats and d.ldr >= d.N and d.ldr % 4 == 0 and d.r % 16 == 0)))
 
     def rih_conv3x3_ok(self, dref):
         return 1 if self._conv3_ok(dref._obj if hasattr(dref, '_obj') else dref) else 0
@@ -391,6 +392,9 @@ class EmulatedLib:
             for kw in range(3):
                 t = kh * 3 + kw
                 y += xp[:, kh:kh + d.H, kw:kw + d.W].reshape(-1, d.C).dot(Wnk[:, t * d.C:(t + 1) * d.C].T).reshape(y.shape)
+        if d.r:             # the residual joins before the ReLU
+            y = y + np.lib.stride_tricks.as_strided(_f(d.r, ((d.imgs * d.H * d.W) - 1) * d.ldr + d.N), (d.imgs, d.H, d.W, d.N),
+                                                    (4 * d.H * d.W * d.ldr, 4 * d.W * d.ldr, 4 * d.ldr, 4))
         if d.relu:
             y = np.maximum(y, 0)
         out = np.lib.stride_tricks.as_strided(_f(d.y, ((d.imgs * d.H * d.W) - 1) * d.ldy + d.N), (d.imgs, d.H, d.W, d.N),
@@ -415,7 +419,7 @@ class EmulatedLib:
         return bool(d.x and d.w_h2 and d.y and d.amax_x and d.amax_w and d.imgs >= 1 and d.H >= 8 and d.W >= 8 and d.H % 2 == 0
                     and d.W % 2 == 0 and d.C == 4 and d.ldx == 4 and d.N == 64 and d.ldy >= d.N and d.ldy % 4 == 0 and d.Kpad == 224
                     and all(int(v or 0) % 16 == 0 for v in (d.x, d.w_h2, d.y, d.stats)) and M % 256 == 0
-                    and d.imgs * d.H * d.W * 16 < (1 << 31))
+                    and d.imgs * d.H * d.W * 16 < (1 << 31) and not d.r)
 
     def rih_stem_ok(self, dref):
         return 1 if self._stem_ok(dref._obj if hasattr(dref, '_obj') else dref) else 0

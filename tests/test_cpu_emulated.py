@@ -142,6 +142,9 @@ def test_conv3x3_halo_host_logic():
     G.test_conv3x3_halo((1, 8, 64, 32, 64, True, True))
     G.test_conv3x3_halo((2, 16, 16, 64, 96, True, True))           # 16 x 16 patches, 32-channel blocks (32-row statistics blocks)
     G.test_conv2d((2, 8, 8, 32, 32, 3, 1, 1, False, True))         # W = 8: not a whole 32-pixel patch -> rih_gemm
+    G.test_conv3x3_halo_with_skip_gradient((2, 8, 32, 32, 32))     # the skip gradient as the kernel's residual (ABI 19)
+    G.test_conv3x3_halo_with_skip_gradient((1, 16, 16, 64, 64))
+    G.test_conv3x3_residual_preconditions()
 
 
 def test_panel_host_logic():

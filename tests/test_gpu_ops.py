@@ -192,6 +192,78 @@ def test_conv3x3_halo(case, monkeypatch=None):
         ops.ENGINE, ops.HALO3 = saved
 
 
+HALO_SKIP_CASES = [(2, 8, 32, 32, 32), (1, 16, 16, 64, 64), (2, 16, 32, 128, 128), (1, 32, 32, 64, 32), (3, 16, 16, 32, 96)]
+
+
+@pytest.mark.parametrize('case', HALO_SKIP_CASES)
+def test_conv3x3_halo_with_skip_gradient(case):
+    """The data gradient of a residual block's FIRST 3x3 convolution (HRNet's BasicBlock.conv1 through ops.conv2d_skip): the skip
+    path's gradient joins in the halo kernel's epilogue (rih_conv3_desc.r, ABI 19; ops.HALO3_RES) -- dx, dw and the forward against
+    fp64 with the skip contribution, and against the tiled kernel's residual epilogue (HALO3_RES off).  The launch really is the halo
+    kernel's: counted through ops.conv3x3_halo.  (N, H, W, Cin, Cout)."""
+    from renderih_amd import ops
+    N, H, W, Cin, Cout = case
+    saved = (ops.ENGINE, ops.HALO3, ops.HALO3_RES, ops.conv3x3_halo)
+    ops.ENGINE, ops.HALO3 = 2, True
+    taken = []
+    real = ops.conv3x3_halo
+
+    def spy(*a, **k):
+        ok = real(*a, **k)
+        taken.append((a[3], k.get('R') is not None, ok))
+        return ok
+    ops.conv3x3_halo = spy
+    try:
+        x = rnd(N, Cin, H, W, seed=51) * 2.0
+        w = rnd(Cout, Cin, 3, 3, seed=52, scale=1.0 / math.sqrt(9 * Cin))
+        xr, wr = x.double().clone().requires_grad_(True), w.double().clone().requires_grad_(True)
+        yr = F.conv2d(xr, wr, padding=1)
+        gy, gs = rnd(*yr.shape, seed=53), rnd(*x.shape, seed=54)
+        (yr * gy.double()).sum().add((xr * gs.double()).sum()).backward()     # the skip path contributes gs to dx
+        d = dev()
+        outs = {}
+        for res in (True, False):
+            ops.HALO3_RES = res
+            del taken[:]
+            xg = nhwc(x).contiguous().to(d).requires_grad_(True)
+            wg = w.clone().to(d).requires_grad_(True)
+            yg, idt = ops.conv2d_skip(xg, wg, None, stride=1, pad=1, relu=False)
+            ((yg * nhwc(gy).contiguous().to(d)).sum() + (idt * nhwc(gs).contiguous().to(d)).sum()).backward()
+            outs[res] = (nchw(yg).detach().cpu(), nchw(xg.grad).cpu(), wg.grad.cpu())
+            assert_close(outs[res][0], yr.float(), 1e-4, 1e-5, 'halo skip %s y %s' % (res, case,))
+            assert_close(outs[res][1], xr.grad.float(), 1e-4, 1e-5, 'halo skip %s dx %s' % (res, case,))
+            assert_close(outs[res][2], wr.grad.float(), 1e-4, 1e-5, 'halo skip %s dw %s' % (res, case,))
+            dgrad = [t for t in taken if t[0]]
+            assert (dgrad == [(True, True, True)]) if res else (dgrad == []), (res, taken)
+        for a_, b_, what in zip(outs[True], outs[False], ('y', 'dx', 'dw')):
+            assert_close(a_, b_, 1e-4, 1e-5, 'halo residual vs tiled residual ' + what)
+    finally:
+        ops.ENGINE, ops.HALO3, ops.HALO3_RES, ops.conv3x3_halo = saved
+
+
+def test_conv3x3_residual_preconditions():
+    """rih_conv3x3_ok with a residual: refused together with statistics, with a pitch below N or a misaligned pointer; rih_stem
+    takes none."""
+    import ctypes as C
+    from renderih_amd import ops
+    from renderih_amd._lib import Conv3Desc
+    d = dev()
+    x = torch.zeros(1, 8, 32, 32, device=d)
+    pd = Conv3Desc()
+    pd.x = pd.w_h2 = pd.y = pd.amax_x = pd.amax_w = x.data_ptr()
+    pd.imgs, pd.H, pd.W, pd.C, pd.N, pd.ldx, pd.ldy, pd.Kpad, pd.relu = 1, 8, 32, 32, 32, 32, 32, 288, 0
+    L = ops._L()
+    assert int(L.rih_conv3x3_ok(C.byref(pd))) == 1
+    pd.r, pd.ldr = x.data_ptr(), 32
+    assert int(L.rih_conv3x3_ok(C.byref(pd))) == 1
+    pd.ldr = 16
+    assert int(L.rih_conv3x3_ok(C.byref(pd))) == 0
+    pd.ldr, pd.r = 32, x.data_ptr() + 4
+    assert int(L.rih_conv3x3_ok(C.byref(pd))) == 0
+    pd.r, pd.stats = x.data_ptr(), x.data_ptr()
+    assert int(L.rih_conv3x3_ok(C.byref(pd))) == 0
+
+
 PANEL_CASES = [(2, 64, 64, 64, 256, False, True), (1, 64, 64, 128, 512, False, True), (2, 64, 32, 64, 64, True, True),
                (2, 64, 64, 64, 128, False, False), (4, 64, 64, 128, 128, True, True)]
 

@@ -74,6 +74,14 @@ def test_conv3x3_halo_kernels(case):
     G.test_conv3x3_halo(case)
 
 
+@pytest.mark.parametrize('case', [(1, 8, 32, 32, 32), (1, 16, 16, 64, 64), (1, 8, 32, 32, 128)])
+def test_conv3x3_halo_residual_kernels(case):
+    """conv3x3_halo_kernel<*, *, false, RES> on the host harness: the residual read of the epilogue (patch addressing on 8 x 32 and
+    16 x 16 patches, 32- / 64- / 128-wide channel blocks) in the data gradient of ops.conv2d_skip."""
+    G.test_conv3x3_halo_with_skip_gradient(case)
+    G.test_conv3x3_residual_preconditions()
+
+
 @pytest.mark.parametrize('case', [(1, 16, 16, 64, 256, False, True), (1, 16, 16, 128, 128, True, True), (1, 16, 8, 64, 64, False, True),
                                   (1, 32, 16, 64, 128, True, False)])
 def test_panel_kernels(case):
