@@ -192,7 +192,8 @@ def test_conv3x3_halo(case, monkeypatch=None):
         ops.ENGINE, ops.HALO3 = saved
 
 
-HALO_SKIP_CASES = [(2, 8, 32, 32, 32), (1, 16, 16, 64, 64), (2, 16, 32, 128, 128), (1, 32, 32, 64, 32), (3, 16, 16, 32, 96)]
+HALO_SKIP_CASES = [(2, 8, 32, 32, 32), (1, 16, 16, 64, 64), (2, 16, 32, 128, 128), (1, 32, 32, 64, 32), (3, 16, 16, 32, 96),
+                   (64, 32, 32, 32, 128), (256, 16, 16, 32, 128)]      # >= 256 patches: the 128-wide channel blocks (8 x 32 / 16 x 16 patches)
 
 
 @pytest.mark.parametrize('case', HALO_SKIP_CASES)
